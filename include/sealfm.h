@@ -1,0 +1,193 @@
+/*
+ * sealfm.h -- C ABI of libsealfm.so, the MI355X (gfx950) FM-index engine that
+ * replaces SEAL's sdsl-lite/SWIG extension `seal.cpp_modules._fm_index`.
+ *
+ * Every entry point cites the reference interface it replaces
+ * (paths relative to /root/reference).  Conventions kept from the reference:
+ *   - all rows / positions / symbols cross the boundary as uint64_t
+ *     (reference: `unsigned long`, seal/cpp_modules/fm_index.hpp:16-18);
+ *   - `backward_search_step` takes and returns the INCLUSIVE interval [l, r];
+ *     `distinct*` take the HALF-OPEN interval [low, high);
+ *     `backward_search_multi` returns (l, r+1);
+ *   - symbols are already re-based (+SHIFT) on this side of the boundary, the
+ *     Python layer adds/subtracts SHIFT (seal/index.py:16,109,141,154);
+ *   - no exceptions: int status (0 = ok), `fmi_last_error()` for the text;
+ *     sentinel results are replicated ((uint64_t)-1 from locate of a row >=
+ *     size, (1,0) for a symbol outside the alphabet, empty result for low==high).
+ *
+ * Query entry points run on the GPU only.  There is no CPU query path in this
+ * library: without a visible gfx950 device they return FMI_ERR_NO_DEVICE.
+ * Host code here is limited to construction, (de)serialisation and upload.
+ *
+ * Two families of query entry points:
+ *   fmi_<op>(...)      host buffers in/out (what the SWIG methods did, one call
+ *                      per Python call); copies in, runs the kernels, copies out.
+ *   fmi_dev_<op>(...)  device pointers + hipStream_t (passed as void*), no
+ *                      synchronisation, no allocation; safe under hipGraph capture
+ *                      once the workspace has been sized (fmi_dev_reserve).
+ */
+#ifndef SEALFM_H
+#define SEALFM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fmi fmi_t;
+
+enum {
+    FMI_OK = 0,
+    FMI_ERR_ARG = 1,
+    FMI_ERR_IO = 2,
+    FMI_ERR_NO_DEVICE = 3,
+    FMI_ERR_HIP = 4,
+    FMI_ERR_STATE = 5,
+    FMI_ERR_UNSUPPORTED = 6,
+    FMI_ERR_CAPACITY = 7
+};
+
+const char *fmi_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+uint32_t fmi_abi_version(void);
+
+/* ---- lifecycle / construction ------------------------------------------- */
+
+/* FMIndex::FMIndex()  (fm_index.cpp:27-29) */
+int fmi_create(fmi_t **out);
+/* FMIndex::~FMIndex() (fm_index.cpp:31) */
+void fmi_free(fmi_t *h);
+
+/* FMIndex::initialize(const vector<char_type>&)  (fm_index.cpp:33-41).
+ * `data` = n_data symbols, none of them 0; a 0 sentinel is appended as sdsl's
+ * construct_im does, so fmi_size() == n_data + 1 afterwards.
+ * Builds on the host (suffix array by prefix doubling) and uploads to `device`
+ * (>= 0) or leaves the index host-only (device < 0; queries then fail). */
+int fmi_build(fmi_t *h, const uint64_t *data, uint64_t n_data, int device);
+
+/* FMIndex::initialize_from_file(file, width)  (fm_index.cpp:43-48): raw
+ * little-endian integers of `width` bytes (1, 2, 4 or 8). */
+int fmi_build_from_file(fmi_t *h, const char *path, int width, int device);
+
+/* Same result as fmi_build, constructed on the GPU (suffix array by prefix
+ * doubling with device radix sorts).  `d_data` is a DEVICE pointer to n_data
+ * uint32 symbols.  Needed for corpora the host builder cannot reach
+ * (NQ: ~2.9e9 symbols).  keep_host != 0 also downloads every array so that
+ * fmi_save works. */
+int fmi_build_device(fmi_t *h, const uint32_t *d_data, uint64_t n_data, int device, int keep_host);
+
+/* FMIndex::save(path)  (fm_index.cpp:186-189).  Own documented format
+ * (DESIGN.md "on-disk layout"), not sdsl's. */
+int fmi_save(const fmi_t *h, const char *path);
+/* load_FMIndex(path)  (fm_index.cpp:191-199) */
+int fmi_load(fmi_t **out, const char *path, int device);
+
+/* Upload a host-resident index (built with device < 0 or loaded) to a GPU. */
+int fmi_to_device(fmi_t *h, int device);
+
+/* Document boundaries `beginnings` (seal/index.py:25,50,59): n_docs+1 cumulative
+ * token offsets; uploaded so that doc-id binning (index.py:77-82) runs on the GPU. */
+int fmi_set_doc_beginnings(fmi_t *h, const uint64_t *beginnings, uint64_t n_entries);
+
+/* FMIndex::size()  (fm_index.cpp:50-52) */
+uint64_t fmi_size(const fmi_t *h);
+/* index.wavelet_tree.sigma (fm_index.cpp:38): distinct symbols incl. sentinel */
+uint64_t fmi_sigma(const fmi_t *h);
+uint64_t fmi_max_symbol(const fmi_t *h);
+uint32_t fmi_levels(const fmi_t *h);
+int fmi_device(const fmi_t *h);
+/* bytes resident in HBM for this index */
+uint64_t fmi_device_bytes(const fmi_t *h);
+
+/* Host-side view of a built array, for tests of the host logic and for
+ * hand-over to other tools.  name in {"sa","bwt","text","C","leaf","q1",
+ * "zeros","wm"}; returns element count via *n_out and element size in bytes
+ * via *elem_out; pointer stays owned by the index.  NULL if not host-resident. */
+const void *fmi_host_array(const fmi_t *h, const char *name, uint64_t *n_out, uint32_t *elem_out);
+
+/* ---- queries, host buffers (the SWIG surface) ---------------------------- */
+
+/* FMIndex::backward_search_step(symbol, low, high)  (fm_index.cpp:67-76) */
+int fmi_backward_search_step(fmi_t *h, uint64_t symbol, uint64_t low, uint64_t high, uint64_t out[2]);
+/* FMIndex::backward_search_multi(query)  (fm_index.cpp:55-65) -> (l, r+1) */
+int fmi_backward_search_multi(fmi_t *h, const uint64_t *query, uint64_t len, uint64_t out[2]);
+/* batched form of the above over CSR sequences (offsets has n_seq+1 entries);
+ * this is FMIndex.get_range (seal/index.py:102-111) for many sequences at once */
+int fmi_backward_search_multi_batch(fmi_t *h, uint64_t n_seq, const uint64_t *offsets,
+                                    const uint64_t *symbols, uint64_t *lo_out, uint64_t *hi_out);
+
+/* FMIndex::distinct_count_multi(lows, highs)  (fm_index.cpp:111-131).
+ * Results in CSR form: offsets_out[n+1]; symbols / counts ascending by symbol
+ * per interval (sdsl interval_symbols order).  cap = capacity of syms_out /
+ * cnts_out in entries; FMI_ERR_CAPACITY (with offsets_out filled so the caller
+ * can size) if too small.  cnts_out may be NULL (FMIndex::distinct, cpp:78-89). */
+int fmi_distinct_count_multi(fmi_t *h, uint64_t n, const uint64_t *lows, const uint64_t *highs,
+                             uint64_t *offsets_out, uint64_t *syms_out, uint64_t *cnts_out, uint64_t cap);
+
+/* FMIndex::locate(row)  (fm_index.cpp:163-167), batched; (uint64_t)-1 if row >= size.
+ * doc_out (may be NULL) = bisect_right(beginnings, pos) - 1 (seal/index.py:77-82). */
+int fmi_locate(fmi_t *h, uint64_t n, const uint64_t *rows, uint64_t *pos_out, uint64_t *doc_out);
+
+/* FMIndex::extract_text(begin, end)  (fm_index.cpp:169-184): T[end-1] ... T[begin] */
+int fmi_extract_text(fmi_t *h, uint64_t begin, uint64_t end, uint64_t *out);
+
+/* ---- queries, device pointers + stream (the decode / retrieval hot path) -- */
+
+/* workspace for the fmi_dev_* calls: rows = max intervals per call */
+int fmi_dev_reserve(fmi_t *h, uint64_t max_rows);
+
+/* backward_search_step for n independent (symbol, [l, r]) triples */
+int fmi_dev_bs_step(fmi_t *h, void *stream, uint64_t n, const uint64_t *d_sym, const uint64_t *d_lo,
+                    const uint64_t *d_hi, uint64_t *d_lo_out, uint64_t *d_hi_out);
+
+/* get_range over CSR sequences of RAW token ids (+shift applied here) */
+int fmi_dev_get_range(fmi_t *h, void *stream, uint64_t n_seq, const int64_t *d_offsets,
+                      const int64_t *d_tokens, int64_t shift, uint64_t *d_lo_out, uint64_t *d_hi_out);
+
+/* IndexBasedLogitsProcessor.__call__ for cur_len >= 2 (seal/beam_search.py:79-140):
+ *   d_input_ids  int64 [rows, cur_len] row-major (decoder ids incl. the start token)
+ *   d_scores_in  fp32 [rows, vocab]; d_scores_out fp32 [rows, vocab] (may alias)
+ *   force_from   host array of n_force raw token ids (force_decoding_from) or NULL
+ * out[r][v] = in[r][v] if v is an allowed continuation of row r else -inf. */
+int fmi_dev_constrain_scores(fmi_t *h, void *stream, uint64_t rows, uint64_t cur_len,
+                             const int64_t *d_input_ids, const float *d_scores_in, float *d_scores_out,
+                             uint64_t vocab, int64_t shift, int64_t pad_id, int64_t eos_id,
+                             const int64_t *force_from, uint64_t n_force,
+                             int64_t stop_at_count, int always_allow_eos);
+
+/* Same constraint as a bitmap: d_bits uint32 [rows, ceil(vocab/32)], bit v of row
+ * r set iff v allowed.  Building block of the fused masked top-k. */
+int fmi_dev_allowed_bits(fmi_t *h, void *stream, uint64_t rows, uint64_t cur_len,
+                         const int64_t *d_input_ids, uint32_t *d_bits,
+                         uint64_t vocab, int64_t shift, int64_t pad_id, int64_t eos_id,
+                         const int64_t *force_from, uint64_t n_force,
+                         int64_t stop_at_count, int always_allow_eos);
+
+/* locate + doc binning for n rows (seal/keys.py:320-324) */
+int fmi_dev_locate(fmi_t *h, void *stream, uint64_t n, const uint64_t *d_rows,
+                   uint64_t *d_pos_out, uint64_t *d_doc_out);
+
+/* rows of many half-open ranges, each truncated to `max_per_range`
+ * (islice(range(*get_range(ngram)), max_hits), seal/keys.py:320), located and
+ * binned in one launch.  d_out_offsets[n_ranges+1] is an INPUT (exclusive scan of
+ * min(hi-lo, max_per_range)), outputs are written at those offsets. */
+int fmi_dev_locate_ranges(fmi_t *h, void *stream, uint64_t n_ranges, const uint64_t *d_lo,
+                          const uint64_t *d_hi, uint64_t max_per_range, const uint64_t *d_out_offsets,
+                          uint64_t total, uint64_t *d_pos_out, uint64_t *d_doc_out);
+
+/* get_doc for many documents (seal/index.py:68-75): forward-order RAW token ids
+ * (symbol - shift) of documents d_docs[i] written at d_out + d_out_offsets[i] */
+int fmi_dev_get_docs(fmi_t *h, void *stream, uint64_t n_docs, const uint64_t *d_docs,
+                     const uint64_t *d_out_offsets, int64_t shift, int64_t *d_out);
+
+/* probe counter of the last fmi_dev_* expansion launch (64-byte wavelet-block
+ * probes issued; DESIGN.md "algorithmic bytes").  Device-side counter, read
+ * back synchronously: for measurement only, never on the timed path. */
+int fmi_dev_enable_probe_count(fmi_t *h, int enable);
+int fmi_dev_read_probe_count(fmi_t *h, uint64_t *probes_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEALFM_H */

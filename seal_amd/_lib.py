@@ -1,0 +1,83 @@
+"""ctypes binding of libsealfm.so (C ABI declared in include/sealfm.h).
+
+There is no Python/CPU fallback: if the shared library is missing this module
+raises, and every query entry point fails with FMI_ERR_NO_DEVICE unless the
+index is resident on a gfx950 GPU."""
+import ctypes
+import os
+
+from . import _build
+
+_u64 = ctypes.c_uint64
+_i64 = ctypes.c_int64
+_p64 = ctypes.POINTER(ctypes.c_uint64)
+_pi64 = ctypes.POINTER(ctypes.c_int64)
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+
+# name -> (restype, argtypes); the list mirrors include/sealfm.h one to one
+SIGNATURES = {
+    "fmi_last_error": (ctypes.c_char_p, []),
+    "fmi_abi_version": (ctypes.c_uint32, []),
+    "fmi_create": (_int, [ctypes.POINTER(_vp)]),
+    "fmi_free": (None, [_vp]),
+    "fmi_build": (_int, [_vp, _p64, _u64, _int]),
+    "fmi_build_from_file": (_int, [_vp, ctypes.c_char_p, _int, _int]),
+    "fmi_build_device": (_int, [_vp, _vp, _u64, _int, _int]),
+    "fmi_save": (_int, [_vp, ctypes.c_char_p]),
+    "fmi_load": (_int, [ctypes.POINTER(_vp), ctypes.c_char_p, _int]),
+    "fmi_to_device": (_int, [_vp, _int]),
+    "fmi_set_doc_beginnings": (_int, [_vp, _p64, _u64]),
+    "fmi_size": (_u64, [_vp]),
+    "fmi_sigma": (_u64, [_vp]),
+    "fmi_max_symbol": (_u64, [_vp]),
+    "fmi_levels": (ctypes.c_uint32, [_vp]),
+    "fmi_device": (_int, [_vp]),
+    "fmi_device_bytes": (_u64, [_vp]),
+    "fmi_host_array": (_vp, [_vp, ctypes.c_char_p, _p64, ctypes.POINTER(ctypes.c_uint32)]),
+    "fmi_backward_search_step": (_int, [_vp, _u64, _u64, _u64, _p64]),
+    "fmi_backward_search_multi": (_int, [_vp, _p64, _u64, _p64]),
+    "fmi_backward_search_multi_batch": (_int, [_vp, _u64, _p64, _p64, _p64, _p64]),
+    "fmi_distinct_count_multi": (_int, [_vp, _u64, _p64, _p64, _p64, _p64, _p64, _u64]),
+    "fmi_locate": (_int, [_vp, _u64, _p64, _p64, _p64]),
+    "fmi_extract_text": (_int, [_vp, _u64, _u64, _p64]),
+    "fmi_dev_reserve": (_int, [_vp, _u64]),
+    "fmi_dev_bs_step": (_int, [_vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "fmi_dev_get_range": (_int, [_vp, _vp, _u64, _vp, _vp, _i64, _vp, _vp]),
+    "fmi_dev_constrain_scores": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _u64, _i64, _i64, _i64, _pi64, _u64, _i64, _int]),
+    "fmi_dev_allowed_bits": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, _i64, _i64, _i64, _pi64, _u64, _i64, _int]),
+    "fmi_dev_locate": (_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
+    "fmi_dev_locate_ranges": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp, _vp]),
+    "fmi_dev_get_docs": (_int, [_vp, _vp, _u64, _vp, _vp, _i64, _vp]),
+    "fmi_dev_enable_probe_count": (_int, [_vp, _int]),
+    "fmi_dev_read_probe_count": (_int, [_vp, _p64]),
+}
+
+_lib = None
+
+
+class SealFMError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libsealfm error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_build.LIB):
+            raise ImportError(
+                f"{_build.LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  seal_amd has no pure-Python or CPU fallback.")
+        L = ctypes.CDLL(_build.LIB)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError here = ABI drift, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise SealFMError(rc, lib().fmi_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,484 @@
+// Host side of libsealfm.so: construction, (de)serialisation, upload.
+// No query arithmetic lives here -- queries are HIP kernels (fmi_kernels.hip).
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "fmi_internal.h"
+
+static thread_local std::string g_err;
+
+void fmi_set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+extern "C" const char *fmi_last_error(void) { return g_err.c_str(); }
+extern "C" uint32_t fmi_abi_version(void) { return 1; }
+
+extern "C" int fmi_create(fmi_t **out)
+{
+    if (!out) { fmi_set_error("fmi_create: null out"); return FMI_ERR_ARG; }
+    *out = new fmi();
+    return FMI_OK;
+}
+
+void fmi_release_device(fmi *h)
+{
+    if (h->device >= 0) {
+        (void)hipSetDevice(h->device);
+        for (void *p : h->dev_allocs) (void)hipFree(p);
+        if (h->ws) (void)hipFree(h->ws);
+        if (h->d_probe_counter) (void)hipFree(h->d_probe_counter);
+    }
+    h->dev_allocs.clear();
+    h->ws = nullptr; h->ws_bytes = 0; h->ws_rows = 0;
+    h->d_probe_counter = nullptr;
+    h->dev = FmiDev{};
+    h->device = -1;
+    h->dev_bytes = 0;
+}
+
+extern "C" void fmi_free(fmi_t *h)
+{
+    if (!h) return;
+    fmi_release_device(h);
+    delete h;
+}
+
+extern "C" uint64_t fmi_size(const fmi_t *h) { return h ? h->n : 0; }
+extern "C" uint64_t fmi_sigma(const fmi_t *h) { return h ? h->sigma : 0; }
+extern "C" uint64_t fmi_max_symbol(const fmi_t *h) { return h ? h->max_sym : 0; }
+extern "C" uint32_t fmi_levels(const fmi_t *h) { return h ? h->levels : 0; }
+extern "C" int fmi_device(const fmi_t *h) { return h ? h->device : -1; }
+extern "C" uint64_t fmi_device_bytes(const fmi_t *h) { return h ? h->dev_bytes : 0; }
+
+// ---------------------------------------------------------------------------
+// Suffix array on the host: prefix doubling.  Round 0 sorts by a 64-bit key
+// packing the first 64/bits symbols; later rounds refine only the groups that
+// are still tied, by the rank of the suffix h symbols further on.
+// The text ends in a unique smallest sentinel (0), so all suffixes are distinct.
+// ---------------------------------------------------------------------------
+void fmi_host_suffix_array(const uint32_t *text, uint64_t n, uint32_t bits, std::vector<uint64_t> &sa)
+{
+    sa.resize(n);
+    if (n == 0) return;
+    if (bits == 0) bits = 1;
+    const uint32_t per = std::max<uint32_t>(1, 64 / bits);
+    std::vector<std::pair<uint64_t, uint64_t>> keyed(n);
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t key = 0;
+        for (uint32_t j = 0; j < per; j++) {
+            uint64_t s = (i + j < n) ? text[i + j] : 0;
+            key = (per * bits >= 64 && j == 0) ? s : ((key << bits) | s);
+        }
+        keyed[i] = {key, i};
+    }
+    std::sort(keyed.begin(), keyed.end());
+    // rank[i] = index of the first row of i's group
+    std::vector<uint64_t> rank(n);
+    bool tied = false;
+    {
+        uint64_t g = 0;
+        for (uint64_t j = 0; j < n; j++) {
+            if (j > 0 && keyed[j].first != keyed[j - 1].first) g = j;
+            else if (j > 0) tied = true;
+            sa[j] = keyed[j].second;
+            rank[sa[j]] = g;
+        }
+    }
+    keyed.clear(); keyed.shrink_to_fit();
+    std::vector<std::pair<uint64_t, uint64_t>> tmp;
+    for (uint64_t h = per; tied; h *= 2) {
+        tied = false;
+        uint64_t j = 0;
+        while (j < n) {
+            uint64_t g = rank[sa[j]], e = j + 1;
+            while (e < n && rank[sa[e]] == g) e++;
+            if (e - j > 1) {
+                // a tied suffix never contains the sentinel within its first h
+                // symbols, so sa[x] + h < n holds for every member
+                tmp.resize(e - j);
+                for (uint64_t x = j; x < e; x++) tmp[x - j] = {rank[sa[x] + h], sa[x]};
+                std::sort(tmp.begin(), tmp.end());
+                // ranks of this group are rewritten only after all second keys
+                // were read (members may reference each other)
+                uint64_t gs = j;
+                for (uint64_t x = 0; x < tmp.size(); x++) {
+                    sa[j + x] = tmp[x].second;
+                }
+                std::vector<uint64_t> newrank(tmp.size());
+                for (uint64_t x = 0; x < tmp.size(); x++) {
+                    if (x > 0 && tmp[x].first != tmp[x - 1].first) gs = j + x;
+                    else if (x > 0) tied = true;
+                    newrank[x] = gs;
+                }
+                for (uint64_t x = 0; x < tmp.size(); x++) rank[tmp[x].second] = newrank[x];
+            }
+            j = e;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Quirk Q1: the reference starts every search from the
+// inclusive interval [0, size()] (seal/index.py:106-107, fm_index.cpp:58-59),
+// one row past the end, so sdsl evaluates wt_int::rank(size()+1, c).  In the
+// level-concatenated pointerless tree that call reads, at every level, the bit
+// that FOLLOWS c's node; the result is occ(c)+1 iff that stray bit equals c's
+// own bit on every level, otherwise occ(c).  The stray bit after a node is the
+// first bit of the next non-empty node on the same level (nodes are laid out in
+// prefix order, empty nodes take no space) or, after the last node of a level,
+// the first bit of the next level (0 beyond the last level).  A node's first
+// bit belongs to the element of that node that comes first in BWT order.
+// All of that is a function of (first occurrence in the BWT of every symbol);
+// this routine evaluates it without ever materialising sdsl's layout.
+// ---------------------------------------------------------------------------
+void fmi_host_q1_table(const uint32_t *bwt, uint64_t n, uint32_t L, uint64_t max_sym,
+                       const std::vector<uint64_t> &C, std::vector<uint8_t> &q1)
+{
+    q1.assign(max_sym + 1, 0);
+    std::vector<uint64_t> first_pos(max_sym + 1, UINT64_MAX);
+    for (uint64_t i = 0; i < n; i++)
+        if (first_pos[bwt[i]] == UINT64_MAX) first_pos[bwt[i]] = i;
+    std::vector<uint32_t> present;
+    for (uint64_t c = 0; c <= max_sym; c++)
+        if (C[c + 1] > C[c]) present.push_back((uint32_t)c);
+    const size_t P = present.size();
+    // per level: for each present symbol, the index of its node among the
+    // non-empty nodes of the level, and per node the bit of its first element
+    std::vector<std::vector<uint8_t>> node_first_bit(L);
+    std::vector<std::vector<uint32_t>> node_of(L, std::vector<uint32_t>(P));
+    for (uint32_t k = 0; k < L; k++) {
+        const uint32_t sh = L - k;   // node prefix = symbol >> sh (k bits)
+        size_t i = 0;
+        while (i < P) {
+            uint64_t prefix = (sh >= 32) ? 0 : (present[i] >> sh);
+            size_t e = i;
+            uint64_t best = UINT64_MAX; uint32_t best_sym = 0;
+            while (e < P && ((sh >= 32) ? 0 : (present[e] >> sh)) == prefix) {
+                if (first_pos[present[e]] < best) { best = first_pos[present[e]]; best_sym = present[e]; }
+                e++;
+            }
+            uint32_t node = (uint32_t)node_first_bit[k].size();
+            node_first_bit[k].push_back((uint8_t)((best_sym >> (L - 1 - k)) & 1));
+            for (size_t x = i; x < e; x++) node_of[k][x] = node;
+            i = e;
+        }
+    }
+    for (size_t x = 0; x < P; x++) {
+        bool all_equal = true;
+        for (uint32_t k = 0; k < L && all_equal; k++) {
+            uint32_t node = node_of[k][x];
+            uint8_t stray;
+            if (node + 1 < node_first_bit[k].size()) stray = node_first_bit[k][node + 1];
+            else if (k + 1 < L) stray = node_first_bit[k + 1][0];
+            else stray = 0;
+            uint8_t cbit = (uint8_t)((present[x] >> (L - 1 - k)) & 1);
+            all_equal = (stray == cbit);
+        }
+        q1[present[x]] = all_equal ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// BWT -> wavelet matrix in the 64-byte block layout + per-symbol tables.
+// ---------------------------------------------------------------------------
+void fmi_host_finish_from_bwt(fmi *h, const uint32_t *bwt, uint64_t n)
+{
+    uint64_t max_sym = 0;
+    for (uint64_t i = 0; i < n; i++) max_sym = std::max<uint64_t>(max_sym, bwt[i]);
+    uint32_t L = 0;
+    while ((max_sym >> L) > 0) L++;   // sdsl: bits::hi(max)+1
+    if (L == 0) L = 1;
+    h->n = n; h->max_sym = max_sym; h->levels = L;
+    h->sym_bytes = (max_sym < 65536) ? 2 : 4;
+    // C[c] = #symbols < c
+    h->C.assign(max_sym + 2, 0);
+    for (uint64_t i = 0; i < n; i++) h->C[bwt[i] + 1]++;
+    uint64_t sigma = 0;
+    for (uint64_t c = 0; c <= max_sym; c++) { if (h->C[c + 1]) sigma++; h->C[c + 1] += h->C[c]; }
+    h->sigma = sigma;
+    // levels
+    h->nblk = n / FMI_BLOCK_BITS + 2;
+    h->wm.assign((uint64_t)L * h->nblk * FMI_BLOCK_WORDS, 0);
+    h->zeros.assign(L, 0);
+    std::vector<uint32_t> cur(bwt, bwt + n), nxt(n);
+    for (uint32_t k = 0; k < L; k++) {
+        const uint32_t sh = L - 1 - k;
+        uint64_t *lvl = h->wm.data() + (uint64_t)k * h->nblk * FMI_BLOCK_WORDS;
+        uint64_t ones = 0;
+        for (uint64_t b = 0; b < h->nblk; b++) {
+            uint64_t *blk = lvl + b * FMI_BLOCK_WORDS;
+            blk[0] = ones;
+            uint64_t base = b * FMI_BLOCK_BITS;
+            for (uint32_t w = 0; w < 7; w++) {
+                uint64_t word = 0;
+                uint64_t p0 = base + (uint64_t)w * 64;
+                for (uint32_t bit = 0; bit < 64 && p0 + bit < n; bit++)
+                    word |= (uint64_t)((cur[p0 + bit] >> sh) & 1) << bit;
+                blk[1 + w] = word;
+                ones += (uint64_t)__builtin_popcountll(word);
+            }
+        }
+        h->zeros[k] = n - ones;
+        // stable partition: zeros first
+        uint64_t z = 0, o = h->zeros[k];
+        for (uint64_t i = 0; i < n; i++) {
+            if ((cur[i] >> sh) & 1) nxt[o++] = cur[i]; else nxt[z++] = cur[i];
+        }
+        cur.swap(nxt);
+    }
+    // after the last partition equal symbols are contiguous
+    h->leaf.assign(max_sym + 1, 0);
+    for (uint64_t i = 0; i < n; i++)
+        if (i == 0 || cur[i] != cur[i - 1]) h->leaf[cur[i]] = i;
+    fmi_host_q1_table(bwt, n, L, max_sym, h->C, h->q1);
+}
+
+static void pack_sa(fmi *h, const std::vector<uint64_t> &sa)
+{
+    const uint64_t n = sa.size();
+    h->sa_lo.resize(n);
+    bool wide = n > (1ull << 32);
+    h->sa_hi.clear();
+    if (wide) h->sa_hi.resize(n);
+    for (uint64_t i = 0; i < n; i++) {
+        h->sa_lo[i] = (uint32_t)sa[i];
+        if (wide) h->sa_hi[i] = (uint8_t)(sa[i] >> 32);
+    }
+}
+
+int fmi_host_build_from_symbols(fmi *h, const uint32_t *text, uint64_t n)
+{
+    uint64_t max_sym = 0;
+    for (uint64_t i = 0; i < n; i++) max_sym = std::max<uint64_t>(max_sym, text[i]);
+    uint32_t L = 0;
+    while ((max_sym >> L) > 0) L++;
+    if (L == 0) L = 1;
+    if (L > FMI_MAX_LEVELS) {
+        fmi_set_error("alphabet needs %u bits per symbol; this build supports <= %u", L, FMI_MAX_LEVELS);
+        return FMI_ERR_UNSUPPORTED;
+    }
+    std::vector<uint64_t> sa;
+    fmi_host_suffix_array(text, n, L, sa);
+    h->bwt.resize(n);
+    for (uint64_t i = 0; i < n; i++) h->bwt[i] = text[sa[i] ? sa[i] - 1 : n - 1];
+    fmi_host_finish_from_bwt(h, h->bwt.data(), n);
+    pack_sa(h, sa);
+    h->text.resize(n * h->sym_bytes);
+    if (h->sym_bytes == 2) {
+        uint16_t *t = reinterpret_cast<uint16_t *>(h->text.data());
+        for (uint64_t i = 0; i < n; i++) t[i] = (uint16_t)text[i];
+    } else {
+        memcpy(h->text.data(), text, n * 4);
+    }
+    h->host_resident = true;
+    return FMI_OK;
+}
+
+extern "C" int fmi_build(fmi_t *h, const uint64_t *data, uint64_t n_data, int device)
+{
+    if (!h || (!data && n_data)) { fmi_set_error("fmi_build: null argument"); return FMI_ERR_ARG; }
+    fmi_release_device(h);
+    std::vector<uint32_t> text(n_data + 1);
+    for (uint64_t i = 0; i < n_data; i++) {
+        if (data[i] == 0 || data[i] >= (1ull << FMI_MAX_LEVELS)) {
+            fmi_set_error("fmi_build: symbol %llu at %llu outside [1, 2^%u)", (unsigned long long)data[i],
+                          (unsigned long long)i, FMI_MAX_LEVELS);
+            return FMI_ERR_ARG;
+        }
+        text[i] = (uint32_t)data[i];
+    }
+    text[n_data] = 0;   // sdsl's construct appends the sentinel
+    int rc = fmi_host_build_from_symbols(h, text.data(), n_data + 1);
+    if (rc != FMI_OK) return rc;
+    if (device >= 0) return fmi_upload(h, device);
+    return FMI_OK;
+}
+
+extern "C" int fmi_build_from_file(fmi_t *h, const char *path, int width, int device)
+{
+    if (!h || !path || !(width == 1 || width == 2 || width == 4 || width == 8)) {
+        fmi_set_error("fmi_build_from_file: bad argument");
+        return FMI_ERR_ARG;
+    }
+    FILE *f = fopen(path, "rb");
+    if (!f) { fmi_set_error("cannot open %s", path); return FMI_ERR_IO; }
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    uint64_t cnt = (uint64_t)sz / (uint64_t)width;
+    std::vector<uint8_t> raw((size_t)sz);
+    if (sz && fread(raw.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); fmi_set_error("short read %s", path); return FMI_ERR_IO; }
+    fclose(f);
+    std::vector<uint64_t> data(cnt);
+    for (uint64_t i = 0; i < cnt; i++) {
+        uint64_t v = 0;
+        memcpy(&v, raw.data() + i * width, width);   // little endian host
+        data[i] = v;
+    }
+    return fmi_build(h, data.data(), cnt, device);
+}
+
+extern "C" int fmi_set_doc_beginnings(fmi_t *h, const uint64_t *b, uint64_t n_entries)
+{
+    if (!h || !b || n_entries == 0) { fmi_set_error("fmi_set_doc_beginnings: bad argument"); return FMI_ERR_ARG; }
+    h->doc_begin.assign(b, b + n_entries);
+    if (h->device >= 0) {
+        if (hipSetDevice(h->device) != hipSuccess) { fmi_set_error("hipSetDevice failed"); return FMI_ERR_HIP; }
+        void *p = nullptr;
+        if (hipMalloc(&p, n_entries * 8) != hipSuccess) { fmi_set_error("hipMalloc(doc_begin) failed"); return FMI_ERR_HIP; }
+        if (hipMemcpy(p, b, n_entries * 8, hipMemcpyHostToDevice) != hipSuccess) { fmi_set_error("hipMemcpy(doc_begin) failed"); return FMI_ERR_HIP; }
+        h->dev_allocs.push_back(p);
+        h->dev_bytes += n_entries * 8;
+        h->dev.doc_begin = (const uint64_t *)p;
+        h->dev.n_begin = n_entries;
+    }
+    return FMI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// upload
+// ---------------------------------------------------------------------------
+template <class T>
+static int up(fmi *h, const std::vector<T> &v, const T **out)
+{
+    *out = nullptr;
+    if (v.empty()) return FMI_OK;
+    void *p = nullptr;
+    size_t bytes = v.size() * sizeof(T);
+    if (hipMalloc(&p, bytes) != hipSuccess) { fmi_set_error("hipMalloc(%zu) failed", bytes); return FMI_ERR_HIP; }
+    if (hipMemcpy(p, v.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { fmi_set_error("hipMemcpy H2D failed"); return FMI_ERR_HIP; }
+    h->dev_allocs.push_back(p);
+    h->dev_bytes += bytes;
+    *out = (const T *)p;
+    return FMI_OK;
+}
+
+int fmi_upload(fmi *h, int device)
+{
+    if (!h->host_resident) { fmi_set_error("fmi_upload: index is not host resident"); return FMI_ERR_STATE; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= device) {
+        fmi_set_error("no HIP device %d visible (this library has no CPU query path)", device);
+        return FMI_ERR_NO_DEVICE;
+    }
+    fmi_release_device(h);
+    if (hipSetDevice(device) != hipSuccess) { fmi_set_error("hipSetDevice(%d) failed", device); return FMI_ERR_HIP; }
+    h->device = device;
+    FmiDev d{};
+    d.nblk = h->nblk; d.n = h->n; d.max_sym = h->max_sym; d.levels = h->levels; d.sym_bytes = h->sym_bytes;
+    for (uint32_t k = 0; k < h->levels; k++) d.zeros[k] = h->zeros[k];
+    int rc;
+    const uint8_t *text8 = nullptr;
+    if ((rc = up(h, h->wm, &d.wm)) || (rc = up(h, h->C, &d.C)) || (rc = up(h, h->leaf, &d.leaf)) ||
+        (rc = up(h, h->q1, &d.q1)) || (rc = up(h, h->sa_lo, &d.sa_lo)) || (rc = up(h, h->sa_hi, &d.sa_hi)) ||
+        (rc = up(h, h->text, &text8)) || (rc = up(h, h->doc_begin, &d.doc_begin))) {
+        fmi_release_device(h);
+        return rc;
+    }
+    d.text = text8;
+    d.n_begin = h->doc_begin.size();
+    h->dev = d;
+    return FMI_OK;
+}
+
+extern "C" int fmi_to_device(fmi_t *h, int device)
+{
+    if (!h) { fmi_set_error("null handle"); return FMI_ERR_ARG; }
+    return fmi_upload(h, device);
+}
+
+// ---------------------------------------------------------------------------
+// on-disk format ".fmi" (little endian):
+//   char[8] "SEALFMI1"; u64 n, max_sym, sigma, nblk; u32 levels, sym_bytes;
+//   u64 sa_wide(0/1); then arrays, each as u64 byte length + raw bytes, in the
+//   order zeros, C, leaf, q1, wm, sa_lo, sa_hi, text, bwt.
+// ---------------------------------------------------------------------------
+template <class T>
+static bool wr(FILE *f, const std::vector<T> &v)
+{
+    uint64_t bytes = v.size() * sizeof(T);
+    if (fwrite(&bytes, 8, 1, f) != 1) return false;
+    return bytes == 0 || fwrite(v.data(), 1, bytes, f) == bytes;
+}
+template <class T>
+static bool rd(FILE *f, std::vector<T> &v)
+{
+    uint64_t bytes = 0;
+    if (fread(&bytes, 8, 1, f) != 1) return false;
+    v.resize(bytes / sizeof(T));
+    return bytes == 0 || fread(v.data(), 1, bytes, f) == bytes;
+}
+
+extern "C" int fmi_save(const fmi_t *h, const char *path)
+{
+    if (!h || !path) { fmi_set_error("fmi_save: null argument"); return FMI_ERR_ARG; }
+    if (!h->host_resident) { fmi_set_error("fmi_save: index has no host copy (built on device without keep_host)"); return FMI_ERR_STATE; }
+    FILE *f = fopen(path, "wb");
+    if (!f) { fmi_set_error("cannot open %s for writing", path); return FMI_ERR_IO; }
+    bool ok = fwrite("SEALFMI1", 1, 8, f) == 8;
+    uint64_t hdr[4] = {h->n, h->max_sym, h->sigma, h->nblk};
+    uint32_t hdr2[2] = {h->levels, h->sym_bytes};
+    ok = ok && fwrite(hdr, 8, 4, f) == 4 && fwrite(hdr2, 4, 2, f) == 2;
+    ok = ok && wr(f, h->zeros) && wr(f, h->C) && wr(f, h->leaf) && wr(f, h->q1) && wr(f, h->wm) &&
+         wr(f, h->sa_lo) && wr(f, h->sa_hi) && wr(f, h->text) && wr(f, h->bwt);
+    fclose(f);
+    if (!ok) { fmi_set_error("write error on %s", path); return FMI_ERR_IO; }
+    return FMI_OK;
+}
+
+extern "C" int fmi_load(fmi_t **out, const char *path, int device)
+{
+    if (!out || !path) { fmi_set_error("fmi_load: null argument"); return FMI_ERR_ARG; }
+    FILE *f = fopen(path, "rb");
+    if (!f) { fmi_set_error("cannot open %s", path); return FMI_ERR_IO; }
+    char magic[8];
+    fmi *h = new fmi();
+    uint64_t hdr[4]; uint32_t hdr2[2];
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "SEALFMI1", 8) == 0;
+    ok = ok && fread(hdr, 8, 4, f) == 4 && fread(hdr2, 4, 2, f) == 2;
+    if (ok) { h->n = hdr[0]; h->max_sym = hdr[1]; h->sigma = hdr[2]; h->nblk = hdr[3]; h->levels = hdr2[0]; h->sym_bytes = hdr2[1]; }
+    ok = ok && rd(f, h->zeros) && rd(f, h->C) && rd(f, h->leaf) && rd(f, h->q1) && rd(f, h->wm) &&
+         rd(f, h->sa_lo) && rd(f, h->sa_hi) && rd(f, h->text) && rd(f, h->bwt);
+    fclose(f);
+    if (!ok || h->levels == 0 || h->levels > FMI_MAX_LEVELS) {
+        delete h;
+        fmi_set_error("%s is not a SEALFMI1 index", path);
+        return FMI_ERR_IO;
+    }
+    h->host_resident = true;
+    if (device >= 0) {
+        int rc = fmi_upload(h, device);
+        if (rc != FMI_OK) { delete h; return rc; }
+    }
+    *out = h;
+    return FMI_OK;
+}
+
+extern "C" const void *fmi_host_array(const fmi_t *h, const char *name, uint64_t *n_out, uint32_t *elem_out)
+{
+    if (!h || !name || !h->host_resident) return nullptr;
+    std::string s(name);
+    auto ret = [&](const void *p, uint64_t n, uint32_t e) { if (n_out) *n_out = n; if (elem_out) *elem_out = e; return p; };
+    if (s == "sa") return ret(h->sa_lo.data(), h->sa_lo.size(), 4);
+    if (s == "sa_hi") return ret(h->sa_hi.data(), h->sa_hi.size(), 1);
+    if (s == "bwt") return ret(h->bwt.data(), h->bwt.size(), 4);
+    if (s == "text") return ret(h->text.data(), h->n, h->sym_bytes);
+    if (s == "C") return ret(h->C.data(), h->C.size(), 8);
+    if (s == "leaf") return ret(h->leaf.data(), h->leaf.size(), 8);
+    if (s == "q1") return ret(h->q1.data(), h->q1.size(), 1);
+    if (s == "zeros") return ret(h->zeros.data(), h->zeros.size(), 8);
+    if (s == "wm") return ret(h->wm.data(), h->wm.size(), 8);
+    return nullptr;
+}

@@ -1,0 +1,709 @@
+// gfx950 (MI355X / CDNA4) kernels of libsealfm.so and the C-ABI query entry points.
+//
+// All work here is HBM-latency/bandwidth bound integer work: dependent 64-byte
+// gathers into a wavelet matrix (one 64-B line per rank probe), 5-byte gathers
+// into the suffix array, binary searches over doc boundaries.  No MFMA.
+// Wave size is 64 throughout.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "fmi_internal.h"
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            fmi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return FMI_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// device primitives
+// ---------------------------------------------------------------------------
+struct alignas(16) U64x2 { uint64_t x, y; };
+
+// ones in level k before position p (0 <= p <= n): ONE 64-byte line.
+__device__ __forceinline__ uint64_t wm_rank1(const FmiDev &ix, uint32_t k, uint64_t p, uint64_t *probes)
+{
+    const uint64_t w = p >> 6;
+    const uint64_t blk = w / 7;
+    const uint32_t wi = (uint32_t)(w - blk * 7);
+    const U64x2 *b = reinterpret_cast<const U64x2 *>(ix.wm + ((uint64_t)k * ix.nblk + blk) * FMI_BLOCK_WORDS);
+    const U64x2 v0 = b[0], v1 = b[1], v2 = b[2], v3 = b[3];
+    const uint64_t words[7] = {v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+    const uint64_t tail = (1ull << (p & 63)) - 1;
+    uint64_t r = v0.x;
+#pragma unroll
+    for (uint32_t j = 0; j < 7; j++) {
+        uint64_t m = (j < wi) ? ~0ull : ((j == wi) ? tail : 0ull);
+        r += (uint64_t)__popcll(words[j] & m);
+    }
+    if (probes) ++*probes;
+    return r;
+}
+
+// number of occurrences of symbol c in BWT[0, i), 0 <= i <= n
+__device__ __forceinline__ uint64_t wm_rank_sym(const FmiDev &ix, uint64_t c, uint64_t i, uint64_t *probes)
+{
+    uint64_t p = i;
+    for (uint32_t k = 0; k < ix.levels; k++) {
+        const uint64_t r1 = wm_rank1(ix, k, p, probes);
+        p = ((c >> (ix.levels - 1 - k)) & 1) ? ix.zeros[k] + r1 : p - r1;
+    }
+    return p - ix.leaf[c];
+}
+
+// sdsl wt_int::rank(i, c) as the reference reaches it, incl. i == size()+1
+// (quirk Q1: occ(c) + q1[c]); i beyond that is undefined in the reference and
+// is clamped to the same value here.
+__device__ __forceinline__ uint64_t rank_like_sdsl(const FmiDev &ix, uint64_t c, uint64_t i, uint64_t *probes)
+{
+    if (i > ix.n) return (ix.C[c + 1] - ix.C[c]) + ix.q1[c];
+    if (i == 0) return 0;
+    return wm_rank_sym(ix, c, i, probes);
+}
+
+// sdsl backward_search(csa, l, r, c, l_res, r_res) on the inclusive [l, r]
+__device__ __forceinline__ void bs_step(const FmiDev &ix, uint64_t c, uint64_t l, uint64_t r,
+                                        uint64_t &l_res, uint64_t &r_res, uint64_t *probes)
+{
+    const bool absent = (c > ix.max_sym) || (ix.C[c + 1] == ix.C[c]);
+    if (absent && c > 0) { l_res = 1; r_res = 0; return; }
+    const uint64_t cb = ix.C[c];
+    l_res = cb + rank_like_sdsl(ix, c, l, probes);
+    r_res = cb + rank_like_sdsl(ix, c, r + 1, probes) - 1;
+}
+
+__device__ __forceinline__ uint64_t sa_at(const FmiDev &ix, uint64_t row)
+{
+    uint64_t v = ix.sa_lo[row];
+    if (ix.sa_hi) v |= (uint64_t)ix.sa_hi[row] << 32;
+    return v;
+}
+
+// bisect_right(beginnings, pos) - 1
+__device__ __forceinline__ uint64_t doc_of(const FmiDev &ix, uint64_t pos)
+{
+    uint64_t lo = 0, hi = ix.n_begin;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (pos < ix.doc_begin[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo - 1;
+}
+
+// ---------------------------------------------------------------------------
+// K1: backward_search_step for n independent triples (fm_index.cpp:67-76)
+// ---------------------------------------------------------------------------
+__global__ void k_bs_step(FmiDev ix, uint64_t n, const uint64_t *sym, const uint64_t *lo, const uint64_t *hi,
+                          uint64_t *lo_out, uint64_t *hi_out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t l, r;
+    bs_step(ix, sym[i], lo[i], hi[i], l, r, nullptr);
+    lo_out[i] = l; hi_out[i] = r;
+}
+
+// K5: get_range / backward_search_multi over CSR sequences (fm_index.cpp:55-65,
+// seal/index.py:102-111): start at (0, size()), one step per token, return (l, r+1)
+template <typename OffT, typename TokT>
+__global__ void k_get_range(FmiDev ix, uint64_t n_seq, const OffT *offsets, const TokT *tokens, int64_t shift,
+                            uint64_t *lo_out, uint64_t *hi_out)
+{
+    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seq) return;
+    uint64_t l = 0, r = ix.n;
+    for (uint64_t t = (uint64_t)offsets[s]; t < (uint64_t)offsets[s + 1]; t++) {
+        uint64_t c = (uint64_t)((int64_t)tokens[t] + shift);
+        bs_step(ix, c, l, r, l, r, nullptr);
+    }
+    lo_out[s] = l; hi_out[s] = r + 1;
+}
+
+// ---------------------------------------------------------------------------
+// K2: interval -> distinct symbols (+counts)   (sdsl interval_symbols as used by
+// fm_index.cpp:78-109).  One wavefront per work item (a wavelet-matrix node
+// [lo, hi) at some level with its symbol prefix).  The wave keeps its frontier
+// in LDS as one small array per relative level (a level-j array can never hold
+// more than min(2^j, 128) nodes: it is only refilled, by at most 64 parents,
+// when every deeper level is empty), pops up to 64 nodes of the deepest
+// non-empty level, does the two rank probes of each node in parallel lanes and
+// compacts the surviving children with ballot + popcount.
+// ---------------------------------------------------------------------------
+struct ExpandItem {
+    uint64_t lo, hi;
+    uint32_t row, level, prefix, pad;
+};
+
+enum { EMIT_BITS = 0, EMIT_DENSE = 1 };
+
+struct EmitTarget {
+    uint32_t *bits;       // EMIT_BITS : [rows][words_per_row]
+    uint64_t words_per_row;
+    int64_t shift;        // token = symbol - shift
+    uint64_t vocab;
+    uint64_t *dense;      // EMIT_DENSE: [rows][dense_stride] counts by symbol
+    uint64_t dense_stride;
+};
+
+// LDS traffic between the lanes of ONE wave: DS operations of a wave execute in
+// order, so a wavefront-scope fence (no cache maintenance) plus a scheduling
+// barrier is all that is needed.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+static constexpr int EXP_WAVES = 4;                 // waves per workgroup
+static constexpr int EXP_LVL_CAP = 128;
+// relative level j occupies [lvl_off(j), lvl_off(j)+min(2^j,128))
+__host__ __device__ constexpr int lvl_off(int j) { return j < 7 ? (1 << j) - 1 : 127 + (j - 7) * EXP_LVL_CAP; }
+static constexpr int EXP_SLOTS = 127 + (FMI_MAX_LEVELS - 7) * EXP_LVL_CAP;   // levels 0..L-2 are ever stored
+
+template <int MODE>
+__device__ __forceinline__ void emit_leaf(const EmitTarget &t, uint32_t row, uint32_t sym, uint64_t count)
+{
+    if (MODE == EMIT_BITS) {
+        int64_t tok = (int64_t)sym - t.shift;
+        if (sym > 0 && tok >= 0 && (uint64_t)tok < t.vocab)
+            atomicOr(&t.bits[(uint64_t)row * t.words_per_row + ((uint64_t)tok >> 5)], 1u << (tok & 31));
+    } else {
+        t.dense[(uint64_t)row * t.dense_stride + sym] = count;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const ExpandItem *items, const uint32_t *n_items_ptr,
+                                                           uint32_t n_items_static, EmitTarget tgt, uint64_t *probe_counter)
+{
+    __shared__ uint32_t s_lo[EXP_WAVES][EXP_SLOTS];
+    __shared__ uint32_t s_hi[EXP_WAVES][EXP_SLOTS];
+    __shared__ uint32_t s_mx[EXP_WAVES][EXP_SLOTS];   // lo[39:32] | hi[39:32]<<8 | prefix<<16 (prefix <= 16 bits)
+    __shared__ uint32_t s_cnt[EXP_WAVES][FMI_MAX_LEVELS];
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t n_items = n_items_ptr ? *n_items_ptr : n_items_static;
+    const uint32_t L = ix.levels;
+    uint64_t probes = 0;
+    uint64_t *pp = probe_counter ? &probes : nullptr;
+
+    for (uint32_t item = blockIdx.x * EXP_WAVES + wv; item < n_items; item += gridDim.x * EXP_WAVES) {
+        const ExpandItem it = items[item];
+        if (it.hi <= it.lo) continue;
+        const uint32_t row = it.row;
+        const uint32_t root = it.level;
+        // a root sitting on the last level is already a leaf
+        if (root >= L) { if (lane == 0) emit_leaf<MODE>(tgt, row, it.prefix, it.hi - it.lo); continue; }
+        if (lane < FMI_MAX_LEVELS) s_cnt[wv][lane] = 0;
+        if (lane == 0) {
+            s_lo[wv][0] = (uint32_t)it.lo; s_hi[wv][0] = (uint32_t)it.hi;
+            // positions < 2^40: 8 high bits each
+            s_mx[wv][0] = (uint32_t)(it.lo >> 32) | ((uint32_t)(it.hi >> 32) << 8) | (it.prefix << 16);
+            s_cnt[wv][0] = 1;
+        }
+        wave_sync();
+        int deepest = 0;   // relative level of the deepest non-empty array (wave uniform)
+        while (deepest >= 0) {
+            const uint32_t cnt = s_cnt[wv][deepest];
+            if (cnt == 0) { deepest--; continue; }
+            const uint32_t m = cnt < 64 ? cnt : 64;
+            const uint32_t base = lvl_off(deepest) + (cnt - m);
+            const uint32_t k = root + deepest;      // absolute level of the popped nodes
+            bool act = lane < m;
+            uint64_t lo = 0, hi = 0; uint32_t prefix = 0;
+            if (act) {
+                const uint32_t mx = s_mx[wv][base + lane];
+                lo = (uint64_t)s_lo[wv][base + lane] | ((uint64_t)(mx & 0xff) << 32);
+                hi = (uint64_t)s_hi[wv][base + lane] | ((uint64_t)((mx >> 8) & 0xff) << 32);
+                prefix = mx >> 16;
+            }
+            wave_sync();
+            if (lane == 0) s_cnt[wv][deepest] = cnt - m;
+            uint64_t r_lo = 0, r_hi = 0;
+            if (act) {
+                r_lo = wm_rank1(ix, k, lo, pp);
+                r_hi = wm_rank1(ix, k, hi, pp);
+            }
+            const uint64_t ones = r_hi - r_lo;
+            const uint64_t zer = (hi - lo) - ones;
+            const bool has0 = act && zer > 0, has1 = act && ones > 0;
+            const uint64_t z = ix.zeros[k];
+            if (k + 1 == L) {
+                if (has0) emit_leaf<MODE>(tgt, row, prefix << 1, zer);
+                if (has1) emit_leaf<MODE>(tgt, row, (prefix << 1) | 1, ones);
+            } else {
+                const uint64_t b0 = __ballot(has0), b1 = __ballot(has1);
+                const uint64_t lt = (1ull << lane) - 1;
+                const uint32_t n0 = (uint32_t)__popcll(b0);
+                const uint32_t dst = lvl_off(deepest + 1) + s_cnt[wv][deepest + 1];
+                if (has0) {
+                    const uint32_t o = dst + (uint32_t)__popcll(b0 & lt);
+                    const uint64_t clo = lo - r_lo, chi = hi - r_hi;
+                    s_lo[wv][o] = (uint32_t)clo; s_hi[wv][o] = (uint32_t)chi;
+                    s_mx[wv][o] = (uint32_t)(clo >> 32) | ((uint32_t)(chi >> 32) << 8) | ((prefix << 1) << 16);
+                }
+                if (has1) {
+                    const uint32_t o = dst + n0 + (uint32_t)__popcll(b1 & lt);
+                    const uint64_t clo = z + r_lo, chi = z + r_hi;
+                    s_lo[wv][o] = (uint32_t)clo; s_hi[wv][o] = (uint32_t)chi;
+                    s_mx[wv][o] = (uint32_t)(clo >> 32) | ((uint32_t)(chi >> 32) << 8) | (((prefix << 1) | 1) << 16);
+                }
+                wave_sync();
+                const uint32_t added = n0 + (uint32_t)__popcll(b1);
+                if (lane == 0) s_cnt[wv][deepest + 1] += added;
+                wave_sync();
+                if (added) deepest++;
+            }
+        }
+        wave_sync();
+    }
+    if (probe_counter && probes) atomicAdd((unsigned long long *)probe_counter, (unsigned long long)probes);
+}
+
+// dense per-row symbol counts -> CSR, ascending symbols.  One workgroup per row.
+__global__ __launch_bounds__(256) void k_dense_count(const uint64_t *dense, uint64_t stride, uint64_t nsym, uint64_t *row_k)
+{
+    __shared__ uint32_t s_part[256];
+    const uint64_t *d = dense + (uint64_t)blockIdx.x * stride;
+    uint32_t c = 0;
+    for (uint64_t s = threadIdx.x; s < nsym; s += 256) c += d[s] != 0;
+    s_part[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) row_k[blockIdx.x] = s_part[0];
+}
+
+__global__ __launch_bounds__(256) void k_dense_compact(const uint64_t *dense, uint64_t stride, uint64_t nsym,
+                                                       const uint64_t *offsets, uint64_t *syms, uint64_t *cnts)
+{
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base;
+    const uint64_t *d = dense + (uint64_t)blockIdx.x * stride;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    const uint64_t out0 = offsets[blockIdx.x];
+    for (uint64_t s0 = 0; s0 < nsym; s0 += 256) {
+        const uint64_t s = s0 + threadIdx.x;
+        const uint64_t v = s < nsym ? d[s] : 0;
+        const uint64_t b = __ballot(v != 0);
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t before = s_base;
+        for (uint32_t w = 0; w < wv; w++) before += s_wave[w];
+        if (v != 0) {
+            const uint64_t o = out0 + before + (uint32_t)__popcll(b & ((1ull << lane) - 1));
+            syms[o] = s;
+            if (cnts) cnts[o] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a9: IndexBasedLogitsProcessor.__call__, cur_len >= 2 (seal/beam_search.py:79-140)
+// ---------------------------------------------------------------------------
+static constexpr int MAX_FORCE = 8;
+struct ForceFrom { int64_t tok[MAX_FORCE]; uint32_t n; };
+
+// one thread per (batch, beam) row: ranges of the prefix, the row's class, and
+// the work item for the expansion.  Lines 87-105 and the branch order of 111-131.
+__global__ void k_prefix_ranges(FmiDev ix, uint64_t rows, uint64_t cur_len, const int64_t *ids, int64_t shift,
+                                int64_t pad_id, int64_t eos_id, ForceFrom ff, int64_t stop_at_count,
+                                int always_allow_eos, uint64_t vocab, uint64_t words_per_row,
+                                uint32_t *bits, ExpandItem *items)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const int64_t *sent = ids + r * cur_len;
+    const int64_t last = sent[cur_len - 1];
+    uint64_t lo = 0, hi = 0, count = 0;
+    if (!(last == eos_id || last == pad_id)) {
+        // get_range(force_decoding_from + sent[1:]) and get_count(... sent[1:-1])
+        uint64_t l = 0, rr = ix.n;
+        const uint64_t total = ff.n + (cur_len - 1);
+        for (uint64_t t = 0; t < total; t++) {
+            if (t + 1 == total) count = (rr + 1) - l;
+            const int64_t tok = t < ff.n ? ff.tok[t] : sent[1 + (t - ff.n)];
+            bs_step(ix, (uint64_t)(tok + shift), l, rr, l, rr, nullptr);
+        }
+        if (total == 0) count = (rr + 1) - l;
+        lo = l; hi = rr + 1;
+    }
+    uint32_t *myrow = bits + r * words_per_row;
+    int64_t single = -1;
+    ExpandItem it{0, 0, (uint32_t)r, 0, 0, 0};
+    if (stop_at_count > 0 && (int64_t)count <= stop_at_count) single = eos_id;
+    else if (last == eos_id || last == pad_id) single = pad_id;
+    else { it.lo = lo; it.hi = hi > ix.n ? ix.n : hi; }
+    items[r] = it;
+    if (single >= 0 && (uint64_t)single < vocab) atomicOr(&myrow[single >> 5], 1u << (single & 31));
+    if (always_allow_eos && eos_id >= 0 && (uint64_t)eos_id < vocab) atomicOr(&myrow[eos_id >> 5], 1u << (eos_id & 31));
+}
+
+// out = allowed ? in : -inf     (scores + mask with mask in {0, -inf}, beam_search.py:64,140)
+__global__ __launch_bounds__(256) void k_apply_bits(const float *in, float *out, const uint32_t *bits, uint64_t rows,
+                                                    uint64_t vocab, uint64_t words_per_row)
+{
+    const uint64_t row = blockIdx.y;
+    const float ninf = -__builtin_huge_valf();
+    const float *src = in + row * vocab;
+    float *dst = out + row * vocab;
+    const uint32_t *b = bits + row * words_per_row;
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < vocab; v += (uint64_t)gridDim.x * blockDim.x)
+        dst[v] = ((b[v >> 5] >> (v & 31)) & 1) ? src[v] : ninf;
+}
+
+// ---------------------------------------------------------------------------
+// K3/K4: locate + doc binning
+// ---------------------------------------------------------------------------
+__global__ void k_locate(FmiDev ix, uint64_t n, const uint64_t *rows, uint64_t *pos_out, uint64_t *doc_out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t row = rows[i];
+    if (row >= ix.n) { pos_out[i] = ~0ull; if (doc_out) doc_out[i] = ~0ull; return; }
+    const uint64_t pos = sa_at(ix, row);
+    pos_out[i] = pos;
+    if (doc_out) doc_out[i] = ix.n_begin ? doc_of(ix, pos) : ~0ull;
+}
+
+// ranges form: output element e belongs to range j = upper_bound(out_offsets, e)-1,
+// row = lo[j] + (e - out_offsets[j])
+__global__ void k_locate_ranges(FmiDev ix, uint64_t n_ranges, const uint64_t *lo, const uint64_t *out_offsets,
+                                uint64_t total, uint64_t *pos_out, uint64_t *doc_out)
+{
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    uint64_t a = 0, b = n_ranges;   // last j with out_offsets[j] <= e
+    while (b - a > 1) { uint64_t mid = (a + b) >> 1; if (out_offsets[mid] <= e) a = mid; else b = mid; }
+    const uint64_t row = lo[a] + (e - out_offsets[a]);
+    if (row >= ix.n) { pos_out[e] = ~0ull; if (doc_out) doc_out[e] = ~0ull; return; }
+    const uint64_t pos = sa_at(ix, row);
+    pos_out[e] = pos;
+    if (doc_out) doc_out[e] = ix.n_begin ? doc_of(ix, pos) : ~0ull;
+}
+
+// ---------------------------------------------------------------------------
+// K6: extract_text / get_doc: the text itself is resident, so
+// T[end-1] ... T[begin] (fm_index.cpp:169-184) is a reversed contiguous read.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t text_at(const FmiDev &ix, uint64_t p)
+{
+    return ix.sym_bytes == 2 ? (uint64_t)((const uint16_t *)ix.text)[p] : (uint64_t)((const uint32_t *)ix.text)[p];
+}
+
+__global__ void k_extract(FmiDev ix, uint64_t begin, uint64_t end, uint64_t *out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (begin + i >= end) return;
+    out[i] = text_at(ix, end - 1 - i);
+}
+
+__global__ void k_get_docs(FmiDev ix, const uint64_t *docs, const uint64_t *out_offsets, int64_t shift, int64_t *out)
+{
+    const uint64_t d = docs[blockIdx.x];
+    const uint64_t b = ix.doc_begin[d], e = ix.doc_begin[d + 1];
+    int64_t *o = out + out_offsets[blockIdx.x];
+    for (uint64_t i = threadIdx.x; b + i < e; i += blockDim.x) o[i] = (int64_t)text_at(ix, e - 1 - i) - shift;
+}
+
+// ---------------------------------------------------------------------------
+// host side of the query entry points
+// ---------------------------------------------------------------------------
+static int need_device(fmi *h)
+{
+    if (!h) { fmi_set_error("null handle"); return FMI_ERR_ARG; }
+    if (h->device < 0) {
+        fmi_set_error("index is not resident on a GPU: libsealfm has no CPU query path (call fmi_to_device on a gfx950 box)");
+        return FMI_ERR_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    return FMI_OK;
+}
+
+static inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) { fmi_set_error("hipMalloc(%zu) failed", bytes); return FMI_ERR_HIP; } return FMI_OK; }
+    template <class T> T *as() { return (T *)p; }
+};
+
+extern "C" int fmi_dev_enable_probe_count(fmi_t *h, int enable)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (enable && !h->d_probe_counter) {
+        HIPCHK(hipMalloc((void **)&h->d_probe_counter, 8));
+    }
+    if (h->d_probe_counter) HIPCHK(hipMemset(h->d_probe_counter, 0, 8));
+    h->probe_count_enabled = enable;
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_read_probe_count(fmi_t *h, uint64_t *out)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (!h->d_probe_counter || !out) { fmi_set_error("probe counter not enabled"); return FMI_ERR_STATE; }
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, h->d_probe_counter, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->d_probe_counter, 0, 8));
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_bs_step(fmi_t *h, void *stream, uint64_t n, const uint64_t *d_sym, const uint64_t *d_lo,
+                               const uint64_t *d_hi, uint64_t *d_lo_out, uint64_t *d_hi_out)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (n == 0) return FMI_OK;
+    hipLaunchKernelGGL(k_bs_step, dim3(blocks_for(n, 64)), dim3(64), 0, (hipStream_t)stream, h->dev, n, d_sym, d_lo, d_hi, d_lo_out, d_hi_out);
+    HIPCHK(hipGetLastError());
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_get_range(fmi_t *h, void *stream, uint64_t n_seq, const int64_t *d_offsets,
+                                 const int64_t *d_tokens, int64_t shift, uint64_t *d_lo_out, uint64_t *d_hi_out)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (n_seq == 0) return FMI_OK;
+    hipLaunchKernelGGL((k_get_range<int64_t, int64_t>), dim3(blocks_for(n_seq, 64)), dim3(64), 0, (hipStream_t)stream,
+                       h->dev, n_seq, d_offsets, d_tokens, shift, d_lo_out, d_hi_out);
+    HIPCHK(hipGetLastError());
+    return FMI_OK;
+}
+
+// workspace = expansion items + allowed-token bitmap (vocab <= 2^17 -> 4096 words/row)
+static constexpr uint64_t WS_BITS_WORDS = (1ull << FMI_MAX_LEVELS) / 32;
+extern "C" int fmi_dev_reserve(fmi_t *h, uint64_t max_rows)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (max_rows <= h->ws_rows) return FMI_OK;
+    if (h->ws) { HIPCHK(hipFree(h->ws)); h->ws = nullptr; h->ws_rows = 0; }
+    const uint64_t bytes = max_rows * (sizeof(ExpandItem) + WS_BITS_WORDS * 4);
+    HIPCHK(hipMalloc(&h->ws, bytes));
+    h->ws_bytes = bytes; h->ws_rows = max_rows;
+    return FMI_OK;
+}
+
+static unsigned expand_grid(uint64_t n_items)
+{
+    uint64_t g = (n_items + EXP_WAVES - 1) / EXP_WAVES;
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(g, 256ull * 16));
+}
+
+static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur_len, const int64_t *d_ids,
+                             uint32_t *d_bits, uint64_t vocab, int64_t shift, int64_t pad_id, int64_t eos_id,
+                             const int64_t *force_from, uint64_t n_force, int64_t stop_at_count, int always_allow_eos)
+{
+    if (cur_len < 2) { fmi_set_error("cur_len must be >= 2 (cur_len == 1 is the constant occurring_distinct mask, beam_search.py:73-77)"); return FMI_ERR_ARG; }
+    if (n_force > MAX_FORCE) { fmi_set_error("force_decoding_from longer than %d", MAX_FORCE); return FMI_ERR_UNSUPPORTED; }
+    if (rows > h->ws_rows) { int rc = fmi_dev_reserve(h, rows); if (rc) return rc; }
+    const uint64_t wpr = (vocab + 31) / 32;
+    ForceFrom ff{}; ff.n = (uint32_t)n_force;
+    for (uint64_t i = 0; i < n_force; i++) ff.tok[i] = force_from[i];
+    ExpandItem *items = (ExpandItem *)h->ws;
+    HIPCHK(hipMemsetAsync(d_bits, 0, rows * wpr * 4, st));
+    hipLaunchKernelGGL(k_prefix_ranges, dim3(blocks_for(rows, 64)), dim3(64), 0, st, h->dev, rows, cur_len, d_ids, shift,
+                       pad_id, eos_id, ff, stop_at_count, always_allow_eos, vocab, wpr, d_bits, items);
+    EmitTarget tgt{}; tgt.bits = d_bits; tgt.words_per_row = wpr; tgt.shift = shift; tgt.vocab = vocab;
+    hipLaunchKernelGGL((k_expand<EMIT_BITS>), dim3(expand_grid(rows)), dim3(EXP_WAVES * 64), 0, st, h->dev, items,
+                       (const uint32_t *)nullptr, (uint32_t)rows, tgt, h->probe_count_enabled ? h->d_probe_counter : nullptr);
+    HIPCHK(hipGetLastError());
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_allowed_bits(fmi_t *h, void *stream, uint64_t rows, uint64_t cur_len, const int64_t *d_input_ids,
+                                    uint32_t *d_bits, uint64_t vocab, int64_t shift, int64_t pad_id, int64_t eos_id,
+                                    const int64_t *force_from, uint64_t n_force, int64_t stop_at_count, int always_allow_eos)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (rows == 0) return FMI_OK;
+    return allowed_bits_impl(h, (hipStream_t)stream, rows, cur_len, d_input_ids, d_bits, vocab, shift, pad_id, eos_id,
+                             force_from, n_force, stop_at_count, always_allow_eos);
+}
+
+extern "C" int fmi_dev_constrain_scores(fmi_t *h, void *stream, uint64_t rows, uint64_t cur_len, const int64_t *d_input_ids,
+                                        const float *d_in, float *d_out, uint64_t vocab, int64_t shift, int64_t pad_id,
+                                        int64_t eos_id, const int64_t *force_from, uint64_t n_force, int64_t stop_at_count,
+                                        int always_allow_eos)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (rows == 0) return FMI_OK;
+    const uint64_t wpr = (vocab + 31) / 32;
+    if (wpr > WS_BITS_WORDS) { fmi_set_error("vocab %llu too large", (unsigned long long)vocab); return FMI_ERR_UNSUPPORTED; }
+    if (rows > h->ws_rows) { rc = fmi_dev_reserve(h, rows); if (rc) return rc; }
+    // bitmap lives behind the items in the workspace
+    uint32_t *bits = (uint32_t *)((char *)h->ws + h->ws_rows * sizeof(ExpandItem));
+    rc = allowed_bits_impl(h, (hipStream_t)stream, rows, cur_len, d_input_ids, bits, vocab, shift, pad_id, eos_id,
+                           force_from, n_force, stop_at_count, always_allow_eos);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_apply_bits, dim3(blocks_for(vocab, 256 * 4), (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                       d_in, d_out, bits, rows, vocab, wpr);
+    HIPCHK(hipGetLastError());
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_locate(fmi_t *h, void *stream, uint64_t n, const uint64_t *d_rows, uint64_t *d_pos_out, uint64_t *d_doc_out)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (n == 0) return FMI_OK;
+    hipLaunchKernelGGL(k_locate, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, h->dev, n, d_rows, d_pos_out, d_doc_out);
+    HIPCHK(hipGetLastError());
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_locate_ranges(fmi_t *h, void *stream, uint64_t n_ranges, const uint64_t *d_lo, const uint64_t *d_hi,
+                                     uint64_t max_per_range, const uint64_t *d_out_offsets, uint64_t total,
+                                     uint64_t *d_pos_out, uint64_t *d_doc_out)
+{
+    (void)d_hi; (void)max_per_range;   // already folded into d_out_offsets by the caller
+    int rc = need_device(h); if (rc) return rc;
+    if (total == 0 || n_ranges == 0) return FMI_OK;
+    hipLaunchKernelGGL(k_locate_ranges, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, h->dev, n_ranges,
+                       d_lo, d_out_offsets, total, d_pos_out, d_doc_out);
+    HIPCHK(hipGetLastError());
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_get_docs(fmi_t *h, void *stream, uint64_t n_docs, const uint64_t *d_docs, const uint64_t *d_out_offsets,
+                                int64_t shift, int64_t *d_out)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (n_docs == 0) return FMI_OK;
+    if (!h->dev.doc_begin) { fmi_set_error("doc beginnings not set"); return FMI_ERR_STATE; }
+    hipLaunchKernelGGL(k_get_docs, dim3((unsigned)n_docs), dim3(64), 0, (hipStream_t)stream, h->dev, d_docs, d_out_offsets, shift, d_out);
+    HIPCHK(hipGetLastError());
+    return FMI_OK;
+}
+
+// ---- host-buffer wrappers (what each SWIG method call becomes) -------------
+
+extern "C" int fmi_backward_search_step(fmi_t *h, uint64_t symbol, uint64_t low, uint64_t high, uint64_t out[2])
+{
+    int rc = need_device(h); if (rc) return rc;
+    DevBuf b; if ((rc = b.alloc(5 * 8))) return rc;
+    uint64_t in[3] = {symbol, low, high};
+    uint64_t *d = b.as<uint64_t>();
+    HIPCHK(hipMemcpy(d, in, 24, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_bs_step, dim3(1), dim3(64), 0, 0, h->dev, (uint64_t)1, d, d + 1, d + 2, d + 3, d + 4);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, d + 3, 16, hipMemcpyDeviceToHost));
+    return FMI_OK;
+}
+
+extern "C" int fmi_backward_search_multi_batch(fmi_t *h, uint64_t n_seq, const uint64_t *offsets, const uint64_t *symbols,
+                                               uint64_t *lo_out, uint64_t *hi_out)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (n_seq == 0) return FMI_OK;
+    const uint64_t ntok = offsets[n_seq];
+    DevBuf off, tok, res;
+    if ((rc = off.alloc((n_seq + 1) * 8)) || (rc = tok.alloc(ntok * 8)) || (rc = res.alloc(n_seq * 16))) return rc;
+    HIPCHK(hipMemcpy(off.p, offsets, (n_seq + 1) * 8, hipMemcpyHostToDevice));
+    if (ntok) HIPCHK(hipMemcpy(tok.p, symbols, ntok * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((k_get_range<uint64_t, uint64_t>), dim3(blocks_for(n_seq, 64)), dim3(64), 0, 0, h->dev, n_seq,
+                       off.as<uint64_t>(), tok.as<uint64_t>(), (int64_t)0, res.as<uint64_t>(), res.as<uint64_t>() + n_seq);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(lo_out, res.p, n_seq * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hi_out, res.as<uint64_t>() + n_seq, n_seq * 8, hipMemcpyDeviceToHost));
+    return FMI_OK;
+}
+
+extern "C" int fmi_backward_search_multi(fmi_t *h, const uint64_t *query, uint64_t len, uint64_t out[2])
+{
+    uint64_t offs[2] = {0, len};
+    return fmi_backward_search_multi_batch(h, 1, offs, query, &out[0], &out[1]);
+}
+
+extern "C" int fmi_distinct_count_multi(fmi_t *h, uint64_t n, const uint64_t *lows, const uint64_t *highs,
+                                        uint64_t *offsets_out, uint64_t *syms_out, uint64_t *cnts_out, uint64_t cap)
+{
+    int rc = need_device(h); if (rc) return rc;
+    offsets_out[0] = 0;
+    if (n == 0) return FMI_OK;
+    const uint64_t nsym = h->max_sym + 1;
+    // bounded dense scratch: process the intervals in chunks of rows
+    const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n, (512ull << 20) / (nsym * 8)));
+    DevBuf dense, items, rowk, offs, osym, ocnt;
+    if ((rc = dense.alloc(chunk * nsym * 8)) || (rc = items.alloc(chunk * sizeof(ExpandItem))) ||
+        (rc = rowk.alloc(chunk * 8)) || (rc = offs.alloc((chunk + 1) * 8))) return rc;
+    std::vector<ExpandItem> hitems(chunk);
+    std::vector<uint64_t> hk(chunk), hoff(chunk + 1);
+    uint64_t written = 0;
+    bool overflow = false;
+    for (uint64_t c0 = 0; c0 < n; c0 += chunk) {
+        const uint64_t m = std::min(chunk, n - c0);
+        for (uint64_t i = 0; i < m; i++) {
+            uint64_t lo = lows[c0 + i], hi = highs[c0 + i];
+            if (hi > h->n) hi = h->n;               // rows past the end do not exist (reference: undefined)
+            if (lo >= hi) { lo = hi = 0; }          // low == high -> empty (fm_index.cpp:81,99)
+            hitems[i] = ExpandItem{lo, hi, (uint32_t)i, 0, 0, 0};
+        }
+        HIPCHK(hipMemcpy(items.p, hitems.data(), m * sizeof(ExpandItem), hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(dense.p, 0, m * nsym * 8));
+        EmitTarget tgt{}; tgt.dense = dense.as<uint64_t>(); tgt.dense_stride = nsym;
+        hipLaunchKernelGGL((k_expand<EMIT_DENSE>), dim3(expand_grid(m)), dim3(EXP_WAVES * 64), 0, 0, h->dev,
+                           items.as<ExpandItem>(), (const uint32_t *)nullptr, (uint32_t)m, tgt,
+                           h->probe_count_enabled ? h->d_probe_counter : nullptr);
+        hipLaunchKernelGGL(k_dense_count, dim3((unsigned)m), dim3(256), 0, 0, dense.as<uint64_t>(), nsym, nsym, rowk.as<uint64_t>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(hk.data(), rowk.p, m * 8, hipMemcpyDeviceToHost));
+        hoff[0] = 0;
+        for (uint64_t i = 0; i < m; i++) { hoff[i + 1] = hoff[i] + hk[i]; offsets_out[c0 + i + 1] = written + hoff[i + 1]; }
+        const uint64_t tot = hoff[m];
+        if (written + tot > cap || overflow || !syms_out) { overflow = true; written += tot; continue; }
+        if (tot) {
+            DevBuf ds, dc;
+            if ((rc = ds.alloc(tot * 8)) || (rc = dc.alloc(tot * 8))) return rc;
+            HIPCHK(hipMemcpy(offs.p, hoff.data(), (m + 1) * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_dense_compact, dim3((unsigned)m), dim3(256), 0, 0, dense.as<uint64_t>(), nsym, nsym,
+                               offs.as<uint64_t>(), ds.as<uint64_t>(), cnts_out ? dc.as<uint64_t>() : (uint64_t *)nullptr);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpy(syms_out + written, ds.p, tot * 8, hipMemcpyDeviceToHost));
+            if (cnts_out) HIPCHK(hipMemcpy(cnts_out + written, dc.p, tot * 8, hipMemcpyDeviceToHost));
+        }
+        written += tot;
+    }
+    if (overflow) { fmi_set_error("output capacity %llu too small, need %llu", (unsigned long long)cap, (unsigned long long)written); return FMI_ERR_CAPACITY; }
+    return FMI_OK;
+}
+
+extern "C" int fmi_locate(fmi_t *h, uint64_t n, const uint64_t *rows, uint64_t *pos_out, uint64_t *doc_out)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (n == 0) return FMI_OK;
+    if (doc_out && !h->dev.doc_begin) { fmi_set_error("doc beginnings not set"); return FMI_ERR_STATE; }
+    DevBuf b; if ((rc = b.alloc(n * 24))) return rc;
+    uint64_t *d = b.as<uint64_t>();
+    HIPCHK(hipMemcpy(d, rows, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_locate, dim3(blocks_for(n, 256)), dim3(256), 0, 0, h->dev, n, d, d + n, doc_out ? d + 2 * n : (uint64_t *)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(pos_out, d + n, n * 8, hipMemcpyDeviceToHost));
+    if (doc_out) HIPCHK(hipMemcpy(doc_out, d + 2 * n, n * 8, hipMemcpyDeviceToHost));
+    return FMI_OK;
+}
+
+extern "C" int fmi_extract_text(fmi_t *h, uint64_t begin, uint64_t end, uint64_t *out)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (end <= begin) return FMI_OK;
+    if (end > h->n) { fmi_set_error("extract_text: end %llu > size %llu", (unsigned long long)end, (unsigned long long)h->n); return FMI_ERR_ARG; }
+    const uint64_t m = end - begin;
+    DevBuf b; if ((rc = b.alloc(m * 8))) return rc;
+    hipLaunchKernelGGL(k_extract, dim3(blocks_for(m, 256)), dim3(256), 0, 0, h->dev, begin, end, b.as<uint64_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, b.p, m * 8, hipMemcpyDeviceToHost));
+    return FMI_OK;
+}
+
+// GPU construction lives in fmi_build_gpu.hip

@@ -1,0 +1,181 @@
+"""``seal.index.FMIndex`` on the MI355X engine.
+
+Keeps the reference's Python surface (reference seal/index.py:20-204): same
+method names, argument meaning and returns, ``SHIFT`` re-basing, per-document
+reversal, ``beginnings`` / ``occurring`` / ``occurring_distinct`` /
+``occurring_counts`` / ``labels`` attributes and the ``.oth`` pickle sidecar --
+on top of ``seal_amd.cpp_modules.fm_index.FMIndex`` (libsealfm.so, HIP kernels).
+
+Additions (not in the reference) are the ``*_batch`` / ``dev_*`` methods the
+GPU decode and retrieval paths use to avoid one launch per Python call.
+"""
+import bisect
+import ctypes
+import pickle
+from typing import Iterable, Iterator, List, Optional, Sequence, Set, Tuple
+
+import numpy as np
+
+from ._lib import _p64, check, lib
+from .cpp_modules.fm_index import FMIndex as _FMIndex
+from .cpp_modules.fm_index import _arr, _ptr, default_device, load_FMIndex
+
+SHIFT = 10        # reference seal/index.py:16
+FORMAT = "<l"     # reference seal/index.py:18
+
+
+class FMIndex(_FMIndex):
+    """FM-index over token-id documents, resident in HBM."""
+
+    beginnings: List[int]
+    occurring: Set[int]
+    occurring_distinct: List[int]
+    occurring_counts: List[int]
+    labels: Optional[List[str]]
+
+    def __init__(self):
+        super().__init__()
+        self.beginnings = [0]
+        self.occurring = set()
+        self.occurring_distinct = []
+        self.occurring_counts = []
+        self.labels = None
+
+    # -- construction (reference index.py:39-66) ---------------------------
+    def initialize(self, sequences: Iterable[List[int]], in_memory: bool = False) -> None:
+        """Build the index from an iterable of token-id lists.
+
+        ``in_memory`` is accepted for signature compatibility; the reference's
+        two branches differ only in how sdsl is handed the symbols (temp file
+        of little-endian int32 vs. vector) and produce the same index.
+        """
+        occurring = set()
+        chunks = []
+        for seq in sequences:
+            seq = np.asarray(list(seq), dtype=np.int64)
+            self.beginnings.append(self.beginnings[-1] + len(seq))
+            occurring.update(seq.tolist())
+            chunks.append(seq[::-1] + SHIFT)
+        self.occurring = list(occurring)
+        data = np.concatenate(chunks).astype(np.uint64) if chunks else np.zeros(0, dtype=np.uint64)
+        _FMIndex.initialize(self, data)
+        self._after_build()
+
+    def _after_build(self) -> None:
+        self._push_beginnings()
+        self.occurring_distinct, self.occurring_counts = self.get_distinct_count(0, len(self))
+
+    def _push_beginnings(self) -> None:
+        b = np.asarray(self.beginnings, dtype=np.uint64)
+        check(lib().fmi_set_doc_beginnings(self._h, _ptr(b), len(b)))
+
+    # -- reference API ------------------------------------------------------
+    def get_doc(self, doc_index: int) -> List[int]:  # index.py:68-75
+        doc = self.extract_text(self.beginnings[doc_index], self.beginnings[doc_index + 1])
+        return [x - SHIFT for x in doc]
+
+    def get_doc_index(self, token_index: int) -> int:  # index.py:77-82
+        return bisect.bisect_right(self.beginnings, token_index) - 1
+
+    def get_doc_length(self, doc_index: int) -> int:  # index.py:84-88
+        return self.beginnings[doc_index + 1] - self.beginnings[doc_index]
+
+    def get_token_index_from_row(self, row: int) -> int:  # index.py:90-94
+        return self.locate(row)
+
+    def get_doc_index_from_row(self, row: int) -> int:  # index.py:96-100
+        return self.get_doc_index(self.locate(row))
+
+    def get_range(self, sequence: List[int]) -> Tuple[int, int]:  # index.py:102-111
+        # one launch for the whole prefix instead of one SWIG call per token;
+        # identical arithmetic: start at (0, size()), one backward step per token
+        lo, hi = self.get_range_batch([sequence])
+        return int(lo[0]), int(hi[0])
+
+    def get_count(self, sequence: List[int]) -> int:  # index.py:113-118
+        start, end = self.get_range(sequence)
+        return end - start
+
+    def get_doc_indices(self, sequence: List[int]) -> Iterator[int]:  # index.py:120-126
+        start, end = self.get_range(sequence)
+        if end > start:
+            _, docs = self.locate_batch(np.arange(start, end, dtype=np.uint64))
+            for d in docs:
+                yield int(d)
+
+    def get_continuations(self, sequence: List[int]) -> List[int]:  # index.py:128-134
+        start, end = self.get_range(sequence)
+        return self.get_distinct(start, end)
+
+    def get_distinct(self, low: int, high: int) -> List[int]:  # index.py:136-142
+        return [c - SHIFT for c in self.distinct(low, high) if c > 0]
+
+    def get_distinct_count(self, low: int, high: int) -> Tuple[List[int], List[int]]:  # index.py:144-156
+        return self.get_distinct_count_multi([low], [high])[0]
+
+    def get_distinct_count_multi(self, lows: List[int], highs: List[int]):  # index.py:158-171
+        offs, syms, cnts = self._distinct_csr(list(lows), list(highs), True)
+        ret = []
+        for i in range(len(offs) - 1):
+            a, b = int(offs[i]), int(offs[i + 1])
+            s, c = syms[a:b], cnts[a:b]
+            keep = s > 0                      # drops the sentinel (index.py:153,167)
+            ret.append(((s[keep].astype(np.int64) - SHIFT).tolist(), c[keep].astype(np.int64).tolist()))
+        return ret
+
+    def __len__(self) -> int:  # index.py:173-177
+        return self.beginnings[-1]
+
+    @property
+    def n_docs(self) -> int:  # index.py:179-184
+        return len(self.beginnings) - 1
+
+    def save(self, path: str) -> None:  # index.py:186-192
+        with open(path + ".oth", "wb") as f:
+            pickle.dump((self.beginnings, self.occurring, self.labels), f)
+        return super().save(path + ".fmi")
+
+    @classmethod
+    def load(cls, path: str) -> "FMIndex":  # index.py:194-204
+        index = load_FMIndex(path + ".fmi")
+        index.__class__ = cls
+        with open(path + ".oth", "rb") as f:
+            index.beginnings, index.occurring, index.labels = pickle.load(f)
+        index._after_build()
+        return index
+
+    # -- batched extras (GPU-friendly forms of the calls above) -------------
+    def get_range_batch(self, sequences: Sequence[Sequence[int]]):
+        """``get_range`` for many sequences in one launch -> (lo[], hi[]) uint64."""
+        n = len(sequences)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        if n:
+            offs[1:] = np.cumsum([len(s) for s in sequences])
+        total = int(offs[-1])
+        toks = np.zeros(max(total, 1), dtype=np.uint64)
+        if total:
+            toks[:total] = (np.fromiter((t for s in sequences for t in s), dtype=np.int64, count=total) + SHIFT).astype(np.uint64)
+        lo = np.zeros(n, dtype=np.uint64)
+        hi = np.zeros(n, dtype=np.uint64)
+        check(lib().fmi_backward_search_multi_batch(self._h, n, _ptr(offs), _ptr(toks), _ptr(lo), _ptr(hi)))
+        return lo, hi
+
+    def get_count_batch(self, sequences: Sequence[Sequence[int]]) -> np.ndarray:
+        lo, hi = self.get_range_batch(sequences)
+        return (hi - lo).astype(np.int64)
+
+    def locate_batch(self, rows) -> Tuple[np.ndarray, np.ndarray]:
+        """(positions, doc indices) for many rows: ``locate`` + ``get_doc_index``."""
+        r = _arr(rows)
+        pos = np.zeros(len(r), dtype=np.uint64)
+        doc = np.zeros(len(r), dtype=np.uint64)
+        check(lib().fmi_locate(self._h, len(r), _ptr(r), _ptr(pos), _ptr(doc)))
+        return pos, doc
+
+    # -- device-pointer forms (torch tensors on the index's GPU) -------------
+    @property
+    def handle(self):
+        return self._h
+
+    def device_bytes(self) -> int:
+        return int(lib().fmi_device_bytes(self._h))

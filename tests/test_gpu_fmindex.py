@@ -1,0 +1,165 @@
+"""GPU parity: the HIP FM-index (through the C ABI) against the CPU oracle on
+the same seeded inputs.  Integer results are compared bit-exactly."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _docs(seed, n_docs, vocab, min_len=2, max_len=30, zipf=None):
+    rng = np.random.default_rng(seed)
+    docs = []
+    for _ in range(n_docs):
+        m = int(rng.integers(min_len, max_len + 1))
+        if zipf:
+            toks = np.minimum(rng.zipf(zipf, size=m) + 3, vocab - 1)
+        else:
+            toks = rng.integers(3, vocab, size=m)
+        docs.append(toks.tolist() + [2])
+    return docs
+
+
+@pytest.fixture(scope="module", params=[(0, 40, 12), (1, 300, 500), (2, 2000, 50265)])
+def pair(request):
+    from oracle.seal_oracle import OracleFMIndex
+    from seal_amd import FMIndex
+    seed, n_docs, vocab = request.param
+    docs = _docs(seed, n_docs, vocab, zipf=1.2 if vocab > 1000 else None)
+    ix, orc = FMIndex(), OracleFMIndex()
+    ix.initialize(docs)
+    orc.initialize(docs)
+    return ix, orc, docs, vocab
+
+
+def test_size_and_first_step_tables(pair):
+    ix, orc, docs, vocab = pair
+    assert ix.size() == orc.size() and len(ix) == len(orc) and ix.n_docs == orc.n_docs
+    assert ix.beginnings == orc.beginnings
+    assert ix.occurring_distinct == orc.occurring_distinct
+    assert ix.occurring_counts == orc.occurring_counts
+    assert sorted(ix.occurring) == sorted(orc.occurring)
+
+
+def test_backward_search_step_and_ranges(pair):
+    ix, orc, docs, vocab = pair
+    rng = random.Random(1)
+    n = ix.size()
+    for _ in range(150):
+        c = rng.choice(rng.choice(docs)) + 10
+        l = rng.randrange(0, n)
+        r = rng.randrange(l, n)
+        assert ix.backward_search_step(c, l, r) == orc.backward_search_step(c, l, r)
+    # the reference's own first step: inclusive r = size() (quirk Q1), all symbols
+    for t in orc.occurring_distinct[:300]:
+        assert ix.backward_search_step(t + 10, 0, n) == orc.backward_search_step(t + 10, 0, n)
+    # symbols outside the alphabet -> (1, 0)
+    assert ix.backward_search_step(7, 0, n) == orc.backward_search_step(7, 0, n) == (1, 0)
+    assert ix.backward_search_step(10**6, 0, n) == orc.backward_search_step(10**6, 0, n) == (1, 0)
+    # empty incoming interval (l = r + 1)
+    assert ix.backward_search_step(docs[0][0] + 10, 5, 4) == orc.backward_search_step(docs[0][0] + 10, 5, 4)
+    seqs = []
+    for _ in range(300):
+        d = rng.choice(docs)
+        a = rng.randrange(len(d))
+        s = d[a:a + rng.randrange(1, 7)]
+        if rng.random() < 0.25:
+            s = s + [rng.randrange(3, vocab)]
+        seqs.append(s)
+    seqs += [[], [vocab + 5], [2], [2, 2]]
+    lo, hi = ix.get_range_batch(seqs)
+    for s, a, b in zip(seqs, lo, hi):
+        assert (int(a), int(b)) == orc.get_range(s), s
+        assert ix.backward_search_multi([t + 10 for t in s]) == orc.backward_search_multi([t + 10 for t in s])
+    assert ix.get_count(seqs[0]) == orc.get_count(seqs[0])
+
+
+def test_distinct_count_matches_interval_symbols(pair):
+    ix, orc, docs, vocab = pair
+    rng = random.Random(2)
+    n = ix.size()
+    lows, highs = [], []
+    for _ in range(60):
+        a = rng.randrange(0, n)
+        b = min(n, a + rng.choice([0, 1, 2, 3, 17, 200, 5000, n]))
+        lows.append(a); highs.append(b)
+    lows += [0, 0, n - 1]; highs += [n, n - 1, n]
+    got = ix.distinct_count_multi(lows, highs)
+    want = orc.distinct_count_multi(lows, highs)
+    assert got == want
+    for a, b in list(zip(lows, highs))[:10]:
+        assert ix.distinct(a, b) == orc.distinct(a, b)
+        assert ix.distinct_count(a, b) == orc.distinct_count(a, b)
+        assert ix.get_distinct(a, b) == orc.get_distinct(a, b)
+        assert ix.get_distinct_count(a, b) == orc.get_distinct_count(a, b)
+    assert ix.get_distinct_count_multi(lows, highs) == orc.get_distinct_count_multi(lows, highs)
+    d = rng.choice(docs)
+    assert ix.get_continuations(d[:2]) == orc.get_continuations(d[:2])
+
+
+def test_locate_docs_extract(pair):
+    ix, orc, docs, vocab = pair
+    n = ix.size()
+    rng = random.Random(3)
+    rows = [rng.randrange(n) for _ in range(400)] + [0, n - 1]
+    pos, doc = ix.locate_batch(rows)
+    for r, p, d in zip(rows, pos, doc):
+        assert int(p) == orc.locate(r)
+        assert int(d) == orc.get_doc_index(int(p))
+    assert ix.locate(n) == orc.locate(n) == 2**64 - 1
+    assert ix.locate(n + 7) == 2**64 - 1
+    assert ix.get_doc_index_from_row(rows[0]) == orc.get_doc_index_from_row(rows[0])
+    assert ix.get_token_index_from_row(rows[1]) == orc.get_token_index_from_row(rows[1])
+    for d in [0, 1, len(docs) // 2, len(docs) - 1]:
+        assert ix.get_doc(d) == orc.get_doc(d) == docs[d]
+        assert ix.get_doc_length(d) == len(docs[d])
+    b = ix.beginnings
+    assert ix.extract_text(b[1], b[1]) == orc.extract_text(b[1], b[1]) == ()
+    assert ix.extract_text(b[1], b[1] + 1) == orc.extract_text(b[1], b[1] + 1)
+    assert ix.extract_text(3, 11) == orc.extract_text(3, 11)
+    d = docs[3]
+    assert sorted(ix.get_doc_indices(d[:2])) == sorted(orc.get_doc_indices(d[:2]))
+
+
+def test_save_load_round_trip_on_gpu(pair, tmp_path):
+    from seal_amd import FMIndex
+    ix, orc, docs, vocab = pair
+    ix.labels = [f"doc{i}" for i in range(len(docs))]
+    ix.save(str(tmp_path / "idx"))
+    ix2 = FMIndex.load(str(tmp_path / "idx"))
+    assert ix2.labels == ix.labels and ix2.beginnings == ix.beginnings
+    assert ix2.occurring_distinct == ix.occurring_distinct and ix2.occurring_counts == ix.occurring_counts
+    assert ix2.get_range(docs[0][:3]) == orc.get_range(docs[0][:3])
+    assert ix2.get_doc(1) == docs[1]
+
+
+def test_logits_processor_matches_reference_semantics(pair):
+    import torch
+    from oracle.beam_oracle import oracle_logits_mask
+    from seal_amd.beam_search import IndexBasedLogitsProcessor
+    ix, orc, docs, vocab = pair
+    rng = random.Random(4)
+    V = vocab + 7
+    beams = 3
+    dev = torch.device("cuda:0")
+    for cur_len, kw in [(1, {}), (2, {}), (3, {}), (5, {}), (4, dict(force_decoding_from=[2])),
+                        (3, dict(stop_at_count=3)), (3, dict(always_allow_eos=True)), (1, dict(always_allow_eos=True)),
+                        (2, dict(forced_bos_token_id=0)), (1, dict(forced_bos_token_id=0))]:
+        rows = []
+        for i in range(4 * beams):
+            d = rng.choice(docs)
+            a = rng.randrange(len(d))
+            sent = [2] + d[a:a + cur_len - 1]
+            sent = sent + [1] * (cur_len - len(sent))           # ran into the doc end -> pad
+            if i % 5 == 4 and cur_len > 2:
+                sent[-1] = rng.randrange(3, vocab)              # likely leaves the index
+            if i % 7 == 6 and cur_len > 1:
+                sent[-1] = 2                                    # finished with eos
+            rows.append(sent[:cur_len])
+        scores = torch.randn(len(rows), V, device=dev)
+        proc = IndexBasedLogitsProcessor(ix, beams, pad_token_id=1, eos_token_id=2, **kw)
+        out = proc(torch.tensor(rows, device=dev), scores)
+        allowed = oracle_logits_mask(orc, rows, V, beams, pad_token_id=1, eos_token_id=2, **kw)
+        want = torch.where(torch.from_numpy(allowed).to(dev), scores, torch.full_like(scores, float("-inf")))
+        assert torch.equal(out, want), (cur_len, kw)

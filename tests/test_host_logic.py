@@ -1,0 +1,172 @@
+"""CPU-side tests of libsealfm.so: the ABI surface, the host builder and the
+on-disk format.  No query kernels run here (there is no GPU in this container)."""
+import ctypes
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+from oracle.seal_oracle import SHIFT, CppFMIndex, brute_bwt, brute_sa, brute_text, lib as orc_lib
+from seal_amd._lib import SIGNATURES, SealFMError, check, lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_p64 = ctypes.POINTER(ctypes.c_uint64)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "sealfm.h")).read()
+    declared = set(re.findall(r"\b(fmi_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(SIGNATURES), (declared ^ set(SIGNATURES))
+    L = lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.fmi_abi_version() == 1
+
+
+def _host_index(data):
+    h = ctypes.c_void_p()
+    check(lib().fmi_create(ctypes.byref(h)))
+    a = np.ascontiguousarray(np.asarray(data, dtype=np.uint64))
+    check(lib().fmi_build(h, a.ctypes.data_as(_p64), len(a), -1))   # host only, no upload
+    return h
+
+
+def _arr(h, name):
+    n = ctypes.c_uint64()
+    e = ctypes.c_uint32()
+    p = lib().fmi_host_array(h, name.encode(), ctypes.byref(n), ctypes.byref(e))
+    assert p, name
+    dt = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[e.value]
+    buf = (ctypes.c_uint8 * (n.value * e.value)).from_address(p)
+    return np.frombuffer(buf, dtype=dt).copy()
+
+
+def _wm_rank1(wm, nblk, k, p):
+    """numpy restatement of the documented block layout."""
+    w = p >> 6
+    blk, wi = divmod(w, 7)
+    base = (k * nblk + blk) * 8
+    r = int(wm[base])
+    for j in range(wi):
+        r += bin(int(wm[base + 1 + j])).count("1")
+    r += bin(int(wm[base + 1 + wi]) & ((1 << (p & 63)) - 1)).count("1")
+    return r
+
+
+def _rand_data(rng, n, vocab):
+    return [rng.randrange(1, vocab) for _ in range(n)]
+
+
+@pytest.mark.parametrize("seed,n,vocab", [(0, 50, 4), (1, 400, 30), (2, 3000, 700), (3, 5000, 60000), (4, 2000, 2)])
+def test_host_builder_matches_brute_force(seed, n, vocab):
+    rng = random.Random(seed)
+    data = _rand_data(rng, n, vocab)
+    if seed == 1:   # long repeats: stress the doubling rounds
+        data = (data[:40] * 10)[:n]
+    h = _host_index(data)
+    try:
+        text = data + [0]
+        sa = brute_sa(text)
+        bwt = brute_bwt(text, sa)
+        N = len(text)
+        assert lib().fmi_size(h) == N
+        assert _arr(h, "sa").tolist() == sa
+        assert _arr(h, "bwt").tolist() == bwt
+        assert _arr(h, "text").tolist() == text
+        L = lib().fmi_levels(h)
+        assert L == max(1, max(text).bit_length())
+        C = _arr(h, "C")
+        max_sym = max(text)
+        assert len(C) == max_sym + 2
+        for c in set(text):
+            assert C[c] == sum(1 for x in text if x < c)
+        assert lib().fmi_sigma(h) == len(set(text))
+        wm, zeros, leaf = _arr(h, "wm"), _arr(h, "zeros"), _arr(h, "leaf")
+        nblk = len(wm) // (8 * L)
+        # rank_c(i) through the wavelet matrix == naive count
+        for _ in range(300):
+            c = rng.choice(text)
+            i = rng.randrange(0, N + 1)
+            p = i
+            for k in range(L):
+                r1 = _wm_rank1(wm, nblk, k, p)
+                p = int(zeros[k]) + r1 if (c >> (L - 1 - k)) & 1 else p - r1
+            assert p - int(leaf[c]) == bwt[:i].count(c)
+        # quirk table == what the faithful sdsl-layout oracle computes for rank(size()+1, c)
+        orc = CppFMIndex()
+        orc.initialize(data)
+        q1 = _arr(h, "q1")
+        for c in set(text):
+            occ = text.count(c)
+            assert int(orc_lib().orc_rank(orc._h, N + 1, c)) - occ == int(q1[c]), c
+    finally:
+        lib().fmi_free(h)
+
+
+def test_zipf_corpus_q1_against_oracle():
+    rng = np.random.default_rng(5)
+    data = (np.minimum(rng.zipf(1.3, size=20000), 50000) + SHIFT).tolist()
+    h = _host_index(data)
+    try:
+        orc = CppFMIndex()
+        orc.initialize(data)
+        N = len(data) + 1
+        q1 = _arr(h, "q1")
+        C = _arr(h, "C")
+        fired = 0
+        for c in set(data) | {0}:
+            occ = int(C[c + 1] - C[c])
+            d = int(orc_lib().orc_rank(orc._h, N + 1, c)) - occ
+            assert d == int(q1[c])
+            fired += d
+        assert fired <= 8   # rare
+    finally:
+        lib().fmi_free(h)
+
+
+def test_save_load_round_trip(tmp_path):
+    rng = random.Random(9)
+    data = _rand_data(rng, 1000, 300)
+    h = _host_index(data)
+    path = str(tmp_path / "x.fmi").encode()
+    check(lib().fmi_save(h, path))
+    h2 = ctypes.c_void_p()
+    check(lib().fmi_load(ctypes.byref(h2), path, -1))
+    try:
+        for name in ("sa", "bwt", "text", "C", "leaf", "q1", "zeros", "wm"):
+            assert np.array_equal(_arr(h, name), _arr(h2, name)), name
+        assert lib().fmi_size(h2) == 1001 and lib().fmi_levels(h2) == lib().fmi_levels(h)
+    finally:
+        lib().fmi_free(h)
+        lib().fmi_free(h2)
+
+
+def test_build_from_file_little_endian(tmp_path):
+    data = [11, 12, 13, 11, 12, 300]
+    p = tmp_path / "d.bin"
+    np.asarray(data, dtype="<i4").tofile(p)   # FORMAT '<l', width 4 (reference index.py:18,65)
+    h = ctypes.c_void_p()
+    check(lib().fmi_create(ctypes.byref(h)))
+    check(lib().fmi_build_from_file(h, str(p).encode(), 4, -1))
+    assert _arr(h, "text").tolist() == data + [0]
+    lib().fmi_free(h)
+
+
+def test_errors_are_loud_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = _host_index([5, 6, 7])
+    out = np.zeros(2, dtype=np.uint64)
+    with pytest.raises(SealFMError) as e:
+        check(lib().fmi_backward_search_step(h, 5, 0, 3, out.ctypes.data_as(_p64)))
+    assert e.value.code == 3 and "no CPU query path" in str(e.value)
+    with pytest.raises(SealFMError):
+        check(lib().fmi_to_device(h, 0))
+    # zero symbols are rejected like sdsl would (text must not contain the sentinel)
+    bad = np.asarray([4, 0, 4], dtype=np.uint64)
+    with pytest.raises(SealFMError):
+        check(lib().fmi_build(h, bad.ctypes.data_as(_p64), 3, -1))
+    lib().fmi_free(h)
