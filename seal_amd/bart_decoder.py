@@ -1,0 +1,107 @@
+"""Incremental BART decoder step for beam search on one GPU.
+
+The reference drives ``BartForConditionalGeneration`` through HF 4.13's
+``generate`` internals (``prepare_inputs_for_generation``, ``_reorder_cache``,
+encoder outputs repeated ``num_beams`` times; reference seal/beam_search.py:
+231-238,331-332,517-521).  This module reads the same weights out of the HF
+module (so a real SEAL checkpoint drops in) and runs the decoder step with:
+
+* one fused QKV projection per self-attention, one fused KV projection per
+  cross-attention (computed once per query, NOT per beam: all beams of a query
+  attend to the same encoder states);
+* a statically allocated self-attention KV cache ``[layers, 2, rows, heads,
+  max_len, head_dim]`` re-ordered in place of HF's tuple-of-tuples cache;
+* the ``lm_head`` logits GEMM (the only large dense contraction of the path,
+  ``[rows, d] x [d, vocab]``) in fp32 through hipBLASLt/MFMA.
+
+Architecture facts used (BART-large, HF ``BartDecoderLayer``): post-LN,
+learned positions with offset 2, ``layernorm_embedding``, GELU FFN, query
+scaled by ``head_dim ** -0.5``, logits = ``x @ shared^T + final_logits_bias``.
+"""
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+
+class BartStepDecoder:
+    def __init__(self, model):
+        self.model = model
+        dec = model.model.decoder
+        cfg = model.config
+        self.d = cfg.d_model
+        self.h = cfg.decoder_attention_heads
+        self.dh = self.d // self.h
+        self.scale = self.dh ** -0.5
+        self.embed = dec.embed_tokens
+        self.embed_scale = float(getattr(dec.embed_tokens, "embed_scale", 1.0))
+        self.pos = dec.embed_positions
+        self.pos_offset = int(getattr(dec.embed_positions, "offset", 2))
+        self.ln_emb = dec.layernorm_embedding
+        self.layers = []
+        for l in dec.layers:
+            sa, ca = l.self_attn, l.encoder_attn
+            self.layers.append(dict(
+                qkv_w=torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0).detach(),
+                qkv_b=torch.cat([sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias], 0).detach(),
+                so=sa.out_proj, ln1=l.self_attn_layer_norm,
+                cq=ca.q_proj,
+                ckv_w=torch.cat([ca.k_proj.weight, ca.v_proj.weight], 0).detach(),
+                ckv_b=torch.cat([ca.k_proj.bias, ca.v_proj.bias], 0).detach(),
+                co=ca.out_proj, ln2=l.encoder_attn_layer_norm,
+                fc1=l.fc1, fc2=l.fc2, ln3=l.final_layer_norm, act=l.activation_fn))
+        self.lm_w = model.lm_head.weight
+        self.lm_b = model.final_logits_bias
+        self.batch = self.beams = self.rows = 0
+
+    @torch.no_grad()
+    def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        return self.model.model.encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+
+    @torch.no_grad()
+    def start(self, enc_hidden: torch.Tensor, attention_mask: torch.Tensor, num_beams: int, max_len: int) -> None:
+        B, S, d = enc_hidden.shape
+        self.batch, self.beams, self.rows, self.max_len = B, num_beams, B * num_beams, max_len
+        dt, dev = enc_hidden.dtype, enc_hidden.device
+        self.cross = []
+        for L in self.layers:
+            kv = F.linear(enc_hidden, L["ckv_w"], L["ckv_b"]).view(B, S, 2, self.h, self.dh)
+            k = kv[:, :, 0].permute(0, 2, 3, 1).contiguous()      # [B, H, dh, S]
+            v = kv[:, :, 1].permute(0, 2, 1, 3).contiguous()      # [B, H, S, dh]
+            self.cross.append((k, v))
+        self.cross_bias = torch.zeros(B, 1, 1, S, dtype=dt, device=dev)
+        self.cross_bias.masked_fill_(attention_mask[:, None, None, :] == 0, torch.finfo(dt).min)
+        self.kv = torch.zeros(len(self.layers), 2, self.rows, self.h, max_len, self.dh, dtype=dt, device=dev)
+        self.t = 0
+
+    @torch.no_grad()
+    def reorder(self, beam_idx: torch.Tensor) -> None:
+        """new row r continues old row beam_idx[r] (HF ``_reorder_cache``)."""
+        self.kv[:, :, :, :, :self.t] = self.kv[:, :, beam_idx, :, :self.t]
+
+    @torch.no_grad()
+    def step(self, tokens: torch.Tensor) -> torch.Tensor:
+        """tokens [rows] at decoder position ``self.t`` -> next-token logits [rows, vocab] (fp32)."""
+        R, B, K, H, dh, t = self.rows, self.batch, self.beams, self.h, self.dh, self.t
+        x = self.embed(tokens) * self.embed_scale if self.embed_scale != 1.0 else self.embed(tokens)
+        x = x + self.pos.weight[t + self.pos_offset]
+        x = self.ln_emb(x)
+        for li, L in enumerate(self.layers):
+            qkv = F.linear(x, L["qkv_w"], L["qkv_b"]).view(R, 3, H, dh)
+            self.kv[li, 0, :, :, t] = qkv[:, 1]
+            self.kv[li, 1, :, :, t] = qkv[:, 2]
+            q = qkv[:, 0].unsqueeze(2) * self.scale                       # [R, H, 1, dh]
+            keys = self.kv[li, 0, :, :, :t + 1]                            # [R, H, t+1, dh]
+            vals = self.kv[li, 1, :, :, :t + 1]
+            att = torch.softmax(q @ keys.transpose(-1, -2), dim=-1)        # [R, H, 1, t+1]
+            a = (att @ vals).reshape(R, self.d)
+            x = L["ln1"](x + L["so"](a))
+            ck, cv = self.cross[li]
+            cq = (L["cq"](x) * self.scale).view(B, K, H, dh).transpose(1, 2)   # [B, H, K, dh]
+            catt = torch.softmax(cq @ ck + self.cross_bias, dim=-1)        # [B, H, K, S]
+            c = (catt @ cv).transpose(1, 2).reshape(R, self.d)
+            x = L["ln2"](x + L["co"](c))
+            x = L["ln3"](x + L["fc2"](L["act"](L["fc1"](x))))
+        self.t += 1
+        logits = F.linear(x, self.lm_w) + self.lm_b
+        return logits.float()

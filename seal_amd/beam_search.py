@@ -92,3 +92,154 @@ class IndexBasedLogitsProcessor:
             src.shape[-1], SHIFT, self.pad_token_id, self.eos_token_id, ff_arr, len(ff),
             int(self.stop_at_count), int(bool(self.always_allow_eos))))
         return out if out.dtype == scores.dtype else out.to(scores.dtype)
+
+
+# ---------------------------------------------------------------------------
+# beam loop (reference beam_search.py:143-389) + keep-history scorer
+# (reference beam_search.py:559-758), tensorised: no .item()/.tolist() per step,
+# one D2H transfer of the recorded history at the end.
+# ---------------------------------------------------------------------------
+def _inf_nan_remove(scores: torch.Tensor) -> torch.Tensor:
+    """HF 4.13 ``InfNanRemoveLogitsProcessor`` (the only stock processor that
+    ``_get_logits_processor`` adds here, beam_search.py:430-445): nan -> 0,
+    +inf -> finfo.max; -inf is left alone."""
+    scores = torch.where(scores != scores, torch.zeros_like(scores), scores)
+    return torch.where(scores == float("inf"), torch.full_like(scores, torch.finfo(scores.dtype).max), scores)
+
+
+@torch.no_grad()
+def constrained_beam_search(decoder, batch_size: int, num_beams: int, max_length: int, decoder_start_token_id: int,
+                            eos_token_id: int, constrained_decoding_processor=None, device=None):
+    """Runs the loop of reference ``constrained_beam_search`` with the
+    ``BeamSearchScorerWithMemory`` bookkeeping and returns the raw history:
+
+    ``steps``: list over decode steps of (prefix_ids [B, 2K, t], tokens [B, 2K],
+    sum_logprobs [B, 2K]) -- every ranked candidate of every step, in rank order
+    (scorer.process, beam_search.py:658-668) -- and ``final``: (input_ids [R, T],
+    beam_scores [R]) re-added by ``finalize`` (beam_search.py:717-725).
+
+    Semantics kept: beam scores start at [0, -1e9, ...] (214-216); fp32
+    log_softmax (251); top-2K is taken on the CONSTRAINED scores but the value
+    carried on is the UNCONSTRAINED one (302-307); the first K non-eos candidates
+    continue (673-685); stop when the sequence length reaches max_length (340).
+    """
+    B, K = batch_size, num_beams
+    R = B * K
+    input_ids = torch.full((R, 1), decoder_start_token_id, dtype=torch.long, device=device)
+    beam_scores = torch.zeros(B, K, dtype=torch.float32, device=device)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(R)
+    row_base = (torch.arange(B, device=device) * K).unsqueeze(1)
+    steps = []
+    while True:
+        logits = decoder.step(input_ids[:, -1])
+        logp = torch.log_softmax(logits.float(), dim=-1)
+        processed = _inf_nan_remove(logp)
+        V = processed.shape[-1]
+        unconstrained = processed + beam_scores[:, None]
+        if constrained_decoding_processor is not None:
+            constrained = constrained_decoding_processor(input_ids, processed) + beam_scores[:, None]
+        else:
+            constrained = unconstrained
+        _, flat = torch.topk(constrained.view(B, K * V), 2 * K, dim=1, largest=True, sorted=True)
+        next_scores = unconstrained.view(B, K * V).gather(-1, flat)
+        next_indices = flat // V                    # (next_tokens / V).long(), exact for K*V < 2^24 (309)
+        next_tokens = flat % V
+        src_rows = row_base + next_indices          # batch_beam_idx (661)
+        steps.append((input_ids[src_rows], next_tokens, next_scores))
+        # first K non-eos candidates, in rank order, become the next beams (670-685)
+        keep = next_tokens != eos_token_id
+        order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)[:, :K]
+        # (the reference's ValueError at 687-690 cannot trigger: each of the K rows holds
+        # exactly one eos entry, so at most K of the 2K picks are eos)
+        beam_scores = next_scores.gather(1, order).view(R)
+        beam_tokens = next_tokens.gather(1, order).view(R)
+        beam_idx = src_rows.gather(1, order).view(R)
+        input_ids = torch.cat([input_ids[beam_idx], beam_tokens.unsqueeze(-1)], dim=-1)
+        decoder.reorder(beam_idx)
+        if input_ids.shape[-1] >= max_length:       # MaxLengthCriteria (340)
+            break
+    return steps, (input_ids, beam_scores)
+
+
+def _history_to_hypotheses(steps, final, batch_size: int, num_beams: int, length_penalty: float):
+    """BeamHypothesesWithMemory.add (752-755) + the output comprehension of
+    fm_index_generate (555), done on the host after one transfer."""
+    B, K = batch_size, num_beams
+    out = [[] for _ in range(B)]
+
+    def add(b, score32: float, toks):
+        size = len(toks)
+        score = score32 / (size ** length_penalty)      # python floats, as .item() gave the reference
+        if score > float("-inf"):
+            out[b].append((score * size ** length_penalty, toks))
+
+    for prefix, tokens, scores in steps:
+        prefix, tokens, scores = prefix.tolist(), tokens.tolist(), scores.tolist()
+        for b in range(B):
+            for j in range(2 * K):
+                add(b, scores[b][j], prefix[b][j] + [tokens[b][j]])
+    ids, fscores = final
+    ids, fscores = ids.tolist(), fscores.tolist()
+    for b in range(B):
+        for j in range(K):
+            add(b, fscores[b * K + j], ids[b * K + j])
+    return out
+
+
+@torch.no_grad()
+def fm_index_generate(
+        model,
+        index: FMIndex,
+        input_ids: torch.LongTensor,
+        attention_mask: torch.LongTensor,
+        min_length: int = 3,
+        max_length: int = 25,
+        length_penalty: float = 1.0,
+        num_beams: int = 3,
+        diverse_bs_groups: int = 1,
+        diverse_bs_penalty: float = 0.0,
+        eos_token_id: Optional[int] = None,
+        force_decoding_from: Optional[List[int]] = None,
+        always_allow_eos: bool = False,
+        keep_history: bool = False,
+        disable_fm_index: bool = False,
+        sample: bool = False,
+        stop_at_count: int = 0,
+        topk: int = 0,
+        transformers_output: bool = False,
+        **kwargs,
+):
+    """Drop-in for ``seal.beam_search.fm_index_generate`` (beam_search.py:391-557)
+    on the configuration the SEAL searcher uses (retrieval.py:70-83,162-176):
+    ``keep_history=True``, one beam group, no sampling, no top-k warper.
+    Returns ``List[List[(score, token_list)]]``, one list per query.
+
+    ``kwargs``: ``forced_bos_token_id`` as in the reference; ``decoder`` (a
+    ``BartStepDecoder``-like object) and ``constrained_decoding_processor`` to
+    inject pre-built pieces.
+    """
+    if diverse_bs_groups != 1 or sample or topk or transformers_output or not keep_history:
+        raise NotImplementedError(
+            "seal_amd.fm_index_generate implements the SEAL search path: keep_history=True, diverse_bs_groups=1, "
+            "sample=False, topk=0 (reference retrieval.py:70-83); other modes of the reference are out of scope")
+    from .bart_decoder import BartStepDecoder
+
+    forced_bos_token_id = kwargs.pop("forced_bos_token_id", getattr(model.config, "forced_bos_token_id", None))
+    decoder = kwargs.pop("decoder", None) or BartStepDecoder(model)
+    processor = kwargs.pop("constrained_decoding_processor", None)
+    if eos_token_id is None:
+        eos_token_id = model.config.eos_token_id
+    if processor is None and not disable_fm_index:
+        processor = IndexBasedLogitsProcessor(
+            num_beams=num_beams, index=index, pad_token_id=model.config.pad_token_id,
+            eos_token_id=eos_token_id or model.config.eos_token_id, force_decoding_from=force_decoding_from,
+            stop_at_count=stop_at_count, always_allow_eos=always_allow_eos, forced_bos_token_id=forced_bos_token_id)
+    if disable_fm_index:
+        processor = None
+    enc = decoder.encode(input_ids, attention_mask)
+    decoder.start(enc, attention_mask, num_beams, max_length)
+    steps, final = constrained_beam_search(
+        decoder, input_ids.shape[0], num_beams, max_length, model.config.decoder_start_token_id, eos_token_id,
+        constrained_decoding_processor=processor, device=input_ids.device)
+    return _history_to_hypotheses(steps, final, input_ids.shape[0], num_beams, length_penalty)

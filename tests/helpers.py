@@ -1,0 +1,71 @@
+"""Shared test fixtures: tiny seeded BART + corpora + oracle-backed processor."""
+import numpy as np
+import torch
+
+
+def tiny_bart(vocab=120, seed=0, d_model=32, layers=2):
+    from transformers import BartConfig, BartForConditionalGeneration
+    cfg = BartConfig(vocab_size=vocab, d_model=d_model, encoder_layers=layers, decoder_layers=layers,
+                     encoder_attention_heads=4, decoder_attention_heads=4, encoder_ffn_dim=2 * d_model,
+                     decoder_ffn_dim=2 * d_model, max_position_embeddings=64)
+    cfg.forced_bos_token_id = None       # as SEALSearcher.load_bart does (reference retrieval.py:566,580)
+    torch.manual_seed(seed)
+    m = BartForConditionalGeneration(cfg).eval()
+    with torch.no_grad():
+        m.final_logits_bias[0, cfg.pad_token_id] = float("-inf")   # reference retrieval.py:584-588
+        m.final_logits_bias[0, cfg.bos_token_id] = float("-inf")
+    return m
+
+
+def make_docs(seed, n_docs, vocab, min_len=3, max_len=14, title_sep=None):
+    rng = np.random.default_rng(seed)
+    docs = []
+    for _ in range(n_docs):
+        m = int(rng.integers(min_len, max_len + 1))
+        toks = rng.integers(4, vocab, size=m).tolist()
+        if title_sep is not None:
+            toks = toks[:2] + [title_sep] + toks[2:]
+        docs.append(toks + [2])
+    return docs
+
+
+class OracleLogitsProcessor:
+    """tests-only: IndexBasedLogitsProcessor protocol backed by the CPU oracle, so the
+    tensorised beam loop (host logic) can be exercised without a GPU."""
+
+    def __init__(self, index, num_beams, vocab, **kw):
+        self.index, self.num_beams, self.vocab, self.kw = index, num_beams, vocab, kw
+
+    def __call__(self, input_ids, scores):
+        from oracle.beam_oracle import oracle_logits_mask
+        allowed = oracle_logits_mask(self.index, input_ids.tolist(), self.vocab, self.num_beams, **self.kw)
+        mask = torch.full_like(scores, float("-inf"))
+        mask[torch.from_numpy(allowed).to(scores.device)] = 0.0
+        return scores + mask
+
+
+def hf_logits_fn(model, enc_ids, enc_mask, num_beams):
+    """next-token logits through HF's own full (cache-free) forward."""
+    ids = enc_ids.repeat_interleave(num_beams, 0)
+    am = enc_mask.repeat_interleave(num_beams, 0)
+
+    def fn(decoder_input_ids):
+        with torch.no_grad():
+            return model(input_ids=ids, attention_mask=am, decoder_input_ids=decoder_input_ids.to(ids.device)).logits[:, -1, :]
+    return fn
+
+
+def valid_set(hyps, index, digits=None):
+    """hypotheses that survive the reference's post-filter (count > 0 after stripping,
+    retrieval.py:85-91) -- the part that is independent of top-k tie order."""
+    out = {}
+    for score, toks in hyps:
+        k = list(toks)
+        for _ in range(2):
+            if k and k[0] in (0, 2):
+                k = k[1:]
+        if k and k[-1] in (0, 2):
+            k = k[:-1]
+        if k and index.get_count(k) > 0:
+            out.setdefault((tuple(toks)), []).append(score)
+    return out

@@ -1,0 +1,84 @@
+"""Host logic of the decode side on CPU: the step decoder against HF's own
+forward, and the tensorised beam loop + history scorer against the line-by-line
+restatement of the reference loop (oracle/beam_oracle.py)."""
+import pytest
+import torch
+
+from oracle.beam_oracle import oracle_fm_index_generate
+from oracle.seal_oracle import OracleFMIndex
+from seal_amd.bart_decoder import BartStepDecoder
+from seal_amd.beam_search import fm_index_generate
+from tests.helpers import OracleLogitsProcessor, hf_logits_fn, make_docs, tiny_bart, valid_set
+
+
+def test_step_decoder_matches_hf_forward():
+    m = tiny_bart()
+    torch.manual_seed(1)
+    enc_ids = torch.randint(4, 120, (3, 9))
+    enc_mask = torch.ones_like(enc_ids)
+    enc_mask[1, 6:] = 0
+    enc_ids[1, 6:] = 1
+    K = 2
+    dec = BartStepDecoder(m)
+    enc = dec.encode(enc_ids, enc_mask)
+    dec.start(enc, enc_mask, K, 8)
+    seq = torch.randint(4, 120, (3 * K, 6))
+    seq[:, 0] = 2
+    fn = hf_logits_fn(m, enc_ids, enc_mask, K)
+    for t in range(6):
+        got = dec.step(seq[:, t])
+        want = fn(seq[:, :t + 1])
+        assert torch.allclose(got, want, atol=2e-5, rtol=1e-5), t
+    # reorder: permute rows within each query and continue
+    perm = torch.tensor([1, 0, 2, 3, 5, 4])
+    dec.reorder(perm)
+    seq2 = torch.cat([seq[perm], torch.randint(4, 120, (6, 1))], 1)
+    got = dec.step(seq2[:, -1])
+    assert torch.allclose(got, fn(seq2), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(max_length=6, num_beams=3, length_penalty=0.0),
+    dict(max_length=5, num_beams=4, length_penalty=1.0),
+    dict(max_length=7, num_beams=3, length_penalty=0.0, force_decoding_from=[2], eos_token_id=7),
+    dict(max_length=5, num_beams=2, length_penalty=0.0, always_allow_eos=True),
+    dict(max_length=5, num_beams=3, length_penalty=0.0, stop_at_count=2),
+    dict(max_length=4, num_beams=3, length_penalty=0.0, disable_fm_index=True),
+])
+def test_beam_loop_matches_reference_restatement(kw):
+    vocab = 120
+    m = tiny_bart(vocab)
+    docs = make_docs(3, 150, vocab, title_sep=7)
+    orc = OracleFMIndex()
+    orc.initialize(docs)
+    torch.manual_seed(2)
+    enc_ids = torch.randint(4, vocab, (4, 8))
+    enc_mask = torch.ones_like(enc_ids)
+    K = kw["num_beams"]
+    eos = kw.get("eos_token_id", 2)
+    pkw = dict(pad_token_id=1, eos_token_id=eos, force_decoding_from=kw.get("force_decoding_from"),
+               stop_at_count=kw.get("stop_at_count", 0), always_allow_eos=kw.get("always_allow_eos", False))
+    proc = OracleLogitsProcessor(orc, K, vocab, **pkw)
+    got = fm_index_generate(m, None, enc_ids, enc_mask, min_length=1, keep_history=True,
+                            constrained_decoding_processor=proc, **kw)
+    want = oracle_fm_index_generate(hf_logits_fn(m, enc_ids, enc_mask, K), orc, 4, K, kw["max_length"], vocab,
+                                    decoder_start_token_id=2, pad_token_id=1, eos_token_id=eos,
+                                    length_penalty=kw["length_penalty"], force_decoding_from=kw.get("force_decoding_from"),
+                                    stop_at_count=kw.get("stop_at_count", 0), always_allow_eos=kw.get("always_allow_eos", False),
+                                    disable_fm_index=kw.get("disable_fm_index", False))
+    assert len(got) == len(want) == 4
+    for g, w in zip(got, want):
+        gv, wv = valid_set(g, orc), valid_set(w, orc)
+        assert set(gv) == set(wv)
+        for k in gv:
+            assert len(gv[k]) == len(wv[k])
+            for a, b in zip(sorted(gv[k]), sorted(wv[k])):
+                assert abs(a - b) <= 1e-4, (k, a, b)     # north_star tolerance on beam scores
+        if kw.get("disable_fm_index"):
+            assert [t for _, t in g] == [t for _, t in w]   # no -inf ties without the constraint
+
+
+def test_unsupported_modes_say_so():
+    with pytest.raises(NotImplementedError):
+        fm_index_generate(tiny_bart(), None, torch.zeros(1, 2, dtype=torch.long), torch.ones(1, 2, dtype=torch.long),
+                          keep_history=False)
