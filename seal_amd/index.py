@@ -172,6 +172,49 @@ class FMIndex(_FMIndex):
         check(lib().fmi_locate(self._h, len(r), _ptr(r), _ptr(pos), _ptr(doc)))
         return pos, doc
 
+    def locate_ranges(self, lows, highs, max_per_range: int):
+        """``locate`` + ``get_doc_index`` for the first ``max_per_range`` rows of many
+        half-open row ranges (``islice(range(*get_range(ngram)), max_hits)``, reference
+        keys.py:320-324) in one launch.  Returns (pos, doc, offsets) as int64 numpy."""
+        import torch
+        lo = np.asarray(lows, dtype=np.int64)
+        hi = np.asarray(highs, dtype=np.int64)
+        width = np.minimum(np.maximum(hi - lo, 0), int(max_per_range))
+        offs = np.zeros(len(lo) + 1, dtype=np.int64)
+        np.cumsum(width, out=offs[1:])
+        total = int(offs[-1])
+        if total == 0:
+            return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), offs
+        dev = torch.device("cuda", lib().fmi_device(self._h))
+        d_lo = torch.from_numpy(lo).to(dev)
+        d_hi = torch.from_numpy(hi).to(dev)
+        d_off = torch.from_numpy(offs).to(dev)
+        out = torch.empty(2, total, dtype=torch.int64, device=dev)
+        check(lib().fmi_dev_locate_ranges(self._h, torch.cuda.current_stream(dev).cuda_stream, len(lo), d_lo.data_ptr(),
+                                          d_hi.data_ptr(), int(max_per_range), d_off.data_ptr(), total,
+                                          out[0].data_ptr(), out[1].data_ptr()))
+        res = out.cpu().numpy()
+        return res[0], res[1], offs
+
+    def get_docs_batch(self, doc_indices) -> List[List[int]]:
+        """``get_doc`` for many documents in one launch (reference index.py:68-75)."""
+        import torch
+        docs = np.asarray(list(doc_indices), dtype=np.int64)
+        if len(docs) == 0:
+            return []
+        b = np.asarray(self.beginnings, dtype=np.int64)
+        lens = b[docs + 1] - b[docs]
+        offs = np.zeros(len(docs) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offs[1:])
+        dev = torch.device("cuda", lib().fmi_device(self._h))
+        d_docs = torch.from_numpy(docs).to(dev)
+        d_off = torch.from_numpy(offs).to(dev)
+        out = torch.empty(max(int(offs[-1]), 1), dtype=torch.int64, device=dev)
+        check(lib().fmi_dev_get_docs(self._h, torch.cuda.current_stream(dev).cuda_stream, len(docs), d_docs.data_ptr(),
+                                     d_off.data_ptr(), SHIFT, out.data_ptr()))
+        flat = out.cpu().numpy()
+        return [flat[offs[i]:offs[i + 1]].tolist() for i in range(len(docs))]
+
     # -- device-pointer forms (torch tensors on the index's GPU) -------------
     @property
     def handle(self):

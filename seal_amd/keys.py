@@ -1,0 +1,425 @@
+"""Key scoring and evidence aggregation (reference seal/keys.py) on the MI355X engine.
+
+What changes with respect to the reference is *where the index work happens*,
+not what is computed:
+
+* every ``index.get_count(ngram)`` of a query (keys.py:212,252,277,287) is served
+  from ONE batched backward-search launch per call of ``aggregate_evidence``
+  (plus a per-index cached table for single-token counts);
+* the ``locate`` + ``get_doc_index`` pair issued per matching row
+  (keys.py:320-324, up to ``max_hits`` rows per rare key) becomes one launch over
+  all rows of all rare keys (suffix-array gather + doc binning on the GPU);
+* the documents that are fully scored are fetched in one launch
+  (``get_doc``, keys.py:388).
+
+The order-sensitive bookkeeping of the reference (dict insertion orders, stable
+sorts, first-come coverage, the ``[tok_end - len, tok_end)`` window, heap order
+of the greedy matcher) is reproduced on the host from those arrays; floating
+point is float64 ``math`` exactly where the reference uses it.
+"""
+import math
+from collections import Counter
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def deduplicate(list_of_lists):
+    """First occurrence wins; elements are token lists or (score, tokens) pairs
+    (reference keys.py:19-35)."""
+    seen = set()
+    kept = []
+    for item in list_of_lists:
+        toks = item[1] if isinstance(item[0], float) else item
+        key = tuple(toks.tolist()) if isinstance(toks, torch.Tensor) else tuple(toks)
+        if key not in seen:
+            seen.add(key)
+            kept.append(item)
+    return kept
+
+
+def strip(seq, symbols_start, symbols_end):
+    """Drop leading symbols in ``symbols_start`` and trailing ones in
+    ``symbols_end`` (reference keys.py:54-61)."""
+    a, b = 0, len(seq)
+    while a < b and seq[a] in symbols_start:
+        a += 1
+    while b > a and seq[b - 1] in symbols_end:
+        b -= 1
+    return seq[a:b]
+
+
+def _pad_batch(seqs: Sequence[Sequence[int]], pad: int, device) -> torch.Tensor:
+    width = max(len(s) for s in seqs)
+    out = torch.full((len(seqs), width), pad, dtype=torch.long)
+    for i, s in enumerate(seqs):
+        out[i, :len(s)] = torch.as_tensor(s, dtype=torch.long)
+    return out.to(device)
+
+
+@torch.inference_mode()
+def rescore_keys(model, inputs, list_of_decoded, batch_size=100, length_penalty=0.0, progress_bar=False, prefix=[],
+                 strip_from_bos=[], strip_from_eos=[]):
+    """Teacher-forced log-probability of every key given its query
+    (reference keys.py:64-141): targets with id < 2 contribute 0 (keys.py:132),
+    chunks of ``batch_size`` keys, score divided by ``len(key) ** length_penalty``."""
+    cfg = model.config
+    device = next(model.parameters()).device
+    if inputs is None:
+        batch_in = [[cfg.bos_token_id, cfg.eos_token_id]] * len(list_of_decoded)
+    else:
+        batch_in = [list(i) for i in inputs]
+    decoded = [[x[1] if isinstance(x[0], float) else x for x in xx] for xx in list_of_decoded]
+    input_ids = _pad_batch(batch_in, cfg.pad_token_id, device)
+    attention_mask = (input_ids != cfg.pad_token_id).to(torch.uint8)
+    enc = model.model.encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+    flat = [(qi, key) for qi, keys in enumerate(decoded) for key in keys]
+    out = {qi: [] for qi in range(len(decoded))}
+    start = cfg.decoder_start_token_id
+    for c0 in range(0, len(flat), batch_size):
+        chunk = flat[c0:c0 + batch_size]
+        qidx = torch.as_tensor([qi for qi, _ in chunk], device=device)
+        dec_in = []
+        for _, key in chunk:
+            d = [start] + list(prefix) + list(strip(list(key), strip_from_bos, strip_from_eos))
+            dec_in.append(d)
+        dec_ids = _pad_batch(dec_in, cfg.pad_token_id, device)
+        logits = model(attention_mask=attention_mask[qidx], encoder_outputs=(enc[qidx],),
+                       decoder_input_ids=dec_ids[:, :-1]).logits
+        logprobs = logits.log_softmax(-1)
+        tgt = dec_ids[:, 1:]
+        lp = torch.gather(logprobs, -1, tgt.unsqueeze(-1)).squeeze(-1)
+        lp = torch.where(tgt < 2, torch.zeros_like(lp), lp)
+        lp = lp[:, len(prefix):].sum(-1).tolist()
+        for (qi, key), ll in zip(chunk, lp):
+            out[qi].append((ll / (len(key) ** length_penalty), list(key)))
+    return [out[qi] for qi in range(len(decoded))]
+
+
+@torch.no_grad()
+def compute_unigram_scores(model, inputs, index=None, tokenizer=None, tolist=True, temperature=1.0, prefix=[]):
+    """One decoder step -> log-softmax over the vocabulary per query
+    (reference keys.py:145-176)."""
+    cfg = model.config
+    device = next(model.parameters()).device
+    if isinstance(inputs[0], str):
+        batch = tokenizer(list(inputs), padding=True, return_tensors="pt")
+        input_ids, attention_mask = batch["input_ids"].to(device), batch["attention_mask"].to(device)
+    else:
+        input_ids = _pad_batch([list(i) for i in inputs], cfg.pad_token_id, device)
+        attention_mask = (input_ids != cfg.pad_token_id).to(torch.uint8)
+    dec = torch.full((input_ids.shape[0], 1 + len(prefix)), cfg.decoder_start_token_id, dtype=torch.long, device=device)
+    for j, tok in enumerate(prefix, start=1):
+        dec[:, j] = tok
+    logits = model(input_ids=input_ids, attention_mask=attention_mask, decoder_input_ids=dec).logits[:, len(prefix)]
+    if temperature != 1.0:
+        logits = logits / temperature
+    logprobs = logits.log_softmax(-1)
+    return logprobs.tolist() if tolist else logprobs
+
+
+# ---------------------------------------------------------------------------
+# aggregate_evidence
+# ---------------------------------------------------------------------------
+def _log_odds(sr: float, count: int, ntokens: float, smoothing: float) -> float:
+    """LM-vs-corpus log-odds of keys.py:221-224 in float64 ``math``."""
+    snr = math.log((count + smoothing) / (ntokens + smoothing))
+    return (sr + math.log(1 - math.exp(snr))) - (snr + math.log(1 - math.exp(sr)))
+
+
+def _unigram_counts(index) -> np.ndarray:
+    """``get_count([i])`` for every token id, one launch, cached on the index."""
+    cache = getattr(index, "_unigram_count_cache", None)
+    if cache is None:
+        vocab = max(index.occurring_distinct) + 1 if index.occurring_distinct else 1
+        cache = np.asarray(index.get_count_batch([[t] for t in range(vocab)]), dtype=np.int64)
+        index._unigram_count_cache = cache
+    return cache
+
+
+class _Counts:
+    """memo of ``index.get_count`` filled by batched launches."""
+
+    def __init__(self, index):
+        self.index = index
+        self.memo: Dict[Tuple[int, ...], int] = {}
+        self.ranges: Dict[Tuple[int, ...], Tuple[int, int]] = {}
+
+    def ensure(self, ngrams) -> None:
+        todo = []
+        for ng in ngrams:
+            t = tuple(ng)
+            if t not in self.memo and t not in todo:
+                todo.append(t)
+        if not todo:
+            return
+        lo, hi = self.index.get_range_batch([list(t) for t in todo])
+        for t, a, b in zip(todo, lo, hi):
+            self.ranges[t] = (int(a), int(b))
+            self.memo[t] = int(b) - int(a)
+
+    def __call__(self, ngram) -> int:
+        t = tuple(ngram)
+        if t not in self.memo:
+            self.ensure([t])
+        return self.memo[t]
+
+
+def _match_order_key(length: int) -> Tuple[int, int]:
+    # The reference's open-match list is rebuilt by popping from the end on every
+    # token (keys.py:400-416); for matches ending on the same token this yields
+    # odd lengths in ascending order followed by even lengths in descending order.
+    return (0, length) if length % 2 else (1, -length)
+
+
+def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_occurrences_1: int = 1500,
+                       max_occurrences_2: int = 10_000_000, n_docs_complete_score: int = 500, alpha: float = 2.0,
+                       beta: float = 0.8, length_penalty: float = 0.0, use_fm_index_frequency: bool = True,
+                       add_best_unigrams_to_ngrams: bool = False, use_top_k_unigrams=1000, sort_by_length=False,
+                       sort_by_freq=False, smoothing=5.0, allow_overlaps=False, single_key=0.0,
+                       single_key_add_unigrams=False, unigrams_ignore_free_places=False, first_stage_only=False):
+    """Drop-in for ``seal.keys.aggregate_evidence`` (reference keys.py:178-497).
+
+    Returns ``(results, all_ngrams)``: ``results`` maps doc index ->
+    ``[score, [(ngram, score)...], None, doc_tokens, [best_ngram, best_score]]``
+    sorted by descending score.  ``first_stage_only=True`` (an addition) stops
+    after the first stage + repetition re-weighting and returns the
+    ``to_fully_score`` ranking as ``{doc: [score, [[ngram, score]...], [best_ngram, best_score]]}``.
+    """
+    def repetition(ngram_set, score, coverage):
+        if not coverage:
+            return score
+        ngram_set = set(ngram_set)
+        return (1.0 - beta + (beta * len(ngram_set.difference(coverage)) / len(ngram_set))) * score
+
+    ntokens = float(index.beginnings[-1])
+    keys: List[Tuple[List[int], float]] = [
+        (ng.tolist() if isinstance(ng, torch.Tensor) else list(ng), sr) for ng, sr in ngrams_and_scores]
+    count_of = _Counts(index)
+    count_of.memo[tuple()] = len(index)
+    count_of.ensure([ng for ng, _ in keys])
+    cutoff = None
+    if not use_fm_index_frequency:
+        cutoff = min(s for _, s in keys) - 0.1 if keys else None
+        if cutoff is None:
+            raise IndexError("list index out of range")
+
+    # ---- key scores (keys.py:207-234) ----
+    seen_unigrams = {0, 1, 2}
+    scored: List[Tuple[List[int], float]] = []
+    for ng, sr in keys:
+        if len(ng) == 1:
+            seen_unigrams.add(ng[0])
+        count = count_of(ng)
+        if count == 0:
+            sco = 0.0
+        elif use_fm_index_frequency:
+            sr = (sr - 1e-10) * (1.0 - length_penalty) ** (len(ng) - 1.0)
+            sco = max(_log_odds(sr, count, ntokens, smoothing), 0.0) ** alpha
+        else:
+            sco = (max(sr - cutoff, 0.0) * (1.0 - length_penalty) ** (len(ng) - 1.0)) ** alpha
+        scored.append((ng, sco))
+
+    # ---- unigram scores (keys.py:236-278) ----
+    if unigram_scores is not None:
+        raw = np.asarray(unigram_scores, dtype=np.float64)
+        V = raw.shape[0]
+        # top-k by log-prob, ties by ascending id (sorted(..., reverse=True) is stable)
+        best = np.argsort(-raw, kind="stable")[:use_top_k_unigrams]
+        uni_counts = _unigram_counts(index)
+        us = np.zeros(V, dtype=np.float64)
+        for i in best.tolist():
+            if i in seen_unigrams:
+                continue
+            count = int(uni_counts[i]) if i < len(uni_counts) else 0
+            if count == 0:
+                continue
+            sr = float(raw[i])
+            if use_fm_index_frequency:
+                sco = max(_log_odds(sr, count, ntokens, smoothing), 0.0)
+            else:
+                sco = max(sr - cutoff, 0.0) ** alpha
+            if sco != 0.0:
+                us[i] = sco
+        unigram_scores = us.tolist()
+        if add_best_unigrams_to_ngrams:
+            for i in np.argsort(-us, kind="stable")[:len(scored)].tolist():
+                scored.append(([i], unigram_scores[i]))
+        count_of.ensure([ng for ng, _ in scored])
+
+    # ---- rare / frequent split (keys.py:280-309) ----
+    rare: Dict[Tuple[int, ...], float] = {}
+    freq: Dict[Tuple[int, ...], float] = {}
+    for ng, sco in scored:
+        count = count_of(ng)
+        if count > max_occurrences_2 or sco == 0.0:
+            continue
+        (freq if (count > max_occurrences_1 or sco < 0.0) else rare)[tuple(ng)] = sco
+    rare = dict(sorted(rare.items(), key=lambda kv: kv[1], reverse=True))
+    freq = dict(sorted(freq.items(), key=lambda kv: kv[1], reverse=True))
+    all_ngrams = dict(sorted(list(rare.items()) + list(freq.items()), key=lambda kv: kv[1], reverse=True))
+
+    # ---- first stage: locate + doc binning for every row of every rare key,
+    #      one launch (keys.py:311-350) ----
+    rare_keys = list(rare.keys())
+    count_of.ensure(rare_keys)
+    if rare_keys:
+        los = np.asarray([count_of.ranges[k][0] if k in count_of.ranges else 0 for k in rare_keys], dtype=np.uint64)
+        his = np.asarray([count_of.ranges[k][1] if k in count_of.ranges else 0 for k in rare_keys], dtype=np.uint64)
+        pos_all, doc_all, offs = index.locate_ranges(los, his, max_occurrences_1)
+    else:
+        pos_all = doc_all = np.zeros(0, dtype=np.int64)
+        offs = np.zeros(1, dtype=np.int64)
+
+    covered = set()
+    first_stage: Dict[int, list] = {}
+    for ki, ngram in enumerate(rare_keys):
+        sco = rare[ngram]
+        a, b = int(offs[ki]), int(offs[ki + 1])
+        if a == b:
+            continue
+        pos = pos_all[a:b].astype(np.int64)
+        docs = doc_all[a:b].astype(np.int64).tolist()
+        m = len(ngram)
+        # window of the reference: [tok_end - len, tok_end)  (sic, keys.py:322-323)
+        pos_l = pos.tolist()
+        sure_new = None
+        if len(pos_l) > 1:
+            srt = np.sort(pos)
+            if m == 0 or bool((np.diff(srt) >= m).all()):
+                sure_new = [all((p - j) not in covered for j in range(1, m + 1)) for p in pos_l]
+        elif pos_l:
+            sure_new = [all((pos_l[0] - j) not in covered for j in range(1, m + 1))]
+        done_docs = set()
+        for r, (p, doc) in enumerate(zip(pos_l, docs)):
+            if sure_new is not None:
+                new = sure_new[r]
+            else:   # windows of this key overlap each other: sequential, as the reference
+                new = all((p - j) not in covered for j in range(1, m + 1))
+            info = first_stage.get(doc)
+            if info is None:
+                info = first_stage[doc] = [0.0, [], [[], 0.0]]
+            if sort_by_length:
+                better = (m, sco) > (len(info[2][0]), info[2][1])
+            elif sort_by_freq:
+                better = (-count_of(ngram), sco) > (-count_of(info[2][0]), info[2][1])
+            else:
+                better = sco > info[2][1]
+            if better:
+                info[2] = [ngram, sco]
+            if new:
+                covered.update(range(p - m, p))
+            if (new or allow_overlaps) and doc not in done_docs:
+                done_docs.add(doc)
+                info[0] += sco
+                info[1].append((ngram, sco))
+
+    # ---- repetition re-weighting per document (keys.py:352-364) ----
+    for info in first_stage.values():
+        cover, total = set(), 0.0
+        for i, (tt, sco) in enumerate(info[1]):
+            tts = set(tt)
+            new_sco = repetition(tts, sco, cover)
+            total += new_sco
+            info[1][i] = [tt, new_sco]
+            cover |= tts
+        info[0] = total
+
+    ranked = sorted(first_stage.items(),
+                    key=lambda kv: (1.0 - single_key) * (-kv[1][0]) + single_key * (-kv[1][2][1]))[:n_docs_complete_score]
+    if first_stage_only:
+        return dict(ranked), all_ngrams
+
+    # ---- full scoring of the top documents (keys.py:366-497) ----
+    trie: dict = {}
+    for ngram, score in all_ngrams.items():
+        if len(ngram) < 1 or score <= 0.0:
+            continue
+        node = trie
+        for t in ngram:
+            node = node.setdefault(t, {})
+        node[-1] = score
+    doc_ids = [d for d, _ in ranked]
+    fetched = index.get_docs_batch(doc_ids) if doc_ids else []
+    results: Dict[int, list] = {}
+    for doc, toks in zip(doc_ids, fetched):
+        doc_tokens = [2] + list(toks)[:-1]
+        res = results[doc] = [0.0, [], None, doc_tokens, [[], 0.0]]
+        if unigram_scores is not None:
+            type_scores = {t: unigram_scores[t] for t in doc_tokens}
+        else:
+            type_scores = {t: 0.0 for t in doc_tokens}
+        # all trie matches, bucketed by end position
+        by_end: List[list] = [[] for _ in doc_tokens]
+        T = len(doc_tokens)
+        for s in range(T):
+            node = trie.get(doc_tokens[s])
+            e = s
+            while node is not None:
+                if -1 in node:
+                    by_end[e].append((e - s + 1, s, node[-1]))
+                e += 1
+                if e >= T:
+                    break
+                node = node.get(doc_tokens[e])
+        matches: Dict[Tuple[int, ...], list] = {}
+        for e in range(T):
+            for length, s, score in sorted(by_end[e], key=lambda x: _match_order_key(x[0])):
+                key = tuple(doc_tokens[s:e + 1])
+                matches.setdefault(key, [score, []])[1].append((s, e + 1))
+        cand = []
+        for n, (s, spans) in matches.items():
+            if sort_by_length:
+                better = (-len(n), -s) < (-len(res[4][0]), -res[4][1])
+            elif sort_by_freq:
+                better = (count_of(n), -s) < (count_of(res[4][0]), -res[4][1])
+            else:
+                better = -s < -res[4][1]
+            for (i, j) in spans:
+                cand.append((-s, n, s, i, j))
+            if better:
+                res[4] = [n, s]
+        cand.sort()     # == successive heappop of the reference's heap
+        cover = set()
+        picked: List[Tuple[Tuple[int, ...], float]] = []
+        prev = None
+        free = [True] * T
+        for _, n, s, i, j in cand:
+            n_set = set(n)
+            if prev == n:
+                new_s = picked[-1][1]
+            elif not n_set:
+                new_s = 0.0
+            else:
+                new_s = repetition(n_set, s, cover)
+            if new_s <= 0.0:
+                continue
+            if not (allow_overlaps or all(free[i:j])):
+                continue
+            if prev == n:
+                picked[-1] = (n, new_s)
+            else:
+                prev = n
+                cover |= n_set
+                picked.append((n, new_s))
+            free[i:j] = [False] * (j - i)
+        if unigrams_ignore_free_places:
+            free = [True] * T
+        single_key_score = res[4][1]
+        multi_key_score = sum(s for _, s in picked)
+        unigram_score = 0.0
+        for t in Counter(t for t, f in zip(doc_tokens, free) if f):
+            s = type_scores[t]
+            if s > 0.0:
+                s = repetition((t,), s, cover)
+                if s != 0.0:
+                    unigram_score += s
+                    picked.append(((t,), s))
+        if single_key_add_unigrams:
+            single_key_score += unigram_score
+        multi_key_score += unigram_score
+        res[0] = (1.0 - single_key) * multi_key_score + single_key * single_key_score
+        res[1] = picked
+    results = dict(sorted(results.items(), key=lambda kv: -kv[1][0]))
+    return results, all_ngrams

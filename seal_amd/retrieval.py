@@ -1,0 +1,486 @@
+"""``SEALSearcher`` / ``SEALDocument`` on the MI355X engine (reference seal/retrieval.py).
+
+The searcher keeps the reference's surface -- ``DEFAULTS`` as the single source
+of parameters (retrieval.py:401-446), ``set_params`` / ``add_args`` /
+``from_args`` / ``load`` / ``search`` / ``batch_search`` / ``generate_keys`` /
+``retrieve_from_keys`` / ``doc`` -- and the same key-generation recipe
+(``process_batch``, retrieval.py:54-305).  Differences are confined to where
+work runs:
+
+* decoding goes through ``seal_amd.fm_index_generate`` (GPU constraint kernels);
+* every ``fm_index.get_count(k) > 0`` post-filter of a batch (retrieval.py:91,
+  130,191,247) is one batched backward-search launch;
+* ``jobs`` (a ``multiprocessing.Pool`` over queries in the reference,
+  retrieval.py:762-775) is accepted and ignored: the per-query index work is
+  already batched on the GPU.
+
+Queries may be strings (a HF tokenizer is then required, as in the reference)
+or pre-tokenised id lists ``[<s>, ..., </s>]`` (no tokenizer needed; the marker
+suffixes " || body", " || title", " || +" are then taken from
+``marker_token_ids``).
+"""
+import logging
+from itertools import islice
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+
+from . import keys as rk
+from .beam_search import fm_index_generate
+from .index import FMIndex
+
+logger = logging.getLogger(__name__)
+
+DEBUG = False
+
+
+class SEALDocument:
+    """A retrieved passage (reference retrieval.py:315-397)."""
+
+    def __init__(self, idx: int, score: float, fm_index: FMIndex, bart_tokenizer, delim1: int = 49314,
+                 delim2: int = None, keys=None, query=None):
+        self.idx = idx
+        self.score = score
+        self.fm_index = fm_index
+        self.bart_tokenizer = bart_tokenizer
+        self.delim1 = delim1
+        self.delim2 = delim2
+        self.keys = keys
+        self.query = query
+        self._raw_tokens = None
+        self._body = None
+        self._title = None
+
+    @property
+    def docid(self):
+        return self.fm_index.labels[self.idx]
+
+    def id(self):
+        return self.idx
+
+    def raw_tokens(self):
+        if self._raw_tokens is None:
+            self._raw_tokens = self.fm_index.get_doc(self.idx)
+        return self._raw_tokens
+
+    def raw_text(self):
+        return self.bart_tokenizer.decode(self.raw_tokens(), clean_up_tokenization_spaces=False)
+
+    def text(self):
+        if self._body is None or self._title is None:
+            title_tokens, body_tokens = self.split_tokens(self.raw_tokens())
+            dec = lambda t: self.bart_tokenizer.decode(t, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+            self._title = dec(title_tokens) if title_tokens else ""
+            self._body = dec(body_tokens)
+        return self._title, self._body
+
+    def split_tokens(self, tokens):
+        """title = tokens before ``delim1`` ('@@'), body = after; ``delim2`` ('||')
+        cuts a leading code section off the body (retrieval.py:368-394)."""
+        if self.delim1 is None:
+            title_tokens, body_tokens = [], []
+        elif self.delim1 in tokens:
+            i = tokens.index(self.delim1)
+            title_tokens, body_tokens = tokens[:i], tokens[i + 1:]
+        else:
+            title_tokens, body_tokens = [], tokens
+        i = 0
+        if self.delim2 is not None and self.delim2 in body_tokens:
+            i = body_tokens.index(self.delim2) + 1
+        return title_tokens, body_tokens[i:]
+
+    def __repr__(self):
+        return f'<GRDocument: {self.idx}, "{self.raw_text()[:30]}[...]">'
+
+
+def _chunks(it, size):
+    it = iter(it)
+    while True:
+        block = list(islice(it, size))
+        if not block:
+            return
+        yield block
+
+
+def batch_generate_keys(searcher, queries, constrained_generation=True):
+    """Generator of per-query keys (reference retrieval.py:49-312)."""
+    for batch in _chunks(queries, searcher.batch_size):
+        for instance in _process_batch(searcher, batch, constrained_generation):
+            yield instance
+
+
+def _count_filter(index: FMIndex, per_query: List[List]) -> List[List]:
+    """``[(s, k) for s, k in fk if k and index.get_count(k) > 0]`` for every query of
+    the batch with one launch."""
+    flat = [k for fk in per_query for _, k in fk if k]
+    counts = iter(index.get_count_batch(flat).tolist() if flat else [])
+    out = []
+    for fk in per_query:
+        kept = []
+        for s, k in fk:
+            if k and next(counts) > 0:
+                kept.append((s, k))
+        out.append(kept)
+    return out
+
+
+def _process_batch(searcher, inputs, constrained_generation):
+    s = searcher
+    tokenised = not isinstance(inputs[0], str)
+    if tokenised:
+        base_tokens = [list(q) for q in inputs]
+    else:
+        inputs = [(" " + q.strip()) if s.prepend_space else q.strip() for q in inputs]
+        base_tokens = s.bart_tokenizer(inputs, padding=False)["input_ids"]
+
+    def marked(kind: str):
+        """encoder inputs with ' || <kind>' and ' || +' appended (retrieval.py:60-65)"""
+        if tokenised:
+            extra = (s.marker_token_ids[kind] if s.use_markers else []) + (s.marker_token_ids["+"] if s.value_conditioning else [])
+            return None, [t[:-1] + extra + t[-1:] for t in base_tokens]
+        strs = inputs
+        if s.use_markers:
+            strs = [i + f" || {kind}" for i in strs]
+        if s.value_conditioning:
+            strs = [i + " || +" for i in strs]
+        return strs, s.bart_tokenizer(strs, padding=False)["input_ids"]
+
+    def encoder_batch(strs, toks):
+        if strs is not None:
+            b = s.bart_tokenizer(strs, return_tensors="pt", padding=True, truncation=True)
+            return {k: v.to(s.device) for k, v in b.items()}
+        ids = rk._pad_batch(toks, s.bart_model.config.pad_token_id, s.device)
+        return dict(input_ids=ids, attention_mask=(ids != s.bart_model.config.pad_token_id).long())
+
+    strip_ids = s.strip_token_ids
+    bos_strip = [s.title_bos_token_id, s.code_bos_token_id, s.bart_model.config.decoder_start_token_id]
+
+    if s.decode_body:
+        strs, toks = marked("body")
+        found_keys = fm_index_generate(
+            s.bart_model, s.fm_index, **encoder_batch(strs, toks),
+            min_length=s.length, max_length=s.length, length_penalty=s.length_penalty, num_beams=s.beam,
+            disable_fm_index=not constrained_generation, diverse_bs_groups=s.diverse_bs_groups,
+            diverse_bs_penalty=s.diverse_bs_penalty, stop_at_count=s.stop_at_count, keep_history=True, topk=s.topk)
+        for fk in found_keys:   # retrieval.py:85-90
+            fk[:] = [(sc, k[1:] if k[0] in strip_ids else k) for sc, k in fk if k]
+            fk[:] = [(sc, k[1:] if k[0] in strip_ids else k) for sc, k in fk if k]
+            fk[:] = [(sc, k[:-1] if k[-1] in strip_ids else k) for sc, k in fk if k]
+            if s.min_length > 0:
+                fk[:] = [(sc, k) for sc, k in fk if len(k) == s.min_length]
+        found_keys = _count_filter(s.fm_index, found_keys)   # retrieval.py:91
+        if s.rescore and s.use_markers:
+            found_keys = rk.rescore_keys(
+                s.bart_model, base_tokens, found_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
+                strip_from_eos=[s.title_eos_token_id, s.code_eos_token_id, s.bart_model.config.eos_token_id])
+    else:
+        found_keys = [[] for _ in inputs]
+
+    if s.add_query_to_keys:
+        if tokenised or s.bart_tokenizer is None:
+            raise RuntimeError("add_query_to_keys decomposes the query STRING into word n-grams (spaCy + tokenizer, "
+                               "reference retrieval.py:113-131); pass string queries or set add_query_to_keys=False")
+        from .query_keys import query_ngram_keys
+        cand = [query_ngram_keys(inp, s) for inp in inputs]
+        cand = [[(0.0, k) for k in kk] for kk in cand]
+        cand = [[k for _, k in kk] for kk in _count_filter(s.fm_index, cand)]
+        _, toks = marked("body")
+        for fk, nfk in zip(found_keys, rk.rescore_keys(s.bart_model, toks, cand, batch_size=100, length_penalty=0.0)):
+            fk += nfk
+
+    if s.decode_titles:
+        strs, toks = marked("title")
+        decoded = fm_index_generate(
+            s.bart_title_model, s.fm_index, **encoder_batch(strs, toks),
+            min_length=1, max_length=15, num_beams=s.beam, length_penalty=s.length_penalty,
+            force_decoding_from=[s.title_bos_token_id], eos_token_id=s.title_eos_token_id,
+            diverse_bs_groups=s.diverse_bs_groups, diverse_bs_penalty=s.diverse_bs_penalty, keep_history=True,
+            disable_fm_index=not constrained_generation, topk=s.topk)
+        title_keys = [[(sc, hyp) for sc, hyp in dec] for dec in decoded]
+        for fk in title_keys:   # retrieval.py:180-190
+            if s.force_decoding_second_token >= 0:
+                fk[:] = [(sc, k[:1] + k[2:]) for sc, k in fk if len(k) >= 3]
+            fk[:] = [(sc, k[:-1] if k[-1] in strip_ids else k) for sc, k in fk]
+            if not s.partial_titles:
+                fk[:] = [(sc, k) for sc, k in fk if k[-1] == s.title_eos_token_id]
+                if s.min_length > 0:
+                    fk[:] = [(sc, k) for sc, k in fk if len(k) == (s.min_length + 1)]
+            fk[:] = [(sc, [s.title_bos_token_id] + k if k[0] != s.title_bos_token_id else k) for sc, k in fk]
+        title_keys = _count_filter(s.fm_index, title_keys)   # retrieval.py:191
+        if s.rescore and s.use_markers:
+            title_keys = rk.rescore_keys(
+                s.bart_title_model, toks, title_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
+                strip_from_eos=[s.bart_model.config.eos_token_id])
+        for nfk, fk in zip(title_keys, found_keys):
+            fk += nfk
+
+    if s.decode_code:
+        raise NotImplementedError("decode_code is off in the reference's defaults (retrieval.py:437) and not built here")
+
+    if s.rescore and not s.use_markers:
+        found_keys = rk.rescore_keys(s.bart_scorer_model, base_tokens, found_keys, batch_size=100, length_penalty=0.0,
+                                     strip_from_bos=bos_strip, strip_from_eos=[s.bart_model.config.eos_token_id])
+
+    found_keys = [rk.deduplicate(fk) for fk in found_keys]
+    found_keys = [[(n, sc) for sc, n in fk] for fk in found_keys]   # flip to (ngram, score), retrieval.py:284
+
+    if s.unigram_scores:
+        _, toks = marked("body")
+        unigram = rk.compute_unigram_scores(
+            s.bart_scorer_model, toks, s.fm_index,
+            prefix=[s.force_decoding_second_token] if s.force_decoding_second_token >= 0 else [])
+        return list(zip(found_keys, unigram))
+    return found_keys
+
+
+class SEALSearcher:
+    """Drop-in for ``seal.retrieval.SEALSearcher`` (reference retrieval.py:399-811)."""
+
+    DEFAULTS = {
+        "backbone": "facebook/bart-large",
+        "fairseq_checkpoint": True,
+        "length": 10,
+        "min_length": 0,
+        "length_penalty": 0.0,
+        "scoring_length_penalty": 0.0,
+        "repetition_penalty": 0.8,
+        "score_exponent": 2.0,
+        "beam": 15,
+        "max_hits": 1500,
+        "fully_score": 1500,
+        "skip_frequent_keys": 10_000_000,
+        "add_query_to_keys": True,
+        "batch_size": 20,
+        "jobs": 1,
+        "progress": False,
+        "free_generation": False,
+        "use_fm_index_frequency": True,
+        "unigram_scores": True,
+        "add_best_unigrams_to_ngrams": True,
+        "use_top_k_ngrams": 5000,
+        "sort_by_length": False,
+        "sort_by_freq": False,
+        "print_n_doc": False,
+        "allow_overlaps": False,
+        "diverse_bs_groups": 1,
+        "diverse_bs_penalty": 0.0,
+        "rescore": True,
+        "detokenize": True,
+        "include_keys": False,
+        "single_key": 0.0,
+        "unigrams_ignore_free_places": False,
+        "use_markers": True,
+        "value_conditioning": True,
+        "decode_body": True,
+        "decode_titles": True,
+        "decode_code": False,
+        "partial_code": False,
+        "partial_titles": False,
+        "smoothing": 5.0,
+        "stop_at_count": 0,
+        "topk": 0,
+        "force_decoding_second_token": -1,
+    }
+
+    def __init__(self, fm_index: FMIndex, bart_tokenizer, bart_model, bart_scorer_model=None, bart_title_model=None,
+                 bart_code_model=None, **params):
+        self.fm_index = fm_index
+        self.docid2idx = {k: i for i, k in enumerate(self.fm_index.labels)} if self.fm_index.labels else {}
+        self.bart_tokenizer = bart_tokenizer
+        self.bart_model = bart_model
+        self.bart_scorer_model = bart_scorer_model if bart_scorer_model is not None else bart_model
+        self.bart_title_model = bart_title_model if bart_title_model is not None else bart_model
+        self.bart_code_model = bart_code_model if bart_code_model is not None else bart_model
+        self.num_docs = fm_index.n_docs
+        self.docids = fm_index.labels
+        self.set_params(params)
+        # extension: ids of the marker suffixes for pre-tokenised queries
+        self.marker_token_ids: Dict[str, List[int]] = params.get(
+            "marker_token_ids", {"body": [45056, 809], "title": [45056, 1270], "code": [45056, 3260], "+": [45056, 2055]})
+        # extension: stop aggregate_evidence after the first stage (keys.py:311-364)
+        self.first_stage_only: bool = params.get("first_stage_only", False)
+        if "bart" in self.backbone:   # retrieval.py:480-491
+            self.title_bos_token, self.title_bos_token_id = "</s>", 2
+            self.title_eos_token, self.title_eos_token_id = "@@", 49314
+            self.code_bos_token, self.code_bos_token_id = "@@", 49314
+            self.code_eos_token, self.code_eos_token_id = "||", 45056
+            self.prepend_space = True
+            self.strip_token_ids = (0, 2)
+        elif "t5" in self.backbone:
+            self.title_bos_token, self.title_bos_token_id = "</s>", 1
+            self.title_eos_token, self.title_eos_token_id = "<extra_id_99>", 32000
+            self.code_bos_token, self.code_bos_token_id = "<extra_id_99>", 32000
+            self.code_eos_token, self.code_eos_token_id = "<extra_id_98>", 32001
+            self.prepend_space = False
+            self.strip_token_ids = (0, 1)
+        else:
+            raise NotImplementedError
+        for k in ("title_eos_token_id", "title_bos_token_id", "code_eos_token_id", "code_bos_token_id"):
+            if k in params:   # extension: small-vocabulary test models
+                setattr(self, k, params[k])
+
+    @property
+    def device(self):
+        return next(self.bart_model.parameters()).device
+
+    @device.setter
+    def device(self, device: str):
+        self.bart_model.to(device)
+
+    def set_params(self, params):
+        for key, val in self.DEFAULTS.items():
+            setattr(self, key, params.get(key, val))
+
+    @classmethod
+    def add_args(cls, parser):
+        parser.add_argument("--fm_index", required=True, type=str)
+        parser.add_argument("--checkpoint", required=False, type=str)
+        parser.add_argument("--checkpoint_scorer", required=False, type=str, default=None)
+        parser.add_argument("--checkpoint_title", required=False, type=str, default=None)
+        parser.add_argument("--checkpoint_code", required=False, type=str, default=None)
+        parser.add_argument("--device", default="cuda:0", type=str)
+        for name, value in cls.DEFAULTS.items():
+            if value is True:
+                parser.add_argument(f"--dont_{name}", action="store_false", dest=name)
+            elif value is False:
+                parser.add_argument(f"--{name}", action="store_true")
+            else:
+                parser.add_argument(f"--{name}", required=False, type=type(value), default=value)
+
+    @classmethod
+    def from_args(cls, args):
+        params = {name: getattr(args, name) for name in cls.DEFAULTS}
+        return cls.load(args.fm_index, args.checkpoint, bart_scorer_model_path=args.checkpoint_scorer,
+                        bart_title_model_path=args.checkpoint_title, bart_code_model_path=args.checkpoint_code,
+                        device=args.device, **params)
+
+    @staticmethod
+    def load_fm_index(fm_index_path: str):
+        logger.warning(f"initializing FM-index from {fm_index_path}")
+        index = FMIndex.load(fm_index_path)
+        logger.warning(f"FM-index resident in HBM ({index.device_bytes() // 1024 ** 2} MBs)")
+        return index
+
+    @staticmethod
+    def load_bart(bart_model_path: str, device: str = "cuda:0", backbone="facebook/bart-large", fairseq_checkpoint=True):
+        """reference retrieval.py:561-592 (needs the HF hub files of ``backbone``)."""
+        from transformers import AutoConfig, AutoModelForSeq2SeqLM, AutoTokenizer
+        config = AutoConfig.from_pretrained(backbone)
+        config.forced_bos_token_id = None
+        tokenizer = AutoTokenizer.from_pretrained(backbone)
+        if bart_model_path:
+            from .utils import load_state_dict_from_fairseq_checkpoint, load_state_dict_from_lightning_checkpoint
+            model = AutoModelForSeq2SeqLM.from_config(config)
+            model.resize_token_embeddings(len(tokenizer))
+            if fairseq_checkpoint:
+                load_state_dict_from_fairseq_checkpoint(model, bart_model_path)
+            else:
+                load_state_dict_from_lightning_checkpoint(model, bart_model_path)
+        else:
+            model = AutoModelForSeq2SeqLM.from_pretrained(backbone)
+            model.resize_token_embeddings(len(tokenizer))
+        model.config.forced_bos_token_id = None
+        model.eval()
+        if hasattr(model, "final_logits_bias"):   # retrieval.py:583-588
+            model.config.add_bias_logits = True
+            model.final_logits_bias[0, tokenizer.pad_token_id] = float("-inf")
+            model.final_logits_bias[0, tokenizer.bos_token_id] = float("-inf")
+            model.final_logits_bias[0, tokenizer.mask_token_id] = float("-inf")
+        model.to(device)
+        return tokenizer, model
+
+    @classmethod
+    def load(cls, fm_index_path, bart_model_path, device="cuda:0", **params):
+        fm_index = cls.load_fm_index(fm_index_path)
+        kw = dict(backbone=params.get("backbone", "facebook/bart-large"), fairseq_checkpoint=params.get("fairseq_checkpoint", True))
+        bart_tokenizer, bart_model = cls.load_bart(bart_model_path, device, **kw)
+        extra = {}
+        for name in ("scorer", "title", "code"):
+            path = params.get(f"bart_{name}_model_path")
+            extra[f"bart_{name}_model"] = cls.load_bart(path, device, **kw)[1] if path is not None else None
+        return cls(fm_index, bart_tokenizer, bart_model, **extra, **params)
+
+    def search(self, query, k: int = 10, added_documents=None, detokenize=True) -> List[SEALDocument]:
+        if added_documents is not None:
+            added_documents = [added_documents]
+        return self.batch_search([query], k=k, added_documents=added_documents, detokenize=True)[0]
+
+    def batch_search(self, queries, k: int = 10, added_documents=None, detokenize=None) -> List[List[SEALDocument]]:
+        """reference retrieval.py:649-691"""
+        if detokenize is None:
+            detokenize = self.detokenize
+        keys = self.batch_generate_keys(queries)
+        if added_documents is not None:
+            if self.unigram_scores:
+                keys = ((kk, us, added_documents[i]) for i, (kk, us) in enumerate(keys))
+            else:
+                keys = ((kk, None, added_documents[i]) for i, kk in enumerate(keys))
+        results, _ = zip(*self.batch_retrieve_from_keys(keys))
+        key_info = {}
+        retrieved = []
+        for query, res in zip(queries, results):
+            docs = []
+            for idx, info in islice(res.items(), k):
+                score, kk, full = info[0], info[1], (info[3] if len(info) == 5 else None)
+                doc = SEALDocument(idx, score, self.fm_index, self.bart_tokenizer, delim1=self.title_eos_token_id,
+                                   delim2=self.code_eos_token_id, keys=None, query=query)
+                if self.include_keys:
+                    for key, _ in kk:
+                        key = tuple(key)
+                        if key not in key_info:
+                            text = (self.bart_tokenizer.decode(list(key), clean_up_tokenization_spaces=False)
+                                    if self.bart_tokenizer is not None else None)
+                            key_info[key] = (text, self.fm_index.get_count(list(key)))
+                    doc.keys = [(*key_info[tuple(key)], sc) for key, sc in kk]
+                doc._raw_tokens = full
+                docs.append(doc)
+            retrieved.append(docs)
+        if detokenize and self.bart_tokenizer is not None:
+            return self.detokenize_retrieved(retrieved)
+        return retrieved
+
+    def detokenize_retrieved(self, retrieved):
+        """reference retrieval.py:693-712"""
+        for docs in retrieved:
+            for d in docs:
+                title, body = d.split_tokens(d._raw_tokens if d._raw_tokens is not None else d.raw_tokens())
+                d._title, d._body = self._batch_detokenize([title, body])
+        return retrieved
+
+    def _batch_detokenize(self, seqs):
+        return [self.bart_tokenizer.decode(seq, skip_special_tokens=True, clean_up_tokenization_spaces=False).strip()
+                if seq else "" for seq in seqs]
+
+    def generate_keys(self, query):
+        return next(self.batch_generate_keys([query]))
+
+    def batch_generate_keys(self, queries):
+        return batch_generate_keys(self, queries, constrained_generation=not self.free_generation)
+
+    def retrieve_from_keys(self, keys):
+        """reference retrieval.py:720-754"""
+        unigram_scores = None
+        if isinstance(keys, tuple) and len(keys) == 1:
+            keys = keys[0]
+        elif isinstance(keys, tuple) and len(keys) == 2:
+            keys, unigram_scores = keys
+        elif isinstance(keys, tuple) and len(keys) == 3:
+            keys, unigram_scores, _ = keys
+        return rk.aggregate_evidence(
+            ngrams_and_scores=keys, unigram_scores=unigram_scores, index=self.fm_index,
+            max_occurrences_1=self.max_hits, n_docs_complete_score=self.fully_score, alpha=self.score_exponent,
+            beta=self.repetition_penalty, length_penalty=self.scoring_length_penalty,
+            use_fm_index_frequency=self.use_fm_index_frequency,
+            add_best_unigrams_to_ngrams=self.add_best_unigrams_to_ngrams, use_top_k_unigrams=self.use_top_k_ngrams,
+            sort_by_length=self.sort_by_length, sort_by_freq=self.sort_by_freq, smoothing=self.smoothing,
+            allow_overlaps=self.allow_overlaps, single_key=self.single_key,
+            unigrams_ignore_free_places=self.unigrams_ignore_free_places, first_stage_only=self.first_stage_only)
+
+    def batch_retrieve_from_keys(self, keys):
+        for kk in keys:
+            yield self.retrieve_from_keys(kk)
+
+    def doc(self, docid: Union[str, int]) -> Optional[SEALDocument]:
+        idx = self.docid2idx[docid] if isinstance(docid, str) else docid
+        return SEALDocument(idx, None, self.fm_index, self.bart_tokenizer, delim1=self.title_eos_token_id,
+                            delim2=self.code_eos_token_id)

@@ -69,3 +69,57 @@ def valid_set(hyps, index, digits=None):
         if k and index.get_count(k) > 0:
             out.setdefault((tuple(toks)), []).append(score)
     return out
+
+
+class OracleBatchIndex:
+    """tests-only adapter: the batched index methods the host logic of
+    seal_amd.keys consumes, answered by scalar calls into the CPU oracle."""
+
+    def __init__(self, orc):
+        self.orc = orc
+        self.beginnings = orc.beginnings
+        self.occurring_distinct = orc.occurring_distinct
+
+    def __len__(self):
+        return len(self.orc)
+
+    def get_range_batch(self, seqs):
+        r = [self.orc.get_range(list(s)) for s in seqs]
+        return np.asarray([a for a, _ in r], dtype=np.uint64), np.asarray([b for _, b in r], dtype=np.uint64)
+
+    def get_count_batch(self, seqs):
+        lo, hi = self.get_range_batch(seqs)
+        return (hi - lo).astype(np.int64)
+
+    def get_count(self, seq):
+        return self.orc.get_count(list(seq))
+
+    def locate_ranges(self, lows, highs, max_per_range):
+        pos, doc, offs = [], [], [0]
+        for a, b in zip(lows, highs):
+            rows = list(range(int(a), int(b)))[:max_per_range]
+            for r in rows:
+                p = self.orc.locate(r)
+                pos.append(p)
+                doc.append(self.orc.get_doc_index(p))
+            offs.append(len(pos))
+        return np.asarray(pos, dtype=np.int64), np.asarray(doc, dtype=np.int64), np.asarray(offs, dtype=np.int64)
+
+    def get_docs_batch(self, docs):
+        return [self.orc.get_doc(int(d)) for d in docs]
+
+
+def synthetic_keys(rng, docs, vocab, n_keys=40, with_titles=False):
+    """(ngram, lm_logprob) pairs shaped like the searcher's output: corpus n-grams
+    (some repeated inside documents), a few absent ones, a few unigrams."""
+    keys = []
+    for _ in range(n_keys):
+        d = docs[int(rng.integers(len(docs)))]
+        a = int(rng.integers(0, len(d) - 1))
+        ng = d[a:a + int(rng.integers(1, 5))]
+        if rng.random() < 0.15:
+            ng = ng + [int(rng.integers(4, vocab))]
+        if with_titles and rng.random() < 0.2:
+            ng = [2] + d[:3]
+        keys.append((list(ng), -float(rng.random() * 6 + 0.05)))
+    return keys

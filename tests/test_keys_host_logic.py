@@ -1,0 +1,57 @@
+"""Host logic of seal_amd.keys on CPU: the batched/vectorised aggregate_evidence
+against the scalar, line-by-line restatement (oracle/keys_oracle.py)."""
+import numpy as np
+import pytest
+
+from oracle.keys_oracle import oracle_aggregate_evidence, oracle_deduplicate, oracle_strip
+from oracle.seal_oracle import OracleFMIndex
+from seal_amd.keys import aggregate_evidence, deduplicate, strip
+from tests.helpers import OracleBatchIndex, make_docs, synthetic_keys
+
+
+def _same(a, b):
+    (ra, na), (rb, nb) = a, b
+    assert list(na.items()) == list(nb.items())
+    assert list(ra.keys()) == list(rb.keys())
+    for d in ra:
+        assert ra[d][0] == rb[d][0], d                      # float64, same operation order -> exact
+        assert [(tuple(n), s) for n, s in ra[d][1]] == [(tuple(n), s) for n, s in rb[d][1]]
+        assert ra[d][-1][1] == rb[d][-1][1] and tuple(ra[d][-1][0]) == tuple(rb[d][-1][0])
+        if len(ra[d]) == 5:
+            assert ra[d][3] == rb[d][3]
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (0, dict()),
+    (1, dict(add_best_unigrams_to_ngrams=True, use_top_k_unigrams=30, n_docs_complete_score=20)),
+    (2, dict(max_occurrences_1=5, n_docs_complete_score=7, beta=0.5, alpha=1.5)),
+    (3, dict(first_stage_only=True, max_occurrences_1=50)),
+    (4, dict(single_key=0.3, allow_overlaps=True, length_penalty=0.1)),
+    (5, dict(sort_by_length=True)),
+    (6, dict(use_fm_index_frequency=False)),
+])
+def test_aggregate_evidence_matches_restatement(seed, kw):
+    vocab = 60
+    rng = np.random.default_rng(seed)
+    docs = make_docs(seed, 120, vocab, min_len=6, max_len=20, title_sep=7)
+    # a repetitive document so that windows of one key overlap each other
+    docs.append([9, 9, 9, 9, 9, 9, 9, 9, 2])
+    orc = OracleFMIndex()
+    orc.initialize(docs)
+    keys = synthetic_keys(rng, docs, vocab, with_titles=True) + [([9, 9], -0.7), ([9, 9, 9], -1.1)]
+    us = (-rng.random(vocab) * 8 - 0.01).tolist()
+    got = aggregate_evidence(keys, unigram_scores=us, index=OracleBatchIndex(orc), **kw)
+    want = oracle_aggregate_evidence(keys, unigram_scores=us, index=orc, **kw)
+    assert len(want[0]) > 0
+    _same(got, want)
+    got = aggregate_evidence(keys, unigram_scores=None, index=OracleBatchIndex(orc), **kw)
+    want = oracle_aggregate_evidence(keys, unigram_scores=None, index=orc, **kw)
+    _same(got, want)
+
+
+def test_small_helpers():
+    assert strip([2, 0, 5, 6, 2], (0, 2), (2,)) == oracle_strip([2, 0, 5, 6, 2], (0, 2), (2,)) == [5, 6]
+    assert strip([2, 2], (2,), (2,)) == oracle_strip([2, 2], (2,), (2,)) == []
+    items = [(0.5, [1, 2]), (0.4, [1, 2]), (0.1, [3])]
+    assert deduplicate(items) == oracle_deduplicate(items) == [(0.5, [1, 2]), (0.1, [3])]
+    assert deduplicate([[1], [1], [2]]) == [[1], [2]]
