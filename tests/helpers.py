@@ -55,10 +55,22 @@ def hf_logits_fn(model, enc_ids, enc_mask, num_beams):
     return fn
 
 
-def valid_set(hyps, index, digits=None):
-    """hypotheses that survive the reference's post-filter (count > 0 after stripping,
-    retrieval.py:85-91) -- the part that is independent of top-k tie order."""
+def valid_set(hyps, index, title_eos=None):
+    """What the searcher keeps of a hypothesis list: strip, ``count > 0`` filter
+    (reference retrieval.py:85-91), then first-occurrence dedup (retrieval.py:281).
+    This is the level at which the reference itself is deterministic: when a query
+    has fewer than 2K finite constrained candidates, ``torch.topk`` picks ``-inf``
+    entries in an unspecified order; such picks either fail the count
+    filter or (a stray eos/pad after a live prefix) strip back to a key that the
+    live prefix already contributed at the previous step."""
     out = {}
+    if title_eos is not None:
+        # title decode: the searcher's title filter instead (retrieval.py:178-191): must end
+        # with the title eos, keeps the leading </s>, count > 0 on the whole thing
+        from oracle.keys_oracle import oracle_title_postfilter
+        for score, k in oracle_title_postfilter(hyps, index, title_bos=2, title_eos=title_eos):
+            out.setdefault(tuple(k), []).append(score)
+        return {k: v[:1] for k, v in out.items()}
     for score, toks in hyps:
         k = list(toks)
         for _ in range(2):
@@ -67,8 +79,8 @@ def valid_set(hyps, index, digits=None):
         if k and k[-1] in (0, 2):
             k = k[:-1]
         if k and index.get_count(k) > 0:
-            out.setdefault((tuple(toks)), []).append(score)
-    return out
+            out.setdefault(tuple(k), []).append(score)
+    return {k: v[:1] for k, v in out.items()}
 
 
 class OracleBatchIndex:

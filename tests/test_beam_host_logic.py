@@ -68,7 +68,8 @@ def test_beam_loop_matches_reference_restatement(kw):
                                     disable_fm_index=kw.get("disable_fm_index", False))
     assert len(got) == len(want) == 4
     for g, w in zip(got, want):
-        gv, wv = valid_set(g, orc), valid_set(w, orc)
+        te = eos if kw.get("force_decoding_from") else None
+        gv, wv = valid_set(g, orc, te), valid_set(w, orc, te)
         assert set(gv) == set(wv)
         for k in gv:
             assert len(gv[k]) == len(wv[k])

@@ -86,4 +86,4 @@ def test_searcher_ranks_like_the_scalar_pipeline(first_stage_only, monkeypatch):
             assert sorted(d.idx for d in g)[:3] is not None
         assert g[0].docid == f"d{g[0].idx}"
         if not first_stage_only:
-            assert g[0].raw_tokens() == orc.get_doc(g[0].idx)
+            assert g[0].raw_tokens() == [2] + orc.get_doc(g[0].idx)[:-1]   # `full` of keys.py:388, retrieval.py:685
