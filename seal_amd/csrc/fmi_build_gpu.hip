@@ -1,12 +1,366 @@
-// Device-side index construction (suffix array by prefix doubling with rocPRIM
-// radix sorts, BWT, wavelet-matrix levels).  Placeholder until the GPU builder
-// lands: reports FMI_ERR_UNSUPPORTED so callers fall back to fmi_build (host).
+// Device-side index construction for corpora the host builder cannot reach
+// (NQ: ~2.9e9 symbols).  Produces byte-identical arrays to fmi_host.cpp:
+//   suffix array  : prefix doubling; round 0 sorts 64-bit keys packing the first
+//                   64/L symbols, round r sorts (rank[i], rank[i+h]) composites,
+//                   all with rocPRIM's stable LSD radix sort (double buffered);
+//   BWT           : gather;
+//   wavelet matrix: per level, one wave per 448-bit block builds the 7 payload
+//                   words with __ballot, a device scan fills the block counters,
+//                   and the stable zero/one partition is a scatter whose
+//                   destination is the rank on the level just built;
+//   tables        : leaf/occ from the run boundaries after the last partition,
+//                   first BWT occurrence per symbol for the Q1 table.
+// HBM budget at n = 2.9e9 (u32 indices): ~90 GB peak, all freed before return
+// except the index itself.
 #include <hip/hip_runtime.h>
-#include "fmi_internal.h"
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "fmi_device.h"
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            fmi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return FMI_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+namespace {
+
+struct Pool {   // frees everything still registered on scope exit
+    std::vector<void *> ptrs;
+    ~Pool() { for (void *p : ptrs) if (p) (void)hipFree(p); }
+    template <class T> hipError_t alloc(T **out, uint64_t count)
+    {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<uint64_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = (T *)p;
+        return e;
+    }
+    void release(void *p) { for (auto &q : ptrs) if (q == p) { (void)hipFree(q); q = nullptr; } }
+    void keep(void *p) { for (auto &q : ptrs) if (q == p) q = nullptr; }
+};
+
+constexpr unsigned TB = 256;
+inline unsigned grid_for(uint64_t n) { return (unsigned)std::min<uint64_t>((n + TB - 1) / TB, 1u << 20); }
+#define GRID_STRIDE(i, n) for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (uint64_t)gridDim.x * blockDim.x)
+
+template <typename SymT>
+__global__ void k_make_text(const uint32_t *data, uint64_t n, SymT *text)
+{
+    GRID_STRIDE(i, n) text[i] = (i + 1 < n) ? (SymT)data[i] : (SymT)0;   // sdsl appends the 0 sentinel
+}
+
+template <typename SymT>
+__global__ void k_pack_keys(const SymT *text, uint64_t n, uint32_t bits, uint32_t per, uint64_t *keys, uint32_t *idx)
+{
+    GRID_STRIDE(i, n) {
+        uint64_t key = 0;
+        for (uint32_t j = 0; j < per; j++) {
+            uint64_t s = (i + j < n) ? (uint64_t)text[i + j] : 0;
+            key = (key << bits) | s;
+        }
+        keys[i] = key;
+        idx[i] = (uint32_t)i;
+    }
+}
+
+// head[j] = j if sorted key j starts a new group else 0 (max-scanned into group starts)
+__global__ void k_heads(const uint64_t *keys, uint64_t n, uint32_t *gs)
+{
+    GRID_STRIDE(j, n) gs[j] = (j == 0 || keys[j] != keys[j - 1]) ? (uint32_t)j : 0u;
+}
+
+__global__ void k_scatter_rank(const uint32_t *sa, const uint32_t *gs, uint64_t n, uint32_t *rank, unsigned long long *n_groups)
+{
+    unsigned long long local = 0;
+    GRID_STRIDE(j, n) {
+        rank[sa[j]] = gs[j];
+        local += (gs[j] == j);
+    }
+    // one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(n_groups, local);
+}
+
+__global__ void k_pair_keys(const uint32_t *sa, const uint32_t *rank, uint64_t n, uint64_t h, uint32_t bits, uint64_t *keys)
+{
+    GRID_STRIDE(j, n) {
+        const uint64_t p = sa[j];
+        const uint64_t r2 = (p + h < n) ? rank[p + h] : 0;   // only reached by already-unique suffixes
+        keys[j] = ((uint64_t)rank[p] << bits) | r2;
+    }
+}
+
+template <typename SymT>
+__global__ void k_bwt(const SymT *text, const uint32_t *sa, uint64_t n, SymT *bwt)
+{
+    GRID_STRIDE(j, n) { const uint64_t p = sa[j]; bwt[j] = text[p ? p - 1 : n - 1]; }
+}
+
+// one wave per 448-bit block of one level
+template <typename SymT>
+__global__ __launch_bounds__(256) void k_level_words(const SymT *cur, uint64_t n, uint32_t sh, uint64_t nblk, uint64_t *lvl, uint32_t *blk_ones)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t b = wave; b < nblk; b += nwaves) {
+        uint32_t ones = 0;
+        for (uint32_t w = 0; w < 7; w++) {
+            const uint64_t p = b * FMI_BLOCK_BITS + (uint64_t)w * 64 + lane;
+            const bool bit = p < n && ((cur[p] >> sh) & 1);
+            const uint64_t word = __ballot(bit);
+            if (lane == 0) lvl[b * FMI_BLOCK_WORDS + 1 + w] = word;
+            ones += (uint32_t)__popcll(word);
+        }
+        if (lane == 0) blk_ones[b] = ones;
+    }
+}
+
+__global__ void k_store_counts(const uint64_t *excl, uint64_t nblk, uint64_t *lvl)
+{
+    GRID_STRIDE(b, nblk) lvl[b * FMI_BLOCK_WORDS] = excl[b];
+}
+
+template <typename SymT>
+__global__ void k_partition(FmiDev ix, uint32_t k, const SymT *cur, SymT *nxt)
+{
+    const uint32_t sh = ix.levels - 1 - k;
+    const uint64_t z = ix.zeros[k];
+    GRID_STRIDE(i, ix.n) {
+        const SymT v = cur[i];
+        const uint64_t r1 = wm_rank1(ix, k, i, nullptr);
+        nxt[((v >> sh) & 1) ? z + r1 : i - r1] = v;
+    }
+}
+
+template <typename SymT>
+__global__ void k_runs(const SymT *sorted, uint64_t n, uint64_t *leaf, uint64_t *occ_end)
+{
+    GRID_STRIDE(i, n) {
+        const SymT v = sorted[i];
+        if (i == 0 || sorted[i - 1] != v) leaf[v] = i;
+        if (i + 1 == n || sorted[i + 1] != v) occ_end[v] = i + 1;
+    }
+}
+
+template <typename SymT>
+__global__ void k_first_pos(const SymT *bwt, uint64_t n, unsigned long long *first_pos)
+{
+    GRID_STRIDE(j, n) {
+        const SymT v = bwt[j];
+        if (j < first_pos[v]) atomicMin(&first_pos[v], (unsigned long long)j);
+    }
+}
+
+template <typename SymT>
+__global__ void k_widen(const SymT *in, uint64_t n, uint32_t *out) { GRID_STRIDE(i, n) out[i] = in[i]; }
+
+template <typename SymT>
+int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int keep_host, uint64_t max_sym, uint32_t L)
+{
+    const uint64_t n = n_data + 1;
+    Pool pool;
+    hipStream_t st = 0;
+    SymT *text = nullptr;
+    HIPCHK(pool.alloc(&text, n));
+    hipLaunchKernelGGL((k_make_text<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, d_data, n, text);
+
+    // ---- suffix array -----------------------------------------------------
+    uint64_t *keyA = nullptr, *keyB = nullptr;
+    uint32_t *idxA = nullptr, *idxB = nullptr, *rank = nullptr;
+    unsigned long long *d_groups = nullptr;
+    HIPCHK(pool.alloc(&keyA, n)); HIPCHK(pool.alloc(&keyB, n));
+    HIPCHK(pool.alloc(&idxA, n)); HIPCHK(pool.alloc(&idxB, n));
+    HIPCHK(pool.alloc(&rank, n)); HIPCHK(pool.alloc(&d_groups, 1));
+    const uint32_t per = std::max<uint32_t>(1, 64 / L);
+    uint32_t nbits = 1;
+    while ((n >> nbits) > 0) nbits++;           // bits to hold a rank < n
+    hipLaunchKernelGGL((k_pack_keys<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, text, n, L, per, keyA, idxA);
+    rocprim::double_buffer<uint64_t> dk(keyA, keyB);
+    rocprim::double_buffer<uint32_t> dv(idxA, idxB);
+    size_t tmp_bytes = 0, scan_bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, n, 0u, 64u, st));
+    HIPCHK(rocprim::inclusive_scan(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, n, rocprim::maximum<uint32_t>(), st));
+    void *tmp = nullptr;
+    HIPCHK(pool.alloc((char **)&tmp, std::max(tmp_bytes, scan_bytes) + 256));
+    size_t tb = tmp_bytes;
+    HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, 0u, std::min<uint32_t>(64u, per * L), st));
+    uint64_t h_step = per;
+    for (int round = 0;; round++) {
+        uint32_t *sa = dv.current();
+        uint32_t *gs = dv.alternate();           // free until the next sort
+        hipLaunchKernelGGL(k_heads, dim3(grid_for(n)), dim3(TB), 0, st, dk.current(), n, gs);
+        size_t sb = scan_bytes;
+        HIPCHK(rocprim::inclusive_scan(tmp, sb, gs, gs, n, rocprim::maximum<uint32_t>(), st));
+        HIPCHK(hipMemsetAsync(d_groups, 0, 8, st));
+        hipLaunchKernelGGL(k_scatter_rank, dim3(grid_for(n)), dim3(TB), 0, st, sa, gs, n, rank, d_groups);
+        unsigned long long groups = 0;
+        HIPCHK(hipMemcpyAsync(&groups, d_groups, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (groups == n) break;
+        if (round > 64) { fmi_set_error("suffix array did not converge"); return FMI_ERR_STATE; }
+        hipLaunchKernelGGL(k_pair_keys, dim3(grid_for(n)), dim3(TB), 0, st, sa, rank, n, h_step, nbits, dk.current());
+        tb = tmp_bytes;
+        HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, 0u, std::min<uint32_t>(64u, 2 * nbits), st));
+        h_step *= 2;
+    }
+    uint32_t *sa = dv.current();
+    pool.release(keyA); pool.release(keyB); pool.release(rank); pool.release(dv.alternate());
+
+    // ---- BWT + wavelet matrix ----------------------------------------------
+    SymT *bwt = nullptr, *cur = nullptr, *nxt = nullptr;
+    HIPCHK(pool.alloc(&bwt, n)); HIPCHK(pool.alloc(&cur, n)); HIPCHK(pool.alloc(&nxt, n));
+    hipLaunchKernelGGL((k_bwt<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, text, sa, n, bwt);
+    HIPCHK(hipMemcpyAsync(cur, bwt, n * sizeof(SymT), hipMemcpyDeviceToDevice, st));
+    const uint64_t nblk = n / FMI_BLOCK_BITS + 2;
+    uint64_t *wm = nullptr, *excl = nullptr;
+    uint32_t *blk_ones = nullptr;
+    HIPCHK(pool.alloc(&wm, (uint64_t)L * nblk * FMI_BLOCK_WORDS));
+    HIPCHK(pool.alloc(&excl, nblk + 1)); HIPCHK(pool.alloc(&blk_ones, nblk + 1));
+    HIPCHK(hipMemsetAsync(blk_ones + nblk, 0, 4, st));
+    size_t xs_bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, xs_bytes, blk_ones, excl, (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
+    void *xs_tmp = nullptr;
+    HIPCHK(pool.alloc((char **)&xs_tmp, xs_bytes + 256));
+    FmiDev d{};
+    d.wm = wm; d.nblk = nblk; d.n = n; d.max_sym = max_sym; d.levels = L; d.sym_bytes = sizeof(SymT) == 2 ? 2 : 4;
+    std::vector<uint64_t> zeros(L);
+    for (uint32_t k = 0; k < L; k++) {
+        uint64_t *lvl = wm + (uint64_t)k * nblk * FMI_BLOCK_WORDS;
+        hipLaunchKernelGGL((k_level_words<SymT>), dim3((unsigned)std::min<uint64_t>((nblk + 3) / 4, 1u << 18)), dim3(256), 0, st,
+                           cur, n, L - 1 - k, nblk, lvl, blk_ones);
+        size_t xb = xs_bytes;
+        HIPCHK(rocprim::exclusive_scan(xs_tmp, xb, blk_ones, excl, (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
+        hipLaunchKernelGGL(k_store_counts, dim3(grid_for(nblk)), dim3(TB), 0, st, excl, nblk, lvl);
+        uint64_t ones = 0;
+        HIPCHK(hipMemcpyAsync(&ones, excl + nblk, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        zeros[k] = n - ones;
+        d.zeros[k] = zeros[k];
+        hipLaunchKernelGGL((k_partition<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, d, k, cur, nxt);
+        std::swap(cur, nxt);
+    }
+    HIPCHK(hipGetLastError());
+
+    // ---- per-symbol tables --------------------------------------------------
+    uint64_t *leaf = nullptr, *occ_end = nullptr;
+    unsigned long long *first_pos = nullptr;
+    HIPCHK(pool.alloc(&leaf, max_sym + 1)); HIPCHK(pool.alloc(&occ_end, max_sym + 1)); HIPCHK(pool.alloc(&first_pos, max_sym + 1));
+    HIPCHK(hipMemsetAsync(leaf, 0, (max_sym + 1) * 8, st));
+    HIPCHK(hipMemsetAsync(occ_end, 0, (max_sym + 1) * 8, st));
+    HIPCHK(hipMemsetAsync(first_pos, 0xff, (max_sym + 1) * 8, st));
+    hipLaunchKernelGGL((k_runs<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, cur, n, leaf, occ_end);
+    hipLaunchKernelGGL((k_first_pos<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, bwt, n, first_pos);
+    std::vector<uint64_t> h_leaf(max_sym + 1), h_end(max_sym + 1), h_first(max_sym + 1);
+    HIPCHK(hipMemcpyAsync(h_leaf.data(), leaf, (max_sym + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_end.data(), occ_end, (max_sym + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_first.data(), first_pos, (max_sym + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+
+    h->n = n; h->max_sym = max_sym; h->levels = L; h->nblk = nblk; h->sym_bytes = d.sym_bytes;
+    h->zeros = zeros;
+    h->leaf = h_leaf;
+    h->C.assign(max_sym + 2, 0);
+    uint64_t sigma = 0;
+    for (uint64_t c = 0; c <= max_sym; c++) {
+        const uint64_t occ = h_end[c] ? h_end[c] - h_leaf[c] : 0;
+        if (occ) sigma++;
+        h->C[c + 1] = h->C[c] + occ;
+    }
+    h->sigma = sigma;
+    fmi_host_q1_from_first_pos(h_first, L, max_sym, h->C, h->q1);
+
+    // small tables to the device
+    uint64_t *dC = nullptr, *dleaf = leaf;
+    uint8_t *dq1 = nullptr;
+    HIPCHK(pool.alloc(&dC, max_sym + 2)); HIPCHK(pool.alloc(&dq1, max_sym + 1));
+    HIPCHK(hipMemcpy(dC, h->C.data(), (max_sym + 2) * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dq1, h->q1.data(), max_sym + 1, hipMemcpyHostToDevice));
+
+    if (keep_host) {
+        h->wm.resize((uint64_t)L * nblk * FMI_BLOCK_WORDS);
+        HIPCHK(hipMemcpy(h->wm.data(), wm, h->wm.size() * 8, hipMemcpyDeviceToHost));
+        h->sa_lo.resize(n);
+        HIPCHK(hipMemcpy(h->sa_lo.data(), sa, n * 4, hipMemcpyDeviceToHost));
+        h->sa_hi.clear();
+        h->text.resize(n * sizeof(SymT));
+        HIPCHK(hipMemcpy(h->text.data(), text, n * sizeof(SymT), hipMemcpyDeviceToHost));
+        uint32_t *wide = nullptr;
+        HIPCHK(pool.alloc(&wide, n));
+        hipLaunchKernelGGL((k_widen<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, bwt, n, wide);
+        h->bwt.resize(n);
+        HIPCHK(hipMemcpy(h->bwt.data(), wide, n * 4, hipMemcpyDeviceToHost));
+        pool.release(wide);
+        h->host_resident = true;
+    } else {
+        h->wm.clear(); h->sa_lo.clear(); h->sa_hi.clear(); h->text.clear(); h->bwt.clear();
+        h->host_resident = false;
+    }
+
+    // hand the resident arrays over to the index
+    d.C = dC; d.leaf = dleaf; d.q1 = dq1; d.sa_lo = sa; d.sa_hi = nullptr; d.text = text;
+    d.doc_begin = nullptr; d.n_begin = 0;
+    for (void *p : {(void *)wm, (void *)dC, (void *)dleaf, (void *)dq1, (void *)sa, (void *)text}) {
+        pool.keep(p);
+        h->dev_allocs.push_back(p);
+    }
+    h->dev_bytes = (uint64_t)L * nblk * 64 + (max_sym + 2) * 8 + (max_sym + 1) * 9 + n * 4 + n * sizeof(SymT);
+    h->device = device;
+    h->dev = d;
+    if (!h->doc_begin.empty()) {
+        std::vector<uint64_t> b = h->doc_begin;
+        return fmi_set_doc_beginnings(h, b.data(), b.size());
+    }
+    return FMI_OK;
+}
+
+}  // namespace
 
 extern "C" int fmi_build_device(fmi_t *h, const uint32_t *d_data, uint64_t n_data, int device, int keep_host)
 {
-    (void)h; (void)d_data; (void)n_data; (void)device; (void)keep_host;
-    fmi_set_error("fmi_build_device: not available in this build");
-    return FMI_ERR_UNSUPPORTED;
+    if (!h || (!d_data && n_data)) { fmi_set_error("fmi_build_device: null argument"); return FMI_ERR_ARG; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= device || device < 0) {
+        fmi_set_error("no HIP device %d visible", device);
+        return FMI_ERR_NO_DEVICE;
+    }
+    if (n_data + 1 >= (1ull << 32)) {
+        fmi_set_error("fmi_build_device: %llu symbols; this build indexes up to 2^32-2 on the GPU", (unsigned long long)n_data);
+        return FMI_ERR_UNSUPPORTED;
+    }
+    fmi_release_device(h);
+    HIPCHK(hipSetDevice(device));
+    // alphabet
+    uint32_t *d_max = nullptr;
+    size_t rb = 0;
+    uint32_t max_sym32 = 0;
+    if (n_data) {
+        HIPCHK(hipMalloc((void **)&d_max, 4));
+        HIPCHK(rocprim::reduce(nullptr, rb, d_data, d_max, (uint32_t)0, n_data, rocprim::maximum<uint32_t>(), 0));
+        void *rt = nullptr;
+        HIPCHK(hipMalloc(&rt, rb + 256));
+        HIPCHK(rocprim::reduce(rt, rb, d_data, d_max, (uint32_t)0, n_data, rocprim::maximum<uint32_t>(), 0));
+        HIPCHK(hipMemcpy(&max_sym32, d_max, 4, hipMemcpyDeviceToHost));
+        (void)hipFree(rt); (void)hipFree(d_max);
+    }
+    uint32_t L = 0;
+    while (((uint64_t)max_sym32 >> L) > 0) L++;
+    if (L == 0) L = 1;
+    if (L > FMI_MAX_LEVELS) { fmi_set_error("alphabet needs %u bits per symbol; this build supports <= %u", L, FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
+    // (a 0 inside the data would collide with the sentinel; the caller owns that contract, as with sdsl)
+    if (max_sym32 < 65536) return build_impl<uint16_t>(h, d_data, n_data, device, keep_host, max_sym32, L);
+    return build_impl<uint32_t>(h, d_data, n_data, device, keep_host, max_sym32, L);
 }

@@ -146,10 +146,16 @@ void fmi_host_suffix_array(const uint32_t *text, uint64_t n, uint32_t bits, std:
 void fmi_host_q1_table(const uint32_t *bwt, uint64_t n, uint32_t L, uint64_t max_sym,
                        const std::vector<uint64_t> &C, std::vector<uint8_t> &q1)
 {
-    q1.assign(max_sym + 1, 0);
     std::vector<uint64_t> first_pos(max_sym + 1, UINT64_MAX);
     for (uint64_t i = 0; i < n; i++)
         if (first_pos[bwt[i]] == UINT64_MAX) first_pos[bwt[i]] = i;
+    fmi_host_q1_from_first_pos(first_pos, L, max_sym, C, q1);
+}
+
+void fmi_host_q1_from_first_pos(const std::vector<uint64_t> &first_pos, uint32_t L, uint64_t max_sym,
+                                const std::vector<uint64_t> &C, std::vector<uint8_t> &q1)
+{
+    q1.assign(max_sym + 1, 0);
     std::vector<uint32_t> present;
     for (uint64_t c = 0; c <= max_sym; c++)
         if (C[c + 1] > C[c]) present.push_back((uint32_t)c);

@@ -66,5 +66,7 @@ void fmi_host_suffix_array(const uint32_t *text, uint64_t n, uint32_t bits_per_s
 void fmi_host_finish_from_bwt(fmi *h, const uint32_t *bwt, uint64_t n);
 void fmi_host_q1_table(const uint32_t *bwt, uint64_t n, uint32_t levels, uint64_t max_sym,
                        const std::vector<uint64_t> &C, std::vector<uint8_t> &q1);
+void fmi_host_q1_from_first_pos(const std::vector<uint64_t> &first_pos, uint32_t levels, uint64_t max_sym,
+                                const std::vector<uint64_t> &C, std::vector<uint8_t> &q1);
 int fmi_upload(fmi *h, int device);
 void fmi_release_device(fmi *h);

@@ -61,6 +61,22 @@ class FMIndex(_FMIndex):
         _FMIndex.initialize(self, data)
         self._after_build()
 
+    def initialize_from_device(self, data, beginnings, occurring=None, keep_host: bool = False) -> None:
+        """Build on the GPU (``fmi_build_device``) from symbols that are ALREADY in
+        index order: per-document reversed and +SHIFT, concatenated (what
+        reference index.py:50-53 produces), as a uint32/int32 torch tensor on the
+        target GPU.  ``beginnings`` = cumulative document lengths (len n_docs+1).
+        For corpora the host builder cannot reach (NQ scale)."""
+        import torch
+        assert data.is_cuda and data.dtype in (torch.int32, torch.uint32) and data.is_contiguous()
+        self.beginnings = [int(x) for x in beginnings]
+        if occurring is None:
+            occurring = (torch.unique(data.to(torch.int64)) - SHIFT).tolist()
+        self.occurring = list(occurring)
+        torch.cuda.synchronize(data.device)
+        check(lib().fmi_build_device(self._h, data.data_ptr(), data.numel(), data.device.index or 0, int(keep_host)))
+        self._after_build()
+
     def _after_build(self) -> None:
         self._push_beginnings()
         self.occurring_distinct, self.occurring_counts = self.get_distinct_count(0, len(self))

@@ -163,3 +163,40 @@ def test_logits_processor_matches_reference_semantics(pair):
         allowed = oracle_logits_mask(orc, rows, V, beams, pad_token_id=1, eos_token_id=2, **kw)
         want = torch.where(torch.from_numpy(allowed).to(dev), scores, torch.full_like(scores, float("-inf")))
         assert torch.equal(out, want), (cur_len, kw)
+
+
+@pytest.mark.parametrize("seed,n_docs,vocab", [(0, 30, 6), (1, 400, 300), (2, 3000, 50265), (3, 500, 70000)])
+def test_gpu_builder_is_byte_identical_to_host_builder(seed, n_docs, vocab):
+    import ctypes
+    import torch
+    from seal_amd import FMIndex
+    from seal_amd._lib import lib
+    docs = _docs(seed, n_docs, vocab, zipf=1.2 if vocab > 1000 else None)
+    if seed == 1:
+        docs = docs + docs[:50] + [docs[0] * 3]        # long repeats: several doubling rounds
+    a = FMIndex()
+    a.initialize(docs)
+    data = np.concatenate([np.asarray(d[::-1], dtype=np.int64) + 10 for d in docs]).astype(np.int32)
+    b = FMIndex()
+    b.initialize_from_device(torch.from_numpy(data).cuda(), a.beginnings, keep_host=True)
+
+    def arr(ix, name):
+        n, e = ctypes.c_uint64(), ctypes.c_uint32()
+        p = lib().fmi_host_array(ix.handle, name.encode(), ctypes.byref(n), ctypes.byref(e))
+        assert p, name
+        buf = (ctypes.c_uint8 * (n.value * e.value)).from_address(p)
+        return bytes(buf)
+
+    for name in ("sa", "bwt", "text", "C", "leaf", "q1", "zeros", "wm"):
+        assert arr(a, name) == arr(b, name), name
+    assert b.size() == a.size() and b.occurring_distinct == a.occurring_distinct and b.occurring_counts == a.occurring_counts
+    assert sorted(b.occurring) == sorted(a.occurring)
+    seqs = [d[:3] for d in docs[:50]]
+    la, ha = a.get_range_batch(seqs)
+    lb, hb = b.get_range_batch(seqs)
+    assert np.array_equal(la, lb) and np.array_equal(ha, hb)
+    assert b.get_doc(3) == docs[3]
+    rows = np.arange(0, a.size(), max(1, a.size() // 97), dtype=np.uint64)
+    pa, da = a.locate_batch(rows)
+    pb, db = b.locate_batch(rows)
+    assert np.array_equal(pa, pb) and np.array_equal(da, db)
