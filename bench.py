@@ -1,0 +1,369 @@
+#!/usr/bin/env python
+"""bench.py -- queries/sec of the SEAL search hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic queries:
+``SEALSearcher.batch_search`` (body decode 10 tokens + title decode <= 15 tokens,
+beam 15, FM-index constrained; count post-filters; rescoring; unigram scores;
+first-stage retrieval = counts + locate + doc binning + evidence aggregation) on
+an NQ-shaped synthetic FM-index with a random-init BART-large (fp32, as the
+reference runs it).  Not in the step: full-document trie rescoring
+(keys.py:366-497, SURVEY.md 8f-1 "next") and query-string n-gram keys (needs
+spaCy + the BART tokenizer, absent offline) -- both stated in `config`.
+
+Contract: python bench.py --gpus N --steps K --warmup W ; for N > 1 launched by
+torch.distributed.run, one rank per GPU; prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SHIFT = 10
+TITLE_EOS, CODE_EOS, VOCAB = 49314, 45056, 50265
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------
+# synthetic NQ-shaped corpus, generated on the GPU directly in
+# index order: per document reversed (+SHIFT), i.e. [</s>, body..., '@@', title...]
+# ---------------------------------------------------------------------------
+def synth_corpus(n_docs: int, device, seed: int = 0):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    lens = torch.normal(137.0, 25.0, (n_docs,), generator=g, device=device).round().clamp(40, 256).long()
+    title_len = torch.randint(2, 9, (n_docs,), generator=g, device=device)
+    beg = torch.zeros(n_docs + 1, dtype=torch.long, device=device)
+    torch.cumsum(lens, 0, out=beg[1:])
+    N = int(beg[-1])
+    usable = torch.arange(4, VOCAB, device=device)
+    usable = usable[(usable != TITLE_EOS) & (usable != CODE_EOS)]
+    ids_by_rank = usable[torch.randperm(usable.numel(), generator=g, device=device)]
+    w = 1.0 / torch.arange(1, usable.numel() + 1, device=device, dtype=torch.float64) ** 1.07
+    cdf = torch.cumsum(w, 0) / w.sum()
+    data = torch.empty(N, dtype=torch.int32, device=device)
+    CH = 1 << 27
+    for a in range(0, N, CH):
+        b = min(N, a + CH)
+        u = torch.rand(b - a, generator=g, device=device, dtype=torch.float64)
+        r = torch.searchsorted(cdf, u).clamp_(max=usable.numel() - 1)
+        data[a:b] = (ids_by_rank[r] + SHIFT).to(torch.int32)
+        del u, r
+    data[beg[:-1]] = 2 + SHIFT
+    data[beg[1:] - 1 - title_len] = TITLE_EOS + SHIFT
+    return data, beg, title_len, ids_by_rank
+
+
+def synth_queries(n, data, beg, title_len, ids_by_rank, device, seed: int = 1):
+    """encoder token ids [<s>, 8..24 tokens, </s>] + per-query logit bias (+8) on the tokens of a
+    corpus 10-gram and of the same document's title, so that a random-init model walks real corpus
+    paths with NQ-like interval sizes."""
+    rng = np.random.default_rng(seed)
+    n_docs = beg.numel() - 1
+    queries, bias = [], torch.zeros(n, VOCAB, device=device)
+    V2 = ids_by_rank.numel()
+    for q in range(n):
+        m = int(rng.integers(8, 25))
+        ranks = np.minimum(rng.zipf(1.3, size=m), V2) - 1
+        queries.append([0] + ids_by_rank[torch.as_tensor(ranks, device=device)].tolist() + [2])
+        d = int(rng.integers(0, n_docs))
+        b, e, tl = int(beg[d]), int(beg[d + 1]), int(title_len[d])
+        rev = (data[b:e].long() - SHIFT)
+        fwd = torch.flip(rev, [0])                       # title..., '@@', body..., </s>
+        body0 = tl + 1
+        s = int(rng.integers(body0, max(body0 + 1, (e - b) - 11)))
+        toks = torch.cat([fwd[s:s + 10], fwd[:tl]])
+        bias[q, toks] = 8.0
+    return queries, bias
+
+
+class _CudaArray:
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def device_array(index, name, typestr):
+    import ctypes
+    from seal_amd._lib import lib
+    n, e = ctypes.c_uint64(), ctypes.c_uint32()
+    p = lib().fmi_dev_array(index.handle, name.encode(), ctypes.byref(n), ctypes.byref(e))
+    if not p:
+        return None
+    return torch.as_tensor(_CudaArray(p, n.value, typestr), device=torch.device("cuda", torch.cuda.current_device()))
+
+
+# ---------------------------------------------------------------------------
+# CPU baseline: the oracle (oracle/, a restatement of the sdsl path), replaying the
+# FM-index operations of one batch with the reference's call pattern.
+# ---------------------------------------------------------------------------
+def build_cpu_oracle(index, threads):
+    from oracle.seal_oracle import CppFMIndex, lib as orc_lib
+    orc_lib().orc_set_threads(threads)
+    n = index.size()
+    sa = device_array(index, "sa_lo", "<i4")
+    assert device_array(index, "sa_hi", "|u1") is None
+    text = device_array(index, "text", "<i2" if index_sym_bytes(index) == 2 else "<i4")
+    bwt = np.empty(n, dtype=np.uint32)
+    isa_s = torch.zeros(n // 64 + 1, dtype=torch.int64, device=sa.device)
+    CH = 1 << 27
+    for a in range(0, n, CH):
+        b = min(n, a + CH)
+        pos = sa[a:b].long() & 0xFFFFFFFF
+        prev = torch.where(pos == 0, torch.full_like(pos, n - 1), pos - 1)
+        sym = text[prev].to(torch.int32) & (0xFFFF if text.dtype == torch.int16 else 0x7FFFFFFF)
+        bwt[a:b] = sym.cpu().numpy().astype(np.uint32)
+        m = (pos & 63) == 0
+        isa_s[pos[m] >> 6] = torch.arange(a, b, device=sa.device)[m]
+        del pos, prev, sym, m
+    sa_s = (sa[::32].long() & 0xFFFFFFFF).cpu().numpy().astype(np.uint64)
+    orc = CppFMIndex()
+    orc.initialize_from_bwt(bwt, sa_s, isa_s.cpu().numpy().astype(np.uint64))
+    return orc
+
+
+def index_sym_bytes(index):
+    from seal_amd._lib import lib
+    return 2 if lib().fmi_max_symbol(index.handle) < 65536 else 4
+
+
+def replay_on_cpu(orc, trace, beginnings, threads, pad=1):
+    """reference call pattern: per decode step and row, get_range(prefix) and
+    get_count(prefix[:-1]) from scratch (beam_search.py:96-101), one task per row for
+    distinct_count_multi (fm_index.cpp:117-121); get_count per key; locate + bisect per row."""
+    t_mask = t_rng = t_loc = 0.0
+    n_rows = n_seq = n_loc = 0
+    b = np.asarray(beginnings, dtype=np.uint64)
+    for op in trace:
+        if op[0] == "mask":
+            ids, ff = op[1].tolist(), op[2]
+            eos = TITLE_EOS if ff else 2
+            seqs, live = [], []
+            for r, sent in enumerate(ids):
+                if sent[-1] in (eos, pad):
+                    continue
+                live.append(r)
+                seqs.append(ff + sent[1:])
+                seqs.append(ff + sent[1:-1])
+            t0 = time.perf_counter()
+            lo, hi = orc.get_range_batch(seqs, threads=threads)
+            orc.distinct_count_sizes(lo[0::2], np.maximum(lo[0::2], np.minimum(hi[0::2], orc.size())), threads=threads)
+            t_mask += time.perf_counter() - t0
+            n_rows += len(live)
+        elif op[0] == "ranges":
+            t0 = time.perf_counter()
+            orc.get_range_batch(op[1], threads=threads)
+            t_rng += time.perf_counter() - t0
+            n_seq += len(op[1])
+        elif op[0] == "locate":
+            lo, hi, mx = op[1], op[2], op[3]
+            rows = np.concatenate([np.arange(a, min(c, a + mx), dtype=np.uint64) for a, c in zip(lo, hi) if c > a] or [np.zeros(0, np.uint64)])
+            t0 = time.perf_counter()
+            orc.locate_bin_batch(rows, b, threads=threads)
+            t_loc += time.perf_counter() - t0
+            n_loc += len(rows)
+    return dict(mask_s=t_mask, ranges_s=t_rng, locate_s=t_loc, rows=n_rows, sequences=n_seq, located=n_loc)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--docs", type=int, default=int(os.environ.get("SEAL_BENCH_DOCS", 21015324)))
+    ap.add_argument("--batch", type=int, default=20)
+    ap.add_argument("--beam", type=int, default=15)
+    ap.add_argument("--topk", type=int, default=100)
+    ap.add_argument("--cpu-threads", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+    from seal_amd import FMIndex
+    from seal_amd._lib import check, lib
+    from seal_amd.retrieval import SEALSearcher
+    from seal_amd import retrieval, keys as rk
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+
+    t0 = time.perf_counter()
+    data, beg, title_len, ids_by_rank = synth_corpus(args.docs, dev, seed=0)
+    torch.cuda.synchronize()
+    log(f"corpus: {args.docs} docs, {data.numel()} symbols in {time.perf_counter() - t0:.1f}s")
+    n_batches = args.warmup + args.steps + 1
+    queries, bias = synth_queries(n_batches * args.batch, data, beg, title_len, ids_by_rank, dev, seed=1 + rank)
+    t0 = time.perf_counter()
+    index = FMIndex()
+    index.initialize_from_device(data, beg.tolist(), occurring=(torch.unique(data.long()) - SHIFT).tolist())
+    index.labels = None
+    del data
+    torch.cuda.empty_cache()
+    log(f"index: n={index.size()} levels={lib().fmi_levels(index.handle)} HBM={index.device_bytes() / 2**30:.1f} GiB "
+        f"built on GPU in {time.perf_counter() - t0:.1f}s")
+
+    from transformers import BartConfig, BartForConditionalGeneration
+    t0 = time.perf_counter()
+    torch.manual_seed(0)
+    cfg = BartConfig()
+    cfg.forced_bos_token_id = None
+    with torch.device(dev):
+        model = BartForConditionalGeneration(cfg)
+    model.eval()
+    with torch.no_grad():
+        for tok in (cfg.pad_token_id, cfg.bos_token_id, VOCAB - 1):      # reference retrieval.py:584-588
+            model.final_logits_bias[0, tok] = float("-inf")
+    log(f"BART-large random init (fp32) in {time.perf_counter() - t0:.1f}s")
+
+    searcher = SEALSearcher(index, None, model, add_query_to_keys=False, detokenize=False, first_stage_only=True,
+                            beam=args.beam, batch_size=args.batch)
+    from seal_amd.bart_decoder import BartStepDecoder
+    model._seal_step_decoder = BartStepDecoder(model)
+    check(lib().fmi_dev_enable_probe_count(index.handle, 1))
+    check(lib().fmi_dev_enable_timing(index.handle, 1))
+
+    def run_batch(i):
+        q = queries[i * args.batch:(i + 1) * args.batch]
+        model._seal_step_decoder.logit_bias = bias[i * args.batch:(i + 1) * args.batch]
+        res = searcher.batch_search(q, k=args.topk)
+        top = torch.full((args.batch, args.topk, 2), -1.0, dtype=torch.float64)
+        for qi, docs in enumerate(res):
+            for j, d in enumerate(docs):
+                top[qi, j, 0], top[qi, j, 1] = d.idx, d.score
+        if world > 1:   # the path's only exchange: top-k (doc id, score) to every rank
+            top = top.to(dev)
+            out = torch.empty(world * args.batch, args.topk, 2, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(out, top)
+            top = out
+        return top, res
+
+    for i in range(args.warmup):
+        run_batch(i)
+    import ctypes
+    probes = ctypes.c_uint64()
+    launches, kms = ctypes.c_uint64(), ctypes.c_double()
+    check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(probes)))
+    check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(launches), ctypes.byref(kms)))
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    step_ms = []
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        t1 = time.perf_counter()
+        top, res = run_batch(args.warmup + i)
+        step_ms.append((time.perf_counter() - t1) * 1e3)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(probes)))
+    check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(launches), ctypes.byref(kms)))
+    n_found = float(np.mean([len(r) for r in res]))
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- per-phase profile of one extra batch (untimed), also records the index ops for the CPU replay ----
+    phases = {}
+
+    def timed(name, fn):
+        def wrap(*a, **kw):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            out = fn(*a, **kw)
+            torch.cuda.synchronize()
+            phases[name] = phases.get(name, 0.0) + (time.perf_counter() - t) * 1e3
+            return out
+        return wrap
+    orig = (retrieval.fm_index_generate, rk.rescore_keys, rk.compute_unigram_scores, rk.aggregate_evidence, retrieval._count_filter)
+    retrieval.fm_index_generate = timed("decode_ms", orig[0])
+    rk.rescore_keys = timed("rescore_ms", orig[1])
+    rk.compute_unigram_scores = timed("unigram_ms", orig[2])
+    rk.aggregate_evidence = timed("aggregate_ms", orig[3])
+    retrieval._count_filter = timed("count_filter_ms", orig[4])
+    index._trace = []
+    run_batch(args.warmup + args.steps)
+    trace, index._trace = index._trace, None
+    retrieval.fm_index_generate, rk.rescore_keys, rk.compute_unigram_scores, rk.aggregate_evidence, retrieval._count_filter = orig
+    p2, l2, k2 = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
+    check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(p2)))
+    check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(l2), ctypes.byref(k2)))
+
+    alg_bytes = probes.value * 64.0
+    achieved = alg_bytes / (kms.value * 1e-3) / 1e9 if kms.value > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_expand<EMIT_BITS>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                "launches": int(launches.value), "avg_launch_us": round(kms.value * 1e3 / max(1, launches.value), 2),
+                "algorithmic_bytes_per_launch": round(alg_bytes / max(1, launches.value), 1)}
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+        t0 = time.perf_counter()
+        orc = build_cpu_oracle(index, threads)
+        log(f"cpu oracle index (sdsl-style wt_int + rank_support_v, SA/32, ISA/64) built in {time.perf_counter() - t0:.1f}s with {threads} threads")
+        rep = replay_on_cpu(orc, trace, index.beginnings, threads)
+        t_cpu = rep["mask_s"] + rep["ranges_s"] + rep["locate_s"]
+        cpu = {"value": round(args.batch / t_cpu, 3), "unit": "queries/s (FM-index path only)", "cores": threads, "kind": "port",
+               "sample": f"FM-index operations of 1 batch of {args.batch} queries (decode-step get_range/get_count from scratch + "
+                         f"distinct_count_multi for {rep['rows']} rows, get_count for {rep['sequences']} keys, locate+bisect for "
+                         f"{rep['located']} rows) replayed on the oracle with the reference's call pattern; the model forward is not "
+                         f"part of the CPU figure",
+               "seconds": {k: round(v, 3) for k, v in rep.items() if k.endswith("_s")}}
+
+    total_q = args.batch * args.steps * world
+    out = {
+        "metric": "queries/sec, NQ-shaped FM-index, BART-large beam=15 batch=20 (p50 batch latency in extra)",
+        "value": round(total_q / elapsed, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed * 1e3 / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64 rank/select (index path); fp32 BART (model path)", "data": "synthetic",
+        "config": {"workload": f"configs[1]: NQ-shaped synthetic FM-index ({args.docs} passages, {index.size()} symbols), random-init "
+                               f"BART-large fp32, beam={args.beam}, batch={args.batch} per GPU, body len 10 + title len<=15, "
+                               f"first-stage retrieval top-{args.topk}",
+                   "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated",
+                   "not_in_step": ["full-document trie rescoring (keys.py:366-497, next)", "query-string n-gram keys (spaCy/tokenizer absent)"]},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "extra": {"p50_batch_ms": round(float(np.median(step_ms)), 2), "docs_returned_per_query": n_found,
+                  "phase_ms_one_batch": {k: round(v, 2) for k, v in phases.items()},
+                  "k_expand_ms_one_batch": round(k2.value, 3), "k_expand_probes_one_batch": int(p2.value)},
+    }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -187,6 +187,16 @@ int fmi_dev_get_docs(fmi_t *h, void *stream, uint64_t n_docs, const uint64_t *d_
 int fmi_dev_enable_probe_count(fmi_t *h, int enable);
 int fmi_dev_read_probe_count(fmi_t *h, uint64_t *probes_out);
 
+/* HIP-event timing of the expansion kernel (k_expand): when enabled, every launch
+ * is bracketed by two events recorded on the launch stream.  read = synchronise,
+ * sum the elapsed times since the last read, reset.  For bench.py's roofline. */
+int fmi_dev_enable_timing(fmi_t *h, int enable);
+int fmi_dev_read_timing(fmi_t *h, uint64_t *launches_out, double *total_ms_out);
+
+/* Device pointer of a resident array, for zero-copy hand-over (e.g. to build the
+ * CPU baseline's samples).  name in {"sa_lo","sa_hi","text","wm","C","leaf","q1","doc_begin"}. */
+const void *fmi_dev_array(const fmi_t *h, const char *name, uint64_t *n_out, uint32_t *elem_out);
+
 #ifdef __cplusplus
 }
 #endif

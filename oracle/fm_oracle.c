@@ -80,18 +80,20 @@ static void build_rank_support(orc_t *o)
     uint64_t nblocks = (o->tree_bits >> 9) + 2;
     o->bb = (uint64_t *)calloc(nblocks * 2, 8);
     uint64_t nwords = (o->tree_bits + 63) / 64;
-    uint64_t abs_cnt = 0;
-    for (uint64_t b = 0; b < nblocks; b++) {
-        o->bb[2 * b] = abs_cnt;
+    /* per-superblock relative counts in parallel, absolute counts by one serial sweep */
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)nblocks; b++) {
         uint64_t rel = 0, packed = 0;
         for (int w = 0; w < 8; w++) {
-            uint64_t wi = b * 8 + w;
+            uint64_t wi = (uint64_t)b * 8 + w;
             if (w > 0) packed |= rel << (63 - 9 * w);
             if (wi < nwords) rel += (uint64_t)__builtin_popcountll(o->tree[wi]);
         }
         o->bb[2 * b + 1] = packed;
-        abs_cnt += rel;
+        o->bb[2 * b] = rel;             /* block total for now */
     }
+    uint64_t abs_cnt = 0;
+    for (uint64_t b = 0; b < nblocks; b++) { uint64_t t = o->bb[2 * b]; o->bb[2 * b] = abs_cnt; abs_cnt += t; }
 }
 
 /* ---- wt_int (sdsl wt_int.hpp, restated) ---------------------------------- */
@@ -239,19 +241,45 @@ static int suffix_cmp(const void *a, const void *b)
     return t[i] < t[j] ? -1 : 1;
 }
 
+static int orc_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 static void finish_build(orc_t *o, const uint32_t *bwt)
 {
     uint64_t n = o->n;
     uint64_t max_sym = 0;
-    for (uint64_t i = 0; i < n; i++) if (bwt[i] > max_sym) max_sym = bwt[i];
+#pragma omp parallel for reduction(max : max_sym) schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++) if (bwt[i] > max_sym) max_sym = bwt[i];
     o->max_sym = max_sym;
     uint32_t L = 0;
     while ((max_sym >> L) > 0) L++;
     if (L == 0) L = 1;
     o->max_level = L;
+    const int T = orc_threads();
     /* alphabet */
     uint64_t *occ = (uint64_t *)calloc(max_sym + 2, 8);
-    for (uint64_t i = 0; i < n; i++) occ[bwt[i]]++;
+    {
+        uint64_t *part = (uint64_t *)calloc((size_t)T * (max_sym + 1), 8);
+#pragma omp parallel num_threads(T)
+        {
+#ifdef _OPENMP
+            int t = omp_get_thread_num();
+#else
+            int t = 0;
+#endif
+            uint64_t *h = part + (size_t)t * (max_sym + 1);
+            uint64_t a = n * (uint64_t)t / T, b = n * (uint64_t)(t + 1) / T;
+            for (uint64_t i = a; i < b; i++) h[bwt[i]]++;
+        }
+        for (int t = 0; t < T; t++) for (uint64_t c = 0; c <= max_sym; c++) occ[c] += part[(size_t)t * (max_sym + 1) + c];
+        free(part);
+    }
     o->present = (uint8_t *)calloc(max_sym + 1, 1);
     o->char2comp = (uint64_t *)calloc(max_sym + 1, 8);
     uint64_t sigma = 0;
@@ -264,27 +292,70 @@ static void finish_build(orc_t *o, const uint32_t *bwt)
     o->C[sigma] = acc;
     free(occ);
     /* wt_int bit tree: level k holds, for the sequence stably sorted by its top-k
-       bits (nodes contiguous in prefix order), bit (L-1-k) of every element */
+       bits (nodes contiguous in prefix order), bit (L-1-k) of every element.
+       Per level: threads own contiguous chunks; bits are flushed a word at a time
+       (atomically: chunk and level boundaries share words), then a parallel stable
+       counting sort by the top (k+1) bits produces the next level's order. */
     o->tree_bits = n * L;
     o->tree = (uint64_t *)calloc(o->tree_bits / 64 + 3, 8);
     uint32_t *cur = (uint32_t *)malloc(n * 4), *nxt = (uint32_t *)malloc(n * 4);
     memcpy(cur, bwt, n * 4);
+    uint64_t *hist = (uint64_t *)malloc(((size_t)T << L) * 8);
     for (uint32_t k = 0; k < L; k++) {
-        uint32_t sh = L - 1 - k;
-        for (uint64_t i = 0; i < n; i++)
-            if ((cur[i] >> sh) & 1) { uint64_t p = (uint64_t)k * n + i; o->tree[p >> 6] |= 1ULL << (p & 63); }
-        if (k + 1 == L) break;
-        /* stable counting sort by the top (k+1) bits */
-        uint64_t nb = 1ULL << (k + 1);
-        uint64_t *cnt = (uint64_t *)calloc(nb + 1, 8);
-        for (uint64_t i = 0; i < n; i++) cnt[(cur[i] >> sh) + 1]++;
-        for (uint64_t b = 0; b < nb; b++) cnt[b + 1] += cnt[b];
-        for (uint64_t i = 0; i < n; i++) nxt[cnt[cur[i] >> sh]++] = cur[i];
-        free(cnt);
-        uint32_t *t = cur; cur = nxt; nxt = t;
+        const uint32_t sh = L - 1 - k;
+        const uint64_t nb = 1ULL << (k + 1);
+        const int last = (k + 1 == L);
+        if (!last) memset(hist, 0, (size_t)T * nb * 8);
+#pragma omp parallel num_threads(T)
+        {
+#ifdef _OPENMP
+            int t = omp_get_thread_num();
+#else
+            int t = 0;
+#endif
+            uint64_t a = n * (uint64_t)t / T, b = n * (uint64_t)(t + 1) / T;
+            uint64_t *h = hist + (size_t)t * nb;
+            uint64_t word = 0, widx = ((uint64_t)k * n + a) >> 6;
+            for (uint64_t i = a; i < b; i++) {
+                uint64_t p = (uint64_t)k * n + i;
+                if ((p >> 6) != widx) {
+                    if (word) __atomic_fetch_or(&o->tree[widx], word, __ATOMIC_RELAXED);
+                    word = 0; widx = p >> 6;
+                }
+                uint32_t v = cur[i];
+                word |= (uint64_t)((v >> sh) & 1) << (p & 63);
+                if (!last) h[v >> sh]++;
+            }
+            if (word) __atomic_fetch_or(&o->tree[widx], word, __ATOMIC_RELAXED);
+        }
+        if (last) break;
+        uint64_t run = 0;
+        for (uint64_t bkt = 0; bkt < nb; bkt++)
+            for (int t = 0; t < T; t++) { uint64_t c = hist[(size_t)t * nb + bkt]; hist[(size_t)t * nb + bkt] = run; run += c; }
+#pragma omp parallel num_threads(T)
+        {
+#ifdef _OPENMP
+            int t = omp_get_thread_num();
+#else
+            int t = 0;
+#endif
+            uint64_t a = n * (uint64_t)t / T, b = n * (uint64_t)(t + 1) / T;
+            uint64_t *h = hist + (size_t)t * nb;
+            for (uint64_t i = a; i < b; i++) nxt[h[cur[i] >> sh]++] = cur[i];
+        }
+        uint32_t *tt = cur; cur = nxt; nxt = tt;
     }
-    free(cur); free(nxt);
+    free(hist); free(cur); free(nxt);
     build_rank_support(o);
+}
+
+void orc_set_threads(int t)
+{
+#ifdef _OPENMP
+    if (t > 0) omp_set_num_threads(t);
+#else
+    (void)t;
+#endif
 }
 
 /* ref cpp:33-41 FMIndex::initialize -> construct_im(index, data, 0): sdsl appends

@@ -52,6 +52,7 @@ def lib():
         L.orc_build_from_bwt.restype = ctypes.c_void_p
         L.orc_build_from_bwt.argtypes = [ctypes.POINTER(ctypes.c_uint32), _u64, _p64, _p64]
         L.orc_free.argtypes = [ctypes.c_void_p]
+        L.orc_set_threads.argtypes = [ctypes.c_int]
         for name in ("orc_size", "orc_sigma"):
             getattr(L, name).restype = _u64
             getattr(L, name).argtypes = [ctypes.c_void_p]

@@ -53,6 +53,9 @@ class BartStepDecoder:
         self.lm_w = model.lm_head.weight
         self.lm_b = model.final_logits_bias
         self.batch = self.beams = self.rows = 0
+        # optional additive bias on the next-token logits, [batch, vocab], shared by the beams of a query
+        # (bench.py shapes a random-init model's preferences towards corpus n-grams with it)
+        self.logit_bias: Optional[torch.Tensor] = None
 
     @torch.no_grad()
     def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
@@ -103,5 +106,7 @@ class BartStepDecoder:
             x = L["ln2"](x + L["co"](c))
             x = L["ln3"](x + L["fc2"](L["act"](L["fc1"](x))))
         self.t += 1
-        logits = F.linear(x, self.lm_w) + self.lm_b
-        return logits.float()
+        logits = (F.linear(x, self.lm_w) + self.lm_b).float()
+        if self.logit_bias is not None:
+            logits = (logits.view(B, K, -1) + self.logit_bias[:, None, :]).view(R, -1)
+        return logits

@@ -78,6 +78,8 @@ class IndexBasedLogitsProcessor:
             raise RuntimeError("IndexBasedLogitsProcessor: scores must live on the GPU that holds the FM-index "
                                "(seal_amd has no CPU path)")
         ids = input_ids.contiguous()
+        if getattr(self.index, "_trace", None) is not None:
+            self.index._trace.append(("mask", ids.clone(), list(self.force_decoding_from or [])))
         if ids.dtype != torch.long:
             ids = ids.long()
         src = scores.contiguous()
@@ -226,7 +228,12 @@ def fm_index_generate(
     from .bart_decoder import BartStepDecoder
 
     forced_bos_token_id = kwargs.pop("forced_bos_token_id", getattr(model.config, "forced_bos_token_id", None))
-    decoder = kwargs.pop("decoder", None) or BartStepDecoder(model)
+    decoder = kwargs.pop("decoder", None)
+    if decoder is None:   # fused projection weights are built once per model
+        decoder = getattr(model, "_seal_step_decoder", None)
+        if decoder is None or decoder.lm_w.device != input_ids.device:
+            decoder = BartStepDecoder(model)
+            model._seal_step_decoder = decoder
     processor = kwargs.pop("constrained_decoding_processor", None)
     if eos_token_id is None:
         eos_token_id = model.config.eos_token_id

@@ -56,6 +56,10 @@ struct fmi {
     uint64_t ws_bytes = 0;
     uint64_t *d_probe_counter = nullptr;
     int probe_count_enabled = 0;
+    // optional event timing of k_expand launches
+    int timing_enabled = 0;
+    std::vector<void *> ev_start, ev_stop;   // hipEvent_t
+    uint64_t ev_used = 0;
 };
 
 void fmi_set_error(const char *fmt, ...);

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "fmi_internal.h"
@@ -461,6 +462,57 @@ extern "C" int fmi_dev_reserve(fmi_t *h, uint64_t max_rows)
     return FMI_OK;
 }
 
+static constexpr size_t MAX_TIMED_LAUNCHES = 8192;
+
+extern "C" int fmi_dev_enable_timing(fmi_t *h, int enable)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (enable && h->ev_start.empty()) {
+        h->ev_start.resize(MAX_TIMED_LAUNCHES); h->ev_stop.resize(MAX_TIMED_LAUNCHES);
+        for (size_t i = 0; i < MAX_TIMED_LAUNCHES; i++) {
+            HIPCHK(hipEventCreate((hipEvent_t *)&h->ev_start[i]));
+            HIPCHK(hipEventCreate((hipEvent_t *)&h->ev_stop[i]));
+        }
+    }
+    h->timing_enabled = enable;
+    h->ev_used = 0;
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_read_timing(fmi_t *h, uint64_t *launches_out, double *total_ms_out)
+{
+    int rc = need_device(h); if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    double total = 0;
+    const uint64_t m = std::min<uint64_t>(h->ev_used, MAX_TIMED_LAUNCHES);
+    for (uint64_t i = 0; i < m; i++) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, (hipEvent_t)h->ev_start[i], (hipEvent_t)h->ev_stop[i]));
+        total += ms;
+    }
+    if (launches_out) *launches_out = m;
+    if (total_ms_out) *total_ms_out = total;
+    h->ev_used = 0;
+    return FMI_OK;
+}
+
+extern "C" const void *fmi_dev_array(const fmi_t *h, const char *name, uint64_t *n_out, uint32_t *elem_out)
+{
+    if (!h || !name || h->device < 0) return nullptr;
+    std::string s(name);
+    auto ret = [&](const void *p, uint64_t n, uint32_t e) { if (n_out) *n_out = n; if (elem_out) *elem_out = e; return p; };
+    const FmiDev &d = h->dev;
+    if (s == "sa_lo") return ret(d.sa_lo, d.n, 4);
+    if (s == "sa_hi") return ret(d.sa_hi, d.sa_hi ? d.n : 0, 1);
+    if (s == "text") return ret(d.text, d.n, d.sym_bytes);
+    if (s == "wm") return ret(d.wm, (uint64_t)d.levels * d.nblk * FMI_BLOCK_WORDS, 8);
+    if (s == "C") return ret(d.C, d.max_sym + 2, 8);
+    if (s == "leaf") return ret(d.leaf, d.max_sym + 1, 8);
+    if (s == "q1") return ret(d.q1, d.max_sym + 1, 1);
+    if (s == "doc_begin") return ret(d.doc_begin, d.n_begin, 8);
+    return nullptr;
+}
+
 static unsigned expand_grid(uint64_t n_items)
 {
     uint64_t g = (n_items + EXP_WAVES - 1) / EXP_WAVES;
@@ -482,8 +534,11 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     hipLaunchKernelGGL(k_prefix_ranges, dim3(blocks_for(rows, 64)), dim3(64), 0, st, h->dev, rows, cur_len, d_ids, shift,
                        pad_id, eos_id, ff, stop_at_count, always_allow_eos, vocab, wpr, d_bits, items);
     EmitTarget tgt{}; tgt.bits = d_bits; tgt.words_per_row = wpr; tgt.shift = shift; tgt.vocab = vocab;
+    const bool timed = h->timing_enabled && h->ev_used < MAX_TIMED_LAUNCHES;
+    if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
     hipLaunchKernelGGL((k_expand<EMIT_BITS>), dim3(expand_grid(rows)), dim3(EXP_WAVES * 64), 0, st, h->dev, items,
                        (const uint32_t *)nullptr, (uint32_t)rows, tgt, h->probe_count_enabled ? h->d_probe_counter : nullptr);
+    if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
     HIPCHK(hipGetLastError());
     return FMI_OK;
 }

@@ -40,6 +40,7 @@ class FMIndex(_FMIndex):
         self.occurring_distinct = []
         self.occurring_counts = []
         self.labels = None
+        self._trace = None      # optional list; bench.py records the index operations of a batch here
 
     # -- construction (reference index.py:39-66) ---------------------------
     def initialize(self, sequences: Iterable[List[int]], in_memory: bool = False) -> None:
@@ -163,6 +164,8 @@ class FMIndex(_FMIndex):
     # -- batched extras (GPU-friendly forms of the calls above) -------------
     def get_range_batch(self, sequences: Sequence[Sequence[int]]):
         """``get_range`` for many sequences in one launch -> (lo[], hi[]) uint64."""
+        if getattr(self, "_trace", None) is not None:
+            self._trace.append(("ranges", [list(s) for s in sequences]))
         n = len(sequences)
         offs = np.zeros(n + 1, dtype=np.uint64)
         if n:
@@ -195,6 +198,8 @@ class FMIndex(_FMIndex):
         import torch
         lo = np.asarray(lows, dtype=np.int64)
         hi = np.asarray(highs, dtype=np.int64)
+        if getattr(self, "_trace", None) is not None:
+            self._trace.append(("locate", lo.copy(), hi.copy(), int(max_per_range)))
         width = np.minimum(np.maximum(hi - lo, 0), int(max_per_range))
         offs = np.zeros(len(lo) + 1, dtype=np.int64)
         np.cumsum(width, out=offs[1:])
