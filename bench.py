@@ -217,7 +217,7 @@ def main():
     queries, bias = synth_queries(n_batches * args.batch, data, beg, title_len, ids_by_rank, dev, seed=1 + rank)
     t0 = time.perf_counter()
     index = FMIndex()
-    index.initialize_from_device(data, beg.tolist(), occurring=(torch.unique(data.long()) - SHIFT).tolist())
+    index.initialize_from_device(data, beg.tolist())
     index.labels = None
     del data
     torch.cuda.empty_cache()
@@ -246,7 +246,7 @@ def main():
 
     def run_batch(i):
         q = queries[i * args.batch:(i + 1) * args.batch]
-        model._seal_step_decoder.logit_bias = bias[i * args.batch:(i + 1) * args.batch]
+        model._seal_step_decoder.logit_bias = searcher.logit_bias = bias[i * args.batch:(i + 1) * args.batch]
         res = searcher.batch_search(q, k=args.topk)
         top = torch.full((args.batch, args.topk, 2), -1.0, dtype=torch.float64)
         for qi, docs in enumerate(res):

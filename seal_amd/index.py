@@ -72,7 +72,10 @@ class FMIndex(_FMIndex):
         assert data.is_cuda and data.dtype in (torch.int32, torch.uint32) and data.is_contiguous()
         self.beginnings = [int(x) for x in beginnings]
         if occurring is None:
-            occurring = (torch.unique(data.to(torch.int64)) - SHIFT).tolist()
+            present = torch.zeros(int(data.max()) + 1, dtype=torch.bool, device=data.device)
+            for a in range(0, data.numel(), 1 << 28):      # chunked: torch.unique refuses > 2^31 elements
+                present[data[a:a + (1 << 28)].long()] = True
+            occurring = (torch.nonzero(present).flatten() - SHIFT).tolist()
         self.occurring = list(occurring)
         torch.cuda.synchronize(data.device)
         check(lib().fmi_build_device(self._h, data.data_ptr(), data.numel(), data.device.index or 0, int(keep_host)))

@@ -60,7 +60,7 @@ def _pad_batch(seqs: Sequence[Sequence[int]], pad: int, device) -> torch.Tensor:
 
 @torch.inference_mode()
 def rescore_keys(model, inputs, list_of_decoded, batch_size=100, length_penalty=0.0, progress_bar=False, prefix=[],
-                 strip_from_bos=[], strip_from_eos=[]):
+                 strip_from_bos=[], strip_from_eos=[], logit_bias=None):
     """Teacher-forced log-probability of every key given its query
     (reference keys.py:64-141): targets with id < 2 contribute 0 (keys.py:132),
     chunks of ``batch_size`` keys, score divided by ``len(key) ** length_penalty``."""
@@ -87,6 +87,8 @@ def rescore_keys(model, inputs, list_of_decoded, batch_size=100, length_penalty=
         dec_ids = _pad_batch(dec_in, cfg.pad_token_id, device)
         logits = model(attention_mask=attention_mask[qidx], encoder_outputs=(enc[qidx],),
                        decoder_input_ids=dec_ids[:, :-1]).logits
+        if logit_bias is not None:      # extension: per-query additive logit bias [n_queries, vocab]
+            logits = logits + logit_bias[qidx][:, None, :]
         logprobs = logits.log_softmax(-1)
         tgt = dec_ids[:, 1:]
         lp = torch.gather(logprobs, -1, tgt.unsqueeze(-1)).squeeze(-1)
@@ -98,7 +100,8 @@ def rescore_keys(model, inputs, list_of_decoded, batch_size=100, length_penalty=
 
 
 @torch.no_grad()
-def compute_unigram_scores(model, inputs, index=None, tokenizer=None, tolist=True, temperature=1.0, prefix=[]):
+def compute_unigram_scores(model, inputs, index=None, tokenizer=None, tolist=True, temperature=1.0, prefix=[],
+                           logit_bias=None):
     """One decoder step -> log-softmax over the vocabulary per query
     (reference keys.py:145-176)."""
     cfg = model.config
@@ -113,6 +116,8 @@ def compute_unigram_scores(model, inputs, index=None, tokenizer=None, tolist=Tru
     for j, tok in enumerate(prefix, start=1):
         dec[:, j] = tok
     logits = model(input_ids=input_ids, attention_mask=attention_mask, decoder_input_ids=dec).logits[:, len(prefix)]
+    if logit_bias is not None:
+        logits = logits + logit_bias
     if temperature != 1.0:
         logits = logits / temperature
     logprobs = logits.log_softmax(-1)

@@ -172,7 +172,7 @@ def _process_batch(searcher, inputs, constrained_generation):
         if s.rescore and s.use_markers:
             found_keys = rk.rescore_keys(
                 s.bart_model, base_tokens, found_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
-                strip_from_eos=[s.title_eos_token_id, s.code_eos_token_id, s.bart_model.config.eos_token_id])
+                strip_from_eos=[s.title_eos_token_id, s.code_eos_token_id, s.bart_model.config.eos_token_id], logit_bias=s.logit_bias)
     else:
         found_keys = [[] for _ in inputs]
 
@@ -210,7 +210,7 @@ def _process_batch(searcher, inputs, constrained_generation):
         if s.rescore and s.use_markers:
             title_keys = rk.rescore_keys(
                 s.bart_title_model, toks, title_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
-                strip_from_eos=[s.bart_model.config.eos_token_id])
+                strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=s.logit_bias)
         for nfk, fk in zip(title_keys, found_keys):
             fk += nfk
 
@@ -228,7 +228,7 @@ def _process_batch(searcher, inputs, constrained_generation):
         _, toks = marked("body")
         unigram = rk.compute_unigram_scores(
             s.bart_scorer_model, toks, s.fm_index,
-            prefix=[s.force_decoding_second_token] if s.force_decoding_second_token >= 0 else [])
+            prefix=[s.force_decoding_second_token] if s.force_decoding_second_token >= 0 else [], logit_bias=s.logit_bias)
         return list(zip(found_keys, unigram))
     return found_keys
 
@@ -299,6 +299,8 @@ class SEALSearcher:
             "marker_token_ids", {"body": [45056, 809], "title": [45056, 1270], "code": [45056, 3260], "+": [45056, 2055]})
         # extension: stop aggregate_evidence after the first stage (keys.py:311-364)
         self.first_stage_only: bool = params.get("first_stage_only", False)
+        # extension (synthetic benchmarks): per-query additive bias on the model's next-token logits, [batch, vocab]
+        self.logit_bias = None
         if "bart" in self.backbone:   # retrieval.py:480-491
             self.title_bos_token, self.title_bos_token_id = "</s>", 2
             self.title_eos_token, self.title_eos_token_id = "@@", 49314
