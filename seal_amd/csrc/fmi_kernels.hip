@@ -129,9 +129,11 @@ __device__ __forceinline__ void wave_sync()
 
 static constexpr int EXP_WAVES = 4;                 // waves per workgroup
 static constexpr int EXP_LVL_CAP = 128;
+static constexpr uint32_t EXP_SPLIT_LEVEL = 6;      // phase 1 stops here and hands sub-trees to phase 2
 // relative level j occupies [lvl_off(j), lvl_off(j)+min(2^j,128))
 __host__ __device__ constexpr int lvl_off(int j) { return j < 7 ? (1 << j) - 1 : 127 + (j - 7) * EXP_LVL_CAP; }
-static constexpr int EXP_SLOTS = 127 + (FMI_MAX_LEVELS - 7) * EXP_LVL_CAP;   // levels 0..L-2 are ever stored
+// LDS slots a wave needs to expand a sub-tree spanning `nlev` stored levels
+__host__ __device__ constexpr int exp_slots(int nlev) { return nlev <= 0 ? 1 : lvl_off(nlev - 1) + ((nlev - 1) < 7 ? (1 << (nlev - 1)) : EXP_LVL_CAP); }
 
 template <int MODE>
 __device__ __forceinline__ void emit_leaf(const EmitTarget &t, uint32_t row, uint32_t sym, uint64_t count)
@@ -145,18 +147,26 @@ __device__ __forceinline__ void emit_leaf(const EmitTarget &t, uint32_t row, uin
     }
 }
 
+// Work items are wavelet-matrix nodes.  Nodes whose children would sit on
+// `stop_level` are not expanded further but appended to `out_items` (phase 1 ->
+// phase 2 hand-over, so that a wide interval is spread over up to 2^stop_level
+// wavefronts instead of one); stop_level >= levels disables the hand-over.
+// Dynamic LDS per wave: 3 x slots words (lo32, hi32, packed high bits + prefix)
+// + FMI_MAX_LEVELS counters.
 template <int MODE>
 __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const ExpandItem *items, const uint32_t *n_items_ptr,
-                                                           uint32_t n_items_static, EmitTarget tgt, uint64_t *probe_counter)
+                                                           uint32_t n_items_static, EmitTarget tgt, uint32_t slots,
+                                                           uint32_t stop_level, ExpandItem *out_items, uint32_t *out_count,
+                                                           uint32_t out_cap, uint64_t *probe_counter)
 {
-    __shared__ uint32_t s_lo[EXP_WAVES][EXP_SLOTS];
-    __shared__ uint32_t s_hi[EXP_WAVES][EXP_SLOTS];
-    __shared__ uint32_t s_mx[EXP_WAVES][EXP_SLOTS];   // lo[39:32] | hi[39:32]<<8 | prefix<<16 (prefix <= 16 bits)
-    __shared__ uint32_t s_cnt[EXP_WAVES][FMI_MAX_LEVELS];
-
+    extern __shared__ uint32_t s_mem[];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t n_items = n_items_ptr ? *n_items_ptr : n_items_static;
+    uint32_t *s_lo = s_mem + (size_t)wv * (3 * slots + FMI_MAX_LEVELS);
+    uint32_t *s_hi = s_lo + slots;
+    uint32_t *s_mx = s_hi + slots;     // lo[39:32] | hi[39:32]<<8 | prefix<<16 (prefix <= 16 bits)
+    uint32_t *s_cnt = s_mx + slots;
+    const uint32_t n_items = n_items_ptr ? min(*n_items_ptr, n_items_static) : n_items_static;
     const uint32_t L = ix.levels;
     uint64_t probes = 0;
     uint64_t *pp = probe_counter ? &probes : nullptr;
@@ -166,33 +176,33 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
         if (it.hi <= it.lo) continue;
         const uint32_t row = it.row;
         const uint32_t root = it.level;
-        // a root sitting on the last level is already a leaf
+        // a root sitting below the last level is already a leaf
         if (root >= L) { if (lane == 0) emit_leaf<MODE>(tgt, row, it.prefix, it.hi - it.lo); continue; }
-        if (lane < FMI_MAX_LEVELS) s_cnt[wv][lane] = 0;
+        if (lane < FMI_MAX_LEVELS) s_cnt[lane] = 0;
         if (lane == 0) {
-            s_lo[wv][0] = (uint32_t)it.lo; s_hi[wv][0] = (uint32_t)it.hi;
+            s_lo[0] = (uint32_t)it.lo; s_hi[0] = (uint32_t)it.hi;
             // positions < 2^40: 8 high bits each
-            s_mx[wv][0] = (uint32_t)(it.lo >> 32) | ((uint32_t)(it.hi >> 32) << 8) | (it.prefix << 16);
-            s_cnt[wv][0] = 1;
+            s_mx[0] = (uint32_t)(it.lo >> 32) | ((uint32_t)(it.hi >> 32) << 8) | (it.prefix << 16);
+            s_cnt[0] = 1;
         }
         wave_sync();
         int deepest = 0;   // relative level of the deepest non-empty array (wave uniform)
         while (deepest >= 0) {
-            const uint32_t cnt = s_cnt[wv][deepest];
+            const uint32_t cnt = s_cnt[deepest];
             if (cnt == 0) { deepest--; continue; }
             const uint32_t m = cnt < 64 ? cnt : 64;
             const uint32_t base = lvl_off(deepest) + (cnt - m);
             const uint32_t k = root + deepest;      // absolute level of the popped nodes
-            bool act = lane < m;
+            const bool act = lane < m;
             uint64_t lo = 0, hi = 0; uint32_t prefix = 0;
             if (act) {
-                const uint32_t mx = s_mx[wv][base + lane];
-                lo = (uint64_t)s_lo[wv][base + lane] | ((uint64_t)(mx & 0xff) << 32);
-                hi = (uint64_t)s_hi[wv][base + lane] | ((uint64_t)((mx >> 8) & 0xff) << 32);
+                const uint32_t mx = s_mx[base + lane];
+                lo = (uint64_t)s_lo[base + lane] | ((uint64_t)(mx & 0xff) << 32);
+                hi = (uint64_t)s_hi[base + lane] | ((uint64_t)((mx >> 8) & 0xff) << 32);
                 prefix = mx >> 16;
             }
             wave_sync();
-            if (lane == 0) s_cnt[wv][deepest] = cnt - m;
+            if (lane == 0) s_cnt[deepest] = cnt - m;
             uint64_t r_lo = 0, r_hi = 0;
             if (act) {
                 r_lo = wm_rank1(ix, k, lo, pp);
@@ -209,24 +219,39 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
                 const uint64_t b0 = __ballot(has0), b1 = __ballot(has1);
                 const uint64_t lt = (1ull << lane) - 1;
                 const uint32_t n0 = (uint32_t)__popcll(b0);
-                const uint32_t dst = lvl_off(deepest + 1) + s_cnt[wv][deepest + 1];
-                if (has0) {
-                    const uint32_t o = dst + (uint32_t)__popcll(b0 & lt);
-                    const uint64_t clo = lo - r_lo, chi = hi - r_hi;
-                    s_lo[wv][o] = (uint32_t)clo; s_hi[wv][o] = (uint32_t)chi;
-                    s_mx[wv][o] = (uint32_t)(clo >> 32) | ((uint32_t)(chi >> 32) << 8) | ((prefix << 1) << 16);
-                }
-                if (has1) {
-                    const uint32_t o = dst + n0 + (uint32_t)__popcll(b1 & lt);
-                    const uint64_t clo = z + r_lo, chi = z + r_hi;
-                    s_lo[wv][o] = (uint32_t)clo; s_hi[wv][o] = (uint32_t)chi;
-                    s_mx[wv][o] = (uint32_t)(clo >> 32) | ((uint32_t)(chi >> 32) << 8) | (((prefix << 1) | 1) << 16);
-                }
-                wave_sync();
                 const uint32_t added = n0 + (uint32_t)__popcll(b1);
-                if (lane == 0) s_cnt[wv][deepest + 1] += added;
-                wave_sync();
-                if (added) deepest++;
+                if (k + 1 == stop_level) {
+                    // hand the children over to phase 2
+                    uint32_t obase = 0;
+                    if (lane == 0 && added) obase = atomicAdd(out_count, added);
+                    obase = __shfl(obase, 0);
+                    if (has0) {
+                        const uint32_t o = obase + (uint32_t)__popcll(b0 & lt);
+                        if (o < out_cap) out_items[o] = ExpandItem{lo - r_lo, hi - r_hi, row, k + 1, prefix << 1, 0};
+                    }
+                    if (has1) {
+                        const uint32_t o = obase + n0 + (uint32_t)__popcll(b1 & lt);
+                        if (o < out_cap) out_items[o] = ExpandItem{z + r_lo, z + r_hi, row, k + 1, (prefix << 1) | 1, 0};
+                    }
+                } else {
+                    const uint32_t dst = lvl_off(deepest + 1) + s_cnt[deepest + 1];
+                    if (has0) {
+                        const uint32_t o = dst + (uint32_t)__popcll(b0 & lt);
+                        const uint64_t clo = lo - r_lo, chi = hi - r_hi;
+                        s_lo[o] = (uint32_t)clo; s_hi[o] = (uint32_t)chi;
+                        s_mx[o] = (uint32_t)(clo >> 32) | ((uint32_t)(chi >> 32) << 8) | ((prefix << 1) << 16);
+                    }
+                    if (has1) {
+                        const uint32_t o = dst + n0 + (uint32_t)__popcll(b1 & lt);
+                        const uint64_t clo = z + r_lo, chi = z + r_hi;
+                        s_lo[o] = (uint32_t)clo; s_hi[o] = (uint32_t)chi;
+                        s_mx[o] = (uint32_t)(clo >> 32) | ((uint32_t)(chi >> 32) << 8) | (((prefix << 1) | 1) << 16);
+                    }
+                    wave_sync();
+                    if (lane == 0) s_cnt[deepest + 1] += added;
+                    wave_sync();
+                    if (added) deepest++;
+                }
             }
         }
         wave_sync();
@@ -451,12 +476,18 @@ extern "C" int fmi_dev_get_range(fmi_t *h, void *stream, uint64_t n_seq, const i
 
 // workspace = expansion items + allowed-token bitmap (vocab <= 2^17 -> 4096 words/row)
 static constexpr uint64_t WS_BITS_WORDS = (1ull << FMI_MAX_LEVELS) / 32;
+static constexpr uint64_t WS_QUEUE_PER_ROW = 1ull << EXP_SPLIT_LEVEL;
+// layout: items[rows] | queue[rows * 64] | bits[rows * WS_BITS_WORDS] | counter
+static inline ExpandItem *ws_items(fmi *h) { return (ExpandItem *)h->ws; }
+static inline ExpandItem *ws_queue(fmi *h) { return ws_items(h) + h->ws_rows; }
+static inline uint32_t *ws_bits(fmi *h) { return (uint32_t *)(ws_queue(h) + h->ws_rows * WS_QUEUE_PER_ROW); }
+static inline uint32_t *ws_qcount(fmi *h) { return ws_bits(h) + h->ws_rows * WS_BITS_WORDS; }
 extern "C" int fmi_dev_reserve(fmi_t *h, uint64_t max_rows)
 {
     int rc = need_device(h); if (rc) return rc;
     if (max_rows <= h->ws_rows) return FMI_OK;
     if (h->ws) { HIPCHK(hipFree(h->ws)); h->ws = nullptr; h->ws_rows = 0; }
-    const uint64_t bytes = max_rows * (sizeof(ExpandItem) + WS_BITS_WORDS * 4);
+    const uint64_t bytes = max_rows * (sizeof(ExpandItem) * (1 + WS_QUEUE_PER_ROW) + WS_BITS_WORDS * 4) + 256;
     HIPCHK(hipMalloc(&h->ws, bytes));
     h->ws_bytes = bytes; h->ws_rows = max_rows;
     return FMI_OK;
@@ -519,6 +550,35 @@ static unsigned expand_grid(uint64_t n_items)
     return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(g, 256ull * 16));
 }
 
+static size_t expand_lds_bytes(int nlev) { return (size_t)EXP_WAVES * (3 * (size_t)exp_slots(nlev) + FMI_MAX_LEVELS) * 4; }
+
+// Expansion of `rows` root intervals (items[0..rows), level 0) in two launches:
+//   phase 1: one wave per row walks levels [0, split) and appends the surviving
+//            level-`split` nodes to the queue behind the roots;
+//   phase 2: one wave per queued node finishes its sub-tree.
+// The queue (rows << split entries) and its counter live in the workspace.
+template <int MODE>
+static int launch_expand(fmi *h, hipStream_t st, ExpandItem *items, uint64_t rows, ExpandItem *queue, uint32_t *qcount,
+                         uint64_t qcap, const EmitTarget &tgt)
+{
+    const uint32_t L = h->levels;
+    uint64_t *pc = h->probe_count_enabled ? h->d_probe_counter : nullptr;
+    const uint32_t split = (L > EXP_SPLIT_LEVEL + 2 && queue) ? EXP_SPLIT_LEVEL : L;   // shallow trees: single phase
+    if (split < L) HIPCHK(hipMemsetAsync(qcount, 0, 4, st));
+    const int nlev1 = (int)split;                          // stored levels 0..split-1
+    hipLaunchKernelGGL((k_expand<MODE>), dim3(expand_grid(rows)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev1), st, h->dev,
+                       (const ExpandItem *)items, (const uint32_t *)nullptr, (uint32_t)rows, tgt, (uint32_t)exp_slots(nlev1),
+                       split, queue, qcount, (uint32_t)qcap, pc);
+    if (split < L) {
+        const int nlev2 = (int)(L - split);
+        hipLaunchKernelGGL((k_expand<MODE>), dim3(expand_grid(qcap)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev2), st, h->dev,
+                           (const ExpandItem *)queue, (const uint32_t *)qcount, (uint32_t)qcap, tgt, (uint32_t)exp_slots(nlev2),
+                           L, (ExpandItem *)nullptr, (uint32_t *)nullptr, 0u, pc);
+    }
+    HIPCHK(hipGetLastError());
+    return FMI_OK;
+}
+
 static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur_len, const int64_t *d_ids,
                              uint32_t *d_bits, uint64_t vocab, int64_t shift, int64_t pad_id, int64_t eos_id,
                              const int64_t *force_from, uint64_t n_force, int64_t stop_at_count, int always_allow_eos)
@@ -529,17 +589,16 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     const uint64_t wpr = (vocab + 31) / 32;
     ForceFrom ff{}; ff.n = (uint32_t)n_force;
     for (uint64_t i = 0; i < n_force; i++) ff.tok[i] = force_from[i];
-    ExpandItem *items = (ExpandItem *)h->ws;
+    ExpandItem *items = ws_items(h);
     HIPCHK(hipMemsetAsync(d_bits, 0, rows * wpr * 4, st));
     hipLaunchKernelGGL(k_prefix_ranges, dim3(blocks_for(rows, 64)), dim3(64), 0, st, h->dev, rows, cur_len, d_ids, shift,
                        pad_id, eos_id, ff, stop_at_count, always_allow_eos, vocab, wpr, d_bits, items);
     EmitTarget tgt{}; tgt.bits = d_bits; tgt.words_per_row = wpr; tgt.shift = shift; tgt.vocab = vocab;
     const bool timed = h->timing_enabled && h->ev_used < MAX_TIMED_LAUNCHES;
     if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
-    hipLaunchKernelGGL((k_expand<EMIT_BITS>), dim3(expand_grid(rows)), dim3(EXP_WAVES * 64), 0, st, h->dev, items,
-                       (const uint32_t *)nullptr, (uint32_t)rows, tgt, h->probe_count_enabled ? h->d_probe_counter : nullptr);
+    int rc = launch_expand<EMIT_BITS>(h, st, items, rows, ws_queue(h), ws_qcount(h), h->ws_rows * WS_QUEUE_PER_ROW, tgt);
+    if (rc) return rc;
     if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
-    HIPCHK(hipGetLastError());
     return FMI_OK;
 }
 
@@ -564,7 +623,7 @@ extern "C" int fmi_dev_constrain_scores(fmi_t *h, void *stream, uint64_t rows, u
     if (wpr > WS_BITS_WORDS) { fmi_set_error("vocab %llu too large", (unsigned long long)vocab); return FMI_ERR_UNSUPPORTED; }
     if (rows > h->ws_rows) { rc = fmi_dev_reserve(h, rows); if (rc) return rc; }
     // bitmap lives behind the items in the workspace
-    uint32_t *bits = (uint32_t *)((char *)h->ws + h->ws_rows * sizeof(ExpandItem));
+    uint32_t *bits = ws_bits(h);
     rc = allowed_bits_impl(h, (hipStream_t)stream, rows, cur_len, d_input_ids, bits, vocab, shift, pad_id, eos_id,
                            force_from, n_force, stop_at_count, always_allow_eos);
     if (rc) return rc;
@@ -673,9 +732,14 @@ extern "C" int fmi_distinct_count_multi(fmi_t *h, uint64_t n, const uint64_t *lo
         HIPCHK(hipMemcpy(items.p, hitems.data(), m * sizeof(ExpandItem), hipMemcpyHostToDevice));
         HIPCHK(hipMemset(dense.p, 0, m * nsym * 8));
         EmitTarget tgt{}; tgt.dense = dense.as<uint64_t>(); tgt.dense_stride = nsym;
-        hipLaunchKernelGGL((k_expand<EMIT_DENSE>), dim3(expand_grid(m)), dim3(EXP_WAVES * 64), 0, 0, h->dev,
-                           items.as<ExpandItem>(), (const uint32_t *)nullptr, (uint32_t)m, tgt,
-                           h->probe_count_enabled ? h->d_probe_counter : nullptr);
+        {
+            DevBuf q, qc;
+            const uint64_t qcap = m * WS_QUEUE_PER_ROW;
+            if ((rc = q.alloc(qcap * sizeof(ExpandItem))) || (rc = qc.alloc(4))) return rc;
+            rc = launch_expand<EMIT_DENSE>(h, 0, items.as<ExpandItem>(), m, q.as<ExpandItem>(), qc.as<uint32_t>(), qcap, tgt);
+            if (rc) return rc;
+            HIPCHK(hipDeviceSynchronize());   // q / qc are freed at scope exit
+        }
         hipLaunchKernelGGL(k_dense_count, dim3((unsigned)m), dim3(256), 0, 0, dense.as<uint64_t>(), nsym, nsym, rowk.as<uint64_t>());
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy(hk.data(), rowk.p, m * 8, hipMemcpyDeviceToHost));

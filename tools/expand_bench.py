@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Isolated measurement of the rank/select expansion path (k_prefix_ranges +
+k_expand) on an NQ-shaped synthetic index, model-free ("trace mode"):
+rows are decoder prefixes drawn from the corpus itself.
+
+  python tools/expand_bench.py --docs 21015324 --rows 300 --prefix-len 1 --iters 20
+
+prints one JSON line: probes, algorithmic bytes (64 B per probe), HIP-event time,
+GB/s and fraction of the 8 TB/s HBM peak.  Run it under
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python tools/expand_bench.py ...
+for the memory-side traffic of the same launches."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--docs", type=int, default=21015324)
+    ap.add_argument("--rows", type=int, default=300)
+    ap.add_argument("--prefix-len", type=int, default=1, help="tokens after the decoder start token")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    from seal_amd import FMIndex
+    from seal_amd._lib import check, lib
+    data, beg, title_len, ids_by_rank = bench.synth_corpus(args.docs, dev, seed=0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(100 + args.seed)
+    # prefixes = corpus n-grams in forward order: pick positions in the reversed text and read backwards
+    N = data.numel()
+    p = torch.randint(args.prefix_len + 1, N - 1, (args.rows,), generator=g, device=dev)
+    offs = torch.arange(args.prefix_len, device=dev)
+    toks = data[(p[:, None] - offs[None, :])].long() - bench.SHIFT          # forward order
+    ids = torch.cat([torch.full((args.rows, 1), 2, device=dev, dtype=torch.long), toks], 1).contiguous()
+    index = FMIndex()
+    index.initialize_from_device(data, beg.tolist())
+    del data
+    h = index.handle
+    V = bench.VOCAB
+    bits = torch.zeros(args.rows, (V + 31) // 32, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    check(lib().fmi_dev_enable_probe_count(h, 1))
+    check(lib().fmi_dev_enable_timing(h, 1))
+
+    def call():
+        check(lib().fmi_dev_allowed_bits(h, st, args.rows, ids.shape[1], ids.data_ptr(), bits.data_ptr(), V, bench.SHIFT, 1, 2,
+                                         None, 0, 0, 0))
+    call()
+    torch.cuda.synchronize()
+    probes, launches, ms = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
+    check(lib().fmi_dev_read_probe_count(h, ctypes.byref(probes)))
+    check(lib().fmi_dev_read_timing(h, ctypes.byref(launches), ctypes.byref(ms)))
+    for _ in range(args.iters):
+        call()
+    check(lib().fmi_dev_read_probe_count(h, ctypes.byref(probes)))
+    check(lib().fmi_dev_read_timing(h, ctypes.byref(launches), ctypes.byref(ms)))
+    allowed = int(sum(bin(x & 0xFFFFFFFF).count("1") for x in bits[:8].flatten().tolist())) / 8.0
+    gbs = probes.value * 64 / (ms.value * 1e-3) / 1e9
+    print(json.dumps({"docs": args.docs, "n": index.size(), "rows": args.rows, "prefix_len": args.prefix_len,
+                      "iters": args.iters, "probes_per_call": probes.value / args.iters,
+                      "alg_MB_per_call": round(probes.value * 64 / args.iters / 1e6, 2),
+                      "us_per_call": round(ms.value * 1e3 / args.iters, 2), "GBps": round(gbs, 1),
+                      "frac_of_8TBps": round(gbs / 8000, 4), "avg_allowed_tokens_first8rows": allowed}))
+
+
+if __name__ == "__main__":
+    main()
