@@ -13,7 +13,9 @@ struct alignas(16) U64x2 { uint64_t x, y; };
 __device__ __forceinline__ uint64_t wm_rank1(const FmiDev &ix, uint32_t k, uint64_t p, uint64_t *probes)
 {
     const uint64_t w = p >> 6;
-    const uint64_t blk = w / 7;
+    uint64_t blk;
+    if (ix.n < (1ull << 37)) blk = (uint32_t)w / 7u;      // word index fits 32 bits: one mul_hi instead of a 64-bit divide
+    else blk = w / 7;
     const uint32_t wi = (uint32_t)(w - blk * 7);
     const U64x2 *b = reinterpret_cast<const U64x2 *>(ix.wm + ((uint64_t)k * ix.nblk + blk) * FMI_BLOCK_WORDS);
     const U64x2 v0 = b[0], v1 = b[1], v2 = b[2], v3 = b[3];

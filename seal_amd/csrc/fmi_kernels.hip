@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -129,7 +130,9 @@ __device__ __forceinline__ void wave_sync()
 
 static constexpr int EXP_WAVES = 4;                 // waves per workgroup
 static constexpr int EXP_LVL_CAP = 128;
-static constexpr uint32_t EXP_SPLIT_LEVEL = 6;      // phase 1 stops here and hands sub-trees to phase 2
+static constexpr uint32_t EXP_SPLIT_LEVEL = 6;      // phase 1 hands the sub-trees of WIDE rows over to phase 2 at this level
+static constexpr uint64_t EXP_WIDE_ROWS = 0;        // rows narrower than this would stay in their phase-1 wave down to the leaves;
+                                                    // measured slower on MI355X (r1: 325 vs 60 us for 300 one-symbol rows), so 0 = always hand over
 // relative level j occupies [lvl_off(j), lvl_off(j)+min(2^j,128))
 __host__ __device__ constexpr int lvl_off(int j) { return j < 7 ? (1 << j) - 1 : 127 + (j - 7) * EXP_LVL_CAP; }
 // LDS slots a wave needs to expand a sub-tree spanning `nlev` stored levels
@@ -157,7 +160,7 @@ template <int MODE>
 __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const ExpandItem *items, const uint32_t *n_items_ptr,
                                                            uint32_t n_items_static, EmitTarget tgt, uint32_t slots,
                                                            uint32_t stop_level, ExpandItem *out_items, uint32_t *out_count,
-                                                           uint32_t out_cap, uint64_t *probe_counter)
+                                                           uint32_t out_cap, uint64_t wide_rows, uint64_t *probe_counter)
 {
     extern __shared__ uint32_t s_mem[];
     const uint32_t lane = threadIdx.x & 63;
@@ -169,13 +172,15 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
     const uint32_t n_items = n_items_ptr ? min(*n_items_ptr, n_items_static) : n_items_static;
     const uint32_t L = ix.levels;
     uint64_t probes = 0;
-    uint64_t *pp = probe_counter ? &probes : nullptr;
 
     for (uint32_t item = blockIdx.x * EXP_WAVES + wv; item < n_items; item += gridDim.x * EXP_WAVES) {
         const ExpandItem it = items[item];
         if (it.hi <= it.lo) continue;
         const uint32_t row = it.row;
         const uint32_t root = it.level;
+        // narrow root intervals have few distinct symbols: finishing them in this wave costs
+        // 16 dependent probes, handing them over would add a launch and nothing else
+        const uint32_t stop = (root == 0 && (it.hi - it.lo) < wide_rows) ? L : stop_level;
         // a root sitting below the last level is already a leaf
         if (root >= L) { if (lane == 0) emit_leaf<MODE>(tgt, row, it.prefix, it.hi - it.lo); continue; }
         if (lane < FMI_MAX_LEVELS) s_cnt[lane] = 0;
@@ -205,8 +210,9 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
             if (lane == 0) s_cnt[deepest] = cnt - m;
             uint64_t r_lo = 0, r_hi = 0;
             if (act) {
-                r_lo = wm_rank1(ix, k, lo, pp);
-                r_hi = wm_rank1(ix, k, hi, pp);
+                r_lo = wm_rank1(ix, k, lo, nullptr);
+                r_hi = wm_rank1(ix, k, hi, nullptr);
+                probes += 2;
             }
             const uint64_t ones = r_hi - r_lo;
             const uint64_t zer = (hi - lo) - ones;
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
                 const uint64_t lt = (1ull << lane) - 1;
                 const uint32_t n0 = (uint32_t)__popcll(b0);
                 const uint32_t added = n0 + (uint32_t)__popcll(b1);
-                if (k + 1 == stop_level) {
+                if (k + 1 == stop) {
                     // hand the children over to phase 2
                     uint32_t obase = 0;
                     if (lane == 0 && added) obase = atomicAdd(out_count, added);
@@ -565,15 +571,17 @@ static int launch_expand(fmi *h, hipStream_t st, ExpandItem *items, uint64_t row
     uint64_t *pc = h->probe_count_enabled ? h->d_probe_counter : nullptr;
     const uint32_t split = (L > EXP_SPLIT_LEVEL + 2 && queue) ? EXP_SPLIT_LEVEL : L;   // shallow trees: single phase
     if (split < L) HIPCHK(hipMemsetAsync(qcount, 0, 4, st));
-    const int nlev1 = (int)split;                          // stored levels 0..split-1
+    static const char *e_wide = getenv("SEALFM_WIDE_ROWS"), *e_nlev = getenv("SEALFM_P1_NLEV");   // tuning knobs
+    const uint64_t wide = e_wide ? strtoull(e_wide, nullptr, 10) : EXP_WIDE_ROWS;
+    const int nlev1 = e_nlev ? atoi(e_nlev) : (wide ? (int)L : (int)split);
     hipLaunchKernelGGL((k_expand<MODE>), dim3(expand_grid(rows)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev1), st, h->dev,
                        (const ExpandItem *)items, (const uint32_t *)nullptr, (uint32_t)rows, tgt, (uint32_t)exp_slots(nlev1),
-                       split, queue, qcount, (uint32_t)qcap, pc);
+                       split, queue, qcount, (uint32_t)qcap, wide, pc);
     if (split < L) {
         const int nlev2 = (int)(L - split);
         hipLaunchKernelGGL((k_expand<MODE>), dim3(expand_grid(qcap)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev2), st, h->dev,
                            (const ExpandItem *)queue, (const uint32_t *)qcount, (uint32_t)qcap, tgt, (uint32_t)exp_slots(nlev2),
-                           L, (ExpandItem *)nullptr, (uint32_t *)nullptr, 0u, pc);
+                           L, (ExpandItem *)nullptr, (uint32_t *)nullptr, 0u, (uint64_t)0, pc);
     }
     HIPCHK(hipGetLastError());
     return FMI_OK;
