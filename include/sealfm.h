@@ -197,6 +197,23 @@ int fmi_dev_read_timing(fmi_t *h, uint64_t *launches_out, double *total_ms_out);
  * CPU baseline's samples).  name in {"sa_lo","sa_hi","text","wm","C","leaf","q1","doc_begin"}. */
 const void *fmi_dev_array(const fmi_t *h, const char *name, uint64_t *n_out, uint32_t *elem_out);
 
+/* ---- first-stage evidence aggregation (host, consumes fmi_dev_locate_ranges output) --
+ * seal/keys.py:311-367 for one query: keys in processing order (descending score),
+ * CSR tokens per key, score per key, CSR of located rows per key with their text
+ * position and document; coverage window [pos - len, pos) as in the reference.
+ * Result = documents in ranked order (stable sort of first-touch order by
+ * (1-single_key)*(-score) + single_key*(-best_score), cut to n_top), each with its
+ * re-weighted score, best key, and the (key index, re-weighted score) list. */
+typedef struct fmi_evidence fmi_evidence_t;
+int fmi_first_stage(uint64_t n_keys, const int64_t *key_tok_off, const int64_t *key_toks, const double *key_score,
+                    const int64_t *occ_off, const int64_t *pos, const int64_t *doc, int allow_overlaps,
+                    double beta, double single_key, uint64_t n_top, fmi_evidence_t **out);
+uint64_t fmi_evidence_docs(const fmi_evidence_t *ev);
+uint64_t fmi_evidence_entries(const fmi_evidence_t *ev);
+int fmi_evidence_read(const fmi_evidence_t *ev, int64_t *doc, double *score, int64_t *best_key, double *best_score,
+                      int64_t *key_off, int32_t *key_idx, double *key_score);
+void fmi_evidence_free(fmi_evidence_t *ev);
+
 #ifdef __cplusplus
 }
 #endif

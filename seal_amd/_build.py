@@ -6,8 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsealfm.so")
-SOURCES = ["fmi_host.cpp", "fmi_kernels.hip", "fmi_build_gpu.hip"]
-HEADERS = ["fmi_internal.h", os.path.join("..", "..", "include", "sealfm.h")]
+SOURCES = ["fmi_host.cpp", "fmi_evidence.cpp", "fmi_kernels.hip", "fmi_build_gpu.hip"]
+HEADERS = ["fmi_internal.h", "fmi_device.h", os.path.join("..", "..", "include", "sealfm.h")]
 
 
 def _hipcc() -> str:
@@ -27,7 +27,7 @@ def stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", LIB]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))

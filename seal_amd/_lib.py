@@ -54,6 +54,12 @@ SIGNATURES = {
     "fmi_dev_enable_timing": (_int, [_vp, _int]),
     "fmi_dev_read_timing": (_int, [_vp, _p64, ctypes.POINTER(ctypes.c_double)]),
     "fmi_dev_array": (_vp, [_vp, ctypes.c_char_p, _p64, ctypes.POINTER(ctypes.c_uint32)]),
+    "fmi_first_stage": (_int, [_u64, _vp, _vp, _vp, _vp, _vp, _vp, _int, ctypes.c_double, ctypes.c_double, _u64,
+                               ctypes.POINTER(_vp)]),
+    "fmi_evidence_docs": (_u64, [_vp]),
+    "fmi_evidence_entries": (_u64, [_vp]),
+    "fmi_evidence_read": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fmi_evidence_free": (None, [_vp]),
 }
 
 _lib = None

@@ -55,3 +55,25 @@ def test_small_helpers():
     items = [(0.5, [1, 2]), (0.4, [1, 2]), (0.1, [3])]
     assert deduplicate(items) == oracle_deduplicate(items) == [(0.5, [1, 2]), (0.1, [3])]
     assert deduplicate([[1], [1], [2]]) == [[1], [2]]
+
+
+def test_rescore_keys_prefix_sharing_matches_row_per_key():
+    import torch
+    from seal_amd.keys import rescore_keys
+    from tests.helpers import tiny_bart
+    m = tiny_bart(120)
+    rng = np.random.default_rng(0)
+    inputs = [[0] + rng.integers(4, 118, size=6).tolist() + [2] for _ in range(3)]
+    keys = []
+    for _ in range(3):
+        base = rng.integers(4, 118, size=7).tolist()
+        other = rng.integers(4, 118, size=5).tolist()
+        kk = [base[:i] for i in range(1, 8)] + [other[:i] for i in range(2, 6)] + [[2] + base[:3], base[:4] + [2], [7] + other[:2] + [7]]
+        keys.append([(-1.0, k) for k in kk])
+    for kw in (dict(), dict(strip_from_bos=[2, 7], strip_from_eos=[7, 2]), dict(prefix=[5]), dict(length_penalty=1.0)):
+        a = rescore_keys(m, inputs, keys, batch_size=4, share_prefixes=True, **kw)
+        b = rescore_keys(m, inputs, keys, batch_size=4, share_prefixes=False, **kw)
+        for qa, qb in zip(a, b):
+            assert [k for _, k in qa] == [k for _, k in qb]
+            for (sa, _), (sb, _) in zip(qa, qb):
+                assert abs(sa - sb) <= 2e-5 * max(1.0, abs(sb)), kw
