@@ -313,7 +313,15 @@ def main():
     rk.aggregate_evidence = timed("aggregate_ms", orig[3])
     retrieval._count_filter = timed("count_filter_ms", orig[4])
     index._trace = []
-    run_batch(args.warmup + args.steps)
+    if os.environ.get("SEAL_BENCH_PROFILE"):
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        run_batch(args.warmup + args.steps)
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
+    else:
+        run_batch(args.warmup + args.steps)
     trace, index._trace = index._trace, None
     retrieval.fm_index_generate, rk.rescore_keys, rk.compute_unigram_scores, rk.aggregate_evidence, retrieval._count_filter = orig
     p2, l2, k2 = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()

@@ -143,6 +143,9 @@ def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_pena
             nxt = sq
         owner.append(own)
     cums = [None] * len(work)
+    # rows per forward: the reference's batch_size (100) is a host-memory knob; rows are independent,
+    # so larger chunks give the same numbers with fewer launch-bound forwards
+    batch_size = max(batch_size, 512)
     for c0 in range(0, len(work), batch_size):
         chunk = work[c0:c0 + batch_size]
         rows = [i for i, (_, sq) in enumerate(chunk) if len(sq) > 0]
@@ -251,6 +254,35 @@ def _match_order_key(length: int) -> Tuple[int, int]:
     return (0, length) if length % 2 else (1, -length)
 
 
+class _KeyList:
+    """``[[ngram, score], ...]`` of one document, materialised on first use (most of the
+    up-to-1500 ranked documents of a query are never looked at again)."""
+    __slots__ = ("_keys", "_ki", "_ks", "_a", "_b", "_list")
+
+    def __init__(self, keys, ki, ks, a, b):
+        self._keys, self._ki, self._ks, self._a, self._b, self._list = keys, ki, ks, a, b, None
+
+    def _get(self):
+        if self._list is None:
+            self._list = [[self._keys[int(self._ki[j])], float(self._ks[j])] for j in range(self._a, self._b)]
+        return self._list
+
+    def __len__(self):
+        return self._b - self._a
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __eq__(self, other):
+        return self._get() == list(other)
+
+    def __repr__(self):
+        return repr(self._get())
+
+
 def _first_stage_native(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps, beta, single_key, n_top):
     """keys.py:311-367 through ``fmi_first_stage`` (seal_amd/csrc/fmi_evidence.cpp)."""
     import ctypes
@@ -275,13 +307,9 @@ def _first_stage_native(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps,
         check(lib().fmi_evidence_read(ev, p(d), p(sc), p(bk), p(bs), p(ko), p(ki), p(ks)))
     finally:
         lib().fmi_evidence_free(ev)
-    d, sc, bk, bs, ko, ki, ks = d.tolist(), sc.tolist(), bk.tolist(), bs.tolist(), ko.tolist(), ki.tolist(), ks.tolist()
-    ranked = []
-    for i in range(nd):
-        a, b = ko[i], ko[i + 1]
-        ranked.append((d[i], [sc[i], [[rare_keys[ki[j]], ks[j]] for j in range(a, b)],
-                              [rare_keys[bk[i]] if bk[i] >= 0 else [], bs[i]]]))
-    return ranked
+    d, sc, bk, bs, ko = d.tolist(), sc.tolist(), bk.tolist(), bs.tolist(), ko.tolist()
+    return [(d[i], [sc[i], _KeyList(rare_keys, ki, ks, ko[i], ko[i + 1]), [rare_keys[bk[i]] if bk[i] >= 0 else [], bs[i]]])
+            for i in range(nd)]
 
 
 def _first_stage_python(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps, beta, single_key, n_docs_complete_score,
