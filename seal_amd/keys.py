@@ -114,6 +114,11 @@ def rescore_keys(model, inputs, list_of_decoded, batch_size=100, length_penalty=
 @torch.inference_mode()
 def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_penalty, prefix, strip_from_bos, strip_from_eos,
                          logit_bias):
+    """Tree-shared teacher forcing.  score(key) = sum_j log p(key[j] | key[:j]).  The keys of a
+    query form the beam-search tree; a decoder row fed with ``[start] + q`` yields, at position j,
+    the distribution after ``q[:j]`` -- i.e. every term of every key whose parent ``key[:-1]`` is a
+    prefix of ``q``.  Rows are therefore only the MAXIMAL PARENTS (about one per beam), and a key
+    reads ``cum_q[len-1] + logp[row, len-1, key[-1]]``."""
     cfg = model.config
     device = next(model.parameters()).device
     if inputs is None:
@@ -125,54 +130,60 @@ def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_pena
     attention_mask = (input_ids != cfg.pad_token_id).to(torch.uint8)
     enc = model.model.encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
     start, npre = cfg.decoder_start_token_id, len(prefix)
-    # decoder-side sequence of every key, and the maximal ones per query
     seqs = [[tuple(list(prefix) + list(strip(list(key), strip_from_bos, strip_from_eos))) for key in keys] for keys in decoded]
-    work = []           # (query, maximal sequence)
-    owner = []          # per query: {sequence -> index into work}
+    work = []           # (query, maximal parent)
+    owner = []          # per query: {parent -> index into work}
     for qi, ss in enumerate(seqs):
-        uniq = sorted(set(ss))
-        own = {}
-        # in lexicographic order every sequence is immediately followed by its extensions
-        nxt = None
-        for sq in reversed(uniq):
-            if nxt is not None and len(nxt) > len(sq) and nxt[:len(sq)] == sq:
-                own[sq] = own[nxt]
+        parents = sorted({sq[:-1] for sq in ss if len(sq) > 0})
+        own, nxt = {}, None
+        for p in reversed(parents):      # lexicographic order: a sequence is followed by its extensions
+            if nxt is not None and len(nxt) > len(p) and nxt[:len(p)] == p:
+                own[p] = own[nxt]
             else:
-                own[sq] = len(work)
-                work.append((qi, sq))
-            nxt = sq
+                own[p] = len(work)
+                work.append((qi, p))
+            nxt = p
         owner.append(own)
-    cums = [None] * len(work)
-    # rows per forward: the reference's batch_size (100) is a host-memory knob; rows are independent,
-    # so larger chunks give the same numbers with fewer launch-bound forwards
-    batch_size = max(batch_size, 512)
-    for c0 in range(0, len(work), batch_size):
-        chunk = work[c0:c0 + batch_size]
-        rows = [i for i, (_, sq) in enumerate(chunk) if len(sq) > 0]
-        if not rows:
-            continue
-        qidx = torch.as_tensor([chunk[i][0] for i in rows], device=device)
-        dec_ids = _pad_batch([[start] + list(chunk[i][1]) for i in rows], cfg.pad_token_id, device)
-        logits = model(attention_mask=attention_mask[qidx], encoder_outputs=(enc[qidx],),
-                       decoder_input_ids=dec_ids[:, :-1]).logits
+    order = sorted(range(len(work)), key=lambda i: len(work[i][1]))     # similar lengths together: less padding
+    slot = {w: j for j, w in enumerate(order)}
+    # keys grouped by the chunk of their owner row
+    chunk_rows = max(batch_size, 256)
+    per_chunk = {}
+    for qi, ss in enumerate(seqs):
+        for ki, sq in enumerate(ss):
+            if len(sq) > 0:
+                j = slot[owner[qi][sq[:-1]]]
+                per_chunk.setdefault(j // chunk_rows, []).append((qi, ki, j % chunk_rows, sq))
+    scores = [[0.0] * len(ss) for ss in seqs]
+    for c, items in per_chunk.items():
+        rows = [work[w] for w in order[c * chunk_rows:(c + 1) * chunk_rows]]
+        qidx = torch.as_tensor([qi for qi, _ in rows], device=device)
+        dec_ids = _pad_batch([[start] + list(p) for _, p in rows], cfg.pad_token_id, device)
+        logits = model(attention_mask=attention_mask[qidx], encoder_outputs=(enc[qidx],), decoder_input_ids=dec_ids).logits
         if logit_bias is not None:
             logits = logits + logit_bias[qidx][:, None, :]
-        tgt = dec_ids[:, 1:]
-        lp = torch.gather(logits.log_softmax(-1), -1, tgt.unsqueeze(-1)).squeeze(-1)
-        lp = torch.where(tgt < 2, torch.zeros_like(lp), lp)
-        cum = torch.cumsum(lp.double(), dim=-1).cpu().numpy()
-        for j, i in enumerate(rows):
-            cums[c0 + i] = cum[j]
-    out = []
-    for qi, (keys, ss) in enumerate(zip(decoded, seqs)):
-        res = []
-        for key, sq in zip(keys, ss):
-            cum = cums[owner[qi][sq]]
-            n = len(sq)
-            ll = 0.0 if n == 0 or n <= npre else float(cum[n - 1] - (cum[npre - 1] if npre else 0.0))
-            res.append((float(np.float32(ll)) / (len(key) ** length_penalty), list(key)))
-        out.append(res)
-    return out
+        logp = logits.log_softmax(-1)                                   # [rows, T, V]; position j: after p[:j]
+        T = dec_ids.shape[1]
+        if T > 1:
+            tgt = dec_ids[:, 1:]
+            own_lp = torch.gather(logp[:, :-1], -1, tgt.unsqueeze(-1)).squeeze(-1)
+            own_lp = torch.where(tgt < 2, torch.zeros_like(own_lp), own_lp)
+            cum = torch.cat([torch.zeros(len(rows), 1, dtype=torch.float64, device=device),
+                             torch.cumsum(own_lp.double(), dim=-1)], dim=1)          # cum[r, m] = first m terms
+        else:
+            cum = torch.zeros(len(rows), 1, dtype=torch.float64, device=device)
+        r_idx = torch.as_tensor([r for _, _, r, _ in items], device=device)
+        n_idx = torch.as_tensor([len(sq) for _, _, _, sq in items], device=device)
+        last = torch.as_tensor([sq[-1] for _, _, _, sq in items], device=device)
+        last_lp = logp[r_idx, n_idx - 1, last].double()
+        last_lp = torch.where(last < 2, torch.zeros_like(last_lp), last_lp)
+        lo = torch.clamp(torch.full_like(n_idx, npre), max=cum.shape[1] - 1)
+        body = cum[r_idx, n_idx - 1] - cum[r_idx, torch.minimum(lo, n_idx - 1)]
+        total = torch.where(n_idx > npre, body + last_lp, torch.zeros_like(body)).float().tolist()
+        for (qi, ki, _, _), ll in zip(items, total):
+            scores[qi][ki] = ll
+    return [[(scores[qi][ki] / (len(key) ** length_penalty), list(key)) for ki, key in enumerate(keys)]
+            for qi, keys in enumerate(decoded)]
 
 
 @torch.no_grad()
@@ -430,8 +441,18 @@ def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_o
     if unigram_scores is not None:
         raw = np.asarray(unigram_scores, dtype=np.float64)
         V = raw.shape[0]
-        # top-k by log-prob, ties by ascending id (sorted(..., reverse=True) is stable)
-        best = np.argsort(-raw, kind="stable")[:use_top_k_unigrams]
+        # the use_top_k_unigrams best by log-prob, ties to the lower id (the reference's
+        # sorted(range(V), reverse=True, key=...) is stable) -- selected without a full sort
+        k = min(int(use_top_k_unigrams), V)
+        if k <= 0:
+            best = np.zeros(0, dtype=np.int64)
+        elif k >= V:
+            best = np.arange(V)
+        else:
+            kth = np.partition(raw, V - k)[V - k]
+            above = np.flatnonzero(raw > kth)
+            ties = np.flatnonzero(raw == kth)[:k - above.size]
+            best = np.concatenate([above, ties])
         uni_counts = _unigram_counts(index)
         us = np.zeros(V, dtype=np.float64)
         for i in best.tolist():
@@ -447,10 +468,22 @@ def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_o
                 sco = max(sr - cutoff, 0.0) ** alpha
             if sco != 0.0:
                 us[i] = sco
-        unigram_scores = us.tolist()
+        unigram_scores = us          # indexable by token id like the reference's list
         if add_best_unigrams_to_ngrams:
-            for i in np.argsort(-us, kind="stable")[:len(scored)].tolist():
-                scored.append(([i], unigram_scores[i]))
+            # sorted(range(V), key=lambda x: -unigram_scores[x])[:n]: positives by descending score
+            # (stable), then the zero-score ids in ascending order
+            n_add = len(scored)
+            nz = np.flatnonzero(us > 0)
+            order = nz[np.argsort(-us[nz], kind="stable")][:n_add].tolist()
+            if len(order) < n_add:
+                taken = set(order)
+                for i in range(V):
+                    if len(order) >= n_add:
+                        break
+                    if us[i] == 0.0 and i not in taken:
+                        order.append(i)
+            for i in order:
+                scored.append(([i], float(us[i])))
         count_of.ensure([ng for ng, _ in scored])
 
     # ---- rare / frequent split (keys.py:280-309) ----
@@ -504,7 +537,7 @@ def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_o
         doc_tokens = [2] + list(toks)[:-1]
         res = results[doc] = [0.0, [], None, doc_tokens, [[], 0.0]]
         if unigram_scores is not None:
-            type_scores = {t: unigram_scores[t] for t in doc_tokens}
+            type_scores = {t: float(unigram_scores[t]) for t in doc_tokens}
         else:
             type_scores = {t: 0.0 for t in doc_tokens}
         # all trie matches, bucketed by end position

@@ -228,7 +228,10 @@ def _process_batch(searcher, inputs, constrained_generation):
         _, toks = marked("body")
         unigram = rk.compute_unigram_scores(
             s.bart_scorer_model, toks, s.fm_index,
-            prefix=[s.force_decoding_second_token] if s.force_decoding_second_token >= 0 else [], logit_bias=s.logit_bias)
+            prefix=[s.force_decoding_second_token] if s.force_decoding_second_token >= 0 else [], logit_bias=s.logit_bias,
+            tolist=False)
+        # one D2H copy; float64 views of the fp32 log-probs == what .tolist() would hold
+        unigram = unigram.double().cpu().numpy()
         return list(zip(found_keys, unigram))
     return found_keys
 
@@ -479,8 +482,16 @@ class SEALSearcher:
             unigrams_ignore_free_places=self.unigrams_ignore_free_places, first_stage_only=self.first_stage_only)
 
     def batch_retrieve_from_keys(self, keys):
-        for kk in keys:
-            yield self.retrieve_from_keys(kk)
+        """The reference forks ``jobs`` processes over queries (retrieval.py:762-775).  Here the
+        index work of a query is a handful of GPU launches and a native host routine, both of
+        which release the GIL, so ``jobs`` threads suffice."""
+        if self.jobs >= 2:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=int(self.jobs)) as pool:
+                yield from pool.map(self.retrieve_from_keys, list(keys))
+        else:
+            for kk in keys:
+                yield self.retrieve_from_keys(kk)
 
     def doc(self, docid: Union[str, int]) -> Optional[SEALDocument]:
         idx = self.docid2idx[docid] if isinstance(docid, str) else docid
