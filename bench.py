@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--beam", type=int, default=15)
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--cpu-threads", type=int, default=64)
+    ap.add_argument("--jobs", type=int, default=4, help="host threads over queries for evidence aggregation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -204,6 +205,7 @@ def main():
     from seal_amd._lib import check, lib
     from seal_amd.retrieval import SEALSearcher
     from seal_amd import retrieval, keys as rk
+    from seal_amd.distributed import gather_topk, pack_topk
     if rank == 0:
         ge.build()
     if world > 1:
@@ -238,7 +240,7 @@ def main():
     log(f"BART-large random init (fp32) in {time.perf_counter() - t0:.1f}s")
 
     searcher = SEALSearcher(index, None, model, add_query_to_keys=False, detokenize=False, first_stage_only=True,
-                            beam=args.beam, batch_size=args.batch)
+                            beam=args.beam, batch_size=args.batch, jobs=args.jobs)
     from seal_amd.bart_decoder import BartStepDecoder
     model._seal_step_decoder = BartStepDecoder(model)
     check(lib().fmi_dev_enable_probe_count(index.handle, 1))
@@ -248,19 +250,17 @@ def main():
         q = queries[i * args.batch:(i + 1) * args.batch]
         model._seal_step_decoder.logit_bias = searcher.logit_bias = bias[i * args.batch:(i + 1) * args.batch]
         res = searcher.batch_search(q, k=args.topk)
-        top = torch.full((args.batch, args.topk, 2), -1.0, dtype=torch.float64)
-        for qi, docs in enumerate(res):
-            for j, d in enumerate(docs):
-                top[qi, j, 0], top[qi, j, 1] = d.idx, d.score
-        if world > 1:   # the path's only exchange: top-k (doc id, score) to every rank
-            top = top.to(dev)
-            out = torch.empty(world * args.batch, args.topk, 2, dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(out, top)
-            top = out
+        # the path's only exchange: top-k (doc id, score) of every query to every rank (RCCL all_gather)
+        top = gather_topk(pack_topk(res, args.topk).to(dev) if world > 1 else pack_topk(res, args.topk), world * args.batch, device=dev)
         return top, res
 
     for i in range(args.warmup):
         run_batch(i)
+    # the index keeps `beginnings` as a 21M-element python list (reference API); keep the cyclic GC
+    # from re-scanning it (and the model) on every full collection
+    import gc
+    gc.collect()
+    gc.freeze()
     import ctypes
     probes = ctypes.c_uint64()
     launches, kms = ctypes.c_uint64(), ctypes.c_double()
