@@ -330,8 +330,16 @@ def main():
 
     alg_bytes = probes.value * 64.0
     achieved = alg_bytes / (kms.value * 1e-3) / 1e9 if kms.value > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_expand<EMIT_BITS>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+    # memory-side traffic comes from a SEPARATE rocprofv3 --pmc FETCH_SIZE pass of this same command
+    # (profiles/README.md); per "launch" = per constraint call = the phase-1 + phase-2 kernel pair
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_size.json")))
+        traffic = round(pmc["void k_expand<0>"]["FETCH_SIZE"]["avg"] * 1024.0 * 2, 1)
+    except Exception:
+        pass
+    roofline = {"bound": "hbm", "kernel": "k_expand<EMIT_BITS> (phase-1 + phase-2 launch pair)", "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                 "launches": int(launches.value), "avg_launch_us": round(kms.value * 1e3 / max(1, launches.value), 2),
                 "algorithmic_bytes_per_launch": round(alg_bytes / max(1, launches.value), 1)}
 

@@ -1,0 +1,15 @@
+#!/usr/bin/env python
+"""Reduces a rocprofv3 counter_collection CSV to per-kernel averages (JSON on stdout)."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+acc = defaultdict(lambda: defaultdict(list))
+for r in rows:
+    acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for k, cs in acc.items():
+    out[k] = {c: {"launches": len(v), "sum": sum(v), "avg": sum(v) / len(v)} for c, v in cs.items()}
+json.dump(out, sys.stdout, indent=1)
