@@ -344,7 +344,7 @@ def main():
                 "algorithmic_bytes_per_launch": round(alg_bytes / max(1, launches.value), 1)}
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
         threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
         t0 = time.perf_counter()
         orc = build_cpu_oracle(index, threads)

@@ -131,6 +131,7 @@ __device__ __forceinline__ void wave_sync()
 static constexpr int EXP_WAVES = 4;                 // waves per workgroup
 static constexpr int EXP_LVL_CAP = 128;
 static constexpr uint32_t EXP_SPLIT_LEVEL = 6;      // phase 1 hands the sub-trees of WIDE rows over to phase 2 at this level
+static constexpr unsigned EXP_P2_BLOCKS = 1024;      // phase-2 grid cap = 4 workgroups per CU; waves loop over the queue
 static constexpr uint64_t EXP_WIDE_ROWS = 0;        // rows narrower than this would stay in their phase-1 wave down to the leaves;
                                                     // measured slower on MI355X (r1: 325 vs 60 us for 300 one-symbol rows), so 0 = always hand over
 // relative level j occupies [lvl_off(j), lvl_off(j)+min(2^j,128))
@@ -579,7 +580,9 @@ static int launch_expand(fmi *h, hipStream_t st, ExpandItem *items, uint64_t row
                        split, queue, qcount, (uint32_t)qcap, wide, pc);
     if (split < L) {
         const int nlev2 = (int)(L - split);
-        hipLaunchKernelGGL((k_expand<MODE>), dim3(expand_grid(qcap)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev2), st, h->dev,
+        static const char *e_p2 = getenv("SEALFM_P2_BLOCKS");
+        const unsigned p2_blocks = e_p2 ? (unsigned)atoi(e_p2) : EXP_P2_BLOCKS;
+        hipLaunchKernelGGL((k_expand<MODE>), dim3(std::min(expand_grid(qcap), p2_blocks)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev2), st, h->dev,
                            (const ExpandItem *)queue, (const uint32_t *)qcount, (uint32_t)qcap, tgt, (uint32_t)exp_slots(nlev2),
                            L, (ExpandItem *)nullptr, (uint32_t *)nullptr, 0u, (uint64_t)0, pc);
     }
