@@ -61,8 +61,102 @@ class BartStepDecoder:
     def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         return self.model.model.encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
 
+    # ------------------------------------------------------------------
+    # static-shape state: one set of buffers (and one hipGraph) per
+    # (batch, beams, padded encoder length, max decode length).  The decode position lives in a
+    # device tensor, the self-attention runs over the whole (masked) cache, so every step of a
+    # decode -- and every later decode of the same shape -- replays the same graph instead of
+    # launching ~300 small kernels from Python.
+    # ------------------------------------------------------------------
+    use_graph = True
+
+    class _Static:
+        pass
+
+    def _static_for(self, B, K, S_pad, T, dtype, dev):
+        key = (B, K, S_pad, T, dtype, str(dev))
+        cache = self.__dict__.setdefault("_static_cache", {})
+        st = cache.get(key)
+        if st is None:
+            st = self._Static()
+            R, H, dh, nl = B * K, self.h, self.dh, len(self.layers)
+            st.tokens = torch.zeros(R, dtype=torch.long, device=dev)
+            st.t = torch.zeros(1, dtype=torch.long, device=dev)
+            st.kv = torch.zeros(nl, 2, R, H, T, dh, dtype=dtype, device=dev)
+            st.ck = torch.zeros(nl, B, H, dh, S_pad, dtype=dtype, device=dev)
+            st.cv = torch.zeros(nl, B, H, S_pad, dh, dtype=dtype, device=dev)
+            st.cbias = torch.zeros(B, 1, 1, S_pad, dtype=dtype, device=dev)
+            st.pos_idx = torch.arange(T, device=dev).view(1, 1, 1, T)
+            st.logits = None
+            st.graph = None
+            st.shape = (B, K, S_pad, T)
+            cache[key] = st
+        return st
+
+    def _step_static(self, st):
+        B, K, S_pad, T = st.shape
+        R, H, dh = B * K, self.h, self.dh
+        x = self.embed(st.tokens)
+        x = x + self.pos.weight.index_select(0, st.t + self.pos_offset)
+        x = self.ln_emb(x)
+        future = st.pos_idx > st.t                                   # cache slots not written yet
+        for li, L in enumerate(self.layers):
+            qkv = F.linear(x, L["qkv_w"], L["qkv_b"]).view(R, 3, H, dh)
+            st.kv[li, 0].index_copy_(2, st.t, qkv[:, 1].unsqueeze(2))
+            st.kv[li, 1].index_copy_(2, st.t, qkv[:, 2].unsqueeze(2))
+            q = qkv[:, 0].unsqueeze(2) * self.scale
+            sc = (q @ st.kv[li, 0].transpose(-1, -2)).masked_fill(future, float("-inf"))
+            a = (torch.softmax(sc, dim=-1) @ st.kv[li, 1]).reshape(R, self.d)
+            x = L["ln1"](x + L["so"](a))
+            cq = (L["cq"](x) * self.scale).view(B, K, H, dh).transpose(1, 2)
+            catt = torch.softmax(cq @ st.ck[li] + st.cbias, dim=-1)
+            c = (catt @ st.cv[li]).transpose(1, 2).reshape(R, self.d)
+            x = L["ln2"](x + L["co"](c))
+            x = L["ln3"](x + L["fc2"](L["act"](L["fc1"](x))))
+        st.t.add_(1)
+        return (F.linear(x, self.lm_w) + self.lm_b).float()
+
     @torch.no_grad()
     def start(self, enc_hidden: torch.Tensor, attention_mask: torch.Tensor, num_beams: int, max_len: int) -> None:
+        if self.use_graph and enc_hidden.is_cuda:
+            return self._start_static(enc_hidden, attention_mask, num_beams, max_len)
+        self._st = None
+        return self._start_eager(enc_hidden, attention_mask, num_beams, max_len)
+
+    @torch.no_grad()
+    def _start_static(self, enc_hidden, attention_mask, num_beams, max_len):
+        B, S, d = enc_hidden.shape
+        self.batch, self.beams, self.rows, self.max_len = B, num_beams, B * num_beams, max_len
+        S_pad = max(16, (S + 15) // 16 * 16)
+        st = self._static_for(B, num_beams, S_pad, max_len, enc_hidden.dtype, enc_hidden.device)
+        for li, L in enumerate(self.layers):
+            kv = F.linear(enc_hidden, L["ckv_w"], L["ckv_b"]).view(B, S, 2, self.h, self.dh)
+            st.ck[li, :, :, :, :S] = kv[:, :, 0].permute(0, 2, 3, 1)
+            st.cv[li, :, :, :S] = kv[:, :, 1].permute(0, 2, 1, 3)
+        st.cbias.fill_(torch.finfo(enc_hidden.dtype).min)
+        st.cbias[:, :, :, :S].masked_fill_(attention_mask[:, None, None, :] != 0, 0.0)
+        st.t.zero_()
+        self._st = st
+        self.t = 0
+        if st.graph is None:
+            # warm up on a side stream, then capture (standard torch recipe); the cache contents
+            # written by the warm-up steps are overwritten/masked once t is reset
+            side = torch.cuda.Stream(device=enc_hidden.device)
+            side.wait_stream(torch.cuda.current_stream(enc_hidden.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    st.t.zero_()
+                    self._step_static(st)
+            torch.cuda.current_stream(enc_hidden.device).wait_stream(side)
+            st.t.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st.logits = self._step_static(st)
+            st.graph = g
+            st.t.zero_()
+
+    @torch.no_grad()
+    def _start_eager(self, enc_hidden: torch.Tensor, attention_mask: torch.Tensor, num_beams: int, max_len: int) -> None:
         B, S, d = enc_hidden.shape
         self.batch, self.beams, self.rows, self.max_len = B, num_beams, B * num_beams, max_len
         dt, dev = enc_hidden.dtype, enc_hidden.device
@@ -80,13 +174,25 @@ class BartStepDecoder:
     @torch.no_grad()
     def reorder(self, beam_idx: torch.Tensor) -> None:
         """new row r continues old row beam_idx[r] (HF ``_reorder_cache``)."""
+        if getattr(self, "_st", None) is not None:
+            self._st.kv.copy_(self._st.kv.index_select(2, beam_idx))
+            return
         self.kv[:, :, :, :, :self.t] = self.kv[:, :, beam_idx, :, :self.t]
 
     @torch.no_grad()
     def step(self, tokens: torch.Tensor) -> torch.Tensor:
         """tokens [rows] at decoder position ``self.t`` -> next-token logits [rows, vocab] (fp32)."""
         R, B, K, H, dh, t = self.rows, self.batch, self.beams, self.h, self.dh, self.t
-        x = self.embed(tokens) * self.embed_scale if self.embed_scale != 1.0 else self.embed(tokens)
+        if getattr(self, "_st", None) is not None:
+            st = self._st
+            st.tokens.copy_(tokens)
+            st.graph.replay()
+            self.t += 1
+            logits = st.logits
+            if self.logit_bias is not None:
+                logits = (logits.view(B, K, -1) + self.logit_bias[:, None, :]).view(R, -1)
+            return logits
+        x = self.embed(tokens)       # HF's BartScaledWordEmbedding applies embed_scale itself
         x = x + self.pos.weight[t + self.pos_offset]
         x = self.ln_emb(x)
         for li, L in enumerate(self.layers):

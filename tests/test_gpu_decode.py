@@ -44,3 +44,31 @@ def test_fm_index_generate_matches_reference_restatement(kw):
             assert len(gv[k]) == len(wv[k])
             for a, b in zip(sorted(gv[k]), sorted(wv[k])):
                 assert abs(a - b) <= 1e-4, (k, a, b)     # north_star: beam scores within 1e-4
+
+
+def test_graph_captured_step_matches_eager_step():
+    from seal_amd.bart_decoder import BartStepDecoder
+    from tests.helpers import tiny_bart
+    dev = torch.device("cuda:0")
+    m = tiny_bart(120).to(dev)
+    torch.manual_seed(3)
+    enc_ids = torch.randint(4, 120, (3, 11), device=dev)
+    enc_mask = torch.ones_like(enc_ids)
+    enc_mask[2, 7:] = 0
+    enc_ids[2, 7:] = 1
+    K, T = 4, 9
+    eager, graph = BartStepDecoder(m), BartStepDecoder(m)
+    eager.use_graph = False
+    for rep in range(2):                      # second round re-uses the captured graph and the stale cache
+        enc = eager.encode(enc_ids, enc_mask)
+        eager.start(enc, enc_mask, K, T)
+        graph.start(enc, enc_mask, K, T)
+        toks = torch.full((3 * K,), 2, device=dev)
+        for t in range(T - 1):
+            a, b = eager.step(toks), graph.step(toks)
+            assert torch.allclose(a, b, atol=2e-5, rtol=1e-5), (rep, t)
+            toks = torch.randint(4, 120, (3 * K,), device=dev)
+            perm = torch.arange(3 * K, device=dev).view(3, K)[:, torch.randperm(K, device=dev)].reshape(-1)
+            eager.reorder(perm)
+            graph.reorder(perm)
+        enc_ids = torch.roll(enc_ids, 1, 0)
