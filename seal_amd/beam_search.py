@@ -235,6 +235,7 @@ def fm_index_generate(
             decoder = BartStepDecoder(model)
             model._seal_step_decoder = decoder
     processor = kwargs.pop("constrained_decoding_processor", None)
+    logit_bias = kwargs.pop("logit_bias", None)     # extension: [batch, vocab] additive bias on the next-token logits
     if eos_token_id is None:
         eos_token_id = model.config.eos_token_id
     if processor is None and not disable_fm_index:
@@ -246,7 +247,13 @@ def fm_index_generate(
         processor = None
     enc = decoder.encode(input_ids, attention_mask)
     decoder.start(enc, attention_mask, num_beams, max_length)
-    steps, final = constrained_beam_search(
-        decoder, input_ids.shape[0], num_beams, max_length, model.config.decoder_start_token_id, eos_token_id,
-        constrained_decoding_processor=processor, device=input_ids.device)
+    saved_bias = decoder.logit_bias
+    if logit_bias is not None:
+        decoder.logit_bias = logit_bias
+    try:
+        steps, final = constrained_beam_search(
+            decoder, input_ids.shape[0], num_beams, max_length, model.config.decoder_start_token_id, eos_token_id,
+            constrained_decoding_processor=processor, device=input_ids.device)
+    finally:
+        decoder.logit_bias = saved_bias
     return _history_to_hypotheses(steps, final, input_ids.shape[0], num_beams, length_penalty)

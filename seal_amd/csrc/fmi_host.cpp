@@ -39,9 +39,11 @@ void fmi_release_device(fmi *h)
         for (void *p : h->dev_allocs) (void)hipFree(p);
         if (h->ws) (void)hipFree(h->ws);
         if (h->d_probe_counter) (void)hipFree(h->d_probe_counter);
+        if (h->service_stream) (void)hipStreamDestroy((hipStream_t)h->service_stream);
         for (void *e : h->ev_start) (void)hipEventDestroy((hipEvent_t)e);
         for (void *e : h->ev_stop) (void)hipEventDestroy((hipEvent_t)e);
     }
+    h->service_stream = nullptr;
     h->ev_start.clear(); h->ev_stop.clear(); h->ev_used = 0; h->timing_enabled = 0;
     h->dev_allocs.clear();
     h->ws = nullptr; h->ws_bytes = 0; h->ws_rows = 0;

@@ -60,6 +60,9 @@ struct fmi {
     int timing_enabled = 0;
     std::vector<void *> ev_start, ev_stop;   // hipEvent_t
     uint64_t ev_used = 0;
+    // non-blocking stream of the host-buffer API (fmi_<op>): its copies/kernels neither wait for nor
+    // stall the caller's (torch's) streams; index arrays are immutable so there is nothing to order
+    void *service_stream = nullptr;
 };
 
 void fmi_set_error(const char *fmt, ...);

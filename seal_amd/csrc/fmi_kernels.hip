@@ -430,6 +430,21 @@ static int need_device(fmi *h)
     return FMI_OK;
 }
 
+static int service_stream(fmi *h, hipStream_t *out)
+{
+    if (!h->service_stream) {
+        hipStream_t s;
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        h->service_stream = (void *)s;
+    }
+    *out = (hipStream_t)h->service_stream;
+    return FMI_OK;
+}
+
+// synchronous copies on the service stream (pageable host memory: staged by the runtime)
+#define COPY_H2D(dst, src, bytes) do { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, sst)); } while (0)
+#define COPY_D2H(dst, src, bytes) do { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, sst)); HIPCHK(hipStreamSynchronize(sst)); } while (0)
+
 static inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
 
 struct DevBuf {
@@ -697,16 +712,17 @@ extern "C" int fmi_backward_search_multi_batch(fmi_t *h, uint64_t n_seq, const u
 {
     int rc = need_device(h); if (rc) return rc;
     if (n_seq == 0) return FMI_OK;
+    hipStream_t sst; if ((rc = service_stream(h, &sst))) return rc;
     const uint64_t ntok = offsets[n_seq];
     DevBuf off, tok, res;
     if ((rc = off.alloc((n_seq + 1) * 8)) || (rc = tok.alloc(ntok * 8)) || (rc = res.alloc(n_seq * 16))) return rc;
-    HIPCHK(hipMemcpy(off.p, offsets, (n_seq + 1) * 8, hipMemcpyHostToDevice));
-    if (ntok) HIPCHK(hipMemcpy(tok.p, symbols, ntok * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL((k_get_range<uint64_t, uint64_t>), dim3(blocks_for(n_seq, 64)), dim3(64), 0, 0, h->dev, n_seq,
+    COPY_H2D(off.p, offsets, (n_seq + 1) * 8);
+    if (ntok) COPY_H2D(tok.p, symbols, ntok * 8);
+    hipLaunchKernelGGL((k_get_range<uint64_t, uint64_t>), dim3(blocks_for(n_seq, 64)), dim3(64), 0, sst, h->dev, n_seq,
                        off.as<uint64_t>(), tok.as<uint64_t>(), (int64_t)0, res.as<uint64_t>(), res.as<uint64_t>() + n_seq);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(lo_out, res.p, n_seq * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(hi_out, res.as<uint64_t>() + n_seq, n_seq * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(lo_out, res.p, n_seq * 8, hipMemcpyDeviceToHost, sst));
+    COPY_D2H(hi_out, res.as<uint64_t>() + n_seq, n_seq * 8);
     return FMI_OK;
 }
 
@@ -779,13 +795,14 @@ extern "C" int fmi_locate(fmi_t *h, uint64_t n, const uint64_t *rows, uint64_t *
     int rc = need_device(h); if (rc) return rc;
     if (n == 0) return FMI_OK;
     if (doc_out && !h->dev.doc_begin) { fmi_set_error("doc beginnings not set"); return FMI_ERR_STATE; }
+    hipStream_t sst; if ((rc = service_stream(h, &sst))) return rc;
     DevBuf b; if ((rc = b.alloc(n * 24))) return rc;
     uint64_t *d = b.as<uint64_t>();
-    HIPCHK(hipMemcpy(d, rows, n * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_locate, dim3(blocks_for(n, 256)), dim3(256), 0, 0, h->dev, n, d, d + n, doc_out ? d + 2 * n : (uint64_t *)nullptr);
+    COPY_H2D(d, rows, n * 8);
+    hipLaunchKernelGGL(k_locate, dim3(blocks_for(n, 256)), dim3(256), 0, sst, h->dev, n, d, d + n, doc_out ? d + 2 * n : (uint64_t *)nullptr);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(pos_out, d + n, n * 8, hipMemcpyDeviceToHost));
-    if (doc_out) HIPCHK(hipMemcpy(doc_out, d + 2 * n, n * 8, hipMemcpyDeviceToHost));
+    if (doc_out) HIPCHK(hipMemcpyAsync(doc_out, d + 2 * n, n * 8, hipMemcpyDeviceToHost, sst));
+    COPY_D2H(pos_out, d + n, n * 8);
     return FMI_OK;
 }
 

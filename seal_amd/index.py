@@ -194,6 +194,15 @@ class FMIndex(_FMIndex):
         check(lib().fmi_locate(self._h, len(r), _ptr(r), _ptr(pos), _ptr(doc)))
         return pos, doc
 
+    def _side_stream(self, dev):
+        """a non-default stream for the retrieval-side launches, so that they (and the host waiting
+        on them) do not queue behind the decoder's work on torch's current stream"""
+        import torch
+        st = self.__dict__.get("_svc_stream")
+        if st is None:
+            st = self.__dict__["_svc_stream"] = torch.cuda.Stream(device=dev)
+        return st
+
     def locate_ranges(self, lows, highs, max_per_range: int):
         """``locate`` + ``get_doc_index`` for the first ``max_per_range`` rows of many
         half-open row ranges (``islice(range(*get_range(ngram)), max_hits)``, reference
@@ -210,14 +219,15 @@ class FMIndex(_FMIndex):
         if total == 0:
             return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), offs
         dev = torch.device("cuda", lib().fmi_device(self._h))
-        d_lo = torch.from_numpy(lo).to(dev)
-        d_hi = torch.from_numpy(hi).to(dev)
-        d_off = torch.from_numpy(offs).to(dev)
-        out = torch.empty(2, total, dtype=torch.int64, device=dev)
-        check(lib().fmi_dev_locate_ranges(self._h, torch.cuda.current_stream(dev).cuda_stream, len(lo), d_lo.data_ptr(),
-                                          d_hi.data_ptr(), int(max_per_range), d_off.data_ptr(), total,
-                                          out[0].data_ptr(), out[1].data_ptr()))
-        res = out.cpu().numpy()
+        st = self._side_stream(dev)
+        with torch.cuda.stream(st):
+            d_lo = torch.from_numpy(lo).to(dev, non_blocking=True)
+            d_hi = torch.from_numpy(hi).to(dev, non_blocking=True)
+            d_off = torch.from_numpy(offs).to(dev, non_blocking=True)
+            out = torch.empty(2, total, dtype=torch.int64, device=dev)
+            check(lib().fmi_dev_locate_ranges(self._h, st.cuda_stream, len(lo), d_lo.data_ptr(), d_hi.data_ptr(),
+                                              int(max_per_range), d_off.data_ptr(), total, out[0].data_ptr(), out[1].data_ptr()))
+            res = out.cpu().numpy()
         return res[0], res[1], offs
 
     def get_docs_batch(self, doc_indices) -> List[List[int]]:
@@ -231,12 +241,14 @@ class FMIndex(_FMIndex):
         offs = np.zeros(len(docs) + 1, dtype=np.int64)
         np.cumsum(lens, out=offs[1:])
         dev = torch.device("cuda", lib().fmi_device(self._h))
-        d_docs = torch.from_numpy(docs).to(dev)
-        d_off = torch.from_numpy(offs).to(dev)
-        out = torch.empty(max(int(offs[-1]), 1), dtype=torch.int64, device=dev)
-        check(lib().fmi_dev_get_docs(self._h, torch.cuda.current_stream(dev).cuda_stream, len(docs), d_docs.data_ptr(),
-                                     d_off.data_ptr(), SHIFT, out.data_ptr()))
-        flat = out.cpu().numpy()
+        st = self._side_stream(dev)
+        with torch.cuda.stream(st):
+            d_docs = torch.from_numpy(docs).to(dev, non_blocking=True)
+            d_off = torch.from_numpy(offs).to(dev, non_blocking=True)
+            out = torch.empty(max(int(offs[-1]), 1), dtype=torch.int64, device=dev)
+            check(lib().fmi_dev_get_docs(self._h, st.cuda_stream, len(docs), d_docs.data_ptr(), d_off.data_ptr(), SHIFT,
+                                         out.data_ptr()))
+            flat = out.cpu().numpy()
         return [flat[offs[i]:offs[i + 1]].tolist() for i in range(len(docs))]
 
     # -- device-pointer forms (torch tensors on the index's GPU) -------------

@@ -104,9 +104,11 @@ def _chunks(it, size):
 
 def batch_generate_keys(searcher, queries, constrained_generation=True):
     """Generator of per-query keys (reference retrieval.py:49-312)."""
+    offset = 0
     for batch in _chunks(queries, searcher.batch_size):
-        for instance in _process_batch(searcher, batch, constrained_generation):
+        for instance in _process_batch(searcher, batch, constrained_generation, offset):
             yield instance
+        offset += len(batch)
 
 
 def _count_filter(index: FMIndex, per_query: List[List]) -> List[List]:
@@ -124,8 +126,11 @@ def _count_filter(index: FMIndex, per_query: List[List]) -> List[List]:
     return out
 
 
-def _process_batch(searcher, inputs, constrained_generation):
+def _process_batch(searcher, inputs, constrained_generation, offset=0):
     s = searcher
+    bias = s.logit_bias
+    if bias is not None and bias.shape[0] != len(inputs):
+        bias = bias[offset:offset + len(inputs)]      # one row per query of the whole call
     tokenised = not isinstance(inputs[0], str)
     if tokenised:
         base_tokens = [list(q) for q in inputs]
@@ -161,7 +166,8 @@ def _process_batch(searcher, inputs, constrained_generation):
             s.bart_model, s.fm_index, **encoder_batch(strs, toks),
             min_length=s.length, max_length=s.length, length_penalty=s.length_penalty, num_beams=s.beam,
             disable_fm_index=not constrained_generation, diverse_bs_groups=s.diverse_bs_groups,
-            diverse_bs_penalty=s.diverse_bs_penalty, stop_at_count=s.stop_at_count, keep_history=True, topk=s.topk)
+            diverse_bs_penalty=s.diverse_bs_penalty, stop_at_count=s.stop_at_count, keep_history=True, topk=s.topk,
+            logit_bias=bias)
         for fk in found_keys:   # retrieval.py:85-90
             fk[:] = [(sc, k[1:] if k[0] in strip_ids else k) for sc, k in fk if k]
             fk[:] = [(sc, k[1:] if k[0] in strip_ids else k) for sc, k in fk if k]
@@ -172,7 +178,7 @@ def _process_batch(searcher, inputs, constrained_generation):
         if s.rescore and s.use_markers:
             found_keys = rk.rescore_keys(
                 s.bart_model, base_tokens, found_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
-                strip_from_eos=[s.title_eos_token_id, s.code_eos_token_id, s.bart_model.config.eos_token_id], logit_bias=s.logit_bias)
+                strip_from_eos=[s.title_eos_token_id, s.code_eos_token_id, s.bart_model.config.eos_token_id], logit_bias=bias)
     else:
         found_keys = [[] for _ in inputs]
 
@@ -195,7 +201,7 @@ def _process_batch(searcher, inputs, constrained_generation):
             min_length=1, max_length=15, num_beams=s.beam, length_penalty=s.length_penalty,
             force_decoding_from=[s.title_bos_token_id], eos_token_id=s.title_eos_token_id,
             diverse_bs_groups=s.diverse_bs_groups, diverse_bs_penalty=s.diverse_bs_penalty, keep_history=True,
-            disable_fm_index=not constrained_generation, topk=s.topk)
+            disable_fm_index=not constrained_generation, topk=s.topk, logit_bias=bias)
         title_keys = [[(sc, hyp) for sc, hyp in dec] for dec in decoded]
         for fk in title_keys:   # retrieval.py:180-190
             if s.force_decoding_second_token >= 0:
@@ -210,7 +216,7 @@ def _process_batch(searcher, inputs, constrained_generation):
         if s.rescore and s.use_markers:
             title_keys = rk.rescore_keys(
                 s.bart_title_model, toks, title_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
-                strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=s.logit_bias)
+                strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=bias)
         for nfk, fk in zip(title_keys, found_keys):
             fk += nfk
 
@@ -228,7 +234,7 @@ def _process_batch(searcher, inputs, constrained_generation):
         _, toks = marked("body")
         unigram = rk.compute_unigram_scores(
             s.bart_scorer_model, toks, s.fm_index,
-            prefix=[s.force_decoding_second_token] if s.force_decoding_second_token >= 0 else [], logit_bias=s.logit_bias,
+            prefix=[s.force_decoding_second_token] if s.force_decoding_second_token >= 0 else [], logit_bias=bias,
             tolist=False)
         # one D2H copy; float64 views of the fp32 log-probs == what .tolist() would hold
         unigram = unigram.double().cpu().numpy()
@@ -488,7 +494,10 @@ class SEALSearcher:
         if self.jobs >= 2:
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=int(self.jobs)) as pool:
-                yield from pool.map(self.retrieve_from_keys, list(keys))
+                # Executor.map pulls `keys` (a generator: decoding of the NEXT chunk on the GPU) in this
+                # thread while the workers aggregate the chunks already produced -- the producer /
+                # consumer overlap the reference gets from Pool.imap (retrieval.py:766)
+                yield from pool.map(self.retrieve_from_keys, keys)
         else:
             for kk in keys:
                 yield self.retrieve_from_keys(kk)
