@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--beam", type=int, default=15)
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--cpu-threads", type=int, default=64)
-    ap.add_argument("--jobs", type=int, default=4, help="host threads over queries for evidence aggregation")
+    ap.add_argument("--jobs", type=int, default=1, help="host threads over queries for evidence aggregation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -260,17 +260,17 @@ def main():
     def run_batch(i):
         return run_batches(i, 1)
 
+    # the index keeps `beginnings` as a 21M-element python list (reference API); keep the cyclic GC
+    # from re-scanning it (and the model) on every full collection
+    import gc
+    gc.collect()
+    gc.freeze()
     step_ms = []                                          # un-pipelined single-batch latency
     for i in range(args.warmup):
         t1 = time.perf_counter()
         run_batch(i)
         torch.cuda.synchronize()
         step_ms.append((time.perf_counter() - t1) * 1e3)
-    # the index keeps `beginnings` as a 21M-element python list (reference API); keep the cyclic GC
-    # from re-scanning it (and the model) on every full collection
-    import gc
-    gc.collect()
-    gc.freeze()
     import ctypes
     probes = ctypes.c_uint64()
     launches, kms = ctypes.c_uint64(), ctypes.c_double()

@@ -214,6 +214,10 @@ int fmi_evidence_read(const fmi_evidence_t *ev, int64_t *doc, double *score, int
                       int64_t *key_off, int32_t *key_idx, double *key_score);
 void fmi_evidence_free(fmi_evidence_t *ev);
 
+/* (sr + log(1-exp(snr))) - (snr + log(1-exp(sr))), snr = log((count+smoothing)/(ntokens+smoothing)), 0 where
+ * count == 0 -- seal/keys.py:221-224,258-261 for n pairs, libm doubles (what python's math module calls). */
+int fmi_log_odds_batch(uint64_t n, const double *sr, const int64_t *count, double ntokens, double smoothing, double *out);
+
 #ifdef __cplusplus
 }
 #endif

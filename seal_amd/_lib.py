@@ -60,6 +60,7 @@ SIGNATURES = {
     "fmi_evidence_entries": (_u64, [_vp]),
     "fmi_evidence_read": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fmi_evidence_free": (None, [_vp]),
+    "fmi_log_odds_batch": (_int, [_u64, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp]),
 }
 
 _lib = None

@@ -205,3 +205,20 @@ extern "C" int fmi_evidence_read(const fmi_evidence *ev, int64_t *doc, double *s
 }
 
 extern "C" void fmi_evidence_free(fmi_evidence *ev) { delete ev; }
+
+// LM-vs-corpus log-odds of seal/keys.py:219-227 / 257-262 for many (score, count) pairs.  Python's
+// math.log / math.exp are libm's log / exp on doubles, so this loop is bit-identical to the
+// reference's per-key python arithmetic (-ffp-contract=off: no fused multiply-add).
+#include <cmath>
+extern "C" int fmi_log_odds_batch(uint64_t n, const double *sr, const int64_t *count, double ntokens, double smoothing,
+                                  double *out)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        if (count[i] == 0) { out[i] = 0.0; continue; }
+        const double snr = std::log(((double)count[i] + smoothing) / (ntokens + smoothing));
+        const double a = sr[i] + std::log(1 - std::exp(snr));
+        const double b = snr + std::log(1 - std::exp(sr[i]));
+        out[i] = a - b;
+    }
+    return FMI_OK;
+}

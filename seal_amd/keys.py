@@ -220,6 +220,18 @@ def _log_odds(sr: float, count: int, ntokens: float, smoothing: float) -> float:
     return (sr + math.log(1 - math.exp(snr))) - (snr + math.log(1 - math.exp(sr)))
 
 
+def _log_odds_many(sr: np.ndarray, counts: np.ndarray, ntokens: float, smoothing: float) -> np.ndarray:
+    """``_log_odds`` for arrays through libsealfm (libm log/exp on doubles == python's math module)."""
+    import ctypes
+    from ._lib import check, lib
+    sr = np.ascontiguousarray(sr, dtype=np.float64)
+    cnt = np.ascontiguousarray(counts, dtype=np.int64)
+    out = np.empty(sr.shape[0], dtype=np.float64)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    check(lib().fmi_log_odds_batch(sr.shape[0], p(sr), p(cnt), float(ntokens), float(smoothing), p(out)))
+    return out
+
+
 def _unigram_counts(index) -> np.ndarray:
     """``get_count([i])`` for every token id, one launch, cached on the index."""
     cache = getattr(index, "_unigram_count_cache", None)
@@ -455,19 +467,15 @@ def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_o
             best = np.concatenate([above, ties])
         uni_counts = _unigram_counts(index)
         us = np.zeros(V, dtype=np.float64)
-        for i in best.tolist():
-            if i in seen_unigrams:
-                continue
-            count = int(uni_counts[i]) if i < len(uni_counts) else 0
-            if count == 0:
-                continue
-            sr = float(raw[i])
+        cand = best[~np.isin(best, np.fromiter(seen_unigrams, dtype=np.int64))]
+        cand = cand[cand < len(uni_counts)]
+        cand = cand[uni_counts[cand] > 0]
+        if cand.size:
             if use_fm_index_frequency:
-                sco = max(_log_odds(sr, count, ntokens, smoothing), 0.0)
+                sco = np.maximum(_log_odds_many(raw[cand], uni_counts[cand], ntokens, smoothing), 0.0)
             else:
-                sco = max(sr - cutoff, 0.0) ** alpha
-            if sco != 0.0:
-                us[i] = sco
+                sco = np.maximum(raw[cand] - cutoff, 0.0) ** alpha
+            us[cand] = sco
         unigram_scores = us          # indexable by token id like the reference's list
         if add_best_unigrams_to_ngrams:
             # sorted(range(V), key=lambda x: -unigram_scores[x])[:n]: positives by descending score
