@@ -426,10 +426,10 @@ class SEALSearcher:
                 keys = ((kk, us, added_documents[i]) for i, (kk, us) in enumerate(keys))
             else:
                 keys = ((kk, None, added_documents[i]) for i, kk in enumerate(keys))
-        results, _ = zip(*self.batch_retrieve_from_keys(keys))
         key_info = {}
         retrieved = []
-        for query, res in zip(queries, results):
+        # streamed: a query's (up to fully_score) ranked documents are cut to k as soon as they arrive
+        for query, (res, _) in zip(queries, self.batch_retrieve_from_keys(keys)):
             docs = []
             for idx, info in islice(res.items(), k):
                 score, kk, full = info[0], info[1], (info[3] if len(info) == 5 else None)
