@@ -498,7 +498,8 @@ extern "C" int fmi_dev_get_range(fmi_t *h, void *stream, uint64_t n_seq, const i
 
 // workspace = expansion items + allowed-token bitmap (vocab <= 2^17 -> 4096 words/row)
 static constexpr uint64_t WS_BITS_WORDS = (1ull << FMI_MAX_LEVELS) / 32;
-static constexpr uint64_t WS_QUEUE_PER_ROW = 1ull << EXP_SPLIT_LEVEL;
+static constexpr uint32_t EXP_SPLIT_MAX = 10;
+static constexpr uint64_t WS_QUEUE_PER_ROW = 1ull << EXP_SPLIT_MAX;     // room for any split level up to EXP_SPLIT_MAX
 // layout: items[rows] | queue[rows * 64] | bits[rows * WS_BITS_WORDS] | counter
 static inline ExpandItem *ws_items(fmi *h) { return (ExpandItem *)h->ws; }
 static inline ExpandItem *ws_queue(fmi *h) { return ws_items(h) + h->ws_rows; }
@@ -585,7 +586,9 @@ static int launch_expand(fmi *h, hipStream_t st, ExpandItem *items, uint64_t row
 {
     const uint32_t L = h->levels;
     uint64_t *pc = h->probe_count_enabled ? h->d_probe_counter : nullptr;
-    const uint32_t split = (L > EXP_SPLIT_LEVEL + 2 && queue) ? EXP_SPLIT_LEVEL : L;   // shallow trees: single phase
+    static const char *e_split = getenv("SEALFM_SPLIT");
+    const uint32_t want = e_split ? std::min<uint32_t>((uint32_t)atoi(e_split), EXP_SPLIT_MAX) : EXP_SPLIT_LEVEL;
+    const uint32_t split = (L > want + 2 && queue && qcap >= (rows << want)) ? want : L;   // shallow trees: single phase
     if (split < L) HIPCHK(hipMemsetAsync(qcount, 0, 4, st));
     static const char *e_wide = getenv("SEALFM_WIDE_ROWS"), *e_nlev = getenv("SEALFM_P1_NLEV");   // tuning knobs
     const uint64_t wide = e_wide ? strtoull(e_wide, nullptr, 10) : EXP_WIDE_ROWS;
