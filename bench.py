@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--beam", type=int, default=15)
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--cpu-threads", type=int, default=64)
-    ap.add_argument("--jobs", type=int, default=1, help="host threads over queries for evidence aggregation")
+    ap.add_argument("--jobs", type=int, default=8, help="host worker processes for the first-stage bookkeeping")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

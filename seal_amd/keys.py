@@ -335,6 +335,27 @@ def _first_stage_native(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps,
             for i in range(nd)]
 
 
+def _first_stage_job(payload):
+    """picklable unit of work for a host worker process: the native first stage of ONE query,
+    returning its top ``keep`` documents with materialised key lists (no GPU involved)."""
+    rare_keys, scores, offs, pos_all, doc_all, allow_overlaps, beta, single_key, n_top, keep = payload
+    rare = dict(zip(rare_keys, scores))
+    ranked = _first_stage_native(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps, beta, single_key, n_top)
+    if keep is not None:
+        ranked = ranked[:keep]
+    return [(d, [info[0], list(info[1]), info[2]]) for d, info in ranked]
+
+
+class _Deferred:
+    """result of a first stage running in a worker process; ``result()`` -> {doc: info}"""
+
+    def __init__(self, future):
+        self._future = future
+
+    def result(self):
+        return dict(self._future.result())
+
+
 def _first_stage_python(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps, beta, single_key, n_docs_complete_score,
                         sort_by_length, sort_by_freq, count_of):
     """reference keys.py:311-367, python (kept for the sort_by_length / sort_by_freq orders)."""
@@ -406,8 +427,14 @@ def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_o
                        beta: float = 0.8, length_penalty: float = 0.0, use_fm_index_frequency: bool = True,
                        add_best_unigrams_to_ngrams: bool = False, use_top_k_unigrams=1000, sort_by_length=False,
                        sort_by_freq=False, smoothing=5.0, allow_overlaps=False, single_key=0.0,
-                       single_key_add_unigrams=False, unigrams_ignore_free_places=False, first_stage_only=False):
+                       single_key_add_unigrams=False, unigrams_ignore_free_places=False, first_stage_only=False,
+                       defer=None, keep=None):
     """Drop-in for ``seal.keys.aggregate_evidence`` (reference keys.py:178-497).
+
+    ``defer`` (an ``concurrent.futures`` executor) + ``first_stage_only``: the GPU part (counts,
+    locate, doc binning) runs here, the host bookkeeping of the first stage is submitted to the
+    executor and ``results`` is a handle whose ``result()`` gives the dict; ``keep`` truncates the
+    ranking to its first ``keep`` documents.
 
     Returns ``(results, all_ngrams)``: ``results`` maps doc index ->
     ``[score, [(ngram, score)...], None, doc_tokens, [best_ngram, best_score]]``
@@ -518,6 +545,10 @@ def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_o
         pos_all = doc_all = np.zeros(0, dtype=np.int64)
         offs = np.zeros(1, dtype=np.int64)
 
+    if defer is not None and first_stage_only and not (sort_by_length or sort_by_freq):
+        payload = (rare_keys, [rare[k] for k in rare_keys], np.asarray(offs), np.asarray(pos_all), np.asarray(doc_all),
+                   allow_overlaps, beta, single_key, n_docs_complete_score, keep)
+        return _Deferred(defer.submit(_first_stage_job, payload)), all_ngrams
     if not (sort_by_length or sort_by_freq):
         # native host routine (libsealfm fmi_first_stage): same bookkeeping, same float64
         # operation order, ~100x faster than the python loop below
@@ -527,7 +558,7 @@ def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_o
         ranked = _first_stage_python(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps, beta, single_key,
                                      n_docs_complete_score, sort_by_length, sort_by_freq, count_of)
     if first_stage_only:
-        return dict(ranked), all_ngrams
+        return dict(ranked[:keep] if keep is not None else ranked), all_ngrams
 
     # ---- full scoring of the top documents (keys.py:366-497) ----
     trie: dict = {}

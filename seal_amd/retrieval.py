@@ -429,7 +429,7 @@ class SEALSearcher:
         key_info = {}
         retrieved = []
         # streamed: a query's (up to fully_score) ranked documents are cut to k as soon as they arrive
-        for query, (res, _) in zip(queries, self.batch_retrieve_from_keys(keys)):
+        for query, (res, _) in zip(queries, self.batch_retrieve_from_keys(keys, keep=k)):
             docs = []
             for idx, info in islice(res.items(), k):
                 score, kk, full = info[0], info[1], (info[3] if len(info) == 5 else None)
@@ -468,7 +468,19 @@ class SEALSearcher:
     def batch_generate_keys(self, queries):
         return batch_generate_keys(self, queries, constrained_generation=not self.free_generation)
 
-    def retrieve_from_keys(self, keys):
+    def _host_pool(self):
+        """``jobs`` worker PROCESSES for the host-side first stage (the reference forks ``jobs``
+        processes over queries, retrieval.py:762-775; here only the GPU-free bookkeeping is shipped,
+        the index never leaves the GPU).  Spawned once, reused across calls."""
+        pool = self.__dict__.get("_pool")
+        if pool is None:
+            import multiprocessing
+            from concurrent.futures import ProcessPoolExecutor
+            pool = ProcessPoolExecutor(max_workers=int(self.jobs), mp_context=multiprocessing.get_context("spawn"))
+            self.__dict__["_pool"] = pool
+        return pool
+
+    def retrieve_from_keys(self, keys, defer=None, keep=None):
         """reference retrieval.py:720-754"""
         unigram_scores = None
         if isinstance(keys, tuple) and len(keys) == 1:
@@ -485,22 +497,21 @@ class SEALSearcher:
             add_best_unigrams_to_ngrams=self.add_best_unigrams_to_ngrams, use_top_k_unigrams=self.use_top_k_ngrams,
             sort_by_length=self.sort_by_length, sort_by_freq=self.sort_by_freq, smoothing=self.smoothing,
             allow_overlaps=self.allow_overlaps, single_key=self.single_key,
-            unigrams_ignore_free_places=self.unigrams_ignore_free_places, first_stage_only=self.first_stage_only)
+            unigrams_ignore_free_places=self.unigrams_ignore_free_places, first_stage_only=self.first_stage_only,
+            defer=defer, keep=keep)
 
-    def batch_retrieve_from_keys(self, keys):
-        """The reference forks ``jobs`` processes over queries (retrieval.py:762-775).  Here the
-        index work of a query is a handful of GPU launches and a native host routine, both of
-        which release the GIL, so ``jobs`` threads suffice."""
-        if self.jobs >= 2:
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=int(self.jobs)) as pool:
-                # Executor.map pulls `keys` (a generator: decoding of the NEXT chunk on the GPU) in this
-                # thread while the workers aggregate the chunks already produced -- the producer /
-                # consumer overlap the reference gets from Pool.imap (retrieval.py:766)
-                yield from pool.map(self.retrieve_from_keys, keys)
+    def batch_retrieve_from_keys(self, keys, keep=None):
+        """With ``jobs >= 2`` and ``first_stage_only`` the host bookkeeping of each query runs in a
+        worker process while this thread keeps the GPU busy with the next queries (key generation is a
+        lazy generator, as in the reference's ``Pool.imap`` pipeline, retrieval.py:766)."""
+        if self.jobs >= 2 and self.first_stage_only:
+            pool = self._host_pool()
+            pending = [self.retrieve_from_keys(kk, defer=pool, keep=keep) for kk in keys]
+            for res, ngrams in pending:
+                yield (res.result() if hasattr(res, "result") else res), ngrams
         else:
             for kk in keys:
-                yield self.retrieve_from_keys(kk)
+                yield self.retrieve_from_keys(kk, keep=keep if self.first_stage_only else None)
 
     def doc(self, docid: Union[str, int]) -> Optional[SEALDocument]:
         idx = self.docid2idx[docid] if isinstance(docid, str) else docid

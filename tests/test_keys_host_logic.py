@@ -77,3 +77,27 @@ def test_rescore_keys_prefix_sharing_matches_row_per_key():
             assert [k for _, k in qa] == [k for _, k in qb]
             for (sa, _), (sb, _) in zip(qa, qb):
                 assert abs(sa - sb) <= 2e-5 * max(1.0, abs(sb)), kw
+
+
+def test_deferred_first_stage_in_a_worker_process_matches_inline():
+    import multiprocessing
+    from concurrent.futures import ProcessPoolExecutor
+    vocab = 60
+    rng = np.random.default_rng(3)
+    docs = make_docs(3, 120, vocab, min_len=6, max_len=20, title_sep=7)
+    orc = OracleFMIndex()
+    orc.initialize(docs)
+    keys = synthetic_keys(rng, docs, vocab, with_titles=True)
+    us = (-rng.random(vocab) * 8 - 0.01).tolist()
+    kw = dict(unigram_scores=us, index=OracleBatchIndex(orc), first_stage_only=True, add_best_unigrams_to_ngrams=True,
+              use_top_k_unigrams=30)
+    inline, ng1 = aggregate_evidence(keys, **kw)
+    with ProcessPoolExecutor(max_workers=1, mp_context=multiprocessing.get_context("spawn")) as pool:
+        handle, ng2 = aggregate_evidence(keys, defer=pool, keep=7, **kw)
+        got = handle.result()
+    assert list(ng1.items()) == list(ng2.items())
+    want = list(inline.items())[:7]
+    assert [d for d, _ in want] == list(got.keys())
+    for d, info in want:
+        assert got[d][0] == info[0] and [(tuple(n), s) for n, s in got[d][1]] == [(tuple(n), s) for n, s in info[1]]
+        assert tuple(got[d][2][0]) == tuple(info[2][0]) and got[d][2][1] == info[2][1]
