@@ -232,30 +232,52 @@ def _log_odds_many(sr: np.ndarray, counts: np.ndarray, ntokens: float, smoothing
     return out
 
 
-def _unigram_counts(index) -> np.ndarray:
-    """``get_count([i])`` for every token id, one launch, cached on the index."""
-    cache = getattr(index, "_unigram_count_cache", None)
+def _unigram_ranges(index):
+    """``get_range([i])`` for every token id, one launch, cached on the index."""
+    cache = getattr(index, "_unigram_range_cache", None)
     if cache is None:
         vocab = max(index.occurring_distinct) + 1 if index.occurring_distinct else 1
-        cache = np.asarray(index.get_count_batch([[t] for t in range(vocab)]), dtype=np.int64)
-        index._unigram_count_cache = cache
+        lo, hi = index.get_range_batch([[t] for t in range(vocab)])
+        cache = (np.asarray(lo, dtype=np.int64), np.asarray(hi, dtype=np.int64))
+        index._unigram_range_cache = cache
     return cache
+
+
+def _unigram_counts(index) -> np.ndarray:
+    """``get_count([i])`` for every token id (cached)."""
+    lo, hi = _unigram_ranges(index)
+    return hi - lo
 
 
 class _Counts:
     """memo of ``index.get_count`` filled by batched launches."""
 
-    def __init__(self, index):
+    def __init__(self, index, shared=None):
         self.index = index
         self.memo: Dict[Tuple[int, ...], int] = {}
         self.ranges: Dict[Tuple[int, ...], Tuple[int, int]] = {}
+        self.shared = shared          # ranges prefetched for a whole batch of queries: {tuple: (lo, hi)}
 
     def ensure(self, ngrams) -> None:
-        todo = []
+        todo, seen = [], set()
+        uni = None
         for ng in ngrams:
             t = tuple(ng)
-            if t not in self.memo and t not in todo:
-                todo.append(t)
+            if t in self.memo or t in seen:
+                continue
+            if self.shared is not None and t in self.shared:
+                self.ranges[t] = self.shared[t]
+                self.memo[t] = self.shared[t][1] - self.shared[t][0]
+                continue
+            if len(t) == 1:               # single tokens come from the per-index table
+                if uni is None:
+                    uni = _unigram_ranges(self.index)
+                if 0 <= t[0] < len(uni[0]):
+                    self.ranges[t] = (int(uni[0][t[0]]), int(uni[1][t[0]]))
+                    self.memo[t] = self.ranges[t][1] - self.ranges[t][0]
+                    continue
+            seen.add(t)
+            todo.append(t)
         if not todo:
             return
         lo, hi = self.index.get_range_batch([list(t) for t in todo])
@@ -442,6 +464,88 @@ def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_o
     after the first stage + repetition re-weighting and returns the
     ``to_fully_score`` ranking as ``{doc: [score, [[ngram, score]...], [best_ngram, best_score]]}``.
     """
+    gen = _aggregate_steps(ngrams_and_scores, unigram_scores, index, max_occurrences_1, max_occurrences_2,
+                           n_docs_complete_score, alpha, beta, length_penalty, use_fm_index_frequency,
+                           add_best_unigrams_to_ngrams, use_top_k_unigrams, sort_by_length, sort_by_freq, smoothing,
+                           allow_overlaps, single_key, single_key_add_unigrams, unigrams_ignore_free_places,
+                           first_stage_only, defer, keep)
+    try:
+        req = next(gen)
+        while True:
+            if req[0] == "locate":
+                req = gen.send(index.locate_ranges(req[1], req[2], req[3]))
+            else:
+                req = gen.send(index.get_docs_batch(req[1]))
+    except StopIteration as done:
+        return done.value
+
+
+def aggregate_evidence_batch(jobs, index, **params):
+    """``aggregate_evidence`` for several queries with the GPU work batched ACROSS them: one
+    backward-search launch for every key of every query, one locate launch for every rare key of
+    every query (and one document fetch when fully scoring).  ``jobs`` = list of
+    ``(ngrams_and_scores, unigram_scores)``; returns the list of ``(results, all_ngrams)``."""
+    all_keys, seen = [], set()
+    for ngrams_and_scores, _ in jobs:
+        for ng, _ in ngrams_and_scores:
+            t = tuple(ng.tolist() if isinstance(ng, torch.Tensor) else ng)
+            if t not in seen:
+                seen.add(t)
+                all_keys.append(t)
+    shared = {}
+    if all_keys:
+        lo, hi = index.get_range_batch([list(t) for t in all_keys])
+        shared = {t: (int(a), int(b)) for t, a, b in zip(all_keys, lo, hi)}
+    gens = [_aggregate_steps(nas, us, index, shared_ranges=shared, **params) for nas, us in jobs]
+    out = [None] * len(gens)
+    reqs = {}
+    for i, g in enumerate(gens):
+        try:
+            reqs[i] = next(g)
+        except StopIteration as done:
+            out[i] = done.value
+    while reqs:
+        loc = [i for i, r in reqs.items() if r[0] == "locate"]
+        answers = {}
+        if loc:
+            mx = reqs[loc[0]][3]
+            los = np.concatenate([np.asarray(reqs[i][1], dtype=np.int64) for i in loc])
+            his = np.concatenate([np.asarray(reqs[i][2], dtype=np.int64) for i in loc])
+            pos, doc, offs = index.locate_ranges(los, his, mx)
+            k0 = 0
+            for i in loc:
+                nk = len(reqs[i][1])
+                o = offs[k0:k0 + nk + 1]
+                answers[i] = (pos[o[0]:o[-1]], doc[o[0]:o[-1]], o - o[0])
+                k0 += nk
+        dcs = [i for i, r in reqs.items() if r[0] == "docs"]
+        if dcs:
+            flat = [d for i in dcs for d in reqs[i][1]]
+            fetched = index.get_docs_batch(flat)
+            k0 = 0
+            for i in dcs:
+                nd = len(reqs[i][1])
+                answers[i] = fetched[k0:k0 + nd]
+                k0 += nd
+        nxt = {}
+        for i, ans in answers.items():
+            try:
+                nxt[i] = gens[i].send(ans)
+            except StopIteration as done:
+                out[i] = done.value
+        reqs = nxt
+    return out
+
+
+def _aggregate_steps(ngrams_and_scores, unigram_scores=None, index=None, max_occurrences_1: int = 1500,
+                       max_occurrences_2: int = 10_000_000, n_docs_complete_score: int = 500, alpha: float = 2.0,
+                       beta: float = 0.8, length_penalty: float = 0.0, use_fm_index_frequency: bool = True,
+                       add_best_unigrams_to_ngrams: bool = False, use_top_k_unigrams=1000, sort_by_length=False,
+                       sort_by_freq=False, smoothing=5.0, allow_overlaps=False, single_key=0.0,
+                       single_key_add_unigrams=False, unigrams_ignore_free_places=False, first_stage_only=False,
+                       defer=None, keep=None, shared_ranges=None):
+    """generator form of ``aggregate_evidence``: yields ("locate", los, his, max) / ("docs", ids) requests
+    that a driver may batch across queries, receives their answers through ``send`` and returns the result."""
     def repetition(ngram_set, score, coverage):
         if not coverage:
             return score
@@ -451,7 +555,7 @@ def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_o
     ntokens = float(index.beginnings[-1])
     keys: List[Tuple[List[int], float]] = [
         (ng.tolist() if isinstance(ng, torch.Tensor) else list(ng), sr) for ng, sr in ngrams_and_scores]
-    count_of = _Counts(index)
+    count_of = _Counts(index, shared_ranges)
     count_of.memo[tuple()] = len(index)
     count_of.ensure([ng for ng, _ in keys])
     cutoff = None
@@ -540,7 +644,7 @@ def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_o
     if rare_keys:
         los = np.asarray([count_of.ranges[k][0] if k in count_of.ranges else 0 for k in rare_keys], dtype=np.uint64)
         his = np.asarray([count_of.ranges[k][1] if k in count_of.ranges else 0 for k in rare_keys], dtype=np.uint64)
-        pos_all, doc_all, offs = index.locate_ranges(los, his, max_occurrences_1)
+        pos_all, doc_all, offs = yield ("locate", los, his, max_occurrences_1)
     else:
         pos_all = doc_all = np.zeros(0, dtype=np.int64)
         offs = np.zeros(1, dtype=np.int64)
@@ -570,7 +674,7 @@ def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_o
             node = node.setdefault(t, {})
         node[-1] = score
     doc_ids = [d for d, _ in ranked]
-    fetched = index.get_docs_batch(doc_ids) if doc_ids else []
+    fetched = (yield ("docs", doc_ids)) if doc_ids else []
     results: Dict[int, list] = {}
     for doc, toks in zip(doc_ids, fetched):
         doc_tokens = [2] + list(toks)[:-1]

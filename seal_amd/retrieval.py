@@ -500,18 +500,42 @@ class SEALSearcher:
             unigrams_ignore_free_places=self.unigrams_ignore_free_places, first_stage_only=self.first_stage_only,
             defer=defer, keep=keep)
 
+    def _aggregate_params(self):
+        return dict(
+            max_occurrences_1=self.max_hits, n_docs_complete_score=self.fully_score, alpha=self.score_exponent,
+            beta=self.repetition_penalty, length_penalty=self.scoring_length_penalty,
+            use_fm_index_frequency=self.use_fm_index_frequency,
+            add_best_unigrams_to_ngrams=self.add_best_unigrams_to_ngrams, use_top_k_unigrams=self.use_top_k_ngrams,
+            sort_by_length=self.sort_by_length, sort_by_freq=self.sort_by_freq, smoothing=self.smoothing,
+            allow_overlaps=self.allow_overlaps, single_key=self.single_key,
+            unigrams_ignore_free_places=self.unigrams_ignore_free_places, first_stage_only=self.first_stage_only)
+
     def batch_retrieve_from_keys(self, keys, keep=None):
-        """With ``jobs >= 2`` and ``first_stage_only`` the host bookkeeping of each query runs in a
-        worker process while this thread keeps the GPU busy with the next queries (key generation is a
-        lazy generator, as in the reference's ``Pool.imap`` pipeline, retrieval.py:766)."""
-        if self.jobs >= 2 and self.first_stage_only:
-            pool = self._host_pool()
-            pending = [self.retrieve_from_keys(kk, defer=pool, keep=keep) for kk in keys]
-            for res, ngrams in pending:
-                yield (res.result() if hasattr(res, "result") else res), ngrams
-        else:
-            for kk in keys:
-                yield self.retrieve_from_keys(kk, keep=keep if self.first_stage_only else None)
+        """Queries are aggregated a chunk (``batch_size``) at a time with the index work batched across
+        the chunk (``aggregate_evidence_batch``).  With ``jobs >= 2`` and ``first_stage_only`` the
+        host bookkeeping of each query runs in a worker process while this thread keeps the GPU busy
+        with the next chunk (the producer/consumer overlap of the reference's ``Pool.imap``,
+        retrieval.py:766)."""
+        defer = self._host_pool() if (self.jobs >= 2 and self.first_stage_only) else None
+        keep = keep if self.first_stage_only else None
+        pending = []
+        for chunk in _chunks(keys, self.batch_size):
+            jobs = []
+            for kk in chunk:
+                if isinstance(kk, tuple) and len(kk) == 1:
+                    kk = (kk[0], None)
+                elif isinstance(kk, tuple) and len(kk) >= 2:
+                    kk = (kk[0], kk[1])
+                else:
+                    kk = (kk, None)
+                jobs.append(kk)
+            out = rk.aggregate_evidence_batch(jobs, self.fm_index, defer=defer, keep=keep, **self._aggregate_params())
+            if defer is None:
+                yield from out
+            else:
+                pending.extend(out)
+        for res, ngrams in pending:
+            yield (res.result() if hasattr(res, "result") else res), ngrams
 
     def doc(self, docid: Union[str, int]) -> Optional[SEALDocument]:
         idx = self.docid2idx[docid] if isinstance(docid, str) else docid

@@ -101,3 +101,25 @@ def test_deferred_first_stage_in_a_worker_process_matches_inline():
     for d, info in want:
         assert got[d][0] == info[0] and [(tuple(n), s) for n, s in got[d][1]] == [(tuple(n), s) for n, s in info[1]]
         assert tuple(got[d][2][0]) == tuple(info[2][0]) and got[d][2][1] == info[2][1]
+
+
+@pytest.mark.parametrize("first_stage_only", [True, False])
+def test_aggregate_evidence_batch_equals_per_query_calls(first_stage_only):
+    from seal_amd.keys import aggregate_evidence_batch
+    vocab = 60
+    rng = np.random.default_rng(11)
+    docs = make_docs(11, 150, vocab, min_len=6, max_len=20, title_sep=7)
+    orc = OracleFMIndex()
+    orc.initialize(docs)
+    jobs = []
+    for q in range(4):
+        keys = synthetic_keys(rng, docs, vocab, with_titles=True)
+        us = (-rng.random(vocab) * 8 - 0.01) if q != 2 else None
+        jobs.append((keys, us))
+    jobs.append(([], None))      # a query without keys
+    params = dict(first_stage_only=first_stage_only, add_best_unigrams_to_ngrams=True, use_top_k_unigrams=25,
+                  n_docs_complete_score=30, max_occurrences_1=40)
+    got = aggregate_evidence_batch(jobs, OracleBatchIndex(orc), **params)
+    for (keys, us), g in zip(jobs, got):
+        want = oracle_aggregate_evidence(keys, unigram_scores=None if us is None else us.tolist(), index=orc, **params)
+        _same(g, want)
