@@ -312,13 +312,14 @@ def main():
             phases[name] = phases.get(name, 0.0) + (time.perf_counter() - t) * 1e3
             return out
         return wrap
-    orig = (retrieval.fm_index_generate, rk.rescore_keys, rk.compute_unigram_scores, rk.aggregate_evidence, retrieval._count_filter)
+    orig = (retrieval.fm_index_generate, rk.rescore_keys, rk.compute_unigram_scores, rk.aggregate_evidence_batch, retrieval._count_filter)
     retrieval.fm_index_generate = timed("decode_ms", orig[0])
     rk.rescore_keys = timed("rescore_ms", orig[1])
     rk.compute_unigram_scores = timed("unigram_ms", orig[2])
-    rk.aggregate_evidence = timed("aggregate_ms", orig[3])
+    rk.aggregate_evidence_batch = timed("aggregate_ms", orig[3])
     retrieval._count_filter = timed("count_filter_ms", orig[4])
     index._trace = []
+    jobs_saved, searcher.jobs = searcher.jobs, 1          # inline first stage: its time shows up in aggregate_ms
     if os.environ.get("SEAL_BENCH_PROFILE"):
         import cProfile, pstats
         pr = cProfile.Profile()
@@ -329,7 +330,8 @@ def main():
     else:
         run_batch(args.warmup + args.steps)
     trace, index._trace = index._trace, None
-    retrieval.fm_index_generate, rk.rescore_keys, rk.compute_unigram_scores, rk.aggregate_evidence, retrieval._count_filter = orig
+    searcher.jobs = jobs_saved
+    retrieval.fm_index_generate, rk.rescore_keys, rk.compute_unigram_scores, rk.aggregate_evidence_batch, retrieval._count_filter = orig
     p2, l2, k2 = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
     check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(p2)))
     check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(l2), ctypes.byref(k2)))
