@@ -357,6 +357,11 @@ def main():
         t0 = time.perf_counter()
         orc = build_cpu_oracle(index, threads)
         log(f"cpu oracle index (sdsl-style wt_int + rank_support_v, SA/32, ISA/64) built in {time.perf_counter() - t0:.1f}s with {threads} threads")
+        # the reference also issues get_count([i]) for the use_top_k_ngrams=5000 best unigrams of every
+        # query (keys.py:236-272); here those come from a per-index table, so add them to the replay
+        rng = np.random.default_rng(5)
+        occ = np.asarray(index.occurring_distinct)
+        trace.append(("ranges", [[int(t)] for t in rng.choice(occ, size=5000 * args.batch)]))
         rep = replay_on_cpu(orc, trace, index.beginnings, threads)
         t_cpu = rep["mask_s"] + rep["ranges_s"] + rep["locate_s"]
         cpu = {"value": round(args.batch / t_cpu, 3), "unit": "queries/s (FM-index path only)", "cores": threads, "kind": "port",
