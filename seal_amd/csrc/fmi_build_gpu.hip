@@ -22,6 +22,7 @@
 #include <rocprim/functional.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "fmi_device.h"
@@ -62,8 +63,8 @@ __global__ void k_make_text(const uint32_t *data, uint64_t n, SymT *text)
     GRID_STRIDE(i, n) text[i] = (i + 1 < n) ? (SymT)data[i] : (SymT)0;   // sdsl appends the 0 sentinel
 }
 
-template <typename SymT>
-__global__ void k_pack_keys(const SymT *text, uint64_t n, uint32_t bits, uint32_t per, uint64_t *keys, uint32_t *idx)
+template <typename SymT, typename IdxT>
+__global__ void k_pack_keys(const SymT *text, uint64_t n, uint32_t bits, uint32_t per, uint64_t *keys, IdxT *idx)
 {
     GRID_STRIDE(i, n) {
         uint64_t key = 0;
@@ -72,17 +73,40 @@ __global__ void k_pack_keys(const SymT *text, uint64_t n, uint32_t bits, uint32_
             key = (key << bits) | s;
         }
         keys[i] = key;
-        idx[i] = (uint32_t)i;
+        idx[i] = (IdxT)i;
     }
 }
 
 // head[j] = j if sorted key j starts a new group else 0 (max-scanned into group starts)
-__global__ void k_heads(const uint64_t *keys, uint64_t n, uint32_t *gs)
+template <typename IdxT>
+__global__ void k_heads(const uint64_t *keys, uint64_t n, IdxT *gs)
 {
-    GRID_STRIDE(j, n) gs[j] = (j == 0 || keys[j] != keys[j - 1]) ? (uint32_t)j : 0u;
+    GRID_STRIDE(j, n) gs[j] = (j == 0 || keys[j] != keys[j - 1]) ? (IdxT)j : (IdxT)0;
 }
 
-__global__ void k_scatter_rank(const uint32_t *sa, const uint32_t *gs, uint64_t n, uint32_t *rank, unsigned long long *n_groups)
+// two-key form (n >= 2^32: the (rank, rank+h) pair no longer fits one 64-bit key)
+template <typename IdxT>
+__global__ void k_heads2(const IdxT *sa, const IdxT *rank, uint64_t n, uint64_t h, IdxT *gs)
+{
+    GRID_STRIDE(j, n) {
+        bool head = (j == 0);
+        if (!head) {
+            const uint64_t p = sa[j], q = sa[j - 1];
+            const uint64_t p2 = (p + h < n) ? (uint64_t)rank[p + h] : 0, q2 = (q + h < n) ? (uint64_t)rank[q + h] : 0;
+            head = rank[p] != rank[q] || p2 != q2;
+        }
+        gs[j] = head ? (IdxT)j : (IdxT)0;
+    }
+}
+
+template <typename IdxT>
+__global__ void k_key_of(const IdxT *sa, const IdxT *rank, uint64_t n, uint64_t h, uint64_t *keys)
+{
+    GRID_STRIDE(j, n) { const uint64_t p = (uint64_t)sa[j] + h; keys[j] = (p < n) ? (uint64_t)rank[p] : 0; }
+}
+
+template <typename IdxT>
+__global__ void k_scatter_rank(const IdxT *sa, const IdxT *gs, uint64_t n, IdxT *rank, unsigned long long *n_groups)
 {
     unsigned long long local = 0;
     GRID_STRIDE(j, n) {
@@ -94,7 +118,8 @@ __global__ void k_scatter_rank(const uint32_t *sa, const uint32_t *gs, uint64_t 
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(n_groups, local);
 }
 
-__global__ void k_pair_keys(const uint32_t *sa, const uint32_t *rank, uint64_t n, uint64_t h, uint32_t bits, uint64_t *keys)
+template <typename IdxT>
+__global__ void k_pair_keys(const IdxT *sa, const IdxT *rank, uint64_t n, uint64_t h, uint32_t bits, uint64_t *keys)
 {
     GRID_STRIDE(j, n) {
         const uint64_t p = sa[j];
@@ -103,8 +128,8 @@ __global__ void k_pair_keys(const uint32_t *sa, const uint32_t *rank, uint64_t n
     }
 }
 
-template <typename SymT>
-__global__ void k_bwt(const SymT *text, const uint32_t *sa, uint64_t n, SymT *bwt)
+template <typename SymT, typename IdxT>
+__global__ void k_bwt(const SymT *text, const IdxT *sa, uint64_t n, SymT *bwt)
 {
     GRID_STRIDE(j, n) { const uint64_t p = sa[j]; bwt[j] = text[p ? p - 1 : n - 1]; }
 }
@@ -165,12 +190,18 @@ __global__ void k_first_pos(const SymT *bwt, uint64_t n, unsigned long long *fir
     }
 }
 
+__global__ void k_split_sa(const uint64_t *sa, uint64_t n, uint32_t *lo, uint8_t *hi)
+{
+    GRID_STRIDE(i, n) { lo[i] = (uint32_t)sa[i]; hi[i] = (uint8_t)(sa[i] >> 32); }
+}
+
 template <typename SymT>
 __global__ void k_widen(const SymT *in, uint64_t n, uint32_t *out) { GRID_STRIDE(i, n) out[i] = in[i]; }
 
-template <typename SymT>
+template <typename SymT, typename IdxT>
 int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int keep_host, uint64_t max_sym, uint32_t L)
 {
+    constexpr bool WIDE = sizeof(IdxT) == 8;
     const uint64_t n = n_data + 1;
     Pool pool;
     hipStream_t st = 0;
@@ -180,7 +211,7 @@ int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int 
 
     // ---- suffix array -----------------------------------------------------
     uint64_t *keyA = nullptr, *keyB = nullptr;
-    uint32_t *idxA = nullptr, *idxB = nullptr, *rank = nullptr;
+    IdxT *idxA = nullptr, *idxB = nullptr, *rank = nullptr;
     unsigned long long *d_groups = nullptr;
     HIPCHK(pool.alloc(&keyA, n)); HIPCHK(pool.alloc(&keyB, n));
     HIPCHK(pool.alloc(&idxA, n)); HIPCHK(pool.alloc(&idxB, n));
@@ -188,42 +219,56 @@ int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int 
     const uint32_t per = std::max<uint32_t>(1, 64 / L);
     uint32_t nbits = 1;
     while ((n >> nbits) > 0) nbits++;           // bits to hold a rank < n
-    hipLaunchKernelGGL((k_pack_keys<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, text, n, L, per, keyA, idxA);
+    hipLaunchKernelGGL((k_pack_keys<SymT, IdxT>), dim3(grid_for(n)), dim3(TB), 0, st, text, n, L, per, keyA, idxA);
     rocprim::double_buffer<uint64_t> dk(keyA, keyB);
-    rocprim::double_buffer<uint32_t> dv(idxA, idxB);
+    rocprim::double_buffer<IdxT> dv(idxA, idxB);
     size_t tmp_bytes = 0, scan_bytes = 0;
     HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, n, 0u, 64u, st));
-    HIPCHK(rocprim::inclusive_scan(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, n, rocprim::maximum<uint32_t>(), st));
+    HIPCHK(rocprim::inclusive_scan(nullptr, scan_bytes, (IdxT *)nullptr, (IdxT *)nullptr, n, rocprim::maximum<IdxT>(), st));
     void *tmp = nullptr;
     HIPCHK(pool.alloc((char **)&tmp, std::max(tmp_bytes, scan_bytes) + 256));
     size_t tb = tmp_bytes;
     HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, 0u, std::min<uint32_t>(64u, per * L), st));
     uint64_t h_step = per;
+    bool first = true;
     for (int round = 0;; round++) {
-        uint32_t *sa = dv.current();
-        uint32_t *gs = dv.alternate();           // free until the next sort
-        hipLaunchKernelGGL(k_heads, dim3(grid_for(n)), dim3(TB), 0, st, dk.current(), n, gs);
+        IdxT *sa = dv.current();
+        IdxT *gs = dv.alternate();           // free until the next sort
+        if (first || !WIDE) hipLaunchKernelGGL((k_heads<IdxT>), dim3(grid_for(n)), dim3(TB), 0, st, dk.current(), n, gs);
+        else hipLaunchKernelGGL((k_heads2<IdxT>), dim3(grid_for(n)), dim3(TB), 0, st, sa, rank, n, h_step / 2, gs);
+        first = false;
         size_t sb = scan_bytes;
-        HIPCHK(rocprim::inclusive_scan(tmp, sb, gs, gs, n, rocprim::maximum<uint32_t>(), st));
+        HIPCHK(rocprim::inclusive_scan(tmp, sb, gs, gs, n, rocprim::maximum<IdxT>(), st));
         HIPCHK(hipMemsetAsync(d_groups, 0, 8, st));
-        hipLaunchKernelGGL(k_scatter_rank, dim3(grid_for(n)), dim3(TB), 0, st, sa, gs, n, rank, d_groups);
+        // (the heads of a two-key round read the OLD ranks: they are all computed before this scatter)
+        hipLaunchKernelGGL((k_scatter_rank<IdxT>), dim3(grid_for(n)), dim3(TB), 0, st, sa, gs, n, rank, d_groups);
         unsigned long long groups = 0;
         HIPCHK(hipMemcpyAsync(&groups, d_groups, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (groups == n) break;
         if (round > 64) { fmi_set_error("suffix array did not converge"); return FMI_ERR_STATE; }
-        hipLaunchKernelGGL(k_pair_keys, dim3(grid_for(n)), dim3(TB), 0, st, sa, rank, n, h_step, nbits, dk.current());
-        tb = tmp_bytes;
-        HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, 0u, std::min<uint32_t>(64u, 2 * nbits), st));
+        if (!WIDE) {
+            hipLaunchKernelGGL((k_pair_keys<IdxT>), dim3(grid_for(n)), dim3(TB), 0, st, sa, rank, n, h_step, nbits, dk.current());
+            tb = tmp_bytes;
+            HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, 0u, std::min<uint32_t>(64u, 2 * nbits), st));
+        } else {
+            // LSD over the pair: stable sort by rank[i+h], then by rank[i]
+            hipLaunchKernelGGL((k_key_of<IdxT>), dim3(grid_for(n)), dim3(TB), 0, st, dv.current(), rank, n, h_step, dk.current());
+            tb = tmp_bytes;
+            HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, 0u, nbits, st));
+            hipLaunchKernelGGL((k_key_of<IdxT>), dim3(grid_for(n)), dim3(TB), 0, st, dv.current(), rank, n, (uint64_t)0, dk.current());
+            tb = tmp_bytes;
+            HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, 0u, nbits, st));
+        }
         h_step *= 2;
     }
-    uint32_t *sa = dv.current();
+    IdxT *sa = dv.current();
     pool.release(keyA); pool.release(keyB); pool.release(rank); pool.release(dv.alternate());
 
     // ---- BWT + wavelet matrix ----------------------------------------------
     SymT *bwt = nullptr, *cur = nullptr, *nxt = nullptr;
     HIPCHK(pool.alloc(&bwt, n)); HIPCHK(pool.alloc(&cur, n)); HIPCHK(pool.alloc(&nxt, n));
-    hipLaunchKernelGGL((k_bwt<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, text, sa, n, bwt);
+    hipLaunchKernelGGL((k_bwt<SymT, IdxT>), dim3(grid_for(n)), dim3(TB), 0, st, text, sa, n, bwt);
     HIPCHK(hipMemcpyAsync(cur, bwt, n * sizeof(SymT), hipMemcpyDeviceToDevice, st));
     const uint64_t nblk = n / FMI_BLOCK_BITS + 2;
     uint64_t *wm = nullptr, *excl = nullptr;
@@ -290,12 +335,27 @@ int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int 
     HIPCHK(hipMemcpy(dC, h->C.data(), (max_sym + 2) * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dq1, h->q1.data(), max_sym + 1, hipMemcpyHostToDevice));
 
+    // suffix array in its resident form: low 32 bits (+ bits 32..39 when indices are 64-bit)
+    uint32_t *sa_lo_dev = nullptr;
+    uint8_t *sa_hi_dev = nullptr;
+    if (WIDE) {
+        HIPCHK(pool.alloc(&sa_lo_dev, n)); HIPCHK(pool.alloc(&sa_hi_dev, n));
+        hipLaunchKernelGGL(k_split_sa, dim3(grid_for(n)), dim3(TB), 0, st, (const uint64_t *)sa, n, sa_lo_dev, sa_hi_dev);
+        HIPCHK(hipStreamSynchronize(st));
+        pool.release(sa);
+    } else {
+        sa_lo_dev = (uint32_t *)sa;
+    }
     if (keep_host) {
         h->wm.resize((uint64_t)L * nblk * FMI_BLOCK_WORDS);
         HIPCHK(hipMemcpy(h->wm.data(), wm, h->wm.size() * 8, hipMemcpyDeviceToHost));
         h->sa_lo.resize(n);
-        HIPCHK(hipMemcpy(h->sa_lo.data(), sa, n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h->sa_lo.data(), sa_lo_dev, n * 4, hipMemcpyDeviceToHost));
         h->sa_hi.clear();
+        if (sa_hi_dev && n > (1ull << 32)) {       // the host format carries sa_hi only past 2^32 rows (fmi_host.cpp pack_sa)
+            h->sa_hi.resize(n);
+            HIPCHK(hipMemcpy(h->sa_hi.data(), sa_hi_dev, n, hipMemcpyDeviceToHost));
+        }
         h->text.resize(n * sizeof(SymT));
         HIPCHK(hipMemcpy(h->text.data(), text, n * sizeof(SymT), hipMemcpyDeviceToHost));
         uint32_t *wide = nullptr;
@@ -311,13 +371,14 @@ int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int 
     }
 
     // hand the resident arrays over to the index
-    d.C = dC; d.leaf = dleaf; d.q1 = dq1; d.sa_lo = sa; d.sa_hi = nullptr; d.text = text;
+    d.C = dC; d.leaf = dleaf; d.q1 = dq1; d.sa_lo = sa_lo_dev; d.sa_hi = sa_hi_dev; d.text = text;
     d.doc_begin = nullptr; d.n_begin = 0;
-    for (void *p : {(void *)wm, (void *)dC, (void *)dleaf, (void *)dq1, (void *)sa, (void *)text}) {
+    for (void *p : {(void *)wm, (void *)dC, (void *)dleaf, (void *)dq1, (void *)sa_lo_dev, (void *)sa_hi_dev, (void *)text}) {
+        if (!p) continue;
         pool.keep(p);
         h->dev_allocs.push_back(p);
     }
-    h->dev_bytes = (uint64_t)L * nblk * 64 + (max_sym + 2) * 8 + (max_sym + 1) * 9 + n * 4 + n * sizeof(SymT);
+    h->dev_bytes = (uint64_t)L * nblk * 64 + (max_sym + 2) * 8 + (max_sym + 1) * 9 + n * (WIDE ? 5 : 4) + n * sizeof(SymT);
     h->device = device;
     h->dev = d;
     if (!h->doc_begin.empty()) {
@@ -337,10 +398,14 @@ extern "C" int fmi_build_device(fmi_t *h, const uint32_t *d_data, uint64_t n_dat
         fmi_set_error("no HIP device %d visible", device);
         return FMI_ERR_NO_DEVICE;
     }
-    if (n_data + 1 >= (1ull << 32)) {
-        fmi_set_error("fmi_build_device: %llu symbols; this build indexes up to 2^32-2 on the GPU", (unsigned long long)n_data);
+    if (n_data + 1 >= (1ull << 40)) {
+        fmi_set_error("fmi_build_device: %llu symbols; positions are 40-bit", (unsigned long long)n_data);
         return FMI_ERR_UNSUPPORTED;
     }
+    // 32-bit suffix indices up to 2^32-1 rows, 64-bit (two-pass sort per round) beyond;
+    // SEALFM_FORCE_IDX64=1 selects the wide path at any size (tests)
+    const char *force = getenv("SEALFM_FORCE_IDX64");
+    const bool wide = (n_data + 1 >= (1ull << 32)) || (force && force[0] == '1');
     fmi_release_device(h);
     HIPCHK(hipSetDevice(device));
     // alphabet
@@ -361,6 +426,9 @@ extern "C" int fmi_build_device(fmi_t *h, const uint32_t *d_data, uint64_t n_dat
     if (L == 0) L = 1;
     if (L > FMI_MAX_LEVELS) { fmi_set_error("alphabet needs %u bits per symbol; this build supports <= %u", L, FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
     // (a 0 inside the data would collide with the sentinel; the caller owns that contract, as with sdsl)
-    if (max_sym32 < 65536) return build_impl<uint16_t>(h, d_data, n_data, device, keep_host, max_sym32, L);
-    return build_impl<uint32_t>(h, d_data, n_data, device, keep_host, max_sym32, L);
+    if (max_sym32 < 65536)
+        return wide ? build_impl<uint16_t, uint64_t>(h, d_data, n_data, device, keep_host, max_sym32, L)
+                    : build_impl<uint16_t, uint32_t>(h, d_data, n_data, device, keep_host, max_sym32, L);
+    return wide ? build_impl<uint32_t, uint64_t>(h, d_data, n_data, device, keep_host, max_sym32, L)
+                : build_impl<uint32_t, uint32_t>(h, d_data, n_data, device, keep_host, max_sym32, L);
 }

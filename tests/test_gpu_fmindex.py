@@ -165,10 +165,14 @@ def test_logits_processor_matches_reference_semantics(pair):
         assert torch.equal(out, want), (cur_len, kw)
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["idx32", "idx64"])
 @pytest.mark.parametrize("seed,n_docs,vocab", [(0, 30, 6), (1, 400, 300), (2, 3000, 50265), (3, 500, 70000)])
-def test_gpu_builder_is_byte_identical_to_host_builder(seed, n_docs, vocab):
+def test_gpu_builder_is_byte_identical_to_host_builder(seed, n_docs, vocab, wide, monkeypatch):
     import ctypes
     import torch
+    # idx64 = the builder's path for > 2^32 symbols (64-bit suffix indices, two-pass radix sort per
+    # doubling round, 40-bit resident SA), forced here at a size a test can afford
+    monkeypatch.setenv("SEALFM_FORCE_IDX64", "1" if wide else "0")
     from seal_amd import FMIndex
     from seal_amd._lib import lib
     docs = _docs(seed, n_docs, vocab, zipf=1.2 if vocab > 1000 else None)
