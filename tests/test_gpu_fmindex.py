@@ -204,3 +204,15 @@ def test_gpu_builder_is_byte_identical_to_host_builder(seed, n_docs, vocab, wide
     pa, da = a.locate_batch(rows)
     pb, db = b.locate_batch(rows)
     assert np.array_equal(pa, pb) and np.array_equal(da, db)
+
+
+def test_scale_check_properties_small():
+    """the size-independent properties of tools/scale_check.py (run there at NQ / KILT size) at CI size"""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "scale_check.py"), "--docs", "20000", "--patterns", "60"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert '"mismatching_rows": 0' in out.stdout
