@@ -77,6 +77,12 @@ int fmi_build_from_file(fmi_t *h, const char *path, int width, int device);
  * fmi_save works. */
 int fmi_build_device(fmi_t *h, const uint32_t *d_data, uint64_t n_data, int device, int keep_host);
 
+/* Rank/select-only index from a BWT that is already on the device (exactly one 0 sentinel in it,
+ * symbols `sym_bytes` = 2 or 4 bytes wide, all <= max_sym): wavelet matrix + tables, NO suffix array and
+ * NO text, so locate / extract_text fail with FMI_ERR_STATE.  For the rank/select bandwidth stress tier
+ * whose suffix array cannot be built on one GPU (SURVEY.md 8d tier X: ~1.4e10 symbols). */
+int fmi_build_from_bwt_device(fmi_t *h, const void *d_bwt, uint64_t n, int sym_bytes, uint64_t max_sym, int device);
+
 /* FMIndex::save(path)  (fm_index.cpp:186-189).  Own documented format
  * (DESIGN.md "on-disk layout"), not sdsl's. */
 int fmi_save(const fmi_t *h, const char *path);

@@ -24,6 +24,7 @@ SIGNATURES = {
     "fmi_build": (_int, [_vp, _p64, _u64, _int]),
     "fmi_build_from_file": (_int, [_vp, ctypes.c_char_p, _int, _int]),
     "fmi_build_device": (_int, [_vp, _vp, _u64, _int, _int]),
+    "fmi_build_from_bwt_device": (_int, [_vp, _vp, _u64, _int, _u64, _int]),
     "fmi_save": (_int, [_vp, ctypes.c_char_p]),
     "fmi_load": (_int, [ctypes.POINTER(_vp), ctypes.c_char_p, _int]),
     "fmi_to_device": (_int, [_vp, _int]),

@@ -198,6 +198,86 @@ __global__ void k_split_sa(const uint64_t *sa, uint64_t n, uint32_t *lo, uint8_t
 template <typename SymT>
 __global__ void k_widen(const SymT *in, uint64_t n, uint32_t *out) { GRID_STRIDE(i, n) out[i] = in[i]; }
 
+// BWT (device) -> wavelet matrix levels + C / leaf / q1 tables, on the device; fills the geometry
+// fields of `h` and `d`.  Shared by the full builder and by fmi_build_from_bwt_device.
+template <typename SymT>
+int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64_t n, uint64_t max_sym, uint32_t L, FmiDev &d,
+                     uint64_t **wm_out, uint64_t **dC_out, uint64_t **dleaf_out, uint8_t **dq1_out)
+{
+    SymT *cur = nullptr, *nxt = nullptr;
+    HIPCHK(pool.alloc(&cur, n)); HIPCHK(pool.alloc(&nxt, n));
+    HIPCHK(hipMemcpyAsync(cur, bwt, n * sizeof(SymT), hipMemcpyDeviceToDevice, st));
+    const uint64_t nblk = n / FMI_BLOCK_BITS + 2;
+    uint64_t *wm = nullptr, *excl = nullptr;
+    uint32_t *blk_ones = nullptr;
+    HIPCHK(pool.alloc(&wm, (uint64_t)L * nblk * FMI_BLOCK_WORDS));
+    HIPCHK(pool.alloc(&excl, nblk + 1)); HIPCHK(pool.alloc(&blk_ones, nblk + 1));
+    HIPCHK(hipMemsetAsync(blk_ones + nblk, 0, 4, st));
+    size_t xs_bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, xs_bytes, blk_ones, excl, (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
+    void *xs_tmp = nullptr;
+    HIPCHK(pool.alloc((char **)&xs_tmp, xs_bytes + 256));
+    d = FmiDev{};
+    d.wm = wm; d.nblk = nblk; d.n = n; d.max_sym = max_sym; d.levels = L; d.sym_bytes = sizeof(SymT) == 2 ? 2 : 4;
+    std::vector<uint64_t> zeros(L);
+    for (uint32_t k = 0; k < L; k++) {
+        uint64_t *lvl = wm + (uint64_t)k * nblk * FMI_BLOCK_WORDS;
+        hipLaunchKernelGGL((k_level_words<SymT>), dim3((unsigned)std::min<uint64_t>((nblk + 3) / 4, 1u << 18)), dim3(256), 0, st,
+                           cur, n, L - 1 - k, nblk, lvl, blk_ones);
+        size_t xb = xs_bytes;
+        HIPCHK(rocprim::exclusive_scan(xs_tmp, xb, blk_ones, excl, (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
+        hipLaunchKernelGGL(k_store_counts, dim3(grid_for(nblk)), dim3(TB), 0, st, excl, nblk, lvl);
+        uint64_t ones = 0;
+        HIPCHK(hipMemcpyAsync(&ones, excl + nblk, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        zeros[k] = n - ones;
+        d.zeros[k] = zeros[k];
+        hipLaunchKernelGGL((k_partition<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, d, k, cur, nxt);
+        std::swap(cur, nxt);
+    }
+    HIPCHK(hipGetLastError());
+
+    // ---- per-symbol tables --------------------------------------------------
+    uint64_t *leaf = nullptr, *occ_end = nullptr;
+    unsigned long long *first_pos = nullptr;
+    HIPCHK(pool.alloc(&leaf, max_sym + 1)); HIPCHK(pool.alloc(&occ_end, max_sym + 1)); HIPCHK(pool.alloc(&first_pos, max_sym + 1));
+    HIPCHK(hipMemsetAsync(leaf, 0, (max_sym + 1) * 8, st));
+    HIPCHK(hipMemsetAsync(occ_end, 0, (max_sym + 1) * 8, st));
+    HIPCHK(hipMemsetAsync(first_pos, 0xff, (max_sym + 1) * 8, st));
+    hipLaunchKernelGGL((k_runs<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, cur, n, leaf, occ_end);
+    hipLaunchKernelGGL((k_first_pos<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, bwt, n, first_pos);
+    std::vector<uint64_t> h_leaf(max_sym + 1), h_end(max_sym + 1), h_first(max_sym + 1);
+    HIPCHK(hipMemcpyAsync(h_leaf.data(), leaf, (max_sym + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_end.data(), occ_end, (max_sym + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_first.data(), first_pos, (max_sym + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+
+    h->n = n; h->max_sym = max_sym; h->levels = L; h->nblk = nblk; h->sym_bytes = d.sym_bytes;
+    h->zeros = zeros;
+    h->leaf = h_leaf;
+    h->C.assign(max_sym + 2, 0);
+    uint64_t sigma = 0;
+    for (uint64_t c = 0; c <= max_sym; c++) {
+        const uint64_t occ = h_end[c] ? h_end[c] - h_leaf[c] : 0;
+        if (occ) sigma++;
+        h->C[c + 1] = h->C[c] + occ;
+    }
+    h->sigma = sigma;
+    fmi_host_q1_from_first_pos(h_first, L, max_sym, h->C, h->q1);
+
+    // small tables to the device
+    uint64_t *dC = nullptr, *dleaf = leaf;
+    uint8_t *dq1 = nullptr;
+    HIPCHK(pool.alloc(&dC, max_sym + 2)); HIPCHK(pool.alloc(&dq1, max_sym + 1));
+    HIPCHK(hipMemcpy(dC, h->C.data(), (max_sym + 2) * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dq1, h->q1.data(), max_sym + 1, hipMemcpyHostToDevice));
+
+    pool.release(cur); pool.release(nxt); pool.release(excl); pool.release(blk_ones); pool.release(xs_tmp);
+    pool.release(occ_end); pool.release(first_pos);
+    *wm_out = wm; *dC_out = dC; *dleaf_out = dleaf; *dq1_out = dq1;
+    return FMI_OK;
+}
+
 template <typename SymT, typename IdxT>
 int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int keep_host, uint64_t max_sym, uint32_t L)
 {
@@ -265,75 +345,18 @@ int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int 
     IdxT *sa = dv.current();
     pool.release(keyA); pool.release(keyB); pool.release(rank); pool.release(dv.alternate());
 
-    // ---- BWT + wavelet matrix ----------------------------------------------
-    SymT *bwt = nullptr, *cur = nullptr, *nxt = nullptr;
-    HIPCHK(pool.alloc(&bwt, n)); HIPCHK(pool.alloc(&cur, n)); HIPCHK(pool.alloc(&nxt, n));
+    // ---- BWT + wavelet matrix + per-symbol tables ------------------------------
+    SymT *bwt = nullptr;
+    HIPCHK(pool.alloc(&bwt, n));
     hipLaunchKernelGGL((k_bwt<SymT, IdxT>), dim3(grid_for(n)), dim3(TB), 0, st, text, sa, n, bwt);
-    HIPCHK(hipMemcpyAsync(cur, bwt, n * sizeof(SymT), hipMemcpyDeviceToDevice, st));
-    const uint64_t nblk = n / FMI_BLOCK_BITS + 2;
-    uint64_t *wm = nullptr, *excl = nullptr;
-    uint32_t *blk_ones = nullptr;
-    HIPCHK(pool.alloc(&wm, (uint64_t)L * nblk * FMI_BLOCK_WORDS));
-    HIPCHK(pool.alloc(&excl, nblk + 1)); HIPCHK(pool.alloc(&blk_ones, nblk + 1));
-    HIPCHK(hipMemsetAsync(blk_ones + nblk, 0, 4, st));
-    size_t xs_bytes = 0;
-    HIPCHK(rocprim::exclusive_scan(nullptr, xs_bytes, blk_ones, excl, (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
-    void *xs_tmp = nullptr;
-    HIPCHK(pool.alloc((char **)&xs_tmp, xs_bytes + 256));
     FmiDev d{};
-    d.wm = wm; d.nblk = nblk; d.n = n; d.max_sym = max_sym; d.levels = L; d.sym_bytes = sizeof(SymT) == 2 ? 2 : 4;
-    std::vector<uint64_t> zeros(L);
-    for (uint32_t k = 0; k < L; k++) {
-        uint64_t *lvl = wm + (uint64_t)k * nblk * FMI_BLOCK_WORDS;
-        hipLaunchKernelGGL((k_level_words<SymT>), dim3((unsigned)std::min<uint64_t>((nblk + 3) / 4, 1u << 18)), dim3(256), 0, st,
-                           cur, n, L - 1 - k, nblk, lvl, blk_ones);
-        size_t xb = xs_bytes;
-        HIPCHK(rocprim::exclusive_scan(xs_tmp, xb, blk_ones, excl, (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
-        hipLaunchKernelGGL(k_store_counts, dim3(grid_for(nblk)), dim3(TB), 0, st, excl, nblk, lvl);
-        uint64_t ones = 0;
-        HIPCHK(hipMemcpyAsync(&ones, excl + nblk, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        zeros[k] = n - ones;
-        d.zeros[k] = zeros[k];
-        hipLaunchKernelGGL((k_partition<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, d, k, cur, nxt);
-        std::swap(cur, nxt);
-    }
-    HIPCHK(hipGetLastError());
-
-    // ---- per-symbol tables --------------------------------------------------
-    uint64_t *leaf = nullptr, *occ_end = nullptr;
-    unsigned long long *first_pos = nullptr;
-    HIPCHK(pool.alloc(&leaf, max_sym + 1)); HIPCHK(pool.alloc(&occ_end, max_sym + 1)); HIPCHK(pool.alloc(&first_pos, max_sym + 1));
-    HIPCHK(hipMemsetAsync(leaf, 0, (max_sym + 1) * 8, st));
-    HIPCHK(hipMemsetAsync(occ_end, 0, (max_sym + 1) * 8, st));
-    HIPCHK(hipMemsetAsync(first_pos, 0xff, (max_sym + 1) * 8, st));
-    hipLaunchKernelGGL((k_runs<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, cur, n, leaf, occ_end);
-    hipLaunchKernelGGL((k_first_pos<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, bwt, n, first_pos);
-    std::vector<uint64_t> h_leaf(max_sym + 1), h_end(max_sym + 1), h_first(max_sym + 1);
-    HIPCHK(hipMemcpyAsync(h_leaf.data(), leaf, (max_sym + 1) * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(h_end.data(), occ_end, (max_sym + 1) * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(h_first.data(), first_pos, (max_sym + 1) * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-
-    h->n = n; h->max_sym = max_sym; h->levels = L; h->nblk = nblk; h->sym_bytes = d.sym_bytes;
-    h->zeros = zeros;
-    h->leaf = h_leaf;
-    h->C.assign(max_sym + 2, 0);
-    uint64_t sigma = 0;
-    for (uint64_t c = 0; c <= max_sym; c++) {
-        const uint64_t occ = h_end[c] ? h_end[c] - h_leaf[c] : 0;
-        if (occ) sigma++;
-        h->C[c + 1] = h->C[c] + occ;
-    }
-    h->sigma = sigma;
-    fmi_host_q1_from_first_pos(h_first, L, max_sym, h->C, h->q1);
-
-    // small tables to the device
-    uint64_t *dC = nullptr, *dleaf = leaf;
+    uint64_t *wm = nullptr, *dC = nullptr, *dleaf = nullptr;
     uint8_t *dq1 = nullptr;
-    HIPCHK(pool.alloc(&dC, max_sym + 2)); HIPCHK(pool.alloc(&dq1, max_sym + 1));
-    HIPCHK(hipMemcpy(dC, h->C.data(), (max_sym + 2) * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dq1, h->q1.data(), max_sym + 1, hipMemcpyHostToDevice));
+    {
+        int rc = wavelet_from_bwt<SymT>(h, pool, st, bwt, n, max_sym, L, d, &wm, &dC, &dleaf, &dq1);
+        if (rc) return rc;
+    }
+    const uint64_t nblk = d.nblk;
 
     // suffix array in its resident form: low 32 bits (+ bits 32..39 when indices are 64-bit)
     uint32_t *sa_lo_dev = nullptr;
@@ -389,6 +412,40 @@ int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int 
 }
 
 }  // namespace
+
+template <typename SymT>
+static int bwt_only_impl(fmi *h, const void *d_bwt, uint64_t n, int device, uint64_t max_sym, uint32_t L)
+{
+    Pool pool;
+    FmiDev d{};
+    uint64_t *wm = nullptr, *dC = nullptr, *dleaf = nullptr;
+    uint8_t *dq1 = nullptr;
+    int rc = wavelet_from_bwt<SymT>(h, pool, 0, (const SymT *)d_bwt, n, max_sym, L, d, &wm, &dC, &dleaf, &dq1);
+    if (rc) return rc;
+    h->wm.clear(); h->sa_lo.clear(); h->sa_hi.clear(); h->text.clear(); h->bwt.clear();
+    h->host_resident = false;
+    d.C = dC; d.leaf = dleaf; d.q1 = dq1; d.sa_lo = nullptr; d.sa_hi = nullptr; d.text = nullptr;
+    for (void *p : {(void *)wm, (void *)dC, (void *)dleaf, (void *)dq1}) { pool.keep(p); h->dev_allocs.push_back(p); }
+    h->dev_bytes = (uint64_t)L * d.nblk * 64 + (max_sym + 2) * 8 + (max_sym + 1) * 9;
+    h->device = device;
+    h->dev = d;
+    return FMI_OK;
+}
+
+extern "C" int fmi_build_from_bwt_device(fmi_t *h, const void *d_bwt, uint64_t n, int sym_bytes, uint64_t max_sym, int device)
+{
+    if (!h || !d_bwt || n == 0 || !(sym_bytes == 2 || sym_bytes == 4)) { fmi_set_error("fmi_build_from_bwt_device: bad argument"); return FMI_ERR_ARG; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= device || device < 0) { fmi_set_error("no HIP device %d visible", device); return FMI_ERR_NO_DEVICE; }
+    if (n >= (1ull << 40)) { fmi_set_error("positions are 40-bit"); return FMI_ERR_UNSUPPORTED; }
+    uint32_t L = 0;
+    while ((max_sym >> L) > 0) L++;
+    if (L == 0) L = 1;
+    if (L > FMI_MAX_LEVELS || (sym_bytes == 2 && max_sym >= 65536)) { fmi_set_error("alphabet too large"); return FMI_ERR_UNSUPPORTED; }
+    fmi_release_device(h);
+    HIPCHK(hipSetDevice(device));
+    return sym_bytes == 2 ? bwt_only_impl<uint16_t>(h, d_bwt, n, device, max_sym, L) : bwt_only_impl<uint32_t>(h, d_bwt, n, device, max_sym, L);
+}
 
 extern "C" int fmi_build_device(fmi_t *h, const uint32_t *d_data, uint64_t n_data, int device, int keep_host)
 {

@@ -666,6 +666,7 @@ extern "C" int fmi_dev_locate(fmi_t *h, void *stream, uint64_t n, const uint64_t
 {
     int rc = need_device(h); if (rc) return rc;
     if (n == 0) return FMI_OK;
+    if (!h->dev.sa_lo) { fmi_set_error("rank/select-only index: no suffix array resident"); return FMI_ERR_STATE; }
     hipLaunchKernelGGL(k_locate, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, h->dev, n, d_rows, d_pos_out, d_doc_out);
     HIPCHK(hipGetLastError());
     return FMI_OK;
@@ -678,6 +679,7 @@ extern "C" int fmi_dev_locate_ranges(fmi_t *h, void *stream, uint64_t n_ranges, 
     (void)d_hi; (void)max_per_range;   // already folded into d_out_offsets by the caller
     int rc = need_device(h); if (rc) return rc;
     if (total == 0 || n_ranges == 0) return FMI_OK;
+    if (!h->dev.sa_lo) { fmi_set_error("rank/select-only index: no suffix array resident"); return FMI_ERR_STATE; }
     hipLaunchKernelGGL(k_locate_ranges, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, h->dev, n_ranges,
                        d_lo, d_out_offsets, total, d_pos_out, d_doc_out);
     HIPCHK(hipGetLastError());
@@ -689,7 +691,7 @@ extern "C" int fmi_dev_get_docs(fmi_t *h, void *stream, uint64_t n_docs, const u
 {
     int rc = need_device(h); if (rc) return rc;
     if (n_docs == 0) return FMI_OK;
-    if (!h->dev.doc_begin) { fmi_set_error("doc beginnings not set"); return FMI_ERR_STATE; }
+    if (!h->dev.doc_begin || !h->dev.text) { fmi_set_error("doc beginnings / text not resident"); return FMI_ERR_STATE; }
     hipLaunchKernelGGL(k_get_docs, dim3((unsigned)n_docs), dim3(64), 0, (hipStream_t)stream, h->dev, d_docs, d_out_offsets, shift, d_out);
     HIPCHK(hipGetLastError());
     return FMI_OK;
@@ -798,6 +800,7 @@ extern "C" int fmi_locate(fmi_t *h, uint64_t n, const uint64_t *rows, uint64_t *
     int rc = need_device(h); if (rc) return rc;
     if (n == 0) return FMI_OK;
     if (doc_out && !h->dev.doc_begin) { fmi_set_error("doc beginnings not set"); return FMI_ERR_STATE; }
+    if (!h->dev.sa_lo) { fmi_set_error("rank/select-only index: no suffix array resident"); return FMI_ERR_STATE; }
     hipStream_t sst; if ((rc = service_stream(h, &sst))) return rc;
     DevBuf b; if ((rc = b.alloc(n * 24))) return rc;
     uint64_t *d = b.as<uint64_t>();
@@ -814,6 +817,7 @@ extern "C" int fmi_extract_text(fmi_t *h, uint64_t begin, uint64_t end, uint64_t
     int rc = need_device(h); if (rc) return rc;
     if (end <= begin) return FMI_OK;
     if (end > h->n) { fmi_set_error("extract_text: end %llu > size %llu", (unsigned long long)end, (unsigned long long)h->n); return FMI_ERR_ARG; }
+    if (!h->dev.text) { fmi_set_error("rank/select-only index: no text resident"); return FMI_ERR_STATE; }
     const uint64_t m = end - begin;
     DevBuf b; if ((rc = b.alloc(m * 8))) return rc;
     hipLaunchKernelGGL(k_extract, dim3(blocks_for(m, 256)), dim3(256), 0, 0, h->dev, begin, end, b.as<uint64_t>());

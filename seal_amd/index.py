@@ -81,6 +81,19 @@ class FMIndex(_FMIndex):
         check(lib().fmi_build_device(self._h, data.data_ptr(), data.numel(), data.device.index or 0, int(keep_host)))
         self._after_build()
 
+    def initialize_rank_only_from_bwt(self, bwt, max_symbol: int) -> None:
+        """Rank/select-only index from a BWT already on the GPU (int16/uint16 or int32 tensor with exactly
+        one 0): backward search, ranges, counts and continuations work; ``locate``/``get_doc`` raise.
+        For the bandwidth stress tier whose suffix array does not fit one GPU (SURVEY.md 8d tier X)."""
+        import torch
+        assert bwt.is_cuda and bwt.is_contiguous()
+        sym_bytes = bwt.element_size()
+        torch.cuda.synchronize(bwt.device)
+        check(lib().fmi_build_from_bwt_device(self._h, bwt.data_ptr(), bwt.numel(), sym_bytes, int(max_symbol), bwt.device.index or 0))
+        self.beginnings = [0, bwt.numel() - 1]
+        self.occurring_distinct, self.occurring_counts = self.get_distinct_count(0, len(self))
+        self.occurring = list(self.occurring_distinct)
+
     def _after_build(self) -> None:
         self._push_beginnings()
         self.occurring_distinct, self.occurring_counts = self.get_distinct_count(0, len(self))

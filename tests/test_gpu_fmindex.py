@@ -216,3 +216,28 @@ def test_scale_check_properties_small():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert '"mismatching_rows": 0' in out.stdout
+
+
+def test_rank_only_index_from_bwt_matches_full_index(pair):
+    """fmi_build_from_bwt_device: same ranges / counts / continuations as the full index over the same BWT;
+    locate and extract refuse loudly."""
+    import ctypes
+    import torch
+    from seal_amd import FMIndex
+    from seal_amd._lib import SealFMError, lib
+    ix, orc, docs, vocab = pair
+    n, e = ctypes.c_uint64(), ctypes.c_uint32()
+    p = lib().fmi_host_array(ix.handle, b"bwt", ctypes.byref(n), ctypes.byref(e))
+    bwt = np.frombuffer((ctypes.c_uint8 * (n.value * 4)).from_address(p), dtype=np.uint32).astype(np.int32)
+    ro = FMIndex()
+    ro.initialize_rank_only_from_bwt(torch.from_numpy(bwt).cuda(), int(bwt.max()))
+    assert ro.size() == ix.size() and ro.occurring_distinct == ix.occurring_distinct and ro.occurring_counts == ix.occurring_counts
+    seqs = [d[a:a + 3] for d in docs[:60] for a in (0, 1)]
+    la, ha = ix.get_range_batch(seqs)
+    lb, hb = ro.get_range_batch(seqs)
+    assert np.array_equal(la, lb) and np.array_equal(ha, hb)
+    assert ro.get_distinct_count_multi(la[:20].tolist(), ha[:20].tolist()) == ix.get_distinct_count_multi(la[:20].tolist(), ha[:20].tolist())
+    with pytest.raises(SealFMError):
+        ro.locate(3)
+    with pytest.raises(SealFMError):
+        ro.extract_text(0, 3)

@@ -29,22 +29,46 @@ def main():
     ap.add_argument("--prefix-len", type=int, default=1, help="tokens after the decoder start token")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--synthetic-bwt", type=float, default=0,
+                    help="N symbols: skip corpus+suffix array and load an i.i.d. Zipf 'BWT' of N symbols straight into the "
+                         "wavelet matrix (rank/select-only index; bandwidth measurement only, SURVEY.md 8d tier X)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     from seal_amd import FMIndex
     from seal_amd._lib import check, lib
-    data, beg, title_len, ids_by_rank = bench.synth_corpus(args.docs, dev, seed=0)
     g = torch.Generator(device=dev)
     g.manual_seed(100 + args.seed)
-    # prefixes = corpus n-grams in forward order: pick positions in the reversed text and read backwards
-    N = data.numel()
-    p = torch.randint(args.prefix_len + 1, N - 1, (args.rows,), generator=g, device=dev)
-    offs = torch.arange(args.prefix_len, device=dev)
-    toks = data[(p[:, None] - offs[None, :])].long() - bench.SHIFT          # forward order
-    ids = torch.cat([torch.full((args.rows, 1), 2, device=dev, dtype=torch.long), toks], 1).contiguous()
-    index = FMIndex()
-    index.initialize_from_device(data, beg.tolist())
-    del data
+    if args.synthetic_bwt:
+        N = int(args.synthetic_bwt)
+        usable = torch.arange(4, bench.VOCAB, device=dev)
+        ids_by_rank = usable[torch.randperm(usable.numel(), generator=g, device=dev)]
+        w = 1.0 / torch.arange(1, usable.numel() + 1, device=dev, dtype=torch.float64) ** 1.07
+        cdf = torch.cumsum(w, 0) / w.sum()
+        bwt = torch.empty(N, dtype=torch.int16, device=dev)
+        for a in range(0, N, 1 << 27):
+            b = min(N, a + (1 << 27))
+            r = torch.searchsorted(cdf, torch.rand(b - a, generator=g, device=dev, dtype=torch.float64)).clamp_(max=usable.numel() - 1)
+            bwt[a:b] = (ids_by_rank[r] + bench.SHIFT).to(torch.int16)      # two's complement view of the u16 symbol
+        bwt[N // 3] = 0
+        r = torch.searchsorted(cdf, torch.rand(args.rows * args.prefix_len, generator=g, device=dev, dtype=torch.float64))
+        toks = ids_by_rank[r.clamp_(max=usable.numel() - 1)].view(args.rows, args.prefix_len)
+        ids = torch.cat([torch.full((args.rows, 1), 2, device=dev, dtype=torch.long), toks], 1).contiguous()
+        index = FMIndex()
+        index.initialize_rank_only_from_bwt(bwt, bench.VOCAB - 1 + bench.SHIFT)
+        del bwt
+        data = None
+    else:
+        data, beg, title_len, ids_by_rank = bench.synth_corpus(args.docs, dev, seed=0)
+    if data is not None:
+        # prefixes = corpus n-grams in forward order: pick positions in the reversed text and read backwards
+        N = data.numel()
+        p = torch.randint(args.prefix_len + 1, N - 1, (args.rows,), generator=g, device=dev)
+        offs = torch.arange(args.prefix_len, device=dev)
+        toks = data[(p[:, None] - offs[None, :])].long() - bench.SHIFT          # forward order
+        ids = torch.cat([torch.full((args.rows, 1), 2, device=dev, dtype=torch.long), toks], 1).contiguous()
+        index = FMIndex()
+        index.initialize_from_device(data, beg.tolist())
+        del data
     h = index.handle
     V = bench.VOCAB
     bits = torch.zeros(args.rows, (V + 31) // 32, dtype=torch.int32, device=dev)
