@@ -170,6 +170,20 @@ int fmi_dev_allowed_bits(fmi_t *h, void *stream, uint64_t rows, uint64_t cur_len
                          const int64_t *force_from, uint64_t n_force,
                          int64_t stop_at_count, int always_allow_eos);
 
+/* One decode step of constrained_beam_search fused (seal/beam_search.py:244-310): log_softmax +
+ * InfNanRemove of d_logits [batch*beams, vocab], + beam score, constraint (as fmi_dev_allowed_bits; for
+ * cur_len == 1 the caller's d_first_bits bitmap of occurring_distinct, with always_allow_eos already folded
+ * in), top-(2*beams) per query on the CONSTRAINED scores; outputs [batch, 2*beams]: flat index
+ * (beam * vocab + token), constrained score, UNCONSTRAINED score (the value the reference carries on).
+ * Ties go to the lower flat index; when a query has fewer finite candidates the rest is filled with
+ * not-allowed tokens (constrained -inf), which torch.topk leaves unspecified.  d_scratch: at least
+ * 4 * batch*beams * (3 + 4*beams) bytes.  Nothing of shape [rows, vocab] is written. */
+int fmi_dev_constrained_topk(fmi_t *h, void *stream, uint64_t batch, uint64_t beams, uint64_t cur_len,
+                             const int64_t *d_input_ids, const float *d_logits, const float *d_beam_scores,
+                             uint64_t vocab, int64_t shift, int64_t pad_id, int64_t eos_id, const int64_t *force_from,
+                             uint64_t n_force, int64_t stop_at_count, int always_allow_eos, const uint32_t *d_first_bits,
+                             void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc);
+
 /* locate + doc binning for n rows (seal/keys.py:320-324) */
 int fmi_dev_locate(fmi_t *h, void *stream, uint64_t n, const uint64_t *d_rows,
                    uint64_t *d_pos_out, uint64_t *d_doc_out);

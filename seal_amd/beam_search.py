@@ -60,6 +60,57 @@ class IndexBasedLogitsProcessor:
             self._first_mask[key] = m
         return m
 
+    # -- fused decode step ----------------------------------------------------
+    def supports_fused_topk(self, logits: torch.Tensor, num_beams: int) -> bool:
+        return (logits.is_cuda and logits.dtype == torch.float32 and self.forced_bos_token_id is None
+                and 2 * num_beams <= 64)
+
+    def _first_bits(self, vocab: int, device) -> torch.Tensor:
+        key = ("bits", device, vocab)
+        b = self._first_mask.get(key)
+        if b is None:
+            allowed = torch.zeros(((vocab + 31) // 32) * 32, dtype=torch.bool)
+            allowed[torch.as_tensor(self.index.occurring_distinct, dtype=torch.long)] = True
+            if self.always_allow_eos:
+                allowed[self.eos_token_id] = True
+            w = allowed.view(-1, 32).to(torch.int64) << torch.arange(32, dtype=torch.int64)
+            b = w.sum(1).to(torch.int64)
+            b = torch.where(b >= 2 ** 31, b - 2 ** 32, b).to(torch.int32).to(device)
+            self._first_mask[key] = b
+        return b
+
+    def fused_topk(self, input_ids: torch.LongTensor, logits: torch.FloatTensor, beam_scores: torch.FloatTensor,
+                   batch: int, num_beams: int):
+        """log_softmax + InfNanRemove + this constraint + beam scores + top-2K per query, fused
+        (``fmi_dev_constrained_topk``): returns (flat indices [B, 2K], unconstrained scores [B, 2K]) -- what
+        reference beam_search.py:244-307 computes through five [rows, vocab] intermediates."""
+        dev = logits.device
+        V = logits.shape[-1]
+        want = 2 * num_beams
+        rows = batch * num_beams
+        ids = input_ids.contiguous()
+        cur_len = ids.shape[1]
+        scratch = self._first_mask.get(("scratch", dev, rows, want))
+        if scratch is None:
+            scratch = torch.empty(rows * (3 + 2 * want) + 64, dtype=torch.float32, device=dev)
+            self._first_mask[("scratch", dev, rows, want)] = scratch
+        top_idx = torch.empty(batch, want, dtype=torch.int64, device=dev)
+        top_con = torch.empty(batch, want, dtype=torch.float32, device=dev)
+        top_unc = torch.empty(batch, want, dtype=torch.float32, device=dev)
+        ff = self.force_decoding_from or []
+        ff_arr = (ctypes.c_int64 * max(len(ff), 1))(*ff)
+        first = self._first_bits(V, dev) if cur_len == 1 else None
+        if getattr(self.index, "_trace", None) is not None and cur_len >= 2:
+            self.index._trace.append(("mask", ids.clone(), list(ff)))
+        lg = logits.contiguous()
+        bs = beam_scores.contiguous()
+        check(lib().fmi_dev_constrained_topk(
+            self.index.handle, _stream_ptr(dev), batch, num_beams, cur_len, ids.data_ptr(), lg.data_ptr(), bs.data_ptr(), V, SHIFT,
+            self.pad_token_id, self.eos_token_id, ff_arr, len(ff), int(self.stop_at_count), int(bool(self.always_allow_eos)),
+            first.data_ptr() if first is not None else None, scratch.data_ptr(), scratch.numel() * 4,
+            top_idx.data_ptr(), top_con.data_ptr(), top_unc.data_ptr()))
+        return top_idx, top_unc
+
     def __call__(self, input_ids: torch.LongTensor, scores: torch.FloatTensor) -> torch.FloatTensor:
         if self.forced_bos_token_id is not None:   # beam_search.py:66-71
             if input_ids.size(1) == 1:
@@ -111,7 +162,7 @@ def _inf_nan_remove(scores: torch.Tensor) -> torch.Tensor:
 
 @torch.no_grad()
 def constrained_beam_search(decoder, batch_size: int, num_beams: int, max_length: int, decoder_start_token_id: int,
-                            eos_token_id: int, constrained_decoding_processor=None, device=None):
+                            eos_token_id: int, constrained_decoding_processor=None, device=None, fused: bool = True):
     """Runs the loop of reference ``constrained_beam_search`` with the
     ``BeamSearchScorerWithMemory`` bookkeeping and returns the raw history:
 
@@ -135,16 +186,20 @@ def constrained_beam_search(decoder, batch_size: int, num_beams: int, max_length
     steps = []
     while True:
         logits = decoder.step(input_ids[:, -1])
-        logp = torch.log_softmax(logits.float(), dim=-1)
-        processed = _inf_nan_remove(logp)
-        V = processed.shape[-1]
-        unconstrained = processed + beam_scores[:, None]
-        if constrained_decoding_processor is not None:
-            constrained = constrained_decoding_processor(input_ids, processed) + beam_scores[:, None]
+        V = logits.shape[-1]
+        proc = constrained_decoding_processor
+        if proc is not None and fused and hasattr(proc, "fused_topk") and proc.supports_fused_topk(logits, K):
+            flat, next_scores = proc.fused_topk(input_ids, logits, beam_scores, B, K)
         else:
-            constrained = unconstrained
-        _, flat = torch.topk(constrained.view(B, K * V), 2 * K, dim=1, largest=True, sorted=True)
-        next_scores = unconstrained.view(B, K * V).gather(-1, flat)
+            logp = torch.log_softmax(logits.float(), dim=-1)
+            processed = _inf_nan_remove(logp)
+            unconstrained = processed + beam_scores[:, None]
+            if proc is not None:
+                constrained = proc(input_ids, processed) + beam_scores[:, None]
+            else:
+                constrained = unconstrained
+            _, flat = torch.topk(constrained.view(B, K * V), 2 * K, dim=1, largest=True, sorted=True)
+            next_scores = unconstrained.view(B, K * V).gather(-1, flat)
         next_indices = flat // V                    # (next_tokens / V).long(), exact for K*V < 2^24 (309)
         next_tokens = flat % V
         src_rows = row_base + next_indices          # batch_beam_idx (661)

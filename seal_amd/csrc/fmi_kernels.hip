@@ -363,6 +363,170 @@ __global__ __launch_bounds__(256) void k_apply_bits(const float *in, float *out,
 }
 
 // ---------------------------------------------------------------------------
+// Fused constrained top-2K of one decode step (reference beam_search.py:244-310):
+//   next_token_scores = log_softmax(logits); InfNanRemove; unconstrained = + beam_score;
+//   constrained = unconstrained where the token is allowed, else -inf; top-2K of the constrained
+//   scores over the K*V candidates of a query; carry the UNCONSTRAINED score of the picks.
+// Nothing of shape [rows, vocab] is written: k_row_lse reads the logits once, k_row_topk reads
+// only the allowed tokens of each row (bitmap from k_prefix_ranges + k_expand), k_query_merge
+// merges the K per-row lists of a query.  Ties go to the lower flat index.
+// ---------------------------------------------------------------------------
+static constexpr int TOPK_MAX = 64;          // 2 * num_beams <= 64
+
+__device__ __forceinline__ float logp_processed(float x, float mx, float lsum)
+{
+    float lp = (x - mx) - lsum;                                  // log_softmax
+    if (lp != lp) lp = 0.0f;                                     // InfNanRemoveLogitsProcessor (HF 4.13): nan -> 0
+    if (lp == __builtin_huge_valf()) lp = 3.402823466e+38f;      // +inf -> finfo.max
+    return lp;
+}
+
+// one workgroup per row: max and log(sum(exp(x - max)))
+__global__ __launch_bounds__(256) void k_row_lse(const float *logits, uint64_t vocab, float *row_max, float *row_lsum)
+{
+    __shared__ float s_a[4], s_b[4];
+    const float *x = logits + (uint64_t)blockIdx.x * vocab;
+    float mx = -__builtin_huge_valf();
+    bool nan = false;
+    for (uint64_t v = threadIdx.x; v < vocab; v += 256) { const float a = x[v]; nan |= (a != a); mx = fmaxf(mx, a); }
+    for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_down(mx, o)); }
+    const uint64_t any_nan = __ballot(nan);
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = mx; s_b[threadIdx.x >> 6] = any_nan ? 1.f : 0.f; }
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_a[0], s_a[1]), fmaxf(s_a[2], s_a[3]));
+    const bool row_nan = (s_b[0] + s_b[1] + s_b[2] + s_b[3]) > 0.f;
+    __syncthreads();
+    float sum = 0.f;
+    for (uint64_t v = threadIdx.x; v < vocab; v += 256) sum += expf(x[v] - mx);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    if ((threadIdx.x & 63) == 0) s_a[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+        const float qnan = __builtin_nanf("");
+        row_max[blockIdx.x] = row_nan ? qnan : mx;
+        row_lsum[blockIdx.x] = row_nan ? qnan : logf(tot);
+    }
+}
+
+// one workgroup per row: the `want` best allowed tokens of the row by processed log-prob
+// (descending, ties to the lower token id) -> row_tok / row_lp [rows, want]; row_cnt = how many exist
+__global__ __launch_bounds__(256) void k_row_topk(const float *logits, const uint32_t *bits, uint64_t words_per_row,
+                                                  uint32_t row_broadcast_bits, uint64_t vocab, const float *row_max,
+                                                  const float *row_lsum, uint32_t want, int32_t *row_tok, float *row_lp,
+                                                  uint32_t *row_cnt)
+{
+    __shared__ float s_v[4];
+    __shared__ int32_t s_t[4];
+    __shared__ int32_t s_win_tok;
+    const uint32_t row = blockIdx.x;
+    const float *x = logits + (uint64_t)row * vocab;
+    const uint32_t *b = bits + (row_broadcast_bits ? 0 : (uint64_t)row * words_per_row);
+    const float mx = row_max[row], ls = row_lsum[row];
+    const float ninf = -__builtin_huge_valf();
+    // this thread's candidates: tokens of words t, t+256, ...; `floor` excludes what it already emitted
+    float last_v = __builtin_huge_valf();
+    int32_t last_t = -1;
+    auto my_best = [&](float &bv, int32_t &bt) {
+        bv = ninf; bt = -1;
+        for (uint64_t w = threadIdx.x; w < words_per_row; w += 256) {
+            uint32_t word = b[w];
+            while (word) {
+                const int j = __ffs(word) - 1;
+                word &= word - 1;
+                const int32_t tok = (int32_t)(w * 32 + j);
+                if ((uint64_t)tok >= vocab) continue;
+                const float lp = logp_processed(x[tok], mx, ls);
+                // strictly after (last_v, last_t) in (value desc, token asc) order
+                const bool after = (lp < last_v) || (lp == last_v && tok > last_t);
+                const bool better = (lp > bv) || (lp == bv && (bt < 0 || tok < bt));
+                if (after && better && !(lp != lp)) { bv = lp; bt = tok; }
+            }
+        }
+    };
+    float bv; int32_t bt;
+    my_best(bv, bt);
+    uint32_t produced = 0;
+    for (uint32_t r = 0; r < want; r++) {
+        // workgroup arg-max of (bv desc, bt asc), bt < 0 = nothing left
+        float v = bv; int32_t t = bt;
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_down(v, o); const int32_t ot = __shfl_down(t, o);
+            if (ot >= 0 && (t < 0 || ov > v || (ov == v && ot < t))) { v = ov; t = ot; }
+        }
+        if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = v; s_t[threadIdx.x >> 6] = t; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float wv = s_v[0]; int32_t wt = s_t[0];
+            for (int i = 1; i < 4; i++) if (s_t[i] >= 0 && (wt < 0 || s_v[i] > wv || (s_v[i] == wv && s_t[i] < wt))) { wv = s_v[i]; wt = s_t[i]; }
+            s_win_tok = wt;
+            if (wt >= 0) { row_tok[(uint64_t)row * want + r] = wt; row_lp[(uint64_t)row * want + r] = wv; }
+        }
+        __syncthreads();
+        const int32_t wt = s_win_tok;
+        if (wt < 0) break;
+        produced++;
+        if (wt == bt) { last_v = bv; last_t = bt; my_best(bv, bt); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row_cnt[row] = produced;
+}
+
+// one wavefront per query: merge the K per-row lists; fill up with not-allowed tokens (constrained
+// score -inf, as torch.topk would when a query has fewer than `want` finite candidates)
+__global__ __launch_bounds__(64) void k_query_merge(const float *logits, const uint32_t *bits, uint64_t words_per_row,
+                                                    uint32_t row_broadcast_bits, uint64_t vocab, uint32_t beams, uint32_t want,
+                                                    const float *beam_scores, const float *row_max, const float *row_lsum,
+                                                    const int32_t *row_tok, const float *row_lp, const uint32_t *row_cnt,
+                                                    int64_t *top_idx, float *top_con, float *top_unc)
+{
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    // lane l < beams walks row q*beams + l
+    const uint32_t row = q * beams + (lane < beams ? lane : 0);
+    uint32_t head = 0;
+    const uint32_t cnt = lane < beams ? row_cnt[row] : 0;
+    const float bs = beam_scores[row];
+    uint32_t out = 0;
+    for (; out < want; out++) {
+        float v = -__builtin_huge_valf(); int64_t idx = -1;
+        if (lane < beams && head < cnt) {
+            v = row_lp[(uint64_t)row * want + head] + bs;
+            idx = (int64_t)lane * (int64_t)vocab + row_tok[(uint64_t)row * want + head];
+        }
+        float bv = v; int64_t bi = idx;
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_down(bv, o); const int64_t oi = __shfl_down(bi, o);
+            if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+        }
+        bv = __shfl(bv, 0); bi = __shfl(bi, 0);
+        if (bi < 0) break;
+        if (idx == bi) head++;
+        if (lane == 0) {
+            top_idx[(uint64_t)q * want + out] = bi;
+            top_con[(uint64_t)q * want + out] = bv;
+            top_unc[(uint64_t)q * want + out] = bv;      // allowed token: constrained == unconstrained
+        }
+    }
+    // fillers: lowest flat indices that are NOT allowed (beam 0 first); constrained -inf, real unconstrained score
+    if (lane == 0) {
+        uint32_t beam = 0; uint64_t tok = 0;
+        while (out < want && beam < beams) {
+            const uint32_t r = q * beams + beam;
+            const uint32_t *b = bits + (row_broadcast_bits ? 0 : (uint64_t)r * words_per_row);
+            if (tok >= vocab) { beam++; tok = 0; continue; }
+            if (!((b[tok >> 5] >> (tok & 31)) & 1)) {
+                const float lp = logp_processed(logits[(uint64_t)r * vocab + tok], row_max[r], row_lsum[r]);
+                top_idx[(uint64_t)q * want + out] = (int64_t)beam * (int64_t)vocab + (int64_t)tok;
+                top_con[(uint64_t)q * want + out] = -__builtin_huge_valf();
+                top_unc[(uint64_t)q * want + out] = lp + beam_scores[r];
+                out++;
+            }
+            tok++;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K3/K4: locate + doc binning
 // ---------------------------------------------------------------------------
 __global__ void k_locate(FmiDev ix, uint64_t n, const uint64_t *rows, uint64_t *pos_out, uint64_t *doc_out)
@@ -658,6 +822,46 @@ extern "C" int fmi_dev_constrain_scores(fmi_t *h, void *stream, uint64_t rows, u
     if (rc) return rc;
     hipLaunchKernelGGL(k_apply_bits, dim3(blocks_for(vocab, 256 * 4), (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
                        d_in, d_out, bits, rows, vocab, wpr);
+    HIPCHK(hipGetLastError());
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_constrained_topk(fmi_t *h, void *stream, uint64_t batch, uint64_t beams, uint64_t cur_len,
+                                        const int64_t *d_input_ids, const float *d_logits, const float *d_beam_scores,
+                                        uint64_t vocab, int64_t shift, int64_t pad_id, int64_t eos_id, const int64_t *force_from,
+                                        uint64_t n_force, int64_t stop_at_count, int always_allow_eos, const uint32_t *d_first_bits,
+                                        void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc)
+{
+    int rc = need_device(h); if (rc) return rc;
+    const uint64_t rows = batch * beams, want = 2 * beams;
+    if (rows == 0) return FMI_OK;
+    if (want > TOPK_MAX || beams > 64) { fmi_set_error("num_beams %llu: at most %d", (unsigned long long)beams, TOPK_MAX / 2); return FMI_ERR_UNSUPPORTED; }
+    const uint64_t wpr = (vocab + 31) / 32;
+    if (wpr > WS_BITS_WORDS) { fmi_set_error("vocab %llu too large", (unsigned long long)vocab); return FMI_ERR_UNSUPPORTED; }
+    // scratch: row_max[rows] row_lsum[rows] row_lp[rows*want] (f32) | row_tok[rows*want] (i32) | row_cnt[rows] (u32)
+    const uint64_t need = rows * 4 * (2 + 2 * want + 1);
+    if (!d_scratch || scratch_bytes < need) { fmi_set_error("scratch too small: need %llu bytes", (unsigned long long)need); return FMI_ERR_CAPACITY; }
+    float *row_max = (float *)d_scratch, *row_lsum = row_max + rows, *row_lp = row_lsum + rows;
+    int32_t *row_tok = (int32_t *)(row_lp + rows * want);
+    uint32_t *row_cnt = (uint32_t *)(row_tok + rows * want);
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t *bits;
+    uint32_t broadcast = 0;
+    if (cur_len < 2) {
+        if (!d_first_bits) { fmi_set_error("cur_len == 1 needs the occurring_distinct bitmap"); return FMI_ERR_ARG; }
+        bits = d_first_bits; broadcast = 1;      // the constant first-step mask (beam_search.py:73-77)
+    } else {
+        if (rows > h->ws_rows) { rc = fmi_dev_reserve(h, rows); if (rc) return rc; }
+        rc = allowed_bits_impl(h, st, rows, cur_len, d_input_ids, ws_bits(h), vocab, shift, pad_id, eos_id, force_from, n_force,
+                               stop_at_count, always_allow_eos);
+        if (rc) return rc;
+        bits = ws_bits(h);
+    }
+    hipLaunchKernelGGL(k_row_lse, dim3((unsigned)rows), dim3(256), 0, st, d_logits, vocab, row_max, row_lsum);
+    hipLaunchKernelGGL(k_row_topk, dim3((unsigned)rows), dim3(256), 0, st, d_logits, bits, wpr, broadcast, vocab, row_max, row_lsum,
+                       (uint32_t)want, row_tok, row_lp, row_cnt);
+    hipLaunchKernelGGL(k_query_merge, dim3((unsigned)batch), dim3(64), 0, st, d_logits, bits, wpr, broadcast, vocab, (uint32_t)beams,
+                       (uint32_t)want, d_beam_scores, row_max, row_lsum, row_tok, row_lp, row_cnt, d_top_idx, d_top_con, d_top_unc);
     HIPCHK(hipGetLastError());
     return FMI_OK;
 }

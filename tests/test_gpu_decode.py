@@ -72,3 +72,52 @@ def test_graph_captured_step_matches_eager_step():
             eager.reorder(perm)
             graph.reorder(perm)
         enc_ids = torch.roll(enc_ids, 1, 0)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(force_decoding_from=[2], eos_token_id=7), dict(always_allow_eos=True),
+                                dict(stop_at_count=2)])
+def test_fused_constrained_topk_matches_unfused_step(kw):
+    """fmi_dev_constrained_topk against the reference's own sequence of ops on the same logits: same picks (as a set
+    per query: ties/-inf fillers are unordered in torch.topk too), unconstrained scores within fp32 noise."""
+    from seal_amd import FMIndex
+    from seal_amd.beam_search import IndexBasedLogitsProcessor, _inf_nan_remove
+    from tests.helpers import make_docs
+    vocab, B, K = 120, 5, 4
+    dev = torch.device("cuda:0")
+    docs = make_docs(3, 150, vocab - 8, title_sep=7)
+    ix = FMIndex()
+    ix.initialize(docs)
+    eos = kw.get("eos_token_id", 2)
+    proc = IndexBasedLogitsProcessor(ix, K, pad_token_id=1, eos_token_id=eos, force_decoding_from=kw.get("force_decoding_from"),
+                                     stop_at_count=kw.get("stop_at_count", 0), always_allow_eos=kw.get("always_allow_eos", False))
+    g = torch.Generator(device="cpu").manual_seed(0)
+    import random
+    rng = random.Random(0)
+    for cur_len in (1, 2, 3, 5):
+        rows = []
+        for i in range(B * K):
+            d = rng.choice(docs)
+            a = 0 if kw.get("force_decoding_from") else rng.randrange(len(d))
+            sent = ([2] + d[a:a + cur_len - 1] + [1] * cur_len)[:cur_len]
+            if i % 6 == 5 and cur_len > 2:
+                sent[-1] = rng.randrange(8, vocab - 8)
+            rows.append(sent)
+        ids = torch.tensor(rows, device=dev)
+        logits = torch.randn(B * K, vocab, generator=g).to(dev) * 3
+        logits[:, 0] = float("-inf")
+        beam_scores = (torch.randn(B * K, generator=g) * 2).to(dev)
+        flat, unc = proc.fused_topk(ids, logits, beam_scores, B, K)
+        processed = _inf_nan_remove(torch.log_softmax(logits, -1))
+        u = (processed + beam_scores[:, None]).view(B, K * vocab)
+        c = (proc(ids, processed) + beam_scores[:, None]).view(B, K * vocab)
+        want_c, want_i = torch.topk(c, 2 * K, dim=1)
+        for q in range(B):
+            finite = int(torch.isfinite(want_c[q]).sum())
+            assert set(flat[q, :finite].tolist()) == set(want_i[q, :finite].tolist()), (cur_len, q)
+            assert torch.allclose(unc[q, :finite], u[q].gather(0, flat[q, :finite]), atol=1e-5)
+            assert torch.allclose(torch.sort(unc[q, :finite], descending=True).values, want_c[q, :finite], atol=1e-5)
+            # fillers: not allowed (constrained -inf) but carry their real unconstrained score
+            for j in range(finite, 2 * K):
+                assert c[q, flat[q, j]] == float("-inf")
+                assert abs(unc[q, j].item() - u[q, flat[q, j]].item()) <= 1e-5
+            assert len(set(flat[q].tolist())) == 2 * K
