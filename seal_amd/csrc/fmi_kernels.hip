@@ -409,67 +409,118 @@ __global__ __launch_bounds__(256) void k_row_lse(const float *logits, uint64_t v
     }
 }
 
-// one workgroup per row: the `want` best allowed tokens of the row by processed log-prob
-// (descending, ties to the lower token id) -> row_tok / row_lp [rows, want]; row_cnt = how many exist
+// order-preserving map float -> uint32 (ascending)
+__device__ __forceinline__ uint32_t float_key(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// one workgroup per row: the `want` (<= 64) best allowed tokens of the row by processed log-prob
+// (descending, ties to the lower token id) -> row_tok / row_lp [rows, want]; row_cnt = how many exist.
+// Exact radix select: 4 coalesced passes (8 bits each) over the row's allowed tokens histogram the
+// keys that match the prefix found so far and pin the want-th largest key T; one more pass collects
+// the keys > T plus as many keys == T as still needed (lowest tokens first); <= 64 survivors are
+// ordered by counting ranks.  Lanes read consecutive tokens, the bitmap word is a broadcast.
 __global__ __launch_bounds__(256) void k_row_topk(const float *logits, const uint32_t *bits, uint64_t words_per_row,
                                                   uint32_t row_broadcast_bits, uint64_t vocab, const float *row_max,
                                                   const float *row_lsum, uint32_t want, int32_t *row_tok, float *row_lp,
                                                   uint32_t *row_cnt)
 {
-    __shared__ float s_v[4];
-    __shared__ int32_t s_t[4];
-    __shared__ int32_t s_win_tok;
-    const uint32_t row = blockIdx.x;
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_prefix, s_remaining, s_n_gt, s_n_eq, s_total;
+    __shared__ int32_t s_ctok[TOPK_MAX];
+    __shared__ float s_cval[TOPK_MAX];
+    __shared__ uint32_t s_wave[4];
+    const uint32_t row = blockIdx.x, tid = threadIdx.x;
     const float *x = logits + (uint64_t)row * vocab;
     const uint32_t *b = bits + (row_broadcast_bits ? 0 : (uint64_t)row * words_per_row);
     const float mx = row_max[row], ls = row_lsum[row];
-    const float ninf = -__builtin_huge_valf();
-    // this thread's candidates: tokens of words t, t+256, ...; `floor` excludes what it already emitted
-    float last_v = __builtin_huge_valf();
-    int32_t last_t = -1;
-    auto my_best = [&](float &bv, int32_t &bt) {
-        bv = ninf; bt = -1;
-        for (uint64_t w = threadIdx.x; w < words_per_row; w += 256) {
+    if (tid == 0) { s_prefix = 0; s_remaining = want; s_n_gt = 0; s_n_eq = 0; s_total = 0; }
+    // number of allowed tokens
+    {
+        uint32_t c = 0;
+        for (uint64_t w = tid; w < words_per_row; w += 256) {
             uint32_t word = b[w];
-            while (word) {
-                const int j = __ffs(word) - 1;
-                word &= word - 1;
-                const int32_t tok = (int32_t)(w * 32 + j);
-                if ((uint64_t)tok >= vocab) continue;
-                const float lp = logp_processed(x[tok], mx, ls);
-                // strictly after (last_v, last_t) in (value desc, token asc) order
-                const bool after = (lp < last_v) || (lp == last_v && tok > last_t);
-                const bool better = (lp > bv) || (lp == bv && (bt < 0 || tok < bt));
-                if (after && better && !(lp != lp)) { bv = lp; bt = tok; }
-            }
+            if ((w + 1) * 32 > vocab) { const uint32_t keep = (uint32_t)(vocab - w * 32); word &= keep >= 32 ? ~0u : ((1u << keep) - 1); }
+            c += (uint32_t)__popc(word);
         }
-    };
-    float bv; int32_t bt;
-    my_best(bv, bt);
-    uint32_t produced = 0;
-    for (uint32_t r = 0; r < want; r++) {
-        // workgroup arg-max of (bv desc, bt asc), bt < 0 = nothing left
-        float v = bv; int32_t t = bt;
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_down(v, o); const int32_t ot = __shfl_down(t, o);
-            if (ot >= 0 && (t < 0 || ov > v || (ov == v && ot < t))) { v = ov; t = ot; }
-        }
-        if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = v; s_t[threadIdx.x >> 6] = t; }
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
         __syncthreads();
-        if (threadIdx.x == 0) {
-            float wv = s_v[0]; int32_t wt = s_t[0];
-            for (int i = 1; i < 4; i++) if (s_t[i] >= 0 && (wt < 0 || s_v[i] > wv || (s_v[i] == wv && s_t[i] < wt))) { wv = s_v[i]; wt = s_t[i]; }
-            s_win_tok = wt;
-            if (wt >= 0) { row_tok[(uint64_t)row * want + r] = wt; row_lp[(uint64_t)row * want + r] = wv; }
-        }
-        __syncthreads();
-        const int32_t wt = s_win_tok;
-        if (wt < 0) break;
-        produced++;
-        if (wt == bt) { last_v = bv; last_t = bt; my_best(bv, bt); }
+        if ((tid & 63) == 0 && c) atomicAdd(&s_total, c);
         __syncthreads();
     }
-    if (threadIdx.x == 0) row_cnt[row] = produced;
+    const uint32_t total = s_total;
+    const uint32_t k_sel = total < want ? total : want;        // how many we will output
+    if (k_sel == 0) { if (tid == 0) row_cnt[row] = 0; return; }
+    uint32_t T = 0;
+    if (total > want) {
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 24 - 8 * pass;
+            s_hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix;
+            const uint32_t pmask = pass == 0 ? 0u : (~0u << (shift + 8));
+            for (uint64_t tok = tid; tok < vocab; tok += 256) {
+                if (!((b[tok >> 5] >> (tok & 31)) & 1)) continue;
+                const uint32_t key = float_key(logp_processed(x[tok], mx, ls));
+                if ((key & pmask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t rem = s_remaining, bin = 255;
+                for (;; bin--) {
+                    const uint32_t c = s_hist[bin];
+                    if (c >= rem || bin == 0) break;
+                    rem -= c;
+                }
+                s_remaining = rem;                 // rank of the target inside the chosen bin
+                s_prefix = prefix | (bin << shift);
+            }
+            __syncthreads();
+        }
+        T = s_prefix;
+    }
+    const uint32_t need_eq_max = total > want ? s_remaining : 0;     // ties with T still needed
+    __syncthreads();
+    // collect: everything (total <= want) or keys > T and the first need_eq_max keys == T
+    for (uint64_t base = 0; base < vocab; base += 256) {
+        const uint64_t tok = base + tid;
+        bool ok = tok < vocab && ((b[tok >> 5] >> (tok & 31)) & 1);
+        float lp = 0.f; uint32_t key = 0;
+        if (ok) { lp = logp_processed(x[tok], mx, ls); key = float_key(lp); }
+        const bool gt = ok && (total <= want || key > T);
+        const bool eq = ok && total > want && key == T;
+        if (gt) { const uint32_t o = atomicAdd(&s_n_gt, 1u); if (o < TOPK_MAX) { s_ctok[o] = (int32_t)tok; s_cval[o] = lp; } }
+        // ties in token order: workgroup prefix count per 256-token chunk
+        const uint64_t be = __ballot(eq);
+        if ((tid & 63) == 0) s_wave[tid >> 6] = (uint32_t)__popcll(be);
+        __syncthreads();
+        if (s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]) {
+            uint32_t before = s_n_eq;
+            for (uint32_t w = 0; w < (tid >> 6); w++) before += s_wave[w];
+            const uint32_t my = before + (uint32_t)__popcll(be & ((1ull << (tid & 63)) - 1));
+            __syncthreads();
+            if (eq && my < need_eq_max) {
+                const uint32_t o = (k_sel - need_eq_max) + my;       // ties fill the tail slots
+                s_ctok[o] = (int32_t)tok; s_cval[o] = lp;
+            }
+            if (tid == 0) s_n_eq += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        }
+        __syncthreads();
+    }
+    // order the k_sel survivors by (value desc, token asc)
+    if (tid < k_sel) {
+        const float v = s_cval[tid]; const int32_t t = s_ctok[tid];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < k_sel; j++) {
+            const float ov = s_cval[j]; const int32_t ot = s_ctok[j];
+            rank += (ov > v) || (ov == v && ot < t);
+        }
+        row_tok[(uint64_t)row * want + rank] = t;
+        row_lp[(uint64_t)row * want + rank] = v;
+    }
+    if (tid == 0) row_cnt[row] = k_sel;
 }
 
 // one wavefront per query: merge the K per-row lists; fill up with not-allowed tokens (constrained
