@@ -1,0 +1,34 @@
+/*
+ * sealnn.h -- fused fp32 decoder-step kernels for the BART step decoder (gfx950), part of libsealfm.so.
+ * They replace runs of small PyTorch kernels inside seal_amd/bart_decoder.py's hipGraph-captured step
+ * (the reference drives HF's BartDecoderLayer through generate(); reference seal/beam_search.py:231-238).
+ * Device pointers + hipStream_t (as void*), no allocation, no synchronisation: capture-safe.
+ */
+#ifndef SEALNN_H
+#define SEALNN_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* single-position self-attention with KV-cache append.
+ *   qkv    [rows, 3, heads, 64] fp32 (q, k, v of the new position; q already scaled or scale passed)
+ *   kcache, vcache [rows, heads, T, 64]; position *d_t is written, positions 0..*d_t attended
+ *   out    [rows, heads*64] */
+int sealnn_self_attn_step(void *stream, const float *qkv, float *kcache, float *vcache, const int64_t *d_t,
+                          uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out);
+
+/* single-position cross-attention, encoder K/V shared by the `beams` rows of a query.
+ *   q [batch*beams, heads, 64]; ck [batch, heads, 64, S]; cv [batch, heads, S, 64]; bias [batch, S] (0 / -big)
+ *   out [batch*beams, heads*64];  S <= 64 */
+int sealnn_cross_attn_step(void *stream, const float *q, const float *ck, const float *cv, const float *bias,
+                           uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S, float scale, float *out);
+
+/* out = LayerNorm(x + y) * gamma + beta over the last dimension d (multiple of 4, <= 4096); eps as torch */
+int sealnn_add_layernorm(void *stream, const float *x, const float *y, const float *gamma, const float *beta,
+                         uint32_t rows, uint32_t d, float eps, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

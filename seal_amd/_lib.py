@@ -66,6 +66,15 @@ SIGNATURES = {
     "fmi_log_odds_batch": (_int, [_u64, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp]),
 }
 
+_f32 = ctypes.c_float
+_u32 = ctypes.c_uint32
+# include/sealnn.h (fused decoder-step kernels, same shared library)
+NN_SIGNATURES = {
+    "sealnn_self_attn_step": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp]),
+    "sealnn_cross_attn_step": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _vp]),
+    "sealnn_add_layernorm": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp]),
+}
+
 _lib = None
 
 
@@ -83,7 +92,7 @@ def lib():
                 f"{_build.LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  seal_amd has no pure-Python or CPU fallback.")
         L = ctypes.CDLL(_build.LIB)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(NN_SIGNATURES.items()):
             fn = getattr(L, name)   # AttributeError here = ABI drift, fail loudly
             fn.restype = res
             fn.argtypes = args

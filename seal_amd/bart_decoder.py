@@ -93,12 +93,40 @@ class BartStepDecoder:
             cache[key] = st
         return st
 
+    use_fused_kernels = True      # include/sealnn.h: self-attn / cross-attn / add+LayerNorm as single HIP kernels
+
     def _step_static(self, st):
         B, K, S_pad, T = st.shape
         R, H, dh = B * K, self.h, self.dh
         x = self.embed(st.tokens)
         x = x + self.pos.weight.index_select(0, st.t + self.pos_offset)
         x = self.ln_emb(x)
+        fused = (self.use_fused_kernels and x.dtype == torch.float32 and dh == 64 and T <= 17 and S_pad <= 64 and x.is_cuda)
+        if fused:
+            from ._lib import check, lib
+            L_ = lib()
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            cbias = st.cbias.view(B, S_pad)
+
+            def add_ln(res, y, ln):
+                out = torch.empty_like(res)
+                check(L_.sealnn_add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                              R, self.d, float(ln.eps), out.data_ptr()))
+                return out
+            for li, L in enumerate(self.layers):
+                qkv = F.linear(x, L["qkv_w"], L["qkv_b"])
+                a = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
+                check(L_.sealnn_self_attn_step(stream, qkv.data_ptr(), st.kv[li, 0].data_ptr(), st.kv[li, 1].data_ptr(),
+                                               st.t.data_ptr(), R, H, T, float(self.scale), a.data_ptr()))
+                x = add_ln(x, L["so"](a), L["ln1"])
+                q = L["cq"](x)
+                c = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
+                check(L_.sealnn_cross_attn_step(stream, q.data_ptr(), st.ck[li].data_ptr(), st.cv[li].data_ptr(), cbias.data_ptr(),
+                                                B, K, H, S_pad, float(self.scale), c.data_ptr()))
+                x = add_ln(x, L["co"](c), L["ln2"])
+                x = add_ln(x, L["fc2"](L["act"](L["fc1"](x))), L["ln3"])
+            st.t.add_(1)
+            return (F.linear(x, self.lm_w) + self.lm_b).float()
         future = st.pos_idx > st.t                                   # cache slots not written yet
         for li, L in enumerate(self.layers):
             qkv = F.linear(x, L["qkv_w"], L["qkv_b"]).view(R, 3, H, dh)

@@ -1,0 +1,146 @@
+// Fused fp32 kernels of the BART step decoder (include/sealnn.h).  Shapes are tiny (one new
+// position, <= 16 cached positions, <= 64 encoder positions, head_dim 64): the point is to replace
+// ~17 launch-bound PyTorch kernels per decoder layer with 3, not to reach a roofline.
+#include <hip/hip_runtime.h>
+
+#include "../../include/sealnn.h"
+#include "fmi_internal.h"
+
+static __device__ __forceinline__ float wave_sum(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+static __device__ __forceinline__ float wave_max(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// one wavefront per (row, head); lane = head dimension
+__global__ __launch_bounds__(256) void k_self_attn_step(const float *qkv, float *kcache, float *vcache, const int64_t *d_t,
+                                                        uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= rows * heads) return;
+    const uint32_t row = item / heads, head = item % heads;
+    const uint32_t t = (uint32_t)*d_t;
+    const float *base = qkv + ((uint64_t)row * 3 * heads + head) * 64;
+    const float q = base[lane] * scale;
+    const float kn = base[(uint64_t)heads * 64 + lane];
+    const float vn = base[(uint64_t)2 * heads * 64 + lane];
+    float *kc = kcache + ((uint64_t)row * heads + head) * T * 64;
+    float *vc = vcache + ((uint64_t)row * heads + head) * T * 64;
+    kc[(uint64_t)t * 64 + lane] = kn;
+    vc[(uint64_t)t * 64 + lane] = vn;
+    // scores over positions 0..t (the new one from registers)
+    float s[FMI_MAX_LEVELS];          // T <= 17 positions kept in registers
+    float m = -__builtin_huge_valf();
+    for (uint32_t p = 0; p <= t; p++) {
+        const float kv = (p == t) ? kn : kc[(uint64_t)p * 64 + lane];
+        const float d = wave_sum(q * kv);
+        s[p] = d;
+        m = fmaxf(m, d);
+    }
+    float denom = 0.f, acc = 0.f;
+    for (uint32_t p = 0; p <= t; p++) {
+        const float e = expf(s[p] - m);
+        denom += e;
+        const float vv = (p == t) ? vn : vc[(uint64_t)p * 64 + lane];
+        acc += e * vv;
+    }
+    out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
+}
+
+// one wavefront per (row, head); scores: lane = encoder position, output: lane = head dimension
+__global__ __launch_bounds__(256) void k_cross_attn_step(const float *q, const float *ck, const float *cv, const float *bias,
+                                                         uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S, float scale,
+                                                         float *out)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= batch * beams * heads) return;
+    const uint32_t row = item / heads, head = item % heads, b = row / beams;
+    const float qd = q[((uint64_t)row * heads + head) * 64 + lane] * scale;
+    const float *k = ck + ((uint64_t)b * heads + head) * 64 * S;      // [64, S]
+    const float *v = cv + ((uint64_t)b * heads + head) * S * 64;      // [S, 64]
+    float sc = 0.f;
+    for (uint32_t d = 0; d < 64; d++) {
+        const float qv = __shfl(qd, d);
+        if (lane < S) sc += qv * k[(uint64_t)d * S + lane];
+    }
+    sc = lane < S ? sc + bias[(uint64_t)b * S + lane] : -__builtin_huge_valf();
+    const float m = wave_max(sc);
+    const float e = lane < S ? expf(sc - m) : 0.f;
+    const float denom = wave_sum(e);
+    float acc = 0.f;
+    for (uint32_t p = 0; p < S; p++) acc += __shfl(e, p) * v[(uint64_t)p * 64 + lane];
+    out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
+}
+
+// one wavefront per row, d <= 4096 (16 float4 per lane)
+__global__ __launch_bounds__(256) void k_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta,
+                                                       uint32_t rows, uint32_t d, float eps, float *out)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (uint64_t)row * d);
+    const float4 *yr = reinterpret_cast<const float4 *>(y + (uint64_t)row * d);
+    const uint32_t n4 = d / 4;
+    float4 v[16];
+    float sum = 0.f;
+    uint32_t c = 0;
+    for (uint32_t i = lane; i < n4; i += 64, c++) {
+        const float4 a = xr[i], b = yr[i];
+        v[c] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        sum += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+    }
+    const float mean = wave_sum(sum) / (float)d;
+    float var = 0.f;
+    for (uint32_t j = 0; j < c; j++) {
+        const float a = v[j].x - mean, b = v[j].y - mean, e = v[j].z - mean, f = v[j].w - mean;
+        var += (a * a + b * b) + (e * e + f * f);
+    }
+    const float rstd = rsqrtf(wave_sum(var) / (float)d + eps);
+    const float4 *g4 = reinterpret_cast<const float4 *>(gamma), *b4 = reinterpret_cast<const float4 *>(beta);
+    float4 *o4 = reinterpret_cast<float4 *>(out + (uint64_t)row * d);
+    c = 0;
+    for (uint32_t i = lane; i < n4; i += 64, c++) {
+        const float4 g = g4[i], bb = b4[i];
+        o4[i] = make_float4((v[c].x - mean) * rstd * g.x + bb.x, (v[c].y - mean) * rstd * g.y + bb.y,
+                            (v[c].z - mean) * rstd * g.z + bb.z, (v[c].w - mean) * rstd * g.w + bb.w);
+    }
+}
+
+#define NNCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { fmi_set_error("sealnn launch failed: %s", hipGetErrorString(e_)); return FMI_ERR_HIP; } } while (0)
+
+extern "C" int sealnn_self_attn_step(void *stream, const float *qkv, float *kcache, float *vcache, const int64_t *d_t, uint32_t rows,
+                                     uint32_t heads, uint32_t T, float scale, float *out)
+{
+    if (T > FMI_MAX_LEVELS) { fmi_set_error("sealnn_self_attn_step: at most %u cached positions", FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
+    const uint32_t items = rows * heads;
+    hipLaunchKernelGGL(k_self_attn_step, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, kcache, vcache, d_t, rows, heads, T, scale, out);
+    NNCHK();
+    return FMI_OK;
+}
+
+extern "C" int sealnn_cross_attn_step(void *stream, const float *q, const float *ck, const float *cv, const float *bias, uint32_t batch,
+                                      uint32_t beams, uint32_t heads, uint32_t S, float scale, float *out)
+{
+    if (S > 64) { fmi_set_error("sealnn_cross_attn_step: encoder length %u > 64", S); return FMI_ERR_UNSUPPORTED; }
+    const uint32_t items = batch * beams * heads;
+    hipLaunchKernelGGL(k_cross_attn_step, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, ck, cv, bias, batch, beams, heads, S, scale, out);
+    NNCHK();
+    return FMI_OK;
+}
+
+extern "C" int sealnn_add_layernorm(void *stream, const float *x, const float *y, const float *gamma, const float *beta, uint32_t rows,
+                                    uint32_t d, float eps, float *out)
+{
+    if (d % 4 || d > 4096) { fmi_set_error("sealnn_add_layernorm: d=%u unsupported", d); return FMI_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(k_add_layernorm, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta, rows, d, eps, out);
+    NNCHK();
+    return FMI_OK;
+}

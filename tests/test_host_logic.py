@@ -23,6 +23,9 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert L.fmi_abi_version() == 1
+    from seal_amd._lib import NN_SIGNATURES
+    nn = set(re.findall(r"\b(sealnn_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "include", "sealnn.h")).read()))
+    assert nn == set(NN_SIGNATURES) and all(hasattr(L, n) for n in nn)
 
 
 def _host_index(data):
