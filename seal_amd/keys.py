@@ -564,21 +564,25 @@ def _aggregate_steps(ngrams_and_scores, unigram_scores=None, index=None, max_occ
         if cutoff is None:
             raise IndexError("list index out of range")
 
-    # ---- key scores (keys.py:207-234) ----
+    # ---- key scores (keys.py:207-234), vectorised; the log-odds go through libm in C exactly as
+    #      python's math module would compute them one key at a time ----
     seen_unigrams = {0, 1, 2}
-    scored: List[Tuple[List[int], float]] = []
-    for ng, sr in keys:
+    for ng, _ in keys:
         if len(ng) == 1:
             seen_unigrams.add(ng[0])
-        count = count_of(ng)
-        if count == 0:
-            sco = 0.0
-        elif use_fm_index_frequency:
-            sr = (sr - 1e-10) * (1.0 - length_penalty) ** (len(ng) - 1.0)
-            sco = max(_log_odds(sr, count, ntokens, smoothing), 0.0) ** alpha
+    scored: List[Tuple[List[int], float]] = []
+    if keys:
+        cnts = np.fromiter((count_of(ng) for ng, _ in keys), dtype=np.int64, count=len(keys))
+        # powers stay python floats (C pow, as the reference's `**`): numpy's vectorised pow may differ by an ulp
+        lp_factor = [(1.0 - length_penalty) ** (len(ng) - 1.0) for ng, _ in keys]
+        if use_fm_index_frequency:
+            sr_adj = np.asarray([(sr - 1e-10) * f for (_, sr), f in zip(keys, lp_factor)], dtype=np.float64)
+            odds = _log_odds_many(sr_adj, cnts, ntokens, smoothing).tolist()
+            sco = [max(o, 0.0) ** alpha for o in odds]
         else:
-            sco = (max(sr - cutoff, 0.0) * (1.0 - length_penalty) ** (len(ng) - 1.0)) ** alpha
-        scored.append((ng, sco))
+            sco = [(max(sr - cutoff, 0.0) * f) ** alpha for (_, sr), f in zip(keys, lp_factor)]
+        sco = [0.0 if c == 0 else v for c, v in zip(cnts.tolist(), sco)]
+        scored = [(ng, float(v)) for (ng, _), v in zip(keys, sco)]
 
     # ---- unigram scores (keys.py:236-278) ----
     if unigram_scores is not None:
@@ -605,7 +609,7 @@ def _aggregate_steps(ngrams_and_scores, unigram_scores=None, index=None, max_occ
             if use_fm_index_frequency:
                 sco = np.maximum(_log_odds_many(raw[cand], uni_counts[cand], ntokens, smoothing), 0.0)
             else:
-                sco = np.maximum(raw[cand] - cutoff, 0.0) ** alpha
+                sco = np.asarray([max(v - cutoff, 0.0) ** alpha for v in raw[cand].tolist()], dtype=np.float64)
             us[cand] = sco
         unigram_scores = us          # indexable by token id like the reference's list
         if add_best_unigrams_to_ngrams:
