@@ -28,6 +28,13 @@ int sealnn_cross_attn_step(void *stream, const float *q, const float *ck, const 
 int sealnn_add_layernorm(void *stream, const float *x, const float *y, const float *gamma, const float *beta,
                          uint32_t rows, uint32_t d, float eps, float *out);
 
+/* teacher-forced causal self-attention: qkv [n_seq, T, 3, heads, 64] -> out [n_seq, T, heads*64]; T <= 17 */
+int sealnn_causal_self_attn(void *stream, const float *qkv, uint32_t n_seq, uint32_t T, uint32_t heads, float scale, float *out);
+
+/* cross-attention of arbitrary rows: row_batch[row] = query whose encoder K/V (layouts as above) the row attends */
+int sealnn_cross_attn_rows(void *stream, const float *q, const float *ck, const float *cv, const float *bias,
+                           const int32_t *row_batch, uint32_t rows, uint32_t heads, uint32_t S, float scale, float *out);
+
 #ifdef __cplusplus
 }
 #endif

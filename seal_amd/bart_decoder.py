@@ -93,6 +93,59 @@ class BartStepDecoder:
             cache[key] = st
         return st
 
+    # ------------------------------------------------------------------
+    # teacher-forced forward for rescoring (reference keys.py:64-141 runs HF's full model per chunk of
+    # keys, re-projecting the encoder states for every row): encoder K/V are projected once per QUERY
+    # and every decoder row points at its query.
+    # ------------------------------------------------------------------
+    def can_teacher_force(self, enc_hidden: torch.Tensor, T: int) -> bool:
+        return (self.use_fused_kernels and enc_hidden.is_cuda and enc_hidden.dtype == torch.float32 and self.dh == 64
+                and T <= 17 and enc_hidden.shape[1] <= 64)
+
+    @torch.no_grad()
+    def teacher_prepare(self, enc_hidden: torch.Tensor, attention_mask: torch.Tensor):
+        """per-query cross-attention K/V ([layers][B, H, 64, S] / [B, H, S, 64]) and additive bias [B, S]"""
+        B, S, _ = enc_hidden.shape
+        cross = []
+        for L in self.layers:
+            kv = F.linear(enc_hidden, L["ckv_w"], L["ckv_b"]).view(B, S, 2, self.h, self.dh)
+            cross.append((kv[:, :, 0].permute(0, 2, 3, 1).contiguous(), kv[:, :, 1].permute(0, 2, 1, 3).contiguous()))
+        bias = torch.zeros(B, S, dtype=enc_hidden.dtype, device=enc_hidden.device)
+        bias.masked_fill_(attention_mask == 0, torch.finfo(enc_hidden.dtype).min)
+        return cross, bias, S
+
+    @torch.no_grad()
+    def teacher_logits(self, dec_ids: torch.Tensor, qidx: torch.Tensor, prepared) -> torch.Tensor:
+        """decoder input ids [N, T] (row n belongs to query qidx[n]) -> logits [N, T, vocab]"""
+        from ._lib import check, lib
+        L_ = lib()
+        cross, bias, S = prepared
+        N, T = dec_ids.shape
+        dev = dec_ids.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        x = self.embed(dec_ids) + self.pos.weight[self.pos_offset:self.pos_offset + T]
+        x = self.ln_emb(x).view(N * T, self.d)
+        row_batch = qidx.to(torch.int32).repeat_interleave(T).contiguous()
+
+        def add_ln(res, y, ln):
+            out = torch.empty_like(res)
+            check(L_.sealnn_add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                          N * T, self.d, float(ln.eps), out.data_ptr()))
+            return out
+        for li, L in enumerate(self.layers):
+            qkv = F.linear(x, L["qkv_w"], L["qkv_b"])
+            a = torch.empty(N * T, self.d, dtype=x.dtype, device=dev)
+            check(L_.sealnn_causal_self_attn(stream, qkv.data_ptr(), N, T, self.h, float(self.scale), a.data_ptr()))
+            x = add_ln(x, L["so"](a), L["ln1"])
+            q = L["cq"](x)
+            c = torch.empty(N * T, self.d, dtype=x.dtype, device=dev)
+            ck, cv = cross[li]
+            check(L_.sealnn_cross_attn_rows(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
+                                            N * T, self.h, S, float(self.scale), c.data_ptr()))
+            x = add_ln(x, L["co"](c), L["ln2"])
+            x = add_ln(x, L["fc2"](L["act"](L["fc1"](x))), L["ln3"])
+        return (F.linear(x, self.lm_w) + self.lm_b).view(N, T, -1)
+
     use_fused_kernels = True      # include/sealnn.h: self-attn / cross-attn / add+LayerNorm as single HIP kernels
 
     def _step_static(self, st):

@@ -79,6 +79,58 @@ __global__ __launch_bounds__(256) void k_cross_attn_step(const float *q, const f
     out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
 }
 
+// teacher-forced causal self-attention over T positions: one wavefront per (sequence, head); lane = dim
+__global__ __launch_bounds__(256) void k_causal_self_attn(const float *qkv, uint32_t n_seq, uint32_t T, uint32_t heads, float scale,
+                                                          float *out)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_seq * heads) return;
+    const uint32_t n = item / heads, head = item % heads;
+    const uint64_t stride = (uint64_t)3 * heads * 64;               // per position
+    const float *base = qkv + (uint64_t)n * T * stride + head * 64;
+    float kreg[FMI_MAX_LEVELS], vreg[FMI_MAX_LEVELS];
+    for (uint32_t j = 0; j < T; j++) {
+        kreg[j] = base[(uint64_t)j * stride + (uint64_t)heads * 64 + lane];
+        vreg[j] = base[(uint64_t)j * stride + (uint64_t)2 * heads * 64 + lane];
+    }
+    for (uint32_t i = 0; i < T; i++) {
+        const float q = base[(uint64_t)i * stride + lane] * scale;
+        float s[FMI_MAX_LEVELS];
+        float m = -__builtin_huge_valf();
+        for (uint32_t j = 0; j <= i; j++) { s[j] = wave_sum(q * kreg[j]); m = fmaxf(m, s[j]); }
+        float denom = 0.f, acc = 0.f;
+        for (uint32_t j = 0; j <= i; j++) { const float e = expf(s[j] - m); denom += e; acc += e * vreg[j]; }
+        out[((uint64_t)n * T + i) * heads * 64 + head * 64 + lane] = acc / denom;
+    }
+}
+
+// cross-attention for arbitrary rows: row_batch[row] selects the query whose encoder K/V to use
+__global__ __launch_bounds__(256) void k_cross_attn_rows(const float *q, const float *ck, const float *cv, const float *bias,
+                                                         const int32_t *row_batch, uint32_t rows, uint32_t heads, uint32_t S,
+                                                         float scale, float *out)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= rows * heads) return;
+    const uint32_t row = item / heads, head = item % heads, b = (uint32_t)row_batch[row];
+    const float qd = q[((uint64_t)row * heads + head) * 64 + lane] * scale;
+    const float *k = ck + ((uint64_t)b * heads + head) * 64 * S;
+    const float *v = cv + ((uint64_t)b * heads + head) * S * 64;
+    float sc = 0.f;
+    for (uint32_t d = 0; d < 64; d++) {
+        const float qv = __shfl(qd, d);
+        if (lane < S) sc += qv * k[(uint64_t)d * S + lane];
+    }
+    sc = lane < S ? sc + bias[(uint64_t)b * S + lane] : -__builtin_huge_valf();
+    const float m = wave_max(sc);
+    const float e = lane < S ? expf(sc - m) : 0.f;
+    const float denom = wave_sum(e);
+    float acc = 0.f;
+    for (uint32_t p = 0; p < S; p++) acc += __shfl(e, p) * v[(uint64_t)p * 64 + lane];
+    out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
+}
+
 // one wavefront per row, d <= 4096 (16 float4 per lane)
 __global__ __launch_bounds__(256) void k_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta,
                                                        uint32_t rows, uint32_t d, float eps, float *out)
@@ -141,6 +193,25 @@ extern "C" int sealnn_add_layernorm(void *stream, const float *x, const float *y
 {
     if (d % 4 || d > 4096) { fmi_set_error("sealnn_add_layernorm: d=%u unsupported", d); return FMI_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_add_layernorm, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta, rows, d, eps, out);
+    NNCHK();
+    return FMI_OK;
+}
+
+extern "C" int sealnn_causal_self_attn(void *stream, const float *qkv, uint32_t n_seq, uint32_t T, uint32_t heads, float scale, float *out)
+{
+    if (T > FMI_MAX_LEVELS) { fmi_set_error("sealnn_causal_self_attn: at most %u positions", FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
+    const uint32_t items = n_seq * heads;
+    hipLaunchKernelGGL(k_causal_self_attn, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, n_seq, T, heads, scale, out);
+    NNCHK();
+    return FMI_OK;
+}
+
+extern "C" int sealnn_cross_attn_rows(void *stream, const float *q, const float *ck, const float *cv, const float *bias,
+                                      const int32_t *row_batch, uint32_t rows, uint32_t heads, uint32_t S, float scale, float *out)
+{
+    if (S > 64) { fmi_set_error("sealnn_cross_attn_rows: encoder length %u > 64", S); return FMI_ERR_UNSUPPORTED; }
+    const uint32_t items = rows * heads;
+    hipLaunchKernelGGL(k_cross_attn_rows, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, ck, cv, bias, row_batch, rows, heads, S, scale, out);
     NNCHK();
     return FMI_OK;
 }

@@ -155,11 +155,24 @@ def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_pena
                 j = slot[owner[qi][sq[:-1]]]
                 per_chunk.setdefault(j // chunk_rows, []).append((qi, ki, j % chunk_rows, sq))
     scores = [[0.0] * len(ss) for ss in seqs]
+    # decoder forward: the fused step-decoder kernels when they apply (GPU, fp32), HF's module otherwise
+    stepdec = getattr(model, "_seal_step_decoder", None)
+    max_T = 1 + max((len(p) for _, p in work), default=0)
+    prepared = None
+    if enc.is_cuda:
+        if stepdec is None:
+            from .bart_decoder import BartStepDecoder
+            stepdec = model._seal_step_decoder = BartStepDecoder(model)
+        if stepdec.can_teacher_force(enc, max_T):
+            prepared = stepdec.teacher_prepare(enc, attention_mask)
     for c, items in per_chunk.items():
         rows = [work[w] for w in order[c * chunk_rows:(c + 1) * chunk_rows]]
         qidx = torch.as_tensor([qi for qi, _ in rows], device=device)
         dec_ids = _pad_batch([[start] + list(p) for _, p in rows], cfg.pad_token_id, device)
-        logits = model(attention_mask=attention_mask[qidx], encoder_outputs=(enc[qidx],), decoder_input_ids=dec_ids).logits
+        if prepared is not None:
+            logits = stepdec.teacher_logits(dec_ids, qidx, prepared)
+        else:
+            logits = model(attention_mask=attention_mask[qidx], encoder_outputs=(enc[qidx],), decoder_input_ids=dec_ids).logits
         if logit_bias is not None:
             logits = logits + logit_bias[qidx][:, None, :]
         logp = logits.log_softmax(-1)                                   # [rows, T, V]; position j: after p[:j]

@@ -122,3 +122,28 @@ def test_fused_constrained_topk_matches_unfused_step(kw):
                 a, b = unc[q, j].item(), u[q, flat[q, j]].item()
                 assert a == b or abs(a - b) <= 1e-5
             assert len(set(flat[q].tolist())) == 2 * K
+
+
+def test_rescore_keys_fused_teacher_forcing_matches_hf_forward():
+    """tree-shared rescoring through the fused step-decoder kernels (GPU) == one HF row per key (reference batching)"""
+    import numpy as np
+    from seal_amd.keys import rescore_keys
+    from tests.helpers import tiny_bart
+    dev = torch.device("cuda:0")
+    m = tiny_bart(120).to(dev)
+    rng = np.random.default_rng(0)
+    inputs = [[0] + rng.integers(4, 118, size=int(rng.integers(4, 9))).tolist() + [2] for _ in range(4)]
+    keys = []
+    for _ in range(4):
+        base = rng.integers(4, 118, size=9).tolist()
+        other = rng.integers(4, 118, size=6).tolist()
+        kk = [base[:i] for i in range(1, 10)] + [other[:i] for i in range(2, 7)] + [[2] + base[:3], base[:4] + [2], [7] + other[:2] + [7]]
+        keys.append([(-1.0, k) for k in kk])
+    bias = torch.randn(4, 120, device=dev)
+    for kw in (dict(), dict(strip_from_bos=[2, 7], strip_from_eos=[7, 2]), dict(logit_bias=bias)):
+        a = rescore_keys(m, inputs, keys, batch_size=4, share_prefixes=True, **kw)
+        b = rescore_keys(m, inputs, keys, batch_size=4, share_prefixes=False, **kw)
+        for qa, qb in zip(a, b):
+            assert [k for _, k in qa] == [k for _, k in qb]
+            for (sa, _), (sb, _) in zip(qa, qb):
+                assert abs(sa - sb) <= 3e-5 * max(1.0, abs(sb)), kw
