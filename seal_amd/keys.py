@@ -52,10 +52,10 @@ def strip(seq, symbols_start, symbols_end):
 
 def _pad_batch(seqs: Sequence[Sequence[int]], pad: int, device) -> torch.Tensor:
     width = max(len(s) for s in seqs)
-    out = torch.full((len(seqs), width), pad, dtype=torch.long)
+    out = np.full((len(seqs), width), pad, dtype=np.int64)
     for i, s in enumerate(seqs):
-        out[i, :len(s)] = torch.as_tensor(s, dtype=torch.long)
-    return out.to(device)
+        out[i, :len(s)] = s
+    return torch.from_numpy(out).to(device)
 
 
 @torch.inference_mode()
