@@ -53,30 +53,36 @@ __global__ __launch_bounds__(256) void k_self_attn_step(const float *qkv, float 
     out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
 }
 
-// one wavefront per (row, head); scores: lane = encoder position, output: lane = head dimension
-__global__ __launch_bounds__(256) void k_cross_attn_step(const float *q, const float *ck, const float *cv, const float *bias,
-                                                         uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S, float scale,
-                                                         float *out)
+// one workgroup per (query, head): the encoder K [64, S] and V [S, 64] of that head are staged in LDS once
+// and shared by the query's beams (one wavefront per beam; scores: lane = encoder position, output: lane = dim)
+__global__ __launch_bounds__(1024) void k_cross_attn_step(const float *q, const float *ck, const float *cv, const float *bias,
+                                                          uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S, float scale,
+                                                          float *out)
 {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= batch * beams * heads) return;
-    const uint32_t row = item / heads, head = item % heads, b = row / beams;
-    const float qd = q[((uint64_t)row * heads + head) * 64 + lane] * scale;
+    __shared__ float s_k[64 * 64], s_v[64 * 64];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t b = blockIdx.x / heads, head = blockIdx.x % heads;
     const float *k = ck + ((uint64_t)b * heads + head) * 64 * S;      // [64, S]
     const float *v = cv + ((uint64_t)b * heads + head) * S * 64;      // [S, 64]
-    float sc = 0.f;
-    for (uint32_t d = 0; d < 64; d++) {
-        const float qv = __shfl(qd, d);
-        if (lane < S) sc += qv * k[(uint64_t)d * S + lane];
+    for (uint32_t i = threadIdx.x; i < 64 * S; i += blockDim.x) { s_k[i] = k[i]; s_v[i] = v[i]; }
+    __syncthreads();
+    const float bi = lane < S ? bias[(uint64_t)b * S + lane] : 0.f;
+    for (uint32_t beam = wv; beam < beams; beam += nw) {
+        const uint32_t row = b * beams + beam;
+        const float qd = q[((uint64_t)row * heads + head) * 64 + lane] * scale;
+        float sc = 0.f;
+        for (uint32_t d = 0; d < 64; d++) {
+            const float qv = __shfl(qd, d);
+            if (lane < S) sc += qv * s_k[d * S + lane];
+        }
+        sc = lane < S ? sc + bi : -__builtin_huge_valf();
+        const float m = wave_max(sc);
+        const float e = lane < S ? expf(sc - m) : 0.f;
+        const float denom = wave_sum(e);
+        float acc = 0.f;
+        for (uint32_t p = 0; p < S; p++) acc += __shfl(e, p) * s_v[p * 64 + lane];
+        out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
     }
-    sc = lane < S ? sc + bias[(uint64_t)b * S + lane] : -__builtin_huge_valf();
-    const float m = wave_max(sc);
-    const float e = lane < S ? expf(sc - m) : 0.f;
-    const float denom = wave_sum(e);
-    float acc = 0.f;
-    for (uint32_t p = 0; p < S; p++) acc += __shfl(e, p) * v[(uint64_t)p * 64 + lane];
-    out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
 }
 
 // teacher-forced causal self-attention over T positions: one wavefront per (sequence, head); lane = dim
@@ -182,8 +188,8 @@ extern "C" int sealnn_cross_attn_step(void *stream, const float *q, const float 
                                       uint32_t beams, uint32_t heads, uint32_t S, float scale, float *out)
 {
     if (S > 64) { fmi_set_error("sealnn_cross_attn_step: encoder length %u > 64", S); return FMI_ERR_UNSUPPORTED; }
-    const uint32_t items = batch * beams * heads;
-    hipLaunchKernelGGL(k_cross_attn_step, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, ck, cv, bias, batch, beams, heads, S, scale, out);
+    const uint32_t waves = beams < 16 ? beams : 16;
+    hipLaunchKernelGGL(k_cross_attn_step, dim3(batch * heads), dim3(waves * 64), 0, (hipStream_t)stream, q, ck, cv, bias, batch, beams, heads, S, scale, out);
     NNCHK();
     return FMI_OK;
 }

@@ -381,28 +381,32 @@ __device__ __forceinline__ float logp_processed(float x, float mx, float lsum)
     return lp;
 }
 
-// one workgroup per row: max and log(sum(exp(x - max)))
-__global__ __launch_bounds__(256) void k_row_lse(const float *logits, uint64_t vocab, float *row_max, float *row_lsum)
+// one workgroup (1024 threads) per row: max and log(sum(exp(x - max)))
+static constexpr int ROW_BLOCK = 1024;
+__global__ __launch_bounds__(ROW_BLOCK) void k_row_lse(const float *logits, uint64_t vocab, float *row_max, float *row_lsum)
 {
-    __shared__ float s_a[4], s_b[4];
+    __shared__ float s_a[ROW_BLOCK / 64], s_b[ROW_BLOCK / 64];
     const float *x = logits + (uint64_t)blockIdx.x * vocab;
     float mx = -__builtin_huge_valf();
     bool nan = false;
-    for (uint64_t v = threadIdx.x; v < vocab; v += 256) { const float a = x[v]; nan |= (a != a); mx = fmaxf(mx, a); }
+    for (uint64_t v = threadIdx.x; v < vocab; v += ROW_BLOCK) { const float a = x[v]; nan |= (a != a); mx = fmaxf(mx, a); }
     for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_down(mx, o)); }
     const uint64_t any_nan = __ballot(nan);
     if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = mx; s_b[threadIdx.x >> 6] = any_nan ? 1.f : 0.f; }
     __syncthreads();
-    mx = fmaxf(fmaxf(s_a[0], s_a[1]), fmaxf(s_a[2], s_a[3]));
-    const bool row_nan = (s_b[0] + s_b[1] + s_b[2] + s_b[3]) > 0.f;
+    mx = s_a[0];
+    float nn = 0.f;
+    for (int i = 0; i < ROW_BLOCK / 64; i++) { mx = fmaxf(mx, s_a[i]); nn += s_b[i]; }
+    const bool row_nan = nn > 0.f;
     __syncthreads();
     float sum = 0.f;
-    for (uint64_t v = threadIdx.x; v < vocab; v += 256) sum += expf(x[v] - mx);
+    for (uint64_t v = threadIdx.x; v < vocab; v += ROW_BLOCK) sum += expf(x[v] - mx);
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
     if ((threadIdx.x & 63) == 0) s_a[threadIdx.x >> 6] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float tot = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+        float tot = 0.f;
+        for (int i = 0; i < ROW_BLOCK / 64; i++) tot += s_a[i];
         const float qnan = __builtin_nanf("");
         row_max[blockIdx.x] = row_nan ? qnan : mx;
         row_lsum[blockIdx.x] = row_nan ? qnan : logf(tot);
@@ -422,7 +426,7 @@ __device__ __forceinline__ uint32_t float_key(float f)
 // keys that match the prefix found so far and pin the want-th largest key T; one more pass collects
 // the keys > T plus as many keys == T as still needed (lowest tokens first); <= 64 survivors are
 // ordered by counting ranks.  Lanes read consecutive tokens, the bitmap word is a broadcast.
-__global__ __launch_bounds__(256) void k_row_topk(const float *logits, const uint32_t *bits, uint64_t words_per_row,
+__global__ __launch_bounds__(ROW_BLOCK) void k_row_topk(const float *logits, const uint32_t *bits, uint64_t words_per_row,
                                                   uint32_t row_broadcast_bits, uint64_t vocab, const float *row_max,
                                                   const float *row_lsum, uint32_t want, int32_t *row_tok, float *row_lp,
                                                   uint32_t *row_cnt)
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(256) void k_row_topk(const float *logits, const uin
     __shared__ uint32_t s_prefix, s_remaining, s_n_gt, s_n_eq, s_total;
     __shared__ int32_t s_ctok[TOPK_MAX];
     __shared__ float s_cval[TOPK_MAX];
-    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_wave[ROW_BLOCK / 64];
     const uint32_t row = blockIdx.x, tid = threadIdx.x;
     const float *x = logits + (uint64_t)row * vocab;
     const uint32_t *b = bits + (row_broadcast_bits ? 0 : (uint64_t)row * words_per_row);
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(256) void k_row_topk(const float *logits, const uin
     // number of allowed tokens
     {
         uint32_t c = 0;
-        for (uint64_t w = tid; w < words_per_row; w += 256) {
+        for (uint64_t w = tid; w < words_per_row; w += ROW_BLOCK) {
             uint32_t word = b[w];
             if ((w + 1) * 32 > vocab) { const uint32_t keep = (uint32_t)(vocab - w * 32); word &= keep >= 32 ? ~0u : ((1u << keep) - 1); }
             c += (uint32_t)__popc(word);
@@ -457,11 +461,11 @@ __global__ __launch_bounds__(256) void k_row_topk(const float *logits, const uin
     if (total > want) {
         for (int pass = 0; pass < 4; pass++) {
             const int shift = 24 - 8 * pass;
-            s_hist[tid] = 0;
+            if (tid < 256) s_hist[tid] = 0;
             __syncthreads();
             const uint32_t prefix = s_prefix;
             const uint32_t pmask = pass == 0 ? 0u : (~0u << (shift + 8));
-            for (uint64_t tok = tid; tok < vocab; tok += 256) {
+            for (uint64_t tok = tid; tok < vocab; tok += ROW_BLOCK) {
                 if (!((b[tok >> 5] >> (tok & 31)) & 1)) continue;
                 const uint32_t key = float_key(logp_processed(x[tok], mx, ls));
                 if ((key & pmask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1u);
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(256) void k_row_topk(const float *logits, const uin
     const uint32_t need_eq_max = total > want ? s_remaining : 0;     // ties with T still needed
     __syncthreads();
     // collect: everything (total <= want) or keys > T and the first need_eq_max keys == T
-    for (uint64_t base = 0; base < vocab; base += 256) {
+    for (uint64_t base = 0; base < vocab; base += ROW_BLOCK) {
         const uint64_t tok = base + tid;
         bool ok = tok < vocab && ((b[tok >> 5] >> (tok & 31)) & 1);
         float lp = 0.f; uint32_t key = 0;
@@ -492,11 +496,13 @@ __global__ __launch_bounds__(256) void k_row_topk(const float *logits, const uin
         const bool gt = ok && (total <= want || key > T);
         const bool eq = ok && total > want && key == T;
         if (gt) { const uint32_t o = atomicAdd(&s_n_gt, 1u); if (o < TOPK_MAX) { s_ctok[o] = (int32_t)tok; s_cval[o] = lp; } }
-        // ties in token order: workgroup prefix count per 256-token chunk
+        // ties in token order: workgroup prefix count per ROW_BLOCK-token chunk
         const uint64_t be = __ballot(eq);
         if ((tid & 63) == 0) s_wave[tid >> 6] = (uint32_t)__popcll(be);
         __syncthreads();
-        if (s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]) {
+        uint32_t chunk_eq = 0;
+        for (int i = 0; i < ROW_BLOCK / 64; i++) chunk_eq += s_wave[i];
+        if (chunk_eq) {
             uint32_t before = s_n_eq;
             for (uint32_t w = 0; w < (tid >> 6); w++) before += s_wave[w];
             const uint32_t my = before + (uint32_t)__popcll(be & ((1ull << (tid & 63)) - 1));
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(256) void k_row_topk(const float *logits, const uin
                 const uint32_t o = (k_sel - need_eq_max) + my;       // ties fill the tail slots
                 s_ctok[o] = (int32_t)tok; s_cval[o] = lp;
             }
-            if (tid == 0) s_n_eq += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            if (tid == 0) s_n_eq += chunk_eq;
         }
         __syncthreads();
     }
@@ -908,8 +914,8 @@ extern "C" int fmi_dev_constrained_topk(fmi_t *h, void *stream, uint64_t batch, 
         if (rc) return rc;
         bits = ws_bits(h);
     }
-    hipLaunchKernelGGL(k_row_lse, dim3((unsigned)rows), dim3(256), 0, st, d_logits, vocab, row_max, row_lsum);
-    hipLaunchKernelGGL(k_row_topk, dim3((unsigned)rows), dim3(256), 0, st, d_logits, bits, wpr, broadcast, vocab, row_max, row_lsum,
+    hipLaunchKernelGGL(k_row_lse, dim3((unsigned)rows), dim3(ROW_BLOCK), 0, st, d_logits, vocab, row_max, row_lsum);
+    hipLaunchKernelGGL(k_row_topk, dim3((unsigned)rows), dim3(ROW_BLOCK), 0, st, d_logits, bits, wpr, broadcast, vocab, row_max, row_lsum,
                        (uint32_t)want, row_tok, row_lp, row_cnt);
     hipLaunchKernelGGL(k_query_merge, dim3((unsigned)batch), dim3(64), 0, st, d_logits, bits, wpr, broadcast, vocab, (uint32_t)beams,
                        (uint32_t)want, d_beam_scores, row_max, row_lsum, row_tok, row_lp, row_cnt, d_top_idx, d_top_con, d_top_unc);
