@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=64)
     ap.add_argument("--jobs", type=int, default=8, help="host worker processes for the first-stage bookkeeping")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-scoring", action="store_true", help="include the full-document rescoring of keys.py:366-497 in the step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -239,7 +240,7 @@ def main():
             model.final_logits_bias[0, tok] = float("-inf")
     log(f"BART-large random init (fp32) in {time.perf_counter() - t0:.1f}s")
 
-    searcher = SEALSearcher(index, None, model, add_query_to_keys=False, detokenize=False, first_stage_only=True,
+    searcher = SEALSearcher(index, None, model, add_query_to_keys=False, detokenize=False, first_stage_only=not args.full_scoring,
                             beam=args.beam, batch_size=args.batch, jobs=args.jobs)
     from seal_amd.bart_decoder import BartStepDecoder
     model._seal_step_decoder = BartStepDecoder(model)

@@ -234,6 +234,22 @@ int fmi_evidence_read(const fmi_evidence_t *ev, int64_t *doc, double *score, int
                       int64_t *key_off, int32_t *key_idx, double *key_score);
 void fmi_evidence_free(fmi_evidence_t *ev);
 
+/* ---- full-document scoring (host) -- seal/keys.py:377-494 for the ranked documents of one query:
+ * keys with score > 0 (CSR tokens, in all_ngrams order), optional per-token unigram scores [vocab],
+ * documents as CSR token arrays (already in the `[2] + doc[:-1]` form of keys.py:388).  Result =
+ * documents sorted by descending score (stable), each with score, best single key, and the list of
+ * accepted (key index | -(token+1) for a unigram, discounted score) in acceptance order. */
+typedef struct fmi_fullscore fmi_fullscore_t;
+int fmi_full_score(uint64_t n_keys, const int64_t *key_tok_off, const int64_t *key_toks, const double *key_score,
+                   const double *type_scores, uint64_t vocab, uint64_t n_docs, const int64_t *doc_off,
+                   const int64_t *doc_toks, int allow_overlaps, double beta, double single_key,
+                   int single_key_add_unigrams, int unigrams_ignore_free_places, fmi_fullscore_t **out);
+uint64_t fmi_fullscore_docs(const fmi_fullscore_t *fs);
+uint64_t fmi_fullscore_entries(const fmi_fullscore_t *fs);
+int fmi_fullscore_read(const fmi_fullscore_t *fs, int64_t *order, double *score, int64_t *best_key, double *best_score,
+                       int64_t *pick_off, int64_t *pick_id, double *pick_score);
+void fmi_fullscore_free(fmi_fullscore_t *fs);
+
 /* (sr + log(1-exp(snr))) - (snr + log(1-exp(sr))), snr = log((count+smoothing)/(ntokens+smoothing)), 0 where
  * count == 0 -- seal/keys.py:221-224,258-261 for n pairs, libm doubles (what python's math module calls). */
 int fmi_log_odds_batch(uint64_t n, const double *sr, const int64_t *count, double ntokens, double smoothing, double *out);

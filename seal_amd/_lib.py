@@ -63,6 +63,12 @@ SIGNATURES = {
     "fmi_evidence_entries": (_u64, [_vp]),
     "fmi_evidence_read": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fmi_evidence_free": (None, [_vp]),
+    "fmi_full_score": (_int, [_u64, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _vp, _int, ctypes.c_double, ctypes.c_double, _int, _int,
+                              ctypes.POINTER(_vp)]),
+    "fmi_fullscore_docs": (_u64, [_vp]),
+    "fmi_fullscore_entries": (_u64, [_vp]),
+    "fmi_fullscore_read": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fmi_fullscore_free": (None, [_vp]),
     "fmi_log_odds_batch": (_int, [_u64, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp]),
 }
 

@@ -243,8 +243,9 @@ class FMIndex(_FMIndex):
             res = out.cpu().numpy()
         return res[0], res[1], offs
 
-    def get_docs_batch(self, doc_indices) -> List[List[int]]:
-        """``get_doc`` for many documents in one launch (reference index.py:68-75)."""
+    def get_docs_batch(self, doc_indices, as_arrays: bool = False):
+        """``get_doc`` for many documents in one launch (reference index.py:68-75); lists of python
+        ints, or int64 numpy views of one flat buffer with ``as_arrays``."""
         import torch
         docs = np.asarray(list(doc_indices), dtype=np.int64)
         if len(docs) == 0:
@@ -262,6 +263,8 @@ class FMIndex(_FMIndex):
             check(lib().fmi_dev_get_docs(self._h, st.cuda_stream, len(docs), d_docs.data_ptr(), d_off.data_ptr(), SHIFT,
                                          out.data_ptr()))
             flat = out.cpu().numpy()
+        if as_arrays:
+            return [flat[offs[i]:offs[i + 1]] for i in range(len(docs))]
         return [flat[offs[i]:offs[i + 1]].tolist() for i in range(len(docs))]
 
     # -- device-pointer forms (torch tensors on the index's GPU) -------------

@@ -370,6 +370,90 @@ def _first_stage_native(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps,
             for i in range(nd)]
 
 
+class _LazyList:
+    """a list materialised on first use (documents beyond the caller's top-k are never looked at)"""
+    __slots__ = ("_make", "_n", "_list")
+
+    def __init__(self, make, n):
+        self._make, self._n, self._list = make, n, None
+
+    def _get(self):
+        if self._list is None:
+            self._list = self._make()
+            self._make = None
+        return self._list
+
+    def __len__(self):
+        return self._n
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __eq__(self, other):
+        return self._get() == list(other)
+
+    def __repr__(self):
+        return repr(self._get())
+
+
+def _full_score_native(doc_ids, fetched, all_ngrams, unigram_scores, allow_overlaps, beta, single_key,
+                       single_key_add_unigrams, unigrams_ignore_free_places):
+    """keys.py:377-497 through ``fmi_full_score`` (seal_amd/csrc/fmi_evidence.cpp)."""
+    import ctypes
+    from ._lib import check, lib
+    keys = [k for k, sc in all_ngrams.items() if len(k) >= 1 and sc > 0.0]
+    nk = len(keys)
+    tok_off = np.zeros(nk + 1, dtype=np.int64)
+    if nk:
+        np.cumsum([len(k) for k in keys], out=tok_off[1:])
+    toks = np.fromiter((t for k in keys for t in k), dtype=np.int64, count=int(tok_off[-1])) if nk else np.zeros(1, np.int64)
+    scores = np.asarray([all_ngrams[k] for k in keys], dtype=np.float64) if nk else np.zeros(1, np.float64)
+    nd = len(doc_ids)
+    doc_arrays = []
+    for t in fetched:                       # doc_tokens = [2] + get_doc(doc)[:-1]   (keys.py:388)
+        a = np.empty(len(t), dtype=np.int64)
+        a[0] = 2
+        a[1:] = t[:-1]
+        doc_arrays.append(a)
+    doc_off = np.zeros(nd + 1, dtype=np.int64)
+    if nd:
+        np.cumsum([len(a) for a in doc_arrays], out=doc_off[1:])
+    doc_toks = np.concatenate(doc_arrays) if nd else np.zeros(1, np.int64)
+    if unigram_scores is not None:
+        ts = np.ascontiguousarray(unigram_scores, dtype=np.float64)
+        ts_ptr, vocab = ts.ctypes.data_as(ctypes.c_void_p), ts.shape[0]
+    else:
+        ts_ptr, vocab = None, 0
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    fs = ctypes.c_void_p()
+    check(lib().fmi_full_score(nk, p(tok_off), p(toks), p(scores), ts_ptr, vocab, nd, p(doc_off), p(doc_toks),
+                               int(bool(allow_overlaps)), float(beta), float(single_key), int(bool(single_key_add_unigrams)),
+                               int(bool(unigrams_ignore_free_places)), ctypes.byref(fs)))
+    try:
+        n, m = int(lib().fmi_fullscore_docs(fs)), int(lib().fmi_fullscore_entries(fs))
+        order = np.zeros(n, np.int64); sc = np.zeros(n, np.float64); bk = np.zeros(n, np.int64); bs = np.zeros(n, np.float64)
+        po = np.zeros(n + 1, np.int64); pid = np.zeros(max(m, 1), np.int64); ps = np.zeros(max(m, 1), np.float64)
+        check(lib().fmi_fullscore_read(fs, p(order), p(sc), p(bk), p(bs), p(po), p(pid), p(ps)))
+    finally:
+        lib().fmi_fullscore_free(fs)
+    order, sc, bk, bs, po = order.tolist(), sc.tolist(), bk.tolist(), bs.tolist(), po.tolist()
+
+    def picks(a, b):
+        return lambda: [((keys[int(pid[j])] if pid[j] >= 0 else (int(-pid[j] - 1),)), float(ps[j])) for j in range(a, b)]
+
+    def tokens(i):
+        return lambda: doc_arrays[i].tolist()
+    results = {}
+    for r in range(n):
+        i = order[r]
+        results[doc_ids[i]] = [sc[r], _LazyList(picks(po[r], po[r + 1]), po[r + 1] - po[r]), None,
+                               _LazyList(tokens(i), len(doc_arrays[i])), [keys[bk[r]] if bk[r] >= 0 else [], bs[r]]]
+    return results
+
+
 def _first_stage_job(payload):
     """picklable unit of work for a host worker process: the native first stage of ONE query,
     returning its top ``keep`` documents with materialised key lists (no GPU involved)."""
@@ -488,9 +572,16 @@ def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_o
             if req[0] == "locate":
                 req = gen.send(index.locate_ranges(req[1], req[2], req[3]))
             else:
-                req = gen.send(index.get_docs_batch(req[1]))
+                req = gen.send(_fetch_docs(index, req[1]))
     except StopIteration as done:
         return done.value
+
+
+def _fetch_docs(index, doc_ids):
+    try:
+        return index.get_docs_batch(doc_ids, as_arrays=True)
+    except TypeError:
+        return index.get_docs_batch(doc_ids)
 
 
 def aggregate_evidence_batch(jobs, index, **params):
@@ -534,7 +625,7 @@ def aggregate_evidence_batch(jobs, index, **params):
         dcs = [i for i, r in reqs.items() if r[0] == "docs"]
         if dcs:
             flat = [d for i in dcs for d in reqs[i][1]]
-            fetched = index.get_docs_batch(flat)
+            fetched = _fetch_docs(index, flat)
             k0 = 0
             for i in dcs:
                 nd = len(reqs[i][1])
@@ -682,6 +773,14 @@ def _aggregate_steps(ngrams_and_scores, unigram_scores=None, index=None, max_occ
         return dict(ranked[:keep] if keep is not None else ranked), all_ngrams
 
     # ---- full scoring of the top documents (keys.py:366-497) ----
+    doc_ids = [d for d, _ in ranked]
+    fetched = (yield ("docs", doc_ids)) if doc_ids else []
+    if not (sort_by_length or sort_by_freq):
+        # native host routine (libsealfm fmi_full_score): trie matching, the reference's registration
+        # and heap orders, greedy non-overlapping selection, unigram fill -- float64, same operation order
+        return _full_score_native(doc_ids, fetched, all_ngrams, unigram_scores, allow_overlaps, beta, single_key,
+                                  single_key_add_unigrams, unigrams_ignore_free_places), all_ngrams
+    # python form (kept for the sort_by_length / sort_by_freq orders)
     trie: dict = {}
     for ngram, score in all_ngrams.items():
         if len(ngram) < 1 or score <= 0.0:
@@ -690,11 +789,9 @@ def _aggregate_steps(ngrams_and_scores, unigram_scores=None, index=None, max_occ
         for t in ngram:
             node = node.setdefault(t, {})
         node[-1] = score
-    doc_ids = [d for d, _ in ranked]
-    fetched = (yield ("docs", doc_ids)) if doc_ids else []
     results: Dict[int, list] = {}
     for doc, toks in zip(doc_ids, fetched):
-        doc_tokens = [2] + list(toks)[:-1]
+        doc_tokens = [2] + [int(x) for x in toks][:-1]
         res = results[doc] = [0.0, [], None, doc_tokens, [[], 0.0]]
         if unigram_scores is not None:
             type_scores = {t: float(unigram_scores[t]) for t in doc_tokens}

@@ -123,3 +123,28 @@ def test_aggregate_evidence_batch_equals_per_query_calls(first_stage_only):
     for (keys, us), g in zip(jobs, got):
         want = oracle_aggregate_evidence(keys, unigram_scores=None if us is None else us.tolist(), index=orc, **params)
         _same(g, want)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_full_scoring_native_stress_small_alphabet(seed):
+    """tiny alphabet + quantised scores: nested / overlapping / tied keys everywhere, to exercise the
+    registration order (odd-ascending, even-descending lengths), heap tie-breaks and coverage discounts"""
+    vocab = 9
+    rng = np.random.default_rng(100 + seed)
+    docs = [rng.integers(3, vocab, size=int(rng.integers(4, 30))).tolist() + [2] for _ in range(40)]
+    orc = OracleFMIndex()
+    orc.initialize(docs)
+    keys = []
+    for _ in range(60):
+        d = docs[int(rng.integers(len(docs)))]
+        a = int(rng.integers(0, len(d) - 1))
+        ng = d[a:a + int(rng.integers(1, 7))]
+        keys.append((list(ng), -float(rng.integers(1, 6)) / 2.0))          # few distinct scores -> ties
+    us = (-rng.integers(1, 9, size=vocab) / 2.0).tolist()
+    kw = dict(n_docs_complete_score=25, max_occurrences_1=int(rng.integers(3, 200)), add_best_unigrams_to_ngrams=bool(seed % 2),
+              use_top_k_unigrams=6, single_key=float(seed % 3) / 4.0, allow_overlaps=bool(seed % 5 == 0),
+              single_key_add_unigrams=bool(seed % 4 == 1), unigrams_ignore_free_places=bool(seed % 7 == 3))
+    got = aggregate_evidence(keys, unigram_scores=us, index=OracleBatchIndex(orc), **kw)
+    want = oracle_aggregate_evidence(keys, unigram_scores=us, index=orc, **kw)
+    assert len(want[0]) > 0
+    _same(got, want)
