@@ -465,6 +465,16 @@ def _first_stage_job(payload):
     return [(d, [info[0], list(info[1]), info[2]]) for d, info in ranked]
 
 
+def _full_score_job(payload):
+    """picklable unit of work for a host worker process: full-document scoring of ONE query"""
+    *args, keep = payload
+    res = _full_score_native(*args)
+    items = list(res.items())
+    if keep is not None:
+        items = items[:keep]
+    return [(d, [info[0], list(info[1]), None, list(info[3]), info[4]]) for d, info in items]
+
+
 class _Deferred:
     """result of a first stage running in a worker process; ``result()`` -> {doc: info}"""
 
@@ -775,6 +785,11 @@ def _aggregate_steps(ngrams_and_scores, unigram_scores=None, index=None, max_occ
     # ---- full scoring of the top documents (keys.py:366-497) ----
     doc_ids = [d for d, _ in ranked]
     fetched = (yield ("docs", doc_ids)) if doc_ids else []
+    if defer is not None and not (sort_by_length or sort_by_freq):
+        payload = (doc_ids, [np.asarray(t) for t in fetched], all_ngrams,
+                   None if unigram_scores is None else np.asarray(unigram_scores, dtype=np.float64), allow_overlaps, beta,
+                   single_key, single_key_add_unigrams, unigrams_ignore_free_places, keep)
+        return _Deferred(defer.submit(_full_score_job, payload)), all_ngrams
     if not (sort_by_length or sort_by_freq):
         # native host routine (libsealfm fmi_full_score): trie matching, the reference's registration
         # and heap orders, greedy non-overlapping selection, unigram fill -- float64, same operation order

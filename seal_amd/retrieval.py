@@ -516,8 +516,7 @@ class SEALSearcher:
         host bookkeeping of each query runs in a worker process while this thread keeps the GPU busy
         with the next chunk (the producer/consumer overlap of the reference's ``Pool.imap``,
         retrieval.py:766)."""
-        defer = self._host_pool() if (self.jobs >= 2 and self.first_stage_only) else None
-        keep = keep if self.first_stage_only else None
+        defer = self._host_pool() if self.jobs >= 2 else None
         pending = []
         for chunk in _chunks(keys, self.batch_size):
             jobs = []

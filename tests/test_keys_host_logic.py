@@ -148,3 +148,27 @@ def test_full_scoring_native_stress_small_alphabet(seed):
     want = oracle_aggregate_evidence(keys, unigram_scores=us, index=orc, **kw)
     assert len(want[0]) > 0
     _same(got, want)
+
+
+def test_deferred_full_scoring_in_a_worker_process_matches_inline():
+    import multiprocessing
+    from concurrent.futures import ProcessPoolExecutor
+    vocab = 60
+    rng = np.random.default_rng(4)
+    docs = make_docs(4, 120, vocab, min_len=6, max_len=20, title_sep=7)
+    orc = OracleFMIndex()
+    orc.initialize(docs)
+    keys = synthetic_keys(rng, docs, vocab, with_titles=True)
+    us = (-rng.random(vocab) * 8 - 0.01).tolist()
+    kw = dict(unigram_scores=us, index=OracleBatchIndex(orc), add_best_unigrams_to_ngrams=True, use_top_k_unigrams=30,
+              n_docs_complete_score=40)
+    inline, _ = aggregate_evidence(keys, **kw)
+    with ProcessPoolExecutor(max_workers=1, mp_context=multiprocessing.get_context("spawn")) as pool:
+        handle, _ = aggregate_evidence(keys, defer=pool, keep=9, **kw)
+        got = handle.result()
+    want = list(inline.items())[:9]
+    assert [d for d, _ in want] == list(got.keys())
+    for d, info in want:
+        assert got[d][0] == info[0] and got[d][3] == info[3]
+        assert [(tuple(n), s) for n, s in got[d][1]] == [(tuple(n), s) for n, s in info[1]]
+        assert tuple(got[d][4][0]) == tuple(info[4][0]) and got[d][4][1] == info[4][1]
