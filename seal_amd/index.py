@@ -263,6 +263,8 @@ class FMIndex(_FMIndex):
             check(lib().fmi_dev_get_docs(self._h, st.cuda_stream, len(docs), d_docs.data_ptr(), d_off.data_ptr(), SHIFT,
                                          out.data_ptr()))
             flat = out.cpu().numpy()
+        if as_arrays == "flat":
+            return flat[:int(offs[-1])], offs
         if as_arrays:
             return [flat[offs[i]:offs[i + 1]] for i in range(len(docs))]
         return [flat[offs[i]:offs[i + 1]].tolist() for i in range(len(docs))]

@@ -412,16 +412,16 @@ def _full_score_native(doc_ids, fetched, all_ngrams, unigram_scores, allow_overl
     toks = np.fromiter((t for k in keys for t in k), dtype=np.int64, count=int(tok_off[-1])) if nk else np.zeros(1, np.int64)
     scores = np.asarray([all_ngrams[k] for k in keys], dtype=np.float64) if nk else np.zeros(1, np.float64)
     nd = len(doc_ids)
-    doc_arrays = []
-    for t in fetched:                       # doc_tokens = [2] + get_doc(doc)[:-1]   (keys.py:388)
-        a = np.empty(len(t), dtype=np.int64)
-        a[0] = 2
-        a[1:] = t[:-1]
-        doc_arrays.append(a)
-    doc_off = np.zeros(nd + 1, dtype=np.int64)
-    if nd:
-        np.cumsum([len(a) for a in doc_arrays], out=doc_off[1:])
-    doc_toks = np.concatenate(doc_arrays) if nd else np.zeros(1, np.int64)
+    if not isinstance(fetched, _DocBatch):
+        fetched = _DocBatch(np.concatenate([np.asarray(t, dtype=np.int64) for t in fetched]) if nd else np.zeros(0, np.int64),
+                            np.concatenate([[0], np.cumsum([len(t) for t in fetched])]) if nd else np.zeros(1, np.int64))
+    # doc_tokens = [2] + get_doc(doc)[:-1] (keys.py:388) for every document at once: shift by one inside each document
+    doc_off = fetched.offs
+    doc_toks = np.empty(max(len(fetched.flat), 1), dtype=np.int64)
+    if len(fetched.flat):
+        doc_toks[1:len(fetched.flat)] = fetched.flat[:-1]
+        doc_toks[doc_off[:-1][doc_off[:-1] < len(fetched.flat)]] = 2
+    doc_arrays = [doc_toks[doc_off[i]:doc_off[i + 1]] for i in range(nd)]
     if unigram_scores is not None:
         ts = np.ascontiguousarray(unigram_scores, dtype=np.float64)
         ts_ptr, vocab = ts.ctypes.data_as(ctypes.c_void_p), ts.shape[0]
@@ -587,11 +587,34 @@ def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_o
         return done.value
 
 
+class _DocBatch:
+    """documents of a request as one flat int64 array + offsets (cheap to slice, cheap to pickle)"""
+
+    def __init__(self, flat, offs):
+        self.flat, self.offs = np.ascontiguousarray(flat, dtype=np.int64), np.ascontiguousarray(offs, dtype=np.int64)
+
+    def __len__(self):
+        return len(self.offs) - 1
+
+    def __iter__(self):
+        return (self.flat[self.offs[i]:self.offs[i + 1]] for i in range(len(self)))
+
+    def slice(self, a, b):
+        o = self.offs[a:b + 1]
+        return _DocBatch(self.flat[o[0]:o[-1]], o - o[0])
+
+
 def _fetch_docs(index, doc_ids):
     try:
-        return index.get_docs_batch(doc_ids, as_arrays=True)
+        flat, offs = index.get_docs_batch(doc_ids, as_arrays="flat")
+        return _DocBatch(flat, offs)
     except TypeError:
-        return index.get_docs_batch(doc_ids)
+        docs = index.get_docs_batch(doc_ids)
+        offs = np.zeros(len(docs) + 1, dtype=np.int64)
+        if docs:
+            np.cumsum([len(d) for d in docs], out=offs[1:])
+        flat = np.fromiter((t for d in docs for t in d), dtype=np.int64, count=int(offs[-1])) if docs else np.zeros(0, np.int64)
+        return _DocBatch(flat, offs)
 
 
 def aggregate_evidence_batch(jobs, index, **params):
@@ -639,7 +662,7 @@ def aggregate_evidence_batch(jobs, index, **params):
             k0 = 0
             for i in dcs:
                 nd = len(reqs[i][1])
-                answers[i] = fetched[k0:k0 + nd]
+                answers[i] = fetched.slice(k0, k0 + nd)
                 k0 += nd
         nxt = {}
         for i, ans in answers.items():
@@ -784,9 +807,9 @@ def _aggregate_steps(ngrams_and_scores, unigram_scores=None, index=None, max_occ
 
     # ---- full scoring of the top documents (keys.py:366-497) ----
     doc_ids = [d for d, _ in ranked]
-    fetched = (yield ("docs", doc_ids)) if doc_ids else []
+    fetched = (yield ("docs", doc_ids)) if doc_ids else _DocBatch(np.zeros(0, np.int64), np.zeros(1, np.int64))
     if defer is not None and not (sort_by_length or sort_by_freq):
-        payload = (doc_ids, [np.asarray(t) for t in fetched], all_ngrams,
+        payload = (doc_ids, fetched, all_ngrams,
                    None if unigram_scores is None else np.asarray(unigram_scores, dtype=np.float64), allow_overlaps, beta,
                    single_key, single_key_add_unigrams, unigrams_ignore_free_places, keep)
         return _Deferred(defer.submit(_full_score_job, payload)), all_ngrams
