@@ -320,7 +320,9 @@ def main():
     rk.aggregate_evidence_batch = timed("aggregate_ms", orig[3])
     retrieval._count_filter = timed("count_filter_ms", orig[4])
     index._trace = []
-    jobs_saved, searcher.jobs = searcher.jobs, 1          # inline first stage: its time shows up in aggregate_ms
+    jobs_saved = searcher.jobs
+    if not os.environ.get("SEAL_BENCH_KEEP_JOBS"):
+        searcher.jobs = 1                                  # inline host stages: their time shows up in aggregate_ms
     if os.environ.get("SEAL_BENCH_PROFILE"):
         import cProfile, pstats
         pr = cProfile.Profile()

@@ -100,6 +100,7 @@ class FMIndex(_FMIndex):
 
     def _push_beginnings(self) -> None:
         b = np.asarray(self.beginnings, dtype=np.uint64)
+        self._beginnings_np = b.astype(np.int64)      # numpy twin of the (possibly 21M-element) python list
         check(lib().fmi_set_doc_beginnings(self._h, _ptr(b), len(b)))
 
     # -- reference API ------------------------------------------------------
@@ -250,7 +251,9 @@ class FMIndex(_FMIndex):
         docs = np.asarray(list(doc_indices), dtype=np.int64)
         if len(docs) == 0:
             return []
-        b = np.asarray(self.beginnings, dtype=np.int64)
+        b = self.__dict__.get("_beginnings_np")
+        if b is None or len(b) != len(self.beginnings):
+            b = self._beginnings_np = np.asarray(self.beginnings, dtype=np.int64)
         lens = b[docs + 1] - b[docs]
         offs = np.zeros(len(docs) + 1, dtype=np.int64)
         np.cumsum(lens, out=offs[1:])
