@@ -141,8 +141,8 @@ def replay_on_cpu(orc, trace, beginnings, threads, pad=1):
     """reference call pattern: per decode step and row, get_range(prefix) and
     get_count(prefix[:-1]) from scratch (beam_search.py:96-101), one task per row for
     distinct_count_multi (fm_index.cpp:117-121); get_count per key; locate + bisect per row."""
-    t_mask = t_rng = t_loc = 0.0
-    n_rows = n_seq = n_loc = 0
+    t_mask = t_rng = t_loc = t_doc = 0.0
+    n_rows = n_seq = n_loc = n_doc = 0
     b = np.asarray(beginnings, dtype=np.uint64)
     for op in trace:
         if op[0] == "mask":
@@ -172,7 +172,13 @@ def replay_on_cpu(orc, trace, beginnings, threads, pad=1):
             orc.locate_bin_batch(rows, b, threads=threads)
             t_loc += time.perf_counter() - t0
             n_loc += len(rows)
-    return dict(mask_s=t_mask, ranges_s=t_rng, locate_s=t_loc, rows=n_rows, sequences=n_seq, located=n_loc)
+        elif op[0] == "docs":
+            d = op[1]
+            t0 = time.perf_counter()
+            orc.extract_batch(b[d], b[d + 1], threads=threads)       # get_doc = extract_text per document (index.py:68-75)
+            t_doc += time.perf_counter() - t0
+            n_doc += len(d)
+    return dict(mask_s=t_mask, ranges_s=t_rng, locate_s=t_loc, docs_s=t_doc, rows=n_rows, sequences=n_seq, located=n_loc, docs=n_doc)
 
 
 def main():
@@ -187,7 +193,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=64)
     ap.add_argument("--jobs", type=int, default=8, help="host worker processes for the first-stage bookkeeping")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--full-scoring", action="store_true", help="include the full-document rescoring of keys.py:366-497 in the step")
+    ap.add_argument("--first-stage-only", action="store_true",
+                    help="stop after the first retrieval stage (SURVEY.md 8d metric) instead of the reference's complete batch_search")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -240,7 +247,7 @@ def main():
             model.final_logits_bias[0, tok] = float("-inf")
     log(f"BART-large random init (fp32) in {time.perf_counter() - t0:.1f}s")
 
-    searcher = SEALSearcher(index, None, model, add_query_to_keys=False, detokenize=False, first_stage_only=not args.full_scoring,
+    searcher = SEALSearcher(index, None, model, add_query_to_keys=False, detokenize=False, first_stage_only=args.first_stage_only,
                             beam=args.beam, batch_size=args.batch, jobs=args.jobs)
     from seal_amd.bart_decoder import BartStepDecoder
     model._seal_step_decoder = BartStepDecoder(model)
@@ -293,7 +300,31 @@ def main():
         elapsed = float(t.item())
     check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(probes)))
     check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(launches), ctypes.byref(kms)))
+    probes, launches, kms = ctypes.c_uint64(probes.value), ctypes.c_uint64(launches.value), ctypes.c_double(kms.value)
     n_found = float(np.mean([len(r) for r in res]))
+
+    # secondary figure: the same K batches through the other retrieval depth (first stage only <-> complete)
+    other_qps = None
+    if not os.environ.get("SEAL_BENCH_SKIP_OTHER"):
+        searcher.first_stage_only = not args.first_stage_only
+        run_batch(0)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t2 = time.perf_counter()
+        run_batches(args.warmup, args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t2 = time.perf_counter() - t2
+        if world > 1:
+            tt = torch.tensor([t2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t2 = float(tt.item())
+        other_qps = args.batch * args.steps * world / t2
+        searcher.first_stage_only = args.first_stage_only
+        check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(ctypes.c_uint64())))
+        check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(ctypes.c_uint64()), ctypes.byref(ctypes.c_double())))
 
     if rank != 0:
         if world > 1:
@@ -366,11 +397,11 @@ def main():
         occ = np.asarray(index.occurring_distinct)
         trace.append(("ranges", [[int(t)] for t in rng.choice(occ, size=5000 * args.batch)]))
         rep = replay_on_cpu(orc, trace, index.beginnings, threads)
-        t_cpu = rep["mask_s"] + rep["ranges_s"] + rep["locate_s"]
+        t_cpu = rep["mask_s"] + rep["ranges_s"] + rep["locate_s"] + rep["docs_s"]
         cpu = {"value": round(args.batch / t_cpu, 3), "unit": "queries/s (FM-index path only)", "cores": threads, "kind": "port",
                "sample": f"FM-index operations of 1 batch of {args.batch} queries (decode-step get_range/get_count from scratch + "
                          f"distinct_count_multi for {rep['rows']} rows, get_count for {rep['sequences']} keys, locate+bisect for "
-                         f"{rep['located']} rows) replayed on the oracle with the reference's call pattern; the model forward is not "
+                         f"{rep['located']} rows, get_doc for {rep['docs']} documents) replayed on the oracle with the reference's call pattern; the model forward is not "
                          f"part of the CPU figure",
                "seconds": {k: round(v, 3) for k, v in rep.items() if k.endswith("_s")}}
 
@@ -382,12 +413,14 @@ def main():
         "dtype": "u64 rank/select (index path); fp32 BART (model path)", "data": "synthetic",
         "config": {"workload": f"configs[1]: NQ-shaped synthetic FM-index ({args.docs} passages, {index.size()} symbols), random-init "
                                f"BART-large fp32, beam={args.beam}, batch={args.batch} per GPU, body len 10 + title len<=15, "
-                               f"first-stage retrieval top-{args.topk}",
+                               f"{'first-stage retrieval' if args.first_stage_only else 'first stage + full-document rescoring of 1500 docs/query'}, top-{args.topk}",
                    "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated",
-                   "not_in_step": ["full-document trie rescoring (keys.py:366-497, next)", "query-string n-gram keys (spaCy/tokenizer absent)"]},
+                   "not_in_step": (["full-document rescoring (keys.py:366-497)"] if args.first_stage_only else []) +
+                                  ["query-string n-gram keys (add_query_to_keys: spaCy/tokenizer absent offline)"]},
         "roofline": roofline,
         "cpu_baseline": cpu,
-        "extra": {"p50_batch_latency_ms_unpipelined": round(float(np.median(step_ms[1:] or step_ms)), 2) if step_ms else None, "docs_returned_per_query": n_found,
+        "extra": {("complete_search_qps" if args.first_stage_only else "first_stage_only_qps"): None if other_qps is None else round(other_qps, 3),
+                  "p50_batch_latency_ms_unpipelined": round(float(np.median(step_ms[1:] or step_ms)), 2) if step_ms else None, "docs_returned_per_query": n_found,
                   "phase_ms_one_batch": {k: round(v, 2) for k, v in phases.items()},
                   "k_expand_ms_one_batch": round(k2.value, 3), "k_expand_probes_one_batch": int(p2.value)},
     }

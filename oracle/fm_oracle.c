@@ -553,3 +553,15 @@ void orc_distinct_count_sizes(const orc_t *o, uint64_t m, const uint64_t *lows, 
         free(buf);
     }
 }
+
+/* index.py:68-75 get_doc for many documents (extract_text per document), timing-only: keeps lengths */
+void orc_extract_batch(const orc_t *o, uint64_t m, const uint64_t *begins, const uint64_t *ends, uint64_t *len_out, int threads)
+{
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
+    for (int64_t i = 0; i < (int64_t)m; i++) {
+        uint64_t n = ends[i] - begins[i];
+        uint64_t *buf = (uint64_t *)malloc((n + 1) * 8);
+        len_out[i] = orc_extract_text(o, begins[i], ends[i], buf);
+        free(buf);
+    }
+}

@@ -79,6 +79,7 @@ def lib():
         L.orc_get_range_batch.argtypes = [ctypes.c_void_p, _u64, _p64, _p64, _p64, _p64, ctypes.c_int]
         L.orc_locate_bin_batch.argtypes = [ctypes.c_void_p, _u64, _p64, _p64, _u64, _p64, _p64, ctypes.c_int]
         L.orc_distinct_count_sizes.argtypes = [ctypes.c_void_p, _u64, _p64, _p64, _p64, ctypes.c_int]
+        L.orc_extract_batch.argtypes = [ctypes.c_void_p, _u64, _p64, _p64, _p64, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -186,6 +187,12 @@ class CppFMIndex:
         doc = np.zeros(len(r), dtype=np.uint64)
         lib().orc_locate_bin_batch(self._h, len(r), _ptr(r), _ptr(b), len(b), _ptr(pos), _ptr(doc), threads)
         return pos, doc
+
+    def extract_batch(self, begins, ends, threads: int = 1):
+        b, e = _arr(begins), _arr(ends)
+        n = np.zeros(len(b), dtype=np.uint64)
+        lib().orc_extract_batch(self._h, len(b), _ptr(b), _ptr(e), _ptr(n), threads)
+        return n
 
     def distinct_count_sizes(self, lows, highs, threads: int = 1):
         lo, hi = _arr(lows), _arr(highs)

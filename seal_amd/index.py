@@ -249,6 +249,8 @@ class FMIndex(_FMIndex):
         ints, or int64 numpy views of one flat buffer with ``as_arrays``."""
         import torch
         docs = np.asarray(list(doc_indices), dtype=np.int64)
+        if getattr(self, "_trace", None) is not None:
+            self._trace.append(("docs", docs.copy()))
         if len(docs) == 0:
             return []
         b = self.__dict__.get("_beginnings_np")
