@@ -475,8 +475,13 @@ class SEALSearcher:
         pool = self.__dict__.get("_pool")
         if pool is None:
             import multiprocessing
-            from concurrent.futures import ProcessPoolExecutor
-            pool = ProcessPoolExecutor(max_workers=int(self.jobs), mp_context=multiprocessing.get_context("spawn"))
+            import os
+            from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
+            if os.environ.get("SEAL_HOST_WORKERS", "process") == "thread":
+                # the native routines release the GIL: threads avoid pickling the documents
+                pool = ThreadPoolExecutor(max_workers=int(self.jobs))
+            else:
+                pool = ProcessPoolExecutor(max_workers=int(self.jobs), mp_context=multiprocessing.get_context("spawn"))
             self.__dict__["_pool"] = pool
         return pool
 

@@ -44,8 +44,8 @@ def _oracle_pipeline(model, orc, queries, K, length, vocab, first_stage_only):
     return out
 
 
-@pytest.mark.parametrize("first_stage_only", [False, True])
-def test_searcher_ranks_like_the_scalar_pipeline(first_stage_only, monkeypatch):
+@pytest.mark.parametrize("first_stage_only,jobs", [(False, 1), (True, 1), (False, 2), (True, 2)])
+def test_searcher_ranks_like_the_scalar_pipeline(first_stage_only, jobs, monkeypatch):
     from oracle.seal_oracle import OracleFMIndex
     from seal_amd import FMIndex
     from seal_amd import retrieval
@@ -66,7 +66,7 @@ def test_searcher_ranks_like_the_scalar_pipeline(first_stage_only, monkeypatch):
     monkeypatch.setattr(retrieval, "fm_index_generate",
                         lambda *a, **kw: real(*a, **{**kw, "max_length": 8 if kw.get("force_decoding_from") else kw["max_length"]}))
     s = SEALSearcher(ix, None, tiny_bart(vocab).to(dev), backbone="bart-tiny", length=length, beam=K, batch_size=2,
-                     add_query_to_keys=False, detokenize=False, first_stage_only=first_stage_only,
+                     add_query_to_keys=False, detokenize=False, first_stage_only=first_stage_only, jobs=jobs,
                      title_eos_token_id=TITLE_EOS, code_eos_token_id=vocab - 6, code_bos_token_id=TITLE_EOS,
                      marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5]})
     got = s.batch_search(queries, k=10)
