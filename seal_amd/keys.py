@@ -341,7 +341,7 @@ class _KeyList:
         return repr(self._get())
 
 
-def _first_stage_native(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps, beta, single_key, n_top):
+def _first_stage_native(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps, beta, single_key, n_top, ids_only=False):
     """keys.py:311-367 through ``fmi_first_stage`` (seal_amd/csrc/fmi_evidence.cpp)."""
     import ctypes
     from ._lib import check, lib
@@ -365,6 +365,8 @@ def _first_stage_native(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps,
         check(lib().fmi_evidence_read(ev, p(d), p(sc), p(bk), p(bs), p(ko), p(ki), p(ks)))
     finally:
         lib().fmi_evidence_free(ev)
+    if ids_only:                 # the caller goes on to full scoring and only needs the ranked document ids
+        return [(x, None) for x in d.tolist()]
     d, sc, bk, bs, ko = d.tolist(), sc.tolist(), bk.tolist(), bs.tolist(), ko.tolist()
     return [(d[i], [sc[i], _KeyList(rare_keys, ki, ks, ko[i], ko[i + 1]), [rare_keys[bk[i]] if bk[i] >= 0 else [], bs[i]]])
             for i in range(nd)]
@@ -459,9 +461,8 @@ def _first_stage_job(payload):
     returning its top ``keep`` documents with materialised key lists (no GPU involved)."""
     rare_keys, scores, offs, pos_all, doc_all, allow_overlaps, beta, single_key, n_top, keep = payload
     rare = dict(zip(rare_keys, scores))
-    ranked = _first_stage_native(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps, beta, single_key, n_top)
-    if keep is not None:
-        ranked = ranked[:keep]
+    ranked = _first_stage_native(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps, beta, single_key,
+                                 n_top if keep is None else min(n_top, keep))
     return [(d, [info[0], list(info[1]), info[2]]) for d, info in ranked]
 
 
@@ -798,7 +799,7 @@ def _aggregate_steps(ngrams_and_scores, unigram_scores=None, index=None, max_occ
         # native host routine (libsealfm fmi_first_stage): same bookkeeping, same float64
         # operation order, ~100x faster than the python loop below
         ranked = _first_stage_native(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps, beta, single_key,
-                                     n_docs_complete_score)
+                                     n_docs_complete_score, ids_only=not first_stage_only)
     else:
         ranked = _first_stage_python(rare_keys, rare, offs, pos_all, doc_all, allow_overlaps, beta, single_key,
                                      n_docs_complete_score, sort_by_length, sort_by_freq, count_of)
