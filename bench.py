@@ -203,10 +203,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = bool(os.environ.get("SEAL_BENCH_FORCE_DIST"))     # exercise the RCCL path with one rank
+    use_dist = world > 1 or force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     from seal_amd import FMIndex
@@ -216,7 +219,7 @@ def main():
     from seal_amd.distributed import gather_topk, pack_topk
     if rank == 0:
         ge.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     t0 = time.perf_counter()
@@ -262,7 +265,7 @@ def main():
         res = searcher.batch_search(queries[lo:hi], k=args.topk)
         # the path's only exchange: top-k (doc id, score) of every query to every rank (RCCL all_gather)
         top = pack_topk(res, args.topk)
-        top = gather_topk(top.to(dev) if world > 1 else top, world * n * args.batch, device=dev)
+        top = gather_topk(top.to(dev) if use_dist else top, world * n * args.batch, device=dev)
         return top, res
 
     def run_batch(i):
@@ -286,15 +289,15 @@ def main():
     check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(launches), ctypes.byref(kms)))
 
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t_start = time.perf_counter()
     top, res = run_batches(args.warmup, args.steps)       # exactly K steps (batches), pipelined
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -309,15 +312,15 @@ def main():
         searcher.first_stage_only = not args.first_stage_only
         run_batch(0)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         t2 = time.perf_counter()
         run_batches(args.warmup, args.steps)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         t2 = time.perf_counter() - t2
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([t2], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t2 = float(tt.item())
@@ -327,7 +330,7 @@ def main():
         check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(ctypes.c_uint64()), ctypes.byref(ctypes.c_double())))
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -425,7 +428,7 @@ def main():
                   "k_expand_ms_one_batch": round(k2.value, 3), "k_expand_probes_one_batch": int(p2.value)},
     }
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

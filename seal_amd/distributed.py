@@ -44,7 +44,7 @@ def gather_topk(local: torch.Tensor, n_total: int, device=None) -> torch.Tensor:
     """all-gather the per-rank ``[n_local, k, 2]`` blocks into ``[n_total, k, 2]`` in query order.
     Ranks may own different numbers of queries (``shard_bounds``); blocks are padded to the
     largest shard for the collective and trimmed afterwards."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local
     world = dist.get_world_size()
     k = local.shape[1]
