@@ -413,11 +413,11 @@ def main():
         "metric": "queries/sec, NQ-shaped FM-index, BART-large beam=15 batch=20 (p50 batch latency in extra)",
         "value": round(total_q / elapsed, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed * 1e3 / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64 rank/select (index path); fp32 BART (model path)", "data": "synthetic",
+        "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"configs[1]: NQ-shaped synthetic FM-index ({args.docs} passages, {index.size()} symbols), random-init "
                                f"BART-large fp32, beam={args.beam}, batch={args.batch} per GPU, body len 10 + title len<=15, "
                                f"{'first-stage retrieval' if args.first_stage_only else 'first stage + full-document rescoring of 1500 docs/query'}, top-{args.topk}",
-                   "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated",
+                   "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated", "model_arithmetic": "fp32 (as the reference runs BART)",
                    "not_in_step": (["full-document rescoring (keys.py:366-497)"] if args.first_stage_only else []) +
                                   ["query-string n-gram keys (add_query_to_keys: spaCy/tokenizer absent offline)"]},
         "roofline": roofline,
