@@ -134,40 +134,51 @@ __global__ void k_bwt(const SymT *text, const IdxT *sa, uint64_t n, SymT *bwt)
     GRID_STRIDE(j, n) { const uint64_t p = sa[j]; bwt[j] = text[p ? p - 1 : n - 1]; }
 }
 
-// one wave per 448-bit block of one level
+// one wave per 448-position block of one quad level: the two bit planes by ballot, the block's
+// digit counts (1, 2, 3) for the header scan, and -- parked in the header chunk until the scan is
+// done -- the counts of its first three groups
 template <typename SymT>
-__global__ __launch_bounds__(256) void k_level_words(const SymT *cur, uint64_t n, uint32_t sh, uint64_t nblk, uint64_t *lvl, uint32_t *blk_ones)
+__global__ __launch_bounds__(256) void k_level_words(const SymT *cur, uint64_t n, uint32_t sh, uint64_t nblk, uint64_t *lvl,
+                                                     uint32_t *cnt1, uint32_t *cnt2, uint32_t *cnt3)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t b = wave; b < nblk; b += nwaves) {
-        uint32_t ones = 0;
-        for (uint32_t w = 0; w < 7; w++) {
-            const uint64_t p = b * FMI_BLOCK_BITS + (uint64_t)w * 64 + lane;
-            const bool bit = p < n && ((cur[p] >> sh) & 1);
-            const uint64_t word = __ballot(bit);
-            if (lane == 0) lvl[b * FMI_BLOCK_WORDS + 1 + w] = word;
-            ones += (uint32_t)__popcll(word);
+        uint32_t nh = 0, nl = 0, nhl = 0;
+        for (uint32_t j = 0; j < 7; j++) {
+            if (j == 3 && lane == 0) {
+                lvl[b * FMI_BLOCK_WORDS + 6] = (uint64_t)(nl - nhl) | ((uint64_t)(nh - nhl) << 16) | ((uint64_t)nhl << 32);
+            }
+            const uint64_t p = b * FMI_BLOCK_BITS + (uint64_t)j * 64 + lane;
+            const uint32_t d = p < n ? (uint32_t)(cur[p] >> sh) & 3u : 0u;
+            const uint64_t H = __ballot(d >> 1), Lw = __ballot(d & 1);
+            const uint32_t w = j < 3 ? 2 * j : 2 * j + 2;
+            if (lane == 0) { lvl[b * FMI_BLOCK_WORDS + w] = H; lvl[b * FMI_BLOCK_WORDS + w + 1] = Lw; }
+            nh += (uint32_t)__popcll(H); nl += (uint32_t)__popcll(Lw); nhl += (uint32_t)__popcll(H & Lw);
         }
-        if (lane == 0) blk_ones[b] = ones;
+        if (lane == 0) { cnt1[b] = nl - nhl; cnt2[b] = nh - nhl; cnt3[b] = nhl; }
     }
 }
 
-__global__ void k_store_counts(const uint64_t *excl, uint64_t nblk, uint64_t *lvl)
+// header = digits before the block (exclusive scans) + digits of its first three groups
+__global__ void k_store_counts(const uint64_t *x1, const uint64_t *x2, const uint64_t *x3, uint64_t nblk, uint64_t *lvl)
 {
-    GRID_STRIDE(b, nblk) lvl[b * FMI_BLOCK_WORDS] = excl[b];
+    GRID_STRIDE(b, nblk) {
+        const uint64_t part = lvl[b * FMI_BLOCK_WORDS + 6];
+        const uint64_t c1 = x1[b] + (part & 0xffff), c2 = x2[b] + ((part >> 16) & 0xffff), c3 = x3[b] + ((part >> 32) & 0xffff);
+        lvl[b * FMI_BLOCK_WORDS + 6] = c1 | (c2 << 40);
+        lvl[b * FMI_BLOCK_WORDS + 7] = (c2 >> 24) | (c3 << 16);
+    }
 }
 
 template <typename SymT>
-__global__ void k_partition(FmiDev ix, uint32_t k, const SymT *cur, SymT *nxt)
+__global__ void k_partition(FmiDev ix, uint32_t q, const SymT *cur, SymT *nxt)
 {
-    const uint32_t sh = ix.levels - 1 - k;
-    const uint64_t z = ix.zeros[k];
+    const uint32_t sh = 2 * (ix.qlevels - 1 - q);
     GRID_STRIDE(i, ix.n) {
         const SymT v = cur[i];
-        const uint64_t r1 = wm_rank1(ix, k, i, nullptr);
-        nxt[((v >> sh) & 1) ? z + r1 : i - r1] = v;
+        nxt[wm_step(ix, q, i, (uint32_t)(v >> sh) & 3u, nullptr)] = v;
     }
 }
 
@@ -208,31 +219,38 @@ int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64
     HIPCHK(pool.alloc(&cur, n)); HIPCHK(pool.alloc(&nxt, n));
     HIPCHK(hipMemcpyAsync(cur, bwt, n * sizeof(SymT), hipMemcpyDeviceToDevice, st));
     const uint64_t nblk = n / FMI_BLOCK_BITS + 2;
-    uint64_t *wm = nullptr, *excl = nullptr;
-    uint32_t *blk_ones = nullptr;
-    HIPCHK(pool.alloc(&wm, (uint64_t)L * nblk * FMI_BLOCK_WORDS));
-    HIPCHK(pool.alloc(&excl, nblk + 1)); HIPCHK(pool.alloc(&blk_ones, nblk + 1));
-    HIPCHK(hipMemsetAsync(blk_ones + nblk, 0, 4, st));
+    const uint32_t Q = (L + 1) / 2;
+    uint64_t *wm = nullptr, *excl[3] = {nullptr, nullptr, nullptr};
+    uint32_t *cnt[3] = {nullptr, nullptr, nullptr};
+    HIPCHK(pool.alloc(&wm, (uint64_t)Q * nblk * FMI_BLOCK_WORDS));
+    for (int e = 0; e < 3; e++) {
+        HIPCHK(pool.alloc(&excl[e], nblk + 1)); HIPCHK(pool.alloc(&cnt[e], nblk + 1));
+        HIPCHK(hipMemsetAsync(cnt[e] + nblk, 0, 4, st));
+    }
     size_t xs_bytes = 0;
-    HIPCHK(rocprim::exclusive_scan(nullptr, xs_bytes, blk_ones, excl, (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
+    HIPCHK(rocprim::exclusive_scan(nullptr, xs_bytes, cnt[0], excl[0], (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
     void *xs_tmp = nullptr;
     HIPCHK(pool.alloc((char **)&xs_tmp, xs_bytes + 256));
     d = FmiDev{};
-    d.wm = wm; d.nblk = nblk; d.n = n; d.max_sym = max_sym; d.levels = L; d.sym_bytes = sizeof(SymT) == 2 ? 2 : 4;
-    std::vector<uint64_t> zeros(L);
-    for (uint32_t k = 0; k < L; k++) {
-        uint64_t *lvl = wm + (uint64_t)k * nblk * FMI_BLOCK_WORDS;
+    d.wm = wm; d.nblk = nblk; d.n = n; d.max_sym = max_sym; d.levels = L; d.qlevels = Q; d.sym_bytes = sizeof(SymT) == 2 ? 2 : 4;
+    std::vector<uint64_t> qbase((size_t)Q * 4, 0);
+    for (uint32_t q = 0; q < Q; q++) {
+        uint64_t *lvl = wm + (uint64_t)q * nblk * FMI_BLOCK_WORDS;
         hipLaunchKernelGGL((k_level_words<SymT>), dim3((unsigned)std::min<uint64_t>((nblk + 3) / 4, 1u << 18)), dim3(256), 0, st,
-                           cur, n, L - 1 - k, nblk, lvl, blk_ones);
-        size_t xb = xs_bytes;
-        HIPCHK(rocprim::exclusive_scan(xs_tmp, xb, blk_ones, excl, (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
-        hipLaunchKernelGGL(k_store_counts, dim3(grid_for(nblk)), dim3(TB), 0, st, excl, nblk, lvl);
-        uint64_t ones = 0;
-        HIPCHK(hipMemcpyAsync(&ones, excl + nblk, 8, hipMemcpyDeviceToHost, st));
+                           cur, n, 2 * (Q - 1 - q), nblk, lvl, cnt[0], cnt[1], cnt[2]);
+        uint64_t tot[3] = {0, 0, 0};
+        for (int e = 0; e < 3; e++) {
+            size_t xb = xs_bytes;
+            HIPCHK(rocprim::exclusive_scan(xs_tmp, xb, cnt[e], excl[e], (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
+            HIPCHK(hipMemcpyAsync(&tot[e], excl[e] + nblk, 8, hipMemcpyDeviceToHost, st));
+        }
+        hipLaunchKernelGGL(k_store_counts, dim3(grid_for(nblk)), dim3(TB), 0, st, excl[0], excl[1], excl[2], nblk, lvl);
         HIPCHK(hipStreamSynchronize(st));
-        zeros[k] = n - ones;
-        d.zeros[k] = zeros[k];
-        hipLaunchKernelGGL((k_partition<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, d, k, cur, nxt);
+        const uint64_t n0 = n - tot[0] - tot[1] - tot[2];
+        uint64_t *qb = qbase.data() + (size_t)q * 4;
+        qb[0] = 0; qb[1] = n0; qb[2] = n0 + tot[0]; qb[3] = n0 + tot[0] + tot[1];
+        for (int e = 0; e < 4; e++) d.qbase[q][e] = qb[e];
+        hipLaunchKernelGGL((k_partition<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, d, q, cur, nxt);
         std::swap(cur, nxt);
     }
     HIPCHK(hipGetLastError());
@@ -252,8 +270,8 @@ int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64
     HIPCHK(hipMemcpyAsync(h_first.data(), first_pos, (max_sym + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
 
-    h->n = n; h->max_sym = max_sym; h->levels = L; h->nblk = nblk; h->sym_bytes = d.sym_bytes;
-    h->zeros = zeros;
+    h->n = n; h->max_sym = max_sym; h->levels = L; h->qlevels = Q; h->nblk = nblk; h->sym_bytes = d.sym_bytes;
+    h->qbase = qbase;
     h->leaf = h_leaf;
     h->C.assign(max_sym + 2, 0);
     uint64_t sigma = 0;
@@ -272,7 +290,8 @@ int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64
     HIPCHK(hipMemcpy(dC, h->C.data(), (max_sym + 2) * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dq1, h->q1.data(), max_sym + 1, hipMemcpyHostToDevice));
 
-    pool.release(cur); pool.release(nxt); pool.release(excl); pool.release(blk_ones); pool.release(xs_tmp);
+    pool.release(cur); pool.release(nxt); pool.release(xs_tmp);
+    for (int e = 0; e < 3; e++) { pool.release(excl[e]); pool.release(cnt[e]); }
     pool.release(occ_end); pool.release(first_pos);
     *wm_out = wm; *dC_out = dC; *dleaf_out = dleaf; *dq1_out = dq1;
     return FMI_OK;
@@ -370,7 +389,7 @@ int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int 
         sa_lo_dev = (uint32_t *)sa;
     }
     if (keep_host) {
-        h->wm.resize((uint64_t)L * nblk * FMI_BLOCK_WORDS);
+        h->wm.resize((uint64_t)h->qlevels * nblk * FMI_BLOCK_WORDS);
         HIPCHK(hipMemcpy(h->wm.data(), wm, h->wm.size() * 8, hipMemcpyDeviceToHost));
         h->sa_lo.resize(n);
         HIPCHK(hipMemcpy(h->sa_lo.data(), sa_lo_dev, n * 4, hipMemcpyDeviceToHost));
@@ -401,7 +420,7 @@ int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int 
         pool.keep(p);
         h->dev_allocs.push_back(p);
     }
-    h->dev_bytes = (uint64_t)L * nblk * 64 + (max_sym + 2) * 8 + (max_sym + 1) * 9 + n * (WIDE ? 5 : 4) + n * sizeof(SymT);
+    h->dev_bytes = (uint64_t)h->qlevels * nblk * FMI_BLOCK_BYTES + (max_sym + 2) * 8 + (max_sym + 1) * 9 + n * (WIDE ? 5 : 4) + n * sizeof(SymT);
     h->device = device;
     h->dev = d;
     if (!h->doc_begin.empty()) {
@@ -426,7 +445,7 @@ static int bwt_only_impl(fmi *h, const void *d_bwt, uint64_t n, int device, uint
     h->host_resident = false;
     d.C = dC; d.leaf = dleaf; d.q1 = dq1; d.sa_lo = nullptr; d.sa_hi = nullptr; d.text = nullptr;
     for (void *p : {(void *)wm, (void *)dC, (void *)dleaf, (void *)dq1}) { pool.keep(p); h->dev_allocs.push_back(p); }
-    h->dev_bytes = (uint64_t)L * d.nblk * 64 + (max_sym + 2) * 8 + (max_sym + 1) * 9;
+    h->dev_bytes = (uint64_t)h->qlevels * d.nblk * FMI_BLOCK_BYTES + (max_sym + 2) * 8 + (max_sym + 1) * 9;
     h->device = device;
     h->dev = d;
     return FMI_OK;

@@ -202,7 +202,7 @@ void fmi_host_q1_from_first_pos(const std::vector<uint64_t> &first_pos, uint32_t
 }
 
 // ---------------------------------------------------------------------------
-// BWT -> wavelet matrix in the 64-byte block layout + per-symbol tables.
+// BWT -> quad wavelet matrix in the 128-byte block layout (fmi_internal.h) + per-symbol tables.
 // ---------------------------------------------------------------------------
 void fmi_host_finish_from_bwt(fmi *h, const uint32_t *bwt, uint64_t n)
 {
@@ -219,34 +219,43 @@ void fmi_host_finish_from_bwt(fmi *h, const uint32_t *bwt, uint64_t n)
     uint64_t sigma = 0;
     for (uint64_t c = 0; c <= max_sym; c++) { if (h->C[c + 1]) sigma++; h->C[c + 1] += h->C[c]; }
     h->sigma = sigma;
-    // levels
+    // quad levels
+    const uint32_t Q = (L + 1) / 2;
+    h->qlevels = Q;
     h->nblk = n / FMI_BLOCK_BITS + 2;
-    h->wm.assign((uint64_t)L * h->nblk * FMI_BLOCK_WORDS, 0);
-    h->zeros.assign(L, 0);
+    h->wm.assign((uint64_t)Q * h->nblk * FMI_BLOCK_WORDS, 0);
+    h->qbase.assign((size_t)Q * 4, 0);
     std::vector<uint32_t> cur(bwt, bwt + n), nxt(n);
-    for (uint32_t k = 0; k < L; k++) {
-        const uint32_t sh = L - 1 - k;
-        uint64_t *lvl = h->wm.data() + (uint64_t)k * h->nblk * FMI_BLOCK_WORDS;
-        uint64_t ones = 0;
+    for (uint32_t q = 0; q < Q; q++) {
+        const uint32_t sh = 2 * (Q - 1 - q);
+        uint64_t *lvl = h->wm.data() + (uint64_t)q * h->nblk * FMI_BLOCK_WORDS;
+        uint64_t cnt[4] = {0, 0, 0, 0};   // digits seen so far
         for (uint64_t b = 0; b < h->nblk; b++) {
             uint64_t *blk = lvl + b * FMI_BLOCK_WORDS;
-            blk[0] = ones;
-            uint64_t base = b * FMI_BLOCK_BITS;
-            for (uint32_t w = 0; w < 7; w++) {
-                uint64_t word = 0;
-                uint64_t p0 = base + (uint64_t)w * 64;
-                for (uint32_t bit = 0; bit < 64 && p0 + bit < n; bit++)
-                    word |= (uint64_t)((cur[p0 + bit] >> sh) & 1) << bit;
-                blk[1 + w] = word;
-                ones += (uint64_t)__builtin_popcountll(word);
+            const uint64_t base = b * FMI_BLOCK_BITS;
+            for (uint32_t j = 0; j < 7; j++) {
+                if (j == 3) {   // header: counts before the group-2 / group-3 boundary
+                    blk[6] = cnt[1] | (cnt[2] << 40);
+                    blk[7] = (cnt[2] >> 24) | (cnt[3] << 16);
+                }
+                uint64_t H = 0, Lw = 0;
+                const uint64_t p0 = base + (uint64_t)j * 64;
+                for (uint32_t bit = 0; bit < 64 && p0 + bit < n; bit++) {
+                    const uint32_t d = (cur[p0 + bit] >> sh) & 3;
+                    H |= (uint64_t)(d >> 1) << bit;
+                    Lw |= (uint64_t)(d & 1) << bit;
+                    cnt[d]++;
+                }
+                const uint32_t w = j < 3 ? 2 * j : 2 * j + 2;
+                blk[w] = H;
+                blk[w + 1] = Lw;
             }
         }
-        h->zeros[k] = n - ones;
-        // stable partition: zeros first
-        uint64_t z = 0, o = h->zeros[k];
-        for (uint64_t i = 0; i < n; i++) {
-            if ((cur[i] >> sh) & 1) nxt[o++] = cur[i]; else nxt[z++] = cur[i];
-        }
+        uint64_t *qb = h->qbase.data() + (size_t)q * 4;
+        qb[0] = 0; qb[1] = cnt[0]; qb[2] = cnt[0] + cnt[1]; qb[3] = cnt[0] + cnt[1] + cnt[2];
+        // stable 4-way partition by digit
+        uint64_t o[4] = {qb[0], qb[1], qb[2], qb[3]};
+        for (uint64_t i = 0; i < n; i++) nxt[o[(cur[i] >> sh) & 3]++] = cur[i];
         cur.swap(nxt);
     }
     // after the last partition equal symbols are contiguous
@@ -388,8 +397,9 @@ int fmi_upload(fmi *h, int device)
     if (hipSetDevice(device) != hipSuccess) { fmi_set_error("hipSetDevice(%d) failed", device); return FMI_ERR_HIP; }
     h->device = device;
     FmiDev d{};
-    d.nblk = h->nblk; d.n = h->n; d.max_sym = h->max_sym; d.levels = h->levels; d.sym_bytes = h->sym_bytes;
-    for (uint32_t k = 0; k < h->levels; k++) d.zeros[k] = h->zeros[k];
+    d.nblk = h->nblk; d.n = h->n; d.max_sym = h->max_sym; d.levels = h->levels; d.qlevels = h->qlevels; d.sym_bytes = h->sym_bytes;
+    for (uint32_t q = 0; q < h->qlevels; q++)
+        for (uint32_t e = 0; e < 4; e++) d.qbase[q][e] = h->qbase[(size_t)q * 4 + e];
     int rc;
     const uint8_t *text8 = nullptr;
     if ((rc = up(h, h->wm, &d.wm)) || (rc = up(h, h->C, &d.C)) || (rc = up(h, h->leaf, &d.leaf)) ||
@@ -412,9 +422,9 @@ extern "C" int fmi_to_device(fmi_t *h, int device)
 
 // ---------------------------------------------------------------------------
 // on-disk format ".fmi" (little endian):
-//   char[8] "SEALFMI1"; u64 n, max_sym, sigma, nblk; u32 levels, sym_bytes;
+//   char[8] "SEALFMI2"; u64 n, max_sym, sigma, nblk; u32 levels, sym_bytes;
 //   u64 sa_wide(0/1); then arrays, each as u64 byte length + raw bytes, in the
-//   order zeros, C, leaf, q1, wm, sa_lo, sa_hi, text, bwt.
+//   order qbase, C, leaf, q1, wm, sa_lo, sa_hi, text, bwt.  (SEALFMI1 was the binary, 64-byte-block layout.)
 // ---------------------------------------------------------------------------
 template <class T>
 static bool wr(FILE *f, const std::vector<T> &v)
@@ -438,11 +448,11 @@ extern "C" int fmi_save(const fmi_t *h, const char *path)
     if (!h->host_resident) { fmi_set_error("fmi_save: index has no host copy (built on device without keep_host)"); return FMI_ERR_STATE; }
     FILE *f = fopen(path, "wb");
     if (!f) { fmi_set_error("cannot open %s for writing", path); return FMI_ERR_IO; }
-    bool ok = fwrite("SEALFMI1", 1, 8, f) == 8;
+    bool ok = fwrite("SEALFMI2", 1, 8, f) == 8;
     uint64_t hdr[4] = {h->n, h->max_sym, h->sigma, h->nblk};
     uint32_t hdr2[2] = {h->levels, h->sym_bytes};
     ok = ok && fwrite(hdr, 8, 4, f) == 4 && fwrite(hdr2, 4, 2, f) == 2;
-    ok = ok && wr(f, h->zeros) && wr(f, h->C) && wr(f, h->leaf) && wr(f, h->q1) && wr(f, h->wm) &&
+    ok = ok && wr(f, h->qbase) && wr(f, h->C) && wr(f, h->leaf) && wr(f, h->q1) && wr(f, h->wm) &&
          wr(f, h->sa_lo) && wr(f, h->sa_hi) && wr(f, h->text) && wr(f, h->bwt);
     fclose(f);
     if (!ok) { fmi_set_error("write error on %s", path); return FMI_ERR_IO; }
@@ -457,15 +467,17 @@ extern "C" int fmi_load(fmi_t **out, const char *path, int device)
     char magic[8];
     fmi *h = new fmi();
     uint64_t hdr[4]; uint32_t hdr2[2];
-    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "SEALFMI1", 8) == 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "SEALFMI2", 8) == 0;
     ok = ok && fread(hdr, 8, 4, f) == 4 && fread(hdr2, 4, 2, f) == 2;
     if (ok) { h->n = hdr[0]; h->max_sym = hdr[1]; h->sigma = hdr[2]; h->nblk = hdr[3]; h->levels = hdr2[0]; h->sym_bytes = hdr2[1]; }
-    ok = ok && rd(f, h->zeros) && rd(f, h->C) && rd(f, h->leaf) && rd(f, h->q1) && rd(f, h->wm) &&
+    ok = ok && rd(f, h->qbase) && rd(f, h->C) && rd(f, h->leaf) && rd(f, h->q1) && rd(f, h->wm) &&
          rd(f, h->sa_lo) && rd(f, h->sa_hi) && rd(f, h->text) && rd(f, h->bwt);
     fclose(f);
-    if (!ok || h->levels == 0 || h->levels > FMI_MAX_LEVELS) {
+    h->qlevels = (h->levels + 1) / 2;
+    if (!ok || h->levels == 0 || h->levels > FMI_MAX_LEVELS || h->qbase.size() != (size_t)h->qlevels * 4 ||
+        h->wm.size() != (uint64_t)h->qlevels * h->nblk * FMI_BLOCK_WORDS) {
         delete h;
-        fmi_set_error("%s is not a SEALFMI1 index", path);
+        fmi_set_error("%s is not a SEALFMI2 index", path);
         return FMI_ERR_IO;
     }
     h->host_resident = true;
@@ -489,7 +501,7 @@ extern "C" const void *fmi_host_array(const fmi_t *h, const char *name, uint64_t
     if (s == "C") return ret(h->C.data(), h->C.size(), 8);
     if (s == "leaf") return ret(h->leaf.data(), h->leaf.size(), 8);
     if (s == "q1") return ret(h->q1.data(), h->q1.size(), 1);
-    if (s == "zeros") return ret(h->zeros.data(), h->zeros.size(), 8);
+    if (s == "qbase") return ret(h->qbase.data(), h->qbase.size(), 8);
     if (s == "wm") return ret(h->wm.data(), h->wm.size(), 8);
     return nullptr;
 }

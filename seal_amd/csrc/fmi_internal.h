@@ -7,23 +7,36 @@
 
 #include "../../include/sealfm.h"
 
-// One wavelet-matrix level = nblk blocks of 64 bytes:
-//   word 0      : number of 1 bits in this level before the block (absolute)
-//   words 1..7  : 448 payload bits, bit p of the level lives in block p/448,
-//                 word 1 + (p%448)/64, bit p%64
-// so that one rank probe touches exactly one 64-byte line.
-static constexpr uint32_t FMI_BLOCK_WORDS = 8;
-static constexpr uint32_t FMI_BLOCK_BITS = 448;
+// The BWT is held as a 4-ary ("quad") wavelet matrix: quad level q stores, for every position of
+// the order reached after q stable 4-way partitions, the 2-bit digit (c >> 2*(qlevels-1-q)) & 3 of the
+// symbol sitting there.  One quad level = nblk blocks of 128 bytes = 8 chunks of 16 bytes; block b
+// covers positions [448 b, 448 b + 448) in 7 groups of 64:
+//   chunk 0..2 : groups 0..2      chunk 3 : header      chunk 4..7 : groups 3..6
+//   group chunk = { H, L }: bit i of H / L = high / low bit of the digit at position 64*group + i
+//   header      = c1, c2, c3 = digits equal to 1 / 2 / 3 in this level before position 448 b + 192
+//                 (the boundary between groups 2 and 3), 40 bits each:
+//                 w0 = c1 | c2 << 40 (low 24 bits of c2);  w1 = c2 >> 24 | c3 << 16
+// rank_d(p) counts from the header towards p: backwards through groups g..2 when p lies in group
+// g < 3 (first 64-byte sector only), forwards through groups 3..g otherwise -- on average 3.3 of the
+// 8 chunks of ONE 128-byte line answer rank_d(p) for all four digits d, and one probe moves a
+// backward search or an interval-symbols node two symbol bits down.  Positions are < 2^40 (FMI_MAX_N).
+static constexpr uint32_t FMI_BLOCK_WORDS = 16;
+static constexpr uint32_t FMI_BLOCK_BYTES = 128;
+static constexpr uint32_t FMI_BLOCK_BITS = 448;  // positions per block
+static constexpr uint32_t FMI_BLOCK_MID = 192;   // header counts refer to this offset inside the block
 static constexpr uint32_t FMI_MAX_LEVELS = 17;   // symbols < 2^17 (BART: 50274 < 2^16); node prefixes fit 16 bits
+static constexpr uint32_t FMI_MAX_QLEVELS = (FMI_MAX_LEVELS + 1) / 2;
+static constexpr uint64_t FMI_MAX_N = 1ull << 40;
 
 struct FmiDev {
-    const uint64_t *wm;       // [levels][nblk][8]
+    const uint64_t *wm;       // [qlevels][nblk][16]
     uint64_t nblk;
     uint64_t n;               // text length incl. sentinel
     uint64_t max_sym;
-    uint32_t levels;
+    uint32_t levels;          // bits per symbol = sdsl's wt_int depth (bits::hi(max)+1); quirk table only
+    uint32_t qlevels;         // (levels + 1) / 2 quad levels
     uint32_t sym_bytes;       // 2 or 4: width of text[]
-    uint64_t zeros[FMI_MAX_LEVELS];  // zeros per level
+    uint64_t qbase[FMI_MAX_QLEVELS][4];  // [q][d] = positions of level q whose digit is < d (qbase[q][0] = 0)
     const uint64_t *C;        // [max_sym+2] number of symbols < c
     const uint64_t *leaf;     // [max_sym+1] start of c's run after the last level
     const uint8_t *q1;        // [max_sym+1] sdsl rank(size()+1, c) - occ(c)  (quirk Q1)
@@ -37,9 +50,9 @@ struct FmiDev {
 struct fmi {
     // geometry
     uint64_t n = 0, max_sym = 0, sigma = 0, nblk = 0;
-    uint32_t levels = 0, sym_bytes = 2;
+    uint32_t levels = 0, qlevels = 0, sym_bytes = 2;
     // host-resident arrays (empty when built on device without keep_host)
-    std::vector<uint64_t> wm, zeros, C, leaf, doc_begin;
+    std::vector<uint64_t> wm, qbase /* [qlevels][4] */, C, leaf, doc_begin;
     std::vector<uint8_t> q1, sa_hi;
     std::vector<uint32_t> sa_lo;
     std::vector<uint32_t> bwt;   // kept for tests / hand-over only (not uploaded)

@@ -1,8 +1,9 @@
 // gfx950 (MI355X / CDNA4) kernels of libsealfm.so and the C-ABI query entry points.
 //
-// All work here is HBM-latency/bandwidth bound integer work: dependent 64-byte
-// gathers into a wavelet matrix (one 64-B line per rank probe), 5-byte gathers
-// into the suffix array, binary searches over doc boundaries.  No MFMA.
+// All work here is HBM-latency/bandwidth bound integer work: dependent 128-byte
+// gathers into a 4-ary wavelet matrix (one 128-B line per rank probe, two symbol
+// bits per probe), 5-byte gathers into the suffix array, binary searches over
+// doc boundaries.  No MFMA.
 // Wave size is 64 throughout.
 #include <hip/hip_runtime.h>
 
@@ -42,8 +43,13 @@ __device__ __forceinline__ void bs_step(const FmiDev &ix, uint64_t c, uint64_t l
     const bool absent = (c > ix.max_sym) || (ix.C[c + 1] == ix.C[c]);
     if (absent && c > 0) { l_res = 1; r_res = 0; return; }
     const uint64_t cb = ix.C[c];
-    l_res = cb + rank_like_sdsl(ix, c, l, probes);
-    r_res = cb + rank_like_sdsl(ix, c, r + 1, probes) - 1;
+    uint64_t rl, rr;
+    const uint64_t j = r + 1;
+    wm_rank_sym_pair(ix, c, l < ix.n ? l : ix.n, j < ix.n ? j : ix.n, rl, rr, probes);
+    if (l > ix.n) rl = rank_like_sdsl(ix, c, l, probes);       // beyond size(): the quirk value, no probe
+    if (j > ix.n) rr = rank_like_sdsl(ix, c, j, probes);
+    l_res = cb + rl;
+    r_res = cb + rr - 1;
 }
 
 __device__ __forceinline__ uint64_t sa_at(const FmiDev &ix, uint64_t row)
@@ -95,13 +101,14 @@ __global__ void k_get_range(FmiDev ix, uint64_t n_seq, const OffT *offsets, cons
 
 // ---------------------------------------------------------------------------
 // K2: interval -> distinct symbols (+counts)   (sdsl interval_symbols as used by
-// fm_index.cpp:78-109).  One wavefront per work item (a wavelet-matrix node
-// [lo, hi) at some level with its symbol prefix).  The wave keeps its frontier
-// in LDS as one small array per relative level (a level-j array can never hold
-// more than min(2^j, 128) nodes: it is only refilled, by at most 64 parents,
-// when every deeper level is empty), pops up to 64 nodes of the deepest
-// non-empty level, does the two rank probes of each node in parallel lanes and
-// compacts the surviving children with ballot + popcount.
+// fm_index.cpp:78-109).  One wavefront per work item (a quad-wavelet-matrix node
+// [lo, hi) at some quad level with its symbol prefix).  The wave keeps its
+// frontier in LDS as one small array per relative level (a level-j array can
+// never hold more than min(4^j, 256) nodes: it is only refilled, by at most 64
+// parents, when it and every deeper level are empty), pops up to 64 nodes of
+// the deepest non-empty level, loads the one or two 128-byte blocks of each node
+// in parallel lanes (one when both ends of the interval share a block) and
+// compacts the up to four surviving children per node with ballot + popcount.
 // ---------------------------------------------------------------------------
 struct ExpandItem {
     uint64_t lo, hi;
@@ -129,15 +136,14 @@ __device__ __forceinline__ void wave_sync()
 }
 
 static constexpr int EXP_WAVES = 4;                 // waves per workgroup
-static constexpr int EXP_LVL_CAP = 128;
-static constexpr uint32_t EXP_SPLIT_LEVEL = 6;      // phase 1 hands the sub-trees of WIDE rows over to phase 2 at this level
-static constexpr unsigned EXP_P2_BLOCKS = 1024;      // phase-2 grid cap = 4 workgroups per CU; waves loop over the queue
-static constexpr uint64_t EXP_WIDE_ROWS = 0;        // rows narrower than this would stay in their phase-1 wave down to the leaves;
-                                                    // measured slower on MI355X (r1: 325 vs 60 us for 300 one-symbol rows), so 0 = always hand over
-// relative level j occupies [lvl_off(j), lvl_off(j)+min(2^j,128))
-__host__ __device__ constexpr int lvl_off(int j) { return j < 7 ? (1 << j) - 1 : 127 + (j - 7) * EXP_LVL_CAP; }
-// LDS slots a wave needs to expand a sub-tree spanning `nlev` stored levels
-__host__ __device__ constexpr int exp_slots(int nlev) { return nlev <= 0 ? 1 : lvl_off(nlev - 1) + ((nlev - 1) < 7 ? (1 << (nlev - 1)) : EXP_LVL_CAP); }
+static constexpr int EXP_LVL_CAP = 256;
+static constexpr uint32_t EXP_SPLIT_LEVEL = 2;      // phase 1 hands the sub-trees over to phase 2 at this quad level (<= 16 per row; r1: 2 beats 3 and 4)
+static constexpr unsigned EXP_P2_BLOCKS = 1024;     // phase-2 grid cap = 4 workgroups per CU; waves loop over the queue
+// relative level j occupies [lvl_off(j), lvl_off(j) + min(4^j, 256))
+__host__ __device__ constexpr int lvl_cap(int j) { return j < 4 ? (1 << (2 * j)) : EXP_LVL_CAP; }
+__host__ __device__ constexpr int lvl_off(int j) { return j <= 4 ? ((1 << (2 * j)) - 1) / 3 : 85 + (j - 4) * EXP_LVL_CAP; }
+// LDS slots a wave needs to expand a sub-tree spanning `nlev` stored quad levels
+__host__ __device__ constexpr int exp_slots(int nlev) { return nlev <= 0 ? 1 : lvl_off(nlev - 1) + lvl_cap(nlev - 1); }
 
 template <int MODE>
 __device__ __forceinline__ void emit_leaf(const EmitTarget &t, uint32_t row, uint32_t sym, uint64_t count)
@@ -151,40 +157,50 @@ __device__ __forceinline__ void emit_leaf(const EmitTarget &t, uint32_t row, uin
     }
 }
 
-// Work items are wavelet-matrix nodes.  Nodes whose children would sit on
+// Work items are quad-wavelet-matrix nodes.  Nodes whose children would sit on
 // `stop_level` are not expanded further but appended to `out_items` (phase 1 ->
-// phase 2 hand-over, so that a wide interval is spread over up to 2^stop_level
-// wavefronts instead of one); stop_level >= levels disables the hand-over.
+// phase 2 hand-over, so that a wide interval is spread over up to 4^stop_level
+// wavefronts instead of one); stop_level >= qlevels disables the hand-over.
 // Dynamic LDS per wave: 3 x slots words (lo32, hi32, packed high bits + prefix)
-// + FMI_MAX_LEVELS counters.
+// + FMI_MAX_QLEVELS counters.
 template <int MODE>
 __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const ExpandItem *items, const uint32_t *n_items_ptr,
                                                            uint32_t n_items_static, EmitTarget tgt, uint32_t slots,
                                                            uint32_t stop_level, ExpandItem *out_items, uint32_t *out_count,
-                                                           uint32_t out_cap, uint64_t wide_rows, uint64_t *probe_counter)
+                                                           uint32_t out_cap, uint32_t *ticket, uint64_t *probe_counter)
 {
     extern __shared__ uint32_t s_mem[];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = threadIdx.x >> 6;
-    uint32_t *s_lo = s_mem + (size_t)wv * (3 * slots + FMI_MAX_LEVELS);
+    uint32_t *s_lo = s_mem + (size_t)wv * (3 * slots + FMI_MAX_QLEVELS);
     uint32_t *s_hi = s_lo + slots;
     uint32_t *s_mx = s_hi + slots;     // lo[39:32] | hi[39:32]<<8 | prefix<<16 (prefix <= 16 bits)
     uint32_t *s_cnt = s_mx + slots;
     const uint32_t n_items = n_items_ptr ? min(*n_items_ptr, n_items_static) : n_items_static;
-    const uint32_t L = ix.levels;
+    const uint32_t Q = ix.qlevels;
+    const uint64_t lt = (1ull << lane) - 1;
     uint64_t probes = 0;
 
-    for (uint32_t item = blockIdx.x * EXP_WAVES + wv; item < n_items; item += gridDim.x * EXP_WAVES) {
+    // phase 2: the first item of a wave is its own slot; further ones are drawn from a ticket counter
+    // (sub-trees differ in size by orders of magnitude, a static stride leaves most waves idle behind
+    // the few that drew dense ones).  Tickets for the first round too would serialise 4096 atomics
+    // on one address at kernel start (measured: +40 us per launch).
+    bool first = true;
+    for (uint32_t item = blockIdx.x * EXP_WAVES + wv;; item += gridDim.x * EXP_WAVES) {
+        if (ticket && !first) {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(ticket, 1u);
+            item = gridDim.x * EXP_WAVES + __shfl(t, 0);
+        }
+        first = false;
+        if (item >= n_items) break;
         const ExpandItem it = items[item];
         if (it.hi <= it.lo) continue;
         const uint32_t row = it.row;
         const uint32_t root = it.level;
-        // narrow root intervals have few distinct symbols: finishing them in this wave costs
-        // 16 dependent probes, handing them over would add a launch and nothing else
-        const uint32_t stop = (root == 0 && (it.hi - it.lo) < wide_rows) ? L : stop_level;
         // a root sitting below the last level is already a leaf
-        if (root >= L) { if (lane == 0) emit_leaf<MODE>(tgt, row, it.prefix, it.hi - it.lo); continue; }
-        if (lane < FMI_MAX_LEVELS) s_cnt[lane] = 0;
+        if (root >= Q) { if (lane == 0) emit_leaf<MODE>(tgt, row, it.prefix, it.hi - it.lo); continue; }
+        if (lane < FMI_MAX_QLEVELS) s_cnt[lane] = 0;
         if (lane == 0) {
             s_lo[0] = (uint32_t)it.lo; s_hi[0] = (uint32_t)it.hi;
             // positions < 2^40: 8 high bits each
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
             if (cnt == 0) { deepest--; continue; }
             const uint32_t m = cnt < 64 ? cnt : 64;
             const uint32_t base = lvl_off(deepest) + (cnt - m);
-            const uint32_t k = root + deepest;      // absolute level of the popped nodes
+            const uint32_t k = root + deepest;      // absolute quad level of the popped nodes
             const bool act = lane < m;
             uint64_t lo = 0, hi = 0; uint32_t prefix = 0;
             if (act) {
@@ -209,51 +225,42 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
             }
             wave_sync();
             if (lane == 0) s_cnt[deepest] = cnt - m;
-            uint64_t r_lo = 0, r_hi = 0;
-            if (act) {
-                r_lo = wm_rank1(ix, k, lo, nullptr);
-                r_hi = wm_rank1(ix, k, hi, nullptr);
-                probes += 2;
-            }
-            const uint64_t ones = r_hi - r_lo;
-            const uint64_t zer = (hi - lo) - ones;
-            const bool has0 = act && zer > 0, has1 = act && ones > 0;
-            const uint64_t z = ix.zeros[k];
-            if (k + 1 == L) {
-                if (has0) emit_leaf<MODE>(tgt, row, prefix << 1, zer);
-                if (has1) emit_leaf<MODE>(tgt, row, (prefix << 1) | 1, ones);
+            // child d of the node = [clo[d], chi[d]) on level k+1
+            uint64_t clo[4] = {0, 0, 0, 0}, chi[4] = {0, 0, 0, 0};
+            if (act) probes += wm_children(ix, k, lo, hi, clo, chi);
+            if (k + 1 == Q) {
+#pragma unroll
+                for (uint32_t d = 0; d < 4; d++)
+                    if (chi[d] > clo[d]) emit_leaf<MODE>(tgt, row, (prefix << 2) | d, chi[d] - clo[d]);
             } else {
-                const uint64_t b0 = __ballot(has0), b1 = __ballot(has1);
-                const uint64_t lt = (1ull << lane) - 1;
-                const uint32_t n0 = (uint32_t)__popcll(b0);
-                const uint32_t added = n0 + (uint32_t)__popcll(b1);
-                if (k + 1 == stop) {
+                uint64_t bal[4];
+                uint32_t before[4], added = 0;
+#pragma unroll
+                for (uint32_t d = 0; d < 4; d++) {
+                    bal[d] = __ballot(chi[d] > clo[d]);
+                    before[d] = added;
+                    added += (uint32_t)__popcll(bal[d]);
+                }
+                if (k + 1 == stop_level) {
                     // hand the children over to phase 2
                     uint32_t obase = 0;
                     if (lane == 0 && added) obase = atomicAdd(out_count, added);
                     obase = __shfl(obase, 0);
-                    if (has0) {
-                        const uint32_t o = obase + (uint32_t)__popcll(b0 & lt);
-                        if (o < out_cap) out_items[o] = ExpandItem{lo - r_lo, hi - r_hi, row, k + 1, prefix << 1, 0};
-                    }
-                    if (has1) {
-                        const uint32_t o = obase + n0 + (uint32_t)__popcll(b1 & lt);
-                        if (o < out_cap) out_items[o] = ExpandItem{z + r_lo, z + r_hi, row, k + 1, (prefix << 1) | 1, 0};
-                    }
+#pragma unroll
+                    for (uint32_t d = 0; d < 4; d++)
+                        if (chi[d] > clo[d]) {
+                            const uint32_t o = obase + before[d] + (uint32_t)__popcll(bal[d] & lt);
+                            if (o < out_cap) out_items[o] = ExpandItem{clo[d], chi[d], row, k + 1, (prefix << 2) | d, 0};
+                        }
                 } else {
                     const uint32_t dst = lvl_off(deepest + 1) + s_cnt[deepest + 1];
-                    if (has0) {
-                        const uint32_t o = dst + (uint32_t)__popcll(b0 & lt);
-                        const uint64_t clo = lo - r_lo, chi = hi - r_hi;
-                        s_lo[o] = (uint32_t)clo; s_hi[o] = (uint32_t)chi;
-                        s_mx[o] = (uint32_t)(clo >> 32) | ((uint32_t)(chi >> 32) << 8) | ((prefix << 1) << 16);
-                    }
-                    if (has1) {
-                        const uint32_t o = dst + n0 + (uint32_t)__popcll(b1 & lt);
-                        const uint64_t clo = z + r_lo, chi = z + r_hi;
-                        s_lo[o] = (uint32_t)clo; s_hi[o] = (uint32_t)chi;
-                        s_mx[o] = (uint32_t)(clo >> 32) | ((uint32_t)(chi >> 32) << 8) | (((prefix << 1) | 1) << 16);
-                    }
+#pragma unroll
+                    for (uint32_t d = 0; d < 4; d++)
+                        if (chi[d] > clo[d]) {
+                            const uint32_t o = dst + before[d] + (uint32_t)__popcll(bal[d] & lt);
+                            s_lo[o] = (uint32_t)clo[d]; s_hi[o] = (uint32_t)chi[d];
+                            s_mx[o] = (uint32_t)(clo[d] >> 32) | ((uint32_t)(chi[d] >> 32) << 8) | (((prefix << 2) | d) << 16);
+                        }
                     wave_sync();
                     if (lane == 0) s_cnt[deepest + 1] += added;
                     wave_sync();
@@ -719,9 +726,9 @@ extern "C" int fmi_dev_get_range(fmi_t *h, void *stream, uint64_t n_seq, const i
 
 // workspace = expansion items + allowed-token bitmap (vocab <= 2^17 -> 4096 words/row)
 static constexpr uint64_t WS_BITS_WORDS = (1ull << FMI_MAX_LEVELS) / 32;
-static constexpr uint32_t EXP_SPLIT_MAX = 10;
-static constexpr uint64_t WS_QUEUE_PER_ROW = 1ull << EXP_SPLIT_MAX;     // room for any split level up to EXP_SPLIT_MAX
-// layout: items[rows] | queue[rows * 64] | bits[rows * WS_BITS_WORDS] | counter
+static constexpr uint32_t EXP_SPLIT_MAX = 5;                                   // quad levels
+static constexpr uint64_t WS_QUEUE_PER_ROW = 1ull << (2 * EXP_SPLIT_MAX);     // room for any split level up to EXP_SPLIT_MAX
+// layout: items[rows] | queue[rows * WS_QUEUE_PER_ROW] | bits[rows * WS_BITS_WORDS] | counter
 static inline ExpandItem *ws_items(fmi *h) { return (ExpandItem *)h->ws; }
 static inline ExpandItem *ws_queue(fmi *h) { return ws_items(h) + h->ws_rows; }
 static inline uint32_t *ws_bits(fmi *h) { return (uint32_t *)(ws_queue(h) + h->ws_rows * WS_QUEUE_PER_ROW); }
@@ -780,7 +787,7 @@ extern "C" const void *fmi_dev_array(const fmi_t *h, const char *name, uint64_t 
     if (s == "sa_lo") return ret(d.sa_lo, d.n, 4);
     if (s == "sa_hi") return ret(d.sa_hi, d.sa_hi ? d.n : 0, 1);
     if (s == "text") return ret(d.text, d.n, d.sym_bytes);
-    if (s == "wm") return ret(d.wm, (uint64_t)d.levels * d.nblk * FMI_BLOCK_WORDS, 8);
+    if (s == "wm") return ret(d.wm, (uint64_t)d.qlevels * d.nblk * FMI_BLOCK_WORDS, 8);
     if (s == "C") return ret(d.C, d.max_sym + 2, 8);
     if (s == "leaf") return ret(d.leaf, d.max_sym + 1, 8);
     if (s == "q1") return ret(d.q1, d.max_sym + 1, 1);
@@ -794,36 +801,34 @@ static unsigned expand_grid(uint64_t n_items)
     return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(g, 256ull * 16));
 }
 
-static size_t expand_lds_bytes(int nlev) { return (size_t)EXP_WAVES * (3 * (size_t)exp_slots(nlev) + FMI_MAX_LEVELS) * 4; }
+static size_t expand_lds_bytes(int nlev) { return (size_t)EXP_WAVES * (3 * (size_t)exp_slots(nlev) + FMI_MAX_QLEVELS) * 4; }
 
-// Expansion of `rows` root intervals (items[0..rows), level 0) in two launches:
-//   phase 1: one wave per row walks levels [0, split) and appends the surviving
-//            level-`split` nodes to the queue behind the roots;
+// Expansion of `rows` root intervals (items[0..rows), quad level 0) in two launches:
+//   phase 1: one wave per row walks quad levels [0, split) and appends the surviving
+//            level-`split` nodes (<= 4^split per row) to the queue behind the roots;
 //   phase 2: one wave per queued node finishes its sub-tree.
-// The queue (rows << split entries) and its counter live in the workspace.
+// The queue (rows << 2*split entries) and its counter live in the workspace.
 template <int MODE>
 static int launch_expand(fmi *h, hipStream_t st, ExpandItem *items, uint64_t rows, ExpandItem *queue, uint32_t *qcount,
                          uint64_t qcap, const EmitTarget &tgt)
 {
-    const uint32_t L = h->levels;
+    const uint32_t Q = h->qlevels;
     uint64_t *pc = h->probe_count_enabled ? h->d_probe_counter : nullptr;
-    static const char *e_split = getenv("SEALFM_SPLIT");
+    static const char *e_split = getenv("SEALFM_SPLIT");   // tuning knob
     const uint32_t want = e_split ? std::min<uint32_t>((uint32_t)atoi(e_split), EXP_SPLIT_MAX) : EXP_SPLIT_LEVEL;
-    const uint32_t split = (L > want + 2 && queue && qcap >= (rows << want)) ? want : L;   // shallow trees: single phase
-    if (split < L) HIPCHK(hipMemsetAsync(qcount, 0, 4, st));
-    static const char *e_wide = getenv("SEALFM_WIDE_ROWS"), *e_nlev = getenv("SEALFM_P1_NLEV");   // tuning knobs
-    const uint64_t wide = e_wide ? strtoull(e_wide, nullptr, 10) : EXP_WIDE_ROWS;
-    const int nlev1 = e_nlev ? atoi(e_nlev) : (wide ? (int)L : (int)split);
+    const uint32_t split = (want > 0 && Q > want + 1 && queue && qcap >= (rows << (2 * want))) ? want : Q;   // shallow trees: single phase
+    if (split < Q) HIPCHK(hipMemsetAsync(qcount, 0, 8, st));   // [0] queue length, [1] phase-2 ticket
+    const int nlev1 = (int)split;
     hipLaunchKernelGGL((k_expand<MODE>), dim3(expand_grid(rows)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev1), st, h->dev,
                        (const ExpandItem *)items, (const uint32_t *)nullptr, (uint32_t)rows, tgt, (uint32_t)exp_slots(nlev1),
-                       split, queue, qcount, (uint32_t)qcap, wide, pc);
-    if (split < L) {
-        const int nlev2 = (int)(L - split);
+                       split, queue, qcount, (uint32_t)qcap, (uint32_t *)nullptr, pc);
+    if (split < Q) {
+        const int nlev2 = (int)(Q - split);
         static const char *e_p2 = getenv("SEALFM_P2_BLOCKS");
         const unsigned p2_blocks = e_p2 ? (unsigned)atoi(e_p2) : EXP_P2_BLOCKS;
         hipLaunchKernelGGL((k_expand<MODE>), dim3(std::min(expand_grid(qcap), p2_blocks)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev2), st, h->dev,
                            (const ExpandItem *)queue, (const uint32_t *)qcount, (uint32_t)qcap, tgt, (uint32_t)exp_slots(nlev2),
-                           L, (ExpandItem *)nullptr, (uint32_t *)nullptr, 0u, (uint64_t)0, pc);
+                           Q, (ExpandItem *)nullptr, (uint32_t *)nullptr, 0u, qcount + 1, pc);
     }
     HIPCHK(hipGetLastError());
     return FMI_OK;
@@ -1028,7 +1033,7 @@ extern "C" int fmi_distinct_count_multi(fmi_t *h, uint64_t n, const uint64_t *lo
         {
             DevBuf q, qc;
             const uint64_t qcap = m * WS_QUEUE_PER_ROW;
-            if ((rc = q.alloc(qcap * sizeof(ExpandItem))) || (rc = qc.alloc(4))) return rc;
+            if ((rc = q.alloc(qcap * sizeof(ExpandItem))) || (rc = qc.alloc(8))) return rc;
             rc = launch_expand<EMIT_DENSE>(h, 0, items.as<ExpandItem>(), m, q.as<ExpandItem>(), qc.as<uint32_t>(), qcap, tgt);
             if (rc) return rc;
             HIPCHK(hipDeviceSynchronize());   // q / qc are freed at scope exit

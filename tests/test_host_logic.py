@@ -46,16 +46,27 @@ def _arr(h, name):
     return np.frombuffer(buf, dtype=dt).copy()
 
 
-def _wm_rank1(wm, nblk, k, p):
-    """numpy restatement of the documented block layout."""
-    w = p >> 6
-    blk, wi = divmod(w, 7)
-    base = (k * nblk + blk) * 8
-    r = int(wm[base])
-    for j in range(wi):
-        r += bin(int(wm[base + 1 + j])).count("1")
-    r += bin(int(wm[base + 1 + wi]) & ((1 << (p & 63)) - 1)).count("1")
-    return r
+def _wm_digit_ranks(wm, nblk, q, p):
+    """Python restatement of the documented 128-byte block layout: digits equal to
+    0 / 1 / 2 / 3 in quad level q before position p."""
+    blk, within = divmod(p, 448)
+    base = (q * nblk + blk) * 16
+
+    def digit(i):   # digit at offset i of the block: group chunks 0..2 | header | group chunks 3..6
+        g, bit = divmod(i, 64)
+        w = 2 * g if g < 3 else 2 * g + 2
+        return ((int(wm[base + w]) >> bit) & 1) << 1 | ((int(wm[base + w + 1]) >> bit) & 1)
+
+    w0, w1 = int(wm[base + 6]), int(wm[base + 7])
+    cnt = [0, w0 & ((1 << 40) - 1), (w0 >> 40) | ((w1 & 0xFFFF) << 24), w1 >> 16]   # before offset 192
+    if within < 192:
+        for i in range(within, 192):
+            cnt[digit(i)] -= 1
+    else:
+        for i in range(192, within):
+            cnt[digit(i)] += 1
+    cnt[0] = p - cnt[1] - cnt[2] - cnt[3]
+    return cnt
 
 
 def _rand_data(rng, n, vocab):
@@ -86,16 +97,19 @@ def test_host_builder_matches_brute_force(seed, n, vocab):
         for c in set(text):
             assert C[c] == sum(1 for x in text if x < c)
         assert lib().fmi_sigma(h) == len(set(text))
-        wm, zeros, leaf = _arr(h, "wm"), _arr(h, "zeros"), _arr(h, "leaf")
-        nblk = len(wm) // (8 * L)
-        # rank_c(i) through the wavelet matrix == naive count
+        wm, qbase, leaf = _arr(h, "wm"), _arr(h, "qbase"), _arr(h, "leaf")
+        Q = (L + 1) // 2
+        assert len(qbase) == 4 * Q
+        nblk = len(wm) // (16 * Q)
+        assert nblk == N // 448 + 2
+        # rank_c(i) through the quad wavelet matrix == naive count
         for _ in range(300):
             c = rng.choice(text)
             i = rng.randrange(0, N + 1)
             p = i
-            for k in range(L):
-                r1 = _wm_rank1(wm, nblk, k, p)
-                p = int(zeros[k]) + r1 if (c >> (L - 1 - k)) & 1 else p - r1
+            for q in range(Q):
+                d = (c >> (2 * (Q - 1 - q))) & 3
+                p = int(qbase[4 * q + d]) + _wm_digit_ranks(wm, nblk, q, p)[d]
             assert p - int(leaf[c]) == bwt[:i].count(c)
         # quirk table == what the faithful sdsl-layout oracle computes for rank(size()+1, c)
         orc = CppFMIndex()
@@ -138,7 +152,7 @@ def test_save_load_round_trip(tmp_path):
     h2 = ctypes.c_void_p()
     check(lib().fmi_load(ctypes.byref(h2), path, -1))
     try:
-        for name in ("sa", "bwt", "text", "C", "leaf", "q1", "zeros", "wm"):
+        for name in ("sa", "bwt", "text", "C", "leaf", "q1", "qbase", "wm"):
             assert np.array_equal(_arr(h, name), _arr(h2, name)), name
         assert lib().fmi_size(h2) == 1001 and lib().fmi_levels(h2) == lib().fmi_levels(h)
     finally:
