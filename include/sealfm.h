@@ -201,11 +201,15 @@ int fmi_dev_locate_ranges(fmi_t *h, void *stream, uint64_t n_ranges, const uint6
 int fmi_dev_get_docs(fmi_t *h, void *stream, uint64_t n_docs, const uint64_t *d_docs,
                      const uint64_t *d_out_offsets, int64_t shift, int64_t *d_out);
 
-/* probe counter of the last fmi_dev_* expansion launch (64-byte wavelet-block
- * probes issued; DESIGN.md "algorithmic bytes").  Device-side counter, read
- * back synchronously: for measurement only, never on the timed path. */
+/* probe counter of the fmi_dev_* expansion launches since the last read: the
+ * 64-byte sectors of wavelet-matrix blocks the rank probes touched (x 64 =
+ * DESIGN.md "algorithmic bytes").  Device-side counter, read back
+ * synchronously: for measurement only, never on the timed path.
+ * fmi_dev_read_expand_stats: {sectors, wave iterations, nodes expanded} without
+ * resetting (nodes / (64 * iterations) = lane utilisation of k_expand). */
 int fmi_dev_enable_probe_count(fmi_t *h, int enable);
 int fmi_dev_read_probe_count(fmi_t *h, uint64_t *probes_out);
+int fmi_dev_read_expand_stats(fmi_t *h, uint64_t *out3);
 
 /* HIP-event timing of the expansion kernel (k_expand): when enabled, every launch
  * is bracketed by two events recorded on the launch stream.  read = synchronise,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "fmi_dev_get_docs": (_int, [_vp, _vp, _u64, _vp, _vp, _i64, _vp]),
     "fmi_dev_enable_probe_count": (_int, [_vp, _int]),
     "fmi_dev_read_probe_count": (_int, [_vp, _p64]),
+    "fmi_dev_read_expand_stats": (_int, [_vp, _p64]),
     "fmi_dev_enable_timing": (_int, [_vp, _int]),
     "fmi_dev_read_timing": (_int, [_vp, _p64, ctypes.POINTER(ctypes.c_double)]),
     "fmi_dev_array": (_vp, [_vp, ctypes.c_char_p, _p64, ctypes.POINTER(ctypes.c_uint32)]),

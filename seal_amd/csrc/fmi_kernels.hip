@@ -135,6 +135,7 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+static constexpr uint32_t PROBE_SLOTS = 256;         // counter slots (measurement mode only), one 64-byte line each
 static constexpr int EXP_WAVES = 4;                 // waves per workgroup
 static constexpr int EXP_LVL_CAP = 256;
 static constexpr uint32_t EXP_SPLIT_LEVEL = 2;      // phase 1 hands the sub-trees over to phase 2 at this quad level (<= 16 per row; r1: 2 beats 3 and 4)
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
     const uint32_t Q = ix.qlevels;
     const uint64_t lt = (1ull << lane) - 1;
     uint64_t probes = 0;
+    uint32_t iters = 0, nodes = 0;
 
     // phase 2: the first item of a wave is its own slot; further ones are drawn from a ticket counter
     // (sub-trees differ in size by orders of magnitude, a static stride leaves most waves idle behind
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
             // child d of the node = [clo[d], chi[d]) on level k+1
             uint64_t clo[4] = {0, 0, 0, 0}, chi[4] = {0, 0, 0, 0};
             if (act) probes += wm_children(ix, k, lo, hi, clo, chi);
+            iters++; nodes += m;
             if (k + 1 == Q) {
 #pragma unroll
                 for (uint32_t d = 0; d < 4; d++)
@@ -270,7 +273,15 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
         }
         wave_sync();
     }
-    if (probe_counter && probes) atomicAdd((unsigned long long *)probe_counter, (unsigned long long)probes);
+    if (probe_counter) {
+        // one 64-byte line per slot: thousands of waves adding to ONE address cost tens of microseconds
+        unsigned long long *slot = (unsigned long long *)probe_counter + (size_t)(blockIdx.x & (PROBE_SLOTS - 1)) * 8;
+        if (probes) atomicAdd(slot, (unsigned long long)probes);
+        if (lane == 0 && iters) {
+            atomicAdd(slot + 1, (unsigned long long)iters);
+            atomicAdd(slot + 2, (unsigned long long)nodes);
+        }
+    }
 }
 
 // dense per-row symbol counts -> CSR, ascending symbols.  One workgroup per row.
@@ -686,21 +697,43 @@ extern "C" int fmi_dev_enable_probe_count(fmi_t *h, int enable)
 {
     int rc = need_device(h); if (rc) return rc;
     if (enable && !h->d_probe_counter) {
-        HIPCHK(hipMalloc((void **)&h->d_probe_counter, 8));
+        HIPCHK(hipMalloc((void **)&h->d_probe_counter, PROBE_SLOTS * 64));
     }
-    if (h->d_probe_counter) HIPCHK(hipMemset(h->d_probe_counter, 0, 8));
+    if (h->d_probe_counter) HIPCHK(hipMemset(h->d_probe_counter, 0, PROBE_SLOTS * 64));
     h->probe_count_enabled = enable;
+    return FMI_OK;
+}
+
+static int read_probe_slots(fmi *h, uint64_t out3[3], bool reset)
+{
+    if (!h->d_probe_counter) { fmi_set_error("probe counter not enabled"); return FMI_ERR_STATE; }
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<uint64_t> slots(PROBE_SLOTS * 8);
+    HIPCHK(hipMemcpy(slots.data(), h->d_probe_counter, PROBE_SLOTS * 64, hipMemcpyDeviceToHost));
+    out3[0] = out3[1] = out3[2] = 0;
+    for (uint32_t i = 0; i < PROBE_SLOTS; i++)
+        for (int e = 0; e < 3; e++) out3[e] += slots[i * 8 + e];
+    if (reset) HIPCHK(hipMemset(h->d_probe_counter, 0, PROBE_SLOTS * 64));
     return FMI_OK;
 }
 
 extern "C" int fmi_dev_read_probe_count(fmi_t *h, uint64_t *out)
 {
     int rc = need_device(h); if (rc) return rc;
-    if (!h->d_probe_counter || !out) { fmi_set_error("probe counter not enabled"); return FMI_ERR_STATE; }
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, h->d_probe_counter, 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(h->d_probe_counter, 0, 8));
+    if (!out) { fmi_set_error("null out"); return FMI_ERR_ARG; }
+    uint64_t v[3];
+    rc = read_probe_slots(h, v, true); if (rc) return rc;
+    *out = v[0];
     return FMI_OK;
+}
+
+// diagnostics of the same counting mode: {sectors, wave iterations, nodes expanded} since the last
+// fmi_dev_read_probe_count (nodes / (64 * iterations) = lane utilisation of k_expand); does not reset.
+extern "C" int fmi_dev_read_expand_stats(fmi_t *h, uint64_t *out3)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (!out3) { fmi_set_error("null out"); return FMI_ERR_ARG; }
+    return read_probe_slots(h, out3, false);
 }
 
 extern "C" int fmi_dev_bs_step(fmi_t *h, void *stream, uint64_t n, const uint64_t *d_sym, const uint64_t *d_lo,

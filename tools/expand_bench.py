@@ -79,7 +79,7 @@ def main():
     V = bench.VOCAB
     bits = torch.zeros(args.rows, (V + 31) // 32, dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream
-    check(lib().fmi_dev_enable_probe_count(h, 1))
+    check(lib().fmi_dev_enable_probe_count(h, 0 if os.environ.get("EXPAND_NO_COUNT") else 1))
     check(lib().fmi_dev_enable_timing(h, 1))
 
     for pl, ids in zip(plens, all_ids):
@@ -89,11 +89,15 @@ def main():
         call()
         torch.cuda.synchronize()
         probes, launches, ms = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
-        check(lib().fmi_dev_read_probe_count(h, ctypes.byref(probes)))
+        if not os.environ.get("EXPAND_NO_COUNT"):
+            check(lib().fmi_dev_read_probe_count(h, ctypes.byref(probes)))
         check(lib().fmi_dev_read_timing(h, ctypes.byref(launches), ctypes.byref(ms)))
         for _ in range(args.iters):
             call()
-        check(lib().fmi_dev_read_probe_count(h, ctypes.byref(probes)))
+        stats = (ctypes.c_uint64 * 3)()
+        if not os.environ.get("EXPAND_NO_COUNT"):
+            check(lib().fmi_dev_read_expand_stats(h, stats))
+            check(lib().fmi_dev_read_probe_count(h, ctypes.byref(probes)))
         check(lib().fmi_dev_read_timing(h, ctypes.byref(launches), ctypes.byref(ms)))
         allowed = int(sum(bin(x & 0xFFFFFFFF).count("1") for x in bits[:8].flatten().tolist())) / 8.0
         gbs = probes.value * 64 / (ms.value * 1e-3) / 1e9
@@ -101,7 +105,8 @@ def main():
                           "iters": args.iters, "sectors_per_call": probes.value / args.iters,
                           "alg_MB_per_call": round(probes.value * 64 / args.iters / 1e6, 2),
                           "us_per_call": round(ms.value * 1e3 / args.iters, 2), "GBps": round(gbs, 1),
-                          "frac_of_8TBps": round(gbs / 8000, 4), "avg_allowed_tokens_first8rows": allowed}), flush=True)
+                          "frac_of_8TBps": round(gbs / 8000, 4), "wave_iters_per_call": stats[1] / args.iters,
+                          "lane_util": round(stats[2] / max(1, 64 * stats[1]), 3), "avg_allowed_tokens_first8rows": allowed}), flush=True)
 
 
 if __name__ == "__main__":
