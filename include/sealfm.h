@@ -205,11 +205,13 @@ int fmi_dev_get_docs(fmi_t *h, void *stream, uint64_t n_docs, const uint64_t *d_
  * 64-byte sectors of wavelet-matrix blocks the rank probes touched (x 64 =
  * DESIGN.md "algorithmic bytes").  Device-side counter, read back
  * synchronously: for measurement only, never on the timed path.
- * fmi_dev_read_expand_stats: {sectors, wave iterations, nodes expanded} without
- * resetting (nodes / (64 * iterations) = lane utilisation of k_expand). */
+ * fmi_dev_read_expand_stats: out4 = {sectors, wave iterations, nodes expanded,
+ * nodes a binary wavelet tree over the same symbols visits} without resetting
+ * (nodes / (64 * iterations) = lane utilisation of k_expand; 2 * out4[3] = the
+ * 64-byte level-probes of the reference-shaped algorithm for the same work). */
 int fmi_dev_enable_probe_count(fmi_t *h, int enable);
 int fmi_dev_read_probe_count(fmi_t *h, uint64_t *probes_out);
-int fmi_dev_read_expand_stats(fmi_t *h, uint64_t *out3);
+int fmi_dev_read_expand_stats(fmi_t *h, uint64_t *out4);
 
 /* HIP-event timing of the expansion kernel (k_expand): when enabled, every launch
  * is bracketed by two events recorded on the launch stream.  read = synchronise,

@@ -134,9 +134,9 @@ __global__ void k_bwt(const SymT *text, const IdxT *sa, uint64_t n, SymT *bwt)
     GRID_STRIDE(j, n) { const uint64_t p = sa[j]; bwt[j] = text[p ? p - 1 : n - 1]; }
 }
 
-// one wave per 448-position block of one quad level: the two bit planes by ballot, the block's
+// one wave per 192-position block of one quad level: the two bit planes by ballot, the block's
 // digit counts (1, 2, 3) for the header scan, and -- parked in the header chunk until the scan is
-// done -- the counts of its first three groups
+// done -- the counts of its first group
 template <typename SymT>
 __global__ __launch_bounds__(256) void k_level_words(const SymT *cur, uint64_t n, uint32_t sh, uint64_t nblk, uint64_t *lvl,
                                                      uint32_t *cnt1, uint32_t *cnt2, uint32_t *cnt3)
@@ -146,14 +146,13 @@ __global__ __launch_bounds__(256) void k_level_words(const SymT *cur, uint64_t n
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t b = wave; b < nblk; b += nwaves) {
         uint32_t nh = 0, nl = 0, nhl = 0;
-        for (uint32_t j = 0; j < 7; j++) {
-            if (j == 3 && lane == 0) {
-                lvl[b * FMI_BLOCK_WORDS + 6] = (uint64_t)(nl - nhl) | ((uint64_t)(nh - nhl) << 16) | ((uint64_t)nhl << 32);
-            }
+        for (uint32_t j = 0; j < 3; j++) {
+            if (j == 1 && lane == 0)
+                lvl[b * FMI_BLOCK_WORDS + 2] = (uint64_t)(nl - nhl) | ((uint64_t)(nh - nhl) << 16) | ((uint64_t)nhl << 32);
             const uint64_t p = b * FMI_BLOCK_BITS + (uint64_t)j * 64 + lane;
             const uint32_t d = p < n ? (uint32_t)(cur[p] >> sh) & 3u : 0u;
             const uint64_t H = __ballot(d >> 1), Lw = __ballot(d & 1);
-            const uint32_t w = j < 3 ? 2 * j : 2 * j + 2;
+            const uint32_t w = j == 0 ? 0 : 2 * j + 2;
             if (lane == 0) { lvl[b * FMI_BLOCK_WORDS + w] = H; lvl[b * FMI_BLOCK_WORDS + w + 1] = Lw; }
             nh += (uint32_t)__popcll(H); nl += (uint32_t)__popcll(Lw); nhl += (uint32_t)__popcll(H & Lw);
         }
@@ -161,14 +160,14 @@ __global__ __launch_bounds__(256) void k_level_words(const SymT *cur, uint64_t n
     }
 }
 
-// header = digits before the block (exclusive scans) + digits of its first three groups
+// header = digits before the block (exclusive scans) + digits of its first group
 __global__ void k_store_counts(const uint64_t *x1, const uint64_t *x2, const uint64_t *x3, uint64_t nblk, uint64_t *lvl)
 {
     GRID_STRIDE(b, nblk) {
-        const uint64_t part = lvl[b * FMI_BLOCK_WORDS + 6];
+        const uint64_t part = lvl[b * FMI_BLOCK_WORDS + 2];
         const uint64_t c1 = x1[b] + (part & 0xffff), c2 = x2[b] + ((part >> 16) & 0xffff), c3 = x3[b] + ((part >> 32) & 0xffff);
-        lvl[b * FMI_BLOCK_WORDS + 6] = c1 | (c2 << 40);
-        lvl[b * FMI_BLOCK_WORDS + 7] = (c2 >> 24) | (c3 << 16);
+        lvl[b * FMI_BLOCK_WORDS + 2] = c1 | (c2 << 40);
+        lvl[b * FMI_BLOCK_WORDS + 3] = (c2 >> 24) | (c3 << 16);
     }
 }
 
@@ -236,7 +235,7 @@ int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64
     std::vector<uint64_t> qbase((size_t)Q * 4, 0);
     for (uint32_t q = 0; q < Q; q++) {
         uint64_t *lvl = wm + (uint64_t)q * nblk * FMI_BLOCK_WORDS;
-        hipLaunchKernelGGL((k_level_words<SymT>), dim3((unsigned)std::min<uint64_t>((nblk + 3) / 4, 1u << 18)), dim3(256), 0, st,
+        hipLaunchKernelGGL((k_level_words<SymT>), dim3((unsigned)std::min<uint64_t>((nblk + 3) / 4, 1u << 20)), dim3(256), 0, st,
                            cur, n, 2 * (Q - 1 - q), nblk, lvl, cnt[0], cnt[1], cnt[2]);
         uint64_t tot[3] = {0, 0, 0};
         for (int e = 0; e < 3; e++) {

@@ -9,10 +9,10 @@
 // ---------------------------------------------------------------------------
 struct alignas(16) U64x2 { uint64_t x, y; };
 
-// The chunks of one 128-byte block that a rank probe at one position needs (fmi_internal.h):
-// the header and the <= 4 group chunks between the position and the header's reference point.
+// The chunks of one 64-byte block that a rank probe at one position needs (fmi_internal.h):
+// the header and the one or two group chunks between the position and the header's reference point.
 struct QProbe {
-    U64x2 hdr, ch[4];
+    U64x2 hdr, ch[2];
     uint32_t group, bit;
 };
 
@@ -21,42 +21,35 @@ __device__ __forceinline__ uint64_t wm_block_of(const FmiDev &ix, uint64_t p, ui
 {
     const uint64_t w = p >> 6;
     uint64_t blk;
-    if (ix.n < (1ull << 37)) blk = (uint32_t)w / 7u;      // word index fits 32 bits: one mul_hi instead of a 64-bit divide
-    else blk = w / 7;
-    group = (uint32_t)(w - blk * 7);
+    if (ix.n < (1ull << 37)) blk = (uint32_t)w / 3u;      // word index fits 32 bits: one mul_hi instead of a 64-bit divide
+    else blk = w / 3;
+    group = (uint32_t)(w - blk * 3);
     return blk;
 }
 
-// issue the loads of a probe: lanes only touch the chunks they need (per-lane predicated 16-byte
-// loads), so a wave-wide probe costs ~3.3 L1 tag look-ups per lane instead of 8
+// issue the loads of a probe: header, the probe's own side of the block, and (group 2 only) one more
+// chunk -- per-lane predicated 16-byte loads, 2.33 L1 tag look-ups per lane on average
 __device__ __forceinline__ void wm_probe_load(const FmiDev &ix, uint32_t q, uint64_t blk, uint32_t group, uint32_t bit, QProbe &pr)
 {
     const U64x2 *src = reinterpret_cast<const U64x2 *>(ix.wm + ((uint64_t)q * ix.nblk + blk) * FMI_BLOCK_WORDS);
     pr.group = group; pr.bit = bit;
-    pr.hdr = src[3];
-    const uint32_t first = group < 3 ? group : 4, nch = group < 3 ? 3 - group : group - 2;
-#pragma unroll
-    for (uint32_t t = 0; t < 4; t++) {
-        pr.ch[t] = U64x2{0, 0};
-        if (t < nch) pr.ch[t] = src[first + t];
-    }
+    pr.hdr = src[1];
+    pr.ch[0] = src[group == 0 ? 0 : 2];         // group 0 (counted backwards) or group 1
+    pr.ch[1] = U64x2{0, 0};
+    if (group == 2) pr.ch[1] = src[3];
 }
 
 // digits equal to 1 / 2 / 3 in the level before the probe's position
 __device__ __forceinline__ void wm_probe_counts(const QProbe &pr, uint64_t &r1, uint64_t &r2, uint64_t &r3)
 {
-    const bool back = pr.group < 3;
-    const uint32_t nch = back ? 3 - pr.group : pr.group - 2;
+    const bool back = pr.group == 0;
     const uint64_t tail = (1ull << pr.bit) - 1;
-    uint32_t nh = 0, nl = 0, nhl = 0;
-#pragma unroll
-    for (uint32_t t = 0; t < 4; t++) {
-        uint64_t m = t < nch ? ~0ull : 0ull;
-        if (back) { if (t == 0) m = ~tail; }          // positions >= p of the probe's own group
-        else if (t + 1 == nch) m = tail;              // positions < p of the probe's own group
-        const uint64_t H = pr.ch[t].x & m, Lw = pr.ch[t].y & m;
-        nh += (uint32_t)__popcll(H); nl += (uint32_t)__popcll(Lw); nhl += (uint32_t)__popcll(H & Lw);
-    }
+    // group 0: positions >= p of chunk 0;  group 1: positions < p of chunk 0;  group 2: all of chunk 0, < p of chunk 1
+    const uint64_t m0 = back ? ~tail : (pr.group == 1 ? tail : ~0ull);
+    const uint64_t m1 = pr.group == 2 ? tail : 0ull;
+    const uint64_t H0 = pr.ch[0].x & m0, L0 = pr.ch[0].y & m0, H1 = pr.ch[1].x & m1, L1 = pr.ch[1].y & m1;
+    const uint32_t nh = (uint32_t)__popcll(H0) + (uint32_t)__popcll(H1), nl = (uint32_t)__popcll(L0) + (uint32_t)__popcll(L1);
+    const uint32_t nhl = (uint32_t)__popcll(H0 & L0) + (uint32_t)__popcll(H1 & L1);
     const uint64_t w0 = pr.hdr.x, w1 = pr.hdr.y;
     const uint64_t c1 = w0 & 0xffffffffffull, c2 = (w0 >> 40) | ((w1 & 0xffffull) << 24), c3 = w1 >> 16;
     const uint64_t d1 = nl - nhl, d2 = nh - nhl, d3 = nhl;
@@ -65,11 +58,8 @@ __device__ __forceinline__ void wm_probe_counts(const QProbe &pr, uint64_t &r1, 
     r3 = back ? c3 - d3 : c3 + d3;
 }
 
-// 64-byte sectors of the block a probe touches: the first always (header), the second iff group >= 3
-__device__ __forceinline__ uint32_t wm_probe_sectors(uint32_t group) { return group < 3 ? 1u : 3u; }
-
 // where position p of quad level q goes in level q+1 if its symbol has digit d there
-// (p = n maps an exclusive upper bound): ONE 128-byte line.
+// (p = n maps an exclusive upper bound): ONE 64-byte sector.
 __device__ __forceinline__ uint64_t wm_step(const FmiDev &ix, uint32_t q, uint64_t p, uint32_t d, uint64_t *sectors)
 {
     uint32_t group;
@@ -78,7 +68,7 @@ __device__ __forceinline__ uint64_t wm_step(const FmiDev &ix, uint32_t q, uint64
     wm_probe_load(ix, q, blk, group, (uint32_t)(p & 63), pr);
     uint64_t r1, r2, r3;
     wm_probe_counts(pr, r1, r2, r3);
-    if (sectors) *sectors += __popc(wm_probe_sectors(group));
+    if (sectors) ++*sectors;
     // q is wave-uniform at every call site: three scalar loads + selects instead of a per-lane table load
     const uint64_t b1 = ix.qbase[q][1], b2 = ix.qbase[q][2], b3 = ix.qbase[q][3];
     return d == 0 ? p - r1 - r2 - r3 : (d == 1 ? b1 + r1 : (d == 2 ? b2 + r2 : b3 + r3));
@@ -94,7 +84,7 @@ __device__ __forceinline__ uint64_t wm_rank_sym(const FmiDev &ix, uint64_t c, ui
 }
 
 // the two ends [lo, hi) of an interval on quad level q -> the four child intervals on level q+1;
-// the loads of both ends are issued back to back.  Returns the 64-byte sectors touched.
+// the loads of both ends are issued back to back.  Returns the 64-byte sectors (blocks) touched.
 __device__ __forceinline__ uint32_t wm_children(const FmiDev &ix, uint32_t q, uint64_t lo, uint64_t hi, uint64_t (&clo)[4], uint64_t (&chi)[4])
 {
     uint32_t glo, ghi;
@@ -110,8 +100,7 @@ __device__ __forceinline__ uint32_t wm_children(const FmiDev &ix, uint32_t q, ui
     clo[1] = q1 + a1; chi[1] = q1 + b1;
     clo[2] = q2 + a2; chi[2] = q2 + b2;
     clo[3] = q3 + a3; chi[3] = q3 + b3;
-    const uint32_t sa = wm_probe_sectors(glo), sb = wm_probe_sectors(ghi);
-    return blo == bhi ? (uint32_t)__popc(sa | sb) : (uint32_t)(__popc(sa) + __popc(sb));
+    return blo == bhi ? 1u : 2u;
 }
 
 // rank_c at two positions at once (the two ends of a backward-search interval): one dependent

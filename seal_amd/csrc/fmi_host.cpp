@@ -202,7 +202,7 @@ void fmi_host_q1_from_first_pos(const std::vector<uint64_t> &first_pos, uint32_t
 }
 
 // ---------------------------------------------------------------------------
-// BWT -> quad wavelet matrix in the 128-byte block layout (fmi_internal.h) + per-symbol tables.
+// BWT -> quad wavelet matrix in the 64-byte block layout (fmi_internal.h) + per-symbol tables.
 // ---------------------------------------------------------------------------
 void fmi_host_finish_from_bwt(fmi *h, const uint32_t *bwt, uint64_t n)
 {
@@ -233,10 +233,10 @@ void fmi_host_finish_from_bwt(fmi *h, const uint32_t *bwt, uint64_t n)
         for (uint64_t b = 0; b < h->nblk; b++) {
             uint64_t *blk = lvl + b * FMI_BLOCK_WORDS;
             const uint64_t base = b * FMI_BLOCK_BITS;
-            for (uint32_t j = 0; j < 7; j++) {
-                if (j == 3) {   // header: counts before the group-2 / group-3 boundary
-                    blk[6] = cnt[1] | (cnt[2] << 40);
-                    blk[7] = (cnt[2] >> 24) | (cnt[3] << 16);
+            for (uint32_t j = 0; j < 3; j++) {
+                if (j == 1) {   // header: counts before the group-0 / group-1 boundary
+                    blk[2] = cnt[1] | (cnt[2] << 40);
+                    blk[3] = (cnt[2] >> 24) | (cnt[3] << 16);
                 }
                 uint64_t H = 0, Lw = 0;
                 const uint64_t p0 = base + (uint64_t)j * 64;
@@ -246,7 +246,7 @@ void fmi_host_finish_from_bwt(fmi *h, const uint32_t *bwt, uint64_t n)
                     Lw |= (uint64_t)(d & 1) << bit;
                     cnt[d]++;
                 }
-                const uint32_t w = j < 3 ? 2 * j : 2 * j + 2;
+                const uint32_t w = j == 0 ? 0 : 2 * j + 2;
                 blk[w] = H;
                 blk[w + 1] = Lw;
             }

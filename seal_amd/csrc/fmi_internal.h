@@ -9,27 +9,27 @@
 
 // The BWT is held as a 4-ary ("quad") wavelet matrix: quad level q stores, for every position of
 // the order reached after q stable 4-way partitions, the 2-bit digit (c >> 2*(qlevels-1-q)) & 3 of the
-// symbol sitting there.  One quad level = nblk blocks of 128 bytes = 8 chunks of 16 bytes; block b
-// covers positions [448 b, 448 b + 448) in 7 groups of 64:
-//   chunk 0..2 : groups 0..2      chunk 3 : header      chunk 4..7 : groups 3..6
+// symbol sitting there.  One quad level = nblk blocks of 64 bytes (ONE memory sector) = 4 chunks of
+// 16 bytes; block b covers positions [192 b, 192 b + 192) in 3 groups of 64:
+//   chunk 0 : group 0      chunk 1 : header      chunk 2 : group 1      chunk 3 : group 2
 //   group chunk = { H, L }: bit i of H / L = high / low bit of the digit at position 64*group + i
-//   header      = c1, c2, c3 = digits equal to 1 / 2 / 3 in this level before position 448 b + 192
-//                 (the boundary between groups 2 and 3), 40 bits each:
+//   header      = c1, c2, c3 = digits equal to 1 / 2 / 3 in this level before position 192 b + 64
+//                 (the boundary between groups 0 and 1), 40 bits each:
 //                 w0 = c1 | c2 << 40 (low 24 bits of c2);  w1 = c2 >> 24 | c3 << 16
-// rank_d(p) counts from the header towards p: backwards through groups g..2 when p lies in group
-// g < 3 (first 64-byte sector only), forwards through groups 3..g otherwise -- on average 3.3 of the
-// 8 chunks of ONE 128-byte line answer rank_d(p) for all four digits d, and one probe moves a
+// rank_d(p) counts from the header towards p: backwards through group 0 when p lies there, forwards
+// through groups 1..g otherwise -- the header plus one or two group chunks (2.33 of the 4 chunks on
+// average) of ONE 64-byte sector answer rank_d(p) for all four digits d, and one probe moves a
 // backward search or an interval-symbols node two symbol bits down.  Positions are < 2^40 (FMI_MAX_N).
-static constexpr uint32_t FMI_BLOCK_WORDS = 16;
-static constexpr uint32_t FMI_BLOCK_BYTES = 128;
-static constexpr uint32_t FMI_BLOCK_BITS = 448;  // positions per block
-static constexpr uint32_t FMI_BLOCK_MID = 192;   // header counts refer to this offset inside the block
+static constexpr uint32_t FMI_BLOCK_WORDS = 8;
+static constexpr uint32_t FMI_BLOCK_BYTES = 64;
+static constexpr uint32_t FMI_BLOCK_BITS = 192;  // positions per block
+static constexpr uint32_t FMI_BLOCK_MID = 64;    // header counts refer to this offset inside the block
 static constexpr uint32_t FMI_MAX_LEVELS = 17;   // symbols < 2^17 (BART: 50274 < 2^16); node prefixes fit 16 bits
 static constexpr uint32_t FMI_MAX_QLEVELS = (FMI_MAX_LEVELS + 1) / 2;
 static constexpr uint64_t FMI_MAX_N = 1ull << 40;
 
 struct FmiDev {
-    const uint64_t *wm;       // [qlevels][nblk][16]
+    const uint64_t *wm;       // [qlevels][nblk][8]
     uint64_t nblk;
     uint64_t n;               // text length incl. sentinel
     uint64_t max_sym;

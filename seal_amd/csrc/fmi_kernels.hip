@@ -181,7 +181,7 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
     const uint32_t Q = ix.qlevels;
     const uint64_t lt = (1ull << lane) - 1;
     uint64_t probes = 0;
-    uint32_t iters = 0, nodes = 0;
+    uint32_t iters = 0, nodes = 0, model = 0;
 
     // phase 2: the first item of a wave is its own slot; further ones are drawn from a ticket counter
     // (sub-trees differ in size by orders of magnitude, a static stride leaves most waves idle behind
@@ -229,7 +229,13 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
             if (lane == 0) s_cnt[deepest] = cnt - m;
             // child d of the node = [clo[d], chi[d]) on level k+1
             uint64_t clo[4] = {0, 0, 0, 0}, chi[4] = {0, 0, 0, 0};
-            if (act) probes += wm_children(ix, k, lo, hi, clo, chi);
+            if (act) {
+                probes += wm_children(ix, k, lo, hi, clo, chi);
+                // the same node in the BINARY 16-level model of SURVEY.md 8(d): itself (level 2k) plus its
+                // non-empty halves (level 2k+1); with an odd bit count quad level 0 has no level of its own
+                const uint32_t halves = (uint32_t)((chi[0] > clo[0]) | (chi[1] > clo[1])) + (uint32_t)((chi[2] > clo[2]) | (chi[3] > clo[3]));
+                model += (k == 0 && (ix.levels & 1)) ? halves : 1 + halves;
+            }
             iters++; nodes += m;
             if (k + 1 == Q) {
 #pragma unroll
@@ -277,6 +283,7 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
         // one 64-byte line per slot: thousands of waves adding to ONE address cost tens of microseconds
         unsigned long long *slot = (unsigned long long *)probe_counter + (size_t)(blockIdx.x & (PROBE_SLOTS - 1)) * 8;
         if (probes) atomicAdd(slot, (unsigned long long)probes);
+        if (model) atomicAdd(slot + 3, (unsigned long long)model);
         if (lane == 0 && iters) {
             atomicAdd(slot + 1, (unsigned long long)iters);
             atomicAdd(slot + 2, (unsigned long long)nodes);
@@ -704,15 +711,15 @@ extern "C" int fmi_dev_enable_probe_count(fmi_t *h, int enable)
     return FMI_OK;
 }
 
-static int read_probe_slots(fmi *h, uint64_t out3[3], bool reset)
+static int read_probe_slots(fmi *h, uint64_t out3[4], bool reset)
 {
     if (!h->d_probe_counter) { fmi_set_error("probe counter not enabled"); return FMI_ERR_STATE; }
     HIPCHK(hipDeviceSynchronize());
     std::vector<uint64_t> slots(PROBE_SLOTS * 8);
     HIPCHK(hipMemcpy(slots.data(), h->d_probe_counter, PROBE_SLOTS * 64, hipMemcpyDeviceToHost));
-    out3[0] = out3[1] = out3[2] = 0;
+    out3[0] = out3[1] = out3[2] = out3[3] = 0;
     for (uint32_t i = 0; i < PROBE_SLOTS; i++)
-        for (int e = 0; e < 3; e++) out3[e] += slots[i * 8 + e];
+        for (int e = 0; e < 4; e++) out3[e] += slots[i * 8 + e];
     if (reset) HIPCHK(hipMemset(h->d_probe_counter, 0, PROBE_SLOTS * 64));
     return FMI_OK;
 }
@@ -721,14 +728,15 @@ extern "C" int fmi_dev_read_probe_count(fmi_t *h, uint64_t *out)
 {
     int rc = need_device(h); if (rc) return rc;
     if (!out) { fmi_set_error("null out"); return FMI_ERR_ARG; }
-    uint64_t v[3];
+    uint64_t v[4];
     rc = read_probe_slots(h, v, true); if (rc) return rc;
     *out = v[0];
     return FMI_OK;
 }
 
-// diagnostics of the same counting mode: {sectors, wave iterations, nodes expanded} since the last
-// fmi_dev_read_probe_count (nodes / (64 * iterations) = lane utilisation of k_expand); does not reset.
+// diagnostics of the same counting mode: {sectors, wave iterations, nodes expanded, nodes of the binary
+// 16-level model} since the last fmi_dev_read_probe_count (nodes / (64 * iterations) = lane utilisation
+// of k_expand; 2 * out[3] = the level-probes of SURVEY.md 8(d) for the same work); does not reset.
 extern "C" int fmi_dev_read_expand_stats(fmi_t *h, uint64_t *out3)
 {
     int rc = need_device(h); if (rc) return rc;

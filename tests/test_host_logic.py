@@ -47,23 +47,23 @@ def _arr(h, name):
 
 
 def _wm_digit_ranks(wm, nblk, q, p):
-    """Python restatement of the documented 128-byte block layout: digits equal to
+    """Python restatement of the documented 64-byte block layout: digits equal to
     0 / 1 / 2 / 3 in quad level q before position p."""
-    blk, within = divmod(p, 448)
-    base = (q * nblk + blk) * 16
+    blk, within = divmod(p, 192)
+    base = (q * nblk + blk) * 8
 
-    def digit(i):   # digit at offset i of the block: group chunks 0..2 | header | group chunks 3..6
+    def digit(i):   # digit at offset i of the block: group 0 | header | group 1 | group 2
         g, bit = divmod(i, 64)
-        w = 2 * g if g < 3 else 2 * g + 2
+        w = 0 if g == 0 else 2 * g + 2
         return ((int(wm[base + w]) >> bit) & 1) << 1 | ((int(wm[base + w + 1]) >> bit) & 1)
 
-    w0, w1 = int(wm[base + 6]), int(wm[base + 7])
-    cnt = [0, w0 & ((1 << 40) - 1), (w0 >> 40) | ((w1 & 0xFFFF) << 24), w1 >> 16]   # before offset 192
-    if within < 192:
-        for i in range(within, 192):
+    w0, w1 = int(wm[base + 2]), int(wm[base + 3])
+    cnt = [0, w0 & ((1 << 40) - 1), (w0 >> 40) | ((w1 & 0xFFFF) << 24), w1 >> 16]   # before offset 64
+    if within < 64:
+        for i in range(within, 64):
             cnt[digit(i)] -= 1
     else:
-        for i in range(192, within):
+        for i in range(64, within):
             cnt[digit(i)] += 1
     cnt[0] = p - cnt[1] - cnt[2] - cnt[3]
     return cnt
@@ -100,8 +100,8 @@ def test_host_builder_matches_brute_force(seed, n, vocab):
         wm, qbase, leaf = _arr(h, "wm"), _arr(h, "qbase"), _arr(h, "leaf")
         Q = (L + 1) // 2
         assert len(qbase) == 4 * Q
-        nblk = len(wm) // (16 * Q)
-        assert nblk == N // 448 + 2
+        nblk = len(wm) // (8 * Q)
+        assert nblk == N // 192 + 2
         # rank_c(i) through the quad wavelet matrix == naive count
         for _ in range(300):
             c = rng.choice(text)

@@ -94,7 +94,7 @@ def main():
         check(lib().fmi_dev_read_timing(h, ctypes.byref(launches), ctypes.byref(ms)))
         for _ in range(args.iters):
             call()
-        stats = (ctypes.c_uint64 * 3)()
+        stats = (ctypes.c_uint64 * 4)()
         if not os.environ.get("EXPAND_NO_COUNT"):
             check(lib().fmi_dev_read_expand_stats(h, stats))
             check(lib().fmi_dev_read_probe_count(h, ctypes.byref(probes)))
@@ -106,7 +106,8 @@ def main():
                           "alg_MB_per_call": round(probes.value * 64 / args.iters / 1e6, 2),
                           "us_per_call": round(ms.value * 1e3 / args.iters, 2), "GBps": round(gbs, 1),
                           "frac_of_8TBps": round(gbs / 8000, 4), "wave_iters_per_call": stats[1] / args.iters,
-                          "lane_util": round(stats[2] / max(1, 64 * stats[1]), 3), "avg_allowed_tokens_first8rows": allowed}), flush=True)
+                          "lane_util": round(stats[2] / max(1, 64 * stats[1]), 3), "model_probes_per_call": 2 * stats[3] / args.iters,
+                          "model_GBps": round(2 * stats[3] * 64 / (ms.value * 1e-3) / 1e9, 1), "avg_allowed_tokens_first8rows": allowed}), flush=True)
 
 
 if __name__ == "__main__":
