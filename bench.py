@@ -373,7 +373,7 @@ def main():
     check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(p2)))
     check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(l2), ctypes.byref(k2)))
 
-    alg_bytes = probes.value * 64.0    # the in-kernel counter counts the 64-byte sectors the rank probes touch
+    alg_bytes = probes.value * 128.0   # the in-kernel counter counts the distinct 128-byte blocks the rank probes load
     achieved = alg_bytes / (kms.value * 1e-3) / 1e9 if kms.value > 0 else 0.0
     # memory-side traffic comes from a SEPARATE rocprofv3 --pmc FETCH_SIZE pass of this same command
     # (profiles/README.md); per "launch" = per constraint call = the phase-1 + phase-2 kernel pair

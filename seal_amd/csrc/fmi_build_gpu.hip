@@ -4,7 +4,7 @@
 //                   64/L symbols, round r sorts (rank[i], rank[i+h]) composites,
 //                   all with rocPRIM's stable LSD radix sort (double buffered);
 //   BWT           : gather;
-//   wavelet matrix: per level, one wave per 448-bit block builds the 7 payload
+//   wavelet matrix: per level, one wave per 64-position block builds the 4 bit
 //                   words with __ballot, a device scan fills the block counters,
 //                   and the stable zero/one partition is a scatter whose
 //                   destination is the rank on the level just built;
@@ -134,50 +134,60 @@ __global__ void k_bwt(const SymT *text, const IdxT *sa, uint64_t n, SymT *bwt)
     GRID_STRIDE(j, n) { const uint64_t p = sa[j]; bwt[j] = text[p ? p - 1 : n - 1]; }
 }
 
-// one wave per 192-position block of one quad level: the two bit planes by ballot, the block's
-// digit counts (1, 2, 3) for the header scan, and -- parked in the header chunk until the scan is
-// done -- the counts of its first group
+// one wave per 64-position block of one level: the four bit planes by ballot; the counters are filled
+// in afterwards, one digit class at a time (k_class_count -> exclusive scan -> k_class_store)
 template <typename SymT>
-__global__ __launch_bounds__(256) void k_level_words(const SymT *cur, uint64_t n, uint32_t sh, uint64_t nblk, uint64_t *lvl,
-                                                     uint32_t *cnt1, uint32_t *cnt2, uint32_t *cnt3)
+__global__ __launch_bounds__(256) void k_level_planes(const SymT *cur, uint64_t n, uint32_t sh, uint64_t nblk, uint64_t *lvl)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t b = wave; b < nblk; b += nwaves) {
-        uint32_t nh = 0, nl = 0, nhl = 0;
-        for (uint32_t j = 0; j < 3; j++) {
-            if (j == 1 && lane == 0)
-                lvl[b * FMI_BLOCK_WORDS + 2] = (uint64_t)(nl - nhl) | ((uint64_t)(nh - nhl) << 16) | ((uint64_t)nhl << 32);
-            const uint64_t p = b * FMI_BLOCK_BITS + (uint64_t)j * 64 + lane;
-            const uint32_t d = p < n ? (uint32_t)(cur[p] >> sh) & 3u : 0u;
-            const uint64_t H = __ballot(d >> 1), Lw = __ballot(d & 1);
-            const uint32_t w = j == 0 ? 0 : 2 * j + 2;
-            if (lane == 0) { lvl[b * FMI_BLOCK_WORDS + w] = H; lvl[b * FMI_BLOCK_WORDS + w + 1] = Lw; }
-            nh += (uint32_t)__popcll(H); nl += (uint32_t)__popcll(Lw); nhl += (uint32_t)__popcll(H & Lw);
+        const uint64_t p = b * FMI_BLOCK_BITS + lane;
+        const uint32_t d = p < n ? (uint32_t)(cur[p] >> sh) & (FMI_ARITY - 1) : 0u;
+        const uint64_t P0 = __ballot(d & 1), P1 = __ballot(d & 2), P2 = __ballot(d & 4), P3 = __ballot(d & 8);
+        if (lane < 32) {      // the whole 128-byte block, coalesced: counters zero for now, planes at dwords 20..27
+            uint32_t v = 0;
+            const uint64_t P = lane < 22 ? P0 : (lane < 24 ? P1 : (lane < 26 ? P2 : P3));
+            if (lane >= 20 && lane < 28) v = (lane & 1) ? (uint32_t)(P >> 32) : (uint32_t)P;
+            reinterpret_cast<uint32_t *>(lvl + b * FMI_BLOCK_WORDS)[lane] = v;
         }
-        if (lane == 0) { cnt1[b] = nl - nhl; cnt2[b] = nh - nhl; cnt3[b] = nhl; }
     }
 }
 
-// header = digits before the block (exclusive scans) + digits of its first group
-__global__ void k_store_counts(const uint64_t *x1, const uint64_t *x2, const uint64_t *x3, uint64_t nblk, uint64_t *lvl)
+// occurrences of digit d inside each block
+__global__ void k_class_count(const uint64_t *lvl, uint64_t nblk, uint64_t n, uint32_t d, uint32_t *cnt)
 {
     GRID_STRIDE(b, nblk) {
-        const uint64_t part = lvl[b * FMI_BLOCK_WORDS + 2];
-        const uint64_t c1 = x1[b] + (part & 0xffff), c2 = x2[b] + ((part >> 16) & 0xffff), c3 = x3[b] + ((part >> 32) & 0xffff);
-        lvl[b * FMI_BLOCK_WORDS + 2] = c1 | (c2 << 40);
-        lvl[b * FMI_BLOCK_WORDS + 3] = (c2 >> 24) | (c3 << 16);
+        const uint64_t *P = lvl + b * FMI_BLOCK_WORDS + 10;
+        const uint64_t begin = b * FMI_BLOCK_BITS;
+        // positions past n carry digit 0 in the planes but are not part of the level
+        uint64_t m = begin >= n ? 0ull : (n - begin >= 64 ? ~0ull : ((1ull << (n - begin)) - 1));
+        m &= (d & 1) ? P[0] : ~P[0];
+        m &= (d & 2) ? P[1] : ~P[1];
+        m &= (d & 4) ? P[2] : ~P[2];
+        m &= (d & 8) ? P[3] : ~P[3];
+        cnt[b] = (uint32_t)__popcll(m);
+    }
+}
+
+// counter c_d of every block = digits equal to d before it
+__global__ void k_class_store(const uint64_t *excl, uint64_t nblk, uint32_t d, uint64_t *lvl)
+{
+    GRID_STRIDE(b, nblk) {
+        uint32_t *w = reinterpret_cast<uint32_t *>(lvl + b * FMI_BLOCK_WORDS);
+        const uint64_t c = excl[b];
+        w[d] = (uint32_t)c;
+        reinterpret_cast<uint8_t *>(w + 16)[d] = (uint8_t)(c >> 32);
     }
 }
 
 template <typename SymT>
-__global__ void k_partition(FmiDev ix, uint32_t q, const SymT *cur, SymT *nxt)
+__global__ void k_partition(FmiDev ix, uint32_t k, const SymT *cur, SymT *nxt)
 {
-    const uint32_t sh = 2 * (ix.qlevels - 1 - q);
     GRID_STRIDE(i, ix.n) {
         const SymT v = cur[i];
-        nxt[wm_step(ix, q, i, (uint32_t)(v >> sh) & 3u, nullptr)] = v;
+        nxt[wm_step(ix, k, i, wm_digit(ix, v, k))] = v;
     }
 }
 
@@ -218,40 +228,44 @@ int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64
     HIPCHK(pool.alloc(&cur, n)); HIPCHK(pool.alloc(&nxt, n));
     HIPCHK(hipMemcpyAsync(cur, bwt, n * sizeof(SymT), hipMemcpyDeviceToDevice, st));
     const uint64_t nblk = n / FMI_BLOCK_BITS + 2;
-    const uint32_t Q = (L + 1) / 2;
-    uint64_t *wm = nullptr, *excl[3] = {nullptr, nullptr, nullptr};
-    uint32_t *cnt[3] = {nullptr, nullptr, nullptr};
-    HIPCHK(pool.alloc(&wm, (uint64_t)Q * nblk * FMI_BLOCK_WORDS));
-    for (int e = 0; e < 3; e++) {
-        HIPCHK(pool.alloc(&excl[e], nblk + 1)); HIPCHK(pool.alloc(&cnt[e], nblk + 1));
-        HIPCHK(hipMemsetAsync(cnt[e] + nblk, 0, 4, st));
-    }
+    const uint32_t D = (L + FMI_DIGIT_BITS - 1) / FMI_DIGIT_BITS;
+    uint64_t *wm = nullptr, *excl = nullptr, *dbase_dev = nullptr;
+    uint32_t *cnt = nullptr;
+    HIPCHK(pool.alloc(&wm, (uint64_t)D * nblk * FMI_BLOCK_WORDS));
+    HIPCHK(pool.alloc(&excl, nblk + 1)); HIPCHK(pool.alloc(&cnt, nblk + 1));
+    HIPCHK(pool.alloc(&dbase_dev, (uint64_t)FMI_MAX_DLEVELS * FMI_ARITY));
+    HIPCHK(hipMemsetAsync(cnt + nblk, 0, 4, st));
     size_t xs_bytes = 0;
-    HIPCHK(rocprim::exclusive_scan(nullptr, xs_bytes, cnt[0], excl[0], (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
+    HIPCHK(rocprim::exclusive_scan(nullptr, xs_bytes, cnt, excl, (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
     void *xs_tmp = nullptr;
     HIPCHK(pool.alloc((char **)&xs_tmp, xs_bytes + 256));
     d = FmiDev{};
-    d.wm = wm; d.nblk = nblk; d.n = n; d.max_sym = max_sym; d.levels = L; d.qlevels = Q; d.sym_bytes = sizeof(SymT) == 2 ? 2 : 4;
-    std::vector<uint64_t> qbase((size_t)Q * 4, 0);
-    for (uint32_t q = 0; q < Q; q++) {
-        uint64_t *lvl = wm + (uint64_t)q * nblk * FMI_BLOCK_WORDS;
-        hipLaunchKernelGGL((k_level_words<SymT>), dim3((unsigned)std::min<uint64_t>((nblk + 3) / 4, 1u << 20)), dim3(256), 0, st,
-                           cur, n, 2 * (Q - 1 - q), nblk, lvl, cnt[0], cnt[1], cnt[2]);
-        uint64_t tot[3] = {0, 0, 0};
-        for (int e = 0; e < 3; e++) {
+    d.wm = wm; d.nblk = nblk; d.n = n; d.max_sym = max_sym; d.levels = L; d.dlevels = D; d.sym_bytes = sizeof(SymT) == 2 ? 2 : 4;
+    d.dbase_tab = dbase_dev;
+    std::vector<uint64_t> dbase((size_t)FMI_MAX_DLEVELS * FMI_ARITY, 0);
+    for (uint32_t k = 0; k < D; k++) {
+        uint64_t *lvl = wm + (uint64_t)k * nblk * FMI_BLOCK_WORDS;
+        hipLaunchKernelGGL((k_level_planes<SymT>), dim3((unsigned)std::min<uint64_t>((nblk + 3) / 4, 1u << 20)), dim3(256), 0, st,
+                           cur, n, FMI_DIGIT_BITS * (D - 1 - k), nblk, lvl);
+        uint64_t tot[FMI_ARITY];
+        for (uint32_t e = 0; e < FMI_ARITY; e++) {
+            hipLaunchKernelGGL(k_class_count, dim3(grid_for(nblk)), dim3(TB), 0, st, (const uint64_t *)lvl, nblk, n, e, cnt);
             size_t xb = xs_bytes;
-            HIPCHK(rocprim::exclusive_scan(xs_tmp, xb, cnt[e], excl[e], (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
-            HIPCHK(hipMemcpyAsync(&tot[e], excl[e] + nblk, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(rocprim::exclusive_scan(xs_tmp, xb, cnt, excl, (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
+            hipLaunchKernelGGL(k_class_store, dim3(grid_for(nblk)), dim3(TB), 0, st, (const uint64_t *)excl, nblk, e, lvl);
+            HIPCHK(hipMemcpyAsync(&tot[e], excl + nblk, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));   // tot[e] lands in pageable memory; excl / cnt are reused by the next class
         }
-        hipLaunchKernelGGL(k_store_counts, dim3(grid_for(nblk)), dim3(TB), 0, st, excl[0], excl[1], excl[2], nblk, lvl);
-        HIPCHK(hipStreamSynchronize(st));
-        const uint64_t n0 = n - tot[0] - tot[1] - tot[2];
-        uint64_t *qb = qbase.data() + (size_t)q * 4;
-        qb[0] = 0; qb[1] = n0; qb[2] = n0 + tot[0]; qb[3] = n0 + tot[0] + tot[1];
-        for (int e = 0; e < 4; e++) d.qbase[q][e] = qb[e];
-        hipLaunchKernelGGL((k_partition<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, d, q, cur, nxt);
+        uint64_t *db = dbase.data() + (size_t)k * FMI_ARITY;
+        db[0] = 0;
+        for (uint32_t e = 1; e < FMI_ARITY; e++) db[e] = db[e - 1] + tot[e - 1];
+        for (uint32_t e = 0; e < FMI_ARITY; e++) d.dbase[k][e] = db[e];
+        HIPCHK(hipMemcpyAsync(dbase_dev + (size_t)k * FMI_ARITY, db, FMI_ARITY * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL((k_partition<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, d, k, cur, nxt);
+        HIPCHK(hipStreamSynchronize(st));       // db is a host buffer
         std::swap(cur, nxt);
     }
+    dbase.resize((size_t)D * FMI_ARITY);
     HIPCHK(hipGetLastError());
 
     // ---- per-symbol tables --------------------------------------------------
@@ -269,8 +283,8 @@ int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64
     HIPCHK(hipMemcpyAsync(h_first.data(), first_pos, (max_sym + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
 
-    h->n = n; h->max_sym = max_sym; h->levels = L; h->qlevels = Q; h->nblk = nblk; h->sym_bytes = d.sym_bytes;
-    h->qbase = qbase;
+    h->n = n; h->max_sym = max_sym; h->levels = L; h->dlevels = D; h->nblk = nblk; h->sym_bytes = d.sym_bytes;
+    h->dbase = dbase;
     h->leaf = h_leaf;
     h->C.assign(max_sym + 2, 0);
     uint64_t sigma = 0;
@@ -289,8 +303,7 @@ int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64
     HIPCHK(hipMemcpy(dC, h->C.data(), (max_sym + 2) * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dq1, h->q1.data(), max_sym + 1, hipMemcpyHostToDevice));
 
-    pool.release(cur); pool.release(nxt); pool.release(xs_tmp);
-    for (int e = 0; e < 3; e++) { pool.release(excl[e]); pool.release(cnt[e]); }
+    pool.release(cur); pool.release(nxt); pool.release(xs_tmp); pool.release(excl); pool.release(cnt);
     pool.release(occ_end); pool.release(first_pos);
     *wm_out = wm; *dC_out = dC; *dleaf_out = dleaf; *dq1_out = dq1;
     return FMI_OK;
@@ -388,7 +401,7 @@ int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int 
         sa_lo_dev = (uint32_t *)sa;
     }
     if (keep_host) {
-        h->wm.resize((uint64_t)h->qlevels * nblk * FMI_BLOCK_WORDS);
+        h->wm.resize((uint64_t)h->dlevels * nblk * FMI_BLOCK_WORDS);
         HIPCHK(hipMemcpy(h->wm.data(), wm, h->wm.size() * 8, hipMemcpyDeviceToHost));
         h->sa_lo.resize(n);
         HIPCHK(hipMemcpy(h->sa_lo.data(), sa_lo_dev, n * 4, hipMemcpyDeviceToHost));
@@ -414,12 +427,12 @@ int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int 
     // hand the resident arrays over to the index
     d.C = dC; d.leaf = dleaf; d.q1 = dq1; d.sa_lo = sa_lo_dev; d.sa_hi = sa_hi_dev; d.text = text;
     d.doc_begin = nullptr; d.n_begin = 0;
-    for (void *p : {(void *)wm, (void *)dC, (void *)dleaf, (void *)dq1, (void *)sa_lo_dev, (void *)sa_hi_dev, (void *)text}) {
+    for (void *p : {(void *)wm, (void *)d.dbase_tab, (void *)dC, (void *)dleaf, (void *)dq1, (void *)sa_lo_dev, (void *)sa_hi_dev, (void *)text}) {
         if (!p) continue;
         pool.keep(p);
         h->dev_allocs.push_back(p);
     }
-    h->dev_bytes = (uint64_t)h->qlevels * nblk * FMI_BLOCK_BYTES + (max_sym + 2) * 8 + (max_sym + 1) * 9 + n * (WIDE ? 5 : 4) + n * sizeof(SymT);
+    h->dev_bytes = (uint64_t)h->dlevels * nblk * FMI_BLOCK_BYTES + (max_sym + 2) * 8 + (max_sym + 1) * 9 + n * (WIDE ? 5 : 4) + n * sizeof(SymT);
     h->device = device;
     h->dev = d;
     if (!h->doc_begin.empty()) {
@@ -443,8 +456,8 @@ static int bwt_only_impl(fmi *h, const void *d_bwt, uint64_t n, int device, uint
     h->wm.clear(); h->sa_lo.clear(); h->sa_hi.clear(); h->text.clear(); h->bwt.clear();
     h->host_resident = false;
     d.C = dC; d.leaf = dleaf; d.q1 = dq1; d.sa_lo = nullptr; d.sa_hi = nullptr; d.text = nullptr;
-    for (void *p : {(void *)wm, (void *)dC, (void *)dleaf, (void *)dq1}) { pool.keep(p); h->dev_allocs.push_back(p); }
-    h->dev_bytes = (uint64_t)h->qlevels * d.nblk * FMI_BLOCK_BYTES + (max_sym + 2) * 8 + (max_sym + 1) * 9;
+    for (void *p : {(void *)wm, (void *)d.dbase_tab, (void *)dC, (void *)dleaf, (void *)dq1}) { pool.keep(p); h->dev_allocs.push_back(p); }
+    h->dev_bytes = (uint64_t)h->dlevels * d.nblk * FMI_BLOCK_BYTES + (max_sym + 2) * 8 + (max_sym + 1) * 9;
     h->device = device;
     h->dev = d;
     return FMI_OK;

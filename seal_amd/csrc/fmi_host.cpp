@@ -202,7 +202,7 @@ void fmi_host_q1_from_first_pos(const std::vector<uint64_t> &first_pos, uint32_t
 }
 
 // ---------------------------------------------------------------------------
-// BWT -> quad wavelet matrix in the 64-byte block layout (fmi_internal.h) + per-symbol tables.
+// BWT -> hex wavelet matrix in the 128-byte block layout (fmi_internal.h) + per-symbol tables.
 // ---------------------------------------------------------------------------
 void fmi_host_finish_from_bwt(fmi *h, const uint32_t *bwt, uint64_t n)
 {
@@ -219,43 +219,37 @@ void fmi_host_finish_from_bwt(fmi *h, const uint32_t *bwt, uint64_t n)
     uint64_t sigma = 0;
     for (uint64_t c = 0; c <= max_sym; c++) { if (h->C[c + 1]) sigma++; h->C[c + 1] += h->C[c]; }
     h->sigma = sigma;
-    // quad levels
-    const uint32_t Q = (L + 1) / 2;
-    h->qlevels = Q;
+    // hex levels
+    const uint32_t D = (L + FMI_DIGIT_BITS - 1) / FMI_DIGIT_BITS;
+    h->dlevels = D;
     h->nblk = n / FMI_BLOCK_BITS + 2;
-    h->wm.assign((uint64_t)Q * h->nblk * FMI_BLOCK_WORDS, 0);
-    h->qbase.assign((size_t)Q * 4, 0);
+    h->wm.assign((uint64_t)D * h->nblk * FMI_BLOCK_WORDS, 0);
+    h->dbase.assign((size_t)D * FMI_ARITY, 0);
     std::vector<uint32_t> cur(bwt, bwt + n), nxt(n);
-    for (uint32_t q = 0; q < Q; q++) {
-        const uint32_t sh = 2 * (Q - 1 - q);
-        uint64_t *lvl = h->wm.data() + (uint64_t)q * h->nblk * FMI_BLOCK_WORDS;
-        uint64_t cnt[4] = {0, 0, 0, 0};   // digits seen so far
+    for (uint32_t k = 0; k < D; k++) {
+        const uint32_t sh = FMI_DIGIT_BITS * (D - 1 - k);
+        uint64_t *lvl = h->wm.data() + (uint64_t)k * h->nblk * FMI_BLOCK_WORDS;
+        uint64_t cnt[FMI_ARITY] = {0};   // digits seen so far
         for (uint64_t b = 0; b < h->nblk; b++) {
-            uint64_t *blk = lvl + b * FMI_BLOCK_WORDS;
-            const uint64_t base = b * FMI_BLOCK_BITS;
-            for (uint32_t j = 0; j < 3; j++) {
-                if (j == 1) {   // header: counts before the group-0 / group-1 boundary
-                    blk[2] = cnt[1] | (cnt[2] << 40);
-                    blk[3] = (cnt[2] >> 24) | (cnt[3] << 16);
-                }
-                uint64_t H = 0, Lw = 0;
-                const uint64_t p0 = base + (uint64_t)j * 64;
-                for (uint32_t bit = 0; bit < 64 && p0 + bit < n; bit++) {
-                    const uint32_t d = (cur[p0 + bit] >> sh) & 3;
-                    H |= (uint64_t)(d >> 1) << bit;
-                    Lw |= (uint64_t)(d & 1) << bit;
-                    cnt[d]++;
-                }
-                const uint32_t w = j == 0 ? 0 : 2 * j + 2;
-                blk[w] = H;
-                blk[w + 1] = Lw;
+            uint32_t *blk = reinterpret_cast<uint32_t *>(lvl + b * FMI_BLOCK_WORDS);
+            uint8_t *hi = reinterpret_cast<uint8_t *>(blk + 16);
+            for (uint32_t d = 0; d < FMI_ARITY; d++) { blk[d] = (uint32_t)cnt[d]; hi[d] = (uint8_t)(cnt[d] >> 32); }
+            uint64_t P[4] = {0, 0, 0, 0};
+            const uint64_t p0 = b * FMI_BLOCK_BITS;
+            for (uint32_t bit = 0; bit < 64 && p0 + bit < n; bit++) {
+                const uint32_t d = (cur[p0 + bit] >> sh) & (FMI_ARITY - 1);
+                for (uint32_t j = 0; j < 4; j++) P[j] |= (uint64_t)((d >> j) & 1) << bit;
+                cnt[d]++;
             }
+            memcpy(blk + 20, P, 32);
         }
-        uint64_t *qb = h->qbase.data() + (size_t)q * 4;
-        qb[0] = 0; qb[1] = cnt[0]; qb[2] = cnt[0] + cnt[1]; qb[3] = cnt[0] + cnt[1] + cnt[2];
-        // stable 4-way partition by digit
-        uint64_t o[4] = {qb[0], qb[1], qb[2], qb[3]};
-        for (uint64_t i = 0; i < n; i++) nxt[o[(cur[i] >> sh) & 3]++] = cur[i];
+        uint64_t *db = h->dbase.data() + (size_t)k * FMI_ARITY;
+        db[0] = 0;
+        for (uint32_t d = 1; d < FMI_ARITY; d++) db[d] = db[d - 1] + cnt[d - 1];
+        // stable 16-way partition by digit
+        uint64_t o[FMI_ARITY];
+        for (uint32_t d = 0; d < FMI_ARITY; d++) o[d] = db[d];
+        for (uint64_t i = 0; i < n; i++) nxt[o[(cur[i] >> sh) & (FMI_ARITY - 1)]++] = cur[i];
         cur.swap(nxt);
     }
     // after the last partition equal symbols are contiguous
@@ -397,12 +391,12 @@ int fmi_upload(fmi *h, int device)
     if (hipSetDevice(device) != hipSuccess) { fmi_set_error("hipSetDevice(%d) failed", device); return FMI_ERR_HIP; }
     h->device = device;
     FmiDev d{};
-    d.nblk = h->nblk; d.n = h->n; d.max_sym = h->max_sym; d.levels = h->levels; d.qlevels = h->qlevels; d.sym_bytes = h->sym_bytes;
-    for (uint32_t q = 0; q < h->qlevels; q++)
-        for (uint32_t e = 0; e < 4; e++) d.qbase[q][e] = h->qbase[(size_t)q * 4 + e];
+    d.nblk = h->nblk; d.n = h->n; d.max_sym = h->max_sym; d.levels = h->levels; d.dlevels = h->dlevels; d.sym_bytes = h->sym_bytes;
+    for (uint32_t k = 0; k < h->dlevels; k++)
+        for (uint32_t e = 0; e < FMI_ARITY; e++) d.dbase[k][e] = h->dbase[(size_t)k * FMI_ARITY + e];
     int rc;
     const uint8_t *text8 = nullptr;
-    if ((rc = up(h, h->wm, &d.wm)) || (rc = up(h, h->C, &d.C)) || (rc = up(h, h->leaf, &d.leaf)) ||
+    if ((rc = up(h, h->wm, &d.wm)) || (rc = up(h, h->dbase, &d.dbase_tab)) || (rc = up(h, h->C, &d.C)) || (rc = up(h, h->leaf, &d.leaf)) ||
         (rc = up(h, h->q1, &d.q1)) || (rc = up(h, h->sa_lo, &d.sa_lo)) || (rc = up(h, h->sa_hi, &d.sa_hi)) ||
         (rc = up(h, h->text, &text8)) || (rc = up(h, h->doc_begin, &d.doc_begin))) {
         fmi_release_device(h);
@@ -422,9 +416,10 @@ extern "C" int fmi_to_device(fmi_t *h, int device)
 
 // ---------------------------------------------------------------------------
 // on-disk format ".fmi" (little endian):
-//   char[8] "SEALFMI2"; u64 n, max_sym, sigma, nblk; u32 levels, sym_bytes;
+//   char[8] "SEALFMI3"; u64 n, max_sym, sigma, nblk; u32 levels, sym_bytes;
 //   u64 sa_wide(0/1); then arrays, each as u64 byte length + raw bytes, in the
-//   order qbase, C, leaf, q1, wm, sa_lo, sa_hi, text, bwt.  (SEALFMI1 was the binary, 64-byte-block layout.)
+//   order dbase, C, leaf, q1, wm, sa_lo, sa_hi, text, bwt.  (SEALFMI1 / 2 were the binary and 4-ary layouts of earlier
+//   development snapshots.)
 // ---------------------------------------------------------------------------
 template <class T>
 static bool wr(FILE *f, const std::vector<T> &v)
@@ -448,11 +443,11 @@ extern "C" int fmi_save(const fmi_t *h, const char *path)
     if (!h->host_resident) { fmi_set_error("fmi_save: index has no host copy (built on device without keep_host)"); return FMI_ERR_STATE; }
     FILE *f = fopen(path, "wb");
     if (!f) { fmi_set_error("cannot open %s for writing", path); return FMI_ERR_IO; }
-    bool ok = fwrite("SEALFMI2", 1, 8, f) == 8;
+    bool ok = fwrite("SEALFMI3", 1, 8, f) == 8;
     uint64_t hdr[4] = {h->n, h->max_sym, h->sigma, h->nblk};
     uint32_t hdr2[2] = {h->levels, h->sym_bytes};
     ok = ok && fwrite(hdr, 8, 4, f) == 4 && fwrite(hdr2, 4, 2, f) == 2;
-    ok = ok && wr(f, h->qbase) && wr(f, h->C) && wr(f, h->leaf) && wr(f, h->q1) && wr(f, h->wm) &&
+    ok = ok && wr(f, h->dbase) && wr(f, h->C) && wr(f, h->leaf) && wr(f, h->q1) && wr(f, h->wm) &&
          wr(f, h->sa_lo) && wr(f, h->sa_hi) && wr(f, h->text) && wr(f, h->bwt);
     fclose(f);
     if (!ok) { fmi_set_error("write error on %s", path); return FMI_ERR_IO; }
@@ -467,17 +462,17 @@ extern "C" int fmi_load(fmi_t **out, const char *path, int device)
     char magic[8];
     fmi *h = new fmi();
     uint64_t hdr[4]; uint32_t hdr2[2];
-    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "SEALFMI2", 8) == 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "SEALFMI3", 8) == 0;
     ok = ok && fread(hdr, 8, 4, f) == 4 && fread(hdr2, 4, 2, f) == 2;
     if (ok) { h->n = hdr[0]; h->max_sym = hdr[1]; h->sigma = hdr[2]; h->nblk = hdr[3]; h->levels = hdr2[0]; h->sym_bytes = hdr2[1]; }
-    ok = ok && rd(f, h->qbase) && rd(f, h->C) && rd(f, h->leaf) && rd(f, h->q1) && rd(f, h->wm) &&
+    ok = ok && rd(f, h->dbase) && rd(f, h->C) && rd(f, h->leaf) && rd(f, h->q1) && rd(f, h->wm) &&
          rd(f, h->sa_lo) && rd(f, h->sa_hi) && rd(f, h->text) && rd(f, h->bwt);
     fclose(f);
-    h->qlevels = (h->levels + 1) / 2;
-    if (!ok || h->levels == 0 || h->levels > FMI_MAX_LEVELS || h->qbase.size() != (size_t)h->qlevels * 4 ||
-        h->wm.size() != (uint64_t)h->qlevels * h->nblk * FMI_BLOCK_WORDS) {
+    h->dlevels = (h->levels + FMI_DIGIT_BITS - 1) / FMI_DIGIT_BITS;
+    if (!ok || h->levels == 0 || h->levels > FMI_MAX_LEVELS || h->dbase.size() != (size_t)h->dlevels * FMI_ARITY ||
+        h->wm.size() != (uint64_t)h->dlevels * h->nblk * FMI_BLOCK_WORDS) {
         delete h;
-        fmi_set_error("%s is not a SEALFMI2 index", path);
+        fmi_set_error("%s is not a SEALFMI3 index", path);
         return FMI_ERR_IO;
     }
     h->host_resident = true;
@@ -501,7 +496,7 @@ extern "C" const void *fmi_host_array(const fmi_t *h, const char *name, uint64_t
     if (s == "C") return ret(h->C.data(), h->C.size(), 8);
     if (s == "leaf") return ret(h->leaf.data(), h->leaf.size(), 8);
     if (s == "q1") return ret(h->q1.data(), h->q1.size(), 1);
-    if (s == "qbase") return ret(h->qbase.data(), h->qbase.size(), 8);
+    if (s == "dbase") return ret(h->dbase.data(), h->dbase.size(), 8);
     if (s == "wm") return ret(h->wm.data(), h->wm.size(), 8);
     return nullptr;
 }

@@ -7,36 +7,37 @@
 
 #include "../../include/sealfm.h"
 
-// The BWT is held as a 4-ary ("quad") wavelet matrix: quad level q stores, for every position of
-// the order reached after q stable 4-way partitions, the 2-bit digit (c >> 2*(qlevels-1-q)) & 3 of the
-// symbol sitting there.  One quad level = nblk blocks of 64 bytes (ONE memory sector) = 4 chunks of
-// 16 bytes; block b covers positions [192 b, 192 b + 192) in 3 groups of 64:
-//   chunk 0 : group 0      chunk 1 : header      chunk 2 : group 1      chunk 3 : group 2
-//   group chunk = { H, L }: bit i of H / L = high / low bit of the digit at position 64*group + i
-//   header      = c1, c2, c3 = digits equal to 1 / 2 / 3 in this level before position 192 b + 64
-//                 (the boundary between groups 0 and 1), 40 bits each:
-//                 w0 = c1 | c2 << 40 (low 24 bits of c2);  w1 = c2 >> 24 | c3 << 16
-// rank_d(p) counts from the header towards p: backwards through group 0 when p lies there, forwards
-// through groups 1..g otherwise -- the header plus one or two group chunks (2.33 of the 4 chunks on
-// average) of ONE 64-byte sector answer rank_d(p) for all four digits d, and one probe moves a
-// backward search or an interval-symbols node two symbol bits down.  Positions are < 2^40 (FMI_MAX_N).
-static constexpr uint32_t FMI_BLOCK_WORDS = 8;
-static constexpr uint32_t FMI_BLOCK_BYTES = 64;
-static constexpr uint32_t FMI_BLOCK_BITS = 192;  // positions per block
-static constexpr uint32_t FMI_BLOCK_MID = 64;    // header counts refer to this offset inside the block
+// The BWT is held as a 16-ary ("hex") wavelet matrix: level k stores, for every position of the
+// order reached after k stable 16-way partitions, the 4-bit digit (c >> 4*(dlevels-1-k)) & 15 of the
+// symbol sitting there.  One level = nblk blocks of 128 bytes (ONE L2 / HBM line) = 32 dwords; block
+// b covers the 64 positions [64 b, 64 b + 64):
+//   dword  d (d = 0..15)      : low 32 bits of c_d = digits equal to d in this level before position 64 b
+//   dwords 16..19, byte d     : bits 32..39 of c_d
+//   dwords 20..27 (4 x u64)   : bit planes P0..P3: bit i of P_j = bit j of the digit at position 64 b + i
+//   dwords 28..31             : zero
+// so ONE 128-byte line answers rank_d(p) for all sixteen digits d: one probe moves a backward search
+// or an interval-symbols node FOUR symbol bits down (BART's 16-bit alphabet = 4 dependent probes).
+// The structure costs 2 bytes per BWT symbol per level (8 n bytes at 4
+// levels): bytes are cheap in 288 GB of HBM, dependent random requests are not.  Positions are < 2^40.
+static constexpr uint32_t FMI_BLOCK_WORDS = 16;  // u64 words
+static constexpr uint32_t FMI_BLOCK_BYTES = 128;
+static constexpr uint32_t FMI_BLOCK_BITS = 64;   // positions per block
+static constexpr uint32_t FMI_DIGIT_BITS = 4;
+static constexpr uint32_t FMI_ARITY = 16;
 static constexpr uint32_t FMI_MAX_LEVELS = 17;   // symbols < 2^17 (BART: 50274 < 2^16); node prefixes fit 16 bits
-static constexpr uint32_t FMI_MAX_QLEVELS = (FMI_MAX_LEVELS + 1) / 2;
+static constexpr uint32_t FMI_MAX_DLEVELS = (FMI_MAX_LEVELS + FMI_DIGIT_BITS - 1) / FMI_DIGIT_BITS;   // 5
 static constexpr uint64_t FMI_MAX_N = 1ull << 40;
 
 struct FmiDev {
-    const uint64_t *wm;       // [qlevels][nblk][8]
+    const uint64_t *wm;       // [dlevels][nblk][16]
     uint64_t nblk;
     uint64_t n;               // text length incl. sentinel
     uint64_t max_sym;
     uint32_t levels;          // bits per symbol = sdsl's wt_int depth (bits::hi(max)+1); quirk table only
-    uint32_t qlevels;         // (levels + 1) / 2 quad levels
+    uint32_t dlevels;         // ceil(levels / 4) digit levels
     uint32_t sym_bytes;       // 2 or 4: width of text[]
-    uint64_t qbase[FMI_MAX_QLEVELS][4];  // [q][d] = positions of level q whose digit is < d (qbase[q][0] = 0)
+    uint64_t dbase[FMI_MAX_DLEVELS][FMI_ARITY];  // [k][d] = positions of level k whose digit is < d (dbase[k][0] = 0)
+    const uint64_t *dbase_tab; // the same table in HBM, for per-lane digits
     const uint64_t *C;        // [max_sym+2] number of symbols < c
     const uint64_t *leaf;     // [max_sym+1] start of c's run after the last level
     const uint8_t *q1;        // [max_sym+1] sdsl rank(size()+1, c) - occ(c)  (quirk Q1)
@@ -50,9 +51,9 @@ struct FmiDev {
 struct fmi {
     // geometry
     uint64_t n = 0, max_sym = 0, sigma = 0, nblk = 0;
-    uint32_t levels = 0, qlevels = 0, sym_bytes = 2;
+    uint32_t levels = 0, dlevels = 0, sym_bytes = 2;
     // host-resident arrays (empty when built on device without keep_host)
-    std::vector<uint64_t> wm, qbase /* [qlevels][4] */, C, leaf, doc_begin;
+    std::vector<uint64_t> wm, dbase /* [dlevels][16] */, C, leaf, doc_begin;
     std::vector<uint8_t> q1, sa_hi;
     std::vector<uint32_t> sa_lo;
     std::vector<uint32_t> bwt;   // kept for tests / hand-over only (not uploaded)
@@ -65,6 +66,7 @@ struct fmi {
     uint64_t dev_bytes = 0;
     // workspace for fmi_dev_* (sized by fmi_dev_reserve)
     uint64_t ws_rows = 0;
+    uint64_t ws_seq = 0;      // parity picks the queue-counter pair of the next fused constraint call
     void *ws = nullptr;
     uint64_t ws_bytes = 0;
     uint64_t *d_probe_counter = nullptr;

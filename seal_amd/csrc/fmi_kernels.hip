@@ -1,7 +1,7 @@
 // gfx950 (MI355X / CDNA4) kernels of libsealfm.so and the C-ABI query entry points.
 //
 // All work here is HBM-latency/bandwidth bound integer work: dependent 128-byte
-// gathers into a 4-ary wavelet matrix (one 128-B line per rank probe, two symbol
+// gathers into a 16-ary wavelet matrix (one 128-B line per rank probe, four symbol
 // bits per probe), 5-byte gathers into the suffix array, binary searches over
 // doc boundaries.  No MFMA.
 // Wave size is 64 throughout.
@@ -101,14 +101,14 @@ __global__ void k_get_range(FmiDev ix, uint64_t n_seq, const OffT *offsets, cons
 
 // ---------------------------------------------------------------------------
 // K2: interval -> distinct symbols (+counts)   (sdsl interval_symbols as used by
-// fm_index.cpp:78-109).  One wavefront per work item (a quad-wavelet-matrix node
-// [lo, hi) at some quad level with its symbol prefix).  The wave keeps its
-// frontier in LDS as one small array per relative level (a level-j array can
-// never hold more than min(4^j, 256) nodes: it is only refilled, by at most 64
-// parents, when it and every deeper level are empty), pops up to 64 nodes of
-// the deepest non-empty level, loads the one or two 128-byte blocks of each node
-// in parallel lanes (one when both ends of the interval share a block) and
-// compacts the up to four surviving children per node with ballot + popcount.
+// fm_index.cpp:78-109).  One wavefront per work item (a hex-wavelet-matrix node
+// [lo, hi) at some level with its symbol prefix).  The wave keeps its frontier
+// in LDS as one small array per relative level (a level-j array can never hold
+// more than min(16^j, 1024) nodes: it is only refilled, by at most 64 parents,
+// when it and every deeper level are empty), pops up to 64 nodes of the deepest
+// non-empty level, loads the one or two 128-byte blocks of each node in
+// parallel lanes (one when both ends of the interval share a block) and
+// compacts the up to sixteen surviving children per node with ballot + popcount.
 // ---------------------------------------------------------------------------
 struct ExpandItem {
     uint64_t lo, hi;
@@ -137,13 +137,13 @@ __device__ __forceinline__ void wave_sync()
 
 static constexpr uint32_t PROBE_SLOTS = 256;         // counter slots (measurement mode only), one 64-byte line each
 static constexpr int EXP_WAVES = 4;                 // waves per workgroup
-static constexpr int EXP_LVL_CAP = 256;
-static constexpr uint32_t EXP_SPLIT_LEVEL = 2;      // phase 1 hands the sub-trees over to phase 2 at this quad level (<= 16 per row; r1: 2 beats 3 and 4)
+static constexpr int EXP_LVL_CAP = 1024;
+static constexpr uint32_t EXP_SPLIT_LEVEL = 1;      // phase 1 hands the sub-trees over to phase 2 at this level (<= 16 per row)
 static constexpr unsigned EXP_P2_BLOCKS = 1024;     // phase-2 grid cap = 4 workgroups per CU; waves loop over the queue
-// relative level j occupies [lvl_off(j), lvl_off(j) + min(4^j, 256))
-__host__ __device__ constexpr int lvl_cap(int j) { return j < 4 ? (1 << (2 * j)) : EXP_LVL_CAP; }
-__host__ __device__ constexpr int lvl_off(int j) { return j <= 4 ? ((1 << (2 * j)) - 1) / 3 : 85 + (j - 4) * EXP_LVL_CAP; }
-// LDS slots a wave needs to expand a sub-tree spanning `nlev` stored quad levels
+// relative level j occupies [lvl_off(j), lvl_off(j) + min(16^j, 1024))
+__host__ __device__ constexpr int lvl_cap(int j) { return j < 3 ? (1 << (4 * j)) : EXP_LVL_CAP; }
+__host__ __device__ constexpr int lvl_off(int j) { return j <= 3 ? ((1 << (4 * j)) - 1) / 15 : 273 + (j - 3) * EXP_LVL_CAP; }
+// LDS slots a wave needs to expand a sub-tree spanning `nlev` stored levels
 __host__ __device__ constexpr int exp_slots(int nlev) { return nlev <= 0 ? 1 : lvl_off(nlev - 1) + lvl_cap(nlev - 1); }
 
 template <int MODE>
@@ -158,51 +158,137 @@ __device__ __forceinline__ void emit_leaf(const EmitTarget &t, uint32_t row, uin
     }
 }
 
-// Work items are quad-wavelet-matrix nodes.  Nodes whose children would sit on
+// The (up to) sixteen leaves below one last-level node are sixteen consecutive symbols, i.e. sixteen
+// consecutive bits of the row's token bitmap: one or two atomicOr per node instead of one per symbol
+// (the bitmap atomics, not the rank probes, were the largest cost of the leaf level before).
+__device__ __forceinline__ void emit_leaf_group_bits(const EmitTarget &t, uint32_t row, uint32_t prefix, uint32_t em)
+{
+    uint32_t mask = em;
+    if (prefix == 0) mask &= ~1u;                       // symbol 0 is the sentinel, never a token
+    int64_t t0 = (int64_t)((uint64_t)prefix << FMI_DIGIT_BITS) - t.shift;   // token of child 0
+    if (t0 < 0) { mask = (-t0 >= 16) ? 0u : (mask >> (uint32_t)(-t0)); t0 = 0; }
+    const int64_t room = (int64_t)t.vocab - t0;         // tokens t0 .. vocab-1 exist
+    if (room <= 0) mask = 0; else if (room < 16) mask &= (1u << (uint32_t)room) - 1;
+    if (!mask) return;
+    const uint64_t big = (uint64_t)mask << ((uint32_t)t0 & 31);
+    uint32_t *w = &t.bits[(uint64_t)row * t.words_per_row + ((uint64_t)t0 >> 5)];
+    if ((uint32_t)big) atomicOr(w, (uint32_t)big);
+    if ((uint32_t)(big >> 32)) atomicOr(w + 1, (uint32_t)(big >> 32));
+}
+
+// rank of every digit at both ends of a node [lo, hi) on level k: child d is
+// [dbase[k][d] + rl[d], dbase[k][d] + rh[d]) on level k+1.  Returns the mask of children that exist.
+__device__ __forceinline__ uint32_t node_ranks(const FmiDev &ix, uint32_t k, uint64_t lo, uint64_t hi, uint64_t (&rl)[16],
+                                               uint64_t (&rh)[16], uint64_t &probes)
+{
+    const uint64_t blo = lo >> 6, bhi = hi >> 6;
+    HBlock a, b;
+    wm_load_block(ix, k, blo, a);
+    if (bhi != blo) wm_load_block(ix, k, bhi, b); else b = a;
+    wm_block_ranks(a, (uint32_t)(lo & 63), rl);
+    wm_block_ranks(b, (uint32_t)(hi & 63), rh);
+    probes += bhi != blo ? 2 : 1;
+    uint32_t em = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < 16; d++) em |= (uint32_t)(rh[d] > rl[d]) << d;
+    return em;
+}
+
+// the same node in the BINARY level-per-bit model of SURVEY.md 8(d): itself plus its non-empty halves,
+// quarters and pairs of children; the phantom high bits of the top digit (level 0) have no level
+__device__ __forceinline__ uint32_t model_nodes(uint32_t em, uint32_t k, uint32_t pad_bits)
+{
+    const uint32_t g2 = (em | (em >> 1)) & 0x5555u, g4 = (g2 | (g2 >> 2)) & 0x1111u, g8 = (g4 | (g4 >> 4)) & 0x0101u;
+    const uint32_t skip = k == 0 ? pad_bits : 0;
+    return (skip < 1 ? 1u : 0u) + (skip < 2 ? (uint32_t)__popc(g8) : 0u) + (skip < 3 ? (uint32_t)__popc(g4) : 0u) + (uint32_t)__popc(g2);
+}
+
+// wave-wide compaction of the existing children: slot of child d of this lane = base + before[d] + rank of the lane in bal[d]
+struct Fanout {
+    uint64_t bal[16];
+    uint32_t before[16], added;
+};
+__device__ __forceinline__ void fanout_of(uint32_t em, Fanout &f)
+{
+    f.added = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < 16; d++) {
+        f.bal[d] = __ballot((em >> d) & 1);
+        f.before[d] = f.added;
+        f.added += (uint32_t)__popcll(f.bal[d]);
+    }
+}
+__device__ __forceinline__ uint32_t fanout_slot(const Fanout &f, uint32_t d)
+{
+    return f.before[d] + __builtin_amdgcn_mbcnt_hi((uint32_t)(f.bal[d] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)f.bal[d], 0));
+}
+
+// append the children of this wave's nodes (level k, wave-uniform) to the phase-2 queue; all lanes call
+__device__ __forceinline__ void hand_over(const FmiDev &ix, uint32_t k, uint32_t row, uint32_t prefix, uint32_t em,
+                                          const uint64_t (&rl)[16], const uint64_t (&rh)[16], ExpandItem *out_items,
+                                          uint32_t *out_count, uint32_t out_cap)
+{
+    Fanout f;
+    fanout_of(em, f);
+    uint32_t obase = 0;
+    if ((threadIdx.x & 63) == 0 && f.added) obase = atomicAdd(out_count, f.added);
+    obase = __shfl(obase, 0);
+#pragma unroll
+    for (uint32_t d = 0; d < 16; d++)
+        if ((em >> d) & 1) {
+            const uint32_t o = obase + fanout_slot(f, d);
+            const uint64_t db = ix.dbase[k][d];
+            if (o < out_cap) out_items[o] = ExpandItem{db + rl[d], db + rh[d], row, k + 1, (prefix << 4) | d, 0};
+        }
+}
+
+__device__ __forceinline__ void flush_counters(uint64_t *probe_counter, uint64_t probes, uint32_t model, uint32_t iters, uint32_t nodes)
+{
+    // one 64-byte line per slot: thousands of waves adding to ONE address cost tens of microseconds
+    unsigned long long *slot = (unsigned long long *)probe_counter + (size_t)(blockIdx.x & (PROBE_SLOTS - 1)) * 8;
+    if (probes) atomicAdd(slot, (unsigned long long)probes);
+    if (model) atomicAdd(slot + 3, (unsigned long long)model);
+    if ((threadIdx.x & 63) == 0 && iters) {
+        atomicAdd(slot + 1, (unsigned long long)iters);
+        atomicAdd(slot + 2, (unsigned long long)nodes);
+    }
+}
+
+// Work items are hex-wavelet-matrix nodes.  Nodes whose children would sit on
 // `stop_level` are not expanded further but appended to `out_items` (phase 1 ->
-// phase 2 hand-over, so that a wide interval is spread over up to 4^stop_level
-// wavefronts instead of one); stop_level >= qlevels disables the hand-over.
+// phase 2 hand-over, so that a wide interval is spread over up to 16^stop_level
+// wavefronts instead of one); stop_level >= dlevels disables the hand-over.
 // Dynamic LDS per wave: 3 x slots words (lo32, hi32, packed high bits + prefix)
-// + FMI_MAX_QLEVELS counters.
+// + FMI_MAX_DLEVELS counters.
 template <int MODE>
 __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const ExpandItem *items, const uint32_t *n_items_ptr,
                                                            uint32_t n_items_static, EmitTarget tgt, uint32_t slots,
                                                            uint32_t stop_level, ExpandItem *out_items, uint32_t *out_count,
-                                                           uint32_t out_cap, uint32_t *ticket, uint64_t *probe_counter)
+                                                           uint32_t out_cap, uint64_t *probe_counter)
 {
     extern __shared__ uint32_t s_mem[];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = threadIdx.x >> 6;
-    uint32_t *s_lo = s_mem + (size_t)wv * (3 * slots + FMI_MAX_QLEVELS);
+    uint32_t *s_lo = s_mem + (size_t)wv * (3 * slots + FMI_MAX_DLEVELS);
     uint32_t *s_hi = s_lo + slots;
     uint32_t *s_mx = s_hi + slots;     // lo[39:32] | hi[39:32]<<8 | prefix<<16 (prefix <= 16 bits)
     uint32_t *s_cnt = s_mx + slots;
     const uint32_t n_items = n_items_ptr ? min(*n_items_ptr, n_items_static) : n_items_static;
-    const uint32_t Q = ix.qlevels;
-    const uint64_t lt = (1ull << lane) - 1;
+    const uint32_t D = ix.dlevels;
+    const uint32_t pad_bits = FMI_DIGIT_BITS * D - ix.levels;   // phantom high bits of the top digit (0..3)
     uint64_t probes = 0;
     uint32_t iters = 0, nodes = 0, model = 0;
 
-    // phase 2: the first item of a wave is its own slot; further ones are drawn from a ticket counter
-    // (sub-trees differ in size by orders of magnitude, a static stride leaves most waves idle behind
-    // the few that drew dense ones).  Tickets for the first round too would serialise 4096 atomics
-    // on one address at kernel start (measured: +40 us per launch).
-    bool first = true;
-    for (uint32_t item = blockIdx.x * EXP_WAVES + wv;; item += gridDim.x * EXP_WAVES) {
-        if (ticket && !first) {
-            uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(ticket, 1u);
-            item = gridDim.x * EXP_WAVES + __shfl(t, 0);
-        }
-        first = false;
-        if (item >= n_items) break;
+    for (uint32_t item = blockIdx.x * EXP_WAVES + wv; item < n_items; item += gridDim.x * EXP_WAVES) {
         const ExpandItem it = items[item];
         if (it.hi <= it.lo) continue;
         const uint32_t row = it.row;
-        const uint32_t root = it.level;
+        // wave-uniform by construction; say so, or every dbase[k][d] becomes a per-lane global load
+        // in the middle of the fan-out instead of a scalar load
+        const uint32_t root = __builtin_amdgcn_readfirstlane(it.level);
         // a root sitting below the last level is already a leaf
-        if (root >= Q) { if (lane == 0) emit_leaf<MODE>(tgt, row, it.prefix, it.hi - it.lo); continue; }
-        if (lane < FMI_MAX_QLEVELS) s_cnt[lane] = 0;
+        if (root >= D) { if (lane == 0) emit_leaf<MODE>(tgt, row, it.prefix, it.hi - it.lo); continue; }
+        if (lane < FMI_MAX_DLEVELS) s_cnt[lane] = 0;
         if (lane == 0) {
             s_lo[0] = (uint32_t)it.lo; s_hi[0] = (uint32_t)it.hi;
             // positions < 2^40: 8 high bits each
@@ -212,11 +298,13 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
         wave_sync();
         int deepest = 0;   // relative level of the deepest non-empty array (wave uniform)
         while (deepest >= 0) {
-            const uint32_t cnt = s_cnt[deepest];
+            // LDS hands the counter back in a VGPR; it is the same in every lane, and the whole loop
+            // (level, offsets, the per-level dbase[] loads) stays scalar only if the compiler knows
+            const uint32_t cnt = __builtin_amdgcn_readfirstlane(s_cnt[deepest]);
             if (cnt == 0) { deepest--; continue; }
             const uint32_t m = cnt < 64 ? cnt : 64;
             const uint32_t base = lvl_off(deepest) + (cnt - m);
-            const uint32_t k = root + deepest;      // absolute quad level of the popped nodes
+            const uint32_t k = root + deepest;      // absolute level of the popped nodes
             const bool act = lane < m;
             uint64_t lo = 0, hi = 0; uint32_t prefix = 0;
             if (act) {
@@ -227,68 +315,45 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
             }
             wave_sync();
             if (lane == 0) s_cnt[deepest] = cnt - m;
-            // child d of the node = [clo[d], chi[d]) on level k+1
-            uint64_t clo[4] = {0, 0, 0, 0}, chi[4] = {0, 0, 0, 0};
+            uint64_t rl[16], rh[16];
+            uint32_t em = 0;                        // children that exist
             if (act) {
-                probes += wm_children(ix, k, lo, hi, clo, chi);
-                // the same node in the BINARY 16-level model of SURVEY.md 8(d): itself (level 2k) plus its
-                // non-empty halves (level 2k+1); with an odd bit count quad level 0 has no level of its own
-                const uint32_t halves = (uint32_t)((chi[0] > clo[0]) | (chi[1] > clo[1])) + (uint32_t)((chi[2] > clo[2]) | (chi[3] > clo[3]));
-                model += (k == 0 && (ix.levels & 1)) ? halves : 1 + halves;
+                em = node_ranks(ix, k, lo, hi, rl, rh, probes);
+                model += model_nodes(em, k, pad_bits);
             }
             iters++; nodes += m;
-            if (k + 1 == Q) {
-#pragma unroll
-                for (uint32_t d = 0; d < 4; d++)
-                    if (chi[d] > clo[d]) emit_leaf<MODE>(tgt, row, (prefix << 2) | d, chi[d] - clo[d]);
-            } else {
-                uint64_t bal[4];
-                uint32_t before[4], added = 0;
-#pragma unroll
-                for (uint32_t d = 0; d < 4; d++) {
-                    bal[d] = __ballot(chi[d] > clo[d]);
-                    before[d] = added;
-                    added += (uint32_t)__popcll(bal[d]);
-                }
-                if (k + 1 == stop_level) {
-                    // hand the children over to phase 2
-                    uint32_t obase = 0;
-                    if (lane == 0 && added) obase = atomicAdd(out_count, added);
-                    obase = __shfl(obase, 0);
-#pragma unroll
-                    for (uint32_t d = 0; d < 4; d++)
-                        if (chi[d] > clo[d]) {
-                            const uint32_t o = obase + before[d] + (uint32_t)__popcll(bal[d] & lt);
-                            if (o < out_cap) out_items[o] = ExpandItem{clo[d], chi[d], row, k + 1, (prefix << 2) | d, 0};
-                        }
+            if (k + 1 == D) {
+                if (MODE == EMIT_BITS) {
+                    if (em) emit_leaf_group_bits(tgt, row, prefix, em);
                 } else {
-                    const uint32_t dst = lvl_off(deepest + 1) + s_cnt[deepest + 1];
 #pragma unroll
-                    for (uint32_t d = 0; d < 4; d++)
-                        if (chi[d] > clo[d]) {
-                            const uint32_t o = dst + before[d] + (uint32_t)__popcll(bal[d] & lt);
-                            s_lo[o] = (uint32_t)clo[d]; s_hi[o] = (uint32_t)chi[d];
-                            s_mx[o] = (uint32_t)(clo[d] >> 32) | ((uint32_t)(chi[d] >> 32) << 8) | (((prefix << 2) | d) << 16);
-                        }
-                    wave_sync();
-                    if (lane == 0) s_cnt[deepest + 1] += added;
-                    wave_sync();
-                    if (added) deepest++;
+                    for (uint32_t d = 0; d < 16; d++)
+                        if ((em >> d) & 1) emit_leaf<MODE>(tgt, row, (prefix << 4) | d, rh[d] - rl[d]);
                 }
+            } else if (k + 1 == stop_level) {
+                hand_over(ix, k, row, prefix, em, rl, rh, out_items, out_count, out_cap);
+            } else {
+                Fanout f;
+                fanout_of(em, f);
+                const uint32_t dst = lvl_off(deepest + 1) + __builtin_amdgcn_readfirstlane(s_cnt[deepest + 1]);
+#pragma unroll
+                for (uint32_t d = 0; d < 16; d++)
+                    if ((em >> d) & 1) {
+                        const uint32_t o = dst + fanout_slot(f, d);
+                        const uint64_t db = ix.dbase[k][d];
+                        const uint64_t clo = db + rl[d], chi = db + rh[d];
+                        s_lo[o] = (uint32_t)clo; s_hi[o] = (uint32_t)chi;
+                        s_mx[o] = (uint32_t)(clo >> 32) | ((uint32_t)(chi >> 32) << 8) | (((prefix << 4) | d) << 16);
+                    }
+                wave_sync();
+                if (lane == 0) s_cnt[deepest + 1] += f.added;
+                wave_sync();
+                if (f.added) deepest++;
             }
         }
         wave_sync();
     }
-    if (probe_counter) {
-        // one 64-byte line per slot: thousands of waves adding to ONE address cost tens of microseconds
-        unsigned long long *slot = (unsigned long long *)probe_counter + (size_t)(blockIdx.x & (PROBE_SLOTS - 1)) * 8;
-        if (probes) atomicAdd(slot, (unsigned long long)probes);
-        if (model) atomicAdd(slot + 3, (unsigned long long)model);
-        if (lane == 0 && iters) {
-            atomicAdd(slot + 1, (unsigned long long)iters);
-            atomicAdd(slot + 2, (unsigned long long)nodes);
-        }
-    }
+    if (probe_counter) flush_counters(probe_counter, probes, model, iters, nodes);
 }
 
 // dense per-row symbol counts -> CSR, ascending symbols.  One workgroup per row.
@@ -341,37 +406,59 @@ struct ForceFrom { int64_t tok[MAX_FORCE]; uint32_t n; };
 
 // one thread per (batch, beam) row: ranges of the prefix, the row's class, and
 // the work item for the expansion.  Lines 87-105 and the branch order of 111-131.
-__global__ void k_prefix_ranges(FmiDev ix, uint64_t rows, uint64_t cur_len, const int64_t *ids, int64_t shift,
+// With a queue (`out_items`) the same lane also expands the root node of its row
+// (level 0) and hands the level-1 children straight to phase 2: the narrow steps of
+// a decode are launch-latency bound, and this saves them a kernel.  `zero_next`
+// (two words) is cleared for the NEXT call, whose counters alternate with this one's.
+__global__ __launch_bounds__(64) void k_prefix_ranges(FmiDev ix, uint64_t rows, uint64_t cur_len, const int64_t *ids, int64_t shift,
                                 int64_t pad_id, int64_t eos_id, ForceFrom ff, int64_t stop_at_count,
                                 int always_allow_eos, uint64_t vocab, uint64_t words_per_row,
-                                uint32_t *bits, ExpandItem *items)
+                                uint32_t *bits, ExpandItem *items, ExpandItem *out_items, uint32_t *out_count,
+                                uint32_t out_cap, uint32_t *zero_next, uint64_t *probe_counter)
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const int64_t *sent = ids + r * cur_len;
-    const int64_t last = sent[cur_len - 1];
-    uint64_t lo = 0, hi = 0, count = 0;
-    if (!(last == eos_id || last == pad_id)) {
-        // get_range(force_decoding_from + sent[1:]) and get_count(... sent[1:-1])
-        uint64_t l = 0, rr = ix.n;
-        const uint64_t total = ff.n + (cur_len - 1);
-        for (uint64_t t = 0; t < total; t++) {
-            if (t + 1 == total) count = (rr + 1) - l;
-            const int64_t tok = t < ff.n ? ff.tok[t] : sent[1 + (t - ff.n)];
-            bs_step(ix, (uint64_t)(tok + shift), l, rr, l, rr, nullptr);
-        }
-        if (total == 0) count = (rr + 1) - l;
-        lo = l; hi = rr + 1;
-    }
-    uint32_t *myrow = bits + r * words_per_row;
-    int64_t single = -1;
+    const bool valid = r < rows;
+    if (zero_next && r == 0) { zero_next[0] = 0; zero_next[1] = 0; }
     ExpandItem it{0, 0, (uint32_t)r, 0, 0, 0};
-    if (stop_at_count > 0 && (int64_t)count <= stop_at_count) single = eos_id;
-    else if (last == eos_id || last == pad_id) single = pad_id;
-    else { it.lo = lo; it.hi = hi > ix.n ? ix.n : hi; }
-    items[r] = it;
-    if (single >= 0 && (uint64_t)single < vocab) atomicOr(&myrow[single >> 5], 1u << (single & 31));
-    if (always_allow_eos && eos_id >= 0 && (uint64_t)eos_id < vocab) atomicOr(&myrow[eos_id >> 5], 1u << (eos_id & 31));
+    uint64_t probes = 0;
+    uint32_t model = 0;      // in nodes of the binary model: one backward-search step = `levels` nodes (2 L probes)
+    if (valid) {
+        const int64_t *sent = ids + r * cur_len;
+        const int64_t last = sent[cur_len - 1];
+        uint64_t lo = 0, hi = 0, count = 0;
+        if (!(last == eos_id || last == pad_id)) {
+            // get_range(force_decoding_from + sent[1:]) and get_count(... sent[1:-1])
+            uint64_t l = 0, rr = ix.n;
+            const uint64_t total = ff.n + (cur_len - 1);
+            for (uint64_t t = 0; t < total; t++) {
+                if (t + 1 == total) count = (rr + 1) - l;
+                const int64_t tok = t < ff.n ? ff.tok[t] : sent[1 + (t - ff.n)];
+                bs_step(ix, (uint64_t)(tok + shift), l, rr, l, rr, &probes);
+                model += ix.levels;
+            }
+            if (total == 0) count = (rr + 1) - l;
+            lo = l; hi = rr + 1;
+        }
+        uint32_t *myrow = bits + r * words_per_row;
+        int64_t single = -1;
+        if (stop_at_count > 0 && (int64_t)count <= stop_at_count) single = eos_id;
+        else if (last == eos_id || last == pad_id) single = pad_id;
+        else { it.lo = lo; it.hi = hi > ix.n ? ix.n : hi; }
+        if (!out_items) items[r] = it;
+        if (single >= 0 && (uint64_t)single < vocab) atomicOr(&myrow[single >> 5], 1u << (single & 31));
+        if (always_allow_eos && eos_id >= 0 && (uint64_t)eos_id < vocab) atomicOr(&myrow[eos_id >> 5], 1u << (eos_id & 31));
+    }
+    if (!out_items) return;
+    // root expansion, the level-0 step of k_expand
+    uint64_t rl[16], rh[16];
+    uint32_t em = 0;
+    const bool act = valid && it.hi > it.lo;
+    if (act) {
+        em = node_ranks(ix, 0, it.lo, it.hi, rl, rh, probes);
+        model += model_nodes(em, 0, FMI_DIGIT_BITS * ix.dlevels - ix.levels);
+    }
+    hand_over(ix, 0, (uint32_t)r, 0, em, rl, rh, out_items, out_count, out_cap);
+    if (probe_counter) flush_counters(probe_counter, probes, model, __ballot(act) ? 1u : 0u, (uint32_t)__popcll(__ballot(act)));
 }
 
 // out = allowed ? in : -inf     (scores + mask with mask in {0, -inf}, beam_search.py:64,140)
@@ -767,8 +854,8 @@ extern "C" int fmi_dev_get_range(fmi_t *h, void *stream, uint64_t n_seq, const i
 
 // workspace = expansion items + allowed-token bitmap (vocab <= 2^17 -> 4096 words/row)
 static constexpr uint64_t WS_BITS_WORDS = (1ull << FMI_MAX_LEVELS) / 32;
-static constexpr uint32_t EXP_SPLIT_MAX = 5;                                   // quad levels
-static constexpr uint64_t WS_QUEUE_PER_ROW = 1ull << (2 * EXP_SPLIT_MAX);     // room for any split level up to EXP_SPLIT_MAX
+static constexpr uint32_t EXP_SPLIT_MAX = 2;                                   // hex levels
+static constexpr uint64_t WS_QUEUE_PER_ROW = 1ull << (4 * EXP_SPLIT_MAX);     // room for any split level up to EXP_SPLIT_MAX
 // layout: items[rows] | queue[rows * WS_QUEUE_PER_ROW] | bits[rows * WS_BITS_WORDS] | counter
 static inline ExpandItem *ws_items(fmi *h) { return (ExpandItem *)h->ws; }
 static inline ExpandItem *ws_queue(fmi *h) { return ws_items(h) + h->ws_rows; }
@@ -782,6 +869,8 @@ extern "C" int fmi_dev_reserve(fmi_t *h, uint64_t max_rows)
     const uint64_t bytes = max_rows * (sizeof(ExpandItem) * (1 + WS_QUEUE_PER_ROW) + WS_BITS_WORDS * 4) + 256;
     HIPCHK(hipMalloc(&h->ws, bytes));
     h->ws_bytes = bytes; h->ws_rows = max_rows;
+    HIPCHK(hipMemset(ws_qcount(h), 0, 64));   // [0..1] / [2..3]: alternating queue counters of the fused path, [4]: generic path
+    h->ws_seq = 0;
     return FMI_OK;
 }
 
@@ -828,7 +917,7 @@ extern "C" const void *fmi_dev_array(const fmi_t *h, const char *name, uint64_t 
     if (s == "sa_lo") return ret(d.sa_lo, d.n, 4);
     if (s == "sa_hi") return ret(d.sa_hi, d.sa_hi ? d.n : 0, 1);
     if (s == "text") return ret(d.text, d.n, d.sym_bytes);
-    if (s == "wm") return ret(d.wm, (uint64_t)d.qlevels * d.nblk * FMI_BLOCK_WORDS, 8);
+    if (s == "wm") return ret(d.wm, (uint64_t)d.dlevels * d.nblk * FMI_BLOCK_WORDS, 8);
     if (s == "C") return ret(d.C, d.max_sym + 2, 8);
     if (s == "leaf") return ret(d.leaf, d.max_sym + 1, 8);
     if (s == "q1") return ret(d.q1, d.max_sym + 1, 1);
@@ -842,36 +931,50 @@ static unsigned expand_grid(uint64_t n_items)
     return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(g, 256ull * 16));
 }
 
-static size_t expand_lds_bytes(int nlev) { return (size_t)EXP_WAVES * (3 * (size_t)exp_slots(nlev) + FMI_MAX_QLEVELS) * 4; }
+static size_t expand_lds_bytes(int nlev) { return (size_t)EXP_WAVES * (3 * (size_t)exp_slots(nlev) + FMI_MAX_DLEVELS) * 4; }
 
-// Expansion of `rows` root intervals (items[0..rows), quad level 0) in two launches:
-//   phase 1: one wave per row walks quad levels [0, split) and appends the surviving
-//            level-`split` nodes (<= 4^split per row) to the queue behind the roots;
+// Expansion of `rows` root intervals (items[0..rows), level 0) in two launches:
+//   phase 1: one wave per row walks levels [0, split) and appends the surviving
+//            level-`split` nodes (<= 16^split per row) to the queue behind the roots;
 //   phase 2: one wave per queued node finishes its sub-tree.
-// The queue (rows << 2*split entries) and its counter live in the workspace.
+// The queue (rows << 4*split entries) and its counter live in the workspace.
+static uint32_t expand_split(const fmi *h, uint64_t rows, const void *queue, uint64_t qcap)
+{
+    const uint32_t Q = h->dlevels;
+    static const char *e_split = getenv("SEALFM_SPLIT");   // tuning knob
+    const uint32_t want = e_split ? std::min<uint32_t>((uint32_t)atoi(e_split), EXP_SPLIT_MAX) : EXP_SPLIT_LEVEL;
+    return (want > 0 && Q > want + 1 && queue && qcap >= (rows << (4 * want))) ? want : Q;   // shallow trees: single phase
+}
+
+template <int MODE>
+static int launch_phase2(fmi *h, hipStream_t st, uint32_t split, const ExpandItem *queue, const uint32_t *qcount, uint64_t qcap,
+                         const EmitTarget &tgt)
+{
+    const uint32_t Q = h->dlevels;
+    uint64_t *pc = h->probe_count_enabled ? h->d_probe_counter : nullptr;
+    const int nlev2 = (int)(Q - split);
+    static const char *e_p2 = getenv("SEALFM_P2_BLOCKS");
+    const unsigned p2_blocks = e_p2 ? (unsigned)atoi(e_p2) : EXP_P2_BLOCKS;
+    hipLaunchKernelGGL((k_expand<MODE>), dim3(std::min(expand_grid(qcap), p2_blocks)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev2), st, h->dev,
+                       queue, qcount, (uint32_t)qcap, tgt, (uint32_t)exp_slots(nlev2), Q, (ExpandItem *)nullptr, (uint32_t *)nullptr, 0u, pc);
+    HIPCHK(hipGetLastError());
+    return FMI_OK;
+}
+
 template <int MODE>
 static int launch_expand(fmi *h, hipStream_t st, ExpandItem *items, uint64_t rows, ExpandItem *queue, uint32_t *qcount,
                          uint64_t qcap, const EmitTarget &tgt)
 {
-    const uint32_t Q = h->qlevels;
+    const uint32_t Q = h->dlevels;
     uint64_t *pc = h->probe_count_enabled ? h->d_probe_counter : nullptr;
-    static const char *e_split = getenv("SEALFM_SPLIT");   // tuning knob
-    const uint32_t want = e_split ? std::min<uint32_t>((uint32_t)atoi(e_split), EXP_SPLIT_MAX) : EXP_SPLIT_LEVEL;
-    const uint32_t split = (want > 0 && Q > want + 1 && queue && qcap >= (rows << (2 * want))) ? want : Q;   // shallow trees: single phase
-    if (split < Q) HIPCHK(hipMemsetAsync(qcount, 0, 8, st));   // [0] queue length, [1] phase-2 ticket
+    const uint32_t split = expand_split(h, rows, queue, qcap);
+    if (split < Q) HIPCHK(hipMemsetAsync(qcount, 0, 4, st));
     const int nlev1 = (int)split;
     hipLaunchKernelGGL((k_expand<MODE>), dim3(expand_grid(rows)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev1), st, h->dev,
                        (const ExpandItem *)items, (const uint32_t *)nullptr, (uint32_t)rows, tgt, (uint32_t)exp_slots(nlev1),
-                       split, queue, qcount, (uint32_t)qcap, (uint32_t *)nullptr, pc);
-    if (split < Q) {
-        const int nlev2 = (int)(Q - split);
-        static const char *e_p2 = getenv("SEALFM_P2_BLOCKS");
-        const unsigned p2_blocks = e_p2 ? (unsigned)atoi(e_p2) : EXP_P2_BLOCKS;
-        hipLaunchKernelGGL((k_expand<MODE>), dim3(std::min(expand_grid(qcap), p2_blocks)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev2), st, h->dev,
-                           (const ExpandItem *)queue, (const uint32_t *)qcount, (uint32_t)qcap, tgt, (uint32_t)exp_slots(nlev2),
-                           Q, (ExpandItem *)nullptr, (uint32_t *)nullptr, 0u, qcount + 1, pc);
-    }
+                       split, queue, qcount, (uint32_t)qcap, pc);
     HIPCHK(hipGetLastError());
+    if (split < Q) return launch_phase2<MODE>(h, st, split, queue, qcount, qcap, tgt);
     return FMI_OK;
 }
 
@@ -886,13 +989,32 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     ForceFrom ff{}; ff.n = (uint32_t)n_force;
     for (uint64_t i = 0; i < n_force; i++) ff.tok[i] = force_from[i];
     ExpandItem *items = ws_items(h);
-    HIPCHK(hipMemsetAsync(d_bits, 0, rows * wpr * 4, st));
-    hipLaunchKernelGGL(k_prefix_ranges, dim3(blocks_for(rows, 64)), dim3(64), 0, st, h->dev, rows, cur_len, d_ids, shift,
-                       pad_id, eos_id, ff, stop_at_count, always_allow_eos, vocab, wpr, d_bits, items);
+    const uint64_t qcap = h->ws_rows * WS_QUEUE_PER_ROW;
+    uint64_t *pc = h->probe_count_enabled ? h->d_probe_counter : nullptr;
     EmitTarget tgt{}; tgt.bits = d_bits; tgt.words_per_row = wpr; tgt.shift = shift; tgt.vocab = vocab;
     const bool timed = h->timing_enabled && h->ev_used < MAX_TIMED_LAUNCHES;
+    HIPCHK(hipMemsetAsync(d_bits, 0, rows * wpr * 4, st));
+    // the usual case (root hand-over at level 1): the prefix kernel expands the roots itself and the
+    // queue counters alternate between calls, each call clearing the other pair -- two launches per
+    // constraint step (prefix + phase 2), no memset, no phase-1 kernel.  The timed region covers both,
+    // i.e. the backward searches of the prefix are inside it.
+    if (expand_split(h, rows, ws_queue(h), qcap) == 1) {
+        uint32_t *cur = ws_qcount(h) + 2 * (h->ws_seq & 1), *nxt = ws_qcount(h) + 2 * ((h->ws_seq + 1) & 1);
+        h->ws_seq++;
+        if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
+        hipLaunchKernelGGL(k_prefix_ranges, dim3(blocks_for(rows, 64)), dim3(64), 0, st, h->dev, rows, cur_len, d_ids, shift,
+                           pad_id, eos_id, ff, stop_at_count, always_allow_eos, vocab, wpr, d_bits, items, ws_queue(h), cur,
+                           (uint32_t)qcap, nxt, pc);
+        int rc = launch_phase2<EMIT_BITS>(h, st, 1, ws_queue(h), cur, qcap, tgt);
+        if (rc) return rc;
+        if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
+        return FMI_OK;
+    }
+    hipLaunchKernelGGL(k_prefix_ranges, dim3(blocks_for(rows, 64)), dim3(64), 0, st, h->dev, rows, cur_len, d_ids, shift,
+                       pad_id, eos_id, ff, stop_at_count, always_allow_eos, vocab, wpr, d_bits, items, (ExpandItem *)nullptr,
+                       (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, (uint64_t *)nullptr);
     if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
-    int rc = launch_expand<EMIT_BITS>(h, st, items, rows, ws_queue(h), ws_qcount(h), h->ws_rows * WS_QUEUE_PER_ROW, tgt);
+    int rc = launch_expand<EMIT_BITS>(h, st, items, rows, ws_queue(h), ws_qcount(h) + 4, qcap, tgt);
     if (rc) return rc;
     if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
     return FMI_OK;

@@ -191,7 +191,7 @@ def test_gpu_builder_is_byte_identical_to_host_builder(seed, n_docs, vocab, wide
         buf = (ctypes.c_uint8 * (n.value * e.value)).from_address(p)
         return bytes(buf)
 
-    for name in ("sa", "bwt", "text", "C", "leaf", "q1", "qbase", "wm"):
+    for name in ("sa", "bwt", "text", "C", "leaf", "q1", "dbase", "wm"):
         assert arr(a, name) == arr(b, name), name
     assert b.size() == a.size() and b.occurring_distinct == a.occurring_distinct and b.occurring_counts == a.occurring_counts
     assert sorted(b.occurring) == sorted(a.occurring)

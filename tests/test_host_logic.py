@@ -46,26 +46,20 @@ def _arr(h, name):
     return np.frombuffer(buf, dtype=dt).copy()
 
 
-def _wm_digit_ranks(wm, nblk, q, p):
-    """Python restatement of the documented 64-byte block layout: digits equal to
-    0 / 1 / 2 / 3 in quad level q before position p."""
-    blk, within = divmod(p, 192)
-    base = (q * nblk + blk) * 8
-
-    def digit(i):   # digit at offset i of the block: group 0 | header | group 1 | group 2
-        g, bit = divmod(i, 64)
-        w = 0 if g == 0 else 2 * g + 2
-        return ((int(wm[base + w]) >> bit) & 1) << 1 | ((int(wm[base + w + 1]) >> bit) & 1)
-
-    w0, w1 = int(wm[base + 2]), int(wm[base + 3])
-    cnt = [0, w0 & ((1 << 40) - 1), (w0 >> 40) | ((w1 & 0xFFFF) << 24), w1 >> 16]   # before offset 64
-    if within < 64:
-        for i in range(within, 64):
-            cnt[digit(i)] -= 1
-    else:
-        for i in range(64, within):
-            cnt[digit(i)] += 1
-    cnt[0] = p - cnt[1] - cnt[2] - cnt[3]
+def _wm_digit_ranks(wm, nblk, k, p):
+    """Python restatement of the documented 128-byte block layout: digits equal to
+    0 .. 15 in level k before position p."""
+    blk, within = divmod(p, 64)
+    base = (k * nblk + blk) * 16                      # u64 words
+    dwords = []
+    for w in wm[base:base + 16]:
+        dwords += [int(w) & 0xFFFFFFFF, int(w) >> 32]
+    hi = b"".join(int(x).to_bytes(4, "little") for x in dwords[16:20])
+    cnt = [dwords[d] | (hi[d] << 32) for d in range(16)]
+    planes = [dwords[20 + 2 * j] | (dwords[21 + 2 * j] << 32) for j in range(4)]
+    assert dwords[28:32] == [0, 0, 0, 0]
+    for i in range(within):
+        cnt[sum(((planes[j] >> i) & 1) << j for j in range(4))] += 1
     return cnt
 
 
@@ -97,19 +91,19 @@ def test_host_builder_matches_brute_force(seed, n, vocab):
         for c in set(text):
             assert C[c] == sum(1 for x in text if x < c)
         assert lib().fmi_sigma(h) == len(set(text))
-        wm, qbase, leaf = _arr(h, "wm"), _arr(h, "qbase"), _arr(h, "leaf")
-        Q = (L + 1) // 2
-        assert len(qbase) == 4 * Q
-        nblk = len(wm) // (8 * Q)
-        assert nblk == N // 192 + 2
-        # rank_c(i) through the quad wavelet matrix == naive count
+        wm, dbase, leaf = _arr(h, "wm"), _arr(h, "dbase"), _arr(h, "leaf")
+        D = (L + 3) // 4
+        assert len(dbase) == 16 * D
+        nblk = len(wm) // (16 * D)
+        assert nblk == N // 64 + 2
+        # rank_c(i) through the hex wavelet matrix == naive count
         for _ in range(300):
             c = rng.choice(text)
             i = rng.randrange(0, N + 1)
             p = i
-            for q in range(Q):
-                d = (c >> (2 * (Q - 1 - q))) & 3
-                p = int(qbase[4 * q + d]) + _wm_digit_ranks(wm, nblk, q, p)[d]
+            for k in range(D):
+                d = (c >> (4 * (D - 1 - k))) & 15
+                p = int(dbase[16 * k + d]) + _wm_digit_ranks(wm, nblk, k, p)[d]
             assert p - int(leaf[c]) == bwt[:i].count(c)
         # quirk table == what the faithful sdsl-layout oracle computes for rank(size()+1, c)
         orc = CppFMIndex()
@@ -152,7 +146,7 @@ def test_save_load_round_trip(tmp_path):
     h2 = ctypes.c_void_p()
     check(lib().fmi_load(ctypes.byref(h2), path, -1))
     try:
-        for name in ("sa", "bwt", "text", "C", "leaf", "q1", "qbase", "wm"):
+        for name in ("sa", "bwt", "text", "C", "leaf", "q1", "dbase", "wm"):
             assert np.array_equal(_arr(h, name), _arr(h2, name)), name
         assert lib().fmi_size(h2) == 1001 and lib().fmi_levels(h2) == lib().fmi_levels(h)
     finally:

@@ -5,7 +5,7 @@ rows are decoder prefixes drawn from the corpus itself.
 
   python tools/expand_bench.py --docs 21015324 --rows 300 --prefix-len 1 --iters 20
 
-prints one JSON line: probes, algorithmic bytes (64 B per sector touched by a rank probe), HIP-event time,
+prints one JSON line: probes, algorithmic bytes (128 B per block probed), HIP-event time,
 GB/s and fraction of the 8 TB/s HBM peak.  Run it under
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python tools/expand_bench.py ...
 for the memory-side traffic of the same launches."""
@@ -100,10 +100,10 @@ def main():
             check(lib().fmi_dev_read_probe_count(h, ctypes.byref(probes)))
         check(lib().fmi_dev_read_timing(h, ctypes.byref(launches), ctypes.byref(ms)))
         allowed = int(sum(bin(x & 0xFFFFFFFF).count("1") for x in bits[:8].flatten().tolist())) / 8.0
-        gbs = probes.value * 64 / (ms.value * 1e-3) / 1e9
+        gbs = probes.value * 128 / (ms.value * 1e-3) / 1e9
         print(json.dumps({"docs": args.docs, "n": index.size(), "rows": args.rows, "prefix_len": pl,
-                          "iters": args.iters, "sectors_per_call": probes.value / args.iters,
-                          "alg_MB_per_call": round(probes.value * 64 / args.iters / 1e6, 2),
+                          "iters": args.iters, "blocks_per_call": probes.value / args.iters,
+                          "alg_MB_per_call": round(probes.value * 128 / args.iters / 1e6, 2),
                           "us_per_call": round(ms.value * 1e3 / args.iters, 2), "GBps": round(gbs, 1),
                           "frac_of_8TBps": round(gbs / 8000, 4), "wave_iters_per_call": stats[1] / args.iters,
                           "lane_util": round(stats[2] / max(1, 64 * stats[1]), 3), "model_probes_per_call": 2 * stats[3] / args.iters,

@@ -62,6 +62,15 @@ int main(int argc, char **argv)
     if (hipMalloc(&buf, max_gib << 30) != hipSuccess) { printf("alloc failed\n"); return 1; }
     hipMalloc(&sink, 4);
     hipMemset(buf, 1, max_gib << 30);
+    if (argc > 2) {      // fine sweep of the TLB-reach knee: working sets in units of 256 MiB, 128-byte granules only
+        for (uint64_t q : {1, 2, 4, 6, 8, 12, 16, 24, 32, 48, 64, 128}) {
+            if ((q << 28) > (max_gib << 30)) break;
+            printf("-- working set %.2f GiB\n", q / 4.0);
+            run<128, 0>(buf, q << 28, 4096, 64, sink);
+            run<64, 0>(buf, q << 28, 4096, 64, sink);
+        }
+        return 0;
+    }
     for (uint64_t gib = 1; gib <= max_gib; gib *= 2) {     // working-set sweep (TLB reach)
         if (gib != 1 && gib != 8 && gib != max_gib) continue;
         printf("-- working set %llu GiB\n", (unsigned long long)gib);
