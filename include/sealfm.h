@@ -108,7 +108,7 @@ uint64_t fmi_device_bytes(const fmi_t *h);
 
 /* Host-side view of a built array, for tests of the host logic and for
  * hand-over to other tools.  name in {"sa","bwt","text","C","leaf","q1",
- * "dbase","wm"}; returns element count via *n_out and element size in bytes
+ * "dbase","sbase","wm"}; returns element count via *n_out and element size in bytes
  * via *elem_out; pointer stays owned by the index.  NULL if not host-resident. */
 const void *fmi_host_array(const fmi_t *h, const char *name, uint64_t *n_out, uint32_t *elem_out);
 

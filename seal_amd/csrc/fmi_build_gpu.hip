@@ -4,7 +4,7 @@
 //                   64/L symbols, round r sorts (rank[i], rank[i+h]) composites,
 //                   all with rocPRIM's stable LSD radix sort (double buffered);
 //   BWT           : gather;
-//   wavelet matrix: per level, one wave per 64-position block builds the 4 bit
+//   wavelet matrix: per level, one wave per 128-position block builds the 4 bit
 //                   words with __ballot, a device scan fills the block counters,
 //                   and the stable zero/one partition is a scatter whose
 //                   destination is the rank on the level just built;
@@ -134,8 +134,9 @@ __global__ void k_bwt(const SymT *text, const IdxT *sa, uint64_t n, SymT *bwt)
     GRID_STRIDE(j, n) { const uint64_t p = sa[j]; bwt[j] = text[p ? p - 1 : n - 1]; }
 }
 
-// one wave per 64-position block of one level: the four bit planes by ballot; the counters are filled
-// in afterwards, one digit class at a time (k_class_count -> exclusive scan -> k_class_store)
+// one wave per 128-position block of one level: the four bit planes by ballot (two halves); the
+// counters are filled in afterwards, one digit class at a time (k_class_count -> exclusive scan ->
+// k_class_store)
 template <typename SymT>
 __global__ __launch_bounds__(256) void k_level_planes(const SymT *cur, uint64_t n, uint32_t sh, uint64_t nblk, uint64_t *lvl)
 {
@@ -143,13 +144,19 @@ __global__ __launch_bounds__(256) void k_level_planes(const SymT *cur, uint64_t 
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t b = wave; b < nblk; b += nwaves) {
-        const uint64_t p = b * FMI_BLOCK_BITS + lane;
-        const uint32_t d = p < n ? (uint32_t)(cur[p] >> sh) & (FMI_ARITY - 1) : 0u;
-        const uint64_t P0 = __ballot(d & 1), P1 = __ballot(d & 2), P2 = __ballot(d & 4), P3 = __ballot(d & 8);
-        if (lane < 32) {      // the whole 128-byte block, coalesced: counters zero for now, planes at dwords 20..27
+        uint64_t P[4][2];
+        for (uint32_t half = 0; half < 2; half++) {
+            const uint64_t p = b * FMI_BLOCK_BITS + 64 * half + lane;
+            const uint32_t d = p < n ? (uint32_t)(cur[p] >> sh) & (FMI_ARITY - 1) : 0u;
+            P[0][half] = __ballot(d & 1); P[1][half] = __ballot(d & 2); P[2][half] = __ballot(d & 4); P[3][half] = __ballot(d & 8);
+        }
+        if (lane < 32) {      // the whole 128-byte block, coalesced: counters zero for now, planes at dwords 16..31
             uint32_t v = 0;
-            const uint64_t P = lane < 22 ? P0 : (lane < 24 ? P1 : (lane < 26 ? P2 : P3));
-            if (lane >= 20 && lane < 28) v = (lane & 1) ? (uint32_t)(P >> 32) : (uint32_t)P;
+            if (lane >= 16) {
+                const uint32_t j = (lane - 16) >> 2, w = lane & 3;
+                const uint64_t q = j == 0 ? P[0][w >> 1] : (j == 1 ? P[1][w >> 1] : (j == 2 ? P[2][w >> 1] : P[3][w >> 1]));
+                v = (w & 1) ? (uint32_t)(q >> 32) : (uint32_t)q;
+            }
             reinterpret_cast<uint32_t *>(lvl + b * FMI_BLOCK_WORDS)[lane] = v;
         }
     }
@@ -159,27 +166,37 @@ __global__ __launch_bounds__(256) void k_level_planes(const SymT *cur, uint64_t 
 __global__ void k_class_count(const uint64_t *lvl, uint64_t nblk, uint64_t n, uint32_t d, uint32_t *cnt)
 {
     GRID_STRIDE(b, nblk) {
-        const uint64_t *P = lvl + b * FMI_BLOCK_WORDS + 10;
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(lvl + b * FMI_BLOCK_WORDS);
         const uint64_t begin = b * FMI_BLOCK_BITS;
         // positions past n carry digit 0 in the planes but are not part of the level
-        uint64_t m = begin >= n ? 0ull : (n - begin >= 64 ? ~0ull : ((1ull << (n - begin)) - 1));
-        m &= (d & 1) ? P[0] : ~P[0];
-        m &= (d & 2) ? P[1] : ~P[1];
-        m &= (d & 4) ? P[2] : ~P[2];
-        m &= (d & 8) ? P[3] : ~P[3];
-        cnt[b] = (uint32_t)__popcll(m);
+        const uint32_t valid = begin >= n ? 0u : (n - begin >= FMI_BLOCK_BITS ? FMI_BLOCK_BITS : (uint32_t)(n - begin));
+        uint32_t c = 0;
+        for (uint32_t x = 0; x < 4; x++) {
+            uint32_t m = valid >= 32 * (x + 1) ? ~0u : (valid <= 32 * x ? 0u : ((1u << (valid - 32 * x)) - 1));
+            m &= (d & 1) ? w[16 + x] : ~w[16 + x];
+            m &= (d & 2) ? w[20 + x] : ~w[20 + x];
+            m &= (d & 4) ? w[24 + x] : ~w[24 + x];
+            m &= (d & 8) ? w[28 + x] : ~w[28 + x];
+            c += (uint32_t)__popc(m);
+        }
+        cnt[b] = c;
     }
 }
 
-// counter c_d of every block = digits equal to d before it
-__global__ void k_class_store(const uint64_t *excl, uint64_t nblk, uint32_t d, uint64_t *lvl)
+// counter of digit d of every block (relative to its superblock) and the superblock rows
+__global__ void k_class_store(const uint64_t *excl, uint64_t nblk, uint32_t d, uint32_t sb_shift, uint64_t *lvl, uint64_t *sb_rows)
 {
     GRID_STRIDE(b, nblk) {
-        uint32_t *w = reinterpret_cast<uint32_t *>(lvl + b * FMI_BLOCK_WORDS);
-        const uint64_t c = excl[b];
-        w[d] = (uint32_t)c;
-        reinterpret_cast<uint8_t *>(w + 16)[d] = (uint8_t)(c >> 32);
+        const uint64_t s = b >> sb_shift, first = s << sb_shift;
+        reinterpret_cast<uint32_t *>(lvl + b * FMI_BLOCK_WORDS)[d] = (uint32_t)(excl[b] - excl[first]);
+        if (b == first) sb_rows[s * FMI_ARITY + d] = excl[b];
     }
+}
+
+// sbase rows += dbase[k][d]
+__global__ void k_add_dbase(uint64_t *sb_rows, uint64_t nsb, const uint64_t *db)
+{
+    GRID_STRIDE(i, nsb * FMI_ARITY) sb_rows[i] += db[i & (FMI_ARITY - 1)];
 }
 
 template <typename SymT>
@@ -229,11 +246,13 @@ int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64
     HIPCHK(hipMemcpyAsync(cur, bwt, n * sizeof(SymT), hipMemcpyDeviceToDevice, st));
     const uint64_t nblk = n / FMI_BLOCK_BITS + 2;
     const uint32_t D = (L + FMI_DIGIT_BITS - 1) / FMI_DIGIT_BITS;
-    uint64_t *wm = nullptr, *excl = nullptr, *dbase_dev = nullptr;
+    const uint32_t sb_shift = fmi_sb_shift_for(n);
+    const uint64_t nsb = (nblk >> sb_shift) + 1;
+    uint64_t *wm = nullptr, *excl = nullptr, *sbase_dev = nullptr, *db_dev = nullptr;
     uint32_t *cnt = nullptr;
     HIPCHK(pool.alloc(&wm, (uint64_t)D * nblk * FMI_BLOCK_WORDS));
     HIPCHK(pool.alloc(&excl, nblk + 1)); HIPCHK(pool.alloc(&cnt, nblk + 1));
-    HIPCHK(pool.alloc(&dbase_dev, (uint64_t)FMI_MAX_DLEVELS * FMI_ARITY));
+    HIPCHK(pool.alloc(&sbase_dev, (uint64_t)D * nsb * FMI_ARITY)); HIPCHK(pool.alloc(&db_dev, (uint64_t)FMI_ARITY));
     HIPCHK(hipMemsetAsync(cnt + nblk, 0, 4, st));
     size_t xs_bytes = 0;
     HIPCHK(rocprim::exclusive_scan(nullptr, xs_bytes, cnt, excl, (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
@@ -241,10 +260,11 @@ int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64
     HIPCHK(pool.alloc((char **)&xs_tmp, xs_bytes + 256));
     d = FmiDev{};
     d.wm = wm; d.nblk = nblk; d.n = n; d.max_sym = max_sym; d.levels = L; d.dlevels = D; d.sym_bytes = sizeof(SymT) == 2 ? 2 : 4;
-    d.dbase_tab = dbase_dev;
-    std::vector<uint64_t> dbase((size_t)FMI_MAX_DLEVELS * FMI_ARITY, 0);
+    d.sbase = sbase_dev; d.nsb = nsb; d.sb_shift = sb_shift;
+    std::vector<uint64_t> dbase((size_t)D * FMI_ARITY, 0);
     for (uint32_t k = 0; k < D; k++) {
         uint64_t *lvl = wm + (uint64_t)k * nblk * FMI_BLOCK_WORDS;
+        uint64_t *sb_rows = sbase_dev + (uint64_t)k * nsb * FMI_ARITY;
         hipLaunchKernelGGL((k_level_planes<SymT>), dim3((unsigned)std::min<uint64_t>((nblk + 3) / 4, 1u << 20)), dim3(256), 0, st,
                            cur, n, FMI_DIGIT_BITS * (D - 1 - k), nblk, lvl);
         uint64_t tot[FMI_ARITY];
@@ -252,7 +272,7 @@ int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64
             hipLaunchKernelGGL(k_class_count, dim3(grid_for(nblk)), dim3(TB), 0, st, (const uint64_t *)lvl, nblk, n, e, cnt);
             size_t xb = xs_bytes;
             HIPCHK(rocprim::exclusive_scan(xs_tmp, xb, cnt, excl, (uint64_t)0, nblk + 1, rocprim::plus<uint64_t>(), st));
-            hipLaunchKernelGGL(k_class_store, dim3(grid_for(nblk)), dim3(TB), 0, st, (const uint64_t *)excl, nblk, e, lvl);
+            hipLaunchKernelGGL(k_class_store, dim3(grid_for(nblk)), dim3(TB), 0, st, (const uint64_t *)excl, nblk, e, sb_shift, lvl, sb_rows);
             HIPCHK(hipMemcpyAsync(&tot[e], excl + nblk, 8, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));   // tot[e] lands in pageable memory; excl / cnt are reused by the next class
         }
@@ -260,12 +280,12 @@ int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64
         db[0] = 0;
         for (uint32_t e = 1; e < FMI_ARITY; e++) db[e] = db[e - 1] + tot[e - 1];
         for (uint32_t e = 0; e < FMI_ARITY; e++) d.dbase[k][e] = db[e];
-        HIPCHK(hipMemcpyAsync(dbase_dev + (size_t)k * FMI_ARITY, db, FMI_ARITY * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(db_dev, db, FMI_ARITY * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_add_dbase, dim3(grid_for(nsb * FMI_ARITY)), dim3(TB), 0, st, sb_rows, nsb, (const uint64_t *)db_dev);
         hipLaunchKernelGGL((k_partition<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, d, k, cur, nxt);
         HIPCHK(hipStreamSynchronize(st));       // db is a host buffer
         std::swap(cur, nxt);
     }
-    dbase.resize((size_t)D * FMI_ARITY);
     HIPCHK(hipGetLastError());
 
     // ---- per-symbol tables --------------------------------------------------
@@ -285,6 +305,9 @@ int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64
 
     h->n = n; h->max_sym = max_sym; h->levels = L; h->dlevels = D; h->nblk = nblk; h->sym_bytes = d.sym_bytes;
     h->dbase = dbase;
+    h->sb_shift = sb_shift; h->nsb = nsb;
+    h->sbase.resize((size_t)D * nsb * FMI_ARITY);
+    HIPCHK(hipMemcpy(h->sbase.data(), sbase_dev, h->sbase.size() * 8, hipMemcpyDeviceToHost));
     h->leaf = h_leaf;
     h->C.assign(max_sym + 2, 0);
     uint64_t sigma = 0;
@@ -303,7 +326,7 @@ int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64
     HIPCHK(hipMemcpy(dC, h->C.data(), (max_sym + 2) * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dq1, h->q1.data(), max_sym + 1, hipMemcpyHostToDevice));
 
-    pool.release(cur); pool.release(nxt); pool.release(xs_tmp); pool.release(excl); pool.release(cnt);
+    pool.release(cur); pool.release(nxt); pool.release(xs_tmp); pool.release(excl); pool.release(cnt); pool.release(db_dev);
     pool.release(occ_end); pool.release(first_pos);
     *wm_out = wm; *dC_out = dC; *dleaf_out = dleaf; *dq1_out = dq1;
     return FMI_OK;
@@ -427,12 +450,12 @@ int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int 
     // hand the resident arrays over to the index
     d.C = dC; d.leaf = dleaf; d.q1 = dq1; d.sa_lo = sa_lo_dev; d.sa_hi = sa_hi_dev; d.text = text;
     d.doc_begin = nullptr; d.n_begin = 0;
-    for (void *p : {(void *)wm, (void *)d.dbase_tab, (void *)dC, (void *)dleaf, (void *)dq1, (void *)sa_lo_dev, (void *)sa_hi_dev, (void *)text}) {
+    for (void *p : {(void *)wm, (void *)d.sbase, (void *)dC, (void *)dleaf, (void *)dq1, (void *)sa_lo_dev, (void *)sa_hi_dev, (void *)text}) {
         if (!p) continue;
         pool.keep(p);
         h->dev_allocs.push_back(p);
     }
-    h->dev_bytes = (uint64_t)h->dlevels * nblk * FMI_BLOCK_BYTES + (max_sym + 2) * 8 + (max_sym + 1) * 9 + n * (WIDE ? 5 : 4) + n * sizeof(SymT);
+    h->dev_bytes = (uint64_t)h->dlevels * nblk * FMI_BLOCK_BYTES + (max_sym + 2) * 8 + (max_sym + 1) * 9 + (uint64_t)h->dlevels * d.nsb * FMI_ARITY * 8 + n * (WIDE ? 5 : 4) + n * sizeof(SymT);
     h->device = device;
     h->dev = d;
     if (!h->doc_begin.empty()) {
@@ -456,7 +479,7 @@ static int bwt_only_impl(fmi *h, const void *d_bwt, uint64_t n, int device, uint
     h->wm.clear(); h->sa_lo.clear(); h->sa_hi.clear(); h->text.clear(); h->bwt.clear();
     h->host_resident = false;
     d.C = dC; d.leaf = dleaf; d.q1 = dq1; d.sa_lo = nullptr; d.sa_hi = nullptr; d.text = nullptr;
-    for (void *p : {(void *)wm, (void *)d.dbase_tab, (void *)dC, (void *)dleaf, (void *)dq1}) { pool.keep(p); h->dev_allocs.push_back(p); }
+    for (void *p : {(void *)wm, (void *)d.sbase, (void *)dC, (void *)dleaf, (void *)dq1}) { pool.keep(p); h->dev_allocs.push_back(p); }
     h->dev_bytes = (uint64_t)h->dlevels * d.nblk * FMI_BLOCK_BYTES + (max_sym + 2) * 8 + (max_sym + 1) * 9;
     h->device = device;
     h->dev = d;

@@ -8,11 +8,10 @@
 // device primitives over the hex wavelet matrix (layout: fmi_internal.h)
 // ---------------------------------------------------------------------------
 
-// One 128-byte block in registers: 7 x global_load_dwordx4 (the eighth chunk is padding).
+// One 128-byte block in registers: 8 x global_load_dwordx4, every byte used.
 struct HBlock {
-    uint32_t lo[16];   // low 32 bits of c_0..c_15
-    uint32_t hi[4];    // packed bits 32..39 of c_0..c_15
-    uint64_t P[4];     // bit planes
+    uint32_t rel[16];    // digits equal to d between the superblock start and the block
+    uint32_t P[4][4];    // bit planes, 128 bits each
 };
 
 __device__ __forceinline__ const uint32_t *wm_block_ptr(const FmiDev &ix, uint32_t k, uint64_t blk)
@@ -23,48 +22,66 @@ __device__ __forceinline__ const uint32_t *wm_block_ptr(const FmiDev &ix, uint32
 __device__ __forceinline__ void wm_load_block(const FmiDev &ix, uint32_t k, uint64_t blk, HBlock &b)
 {
     const uint4 *src = reinterpret_cast<const uint4 *>(wm_block_ptr(ix, k, blk));
-    const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6];
-    b.lo[0] = v0.x; b.lo[1] = v0.y; b.lo[2] = v0.z; b.lo[3] = v0.w;
-    b.lo[4] = v1.x; b.lo[5] = v1.y; b.lo[6] = v1.z; b.lo[7] = v1.w;
-    b.lo[8] = v2.x; b.lo[9] = v2.y; b.lo[10] = v2.z; b.lo[11] = v2.w;
-    b.lo[12] = v3.x; b.lo[13] = v3.y; b.lo[14] = v3.z; b.lo[15] = v3.w;
-    b.hi[0] = v4.x; b.hi[1] = v4.y; b.hi[2] = v4.z; b.hi[3] = v4.w;
-    b.P[0] = (uint64_t)v5.x | ((uint64_t)v5.y << 32); b.P[1] = (uint64_t)v5.z | ((uint64_t)v5.w << 32);
-    b.P[2] = (uint64_t)v6.x | ((uint64_t)v6.y << 32); b.P[3] = (uint64_t)v6.z | ((uint64_t)v6.w << 32);
+    const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6], v7 = src[7];
+    b.rel[0] = v0.x; b.rel[1] = v0.y; b.rel[2] = v0.z; b.rel[3] = v0.w;
+    b.rel[4] = v1.x; b.rel[5] = v1.y; b.rel[6] = v1.z; b.rel[7] = v1.w;
+    b.rel[8] = v2.x; b.rel[9] = v2.y; b.rel[10] = v2.z; b.rel[11] = v2.w;
+    b.rel[12] = v3.x; b.rel[13] = v3.y; b.rel[14] = v3.z; b.rel[15] = v3.w;
+    b.P[0][0] = v4.x; b.P[0][1] = v4.y; b.P[0][2] = v4.z; b.P[0][3] = v4.w;
+    b.P[1][0] = v5.x; b.P[1][1] = v5.y; b.P[1][2] = v5.z; b.P[1][3] = v5.w;
+    b.P[2][0] = v6.x; b.P[2][1] = v6.y; b.P[2][2] = v6.z; b.P[2][3] = v6.w;
+    b.P[3][0] = v7.x; b.P[3][1] = v7.y; b.P[3][2] = v7.z; b.P[3][3] = v7.w;
 }
 
-// rank_d(p) for all sixteen digits d, p = 64 * block + bit
-__device__ __forceinline__ void wm_block_ranks(const HBlock &b, uint32_t bit, uint64_t (&r)[16])
+// mask of the first `bit` (0..127) positions of a block, dword w
+__device__ __forceinline__ uint32_t wm_tail_word(uint32_t bit, uint32_t w)
 {
-    const uint64_t T = (1ull << bit) - 1;
-    const uint64_t a[4] = {~b.P[3] & ~b.P[2], ~b.P[3] & b.P[2], b.P[3] & ~b.P[2], b.P[3] & b.P[2]};
-    const uint64_t c[4] = {~b.P[1] & ~b.P[0] & T, ~b.P[1] & b.P[0] & T, b.P[1] & ~b.P[0] & T, b.P[1] & b.P[0] & T};
+    const int32_t s = (int32_t)bit - (int32_t)(32 * w);
+    return s >= 32 ? ~0u : (s <= 0 ? 0u : ((1u << s) - 1));
+}
+
+// digits equal to d in [superblock start, 128 * block + bit), for all sixteen d
+__device__ __forceinline__ void wm_block_ranks(const HBlock &b, uint32_t bit, uint32_t (&r)[16])
+{
 #pragma unroll
-    for (uint32_t d = 0; d < 16; d++) {
-        const uint64_t base = (uint64_t)b.lo[d] | ((uint64_t)((b.hi[d >> 2] >> (8 * (d & 3))) & 0xffu) << 32);
-        r[d] = base + (uint64_t)__popcll(a[d >> 2] & c[d & 3]);
+    for (uint32_t d = 0; d < 16; d++) r[d] = b.rel[d];
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) {
+        const uint32_t T = wm_tail_word(bit, w);
+        const uint32_t p0 = b.P[0][w], p1 = b.P[1][w], p2 = b.P[2][w], p3 = b.P[3][w];
+        const uint32_t a[4] = {~p3 & ~p2, ~p3 & p2, p3 & ~p2, p3 & p2};
+        const uint32_t c[4] = {~p1 & ~p0 & T, ~p1 & p0 & T, p1 & ~p0 & T, p1 & p0 & T};
+#pragma unroll
+        for (uint32_t d = 0; d < 16; d++) r[d] += (uint32_t)__popc(a[d >> 2] & c[d & 3]);
     }
 }
 
 // where position p of level k goes in level k+1 if its symbol has digit d there (p = n maps an
-// exclusive upper bound): ONE 128-byte line, of which a single digit needs the two plane chunks,
-// one counter dword and one counter byte.  The per-level offset table is read from HBM (d is
-// per-lane); that load does not depend on the block and is issued alongside it.
+// exclusive upper bound): ONE 128-byte line, of which a single digit needs the four plane chunks and
+// one counter dword, plus its word of the superblock row (L2-resident; the address depends on p
+// only, so that load is issued alongside the block's).
 __device__ __forceinline__ uint64_t wm_step(const FmiDev &ix, uint32_t k, uint64_t p, uint32_t d)
 {
-    const uint32_t *w = wm_block_ptr(ix, k, p >> 6);
-    const uint64_t base = ix.dbase_tab[k * FMI_ARITY + d];
-    const uint4 pa = *reinterpret_cast<const uint4 *>(w + 20), pb = *reinterpret_cast<const uint4 *>(w + 24);
-    const uint32_t lo = w[d];
-    const uint32_t hi = reinterpret_cast<const uint8_t *>(w)[64 + d];
-    const uint64_t P0 = (uint64_t)pa.x | ((uint64_t)pa.y << 32), P1 = (uint64_t)pa.z | ((uint64_t)pa.w << 32);
-    const uint64_t P2 = (uint64_t)pb.x | ((uint64_t)pb.y << 32), P3 = (uint64_t)pb.z | ((uint64_t)pb.w << 32);
-    uint64_t m = (1ull << (p & 63)) - 1;
-    m &= (d & 1) ? P0 : ~P0;
-    m &= (d & 2) ? P1 : ~P1;
-    m &= (d & 4) ? P2 : ~P2;
-    m &= (d & 8) ? P3 : ~P3;
-    return base + ((uint64_t)lo | ((uint64_t)hi << 32)) + (uint64_t)__popcll(m);
+    const uint64_t blk = p >> FMI_BLOCK_SHIFT;
+    const uint32_t *w = wm_block_ptr(ix, k, blk);
+    const uint64_t base = ix.sbase[((uint64_t)k * ix.nsb + (blk >> ix.sb_shift)) * FMI_ARITY + d];
+    const uint4 q0 = *reinterpret_cast<const uint4 *>(w + 16), q1 = *reinterpret_cast<const uint4 *>(w + 20);
+    const uint4 q2 = *reinterpret_cast<const uint4 *>(w + 24), q3 = *reinterpret_cast<const uint4 *>(w + 28);
+    const uint32_t rel = w[d];
+    const uint32_t bit = (uint32_t)p & (FMI_BLOCK_BITS - 1);
+    const uint32_t P0[4] = {q0.x, q0.y, q0.z, q0.w}, P1[4] = {q1.x, q1.y, q1.z, q1.w};
+    const uint32_t P2[4] = {q2.x, q2.y, q2.z, q2.w}, P3[4] = {q3.x, q3.y, q3.z, q3.w};
+    uint32_t cnt = rel;
+#pragma unroll
+    for (uint32_t x = 0; x < 4; x++) {
+        uint32_t m = wm_tail_word(bit, x);
+        m &= (d & 1) ? P0[x] : ~P0[x];
+        m &= (d & 2) ? P1[x] : ~P1[x];
+        m &= (d & 4) ? P2[x] : ~P2[x];
+        m &= (d & 8) ? P3[x] : ~P3[x];
+        cnt += (uint32_t)__popc(m);
+    }
+    return base + cnt;
 }
 
 __device__ __forceinline__ uint32_t wm_digit(const FmiDev &ix, uint64_t c, uint32_t k)
@@ -90,7 +107,7 @@ __device__ __forceinline__ void wm_rank_sym_pair(const FmiDev &ix, uint64_t c, u
     for (uint32_t k = 0; k < ix.dlevels; k++) {
         const uint32_t d = wm_digit(ix, c, k);
         const uint64_t p2 = wm_step(ix, k, p, d), s2 = wm_step(ix, k, s, d);
-        if (probes) *probes += ((p >> 6) == (s >> 6)) ? 1 : 2;
+        if (probes) *probes += ((p >> FMI_BLOCK_SHIFT) == (s >> FMI_BLOCK_SHIFT)) ? 1 : 2;
         p = p2; s = s2;
     }
     ri = p - ix.leaf[c]; rj = s - ix.leaf[c];

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -23,6 +24,13 @@ void fmi_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *fmi_last_error(void) { return g_err.c_str(); }
+
+uint32_t fmi_sb_shift_for(uint64_t n)
+{
+    const char *e = getenv("SEALFM_FORCE_SB");
+    if (e && *e) return (uint32_t)std::max(0, std::min(30, atoi(e)));
+    return n >= (1ull << 32) ? FMI_SB_SHIFT : FMI_SB_NONE;
+}
 extern "C" uint32_t fmi_abi_version(void) { return 1; }
 
 extern "C" int fmi_create(fmi_t **out)
@@ -223,29 +231,36 @@ void fmi_host_finish_from_bwt(fmi *h, const uint32_t *bwt, uint64_t n)
     const uint32_t D = (L + FMI_DIGIT_BITS - 1) / FMI_DIGIT_BITS;
     h->dlevels = D;
     h->nblk = n / FMI_BLOCK_BITS + 2;
+    h->sb_shift = fmi_sb_shift_for(n);
+    h->nsb = (h->nblk >> h->sb_shift) + 1;
     h->wm.assign((uint64_t)D * h->nblk * FMI_BLOCK_WORDS, 0);
     h->dbase.assign((size_t)D * FMI_ARITY, 0);
+    h->sbase.assign((size_t)D * h->nsb * FMI_ARITY, 0);
+    const uint64_t sb_mask = (1ull << h->sb_shift) - 1;
     std::vector<uint32_t> cur(bwt, bwt + n), nxt(n);
     for (uint32_t k = 0; k < D; k++) {
         const uint32_t sh = FMI_DIGIT_BITS * (D - 1 - k);
         uint64_t *lvl = h->wm.data() + (uint64_t)k * h->nblk * FMI_BLOCK_WORDS;
-        uint64_t cnt[FMI_ARITY] = {0};   // digits seen so far
+        uint64_t *sb = h->sbase.data() + (size_t)k * h->nsb * FMI_ARITY;
+        uint64_t cnt[FMI_ARITY] = {0}, at_sb[FMI_ARITY] = {0};   // digits seen so far / up to the current superblock
         for (uint64_t b = 0; b < h->nblk; b++) {
             uint32_t *blk = reinterpret_cast<uint32_t *>(lvl + b * FMI_BLOCK_WORDS);
-            uint8_t *hi = reinterpret_cast<uint8_t *>(blk + 16);
-            for (uint32_t d = 0; d < FMI_ARITY; d++) { blk[d] = (uint32_t)cnt[d]; hi[d] = (uint8_t)(cnt[d] >> 32); }
-            uint64_t P[4] = {0, 0, 0, 0};
+            if ((b & sb_mask) == 0) {
+                for (uint32_t d = 0; d < FMI_ARITY; d++) { at_sb[d] = cnt[d]; sb[(b >> h->sb_shift) * FMI_ARITY + d] = cnt[d]; }
+            }
+            for (uint32_t d = 0; d < FMI_ARITY; d++) blk[d] = (uint32_t)(cnt[d] - at_sb[d]);
             const uint64_t p0 = b * FMI_BLOCK_BITS;
-            for (uint32_t bit = 0; bit < 64 && p0 + bit < n; bit++) {
+            for (uint32_t bit = 0; bit < FMI_BLOCK_BITS && p0 + bit < n; bit++) {
                 const uint32_t d = (cur[p0 + bit] >> sh) & (FMI_ARITY - 1);
-                for (uint32_t j = 0; j < 4; j++) P[j] |= (uint64_t)((d >> j) & 1) << bit;
+                for (uint32_t j = 0; j < 4; j++) blk[16 + 4 * j + (bit >> 5)] |= ((d >> j) & 1u) << (bit & 31);
                 cnt[d]++;
             }
-            memcpy(blk + 20, P, 32);
         }
         uint64_t *db = h->dbase.data() + (size_t)k * FMI_ARITY;
         db[0] = 0;
         for (uint32_t d = 1; d < FMI_ARITY; d++) db[d] = db[d - 1] + cnt[d - 1];
+        for (uint64_t s2 = 0; s2 < h->nsb; s2++)
+            for (uint32_t d = 0; d < FMI_ARITY; d++) sb[s2 * FMI_ARITY + d] += db[d];
         // stable 16-way partition by digit
         uint64_t o[FMI_ARITY];
         for (uint32_t d = 0; d < FMI_ARITY; d++) o[d] = db[d];
@@ -392,11 +407,12 @@ int fmi_upload(fmi *h, int device)
     h->device = device;
     FmiDev d{};
     d.nblk = h->nblk; d.n = h->n; d.max_sym = h->max_sym; d.levels = h->levels; d.dlevels = h->dlevels; d.sym_bytes = h->sym_bytes;
+    d.nsb = h->nsb; d.sb_shift = h->sb_shift;
     for (uint32_t k = 0; k < h->dlevels; k++)
         for (uint32_t e = 0; e < FMI_ARITY; e++) d.dbase[k][e] = h->dbase[(size_t)k * FMI_ARITY + e];
     int rc;
     const uint8_t *text8 = nullptr;
-    if ((rc = up(h, h->wm, &d.wm)) || (rc = up(h, h->dbase, &d.dbase_tab)) || (rc = up(h, h->C, &d.C)) || (rc = up(h, h->leaf, &d.leaf)) ||
+    if ((rc = up(h, h->wm, &d.wm)) || (rc = up(h, h->sbase, &d.sbase)) || (rc = up(h, h->C, &d.C)) || (rc = up(h, h->leaf, &d.leaf)) ||
         (rc = up(h, h->q1, &d.q1)) || (rc = up(h, h->sa_lo, &d.sa_lo)) || (rc = up(h, h->sa_hi, &d.sa_hi)) ||
         (rc = up(h, h->text, &text8)) || (rc = up(h, h->doc_begin, &d.doc_begin))) {
         fmi_release_device(h);
@@ -416,9 +432,9 @@ extern "C" int fmi_to_device(fmi_t *h, int device)
 
 // ---------------------------------------------------------------------------
 // on-disk format ".fmi" (little endian):
-//   char[8] "SEALFMI3"; u64 n, max_sym, sigma, nblk; u32 levels, sym_bytes;
+//   char[8] "SEALFMI4"; u64 n, max_sym, sigma, nblk; u32 levels, sym_bytes; u32 sb_shift, 0;
 //   u64 sa_wide(0/1); then arrays, each as u64 byte length + raw bytes, in the
-//   order dbase, C, leaf, q1, wm, sa_lo, sa_hi, text, bwt.  (SEALFMI1 / 2 were the binary and 4-ary layouts of earlier
+//   order dbase, sbase, C, leaf, q1, wm, sa_lo, sa_hi, text, bwt.  (SEALFMI1..3 were the binary and 4-ary layouts of earlier
 //   development snapshots.)
 // ---------------------------------------------------------------------------
 template <class T>
@@ -443,11 +459,11 @@ extern "C" int fmi_save(const fmi_t *h, const char *path)
     if (!h->host_resident) { fmi_set_error("fmi_save: index has no host copy (built on device without keep_host)"); return FMI_ERR_STATE; }
     FILE *f = fopen(path, "wb");
     if (!f) { fmi_set_error("cannot open %s for writing", path); return FMI_ERR_IO; }
-    bool ok = fwrite("SEALFMI3", 1, 8, f) == 8;
+    bool ok = fwrite("SEALFMI4", 1, 8, f) == 8;
     uint64_t hdr[4] = {h->n, h->max_sym, h->sigma, h->nblk};
-    uint32_t hdr2[2] = {h->levels, h->sym_bytes};
-    ok = ok && fwrite(hdr, 8, 4, f) == 4 && fwrite(hdr2, 4, 2, f) == 2;
-    ok = ok && wr(f, h->dbase) && wr(f, h->C) && wr(f, h->leaf) && wr(f, h->q1) && wr(f, h->wm) &&
+    uint32_t hdr2[4] = {h->levels, h->sym_bytes, h->sb_shift, 0};
+    ok = ok && fwrite(hdr, 8, 4, f) == 4 && fwrite(hdr2, 4, 4, f) == 4;
+    ok = ok && wr(f, h->dbase) && wr(f, h->sbase) && wr(f, h->C) && wr(f, h->leaf) && wr(f, h->q1) && wr(f, h->wm) &&
          wr(f, h->sa_lo) && wr(f, h->sa_hi) && wr(f, h->text) && wr(f, h->bwt);
     fclose(f);
     if (!ok) { fmi_set_error("write error on %s", path); return FMI_ERR_IO; }
@@ -461,18 +477,19 @@ extern "C" int fmi_load(fmi_t **out, const char *path, int device)
     if (!f) { fmi_set_error("cannot open %s", path); return FMI_ERR_IO; }
     char magic[8];
     fmi *h = new fmi();
-    uint64_t hdr[4]; uint32_t hdr2[2];
-    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "SEALFMI3", 8) == 0;
-    ok = ok && fread(hdr, 8, 4, f) == 4 && fread(hdr2, 4, 2, f) == 2;
-    if (ok) { h->n = hdr[0]; h->max_sym = hdr[1]; h->sigma = hdr[2]; h->nblk = hdr[3]; h->levels = hdr2[0]; h->sym_bytes = hdr2[1]; }
-    ok = ok && rd(f, h->dbase) && rd(f, h->C) && rd(f, h->leaf) && rd(f, h->q1) && rd(f, h->wm) &&
+    uint64_t hdr[4]; uint32_t hdr2[4];
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "SEALFMI4", 8) == 0;
+    ok = ok && fread(hdr, 8, 4, f) == 4 && fread(hdr2, 4, 4, f) == 4;
+    if (ok) { h->n = hdr[0]; h->max_sym = hdr[1]; h->sigma = hdr[2]; h->nblk = hdr[3]; h->levels = hdr2[0]; h->sym_bytes = hdr2[1]; h->sb_shift = hdr2[2]; }
+    ok = ok && rd(f, h->dbase) && rd(f, h->sbase) && rd(f, h->C) && rd(f, h->leaf) && rd(f, h->q1) && rd(f, h->wm) &&
          rd(f, h->sa_lo) && rd(f, h->sa_hi) && rd(f, h->text) && rd(f, h->bwt);
     fclose(f);
     h->dlevels = (h->levels + FMI_DIGIT_BITS - 1) / FMI_DIGIT_BITS;
-    if (!ok || h->levels == 0 || h->levels > FMI_MAX_LEVELS || h->dbase.size() != (size_t)h->dlevels * FMI_ARITY ||
+    h->nsb = ok && h->sb_shift < 64 ? (h->nblk >> h->sb_shift) + 1 : 0;
+    if (!ok || h->sbase.size() != (size_t)h->dlevels * h->nsb * FMI_ARITY || h->levels == 0 || h->levels > FMI_MAX_LEVELS || h->dbase.size() != (size_t)h->dlevels * FMI_ARITY ||
         h->wm.size() != (uint64_t)h->dlevels * h->nblk * FMI_BLOCK_WORDS) {
         delete h;
-        fmi_set_error("%s is not a SEALFMI3 index", path);
+        fmi_set_error("%s is not a SEALFMI4 index", path);
         return FMI_ERR_IO;
     }
     h->host_resident = true;
@@ -497,6 +514,7 @@ extern "C" const void *fmi_host_array(const fmi_t *h, const char *name, uint64_t
     if (s == "leaf") return ret(h->leaf.data(), h->leaf.size(), 8);
     if (s == "q1") return ret(h->q1.data(), h->q1.size(), 1);
     if (s == "dbase") return ret(h->dbase.data(), h->dbase.size(), 8);
+    if (s == "sbase") return ret(h->sbase.data(), h->sbase.size(), 8);
     if (s == "wm") return ret(h->wm.data(), h->wm.size(), 8);
     return nullptr;
 }

@@ -10,18 +10,23 @@
 // The BWT is held as a 16-ary ("hex") wavelet matrix: level k stores, for every position of the
 // order reached after k stable 16-way partitions, the 4-bit digit (c >> 4*(dlevels-1-k)) & 15 of the
 // symbol sitting there.  One level = nblk blocks of 128 bytes (ONE L2 / HBM line) = 32 dwords; block
-// b covers the 64 positions [64 b, 64 b + 64):
-//   dword  d (d = 0..15)      : low 32 bits of c_d = digits equal to d in this level before position 64 b
-//   dwords 16..19, byte d     : bits 32..39 of c_d
-//   dwords 20..27 (4 x u64)   : bit planes P0..P3: bit i of P_j = bit j of the digit at position 64 b + i
-//   dwords 28..31             : zero
-// so ONE 128-byte line answers rank_d(p) for all sixteen digits d: one probe moves a backward search
-// or an interval-symbols node FOUR symbol bits down (BART's 16-bit alphabet = 4 dependent probes).
-// The structure costs 2 bytes per BWT symbol per level (8 n bytes at 4
-// levels): bytes are cheap in 288 GB of HBM, dependent random requests are not.  Positions are < 2^40.
+// b covers the 128 positions [128 b, 128 b + 128):
+//   dword  d (d = 0..15)        : digits equal to d in this level in [superblock start, 128 b)
+//   dwords 16+4j .. 19+4j       : bit plane P_j (128 bits): bit i = bit j of the digit at position 128 b + i
+// and superblock s = b >> sb_shift has one row of sixteen 64-bit words in a side table,
+//   sbase[k][s][d] = (positions of level k whose digit is < d) + (digits equal to d before the superblock)
+// so that ONE 128-byte line (plus an L2-resident table row) answers "where does position p go on
+// level k+1" for all sixteen digits: one probe moves a backward search or an interval-symbols node
+// FOUR symbol bits down (BART's 16-bit alphabet = 4 dependent probes).  Texts below 2^32 symbols
+// have a single superblock per level (sb_shift = 40: the row is just dbase[k][], kept in kernel
+// arguments); longer ones use 2^13 blocks = 2^20 positions per superblock so that the in-block
+// counters stay 32-bit.  Every byte of the line is payload or counter: 1 byte per symbol per level.
 static constexpr uint32_t FMI_BLOCK_WORDS = 16;  // u64 words
 static constexpr uint32_t FMI_BLOCK_BYTES = 128;
-static constexpr uint32_t FMI_BLOCK_BITS = 64;   // positions per block
+static constexpr uint32_t FMI_BLOCK_BITS = 128;  // positions per block
+static constexpr uint32_t FMI_BLOCK_SHIFT = 7;
+static constexpr uint32_t FMI_SB_SHIFT = 13;     // blocks per superblock (log2) when superblocks are in use
+static constexpr uint32_t FMI_SB_NONE = 40;      // sb_shift of a single-superblock index
 static constexpr uint32_t FMI_DIGIT_BITS = 4;
 static constexpr uint32_t FMI_ARITY = 16;
 static constexpr uint32_t FMI_MAX_LEVELS = 17;   // symbols < 2^17 (BART: 50274 < 2^16); node prefixes fit 16 bits
@@ -37,7 +42,9 @@ struct FmiDev {
     uint32_t dlevels;         // ceil(levels / 4) digit levels
     uint32_t sym_bytes;       // 2 or 4: width of text[]
     uint64_t dbase[FMI_MAX_DLEVELS][FMI_ARITY];  // [k][d] = positions of level k whose digit is < d (dbase[k][0] = 0)
-    const uint64_t *dbase_tab; // the same table in HBM, for per-lane digits
+    const uint64_t *sbase;    // [dlevels][nsb][16] superblock rows (see above); nsb == 1: equals dbase
+    uint64_t nsb;             // superblocks per level
+    uint32_t sb_shift;        // blocks per superblock (log2), FMI_SB_NONE when nsb == 1
     const uint64_t *C;        // [max_sym+2] number of symbols < c
     const uint64_t *leaf;     // [max_sym+1] start of c's run after the last level
     const uint8_t *q1;        // [max_sym+1] sdsl rank(size()+1, c) - occ(c)  (quirk Q1)
@@ -51,9 +58,10 @@ struct FmiDev {
 struct fmi {
     // geometry
     uint64_t n = 0, max_sym = 0, sigma = 0, nblk = 0;
-    uint32_t levels = 0, dlevels = 0, sym_bytes = 2;
+    uint32_t levels = 0, dlevels = 0, sym_bytes = 2, sb_shift = FMI_SB_NONE;
+    uint64_t nsb = 1;
     // host-resident arrays (empty when built on device without keep_host)
-    std::vector<uint64_t> wm, dbase /* [dlevels][16] */, C, leaf, doc_begin;
+    std::vector<uint64_t> wm, dbase /* [dlevels][16] */, sbase /* [dlevels][nsb][16] */, C, leaf, doc_begin;
     std::vector<uint8_t> q1, sa_hi;
     std::vector<uint32_t> sa_lo;
     std::vector<uint32_t> bwt;   // kept for tests / hand-over only (not uploaded)
@@ -81,6 +89,8 @@ struct fmi {
 };
 
 void fmi_set_error(const char *fmt, ...);
+// blocks per superblock (log2) for a text of n symbols; SEALFM_FORCE_SB=<shift> forces superblocks (tests)
+uint32_t fmi_sb_shift_for(uint64_t n);
 
 // host builder pieces (fmi_host.cpp)
 int fmi_host_build_from_symbols(fmi *h, const uint32_t *text_with_sentinel, uint64_t n);

@@ -176,21 +176,64 @@ __device__ __forceinline__ void emit_leaf_group_bits(const EmitTarget &t, uint32
     if ((uint32_t)(big >> 32)) atomicOr(w + 1, (uint32_t)(big >> 32));
 }
 
-// rank of every digit at both ends of a node [lo, hi) on level k: child d is
-// [dbase[k][d] + rl[d], dbase[k][d] + rh[d]) on level k+1.  Returns the mask of children that exist.
-__device__ __forceinline__ uint32_t node_ranks(const FmiDev &ix, uint32_t k, uint64_t lo, uint64_t hi, uint64_t (&rl)[16],
-                                               uint64_t (&rh)[16], uint64_t &probes)
+// The sixteen children of a node [lo, hi) on level k: child d is [kid_lo(d), kid_hi(d)) on level
+// k+1 = superblock row + in-superblock rank.  SB = false: single-superblock index (n < 2^32), the row
+// is dbase[k][] in scalar registers and only the 32-bit ranks live in VGPRs; SB = true: the rows of
+// the two ends come from the sbase table.
+template <bool SB> struct Kids;
+template <> struct Kids<false> { uint32_t rl[16], rh[16]; };
+template <> struct Kids<true> { uint32_t rl[16], rh[16]; uint64_t bl[16], bh[16]; };
+
+__device__ __forceinline__ uint64_t kid_lo(const FmiDev &ix, uint32_t k, const Kids<false> &c, uint32_t d) { return ix.dbase[k][d] + c.rl[d]; }
+__device__ __forceinline__ uint64_t kid_hi(const FmiDev &ix, uint32_t k, const Kids<false> &c, uint32_t d) { return ix.dbase[k][d] + c.rh[d]; }
+__device__ __forceinline__ uint64_t kid_lo(const FmiDev &, uint32_t, const Kids<true> &c, uint32_t d) { return c.bl[d] + c.rl[d]; }
+__device__ __forceinline__ uint64_t kid_hi(const FmiDev &, uint32_t, const Kids<true> &c, uint32_t d) { return c.bh[d] + c.rh[d]; }
+
+// returns the mask of children that exist
+template <bool SB>
+__device__ __forceinline__ uint32_t node_children(const FmiDev &ix, uint32_t k, uint64_t lo, uint64_t hi, Kids<SB> &c, uint64_t &probes)
 {
-    const uint64_t blo = lo >> 6, bhi = hi >> 6;
-    HBlock a, b;
-    wm_load_block(ix, k, blo, a);
-    if (bhi != blo) wm_load_block(ix, k, bhi, b); else b = a;
-    wm_block_ranks(a, (uint32_t)(lo & 63), rl);
-    wm_block_ranks(b, (uint32_t)(hi & 63), rh);
-    probes += bhi != blo ? 2 : 1;
+    const uint64_t blo = lo >> FMI_BLOCK_SHIFT, bhi = hi >> FMI_BLOCK_SHIFT;
     uint32_t em = 0;
+    {
+        HBlock a;
+        wm_load_block(ix, k, blo, a);
+        if (bhi != blo) {
+            HBlock b;
+            wm_load_block(ix, k, bhi, b);
+            wm_block_ranks(a, (uint32_t)lo & (FMI_BLOCK_BITS - 1), c.rl);
+            wm_block_ranks(b, (uint32_t)hi & (FMI_BLOCK_BITS - 1), c.rh);
+        } else {
+            wm_block_ranks(a, (uint32_t)lo & (FMI_BLOCK_BITS - 1), c.rl);
+            wm_block_ranks(a, (uint32_t)hi & (FMI_BLOCK_BITS - 1), c.rh);
+        }
+    }
+    if constexpr (SB) {
+        const uint64_t slo = blo >> ix.sb_shift, shi = bhi >> ix.sb_shift;
+        const uint64_t *rowl = ix.sbase + ((uint64_t)k * ix.nsb + slo) * FMI_ARITY;
+        const uint64_t *rowh = ix.sbase + ((uint64_t)k * ix.nsb + shi) * FMI_ARITY;
 #pragma unroll
-    for (uint32_t d = 0; d < 16; d++) em |= (uint32_t)(rh[d] > rl[d]) << d;
+        for (uint32_t d = 0; d < 16; d += 2) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(rowl + d);
+            c.bl[d] = v.x; c.bl[d + 1] = v.y;
+        }
+        if (shi != slo) {
+#pragma unroll
+            for (uint32_t d = 0; d < 16; d += 2) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(rowh + d);
+                c.bh[d] = v.x; c.bh[d + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t d = 0; d < 16; d++) c.bh[d] = c.bl[d];
+        }
+#pragma unroll
+        for (uint32_t d = 0; d < 16; d++) em |= (uint32_t)(c.bh[d] + c.rh[d] > c.bl[d] + c.rl[d]) << d;
+    } else {
+#pragma unroll
+        for (uint32_t d = 0; d < 16; d++) em |= (uint32_t)(c.rh[d] > c.rl[d]) << d;
+    }
+    probes += bhi != blo ? 2 : 1;
     return em;
 }
 
@@ -203,43 +246,33 @@ __device__ __forceinline__ uint32_t model_nodes(uint32_t em, uint32_t k, uint32_
     return (skip < 1 ? 1u : 0u) + (skip < 2 ? (uint32_t)__popc(g8) : 0u) + (skip < 3 ? (uint32_t)__popc(g4) : 0u) + (uint32_t)__popc(g2);
 }
 
-// wave-wide compaction of the existing children: slot of child d of this lane = base + before[d] + rank of the lane in bal[d]
-struct Fanout {
-    uint64_t bal[16];
-    uint32_t before[16], added;
-};
-__device__ __forceinline__ void fanout_of(uint32_t em, Fanout &f)
+// wave-wide compaction of the existing children, one digit at a time: the slot of child d of this
+// lane is (children of smaller digits in the wave) + (rank of the lane among the lanes having child d)
+__device__ __forceinline__ uint32_t lane_rank_in(uint64_t bal)
 {
-    f.added = 0;
-#pragma unroll
-    for (uint32_t d = 0; d < 16; d++) {
-        f.bal[d] = __ballot((em >> d) & 1);
-        f.before[d] = f.added;
-        f.added += (uint32_t)__popcll(f.bal[d]);
-    }
-}
-__device__ __forceinline__ uint32_t fanout_slot(const Fanout &f, uint32_t d)
-{
-    return f.before[d] + __builtin_amdgcn_mbcnt_hi((uint32_t)(f.bal[d] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)f.bal[d], 0));
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
 }
 
 // append the children of this wave's nodes (level k, wave-uniform) to the phase-2 queue; all lanes call
+template <bool SB>
 __device__ __forceinline__ void hand_over(const FmiDev &ix, uint32_t k, uint32_t row, uint32_t prefix, uint32_t em,
-                                          const uint64_t (&rl)[16], const uint64_t (&rh)[16], ExpandItem *out_items,
-                                          uint32_t *out_count, uint32_t out_cap)
+                                          const Kids<SB> &c, ExpandItem *out_items, uint32_t *out_count, uint32_t out_cap)
 {
-    Fanout f;
-    fanout_of(em, f);
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < 16; d++) total += (uint32_t)__popcll(__ballot((em >> d) & 1));
     uint32_t obase = 0;
-    if ((threadIdx.x & 63) == 0 && f.added) obase = atomicAdd(out_count, f.added);
+    if ((threadIdx.x & 63) == 0 && total) obase = atomicAdd(out_count, total);
     obase = __shfl(obase, 0);
 #pragma unroll
-    for (uint32_t d = 0; d < 16; d++)
+    for (uint32_t d = 0; d < 16; d++) {
+        const uint64_t bal = __ballot((em >> d) & 1);
         if ((em >> d) & 1) {
-            const uint32_t o = obase + fanout_slot(f, d);
-            const uint64_t db = ix.dbase[k][d];
-            if (o < out_cap) out_items[o] = ExpandItem{db + rl[d], db + rh[d], row, k + 1, (prefix << 4) | d, 0};
+            const uint32_t o = obase + lane_rank_in(bal);
+            if (o < out_cap) out_items[o] = ExpandItem{kid_lo(ix, k, c, d), kid_hi(ix, k, c, d), row, k + 1, (prefix << 4) | d, 0};
         }
+        obase += (uint32_t)__popcll(bal);
+    }
 }
 
 __device__ __forceinline__ void flush_counters(uint64_t *probe_counter, uint64_t probes, uint32_t model, uint32_t iters, uint32_t nodes)
@@ -260,11 +293,11 @@ __device__ __forceinline__ void flush_counters(uint64_t *probe_counter, uint64_t
 // wavefronts instead of one); stop_level >= dlevels disables the hand-over.
 // Dynamic LDS per wave: 3 x slots words (lo32, hi32, packed high bits + prefix)
 // + FMI_MAX_DLEVELS counters.
-template <int MODE>
-__global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const ExpandItem *items, const uint32_t *n_items_ptr,
-                                                           uint32_t n_items_static, EmitTarget tgt, uint32_t slots,
-                                                           uint32_t stop_level, ExpandItem *out_items, uint32_t *out_count,
-                                                           uint32_t out_cap, uint64_t *probe_counter)
+template <int MODE, bool SB>
+__device__ __forceinline__ void expand_body(const FmiDev &ix, const ExpandItem *items, const uint32_t *n_items_ptr,
+                                            uint32_t n_items_static, const EmitTarget &tgt, uint32_t slots,
+                                            uint32_t stop_level, ExpandItem *out_items, uint32_t *out_count,
+                                            uint32_t out_cap, uint64_t *probe_counter)
 {
     extern __shared__ uint32_t s_mem[];
     const uint32_t lane = threadIdx.x & 63;
@@ -315,10 +348,10 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
             }
             wave_sync();
             if (lane == 0) s_cnt[deepest] = cnt - m;
-            uint64_t rl[16], rh[16];
+            Kids<SB> kids;
             uint32_t em = 0;                        // children that exist
             if (act) {
-                em = node_ranks(ix, k, lo, hi, rl, rh, probes);
+                em = node_children<SB>(ix, k, lo, hi, kids, probes);
                 model += model_nodes(em, k, pad_bits);
             }
             iters++; nodes += m;
@@ -328,32 +361,51 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(FmiDev ix, const Expa
                 } else {
 #pragma unroll
                     for (uint32_t d = 0; d < 16; d++)
-                        if ((em >> d) & 1) emit_leaf<MODE>(tgt, row, (prefix << 4) | d, rh[d] - rl[d]);
+                        if ((em >> d) & 1) emit_leaf<MODE>(tgt, row, (prefix << 4) | d, kid_hi(ix, k, kids, d) - kid_lo(ix, k, kids, d));
                 }
             } else if (k + 1 == stop_level) {
-                hand_over(ix, k, row, prefix, em, rl, rh, out_items, out_count, out_cap);
+                hand_over<SB>(ix, k, row, prefix, em, kids, out_items, out_count, out_cap);
             } else {
-                Fanout f;
-                fanout_of(em, f);
-                const uint32_t dst = lvl_off(deepest + 1) + __builtin_amdgcn_readfirstlane(s_cnt[deepest + 1]);
+                uint32_t dst = lvl_off(deepest + 1) + __builtin_amdgcn_readfirstlane(s_cnt[deepest + 1]), added = 0;
 #pragma unroll
-                for (uint32_t d = 0; d < 16; d++)
+                for (uint32_t d = 0; d < 16; d++) {
+                    const uint64_t bal = __ballot((em >> d) & 1);
                     if ((em >> d) & 1) {
-                        const uint32_t o = dst + fanout_slot(f, d);
-                        const uint64_t db = ix.dbase[k][d];
-                        const uint64_t clo = db + rl[d], chi = db + rh[d];
+                        const uint32_t o = dst + added + lane_rank_in(bal);
+                        const uint64_t clo = kid_lo(ix, k, kids, d), chi = kid_hi(ix, k, kids, d);
                         s_lo[o] = (uint32_t)clo; s_hi[o] = (uint32_t)chi;
                         s_mx[o] = (uint32_t)(clo >> 32) | ((uint32_t)(chi >> 32) << 8) | (((prefix << 4) | d) << 16);
                     }
+                    added += (uint32_t)__popcll(bal);
+                }
                 wave_sync();
-                if (lane == 0) s_cnt[deepest + 1] += f.added;
+                if (lane == 0) s_cnt[deepest + 1] += added;
                 wave_sync();
-                if (f.added) deepest++;
+                if (added) deepest++;
             }
         }
         wave_sync();
     }
     if (probe_counter) flush_counters(probe_counter, probes, model, iters, nodes);
+}
+
+// Single-superblock indexes (n < 2^32, the NQ case).  226 VGPRs = two waves per SIMD; forcing three
+// (amdgpu_waves_per_eu(3,3), 168 VGPRs + 84 B of scratch) measured slower: 120 vs 97 us per wide call.
+template <int MODE>
+__global__ __launch_bounds__(EXP_WAVES * 64)
+void k_expand(FmiDev ix, const ExpandItem *items, const uint32_t *n_items_ptr, uint32_t n_items_static, EmitTarget tgt, uint32_t slots,
+              uint32_t stop_level, ExpandItem *out_items, uint32_t *out_count, uint32_t out_cap, uint64_t *probe_counter)
+{
+    expand_body<MODE, false>(ix, items, n_items_ptr, n_items_static, tgt, slots, stop_level, out_items, out_count, out_cap, probe_counter);
+}
+
+// Superblocked indexes (n >= 2^32): the two superblock rows add 64 VGPRs
+template <int MODE>
+__global__ __launch_bounds__(EXP_WAVES * 64)
+void k_expand_sb(FmiDev ix, const ExpandItem *items, const uint32_t *n_items_ptr, uint32_t n_items_static, EmitTarget tgt, uint32_t slots,
+                 uint32_t stop_level, ExpandItem *out_items, uint32_t *out_count, uint32_t out_cap, uint64_t *probe_counter)
+{
+    expand_body<MODE, true>(ix, items, n_items_ptr, n_items_static, tgt, slots, stop_level, out_items, out_count, out_cap, probe_counter);
 }
 
 // dense per-row symbol counts -> CSR, ascending symbols.  One workgroup per row.
@@ -410,6 +462,7 @@ struct ForceFrom { int64_t tok[MAX_FORCE]; uint32_t n; };
 // (level 0) and hands the level-1 children straight to phase 2: the narrow steps of
 // a decode are launch-latency bound, and this saves them a kernel.  `zero_next`
 // (two words) is cleared for the NEXT call, whose counters alternate with this one's.
+template <bool SB>
 __global__ __launch_bounds__(64) void k_prefix_ranges(FmiDev ix, uint64_t rows, uint64_t cur_len, const int64_t *ids, int64_t shift,
                                 int64_t pad_id, int64_t eos_id, ForceFrom ff, int64_t stop_at_count,
                                 int always_allow_eos, uint64_t vocab, uint64_t words_per_row,
@@ -450,14 +503,14 @@ __global__ __launch_bounds__(64) void k_prefix_ranges(FmiDev ix, uint64_t rows, 
     }
     if (!out_items) return;
     // root expansion, the level-0 step of k_expand
-    uint64_t rl[16], rh[16];
+    Kids<SB> kids;
     uint32_t em = 0;
     const bool act = valid && it.hi > it.lo;
     if (act) {
-        em = node_ranks(ix, 0, it.lo, it.hi, rl, rh, probes);
+        em = node_children<SB>(ix, 0, it.lo, it.hi, kids, probes);
         model += model_nodes(em, 0, FMI_DIGIT_BITS * ix.dlevels - ix.levels);
     }
-    hand_over(ix, 0, (uint32_t)r, 0, em, rl, rh, out_items, out_count, out_cap);
+    hand_over<SB>(ix, 0, (uint32_t)r, 0, em, kids, out_items, out_count, out_cap);
     if (probe_counter) flush_counters(probe_counter, probes, model, __ballot(act) ? 1u : 0u, (uint32_t)__popcll(__ballot(act)));
 }
 
@@ -955,7 +1008,8 @@ static int launch_phase2(fmi *h, hipStream_t st, uint32_t split, const ExpandIte
     const int nlev2 = (int)(Q - split);
     static const char *e_p2 = getenv("SEALFM_P2_BLOCKS");
     const unsigned p2_blocks = e_p2 ? (unsigned)atoi(e_p2) : EXP_P2_BLOCKS;
-    hipLaunchKernelGGL((k_expand<MODE>), dim3(std::min(expand_grid(qcap), p2_blocks)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev2), st, h->dev,
+    auto kern = h->dev.nsb > 1 ? k_expand_sb<MODE> : k_expand<MODE>;
+    hipLaunchKernelGGL(kern, dim3(std::min(expand_grid(qcap), p2_blocks)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev2), st, h->dev,
                        queue, qcount, (uint32_t)qcap, tgt, (uint32_t)exp_slots(nlev2), Q, (ExpandItem *)nullptr, (uint32_t *)nullptr, 0u, pc);
     HIPCHK(hipGetLastError());
     return FMI_OK;
@@ -970,7 +1024,8 @@ static int launch_expand(fmi *h, hipStream_t st, ExpandItem *items, uint64_t row
     const uint32_t split = expand_split(h, rows, queue, qcap);
     if (split < Q) HIPCHK(hipMemsetAsync(qcount, 0, 4, st));
     const int nlev1 = (int)split;
-    hipLaunchKernelGGL((k_expand<MODE>), dim3(expand_grid(rows)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev1), st, h->dev,
+    auto kern = h->dev.nsb > 1 ? k_expand_sb<MODE> : k_expand<MODE>;
+    hipLaunchKernelGGL(kern, dim3(expand_grid(rows)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev1), st, h->dev,
                        (const ExpandItem *)items, (const uint32_t *)nullptr, (uint32_t)rows, tgt, (uint32_t)exp_slots(nlev1),
                        split, queue, qcount, (uint32_t)qcap, pc);
     HIPCHK(hipGetLastError());
@@ -1002,7 +1057,8 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
         uint32_t *cur = ws_qcount(h) + 2 * (h->ws_seq & 1), *nxt = ws_qcount(h) + 2 * ((h->ws_seq + 1) & 1);
         h->ws_seq++;
         if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
-        hipLaunchKernelGGL(k_prefix_ranges, dim3(blocks_for(rows, 64)), dim3(64), 0, st, h->dev, rows, cur_len, d_ids, shift,
+        auto pk = h->dev.nsb > 1 ? k_prefix_ranges<true> : k_prefix_ranges<false>;
+        hipLaunchKernelGGL(pk, dim3(blocks_for(rows, 64)), dim3(64), 0, st, h->dev, rows, cur_len, d_ids, shift,
                            pad_id, eos_id, ff, stop_at_count, always_allow_eos, vocab, wpr, d_bits, items, ws_queue(h), cur,
                            (uint32_t)qcap, nxt, pc);
         int rc = launch_phase2<EMIT_BITS>(h, st, 1, ws_queue(h), cur, qcap, tgt);
@@ -1010,7 +1066,7 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
         if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
         return FMI_OK;
     }
-    hipLaunchKernelGGL(k_prefix_ranges, dim3(blocks_for(rows, 64)), dim3(64), 0, st, h->dev, rows, cur_len, d_ids, shift,
+    hipLaunchKernelGGL(k_prefix_ranges<false>, dim3(blocks_for(rows, 64)), dim3(64), 0, st, h->dev, rows, cur_len, d_ids, shift,
                        pad_id, eos_id, ff, stop_at_count, always_allow_eos, vocab, wpr, d_bits, items, (ExpandItem *)nullptr,
                        (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, (uint64_t *)nullptr);
     if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));

@@ -21,14 +21,23 @@ def _docs(seed, n_docs, vocab, min_len=2, max_len=30, zipf=None):
     return docs
 
 
-@pytest.fixture(scope="module", params=[(0, 40, 12), (1, 300, 500), (2, 2000, 50265)])
+@pytest.fixture(scope="module", params=[(0, 40, 12, None), (1, 300, 500, None), (2, 2000, 50265, None), (2, 2000, 50265, 3)],
+                ids=["tiny", "small", "bart-vocab", "bart-vocab-superblocks"])
 def pair(request):
+    import os
     from oracle.seal_oracle import OracleFMIndex
     from seal_amd import FMIndex
-    seed, n_docs, vocab = request.param
+    seed, n_docs, vocab, force_sb = request.param
     docs = _docs(seed, n_docs, vocab, zipf=1.2 if vocab > 1000 else None)
     ix, orc = FMIndex(), OracleFMIndex()
-    ix.initialize(docs)
+    # force_sb: the superblocked layout (and kernel instantiations) of texts beyond 2^32 symbols,
+    # here with 2^3 blocks per superblock so that a test-sized text spans hundreds of them
+    if force_sb is not None:
+        os.environ["SEALFM_FORCE_SB"] = str(force_sb)
+    try:
+        ix.initialize(docs)
+    finally:
+        os.environ.pop("SEALFM_FORCE_SB", None)
     orc.initialize(docs)
     return ix, orc, docs, vocab
 
@@ -173,6 +182,8 @@ def test_gpu_builder_is_byte_identical_to_host_builder(seed, n_docs, vocab, wide
     # idx64 = the builder's path for > 2^32 symbols (64-bit suffix indices, two-pass radix sort per
     # doubling round, 40-bit resident SA), forced here at a size a test can afford
     monkeypatch.setenv("SEALFM_FORCE_IDX64", "1" if wide else "0")
+    if wide:
+        monkeypatch.setenv("SEALFM_FORCE_SB", "2")     # ... and the superblocked wavelet layout that goes with it
     from seal_amd import FMIndex
     from seal_amd._lib import lib
     docs = _docs(seed, n_docs, vocab, zipf=1.2 if vocab > 1000 else None)
@@ -191,7 +202,7 @@ def test_gpu_builder_is_byte_identical_to_host_builder(seed, n_docs, vocab, wide
         buf = (ctypes.c_uint8 * (n.value * e.value)).from_address(p)
         return bytes(buf)
 
-    for name in ("sa", "bwt", "text", "C", "leaf", "q1", "dbase", "wm"):
+    for name in ("sa", "bwt", "text", "C", "leaf", "q1", "dbase", "sbase", "wm"):
         assert arr(a, name) == arr(b, name), name
     assert b.size() == a.size() and b.occurring_distinct == a.occurring_distinct and b.occurring_counts == a.occurring_counts
     assert sorted(b.occurring) == sorted(a.occurring)

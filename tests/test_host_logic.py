@@ -46,29 +46,33 @@ def _arr(h, name):
     return np.frombuffer(buf, dtype=dt).copy()
 
 
-def _wm_digit_ranks(wm, nblk, k, p):
-    """Python restatement of the documented 128-byte block layout: digits equal to
-    0 .. 15 in level k before position p."""
-    blk, within = divmod(p, 64)
+def _wm_child_positions(wm, sbase, nblk, nsb, sb_shift, k, p):
+    """Python restatement of the documented 128-byte block layout: where position p
+    of level k goes on level k+1 for each of the sixteen digits."""
+    blk, within = divmod(p, 128)
     base = (k * nblk + blk) * 16                      # u64 words
     dwords = []
     for w in wm[base:base + 16]:
         dwords += [int(w) & 0xFFFFFFFF, int(w) >> 32]
-    hi = b"".join(int(x).to_bytes(4, "little") for x in dwords[16:20])
-    cnt = [dwords[d] | (hi[d] << 32) for d in range(16)]
-    planes = [dwords[20 + 2 * j] | (dwords[21 + 2 * j] << 32) for j in range(4)]
-    assert dwords[28:32] == [0, 0, 0, 0]
+    row = sbase[(k * nsb + (blk >> sb_shift)) * 16:][:16]
+    out = [int(row[d]) + dwords[d] for d in range(16)]
+    planes = [sum(dwords[16 + 4 * j + x] << (32 * x) for x in range(4)) for j in range(4)]
     for i in range(within):
-        cnt[sum(((planes[j] >> i) & 1) << j for j in range(4))] += 1
-    return cnt
+        out[sum(((planes[j] >> i) & 1) << j for j in range(4))] += 1
+    return out
 
 
 def _rand_data(rng, n, vocab):
     return [rng.randrange(1, vocab) for _ in range(n)]
 
 
-@pytest.mark.parametrize("seed,n,vocab", [(0, 50, 4), (1, 400, 30), (2, 3000, 700), (3, 5000, 60000), (4, 2000, 2)])
-def test_host_builder_matches_brute_force(seed, n, vocab):
+@pytest.mark.parametrize("seed,n,vocab,force_sb", [(0, 50, 4, None), (1, 400, 30, None), (2, 3000, 700, None), (3, 5000, 60000, None),
+                                                   (4, 2000, 2, None), (2, 3000, 700, 1), (3, 5000, 60000, 0)])
+def test_host_builder_matches_brute_force(seed, n, vocab, force_sb, monkeypatch):
+    # force_sb: superblocks of 2^force_sb blocks, the layout texts beyond 2^32 symbols get
+    if force_sb is not None:
+        monkeypatch.setenv("SEALFM_FORCE_SB", str(force_sb))
+    sb_shift = 40 if force_sb is None else force_sb
     rng = random.Random(seed)
     data = _rand_data(rng, n, vocab)
     if seed == 1:   # long repeats: stress the doubling rounds
@@ -91,11 +95,15 @@ def test_host_builder_matches_brute_force(seed, n, vocab):
         for c in set(text):
             assert C[c] == sum(1 for x in text if x < c)
         assert lib().fmi_sigma(h) == len(set(text))
-        wm, dbase, leaf = _arr(h, "wm"), _arr(h, "dbase"), _arr(h, "leaf")
+        wm, dbase, sbase, leaf = _arr(h, "wm"), _arr(h, "dbase"), _arr(h, "sbase"), _arr(h, "leaf")
         D = (L + 3) // 4
         assert len(dbase) == 16 * D
         nblk = len(wm) // (16 * D)
-        assert nblk == N // 64 + 2
+        assert nblk == N // 128 + 2
+        nsb = len(sbase) // (16 * D)
+        assert nsb == (nblk >> sb_shift) + 1
+        if nsb == 1:
+            assert sbase.tolist() == dbase.tolist()
         # rank_c(i) through the hex wavelet matrix == naive count
         for _ in range(300):
             c = rng.choice(text)
@@ -103,7 +111,7 @@ def test_host_builder_matches_brute_force(seed, n, vocab):
             p = i
             for k in range(D):
                 d = (c >> (4 * (D - 1 - k))) & 15
-                p = int(dbase[16 * k + d]) + _wm_digit_ranks(wm, nblk, k, p)[d]
+                p = _wm_child_positions(wm, sbase, nblk, nsb, sb_shift, k, p)[d]
             assert p - int(leaf[c]) == bwt[:i].count(c)
         # quirk table == what the faithful sdsl-layout oracle computes for rank(size()+1, c)
         orc = CppFMIndex()
@@ -146,7 +154,7 @@ def test_save_load_round_trip(tmp_path):
     h2 = ctypes.c_void_p()
     check(lib().fmi_load(ctypes.byref(h2), path, -1))
     try:
-        for name in ("sa", "bwt", "text", "C", "leaf", "q1", "dbase", "wm"):
+        for name in ("sa", "bwt", "text", "C", "leaf", "q1", "dbase", "sbase", "wm"):
             assert np.array_equal(_arr(h, name), _arr(h2, name)), name
         assert lib().fmi_size(h2) == 1001 and lib().fmi_levels(h2) == lib().fmi_levels(h)
     finally:
