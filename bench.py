@@ -301,6 +301,8 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    xstats = (ctypes.c_uint64 * 4)()
+    check(lib().fmi_dev_read_expand_stats(index.handle, xstats))
     check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(probes)))
     check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(launches), ctypes.byref(kms)))
     probes, launches, kms = ctypes.c_uint64(probes.value), ctypes.c_uint64(launches.value), ctypes.c_double(kms.value)
@@ -373,20 +375,33 @@ def main():
     check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(p2)))
     check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(l2), ctypes.byref(k2)))
 
-    alg_bytes = probes.value * 128.0   # the in-kernel counter counts the distinct 128-byte blocks the rank probes load
+    # one probe = one 128-byte block of the hex wavelet matrix, counted in-kernel (distinct blocks per
+    # node): the bytes THIS data structure has to read for the work
+    alg_bytes = probes.value * 128.0
     achieved = alg_bytes / (kms.value * 1e-3) / 1e9 if kms.value > 0 else 0.0
+    # SURVEY.md §8(d) prices the same work on the reference-shaped structure (binary wavelet tree, one
+    # 64-byte level-probe per node end): counted exactly in-kernel as well, reported beside it
+    model_bytes = 2.0 * xstats[3] * 64.0
+    model_gbps = model_bytes / (kms.value * 1e-3) / 1e9 if kms.value > 0 else 0.0
     # memory-side traffic comes from a SEPARATE rocprofv3 --pmc FETCH_SIZE pass of this same command
-    # (profiles/README.md); per "launch" = per constraint call = the phase-1 + phase-2 kernel pair
+    # (profiles/README.md); per "launch" = per constraint call = the prefix + expansion kernel pair.
+    # FETCH_SIZE counts 128-byte requests at 64 bytes on gfx950 (MI355X guide; tools/gather_calib.hip): x 2.
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_size.json")))
-        traffic = round(pmc["void k_expand<0>"]["FETCH_SIZE"]["avg"] * 1024.0 * 2, 1)
+        kib = sum(v["FETCH_SIZE"]["avg"] for k, v in pmc.items() if k.startswith("void k_expand<0>") or k.startswith("void k_prefix_ranges"))
+        traffic = round(kib * 1024.0 * 2, 1) if kib else None
     except Exception:
         pass
-    roofline = {"bound": "hbm", "kernel": "k_expand<EMIT_BITS> (phase-1 + phase-2 launch pair)", "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                "launches": int(launches.value), "avg_launch_us": round(kms.value * 1e3 / max(1, launches.value), 2),
-                "algorithmic_bytes_per_launch": round(alg_bytes / max(1, launches.value), 1)}
+    nl = max(1, launches.value)
+    roofline = {"bound": "hbm", "kernel": "k_prefix_ranges + k_expand<EMIT_BITS> (one constraint call: prefix ranges, root fan-out, sub-tree expansion)",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                "traffic": traffic, "launches": int(launches.value), "avg_launch_us": round(kms.value * 1e3 / nl, 2),
+                "algorithmic_bytes_per_launch": round(alg_bytes / nl, 1),
+                "survey_8d_model": {"bytes_per_launch": round(model_bytes / nl, 1), "achieved": round(model_gbps, 2),
+                                    "frac": round(model_gbps / HBM_PEAK_GBPS, 5),
+                                    "note": "binary 16-level wavelet tree, 64 B per level-probe, same symbols emitted"},
+                "wave_iterations_per_launch": round(xstats[1] / nl, 1), "lane_utilisation": round(xstats[2] / max(1, 64 * xstats[1]), 3)}
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
