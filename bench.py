@@ -339,6 +339,8 @@ def main():
 
     # ---- per-phase profile of one extra batch (untimed), also records the index ops for the CPU replay ----
     phases = {}
+    gc.collect()
+    gc.freeze()                                           # the runs above left long-lived results behind
 
     def timed(name, fn):
         def wrap(*a, **kw):
