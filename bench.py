@@ -367,7 +367,7 @@ def main():
         pr.enable()
         run_batch(args.warmup + args.steps)
         pr.disable()
-        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
+        pstats.Stats(pr, stream=sys.stderr).sort_stats(os.environ.get("SEAL_BENCH_PROFILE_SORT", "cumulative")).print_stats(int(os.environ.get("SEAL_BENCH_PROFILE_N", "45")))
     else:
         run_batch(args.warmup + args.steps)
     trace, index._trace = index._trace, None

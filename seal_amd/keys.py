@@ -623,6 +623,12 @@ def aggregate_evidence_batch(jobs, index, **params):
     backward-search launch for every key of every query, one locate launch for every rare key of
     every query (and one document fetch when fully scoring).  ``jobs`` = list of
     ``(ngrams_and_scores, unigram_scores)``; returns the list of ``(results, all_ngrams)``."""
+    import os, time, sys
+    _tm = os.environ.get("SEAL_AGG_TIMING")
+    _t = {"t0": time.perf_counter()}
+    def _mark(name):
+        if _tm:
+            now = time.perf_counter(); _t[name] = _t.get(name, 0.0) + (now - _t["t0"]) * 1e3; _t["t0"] = now
     all_keys, seen = [], set()
     for ngrams_and_scores, _ in jobs:
         for ng, _ in ngrams_and_scores:
@@ -634,6 +640,7 @@ def aggregate_evidence_batch(jobs, index, **params):
     if all_keys:
         lo, hi = index.get_range_batch([list(t) for t in all_keys])
         shared = {t: (int(a), int(b)) for t, a, b in zip(all_keys, lo, hi)}
+    _mark("ranges")
     gens = [_aggregate_steps(nas, us, index, shared_ranges=shared, **params) for nas, us in jobs]
     out = [None] * len(gens)
     reqs = {}
@@ -642,6 +649,7 @@ def aggregate_evidence_batch(jobs, index, **params):
             reqs[i] = next(g)
         except StopIteration as done:
             out[i] = done.value
+    _mark("score_split")
     while reqs:
         loc = [i for i, r in reqs.items() if r[0] == "locate"]
         answers = {}
@@ -656,6 +664,7 @@ def aggregate_evidence_batch(jobs, index, **params):
                 o = offs[k0:k0 + nk + 1]
                 answers[i] = (pos[o[0]:o[-1]], doc[o[0]:o[-1]], o - o[0])
                 k0 += nk
+            _mark("locate")
         dcs = [i for i, r in reqs.items() if r[0] == "docs"]
         if dcs:
             flat = [d for i in dcs for d in reqs[i][1]]
@@ -665,13 +674,18 @@ def aggregate_evidence_batch(jobs, index, **params):
                 nd = len(reqs[i][1])
                 answers[i] = fetched.slice(k0, k0 + nd)
                 k0 += nd
+            _mark("fetch_docs")
         nxt = {}
         for i, ans in answers.items():
             try:
                 nxt[i] = gens[i].send(ans)
             except StopIteration as done:
                 out[i] = done.value
+        _mark("host_after_docs" if dcs else "host_after_locate")
         reqs = nxt
+    if _tm:
+        _t.pop("t0")
+        print("[agg]", {k: round(v, 1) for k, v in _t.items()}, file=sys.stderr, flush=True)
     return out
 
 

@@ -523,6 +523,10 @@ class SEALSearcher:
         retrieval.py:766)."""
         defer = self._host_pool() if self.jobs >= 2 else None
         pending = []
+        # with workers: the chunk's aggregation (index kernels on their own stream + native host
+        # bookkeeping, both of which release the GIL) runs on one background thread, so that pulling
+        # the next chunk of keys -- the decode of the next batch -- starts right away
+        bg = self._agg_thread() if defer is not None else None
         for chunk in _chunks(keys, self.batch_size):
             jobs = []
             for kk in chunk:
@@ -533,13 +537,20 @@ class SEALSearcher:
                 else:
                     kk = (kk, None)
                 jobs.append(kk)
-            out = rk.aggregate_evidence_batch(jobs, self.fm_index, defer=defer, keep=keep, **self._aggregate_params())
-            if defer is None:
-                yield from out
-            else:
-                pending.extend(out)
-        for res, ngrams in pending:
-            yield (res.result() if hasattr(res, "result") else res), ngrams
+            if bg is not None:
+                pending.append(bg.submit(rk.aggregate_evidence_batch, jobs, self.fm_index, defer=defer, keep=keep,
+                                         **self._aggregate_params()))
+                continue
+            yield from rk.aggregate_evidence_batch(jobs, self.fm_index, defer=defer, keep=keep, **self._aggregate_params())
+        for fut in pending:
+            for res, ngrams in fut.result():
+                yield (res.result() if hasattr(res, "result") else res), ngrams
+
+    def _agg_thread(self):
+        if getattr(self, "_agg_pool", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._agg_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="seal-aggregate")
+        return self._agg_pool
 
     def doc(self, docid: Union[str, int]) -> Optional[SEALDocument]:
         idx = self.docid2idx[docid] if isinstance(docid, str) else docid
