@@ -252,3 +252,40 @@ def test_rank_only_index_from_bwt_matches_full_index(pair):
         ro.locate(3)
     with pytest.raises(SealFMError):
         ro.extract_text(0, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_symbols", [127, 128, 129, 255, 256, 257, 1024, 128 * 8 - 1])
+def test_text_lengths_around_block_boundaries(n_symbols):
+    """the index length (incl. sentinel) on, one below and one above multiples of the 128-position
+    wavelet block: every rank up to position n, ranges of every symbol, the distinct symbols of
+    prefixes of every length and all located rows against the oracle"""
+    from oracle.seal_oracle import OracleFMIndex
+    from seal_amd import FMIndex
+    rng = random.Random(n_symbols)
+    # documents of 7 tokens + eos (8 symbols), the last one cut so that size() == n_symbols
+    body = n_symbols - 1
+    docs, left = [], body
+    while left > 0:
+        m = min(8, left)
+        docs.append([rng.randrange(3, 40) for _ in range(m - 1)] + [2] if m > 1 else [2])
+        left -= m
+    ix, orc = FMIndex(), OracleFMIndex()
+    ix.initialize(docs)
+    orc.initialize(docs)
+    assert ix.size() == orc.size() == n_symbols
+    n = ix.size()
+    for c in sorted({t + 10 for d in docs for t in d}):
+        assert ix.backward_search_step(c, 0, n) == orc.backward_search_step(c, 0, n)          # r + 1 = n + 1: quirk Q1
+        assert ix.backward_search_step(c, 0, n - 1) == orc.backward_search_step(c, 0, n - 1)  # r + 1 = n
+        assert ix.backward_search_step(c, n - 1, n - 1) == orc.backward_search_step(c, n - 1, n - 1)
+    seqs = [d[a:b] for d in docs[:20] for a in range(len(d)) for b in range(a + 1, len(d) + 1)]
+    lo, hi = ix.get_range_batch(seqs)
+    assert [(int(a), int(b)) for a, b in zip(lo, hi)] == [orc.get_range(s) for s in seqs]
+    for low, high in [(0, n), (0, n - 1), (1, n), (n - 1, n), (n // 2, n // 2 + 1), (126, min(n, 130))]:
+        if low < high <= n:
+            assert ix.distinct_count(low, high) == orc.distinct_count(low, high)
+    rows = list(range(n))
+    pos, doc = ix.locate_batch(rows)
+    assert pos.tolist() == [orc.locate(r) for r in rows]
+    assert doc.tolist() == [orc.get_doc_index_from_row(r) for r in rows]
