@@ -184,6 +184,21 @@ int fmi_dev_constrained_topk(fmi_t *h, void *stream, uint64_t batch, uint64_t be
                              uint64_t n_force, int64_t stop_at_count, int always_allow_eos, const uint32_t *d_first_bits,
                              void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc);
 
+/* The same step inside a decode LOOP that can vouch for its own continuity: `state_tag` (non-zero,
+ * the same for every step of one generate call) + `d_parent_rows[rows]` = for every row the row of
+ * the PREVIOUS call (same tag, cur_len - 1) whose sequence it extends by one token (the beam_idx of
+ * beam_search.py:661).  The index then keeps every row's prefix range between calls and advances it
+ * by ONE backward-search step instead of re-searching the whole prefix as the reference does
+ * (beam_search.py:87-105) -- same ranges, bit for bit.  Any break in the chain (other tag, other row
+ * count, cur_len not previous + 1, cur_len == 1) falls back to the full search.  state_tag == 0:
+ * identical to fmi_dev_constrained_topk.  One decode loop per index handle at a time. */
+int fmi_dev_constrained_topk_step(fmi_t *h, void *stream, uint64_t batch, uint64_t beams, uint64_t cur_len,
+                                  const int64_t *d_input_ids, const float *d_logits, const float *d_beam_scores,
+                                  uint64_t vocab, int64_t shift, int64_t pad_id, int64_t eos_id, const int64_t *force_from,
+                                  uint64_t n_force, int64_t stop_at_count, int always_allow_eos, const uint32_t *d_first_bits,
+                                  void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc,
+                                  uint64_t state_tag, const int64_t *d_parent_rows);
+
 /* locate + doc binning for n rows (seal/keys.py:320-324) */
 int fmi_dev_locate(fmi_t *h, void *stream, uint64_t n, const uint64_t *d_rows,
                    uint64_t *d_pos_out, uint64_t *d_doc_out);

@@ -80,10 +80,13 @@ class IndexBasedLogitsProcessor:
         return b
 
     def fused_topk(self, input_ids: torch.LongTensor, logits: torch.FloatTensor, beam_scores: torch.FloatTensor,
-                   batch: int, num_beams: int):
+                   batch: int, num_beams: int, parent_rows: Optional[torch.LongTensor] = None):
         """log_softmax + InfNanRemove + this constraint + beam scores + top-2K per query, fused
-        (``fmi_dev_constrained_topk``): returns (flat indices [B, 2K], unconstrained scores [B, 2K]) -- what
-        reference beam_search.py:244-307 computes through five [rows, vocab] intermediates."""
+        (``fmi_dev_constrained_topk_step``): returns (flat indices [B, 2K], unconstrained scores [B, 2K]) -- what
+        reference beam_search.py:244-307 computes through five [rows, vocab] intermediates.
+
+        ``parent_rows`` (the previous step's ``beam_idx``) lets the index advance every row's prefix
+        range by one backward-search step instead of re-searching the prefix (same ranges)."""
         dev = logits.device
         V = logits.shape[-1]
         want = 2 * num_beams
@@ -104,11 +107,13 @@ class IndexBasedLogitsProcessor:
             self.index._trace.append(("mask", ids.clone(), list(ff)))
         lg = logits.contiguous()
         bs = beam_scores.contiguous()
-        check(lib().fmi_dev_constrained_topk(
+        parent = parent_rows.contiguous() if parent_rows is not None else None
+        check(lib().fmi_dev_constrained_topk_step(
             self.index.handle, _stream_ptr(dev), batch, num_beams, cur_len, ids.data_ptr(), lg.data_ptr(), bs.data_ptr(), V, SHIFT,
             self.pad_token_id, self.eos_token_id, ff_arr, len(ff), int(self.stop_at_count), int(bool(self.always_allow_eos)),
             first.data_ptr() if first is not None else None, scratch.data_ptr(), scratch.numel() * 4,
-            top_idx.data_ptr(), top_con.data_ptr(), top_unc.data_ptr()))
+            top_idx.data_ptr(), top_con.data_ptr(), top_unc.data_ptr(),
+            (id(self) & 0x7FFFFFFFFFFFFFFF) or 1, parent.data_ptr() if parent is not None else None))
         return top_idx, top_unc
 
     def __call__(self, input_ids: torch.LongTensor, scores: torch.FloatTensor) -> torch.FloatTensor:
@@ -184,12 +189,13 @@ def constrained_beam_search(decoder, batch_size: int, num_beams: int, max_length
     beam_scores = beam_scores.view(R)
     row_base = (torch.arange(B, device=device) * K).unsqueeze(1)
     steps = []
+    beam_idx = None     # rows of the previous step that this step's rows extend (incremental constraint state)
     while True:
         logits = decoder.step(input_ids[:, -1])
         V = logits.shape[-1]
         proc = constrained_decoding_processor
         if proc is not None and fused and hasattr(proc, "fused_topk") and proc.supports_fused_topk(logits, K):
-            flat, next_scores = proc.fused_topk(input_ids, logits, beam_scores, B, K)
+            flat, next_scores = proc.fused_topk(input_ids, logits, beam_scores, B, K, parent_rows=beam_idx)
         else:
             logp = torch.log_softmax(logits.float(), dim=-1)
             processed = _inf_nan_remove(logp)

@@ -75,6 +75,9 @@ struct fmi {
     // workspace for fmi_dev_* (sized by fmi_dev_reserve)
     uint64_t ws_rows = 0;
     uint64_t ws_seq = 0;      // parity picks the queue-counter pair of the next fused constraint call
+    // incremental constraint state of fmi_dev_constrained_topk_step (per-row prefix ranges of the last call)
+    uint64_t state_tag = 0, state_rows = 0, state_len = 0;
+    int state_flip = 0;
     void *ws = nullptr;
     uint64_t ws_bytes = 0;
     uint64_t *d_probe_counter = nullptr;

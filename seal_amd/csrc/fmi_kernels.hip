@@ -467,7 +467,8 @@ __global__ __launch_bounds__(64) void k_prefix_ranges(FmiDev ix, uint64_t rows, 
                                 int64_t pad_id, int64_t eos_id, ForceFrom ff, int64_t stop_at_count,
                                 int always_allow_eos, uint64_t vocab, uint64_t words_per_row,
                                 uint32_t *bits, ExpandItem *items, ExpandItem *out_items, uint32_t *out_count,
-                                uint32_t out_cap, uint32_t *zero_next, uint64_t *probe_counter)
+                                uint32_t out_cap, uint32_t *zero_next, uint64_t *probe_counter,
+                                const uint64_t *st_in, const int64_t *parent, uint64_t *st_out)
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = r < rows;
@@ -482,14 +483,25 @@ __global__ __launch_bounds__(64) void k_prefix_ranges(FmiDev ix, uint64_t rows, 
         if (!(last == eos_id || last == pad_id)) {
             // get_range(force_decoding_from + sent[1:]) and get_count(... sent[1:-1])
             uint64_t l = 0, rr = ix.n;
-            const uint64_t total = ff.n + (cur_len - 1);
-            for (uint64_t t = 0; t < total; t++) {
-                if (t + 1 == total) count = (rr + 1) - l;
-                const int64_t tok = t < ff.n ? ff.tok[t] : sent[1 + (t - ff.n)];
-                bs_step(ix, (uint64_t)(tok + shift), l, rr, l, rr, &probes);
-                model += ix.levels;
+            if (st_in) {
+                // incremental: the row extends row parent[r] of the previous step, whose inclusive range
+                // [l, rr] after the same prefix was kept -- one backward-search step instead of len
+                const uint64_t pr = (uint64_t)parent[r];
+                l = st_in[2 * pr]; rr = st_in[2 * pr + 1];
+                count = (rr + 1) - l;
+                bs_step(ix, (uint64_t)(last + shift), l, rr, l, rr, &probes);
+                model += ix.levels * (uint32_t)(ff.n + (cur_len - 1));    // the reference re-searches the whole prefix
+            } else {
+                const uint64_t total = ff.n + (cur_len - 1);
+                for (uint64_t t = 0; t < total; t++) {
+                    if (t + 1 == total) count = (rr + 1) - l;
+                    const int64_t tok = t < ff.n ? ff.tok[t] : sent[1 + (t - ff.n)];
+                    bs_step(ix, (uint64_t)(tok + shift), l, rr, l, rr, &probes);
+                    model += ix.levels;
+                }
+                if (total == 0) count = (rr + 1) - l;
             }
-            if (total == 0) count = (rr + 1) - l;
+            if (st_out) { st_out[2 * r] = l; st_out[2 * r + 1] = rr; }
             lo = l; hi = rr + 1;
         }
         uint32_t *myrow = bits + r * words_per_row;
@@ -914,16 +926,19 @@ static inline ExpandItem *ws_items(fmi *h) { return (ExpandItem *)h->ws; }
 static inline ExpandItem *ws_queue(fmi *h) { return ws_items(h) + h->ws_rows; }
 static inline uint32_t *ws_bits(fmi *h) { return (uint32_t *)(ws_queue(h) + h->ws_rows * WS_QUEUE_PER_ROW); }
 static inline uint32_t *ws_qcount(fmi *h) { return ws_bits(h) + h->ws_rows * WS_BITS_WORDS; }
+// two buffers of (lo, inclusive hi) per row: the incremental constraint state of consecutive decode steps
+static inline uint64_t *ws_state(fmi *h, int which) { return (uint64_t *)(ws_qcount(h) + 64) + (uint64_t)which * 2 * h->ws_rows; }
 extern "C" int fmi_dev_reserve(fmi_t *h, uint64_t max_rows)
 {
     int rc = need_device(h); if (rc) return rc;
     if (max_rows <= h->ws_rows) return FMI_OK;
     if (h->ws) { HIPCHK(hipFree(h->ws)); h->ws = nullptr; h->ws_rows = 0; }
-    const uint64_t bytes = max_rows * (sizeof(ExpandItem) * (1 + WS_QUEUE_PER_ROW) + WS_BITS_WORDS * 4) + 256;
+    const uint64_t bytes = max_rows * (sizeof(ExpandItem) * (1 + WS_QUEUE_PER_ROW) + WS_BITS_WORDS * 4 + 32) + 256;
     HIPCHK(hipMalloc(&h->ws, bytes));
     h->ws_bytes = bytes; h->ws_rows = max_rows;
     HIPCHK(hipMemset(ws_qcount(h), 0, 64));   // [0..1] / [2..3]: alternating queue counters of the fused path, [4]: generic path
     h->ws_seq = 0;
+    h->state_tag = 0;
     return FMI_OK;
 }
 
@@ -1035,7 +1050,8 @@ static int launch_expand(fmi *h, hipStream_t st, ExpandItem *items, uint64_t row
 
 static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur_len, const int64_t *d_ids,
                              uint32_t *d_bits, uint64_t vocab, int64_t shift, int64_t pad_id, int64_t eos_id,
-                             const int64_t *force_from, uint64_t n_force, int64_t stop_at_count, int always_allow_eos)
+                             const int64_t *force_from, uint64_t n_force, int64_t stop_at_count, int always_allow_eos,
+                             uint64_t state_tag = 0, const int64_t *d_parent = nullptr)
 {
     if (cur_len < 2) { fmi_set_error("cur_len must be >= 2 (cur_len == 1 is the constant occurring_distinct mask, beam_search.py:73-77)"); return FMI_ERR_ARG; }
     if (n_force > MAX_FORCE) { fmi_set_error("force_decoding_from longer than %d", MAX_FORCE); return FMI_ERR_UNSUPPORTED; }
@@ -1056,11 +1072,18 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     if (expand_split(h, rows, ws_queue(h), qcap) == 1) {
         uint32_t *cur = ws_qcount(h) + 2 * (h->ws_seq & 1), *nxt = ws_qcount(h) + 2 * ((h->ws_seq + 1) & 1);
         h->ws_seq++;
+        // incremental prefix state: valid when the caller vouches (tag + parent rows) that this call extends,
+        // by exactly one token, the rows of the previous call with the same tag
+        const bool inc = state_tag && d_parent && h->state_tag == state_tag && h->state_rows == rows && h->state_len + 1 == cur_len;
+        const uint64_t *st_in = inc ? ws_state(h, h->state_flip) : nullptr;
+        uint64_t *st_out = state_tag ? ws_state(h, h->state_flip ^ 1) : nullptr;
+        if (state_tag) { h->state_tag = state_tag; h->state_rows = rows; h->state_len = cur_len; h->state_flip ^= 1; }
+        else h->state_tag = 0;
         if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
         auto pk = h->dev.nsb > 1 ? k_prefix_ranges<true> : k_prefix_ranges<false>;
         hipLaunchKernelGGL(pk, dim3(blocks_for(rows, 64)), dim3(64), 0, st, h->dev, rows, cur_len, d_ids, shift,
                            pad_id, eos_id, ff, stop_at_count, always_allow_eos, vocab, wpr, d_bits, items, ws_queue(h), cur,
-                           (uint32_t)qcap, nxt, pc);
+                           (uint32_t)qcap, nxt, pc, st_in, d_parent, st_out);
         int rc = launch_phase2<EMIT_BITS>(h, st, 1, ws_queue(h), cur, qcap, tgt);
         if (rc) return rc;
         if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
@@ -1068,7 +1091,9 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     }
     hipLaunchKernelGGL(k_prefix_ranges<false>, dim3(blocks_for(rows, 64)), dim3(64), 0, st, h->dev, rows, cur_len, d_ids, shift,
                        pad_id, eos_id, ff, stop_at_count, always_allow_eos, vocab, wpr, d_bits, items, (ExpandItem *)nullptr,
-                       (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, (uint64_t *)nullptr);
+                       (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, (uint64_t *)nullptr, (const uint64_t *)nullptr,
+                       (const int64_t *)nullptr, (uint64_t *)nullptr);
+    h->state_tag = 0;
     if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
     int rc = launch_expand<EMIT_BITS>(h, st, items, rows, ws_queue(h), ws_qcount(h) + 4, qcap, tgt);
     if (rc) return rc;
@@ -1113,6 +1138,18 @@ extern "C" int fmi_dev_constrained_topk(fmi_t *h, void *stream, uint64_t batch, 
                                         uint64_t n_force, int64_t stop_at_count, int always_allow_eos, const uint32_t *d_first_bits,
                                         void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc)
 {
+    return fmi_dev_constrained_topk_step(h, stream, batch, beams, cur_len, d_input_ids, d_logits, d_beam_scores, vocab, shift, pad_id,
+                                         eos_id, force_from, n_force, stop_at_count, always_allow_eos, d_first_bits, d_scratch,
+                                         scratch_bytes, d_top_idx, d_top_con, d_top_unc, 0, nullptr);
+}
+
+extern "C" int fmi_dev_constrained_topk_step(fmi_t *h, void *stream, uint64_t batch, uint64_t beams, uint64_t cur_len,
+                                             const int64_t *d_input_ids, const float *d_logits, const float *d_beam_scores,
+                                             uint64_t vocab, int64_t shift, int64_t pad_id, int64_t eos_id, const int64_t *force_from,
+                                             uint64_t n_force, int64_t stop_at_count, int always_allow_eos, const uint32_t *d_first_bits,
+                                             void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc,
+                                             uint64_t state_tag, const int64_t *d_parent_rows)
+{
     int rc = need_device(h); if (rc) return rc;
     const uint64_t rows = batch * beams, want = 2 * beams;
     if (rows == 0) return FMI_OK;
@@ -1131,10 +1168,11 @@ extern "C" int fmi_dev_constrained_topk(fmi_t *h, void *stream, uint64_t batch, 
     if (cur_len < 2) {
         if (!d_first_bits) { fmi_set_error("cur_len == 1 needs the occurring_distinct bitmap"); return FMI_ERR_ARG; }
         bits = d_first_bits; broadcast = 1;      // the constant first-step mask (beam_search.py:73-77)
+        h->state_tag = 0;
     } else {
         if (rows > h->ws_rows) { rc = fmi_dev_reserve(h, rows); if (rc) return rc; }
         rc = allowed_bits_impl(h, st, rows, cur_len, d_input_ids, ws_bits(h), vocab, shift, pad_id, eos_id, force_from, n_force,
-                               stop_at_count, always_allow_eos);
+                               stop_at_count, always_allow_eos, state_tag, d_parent_rows);
         if (rc) return rc;
         bits = ws_bits(h);
     }
