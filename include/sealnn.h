@@ -14,9 +14,12 @@ extern "C" {
 /* single-position self-attention with KV-cache append.
  *   qkv    [rows, 3, heads, 64] fp32 (q, k, v of the new position; q already scaled or scale passed)
  *   kcache, vcache [rows, heads, T, 64]; position *d_t is written, positions 0..*d_t attended
- *   out    [rows, heads*64] */
+ *   out    [rows, heads*64]
+ *   anc    NULL, or [T, rows] int32: the cache is addressed through it -- position p of `row`'s history
+ *          is slot p of row anc[p][row] -- and anc[*d_t][row] = row is written.  Re-ranking beams
+ *          (HF _reorder_cache) then permutes the columns of this table instead of the cache. */
 int sealnn_self_attn_step(void *stream, const float *qkv, float *kcache, float *vcache, const int64_t *d_t,
-                          uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out);
+                          uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out, int32_t *anc);
 
 /* single-position cross-attention, encoder K/V shared by the `beams` rows of a query.
  *   q [batch*beams, heads, 64]; ck [batch, heads, 64, S]; cv [batch, heads, S, 64]; bias [batch, S] (0 / -big)

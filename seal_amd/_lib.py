@@ -79,7 +79,7 @@ _f32 = ctypes.c_float
 _u32 = ctypes.c_uint32
 # include/sealnn.h (fused decoder-step kernels, same shared library)
 NN_SIGNATURES = {
-    "sealnn_self_attn_step": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp]),
+    "sealnn_self_attn_step": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp, _vp]),
     "sealnn_cross_attn_step": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _vp]),
     "sealnn_add_layernorm": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp]),
     "sealnn_causal_self_attn": (_int, [_vp, _vp, _u32, _u32, _u32, _f32, _vp]),

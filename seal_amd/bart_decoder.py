@@ -83,6 +83,10 @@ class BartStepDecoder:
             st.tokens = torch.zeros(R, dtype=torch.long, device=dev)
             st.t = torch.zeros(1, dtype=torch.long, device=dev)
             st.kv = torch.zeros(nl, 2, R, H, T, dh, dtype=dtype, device=dev)
+            # fused path: history of row r at position p = cache slot (anc[p, r], p); beams are re-ranked
+            # by permuting the columns of this table, the cache itself never moves
+            st.anc = torch.arange(R, dtype=torch.int32, device=dev).repeat(T, 1).contiguous()
+            st.fused = False
             st.ck = torch.zeros(nl, B, H, dh, S_pad, dtype=dtype, device=dev)
             st.cv = torch.zeros(nl, B, H, S_pad, dh, dtype=dtype, device=dev)
             st.cbias = torch.zeros(B, 1, 1, S_pad, dtype=dtype, device=dev)
@@ -155,6 +159,7 @@ class BartStepDecoder:
         x = x + self.pos.weight.index_select(0, st.t + self.pos_offset)
         x = self.ln_emb(x)
         fused = (self.use_fused_kernels and x.dtype == torch.float32 and dh == 64 and T <= 17 and S_pad <= 64 and x.is_cuda)
+        st.fused = fused
         if fused:
             from ._lib import check, lib
             L_ = lib()
@@ -170,7 +175,7 @@ class BartStepDecoder:
                 qkv = F.linear(x, L["qkv_w"], L["qkv_b"])
                 a = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
                 check(L_.sealnn_self_attn_step(stream, qkv.data_ptr(), st.kv[li, 0].data_ptr(), st.kv[li, 1].data_ptr(),
-                                               st.t.data_ptr(), R, H, T, float(self.scale), a.data_ptr()))
+                                               st.t.data_ptr(), R, H, T, float(self.scale), a.data_ptr(), st.anc.data_ptr()))
                 x = add_ln(x, L["so"](a), L["ln1"])
                 q = L["cq"](x)
                 c = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
@@ -256,7 +261,10 @@ class BartStepDecoder:
     def reorder(self, beam_idx: torch.Tensor) -> None:
         """new row r continues old row beam_idx[r] (HF ``_reorder_cache``)."""
         if getattr(self, "_st", None) is not None:
-            self._st.kv.copy_(self._st.kv.index_select(2, beam_idx))
+            if self._st.fused:
+                self._st.anc.copy_(self._st.anc.index_select(1, beam_idx))
+            else:
+                self._st.kv.copy_(self._st.kv.index_select(2, beam_idx))
             return
         self.kv[:, :, :, :, :self.t] = self.kv[:, :, beam_idx, :, :self.t]
 

@@ -17,9 +17,12 @@ static __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
-// one wavefront per (row, head); lane = head dimension
+// one wavefront per (row, head); lane = head dimension.  `anc` (optional, [T][rows]): the cache is
+// never reordered when beams are re-ranked; instead anc[p][row] names the row whose slot at position p
+// belongs to `row`'s history (the decoder permutes this 20 KB table, not the 100+ MB cache).
 __global__ __launch_bounds__(256) void k_self_attn_step(const float *qkv, float *kcache, float *vcache, const int64_t *d_t,
-                                                        uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out)
+                                                        uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out,
+                                                        int32_t *anc)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -34,11 +37,13 @@ __global__ __launch_bounds__(256) void k_self_attn_step(const float *qkv, float 
     float *vc = vcache + ((uint64_t)row * heads + head) * T * 64;
     kc[(uint64_t)t * 64 + lane] = kn;
     vc[(uint64_t)t * 64 + lane] = vn;
+    if (anc && head == 0 && lane == 0) anc[(uint64_t)t * rows + row] = (int32_t)row;
     // scores over positions 0..t (the new one from registers)
     float s[FMI_MAX_LEVELS];          // T <= 17 positions kept in registers
     float m = -__builtin_huge_valf();
     for (uint32_t p = 0; p <= t; p++) {
-        const float kv = (p == t) ? kn : kc[(uint64_t)p * 64 + lane];
+        const uint64_t src = anc ? ((uint64_t)anc[(uint64_t)p * rows + row] * heads + head) * T * 64 : ((uint64_t)row * heads + head) * T * 64;
+        const float kv = (p == t) ? kn : kcache[src + (uint64_t)p * 64 + lane];
         const float d = wave_sum(q * kv);
         s[p] = d;
         m = fmaxf(m, d);
@@ -47,7 +52,8 @@ __global__ __launch_bounds__(256) void k_self_attn_step(const float *qkv, float 
     for (uint32_t p = 0; p <= t; p++) {
         const float e = expf(s[p] - m);
         denom += e;
-        const float vv = (p == t) ? vn : vc[(uint64_t)p * 64 + lane];
+        const uint64_t src = anc ? ((uint64_t)anc[(uint64_t)p * rows + row] * heads + head) * T * 64 : ((uint64_t)row * heads + head) * T * 64;
+        const float vv = (p == t) ? vn : vcache[src + (uint64_t)p * 64 + lane];
         acc += e * vv;
     }
     out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
@@ -175,11 +181,11 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const float *x, const flo
 #define NNCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { fmi_set_error("sealnn launch failed: %s", hipGetErrorString(e_)); return FMI_ERR_HIP; } } while (0)
 
 extern "C" int sealnn_self_attn_step(void *stream, const float *qkv, float *kcache, float *vcache, const int64_t *d_t, uint32_t rows,
-                                     uint32_t heads, uint32_t T, float scale, float *out)
+                                     uint32_t heads, uint32_t T, float scale, float *out, int32_t *anc)
 {
     if (T > FMI_MAX_LEVELS) { fmi_set_error("sealnn_self_attn_step: at most %u cached positions", FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
     const uint32_t items = rows * heads;
-    hipLaunchKernelGGL(k_self_attn_step, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, kcache, vcache, d_t, rows, heads, T, scale, out);
+    hipLaunchKernelGGL(k_self_attn_step, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, kcache, vcache, d_t, rows, heads, T, scale, out, anc);
     NNCHK();
     return FMI_OK;
 }
