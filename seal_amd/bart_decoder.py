@@ -148,7 +148,7 @@ class BartStepDecoder:
                                             N * T, self.h, S, float(self.scale), c.data_ptr()))
             x = add_ln(x, L["co"](c), L["ln2"])
             x = add_ln(x, L["fc2"](L["act"](L["fc1"](x))), L["ln3"])
-        return (F.linear(x, self.lm_w) + self.lm_b).view(N, T, -1)
+        return F.linear(x, self.lm_w, self.lm_b.view(-1)).view(N, T, -1)
 
     use_fused_kernels = True      # include/sealnn.h: self-attn / cross-attn / add+LayerNorm as single HIP kernels
 
@@ -184,7 +184,7 @@ class BartStepDecoder:
                 x = add_ln(x, L["co"](c), L["ln2"])
                 x = add_ln(x, L["fc2"](L["act"](L["fc1"](x))), L["ln3"])
             st.t.add_(1)
-            return (F.linear(x, self.lm_w) + self.lm_b).float()
+            return F.linear(x, self.lm_w, self.lm_b.view(-1)).float()
         future = st.pos_idx > st.t                                   # cache slots not written yet
         for li, L in enumerate(self.layers):
             qkv = F.linear(x, L["qkv_w"], L["qkv_b"]).view(R, 3, H, dh)
@@ -200,7 +200,7 @@ class BartStepDecoder:
             x = L["ln2"](x + L["co"](c))
             x = L["ln3"](x + L["fc2"](L["act"](L["fc1"](x))))
         st.t.add_(1)
-        return (F.linear(x, self.lm_w) + self.lm_b).float()
+        return F.linear(x, self.lm_w, self.lm_b.view(-1)).float()
 
     @torch.no_grad()
     def start(self, enc_hidden: torch.Tensor, attention_mask: torch.Tensor, num_beams: int, max_len: int) -> None:
@@ -301,7 +301,7 @@ class BartStepDecoder:
             x = L["ln2"](x + L["co"](c))
             x = L["ln3"](x + L["fc2"](L["act"](L["fc1"](x))))
         self.t += 1
-        logits = (F.linear(x, self.lm_w) + self.lm_b).float()
+        logits = F.linear(x, self.lm_w, self.lm_b.view(-1)).float()
         if self.logit_bias is not None:
             logits = (logits.view(B, K, -1) + self.logit_bias[:, None, :]).view(R, -1)
         return logits
