@@ -542,14 +542,29 @@ class SEALSearcher:
                                          **self._aggregate_params()))
                 continue
             yield from rk.aggregate_evidence_batch(jobs, self.fm_index, defer=defer, keep=keep, **self._aggregate_params())
+        import os, sys, time
+        tm = os.environ.get("SEAL_AGG_TIMING")
+        t_end = time.perf_counter()
         for fut in pending:
-            for res, ngrams in fut.result():
+            t0 = time.perf_counter()
+            batch_out = fut.result()
+            t1 = time.perf_counter()
+            for res, ngrams in batch_out:
                 yield (res.result() if hasattr(res, "result") else res), ngrams
+            if tm:
+                print("[agg] after the last chunk was decoded: waited %.1f ms for the aggregation thread, %.1f ms for the workers of a chunk; %.1f ms since the decode ended"
+                      % ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3, (time.perf_counter() - t_end) * 1e3), file=sys.stderr, flush=True)
 
     def _agg_thread(self):
         if getattr(self, "_agg_pool", None) is None:
+            import sys
             from concurrent.futures import ThreadPoolExecutor
             self._agg_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="seal-aggregate")
+            # the decode loop on the main thread feeds the GPU a ~3 ms step at a time; with CPython's
+            # default 5 ms switch interval every hand-over of the GIL from the aggregation thread
+            # starves the GPU for up to two steps
+            if sys.getswitchinterval() > 5e-4:
+                sys.setswitchinterval(5e-4)
         return self._agg_pool
 
     def doc(self, docid: Union[str, int]) -> Optional[SEALDocument]:
