@@ -236,7 +236,7 @@ class BartStepDecoder:
             torch.cuda.current_stream(enc_hidden.device).wait_stream(side)
             st.t.zero_()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # the aggregation thread may touch the GPU meanwhile
                 st.logits = self._step_static(st)
             st.graph = g
             st.t.zero_()
