@@ -147,3 +147,49 @@ def test_rescore_keys_fused_teacher_forcing_matches_hf_forward():
             assert [k for _, k in qa] == [k for _, k in qb]
             for (sa, _), (sb, _) in zip(qa, qb):
                 assert abs(sa - sb) <= 3e-5 * max(1.0, abs(sb)), kw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(force_decoding_from=[2], eos_token_id=7), dict(stop_at_count=2)])
+def test_incremental_constraint_state_equals_full_prefix_search(kw):
+    """constrained_beam_search hands the previous step's beam_idx to fmi_dev_constrained_topk_step, which then
+    advances every row's prefix range by one backward-search step; a processor that withholds the parents
+    makes the index re-search the whole prefix every step (the reference's way).  Same logits -> the two
+    loops must produce identical histories, bit for bit."""
+    from seal_amd import FMIndex
+    from seal_amd.beam_search import IndexBasedLogitsProcessor, constrained_beam_search
+    from tests.helpers import make_docs
+    vocab, B, K, T = 120, 6, 5, 9
+    dev = torch.device("cuda:0")
+    docs = make_docs(5, 200, vocab - 8, title_sep=7)
+    eos = kw.get("eos_token_id", 2)
+
+    class RandomDecoder:
+        """deterministic logits per (step, row): biased towards low token ids so that eos/pad and real
+        corpus continuations all show up"""
+        def __init__(self):
+            self.t = 0
+
+        def step(self, tokens):
+            g = torch.Generator(device="cpu").manual_seed(100 + self.t)
+            self.t += 1
+            lg = torch.randn(B * K, vocab, generator=g) * 3
+            lg[:, 0] = float("-inf")
+            return lg.to(dev)
+
+        def reorder(self, beam_idx):
+            pass
+
+    class NoParents(IndexBasedLogitsProcessor):
+        def fused_topk(self, input_ids, logits, beam_scores, batch, num_beams, parent_rows=None):
+            return super().fused_topk(input_ids, logits, beam_scores, batch, num_beams, parent_rows=None)
+
+    out = []
+    for cls in (IndexBasedLogitsProcessor, NoParents):
+        ix = FMIndex()                  # one index handle per loop: the state lives in the handle
+        ix.initialize(docs)
+        proc = cls(ix, K, pad_token_id=1, eos_token_id=eos, force_decoding_from=kw.get("force_decoding_from"),
+                   stop_at_count=kw.get("stop_at_count", 0))
+        steps, final = constrained_beam_search(RandomDecoder(), B, K, T, 2, eos, proc, device=dev)
+        out.append(([tuple(x.tolist() for x in s) for s in steps], final[0].tolist(), final[1].tolist()))
+    assert out[0] == out[1]
