@@ -311,6 +311,8 @@ def main():
     # secondary figure: the same K batches through the other retrieval depth (first stage only <-> complete)
     other_qps = None
     if not os.environ.get("SEAL_BENCH_SKIP_OTHER"):
+        gc.collect()
+        gc.freeze()                                       # keep the timed run's results out of later collections
         searcher.first_stage_only = not args.first_stage_only
         run_batch(0)
         torch.cuda.synchronize()
