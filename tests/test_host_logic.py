@@ -145,10 +145,14 @@ def test_zipf_corpus_q1_against_oracle():
         lib().fmi_free(h)
 
 
-def test_save_load_round_trip(tmp_path):
+@pytest.mark.parametrize("force_sb", [None, 1])
+def test_save_load_round_trip(tmp_path, force_sb, monkeypatch):
     rng = random.Random(9)
     data = _rand_data(rng, 1000, 300)
+    if force_sb is not None:          # the superblocked layout; the file carries sb_shift, the loader must not need the env
+        monkeypatch.setenv("SEALFM_FORCE_SB", str(force_sb))
     h = _host_index(data)
+    monkeypatch.delenv("SEALFM_FORCE_SB", raising=False)
     path = str(tmp_path / "x.fmi").encode()
     check(lib().fmi_save(h, path))
     h2 = ctypes.c_void_p()
@@ -157,6 +161,7 @@ def test_save_load_round_trip(tmp_path):
         for name in ("sa", "bwt", "text", "C", "leaf", "q1", "dbase", "sbase", "wm"):
             assert np.array_equal(_arr(h, name), _arr(h2, name)), name
         assert lib().fmi_size(h2) == 1001 and lib().fmi_levels(h2) == lib().fmi_levels(h)
+        assert len(_arr(h2, "sbase")) == (16 * ((1001 // 128 + 2 >> force_sb) + 1) if force_sb is not None else 16) * ((lib().fmi_levels(h) + 3) // 4)
     finally:
         lib().fmi_free(h)
         lib().fmi_free(h2)
