@@ -560,6 +560,7 @@ __device__ __forceinline__ float logp_processed(float x, float mx, float lsum)
 
 // one workgroup (1024 threads) per row: max and log(sum(exp(x - max)))
 static constexpr int ROW_BLOCK = 1024;
+static constexpr int TOPK_NARROW = 1024;     // rows with at most this many allowed tokens are selected in LDS (k_row_topk)
 __global__ __launch_bounds__(ROW_BLOCK) void k_row_lse(const float *logits, uint64_t vocab, float *row_max, float *row_lsum)
 {
     __shared__ float s_a[ROW_BLOCK / 64], s_b[ROW_BLOCK / 64];
@@ -606,8 +607,10 @@ __device__ __forceinline__ uint32_t float_key(float f)
 __global__ __launch_bounds__(ROW_BLOCK) void k_row_topk(const float *logits, const uint32_t *bits, uint64_t words_per_row,
                                                   uint32_t row_broadcast_bits, uint64_t vocab, const float *row_max,
                                                   const float *row_lsum, uint32_t want, int32_t *row_tok, float *row_lp,
-                                                  uint32_t *row_cnt)
+                                                  uint32_t *row_cnt, uint32_t narrow_max)
 {
+    __shared__ int32_t s_gtok[TOPK_NARROW];
+    __shared__ float s_gval[TOPK_NARROW];
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_prefix, s_remaining, s_n_gt, s_n_eq, s_total;
     __shared__ int32_t s_ctok[TOPK_MAX];
@@ -634,6 +637,33 @@ __global__ __launch_bounds__(ROW_BLOCK) void k_row_topk(const float *logits, con
     const uint32_t total = s_total;
     const uint32_t k_sel = total < want ? total : want;        // how many we will output
     if (k_sel == 0) { if (tid == 0) row_cnt[row] = 0; return; }
+    if (total <= narrow_max) {
+        // narrow row (most decode steps after the first few): one pass over the bitmap words gathers the
+        // allowed tokens into LDS, every candidate then finds its own rank under the output order
+        // (value descending, ties to the lower token id) -- no radix passes, no per-chunk barriers
+        for (uint64_t w = tid; w < words_per_row; w += ROW_BLOCK) {
+            uint32_t word = b[w];
+            if ((w + 1) * 32 > vocab) { const uint32_t keep = (uint32_t)(vocab - w * 32); word &= keep >= 32 ? ~0u : ((1u << keep) - 1); }
+            while (word) {
+                const uint32_t tok = (uint32_t)(w * 32) + (uint32_t)__builtin_ctz(word);
+                word &= word - 1;
+                const uint32_t o = atomicAdd(&s_n_gt, 1u);
+                s_gtok[o] = (int32_t)tok; s_gval[o] = logp_processed(x[tok], mx, ls);
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < total; i += ROW_BLOCK) {
+            const float v = s_gval[i]; const int32_t t = s_gtok[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < total; j++) {
+                const float ov = s_gval[j]; const int32_t ot = s_gtok[j];
+                rank += (ov > v) || (ov == v && ot < t);
+            }
+            if (rank < k_sel) { row_tok[(uint64_t)row * want + rank] = t; row_lp[(uint64_t)row * want + rank] = v; }
+        }
+        if (tid == 0) row_cnt[row] = k_sel;
+        return;
+    }
     uint32_t T = 0;
     if (total > want) {
         for (int pass = 0; pass < 4; pass++) {
@@ -1177,8 +1207,10 @@ extern "C" int fmi_dev_constrained_topk_step(fmi_t *h, void *stream, uint64_t ba
         bits = ws_bits(h);
     }
     hipLaunchKernelGGL(k_row_lse, dim3((unsigned)rows), dim3(ROW_BLOCK), 0, st, d_logits, vocab, row_max, row_lsum);
+    const char *e_narrow = getenv("SEALFM_TOPK_NARROW");      // tests: 0 forces the radix-select path on every row
+    const uint32_t narrow_max = e_narrow ? std::min<uint32_t>((uint32_t)atoi(e_narrow), TOPK_NARROW) : TOPK_NARROW;
     hipLaunchKernelGGL(k_row_topk, dim3((unsigned)rows), dim3(ROW_BLOCK), 0, st, d_logits, bits, wpr, broadcast, vocab, row_max, row_lsum,
-                       (uint32_t)want, row_tok, row_lp, row_cnt);
+                       (uint32_t)want, row_tok, row_lp, row_cnt, narrow_max);
     hipLaunchKernelGGL(k_query_merge, dim3((unsigned)batch), dim3(64), 0, st, d_logits, bits, wpr, broadcast, vocab, (uint32_t)beams,
                        (uint32_t)want, d_beam_scores, row_max, row_lsum, row_tok, row_lp, row_cnt, d_top_idx, d_top_con, d_top_unc);
     HIPCHK(hipGetLastError());

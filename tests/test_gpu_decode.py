@@ -74,11 +74,14 @@ def test_graph_captured_step_matches_eager_step():
         enc_ids = torch.roll(enc_ids, 1, 0)
 
 
+@pytest.mark.parametrize("narrow", ["1024", "0"], ids=["lds-select", "radix-select"])
 @pytest.mark.parametrize("kw", [dict(), dict(force_decoding_from=[2], eos_token_id=7), dict(always_allow_eos=True),
                                 dict(stop_at_count=2)])
-def test_fused_constrained_topk_matches_unfused_step(kw):
+def test_fused_constrained_topk_matches_unfused_step(kw, narrow, monkeypatch):
     """fmi_dev_constrained_topk against the reference's own sequence of ops on the same logits: same picks (as a set
-    per query: ties/-inf fillers are unordered in torch.topk too), unconstrained scores within fp32 noise."""
+    per query: ties/-inf fillers are unordered in torch.topk too), unconstrained scores within fp32 noise.
+    Both selection paths of k_row_topk: rows of <= 1024 allowed tokens ranked in LDS, and the radix select."""
+    monkeypatch.setenv("SEALFM_TOPK_NARROW", narrow)
     from seal_amd import FMIndex
     from seal_amd.beam_search import IndexBasedLogitsProcessor, _inf_nan_remove
     from tests.helpers import make_docs
@@ -193,3 +196,36 @@ def test_incremental_constraint_state_equals_full_prefix_search(kw):
         steps, final = constrained_beam_search(RandomDecoder(), B, K, T, 2, eos, proc, device=dev)
         out.append(([tuple(x.tolist() for x in s) for s in steps], final[0].tolist(), final[1].tolist()))
     assert out[0] == out[1]
+
+
+@pytest.mark.gpu
+def test_topk_selection_paths_agree_on_ties(monkeypatch):
+    """k_row_topk has two selection paths (LDS ranking for rows of <= 1024 allowed tokens, radix select beyond);
+    on heavily tied logits both must return the same picks in the same order (ties go to the lower token id)."""
+    from seal_amd import FMIndex
+    from seal_amd.beam_search import IndexBasedLogitsProcessor
+    from tests.helpers import make_docs
+    vocab, B, K = 300, 4, 6
+    dev = torch.device("cuda:0")
+    docs = make_docs(11, 400, vocab - 8, title_sep=7)
+    ix = FMIndex()
+    ix.initialize(docs)
+    proc = IndexBasedLogitsProcessor(ix, K, pad_token_id=1, eos_token_id=2)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    import random
+    rng = random.Random(3)
+    for cur_len in (1, 2, 3):
+        rows = []
+        for _ in range(B * K):
+            d = rng.choice(docs)
+            a = rng.randrange(len(d))
+            rows.append(([2] + d[a:a + cur_len - 1] + [1] * cur_len)[:cur_len])
+        ids = torch.tensor(rows, device=dev)
+        logits = torch.randint(-2, 3, (B * K, vocab), generator=g).float().to(dev)     # five distinct values: ties everywhere
+        beam_scores = torch.randint(-2, 2, (B * K,), generator=g).float().to(dev)
+        got = []
+        for narrow in ("1024", "0"):
+            monkeypatch.setenv("SEALFM_TOPK_NARROW", narrow)
+            flat, unc = proc.fused_topk(ids, logits, beam_scores, B, K)
+            got.append((flat.tolist(), unc.tolist()))
+        assert got[0] == got[1], cur_len
