@@ -227,26 +227,31 @@ def constrained_beam_search(decoder, batch_size: int, num_beams: int, max_length
 
 def _history_to_hypotheses(steps, final, batch_size: int, num_beams: int, length_penalty: float):
     """BeamHypothesesWithMemory.add (752-755) + the output comprehension of
-    fm_index_generate (555), done on the host after one transfer."""
+    fm_index_generate (555), done on the host after the transfer.  ``add`` computes
+    ``score = sum_logprobs / size**lp``, keeps the hypothesis iff ``score > -inf`` and the output
+    multiplies the ``size**lp`` back: the same python-float operations here, per element, with the
+    token lists built by one ``tolist`` per step instead of a list concatenation per hypothesis."""
     B, K = batch_size, num_beams
     out = [[] for _ in range(B)]
+    ninf = float("-inf")
 
-    def add(b, score32: float, toks):
-        size = len(toks)
-        score = score32 / (size ** length_penalty)      # python floats, as .item() gave the reference
-        if score > float("-inf"):
-            out[b].append((score * size ** length_penalty, toks))
+    def extend(scores, seqs, size):
+        norm = size ** length_penalty                    # python pow, as .item() floats gave the reference
+        if norm == 1.0:                                   # x / 1.0 * 1.0 == x exactly
+            return [(s, q) for s, q in zip(scores, seqs) if s > ninf]
+        return [((s / norm) * norm, q) for s, q in zip(scores, seqs) if (s / norm) > ninf]
 
     for prefix, tokens, scores in steps:
-        prefix, tokens, scores = prefix.tolist(), tokens.tolist(), scores.tolist()
+        size = prefix.shape[-1] + 1
+        seqs = torch.cat([prefix, tokens.unsqueeze(-1)], dim=-1).tolist()      # [B][2K][size]
+        sc = scores.tolist()
         for b in range(B):
-            for j in range(2 * K):
-                add(b, scores[b][j], prefix[b][j] + [tokens[b][j]])
+            out[b] += extend(sc[b], seqs[b], size)
     ids, fscores = final
+    size = ids.shape[-1]
     ids, fscores = ids.tolist(), fscores.tolist()
     for b in range(B):
-        for j in range(K):
-            add(b, fscores[b * K + j], ids[b * K + j])
+        out[b] += extend(fscores[b * K:(b + 1) * K], ids[b * K:(b + 1) * K], size)
     return out
 
 
