@@ -1,5 +1,5 @@
 """Host logic of the decode side on CPU: the step decoder against HF's own
-forward, and the tensorised beam loop + history scorer against the line-by-line
+forward, and the tensorised beam loop + history scorer against the scalar
 restatement of the reference loop (oracle/beam_oracle.py)."""
 import pytest
 import torch

@@ -1,5 +1,5 @@
 """Host logic of seal_amd.keys on CPU: the batched/vectorised aggregate_evidence
-against the scalar, line-by-line restatement (oracle/keys_oracle.py)."""
+against the scalar, stage-by-stage model of the reference (oracle/keys_oracle.py)."""
 import numpy as np
 import pytest
 
