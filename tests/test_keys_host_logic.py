@@ -172,3 +172,41 @@ def test_deferred_full_scoring_in_a_worker_process_matches_inline():
         assert got[d][0] == info[0] and got[d][3] == info[3]
         assert [(tuple(n), s) for n, s in got[d][1]] == [(tuple(n), s) for n, s in info[1]]
         assert tuple(got[d][4][0]) == tuple(info[4][0]) and got[d][4][1] == info[4][1]
+
+
+def test_aggregate_evidence_random_option_sweep():
+    """60 random draws over every option of aggregate_evidence (both stages, all three "best key"
+    modes, overlaps, single-key blending, unigram fill variants, tied unigram scores, repeated keys,
+    tight occurrence / shortlist limits): product == oracle, exactly"""
+    import random
+    opts = dict(
+        with_unigrams=[False, True], first_stage_only=[False, True], mode=["score", "length", "freq"],
+        allow_overlaps=[False, True], single_key=[0.0, 0.3, 1.0], use_fm_index_frequency=[True, False],
+        add_best_unigrams_to_ngrams=[False, True], single_key_add_unigrams=[False, True],
+        unigrams_ignore_free_places=[False, True], max_occurrences_1=[3, 20, 1500], n_docs_complete_score=[2, 10, 500],
+        use_top_k_unigrams=[0, 5, 1000], beta=[0.0, 0.8, 1.0], alpha=[1.0, 2.0], length_penalty=[0.0, 0.2], smoothing=[5.0, 0.5])
+    pick = random.Random(7)
+    compared = 0
+    for it in range(60):
+        kw = {k: pick.choice(v) for k, v in opts.items()}
+        mode = kw.pop("mode")
+        kw["sort_by_length"], kw["sort_by_freq"] = mode == "length", mode == "freq"
+        with_unigrams = kw.pop("with_unigrams")
+        vocab, n_docs = pick.choice([12, 40, 300]), pick.choice([5, 40, 150])
+        rng = np.random.default_rng(1000 + it)
+        docs = make_docs(1000 + it, n_docs, vocab, title_sep=7)
+        orc = OracleFMIndex()
+        orc.initialize(docs)
+        keys = synthetic_keys(rng, docs, vocab, n_keys=int(rng.integers(5, 50)), with_titles=True)
+        if it % 2:
+            keys += [keys[0], (keys[1][0], keys[1][1] - 0.3)]       # a repeated key keeps its place, takes the later score
+        us = None
+        if with_unigrams:
+            us = (-(rng.random(vocab + 12) * 9 + 0.05)).tolist()
+            if it % 3 == 0:
+                us = [float(min(round(x), -1)) for x in us]        # ties among unigram scores
+        got = aggregate_evidence(keys, unigram_scores=us, index=OracleBatchIndex(orc), **kw)
+        want = oracle_aggregate_evidence(keys, unigram_scores=us, index=orc, **kw)
+        _same(got, want)
+        compared += len(want[0])
+    assert compared > 300
