@@ -1,5 +1,9 @@
 """TEST INFRASTRUCTURE ONLY -- plain restatements of the reference's decode-side
-Python semantics, run on the CPU against an ``OracleFMIndex``.
+Python semantics, run on the CPU against an ``OracleFMIndex``.  PINNED against the reference's
+own code: tests/golden/ref_index_and_mask.json (IndexBasedLogitsProcessor.__call__) and
+ref_beam_search.json (the whole fm_index_generate with keep_history) were produced by running
+seal/beam_search.py itself (tests/golden/make_reference_golden.py); tests/test_reference_golden.py
+checks both functions below against them.
 
 * ``oracle_logits_mask``: IndexBasedLogitsProcessor.__call__
   (reference seal/beam_search.py:62-140), returning the boolean "allowed" matrix.

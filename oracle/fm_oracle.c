@@ -25,6 +25,11 @@
  *     sort + naive substring counting (mathematical facts: counts, SA
  *     positions, doc ids are layout independent) and the SURVEY.md G1/G2
  *     vectors.
+ * Everything ABOVE this file is pinned against the reference's own Python, run
+ * in this container on top of this file (tests/golden/make_reference_golden.py,
+ * tests/test_reference_golden.py): seal/index.py, the logits processor and the
+ * whole decode of seal/beam_search.py, aggregate_evidence / rescore_keys /
+ * compute_unigram_scores of seal/keys.py.  "Unpinned" is this C layer only.
  * The only layout-dependent behaviour is quirk Q1 (search started from the
  * inclusive upper end r = size(), index.py:106-107, one past the last row, with
  * sdsl's asserts compiled out); it falls out of the faithful wt_int::rank loop

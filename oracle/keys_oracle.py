@@ -6,7 +6,11 @@ way the reference does (get_count per key, locate + get_doc_index per row, get_d
 document), and every place where the reference's RESULT depends on an order of evaluation
 (dict insertion order, stable sorts, the order in which overlapping matches are registered,
 heap order, float operation order) reproduces that order explicitly and says why.
-Runs against an ``OracleFMIndex``.  PARITY UNPINNED (see fm_oracle.c header).
+Runs against an ``OracleFMIndex``.  PINNED against the reference's own code for this layer:
+tests/golden/ref_aggregate_evidence.json and ref_helpers.json were produced by running
+seal/keys.py itself (tests/golden/make_reference_golden.py) and tests/test_reference_golden.py
+checks this file (and the product's host logic) against them bit for bit.  The C++/sdsl layer
+underneath stays PARITY UNPINNED (see fm_oracle.c header).
 """
 import heapq
 import math

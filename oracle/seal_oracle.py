@@ -1,7 +1,10 @@
 """TEST INFRASTRUCTURE ONLY -- CPU oracle for the SEAL FM-index path.
 
-PARITY UNPINNED (see oracle/fm_oracle.c header): the reference cannot be run
-here (sdsl-lite + SWIG absent, no golden vectors in the reference tree).
+PARITY UNPINNED for the C++ layer (see oracle/fm_oracle.c header): sdsl-lite + SWIG are absent and the
+reference tree holds no golden vectors, so ``CppFMIndex`` is pinned by brute force only.  The Python
+layer above it is pinned: tests/golden/ref_index_and_mask.json was produced by the reference's own
+``seal/index.py`` running on ``CppFMIndex`` (tests/golden/make_reference_golden.py) and
+tests/test_reference_golden.py checks ``OracleFMIndex`` against it.
 
 Two layers, each a restatement of a reference layer:
 

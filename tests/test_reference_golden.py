@@ -1,0 +1,174 @@
+"""Vectors produced by the reference's OWN Python (tests/golden/ref_*.json, written by
+tests/golden/make_reference_golden.py from /root/reference/seal/{index,keys,beam_search}.py running on the oracle's
+model of the C++ layer) against the oracle restatements and the product's host logic.  Everything above the
+SWIG boundary is pinned to the reference's real code here; the HIP index joins through the -m gpu tests that
+compare it with the same oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle.beam_oracle import oracle_logits_mask
+from oracle.keys_oracle import oracle_aggregate_evidence, oracle_deduplicate, oracle_strip
+from oracle.seal_oracle import OracleFMIndex
+from seal_amd.keys import aggregate_evidence, deduplicate, strip
+from tests.helpers import OracleBatchIndex
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def _unhex(x):
+    return float.fromhex(x)
+
+
+def _as_golden(results):
+    out = []
+    for doc, info in results.items():
+        out.append({"doc": int(doc), "score": float(info[0]).hex(),
+                    "keys": [[[int(t) for t in k], float(s).hex()] for k, s in info[1]],
+                    "tokens": [int(t) for t in info[3]],
+                    "best": [[int(t) for t in info[4][0]], float(info[4][1]).hex()]})
+    return out
+
+
+AGG = _load("ref_aggregate_evidence.json")["cases"]
+
+
+@pytest.mark.parametrize("case_no", range(len(AGG)))
+def test_aggregate_evidence_equals_the_reference(case_no):
+    case = AGG[case_no]
+    orc = OracleFMIndex()
+    orc.initialize(case["docs"])
+    keys = [(list(k), _unhex(s)) for k, s in case["keys"]]
+    us = None if case["unigram_scores"] is None else [_unhex(x) for x in case["unigram_scores"]]
+    want_ngrams = [[list(k), s] for k, s in case["all_ngrams"]]
+    for name, run in (("oracle", lambda: oracle_aggregate_evidence(keys, unigram_scores=us, index=orc, **case["kwargs"])),
+                      ("product host logic", lambda: aggregate_evidence(keys, unigram_scores=us, index=OracleBatchIndex(orc), **case["kwargs"]))):
+        results, all_ngrams = run()
+        assert [[list(k), float(s).hex()] for k, s in all_ngrams.items()] == want_ngrams, name
+        got = _as_golden(results)
+        assert [g["doc"] for g in got] == [w["doc"] for w in case["results"]], name       # ranking
+        assert got == case["results"], name                                                 # scores (bit-exact), keys, tokens, best key
+
+
+def test_strip_and_deduplicate_equal_the_reference():
+    h = _load("ref_helpers.json")
+    for c in h["strip"]:
+        assert oracle_strip(list(c["seq"]), c["start"], c["end"]) == c["out"]
+        assert strip(list(c["seq"]), c["start"], c["end"]) == c["out"]
+    for c in h["deduplicate"]:
+        typed = [(x[0], x[1]) if isinstance(x[0], float) else x for x in c["items"]]
+        want = [typed[i] for i in c["kept_positions"]]
+        assert oracle_deduplicate(typed) == want
+        assert deduplicate(typed) == want
+
+
+IDX = _load("ref_index_and_mask.json")["cases"]
+
+
+@pytest.mark.parametrize("case_no", range(len(IDX)))
+def test_oracle_index_and_mask_equal_the_reference_python(case_no):
+    """seal/index.py's wrapper logic and IndexBasedLogitsProcessor.__call__ as the reference computes them"""
+    case = IDX[case_no]
+    orc = OracleFMIndex()
+    orc.initialize(case["docs"])
+    assert orc.size() == case["size"] and len(orc) == case["len"] and orc.n_docs == case["n_docs"]
+    assert orc.beginnings == case["beginnings"]
+    assert sorted(orc.occurring) == case["occurring_sorted"]
+    assert orc.occurring_distinct == case["occurring_distinct"] and orc.occurring_counts == case["occurring_counts"]
+    for seq, rng, cnt in case["ranges"]:
+        assert list(orc.get_range(list(seq))) == rng and orc.get_count(list(seq)) == cnt
+    for seq, conts in case["continuations"]:
+        assert sorted(orc.get_continuations(list(seq))) == conts
+    for row, tok, doc in case["rows"]:
+        assert orc.get_token_index_from_row(row) == tok and orc.get_doc_index_from_row(row) == doc
+    assert [orc.get_doc(i) for i in range(orc.n_docs)] == case["docs_back"]
+    for lo, hi, want in case["distinct_count"]:
+        assert [list(x) for x in orc.get_distinct_count(lo, hi)] == want
+    assert case["distinct_count_multi_equals_single"]
+    vocab = case["vocab"]
+    for m in case["masks"]:
+        kw = dict(m["kwargs"])
+        eos = kw.pop("eos_token_id", 2)
+        got = oracle_logits_mask(orc, m["input_ids"], vocab, 4, pad_token_id=1, eos_token_id=eos, **kw)
+        assert [np.flatnonzero(r).tolist() for r in got] == m["allowed"], (m["kwargs"], m["input_ids"])
+
+
+def test_model_side_scores_equal_the_reference():
+    """compute_unigram_scores and rescore_keys (prefix-sharing and row-per-key) against the numbers the
+    reference's own functions produced with the same seeded tiny BART on CPU (fp32: 1e-5, the summation
+    order differs)"""
+    import torch
+    from seal_amd.keys import compute_unigram_scores, rescore_keys
+    from tests.helpers import tiny_bart
+    g = _load("ref_model_side.json")
+    model = tiny_bart(vocab=g["vocab"], seed=g["model_seed"])
+    inputs = g["inputs"]
+    with torch.no_grad():
+        got = compute_unigram_scores(model, inputs, None, tolist=True)
+        want = [[_unhex(x) for x in row] for row in g["unigram_scores"]]
+        assert np.allclose(np.asarray(got, dtype=np.float64), np.asarray(want), atol=1e-5, rtol=0, equal_nan=True)
+        got = compute_unigram_scores(model, inputs, None, tolist=True, prefix=[5, 9])
+        want = [[_unhex(x) for x in row] for row in g["unigram_scores_prefix"]]
+        assert np.allclose(np.asarray(got, dtype=np.float64), np.asarray(want), atol=1e-5, rtol=0, equal_nan=True)
+        decoded = [[(_unhex(x[0]), x[1]) if isinstance(x[0], str) else x for x in kk] for kk in g["decoded"]]
+        for run in g["rescore"]:
+            for share in (True, False):
+                res = rescore_keys(model, inputs, decoded, batch_size=4, share_prefixes=share, **run["kwargs"])
+                assert len(res) == len(run["scores"])
+                for per_query, want_q in zip(res, run["scores"]):
+                    assert [list(k) for _, k in per_query] == [k for _, k in want_q], run["kwargs"]     # same keys, same order
+                    a = np.asarray([s for s, _ in per_query], dtype=np.float64)
+                    b = np.asarray([_unhex(s) for s, _ in want_q])
+                    assert np.allclose(a, b, atol=1e-5, rtol=0), (run["kwargs"], share)
+
+
+BEAM = _load("ref_beam_search.json")
+
+
+@pytest.mark.parametrize("case_no", range(len(BEAM["cases"])))
+def test_decode_equals_the_reference_loop(case_no):
+    """hypotheses of the reference's whole fm_index_generate(keep_history=True) -- its beam loop, scorer with
+    memory and constraint processor, run for real by the generator -- against the oracle's restatement of that
+    loop and against the product's tensorised loop (on CPU through the oracle-backed constraint; the HIP
+    constraint joins through the -m gpu tests).  Compared the way the searcher consumes them (strip, count > 0,
+    first occurrence): that is the level at which the reference itself is deterministic, because torch.topk
+    orders the -inf candidates of a short beam arbitrarily.  Scores: 1e-4 (north_star)."""
+    import torch
+    from oracle.beam_oracle import oracle_fm_index_generate
+    from seal_amd.beam_search import fm_index_generate
+    from tests.helpers import OracleLogitsProcessor, hf_logits_fn, tiny_bart, valid_set
+    vocab = BEAM["vocab"]
+    case = BEAM["cases"][case_no]
+    kw = dict(case["kwargs"])
+    orc = OracleFMIndex()
+    orc.initialize(BEAM["docs"])
+    bart = tiny_bart(vocab)
+    enc_ids = torch.tensor(BEAM["enc_ids"])
+    enc_mask = torch.ones_like(enc_ids)
+    K, eos = kw["num_beams"], kw.get("eos_token_id", 2)
+    want = [[(_unhex(s), toks) for s, toks in per_query] for per_query in case["hypotheses"]]
+    opts = dict(force_decoding_from=kw.get("force_decoding_from"), stop_at_count=kw.get("stop_at_count", 0),
+                always_allow_eos=kw.get("always_allow_eos", False))
+    by_oracle = oracle_fm_index_generate(hf_logits_fn(bart, enc_ids, enc_mask, K), orc, len(enc_ids), K, kw["max_length"], vocab,
+                                         decoder_start_token_id=2, pad_token_id=1, eos_token_id=eos, length_penalty=kw["length_penalty"],
+                                         disable_fm_index=kw.get("disable_fm_index", False), **opts)
+    proc = OracleLogitsProcessor(orc, K, vocab, pad_token_id=1, eos_token_id=eos, **opts)
+    by_product = fm_index_generate(bart, None, enc_ids, enc_mask, min_length=1, keep_history=True, constrained_decoding_processor=proc, **kw)
+    title_eos = eos if kw.get("force_decoding_from") else None
+    for name, got in (("oracle", by_oracle), ("product loop", by_product)):
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            gv, wv = valid_set(g, orc, title_eos), valid_set(w, orc, title_eos)
+            assert set(gv) == set(wv), name
+            for k in wv:
+                assert abs(gv[k][0] - wv[k][0]) <= 1e-4, (name, k)
+            if kw.get("disable_fm_index"):                  # no -inf candidates without the constraint: the full list, in order
+                assert [list(t) for _, t in g] == [list(t) for _, t in w], name
+                assert np.allclose([s for s, _ in g], [s for s, _ in w], atol=1e-4, rtol=0), name
