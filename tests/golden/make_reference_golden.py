@@ -391,8 +391,122 @@ def beam_cases():
     return {"vocab": vocab, "docs": docs, "enc_ids": enc_ids.tolist(), "cases": cases}
 
 
+class _ToyTokenizer:
+    """"w17 w3 || body" <-> [0, 17, 3, V-2, V-3, 2]: enough of a tokenizer for retrieval.py's process_batch
+    (pre-tokenised corpora have no text); markers get the ids the product's marker_token_ids default to in tests"""
+
+    def __init__(self, vocab):
+        self.special = {"||": vocab - 2, "body": vocab - 3, "title": vocab - 4, "+": vocab - 5}
+        self.back = {v: k for k, v in self.special.items()}
+
+    def _ids(self, text, add_special_tokens=True):
+        ids = [self.special[t] if t in self.special else int(t[1:]) for t in text.split()]
+        return [0] + ids + [2] if add_special_tokens else ids
+
+    def __call__(self, texts, return_tensors=None, padding=False, truncation=False, add_special_tokens=True):
+        import torch
+        rows = [self._ids(t, add_special_tokens) for t in texts]
+        if return_tensors != "pt":
+            return {"input_ids": rows}
+        width = max(len(r) for r in rows)
+        ids = torch.tensor([r + [1] * (width - len(r)) for r in rows])
+        return {"input_ids": ids, "attention_mask": (ids != 1).long()}
+
+    def decode(self, ids, skip_special_tokens=False, clean_up_tokenization_spaces=False):
+        out = []
+        for t in ids:
+            t = int(t)
+            if skip_special_tokens and t in (0, 1, 2):
+                continue
+            out.append(self.back.get(t, f"w{t}"))
+        return " ".join(out)
+
+    def batch_decode(self, seqs, **kw):
+        return [self.decode(s, **kw) for s in seqs]
+
+
+class _ModelForTheReferenceSearcher(_ModelForTheReferenceLoop):
+    """the same hand-made HF-4.1x hooks, for a model that is handed encoder inputs per call (process_batch,
+    rescore_keys and compute_unigram_scores all use it)"""
+
+    def __init__(self, bart):
+        import torch
+        super().__init__(bart, torch.zeros(1, 1, dtype=torch.long), torch.ones(1, 1, dtype=torch.long))
+
+    def parameters(self):
+        return self.bart.parameters()
+
+    def _prepare_encoder_decoder_kwargs_for_generation(self, input_ids, kwargs):
+        self.enc_ids, self.enc_mask = input_ids, kwargs["attention_mask"]
+        enc = self.bart.get_encoder()(input_ids=input_ids, attention_mask=kwargs["attention_mask"], return_dict=True)
+        return dict(kwargs, encoder_outputs=enc)
+
+    def _expand_inputs_for_generation(self, decoder_input_ids, expand_size, is_encoder_decoder, **model_kwargs):
+        model_kwargs.pop("encoder_outputs", None)
+        return super()._expand_inputs_for_generation(decoder_input_ids, expand_size, is_encoder_decoder, **model_kwargs)
+
+    def __call__(self, decoder_input_ids=None, return_dict=True, output_attentions=None, output_hidden_states=None, **kw):
+        if "input_ids" in kw:                      # rescore_keys / compute_unigram_scores: a plain forward
+            return self.bart(decoder_input_ids=decoder_input_ids, **kw)
+        return super().__call__(decoder_input_ids)
+
+
+def searcher_cases():
+    """seal/retrieval.py end to end: SEALSearcher.batch_search = batch_generate_keys.process_batch (body decode,
+    post-filters, rescoring, title decode, title filters, rescoring, dedup, unigram scores) + retrieve_from_keys
+    (aggregate_evidence with the searcher's parameters) + SEALDocument.  add_query_to_keys is off (spaCy + a real
+    tokenizer); the 'bart' backbone's hard-wired title / code delimiter ids are re-pointed at this toy vocabulary."""
+    import numpy as np
+    import torch
+    import seal.retrieval as ref_retrieval
+    from seal.index import FMIndex
+    from seal.retrieval import SEALSearcher
+    from tests.helpers import make_docs as helper_docs, tiny_bart
+    vocab, K, length, title_eos = 120, 4, 6, 7
+    docs = helper_docs(5, 200, vocab - 8, min_len=6, max_len=18, title_sep=title_eos)
+    index = FMIndex()
+    index.initialize(docs, in_memory=True)
+    index.labels = [f"d{i}" for i in range(len(docs))]
+    rng = np.random.default_rng(0)
+    queries_ids = [[0] + rng.integers(4, vocab - 8, size=int(rng.integers(4, 9))).tolist() + [2] for _ in range(3)]
+    queries = [" ".join(f"w{t}" for t in q[1:-1]) for q in queries_ids]
+    real_generate = ref_retrieval.fm_index_generate
+    out = {"vocab": vocab, "beam": K, "length": length, "title_eos": title_eos, "docs": docs, "queries": queries_ids, "runs": []}
+    for title_length in (8, 15):                  # 15 is the reference's constant; 8 is what tests/test_gpu_search.py runs both sides at
+        def generate(*a, **kw):
+            if kw.get("force_decoding_from"):
+                kw = {**kw, "max_length": title_length}
+            return real_generate(*a, **kw)
+        ref_retrieval.fm_index_generate = generate
+        try:
+            s = SEALSearcher(index, _ToyTokenizer(vocab), _ModelForTheReferenceSearcher(tiny_bart(vocab)), backbone="bart-tiny",
+                             length=length, beam=K, batch_size=2, add_query_to_keys=False, detokenize=True)
+            # (include_keys=True cannot be used with more than one query: batch_search's `for k, _ in kk` rebinds its own
+            #  parameter k, the islice stop; the per-document keys are read from retrieve_from_keys below instead)
+            s.title_eos_token_id, s.code_bos_token_id, s.code_eos_token_id = title_eos, title_eos, vocab - 6
+            with torch.no_grad():
+                keys = list(s.batch_generate_keys(queries))
+                evidence = [s.retrieve_from_keys(kk) for kk in keys]
+                retrieved = s.batch_search(queries, k=10)
+        finally:
+            ref_retrieval.fm_index_generate = real_generate
+        run = {"title_length": title_length, "queries": []}
+        for (kk, us), (res, _), docs_q in zip(keys, evidence, retrieved):
+            assert [d.idx for d in docs_q] == list(res)[:10] and [d.score for d in docs_q] == [res[d.idx][0] for d in docs_q]
+            run["queries"].append({
+                "keys": [[list(map(int, n)), fhex(sc)] for n, sc in kk],
+                "unigram_scores": [fhex(x) for x in us],
+                "evidence": dump_results(dict(list(res.items())[:10])),
+                "ranked": [{"doc": int(d.idx), "docid": d.docid, "score": fhex(d.score), "title": d.text()[0], "body": d.text()[1],
+                            "raw_tokens": [int(t) for t in d._raw_tokens]} for d in docs_q]})
+        out["runs"].append(run)
+    return out
+
+
 def main():
     _install_stand_ins()
+    with open(os.path.join(HERE, "ref_searcher.json"), "w") as f:
+        json.dump({"source": "seal/retrieval.py::SEALSearcher.batch_search on tests.helpers.tiny_bart(120), CPU fp32", **searcher_cases()}, f)
     with open(os.path.join(HERE, "ref_beam_search.json"), "w") as f:
         json.dump({"source": "seal/beam_search.py::fm_index_generate on tests.helpers.tiny_bart(120), CPU fp32, HF-4.1x hooks given back by hand",
                    **beam_cases()}, f)
@@ -406,7 +520,7 @@ def main():
     with open(os.path.join(HERE, "ref_index_and_mask.json"), "w") as f:
         json.dump({"source": "seal/index.py::FMIndex and seal/beam_search.py::IndexBasedLogitsProcessor.__call__",
                    "cases": index_and_processor_cases()}, f)
-    for name in ("ref_aggregate_evidence.json", "ref_helpers.json", "ref_index_and_mask.json", "ref_model_side.json", "ref_beam_search.json"):
+    for name in ("ref_aggregate_evidence.json", "ref_helpers.json", "ref_index_and_mask.json", "ref_model_side.json", "ref_beam_search.json", "ref_searcher.json"):
         print(name, os.path.getsize(os.path.join(HERE, name)), "bytes")
 
 

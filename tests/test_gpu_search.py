@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 TITLE_EOS = 7
 
 
-def _oracle_pipeline(model, orc, queries, K, length, vocab, first_stage_only):
+def _oracle_pipeline(model, orc, queries, K, length, vocab, first_stage_only, title_length=8, return_keys=False):
     from oracle.beam_oracle import oracle_fm_index_generate
     from oracle.keys_oracle import (oracle_aggregate_evidence, oracle_body_postfilter, oracle_deduplicate,
                                     oracle_title_postfilter)
@@ -30,18 +30,19 @@ def _oracle_pipeline(model, orc, queries, K, length, vocab, first_stage_only):
     body = [oracle_body_postfilter(fk, orc) for fk in body]
     body = rk.rescore_keys(model, queries, body, strip_from_bos=[2, TITLE_EOS, 2], strip_from_eos=[TITLE_EOS, vocab - 6, 2])
     ttoks, ids, am = enc("title")
-    title = oracle_fm_index_generate(hf_logits_fn(model, ids, am, K), orc, len(queries), K, 8, vocab,
+    title = oracle_fm_index_generate(hf_logits_fn(model, ids, am, K), orc, len(queries), K, title_length, vocab,
                                      pad_token_id=pad, eos_token_id=TITLE_EOS, length_penalty=0.0, force_decoding_from=[2])
     title = [oracle_title_postfilter(fk, orc, title_bos=2, title_eos=TITLE_EOS) for fk in title]
     title = rk.rescore_keys(model, ttoks, title, strip_from_bos=[2, TITLE_EOS, 2], strip_from_eos=[2])
-    out = []
+    out, all_keys = [], []
     uni = rk.compute_unigram_scores(model, toks)
     for b, t, u in zip(body, title, uni):
         keys = [(n, s) for s, n in oracle_deduplicate(b + t)]
+        all_keys.append(keys)
         out.append(oracle_aggregate_evidence(keys, unigram_scores=u, index=orc, max_occurrences_1=1500,
                                              n_docs_complete_score=1500, alpha=2.0, beta=0.8, add_best_unigrams_to_ngrams=True,
                                              use_top_k_unigrams=5000, smoothing=5.0, first_stage_only=first_stage_only)[0])
-    return out
+    return (out, all_keys) if return_keys else out
 
 
 @pytest.mark.parametrize("first_stage_only,jobs", [(False, 1), (True, 1), (False, 2), (True, 2)])

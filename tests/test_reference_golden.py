@@ -172,3 +172,40 @@ def test_decode_equals_the_reference_loop(case_no):
             if kw.get("disable_fm_index"):                  # no -inf candidates without the constraint: the full list, in order
                 assert [list(t) for _, t in g] == [list(t) for _, t in w], name
                 assert np.allclose([s for s, _ in g], [s for s, _ in w], atol=1e-4, rtol=0), name
+
+
+SEARCH = _load("ref_searcher.json")
+
+
+@pytest.mark.parametrize("run_no", range(len(SEARCH["runs"])))
+def test_search_pipeline_equals_the_reference_searcher(run_no):
+    """the reference's SEALSearcher.batch_search run end to end by the generator (process_batch: body decode,
+    post-filters, rescoring, title decode, title filters, rescoring, dedup, unigram scores; then aggregate_evidence
+    with the searcher's parameters) against the scalar pipeline that tests/test_gpu_search.py holds the HIP
+    searcher to.  Keys: same set, scores 1e-4; ranked documents: same ids wherever the reference's scores are
+    separated by more than the tolerance, scores 1e-4 relative (fp32 model scores enter a float64 pipeline)."""
+    from tests.helpers import tiny_bart
+    from tests.test_gpu_search import _oracle_pipeline
+    run = SEARCH["runs"][run_no]
+    vocab, K, length = SEARCH["vocab"], SEARCH["beam"], SEARCH["length"]
+    orc = OracleFMIndex()
+    orc.initialize(SEARCH["docs"])
+    results, keys = _oracle_pipeline(tiny_bart(vocab), orc, SEARCH["queries"], K, length, vocab, False,
+                                     title_length=run["title_length"], return_keys=True)
+    for got, got_keys, want in zip(results, keys, run["queries"]):
+        want_keys = {tuple(n): _unhex(s) for n, s in want["keys"]}
+        have_keys = {tuple(n): s for n, s in got_keys}
+        assert set(have_keys) == set(want_keys)
+        for n in want_keys:
+            assert abs(have_keys[n] - want_keys[n]) <= 1e-4, n
+        ranked = list(got.items())[:10]
+        assert len(ranked) == len(want["ranked"]) > 0
+        w_scores = [_unhex(d["score"]) for d in want["ranked"]]
+        for (doc, info), w in zip(ranked, w_scores):
+            assert abs(info[0] - w) <= 1e-4 * max(1.0, abs(w))
+        if all(abs(a - b) > 1e-4 * max(1.0, abs(a)) for a, b in zip(w_scores, w_scores[1:])):
+            assert [doc for doc, _ in ranked] == [d["doc"] for d in want["ranked"]]
+        for d in want["ranked"]:
+            assert d["docid"] == f"d{d['doc']}"
+            assert d["raw_tokens"] == [2] + orc.get_doc(d["doc"])[:-1]        # keys.py:388 / retrieval.py:685
+            assert d["raw_tokens"] == got[d["doc"]][3] if d["doc"] in got else True
