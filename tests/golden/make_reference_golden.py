@@ -503,8 +503,33 @@ def searcher_cases():
     return out
 
 
+def checkpoint_cases():
+    """seal/utils.py::load_state_dict_from_fairseq_checkpoint on a synthetic checkpoint (tests.helpers): checksums of
+    every tensor of the loaded model and its logits on a fixed input"""
+    import tempfile
+    import torch
+    from seal.utils import load_state_dict_from_fairseq_checkpoint
+    from tests.helpers import synthetic_fairseq_checkpoint, tiny_bart
+    vocab = 120
+    model = tiny_bart(vocab, seed=99)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "ckpt.pt")
+        synthetic_fairseq_checkpoint(path, vocab=vocab, seed=11)
+        load_state_dict_from_fairseq_checkpoint(model, path)
+    model.eval()
+    state = {k: [list(v.shape), fhex(v.double().sum().item()), fhex(v.double().abs().sum().item())] for k, v in model.state_dict().items()}
+    enc = torch.tensor([[0, 5, 17, 33, 2], [0, 9, 9, 2, 1]])
+    with torch.no_grad():
+        logits = model(input_ids=enc, attention_mask=(enc != 1).long(), decoder_input_ids=torch.tensor([[2, 5], [2, 9]])).logits
+    return {"vocab": vocab, "target_seed": 99, "checkpoint_seed": 11, "state": state,
+            "logits_sample": [fhex(x) for x in logits[:, -1, :16].flatten().tolist()],
+            "lm_head_is_embedding": bool(torch.equal(model.lm_head.weight, model.model.shared.weight))}
+
+
 def main():
     _install_stand_ins()
+    with open(os.path.join(HERE, "ref_checkpoint.json"), "w") as f:
+        json.dump({"source": "seal/utils.py::load_state_dict_from_fairseq_checkpoint", **checkpoint_cases()}, f)
     with open(os.path.join(HERE, "ref_searcher.json"), "w") as f:
         json.dump({"source": "seal/retrieval.py::SEALSearcher.batch_search on tests.helpers.tiny_bart(120), CPU fp32", **searcher_cases()}, f)
     with open(os.path.join(HERE, "ref_beam_search.json"), "w") as f:
@@ -520,7 +545,7 @@ def main():
     with open(os.path.join(HERE, "ref_index_and_mask.json"), "w") as f:
         json.dump({"source": "seal/index.py::FMIndex and seal/beam_search.py::IndexBasedLogitsProcessor.__call__",
                    "cases": index_and_processor_cases()}, f)
-    for name in ("ref_aggregate_evidence.json", "ref_helpers.json", "ref_index_and_mask.json", "ref_model_side.json", "ref_beam_search.json", "ref_searcher.json"):
+    for name in ("ref_aggregate_evidence.json", "ref_helpers.json", "ref_index_and_mask.json", "ref_model_side.json", "ref_beam_search.json", "ref_searcher.json", "ref_checkpoint.json"):
         print(name, os.path.getsize(os.path.join(HERE, name)), "bytes")
 
 

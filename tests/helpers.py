@@ -135,3 +135,19 @@ def synthetic_keys(rng, docs, vocab, n_keys=40, with_titles=False):
             ng = [2] + d[:3]
         keys.append((list(ng), -float(rng.random() * 6 + 0.05)))
     return keys
+
+
+def synthetic_fairseq_checkpoint(path, vocab=120, seed=11):
+    """a fairseq-style BART checkpoint of tiny_bart geometry: BartModel key names without the "model." prefix,
+    the shared embedding stored three times with ONE ROW FEWER than the HF model has (the reference loader
+    appends a zero row, seal/utils.py:44-46), plus the bookkeeping entries it drops"""
+    src = tiny_bart(vocab, seed=seed)
+    sd = {k: v.clone() for k, v in src.model.state_dict().items()}
+    emb = sd["shared.weight"][:-1].clone()
+    for k in ("shared.weight", "encoder.embed_tokens.weight", "decoder.embed_tokens.weight"):
+        sd[k] = emb.clone()
+    del sd["shared.weight"]                      # fairseq has no such key; the loader creates it
+    sd["encoder.version"] = torch.tensor([3.0])
+    sd["decoder.version"] = torch.tensor([3.0])
+    sd["decoder.output_projection.weight"] = emb.clone()
+    torch.save({"model": sd}, path)

@@ -209,3 +209,30 @@ def test_search_pipeline_equals_the_reference_searcher(run_no):
             assert d["docid"] == f"d{d['doc']}"
             assert d["raw_tokens"] == [2] + orc.get_doc(d["doc"])[:-1]        # keys.py:388 / retrieval.py:685
             assert d["raw_tokens"] == got[d["doc"]][3] if d["doc"] in got else True
+
+
+def test_fairseq_checkpoint_loader_equals_the_reference(tmp_path):
+    """seal_amd.utils.load_state_dict_from_fairseq_checkpoint leaves the model in the state the reference's loader
+    (seal/utils.py:42-50) leaves it in: every tensor (shape, sum, sum of magnitudes), the lm_head tied to the
+    embedding with the appended zero row, and the logits of a fixed input"""
+    import torch
+    from seal_amd.utils import load_state_dict_from_fairseq_checkpoint
+    from tests.helpers import synthetic_fairseq_checkpoint, tiny_bart
+    g = _load("ref_checkpoint.json")
+    model = tiny_bart(g["vocab"], seed=g["target_seed"])
+    path = str(tmp_path / "ckpt.pt")
+    synthetic_fairseq_checkpoint(path, vocab=g["vocab"], seed=g["checkpoint_seed"])
+    load_state_dict_from_fairseq_checkpoint(model, path)
+    model.eval()
+    state = model.state_dict()
+    assert set(state) == set(g["state"])
+    for k, (shape, total, magnitude) in g["state"].items():
+        v = state[k]
+        assert list(v.shape) == shape, k
+        assert v.double().sum().item() == _unhex(total) and v.double().abs().sum().item() == _unhex(magnitude), k
+    assert torch.equal(model.lm_head.weight, model.model.shared.weight) == g["lm_head_is_embedding"]
+    enc = torch.tensor([[0, 5, 17, 33, 2], [0, 9, 9, 2, 1]])
+    with torch.no_grad():
+        logits = model(input_ids=enc, attention_mask=(enc != 1).long(), decoder_input_ids=torch.tensor([[2, 5], [2, 9]])).logits
+    want = np.asarray([_unhex(x) for x in g["logits_sample"]])
+    assert np.allclose(logits[:, -1, :16].flatten().double().numpy(), want, atol=1e-6, rtol=0, equal_nan=True)
