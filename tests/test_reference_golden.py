@@ -236,3 +236,58 @@ def test_fairseq_checkpoint_loader_equals_the_reference(tmp_path):
         logits = model(input_ids=enc, attention_mask=(enc != 1).long(), decoder_input_ids=torch.tensor([[2, 5], [2, 9]])).logits
     want = np.asarray([_unhex(x) for x in g["logits_sample"]])
     assert np.allclose(logits[:, -1, :16].flatten().double().numpy(), want, atol=1e-6, rtol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("title_length,jobs", [(8, 1), (15, 1), (8, 2)])
+def test_product_searcher_equals_the_reference_searcher(title_length, jobs, monkeypatch):
+    """the PRODUCT's SEALSearcher.batch_search, all of its Python (key generation recipe, batched post-filters,
+    prefix-sharing rescoring, batched evidence aggregation with the native host routines, worker processes,
+    SEALDocument) run on CPU -- index queries answered by the oracle, the constraint by the oracle's mask -- against
+    what the reference's own SEALSearcher returned for the same corpus, model and queries"""
+    from seal_amd import retrieval
+    from seal_amd.retrieval import SEALSearcher
+    from tests.helpers import OracleLogitsProcessor, tiny_bart
+    run = [r for r in SEARCH["runs"] if r["title_length"] == title_length][0]
+    vocab, K, length, title_eos = SEARCH["vocab"], SEARCH["beam"], SEARCH["length"], SEARCH["title_eos"]
+    orc = OracleFMIndex()
+    orc.initialize(SEARCH["docs"])
+
+    class CpuIndex(OracleBatchIndex):
+        labels = None
+
+        @property
+        def n_docs(self):
+            return self.orc.n_docs
+
+        def get_doc(self, i):
+            return self.orc.get_doc(i)
+
+        def get_range(self, seq):
+            return self.orc.get_range(list(seq))
+    index = CpuIndex(orc)
+    index.labels = [f"d{i}" for i in range(len(SEARCH["docs"]))]
+    real = retrieval.fm_index_generate
+
+    def generate(model, _index, *a, **kw):
+        proc = OracleLogitsProcessor(orc, kw["num_beams"], vocab, pad_token_id=1, eos_token_id=kw.get("eos_token_id") or 2,
+                                     force_decoding_from=kw.get("force_decoding_from"), stop_at_count=kw.get("stop_at_count", 0),
+                                     always_allow_eos=kw.get("always_allow_eos", False))
+        if kw.get("force_decoding_from"):        # the title decode length is a constant (15) in both code bases
+            kw = {**kw, "max_length": title_length}
+        return real(model, None, *a, constrained_decoding_processor=proc, **kw)
+    monkeypatch.setattr(retrieval, "fm_index_generate", generate)
+    s = SEALSearcher(index, None, tiny_bart(vocab), backbone="bart-tiny", length=length, beam=K, batch_size=2, add_query_to_keys=False,
+                     detokenize=False, jobs=jobs, title_eos_token_id=title_eos, code_eos_token_id=vocab - 6, code_bos_token_id=title_eos,
+                     marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5]})
+    got = s.batch_search(SEARCH["queries"], k=10)
+    assert len(got) == len(run["queries"])
+    for docs, want in zip(got, run["queries"]):
+        w_scores = [_unhex(d["score"]) for d in want["ranked"]]
+        assert len(docs) == len(w_scores) > 0
+        for d, w in zip(docs, w_scores):
+            assert abs(d.score - w) <= 1e-4 * max(1.0, abs(w))
+        if all(abs(a - b) > 1e-4 * max(1.0, abs(a)) for a, b in zip(w_scores, w_scores[1:])):
+            assert [d.idx for d in docs] == [d["doc"] for d in want["ranked"]]
+            for d, w in zip(docs, want["ranked"]):
+                assert d.docid == w["docid"]
+                assert list(d.raw_tokens()) == w["raw_tokens"]
