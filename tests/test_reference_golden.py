@@ -72,32 +72,60 @@ def test_strip_and_deduplicate_equal_the_reference():
 IDX = _load("ref_index_and_mask.json")["cases"]
 
 
-@pytest.mark.parametrize("case_no", range(len(IDX)))
-def test_oracle_index_and_mask_equal_the_reference_python(case_no):
-    """seal/index.py's wrapper logic and IndexBasedLogitsProcessor.__call__ as the reference computes them"""
-    case = IDX[case_no]
-    orc = OracleFMIndex()
-    orc.initialize(case["docs"])
-    assert orc.size() == case["size"] and len(orc) == case["len"] and orc.n_docs == case["n_docs"]
-    assert orc.beginnings == case["beginnings"]
-    assert sorted(orc.occurring) == case["occurring_sorted"]
-    assert orc.occurring_distinct == case["occurring_distinct"] and orc.occurring_counts == case["occurring_counts"]
+def _check_index_and_masks(ix, case, allowed_tokens):
+    """seal/index.py's wrapper logic and IndexBasedLogitsProcessor.__call__ as the reference computed them"""
+    assert ix.size() == case["size"] and len(ix) == case["len"] and ix.n_docs == case["n_docs"]
+    assert list(ix.beginnings) == case["beginnings"]
+    assert sorted(ix.occurring) == case["occurring_sorted"]
+    assert list(ix.occurring_distinct) == case["occurring_distinct"] and list(ix.occurring_counts) == case["occurring_counts"]
     for seq, rng, cnt in case["ranges"]:
-        assert list(orc.get_range(list(seq))) == rng and orc.get_count(list(seq)) == cnt
+        lo, hi = ix.get_range(list(seq))
+        assert [int(lo), int(hi)] == rng and int(ix.get_count(list(seq))) == cnt
     for seq, conts in case["continuations"]:
-        assert sorted(orc.get_continuations(list(seq))) == conts
+        assert sorted(int(t) for t in ix.get_continuations(list(seq))) == conts
     for row, tok, doc in case["rows"]:
-        assert orc.get_token_index_from_row(row) == tok and orc.get_doc_index_from_row(row) == doc
-    assert [orc.get_doc(i) for i in range(orc.n_docs)] == case["docs_back"]
+        assert int(ix.get_token_index_from_row(row)) == tok and int(ix.get_doc_index_from_row(row)) == doc
+    assert [[int(t) for t in ix.get_doc(i)] for i in range(ix.n_docs)] == case["docs_back"]
     for lo, hi, want in case["distinct_count"]:
-        assert [list(x) for x in orc.get_distinct_count(lo, hi)] == want
+        toks, cnts = ix.get_distinct_count(lo, hi)
+        assert [[int(t) for t in toks], [int(c) for c in cnts]] == want
     assert case["distinct_count_multi_equals_single"]
-    vocab = case["vocab"]
     for m in case["masks"]:
         kw = dict(m["kwargs"])
         eos = kw.pop("eos_token_id", 2)
-        got = oracle_logits_mask(orc, m["input_ids"], vocab, 4, pad_token_id=1, eos_token_id=eos, **kw)
-        assert [np.flatnonzero(r).tolist() for r in got] == m["allowed"], (m["kwargs"], m["input_ids"])
+        assert allowed_tokens(m["input_ids"], eos, kw) == m["allowed"], (m["kwargs"], m["input_ids"])
+
+
+@pytest.mark.parametrize("case_no", range(len(IDX)))
+def test_oracle_index_and_mask_equal_the_reference_python(case_no):
+    case = IDX[case_no]
+    orc = OracleFMIndex()
+    orc.initialize(case["docs"])
+
+    def allowed_tokens(input_ids, eos, kw):
+        got = oracle_logits_mask(orc, input_ids, case["vocab"], 4, pad_token_id=1, eos_token_id=eos, **kw)
+        return [np.flatnonzero(r).tolist() for r in got]
+    _check_index_and_masks(orc, case, allowed_tokens)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case_no", range(len(IDX)))
+def test_hip_index_and_mask_equal_the_reference_python(case_no):
+    """the HIP index behind the reference's FMIndex API, and the product's IndexBasedLogitsProcessor, against the same
+    reference-produced vectors"""
+    import torch
+    from seal_amd import FMIndex
+    from seal_amd.beam_search import IndexBasedLogitsProcessor
+    case = IDX[case_no]
+    ix = FMIndex()
+    ix.initialize(case["docs"])
+    dev = torch.device("cuda:0")
+
+    def allowed_tokens(input_ids, eos, kw):
+        proc = IndexBasedLogitsProcessor(ix, 4, pad_token_id=1, eos_token_id=eos, **kw)
+        out = proc(torch.tensor(input_ids, device=dev), torch.zeros(len(input_ids), case["vocab"], device=dev))
+        return [torch.nonzero(r == 0.0).flatten().tolist() for r in out]
+    _check_index_and_masks(ix, case, allowed_tokens)
 
 
 def test_model_side_scores_equal_the_reference():
