@@ -1,8 +1,8 @@
 """Vectors produced by the reference's OWN Python (tests/golden/ref_*.json, written by
 tests/golden/make_reference_golden.py from /root/reference/seal/{index,keys,beam_search}.py running on the oracle's
 model of the C++ layer) against the oracle restatements and the product's host logic.  Everything above the
-SWIG boundary is pinned to the reference's real code here; the HIP index joins through the -m gpu tests that
-compare it with the same oracle."""
+SWIG boundary is pinned to the reference's real code here; the HIP index is held to the index / mask vectors
+directly (-m gpu) and joins the rest through the -m gpu tests that compare it with the same oracle."""
 import json
 import os
 
