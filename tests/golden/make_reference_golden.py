@@ -177,10 +177,23 @@ def aggregate_cases():
     return cases
 
 
+class _Word:
+    def __init__(self, text):
+        self.text = text
+
+
+def _split_words(query):
+    """stands in for spaCy's English tokenizer (absent offline): whitespace words as objects with .text"""
+    return [_Word(w) for w in query.split()]
+
+
 def helper_cases():
-    from seal.keys import deduplicate, strip
+    from seal.keys import decompose_query_into_keys, deduplicate, strip
     rng = random.Random(77)
-    out = {"strip": [], "deduplicate": []}
+    out = {"strip": [], "deduplicate": [], "decompose": []}
+    for q in ("who wrote the hobbit", " a ", "x", "", "New york city marathon 2019 winner", "a b"):
+        for length in (1, 3):
+            out["decompose"].append({"query": q, "length": length, "keys_sorted": sorted(decompose_query_into_keys(q, _split_words, length))})
     for _ in range(60):
         seq = [rng.randrange(0, 6) for _ in range(rng.randrange(0, 9))]
         st, en = sorted(rng.sample(range(6), 2)), sorted(rng.sample(range(6), 2))

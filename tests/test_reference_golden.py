@@ -69,6 +69,19 @@ def test_strip_and_deduplicate_equal_the_reference():
         assert deduplicate(typed) == want
 
 
+def test_query_decomposition_equals_the_reference(monkeypatch):
+    """add_query_to_keys: every word 1..n-gram of the query in every capitalisation pattern (keys.py:38-51), with
+    whitespace words standing in for spaCy's tokenizer on both sides"""
+    from seal_amd import query_keys
+
+    class Word:
+        def __init__(self, text):
+            self.text = text
+    monkeypatch.setattr(query_keys, "_word_tokenizer", lambda q: [Word(w) for w in q.split()])
+    for c in _load("ref_helpers.json")["decompose"]:
+        assert sorted(query_keys.decompose_query_into_keys(c["query"], c["length"])) == c["keys_sorted"], c["query"]
+
+
 IDX = _load("ref_index_and_mask.json")["cases"]
 
 
