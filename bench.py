@@ -137,48 +137,107 @@ def index_sym_bytes(index):
     return 2 if lib().fmi_max_symbol(index.handle) < 65536 else 4
 
 
-def replay_on_cpu(orc, trace, beginnings, threads, pad=1):
+def replay_on_cpu(orc, trace, beginnings, threads, vocab=VOCAB):
     """reference call pattern: per decode step and row, get_range(prefix) and
     get_count(prefix[:-1]) from scratch (beam_search.py:96-101), one task per row for
-    distinct_count_multi (fm_index.cpp:117-121); get_count per key; locate + bisect per row."""
+    distinct_count_multi (fm_index.cpp:117-121); get_count per key; locate + bisect per row;
+    extract_text per document.  Returns the timings AND every answer (for the parity check)."""
     t_mask = t_rng = t_loc = t_doc = 0.0
     n_rows = n_seq = n_loc = n_doc = 0
     b = np.asarray(beginnings, dtype=np.uint64)
+    answers = []
     for op in trace:
         if op[0] == "mask":
-            ids, ff = op[1].tolist(), op[2]
-            eos = TITLE_EOS if ff else 2
+            ids, ff, kw = op[1].tolist(), op[2], op[3]
             seqs, live = [], []
             for r, sent in enumerate(ids):
-                if sent[-1] in (eos, pad):
+                if sent[-1] in (kw["eos"], kw["pad"]):
                     continue
                 live.append(r)
                 seqs.append(ff + sent[1:])
                 seqs.append(ff + sent[1:-1])
             t0 = time.perf_counter()
             lo, hi = orc.get_range_batch(seqs, threads=threads)
-            orc.distinct_count_sizes(lo[0::2], np.maximum(lo[0::2], np.minimum(hi[0::2], orc.size())), threads=threads)
+            bits, k, cs = orc.distinct_bitmaps(lo[0::2], np.maximum(lo[0::2], np.minimum(hi[0::2], orc.size())), vocab, threads=threads)
             t_mask += time.perf_counter() - t0
             n_rows += len(live)
+            answers.append((np.asarray(live, dtype=np.int64), bits, k))
         elif op[0] == "ranges":
             t0 = time.perf_counter()
-            orc.get_range_batch(op[1], threads=threads)
+            answers.append(orc.get_range_batch(op[1], threads=threads))
             t_rng += time.perf_counter() - t0
             n_seq += len(op[1])
         elif op[0] == "locate":
             lo, hi, mx = op[1], op[2], op[3]
             rows = np.concatenate([np.arange(a, min(c, a + mx), dtype=np.uint64) for a, c in zip(lo, hi) if c > a] or [np.zeros(0, np.uint64)])
             t0 = time.perf_counter()
-            orc.locate_bin_batch(rows, b, threads=threads)
+            answers.append(orc.locate_bin_batch(rows, b, threads=threads))
             t_loc += time.perf_counter() - t0
             n_loc += len(rows)
         elif op[0] == "docs":
             d = op[1]
             t0 = time.perf_counter()
-            orc.extract_batch(b[d], b[d + 1], threads=threads)       # get_doc = extract_text per document (index.py:68-75)
+            answers.append(orc.extract_batch_tokens(b[d], b[d + 1], threads=threads))    # get_doc = extract_text per document (index.py:68-75)
             t_doc += time.perf_counter() - t0
             n_doc += len(d)
-    return dict(mask_s=t_mask, ranges_s=t_rng, locate_s=t_loc, docs_s=t_doc, rows=n_rows, sequences=n_seq, located=n_loc, docs=n_doc)
+        else:
+            answers.append(None)
+    return dict(mask_s=t_mask, ranges_s=t_rng, locate_s=t_loc, docs_s=t_doc, rows=n_rows, sequences=n_seq, located=n_loc, docs=n_doc), answers
+
+
+def gpu_allowed_bits(index, ids, ff, kw, vocab=VOCAB):
+    """the constraint the decode step applied, as the bitmap ``fmi_dev_allowed_bits`` returns for the same rows"""
+    import ctypes
+    from seal_amd._lib import check, lib
+    rows, cur_len = ids.shape
+    bits = torch.zeros(rows, (vocab + 31) // 32, dtype=torch.int32, device=ids.device)
+    ff_arr = (ctypes.c_int64 * max(len(ff), 1))(*ff)
+    check(lib().fmi_dev_allowed_bits(index.handle, torch.cuda.current_stream(ids.device).cuda_stream, rows, cur_len,
+                                     ids.contiguous().data_ptr(), bits.data_ptr(), vocab, SHIFT, kw["pad"], kw["eos"], ff_arr, len(ff),
+                                     kw["stop_at_count"], int(kw["always_allow_eos"])))
+    torch.cuda.synchronize(ids.device)
+    return bits.cpu().numpy().view(np.uint32)
+
+
+def parity_check(index, trace, answers, vocab=VOCAB):
+    """every recorded FM-index operation of one batch at BASELINE scale: what the GPU answered vs what the CPU oracle
+    answers for the same operation on the same index -- bit-exact (ranges and counts of every key, the allowed-token
+    set of every decode row = its distinct symbols, located positions + doc ids, extracted documents)"""
+    ops = vals = bad = 0
+    detail = {}
+
+    def tally(name, n, nbad):
+        nonlocal ops, vals, bad
+        ops += 1
+        vals += int(n)
+        bad += int(nbad)
+        d = detail.setdefault(name, {"ops": 0, "values": 0, "mismatches": 0})
+        d["ops"] += 1; d["values"] += int(n); d["mismatches"] += int(nbad)
+    for op, ans in zip(trace, answers):
+        if op[0] == "mask":
+            ids, ff, kw = op[1], op[2], op[3]
+            assert kw["stop_at_count"] == 0 and not kw["always_allow_eos"]
+            got = gpu_allowed_bits(index, ids, ff, kw, vocab)
+            live, bits, k = ans
+            want = np.zeros_like(got)
+            want[:, kw["pad"] >> 5] |= np.uint32(1 << (kw["pad"] & 31))       # finished rows: only pad (beam_search.py:119-127)
+            want[live] = bits
+            tally("allowed_token_sets", got.shape[0], int((got != want).any(axis=1).sum()))
+            pop = np.unpackbits(got[live].view(np.uint8), axis=1).sum(axis=1)
+            tally("distinct_symbol_counts", len(live), int((pop != k.astype(np.int64)).sum()))
+        elif op[0] == "ranges":
+            lo, hi = ans
+            tally("ranges_and_counts", 2 * len(lo), int((lo != op[2]).sum() + (hi != op[3]).sum()))
+        elif op[0] == "locate":
+            pos, doc = ans
+            tally("located_positions_and_doc_ids", 2 * len(pos), int((pos.astype(np.int64) != op[4]).sum() + (doc.astype(np.int64) != op[5]).sum())
+                  if len(pos) == len(op[4]) else max(len(pos), len(op[4])))
+        elif op[0] == "docs":
+            flat, offs = ans
+            same_shape = len(flat) == len(op[2]) and np.array_equal(offs, op[3])
+            tally("extracted_document_tokens", len(flat), int((flat != op[2]).sum()) if same_shape else max(len(flat), len(op[2])))
+    return {"ops": ops, "values_compared": vals, "mismatches": bad, "by_kind": detail,
+            "against": "oracle/fm_oracle.c (sdsl-style wt_int + rank_support_v, SA/32, ISA/64) built from this index's BWT"}
 
 
 def main():
@@ -407,7 +466,7 @@ def main():
                                     "note": "binary 16-level wavelet tree, 64 B per level-probe, same symbols emitted"},
                 "wave_iterations_per_launch": round(xstats[1] / nl, 1), "lane_utilisation": round(xstats[2] / max(1, 64 * xstats[1]), 3)}
 
-    cpu = None
+    cpu = parity = None
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
         threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
         t0 = time.perf_counter()
@@ -417,8 +476,11 @@ def main():
         # query (keys.py:236-272); here those come from a per-index table, so add them to the replay
         rng = np.random.default_rng(5)
         occ = np.asarray(index.occurring_distinct)
-        trace.append(("ranges", [[int(t)] for t in rng.choice(occ, size=5000 * args.batch)]))
-        rep = replay_on_cpu(orc, trace, index.beginnings, threads)
+        trace.append(("ranges", [[int(t)] for t in rng.choice(occ, size=5000 * args.batch)], None, None))
+        n_real_ops = len(trace) - 1
+        rep, answers = replay_on_cpu(orc, trace, index.beginnings, threads)
+        parity = parity_check(index, trace[:n_real_ops], answers[:n_real_ops])
+        log(f"parity_check: {parity['ops']} ops, {parity['values_compared']} values, {parity['mismatches']} mismatches")
         t_cpu = rep["mask_s"] + rep["ranges_s"] + rep["locate_s"] + rep["docs_s"]
         cpu = {"value": round(args.batch / t_cpu, 3), "unit": "queries/s (FM-index path only)", "cores": threads, "kind": "port",
                "sample": f"FM-index operations of 1 batch of {args.batch} queries (decode-step get_range/get_count from scratch + "
@@ -441,6 +503,7 @@ def main():
                                   ["query-string n-gram keys (add_query_to_keys: spaCy/tokenizer absent offline)"]},
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "parity_check": parity,
         "extra": {("complete_search_qps" if args.first_stage_only else "first_stage_only_qps"): None if other_qps is None else round(other_qps, 3),
                   "p50_batch_latency_ms_unpipelined": round(float(np.median(step_ms[1:] or step_ms)), 2) if step_ms else None, "docs_returned_per_query": n_found,
                   "phase_ms_one_batch": {k: round(v, 2) for k, v in phases.items()},
@@ -450,6 +513,9 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if parity is not None and parity["mismatches"]:
+        log("PARITY FAILURE: the GPU's answers differ from the CPU oracle's", json.dumps(parity["by_kind"]))
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -570,3 +570,38 @@ void orc_extract_batch(const orc_t *o, uint64_t m, const uint64_t *begins, const
         free(buf);
     }
 }
+
+/* ---- result-returning forms of the drivers above: bench.py replays the recorded operations of a batch through
+ * these, times them as the CPU baseline AND compares what they return with what the GPU returned (parity_check) */
+
+/* get_distinct_count_multi (index.py:158-171) per interval, as a bitmap over raw token ids: bit (symbol - shift) of
+ * row i set for every distinct symbol > 0 of rows [lows[i], highs[i]); k_out = number of distinct symbols > 0;
+ * count_sum_out = sum of their multiplicities */
+void orc_distinct_bitmaps(const orc_t *o, uint64_t m, const uint64_t *lows, const uint64_t *highs, uint64_t shift,
+                          uint64_t words_per_row, uint32_t *bits_out, uint64_t *k_out, uint64_t *count_sum_out, int threads)
+{
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (int64_t i = 0; i < (int64_t)m; i++) {
+        uint64_t w = highs[i] > lows[i] ? highs[i] - lows[i] : 0;
+        uint64_t cap = 2 * (w < o->sigma ? w : o->sigma) + 2;
+        uint64_t *buf = (uint64_t *)malloc(cap * 8);
+        uint64_t len = orc_distinct_count(o, lows[i], highs[i], buf), k = 0, cs = 0;
+        uint32_t *row = bits_out + (uint64_t)i * words_per_row;
+        for (uint64_t j = 0; j + 1 < len; j += 2) {
+            if (buf[j] == 0) continue;                      /* sentinel: index.py:153,167 */
+            uint64_t t = buf[j] - shift;
+            if (buf[j] >= shift && (t >> 5) < words_per_row) row[t >> 5] |= 1u << (t & 31);
+            k++; cs += buf[j + 1];
+        }
+        k_out[i] = k; count_sum_out[i] = cs;
+        free(buf);
+    }
+}
+
+/* get_doc (index.py:68-75) for many documents into one flat buffer at the given offsets (symbols, not yet un-shifted) */
+void orc_extract_batch_tokens(const orc_t *o, uint64_t m, const uint64_t *begins, const uint64_t *ends,
+                              const uint64_t *out_offsets, uint64_t *out, int threads)
+{
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
+    for (int64_t i = 0; i < (int64_t)m; i++) orc_extract_text(o, begins[i], ends[i], out + out_offsets[i]);
+}

@@ -83,6 +83,9 @@ def lib():
         L.orc_locate_bin_batch.argtypes = [ctypes.c_void_p, _u64, _p64, _p64, _u64, _p64, _p64, ctypes.c_int]
         L.orc_distinct_count_sizes.argtypes = [ctypes.c_void_p, _u64, _p64, _p64, _p64, ctypes.c_int]
         L.orc_extract_batch.argtypes = [ctypes.c_void_p, _u64, _p64, _p64, _p64, ctypes.c_int]
+        L.orc_distinct_bitmaps.argtypes = [ctypes.c_void_p, _u64, _p64, _p64, _u64, _u64, ctypes.POINTER(ctypes.c_uint32), _p64, _p64,
+                                           ctypes.c_int]
+        L.orc_extract_batch_tokens.argtypes = [ctypes.c_void_p, _u64, _p64, _p64, _p64, _p64, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -196,6 +199,27 @@ class CppFMIndex:
         n = np.zeros(len(b), dtype=np.uint64)
         lib().orc_extract_batch(self._h, len(b), _ptr(b), _ptr(e), _ptr(n), threads)
         return n
+
+    def distinct_bitmaps(self, lows, highs, vocab: int, threads: int = 1):
+        """get_distinct_count_multi per interval as bitmaps over raw token ids: (bits uint32 [m, ceil(vocab/32)],
+        number of distinct tokens, sum of their counts)"""
+        lo, hi = _arr(lows), _arr(highs)
+        words = (int(vocab) + 31) // 32
+        bits = np.zeros((len(lo), words), dtype=np.uint32)
+        k = np.zeros(len(lo), dtype=np.uint64)
+        cs = np.zeros(len(lo), dtype=np.uint64)
+        lib().orc_distinct_bitmaps(self._h, len(lo), _ptr(lo), _ptr(hi), SHIFT, words,
+                                   bits.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), _ptr(k), _ptr(cs), threads)
+        return bits, k, cs
+
+    def extract_batch_tokens(self, begins, ends, threads: int = 1):
+        """get_doc for many documents: (flat raw token ids int64, offsets)"""
+        b, e = _arr(begins), _arr(ends)
+        offs = np.zeros(len(b) + 1, dtype=np.uint64)
+        np.cumsum(e - b, out=offs[1:])
+        out = np.zeros(max(int(offs[-1]), 1), dtype=np.uint64)
+        lib().orc_extract_batch_tokens(self._h, len(b), _ptr(b), _ptr(e), _ptr(offs), _ptr(out), threads)
+        return out[:int(offs[-1])].astype(np.int64) - SHIFT, offs.astype(np.int64)
 
     def distinct_count_sizes(self, lows, highs, threads: int = 1):
         lo, hi = _arr(lows), _arr(highs)

@@ -104,7 +104,9 @@ class IndexBasedLogitsProcessor:
         ff_arr = (ctypes.c_int64 * max(len(ff), 1))(*ff)
         first = self._first_bits(V, dev) if cur_len == 1 else None
         if getattr(self.index, "_trace", None) is not None and cur_len >= 2:
-            self.index._trace.append(("mask", ids.clone(), list(ff)))
+            self.index._trace.append(("mask", ids.clone(), list(ff), dict(pad=self.pad_token_id, eos=self.eos_token_id,
+                                                                          stop_at_count=int(self.stop_at_count),
+                                                                          always_allow_eos=bool(self.always_allow_eos))))
         lg = logits.contiguous()
         bs = beam_scores.contiguous()
         parent = parent_rows.contiguous() if parent_rows is not None else None
@@ -135,7 +137,9 @@ class IndexBasedLogitsProcessor:
                                "(seal_amd has no CPU path)")
         ids = input_ids.contiguous()
         if getattr(self.index, "_trace", None) is not None:
-            self.index._trace.append(("mask", ids.clone(), list(self.force_decoding_from or [])))
+            self.index._trace.append(("mask", ids.clone(), list(self.force_decoding_from or []),
+                                      dict(pad=self.pad_token_id, eos=self.eos_token_id, stop_at_count=int(self.stop_at_count),
+                                           always_allow_eos=bool(self.always_allow_eos))))
         if ids.dtype != torch.long:
             ids = ids.long()
         src = scores.contiguous()

@@ -181,8 +181,6 @@ class FMIndex(_FMIndex):
     # -- batched extras (GPU-friendly forms of the calls above) -------------
     def get_range_batch(self, sequences: Sequence[Sequence[int]]):
         """``get_range`` for many sequences in one launch -> (lo[], hi[]) uint64."""
-        if getattr(self, "_trace", None) is not None:
-            self._trace.append(("ranges", [list(s) for s in sequences]))
         n = len(sequences)
         offs = np.zeros(n + 1, dtype=np.uint64)
         if n:
@@ -194,6 +192,8 @@ class FMIndex(_FMIndex):
         lo = np.zeros(n, dtype=np.uint64)
         hi = np.zeros(n, dtype=np.uint64)
         check(lib().fmi_backward_search_multi_batch(self._h, n, _ptr(offs), _ptr(toks), _ptr(lo), _ptr(hi)))
+        if getattr(self, "_trace", None) is not None:      # bench.py: the operation AND what the GPU answered
+            self._trace.append(("ranges", [list(s) for s in sequences], lo.copy(), hi.copy()))
         return lo, hi
 
     def get_count_batch(self, sequences: Sequence[Sequence[int]]) -> np.ndarray:
@@ -224,8 +224,6 @@ class FMIndex(_FMIndex):
         import torch
         lo = np.asarray(lows, dtype=np.int64)
         hi = np.asarray(highs, dtype=np.int64)
-        if getattr(self, "_trace", None) is not None:
-            self._trace.append(("locate", lo.copy(), hi.copy(), int(max_per_range)))
         width = np.minimum(np.maximum(hi - lo, 0), int(max_per_range))
         offs = np.zeros(len(lo) + 1, dtype=np.int64)
         np.cumsum(width, out=offs[1:])
@@ -242,6 +240,8 @@ class FMIndex(_FMIndex):
             check(lib().fmi_dev_locate_ranges(self._h, st.cuda_stream, len(lo), d_lo.data_ptr(), d_hi.data_ptr(),
                                               int(max_per_range), d_off.data_ptr(), total, out[0].data_ptr(), out[1].data_ptr()))
             res = out.cpu().numpy()
+        if getattr(self, "_trace", None) is not None:
+            self._trace.append(("locate", lo.copy(), hi.copy(), int(max_per_range), res[0].copy(), res[1].copy()))
         return res[0], res[1], offs
 
     def get_docs_batch(self, doc_indices, as_arrays: bool = False):
@@ -249,8 +249,6 @@ class FMIndex(_FMIndex):
         ints, or int64 numpy views of one flat buffer with ``as_arrays``."""
         import torch
         docs = np.asarray(list(doc_indices), dtype=np.int64)
-        if getattr(self, "_trace", None) is not None:
-            self._trace.append(("docs", docs.copy()))
         if len(docs) == 0:
             return []
         b = self.__dict__.get("_beginnings_np")
@@ -268,6 +266,8 @@ class FMIndex(_FMIndex):
             check(lib().fmi_dev_get_docs(self._h, st.cuda_stream, len(docs), d_docs.data_ptr(), d_off.data_ptr(), SHIFT,
                                          out.data_ptr()))
             flat = out.cpu().numpy()
+        if getattr(self, "_trace", None) is not None:
+            self._trace.append(("docs", docs.copy(), flat[:int(offs[-1])].copy(), offs.copy()))
         if as_arrays == "flat":
             return flat[:int(offs[-1])], offs
         if as_arrays:

@@ -400,6 +400,12 @@ class _LazyList:
     def __repr__(self):
         return repr(self._get())
 
+    def index(self, *a):
+        return self._get().index(*a)
+
+    def count(self, x):
+        return self._get().count(x)
+
 
 def _full_score_native(doc_ids, fetched, all_ngrams, unigram_scores, allow_overlaps, beta, single_key,
                        single_key_add_unigrams, unigrams_ignore_free_places):

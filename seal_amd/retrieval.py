@@ -11,8 +11,11 @@ work runs:
 * every ``fm_index.get_count(k) > 0`` post-filter of a batch (retrieval.py:91,
   130,191,247) is one batched backward-search launch;
 * ``jobs`` (a ``multiprocessing.Pool`` over queries in the reference,
-  retrieval.py:762-775) is accepted and ignored: the per-query index work is
-  already batched on the GPU.
+  retrieval.py:762-775): the per-query index work is batched on the GPU and the
+  evidence aggregation runs there too (``seal_amd/csrc/fmi_aggregate.hip``);
+  ``jobs >= 2`` only moves the bit-exact host checker routines
+  (``fmi_first_stage`` / ``fmi_full_score``) into worker processes when the
+  GPU aggregation is switched off (``gpu_aggregate=False``).
 
 Queries may be strings (a HF tokenizer is then required, as in the reference)
 or pre-tokenised id lists ``[<s>, ..., </s>]`` (no tokenizer needed; the marker
@@ -157,6 +160,9 @@ def _process_batch(searcher, inputs, constrained_generation, offset=0):
         ids = rk._pad_batch(toks, s.bart_model.config.pad_token_id, s.device)
         return dict(input_ids=ids, attention_mask=(ids != s.bart_model.config.pad_token_id).long())
 
+    # `input_tokens` of the reference as its final rescoring sees it (retrieval.py:269-279 uses whatever was
+    # bound last: the bare query, retrieval.py:57, unless the query-n-gram branch re-bound it, :139)
+    last_input_tokens = base_tokens
     strip_ids = s.strip_token_ids
     bos_strip = [s.title_bos_token_id, s.code_bos_token_id, s.bart_model.config.decoder_start_token_id]
 
@@ -191,6 +197,7 @@ def _process_batch(searcher, inputs, constrained_generation, offset=0):
         cand = [[(0.0, k) for k in kk] for kk in cand]
         cand = [[k for _, k in kk] for kk in _count_filter(s.fm_index, cand)]
         _, toks = marked("body")
+        last_input_tokens = toks                # the reference re-binds `input_tokens` here (retrieval.py:139)
         for fk, nfk in zip(found_keys, rk.rescore_keys(s.bart_model, toks, cand, batch_size=100, length_penalty=0.0)):
             fk += nfk
 
@@ -224,7 +231,7 @@ def _process_batch(searcher, inputs, constrained_generation, offset=0):
         raise NotImplementedError("decode_code is off in the reference's defaults (retrieval.py:437) and not built here")
 
     if s.rescore and not s.use_markers:
-        found_keys = rk.rescore_keys(s.bart_scorer_model, base_tokens, found_keys, batch_size=100, length_penalty=0.0,
+        found_keys = rk.rescore_keys(s.bart_scorer_model, last_input_tokens, found_keys, batch_size=100, length_penalty=0.0,
                                      strip_from_bos=bos_strip, strip_from_eos=[s.bart_model.config.eos_token_id])
 
     found_keys = [rk.deduplicate(fk) for fk in found_keys]
@@ -443,7 +450,7 @@ class SEALSearcher:
                                     if self.bart_tokenizer is not None else None)
                             key_info[key] = (text, self.fm_index.get_count(list(key)))
                     doc.keys = [(*key_info[tuple(key)], sc) for key, sc in kk]
-                doc._raw_tokens = full
+                doc._raw_tokens = list(full) if full is not None else None     # a real list: split_tokens uses .index()
                 docs.append(doc)
             retrieved.append(docs)
         if detokenize and self.bart_tokenizer is not None:

@@ -3,11 +3,13 @@ import numpy as np
 import torch
 
 
-def tiny_bart(vocab=120, seed=0, d_model=32, layers=2):
+def tiny_bart(vocab=120, seed=0, d_model=32, layers=2, heads=4, max_positions=64):
+    """seeded random-init BART.  ``d_model=128, heads=2`` gives head_dim 64 = BART-large's, the geometry
+    the fused ``sealnn_*`` decoder kernels are built for (seal_amd/bart_decoder.py)."""
     from transformers import BartConfig, BartForConditionalGeneration
     cfg = BartConfig(vocab_size=vocab, d_model=d_model, encoder_layers=layers, decoder_layers=layers,
-                     encoder_attention_heads=4, decoder_attention_heads=4, encoder_ffn_dim=2 * d_model,
-                     decoder_ffn_dim=2 * d_model, max_position_embeddings=64)
+                     encoder_attention_heads=heads, decoder_attention_heads=heads, encoder_ffn_dim=2 * d_model,
+                     decoder_ffn_dim=2 * d_model, max_position_embeddings=max_positions)
     cfg.forced_bos_token_id = None       # as SEALSearcher.load_bart does (reference retrieval.py:566,580)
     torch.manual_seed(seed)
     m = BartForConditionalGeneration(cfg).eval()
@@ -27,6 +29,11 @@ def make_docs(seed, n_docs, vocab, min_len=3, max_len=14, title_sep=None):
             toks = toks[:2] + [title_sep] + toks[2:]
         docs.append(toks + [2])
     return docs
+
+
+# head_dim 8 (torch fallback of the step decoder) and head_dim 64 (fused sealnn_* kernels, as BART-large)
+MODEL_GEOMETRIES = [dict(d_model=32, heads=4), dict(d_model=128, heads=2)]
+MODEL_IDS = ["dh8-fallback", "dh64-fused"]
 
 
 class OracleLogitsProcessor:

@@ -4,24 +4,33 @@ by HF's cache-free forward on the same seeded tiny BART."""
 import pytest
 import torch
 
+from tests.helpers import MODEL_GEOMETRIES, MODEL_IDS
+
 pytestmark = pytest.mark.gpu
 
 
+def _assert_decoder_path(model, geom):
+    """a silent fall back from the fused sealnn_* kernels to the torch ops must fail the test"""
+    st = model._seal_step_decoder._st
+    assert st.fused is (geom["d_model"] // geom["heads"] == 64), (geom, st.fused)
+
+
+@pytest.mark.parametrize("geom", MODEL_GEOMETRIES, ids=MODEL_IDS)
 @pytest.mark.parametrize("kw", [
     dict(max_length=6, num_beams=3, length_penalty=0.0),
     dict(max_length=8, num_beams=5, length_penalty=0.0, force_decoding_from=[2], eos_token_id=7),
     dict(max_length=5, num_beams=4, length_penalty=1.0, always_allow_eos=True),
     dict(max_length=5, num_beams=3, length_penalty=0.0, stop_at_count=2),
 ])
-def test_fm_index_generate_matches_reference_restatement(kw):
+def test_fm_index_generate_matches_reference_restatement(kw, geom):
     from oracle.beam_oracle import oracle_fm_index_generate
     from oracle.seal_oracle import OracleFMIndex
     from seal_amd import FMIndex, fm_index_generate
     from tests.helpers import hf_logits_fn, make_docs, tiny_bart, valid_set
     vocab = 120
     dev = torch.device("cuda:0")
-    m_cpu = tiny_bart(vocab)
-    m_gpu = tiny_bart(vocab).to(dev)
+    m_cpu = tiny_bart(vocab, **geom)
+    m_gpu = tiny_bart(vocab, **geom).to(dev)
     docs = make_docs(3, 150, vocab, title_sep=7)
     ix, orc = FMIndex(), OracleFMIndex()
     ix.initialize(docs)
@@ -32,6 +41,7 @@ def test_fm_index_generate_matches_reference_restatement(kw):
     K = kw["num_beams"]
     eos = kw.get("eos_token_id", 2)
     got = fm_index_generate(m_gpu, ix, enc_ids.to(dev), enc_mask.to(dev), min_length=1, keep_history=True, **kw)
+    _assert_decoder_path(m_gpu, geom)
     want = oracle_fm_index_generate(hf_logits_fn(m_cpu, enc_ids, enc_mask, K), orc, 3, K, kw["max_length"], vocab,
                                     decoder_start_token_id=2, pad_token_id=1, eos_token_id=eos,
                                     length_penalty=kw["length_penalty"], force_decoding_from=kw.get("force_decoding_from"),
@@ -72,6 +82,48 @@ def test_graph_captured_step_matches_eager_step():
             eager.reorder(perm)
             graph.reorder(perm)
         enc_ids = torch.roll(enc_ids, 1, 0)
+
+
+@pytest.mark.parametrize("S", [1, 17, 63, 64])
+def test_fused_step_decoder_matches_hf_cache_free_forward(S):
+    """``BartStepDecoder.step`` at head_dim 64 -- sealnn_self_attn_step (ancestry-addressed KV cache),
+    sealnn_cross_attn_step, sealnn_add_layernorm inside the captured graph -- against HF's own cache-free fp32
+    forward over a whole 17-position decode with the beams re-ranked at random after every step
+    (reference beam_search.py:231-253 forward + 331-332 ``_reorder_cache``), masked encoder positions included."""
+    from seal_amd.bart_decoder import BartStepDecoder
+    from tests.helpers import tiny_bart
+    dev = torch.device("cuda:0")
+    vocab, B, K, T = 120, 3, 5, 17
+    m = tiny_bart(vocab, d_model=128, heads=2, max_positions=64).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(S)
+    enc_ids = torch.randint(4, vocab, (B, S), generator=g).to(dev)
+    enc_mask = torch.ones_like(enc_ids)
+    if S > 2:                                  # ragged batch: padded + masked encoder tails
+        enc_mask[1, S // 2:] = 0
+        enc_ids[1, S // 2:] = 1
+        enc_mask[2, S - 1:] = 0
+        enc_ids[2, S - 1:] = 1
+    dec = BartStepDecoder(m)
+    for rep in range(2):                       # the second decode replays the captured graph over a stale cache
+        enc = dec.encode(enc_ids, enc_mask)
+        dec.start(enc, enc_mask, K, T)
+        rows = torch.full((B * K, 1), 2, dtype=torch.long, device=dev)
+        ids_rep, am_rep = enc_ids.repeat_interleave(K, 0), enc_mask.repeat_interleave(K, 0)
+        for t in range(T - 1):
+            got = dec.step(rows[:, -1])
+            assert dec._st.fused is True
+            with torch.no_grad():
+                want = m(input_ids=ids_rep, attention_mask=am_rep, decoder_input_ids=rows).logits[:, -1, :]
+            finite = torch.isfinite(want)
+            assert torch.equal(finite, torch.isfinite(got))
+            err = (got[finite] - want[finite]).abs().max().item()
+            assert err <= 2e-5, (rep, t, err)
+            nxt = torch.randint(4, vocab, (B * K,), generator=g).to(dev)
+            perm = (torch.arange(B * K).view(B, K).gather(1, torch.randint(0, K, (B, K), generator=g))).reshape(-1).to(dev)
+            rows = torch.cat([rows[perm], nxt[:, None]], 1)     # beams may be duplicated and dropped, as in a real search
+            dec.reorder(perm)
+        enc_ids = torch.roll(enc_ids, 1, 0)
+        enc_mask = torch.roll(enc_mask, 1, 0)
 
 
 @pytest.mark.parametrize("narrow", ["1024", "0"], ids=["lds-select", "radix-select"])
@@ -127,24 +179,35 @@ def test_fused_constrained_topk_matches_unfused_step(kw, narrow, monkeypatch):
             assert len(set(flat[q].tolist())) == 2 * K
 
 
-def test_rescore_keys_fused_teacher_forcing_matches_hf_forward():
-    """tree-shared rescoring through the fused step-decoder kernels (GPU) == one HF row per key (reference batching)"""
+@pytest.mark.parametrize("geom", MODEL_GEOMETRIES, ids=MODEL_IDS)
+def test_rescore_keys_tree_shared_teacher_forcing_matches_one_hf_row_per_key(geom, monkeypatch):
+    """tree-shared rescoring (``share_prefixes=True``: at head_dim 64 through sealnn_causal_self_attn /
+    sealnn_cross_attn_rows / sealnn_add_layernorm, per-query cross K/V) == one row per key through HF's own
+    forward (``share_prefixes=False``, the reference's batching, keys.py:64-141).  Encoder lengths 1, 63 and 64
+    in one ragged batch, keys up to 17 tokens (T = 17 decoder positions)."""
     import numpy as np
+    from seal_amd.bart_decoder import BartStepDecoder
     from seal_amd.keys import rescore_keys
     from tests.helpers import tiny_bart
     dev = torch.device("cuda:0")
-    m = tiny_bart(120).to(dev)
+    m = tiny_bart(120, **geom).to(dev)
+    fused_calls = []
+    real = BartStepDecoder.teacher_logits
+    monkeypatch.setattr(BartStepDecoder, "teacher_logits", lambda self, *a: (fused_calls.append(1), real(self, *a))[1])
     rng = np.random.default_rng(0)
-    inputs = [[0] + rng.integers(4, 118, size=int(rng.integers(4, 9))).tolist() + [2] for _ in range(4)]
+    inputs = [[0] + rng.integers(4, 118, size=n).tolist() + [2] for n in (0, 61, 62, 5)]
+    inputs[0] = [2]                                      # a one-token encoder input
     keys = []
     for _ in range(4):
-        base = rng.integers(4, 118, size=9).tolist()
+        base = rng.integers(4, 118, size=17).tolist()
         other = rng.integers(4, 118, size=6).tolist()
-        kk = [base[:i] for i in range(1, 10)] + [other[:i] for i in range(2, 7)] + [[2] + base[:3], base[:4] + [2], [7] + other[:2] + [7]]
+        kk = [base[:i] for i in range(1, 18)] + [other[:i] for i in range(2, 7)] + [[2] + base[:3], base[:4] + [2], [7] + other[:2] + [7]]
         keys.append([(-1.0, k) for k in kk])
     bias = torch.randn(4, 120, device=dev)
     for kw in (dict(), dict(strip_from_bos=[2, 7], strip_from_eos=[7, 2]), dict(logit_bias=bias)):
+        n0 = len(fused_calls)
         a = rescore_keys(m, inputs, keys, batch_size=4, share_prefixes=True, **kw)
+        assert (len(fused_calls) > n0) is (geom["d_model"] // geom["heads"] == 64)      # no silent fallback
         b = rescore_keys(m, inputs, keys, batch_size=4, share_prefixes=False, **kw)
         for qa, qb in zip(a, b):
             assert [k for _, k in qa] == [k for _, k in qb]

@@ -194,3 +194,27 @@ def test_errors_are_loud_without_a_gpu():
     with pytest.raises(SealFMError):
         check(lib().fmi_build(h, bad.ctypes.data_as(_p64), 3, -1))
     lib().fmi_free(h)
+
+
+def test_lightning_loader_accepts_both_layouts_and_rejects_a_wrong_checkpoint(tmp_path):
+    """reference seal/utils.py:31-39 loads a PLAIN HF state dict strictly; lightning wrappers prefix keys with
+    "model." under "state_dict".  Both must load to the same weights; a checkpoint of another geometry must raise
+    instead of loading silently with missing keys."""
+    import pytest
+    import torch
+    from seal_amd.utils import load_state_dict_from_lightning_checkpoint
+    from tests.helpers import tiny_bart
+    src = tiny_bart(120, seed=5)
+    plain, wrapped = str(tmp_path / "plain.pt"), str(tmp_path / "wrapped.pt")
+    torch.save(src.state_dict(), plain)
+    torch.save({"state_dict": {"model." + k: v for k, v in src.state_dict().items()}}, wrapped)
+    for path in (plain, wrapped):
+        dst = tiny_bart(120, seed=9)
+        load_state_dict_from_lightning_checkpoint(dst, path)
+        for k, v in src.state_dict().items():
+            assert torch.equal(dst.state_dict()[k], v), k
+    other = tiny_bart(120, seed=5, layers=1)
+    bad = str(tmp_path / "bad.pt")
+    torch.save(other.state_dict(), bad)
+    with pytest.raises(RuntimeError, match="does not match"):
+        load_state_dict_from_lightning_checkpoint(tiny_bart(120, seed=9), bad)

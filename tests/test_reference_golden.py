@@ -141,6 +141,44 @@ def test_hip_index_and_mask_equal_the_reference_python(case_no):
     _check_index_and_masks(ix, case, allowed_tokens)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case_no", range(len(IDX)))
+def test_reference_call_pattern_on_the_hip_swig_shim(case_no):
+    """``seal/index.py`` on top of ``seal_amd.cpp_modules.fm_index`` (the class that takes
+    the place of the SWIG module, reference index.py:13-14).  The reference's sources cannot travel to the GPU box
+    and this container has no GPU, so the layer above the SWIG surface is its restatement (oracle/seal_oracle.py
+    ``OracleFMIndex``: the SCALAR call pattern of index.py:39-204 -- one ``backward_search_step`` per token,
+    ``distinct_count_multi`` + python unzip, ``locate`` + bisect, ``extract_text``) re-based onto the HIP shim's ten
+    SWIG methods, and the reference's mask logic (beam_search.py:62-140, restated in oracle/beam_oracle.py) on top of
+    that -- held to the vectors the reference's own classes produced."""
+    from seal_amd.cpp_modules.fm_index import FMIndex as HipSwigFMIndex
+    case = IDX[case_no]
+    layer = {k: v for k, v in OracleFMIndex.__dict__.items() if k not in ("__dict__", "__weakref__", "__init__", "initialize", "__doc__")}
+
+    def init(self):
+        HipSwigFMIndex.__init__(self)
+        self.beginnings, self.occurring, self.occurring_distinct, self.occurring_counts, self.labels = [0], set(), [], [], None
+
+    def initialize(self, sequences, in_memory=False):          # reference index.py:39-66
+        data, occurring = [], set()
+        for seq in sequences:
+            self.beginnings.append(self.beginnings[-1] + len(seq))
+            occurring |= set(seq)
+            data.extend(x + 10 for x in reversed(seq))
+        self.occurring = list(occurring)
+        HipSwigFMIndex.initialize(self, data)
+        self.occurring_distinct, self.occurring_counts = self.get_distinct_count(0, len(self))
+    cls = type("ReferenceLayerOnHipShim", (HipSwigFMIndex,), {**layer, "__init__": init, "initialize": initialize})
+    ix = cls()
+    ix.initialize(case["docs"])
+    assert type(ix).get_range is OracleFMIndex.get_range and type(ix).backward_search_step is HipSwigFMIndex.backward_search_step
+
+    def allowed_tokens(input_ids, eos, kw):
+        got = oracle_logits_mask(ix, input_ids, case["vocab"], 4, pad_token_id=1, eos_token_id=eos, **kw)
+        return [np.flatnonzero(r).tolist() for r in got]
+    _check_index_and_masks(ix, case, allowed_tokens)
+
+
 def test_model_side_scores_equal_the_reference():
     """compute_unigram_scores and rescore_keys (prefix-sharing and row-per-key) against the numbers the
     reference's own functions produced with the same seeded tiny BART on CPU (fp32: 1e-5, the summation
@@ -332,3 +370,51 @@ def test_product_searcher_equals_the_reference_searcher(title_length, jobs, monk
             for d, w in zip(docs, want["ranked"]):
                 assert d.docid == w["docid"]
                 assert list(d.raw_tokens()) == w["raw_tokens"]
+
+
+@pytest.mark.parametrize("jobs", [1, 2])
+def test_product_search_detokenizes_through_the_title_delimiter(jobs, monkeypatch):
+    """``SEALSearcher.search`` always detokenises (reference retrieval.py:644-647): ``split_tokens`` must work on the
+    document tokens the full scoring hands over (``doc._raw_tokens``), inline and through worker processes --
+    every 'title @@ body' passage holds the delimiter"""
+    from seal_amd import retrieval
+    from seal_amd.retrieval import SEALSearcher
+    from tests.helpers import OracleLogitsProcessor, tiny_bart
+    vocab, K, length, title_eos = SEARCH["vocab"], SEARCH["beam"], SEARCH["length"], SEARCH["title_eos"]
+    orc = OracleFMIndex()
+    orc.initialize(SEARCH["docs"])
+
+    class CpuIndex(OracleBatchIndex):
+        labels = None
+        n_docs = property(lambda self: self.orc.n_docs)
+
+        def get_doc(self, i):
+            return self.orc.get_doc(i)
+
+    class WordTokenizer:
+        def decode(self, ids, skip_special_tokens=False, clean_up_tokenization_spaces=False):
+            return " ".join(f"w{int(t)}" for t in ids if not (skip_special_tokens and int(t) in (0, 1, 2)))
+    real = retrieval.fm_index_generate
+
+    def generate(model, _index, *a, **kw):
+        proc = OracleLogitsProcessor(orc, kw["num_beams"], vocab, pad_token_id=1, eos_token_id=kw.get("eos_token_id") or 2,
+                                     force_decoding_from=kw.get("force_decoding_from"))
+        if kw.get("force_decoding_from"):
+            kw = {**kw, "max_length": 8}
+        return real(model, None, *a, constrained_decoding_processor=proc, **kw)
+    monkeypatch.setattr(retrieval, "fm_index_generate", generate)
+    s = SEALSearcher(CpuIndex(orc), WordTokenizer(), tiny_bart(vocab), backbone="bart-tiny", length=length, beam=K, batch_size=2,
+                     add_query_to_keys=False, jobs=jobs, title_eos_token_id=title_eos, code_eos_token_id=vocab - 6,
+                     code_bos_token_id=title_eos,
+                     marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5]})
+    found = s.search(SEARCH["queries"][0], k=5)
+    assert len(found) > 0
+    for d in found:
+        toks = [2] + orc.get_doc(d.idx)[:-1]
+        title, body = d.text()
+        if title_eos in toks:
+            i = toks.index(title_eos)
+            assert title == " ".join(f"w{t}" for t in toks[:i] if t > 2)
+            assert body == " ".join(f"w{t}" for t in toks[i + 1:] if t > 2)
+        else:
+            assert title == "" and body == " ".join(f"w{t}" for t in toks if t > 2)
