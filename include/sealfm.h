@@ -271,6 +271,58 @@ int fmi_fullscore_read(const fmi_fullscore_t *fs, int64_t *order, double *score,
                        int64_t *pick_off, int64_t *pick_id, double *pick_score);
 void fmi_fullscore_free(fmi_fullscore_t *fs);
 
+/* ---- evidence aggregation on the GPU: seal/keys.py:311-497 (first stage + full-document scoring) for a chunk of
+ * queries, from the scored keys to the ranked documents, without the located rows, the candidate documents or their
+ * text ever leaving the device.  Replaces what fmi_first_stage + fmi_full_score compute on the host (those two stay
+ * as the bit-exact checkers); same results, same order, same float64 arithmetic.
+ *
+ * fmi_agg_pack (host): the "table keys" of every query = the keys of `all_ngrams` with score > 0 (keys.py:305-309,
+ * 377-381) in all_ngrams order (descending score, stable), CSR over the queries; key_rare marks the keys of
+ * `rare_ngrams` (keys.py:285-299), whose rows [key_lo, key_hi) -- cut to max_hits -- the first stage locates;
+ * type_scores[q] = the query's `unigram_scores` after keys.py:236-272 (dense [vocab], or NULL).  The plan owns one
+ * packed blob (layout: seal_amd/csrc/fmi_agg.h) that the caller copies to the GPU as it is. */
+typedef struct fmi_agg_plan fmi_agg_plan_t;
+int fmi_agg_pack(uint64_t n_queries, const int64_t *q_key_off, const int64_t *key_tok_off, const int64_t *key_toks,
+                 const double *key_score, const uint8_t *key_rare, const uint64_t *key_lo, const uint64_t *key_hi,
+                 uint64_t max_hits, uint64_t index_size, const double *const *type_scores, uint64_t vocab,
+                 fmi_agg_plan_t **out);
+const void *fmi_agg_plan_blob(const fmi_agg_plan_t *plan, uint64_t *bytes_out);
+uint64_t fmi_agg_plan_occurrences(const fmi_agg_plan_t *plan);
+void fmi_agg_plan_free(fmi_agg_plan_t *plan);
+
+/* byte offsets into the output buffer of fmi_dev_aggregate, as fmi_dev_aggregate_sizes reports them in out_layout[20].
+ * R = n_queries * keep records, record (q, x) = x-th best document of query q at index q * keep + x. */
+enum {
+    FMI_AGG_OUT_N_OUT = 0,        /* u32 [nq]   documents returned for the query (<= keep) */
+    FMI_AGG_OUT_FLAGS = 1,        /* u32 [nq]   bit 0: the query exceeded a device limit -> recompute it with the host checkers */
+    FMI_AGG_OUT_CURSOR = 2,       /* u32 [2]    used entries of the pick pool / the token pool */
+    FMI_AGG_OUT_REC_DOC = 3,      /* u64 [R]    document index */
+    FMI_AGG_OUT_REC_SCORE = 4,    /* f64 [R]    keys.py:493 */
+    FMI_AGG_OUT_REC_BEST_SCORE = 5, /* f64 [R]  score of the best single key (keys.py:424-441) */
+    FMI_AGG_OUT_REC_BEST_KEY = 6, /* i32 [R]    its table key id, -1 if no key occurs in the document */
+    FMI_AGG_OUT_REC_T = 7,        /* u32 [R]    tokens of the document */
+    FMI_AGG_OUT_REC_NPICKS = 8,   /* u32 [R]    accepted keys + unigrams (keys.py:466,487) */
+    FMI_AGG_OUT_REC_PICK_OFF = 9, /* u32 [R]    first pick of the record in the pick pool */
+    FMI_AGG_OUT_REC_TOK_OFF = 10, /* u32 [R]    first token of the record in the token pool */
+    FMI_AGG_OUT_FS_CNT = 11,      /* u32 [nq]   documents of the first-stage ranking (<= n_top) */
+    FMI_AGG_OUT_PICK_ID = 12,     /* i32 pool   table key id, or -(token + 1) for a unigram */
+    FMI_AGG_OUT_PICK_SCORE = 13,  /* f64 pool   its discounted score */
+    FMI_AGG_OUT_TOKENS = 14,      /* i32 pool   document tokens as scored: [2] + get_doc(doc)[:-1] (keys.py:388) */
+    FMI_AGG_OUT_FS_DOC = 15,      /* u32 [nq][n_top]  first-stage ranking (keys.py:366) */
+    FMI_AGG_OUT_FS_SCORE = 16,    /* f64 [nq][n_top]  its scores after the repetition discount (keys.py:352-364) */
+    FMI_AGG_OUT_FIXED_BYTES = 17, /* arrays 0..11 live in [0, fixed_bytes): one small copy tells how much of the pools to fetch */
+    FMI_AGG_OUT_BYTES = 18
+};
+int fmi_dev_aggregate_sizes(fmi_t *h, const fmi_agg_plan_t *plan, uint64_t n_top, uint64_t keep, int allow_overlaps,
+                            uint64_t *ws_bytes, uint64_t *out_layout /* [20] */);
+
+/* the whole aggregation on `stream`: d_plan_blob = the plan's blob copied to the device, d_ws / d_out = device buffers of
+ * the sizes reported above.  n_top = n_docs_complete_score (documents that are fully scored), keep = documents recorded
+ * per query (the caller's k); the other parameters are aggregate_evidence's (keys.py:178-204).  Asynchronous. */
+int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan_t *plan, const void *d_plan_blob, uint64_t n_top, uint64_t keep,
+                      int allow_overlaps, double beta, double single_key, int single_key_add_unigrams,
+                      int unigrams_ignore_free_places, int64_t shift, void *d_ws, uint64_t ws_bytes, void *d_out, uint64_t out_bytes);
+
 /* (sr + log(1-exp(snr))) - (snr + log(1-exp(sr))), snr = log((count+smoothing)/(ntokens+smoothing)), 0 where
  * count == 0 -- seal/keys.py:221-224,258-261 for n pairs, libm doubles (what python's math module calls). */
 int fmi_log_odds_batch(uint64_t n, const double *sr, const int64_t *count, double ntokens, double smoothing, double *out);

@@ -72,6 +72,13 @@ SIGNATURES = {
     "fmi_fullscore_entries": (_u64, [_vp]),
     "fmi_fullscore_read": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fmi_fullscore_free": (None, [_vp]),
+    "fmi_agg_pack": (_int, [_u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _u64, ctypes.POINTER(_vp)]),
+    "fmi_agg_plan_blob": (_vp, [_vp, _p64]),
+    "fmi_agg_plan_occurrences": (_u64, [_vp]),
+    "fmi_agg_plan_free": (None, [_vp]),
+    "fmi_dev_aggregate_sizes": (_int, [_vp, _vp, _u64, _u64, _int, _p64, _p64]),
+    "fmi_dev_aggregate": (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, ctypes.c_double, ctypes.c_double, _int, _int, _i64,
+                                 _vp, _u64, _vp, _u64]),
     "fmi_log_odds_batch": (_int, [_u64, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp]),
 }
 

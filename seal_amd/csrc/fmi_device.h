@@ -112,3 +112,29 @@ __device__ __forceinline__ void wm_rank_sym_pair(const FmiDev &ix, uint64_t c, u
     }
     ri = p - ix.leaf[c]; rj = s - ix.leaf[c];
 }
+
+// ---------------------------------------------------------------------------
+// suffix array / text / document boundaries (all resident)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t sa_at(const FmiDev &ix, uint64_t row)
+{
+    uint64_t v = ix.sa_lo[row];
+    if (ix.sa_hi) v |= (uint64_t)ix.sa_hi[row] << 32;
+    return v;
+}
+
+// bisect_right(beginnings, pos) - 1
+__device__ __forceinline__ uint64_t doc_of(const FmiDev &ix, uint64_t pos)
+{
+    uint64_t lo = 0, hi = ix.n_begin;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (pos < ix.doc_begin[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo - 1;
+}
+
+__device__ __forceinline__ uint64_t text_at(const FmiDev &ix, uint64_t p)
+{
+    return ix.sym_bytes == 2 ? (uint64_t)((const uint16_t *)ix.text)[p] : (uint64_t)((const uint32_t *)ix.text)[p];
+}

@@ -363,6 +363,8 @@ extern "C" int fmi_set_doc_beginnings(fmi_t *h, const uint64_t *b, uint64_t n_en
 {
     if (!h || !b || n_entries == 0) { fmi_set_error("fmi_set_doc_beginnings: bad argument"); return FMI_ERR_ARG; }
     h->doc_begin.assign(b, b + n_entries);
+    h->max_doc_len = 0;
+    for (uint64_t i = 1; i < n_entries; i++) h->max_doc_len = std::max<uint64_t>(h->max_doc_len, b[i] - b[i - 1]);
     if (h->device >= 0) {
         if (hipSetDevice(h->device) != hipSuccess) { fmi_set_error("hipSetDevice failed"); return FMI_ERR_HIP; }
         void *p = nullptr;

@@ -66,6 +66,7 @@ struct fmi {
     std::vector<uint32_t> sa_lo;
     std::vector<uint32_t> bwt;   // kept for tests / hand-over only (not uploaded)
     std::vector<uint8_t> text;   // n * sym_bytes
+    uint64_t max_doc_len = 0;    // longest document (fmi_set_doc_beginnings): sizes the LDS of the scoring kernel
     bool host_resident = false;
     // device
     int device = -1;

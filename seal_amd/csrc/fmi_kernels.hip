@@ -52,24 +52,6 @@ __device__ __forceinline__ void bs_step(const FmiDev &ix, uint64_t c, uint64_t l
     r_res = cb + rr - 1;
 }
 
-__device__ __forceinline__ uint64_t sa_at(const FmiDev &ix, uint64_t row)
-{
-    uint64_t v = ix.sa_lo[row];
-    if (ix.sa_hi) v |= (uint64_t)ix.sa_hi[row] << 32;
-    return v;
-}
-
-// bisect_right(beginnings, pos) - 1
-__device__ __forceinline__ uint64_t doc_of(const FmiDev &ix, uint64_t pos)
-{
-    uint64_t lo = 0, hi = ix.n_begin;
-    while (lo < hi) {
-        uint64_t mid = (lo + hi) >> 1;
-        if (pos < ix.doc_begin[mid]) hi = mid; else lo = mid + 1;
-    }
-    return lo - 1;
-}
-
 // ---------------------------------------------------------------------------
 // K1: backward_search_step for n independent triples (fm_index.cpp:67-76)
 // ---------------------------------------------------------------------------
@@ -824,11 +806,6 @@ __global__ void k_locate_ranges(FmiDev ix, uint64_t n_ranges, const uint64_t *lo
 // K6: extract_text / get_doc: the text itself is resident, so
 // T[end-1] ... T[begin] (fm_index.cpp:169-184) is a reversed contiguous read.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t text_at(const FmiDev &ix, uint64_t p)
-{
-    return ix.sym_bytes == 2 ? (uint64_t)((const uint16_t *)ix.text)[p] : (uint64_t)((const uint32_t *)ix.text)[p];
-}
-
 __global__ void k_extract(FmiDev ix, uint64_t begin, uint64_t end, uint64_t *out)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -578,6 +578,15 @@ def aggregate_evidence(ngrams_and_scores, unigram_scores=None, index=None, max_o
     after the first stage + repetition re-weighting and returns the
     ``to_fully_score`` ranking as ``{doc: [score, [[ngram, score]...], [best_ngram, best_score]]}``.
     """
+    params = dict(max_occurrences_1=max_occurrences_1, max_occurrences_2=max_occurrences_2, n_docs_complete_score=n_docs_complete_score,
+                  alpha=alpha, beta=beta, length_penalty=length_penalty, use_fm_index_frequency=use_fm_index_frequency,
+                  add_best_unigrams_to_ngrams=add_best_unigrams_to_ngrams, use_top_k_unigrams=use_top_k_unigrams,
+                  sort_by_length=sort_by_length, sort_by_freq=sort_by_freq, smoothing=smoothing, allow_overlaps=allow_overlaps,
+                  single_key=single_key, single_key_add_unigrams=single_key_add_unigrams,
+                  unigrams_ignore_free_places=unigrams_ignore_free_places, first_stage_only=first_stage_only, defer=defer, keep=keep)
+    if defer is None and gpu_aggregation_applies(index, params):
+        # first stage + full-document scoring on the GPU (one-query chunk of aggregate_evidence_batch)
+        return aggregate_evidence_batch([(ngrams_and_scores, unigram_scores)], index, **params)[0]
     gen = _aggregate_steps(ngrams_and_scores, unigram_scores, index, max_occurrences_1, max_occurrences_2,
                            n_docs_complete_score, alpha, beta, length_penalty, use_fm_index_frequency,
                            add_best_unigrams_to_ngrams, use_top_k_unigrams, sort_by_length, sort_by_freq, smoothing,
@@ -624,6 +633,16 @@ def _fetch_docs(index, doc_ids):
         return _DocBatch(flat, offs)
 
 
+def gpu_aggregation_applies(index, params) -> bool:
+    from .gpu_aggregate import gpu_aggregation_applies as applies
+    return applies(index, params)
+
+
+def _aggregate_on_gpu(index, requests, params):
+    from .gpu_aggregate import aggregate_on_gpu
+    return aggregate_on_gpu(index, requests, params)
+
+
 def aggregate_evidence_batch(jobs, index, **params):
     """``aggregate_evidence`` for several queries with the GPU work batched ACROSS them: one
     backward-search launch for every key of every query, one locate launch for every rare key of
@@ -656,6 +675,17 @@ def aggregate_evidence_batch(jobs, index, **params):
         except StopIteration as done:
             out[i] = done.value
     _mark("score_split")
+    if reqs and gpu_aggregation_applies(index, params):
+        # first stage + full-document scoring on the GPU (seal_amd/csrc/fmi_aggregate.hip): nothing but the top
+        # documents comes back.  A query that exceeds a device limit is handed back to the host routines below.
+        live = sorted(reqs)
+        results = _aggregate_on_gpu(index, [reqs[i] for i in live], params)
+        _mark("gpu_aggregate")
+        for i, res in zip(live, results):
+            if res is not None:
+                out[i] = (res, reqs[i][4]["all_ngrams"])
+                gens[i].close()
+                del reqs[i]
     while reqs:
         loc = [i for i, r in reqs.items() if r[0] == "locate"]
         answers = {}
@@ -806,7 +836,9 @@ def _aggregate_steps(ngrams_and_scores, unigram_scores=None, index=None, max_occ
     if rare_keys:
         los = np.asarray([count_of.ranges[k][0] if k in count_of.ranges else 0 for k in rare_keys], dtype=np.uint64)
         his = np.asarray([count_of.ranges[k][1] if k in count_of.ranges else 0 for k in rare_keys], dtype=np.uint64)
-        pos_all, doc_all, offs = yield ("locate", los, his, max_occurrences_1)
+        # the 5th element hands the scored keys to a driver that runs the rest on the GPU (_aggregate_on_gpu)
+        pos_all, doc_all, offs = yield ("locate", los, his, max_occurrences_1,
+                                        dict(rare=rare, all_ngrams=all_ngrams, unigram_scores=unigram_scores))
     else:
         pos_all = doc_all = np.zeros(0, dtype=np.int64)
         offs = np.zeros(1, dtype=np.int64)
