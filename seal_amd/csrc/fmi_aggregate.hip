@@ -157,7 +157,7 @@ __device__ uint32_t mis_first_boundary(const uint64_t *E, const uint16_t *M, uin
 
 // E: sorted (query, end position) keys; M: window length; PRI: processing order of the occurrence (lower = earlier)
 __global__ __launch_bounds__(256) void k_mis(const uint64_t *E, const uint16_t *M, const uint32_t *PRI, uint8_t *state, uint8_t *newflag,
-                                             uint32_t total, uint32_t maxlen)
+                                             uint32_t total, uint32_t maxlen, uint32_t *err)
 {
     __shared__ uint32_t s_min, s_pending;
     const uint32_t c0 = blockIdx.x * MIS_CHUNK;
@@ -165,7 +165,9 @@ __global__ __launch_bounds__(256) void k_mis(const uint64_t *E, const uint16_t *
     const uint32_t a = mis_first_boundary(E, M, total, maxlen, c0, &s_min);
     if (a >= c1) return;                      // no cluster starts in this chunk (uniform across the workgroup)
     const uint32_t b = (c1 == total) ? total : mis_first_boundary(E, M, total, maxlen, c1, &s_min);
-    for (;;) {
+    // every round decides at least the earliest undecided occurrence of the range: b - a rounds always suffice
+    for (uint32_t round = 0;; round++) {
+        if (round > b - a + 1) { if (threadIdx.x == 0) atomicOr(err, 1u); break; }
         __syncthreads();
         if (threadIdx.x == 0) s_pending = 0;
         __syncthreads();
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void k_entry_starts(const uint32_t *head, cons
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= total) return;
     if (head[j]) estart[eid[j]] = (uint32_t)j;
-    if (j == total - 1) { estart[eid[j] + 1] = (uint32_t)total; *n_entries = eid[j] + 1; }
+    if (j == total - 1) { const uint32_t ne = eid[j] + head[j]; estart[ne] = (uint32_t)total; *n_entries = ne; }   // eid = heads BEFORE j
 }
 
 // one wave per document entry (persistent grid): the keys that count for the document and their discounted scores
@@ -385,17 +387,19 @@ struct ScoreOut {                // what the recording pass writes (device point
     int32_t *stage_id; double *stage_score;                      // per-wave staging [waves][pick_cap]
 };
 
-struct OverflowPool { uint64_t *sk; uint32_t *key; uint32_t *cursor; uint32_t cap; };
+struct OverflowPool { uint64_t *sk; uint32_t *key; uint32_t *cursor; uint32_t cap; const uint32_t *err; };
 
 enum : uint32_t { AGG_FLAG_FALLBACK = 1u };      // the host must recompute this query with the checker routines
 
 __device__ __forceinline__ bool trie_lookup(const AggView &v, uint32_t tbase, uint32_t tmask, uint32_t node, uint32_t tok, uint32_t &child, uint32_t &key)
 {
-    for (uint32_t i = fmi_agg_trie_hash(node, tok) & tmask;; i = (i + 1) & tmask) {
+    uint32_t i = fmi_agg_trie_hash(node, tok) & tmask;
+    for (uint32_t n = 0; n <= tmask; n++, i = (i + 1) & tmask) {      // the table is at most half full
         const uint4 s = v.trie[tbase + i];
         if (s.x == FMI_AGG_TRIE_EMPTY) return false;
         if (s.x == node && s.y == tok) { child = s.z; key = s.w; return true; }
     }
+    return false;
 }
 
 // LDS per wave: tokens [t_cap] | free [t_cap/32] | cover [cover_words] | cand_sk 2 x u64 [cand_cap] | cand_key 2 x u32 [cand_cap] | counter
@@ -415,7 +419,10 @@ __global__ __launch_bounds__(256) void k_full_score(FmiDev ix, AggView v, ScoreP
     const uint32_t q = w / p.per_q, x = w % p.per_q;
     if (q >= v.nq) return;
     const uint32_t cnt = top_cnt[q];
-    if (RECORD && x == 0 && lane == 0) out.n_out[q] = min(cnt, p.per_q);
+    if (RECORD && x == 0 && lane == 0) {
+        out.n_out[q] = min(cnt, p.per_q);
+        if (*pool.err) atomicOr(&out.flags[q], AGG_FLAG_FALLBACK);          // an internal invariant of the first stage broke
+    }
     if (x >= min(cnt, p.per_q)) return;
     const uint32_t r = RECORD ? order[(uint64_t)q * p.n_top + x] : x;
     const uint32_t d = top_doc[(uint64_t)q * p.n_top + r];
@@ -704,7 +711,7 @@ Work carve(void *base, const FmiAggHeader &H, uint32_t n_top, uint32_t keep, uin
     w.top_doc = c.take<uint32_t>(nq * n_top); w.top_ent = c.take<uint32_t>(nq * n_top); w.top_cnt = c.take<uint32_t>(nq);
     w.scores = c.take<double>(nq * n_top); w.order = c.take<uint32_t>(nq * n_top);
     w.pool_cap = 1ull << 23;                                   // 8 M candidate slots (96 MB) for documents that overflow the LDS list
-    w.pool_sk = c.take<uint64_t>(w.pool_cap); w.pool_key = c.take<uint32_t>(w.pool_cap); w.pool_cursor = c.take<uint32_t>(4);
+    w.pool_sk = c.take<uint64_t>(w.pool_cap); w.pool_key = c.take<uint32_t>(w.pool_cap); w.pool_cursor = c.take<uint32_t>(8);
     w.stage_id = c.take<int32_t>(nq * (uint64_t)keep * pick_cap); w.stage_score = c.take<double>(nq * (uint64_t)keep * pick_cap);
     w.rp_bytes = rocprim_temp_bytes(N);
     w.rp_tmp = c.take<uint8_t>(w.rp_bytes);
@@ -818,6 +825,7 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
     const uint32_t nq = (uint32_t)H.nq;
     HIPCHK(hipMemsetAsync(d_out, 0, L.fixed_bytes, st));
     HIPCHK(hipMemsetAsync(w.top_cnt, 0, nq * 4, st));
+    HIPCHK(hipMemsetAsync(w.pool_cursor, 0, 32, st));          // [0]: pool cursor, [4]: error word of the first stage
     if (N) {
         // ---- first stage ----
         uint64_t *ka = w.k0, *kb = w.k1;
@@ -825,7 +833,8 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
         hipLaunchKernelGGL(k_agg_locate, dim3(blocks_for(N, 256)), dim3(256), 0, st, h->dev, v, w.occ_rk, w.doc, ka, va);
         if ((rc = sort_pairs(w, ka, kb, va, vb, N, FMI_AGG_POS_BITS + bits_for(nq - 1), st))) return rc;
         hipLaunchKernelGGL(k_mis_prepare, dim3(blocks_for(N, 256)), dim3(256), 0, st, v, va, w.occ_rk, w.M, w.state);
-        hipLaunchKernelGGL(k_mis, dim3(blocks_for(N, MIS_CHUNK)), dim3(256), 0, st, ka, w.M, va, w.state, w.newflag, (uint32_t)N, (uint32_t)H.max_key_len);
+        hipLaunchKernelGGL(k_mis, dim3(blocks_for(N, MIS_CHUNK)), dim3(256), 0, st, ka, w.M, va, w.state, w.newflag, (uint32_t)N, (uint32_t)H.max_key_len,
+                           w.pool_cursor + 4);
         hipLaunchKernelGGL(k_doc_keys, dim3(blocks_for(N, 256)), dim3(256), 0, st, v, w.occ_rk, w.doc, ka, va);
         if ((rc = sort_pairs(w, ka, kb, va, vb, N, 32 + bits_for(nq - 1), st))) return rc;
         hipLaunchKernelGGL(k_heads, dim3(blocks_for(N, 256)), dim3(256), 0, st, ka, w.head, N);
@@ -853,7 +862,6 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
     // ---- full scoring ----
     HIPCHK(hipMemsetAsync(w.type_dense, 0, (uint64_t)nq * H.vocab * 8, st));
     HIPCHK(hipMemsetAsync(w.tok2local, 0xFF, (uint64_t)nq * H.vocab * 4, st));
-    HIPCHK(hipMemsetAsync(w.pool_cursor, 0, 16, st));
     if (H.n_uni) hipLaunchKernelGGL(k_scatter_unigrams, dim3(blocks_for(H.n_uni, 256)), dim3(256), 0, st, v, H.n_uni, w.type_dense);
     if (H.n_tok) hipLaunchKernelGGL(k_scatter_local_ids, dim3(blocks_for(H.n_tok, 256)), dim3(256), 0, st, v, H.n_tok, w.tok2local);
     ScoreParams p{};
@@ -868,7 +876,7 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
         HIPCHK(hipFuncSetAttribute((const void *)k_full_score<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         HIPCHK(hipFuncSetAttribute((const void *)k_full_score<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
-    OverflowPool pool{w.pool_sk, w.pool_key, w.pool_cursor, (uint32_t)w.pool_cap};
+    OverflowPool pool{w.pool_sk, w.pool_key, w.pool_cursor, (uint32_t)w.pool_cap, w.pool_cursor + 4};
     ScoreOut so = L.o;
     so.stage_id = w.stage_id; so.stage_score = w.stage_score;
     p.per_q = (uint32_t)n_top;
