@@ -2,13 +2,15 @@
 """bench.py -- queries/sec of the SEAL search hot path on MI355X.
 
 One "step" = one pass of the hot path over one batch of synthetic queries:
-``SEALSearcher.batch_search`` (body decode 10 tokens + title decode <= 15 tokens,
-beam 15, FM-index constrained; count post-filters; rescoring; unigram scores;
-first-stage retrieval = counts + locate + doc binning + evidence aggregation) on
-an NQ-shaped synthetic FM-index with a random-init BART-large (fp32, as the
-reference runs it).  Not in the step: full-document trie rescoring
-(keys.py:366-497, SURVEY.md 8f-1 "next") and query-string n-gram keys (needs
-spaCy + the BART tokenizer, absent offline) -- both stated in `config`.
+the reference's complete ``SEALSearcher.batch_search`` (body decode 10 tokens +
+title decode <= 15 tokens, beam 15, FM-index constrained; count post-filters;
+rescoring; unigram scores; first-stage retrieval = counts + locate + doc binning +
+evidence aggregation; full-document rescoring of the 1500 best documents per query,
+keys.py:366-497 -- both aggregation stages as GPU kernels) on an NQ-shaped synthetic
+FM-index with a random-init BART-large (fp32, as the reference runs it).  After the
+timed region the GPU's answers for one batch are compared with the CPU oracle's
+and with the bit-exact host routines (``parity_check`` in the JSON line; a mismatch
+exits non-zero).
 
 Contract: python bench.py --gpus N --steps K --warmup W ; for N > 1 launched by
 torch.distributed.run, one rank per GPU; prints ONE JSON line on rank 0.
@@ -250,7 +252,9 @@ def main():
     ap.add_argument("--beam", type=int, default=15)
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--cpu-threads", type=int, default=64)
-    ap.add_argument("--jobs", type=int, default=8, help="host worker processes for the first-stage bookkeeping")
+    ap.add_argument("--jobs", type=int, default=1, help="host worker processes (only used by the host aggregation routines)")
+    ap.add_argument("--pipeline", type=int, default=1, help="query batches in flight on worker threads (each on its own stream); 1 = none")
+    ap.add_argument("--no-overlap", action="store_true", help="do not enqueue the next batch's decodes ahead of this batch's rescoring/aggregation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--first-stage-only", action="store_true",
                     help="stop after the first retrieval stage (SURVEY.md 8d metric) instead of the reference's complete batch_search")
@@ -310,11 +314,30 @@ def main():
     log(f"BART-large random init (fp32) in {time.perf_counter() - t0:.1f}s")
 
     searcher = SEALSearcher(index, None, model, add_query_to_keys=False, detokenize=False, first_stage_only=args.first_stage_only,
-                            beam=args.beam, batch_size=args.batch, jobs=args.jobs)
+                            beam=args.beam, batch_size=args.batch, jobs=args.jobs, pipeline=args.pipeline, overlap=not args.no_overlap)
     from seal_amd.bart_decoder import BartStepDecoder
     model._seal_step_decoder = BartStepDecoder(model)
-    check(lib().fmi_dev_enable_probe_count(index.handle, 1))
-    check(lib().fmi_dev_enable_timing(index.handle, 1))
+    # every pipeline drives the constraint kernels through its own view of the index: count / time all of them
+    handles = [index.handle] + ([p.index.handle for p in searcher._pipelines()] if searcher._pipelined() else [])
+    for hd in handles:
+        check(lib().fmi_dev_enable_probe_count(hd, 1))
+        check(lib().fmi_dev_enable_timing(hd, 1))
+
+    def read_counters(stats=None):
+        """(probes, launches, kernel ms) summed over the handles since the last read; expand stats accumulate"""
+        import ctypes as C
+        tp, tl, tk = 0, 0, 0.0
+        for hd in handles:
+            if stats is not None:
+                xs = (C.c_uint64 * 4)()
+                check(lib().fmi_dev_read_expand_stats(hd, xs))
+                for j in range(4):
+                    stats[j] += xs[j]
+            pr, ln, km = C.c_uint64(), C.c_uint64(), C.c_double()
+            check(lib().fmi_dev_read_probe_count(hd, C.byref(pr)))
+            check(lib().fmi_dev_read_timing(hd, C.byref(ln), C.byref(km)))
+            tp += pr.value; tl += ln.value; tk += km.value
+        return tp, tl, tk
 
     def run_batches(i0, n):
         """n consecutive batches in ONE searcher call: key generation of batch i+1 (GPU) overlaps the
@@ -342,10 +365,7 @@ def main():
         torch.cuda.synchronize()
         step_ms.append((time.perf_counter() - t1) * 1e3)
     import ctypes
-    probes = ctypes.c_uint64()
-    launches, kms = ctypes.c_uint64(), ctypes.c_double()
-    check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(probes)))
-    check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(launches), ctypes.byref(kms)))
+    read_counters()                                        # drop the warm-up's counts
 
     torch.cuda.synchronize()
     if use_dist:
@@ -360,11 +380,9 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    xstats = (ctypes.c_uint64 * 4)()
-    check(lib().fmi_dev_read_expand_stats(index.handle, xstats))
-    check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(probes)))
-    check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(launches), ctypes.byref(kms)))
-    probes, launches, kms = ctypes.c_uint64(probes.value), ctypes.c_uint64(launches.value), ctypes.c_double(kms.value)
+    xstats = [0, 0, 0, 0]
+    _p, _l, _k = read_counters(xstats)
+    probes, launches, kms = ctypes.c_uint64(_p), ctypes.c_uint64(_l), ctypes.c_double(_k)
     n_found = float(np.mean([len(r) for r in res]))
 
     # secondary figure: the same K batches through the other retrieval depth (first stage only <-> complete)
@@ -389,8 +407,7 @@ def main():
             t2 = float(tt.item())
         other_qps = args.batch * args.steps * world / t2
         searcher.first_stage_only = args.first_stage_only
-        check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(ctypes.c_uint64())))
-        check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(ctypes.c_uint64()), ctypes.byref(ctypes.c_double())))
+        read_counters()
 
     if rank != 0:
         if use_dist:
@@ -418,10 +435,12 @@ def main():
     rk.compute_unigram_scores = timed("unigram_ms", orig[2])
     rk.aggregate_evidence_batch = timed("aggregate_ms", orig[3])
     retrieval._count_filter = timed("count_filter_ms", orig[4])
-    index._trace = []
-    jobs_saved = searcher.jobs
+    jobs_saved, pipeline_saved, overlap_saved = searcher.jobs, searcher.pipeline, searcher.overlap
+    searcher.overlap = False
     if not os.environ.get("SEAL_BENCH_KEEP_JOBS"):
         searcher.jobs = 1                                  # inline host stages: their time shows up in aggregate_ms
+    searcher.pipeline = 1                                  # one batch, on this thread: phase times are not interleaved
+    read_counters()
     if os.environ.get("SEAL_BENCH_PROFILE"):
         import cProfile, pstats
         pr = cProfile.Profile()
@@ -431,12 +450,23 @@ def main():
         pstats.Stats(pr, stream=sys.stderr).sort_stats(os.environ.get("SEAL_BENCH_PROFILE_SORT", "cumulative")).print_stats(int(os.environ.get("SEAL_BENCH_PROFILE_N", "45")))
     else:
         run_batch(args.warmup + args.steps)
-    trace, index._trace = index._trace, None
-    searcher.jobs = jobs_saved
     retrieval.fm_index_generate, rk.rescore_keys, rk.compute_unigram_scores, rk.aggregate_evidence_batch, retrieval._count_filter = orig
-    p2, l2, k2 = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
-    check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(p2)))
-    check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(l2), ctypes.byref(k2)))
+    _p, _l, _k = read_counters()
+    p2, l2, k2 = ctypes.c_uint64(_p), ctypes.c_uint64(_l), ctypes.c_double(_k)
+    # the same batch once more, untimed, RECORDING every index operation with the GPU's answer (parity_check below)
+    agg_calls = []
+
+    def recording_aggregate(*a, **kw):
+        res = orig[3](*a, **kw)
+        agg_calls.append((a, kw, res))
+        return res
+    rk.aggregate_evidence_batch = recording_aggregate
+    trace = []
+    index.set_trace(trace)
+    run_batch(args.warmup + args.steps)
+    index.set_trace(None)
+    rk.aggregate_evidence_batch = orig[3]
+    searcher.jobs, searcher.pipeline, searcher.overlap = jobs_saved, pipeline_saved, overlap_saved
 
     # one probe = one 128-byte block of the hex wavelet matrix, counted in-kernel (distinct blocks per
     # node): the bytes THIS data structure has to read for the work
@@ -480,6 +510,25 @@ def main():
         n_real_ops = len(trace) - 1
         rep, answers = replay_on_cpu(orc, trace, index.beginnings, threads)
         parity = parity_check(index, trace[:n_real_ops], answers[:n_real_ops])
+        # the evidence aggregation itself (first stage + full-document scoring on the GPU) against the bit-exact host
+        # routines (fmi_first_stage / fmi_full_score) on the same keys: ranked documents, float64 scores, accepted keys
+        t0 = time.perf_counter()
+        n_docs_cmp = n_bad = 0
+        for a, kw, res in agg_calls:
+            host = orig[3](*a, **{**kw, "gpu_aggregate": False, "defer": None})
+            for (g, _), (w, _) in zip(res, host):
+                g = g.result() if hasattr(g, "result") else g
+                w = w.result() if hasattr(w, "result") else w
+                wl = list(w.items())[:len(g)]
+                n_docs_cmp += len(wl)
+                for (gd, gi), (wd, wi) in zip(g.items(), wl):
+                    same = gd == wd and gi[0] == wi[0] and list(gi[1]) == list(wi[1]) and list(gi[3]) == list(wi[3]) and gi[4][1] == wi[4][1]
+                    n_bad += 0 if same else 1
+                n_bad += abs(len(g) - len(wl))
+        parity["ops"] += len(agg_calls); parity["values_compared"] += n_docs_cmp; parity["mismatches"] += n_bad
+        parity["by_kind"]["aggregated_documents_scores_and_keys"] = {"ops": len(agg_calls), "values": n_docs_cmp, "mismatches": n_bad,
+                                                                      "against": "fmi_first_stage + fmi_full_score (host float64 routines) on the same keys"}
+        log(f"aggregation parity: {n_docs_cmp} ranked documents vs the host routines in {time.perf_counter() - t0:.1f}s, {n_bad} mismatches")
         log(f"parity_check: {parity['ops']} ops, {parity['values_compared']} values, {parity['mismatches']} mismatches")
         t_cpu = rep["mask_s"] + rep["ranges_s"] + rep["locate_s"] + rep["docs_s"]
         cpu = {"value": round(args.batch / t_cpu, 3), "unit": "queries/s (FM-index path only)", "cores": threads, "kind": "port",
@@ -498,7 +547,7 @@ def main():
         "config": {"workload": f"configs[1]: NQ-shaped synthetic FM-index ({args.docs} passages, {index.size()} symbols), random-init "
                                f"BART-large fp32, beam={args.beam}, batch={args.batch} per GPU, body len 10 + title len<=15, "
                                f"{'first-stage retrieval' if args.first_stage_only else 'first stage + full-document rescoring of 1500 docs/query'}, top-{args.topk}",
-                   "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated", "model_arithmetic": "fp32 (as the reference runs BART)",
+                   "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated; " + ("next batch's decodes enqueued ahead of this batch's rescoring/aggregation (2 streams)" if not args.no_overlap and args.pipeline <= 1 else f"{args.pipeline} query batches in flight per GPU"), "model_arithmetic": "fp32 (as the reference runs BART)",
                    "not_in_step": (["full-document rescoring (keys.py:366-497)"] if args.first_stage_only else []) +
                                   ["query-string n-gram keys (add_query_to_keys: spaCy/tokenizer absent offline)"]},
         "roofline": roofline,

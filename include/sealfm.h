@@ -96,6 +96,11 @@ int fmi_to_device(fmi_t *h, int device);
  * token offsets; uploaded so that doc-id binning (index.py:77-82) runs on the GPU. */
 int fmi_set_doc_beginnings(fmi_t *h, const uint64_t *beginnings, uint64_t n_entries);
 
+/* A second handle on the same resident index: shares the device arrays of `src` (which must outlive the view) and
+ * owns only the mutable per-pipeline state (workspace, incremental constraint state, counters, service stream), so that
+ * several decode / retrieval pipelines can run on one GPU at a time, each on its own stream.  Free with fmi_free. */
+int fmi_view_create(const fmi_t *src, fmi_t **out);
+
 /* FMIndex::size()  (fm_index.cpp:50-52) */
 uint64_t fmi_size(const fmi_t *h);
 /* index.wavelet_tree.sigma (fm_index.cpp:38): distinct symbols incl. sentinel */
@@ -289,6 +294,21 @@ int fmi_agg_pack(uint64_t n_queries, const int64_t *q_key_off, const int64_t *ke
 const void *fmi_agg_plan_blob(const fmi_agg_plan_t *plan, uint64_t *bytes_out);
 uint64_t fmi_agg_plan_occurrences(const fmi_agg_plan_t *plan);
 void fmi_agg_plan_free(fmi_agg_plan_t *plan);
+
+/* Key scoring of aggregate_evidence (keys.py:207-309) + fmi_agg_pack in one call, for a chunk of queries: input = the keys
+ * as the searcher hands them over (CSR tokens, LM log-probabilities, row ranges from one backward-search launch), the
+ * model's unigram log-probabilities per query ([vocab] each, or NULL), the per-index single-token range table, and
+ * aggregate_evidence's parameters; float64 through libm (log, exp, pow) in the reference's operation order.  The plan
+ * additionally holds `all_ngrams` of every query (fmi_agg_plan_ngrams: src = index into the query's input keys, or
+ * -(token+1) for a unigram added by keys.py:274-278; score; rare flag) and, per table key, its src (fmi_agg_plan_table_src). */
+int fmi_agg_score_pack(uint64_t n_queries, const int64_t *q_key_off, const int64_t *key_tok_off, const int64_t *key_toks,
+                       const double *key_lm_score, const uint64_t *key_lo, const uint64_t *key_hi,
+                       const double *const *unigram_logprobs, uint64_t vocab, const int64_t *uni_lo, const int64_t *uni_hi,
+                       uint64_t n_uni_table, double ntokens, double alpha, double length_penalty, double smoothing,
+                       int use_fm_index_frequency, int add_best_unigrams_to_ngrams, int64_t use_top_k_unigrams,
+                       uint64_t max_occurrences_1, uint64_t max_occurrences_2, uint64_t index_size, fmi_agg_plan_t **out);
+uint64_t fmi_agg_plan_ngrams(const fmi_agg_plan_t *plan, uint64_t query, int64_t *src, double *score, uint8_t *rare);
+uint64_t fmi_agg_plan_table_src(const fmi_agg_plan_t *plan, int64_t *src);
 
 /* byte offsets into the output buffer of fmi_dev_aggregate, as fmi_dev_aggregate_sizes reports them in out_layout[20].
  * R = n_queries * keep records, record (q, x) = x-th best document of query q at index q * keep + x. */

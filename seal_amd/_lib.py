@@ -21,6 +21,7 @@ SIGNATURES = {
     "fmi_abi_version": (ctypes.c_uint32, []),
     "fmi_create": (_int, [ctypes.POINTER(_vp)]),
     "fmi_free": (None, [_vp]),
+    "fmi_view_create": (_int, [_vp, ctypes.POINTER(_vp)]),
     "fmi_build": (_int, [_vp, _p64, _u64, _int]),
     "fmi_build_from_file": (_int, [_vp, ctypes.c_char_p, _int, _int]),
     "fmi_build_device": (_int, [_vp, _vp, _u64, _int, _int]),
@@ -73,6 +74,10 @@ SIGNATURES = {
     "fmi_fullscore_read": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fmi_fullscore_free": (None, [_vp]),
     "fmi_agg_pack": (_int, [_u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _u64, ctypes.POINTER(_vp)]),
+    "fmi_agg_score_pack": (_int, [_u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _u64, ctypes.c_double, ctypes.c_double,
+                                  ctypes.c_double, ctypes.c_double, _int, _int, _i64, _u64, _u64, _u64, ctypes.POINTER(_vp)]),
+    "fmi_agg_plan_ngrams": (_u64, [_vp, _u64, _vp, _vp, _vp]),
+    "fmi_agg_plan_table_src": (_u64, [_vp, _vp]),
     "fmi_agg_plan_blob": (_vp, [_vp, _p64]),
     "fmi_agg_plan_occurrences": (_u64, [_vp]),
     "fmi_agg_plan_free": (None, [_vp]),

@@ -24,6 +24,11 @@ import torch
 import torch.nn.functional as F
 
 
+import threading
+
+_CAPTURE_LOCK = threading.Lock()      # one hipGraph capture at a time (concurrent captures from two pipelines fail on HIP)
+
+
 class BartStepDecoder:
     def __init__(self, model):
         self.model = model
@@ -56,6 +61,17 @@ class BartStepDecoder:
         # optional additive bias on the next-token logits, [batch, vocab], shared by the beams of a query
         # (bench.py shapes a random-init model's preferences towards corpus n-grams with it)
         self.logit_bias: Optional[torch.Tensor] = None
+
+    def clone_for_pipeline(self) -> "BartStepDecoder":
+        """a decoder over the SAME weights with its own static buffers / captured graphs / decode position: one per
+        concurrent query-batch pipeline (the buffers of a shape are reused by every decode of that shape, so two
+        decodes in flight need two sets)"""
+        import copy
+        c = copy.copy(self)
+        c.__dict__.pop("_static_cache", None)
+        c._st = None
+        c.logit_bias = None
+        return c
 
     @torch.no_grad()
     def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
@@ -225,6 +241,7 @@ class BartStepDecoder:
         self._st = st
         self.t = 0
         if st.graph is None:
+          with _CAPTURE_LOCK:
             # warm up on a side stream, then capture (standard torch recipe); the cache contents
             # written by the warm-up steps are overwritten/masked once t is reset
             side = torch.cuda.Stream(device=enc_hidden.device)

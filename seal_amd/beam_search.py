@@ -315,6 +315,7 @@ def fm_index_generate(
             stop_at_count=stop_at_count, always_allow_eos=always_allow_eos, forced_bos_token_id=forced_bos_token_id)
     if disable_fm_index:
         processor = None
+    pending = kwargs.pop("pending", False)
     enc = decoder.encode(input_ids, attention_mask)
     decoder.start(enc, attention_mask, num_beams, max_length)
     saved_bias = decoder.logit_bias
@@ -326,4 +327,28 @@ def fm_index_generate(
             constrained_decoding_processor=processor, device=input_ids.device)
     finally:
         decoder.logit_bias = saved_bias
+    if pending:
+        # the whole decode is enqueued by now and nothing has waited for the GPU: hand back a handle, so that the caller
+        # can put more work behind it (the next decode) before it asks for the hypotheses
+        return PendingGenerate(steps, final, input_ids.shape[0], num_beams, length_penalty, enc=enc)
     return _history_to_hypotheses(steps, final, input_ids.shape[0], num_beams, length_penalty)
+
+
+class PendingGenerate:
+    """an enqueued ``fm_index_generate``: ``result()`` waits for the GPU and builds the hypothesis lists.
+    ``enc`` = the encoder states of the call (the searcher reuses them where the reference re-encodes the same input)."""
+
+    def __init__(self, steps, final, batch, beams, length_penalty, enc=None):
+        self._args = (steps, final, batch, beams, length_penalty)
+        self.enc = enc
+        self.first_logits = None
+        self._event = torch.cuda.Event() if final[0].is_cuda else None
+        if self._event is not None:
+            self._event.record(torch.cuda.current_stream(final[0].device))
+
+    def result(self):
+        if self._event is not None:
+            self._event.synchronize()
+        out = _history_to_hypotheses(*self._args)
+        self._args = None
+        return out

@@ -776,7 +776,7 @@ static int agg_check(fmi *h, const FmiAggHeader &H, uint64_t n_top, uint64_t kee
     if (!h->dev.sa_lo || !h->dev.text || !h->dev.doc_begin) { fmi_set_error("fmi_dev_aggregate needs the suffix array, the text and the document boundaries resident"); return FMI_ERR_STATE; }
     if (h->max_doc_len == 0 || h->max_doc_len > AGG_MAX_DOC_LEN) { fmi_set_error("fmi_dev_aggregate: longest document %llu tokens (1..%u supported)", (unsigned long long)h->max_doc_len, AGG_MAX_DOC_LEN); return FMI_ERR_ARG; }
     if (n_top == 0 || n_top > AGG_MAX_TOP || keep == 0 || keep > n_top) { fmi_set_error("fmi_dev_aggregate: 1 <= keep <= n_top <= %u", AGG_MAX_TOP); return FMI_ERR_ARG; }
-    if (h->n >= (1ull << 40) || h->doc_begin.size() >= (1ull << 32)) { fmi_set_error("fmi_dev_aggregate: index too large for the sort keys"); return FMI_ERR_ARG; }
+    if (h->n >= (1ull << 40) || h->dev.n_begin >= (1ull << 32)) { fmi_set_error("fmi_dev_aggregate: index too large for the sort keys"); return FMI_ERR_ARG; }
     return FMI_OK;
 }
 

@@ -61,6 +61,24 @@ void fmi_release_device(fmi *h)
     h->dev_bytes = 0;
 }
 
+// A second handle on the SAME resident index: shares every device array of `src` (which must outlive it) and owns
+// only what a decode / retrieval pipeline mutates -- workspace, incremental constraint state, counters, service
+// stream.  One view per concurrent pipeline (seal_amd/retrieval.py runs two query batches at a time on one GPU).
+extern "C" int fmi_view_create(const fmi_t *src, fmi_t **out)
+{
+    if (!src || !out) { fmi_set_error("fmi_view_create: null argument"); return FMI_ERR_ARG; }
+    if (src->device < 0) { fmi_set_error("fmi_view_create: the index is not resident on a GPU"); return FMI_ERR_NO_DEVICE; }
+    fmi *v = new fmi();
+    v->n = src->n; v->max_sym = src->max_sym; v->sigma = src->sigma; v->nblk = src->nblk;
+    v->levels = src->levels; v->dlevels = src->dlevels; v->sym_bytes = src->sym_bytes; v->sb_shift = src->sb_shift; v->nsb = src->nsb;
+    v->max_doc_len = src->max_doc_len;
+    v->device = src->device;
+    v->dev = src->dev;              // pointers into src's allocations; dev_allocs stays empty: nothing to free here
+    v->dev_bytes = 0;
+    *out = v;
+    return FMI_OK;
+}
+
 extern "C" void fmi_free(fmi_t *h)
 {
     if (!h) return;

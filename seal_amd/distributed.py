@@ -32,12 +32,13 @@ def shard_queries(queries: Sequence, rank: int = None, world: int = None) -> Lis
 
 def pack_topk(results, k: int) -> torch.Tensor:
     """``[[SEALDocument...]...]`` (or ``[[(doc, score)...]...]``) -> float64 ``[n, k, 2]``, padded with -1."""
-    out = torch.full((len(results), k, 2), -1.0, dtype=torch.float64)
+    import numpy as np
+    out = np.full((len(results), k, 2), -1.0, dtype=np.float64)
     for qi, docs in enumerate(results):
-        for j, d in enumerate(docs[:k]):
-            idx, score = (d.idx, d.score) if hasattr(d, "idx") else d
-            out[qi, j, 0], out[qi, j, 1] = float(idx), float(score)
-    return out
+        docs = docs[:k]
+        if docs:
+            out[qi, :len(docs)] = [(d.idx, d.score) if hasattr(d, "idx") else d for d in docs]
+    return torch.from_numpy(out)
 
 
 def gather_topk(local: torch.Tensor, n_total: int, device=None) -> torch.Tensor:

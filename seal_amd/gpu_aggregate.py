@@ -134,14 +134,112 @@ def aggregate_on_gpu(index, requests, params) -> List[Optional[dict]]:
     return out
 
 
-def _aggregate_plan(index, requests, params):
+def _plan_header(blob_ptr):
+    """the FmiAggHeader fields of a plan blob (seal_amd/csrc/fmi_agg.h) as a dict"""
+    import struct
+    names = ["magic", "bytes", "nq", "n_keys", "n_rare", "total_occ", "vocab", "max_key_len", "max_u", "max_q_keys", "n_uni",
+             "n_trie_slots", "n_tok", "o_q_key_off", "o_q_rare_off", "o_rare_key", "o_rare_occ_off", "o_key_lo"]
+    raw = ctypes.string_at(blob_ptr, 8 * len(names))
+    return dict(zip(names, struct.unpack("<%dQ" % len(names), raw)))
+
+
+def _run_plan(index, plan, nq, params):
+    """copies the plan to the GPU, runs ``fmi_dev_aggregate`` on the index's retrieval stream and fetches the records of
+    the top documents.  Returns (keep, n_out, flags, records..., pools...) as numpy arrays."""
     import torch
     from .index import SHIFT
     L = lib()
-    nq = len(requests)
     n_top = int(params.get("n_docs_complete_score", 500))
     keep = params.get("keep")
     keep = n_top if keep is None else max(1, min(int(keep), n_top))
+    blob_bytes = ctypes.c_uint64()
+    blob_ptr = L.fmi_agg_plan_blob(plan, ctypes.byref(blob_bytes))
+    blob_bytes = int(blob_bytes.value)
+    ws_bytes = ctypes.c_uint64()
+    layout = (ctypes.c_uint64 * 20)()
+    allow = int(bool(params.get("allow_overlaps", False)))
+    check(L.fmi_dev_aggregate_sizes(index.handle, plan, n_top, keep, allow, ctypes.byref(ws_bytes), layout))
+    off = list(layout)
+    fixed_bytes, out_bytes = off[17], off[18]
+    dev = torch.device("cuda", L.fmi_device(index.handle))
+    bufs = index.__dict__.get("_agg_buffers")
+    if bufs is None:
+        bufs = index.__dict__["_agg_buffers"] = _Buffers()
+    R = nq * keep
+    bufs.fit(dev, ws_bytes.value, out_bytes, blob_bytes, max(fixed_bytes, 1 << 20))
+    st = index._side_stream(dev)
+    with torch.cuda.stream(st):
+        ctypes.memmove(bufs.pin_in.data_ptr(), blob_ptr, blob_bytes)
+        bufs.blob[:blob_bytes].copy_(bufs.pin_in[:blob_bytes], non_blocking=True)
+        check(L.fmi_dev_aggregate(
+            index.handle, st.cuda_stream, plan, bufs.blob.data_ptr(), n_top, keep, allow, float(params.get("beta", 0.8)),
+            float(params.get("single_key", 0.0)), int(bool(params.get("single_key_add_unigrams", False))),
+            int(bool(params.get("unigrams_ignore_free_places", False))), SHIFT, bufs.ws.data_ptr(), bufs.ws.numel(),
+            bufs.out.data_ptr(), bufs.out.numel()))
+        bufs.pin_out[:fixed_bytes].copy_(bufs.out[:fixed_bytes], non_blocking=True)
+        st.synchronize()
+        fixed = bufs.pin_out[:fixed_bytes].numpy().copy()
+        view = lambda slot, dt, n: fixed[off[slot]:off[slot] + n * np.dtype(dt).itemsize].view(dt)
+        cursor = view(2, np.uint32, 2)
+        n_picks, n_toks = int(cursor[0]), int(cursor[1])
+        # the used prefixes of the pick and token pools, one more round trip
+        need = 4 * n_picks + 8 * n_picks + 4 * n_toks + 64
+        bufs.pin_out = bufs._fit(bufs.pin_out, need, pin_memory=True)
+        a0, a1, a2 = 0, (4 * n_picks + 15) & ~15, ((4 * n_picks + 15) & ~15) + 8 * n_picks
+        if n_picks:
+            bufs.pin_out[a0:a0 + 4 * n_picks].copy_(bufs.out[off[12]:off[12] + 4 * n_picks], non_blocking=True)
+            bufs.pin_out[a1:a1 + 8 * n_picks].copy_(bufs.out[off[13]:off[13] + 8 * n_picks], non_blocking=True)
+        if n_toks:
+            bufs.pin_out[a2:a2 + 4 * n_toks].copy_(bufs.out[off[14]:off[14] + 4 * n_toks], non_blocking=True)
+        st.synchronize()
+        host = bufs.pin_out.numpy()
+        out = dict(keep=keep, n_out=view(0, np.uint32, nq), flags=view(1, np.uint32, nq),
+                   pick_id=host[a0:a0 + 4 * n_picks].view(np.int32).copy(), pick_score=host[a1:a1 + 8 * n_picks].view(np.float64).copy(),
+                   tokens=host[a2:a2 + 4 * n_toks].view(np.int32).copy(),
+                   doc=view(3, np.uint64, R), score=view(4, np.float64, R), best_score=view(5, np.float64, R),
+                   best_key=view(6, np.int32, R), T=view(7, np.uint32, R), npicks=view(8, np.uint32, R),
+                   pick_off=view(9, np.uint32, R), tok_off=view(10, np.uint32, R))
+        tracing = getattr(index, "_trace", None) is not None
+        if index.__dict__.get("_agg_debug") is not None or tracing:       # tests / bench.py parity: the first-stage ranking as well
+            fs_cnt = view(11, np.uint32, nq).copy()
+            fs_doc = bufs.out[off[15]:off[15] + 4 * nq * n_top].cpu().numpy().view(np.uint32).reshape(nq, n_top)
+            fs_score = bufs.out[off[16]:off[16] + 8 * nq * n_top].cpu().numpy().view(np.float64).reshape(nq, n_top)
+            if index.__dict__.get("_agg_debug") is not None:
+                index.__dict__["_agg_debug"].append([(fs_doc[q, :fs_cnt[q]].copy(), fs_score[q, :fs_cnt[q]].copy()) for q in range(nq)])
+            if tracing:
+                # bench.py records every index operation of a batch with the GPU's answer to compare them with the CPU
+                # oracle's: the located rows and the candidate documents never reach the host on this path, so the same
+                # rows / documents are fetched once more through the host-visible calls (which record)
+                H = _plan_header(blob_ptr)
+                rare_key = np.frombuffer(ctypes.string_at(blob_ptr + H["o_rare_key"], 4 * H["n_rare"]), dtype=np.uint32)
+                occ = np.frombuffer(ctypes.string_at(blob_ptr + H["o_rare_occ_off"], 8 * (H["n_rare"] + 1)), dtype=np.uint64).astype(np.int64)
+                key_lo = np.frombuffer(ctypes.string_at(blob_ptr + H["o_key_lo"], 8 * max(H["n_keys"], 1)), dtype=np.uint64).astype(np.int64)
+                lo = key_lo[rare_key.astype(np.int64)] if H["n_rare"] else np.zeros(0, np.int64)
+                index.locate_ranges(lo, lo + np.diff(occ), int(params.get("max_occurrences_1", 1500)))
+                index.get_docs_batch(np.concatenate([fs_doc[q, :fs_cnt[q]] for q in range(nq)]).astype(np.int64), as_arrays="flat")
+    return out
+
+
+def _results_of(out, qi, k0, ngram_of):
+    """``results`` of query qi from the fetched records: doc -> [score, picks, None, tokens, [best ngram, best score]]"""
+    keep = out["keep"]
+    a, n = qi * keep, int(out["n_out"][qi])
+    docs, sc = out["doc"][a:a + n].tolist(), out["score"][a:a + n].tolist()
+    bk, bs = out["best_key"][a:a + n].tolist(), out["best_score"][a:a + n].tolist()
+    po, npk, to, T = out["pick_off"][a:a + n].tolist(), out["npicks"][a:a + n].tolist(), out["tok_off"][a:a + n].tolist(), out["T"][a:a + n].tolist()
+    res = {}
+    for x, d in enumerate(docs):
+        ids = out["pick_id"][po[x]:po[x] + npk[x]]
+        ids = np.where(ids >= 0, ids - k0, ids)                 # table key id -> index into this query's table
+        res[d] = [sc[x], _LazyPicks(ids, out["pick_score"][po[x]:po[x] + npk[x]], ngram_of), None,
+                  _LazyTokens(out["tokens"][to[x]:to[x] + T[x]]), [ngram_of[bk[x] - k0] if bk[x] >= 0 else [], bs[x]]]
+    return res
+
+
+def _aggregate_plan(index, requests, params):
+    """the python-scored keys of the queries (``_aggregate_steps`` requests) -> fmi_agg_pack -> device"""
+    L = lib()
+    nq = len(requests)
     max_hits = int(requests[0][3])
     # ---- table keys: the positive keys of all_ngrams, in its order; rare ones carry their row range ----
     table: List[list] = []
@@ -189,79 +287,125 @@ def _aggregate_plan(index, requests, params):
     check(L.fmi_agg_pack(nq, p(q_key_off), p(key_tok_off), p(key_toks), p(key_score), p(key_rare), p(key_lo), p(key_hi), max_hits,
                          int(index.size()), tp, vocab, ctypes.byref(plan)))
     try:
-        blob_bytes = ctypes.c_uint64()
-        blob_ptr = L.fmi_agg_plan_blob(plan, ctypes.byref(blob_bytes))
-        blob_bytes = int(blob_bytes.value)
-        ws_bytes = ctypes.c_uint64()
-        layout = (ctypes.c_uint64 * 20)()
-        allow = int(bool(params.get("allow_overlaps", False)))
-        check(L.fmi_dev_aggregate_sizes(index.handle, plan, n_top, keep, allow, ctypes.byref(ws_bytes), layout))
-        off = list(layout)
-        fixed_bytes, out_bytes = off[17], off[18]
-        dev = torch.device("cuda", L.fmi_device(index.handle))
-        bufs = index.__dict__.get("_agg_buffers")
-        if bufs is None:
-            bufs = index.__dict__["_agg_buffers"] = _Buffers()
-        R = nq * keep
-        bufs.fit(dev, ws_bytes.value, out_bytes, blob_bytes, max(fixed_bytes, 1 << 20))
-        st = index._side_stream(dev)
-        with torch.cuda.stream(st):
-            ctypes.memmove(bufs.pin_in.data_ptr(), blob_ptr, blob_bytes)
-            bufs.blob[:blob_bytes].copy_(bufs.pin_in[:blob_bytes], non_blocking=True)
-            check(L.fmi_dev_aggregate(
-                index.handle, st.cuda_stream, plan, bufs.blob.data_ptr(), n_top, keep, allow, float(params.get("beta", 0.8)),
-                float(params.get("single_key", 0.0)), int(bool(params.get("single_key_add_unigrams", False))),
-                int(bool(params.get("unigrams_ignore_free_places", False))), SHIFT, bufs.ws.data_ptr(), bufs.ws.numel(),
-                bufs.out.data_ptr(), bufs.out.numel()))
-            bufs.pin_out[:fixed_bytes].copy_(bufs.out[:fixed_bytes], non_blocking=True)
-            st.synchronize()
-            fixed = bufs.pin_out[:fixed_bytes].numpy().copy()
-            view = lambda slot, dt, n: fixed[off[slot]:off[slot] + n * np.dtype(dt).itemsize].view(dt)
-            n_out, flags, cursor = view(0, np.uint32, nq), view(1, np.uint32, nq), view(2, np.uint32, 2)
-            n_picks, n_toks = int(cursor[0]), int(cursor[1])
-            # the used prefixes of the pick and token pools, one more round trip
-            need = 4 * n_picks + 8 * n_picks + 4 * n_toks + 64
-            bufs.pin_out = bufs._fit(bufs.pin_out, need, pin_memory=True)
-            a0, a1, a2 = 0, (4 * n_picks + 15) & ~15, ((4 * n_picks + 15) & ~15) + 8 * n_picks
-            if n_picks:
-                bufs.pin_out[a0:a0 + 4 * n_picks].copy_(bufs.out[off[12]:off[12] + 4 * n_picks], non_blocking=True)
-                bufs.pin_out[a1:a1 + 8 * n_picks].copy_(bufs.out[off[13]:off[13] + 8 * n_picks], non_blocking=True)
-            if n_toks:
-                bufs.pin_out[a2:a2 + 4 * n_toks].copy_(bufs.out[off[14]:off[14] + 4 * n_toks], non_blocking=True)
-            st.synchronize()
-            host = bufs.pin_out.numpy()
-            pick_id = host[a0:a0 + 4 * n_picks].view(np.int32).copy()
-            pick_score = host[a1:a1 + 8 * n_picks].view(np.float64).copy()
-            tokens = host[a2:a2 + 4 * n_toks].view(np.int32).copy()
-            if index.__dict__.get("_agg_debug") is not None:       # tests: the first-stage ranking as well
-                fs_cnt = view(11, np.uint32, nq).copy()
-                fs_doc = bufs.out[off[15]:off[15] + 4 * nq * n_top].cpu().numpy().view(np.uint32).reshape(nq, n_top)
-                fs_score = bufs.out[off[16]:off[16] + 8 * nq * n_top].cpu().numpy().view(np.float64).reshape(nq, n_top)
-                index.__dict__["_agg_debug"].append([(fs_doc[q, :fs_cnt[q]].copy(), fs_score[q, :fs_cnt[q]].copy()) for q in range(nq)])
+        out = _run_plan(index, plan, nq, params)
     finally:
         L.fmi_agg_plan_free(plan)
-    rec_doc, rec_score, rec_best_score = view(3, np.uint64, R), view(4, np.float64, R), view(5, np.float64, R)
-    rec_best_key, rec_T, rec_np = view(6, np.int32, R), view(7, np.uint32, R), view(8, np.uint32, R)
-    rec_po, rec_to = view(9, np.uint32, R), view(10, np.uint32, R)
-    results: List[Optional[dict]] = []
+    return [None if out["flags"][qi] & 1 else _results_of(out, qi, int(q_key_off[qi]), table[qi]) for qi in range(nq)]
+
+
+# ---------------------------------------------------------------------------
+# the searcher's path: key scoring in C++ as well (fmi_agg_score_pack)
+# ---------------------------------------------------------------------------
+class _NgramTable:
+    """table key index -> ngram tuple of one query (built on demand from the query's input keys)"""
+    __slots__ = ("_src", "_keys")
+
+    def __init__(self, src, keys):
+        self._src, self._keys = src, keys
+
+    def __getitem__(self, i):
+        s = int(self._src[i])
+        return tuple(self._keys[s]) if s >= 0 else (-s - 1,)
+
+
+def score_and_aggregate_on_gpu(index, jobs, params, want_ngrams=True):
+    """``aggregate_evidence`` for the queries of a chunk with the key scoring (keys.py:207-309) in C++
+    (``fmi_agg_score_pack``) and everything after it on the GPU.  ``jobs`` = [(ngrams_and_scores, unigram_scores)].
+    Returns a list of ``(results, all_ngrams)`` -- ``all_ngrams`` None unless ``want_ngrams`` -- with ``None`` in place of
+    a pair where the query must take the python route (device limit exceeded), or None for the whole chunk when the
+    input is outside what the C++ scorer takes (an empty key)."""
+    import torch
+    from .index import SHIFT
+    from .keys import _unigram_ranges
+    L = lib()
+    nq = len(jobs)
+    if nq > MAX_QUERIES_PER_PLAN:
+        out = []
+        for a in range(0, nq, MAX_QUERIES_PER_PLAN):
+            part = score_and_aggregate_on_gpu(index, jobs[a:a + MAX_QUERIES_PER_PLAN], params, want_ngrams)
+            if part is None:
+                return None
+            out += part
+        return out
+    key_lists, lens, lm, type_ptrs, keep_alive = [], [], [], [], []
+    q_key_off = np.zeros(nq + 1, dtype=np.int64)
+    vocab = 1
+    for qi, (nas, us) in enumerate(jobs):
+        keys = [k.tolist() if isinstance(k, torch.Tensor) else k for k, _ in nas]
+        key_lists.append(keys)
+        ln = [len(k) for k in keys]
+        if ln and (min(ln) < 1 or max(ln) > MAX_KEY_LEN):
+            return None
+        lens += ln
+        lm += [sr for _, sr in nas]
+        q_key_off[qi + 1] = q_key_off[qi] + len(keys)
+        if us is not None:
+            us = np.ascontiguousarray(us, dtype=np.float64)
+            keep_alive.append(us)
+            type_ptrs.append(us.ctypes.data)
+            vocab = max(vocab, us.shape[0])
+        else:
+            type_ptrs.append(None)
+    if len({u.shape[0] for u in keep_alive}) > 1 or (not params.get("use_fm_index_frequency", True) and any(len(k) == 0 for k in key_lists)):
+        return None
+    nk = int(q_key_off[-1])
+    key_tok_off = np.zeros(nk + 1, dtype=np.int64)
+    if nk:
+        np.cumsum(lens, out=key_tok_off[1:])
+    ntok = int(key_tok_off[-1])
+    key_toks = np.fromiter(chain.from_iterable(chain.from_iterable(key_lists)), dtype=np.int64, count=ntok) if ntok else np.zeros(1, np.int64)
+    key_lm = np.asarray(lm if nk else [0.0], dtype=np.float64)
+    # ---- one backward-search launch for every key of the chunk ----
+    dev = torch.device("cuda", L.fmi_device(index.handle))
+    if nk:
+        st = torch.cuda.current_stream(dev)
+        d_off = torch.from_numpy(key_tok_off).to(dev, non_blocking=True)
+        d_tok = torch.from_numpy(key_toks).to(dev, non_blocking=True)
+        rng = torch.empty(2, nk, dtype=torch.int64, device=dev)
+        check(L.fmi_dev_get_range(index.handle, st.cuda_stream, nk, d_off.data_ptr(), d_tok.data_ptr(), SHIFT, rng[0].data_ptr(), rng[1].data_ptr()))
+        rng = rng.cpu().numpy().view(np.uint64)
+        key_lo, key_hi = np.ascontiguousarray(rng[0]), np.ascontiguousarray(rng[1])
+        if getattr(index, "_trace", None) is not None:
+            index._trace.append(("ranges", [k for keys in key_lists for k in keys], key_lo.copy(), key_hi.copy()))
+    else:
+        key_lo = key_hi = np.zeros(1, dtype=np.uint64)
+    uni_lo, uni_hi = _unigram_ranges(index)
+    tp = (ctypes.c_void_p * nq)(*type_ptrs)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    plan = ctypes.c_void_p()
+    check(L.fmi_agg_score_pack(
+        nq, p(q_key_off), p(key_tok_off), p(key_toks), p(key_lm), p(key_lo), p(key_hi), tp if keep_alive else None, vocab,
+        p(uni_lo), p(uni_hi), len(uni_lo), float(index.beginnings[-1]), float(params.get("alpha", 2.0)),
+        float(params.get("length_penalty", 0.0)), float(params.get("smoothing", 5.0)), int(bool(params.get("use_fm_index_frequency", True))),
+        int(bool(params.get("add_best_unigrams_to_ngrams", False))), int(params.get("use_top_k_unigrams", 1000)),
+        int(params.get("max_occurrences_1", 1500)), int(params.get("max_occurrences_2", 10_000_000)), int(index.size()), ctypes.byref(plan)))
+    try:
+        nt = int(L.fmi_agg_plan_table_src(plan, None))
+        table_src = np.zeros(max(nt, 1), dtype=np.int64)
+        L.fmi_agg_plan_table_src(plan, p(table_src))
+        H = _plan_header(L.fmi_agg_plan_blob(plan, None))
+        q_tab = np.frombuffer(ctypes.string_at(L.fmi_agg_plan_blob(plan, None) + H["o_q_key_off"], 4 * (nq + 1)), dtype=np.uint32).astype(np.int64)
+        ngrams = None
+        if want_ngrams:
+            ngrams = []
+            for qi in range(nq):
+                n = int(L.fmi_agg_plan_ngrams(plan, qi, None, None, None))
+                src, sc = np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.float64)
+                L.fmi_agg_plan_ngrams(plan, qi, p(src), p(sc), None)
+                keys = key_lists[qi]
+                ngrams.append({(tuple(keys[s]) if s >= 0 else (-s - 1,)): v for s, v in zip(src[:n].tolist(), sc[:n].tolist())})
+        if H["total_occ"] == 0 and not H["n_rare"]:
+            # no query has a rare key: nothing to locate, every result is empty (keys.py:311 never iterates)
+            return [({}, None if ngrams is None else ngrams[qi]) for qi in range(nq)]
+        out = _run_plan(index, plan, nq, params)
+    finally:
+        L.fmi_agg_plan_free(plan)
+    res = []
     for qi in range(nq):
-        if flags[qi] & 1:
-            results.append(None)
+        if out["flags"][qi] & 1:
+            res.append(None)
             continue
-        keys = table[qi]
-        k0 = int(q_key_off[qi])
-        res = {}
-        a = qi * keep
-        docs = rec_doc[a:a + n_out[qi]].tolist()
-        sc = rec_score[a:a + n_out[qi]].tolist()
-        bk = rec_best_key[a:a + n_out[qi]].tolist()
-        bs = rec_best_score[a:a + n_out[qi]].tolist()
-        for x, d in enumerate(docs):
-            r = a + x
-            po, npk, to, T = int(rec_po[r]), int(rec_np[r]), int(rec_to[r]), int(rec_T[r])
-            ids = pick_id[po:po + npk]
-            ids = np.where(ids >= 0, ids - k0, ids)             # table key id -> index into this query's key list
-            res[d] = [sc[x], _LazyPicks(ids, pick_score[po:po + npk], keys), None, _LazyTokens(tokens[to:to + T]),
-                      [keys[bk[x] - k0] if bk[x] >= 0 else [], bs[x]]]
-        results.append(res)
-    return results
+        k0 = int(q_tab[qi])
+        table = _NgramTable(table_src[k0:int(q_tab[qi + 1])], key_lists[qi])
+        res.append((_results_of(out, qi, k0, table), None if ngrams is None else ngrams[qi]))
+    return res

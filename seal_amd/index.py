@@ -180,18 +180,28 @@ class FMIndex(_FMIndex):
 
     # -- batched extras (GPU-friendly forms of the calls above) -------------
     def get_range_batch(self, sequences: Sequence[Sequence[int]]):
-        """``get_range`` for many sequences in one launch -> (lo[], hi[]) uint64."""
+        """``get_range`` for many sequences in one launch -> (lo[], hi[]) uint64.  Runs on the current torch stream with
+        torch-managed buffers (no hipMalloc/hipFree on the way: those synchronise the whole device, i.e. every other
+        pipeline's stream)."""
+        import torch
         n = len(sequences)
-        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs = np.zeros(n + 1, dtype=np.int64)
         if n:
             offs[1:] = np.cumsum([len(s) for s in sequences])
         total = int(offs[-1])
-        toks = np.zeros(max(total, 1), dtype=np.uint64)
+        if n == 0:
+            return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64)
+        toks = np.zeros(max(total, 1), dtype=np.int64)
         if total:
-            toks[:total] = (np.fromiter((t for s in sequences for t in s), dtype=np.int64, count=total) + SHIFT).astype(np.uint64)
-        lo = np.zeros(n, dtype=np.uint64)
-        hi = np.zeros(n, dtype=np.uint64)
-        check(lib().fmi_backward_search_multi_batch(self._h, n, _ptr(offs), _ptr(toks), _ptr(lo), _ptr(hi)))
+            toks[:total] = np.fromiter((t for s in sequences for t in s), dtype=np.int64, count=total)
+        dev = torch.device("cuda", lib().fmi_device(self._h))
+        st = torch.cuda.current_stream(dev)
+        d_off = torch.from_numpy(offs).to(dev, non_blocking=True)
+        d_tok = torch.from_numpy(toks).to(dev, non_blocking=True)
+        out = torch.empty(2, n, dtype=torch.int64, device=dev)
+        check(lib().fmi_dev_get_range(self._h, st.cuda_stream, n, d_off.data_ptr(), d_tok.data_ptr(), SHIFT, out[0].data_ptr(), out[1].data_ptr()))
+        res = out.cpu().numpy().view(np.uint64)
+        lo, hi = res[0], res[1]
         if getattr(self, "_trace", None) is not None:      # bench.py: the operation AND what the GPU answered
             self._trace.append(("ranges", [list(s) for s in sequences], lo.copy(), hi.copy()))
         return lo, hi
@@ -209,13 +219,37 @@ class FMIndex(_FMIndex):
         return pos, doc
 
     def _side_stream(self, dev):
-        """a non-default stream for the retrieval-side launches, so that they (and the host waiting
-        on them) do not queue behind the decoder's work on torch's current stream"""
+        """the stream of the retrieval-side launches.  The index itself uses a non-default stream of its own, so that
+        those launches (and the host waiting on them) do not queue behind the decoder's work on torch's current
+        stream; a view (``view()``: one per concurrent pipeline) runs everything on its pipeline's current stream."""
         import torch
+        if self.__dict__.get("_is_view"):
+            return torch.cuda.current_stream(dev)
         st = self.__dict__.get("_svc_stream")
         if st is None:
             st = self.__dict__["_svc_stream"] = torch.cuda.Stream(device=dev)
         return st
+
+    def set_trace(self, trace) -> None:
+        """bench.py: record every index operation (with the GPU's answer) of this index and its views into ``trace``"""
+        self._trace = trace
+        for v in self.__dict__.get("_views", []):
+            v._trace = trace
+
+    def view(self) -> "FMIndex":
+        """A second handle on the same resident index (``fmi_view_create``): shares the device arrays and the python-side
+        tables, owns the mutable per-pipeline state (constraint workspace and incremental ranges, aggregation
+        buffers).  The searcher gives each of its concurrent query-batch pipelines one."""
+        h = ctypes.c_void_p()
+        check(lib().fmi_view_create(self._h, ctypes.byref(h)))
+        v = FMIndex.__new__(FMIndex)
+        v.__dict__.update({k: val for k, val in self.__dict__.items() if k not in ("_h", "_svc_stream", "_agg_buffers", "_agg_debug", "_views")})
+        v._h = h
+        v._device = None
+        v.__dict__["_is_view"] = True
+        v.__dict__["_parent"] = self          # keeps the owner of the device arrays alive
+        self.__dict__.setdefault("_views", []).append(v)
+        return v
 
     def locate_ranges(self, lows, highs, max_per_range: int):
         """``locate`` + ``get_doc_index`` for the first ``max_per_range`` rows of many

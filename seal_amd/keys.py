@@ -649,11 +649,32 @@ def aggregate_evidence_batch(jobs, index, **params):
     every query (and one document fetch when fully scoring).  ``jobs`` = list of
     ``(ngrams_and_scores, unigram_scores)``; returns the list of ``(results, all_ngrams)``."""
     import os, time, sys
+    use_gpu = params.pop("gpu_aggregate", True)          # False: the host routines (fmi_first_stage / fmi_full_score) for every query
+    want_ngrams = params.pop("want_ngrams", True)        # False: the caller ignores `all_ngrams` (the searcher does)
+    python_scoring = params.pop("python_scoring", os.environ.get("SEAL_PYTHON_SCORING") == "1")
     _tm = os.environ.get("SEAL_AGG_TIMING")
     _t = {"t0": time.perf_counter()}
     def _mark(name):
         if _tm:
             now = time.perf_counter(); _t[name] = _t.get(name, 0.0) + (now - _t["t0"]) * 1e3; _t["t0"] = now
+    done_on_gpu = None
+    if use_gpu and not python_scoring and gpu_aggregation_applies(index, params):
+        # key scoring in C++ (fmi_agg_score_pack), everything per row / per document on the GPU (fmi_dev_aggregate);
+        # the python below (generators, python scoring) stays for what that route hands back
+        from .gpu_aggregate import score_and_aggregate_on_gpu
+        done_on_gpu = score_and_aggregate_on_gpu(index, jobs, params, want_ngrams)
+        _mark("score_pack_gpu")
+        if done_on_gpu is not None and all(r is not None for r in done_on_gpu):
+            if _tm:
+                _t.pop("t0")
+                print("[agg]", {k: round(v, 1) for k, v in _t.items()}, file=sys.stderr, flush=True)
+            return done_on_gpu
+        if done_on_gpu is not None:
+            left = [i for i, r in enumerate(done_on_gpu) if r is None]
+            rest = aggregate_evidence_batch([jobs[i] for i in left], index, gpu_aggregate=False, want_ngrams=want_ngrams, **params)
+            for i, r in zip(left, rest):
+                done_on_gpu[i] = r
+            return done_on_gpu
     all_keys, seen = [], set()
     for ngrams_and_scores, _ in jobs:
         for ng, _ in ngrams_and_scores:
@@ -675,7 +696,7 @@ def aggregate_evidence_batch(jobs, index, **params):
         except StopIteration as done:
             out[i] = done.value
     _mark("score_split")
-    if reqs and gpu_aggregation_applies(index, params):
+    if reqs and use_gpu and gpu_aggregation_applies(index, params):
         # first stage + full-document scoring on the GPU (seal_amd/csrc/fmi_aggregate.hip): nothing but the top
         # documents comes back.  A query that exceeds a device limit is handed back to the host routines below.
         live = sorted(reqs)

@@ -114,6 +114,29 @@ def batch_generate_keys(searcher, queries, constrained_generation=True):
         offset += len(batch)
 
 
+class _Pipeline:
+    """what one of the searcher's concurrent query-batch pipelines owns: a stream, a view of the index (its own
+    constraint workspace and aggregation buffers over the shared device arrays) and step decoders with their own
+    static buffers over the shared weights"""
+
+    def __init__(self, searcher):
+        import torch
+        self.device = searcher.device
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.index = searcher.fm_index.view()
+        self._decoders = {}
+
+    def decoder(self, model):
+        d = self._decoders.get(id(model))
+        if d is None:
+            from .bart_decoder import BartStepDecoder
+            base = getattr(model, "_seal_step_decoder", None)
+            if base is None:
+                base = model._seal_step_decoder = BartStepDecoder(model)
+            d = self._decoders[id(model)] = base.clone_for_pipeline()
+        return d
+
+
 def _count_filter(index: FMIndex, per_query: List[List]) -> List[List]:
     """``[(s, k) for s, k in fk if k and index.get_count(k) > 0]`` for every query of
     the batch with one launch."""
@@ -129,8 +152,29 @@ def _count_filter(index: FMIndex, per_query: List[List]) -> List[List]:
     return out
 
 
-def _process_batch(searcher, inputs, constrained_generation, offset=0):
+def _process_batch(searcher, inputs, constrained_generation, offset=0, pipe=None):
+    """keys of one batch of queries (reference retrieval.py:54-305)"""
+    steps = _batch_steps(searcher, inputs, constrained_generation, offset, pipe)
+    try:
+        while True:
+            next(steps)
+    except StopIteration as done:
+        return done.value
+
+
+def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
+    """``process_batch`` of the reference (retrieval.py:54-305) as a generator in three segments, so that a scheduler can
+    put other work between them (``SEALSearcher._overlapped_results``):
+
+    1. both constrained decodes (body, titles) are ENQUEUED -- nothing waits for the GPU -- then ``yield "decoding"``;
+    2. the hypotheses come to the host (the one wait for the decodes), then ``yield "decoded"``;
+    3. post-filters, rescoring, query n-grams, unigram scores -> returns the keys (``StopIteration.value``).
+
+    The reference runs body decode -> body filters/rescoring -> query keys -> title decode -> title filters/rescoring;
+    the two decodes do not depend on anything in between, so issuing them back to back changes no result."""
     s = searcher
+    fm_index = pipe.index if pipe is not None else s.fm_index
+    dec = (lambda model: dict(decoder=pipe.decoder(model))) if pipe is not None else (lambda model: {})
     bias = s.logit_bias
     if bias is not None and bias.shape[0] != len(inputs):
         bias = bias[offset:offset + len(inputs)]      # one row per query of the whole call
@@ -166,27 +210,44 @@ def _process_batch(searcher, inputs, constrained_generation, offset=0):
     strip_ids = s.strip_token_ids
     bos_strip = [s.title_bos_token_id, s.code_bos_token_id, s.bart_model.config.decoder_start_token_id]
 
+    # ---- segment 1: enqueue the decodes ----
+    body = titles = None
     if s.decode_body:
         strs, toks = marked("body")
-        found_keys = fm_index_generate(
-            s.bart_model, s.fm_index, **encoder_batch(strs, toks),
+        body = fm_index_generate(
+            s.bart_model, fm_index, **encoder_batch(strs, toks),
             min_length=s.length, max_length=s.length, length_penalty=s.length_penalty, num_beams=s.beam,
             disable_fm_index=not constrained_generation, diverse_bs_groups=s.diverse_bs_groups,
             diverse_bs_penalty=s.diverse_bs_penalty, stop_at_count=s.stop_at_count, keep_history=True, topk=s.topk,
-            logit_bias=bias)
+            logit_bias=bias, pending=True, **dec(s.bart_model))
+    if s.decode_titles:
+        strs, title_toks = marked("title")
+        titles = fm_index_generate(
+            s.bart_title_model, fm_index, **encoder_batch(strs, title_toks),
+            min_length=1, max_length=15, num_beams=s.beam, length_penalty=s.length_penalty,
+            force_decoding_from=[s.title_bos_token_id], eos_token_id=s.title_eos_token_id,
+            diverse_bs_groups=s.diverse_bs_groups, diverse_bs_penalty=s.diverse_bs_penalty, keep_history=True,
+            disable_fm_index=not constrained_generation, topk=s.topk, logit_bias=bias, pending=True, **dec(s.bart_title_model))
+    yield "decoding"
+
+    # ---- segment 2: the hypotheses (waits for the decodes) ----
+    found_keys = body.result() if body is not None else [[] for _ in inputs]
+    decoded = titles.result() if titles is not None else None
+    yield "decoded"
+
+    # ---- segment 3: filters, rescoring, query n-grams, unigram scores ----
+    if s.decode_body:
         for fk in found_keys:   # retrieval.py:85-90
             fk[:] = [(sc, k[1:] if k[0] in strip_ids else k) for sc, k in fk if k]
             fk[:] = [(sc, k[1:] if k[0] in strip_ids else k) for sc, k in fk if k]
             fk[:] = [(sc, k[:-1] if k[-1] in strip_ids else k) for sc, k in fk if k]
             if s.min_length > 0:
                 fk[:] = [(sc, k) for sc, k in fk if len(k) == s.min_length]
-        found_keys = _count_filter(s.fm_index, found_keys)   # retrieval.py:91
+        found_keys = _count_filter(fm_index, found_keys)   # retrieval.py:91
         if s.rescore and s.use_markers:
             found_keys = rk.rescore_keys(
                 s.bart_model, base_tokens, found_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
                 strip_from_eos=[s.title_eos_token_id, s.code_eos_token_id, s.bart_model.config.eos_token_id], logit_bias=bias)
-    else:
-        found_keys = [[] for _ in inputs]
 
     if s.add_query_to_keys:
         if tokenised or s.bart_tokenizer is None:
@@ -195,21 +256,14 @@ def _process_batch(searcher, inputs, constrained_generation, offset=0):
         from .query_keys import query_ngram_keys
         cand = [query_ngram_keys(inp, s) for inp in inputs]
         cand = [[(0.0, k) for k in kk] for kk in cand]
-        cand = [[k for _, k in kk] for kk in _count_filter(s.fm_index, cand)]
+        cand = [[k for _, k in kk] for kk in _count_filter(fm_index, cand)]
         _, toks = marked("body")
         last_input_tokens = toks                # the reference re-binds `input_tokens` here (retrieval.py:139)
         for fk, nfk in zip(found_keys, rk.rescore_keys(s.bart_model, toks, cand, batch_size=100, length_penalty=0.0)):
             fk += nfk
 
     if s.decode_titles:
-        strs, toks = marked("title")
-        decoded = fm_index_generate(
-            s.bart_title_model, s.fm_index, **encoder_batch(strs, toks),
-            min_length=1, max_length=15, num_beams=s.beam, length_penalty=s.length_penalty,
-            force_decoding_from=[s.title_bos_token_id], eos_token_id=s.title_eos_token_id,
-            diverse_bs_groups=s.diverse_bs_groups, diverse_bs_penalty=s.diverse_bs_penalty, keep_history=True,
-            disable_fm_index=not constrained_generation, topk=s.topk, logit_bias=bias)
-        title_keys = [[(sc, hyp) for sc, hyp in dec] for dec in decoded]
+        title_keys = [[(sc, hyp) for sc, hyp in dec_] for dec_ in decoded]
         for fk in title_keys:   # retrieval.py:180-190
             if s.force_decoding_second_token >= 0:
                 fk[:] = [(sc, k[:1] + k[2:]) for sc, k in fk if len(k) >= 3]
@@ -219,10 +273,10 @@ def _process_batch(searcher, inputs, constrained_generation, offset=0):
                 if s.min_length > 0:
                     fk[:] = [(sc, k) for sc, k in fk if len(k) == (s.min_length + 1)]
             fk[:] = [(sc, [s.title_bos_token_id] + k if k[0] != s.title_bos_token_id else k) for sc, k in fk]
-        title_keys = _count_filter(s.fm_index, title_keys)   # retrieval.py:191
+        title_keys = _count_filter(fm_index, title_keys)   # retrieval.py:191
         if s.rescore and s.use_markers:
             title_keys = rk.rescore_keys(
-                s.bart_title_model, toks, title_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
+                s.bart_title_model, title_toks, title_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
                 strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=bias)
         for nfk, fk in zip(title_keys, found_keys):
             fk += nfk
@@ -240,7 +294,7 @@ def _process_batch(searcher, inputs, constrained_generation, offset=0):
     if s.unigram_scores:
         _, toks = marked("body")
         unigram = rk.compute_unigram_scores(
-            s.bart_scorer_model, toks, s.fm_index,
+            s.bart_scorer_model, toks, fm_index,
             prefix=[s.force_decoding_second_token] if s.force_decoding_second_token >= 0 else [], logit_bias=bias,
             tolist=False)
         # one D2H copy; float64 views of the fp32 log-probs == what .tolist() would hold
@@ -315,6 +369,12 @@ class SEALSearcher:
             "marker_token_ids", {"body": [45056, 809], "title": [45056, 1270], "code": [45056, 3260], "+": [45056, 2055]})
         # extension: stop aggregate_evidence after the first stage (keys.py:311-364)
         self.first_stage_only: bool = params.get("first_stage_only", False)
+        # extension: False = evidence aggregation through the host checker routines instead of the GPU kernels
+        self.gpu_aggregate: bool = params.get("gpu_aggregate", True)
+        # extension: query batches in flight on the GPU at a time (each batch_size queries, own stream); 1 = one after the other
+        self.pipeline: int = int(params.get("pipeline", 1))
+        # extension: enqueue the next batch's decodes before this batch's rescoring / aggregation (same thread, second stream)
+        self.overlap: bool = bool(params.get("overlap", True))
         # extension (synthetic benchmarks): per-query additive bias on the model's next-token logits, [batch, vocab]
         self.logit_bias = None
         if "bart" in self.backbone:   # retrieval.py:480-491
@@ -427,16 +487,25 @@ class SEALSearcher:
         """reference retrieval.py:649-691"""
         if detokenize is None:
             detokenize = self.detokenize
-        keys = self.batch_generate_keys(queries)
-        if added_documents is not None:
-            if self.unigram_scores:
-                keys = ((kk, us, added_documents[i]) for i, (kk, us) in enumerate(keys))
-            else:
-                keys = ((kk, None, added_documents[i]) for i, kk in enumerate(keys))
+        if self._overlapped() and added_documents is None:
+            # the next batch's decodes are enqueued before this batch's rescoring / aggregation start (second stream)
+            ranked = self._overlapped_results(queries, keep=k)
+        elif self._pipelined() and added_documents is None:
+            # `pipeline` query batches in flight, each on its own stream (key generation + aggregation of one batch
+            # overlap the other batches' GPU and host work)
+            ranked = self._pipelined_results(queries, keep=k)
+        else:
+            keys = self.batch_generate_keys(queries)
+            if added_documents is not None:
+                if self.unigram_scores:
+                    keys = ((kk, us, added_documents[i]) for i, (kk, us) in enumerate(keys))
+                else:
+                    keys = ((kk, None, added_documents[i]) for i, kk in enumerate(keys))
+            ranked = self.batch_retrieve_from_keys(keys, keep=k)
         key_info = {}
         retrieved = []
         # streamed: a query's (up to fully_score) ranked documents are cut to k as soon as they arrive
-        for query, (res, _) in zip(queries, self.batch_retrieve_from_keys(keys, keep=k)):
+        for query, (res, _) in zip(queries, ranked):
             docs = []
             for idx, info in islice(res.items(), k):
                 score, kk, full = info[0], info[1], (info[3] if len(info) == 5 else None)
@@ -456,6 +525,116 @@ class SEALSearcher:
         if detokenize and self.bart_tokenizer is not None:
             return self.detokenize_retrieved(retrieved)
         return retrieved
+
+    # ------------------------------------------------------------------
+    # concurrent query-batch pipelines on one GPU
+    # ------------------------------------------------------------------
+    def _overlapped(self) -> bool:
+        return bool(self.overlap) and int(self.pipeline) <= 1 and self.device.type == "cuda" and hasattr(self.fm_index, "handle")
+
+    def _overlapped_results(self, queries, keep=None):
+        """``(results, all_ngrams)`` per query, in query order, one batch after the other as always -- but the decodes of
+        batch i+1 are enqueued (on the caller's stream) as soon as the hypotheses of batch i are on the host, and batch
+        i's filters, rescoring, unigram scores and evidence aggregation then run on a second stream: the GPU works on
+        the next decode while the host walks through this batch's python, and the rescoring GEMMs fill the gaps.  One
+        thread, one index handle (a decode uses the constraint workspace, the rest of a batch does not), no result
+        depends on the schedule."""
+        import torch
+        dev = self.device
+        post = self.__dict__.get("_post_stream")
+        if post is None:
+            post = self.__dict__["_post_stream"] = torch.cuda.Stream(device=dev)
+        params = self._aggregate_params()
+        constrained = not self.free_generation
+        batches, offsets, off = [], [], 0
+        for b in _chunks(queries, self.batch_size):
+            batches.append(b)
+            offsets.append(off)
+            off += len(b)
+        if not batches:
+            return
+        post.wait_stream(torch.cuda.current_stream(dev))      # whatever the caller queued (weights, logit bias) is visible
+        import os, sys, time
+        tm = os.environ.get("SEAL_OVERLAP_TIMING")
+        cur = _batch_steps(self, batches[0], constrained, offsets[0])
+        next(cur)                                             # decodes of batch 0 enqueued
+        for i in range(len(batches)):
+            t0 = time.perf_counter()
+            next(cur)                                         # hypotheses of batch i on the host
+            t1 = time.perf_counter()
+            nxt = None
+            if i + 1 < len(batches):
+                nxt = _batch_steps(self, batches[i + 1], constrained, offsets[i + 1])
+                next(nxt)                                     # decodes of batch i+1 enqueued behind nothing
+            t2 = time.perf_counter()
+            if tm:
+                print("[overlap] batch %d: waited %.1f ms for its decodes; enqueued the next decodes in %.1f ms" % (i, (t1 - t0) * 1e3, (t2 - t1) * 1e3),
+                      file=sys.stderr, flush=True)
+            with torch.cuda.stream(post):
+                try:
+                    next(cur)
+                    raise RuntimeError("_batch_steps yielded more than twice")
+                except StopIteration as done:
+                    keys = done.value
+                jobs = [(kk[0], kk[1]) if isinstance(kk, tuple) else (kk, None) for kk in keys]
+                out = rk.aggregate_evidence_batch(jobs, self.fm_index, keep=keep, gpu_aggregate=self.gpu_aggregate, want_ngrams=False, **params)
+                post.synchronize()
+            yield from out
+            cur = nxt
+
+    def _pipelined(self) -> bool:
+        return (int(self.pipeline) >= 2 and hasattr(self.fm_index, "view") and self.device.type == "cuda"
+                and self.gpu_aggregate and rk.gpu_aggregation_applies(self.fm_index, self._aggregate_params()))
+
+    def _pipelines(self):
+        pipes = self.__dict__.get("_pipes")
+        if pipes is None or len(pipes) != int(self.pipeline):
+            pipes = self.__dict__["_pipes"] = [_Pipeline(self) for _ in range(int(self.pipeline))]
+        return pipes
+
+    def _pipelined_results(self, queries, keep=None):
+        """``(results, all_ngrams)`` per query, in query order: the queries are cut into batches of ``batch_size`` as
+        always; up to ``pipeline`` batches are in flight, each through the whole path (decode -> filters -> rescoring
+        -> unigram scores -> evidence aggregation) on its own stream, index view and decoder buffers.  A batch gives
+        the same results whichever pipeline runs it."""
+        import queue
+        import sys
+        from concurrent.futures import ThreadPoolExecutor
+        import torch
+        pipes = self._pipelines()
+        free = queue.SimpleQueue()
+        for p in pipes:
+            free.put(p)
+        params = self._aggregate_params()
+        constrained = not self.free_generation
+        dev = self.device
+        if sys.getswitchinterval() > 1e-3:
+            sys.setswitchinterval(1e-3)         # the pipelines hand the interpreter to each other at every GPU wait
+
+        def run(batch, offset):
+            pipe = free.get()
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(pipe.stream):
+                    keys = _process_batch(self, batch, constrained, offset, pipe)
+                    jobs = [(kk[0], kk[1]) if isinstance(kk, tuple) else (kk, None) for kk in keys]
+                    out = rk.aggregate_evidence_batch(jobs, pipe.index, keep=keep, gpu_aggregate=True, want_ngrams=False, **params)
+                    pipe.stream.synchronize()
+                return out
+            finally:
+                free.put(pipe)
+        pool = self.__dict__.get("_pipe_pool")
+        if pool is None or pool._max_workers != len(pipes):
+            pool = self.__dict__["_pipe_pool"] = ThreadPoolExecutor(max_workers=len(pipes), thread_name_prefix="seal-pipeline")
+        main = torch.cuda.current_stream(dev)
+        for p in pipes:
+            p.stream.wait_stream(main)          # whatever the caller queued (model weights, logit bias) is visible
+        futures, offset = [], 0
+        for batch in _chunks(queries, self.batch_size):
+            futures.append(pool.submit(run, batch, offset))
+            offset += len(batch)
+        for fut in futures:
+            yield from fut.result()
 
     def detokenize_retrieved(self, retrieved):
         """reference retrieval.py:693-712"""
@@ -528,12 +707,16 @@ class SEALSearcher:
         host bookkeeping of each query runs in a worker process while this thread keeps the GPU busy
         with the next chunk (the producer/consumer overlap of the reference's ``Pool.imap``,
         retrieval.py:766)."""
-        defer = self._host_pool() if self.jobs >= 2 else None
+        params = self._aggregate_params()
+        on_gpu = self.gpu_aggregate and rk.gpu_aggregation_applies(self.fm_index, params)
+        # worker processes only serve the host routines; on the GPU path the aggregation of a chunk is a handful of
+        # launches on the index's side stream
+        defer = self._host_pool() if (self.jobs >= 2 and not on_gpu) else None
         pending = []
-        # with workers: the chunk's aggregation (index kernels on their own stream + native host
-        # bookkeeping, both of which release the GIL) runs on one background thread, so that pulling
-        # the next chunk of keys -- the decode of the next batch -- starts right away
-        bg = self._agg_thread() if defer is not None else None
+        # with jobs >= 2 the chunk's aggregation (key scoring on the host, index kernels on their own stream; both
+        # release the GIL) runs on one background thread, so that pulling the next chunk of keys -- the decode of the
+        # next batch -- starts right away
+        bg = self._agg_thread() if self.jobs >= 2 else None
         for chunk in _chunks(keys, self.batch_size):
             jobs = []
             for kk in chunk:
@@ -546,9 +729,10 @@ class SEALSearcher:
                 jobs.append(kk)
             if bg is not None:
                 pending.append(bg.submit(rk.aggregate_evidence_batch, jobs, self.fm_index, defer=defer, keep=keep,
-                                         **self._aggregate_params()))
+                                         gpu_aggregate=self.gpu_aggregate, want_ngrams=False, **params))
                 continue
-            yield from rk.aggregate_evidence_batch(jobs, self.fm_index, defer=defer, keep=keep, **self._aggregate_params())
+            yield from rk.aggregate_evidence_batch(jobs, self.fm_index, defer=defer, keep=keep, gpu_aggregate=self.gpu_aggregate,
+                                                   want_ngrams=False, **params)
         import os, sys, time
         tm = os.environ.get("SEAL_AGG_TIMING")
         t_end = time.perf_counter()

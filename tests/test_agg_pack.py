@@ -6,6 +6,7 @@ import ctypes
 import struct
 
 import numpy as np
+import pytest
 
 from seal_amd._lib import check, lib
 
@@ -138,3 +139,101 @@ def test_plan_rejects_what_the_kernels_cannot_take():
         _pack([[((3, 4), 0.0, 1, 0, 5)]], 10, 100, [None], 1)
     with pytest.raises(SealFMError):       # window lengths are 8-bit in the position sort keys
         _pack([[(tuple(range(3, 3 + 300)), 1.0, 1, 0, 5)]], 10, 100, [None], 1)
+
+
+# ---------------------------------------------------------------------------
+# fmi_agg_score_pack: the key scoring of aggregate_evidence (reference keys.py:207-309) in C++ against the python that
+# is itself held to the reference's vectors (seal_amd.keys._aggregate_steps, tests/test_reference_golden.py)
+# ---------------------------------------------------------------------------
+def _score_pack(index, jobs, kw):
+    from seal_amd.keys import _unigram_ranges
+    nq = len(jobs)
+    q_off = np.zeros(nq + 1, dtype=np.int64)
+    toks, tok_off, lm, ptrs, alive = [], [0], [], [], []
+    vocab = 1
+    for i, (keys, us) in enumerate(jobs):
+        q_off[i + 1] = q_off[i] + len(keys)
+        for k, s in keys:
+            toks += list(k)
+            tok_off.append(len(toks))
+            lm.append(s)
+        if us is not None:
+            us = np.ascontiguousarray(us, dtype=np.float64)
+            alive.append(us); ptrs.append(us.ctypes.data); vocab = max(vocab, len(us))
+        else:
+            ptrs.append(None)
+    flat = [list(k) for keys, _ in jobs for k, _ in keys]
+    lo, hi = index.get_range_batch(flat)
+    arr = lambda x, dt: np.ascontiguousarray(np.asarray(x if len(x) else [0], dtype=dt))
+    tok_off, toks, lm = arr(tok_off, np.int64), arr(toks, np.int64), arr(lm, np.float64)
+    lo, hi = arr(lo, np.uint64), arr(hi, np.uint64)
+    ulo, uhi = _unigram_ranges(index)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    tp = (ctypes.c_void_p * nq)(*ptrs)
+    plan = ctypes.c_void_p()
+    check(lib().fmi_agg_score_pack(nq, p(q_off), p(tok_off), p(toks), p(lm), p(lo), p(hi), tp if alive else None, vocab, p(ulo), p(uhi), len(ulo),
+                                   float(index.beginnings[-1]), float(kw.get("alpha", 2.0)), float(kw.get("length_penalty", 0.0)),
+                                   float(kw.get("smoothing", 5.0)), int(kw.get("use_fm_index_frequency", True)),
+                                   int(kw.get("add_best_unigrams_to_ngrams", False)), int(kw.get("use_top_k_unigrams", 1000)),
+                                   int(kw.get("max_occurrences_1", 1500)), int(kw.get("max_occurrences_2", 10_000_000)), int(index.orc.size()),
+                                   ctypes.byref(plan)))
+    out = []
+    for q in range(nq):
+        n = int(lib().fmi_agg_plan_ngrams(plan, q, None, None, None))
+        src, sc, rare = np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.float64), np.zeros(max(n, 1), np.uint8)
+        lib().fmi_agg_plan_ngrams(plan, q, p(src), p(sc), p(rare))
+        keys = jobs[q][0]
+        out.append([((tuple(keys[s][0]) if s >= 0 else (-s - 1,)), v, bool(r)) for s, v, r in zip(src[:n].tolist(), sc[:n].tolist(), rare[:n].tolist())])
+    n = ctypes.c_uint64()
+    blob = ctypes.string_at(lib().fmi_agg_plan_blob(plan, ctypes.byref(n)), n.value)
+    lib().fmi_agg_plan_free(plan)
+    return out, blob
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (0, dict()),
+    (1, dict(add_best_unigrams_to_ngrams=True, use_top_k_unigrams=30)),
+    (2, dict(add_best_unigrams_to_ngrams=True, use_top_k_unigrams=5000, max_occurrences_1=5, alpha=1.5, smoothing=0.5)),
+    (3, dict(use_fm_index_frequency=False, add_best_unigrams_to_ngrams=True, use_top_k_unigrams=12, length_penalty=0.2)),
+    (4, dict(add_best_unigrams_to_ngrams=True, use_top_k_unigrams=0)),
+    (5, dict(max_occurrences_2=8, length_penalty=0.1, alpha=1.0)),
+])
+def test_cpp_key_scoring_equals_the_python_scoring(seed, kw):
+    import pytest  # noqa: F401
+    from oracle.seal_oracle import OracleFMIndex
+    from seal_amd.keys import _aggregate_steps
+    from tests.helpers import OracleBatchIndex, make_docs, synthetic_keys
+    vocab = 60
+    rng = np.random.default_rng(seed)
+    docs = make_docs(seed, 150, vocab, min_len=6, max_len=20, title_sep=7)
+    orc = OracleFMIndex()
+    orc.initialize(docs)
+    index = OracleBatchIndex(orc)
+    jobs = []
+    for q in range(4):
+        keys = synthetic_keys(rng, docs, vocab, n_keys=50, with_titles=True)
+        keys += [(k, s - 0.5) for k, s in keys[:3]]                         # repeated n-grams: dict semantics (value replaced, place kept)
+        keys += [([int(rng.integers(4, vocab))], -float(int(rng.integers(1, 4)))) for _ in range(6)]      # single tokens, tied scores
+        us = None if q == 3 else np.round(-rng.random(vocab) * 6 - 0.01, 1 if q == 1 else 6)             # q == 1: ties at the top-k boundary
+        jobs.append((keys, us))
+    got, blob = _score_pack(index, jobs, kw)
+    params = dict(max_occurrences_1=1500, n_docs_complete_score=500, alpha=2.0, beta=0.8, smoothing=5.0, use_top_k_unigrams=1000)
+    params.update(kw)
+    H = dict(zip(HDR_FIELDS, struct.unpack_from("<%dQ" % len(HDR_FIELDS), blob, 0)))
+    n_table = 0
+    for q, (keys, us) in enumerate(jobs):
+        g = _aggregate_steps(keys, None if us is None else us.tolist(), index, **params)
+        try:
+            req = next(g)
+            rare, all_ngrams = req[4]["rare"], req[4]["all_ngrams"]
+            g.close()
+        except StopIteration:                                   # no rare key at all: the python returns without asking for rows
+            rare, all_ngrams = {}, None
+        if all_ngrams is not None:
+            assert [(k, v) for k, v, _ in got[q]] == list(all_ngrams.items()), (q, kw)      # order and float64 values exactly
+            assert [k for k, _, r in got[q] if r] == list(rare.keys())
+            n_table += sum(1 for _, v, _ in got[q] if v > 0.0)
+        else:
+            assert not any(r for _, _, r in got[q])
+            n_table += sum(1 for _, v, _ in got[q] if v > 0.0)
+    assert H["n_keys"] == n_table and H["nq"] == 4

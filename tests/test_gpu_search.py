@@ -152,3 +152,40 @@ def test_search_detokenizes_title_and_body(jobs, monkeypatch):
         title, body = d.text()
         assert title == " ".join(f"w{t}" for t in toks[:i] if t > 2)
         assert body == " ".join(f"w{t}" for t in toks[i + 1:] if t > 2)
+
+
+@pytest.mark.parametrize("geom", MODEL_GEOMETRIES, ids=MODEL_IDS)
+def test_pipelined_batches_give_the_results_of_sequential_batches(geom, monkeypatch):
+    """the two ways of keeping the GPU busy across batches -- ``overlap`` (next batch's decodes enqueued before this
+    batch's rescoring / aggregation, second stream) and ``pipeline`` query batches in flight on worker threads (own
+    stream, index view -- constraint workspace, incremental ranges, aggregation buffers -- and decoder buffers each)
+    -- return exactly what one batch after the other returns: same documents, bit-equal scores, same keys, in order"""
+    from seal_amd import FMIndex
+    from seal_amd import retrieval
+    from seal_amd.retrieval import SEALSearcher
+    from tests.helpers import make_docs, tiny_bart
+    vocab = 120
+    dev = torch.device("cuda:0")
+    docs = make_docs(5, 300, vocab - 8, min_len=6, max_len=18, title_sep=TITLE_EOS)
+    ix = FMIndex()
+    ix.initialize(docs)
+    rng = np.random.default_rng(3)
+    queries = [[0] + rng.integers(4, vocab - 8, size=int(rng.integers(4, 9))).tolist() + [2] for _ in range(11)]
+    real = retrieval.fm_index_generate
+    monkeypatch.setattr(retrieval, "fm_index_generate",
+                        lambda *a, **kw: real(*a, **{**kw, "max_length": 8 if kw.get("force_decoding_from") else kw["max_length"]}))
+    model = tiny_bart(vocab, **geom).to(dev)
+    out = {}
+    for depth, overlap in ((1, False), (1, True), (2, False), (3, False)):
+        s = SEALSearcher(ix, None, model, backbone="bart-tiny", length=6, beam=4, batch_size=2, add_query_to_keys=False,
+                         detokenize=False, pipeline=depth, overlap=overlap, include_keys=True, title_eos_token_id=TITLE_EOS,
+                         code_eos_token_id=vocab - 6, code_bos_token_id=TITLE_EOS,
+                         marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5]})
+        assert s._pipelined() is (depth > 1) and s._overlapped() is (overlap and depth == 1)
+        for rep in range(2):           # the second call reuses the captured graphs and buffers
+            res = s.batch_search(queries, k=10)
+            out[(depth, overlap, rep)] = [[(d.idx, d.score, list(d.raw_tokens()), d.keys) for d in docs_] for docs_ in res]
+    base = out[(1, False, 0)]
+    assert sum(len(r) for r in base) > 30
+    for key, val in out.items():
+        assert val == base, key
