@@ -66,8 +66,10 @@ class IndexBasedLogitsProcessor:
                 and 2 * num_beams <= 64)
 
     def _first_bits(self, vocab: int, device) -> torch.Tensor:
-        key = ("bits", device, vocab)
-        b = self._first_mask.get(key)
+        """allowed-token bitmap of the first step (``occurring_distinct``, beam_search.py:73-77), cached on the index"""
+        cache = self.index.__dict__.setdefault("_first_bits_cache", {})
+        key = (str(device), vocab, bool(self.always_allow_eos), self.eos_token_id if self.always_allow_eos else -1)
+        b = cache.get(key)
         if b is None:
             allowed = torch.zeros(((vocab + 31) // 32) * 32, dtype=torch.bool)
             allowed[torch.as_tensor(self.index.occurring_distinct, dtype=torch.long)] = True
@@ -76,7 +78,7 @@ class IndexBasedLogitsProcessor:
             w = allowed.view(-1, 32).to(torch.int64) << torch.arange(32, dtype=torch.int64)
             b = w.sum(1).to(torch.int64)
             b = torch.where(b >= 2 ** 31, b - 2 ** 32, b).to(torch.int32).to(device)
-            self._first_mask[key] = b
+            cache[key] = b
         return b
 
     def fused_topk(self, input_ids: torch.LongTensor, logits: torch.FloatTensor, beam_scores: torch.FloatTensor,
@@ -194,9 +196,14 @@ def constrained_beam_search(decoder, batch_size: int, num_beams: int, max_length
     row_base = (torch.arange(B, device=device) * K).unsqueeze(1)
     steps = []
     beam_idx = None     # rows of the previous step that this step's rows extend (incremental constraint state)
+    first_logits = None
     while True:
         logits = decoder.step(input_ids[:, -1])
         V = logits.shape[-1]
+        if first_logits is None:
+            # every beam of a query sees the same first step: the model's next-token logits after the start token,
+            # i.e. what compute_unigram_scores (keys.py:145-176) runs the whole model for
+            first_logits = logits.view(B, K, V)[:, 0].clone()
         proc = constrained_decoding_processor
         if proc is not None and fused and hasattr(proc, "fused_topk") and proc.supports_fused_topk(logits, K):
             flat, next_scores = proc.fused_topk(input_ids, logits, beam_scores, B, K, parent_rows=beam_idx)
@@ -226,6 +233,10 @@ def constrained_beam_search(decoder, batch_size: int, num_beams: int, max_length
         decoder.reorder(beam_idx)
         if input_ids.shape[-1] >= max_length:       # MaxLengthCriteria (340)
             break
+    try:
+        decoder.first_logits = first_logits          # picked up by fm_index_generate(pending=True)
+    except AttributeError:
+        pass
     return steps, (input_ids, beam_scores)
 
 
@@ -330,7 +341,9 @@ def fm_index_generate(
     if pending:
         # the whole decode is enqueued by now and nothing has waited for the GPU: hand back a handle, so that the caller
         # can put more work behind it (the next decode) before it asks for the hypotheses
-        return PendingGenerate(steps, final, input_ids.shape[0], num_beams, length_penalty, enc=enc)
+        pg = PendingGenerate(steps, final, input_ids.shape[0], num_beams, length_penalty, enc=enc, attention_mask=attention_mask)
+        pg.first_logits = getattr(decoder, "first_logits", None)
+        return pg
     return _history_to_hypotheses(steps, final, input_ids.shape[0], num_beams, length_penalty)
 
 
@@ -338,10 +351,10 @@ class PendingGenerate:
     """an enqueued ``fm_index_generate``: ``result()`` waits for the GPU and builds the hypothesis lists.
     ``enc`` = the encoder states of the call (the searcher reuses them where the reference re-encodes the same input)."""
 
-    def __init__(self, steps, final, batch, beams, length_penalty, enc=None):
+    def __init__(self, steps, final, batch, beams, length_penalty, enc=None, attention_mask=None):
         self._args = (steps, final, batch, beams, length_penalty)
-        self.enc = enc
-        self.first_logits = None
+        self.enc, self.attention_mask = enc, attention_mask
+        self.first_logits = None          # [batch, vocab]: next-token logits of the first decoder position (logit bias included)
         self._event = torch.cuda.Event() if final[0].is_cuda else None
         if self._event is not None:
             self._event.record(torch.cuda.current_stream(final[0].device))

@@ -60,7 +60,7 @@ def _pad_batch(seqs: Sequence[Sequence[int]], pad: int, device) -> torch.Tensor:
 
 @torch.inference_mode()
 def rescore_keys(model, inputs, list_of_decoded, batch_size=100, length_penalty=0.0, progress_bar=False, prefix=[],
-                 strip_from_bos=[], strip_from_eos=[], logit_bias=None, share_prefixes=True):
+                 strip_from_bos=[], strip_from_eos=[], logit_bias=None, share_prefixes=True, encoded=None):
     """Teacher-forced log-probability of every key given its query
     (reference keys.py:64-141): targets with id < 2 contribute 0 (keys.py:132),
     score divided by ``len(key) ** length_penalty``.
@@ -75,7 +75,7 @@ def rescore_keys(model, inputs, list_of_decoded, batch_size=100, length_penalty=
     the reference's one-row-per-key batching."""
     if share_prefixes:
         return _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_penalty, prefix, strip_from_bos,
-                                    strip_from_eos, logit_bias)
+                                    strip_from_eos, logit_bias, encoded)
     cfg = model.config
     device = next(model.parameters()).device
     if inputs is None:
@@ -113,7 +113,7 @@ def rescore_keys(model, inputs, list_of_decoded, batch_size=100, length_penalty=
 
 @torch.inference_mode()
 def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_penalty, prefix, strip_from_bos, strip_from_eos,
-                         logit_bias):
+                         logit_bias, encoded=None):
     """Tree-shared teacher forcing.  score(key) = sum_j log p(key[j] | key[:j]).  The keys of a
     query form the beam-search tree; a decoder row fed with ``[start] + q`` yields, at position j,
     the distribution after ``q[:j]`` -- i.e. every term of every key whose parent ``key[:-1]`` is a
@@ -126,9 +126,14 @@ def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_pena
     else:
         batch_in = [list(i) for i in inputs]
     decoded = [[x[1] if isinstance(x[0], float) else x for x in xx] for xx in list_of_decoded]
-    input_ids = _pad_batch(batch_in, cfg.pad_token_id, device)
-    attention_mask = (input_ids != cfg.pad_token_id).to(torch.uint8)
-    enc = model.model.encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+    if encoded is not None:
+        # (encoder states, attention mask) of exactly these inputs from an earlier pass of the same model (the searcher's
+        # title decode encodes what the title rescoring would encode again, retrieval.py:157-160 vs 195)
+        enc, attention_mask = encoded
+    else:
+        input_ids = _pad_batch(batch_in, cfg.pad_token_id, device)
+        attention_mask = (input_ids != cfg.pad_token_id).to(torch.uint8)
+        enc = model.model.encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
     start, npre = cfg.decoder_start_token_id, len(prefix)
     seqs = [[tuple(list(prefix) + list(strip(list(key), strip_from_bos, strip_from_eos))) for key in keys] for keys in decoded]
     work = []           # (query, maximal parent)

@@ -277,7 +277,8 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
         if s.rescore and s.use_markers:
             title_keys = rk.rescore_keys(
                 s.bart_title_model, title_toks, title_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
-                strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=bias)
+                strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=bias,
+                encoded=(titles.enc, titles.attention_mask) if tokenised and titles.enc is not None else None)
         for nfk, fk in zip(title_keys, found_keys):
             fk += nfk
 
@@ -291,6 +292,12 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
     found_keys = [rk.deduplicate(fk) for fk in found_keys]
     found_keys = [[(n, sc) for sc, n in fk] for fk in found_keys]   # flip to (ngram, score), retrieval.py:284
 
+    if (s.unigram_scores and body is not None and body.first_logits is not None and s.bart_scorer_model is s.bart_model
+            and s.force_decoding_second_token < 0):
+        # compute_unigram_scores (keys.py:145-176) = the model's next-token distribution after the decoder start token
+        # for the ' || body' input: exactly the first step of the body decode above
+        unigram = torch.log_softmax(body.first_logits.float(), dim=-1).double().cpu().numpy()
+        return list(zip(found_keys, unigram))
     if s.unigram_scores:
         _, toks = marked("body")
         unigram = rk.compute_unigram_scores(

@@ -45,8 +45,8 @@ def test_gpu_aggregation_equals_the_reference(case_no, monkeypatch):
     keys = [(list(k), _unhex(s)) for k, s in case["keys"]]
     us = None if case["unigram_scores"] is None else [_unhex(x) for x in case["unigram_scores"]]
     calls = []
-    real = gpu_aggregate.aggregate_on_gpu
-    monkeypatch.setattr(gpu_aggregate, "aggregate_on_gpu", lambda *a: (calls.append(1), real(*a))[1])
+    real = gpu_aggregate._run_plan
+    monkeypatch.setattr(gpu_aggregate, "_run_plan", lambda *a: (calls.append(1), real(*a))[1])
     results, all_ngrams = aggregate_evidence(keys, unigram_scores=us, index=ix, **kw)
     on_gpu = not (kw.get("sort_by_length") or kw.get("sort_by_freq") or kw.get("first_stage_only"))
     if on_gpu and len(case["results"]) > 0:
@@ -116,9 +116,10 @@ OPTIONS = [
 ]
 
 
+@pytest.mark.parametrize("python_scoring", [False, True], ids=["cpp-scoring", "python-scoring"])
 @pytest.mark.parametrize("seed", [0, 1, 2])
 @pytest.mark.parametrize("kw", OPTIONS, ids=[str(i) for i in range(len(OPTIONS))])
-def test_gpu_aggregation_equals_the_host_routines(seed, kw, monkeypatch):
+def test_gpu_aggregation_equals_the_host_routines(seed, kw, python_scoring, monkeypatch):
     from seal_amd.keys import aggregate_evidence, aggregate_evidence_batch
     vocab = 40 if seed == 2 else 60                           # the small alphabet: ties and overlaps everywhere
     rng = np.random.default_rng(seed)
@@ -134,7 +135,8 @@ def test_gpu_aggregation_equals_the_host_routines(seed, kw, monkeypatch):
         want = [aggregate_evidence(k, unigram_scores=u, index=ix, **kw) for k, u in jobs]
         monkeypatch.delenv("SEAL_HOST_AGGREGATE")
         ix._agg_debug = []
-        got = aggregate_evidence_batch(jobs, ix, keep=keep, **{**dict(n_docs_complete_score=500, max_occurrences_1=1500), **kw})
+        got = aggregate_evidence_batch(jobs, ix, keep=keep, python_scoring=python_scoring,
+                                       **{**dict(n_docs_complete_score=500, max_occurrences_1=1500), **kw})
         assert len(ix._agg_debug) == 1, "the device path did not run"
         fs = ix._agg_debug[0]
         ix._agg_debug = None
