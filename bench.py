@@ -7,7 +7,9 @@ title decode <= 15 tokens, beam 15, FM-index constrained; count post-filters;
 rescoring; unigram scores; first-stage retrieval = counts + locate + doc binning +
 evidence aggregation; full-document rescoring of the 1500 best documents per query,
 keys.py:366-497 -- both aggregation stages as GPU kernels) on an NQ-shaped synthetic
-FM-index with a random-init BART-large (fp32, as the reference runs it).  After the
+FM-index with a random-init BART-large (fp32, as the reference runs it); the query
+n-gram keys of the reference's default configuration (add_query_to_keys) are in
+the step in their token-id form.  After the
 timed region the GPU's answers for one batch are compared with the CPU oracle's
 and with the bit-exact host routines (``parity_check`` in the JSON line; a mismatch
 exits non-zero).
@@ -256,6 +258,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1, help="query batches in flight on worker threads (each on its own stream); 1 = none")
     ap.add_argument("--no-overlap", action="store_true", help="do not enqueue the next batch's decodes ahead of this batch's rescoring/aggregation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-query-keys", action="store_true", help="leave out the query n-gram keys (add_query_to_keys, the reference's default)")
     ap.add_argument("--first-stage-only", action="store_true",
                     help="stop after the first retrieval stage (SURVEY.md 8d metric) instead of the reference's complete batch_search")
     args = ap.parse_args()
@@ -313,7 +316,7 @@ def main():
             model.final_logits_bias[0, tok] = float("-inf")
     log(f"BART-large random init (fp32) in {time.perf_counter() - t0:.1f}s")
 
-    searcher = SEALSearcher(index, None, model, add_query_to_keys=False, detokenize=False, first_stage_only=args.first_stage_only,
+    searcher = SEALSearcher(index, None, model, add_query_to_keys=not args.no_query_keys, detokenize=False, first_stage_only=args.first_stage_only,
                             beam=args.beam, batch_size=args.batch, jobs=args.jobs, pipeline=args.pipeline, overlap=not args.no_overlap)
     from seal_amd.bart_decoder import BartStepDecoder
     model._seal_step_decoder = BartStepDecoder(model)
@@ -548,8 +551,10 @@ def main():
                                f"BART-large fp32, beam={args.beam}, batch={args.batch} per GPU, body len 10 + title len<=15, "
                                f"{'first-stage retrieval' if args.first_stage_only else 'first stage + full-document rescoring of 1500 docs/query'}, top-{args.topk}",
                    "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated; " + ("next batch's decodes enqueued ahead of this batch's rescoring/aggregation (2 streams)" if not args.no_overlap and args.pipeline <= 1 else f"{args.pipeline} query batches in flight per GPU"), "model_arithmetic": "fp32 (as the reference runs BART)",
+                   "query_ngram_keys": "off" if args.no_query_keys else "token 1..3-grams of the query ids (add_query_to_keys=True, the reference's default; "
+                                                                                 "spaCy/BART tokenizer absent offline: seal_amd.query_keys.token_ngram_keys)",
                    "not_in_step": (["full-document rescoring (keys.py:366-497)"] if args.first_stage_only else []) +
-                                  ["query-string n-gram keys (add_query_to_keys: spaCy/tokenizer absent offline)"]},
+                                  (["query n-gram keys (add_query_to_keys)"] if args.no_query_keys else [])},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "parity_check": parity,

@@ -38,3 +38,26 @@ def query_ngram_keys(query: str, searcher):
     if searcher.min_length > 0:
         ids = [k for k in ids if len(k) == searcher.min_length]
     return ids
+
+
+def token_ngram_keys(tokens, searcher=None, length: int = 3):
+    """query keys for a PRE-TOKENISED query (an extension: the reference only takes strings): every contiguous span of
+    1..``length`` content tokens of the query (its ids without the leading <s> and the trailing </s>), first occurrence
+    first -- what reference keys.py:38-51 + retrieval.py:115-126 yield when every word is one token and capitalisation
+    does not change it.  The count > 0 filter and the rescoring follow in the caller as for string queries."""
+    strip = searcher.strip_token_ids if searcher is not None else (0, 2)
+    body = list(tokens)
+    while body and body[0] in strip:
+        body = body[1:]
+    while body and body[-1] in strip:
+        body = body[:-1]
+    seen, out = set(), []
+    for i in range(len(body)):
+        for j in range(i + 1, min(len(body), i + length) + 1):
+            k = tuple(body[i:j])
+            if k not in seen:
+                seen.add(k)
+                out.append(list(k))
+    if searcher is not None and searcher.min_length > 0:
+        out = [k for k in out if len(k) == searcher.min_length]
+    return out

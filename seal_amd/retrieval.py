@@ -250,16 +250,24 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
                 strip_from_eos=[s.title_eos_token_id, s.code_eos_token_id, s.bart_model.config.eos_token_id], logit_bias=bias)
 
     if s.add_query_to_keys:
-        if tokenised or s.bart_tokenizer is None:
-            raise RuntimeError("add_query_to_keys decomposes the query STRING into word n-grams (spaCy + tokenizer, "
-                               "reference retrieval.py:113-131); pass string queries or set add_query_to_keys=False")
-        from .query_keys import query_ngram_keys
-        cand = [query_ngram_keys(inp, s) for inp in inputs]
+        if tokenised:
+            # pre-tokenised queries (an extension): the word n-grams are token n-grams (seal_amd/query_keys.py)
+            from .query_keys import token_ngram_keys
+            cand = [token_ngram_keys(q, s) for q in base_tokens]
+        else:
+            if s.bart_tokenizer is None:
+                raise RuntimeError("add_query_to_keys decomposes the query STRING into word n-grams (spaCy + tokenizer, "
+                                   "reference retrieval.py:113-131): a tokenizer is needed for string queries")
+            from .query_keys import query_ngram_keys
+            cand = [query_ngram_keys(inp, s) for inp in inputs]
         cand = [[(0.0, k) for k in kk] for kk in cand]
         cand = [[k for _, k in kk] for kk in _count_filter(fm_index, cand)]
         _, toks = marked("body")
         last_input_tokens = toks                # the reference re-binds `input_tokens` here (retrieval.py:139)
-        for fk, nfk in zip(found_keys, rk.rescore_keys(s.bart_model, toks, cand, batch_size=100, length_penalty=0.0)):
+        # same encoder input as the body decode (' || body || +'): its encoder states are reused where there are any
+        reuse = (body.enc, body.attention_mask) if (tokenised and body is not None and body.enc is not None) else None
+        for fk, nfk in zip(found_keys, rk.rescore_keys(s.bart_model, toks, cand, batch_size=100, length_penalty=0.0, logit_bias=bias,
+                                                       encoded=reuse)):
             fk += nfk
 
     if s.decode_titles:

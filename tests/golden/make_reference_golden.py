@@ -177,14 +177,10 @@ def aggregate_cases():
     return cases
 
 
-class _Word:
-    def __init__(self, text):
-        self.text = text
-
-
 def _split_words(query):
     """stands in for spaCy's English tokenizer (absent offline): whitespace words as objects with .text"""
-    return [_Word(w) for w in query.split()]
+    from tests.helpers import split_words
+    return split_words(query)
 
 
 def helper_cases():
@@ -404,40 +400,6 @@ def beam_cases():
     return {"vocab": vocab, "docs": docs, "enc_ids": enc_ids.tolist(), "cases": cases}
 
 
-class _ToyTokenizer:
-    """"w17 w3 || body" <-> [0, 17, 3, V-2, V-3, 2]: enough of a tokenizer for retrieval.py's process_batch
-    (pre-tokenised corpora have no text); markers get the ids the product's marker_token_ids default to in tests"""
-
-    def __init__(self, vocab):
-        self.special = {"||": vocab - 2, "body": vocab - 3, "title": vocab - 4, "+": vocab - 5}
-        self.back = {v: k for k, v in self.special.items()}
-
-    def _ids(self, text, add_special_tokens=True):
-        ids = [self.special[t] if t in self.special else int(t[1:]) for t in text.split()]
-        return [0] + ids + [2] if add_special_tokens else ids
-
-    def __call__(self, texts, return_tensors=None, padding=False, truncation=False, add_special_tokens=True):
-        import torch
-        rows = [self._ids(t, add_special_tokens) for t in texts]
-        if return_tensors != "pt":
-            return {"input_ids": rows}
-        width = max(len(r) for r in rows)
-        ids = torch.tensor([r + [1] * (width - len(r)) for r in rows])
-        return {"input_ids": ids, "attention_mask": (ids != 1).long()}
-
-    def decode(self, ids, skip_special_tokens=False, clean_up_tokenization_spaces=False):
-        out = []
-        for t in ids:
-            t = int(t)
-            if skip_special_tokens and t in (0, 1, 2):
-                continue
-            out.append(self.back.get(t, f"w{t}"))
-        return " ".join(out)
-
-    def batch_decode(self, seqs, **kw):
-        return [self.decode(s, **kw) for s in seqs]
-
-
 class _ModelForTheReferenceSearcher(_ModelForTheReferenceLoop):
     """the same hand-made HF-4.1x hooks, for a model that is handed encoder inputs per call (process_batch,
     rescore_keys and compute_unigram_scores all use it)"""
@@ -467,14 +429,16 @@ class _ModelForTheReferenceSearcher(_ModelForTheReferenceLoop):
 def searcher_cases():
     """seal/retrieval.py end to end: SEALSearcher.batch_search = batch_generate_keys.process_batch (body decode,
     post-filters, rescoring, title decode, title filters, rescoring, dedup, unigram scores) + retrieve_from_keys
-    (aggregate_evidence with the searcher's parameters) + SEALDocument.  add_query_to_keys is off (spaCy + a real
-    tokenizer); the 'bart' backbone's hard-wired title / code delimiter ids are re-pointed at this toy vocabulary."""
+    (aggregate_evidence with the searcher's parameters) + SEALDocument.  Two runs without the query n-gram keys and one
+    with them (add_query_to_keys=True, the reference's default: retrieval.py:115-149 with a whitespace word tokenizer in
+    spaCy's place and tests.helpers.ToyTokenizer as the BART tokenizer); the 'bart' backbone's hard-wired title / code
+    delimiter ids are re-pointed at this toy vocabulary."""
     import numpy as np
     import torch
     import seal.retrieval as ref_retrieval
     from seal.index import FMIndex
     from seal.retrieval import SEALSearcher
-    from tests.helpers import make_docs as helper_docs, tiny_bart
+    from tests.helpers import ToyTokenizer, make_docs as helper_docs, tiny_bart
     vocab, K, length, title_eos = 120, 4, 6, 7
     docs = helper_docs(5, 200, vocab - 8, min_len=6, max_len=18, title_sep=title_eos)
     index = FMIndex()
@@ -485,15 +449,17 @@ def searcher_cases():
     queries = [" ".join(f"w{t}" for t in q[1:-1]) for q in queries_ids]
     real_generate = ref_retrieval.fm_index_generate
     out = {"vocab": vocab, "beam": K, "length": length, "title_eos": title_eos, "docs": docs, "queries": queries_ids, "runs": []}
-    for title_length in (8, 15):                  # 15 is the reference's constant; 8 is what tests/test_gpu_search.py runs both sides at
+    ref_retrieval.word_tokenizer = _split_words
+    # 15 is the reference's constant; 8 is what tests/test_gpu_search.py runs both sides at
+    for title_length, query_keys in ((8, False), (15, False), (8, True)):
         def generate(*a, **kw):
             if kw.get("force_decoding_from"):
                 kw = {**kw, "max_length": title_length}
             return real_generate(*a, **kw)
         ref_retrieval.fm_index_generate = generate
         try:
-            s = SEALSearcher(index, _ToyTokenizer(vocab), _ModelForTheReferenceSearcher(tiny_bart(vocab)), backbone="bart-tiny",
-                             length=length, beam=K, batch_size=2, add_query_to_keys=False, detokenize=True)
+            s = SEALSearcher(index, ToyTokenizer(vocab), _ModelForTheReferenceSearcher(tiny_bart(vocab)), backbone="bart-tiny",
+                             length=length, beam=K, batch_size=2, add_query_to_keys=query_keys, detokenize=True)
             # (include_keys=True cannot be used with more than one query: batch_search's `for k, _ in kk` rebinds its own
             #  parameter k, the islice stop; the per-document keys are read from retrieve_from_keys below instead)
             s.title_eos_token_id, s.code_bos_token_id, s.code_eos_token_id = title_eos, title_eos, vocab - 6
@@ -503,7 +469,7 @@ def searcher_cases():
                 retrieved = s.batch_search(queries, k=10)
         finally:
             ref_retrieval.fm_index_generate = real_generate
-        run = {"title_length": title_length, "queries": []}
+        run = {"title_length": title_length, "add_query_to_keys": query_keys, "queries": []}
         for (kk, us), (res, _), docs_q in zip(keys, evidence, retrieved):
             assert [d.idx for d in docs_q] == list(res)[:10] and [d.score for d in docs_q] == [res[d.idx][0] for d in docs_q]
             run["queries"].append({

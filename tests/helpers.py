@@ -158,3 +158,52 @@ def synthetic_fairseq_checkpoint(path, vocab=120, seed=11):
     sd["decoder.version"] = torch.tensor([3.0])
     sd["decoder.output_projection.weight"] = emb.clone()
     torch.save({"model": sd}, path)
+
+
+class ToyTokenizer:
+    """"w17 w3 || body" <-> [0, 17, 3, V-2, V-3, 2]: enough of a tokenizer for retrieval.py's process_batch (pre-tokenised
+    corpora have no text); markers get the ids the product's marker_token_ids are given in tests.  A capitalised word
+    ("W17", reference keys.py:46-47) is the same token.  Shared by tests/golden/make_reference_golden.py (the
+    reference's searcher) and the product's tests."""
+
+    def __init__(self, vocab):
+        self.special = {"||": vocab - 2, "body": vocab - 3, "title": vocab - 4, "+": vocab - 5}
+        self.back = {v: k for k, v in self.special.items()}
+
+    def _ids(self, text, add_special_tokens=True):
+        ids = [self.special[t] if t in self.special else int(t[1:]) for t in text.split()]
+        return [0] + ids + [2] if add_special_tokens else ids
+
+    def __call__(self, texts, return_tensors=None, padding=False, truncation=False, add_special_tokens=True):
+        rows = [self._ids(t, add_special_tokens) for t in texts]
+        if return_tensors != "pt":
+            return {"input_ids": rows}
+        width = max(len(r) for r in rows)
+        ids = torch.tensor([r + [1] * (width - len(r)) for r in rows])
+        return {"input_ids": ids, "attention_mask": (ids != 1).long()}
+
+    def decode(self, ids, skip_special_tokens=False, clean_up_tokenization_spaces=False):
+        out = []
+        for t in ids:
+            t = int(t)
+            if skip_special_tokens and t in (0, 1, 2):
+                continue
+            out.append(self.back.get(t, f"w{t}"))
+        return " ".join(out)
+
+    def batch_decode(self, seqs, **kw):
+        return [self.decode(s, **kw) for s in seqs]
+
+    def as_target_tokenizer(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+
+class Word:
+    def __init__(self, text):
+        self.text = text
+
+
+def split_words(query):
+    """stands in for spaCy's English tokenizer (absent offline): whitespace words as objects with .text"""
+    return [Word(w) for w in query.split()]

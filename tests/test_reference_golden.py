@@ -317,8 +317,8 @@ def test_fairseq_checkpoint_loader_equals_the_reference(tmp_path):
     assert np.allclose(logits[:, -1, :16].flatten().double().numpy(), want, atol=1e-6, rtol=0, equal_nan=True)
 
 
-@pytest.mark.parametrize("title_length,jobs", [(8, 1), (15, 1), (8, 2)])
-def test_product_searcher_equals_the_reference_searcher(title_length, jobs, monkeypatch):
+@pytest.mark.parametrize("title_length,jobs,query_keys", [(8, 1, None), (15, 1, None), (8, 2, None), (8, 1, "strings"), (8, 1, "token ids")])
+def test_product_searcher_equals_the_reference_searcher(title_length, jobs, query_keys, monkeypatch):
     """the PRODUCT's SEALSearcher.batch_search, all of its Python (key generation recipe, batched post-filters,
     prefix-sharing rescoring, batched evidence aggregation with the native host routines, worker processes,
     SEALDocument) run on CPU -- index queries answered by the oracle, the constraint by the oracle's mask -- against
@@ -326,7 +326,7 @@ def test_product_searcher_equals_the_reference_searcher(title_length, jobs, monk
     from seal_amd import retrieval
     from seal_amd.retrieval import SEALSearcher
     from tests.helpers import OracleLogitsProcessor, tiny_bart
-    run = [r for r in SEARCH["runs"] if r["title_length"] == title_length][0]
+    run = [r for r in SEARCH["runs"] if r["title_length"] == title_length and r["add_query_to_keys"] == (query_keys is not None)][0]
     vocab, K, length, title_eos = SEARCH["vocab"], SEARCH["beam"], SEARCH["length"], SEARCH["title_eos"]
     orc = OracleFMIndex()
     orc.initialize(SEARCH["docs"])
@@ -355,10 +355,26 @@ def test_product_searcher_equals_the_reference_searcher(title_length, jobs, monk
             kw = {**kw, "max_length": title_length}
         return real(model, None, *a, constrained_decoding_processor=proc, **kw)
     monkeypatch.setattr(retrieval, "fm_index_generate", generate)
-    s = SEALSearcher(index, None, tiny_bart(vocab), backbone="bart-tiny", length=length, beam=K, batch_size=2, add_query_to_keys=False,
-                     detokenize=False, jobs=jobs, title_eos_token_id=title_eos, code_eos_token_id=vocab - 6, code_bos_token_id=title_eos,
+    # add_query_to_keys (the reference's default, retrieval.py:115-149): as the reference ran it -- query STRINGS, a
+    # whitespace word tokenizer in spaCy's place, the toy BART tokenizer -- and through the product's token-id form
+    # (seal_amd.query_keys.token_ngram_keys: with one token per word and case-insensitive tokens the same key set)
+    tokenizer, queries = None, SEARCH["queries"]
+    if query_keys == "strings":
+        from seal_amd import query_keys as qk
+        from tests.helpers import ToyTokenizer, split_words
+        monkeypatch.setattr(qk, "_word_tokenizer", split_words)
+        tokenizer, queries = ToyTokenizer(vocab), [" ".join(f"w{t}" for t in q[1:-1]) for q in SEARCH["queries"]]
+    s = SEALSearcher(index, tokenizer, tiny_bart(vocab), backbone="bart-tiny", length=length, beam=K, batch_size=2,
+                     add_query_to_keys=query_keys is not None, detokenize=False, jobs=jobs, title_eos_token_id=title_eos,
+                     code_eos_token_id=vocab - 6, code_bos_token_id=title_eos,
                      marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5]})
-    got = s.batch_search(SEARCH["queries"], k=10)
+    if query_keys is not None:       # the keys themselves: same n-grams, scores within fp32 noise (their order follows a python set's)
+        for got_q, want_q in zip(s.batch_generate_keys(queries), run["queries"]):
+            gk = {tuple(k): v for k, v in got_q[0]}
+            wk = {tuple(k): _unhex(v) for k, v in want_q["keys"]}
+            assert set(gk) == set(wk)
+            assert all(abs(gk[k] - wk[k]) <= 1e-4 * max(1.0, abs(wk[k])) for k in wk)
+    got = s.batch_search(queries, k=10)
     assert len(got) == len(run["queries"])
     for docs, want in zip(got, run["queries"]):
         w_scores = [_unhex(d["score"]) for d in want["ranked"]]
