@@ -267,6 +267,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # host budget of a rank: the search step is one python thread + the key-scoring threads of fmi_agg_score_pack; all
+    # ranks of a node share its cores (the CPU baseline leg alone uses --cpu-threads, on rank 0 at N=1 only)
+    cores = os.cpu_count() or 1
+    host_threads = max(1, min(8, cores // (2 * max(world, 1))))
+    os.environ.setdefault("SEAL_HOST_THREADS", str(host_threads))
+    torch.set_num_threads(max(1, min(8, cores // max(world, 1))))
+    log(f"host: {cores} cores / {world} rank(s): {os.environ['SEAL_HOST_THREADS']} key-scoring threads, {torch.get_num_threads()} torch CPU threads per rank")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dist = bool(os.environ.get("SEAL_BENCH_FORCE_DIST"))     # exercise the RCCL path with one rank

@@ -57,3 +57,16 @@ def gather_topk(local: torch.Tensor, n_total: int, device=None) -> torch.Tensor:
     dist.all_gather_into_tensor(out, buf)
     out = out.view(world, pad, k, 2)
     return torch.cat([out[r, :hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
+
+
+def sharded_batch_search(searcher, queries: Sequence, k: int = 100, device=None) -> torch.Tensor:
+    """``SEALSearcher.batch_search`` over the ranks of the default process group: this rank searches its contiguous
+    block of ``queries`` (``shard_bounds``), then ONE all-gather brings every query's top-k (doc id, score) to every rank,
+    in query order: float64 ``[len(queries), k, 2]``, -1 where a query has fewer than k hits.  Without a process group it
+    is a plain local search."""
+    mine = shard_queries(queries)
+    results = searcher.batch_search(mine, k=k, detokenize=False) if mine else []
+    local = pack_topk(results, k)
+    if device is not None:
+        local = local.to(device)
+    return gather_topk(local, len(queries), device=device)

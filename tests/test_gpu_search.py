@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 TITLE_EOS = 7
 
 
-def _oracle_pipeline(model, orc, queries, K, length, vocab, first_stage_only, title_length=8, return_keys=False):
+def _oracle_pipeline(model, orc, queries, K, length, vocab, first_stage_only, title_length=8, return_keys=False, query_keys=False):
     from oracle.beam_oracle import oracle_fm_index_generate
     from oracle.keys_oracle import (oracle_aggregate_evidence, oracle_body_postfilter, oracle_deduplicate,
                                     oracle_title_postfilter)
@@ -31,6 +31,11 @@ def _oracle_pipeline(model, orc, queries, K, length, vocab, first_stage_only, ti
                                     pad_token_id=pad, eos_token_id=2, length_penalty=0.0)
     body = [oracle_body_postfilter(fk, orc) for fk in body]
     body = rk.rescore_keys(model, queries, body, strip_from_bos=[2, TITLE_EOS, 2], strip_from_eos=[TITLE_EOS, vocab - 6, 2])
+    if query_keys:       # reference retrieval.py:115-149 for one-token words: every 1..3-gram of the query that occurs, rescored
+        for q, fk, row in zip(queries, body, rk.rescore_keys(model, toks, [
+                [list(k) for k in dict.fromkeys(tuple(q[1:-1][i:j]) for i in range(len(q) - 2) for j in range(i + 1, min(len(q) - 2, i + 3) + 1))
+                 if orc.get_count(list(k)) > 0] for q in queries])):
+            fk += row
     ttoks, ids, am = enc("title")
     title = oracle_fm_index_generate(hf_logits_fn(model, ids, am, K), orc, len(queries), K, title_length, vocab,
                                      pad_token_id=pad, eos_token_id=TITLE_EOS, length_penalty=0.0, force_decoding_from=[2])
@@ -67,8 +72,8 @@ def _tie_groups(items, rel=1e-3):
 
 
 @pytest.mark.parametrize("geom", MODEL_GEOMETRIES, ids=MODEL_IDS)
-@pytest.mark.parametrize("first_stage_only,jobs", [(False, 1), (True, 1), (False, 2), (True, 2)])
-def test_searcher_ranks_like_the_scalar_pipeline(first_stage_only, jobs, geom, monkeypatch):
+@pytest.mark.parametrize("first_stage_only,jobs,query_keys", [(False, 1, False), (True, 1, False), (False, 2, False), (True, 2, False), (False, 1, True)])
+def test_searcher_ranks_like_the_scalar_pipeline(first_stage_only, jobs, query_keys, geom, monkeypatch):
     from oracle.seal_oracle import OracleFMIndex
     from seal_amd import FMIndex
     from seal_amd import retrieval
@@ -89,13 +94,13 @@ def test_searcher_ranks_like_the_scalar_pipeline(first_stage_only, jobs, geom, m
     monkeypatch.setattr(retrieval, "fm_index_generate",
                         lambda *a, **kw: real(*a, **{**kw, "max_length": 8 if kw.get("force_decoding_from") else kw["max_length"]}))
     s = SEALSearcher(ix, None, tiny_bart(vocab, **geom).to(dev), backbone="bart-tiny", length=length, beam=K, batch_size=2,
-                     add_query_to_keys=False, detokenize=False, first_stage_only=first_stage_only, jobs=jobs,
+                     add_query_to_keys=query_keys, detokenize=False, first_stage_only=first_stage_only, jobs=jobs,
                      title_eos_token_id=TITLE_EOS, code_eos_token_id=vocab - 6, code_bos_token_id=TITLE_EOS,
                      marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5]})
     got = s.batch_search(queries, k=10)
     st = s.bart_model._seal_step_decoder._st
     assert st.fused is (geom["d_model"] // geom["heads"] == 64)       # no silent fallback from the sealnn_* kernels
-    want = _oracle_pipeline(tiny_bart(vocab, **geom), orc, queries, K, length, vocab, first_stage_only)
+    want = _oracle_pipeline(tiny_bart(vocab, **geom), orc, queries, K, length, vocab, first_stage_only, query_keys=query_keys)
     for g, w in zip(got, want):
         w_all = list(w.items())
         w_items = w_all[:10]

@@ -270,7 +270,7 @@ def test_search_pipeline_equals_the_reference_searcher(run_no):
     orc = OracleFMIndex()
     orc.initialize(SEARCH["docs"])
     results, keys = _oracle_pipeline(tiny_bart(vocab), orc, SEARCH["queries"], K, length, vocab, False,
-                                     title_length=run["title_length"], return_keys=True)
+                                     title_length=run["title_length"], return_keys=True, query_keys=run["add_query_to_keys"])
     for got, got_keys, want in zip(results, keys, run["queries"]):
         want_keys = {tuple(n): _unhex(s) for n, s in want["keys"]}
         have_keys = {tuple(n): s for n, s in got_keys}
