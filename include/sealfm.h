@@ -86,8 +86,14 @@ int fmi_build_from_bwt_device(fmi_t *h, const void *d_bwt, uint64_t n, int sym_b
 /* FMIndex::save(path)  (fm_index.cpp:186-189).  Own documented format
  * (DESIGN.md "on-disk layout"), not sdsl's. */
 int fmi_save(const fmi_t *h, const char *path);
-/* load_FMIndex(path)  (fm_index.cpp:191-199) */
+/* load_FMIndex(path)  (fm_index.cpp:191-199).  Accepts this engine's own container (fmi_save) and the files the
+ * REFERENCE writes: sdsl-lite's serialisation of csa_wt_int<> (fm_index.cpp:186-189; the published SEAL indices,
+ * README.md:67-69).  For the latter the text is recovered from the file (parallel LF walks from the ISA samples), the
+ * index is rebuilt from it by the engine's builder, and the quirk table of DESIGN.md section 4 is taken from the file's
+ * own bit layout (fmi_load_sdsl, seal_amd/csrc/fmi_sdsl.cpp; format restated from sdsl's published sources: unpinned
+ * until a file written by sdsl itself has been read). */
 int fmi_load(fmi_t **out, const char *path, int device);
+int fmi_load_sdsl(fmi_t **out, const char *path, int device);
 
 /* Upload a host-resident index (built with device < 0 or loaded) to a GPU. */
 int fmi_to_device(fmi_t *h, int device);

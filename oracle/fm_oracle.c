@@ -605,3 +605,163 @@ void orc_extract_batch_tokens(const orc_t *o, uint64_t m, const uint64_t *begins
 #pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
     for (int64_t i = 0; i < (int64_t)m; i++) orc_extract_text(o, begins[i], ends[i], out + out_offsets[i]);
 }
+
+/* ---- sdsl-lite on-disk format of csa_wt_int<> (store_to_file, ref cpp:186-189) -------------------------------------
+ * Written from this oracle's own structures so that the product's reader of real SEAL indices (seal_amd/csrc/
+ * fmi_sdsl.cpp) can be round-trip tested without sdsl.  PARITY UNPINNED: the layout below is restated from the published
+ * sdsl-lite v2.1.x sources (csa_wt::serialize = wavelet_tree, sa_sample, isa_sample, alphabet; wt_int::serialize = size,
+ * sigma, tree, tree_rank, tree_select_1, tree_select_0, max_level; int_alphabet = sd_vector m_char (+ stateless rank /
+ * select), m_C, m_sigma) and has never been compared with a file sdsl wrote -- the sdsl sources are not in this image.
+ * int_vector<w>: u64 size in BITS (+ u8 width when w == 0), then ceil(size/64) little-endian words, elements packed
+ * LSB-first. */
+static void w_u64(FILE *f, uint64_t v) { fwrite(&v, 8, 1, f); }
+static void w_u8(FILE *f, uint8_t v) { fwrite(&v, 1, 1, f); }
+static uint8_t hi_bit(uint64_t x) { uint8_t h = 0; while (x >>= 1) h++; return h; }   /* bits::hi, hi(0) = 0 */
+
+static void w_words(FILE *f, const uint64_t *w, uint64_t nbits) { if (nbits) fwrite(w, 8, (nbits + 63) / 64, f); }
+static void w_bit_vector(FILE *f, const uint64_t *w, uint64_t nbits) { w_u64(f, nbits); w_words(f, w, nbits); }
+
+static void w_int_vector0(FILE *f, const uint64_t *vals, uint64_t n, uint8_t width)
+{
+    uint64_t nbits = n * width, nw = (nbits + 63) / 64;
+    uint64_t *buf = (uint64_t *)calloc(nw + 1, 8);
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t pos = i * width, v = width < 64 ? (vals[i] & ((1ULL << width) - 1)) : vals[i];
+        buf[pos >> 6] |= v << (pos & 63);
+        if ((pos & 63) + width > 64) buf[(pos >> 6) + 1] |= v >> (64 - (pos & 63));
+    }
+    w_u64(f, nbits); w_u8(f, width); w_words(f, buf, nbits);
+    free(buf);
+}
+
+/* rank_support_v<1>::serialize = its int_vector<64> of ((capacity >> 9) + 1) * 2 words */
+static void w_rank_support_v(FILE *f, const uint64_t *bits, uint64_t nbits)
+{
+    uint64_t cap = ((nbits + 63) >> 6) << 6, nblk = (cap >> 9) + 1, nwords = cap >> 6;
+    uint64_t *bb = (uint64_t *)calloc(2 * nblk, 8), abs_cnt = 0;
+    for (uint64_t b = 0; b < nblk; b++) {
+        uint64_t rel = 0, packed = 0;
+        for (int w = 0; w < 8; w++) {
+            uint64_t wi = b * 8 + w;
+            if (w > 0) packed |= rel << (63 - 9 * w);
+            if (wi < nwords) rel += (uint64_t)__builtin_popcountll(bits[wi]);
+        }
+        bb[2 * b] = abs_cnt; bb[2 * b + 1] = packed;
+        abs_cnt += rel;
+    }
+    w_u64(f, 2 * nblk * 64); fwrite(bb, 8, 2 * nblk, f);
+    free(bb);
+}
+
+/* select_support_mcl<b,1>::serialize: arg count; then (if any) the superblock vector, the mini-or-long indicator and
+ * per superblock of 4096 arguments either all positions (span > log^4) or every 64th position relative to the first */
+static void w_select_mcl(FILE *f, const uint64_t *bits, uint64_t nbits, int b)
+{
+    uint64_t cnt = 0;
+    for (uint64_t i = 0; i < nbits; i++) cnt += (((bits[i >> 6] >> (i & 63)) & 1) == (uint64_t)b);
+    w_u64(f, cnt);
+    if (!cnt) return;
+    uint64_t cap = ((nbits + 63) >> 6) << 6;
+    uint8_t logn = hi_bit(cap) + 1;
+    uint64_t logn4 = (uint64_t)logn * logn * logn * logn;
+    uint64_t sb = (cnt + 4095) >> 12;
+    uint64_t *first = (uint64_t *)calloc(sb, 8);
+    uint64_t *pos = (uint64_t *)malloc(4096 * 8);
+    uint8_t *is_long = (uint8_t *)calloc(sb, 1);
+    int any_long = 0;
+    /* pass 1: superblock starts and kinds */
+    uint64_t k = 0, s = 0;
+    for (uint64_t i = 0; i < nbits; i++) {
+        if ((((bits[i >> 6] >> (i & 63)) & 1) != (uint64_t)b)) continue;
+        pos[k & 4095] = i; k++;
+        if ((k & 4095) == 0 || k == cnt) {
+            uint64_t in_sb = (k & 4095) ? (k & 4095) : 4096;
+            first[s] = pos[0];
+            if (pos[in_sb - 1] - pos[0] > logn4) { is_long[s] = 1; any_long = 1; }
+            s++;
+        }
+    }
+    w_int_vector0(f, first, sb, logn);
+    if (any_long) {
+        uint64_t *mol = (uint64_t *)calloc((sb + 63) / 64 + 1, 8);
+        for (uint64_t i = 0; i < sb; i++) if (!is_long[i]) mol[i >> 6] |= 1ULL << (i & 63);    /* bit = "has miniblocks" */
+        w_bit_vector(f, mol, sb);
+        free(mol);
+    } else {
+        w_bit_vector(f, NULL, 0);
+    }
+    /* pass 2: the blocks themselves, in superblock order */
+    k = 0; s = 0;
+    uint64_t mini[64];
+    for (uint64_t i = 0; i < nbits; i++) {
+        if ((((bits[i >> 6] >> (i & 63)) & 1) != (uint64_t)b)) continue;
+        pos[k & 4095] = i; k++;
+        if ((k & 4095) == 0 || k == cnt) {
+            uint64_t in_sb = (k & 4095) ? (k & 4095) : 4096;
+            if (is_long[s]) {
+                uint64_t *all = (uint64_t *)calloc(4096, 8);
+                memcpy(all, pos, in_sb * 8);
+                w_int_vector0(f, all, 4096, hi_bit(pos[in_sb - 1]) + 1);
+                free(all);
+            } else {
+                memset(mini, 0, sizeof(mini));
+                for (uint64_t j = 0; j < in_sb; j += 64) mini[j / 64] = pos[j] - pos[0];
+                w_int_vector0(f, mini, 64, hi_bit(pos[in_sb - 1] - pos[0]) + 1);
+            }
+            s++;
+        }
+    }
+    free(first); free(pos); free(is_long);
+}
+
+/* sd_vector<> of a bit vector with ones at ones[0..m) (ascending) over [0, size) */
+static void w_sd_vector(FILE *f, const uint64_t *ones, uint64_t m, uint64_t size)
+{
+    uint8_t logm = hi_bit(m) + 1, logn = hi_bit(size) + 1;
+    if (logm == logn) --logm;
+    uint8_t wl = logn - logm;
+    uint64_t hbits = m + (1ULL << logm);
+    uint64_t *high = (uint64_t *)calloc((hbits + 63) / 64 + 1, 8), *low = (uint64_t *)calloc(m + 1, 8);
+    uint64_t highpos = 0, last_high = 0;
+    for (uint64_t i = 0; i < m; i++) {
+        uint64_t cur_high = ones[i] >> wl;
+        highpos += cur_high - last_high;
+        last_high = cur_high;
+        low[i] = wl ? (ones[i] & ((1ULL << wl) - 1)) : 0;
+        high[highpos >> 6] |= 1ULL << (highpos & 63);
+        highpos++;
+    }
+    w_u64(f, size); w_u8(f, wl);
+    w_int_vector0(f, low, m, wl);
+    w_bit_vector(f, high, hbits);
+    w_select_mcl(f, high, hbits, 1);
+    w_select_mcl(f, high, hbits, 0);
+    free(high); free(low);
+}
+
+int orc_save_sdsl(const orc_t *o, const char *path)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    /* wt_int */
+    w_u64(f, o->n); w_u64(f, o->sigma);
+    w_bit_vector(f, o->tree, o->tree_bits);
+    w_rank_support_v(f, o->tree, o->tree_bits);
+    w_select_mcl(f, o->tree, o->tree_bits, 1);
+    w_select_mcl(f, o->tree, o->tree_bits, 0);
+    { uint32_t ml = o->max_level; fwrite(&ml, 4, 1, f); }
+    /* sa_order_sa_sampling<>: SA[i], i % 32 == 0; isa_sampling<>: ISA[j], j % 64 == 0; both int_vector<0> of width hi(n)+1 */
+    uint8_t w = hi_bit(o->n) + 1;
+    w_int_vector0(f, o->sa_sample, (o->n + SA_DENS - 1) / SA_DENS, w);
+    w_int_vector0(f, o->isa_sample, (o->n + ISA_DENS - 1) / ISA_DENS, w);
+    /* int_alphabet<>: m_char (sd_vector over [0, max_sym]), rank / select supports of an sd_vector hold no data, m_C, m_sigma */
+    uint64_t *ones = (uint64_t *)malloc((o->sigma + 1) * 8), m = 0;
+    for (uint64_t c = 0; c <= o->max_sym; c++) if (o->present[c]) ones[m++] = c;
+    w_sd_vector(f, ones, m, o->max_sym + 1);
+    w_int_vector0(f, o->C, o->sigma + 1, w);
+    w_u64(f, o->sigma);
+    free(ones);
+    int bad = ferror(f);
+    fclose(f);
+    return bad ? -1 : 0;
+}

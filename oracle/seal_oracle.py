@@ -83,6 +83,8 @@ def lib():
         L.orc_locate_bin_batch.argtypes = [ctypes.c_void_p, _u64, _p64, _p64, _u64, _p64, _p64, ctypes.c_int]
         L.orc_distinct_count_sizes.argtypes = [ctypes.c_void_p, _u64, _p64, _p64, _p64, ctypes.c_int]
         L.orc_extract_batch.argtypes = [ctypes.c_void_p, _u64, _p64, _p64, _p64, ctypes.c_int]
+        L.orc_save_sdsl.restype = ctypes.c_int
+        L.orc_save_sdsl.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
         L.orc_distinct_bitmaps.argtypes = [ctypes.c_void_p, _u64, _p64, _p64, _u64, _u64, ctypes.POINTER(ctypes.c_uint32), _p64, _p64,
                                            ctypes.c_int]
         L.orc_extract_batch_tokens.argtypes = [ctypes.c_void_p, _u64, _p64, _p64, _p64, _p64, ctypes.c_int]
@@ -126,6 +128,12 @@ class CppFMIndex:
         b = np.ascontiguousarray(bwt_u32, dtype=np.uint32)
         s, i = _arr(sa_samples), _arr(isa_samples)
         self._h = lib().orc_build_from_bwt(b.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), len(b), _ptr(s), _ptr(i))
+
+    def save_sdsl(self, path: str) -> None:
+        """the file the reference's ``FMIndex::save`` would write (sdsl ``store_to_file`` of the csa_wt_int<>, ref cpp:186-189),
+        as far as the layout is recalled (fm_oracle.c orc_save_sdsl: parity unpinned)"""
+        if lib().orc_save_sdsl(self._h, path.encode()) != 0:
+            raise IOError(f"cannot write {path}")
 
     def size(self) -> int:  # ref cpp:50
         return int(lib().orc_size(self._h))

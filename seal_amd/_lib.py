@@ -28,6 +28,7 @@ SIGNATURES = {
     "fmi_build_from_bwt_device": (_int, [_vp, _vp, _u64, _int, _u64, _int]),
     "fmi_save": (_int, [_vp, ctypes.c_char_p]),
     "fmi_load": (_int, [ctypes.POINTER(_vp), ctypes.c_char_p, _int]),
+    "fmi_load_sdsl": (_int, [ctypes.POINTER(_vp), ctypes.c_char_p, _int]),
     "fmi_to_device": (_int, [_vp, _int]),
     "fmi_set_doc_beginnings": (_int, [_vp, _p64, _u64]),
     "fmi_size": (_u64, [_vp]),

@@ -490,15 +490,23 @@ extern "C" int fmi_save(const fmi_t *h, const char *path)
     return FMI_OK;
 }
 
+extern "C" int fmi_load_sdsl(fmi_t **out, const char *path, int device);
+
 extern "C" int fmi_load(fmi_t **out, const char *path, int device)
 {
     if (!out || !path) { fmi_set_error("fmi_load: null argument"); return FMI_ERR_ARG; }
     FILE *f = fopen(path, "rb");
     if (!f) { fmi_set_error("cannot open %s", path); return FMI_ERR_IO; }
     char magic[8];
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "SEALFMI4", 8) == 0;
+    if (!ok) {
+        // not this engine's container: the reference's own files are sdsl-lite serialisations of csa_wt_int<>
+        // (fm_index.cpp:186-199); fmi_sdsl.cpp reads those (and refuses anything it cannot vouch for)
+        fclose(f);
+        return fmi_load_sdsl(out, path, device);
+    }
     fmi *h = new fmi();
     uint64_t hdr[4]; uint32_t hdr2[4];
-    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "SEALFMI4", 8) == 0;
     ok = ok && fread(hdr, 8, 4, f) == 4 && fread(hdr2, 4, 4, f) == 4;
     if (ok) { h->n = hdr[0]; h->max_sym = hdr[1]; h->sigma = hdr[2]; h->nblk = hdr[3]; h->levels = hdr2[0]; h->sym_bytes = hdr2[1]; h->sb_shift = hdr2[2]; }
     ok = ok && rd(f, h->dbase) && rd(f, h->sbase) && rd(f, h->C) && rd(f, h->leaf) && rd(f, h->q1) && rd(f, h->wm) &&
