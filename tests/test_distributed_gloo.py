@@ -72,7 +72,7 @@ def test_shard_bounds_cover_everything():
 # filters, rescoring, evidence aggregation -- on its block of the queries, then the top-k gather.  CPU: the index
 # queries are answered by the oracle, as in tests/test_reference_golden.py.
 # ---------------------------------------------------------------------------
-def _cpu_searcher(batch_size):
+def _cpu_searcher(batch_size, patch=None):
     import json
     from oracle.seal_oracle import OracleFMIndex
     from seal_amd import retrieval
@@ -98,7 +98,10 @@ def _cpu_searcher(batch_size):
         if kw.get("force_decoding_from"):
             kw = {**kw, "max_length": 8}
         return real(model, None, *a, constrained_decoding_processor=proc, **kw)
-    retrieval.fm_index_generate = generate
+    if patch is not None:
+        patch.setattr(retrieval, "fm_index_generate", generate)     # restored after the test (the main pytest process)
+    else:
+        retrieval.fm_index_generate = generate                       # a worker process of its own
     s = SEALSearcher(CpuIndex(orc), None, tiny_bart(vocab), backbone="bart-tiny", length=length, beam=K, batch_size=batch_size,
                      add_query_to_keys=True, detokenize=False, title_eos_token_id=title_eos, code_eos_token_id=vocab - 6,
                      code_bos_token_id=title_eos,
@@ -122,7 +125,7 @@ def _search_worker(rank, world, port, k, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_search_equals_the_single_process_search():
+def test_two_rank_sharded_search_equals_the_single_process_search(monkeypatch):
     from seal_amd.distributed import pack_topk
     world, k = 2, 10
     ctx = mp.get_context("spawn")
@@ -131,7 +134,7 @@ def test_two_rank_sharded_search_equals_the_single_process_search():
     procs = [ctx.Process(target=_search_worker, args=(r, world, port, k, q)) for r in range(world)]
     for p in procs:
         p.start()
-    s, queries = _cpu_searcher(batch_size=1)           # one query per batch on both sides: identical arithmetic
+    s, queries = _cpu_searcher(batch_size=1, patch=monkeypatch)           # one query per batch on both sides: identical arithmetic
     want = pack_topk(s.batch_search(queries, k=k, detokenize=False), k)
     got = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
