@@ -486,25 +486,32 @@ def main():
     # 64-byte level-probe per node end): counted exactly in-kernel as well, reported beside it
     model_bytes = 2.0 * xstats[3] * 64.0
     model_gbps = model_bytes / (kms.value * 1e-3) / 1e9 if kms.value > 0 else 0.0
-    # memory-side traffic comes from a SEPARATE rocprofv3 --pmc FETCH_SIZE pass of this same command
-    # (profiles/README.md); per "launch" = per constraint call = the prefix + expansion kernel pair.
+    # memory-side traffic comes from a SEPARATE rocprofv3 --pmc FETCH_SIZE pass of this same command over the
+    # CURRENT kernel (tools/prof_bench.sh -> profiles/r*_pmc_fetch_size.json, which names the commit it was taken
+    # at); a profile of another kernel generation is not used.  Per launch = per constraint call = one k_constrain.
     # FETCH_SIZE counts 128-byte requests at 64 bytes on gfx950 (MI355X guide; tools/gather_calib.hip): x 2.
-    traffic = None
+    traffic = traffic_src = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_size.json")))
-        kib = sum(v["FETCH_SIZE"]["avg"] for k, v in pmc.items() if k.startswith("void k_expand<0>") or k.startswith("void k_prefix_ranges"))
-        traffic = round(kib * 1024.0 * 2, 1) if kib else None
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size.json")), reverse=True):
+            pmc = json.load(open(f))
+            kib = sum(v["FETCH_SIZE"]["avg"] for k, v in pmc.items() if k.startswith("void k_constrain"))
+            if kib:
+                traffic = round(kib * 1024.0 * 2, 1)
+                traffic_src = {"file": os.path.relpath(f, ROOT), "commit": pmc.get("_commit")}
+                break
     except Exception:
         pass
     nl = max(1, launches.value)
-    roofline = {"bound": "hbm", "kernel": "k_prefix_ranges + k_expand<EMIT_BITS> (one constraint call: prefix ranges, root fan-out, sub-tree expansion)",
+    roofline = {"bound": "hbm", "kernel": "k_constrain (one constraint call = one launch: prefix range, row class, root digit and sub-tree "
+                                          "expansion of every (row, top digit) in one wave)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": traffic, "launches": int(launches.value), "avg_launch_us": round(kms.value * 1e3 / nl, 2),
+                "traffic": traffic, "traffic_source": traffic_src, "launches": int(launches.value), "avg_launch_us": round(kms.value * 1e3 / nl, 2),
                 "algorithmic_bytes_per_launch": round(alg_bytes / nl, 1),
                 "survey_8d_model": {"bytes_per_launch": round(model_bytes / nl, 1), "achieved": round(model_gbps, 2),
                                     "frac": round(model_gbps / HBM_PEAK_GBPS, 5),
                                     "note": "binary 16-level wavelet tree, 64 B per level-probe, same symbols emitted"},
-                "wave_iterations_per_launch": round(xstats[1] / nl, 1), "lane_utilisation": round(xstats[2] / max(1, 64 * xstats[1]), 3)}
+                "wave_iterations_per_launch": round(xstats[1] / nl, 1), "lane_pair_utilisation": round(xstats[2] / max(1, 32 * xstats[1]), 3)}
 
     cpu = parity = None
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
@@ -568,7 +575,7 @@ def main():
         "extra": {("complete_search_qps" if args.first_stage_only else "first_stage_only_qps"): None if other_qps is None else round(other_qps, 3),
                   "p50_batch_latency_ms_unpipelined": round(float(np.median(step_ms[1:] or step_ms)), 2) if step_ms else None, "docs_returned_per_query": n_found,
                   "phase_ms_one_batch": {k: round(v, 2) for k, v in phases.items()},
-                  "k_expand_ms_one_batch": round(k2.value, 3), "k_expand_probes_one_batch": int(p2.value)},
+                  "k_constrain_ms_one_batch": round(k2.value, 3), "k_constrain_blocks_one_batch": int(p2.value)},
     }
     print(json.dumps(out), flush=True)
     if use_dist:

@@ -227,19 +227,20 @@ int fmi_dev_locate_ranges(fmi_t *h, void *stream, uint64_t n_ranges, const uint6
 int fmi_dev_get_docs(fmi_t *h, void *stream, uint64_t n_docs, const uint64_t *d_docs,
                      const uint64_t *d_out_offsets, int64_t shift, int64_t *d_out);
 
-/* probe counter of the fmi_dev_* expansion launches since the last read: the
- * 64-byte sectors of wavelet-matrix blocks the rank probes touched (x 64 =
- * DESIGN.md "algorithmic bytes").  Device-side counter, read back
- * synchronously: for measurement only, never on the timed path.
- * fmi_dev_read_expand_stats: out4 = {sectors, wave iterations, nodes expanded,
- * nodes a binary wavelet tree over the same symbols visits} without resetting
- * (nodes / (64 * iterations) = lane utilisation of k_expand; 2 * out4[3] = the
- * 64-byte level-probes of the reference-shaped algorithm for the same work). */
+/* probe counter of the fmi_dev_* constraint / expansion launches since the last
+ * read: the distinct 128-byte wavelet-matrix blocks the rank probes loaded (x 128 =
+ * DESIGN.md "algorithmic bytes").  Device-side counter, read back synchronously:
+ * for measurement only.
+ * fmi_dev_read_expand_stats: out4 = {blocks, wave iterations of the sub-tree
+ * expansion, nodes expanded, nodes a binary wavelet tree over the same symbols
+ * visits} without resetting (nodes / (32 * iterations) = lane-pair utilisation of
+ * k_constrain: one node per pair of lanes; 2 * out4[3] = the 64-byte level-probes
+ * of the reference-shaped algorithm for the same work). */
 int fmi_dev_enable_probe_count(fmi_t *h, int enable);
 int fmi_dev_read_probe_count(fmi_t *h, uint64_t *probes_out);
 int fmi_dev_read_expand_stats(fmi_t *h, uint64_t *out4);
 
-/* HIP-event timing of the expansion kernel (k_expand): when enabled, every launch
+/* HIP-event timing of the constraint kernel (k_constrain): when enabled, every launch
  * is bracketed by two events recorded on the launch stream.  read = synchronise,
  * sum the elapsed times since the last read, reset.  For bench.py's roofline. */
 int fmi_dev_enable_timing(fmi_t *h, int enable);

@@ -75,7 +75,8 @@ struct fmi {
     uint64_t dev_bytes = 0;
     // workspace for fmi_dev_* (sized by fmi_dev_reserve)
     uint64_t ws_rows = 0;
-    uint64_t ws_seq = 0;      // parity picks the queue-counter pair of the next fused constraint call
+    uint64_t ws_seq = 0;      // parity picks the workspace bitmap of the next constraint call
+    uint64_t ws_dirty[2] = {0, 0};   // words of each workspace bitmap that its last use may have left non-zero
     // incremental constraint state of fmi_dev_constrained_topk_step (per-row prefix ranges of the last call)
     uint64_t state_tag = 0, state_rows = 0, state_len = 0;
     int state_flip = 0;
@@ -83,7 +84,7 @@ struct fmi {
     uint64_t ws_bytes = 0;
     uint64_t *d_probe_counter = nullptr;
     int probe_count_enabled = 0;
-    // optional event timing of k_expand launches
+    // optional event timing of k_constrain launches
     int timing_enabled = 0;
     std::vector<void *> ev_start, ev_stop;   // hipEvent_t
     uint64_t ev_used = 0;

@@ -83,18 +83,34 @@ __global__ void k_get_range(FmiDev ix, uint64_t n_seq, const OffT *offsets, cons
 
 // ---------------------------------------------------------------------------
 // K2: interval -> distinct symbols (+counts)   (sdsl interval_symbols as used by
-// fm_index.cpp:78-109).  One wavefront per work item (a hex-wavelet-matrix node
-// [lo, hi) at some level with its symbol prefix).  The wave keeps its frontier
-// in LDS as one small array per relative level (a level-j array can never hold
-// more than min(16^j, 1024) nodes: it is only refilled, by at most 64 parents,
-// when it and every deeper level are empty), pops up to 64 nodes of the deepest
-// non-empty level, loads the one or two 128-byte blocks of each node in
-// parallel lanes (one when both ends of the interval share a block) and
-// compacts the up to sixteen surviving children per node with ballot + popcount.
+// fm_index.cpp:78-109).
+//
+// Work item = (row, top digit d1): ONE wavefront finds child d1 of the row's root
+// interval itself (a single-digit rank at both ends -- every wave of a row repeats
+// that probe, an L2/MALL hit for all but the first) and then expands the whole
+// sub-tree below it.  No queue, no second launch, no inter-wave traffic.  Items are
+// laid out d1-major: the waves resident at any moment work below the same few top
+// digits, i.e. inside the same slices of every deeper level of the wavelet matrix
+// (a level is sorted by the digits above it), which keeps the address-translation
+// working set a fraction of the 11.5 GB structure (profiles/r1_gather_calib.txt:
+// random 128-byte requests run 3.6x slower once they spread over more than ~3 GiB).
+//
+// Inside the wave the frontier lives in LDS, one array per relative level (a level-j
+// array never holds more than min(16^j, 1024) nodes: it is only refilled, by at most
+// 32 parents, when it and every deeper level are empty).  Each iteration pops up to
+// 32 nodes of the deepest non-empty level; a node is served by a PAIR of lanes, one
+// per interval end: each lane loads one 128-byte block and computes the sixteen
+// ranks of its end (32 + 16 live registers instead of 64 + 32 for both ends in one
+// lane: < 128 VGPRs, four waves per SIMD), the partner's ranks arrive by DPP
+// (quad_perm), and each lane of the pair compacts eight of the sixteen children with
+// ballot + mbcnt.  In mask mode the leaves of a sub-tree are one contiguous symbol
+// range owned by this wave alone: they are collected in an LDS bitmap (one byte store
+// per leaf-level half node) and flushed with plain coalesced stores -- no global
+// atomics except on the (at most two) words a wave shares with its neighbours.
 // ---------------------------------------------------------------------------
 struct ExpandItem {
     uint64_t lo, hi;
-    uint32_t row, level, prefix, pad;
+    uint32_t row, pad;
 };
 
 enum { EMIT_BITS = 0, EMIT_DENSE = 1 };
@@ -118,105 +134,28 @@ __device__ __forceinline__ void wave_sync()
 }
 
 static constexpr uint32_t PROBE_SLOTS = 256;         // counter slots (measurement mode only), one 64-byte line each
-static constexpr int EXP_WAVES = 4;                 // waves per workgroup
 static constexpr int EXP_LVL_CAP = 1024;
-static constexpr uint32_t EXP_SPLIT_LEVEL = 1;      // phase 1 hands the sub-trees over to phase 2 at this level (<= 16 per row)
-static constexpr unsigned EXP_P2_BLOCKS = 1024;     // phase-2 grid cap = 4 workgroups per CU; waves loop over the queue
+static constexpr uint32_t EXP_PAIRS = 32;            // nodes per wave iteration (one lane pair each)
 // relative level j occupies [lvl_off(j), lvl_off(j) + min(16^j, 1024))
 __host__ __device__ constexpr int lvl_cap(int j) { return j < 3 ? (1 << (4 * j)) : EXP_LVL_CAP; }
 __host__ __device__ constexpr int lvl_off(int j) { return j <= 3 ? ((1 << (4 * j)) - 1) / 15 : 273 + (j - 3) * EXP_LVL_CAP; }
 // LDS slots a wave needs to expand a sub-tree spanning `nlev` stored levels
 __host__ __device__ constexpr int exp_slots(int nlev) { return nlev <= 0 ? 1 : lvl_off(nlev - 1) + lvl_cap(nlev - 1); }
 
-template <int MODE>
-__device__ __forceinline__ void emit_leaf(const EmitTarget &t, uint32_t row, uint32_t sym, uint64_t count)
+// measurement mode (fmi_dev_enable_probe_count): distinct blocks loaded, nodes of the binary model of
+// SURVEY.md 8(d), wave iterations, nodes expanded
+struct ExpCounters { uint64_t probes; uint32_t model, iters, nodes; };
+
+// lane <-> lane^1
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v)
 {
-    if (MODE == EMIT_BITS) {
-        int64_t tok = (int64_t)sym - t.shift;
-        if (sym > 0 && tok >= 0 && (uint64_t)tok < t.vocab)
-            atomicOr(&t.bits[(uint64_t)row * t.words_per_row + ((uint64_t)tok >> 5)], 1u << (tok & 31));
-    } else {
-        t.dense[(uint64_t)row * t.dense_stride + sym] = count;
-    }
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
 }
 
-// The (up to) sixteen leaves below one last-level node are sixteen consecutive symbols, i.e. sixteen
-// consecutive bits of the row's token bitmap: one or two atomicOr per node instead of one per symbol
-// (the bitmap atomics, not the rank probes, were the largest cost of the leaf level before).
-__device__ __forceinline__ void emit_leaf_group_bits(const EmitTarget &t, uint32_t row, uint32_t prefix, uint32_t em)
+// frontier slot: positions < 2^40 (8 high bits each) + the node's symbol prefix (<= 16 bits)
+__device__ __forceinline__ uint4 pack_node(uint64_t lo, uint64_t hi, uint32_t prefix)
 {
-    uint32_t mask = em;
-    if (prefix == 0) mask &= ~1u;                       // symbol 0 is the sentinel, never a token
-    int64_t t0 = (int64_t)((uint64_t)prefix << FMI_DIGIT_BITS) - t.shift;   // token of child 0
-    if (t0 < 0) { mask = (-t0 >= 16) ? 0u : (mask >> (uint32_t)(-t0)); t0 = 0; }
-    const int64_t room = (int64_t)t.vocab - t0;         // tokens t0 .. vocab-1 exist
-    if (room <= 0) mask = 0; else if (room < 16) mask &= (1u << (uint32_t)room) - 1;
-    if (!mask) return;
-    const uint64_t big = (uint64_t)mask << ((uint32_t)t0 & 31);
-    uint32_t *w = &t.bits[(uint64_t)row * t.words_per_row + ((uint64_t)t0 >> 5)];
-    if ((uint32_t)big) atomicOr(w, (uint32_t)big);
-    if ((uint32_t)(big >> 32)) atomicOr(w + 1, (uint32_t)(big >> 32));
-}
-
-// The sixteen children of a node [lo, hi) on level k: child d is [kid_lo(d), kid_hi(d)) on level
-// k+1 = superblock row + in-superblock rank.  SB = false: single-superblock index (n < 2^32), the row
-// is dbase[k][] in scalar registers and only the 32-bit ranks live in VGPRs; SB = true: the rows of
-// the two ends come from the sbase table.
-template <bool SB> struct Kids;
-template <> struct Kids<false> { uint32_t rl[16], rh[16]; };
-template <> struct Kids<true> { uint32_t rl[16], rh[16]; uint64_t bl[16], bh[16]; };
-
-__device__ __forceinline__ uint64_t kid_lo(const FmiDev &ix, uint32_t k, const Kids<false> &c, uint32_t d) { return ix.dbase[k][d] + c.rl[d]; }
-__device__ __forceinline__ uint64_t kid_hi(const FmiDev &ix, uint32_t k, const Kids<false> &c, uint32_t d) { return ix.dbase[k][d] + c.rh[d]; }
-__device__ __forceinline__ uint64_t kid_lo(const FmiDev &, uint32_t, const Kids<true> &c, uint32_t d) { return c.bl[d] + c.rl[d]; }
-__device__ __forceinline__ uint64_t kid_hi(const FmiDev &, uint32_t, const Kids<true> &c, uint32_t d) { return c.bh[d] + c.rh[d]; }
-
-// returns the mask of children that exist
-template <bool SB>
-__device__ __forceinline__ uint32_t node_children(const FmiDev &ix, uint32_t k, uint64_t lo, uint64_t hi, Kids<SB> &c, uint64_t &probes)
-{
-    const uint64_t blo = lo >> FMI_BLOCK_SHIFT, bhi = hi >> FMI_BLOCK_SHIFT;
-    uint32_t em = 0;
-    {
-        HBlock a;
-        wm_load_block(ix, k, blo, a);
-        if (bhi != blo) {
-            HBlock b;
-            wm_load_block(ix, k, bhi, b);
-            wm_block_ranks(a, (uint32_t)lo & (FMI_BLOCK_BITS - 1), c.rl);
-            wm_block_ranks(b, (uint32_t)hi & (FMI_BLOCK_BITS - 1), c.rh);
-        } else {
-            wm_block_ranks(a, (uint32_t)lo & (FMI_BLOCK_BITS - 1), c.rl);
-            wm_block_ranks(a, (uint32_t)hi & (FMI_BLOCK_BITS - 1), c.rh);
-        }
-    }
-    if constexpr (SB) {
-        const uint64_t slo = blo >> ix.sb_shift, shi = bhi >> ix.sb_shift;
-        const uint64_t *rowl = ix.sbase + ((uint64_t)k * ix.nsb + slo) * FMI_ARITY;
-        const uint64_t *rowh = ix.sbase + ((uint64_t)k * ix.nsb + shi) * FMI_ARITY;
-#pragma unroll
-        for (uint32_t d = 0; d < 16; d += 2) {
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(rowl + d);
-            c.bl[d] = v.x; c.bl[d + 1] = v.y;
-        }
-        if (shi != slo) {
-#pragma unroll
-            for (uint32_t d = 0; d < 16; d += 2) {
-                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(rowh + d);
-                c.bh[d] = v.x; c.bh[d + 1] = v.y;
-            }
-        } else {
-#pragma unroll
-            for (uint32_t d = 0; d < 16; d++) c.bh[d] = c.bl[d];
-        }
-#pragma unroll
-        for (uint32_t d = 0; d < 16; d++) em |= (uint32_t)(c.bh[d] + c.rh[d] > c.bl[d] + c.rl[d]) << d;
-    } else {
-#pragma unroll
-        for (uint32_t d = 0; d < 16; d++) em |= (uint32_t)(c.rh[d] > c.rl[d]) << d;
-    }
-    probes += bhi != blo ? 2 : 1;
-    return em;
+    return make_uint4((uint32_t)lo, (uint32_t)hi, (uint32_t)(lo >> 32) | ((uint32_t)(hi >> 32) << 8) | (prefix << 16), 0u);
 }
 
 // the same node in the BINARY level-per-bit model of SURVEY.md 8(d): itself plus its non-empty halves,
@@ -228,168 +167,205 @@ __device__ __forceinline__ uint32_t model_nodes(uint32_t em, uint32_t k, uint32_
     return (skip < 1 ? 1u : 0u) + (skip < 2 ? (uint32_t)__popc(g8) : 0u) + (skip < 3 ? (uint32_t)__popc(g4) : 0u) + (uint32_t)__popc(g2);
 }
 
-// wave-wide compaction of the existing children, one digit at a time: the slot of child d of this
-// lane is (children of smaller digits in the wave) + (rank of the lane among the lanes having child d)
+// rank of the lane among the lanes of a ballot
 __device__ __forceinline__ uint32_t lane_rank_in(uint64_t bal)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
 }
 
-// append the children of this wave's nodes (level k, wave-uniform) to the phase-2 queue; all lanes call
-template <bool SB>
-__device__ __forceinline__ void hand_over(const FmiDev &ix, uint32_t k, uint32_t row, uint32_t prefix, uint32_t em,
-                                          const Kids<SB> &c, ExpandItem *out_items, uint32_t *out_count, uint32_t out_cap)
-{
-    uint32_t total = 0;
-#pragma unroll
-    for (uint32_t d = 0; d < 16; d++) total += (uint32_t)__popcll(__ballot((em >> d) & 1));
-    uint32_t obase = 0;
-    if ((threadIdx.x & 63) == 0 && total) obase = atomicAdd(out_count, total);
-    obase = __shfl(obase, 0);
-#pragma unroll
-    for (uint32_t d = 0; d < 16; d++) {
-        const uint64_t bal = __ballot((em >> d) & 1);
-        if ((em >> d) & 1) {
-            const uint32_t o = obase + lane_rank_in(bal);
-            if (o < out_cap) out_items[o] = ExpandItem{kid_lo(ix, k, c, d), kid_hi(ix, k, c, d), row, k + 1, (prefix << 4) | d, 0};
-        }
-        obase += (uint32_t)__popcll(bal);
-    }
-}
-
-__device__ __forceinline__ void flush_counters(uint64_t *probe_counter, uint64_t probes, uint32_t model, uint32_t iters, uint32_t nodes)
+__device__ __forceinline__ void flush_counters(uint64_t *probe_counter, const ExpCounters &c)
 {
     // one 64-byte line per slot: thousands of waves adding to ONE address cost tens of microseconds
     unsigned long long *slot = (unsigned long long *)probe_counter + (size_t)(blockIdx.x & (PROBE_SLOTS - 1)) * 8;
-    if (probes) atomicAdd(slot, (unsigned long long)probes);
-    if (model) atomicAdd(slot + 3, (unsigned long long)model);
-    if ((threadIdx.x & 63) == 0 && iters) {
-        atomicAdd(slot + 1, (unsigned long long)iters);
-        atomicAdd(slot + 2, (unsigned long long)nodes);
+    if (c.probes) atomicAdd(slot, (unsigned long long)c.probes);
+    if (c.model) atomicAdd(slot + 3, (unsigned long long)c.model);
+    if ((threadIdx.x & 63) == 0 && c.iters) {
+        atomicAdd(slot + 1, (unsigned long long)c.iters);
+        atomicAdd(slot + 2, (unsigned long long)c.nodes);
     }
 }
 
-// Work items are hex-wavelet-matrix nodes.  Nodes whose children would sit on
-// `stop_level` are not expanded further but appended to `out_items` (phase 1 ->
-// phase 2 hand-over, so that a wide interval is spread over up to 16^stop_level
-// wavefronts instead of one); stop_level >= dlevels disables the hand-over.
-// Dynamic LDS per wave: 3 x slots words (lo32, hi32, packed high bits + prefix)
-// + FMI_MAX_DLEVELS counters.
-template <int MODE, bool SB>
-__device__ __forceinline__ void expand_body(const FmiDev &ix, const ExpandItem *items, const uint32_t *n_items_ptr,
-                                            uint32_t n_items_static, const EmitTarget &tgt, uint32_t slots,
-                                            uint32_t stop_level, ExpandItem *out_items, uint32_t *out_count,
-                                            uint32_t out_cap, uint64_t *probe_counter)
+// the sixteen existing-children flags of the ROOT node of a row (measurement mode only: the binary
+// model needs the whole mask, the expansion itself only ever asks for one digit per wave); a rolled
+// loop of single-digit ranks over the same one or two blocks, so that it costs no registers
+__device__ __forceinline__ uint32_t root_children_mask(const FmiDev &ix, uint64_t lo, uint64_t hi)
 {
-    extern __shared__ uint32_t s_mem[];
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wv = threadIdx.x >> 6;
-    uint32_t *s_lo = s_mem + (size_t)wv * (3 * slots + FMI_MAX_DLEVELS);
-    uint32_t *s_hi = s_lo + slots;
-    uint32_t *s_mx = s_hi + slots;     // lo[39:32] | hi[39:32]<<8 | prefix<<16 (prefix <= 16 bits)
-    uint32_t *s_cnt = s_mx + slots;
-    const uint32_t n_items = n_items_ptr ? min(*n_items_ptr, n_items_static) : n_items_static;
+    uint32_t em = 0;
+#pragma unroll 1
+    for (uint32_t d = 0; d < 16; d++) em |= (uint32_t)(wm_step(ix, 0, hi, d) > wm_step(ix, 0, lo, d)) << d;
+    return em;
+}
+
+// Expansion of the sub-tree below ONE node (level `root` >= 1 ... D-1, interval [rlo, rhi), symbol
+// prefix rprefix) by one wavefront.  s_node: exp_slots(D - root) frontier slots; s_cnt: one counter per
+// relative level; EMIT_BITS: s_bits8 = the wave's leaf bitmap (16^(D-root) bits, zeroed by the caller):
+// bit i = symbol (rprefix << 4 (D-root)) + i.  `counting` (wave-uniform) switches the measurement
+// bookkeeping on.
+template <int MODE, bool SB>
+__device__ __forceinline__ void expand_subtree(const FmiDev &ix, uint4 *s_node, uint32_t *s_cnt, uint8_t *s_bits8,
+                                               const uint32_t row, const uint32_t root, const uint64_t rlo, const uint64_t rhi,
+                                               const uint32_t rprefix, const EmitTarget &tgt, const bool counting, ExpCounters &ctr)
+{
+    const uint32_t lane = threadIdx.x & 63, end = lane & 1, pair = lane >> 1;
     const uint32_t D = ix.dlevels;
     const uint32_t pad_bits = FMI_DIGIT_BITS * D - ix.levels;   // phantom high bits of the top digit (0..3)
-    uint64_t probes = 0;
-    uint32_t iters = 0, nodes = 0, model = 0;
-
-    for (uint32_t item = blockIdx.x * EXP_WAVES + wv; item < n_items; item += gridDim.x * EXP_WAVES) {
-        const ExpandItem it = items[item];
-        if (it.hi <= it.lo) continue;
-        const uint32_t row = it.row;
-        // wave-uniform by construction; say so, or every dbase[k][d] becomes a per-lane global load
-        // in the middle of the fan-out instead of a scalar load
-        const uint32_t root = __builtin_amdgcn_readfirstlane(it.level);
-        // a root sitting below the last level is already a leaf
-        if (root >= D) { if (lane == 0) emit_leaf<MODE>(tgt, row, it.prefix, it.hi - it.lo); continue; }
-        if (lane < FMI_MAX_DLEVELS) s_cnt[lane] = 0;
-        if (lane == 0) {
-            s_lo[0] = (uint32_t)it.lo; s_hi[0] = (uint32_t)it.hi;
-            // positions < 2^40: 8 high bits each
-            s_mx[0] = (uint32_t)(it.lo >> 32) | ((uint32_t)(it.hi >> 32) << 8) | (it.prefix << 16);
-            s_cnt[0] = 1;
-        }
+    const uint32_t rel_mask = (1u << (FMI_DIGIT_BITS * (D - 1 - root))) - 1;   // prefix bits of a leaf-level node below the root
+    if (lane < FMI_MAX_DLEVELS) s_cnt[lane] = lane == 0 ? 1u : 0u;
+    if (lane == 0) s_node[0] = pack_node(rlo, rhi, rprefix);
+    wave_sync();
+    int deepest = 0;   // relative level of the deepest non-empty array (wave uniform)
+    while (deepest >= 0) {
+        // LDS hands the counter back in a VGPR; it is the same in every lane, and the whole loop
+        // (level, offsets, the per-level dbase[] loads) stays scalar only if the compiler knows
+        const uint32_t cnt = __builtin_amdgcn_readfirstlane(s_cnt[deepest]);
+        if (cnt == 0) { deepest--; continue; }
+        const uint32_t m = cnt < EXP_PAIRS ? cnt : EXP_PAIRS;
+        const uint32_t base = lvl_off(deepest) + (cnt - m);
+        const uint32_t k = root + deepest;      // absolute level of the popped nodes
+        const bool act = pair < m;
+        uint4 nd = make_uint4(0u, 0u, 0u, 0u);
+        if (act) nd = s_node[base + pair];      // both lanes of the pair read the same slot (LDS broadcast)
         wave_sync();
-        int deepest = 0;   // relative level of the deepest non-empty array (wave uniform)
-        while (deepest >= 0) {
-            // LDS hands the counter back in a VGPR; it is the same in every lane, and the whole loop
-            // (level, offsets, the per-level dbase[] loads) stays scalar only if the compiler knows
-            const uint32_t cnt = __builtin_amdgcn_readfirstlane(s_cnt[deepest]);
-            if (cnt == 0) { deepest--; continue; }
-            const uint32_t m = cnt < 64 ? cnt : 64;
-            const uint32_t base = lvl_off(deepest) + (cnt - m);
-            const uint32_t k = root + deepest;      // absolute level of the popped nodes
-            const bool act = lane < m;
-            uint64_t lo = 0, hi = 0; uint32_t prefix = 0;
-            if (act) {
-                const uint32_t mx = s_mx[base + lane];
-                lo = (uint64_t)s_lo[base + lane] | ((uint64_t)(mx & 0xff) << 32);
-                hi = (uint64_t)s_hi[base + lane] | ((uint64_t)((mx >> 8) & 0xff) << 32);
-                prefix = mx >> 16;
-            }
-            wave_sync();
-            if (lane == 0) s_cnt[deepest] = cnt - m;
-            Kids<SB> kids;
-            uint32_t em = 0;                        // children that exist
-            if (act) {
-                em = node_children<SB>(ix, k, lo, hi, kids, probes);
-                model += model_nodes(em, k, pad_bits);
-            }
-            iters++; nodes += m;
-            if (k + 1 == D) {
-                if (MODE == EMIT_BITS) {
-                    if (em) emit_leaf_group_bits(tgt, row, prefix, em);
-                } else {
+        if (lane == 0) s_cnt[deepest] = cnt - m;
+        const uint64_t lo = (uint64_t)nd.x | ((uint64_t)(nd.z & 0xff) << 32);
+        const uint64_t hi = (uint64_t)nd.y | ((uint64_t)((nd.z >> 8) & 0xff) << 32);
+        const uint32_t prefix = nd.z >> 16;
+        const uint64_t p = end ? hi : lo;                              // my end of the interval
+        const uint64_t blk = p >> FMI_BLOCK_SHIFT, oblk = (end ? lo : hi) >> FMI_BLOCK_SHIFT;
+        uint32_t r[16];
 #pragma unroll
-                    for (uint32_t d = 0; d < 16; d++)
-                        if ((em >> d) & 1) emit_leaf<MODE>(tgt, row, (prefix << 4) | d, kid_hi(ix, k, kids, d) - kid_lo(ix, k, kids, d));
-                }
-            } else if (k + 1 == stop_level) {
-                hand_over<SB>(ix, k, row, prefix, em, kids, out_items, out_count, out_cap);
+        for (uint32_t d = 0; d < 16; d++) r[d] = 0;
+        if (act) {
+            HBlock b;
+            wm_load_block(ix, k, blk, b);        // when both ends share a block the pair asks for the same line once
+            wm_block_ranks(b, (uint32_t)p & (FMI_BLOCK_BITS - 1), r);
+        }
+        // superblocked index: the rows of the two ends
+        const uint64_t *rowl = nullptr, *rowh = nullptr;
+        if constexpr (SB) {
+            const uint64_t mine = ((uint64_t)k * ix.nsb + (blk >> ix.sb_shift)) * FMI_ARITY;
+            const uint64_t other = ((uint64_t)k * ix.nsb + (oblk >> ix.sb_shift)) * FMI_ARITY;
+            rowl = ix.sbase + (end ? other : mine);
+            rowh = ix.sbase + (end ? mine : other);
+        }
+        const bool leaf = (k + 1 == D);
+        uint32_t hm = 0;                         // which of MY eight children (digits s + 8 * end) exist
+        uint32_t added = 0;
+        const uint32_t dst = leaf ? 0u : lvl_off(deepest + 1) + __builtin_amdgcn_readfirstlane(s_cnt[deepest + 1]);
+#pragma unroll
+        for (uint32_t s = 0; s < 8; s++) {
+            // lane `end` = 0 holds rank_lo[] and takes digit s, lane 1 holds rank_hi[] and takes digit s + 8
+            const uint32_t x = dpp_xor1(r[s]), y = dpp_xor1(r[s + 8]);
+            const uint32_t cl = end ? y : r[s], ch = end ? r[s + 8] : x;
+            const uint32_t dm = s + 8 * end;
+            uint64_t clo, chi;
+            if constexpr (SB) {
+                clo = (act ? rowl[dm] : 0) + cl; chi = (act ? rowh[dm] : 0) + ch;
             } else {
-                uint32_t dst = lvl_off(deepest + 1) + __builtin_amdgcn_readfirstlane(s_cnt[deepest + 1]), added = 0;
-#pragma unroll
-                for (uint32_t d = 0; d < 16; d++) {
-                    const uint64_t bal = __ballot((em >> d) & 1);
-                    if ((em >> d) & 1) {
-                        const uint32_t o = dst + added + lane_rank_in(bal);
-                        const uint64_t clo = kid_lo(ix, k, kids, d), chi = kid_hi(ix, k, kids, d);
-                        s_lo[o] = (uint32_t)clo; s_hi[o] = (uint32_t)chi;
-                        s_mx[o] = (uint32_t)(clo >> 32) | ((uint32_t)(chi >> 32) << 8) | (((prefix << 4) | d) << 16);
-                    }
-                    added += (uint32_t)__popcll(bal);
-                }
-                wave_sync();
-                if (lane == 0) s_cnt[deepest + 1] += added;
-                wave_sync();
-                if (added) deepest++;
+                const uint64_t bs = end ? ix.dbase[k][s + 8] : ix.dbase[k][s];
+                clo = bs + cl; chi = bs + ch;
+            }
+            const bool ex = act && chi > clo;
+            hm |= (uint32_t)ex << s;
+            if (leaf) {
+                if (MODE == EMIT_DENSE && ex) tgt.dense[(uint64_t)row * tgt.dense_stride + ((prefix << 4) | dm)] = chi - clo;
+            } else {
+                const uint64_t bal = __ballot(ex);
+                if (ex) s_node[dst + added + lane_rank_in(bal)] = pack_node(clo, chi, (prefix << 4) | dm);
+                added += (uint32_t)__popcll(bal);
             }
         }
-        wave_sync();
+        if (counting) {
+            const uint32_t other_hm = dpp_xor1(hm);
+            if (act && end == 0) {
+                ctr.model += model_nodes(hm | (other_hm << 8), k, pad_bits);
+                ctr.probes += oblk != blk ? 2 : 1;
+            }
+            ctr.iters++; ctr.nodes += m;
+        }
+        if (leaf) {
+            if (MODE == EMIT_BITS) {
+                if (prefix == 0 && end == 0) hm &= ~1u;      // symbol 0 is the sentinel, never a token
+                if (hm) s_bits8[((prefix & rel_mask) << 1) + end] = (uint8_t)hm;
+            }
+        } else {
+            wave_sync();
+            if (lane == 0) s_cnt[deepest + 1] += added;
+            wave_sync();
+            if (added) deepest++;
+        }
     }
-    if (probe_counter) flush_counters(probe_counter, probes, model, iters, nodes);
+    wave_sync();
 }
 
-// Single-superblock indexes (n < 2^32, the NQ case).  226 VGPRs = two waves per SIMD; forcing three
-// (amdgpu_waves_per_eu(3,3), 168 VGPRs + 84 B of scratch) measured slower: 120 vs 97 us per wide call.
-template <int MODE>
-__global__ __launch_bounds__(EXP_WAVES * 64)
-void k_expand(FmiDev ix, const ExpandItem *items, const uint32_t *n_items_ptr, uint32_t n_items_static, EmitTarget tgt, uint32_t slots,
-              uint32_t stop_level, ExpandItem *out_items, uint32_t *out_count, uint32_t out_cap, uint64_t *probe_counter)
+// 32 bits [o, o + 32) of an LDS bit array of nw words, zeros outside it
+__device__ __forceinline__ uint32_t lds_bits32(const uint32_t *s_w, int32_t nw, int64_t o)
 {
-    expand_body<MODE, false>(ix, items, n_items_ptr, n_items_static, tgt, slots, stop_level, out_items, out_count, out_cap, probe_counter);
+    const int64_t i = o >> 5;                    // arithmetic shift: floor
+    const uint32_t sh = (uint32_t)o & 31;
+    const uint32_t w0 = (i >= 0 && i < nw) ? s_w[i] : 0u;
+    const uint32_t w1 = (i + 1 >= 0 && i + 1 < nw) ? s_w[i + 1] : 0u;
+    return sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
 }
 
-// Superblocked indexes (n >= 2^32): the two superblock rows add 64 VGPRs
-template <int MODE>
-__global__ __launch_bounds__(EXP_WAVES * 64)
-void k_expand_sb(FmiDev ix, const ExpandItem *items, const uint32_t *n_items_ptr, uint32_t n_items_static, EmitTarget tgt, uint32_t slots,
-                 uint32_t stop_level, ExpandItem *out_items, uint32_t *out_count, uint32_t out_cap, uint64_t *probe_counter)
+// The wave's leaf bitmap (symbols [sym0, sym0 + nsym)) -> the row's token bitmap (token = symbol - shift,
+// clipped to [0, vocab)).  Words that lie entirely inside the wave's own token range are written with plain
+// stores (the bitmap was zero and nobody else owns a bit of them), the at most two shared words with atomicOr.
+__device__ __forceinline__ void flush_leaf_bits(const EmitTarget &t, uint32_t row, const uint32_t *s_w, uint32_t sym0, uint32_t nsym)
 {
-    expand_body<MODE, true>(ix, items, n_items_ptr, n_items_static, tgt, slots, stop_level, out_items, out_count, out_cap, probe_counter);
+    const uint32_t lane = threadIdx.x & 63;
+    const int64_t tlo = (int64_t)sym0 - t.shift;
+    int64_t a = tlo, b = tlo + (int64_t)nsym;
+    if (a < 0) a = 0;
+    if (b > (int64_t)t.vocab) b = (int64_t)t.vocab;
+    if (a >= b) return;
+    const int32_t nw = (int32_t)((nsym + 31) >> 5);
+    uint32_t *rowp = t.bits + (uint64_t)row * t.words_per_row;
+    const int64_t W1 = (b - 1) >> 5;
+    for (int64_t W = (a >> 5) + lane; W <= W1; W += 64) {
+        uint32_t v = lds_bits32(s_w, nw, 32 * W - tlo);
+        uint32_t keep = ~0u;
+        if (32 * W < a) keep &= ~0u << (uint32_t)(a - 32 * W);
+        if (32 * W + 32 > b) keep &= (1u << (uint32_t)(b - 32 * W)) - 1;
+        v &= keep;
+        if (!v) continue;
+        if (keep == ~0u) rowp[W] = v; else atomicOr(&rowp[W], v);
+    }
 }
 
+// child `d` of the root interval [lo, hi) (level 0): two single-digit ranks, loads issued back to back
+__device__ __forceinline__ void root_child(const FmiDev &ix, uint64_t lo, uint64_t hi, uint32_t d, uint64_t &clo, uint64_t &chi)
+{
+    const uint64_t a = wm_step(ix, 0, lo, d), b = wm_step(ix, 0, hi, d);
+    clo = a; chi = b;
+}
+
+// API mode (distinct / distinct_count / distinct_count_multi): dense per-row counts.  One wave per
+// (interval, top digit), d1-major; dynamic LDS = exp_slots(D - 1) frontier slots + counters.
+template <bool SB>
+__global__ __launch_bounds__(64) void k_expand_dense(FmiDev ix, const ExpandItem *items, uint32_t rows, EmitTarget tgt, uint64_t *probe_counter)
+{
+    extern __shared__ uint4 s_dyn[];
+    const uint32_t D = ix.dlevels;
+    uint4 *s_node = s_dyn;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_node + exp_slots((int)D - 1));
+    const uint32_t d1 = blockIdx.x / rows, i = blockIdx.x - d1 * rows;
+    const ExpandItem it = items[i];
+    if (it.hi <= it.lo) return;
+    const bool counting = probe_counter != nullptr;
+    ExpCounters ctr{0, 0, 0, 0};
+    uint64_t clo, chi;
+    root_child(ix, it.lo, it.hi, d1, clo, chi);
+    if (counting && d1 == 0 && (threadIdx.x & 63) == 0) {
+        ctr.probes += (it.lo >> FMI_BLOCK_SHIFT) != (it.hi >> FMI_BLOCK_SHIFT) ? 2 : 1;
+        ctr.model += model_nodes(root_children_mask(ix, it.lo, it.hi), 0, FMI_DIGIT_BITS * D - ix.levels);
+    }
+    if (chi > clo) {
+        if (D == 1) { if ((threadIdx.x & 63) == 0) tgt.dense[(uint64_t)it.row * tgt.dense_stride + d1] = chi - clo; }
+        else expand_subtree<EMIT_DENSE, SB>(ix, s_node, s_cnt, nullptr, it.row, 1, clo, chi, d1, tgt, counting, ctr);
+    }
+    if (counting) flush_counters(probe_counter, ctr);
+}
 // dense per-row symbol counts -> CSR, ascending symbols.  One workgroup per row.
 __global__ __launch_bounds__(256) void k_dense_count(const uint64_t *dense, uint64_t stride, uint64_t nsym, uint64_t *row_k)
 {
@@ -434,80 +410,143 @@ __global__ __launch_bounds__(256) void k_dense_compact(const uint64_t *dense, ui
 
 // ---------------------------------------------------------------------------
 // a9: IndexBasedLogitsProcessor.__call__, cur_len >= 2 (seal/beam_search.py:79-140)
+// as ONE launch.  One wave per (row, top digit d1), d1-major (see K2).  Every wave of
+// a row repeats the row's own few dependent probes -- range of the prefix (one
+// backward-search step from the parent's kept range, or the full search), class of
+// the row (lines 87-105 and the branch order of 111-131), child d1 of the root node --
+// with wave-uniform addresses (one request each, L2/MALL hits for all but the first
+// wave), then expands its sub-tree into its LDS bitmap and stores it.  Only the d1 = 0
+// wave writes the row's side effects (kept range, measurement counters).
 // ---------------------------------------------------------------------------
 static constexpr int MAX_FORCE = 8;
 struct ForceFrom { int64_t tok[MAX_FORCE]; uint32_t n; };
 
-// one thread per (batch, beam) row: ranges of the prefix, the row's class, and
-// the work item for the expansion.  Lines 87-105 and the branch order of 111-131.
-// With a queue (`out_items`) the same lane also expands the root node of its row
-// (level 0) and hands the level-1 children straight to phase 2: the narrow steps of
-// a decode are launch-latency bound, and this saves them a kernel.  `zero_next`
-// (two words) is cleared for the NEXT call, whose counters alternate with this one's.
-template <bool SB>
-__global__ __launch_bounds__(64) void k_prefix_ranges(FmiDev ix, uint64_t rows, uint64_t cur_len, const int64_t *ids, int64_t shift,
-                                int64_t pad_id, int64_t eos_id, ForceFrom ff, int64_t stop_at_count,
-                                int always_allow_eos, uint64_t vocab, uint64_t words_per_row,
-                                uint32_t *bits, ExpandItem *items, ExpandItem *out_items, uint32_t *out_count,
-                                uint32_t out_cap, uint32_t *zero_next, uint64_t *probe_counter,
-                                const uint64_t *st_in, const int64_t *parent, uint64_t *st_out)
+struct ConstrainArgs {
+    uint32_t rows, ndig0;          // grid = rows * ndig0 waves
+    uint64_t cur_len;
+    const int64_t *ids;            // [rows, cur_len]
+    int64_t shift, pad_id, eos_id;
+    ForceFrom ff;
+    int64_t stop_at_count;
+    int always_allow_eos;
+    uint64_t vocab, words_per_row;
+    uint32_t *bits;                // [rows][words_per_row], zero on entry
+    uint32_t *clear;               // words [0, clear_words) of the OTHER bitmap buffer are zeroed for the next call
+    uint64_t clear_words;
+    const uint64_t *st_in;         // incremental prefix state of the previous step, or null
+    const int64_t *parent;
+    uint64_t *st_out;
+    uint64_t *probe_counter;
+};
+
+// a special token (pad / eos) of the row: into the LDS bitmap of the wave that owns its symbol; tokens
+// whose symbol lies above every wave's range are set by the d1 = 0 wave directly
+__device__ __forceinline__ void set_special(const FmiDev &ix, const ConstrainArgs &a, uint32_t *s_bits, uint32_t row, uint32_t d1,
+                                            uint32_t sub_bits, int64_t tok)
 {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = r < rows;
-    if (zero_next && r == 0) { zero_next[0] = 0; zero_next[1] = 0; }
-    ExpandItem it{0, 0, (uint32_t)r, 0, 0, 0};
-    uint64_t probes = 0;
-    uint32_t model = 0;      // in nodes of the binary model: one backward-search step = `levels` nodes (2 L probes)
-    if (valid) {
-        const int64_t *sent = ids + r * cur_len;
-        const int64_t last = sent[cur_len - 1];
-        uint64_t lo = 0, hi = 0, count = 0;
-        if (!(last == eos_id || last == pad_id)) {
-            // get_range(force_decoding_from + sent[1:]) and get_count(... sent[1:-1])
-            uint64_t l = 0, rr = ix.n;
-            if (st_in) {
-                // incremental: the row extends row parent[r] of the previous step, whose inclusive range
-                // [l, rr] after the same prefix was kept -- one backward-search step instead of len
-                const uint64_t pr = (uint64_t)parent[r];
-                l = st_in[2 * pr]; rr = st_in[2 * pr + 1];
-                count = (rr + 1) - l;
-                bs_step(ix, (uint64_t)(last + shift), l, rr, l, rr, &probes);
-                model += ix.levels * (uint32_t)(ff.n + (cur_len - 1));    // the reference re-searches the whole prefix
-            } else {
-                const uint64_t total = ff.n + (cur_len - 1);
-                for (uint64_t t = 0; t < total; t++) {
-                    if (t + 1 == total) count = (rr + 1) - l;
-                    const int64_t tok = t < ff.n ? ff.tok[t] : sent[1 + (t - ff.n)];
-                    bs_step(ix, (uint64_t)(tok + shift), l, rr, l, rr, &probes);
-                    model += ix.levels;
-                }
-                if (total == 0) count = (rr + 1) - l;
-            }
-            if (st_out) { st_out[2 * r] = l; st_out[2 * r + 1] = rr; }
-            lo = l; hi = rr + 1;
+    if (tok < 0 || (uint64_t)tok >= a.vocab) return;
+    const int64_t sym = tok + a.shift;
+    const bool owned = sym >= 0 && (uint64_t)(sym >> sub_bits) < a.ndig0;
+    if (owned) {
+        if ((uint32_t)(sym >> sub_bits) == d1) {
+            const uint32_t o = (uint32_t)sym & ((1u << sub_bits) - 1);
+            s_bits[o >> 5] |= 1u << (o & 31);
         }
-        uint32_t *myrow = bits + r * words_per_row;
-        int64_t single = -1;
-        if (stop_at_count > 0 && (int64_t)count <= stop_at_count) single = eos_id;
-        else if (last == eos_id || last == pad_id) single = pad_id;
-        else { it.lo = lo; it.hi = hi > ix.n ? ix.n : hi; }
-        if (!out_items) items[r] = it;
-        if (single >= 0 && (uint64_t)single < vocab) atomicOr(&myrow[single >> 5], 1u << (single & 31));
-        if (always_allow_eos && eos_id >= 0 && (uint64_t)eos_id < vocab) atomicOr(&myrow[eos_id >> 5], 1u << (eos_id & 31));
+    } else if (d1 == 0) {
+        atomicOr(&a.bits[(uint64_t)row * a.words_per_row + ((uint64_t)tok >> 5)], 1u << (tok & 31));
     }
-    if (!out_items) return;
-    // root expansion, the level-0 step of k_expand
-    Kids<SB> kids;
-    uint32_t em = 0;
-    const bool act = valid && it.hi > it.lo;
-    if (act) {
-        em = node_children<SB>(ix, 0, it.lo, it.hi, kids, probes);
-        model += model_nodes(em, 0, FMI_DIGIT_BITS * ix.dlevels - ix.levels);
-    }
-    hand_over<SB>(ix, 0, (uint32_t)r, 0, em, kids, out_items, out_count, out_cap);
-    if (probe_counter) flush_counters(probe_counter, probes, model, __ballot(act) ? 1u : 0u, (uint32_t)__popcll(__ballot(act)));
 }
 
+template <bool SB>
+__global__ __launch_bounds__(64) void k_constrain(FmiDev ix, ConstrainArgs a)
+{
+    extern __shared__ uint4 s_dyn[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t D = ix.dlevels;
+    const uint32_t sub_bits = FMI_DIGIT_BITS * (D - 1);        // symbol bits below the top digit
+    const uint32_t nsym = 1u << sub_bits;                       // symbols of one wave's sub-tree
+    const uint32_t nw = (nsym + 31) >> 5;
+    uint4 *s_node = s_dyn;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_node + exp_slots((int)D - 1));
+    uint32_t *s_bits = s_cnt + 8;
+    const uint32_t d1 = blockIdx.x / a.rows, r = blockIdx.x - d1 * a.rows;
+    const bool writer = d1 == 0;
+    const bool counting = a.probe_counter != nullptr;
+    ExpCounters ctr{0, 0, 0, 0};
+
+    // housekeeping for the next call: this wave's share of the other bitmap buffer
+    if (a.clear) {
+        const uint64_t per = (a.clear_words + gridDim.x - 1) / gridDim.x;
+        const uint64_t w0 = (uint64_t)blockIdx.x * per;
+        for (uint64_t w = w0 + lane; w < w0 + per && w < a.clear_words; w += 64) a.clear[w] = 0u;
+    }
+    for (uint32_t w = lane; w < nw; w += 64) s_bits[w] = 0u;
+
+    // ---- the row: prefix range, class (identical in every wave of the row) ----
+    const int64_t *sent = a.ids + (uint64_t)r * a.cur_len;
+    const int64_t last = sent[a.cur_len - 1];
+    const bool dead = last == a.eos_id || last == a.pad_id;
+    uint64_t lo = 0, hi = 0, count = 0, probes = 0;
+    uint32_t model = 0;      // in nodes of the binary model: one backward-search step = `levels` nodes (2 L probes)
+    if (!dead) {
+        // get_range(force_decoding_from + sent[1:]) and get_count(... sent[1:-1])
+        uint64_t l = 0, rr = ix.n;
+        if (a.st_in) {
+            // incremental: the row extends row parent[r] of the previous step, whose inclusive range
+            // [l, rr] after the same prefix was kept -- one backward-search step instead of len
+            const uint64_t pr = (uint64_t)a.parent[r];
+            l = a.st_in[2 * pr]; rr = a.st_in[2 * pr + 1];
+            count = (rr + 1) - l;
+            bs_step(ix, (uint64_t)(last + a.shift), l, rr, l, rr, &probes);
+            model += ix.levels * (uint32_t)(a.ff.n + (a.cur_len - 1));    // the reference re-searches the whole prefix
+        } else {
+            const uint64_t total = a.ff.n + (a.cur_len - 1);
+            for (uint64_t t = 0; t < total; t++) {
+                if (t + 1 == total) count = (rr + 1) - l;
+                const int64_t tok = t < a.ff.n ? a.ff.tok[t] : sent[1 + (t - a.ff.n)];
+                bs_step(ix, (uint64_t)(tok + a.shift), l, rr, l, rr, &probes);
+                model += ix.levels;
+            }
+            if (total == 0) count = (rr + 1) - l;
+        }
+        if (writer && lane == 0 && a.st_out) { a.st_out[2 * r] = l; a.st_out[2 * r + 1] = rr; }
+        lo = l; hi = rr + 1;
+    }
+    int64_t single = -1;
+    bool expand = false;
+    if (a.stop_at_count > 0 && (int64_t)count <= a.stop_at_count) single = a.eos_id;
+    else if (dead) single = a.pad_id;
+    else { expand = true; if (hi > ix.n) hi = ix.n; }
+    wave_sync();            // bitmap zeroed
+    // ---- child d1 of the row's root node, then its sub-tree ----
+    if (expand && hi > lo) {
+        uint64_t clo, chi;
+        root_child(ix, lo, hi, d1, clo, chi);
+        if (counting && writer && lane == 0) {
+            probes += (lo >> FMI_BLOCK_SHIFT) != (hi >> FMI_BLOCK_SHIFT) ? 2 : 1;
+            model += model_nodes(root_children_mask(ix, lo, hi), 0, FMI_DIGIT_BITS * D - ix.levels);
+        }
+        if (chi > clo) {
+            if (D == 1) { if (lane == 0 && d1 != 0) s_bits[0] |= 1u; }
+            else expand_subtree<EMIT_BITS, SB>(ix, s_node, s_cnt, reinterpret_cast<uint8_t *>(s_bits), r, 1, clo, chi, d1,
+                                               EmitTarget{}, counting, ctr);
+        }
+    }
+    wave_sync();
+    // pad / eos of the row's class: after the expansion, whose byte stores would overwrite them
+    if (lane == 0) {
+        if (single >= 0) set_special(ix, a, s_bits, r, d1, sub_bits, single);
+        if (a.always_allow_eos) set_special(ix, a, s_bits, r, d1, sub_bits, a.eos_id);
+    }
+    wave_sync();
+    EmitTarget tgt{};
+    tgt.bits = a.bits; tgt.words_per_row = a.words_per_row; tgt.shift = a.shift; tgt.vocab = a.vocab;
+    flush_leaf_bits(tgt, r, s_bits, d1 << sub_bits, nsym);
+    if (counting) {
+        if (writer && lane == 0) { ctr.probes += probes; ctr.model += model; }
+        flush_counters(a.probe_counter, ctr);
+    }
+}
 // out = allowed ? in : -inf     (scores + mask with mask in {0, -inf}, beam_search.py:64,140)
 __global__ __launch_bounds__(256) void k_apply_bits(const float *in, float *out, const uint32_t *bits, uint64_t rows,
                                                     uint64_t vocab, uint64_t words_per_row)
@@ -718,6 +757,198 @@ __global__ __launch_bounds__(ROW_BLOCK) void k_row_topk(const float *logits, con
     if (tid == 0) row_cnt[row] = k_sel;
 }
 
+// k_row_lse + k_row_topk in ONE pass over the logits (the decode step's path when the vocabulary fits
+// ITEMS x 1024 tokens): every thread keeps its ITEMS logits in registers (token = tid + 1024 j, coalesced
+// dword loads), so the row is read from memory exactly once; max / log-sum-exp are reduced in the same
+// order as k_row_lse (bit-identical row_max / row_lsum), the row's bitmap is staged in LDS, and the
+// selection works on register data: rows with few allowed tokens are ranked directly in LDS; wider rows
+// take one 12-bit histogram round over the keys of their allowed tokens (LDS atomics) that pins the bin
+// of the want-th largest key -- the keys above it plus the bin's own are then ranked in LDS, which is the
+// end of it unless more than SEL_CAP keys share that bin; only then the remaining 12 + 8 key bits are
+// resolved by further rounds, and an exact tie larger than SEL_CAP by token order.  Same output as
+// k_row_topk: value descending, ties to the lower token id.
+static constexpr int SEL_CAP = 1024;
+static constexpr int SEL_BINS = 4096;
+
+template <int ITEMS>
+__global__ __launch_bounds__(ROW_BLOCK) void k_row_select(const float *logits, const uint32_t *bits, uint64_t words_per_row,
+                                                          uint32_t row_broadcast_bits, uint64_t vocab, uint32_t want,
+                                                          float *row_max, float *row_lsum, int32_t *row_tok, float *row_lp,
+                                                          uint32_t *row_cnt, uint32_t narrow_max)
+{
+    __shared__ uint32_t s_bm[ITEMS * 32];
+    __shared__ uint32_t s_hist[SEL_BINS];
+    __shared__ int32_t s_ctok[SEL_CAP];
+    __shared__ float s_cval[SEL_CAP];
+    __shared__ float s_a[ROW_BLOCK / 64], s_b[ROW_BLOCK / 64];
+    __shared__ uint32_t s_wave[ROW_BLOCK / 64];
+    __shared__ float s_ls;
+    __shared__ uint32_t s_n, s_total, s_bin, s_above, s_inbin;
+    const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float *xrow = logits + (uint64_t)row * vocab;
+    const float ninf = -__builtin_huge_valf();
+    const uint32_t nvocab = (uint32_t)vocab;
+    // ---- the row, once: max and log(sum(exp(x - max))), reduced as k_row_lse does ----
+    float x[ITEMS];
+    float mx = ninf;
+    bool nan = false;
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+        const uint32_t tok = tid + (uint32_t)j * ROW_BLOCK;
+        const float v = xrow[tok < nvocab ? tok : nvocab - 1];      // clamped: no long-lived predicate per item
+        x[j] = tok < nvocab ? v : ninf;
+        nan |= (x[j] != x[j]);
+        mx = fmaxf(mx, x[j]);
+        if (j % 16 == 15) __builtin_amdgcn_sched_barrier(0);       // sixteen loads in flight at a time
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o));
+    const uint64_t any_nan = __ballot(nan);
+    if (lane == 0) { s_a[wv] = mx; s_b[wv] = any_nan ? 1.f : 0.f; }
+    if (tid == 0) { s_n = 0; s_total = 0; }
+    // the row's bitmap -> LDS
+    const uint32_t *b = bits + (row_broadcast_bits ? 0 : (uint64_t)row * words_per_row);
+    for (uint32_t w = tid; w < (uint32_t)(ITEMS * 32); w += ROW_BLOCK) {
+        uint32_t word = w < words_per_row && 32 * w < nvocab ? b[w] : 0u;
+        if (32 * w + 32 > nvocab && 32 * w < nvocab) word &= (1u << (nvocab - 32 * w)) - 1;     // tokens >= vocab do not exist
+        s_bm[w] = word;
+    }
+    __syncthreads();
+    mx = s_a[0];
+    float nn = 0.f;
+    for (int i = 0; i < ROW_BLOCK / 64; i++) { mx = fmaxf(mx, s_a[i]); nn += s_b[i]; }
+    const bool row_nan = nn > 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+        sum += expf(x[j] - mx);                 // padding items are -inf: they add exactly 0
+        __builtin_amdgcn_sched_barrier(0);      // one expf at a time: the ITEMS logits stay in registers, nothing else may pile up
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    __syncthreads();
+    if (lane == 0) s_a[wv] = sum;
+    // allowed tokens of this thread: bit j <-> token tid + 1024 j
+    // (am is laundered through an empty asm before each unrolled loop that tests its bits: otherwise the
+    // compiler hoists the ITEMS per-item predicates out of the loops and parks them in 2 x ITEMS SGPRs)
+    uint64_t am = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) am |= (uint64_t)((s_bm[(tid >> 5) + 32 * j] >> (tid & 31)) & 1u) << j;
+    {
+        uint32_t c = (uint32_t)__popcll(am);
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+        if (lane == 0 && c) atomicAdd(&s_total, c);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < ROW_BLOCK / 64; i++) tot += s_a[i];
+        const float qnan = __builtin_nanf("");
+        const float l = row_nan ? qnan : logf(tot);
+        row_max[row] = row_nan ? qnan : mx;
+        row_lsum[row] = l;
+        s_ls = l;
+    }
+    __syncthreads();
+    float ls = s_ls;       // (laundered with am: the keys are recomputed where they are used, not kept in ITEMS more registers)
+    if (row_nan) mx = __builtin_nanf("");
+    const uint32_t total = s_total;
+    const uint32_t k_sel = total < want ? total : want;
+    if (k_sel == 0) { if (tid == 0) row_cnt[row] = 0; return; }
+    // ---- which keys can be among the k_sel best: all of them, or (key >> sh) >= thr ----
+    const bool all = total <= (narrow_max > want ? narrow_max : want);
+    uint32_t sh = 0, thr = 0, need = want;
+    bool exact_ties = false;
+    if (!all) {
+        uint32_t prefix_hi = 0;
+        for (int rd = 0; rd < 3; rd++) {
+            const uint32_t width = rd == 2 ? 8u : 12u;
+            sh = rd == 0 ? 20u : (rd == 1 ? 8u : 0u);
+            for (uint32_t i = tid; i < (uint32_t)SEL_BINS; i += ROW_BLOCK) s_hist[i] = 0u;
+            __syncthreads();
+            { uint32_t al = (uint32_t)am, ah = (uint32_t)(am >> 32); asm volatile("" : "+v"(al), "+v"(ah), "+v"(ls)); am = (uint64_t)al | ((uint64_t)ah << 32); }
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++) {
+                if (!((am >> j) & 1)) continue;
+                const uint32_t key = float_key(logp_processed(x[j], mx, ls));
+                if (rd == 0 || (key >> (sh + width)) == prefix_hi) atomicAdd(&s_hist[(key >> sh) & ((1u << width) - 1)], 1u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            // the bin B with  #(keys in bins > B) < need <= #(keys in bins >= B): suffix sums, 4 bins per thread
+            const uint32_t h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
+            const uint32_t mine = h0 + h1 + h2 + h3;
+            uint32_t inc = mine;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_down(inc, o); if (lane + o < 64) inc += v; }
+            if (lane == 0) s_wave[wv] = inc;
+            __syncthreads();
+            uint32_t running = inc - mine;
+            for (uint32_t w = wv + 1; w < ROW_BLOCK / 64; w++) running += s_wave[w];
+            const uint32_t hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+            for (int q = 3; q >= 0; q--) {
+                if (running < need && need <= running + hh[q]) { s_bin = 4 * tid + q; s_above = running; s_inbin = hh[q]; }
+                running += hh[q];
+            }
+            __syncthreads();
+            const uint32_t above = s_above, inbin = s_inbin;
+            thr = (prefix_hi << width) | s_bin;
+            const uint32_t certain = (want - need) + above;          // keys known to be above the target's bin
+            if (certain + inbin <= (uint32_t)SEL_CAP) break;
+            need -= above;
+            prefix_hi = thr;
+            if (rd == 2) exact_ties = true;
+            __syncthreads();
+        }
+    }
+    // ---- collect the candidates ----
+    { uint32_t al = (uint32_t)am, ah = (uint32_t)(am >> 32); asm volatile("" : "+v"(al), "+v"(ah), "+v"(ls)); am = (uint64_t)al | ((uint64_t)ah << 32); }
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+        if (!((am >> j) & 1)) continue;
+        const float lp = logp_processed(x[j], mx, ls);
+        const uint32_t ks = float_key(lp) >> sh;
+        if (all || (exact_ties ? ks > thr : ks >= thr)) {
+            const uint32_t o = atomicAdd(&s_n, 1u);
+            s_ctok[o] = (int32_t)(tid + (uint32_t)j * ROW_BLOCK); s_cval[o] = lp;
+        }
+    }
+    __syncthreads();
+    uint32_t n_list = s_n;
+    if (exact_ties) {
+        // more than SEL_CAP keys equal to the target: the `need` lowest tokens among them, in token order
+        // (token = tid + 1024 j: j ascending, then tid)
+        uint32_t seen = 0;
+        { uint32_t al = (uint32_t)am, ah = (uint32_t)(am >> 32); asm volatile("" : "+v"(al), "+v"(ah), "+v"(ls)); am = (uint64_t)al | ((uint64_t)ah << 32); }
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            float lp = 0.f;
+            bool eq = false;
+            if ((am >> j) & 1) { lp = logp_processed(x[j], mx, ls); eq = float_key(lp) == thr; }
+            const uint64_t be = __ballot(eq);
+            if (lane == 0) s_wave[wv] = (uint32_t)__popcll(be);
+            __syncthreads();
+            uint32_t before = seen, chunk = 0;
+            for (uint32_t w = 0; w < ROW_BLOCK / 64; w++) { if (w < wv) before += s_wave[w]; chunk += s_wave[w]; }
+            before += (uint32_t)__popcll(be & ((1ull << lane) - 1));
+            if (eq && before < need) { s_ctok[n_list + before] = (int32_t)(tid + (uint32_t)j * ROW_BLOCK); s_cval[n_list + before] = lp; }
+            seen += chunk;
+            __syncthreads();
+            if (seen >= need) break;
+        }
+        n_list += need;
+    }
+    // ---- order them: value descending, ties to the lower token id ----
+    for (uint32_t i = tid; i < n_list; i += ROW_BLOCK) {
+        const float v = s_cval[i]; const int32_t t = s_ctok[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n_list; j++) {
+            const float ov = s_cval[j]; const int32_t ot = s_ctok[j];
+            rank += (ov > v) || (ov == v && ot < t);
+        }
+        if (rank < k_sel) { row_tok[(uint64_t)row * want + rank] = t; row_lp[(uint64_t)row * want + rank] = v; }
+    }
+    if (tid == 0) row_cnt[row] = k_sel;
+}
+
 // one wavefront per query: merge the K per-row lists; fill up with not-allowed tokens (constrained
 // score -inf, as torch.topk would when a query has fewer than `want` finite candidates)
 __global__ __launch_bounds__(64) void k_query_merge(const float *logits, const uint32_t *bits, uint64_t words_per_row,
@@ -924,27 +1155,23 @@ extern "C" int fmi_dev_get_range(fmi_t *h, void *stream, uint64_t n_seq, const i
     return FMI_OK;
 }
 
-// workspace = expansion items + allowed-token bitmap (vocab <= 2^17 -> 4096 words/row)
+// workspace of the fmi_dev_* constraint calls: two allowed-token bitmaps (vocab <= 2^17 -> 4096 words/row;
+// a call fills one and clears what the previous call left in the other, so no memset launch sits in front
+// of a decode step's constraint) and two buffers of (lo, inclusive hi) per row, the incremental constraint
+// state of consecutive decode steps
 static constexpr uint64_t WS_BITS_WORDS = (1ull << FMI_MAX_LEVELS) / 32;
-static constexpr uint32_t EXP_SPLIT_MAX = 2;                                   // hex levels
-static constexpr uint64_t WS_QUEUE_PER_ROW = 1ull << (4 * EXP_SPLIT_MAX);     // room for any split level up to EXP_SPLIT_MAX
-// layout: items[rows] | queue[rows * WS_QUEUE_PER_ROW] | bits[rows * WS_BITS_WORDS] | counter
-static inline ExpandItem *ws_items(fmi *h) { return (ExpandItem *)h->ws; }
-static inline ExpandItem *ws_queue(fmi *h) { return ws_items(h) + h->ws_rows; }
-static inline uint32_t *ws_bits(fmi *h) { return (uint32_t *)(ws_queue(h) + h->ws_rows * WS_QUEUE_PER_ROW); }
-static inline uint32_t *ws_qcount(fmi *h) { return ws_bits(h) + h->ws_rows * WS_BITS_WORDS; }
-// two buffers of (lo, inclusive hi) per row: the incremental constraint state of consecutive decode steps
-static inline uint64_t *ws_state(fmi *h, int which) { return (uint64_t *)(ws_qcount(h) + 64) + (uint64_t)which * 2 * h->ws_rows; }
+static inline uint32_t *ws_bits(fmi *h, int which) { return (uint32_t *)h->ws + (uint64_t)which * h->ws_rows * WS_BITS_WORDS; }
+static inline uint64_t *ws_state(fmi *h, int which) { return (uint64_t *)(ws_bits(h, 2)) + (uint64_t)which * 2 * h->ws_rows; }
 extern "C" int fmi_dev_reserve(fmi_t *h, uint64_t max_rows)
 {
     int rc = need_device(h); if (rc) return rc;
     if (max_rows <= h->ws_rows) return FMI_OK;
     if (h->ws) { HIPCHK(hipFree(h->ws)); h->ws = nullptr; h->ws_rows = 0; }
-    const uint64_t bytes = max_rows * (sizeof(ExpandItem) * (1 + WS_QUEUE_PER_ROW) + WS_BITS_WORDS * 4 + 32) + 256;
+    const uint64_t bytes = max_rows * (2 * WS_BITS_WORDS * 4 + 32) + 256;
     HIPCHK(hipMalloc(&h->ws, bytes));
     h->ws_bytes = bytes; h->ws_rows = max_rows;
-    HIPCHK(hipMemset(ws_qcount(h), 0, 64));   // [0..1] / [2..3]: alternating queue counters of the fused path, [4]: generic path
-    h->ws_seq = 0;
+    HIPCHK(hipMemset(h->ws, 0, max_rows * 2 * WS_BITS_WORDS * 4));
+    h->ws_seq = 0; h->ws_dirty[0] = h->ws_dirty[1] = 0;
     h->state_tag = 0;
     return FMI_OK;
 }
@@ -1000,110 +1227,75 @@ extern "C" const void *fmi_dev_array(const fmi_t *h, const char *name, uint64_t 
     return nullptr;
 }
 
-static unsigned expand_grid(uint64_t n_items)
+static size_t expand_lds_bytes(uint32_t dlevels, bool with_bits)
 {
-    uint64_t g = (n_items + EXP_WAVES - 1) / EXP_WAVES;
-    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(g, 256ull * 16));
+    const size_t nsym = (size_t)1 << (FMI_DIGIT_BITS * (dlevels - 1));
+    return (size_t)exp_slots((int)dlevels - 1) * 16 + 8 * 4 + (with_bits ? ((nsym + 31) / 32) * 4 : 0);
 }
 
-static size_t expand_lds_bytes(int nlev) { return (size_t)EXP_WAVES * (3 * (size_t)exp_slots(nlev) + FMI_MAX_DLEVELS) * 4; }
+// top digits that occur: one wave per (row, top digit)
+static uint32_t top_digits(const fmi *h) { return (uint32_t)(h->max_sym >> (FMI_DIGIT_BITS * (h->dlevels - 1))) + 1; }
 
-// Expansion of `rows` root intervals (items[0..rows), level 0) in two launches:
-//   phase 1: one wave per row walks levels [0, split) and appends the surviving
-//            level-`split` nodes (<= 16^split per row) to the queue behind the roots;
-//   phase 2: one wave per queued node finishes its sub-tree.
-// The queue (rows << 4*split entries) and its counter live in the workspace.
-static uint32_t expand_split(const fmi *h, uint64_t rows, const void *queue, uint64_t qcap)
+// dense per-row symbol counts of `rows` intervals (items[0..rows)), one launch
+static int launch_expand_dense(fmi *h, hipStream_t st, const ExpandItem *items, uint64_t rows, const EmitTarget &tgt)
 {
-    const uint32_t Q = h->dlevels;
-    static const char *e_split = getenv("SEALFM_SPLIT");   // tuning knob
-    const uint32_t want = e_split ? std::min<uint32_t>((uint32_t)atoi(e_split), EXP_SPLIT_MAX) : EXP_SPLIT_LEVEL;
-    return (want > 0 && Q > want + 1 && queue && qcap >= (rows << (4 * want))) ? want : Q;   // shallow trees: single phase
-}
-
-template <int MODE>
-static int launch_phase2(fmi *h, hipStream_t st, uint32_t split, const ExpandItem *queue, const uint32_t *qcount, uint64_t qcap,
-                         const EmitTarget &tgt)
-{
-    const uint32_t Q = h->dlevels;
     uint64_t *pc = h->probe_count_enabled ? h->d_probe_counter : nullptr;
-    const int nlev2 = (int)(Q - split);
-    static const char *e_p2 = getenv("SEALFM_P2_BLOCKS");
-    const unsigned p2_blocks = e_p2 ? (unsigned)atoi(e_p2) : EXP_P2_BLOCKS;
-    auto kern = h->dev.nsb > 1 ? k_expand_sb<MODE> : k_expand<MODE>;
-    hipLaunchKernelGGL(kern, dim3(std::min(expand_grid(qcap), p2_blocks)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev2), st, h->dev,
-                       queue, qcount, (uint32_t)qcap, tgt, (uint32_t)exp_slots(nlev2), Q, (ExpandItem *)nullptr, (uint32_t *)nullptr, 0u, pc);
+    const uint64_t grid = rows * top_digits(h);
+    if (grid > 0x7fffffffull) { fmi_set_error("too many intervals in one call"); return FMI_ERR_CAPACITY; }
+    auto kern = h->dev.nsb > 1 ? k_expand_dense<true> : k_expand_dense<false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), expand_lds_bytes(h->dlevels, false), st, h->dev, items, (uint32_t)rows, tgt, pc);
     HIPCHK(hipGetLastError());
     return FMI_OK;
 }
 
-template <int MODE>
-static int launch_expand(fmi *h, hipStream_t st, ExpandItem *items, uint64_t rows, ExpandItem *queue, uint32_t *qcount,
-                         uint64_t qcap, const EmitTarget &tgt)
-{
-    const uint32_t Q = h->dlevels;
-    uint64_t *pc = h->probe_count_enabled ? h->d_probe_counter : nullptr;
-    const uint32_t split = expand_split(h, rows, queue, qcap);
-    if (split < Q) HIPCHK(hipMemsetAsync(qcount, 0, 4, st));
-    const int nlev1 = (int)split;
-    auto kern = h->dev.nsb > 1 ? k_expand_sb<MODE> : k_expand<MODE>;
-    hipLaunchKernelGGL(kern, dim3(expand_grid(rows)), dim3(EXP_WAVES * 64), expand_lds_bytes(nlev1), st, h->dev,
-                       (const ExpandItem *)items, (const uint32_t *)nullptr, (uint32_t)rows, tgt, (uint32_t)exp_slots(nlev1),
-                       split, queue, qcount, (uint32_t)qcap, pc);
-    HIPCHK(hipGetLastError());
-    if (split < Q) return launch_phase2<MODE>(h, st, split, queue, qcount, qcap, tgt);
-    return FMI_OK;
-}
-
+// One constraint call = ONE launch of k_constrain.  `d_bits` = null: the workspace bitmaps, alternating
+// between calls (the kernel clears the other one); otherwise the caller's buffer, cleared here first.
 static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur_len, const int64_t *d_ids,
                              uint32_t *d_bits, uint64_t vocab, int64_t shift, int64_t pad_id, int64_t eos_id,
                              const int64_t *force_from, uint64_t n_force, int64_t stop_at_count, int always_allow_eos,
-                             uint64_t state_tag = 0, const int64_t *d_parent = nullptr)
+                             uint64_t state_tag = 0, const int64_t *d_parent = nullptr, const uint32_t **bits_out = nullptr)
 {
     if (cur_len < 2) { fmi_set_error("cur_len must be >= 2 (cur_len == 1 is the constant occurring_distinct mask, beam_search.py:73-77)"); return FMI_ERR_ARG; }
     if (n_force > MAX_FORCE) { fmi_set_error("force_decoding_from longer than %d", MAX_FORCE); return FMI_ERR_UNSUPPORTED; }
     if (rows > h->ws_rows) { int rc = fmi_dev_reserve(h, rows); if (rc) return rc; }
     const uint64_t wpr = (vocab + 31) / 32;
-    ForceFrom ff{}; ff.n = (uint32_t)n_force;
-    for (uint64_t i = 0; i < n_force; i++) ff.tok[i] = force_from[i];
-    ExpandItem *items = ws_items(h);
-    const uint64_t qcap = h->ws_rows * WS_QUEUE_PER_ROW;
-    uint64_t *pc = h->probe_count_enabled ? h->d_probe_counter : nullptr;
-    EmitTarget tgt{}; tgt.bits = d_bits; tgt.words_per_row = wpr; tgt.shift = shift; tgt.vocab = vocab;
-    const bool timed = h->timing_enabled && h->ev_used < MAX_TIMED_LAUNCHES;
-    HIPCHK(hipMemsetAsync(d_bits, 0, rows * wpr * 4, st));
-    // the usual case (root hand-over at level 1): the prefix kernel expands the roots itself and the
-    // queue counters alternate between calls, each call clearing the other pair -- two launches per
-    // constraint step (prefix + phase 2), no memset, no phase-1 kernel.  The timed region covers both,
-    // i.e. the backward searches of the prefix are inside it.
-    if (expand_split(h, rows, ws_queue(h), qcap) == 1) {
-        uint32_t *cur = ws_qcount(h) + 2 * (h->ws_seq & 1), *nxt = ws_qcount(h) + 2 * ((h->ws_seq + 1) & 1);
+    ConstrainArgs a{};
+    a.rows = (uint32_t)rows; a.ndig0 = top_digits(h);
+    if (rows * a.ndig0 > 0x7fffffffull) { fmi_set_error("too many rows in one call"); return FMI_ERR_CAPACITY; }
+    a.cur_len = cur_len; a.ids = d_ids; a.shift = shift; a.pad_id = pad_id; a.eos_id = eos_id;
+    a.ff.n = (uint32_t)n_force;
+    for (uint64_t i = 0; i < n_force; i++) a.ff.tok[i] = force_from[i];
+    a.stop_at_count = stop_at_count; a.always_allow_eos = always_allow_eos; a.vocab = vocab; a.words_per_row = wpr;
+    a.probe_counter = h->probe_count_enabled ? h->d_probe_counter : nullptr;
+    const unsigned grid = (unsigned)(rows * a.ndig0);
+    if (d_bits) {
+        HIPCHK(hipMemsetAsync(d_bits, 0, rows * wpr * 4, st));
+        a.bits = d_bits;
+    } else {
+        const int cur = (int)(h->ws_seq & 1), nxt = cur ^ 1;
         h->ws_seq++;
-        // incremental prefix state: valid when the caller vouches (tag + parent rows) that this call extends,
-        // by exactly one token, the rows of the previous call with the same tag
-        const bool inc = state_tag && d_parent && h->state_tag == state_tag && h->state_rows == rows && h->state_len + 1 == cur_len;
-        const uint64_t *st_in = inc ? ws_state(h, h->state_flip) : nullptr;
-        uint64_t *st_out = state_tag ? ws_state(h, h->state_flip ^ 1) : nullptr;
-        if (state_tag) { h->state_tag = state_tag; h->state_rows = rows; h->state_len = cur_len; h->state_flip ^= 1; }
-        else h->state_tag = 0;
-        if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
-        auto pk = h->dev.nsb > 1 ? k_prefix_ranges<true> : k_prefix_ranges<false>;
-        hipLaunchKernelGGL(pk, dim3(blocks_for(rows, 64)), dim3(64), 0, st, h->dev, rows, cur_len, d_ids, shift,
-                           pad_id, eos_id, ff, stop_at_count, always_allow_eos, vocab, wpr, d_bits, items, ws_queue(h), cur,
-                           (uint32_t)qcap, nxt, pc, st_in, d_parent, st_out);
-        int rc = launch_phase2<EMIT_BITS>(h, st, 1, ws_queue(h), cur, qcap, tgt);
-        if (rc) return rc;
-        if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
-        return FMI_OK;
+        a.bits = ws_bits(h, cur);
+        // the other buffer still holds the previous call's bitmap: this launch clears it, unless that would
+        // be more than a few stores per lane (a much larger previous call) -- then a memset does
+        if (h->ws_dirty[nxt] > (uint64_t)grid * 64 * 8) HIPCHK(hipMemsetAsync(ws_bits(h, nxt), 0, h->ws_dirty[nxt] * 4, st));
+        else if (h->ws_dirty[nxt]) { a.clear = ws_bits(h, nxt); a.clear_words = h->ws_dirty[nxt]; }
+        h->ws_dirty[nxt] = 0;
+        h->ws_dirty[cur] = rows * wpr;
     }
-    hipLaunchKernelGGL(k_prefix_ranges<false>, dim3(blocks_for(rows, 64)), dim3(64), 0, st, h->dev, rows, cur_len, d_ids, shift,
-                       pad_id, eos_id, ff, stop_at_count, always_allow_eos, vocab, wpr, d_bits, items, (ExpandItem *)nullptr,
-                       (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, (uint64_t *)nullptr, (const uint64_t *)nullptr,
-                       (const int64_t *)nullptr, (uint64_t *)nullptr);
-    h->state_tag = 0;
+    if (bits_out) *bits_out = a.bits;
+    // incremental prefix state: valid when the caller vouches (tag + parent rows) that this call extends,
+    // by exactly one token, the rows of the previous call with the same tag
+    const bool inc = state_tag && d_parent && h->state_tag == state_tag && h->state_rows == rows && h->state_len + 1 == cur_len;
+    a.st_in = inc ? ws_state(h, h->state_flip) : nullptr;
+    a.parent = d_parent;
+    a.st_out = state_tag ? ws_state(h, h->state_flip ^ 1) : nullptr;
+    if (state_tag) { h->state_tag = state_tag; h->state_rows = rows; h->state_len = cur_len; h->state_flip ^= 1; }
+    else h->state_tag = 0;
+    const bool timed = h->timing_enabled && h->ev_used < MAX_TIMED_LAUNCHES;
     if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
-    int rc = launch_expand<EMIT_BITS>(h, st, items, rows, ws_queue(h), ws_qcount(h) + 4, qcap, tgt);
-    if (rc) return rc;
+    auto kern = h->dev.nsb > 1 ? k_constrain<true> : k_constrain<false>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), expand_lds_bytes(h->dlevels, true), st, h->dev, a);
+    HIPCHK(hipGetLastError());
     if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
     return FMI_OK;
 }
@@ -1128,10 +1320,9 @@ extern "C" int fmi_dev_constrain_scores(fmi_t *h, void *stream, uint64_t rows, u
     const uint64_t wpr = (vocab + 31) / 32;
     if (wpr > WS_BITS_WORDS) { fmi_set_error("vocab %llu too large", (unsigned long long)vocab); return FMI_ERR_UNSUPPORTED; }
     if (rows > h->ws_rows) { rc = fmi_dev_reserve(h, rows); if (rc) return rc; }
-    // bitmap lives behind the items in the workspace
-    uint32_t *bits = ws_bits(h);
-    rc = allowed_bits_impl(h, (hipStream_t)stream, rows, cur_len, d_input_ids, bits, vocab, shift, pad_id, eos_id,
-                           force_from, n_force, stop_at_count, always_allow_eos);
+    const uint32_t *bits = nullptr;
+    rc = allowed_bits_impl(h, (hipStream_t)stream, rows, cur_len, d_input_ids, nullptr, vocab, shift, pad_id, eos_id,
+                           force_from, n_force, stop_at_count, always_allow_eos, 0, nullptr, &bits);
     if (rc) return rc;
     hipLaunchKernelGGL(k_apply_bits, dim3(blocks_for(vocab, 256 * 4), (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
                        d_in, d_out, bits, rows, vocab, wpr);
@@ -1178,16 +1369,28 @@ extern "C" int fmi_dev_constrained_topk_step(fmi_t *h, void *stream, uint64_t ba
         h->state_tag = 0;
     } else {
         if (rows > h->ws_rows) { rc = fmi_dev_reserve(h, rows); if (rc) return rc; }
-        rc = allowed_bits_impl(h, st, rows, cur_len, d_input_ids, ws_bits(h), vocab, shift, pad_id, eos_id, force_from, n_force,
-                               stop_at_count, always_allow_eos, state_tag, d_parent_rows);
+        rc = allowed_bits_impl(h, st, rows, cur_len, d_input_ids, nullptr, vocab, shift, pad_id, eos_id, force_from, n_force,
+                               stop_at_count, always_allow_eos, state_tag, d_parent_rows, &bits);
         if (rc) return rc;
-        bits = ws_bits(h);
     }
-    hipLaunchKernelGGL(k_row_lse, dim3((unsigned)rows), dim3(ROW_BLOCK), 0, st, d_logits, vocab, row_max, row_lsum);
-    const char *e_narrow = getenv("SEALFM_TOPK_NARROW");      // tests: 0 forces the radix-select path on every row
+    const char *e_narrow = getenv("SEALFM_TOPK_NARROW");      // tests: 0 sends every row through the histogram rounds
     const uint32_t narrow_max = e_narrow ? std::min<uint32_t>((uint32_t)atoi(e_narrow), TOPK_NARROW) : TOPK_NARROW;
-    hipLaunchKernelGGL(k_row_topk, dim3((unsigned)rows), dim3(ROW_BLOCK), 0, st, d_logits, bits, wpr, broadcast, vocab, row_max, row_lsum,
-                       (uint32_t)want, row_tok, row_lp, row_cnt, narrow_max);
+    const char *e_legacy = getenv("SEALFM_TOPK_LEGACY");      // tests: the two-kernel path (also the path of vocabularies > 102 400)
+    const uint64_t items = (vocab + ROW_BLOCK - 1) / ROW_BLOCK;
+    if ((e_legacy && atoi(e_legacy)) || items > 100) {
+        hipLaunchKernelGGL(k_row_lse, dim3((unsigned)rows), dim3(ROW_BLOCK), 0, st, d_logits, vocab, row_max, row_lsum);
+        hipLaunchKernelGGL(k_row_topk, dim3((unsigned)rows), dim3(ROW_BLOCK), 0, st, d_logits, bits, wpr, broadcast, vocab, row_max, row_lsum,
+                           (uint32_t)want, row_tok, row_lp, row_cnt, narrow_max);
+    } else {
+#define SEL_LAUNCH(N) hipLaunchKernelGGL(k_row_select<N>, dim3((unsigned)rows), dim3(ROW_BLOCK), 0, st, d_logits, bits, wpr, broadcast, \
+                                         vocab, (uint32_t)want, row_max, row_lsum, row_tok, row_lp, row_cnt, narrow_max)
+        if (items <= 4) SEL_LAUNCH(4);
+        else if (items <= 16) SEL_LAUNCH(16);
+        else if (items <= 50) SEL_LAUNCH(50);           // BART: 50 265 tokens
+        else if (items <= 64) SEL_LAUNCH(64);
+        else SEL_LAUNCH(100);
+#undef SEL_LAUNCH
+    }
     hipLaunchKernelGGL(k_query_merge, dim3((unsigned)batch), dim3(64), 0, st, d_logits, bits, wpr, broadcast, vocab, (uint32_t)beams,
                        (uint32_t)want, d_beam_scores, row_max, row_lsum, row_tok, row_lp, row_cnt, d_top_idx, d_top_con, d_top_unc);
     HIPCHK(hipGetLastError());
@@ -1291,19 +1494,13 @@ extern "C" int fmi_distinct_count_multi(fmi_t *h, uint64_t n, const uint64_t *lo
             uint64_t lo = lows[c0 + i], hi = highs[c0 + i];
             if (hi > h->n) hi = h->n;               // rows past the end do not exist (reference: undefined)
             if (lo >= hi) { lo = hi = 0; }          // low == high -> empty (fm_index.cpp:81,99)
-            hitems[i] = ExpandItem{lo, hi, (uint32_t)i, 0, 0, 0};
+            hitems[i] = ExpandItem{lo, hi, (uint32_t)i, 0};
         }
         HIPCHK(hipMemcpy(items.p, hitems.data(), m * sizeof(ExpandItem), hipMemcpyHostToDevice));
         HIPCHK(hipMemset(dense.p, 0, m * nsym * 8));
         EmitTarget tgt{}; tgt.dense = dense.as<uint64_t>(); tgt.dense_stride = nsym;
-        {
-            DevBuf q, qc;
-            const uint64_t qcap = m * WS_QUEUE_PER_ROW;
-            if ((rc = q.alloc(qcap * sizeof(ExpandItem))) || (rc = qc.alloc(8))) return rc;
-            rc = launch_expand<EMIT_DENSE>(h, 0, items.as<ExpandItem>(), m, q.as<ExpandItem>(), qc.as<uint32_t>(), qcap, tgt);
-            if (rc) return rc;
-            HIPCHK(hipDeviceSynchronize());   // q / qc are freed at scope exit
-        }
+        rc = launch_expand_dense(h, 0, items.as<ExpandItem>(), m, tgt);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_dense_count, dim3((unsigned)m), dim3(256), 0, 0, dense.as<uint64_t>(), nsym, nsym, rowk.as<uint64_t>());
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy(hk.data(), rowk.p, m * 8, hipMemcpyDeviceToHost));

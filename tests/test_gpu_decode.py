@@ -292,3 +292,87 @@ def test_topk_selection_paths_agree_on_ties(monkeypatch):
             flat, unc = proc.fused_topk(ids, logits, beam_scores, B, K)
             got.append((flat.tolist(), unc.tolist()))
         assert got[0] == got[1], cur_len
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["randn", "five-values", "constant", "nan-row"])
+def test_row_select_at_bart_vocabulary_agrees_with_the_two_kernel_path_and_torch(kind, monkeypatch):
+    """k_row_select<50> (one pass, logits in registers: the decode step's kernel at BART's 50 265 tokens) against the
+    two-kernel path k_row_lse + k_row_topk it replaces (exactly equal picks, order and scores, ties included) and
+    against the reference's op sequence in torch (beam_search.py:244-307).  Allowed sets from 5 to 45 000 tokens per
+    row: direct LDS ranking, one histogram round, and -- on constant logits -- the further rounds and the token-order
+    tie path (more than 1024 equal keys)."""
+    import ctypes
+    from seal_amd import FMIndex
+    from seal_amd._lib import check, lib
+    from seal_amd.beam_search import _inf_nan_remove
+    from tests.helpers import make_docs
+    V, B, K = 50265, 3, 5
+    want, rows = 2 * K, B * K
+    dev = torch.device("cuda:0")
+    ix = FMIndex()
+    ix.initialize(make_docs(3, 20, 100, title_sep=7))
+    g = torch.Generator(device="cpu").manual_seed(11)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    scratch = torch.empty(rows * (3 + 2 * want) + 64, dtype=torch.float32, device=dev)
+    ids = torch.full((rows, 1), 2, dtype=torch.long, device=dev)
+    ff = (ctypes.c_int64 * 1)(0)
+    for n_allowed in (5, 40, 1000, 1025, 3000, 45000):
+        allowed = torch.zeros(V, dtype=torch.bool)
+        allowed[torch.randperm(V - 1, generator=g)[:n_allowed] + 1] = True
+        words = torch.zeros((V + 31) // 32 * 32, dtype=torch.int64)
+        words[:V] = allowed.long()
+        bits = (words.view(-1, 32) << torch.arange(32)).sum(1)
+        bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32).to(dev)
+        if kind == "randn":
+            logits = torch.randn(rows, V, generator=g) * 4
+        elif kind == "five-values":
+            logits = torch.randint(-2, 3, (rows, V), generator=g).float()
+        elif kind == "constant":
+            logits = torch.full((rows, V), 0.25)
+        else:
+            logits = torch.randn(rows, V, generator=g)
+            logits[1, 77] = float("nan")
+            logits[2, 5] = float("inf")
+        logits[:, 0] = float("-inf")
+        logits = logits.to(dev).contiguous()
+        beam_scores = (torch.randn(rows, generator=g) * 2).to(dev)
+        got = {}
+        for mode, env in (("select", {}), ("select-rounds", {"SEALFM_TOPK_NARROW": "0"}), ("two-kernel", {"SEALFM_TOPK_LEGACY": "1"}),
+                          ("two-kernel-radix", {"SEALFM_TOPK_LEGACY": "1", "SEALFM_TOPK_NARROW": "0"})):
+            for k in ("SEALFM_TOPK_NARROW", "SEALFM_TOPK_LEGACY"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            top_idx = torch.empty(B, want, dtype=torch.int64, device=dev)
+            top_con = torch.empty(B, want, dtype=torch.float32, device=dev)
+            top_unc = torch.empty(B, want, dtype=torch.float32, device=dev)
+            check(lib().fmi_dev_constrained_topk_step(ix.handle, st, B, K, 1, ids.data_ptr(), logits.data_ptr(), beam_scores.data_ptr(), V, 0,
+                                                      1, 2, ff, 0, 0, 0, bits.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,
+                                                      top_idx.data_ptr(), top_con.data_ptr(), top_unc.data_ptr(), 0, None))
+            torch.cuda.synchronize()
+            got[mode] = (top_idx.cpu(), top_con.cpu(), top_unc.cpu())
+        for mode in ("select-rounds", "two-kernel", "two-kernel-radix"):
+            for a, b in zip(got["select"], got[mode]):
+                assert torch.equal(a, b) or torch.equal(torch.nan_to_num(a.float(), nan=7.0), torch.nan_to_num(b.float(), nan=7.0)), (n_allowed, mode)
+        if kind == "nan-row":
+            continue        # torch.topk orders NaN rows its own way; the paths above agree with each other
+        processed = _inf_nan_remove(torch.log_softmax(logits, -1))
+        u = (processed + beam_scores[:, None]).view(B, K * V)
+        c = torch.where(allowed.to(dev)[None, :], processed, torch.full_like(processed, float("-inf")))
+        c = (c + beam_scores[:, None]).view(B, K * V)
+        want_c, _ = torch.topk(c, want, dim=1)
+        flat, con, unc = (t.to(dev) for t in got["select"])
+        assert torch.allclose(con, want_c, atol=1e-5), n_allowed                      # the same scores, in descending order
+        assert torch.allclose(unc, u.gather(1, flat), atol=1e-5)                       # each pick carries its own unconstrained score
+        assert torch.allclose(c.gather(1, flat), con, atol=1e-5)                       # ... and is an allowed token with that score
+        for q in range(B):
+            assert len(set(flat[q].tolist())) == want
+            # ties go to the lower flat index: among candidates of equal score the picks are the lowest ones
+            if kind != "randn":
+                vals = c[q]
+                mine = vals[flat[q]].tolist()
+                for v in set(mine):
+                    cand = torch.nonzero(vals == v).flatten().tolist()
+                    picked = sorted(i for i, s in zip(flat[q].tolist(), mine) if s == v)
+                    assert picked == cand[:len(picked)], (n_allowed, q, v)

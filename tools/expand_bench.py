@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Isolated measurement of the rank/select expansion path (k_prefix_ranges +
-k_expand) on an NQ-shaped synthetic index, model-free ("trace mode"):
+"""Isolated measurement of the rank/select constraint kernel (k_constrain: prefix
+range + expansion, one launch) on an NQ-shaped synthetic index, model-free ("trace mode"):
 rows are decoder prefixes drawn from the corpus itself.
 
   python tools/expand_bench.py --docs 21015324 --rows 300 --prefix-len 1 --iters 20
@@ -106,7 +106,7 @@ def main():
                           "alg_MB_per_call": round(probes.value * 128 / args.iters / 1e6, 2),
                           "us_per_call": round(ms.value * 1e3 / args.iters, 2), "GBps": round(gbs, 1),
                           "frac_of_8TBps": round(gbs / 8000, 4), "wave_iters_per_call": stats[1] / args.iters,
-                          "lane_util": round(stats[2] / max(1, 64 * stats[1]), 3), "model_probes_per_call": 2 * stats[3] / args.iters,
+                          "lane_pair_util": round(stats[2] / max(1, 32 * stats[1]), 3), "model_probes_per_call": 2 * stats[3] / args.iters,
                           "model_GBps": round(2 * stats[3] * 64 / (ms.value * 1e-3) / 1e9, 1), "avg_allowed_tokens_first8rows": allowed}), flush=True)
 
 

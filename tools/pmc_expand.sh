@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over tools/expand_bench.py (k_expand only).  usage: tools/pmc_expand.sh <outdir> [expand_bench args...]
+# PMC passes over tools/expand_bench.py (k_constrain).  usage: tools/pmc_expand.sh <outdir> [expand_bench args...]
 # One counter group per pass (rocprofv3 --pmc with --kernel-trace only, as gpurun requires).
 out=$1; shift
 mkdir -p "$out"
@@ -13,7 +13,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VME
   i=$((i+1))
   d=/tmp/pmc_$i
   rm -rf $d
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex k_expand --output-format csv -d $d -- python $GRAFT_REPO_ROOT/tools/expand_bench.py "$@" > $d.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "k_constrain|k_expand" --output-format csv -d $d -- python $GRAFT_REPO_ROOT/tools/expand_bench.py "$@" > $d.log 2>&1)
   f=$(find $d -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python $GRAFT_REPO_ROOT/tools/summarize_pmc.py $f > "$out/pmc_$i.json"; else echo "pass $i failed"; tail -5 $d.log; fi
 done
