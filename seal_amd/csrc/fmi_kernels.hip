@@ -45,6 +45,9 @@ __device__ __forceinline__ void bs_step(const FmiDev &ix, uint64_t c, uint64_t l
     const uint64_t cb = ix.C[c];
     uint64_t rl, rr;
     const uint64_t j = r + 1;
+    // the first step of every search starts from [0, size()] (index.py:106-107): rank(0) = 0 and the
+    // rank one past the end is the quirk value -- a table look-up, no probe of the wavelet matrix
+    if (l == 0 && j > ix.n) { l_res = cb; r_res = cb + rank_like_sdsl(ix, c, j, probes) - 1; return; }
     wm_rank_sym_pair(ix, c, l < ix.n ? l : ix.n, j < ix.n ? j : ix.n, rl, rr, probes);
     if (l > ix.n) rl = rank_like_sdsl(ix, c, l, probes);       // beyond size(): the quirk value, no probe
     if (j > ix.n) rr = rank_like_sdsl(ix, c, j, probes);
@@ -1171,6 +1174,7 @@ extern "C" int fmi_dev_reserve(fmi_t *h, uint64_t max_rows)
     HIPCHK(hipMalloc(&h->ws, bytes));
     h->ws_bytes = bytes; h->ws_rows = max_rows;
     HIPCHK(hipMemset(h->ws, 0, max_rows * 2 * WS_BITS_WORDS * 4));
+    HIPCHK(hipDeviceSynchronize());     // the memset runs on the null stream; the callers' streams are non-blocking
     h->ws_seq = 0; h->ws_dirty[0] = h->ws_dirty[1] = 0;
     h->state_tag = 0;
     return FMI_OK;

@@ -22,6 +22,7 @@
 // the same index.  The file's REAL bit layout is additionally used for quirk Q1: the table
 // rank(size()+1, c) - occ(c) is computed from the file's own tree with sdsl's rank loop and replaces the builder's
 // analytic model of it.
+#include <cstdlib>
 #include <hip/hip_runtime_api.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -253,9 +254,13 @@ extern "C" int fmi_load_sdsl(fmi_t **out, const char *path, int device)
     int rc = fmi_create(&h);
     if (rc) return rc;
     if (device >= 0) {
+        // a host copy makes the loaded index saveable in the engine's own container (fmi_save), i.e. turns load + save
+        // into a converter; it costs ~9.4 bytes per symbol of host memory, so beyond 2^28 symbols only on request
+        const char *e_keep = getenv("SEALFM_KEEP_HOST");
+        const int keep_host = e_keep ? atoi(e_keep) != 0 : n <= (1ull << 28);
         uint32_t *d = nullptr;
         if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&d, std::max<uint64_t>(n - 1, 1) * 4) != hipSuccess) { fmi_free(h); fmi_set_error("hipMalloc for the recovered text failed"); return FMI_ERR_HIP; }
-        rc = hipMemcpy(d, text.data(), (n - 1) * 4, hipMemcpyHostToDevice) == hipSuccess ? fmi_build_device(h, d, n - 1, device, 0) : FMI_ERR_HIP;
+        rc = hipMemcpy(d, text.data(), (n - 1) * 4, hipMemcpyHostToDevice) == hipSuccess ? fmi_build_device(h, d, n - 1, device, keep_host) : FMI_ERR_HIP;
         (void)hipFree(d);
     } else {
         std::vector<uint64_t> data(text.begin(), text.end() - 1);
