@@ -210,6 +210,21 @@ int fmi_dev_constrained_topk_step(fmi_t *h, void *stream, uint64_t batch, uint64
                                   void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc,
                                   uint64_t state_tag, const int64_t *d_parent_rows);
 
+/* fmi_dev_allowed_bits with the continuity contract of fmi_dev_constrained_topk_step (state_tag / d_parent_rows:
+ * the rows extend, by one token, rows d_parent_rows[] of the previous call with the same tag, so the prefix range
+ * advances by ONE backward-search step).  d_bits == NULL: the bitmap is written to the index's own workspace
+ * (two buffers alternating between calls, each call clearing the other: no memset launch) and *d_bits_out
+ * points at it, valid until the next constraint call but one on this handle. */
+int fmi_dev_allowed_bits_step(fmi_t *h, void *stream, uint64_t rows, uint64_t cur_len, const int64_t *d_input_ids,
+                              uint32_t *d_bits, uint64_t vocab, int64_t shift, int64_t pad_id, int64_t eos_id,
+                              const int64_t *force_from, uint64_t n_force, int64_t stop_at_count, int always_allow_eos,
+                              uint64_t state_tag, const int64_t *d_parent_rows, const uint32_t **d_bits_out);
+
+/* tools only: while d_buf (n_words uint64, >= 8 per wave of the constraint launch) is set, every wave of
+ * k_constrain stores realtime stamps (100 MHz) at {start, prefix range known, root child known (0: none),
+ * sub-tree expanded, bitmap stored}.  NULL switches it off. */
+int fmi_dev_debug_timestamps(fmi_t *h, uint64_t *d_buf, uint64_t n_words);
+
 /* locate + doc binning for n rows (seal/keys.py:320-324) */
 int fmi_dev_locate(fmi_t *h, void *stream, uint64_t n, const uint64_t *d_rows,
                    uint64_t *d_pos_out, uint64_t *d_doc_out);

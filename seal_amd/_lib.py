@@ -49,6 +49,8 @@ SIGNATURES = {
     "fmi_dev_get_range": (_int, [_vp, _vp, _u64, _vp, _vp, _i64, _vp, _vp]),
     "fmi_dev_constrain_scores": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _u64, _i64, _i64, _i64, _pi64, _u64, _i64, _int]),
     "fmi_dev_allowed_bits": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, _i64, _i64, _i64, _pi64, _u64, _i64, _int]),
+    "fmi_dev_allowed_bits_step": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, _i64, _i64, _i64, _pi64, _u64, _i64, _int, _u64, _vp, _vp]),
+    "fmi_dev_debug_timestamps": (_int, [_vp, _vp, _u64]),
     "fmi_dev_constrained_topk": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _u64, _i64, _i64, _i64, _pi64, _u64, _i64, _int,
                                         _vp, _vp, _u64, _vp, _vp, _vp]),
     "fmi_dev_constrained_topk_step": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _u64, _i64, _i64, _i64, _pi64, _u64, _i64, _int,

@@ -83,6 +83,8 @@ struct fmi {
     void *ws = nullptr;
     uint64_t ws_bytes = 0;
     uint64_t *d_probe_counter = nullptr;
+    uint64_t *dbg_tstamp = nullptr;   // tools: per-wave realtime stamps of k_constrain (fmi_dev_debug_timestamps)
+    uint64_t dbg_tstamp_cap = 0;
     int probe_count_enabled = 0;
     // optional event timing of k_constrain launches
     int timing_enabled = 0;

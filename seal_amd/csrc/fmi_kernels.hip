@@ -440,6 +440,7 @@ struct ConstrainArgs {
     const int64_t *parent;
     uint64_t *st_out;
     uint64_t *probe_counter;
+    uint64_t *tstamp;              // tools only: 8 realtime stamps (100 MHz) per wave, or null
 };
 
 // a special token (pad / eos) of the row: into the LDS bitmap of the wave that owns its symbol; tokens
@@ -472,10 +473,15 @@ __global__ __launch_bounds__(64) void k_constrain(FmiDev ix, ConstrainArgs a)
     uint4 *s_node = s_dyn;
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_node + exp_slots((int)D - 1));
     uint32_t *s_bits = s_cnt + 8;
-    const uint32_t d1 = blockIdx.x / a.rows, r = blockIdx.x - d1 * a.rows;
+    // rows are padded to a multiple of 8 in the grid: workgroup i runs on XCD i % 8, so every wave of a row lands on
+    // the same XCD and the row's own probes (prefix step, root) miss its L2 once instead of once per XCD
+    const uint32_t rows8 = (a.rows + 7) & ~7u;
+    const uint32_t d1 = blockIdx.x / rows8, r = blockIdx.x - d1 * rows8;
     const bool writer = d1 == 0;
     const bool counting = a.probe_counter != nullptr;
     ExpCounters ctr{0, 0, 0, 0};
+#define STAMP(i) do { if (a.tstamp && lane == 0) a.tstamp[(uint64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    STAMP(0);
 
     // housekeeping for the next call: this wave's share of the other bitmap buffer
     if (a.clear) {
@@ -483,6 +489,7 @@ __global__ __launch_bounds__(64) void k_constrain(FmiDev ix, ConstrainArgs a)
         const uint64_t w0 = (uint64_t)blockIdx.x * per;
         for (uint64_t w = w0 + lane; w < w0 + per && w < a.clear_words; w += 64) a.clear[w] = 0u;
     }
+    if (r >= a.rows) return;            // padding workgroup: its share of the clearing is all it does
     for (uint32_t w = lane; w < nw; w += 64) s_bits[w] = 0u;
 
     // ---- the row: prefix range, class (identical in every wave of the row) ----
@@ -515,6 +522,7 @@ __global__ __launch_bounds__(64) void k_constrain(FmiDev ix, ConstrainArgs a)
         if (writer && lane == 0 && a.st_out) { a.st_out[2 * r] = l; a.st_out[2 * r + 1] = rr; }
         lo = l; hi = rr + 1;
     }
+    STAMP(1);
     int64_t single = -1;
     bool expand = false;
     if (a.stop_at_count > 0 && (int64_t)count <= a.stop_at_count) single = a.eos_id;
@@ -525,6 +533,7 @@ __global__ __launch_bounds__(64) void k_constrain(FmiDev ix, ConstrainArgs a)
     if (expand && hi > lo) {
         uint64_t clo, chi;
         root_child(ix, lo, hi, d1, clo, chi);
+        if (a.tstamp && lane == 0) a.tstamp[(uint64_t)blockIdx.x * 8 + 2] = chi > clo ? __builtin_amdgcn_s_memrealtime() : 0;
         if (counting && writer && lane == 0) {
             probes += (lo >> FMI_BLOCK_SHIFT) != (hi >> FMI_BLOCK_SHIFT) ? 2 : 1;
             model += model_nodes(root_children_mask(ix, lo, hi), 0, FMI_DIGIT_BITS * D - ix.levels);
@@ -536,6 +545,7 @@ __global__ __launch_bounds__(64) void k_constrain(FmiDev ix, ConstrainArgs a)
         }
     }
     wave_sync();
+    STAMP(3);
     // pad / eos of the row's class: after the expansion, whose byte stores would overwrite them
     if (lane == 0) {
         if (single >= 0) set_special(ix, a, s_bits, r, d1, sub_bits, single);
@@ -545,6 +555,8 @@ __global__ __launch_bounds__(64) void k_constrain(FmiDev ix, ConstrainArgs a)
     EmitTarget tgt{};
     tgt.bits = a.bits; tgt.words_per_row = a.words_per_row; tgt.shift = a.shift; tgt.vocab = a.vocab;
     flush_leaf_bits(tgt, r, s_bits, d1 << sub_bits, nsym);
+    STAMP(4);
+#undef STAMP
     if (counting) {
         if (writer && lane == 0) { ctr.probes += probes; ctr.model += model; }
         flush_counters(a.probe_counter, ctr);
@@ -1265,13 +1277,14 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     const uint64_t wpr = (vocab + 31) / 32;
     ConstrainArgs a{};
     a.rows = (uint32_t)rows; a.ndig0 = top_digits(h);
-    if (rows * a.ndig0 > 0x7fffffffull) { fmi_set_error("too many rows in one call"); return FMI_ERR_CAPACITY; }
+    if ((rows + 8) * a.ndig0 > 0x7fffffffull) { fmi_set_error("too many rows in one call"); return FMI_ERR_CAPACITY; }
     a.cur_len = cur_len; a.ids = d_ids; a.shift = shift; a.pad_id = pad_id; a.eos_id = eos_id;
     a.ff.n = (uint32_t)n_force;
     for (uint64_t i = 0; i < n_force; i++) a.ff.tok[i] = force_from[i];
     a.stop_at_count = stop_at_count; a.always_allow_eos = always_allow_eos; a.vocab = vocab; a.words_per_row = wpr;
     a.probe_counter = h->probe_count_enabled ? h->d_probe_counter : nullptr;
-    const unsigned grid = (unsigned)(rows * a.ndig0);
+    const unsigned grid = (unsigned)(((rows + 7) & ~7ull) * a.ndig0);
+    a.tstamp = h->dbg_tstamp && h->dbg_tstamp_cap >= (uint64_t)grid * 8 ? h->dbg_tstamp : nullptr;
     if (d_bits) {
         HIPCHK(hipMemsetAsync(d_bits, 0, rows * wpr * 4, st));
         a.bits = d_bits;
@@ -1312,6 +1325,25 @@ extern "C" int fmi_dev_allowed_bits(fmi_t *h, void *stream, uint64_t rows, uint6
     if (rows == 0) return FMI_OK;
     return allowed_bits_impl(h, (hipStream_t)stream, rows, cur_len, d_input_ids, d_bits, vocab, shift, pad_id, eos_id,
                              force_from, n_force, stop_at_count, always_allow_eos);
+}
+
+extern "C" int fmi_dev_allowed_bits_step(fmi_t *h, void *stream, uint64_t rows, uint64_t cur_len, const int64_t *d_input_ids,
+                                         uint32_t *d_bits, uint64_t vocab, int64_t shift, int64_t pad_id, int64_t eos_id,
+                                         const int64_t *force_from, uint64_t n_force, int64_t stop_at_count, int always_allow_eos,
+                                         uint64_t state_tag, const int64_t *d_parent_rows, const uint32_t **d_bits_out)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (rows == 0) return FMI_OK;
+    if ((vocab + 31) / 32 > WS_BITS_WORDS) { fmi_set_error("vocab %llu too large", (unsigned long long)vocab); return FMI_ERR_UNSUPPORTED; }
+    return allowed_bits_impl(h, (hipStream_t)stream, rows, cur_len, d_input_ids, d_bits, vocab, shift, pad_id, eos_id,
+                             force_from, n_force, stop_at_count, always_allow_eos, state_tag, d_parent_rows, d_bits_out);
+}
+
+extern "C" int fmi_dev_debug_timestamps(fmi_t *h, uint64_t *d_buf, uint64_t n_words)
+{
+    if (!h) { fmi_set_error("null handle"); return FMI_ERR_ARG; }
+    h->dbg_tstamp = d_buf; h->dbg_tstamp_cap = d_buf ? n_words : 0;
+    return FMI_OK;
 }
 
 extern "C" int fmi_dev_constrain_scores(fmi_t *h, void *stream, uint64_t rows, uint64_t cur_len, const int64_t *d_input_ids,
