@@ -24,9 +24,61 @@ import torch
 import torch.nn.functional as F
 
 
+import contextlib
 import threading
 
-_CAPTURE_LOCK = threading.Lock()      # one hipGraph capture at a time (concurrent captures from two pipelines fail on HIP)
+class _CaptureGate:
+    """hipGraph capture needs the GPU-issuing side of the process to itself: with two query pipelines on worker
+    threads a capture on one thread aborted (inside hipBLASLt) every few runs while the other thread was launching.
+    Pipeline workers hold the gate SHARED while they issue a batch (``issuing()``); a capture takes it EXCLUSIVELY
+    (``capturing()``: gives up the caller's own shared hold, waits until nobody else holds one, blocks newcomers,
+    takes the shared hold back afterwards).  Captures are rare (one per (batch, beams, S_pad, T) shape), so the
+    stall is a one-off.  Threads that never entered ``issuing()`` (the single-threaded default) pay one uncontended
+    lock."""
+
+    def __init__(self):
+        self._cond = threading.Condition()
+        self._readers = 0
+        self._writer = False
+        self._writers_waiting = 0
+        self._local = threading.local()
+
+    @contextlib.contextmanager
+    def issuing(self):
+        with self._cond:
+            while self._writer or self._writers_waiting:
+                self._cond.wait()
+            self._readers += 1
+        self._local.depth = getattr(self._local, "depth", 0) + 1
+        try:
+            yield
+        finally:
+            self._local.depth -= 1
+            with self._cond:
+                self._readers -= 1
+                self._cond.notify_all()
+
+    @contextlib.contextmanager
+    def capturing(self):
+        mine = getattr(self._local, "depth", 0)
+        with self._cond:
+            self._readers -= mine
+            self._writers_waiting += 1
+            self._cond.notify_all()
+            while self._writer or self._readers:
+                self._cond.wait()
+            self._writers_waiting -= 1
+            self._writer = True
+        try:
+            yield
+        finally:
+            with self._cond:
+                self._writer = False
+                self._readers += mine
+                self._cond.notify_all()
+
+
+CAPTURE_GATE = _CaptureGate()
 
 
 class BartStepDecoder:
@@ -241,7 +293,7 @@ class BartStepDecoder:
         self._st = st
         self.t = 0
         if st.graph is None:
-          with _CAPTURE_LOCK:
+          with CAPTURE_GATE.capturing():
             # warm up on a side stream, then capture (standard torch recipe); the cache contents
             # written by the warm-up steps are overwritten/masked once t is reset
             side = torch.cuda.Stream(device=enc_hidden.device)

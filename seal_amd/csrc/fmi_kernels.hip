@@ -580,9 +580,9 @@ __global__ __launch_bounds__(256) void k_apply_bits(const float *in, float *out,
 //   next_token_scores = log_softmax(logits); InfNanRemove; unconstrained = + beam_score;
 //   constrained = unconstrained where the token is allowed, else -inf; top-2K of the constrained
 //   scores over the K*V candidates of a query; carry the UNCONSTRAINED score of the picks.
-// Nothing of shape [rows, vocab] is written: k_row_lse reads the logits once, k_row_topk reads
-// only the allowed tokens of each row (bitmap from k_prefix_ranges + k_expand), k_query_merge
-// merges the K per-row lists of a query.  Ties go to the lower flat index.
+// Nothing of shape [rows, vocab] is written: k_row_pick streams each row's logits (statistics, then the
+// best allowed tokens of the row under the bitmap of k_constrain), k_query_merge merges the K per-row
+// lists of a query.  Ties go to the lower flat index.
 // ---------------------------------------------------------------------------
 static constexpr int TOPK_MAX = 64;          // 2 * num_beams <= 64
 
@@ -594,39 +594,6 @@ __device__ __forceinline__ float logp_processed(float x, float mx, float lsum)
     return lp;
 }
 
-// one workgroup (1024 threads) per row: max and log(sum(exp(x - max)))
-static constexpr int ROW_BLOCK = 1024;
-static constexpr int TOPK_NARROW = 1024;     // rows with at most this many allowed tokens are selected in LDS (k_row_topk)
-__global__ __launch_bounds__(ROW_BLOCK) void k_row_lse(const float *logits, uint64_t vocab, float *row_max, float *row_lsum)
-{
-    __shared__ float s_a[ROW_BLOCK / 64], s_b[ROW_BLOCK / 64];
-    const float *x = logits + (uint64_t)blockIdx.x * vocab;
-    float mx = -__builtin_huge_valf();
-    bool nan = false;
-    for (uint64_t v = threadIdx.x; v < vocab; v += ROW_BLOCK) { const float a = x[v]; nan |= (a != a); mx = fmaxf(mx, a); }
-    for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_down(mx, o)); }
-    const uint64_t any_nan = __ballot(nan);
-    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = mx; s_b[threadIdx.x >> 6] = any_nan ? 1.f : 0.f; }
-    __syncthreads();
-    mx = s_a[0];
-    float nn = 0.f;
-    for (int i = 0; i < ROW_BLOCK / 64; i++) { mx = fmaxf(mx, s_a[i]); nn += s_b[i]; }
-    const bool row_nan = nn > 0.f;
-    __syncthreads();
-    float sum = 0.f;
-    for (uint64_t v = threadIdx.x; v < vocab; v += ROW_BLOCK) sum += expf(x[v] - mx);
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
-    if ((threadIdx.x & 63) == 0) s_a[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float tot = 0.f;
-        for (int i = 0; i < ROW_BLOCK / 64; i++) tot += s_a[i];
-        const float qnan = __builtin_nanf("");
-        row_max[blockIdx.x] = row_nan ? qnan : mx;
-        row_lsum[blockIdx.x] = row_nan ? qnan : logf(tot);
-    }
-}
-
 // order-preserving map float -> uint32 (ascending)
 __device__ __forceinline__ uint32_t float_key(float f)
 {
@@ -634,325 +601,56 @@ __device__ __forceinline__ uint32_t float_key(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// one workgroup per row: the `want` (<= 64) best allowed tokens of the row by processed log-prob
-// (descending, ties to the lower token id) -> row_tok / row_lp [rows, want]; row_cnt = how many exist.
-// Exact radix select: 4 coalesced passes (8 bits each) over the row's allowed tokens histogram the
-// keys that match the prefix found so far and pin the want-th largest key T; one more pass collects
-// the keys > T plus as many keys == T as still needed (lowest tokens first); <= 64 survivors are
-// ordered by counting ranks.  Lanes read consecutive tokens, the bitmap word is a broadcast.
-__global__ __launch_bounds__(ROW_BLOCK) void k_row_topk(const float *logits, const uint32_t *bits, uint64_t words_per_row,
-                                                  uint32_t row_broadcast_bits, uint64_t vocab, const float *row_max,
-                                                  const float *row_lsum, uint32_t want, int32_t *row_tok, float *row_lp,
-                                                  uint32_t *row_cnt, uint32_t narrow_max)
+// One workgroup of 512 threads per row: log-softmax statistics of the row and its `want` (<= 64) best
+// ALLOWED tokens by processed log-prob (descending, ties to the lower token id) -> row_tok / row_lp
+// [rows, want]; row_cnt = how many exist.  The row (200 KB at BART's vocabulary) is streamed from L2 with
+// coalesced loads, a few registers per thread, so that all rows of a decode step are resident at once:
+//   sweep 1, 2   max, log(sum(exp(x - max)))                    (every row)
+//   narrow rows  (<= 1024 allowed tokens): the allowed tokens are gathered by walking the bitmap and ranked
+//                in LDS -- nothing else is read;
+//   wide rows    sweep 3: every thread's best allowed key; the want-th largest of the 512 thread maxima is a
+//                lower bound of the want-th largest key of the row, so sweep 4 collects the keys >= it (a few
+//                dozen on any real distribution) and they are ranked in LDS.  No histogram, no atomics
+//                beyond the list counter.  Only if more than PICK_CAP keys pass (mass ties) the exact radix
+//                select runs: four 8-bit histogram passes pin the want-th largest key, one pass collects the
+//                keys above it and the lowest tokens among its ties.
+static constexpr int PICK_BLOCK = 512;
+static constexpr int PICK_WAVES = PICK_BLOCK / 64;
+static constexpr int PICK_CAP = 1024;        // candidate list in LDS; also the widest "narrow" row
+static constexpr int TOPK_NARROW = PICK_CAP;
+enum { PICK_NO_PREFILTER = 1 };              // test switch: wide rows go straight to the radix select
+
+__device__ __forceinline__ bool bm_bit(const uint32_t *s_bm, uint32_t tok) { return (s_bm[tok >> 5] >> (tok & 31)) & 1u; }
+
+// f(token, logit) for every token of a row, PICK_BLOCK threads.  The loads are unconditional and wide:
+// a scalar head up to the first 16-byte boundary (rows are vocab floats apart, vocab odd for BART), an
+// aligned float4 body -- 16 bytes per lane per load, several loads in flight per thread: one CU has to
+// pull a 200 KB row out of L2 / MALL in a few microseconds, which is a matter of bytes in flight --, a
+// scalar tail.  Whatever f tests (bitmap bits) is applied to values that are already on their way.
+template <typename F>
+__device__ __forceinline__ void row_sweep(const float *x, uint32_t vocab, F &&f)
 {
-    __shared__ int32_t s_gtok[TOPK_NARROW];
-    __shared__ float s_gval[TOPK_NARROW];
-    __shared__ uint32_t s_hist[256];
-    __shared__ uint32_t s_prefix, s_remaining, s_n_gt, s_n_eq, s_total;
-    __shared__ int32_t s_ctok[TOPK_MAX];
-    __shared__ float s_cval[TOPK_MAX];
-    __shared__ uint32_t s_wave[ROW_BLOCK / 64];
-    const uint32_t row = blockIdx.x, tid = threadIdx.x;
-    const float *x = logits + (uint64_t)row * vocab;
-    const uint32_t *b = bits + (row_broadcast_bits ? 0 : (uint64_t)row * words_per_row);
-    const float mx = row_max[row], ls = row_lsum[row];
-    if (tid == 0) { s_prefix = 0; s_remaining = want; s_n_gt = 0; s_n_eq = 0; s_total = 0; }
-    // number of allowed tokens
-    {
-        uint32_t c = 0;
-        for (uint64_t w = tid; w < words_per_row; w += ROW_BLOCK) {
-            uint32_t word = b[w];
-            if ((w + 1) * 32 > vocab) { const uint32_t keep = (uint32_t)(vocab - w * 32); word &= keep >= 32 ? ~0u : ((1u << keep) - 1); }
-            c += (uint32_t)__popc(word);
-        }
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-        __syncthreads();
-        if ((tid & 63) == 0 && c) atomicAdd(&s_total, c);
-        __syncthreads();
+    const uint32_t tid = threadIdx.x;
+    uint32_t head = (4u - (uint32_t)((reinterpret_cast<uintptr_t>(x) >> 2) & 3u)) & 3u;
+    if (head > vocab) head = vocab;
+    if (tid < head) f(tid, x[tid]);
+    const float4 *x4 = reinterpret_cast<const float4 *>(x + head);
+    const uint32_t n4 = (vocab - head) >> 2;
+#pragma unroll 4
+    for (uint32_t i = tid; i < n4; i += PICK_BLOCK) {
+        const float4 v = x4[i];
+        const uint32_t t = head + 4 * i;
+        f(t, v.x); f(t + 1, v.y); f(t + 2, v.z); f(t + 3, v.w);
     }
-    const uint32_t total = s_total;
-    const uint32_t k_sel = total < want ? total : want;        // how many we will output
-    if (k_sel == 0) { if (tid == 0) row_cnt[row] = 0; return; }
-    if (total <= narrow_max) {
-        // narrow row (most decode steps after the first few): one pass over the bitmap words gathers the
-        // allowed tokens into LDS, every candidate then finds its own rank under the output order
-        // (value descending, ties to the lower token id) -- no radix passes, no per-chunk barriers
-        for (uint64_t w = tid; w < words_per_row; w += ROW_BLOCK) {
-            uint32_t word = b[w];
-            if ((w + 1) * 32 > vocab) { const uint32_t keep = (uint32_t)(vocab - w * 32); word &= keep >= 32 ? ~0u : ((1u << keep) - 1); }
-            while (word) {
-                const uint32_t tok = (uint32_t)(w * 32) + (uint32_t)__builtin_ctz(word);
-                word &= word - 1;
-                const uint32_t o = atomicAdd(&s_n_gt, 1u);
-                s_gtok[o] = (int32_t)tok; s_gval[o] = logp_processed(x[tok], mx, ls);
-            }
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < total; i += ROW_BLOCK) {
-            const float v = s_gval[i]; const int32_t t = s_gtok[i];
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < total; j++) {
-                const float ov = s_gval[j]; const int32_t ot = s_gtok[j];
-                rank += (ov > v) || (ov == v && ot < t);
-            }
-            if (rank < k_sel) { row_tok[(uint64_t)row * want + rank] = t; row_lp[(uint64_t)row * want + rank] = v; }
-        }
-        if (tid == 0) row_cnt[row] = k_sel;
-        return;
-    }
-    uint32_t T = 0;
-    if (total > want) {
-        for (int pass = 0; pass < 4; pass++) {
-            const int shift = 24 - 8 * pass;
-            if (tid < 256) s_hist[tid] = 0;
-            __syncthreads();
-            const uint32_t prefix = s_prefix;
-            const uint32_t pmask = pass == 0 ? 0u : (~0u << (shift + 8));
-            for (uint64_t tok = tid; tok < vocab; tok += ROW_BLOCK) {
-                if (!((b[tok >> 5] >> (tok & 31)) & 1)) continue;
-                const uint32_t key = float_key(logp_processed(x[tok], mx, ls));
-                if ((key & pmask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t rem = s_remaining, bin = 255;
-                for (;; bin--) {
-                    const uint32_t c = s_hist[bin];
-                    if (c >= rem || bin == 0) break;
-                    rem -= c;
-                }
-                s_remaining = rem;                 // rank of the target inside the chosen bin
-                s_prefix = prefix | (bin << shift);
-            }
-            __syncthreads();
-        }
-        T = s_prefix;
-    }
-    const uint32_t need_eq_max = total > want ? s_remaining : 0;     // ties with T still needed
-    __syncthreads();
-    // collect: everything (total <= want) or keys > T and the first need_eq_max keys == T
-    for (uint64_t base = 0; base < vocab; base += ROW_BLOCK) {
-        const uint64_t tok = base + tid;
-        bool ok = tok < vocab && ((b[tok >> 5] >> (tok & 31)) & 1);
-        float lp = 0.f; uint32_t key = 0;
-        if (ok) { lp = logp_processed(x[tok], mx, ls); key = float_key(lp); }
-        const bool gt = ok && (total <= want || key > T);
-        const bool eq = ok && total > want && key == T;
-        if (gt) { const uint32_t o = atomicAdd(&s_n_gt, 1u); if (o < TOPK_MAX) { s_ctok[o] = (int32_t)tok; s_cval[o] = lp; } }
-        // ties in token order: workgroup prefix count per ROW_BLOCK-token chunk
-        const uint64_t be = __ballot(eq);
-        if ((tid & 63) == 0) s_wave[tid >> 6] = (uint32_t)__popcll(be);
-        __syncthreads();
-        uint32_t chunk_eq = 0;
-        for (int i = 0; i < ROW_BLOCK / 64; i++) chunk_eq += s_wave[i];
-        if (chunk_eq) {
-            uint32_t before = s_n_eq;
-            for (uint32_t w = 0; w < (tid >> 6); w++) before += s_wave[w];
-            const uint32_t my = before + (uint32_t)__popcll(be & ((1ull << (tid & 63)) - 1));
-            __syncthreads();
-            if (eq && my < need_eq_max) {
-                const uint32_t o = (k_sel - need_eq_max) + my;       // ties fill the tail slots
-                s_ctok[o] = (int32_t)tok; s_cval[o] = lp;
-            }
-            if (tid == 0) s_n_eq += chunk_eq;
-        }
-        __syncthreads();
-    }
-    // order the k_sel survivors by (value desc, token asc)
-    if (tid < k_sel) {
-        const float v = s_cval[tid]; const int32_t t = s_ctok[tid];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < k_sel; j++) {
-            const float ov = s_cval[j]; const int32_t ot = s_ctok[j];
-            rank += (ov > v) || (ov == v && ot < t);
-        }
-        row_tok[(uint64_t)row * want + rank] = t;
-        row_lp[(uint64_t)row * want + rank] = v;
-    }
-    if (tid == 0) row_cnt[row] = k_sel;
+    const uint32_t t = head + 4 * n4 + tid;
+    if (t < vocab) f(t, x[t]);
 }
 
-// k_row_lse + k_row_topk in ONE pass over the logits (the decode step's path when the vocabulary fits
-// ITEMS x 1024 tokens): every thread keeps its ITEMS logits in registers (token = tid + 1024 j, coalesced
-// dword loads), so the row is read from memory exactly once; max / log-sum-exp are reduced in the same
-// order as k_row_lse (bit-identical row_max / row_lsum), the row's bitmap is staged in LDS, and the
-// selection works on register data: rows with few allowed tokens are ranked directly in LDS; wider rows
-// take one 12-bit histogram round over the keys of their allowed tokens (LDS atomics) that pins the bin
-// of the want-th largest key -- the keys above it plus the bin's own are then ranked in LDS, which is the
-// end of it unless more than SEL_CAP keys share that bin; only then the remaining 12 + 8 key bits are
-// resolved by further rounds, and an exact tie larger than SEL_CAP by token order.  Same output as
-// k_row_topk: value descending, ties to the lower token id.
-static constexpr int SEL_CAP = 1024;
-static constexpr int SEL_BINS = 4096;
-
-template <int ITEMS>
-__global__ __launch_bounds__(ROW_BLOCK) void k_row_select(const float *logits, const uint32_t *bits, uint64_t words_per_row,
-                                                          uint32_t row_broadcast_bits, uint64_t vocab, uint32_t want,
-                                                          float *row_max, float *row_lsum, int32_t *row_tok, float *row_lp,
-                                                          uint32_t *row_cnt, uint32_t narrow_max)
+// the n_list candidates in s_ctok / s_cval -> their places under (value descending, token ascending); the first k_sel leave
+__device__ __forceinline__ void pick_rank_and_store(const int32_t *s_ctok, const float *s_cval, uint32_t n_list, uint32_t k_sel,
+                                                    uint32_t row, uint32_t want, int32_t *row_tok, float *row_lp)
 {
-    __shared__ uint32_t s_bm[ITEMS * 32];
-    __shared__ uint32_t s_hist[SEL_BINS];
-    __shared__ int32_t s_ctok[SEL_CAP];
-    __shared__ float s_cval[SEL_CAP];
-    __shared__ float s_a[ROW_BLOCK / 64], s_b[ROW_BLOCK / 64];
-    __shared__ uint32_t s_wave[ROW_BLOCK / 64];
-    __shared__ float s_ls;
-    __shared__ uint32_t s_n, s_total, s_bin, s_above, s_inbin;
-    const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const float *xrow = logits + (uint64_t)row * vocab;
-    const float ninf = -__builtin_huge_valf();
-    const uint32_t nvocab = (uint32_t)vocab;
-    // ---- the row, once: max and log(sum(exp(x - max))), reduced as k_row_lse does ----
-    float x[ITEMS];
-    float mx = ninf;
-    bool nan = false;
-#pragma unroll
-    for (int j = 0; j < ITEMS; j++) {
-        const uint32_t tok = tid + (uint32_t)j * ROW_BLOCK;
-        const float v = xrow[tok < nvocab ? tok : nvocab - 1];      // clamped: no long-lived predicate per item
-        x[j] = tok < nvocab ? v : ninf;
-        nan |= (x[j] != x[j]);
-        mx = fmaxf(mx, x[j]);
-        if (j % 16 == 15) __builtin_amdgcn_sched_barrier(0);       // sixteen loads in flight at a time
-    }
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o));
-    const uint64_t any_nan = __ballot(nan);
-    if (lane == 0) { s_a[wv] = mx; s_b[wv] = any_nan ? 1.f : 0.f; }
-    if (tid == 0) { s_n = 0; s_total = 0; }
-    // the row's bitmap -> LDS
-    const uint32_t *b = bits + (row_broadcast_bits ? 0 : (uint64_t)row * words_per_row);
-    for (uint32_t w = tid; w < (uint32_t)(ITEMS * 32); w += ROW_BLOCK) {
-        uint32_t word = w < words_per_row && 32 * w < nvocab ? b[w] : 0u;
-        if (32 * w + 32 > nvocab && 32 * w < nvocab) word &= (1u << (nvocab - 32 * w)) - 1;     // tokens >= vocab do not exist
-        s_bm[w] = word;
-    }
-    __syncthreads();
-    mx = s_a[0];
-    float nn = 0.f;
-    for (int i = 0; i < ROW_BLOCK / 64; i++) { mx = fmaxf(mx, s_a[i]); nn += s_b[i]; }
-    const bool row_nan = nn > 0.f;
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < ITEMS; j++) {
-        sum += expf(x[j] - mx);                 // padding items are -inf: they add exactly 0
-        __builtin_amdgcn_sched_barrier(0);      // one expf at a time: the ITEMS logits stay in registers, nothing else may pile up
-    }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
-    __syncthreads();
-    if (lane == 0) s_a[wv] = sum;
-    // allowed tokens of this thread: bit j <-> token tid + 1024 j
-    // (am is laundered through an empty asm before each unrolled loop that tests its bits: otherwise the
-    // compiler hoists the ITEMS per-item predicates out of the loops and parks them in 2 x ITEMS SGPRs)
-    uint64_t am = 0;
-#pragma unroll
-    for (int j = 0; j < ITEMS; j++) am |= (uint64_t)((s_bm[(tid >> 5) + 32 * j] >> (tid & 31)) & 1u) << j;
-    {
-        uint32_t c = (uint32_t)__popcll(am);
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-        if (lane == 0 && c) atomicAdd(&s_total, c);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float tot = 0.f;
-        for (int i = 0; i < ROW_BLOCK / 64; i++) tot += s_a[i];
-        const float qnan = __builtin_nanf("");
-        const float l = row_nan ? qnan : logf(tot);
-        row_max[row] = row_nan ? qnan : mx;
-        row_lsum[row] = l;
-        s_ls = l;
-    }
-    __syncthreads();
-    float ls = s_ls;       // (laundered with am: the keys are recomputed where they are used, not kept in ITEMS more registers)
-    if (row_nan) mx = __builtin_nanf("");
-    const uint32_t total = s_total;
-    const uint32_t k_sel = total < want ? total : want;
-    if (k_sel == 0) { if (tid == 0) row_cnt[row] = 0; return; }
-    // ---- which keys can be among the k_sel best: all of them, or (key >> sh) >= thr ----
-    const bool all = total <= (narrow_max > want ? narrow_max : want);
-    uint32_t sh = 0, thr = 0, need = want;
-    bool exact_ties = false;
-    if (!all) {
-        uint32_t prefix_hi = 0;
-        for (int rd = 0; rd < 3; rd++) {
-            const uint32_t width = rd == 2 ? 8u : 12u;
-            sh = rd == 0 ? 20u : (rd == 1 ? 8u : 0u);
-            for (uint32_t i = tid; i < (uint32_t)SEL_BINS; i += ROW_BLOCK) s_hist[i] = 0u;
-            __syncthreads();
-            { uint32_t al = (uint32_t)am, ah = (uint32_t)(am >> 32); asm volatile("" : "+v"(al), "+v"(ah), "+v"(ls)); am = (uint64_t)al | ((uint64_t)ah << 32); }
-#pragma unroll
-            for (int j = 0; j < ITEMS; j++) {
-                if (!((am >> j) & 1)) continue;
-                const uint32_t key = float_key(logp_processed(x[j], mx, ls));
-                if (rd == 0 || (key >> (sh + width)) == prefix_hi) atomicAdd(&s_hist[(key >> sh) & ((1u << width) - 1)], 1u);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();
-            // the bin B with  #(keys in bins > B) < need <= #(keys in bins >= B): suffix sums, 4 bins per thread
-            const uint32_t h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
-            const uint32_t mine = h0 + h1 + h2 + h3;
-            uint32_t inc = mine;
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_down(inc, o); if (lane + o < 64) inc += v; }
-            if (lane == 0) s_wave[wv] = inc;
-            __syncthreads();
-            uint32_t running = inc - mine;
-            for (uint32_t w = wv + 1; w < ROW_BLOCK / 64; w++) running += s_wave[w];
-            const uint32_t hh[4] = {h0, h1, h2, h3};
-#pragma unroll
-            for (int q = 3; q >= 0; q--) {
-                if (running < need && need <= running + hh[q]) { s_bin = 4 * tid + q; s_above = running; s_inbin = hh[q]; }
-                running += hh[q];
-            }
-            __syncthreads();
-            const uint32_t above = s_above, inbin = s_inbin;
-            thr = (prefix_hi << width) | s_bin;
-            const uint32_t certain = (want - need) + above;          // keys known to be above the target's bin
-            if (certain + inbin <= (uint32_t)SEL_CAP) break;
-            need -= above;
-            prefix_hi = thr;
-            if (rd == 2) exact_ties = true;
-            __syncthreads();
-        }
-    }
-    // ---- collect the candidates ----
-    { uint32_t al = (uint32_t)am, ah = (uint32_t)(am >> 32); asm volatile("" : "+v"(al), "+v"(ah), "+v"(ls)); am = (uint64_t)al | ((uint64_t)ah << 32); }
-#pragma unroll
-    for (int j = 0; j < ITEMS; j++) {
-        if (!((am >> j) & 1)) continue;
-        const float lp = logp_processed(x[j], mx, ls);
-        const uint32_t ks = float_key(lp) >> sh;
-        if (all || (exact_ties ? ks > thr : ks >= thr)) {
-            const uint32_t o = atomicAdd(&s_n, 1u);
-            s_ctok[o] = (int32_t)(tid + (uint32_t)j * ROW_BLOCK); s_cval[o] = lp;
-        }
-    }
-    __syncthreads();
-    uint32_t n_list = s_n;
-    if (exact_ties) {
-        // more than SEL_CAP keys equal to the target: the `need` lowest tokens among them, in token order
-        // (token = tid + 1024 j: j ascending, then tid)
-        uint32_t seen = 0;
-        { uint32_t al = (uint32_t)am, ah = (uint32_t)(am >> 32); asm volatile("" : "+v"(al), "+v"(ah), "+v"(ls)); am = (uint64_t)al | ((uint64_t)ah << 32); }
-#pragma unroll
-        for (int j = 0; j < ITEMS; j++) {
-            float lp = 0.f;
-            bool eq = false;
-            if ((am >> j) & 1) { lp = logp_processed(x[j], mx, ls); eq = float_key(lp) == thr; }
-            const uint64_t be = __ballot(eq);
-            if (lane == 0) s_wave[wv] = (uint32_t)__popcll(be);
-            __syncthreads();
-            uint32_t before = seen, chunk = 0;
-            for (uint32_t w = 0; w < ROW_BLOCK / 64; w++) { if (w < wv) before += s_wave[w]; chunk += s_wave[w]; }
-            before += (uint32_t)__popcll(be & ((1ull << lane) - 1));
-            if (eq && before < need) { s_ctok[n_list + before] = (int32_t)(tid + (uint32_t)j * ROW_BLOCK); s_cval[n_list + before] = lp; }
-            seen += chunk;
-            __syncthreads();
-            if (seen >= need) break;
-        }
-        n_list += need;
-    }
-    // ---- order them: value descending, ties to the lower token id ----
-    for (uint32_t i = tid; i < n_list; i += ROW_BLOCK) {
+    for (uint32_t i = threadIdx.x; i < n_list; i += PICK_BLOCK) {
         const float v = s_cval[i]; const int32_t t = s_ctok[i];
         uint32_t rank = 0;
         for (uint32_t j = 0; j < n_list; j++) {
@@ -961,47 +659,235 @@ __global__ __launch_bounds__(ROW_BLOCK) void k_row_select(const float *logits, c
         }
         if (rank < k_sel) { row_tok[(uint64_t)row * want + rank] = t; row_lp[(uint64_t)row * want + rank] = v; }
     }
+}
+
+__global__ __launch_bounds__(PICK_BLOCK) void k_row_pick(const float *logits, const uint32_t *bits, uint64_t words_per_row,
+                                                         uint32_t row_broadcast_bits, uint64_t vocab64, uint32_t want,
+                                                         float *row_max, float *row_lsum, int32_t *row_tok, float *row_lp,
+                                                         uint32_t *row_cnt, uint32_t narrow_max, uint32_t flags)
+{
+    extern __shared__ uint32_t s_bm[];               // the row's bitmap, words_per_row words
+    __shared__ int32_t s_ctok[PICK_CAP];
+    __shared__ float s_cval[PICK_CAP];
+    __shared__ uint32_t s_tmax[PICK_BLOCK];
+    __shared__ uint32_t s_hist[256];
+    __shared__ float s_a[PICK_WAVES], s_b[PICK_WAVES];
+    __shared__ float s_ls;
+    __shared__ uint32_t s_n, s_total, s_t0, s_prefix, s_remaining, s_tie_rank;
+    const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t vocab = (uint32_t)vocab64, wpr = (uint32_t)words_per_row;
+    const float *x = logits + (uint64_t)row * vocab64;
+    const float ninf = -__builtin_huge_valf();
+    // ---- sweep 1: max (and NaN) ----
+    float mx = ninf;
+    bool nan = false;
+    row_sweep(x, vocab, [&](uint32_t, float a) { nan |= (a != a); mx = fmaxf(mx, a); });
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o));
+    const uint64_t any_nan = __ballot(nan);
+    if (lane == 0) { s_a[wv] = mx; s_b[wv] = any_nan ? 1.f : 0.f; }
+    if (tid == 0) { s_n = 0; s_total = 0; s_prefix = 0; }
+    // the row's bitmap -> LDS (tokens >= vocab do not exist), number of allowed tokens
+    {
+        const uint32_t *b = bits + (row_broadcast_bits ? 0 : (uint64_t)row * words_per_row);
+        uint32_t c = 0;
+        for (uint32_t w = tid; w < wpr; w += PICK_BLOCK) {
+            uint32_t word = 32 * w < vocab ? b[w] : 0u;
+            if (32 * w + 32 > vocab && 32 * w < vocab) word &= (1u << (vocab - 32 * w)) - 1;
+            s_bm[w] = word;
+            c += (uint32_t)__popc(word);
+        }
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+        __syncthreads();
+        if (lane == 0 && c) atomicAdd(&s_total, c);
+    }
+    mx = s_a[0];
+    float nn = 0.f;
+    for (int i = 0; i < PICK_WAVES; i++) { mx = fmaxf(mx, s_a[i]); nn += s_b[i]; }
+    const bool row_nan = nn > 0.f;
+    // ---- sweep 2: sum(exp(x - max)) ----
+    float sum = 0.f;
+    row_sweep(x, vocab, [&](uint32_t, float a) { sum += expf(a - mx); });
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    __syncthreads();
+    if (lane == 0) s_a[wv] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < PICK_WAVES; i++) tot += s_a[i];
+        const float qnan = __builtin_nanf("");
+        const float l = row_nan ? qnan : logf(tot);
+        row_max[row] = row_nan ? qnan : mx;
+        row_lsum[row] = l;
+        s_ls = l;
+    }
+    __syncthreads();
+    const float ls = s_ls;
+    if (row_nan) mx = __builtin_nanf("");
+    const uint32_t total = s_total;
+    const uint32_t k_sel = total < want ? total : want;
+    if (k_sel == 0) { if (tid == 0) row_cnt[row] = 0; return; }
+    // ---- narrow row: walk the bitmap, rank everything ----
+    if (total <= (narrow_max > want ? narrow_max : want)) {
+        for (uint32_t w = tid; w < wpr; w += PICK_BLOCK) {
+            uint32_t word = s_bm[w];
+            while (word) {
+                const uint32_t tok = 32 * w + (uint32_t)__builtin_ctz(word);
+                word &= word - 1;
+                const uint32_t o = atomicAdd(&s_n, 1u);
+                s_ctok[o] = (int32_t)tok; s_cval[o] = logp_processed(x[tok], mx, ls);
+            }
+        }
+        __syncthreads();
+        pick_rank_and_store(s_ctok, s_cval, total, k_sel, row, want, row_tok, row_lp);
+        if (tid == 0) row_cnt[row] = k_sel;
+        return;
+    }
+    // ---- wide row: lower bound from the thread maxima, then the few keys above it ----
+    if (!(flags & PICK_NO_PREFILTER)) {
+        uint32_t tmax = 0;                       // below every real key (float_key(-inf) = 0x007fffff)
+        row_sweep(x, vocab, [&](uint32_t v, float a) {
+            const uint32_t key = bm_bit(s_bm, v) ? float_key(logp_processed(a, mx, ls)) : 0u;
+            tmax = key > tmax ? key : tmax;
+        });
+        s_tmax[tid] = tmax;
+        __syncthreads();
+        {
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < (uint32_t)PICK_BLOCK; j++) { const uint32_t o = s_tmax[j]; rank += (o > tmax) || (o == tmax && j < tid); }
+            if (rank == want - 1) s_t0 = tmax;   // want <= 64 < PICK_BLOCK: exactly one thread
+        }
+        __syncthreads();
+        const uint32_t t0 = s_t0;               // 0 when fewer than `want` threads own an allowed token: everything passes
+        row_sweep(x, vocab, [&](uint32_t v, float a) {
+            const float lp = logp_processed(a, mx, ls);
+            if (bm_bit(s_bm, v) && float_key(lp) >= t0) {
+                const uint32_t o = atomicAdd(&s_n, 1u);
+                if (o < (uint32_t)PICK_CAP) { s_ctok[o] = (int32_t)v; s_cval[o] = lp; }
+            }
+        });
+        __syncthreads();
+        const uint32_t n = s_n;
+        if (n <= (uint32_t)PICK_CAP) {
+            pick_rank_and_store(s_ctok, s_cval, n, k_sel, row, want, row_tok, row_lp);
+            if (tid == 0) row_cnt[row] = k_sel;
+            return;
+        }
+        __syncthreads();
+        if (tid == 0) s_n = 0;
+    }
+    // ---- exact radix select (mass ties): 4 x 8 bits pin the want-th largest key T ----
+    if (tid == 0) s_remaining = want;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        const uint32_t pmask = pass == 0 ? 0u : (~0u << (shift + 8));
+        row_sweep(x, vocab, [&](uint32_t v, float a) {
+            const uint32_t key = float_key(logp_processed(a, mx, ls));
+            if (bm_bit(s_bm, v) && (key & pmask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1u);
+        });
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t rem = s_remaining, bin = 255;
+            for (;; bin--) {
+                const uint32_t c = s_hist[bin];
+                if (c >= rem || bin == 0) break;
+                rem -= c;
+            }
+            s_remaining = rem;                 // rank of the target inside the chosen bin
+            s_prefix = prefix | (bin << shift);
+        }
+        __syncthreads();
+    }
+    const uint32_t T = s_prefix;
+    const uint32_t need_eq = s_remaining;       // ties with T still needed: the need_eq LOWEST tokens among them
+    // ties by token order without a token-ordered sweep: the token below which exactly need_eq ties lie is found
+    // by bisection on the token id (17 counting passes over the LDS bitmap words would need the keys; the ties
+    // are re-derived from the logits instead): count(ties with token < m) is monotone in m
+    uint32_t lo_t = 0, hi_t = vocab;            // smallest m with count(ties < m) >= need_eq
+    while (lo_t < hi_t) {
+        const uint32_t mid = lo_t + ((hi_t - lo_t) >> 1);
+        if (tid == 0) s_tie_rank = 0;
+        __syncthreads();
+        uint32_t c = 0;
+        row_sweep(x, vocab, [&](uint32_t v, float a) {
+            c += (v < mid && bm_bit(s_bm, v) && float_key(logp_processed(a, mx, ls)) == T) ? 1u : 0u;
+        });
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+        if (lane == 0 && c) atomicAdd(&s_tie_rank, c);
+        __syncthreads();
+        const uint32_t below = s_tie_rank;
+        __syncthreads();
+        if (below >= need_eq) hi_t = mid; else lo_t = mid + 1;
+    }
+    // lo_t = one past the need_eq-th lowest tie.  Collect keys > T and ties with token < lo_t: exactly k_sel entries
+    row_sweep(x, vocab, [&](uint32_t v, float a) {
+        const float lp = logp_processed(a, mx, ls);
+        const uint32_t key = float_key(lp);
+        if (bm_bit(s_bm, v) && (key > T || (key == T && v < lo_t))) {
+            const uint32_t o = atomicAdd(&s_n, 1u);
+            if (o < (uint32_t)PICK_CAP) { s_ctok[o] = (int32_t)v; s_cval[o] = lp; }
+        }
+    });
+    __syncthreads();
+    pick_rank_and_store(s_ctok, s_cval, k_sel, k_sel, row, want, row_tok, row_lp);
     if (tid == 0) row_cnt[row] = k_sel;
 }
 
-// one wavefront per query: merge the K per-row lists; fill up with not-allowed tokens (constrained
-// score -inf, as torch.topk would when a query has fewer than `want` finite candidates)
-__global__ __launch_bounds__(64) void k_query_merge(const float *logits, const uint32_t *bits, uint64_t words_per_row,
-                                                    uint32_t row_broadcast_bits, uint64_t vocab, uint32_t beams, uint32_t want,
-                                                    const float *beam_scores, const float *row_max, const float *row_lsum,
-                                                    const int32_t *row_tok, const float *row_lp, const uint32_t *row_cnt,
-                                                    int64_t *top_idx, float *top_con, float *top_unc)
+// One workgroup per query: merge the K per-row lists.  The lists (with the beam scores added) are staged in
+// LDS; every candidate finds its place in the merged order by itself -- its own position in its list plus, for
+// every other list, the number of entries that beat it (a binary search: the lists are sorted) -- and the
+// first `want` write themselves out.  If a query has fewer than `want` finite candidates the rest is filled
+// with not-allowed tokens (constrained score -inf, as torch.topk would).
+static constexpr int MERGE_BLOCK = 256;
+__global__ __launch_bounds__(MERGE_BLOCK) void k_query_merge(const float *logits, const uint32_t *bits, uint64_t words_per_row,
+                                                             uint32_t row_broadcast_bits, uint64_t vocab, uint32_t beams, uint32_t want,
+                                                             const float *beam_scores, const float *row_max, const float *row_lsum,
+                                                             const int32_t *row_tok, const float *row_lp, const uint32_t *row_cnt,
+                                                             int64_t *top_idx, float *top_con, float *top_unc)
 {
-    const uint32_t q = blockIdx.x, lane = threadIdx.x;
-    // lane l < beams walks row q*beams + l
-    const uint32_t row = q * beams + (lane < beams ? lane : 0);
-    uint32_t head = 0;
-    const uint32_t cnt = lane < beams ? row_cnt[row] : 0;
-    const float bs = beam_scores[row];
-    uint32_t out = 0;
-    for (; out < want; out++) {
-        float v = -__builtin_huge_valf(); int64_t idx = -1;
-        if (lane < beams && head < cnt) {
-            v = row_lp[(uint64_t)row * want + head] + bs;
-            idx = (int64_t)lane * (int64_t)vocab + row_tok[(uint64_t)row * want + head];
+    __shared__ float s_val[32 * TOPK_MAX];
+    __shared__ int32_t s_tok[32 * TOPK_MAX];
+    __shared__ uint32_t s_cnt[32];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n_all = beams * want;
+    if (tid < beams) s_cnt[tid] = row_cnt[q * beams + tid];
+    for (uint32_t i = tid; i < n_all; i += MERGE_BLOCK) {
+        const uint32_t bm = i / want, j = i - bm * want, r = q * beams + bm;
+        const bool ok = j < row_cnt[r];
+        s_val[i] = ok ? row_lp[(uint64_t)r * want + j] + beam_scores[r] : 0.f;
+        s_tok[i] = ok ? row_tok[(uint64_t)r * want + j] : -1;
+    }
+    __syncthreads();
+    uint32_t n_cand = 0;
+    for (uint32_t bm = 0; bm < beams; bm++) n_cand += s_cnt[bm];
+    for (uint32_t i = tid; i < n_all; i += MERGE_BLOCK) {
+        const uint32_t bm = i / want, j = i - bm * want;
+        if (j >= s_cnt[bm]) continue;
+        const float v = s_val[i]; const int32_t t = s_tok[i];
+        uint32_t rank = j;                                   // its own list is strictly ordered
+        for (uint32_t ob = 0; ob < beams; ob++) {
+            if (ob == bm) continue;
+            // entries of list ob that come before (v, bm, t): value descending, then the lower flat index
+            uint32_t lo = 0, hi = s_cnt[ob];
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const float ov = s_val[ob * want + mid];
+                const bool before = ov > v || (ov == v && (ob < bm || (ob == bm && s_tok[ob * want + mid] < t)));
+                if (before) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
         }
-        float bv = v; int64_t bi = idx;
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_down(bv, o); const int64_t oi = __shfl_down(bi, o);
-            if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
-        }
-        bv = __shfl(bv, 0); bi = __shfl(bi, 0);
-        if (bi < 0) break;
-        if (idx == bi) head++;
-        if (lane == 0) {
-            top_idx[(uint64_t)q * want + out] = bi;
-            top_con[(uint64_t)q * want + out] = bv;
-            top_unc[(uint64_t)q * want + out] = bv;      // allowed token: constrained == unconstrained
+        if (rank < want) {
+            top_idx[(uint64_t)q * want + rank] = (int64_t)bm * (int64_t)vocab + t;
+            top_con[(uint64_t)q * want + rank] = v;
+            top_unc[(uint64_t)q * want + rank] = v;          // allowed token: constrained == unconstrained
         }
     }
     // fillers: lowest flat indices that are NOT allowed (beam 0 first); constrained -inf, real unconstrained score
-    if (lane == 0) {
-        uint32_t beam = 0; uint64_t tok = 0;
+    if (tid == 0 && n_cand < want) {
+        uint32_t out = n_cand, beam = 0; uint64_t tok = 0;
         while (out < want && beam < beams) {
             const uint32_t r = q * beams + beam;
             const uint32_t *b = bits + (row_broadcast_bits ? 0 : (uint64_t)r * words_per_row);
@@ -1409,25 +1295,13 @@ extern "C" int fmi_dev_constrained_topk_step(fmi_t *h, void *stream, uint64_t ba
                                stop_at_count, always_allow_eos, state_tag, d_parent_rows, &bits);
         if (rc) return rc;
     }
-    const char *e_narrow = getenv("SEALFM_TOPK_NARROW");      // tests: 0 sends every row through the histogram rounds
+    const char *e_narrow = getenv("SEALFM_TOPK_NARROW");      // tests: 0 sends every row down the wide-row path
     const uint32_t narrow_max = e_narrow ? std::min<uint32_t>((uint32_t)atoi(e_narrow), TOPK_NARROW) : TOPK_NARROW;
-    const char *e_legacy = getenv("SEALFM_TOPK_LEGACY");      // tests: the two-kernel path (also the path of vocabularies > 102 400)
-    const uint64_t items = (vocab + ROW_BLOCK - 1) / ROW_BLOCK;
-    if ((e_legacy && atoi(e_legacy)) || items > 100) {
-        hipLaunchKernelGGL(k_row_lse, dim3((unsigned)rows), dim3(ROW_BLOCK), 0, st, d_logits, vocab, row_max, row_lsum);
-        hipLaunchKernelGGL(k_row_topk, dim3((unsigned)rows), dim3(ROW_BLOCK), 0, st, d_logits, bits, wpr, broadcast, vocab, row_max, row_lsum,
-                           (uint32_t)want, row_tok, row_lp, row_cnt, narrow_max);
-    } else {
-#define SEL_LAUNCH(N) hipLaunchKernelGGL(k_row_select<N>, dim3((unsigned)rows), dim3(ROW_BLOCK), 0, st, d_logits, bits, wpr, broadcast, \
-                                         vocab, (uint32_t)want, row_max, row_lsum, row_tok, row_lp, row_cnt, narrow_max)
-        if (items <= 4) SEL_LAUNCH(4);
-        else if (items <= 16) SEL_LAUNCH(16);
-        else if (items <= 50) SEL_LAUNCH(50);           // BART: 50 265 tokens
-        else if (items <= 64) SEL_LAUNCH(64);
-        else SEL_LAUNCH(100);
-#undef SEL_LAUNCH
-    }
-    hipLaunchKernelGGL(k_query_merge, dim3((unsigned)batch), dim3(64), 0, st, d_logits, bits, wpr, broadcast, vocab, (uint32_t)beams,
+    const char *e_legacy = getenv("SEALFM_TOPK_LEGACY");      // tests: wide rows skip the thread-maxima bound and radix-select
+    const uint32_t pick_flags = (e_legacy && atoi(e_legacy)) ? (uint32_t)PICK_NO_PREFILTER : 0u;
+    hipLaunchKernelGGL(k_row_pick, dim3((unsigned)rows), dim3(PICK_BLOCK), wpr * 4, st, d_logits, bits, wpr, broadcast, vocab,
+                       (uint32_t)want, row_max, row_lsum, row_tok, row_lp, row_cnt, narrow_max, pick_flags);
+    hipLaunchKernelGGL(k_query_merge, dim3((unsigned)batch), dim3(MERGE_BLOCK), 0, st, d_logits, bits, wpr, broadcast, vocab, (uint32_t)beams,
                        (uint32_t)want, d_beam_scores, row_max, row_lsum, row_tok, row_lp, row_cnt, d_top_idx, d_top_con, d_top_unc);
     HIPCHK(hipGetLastError());
     return FMI_OK;

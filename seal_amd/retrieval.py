@@ -630,7 +630,8 @@ class SEALSearcher:
             pipe = free.get()
             try:
                 torch.cuda.set_device(dev)
-                with torch.cuda.stream(pipe.stream):
+                from .bart_decoder import CAPTURE_GATE
+                with CAPTURE_GATE.issuing(), torch.cuda.stream(pipe.stream):
                     keys = _process_batch(self, batch, constrained, offset, pipe)
                     jobs = [(kk[0], kk[1]) if isinstance(kk, tuple) else (kk, None) for kk in keys]
                     out = rk.aggregate_evidence_batch(jobs, pipe.index, keep=keep, gpu_aggregate=True, want_ngrams=False, **params)

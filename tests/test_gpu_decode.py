@@ -296,12 +296,12 @@ def test_topk_selection_paths_agree_on_ties(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["randn", "five-values", "constant", "nan-row"])
-def test_row_select_at_bart_vocabulary_agrees_with_the_two_kernel_path_and_torch(kind, monkeypatch):
-    """k_row_select<50> (one pass, logits in registers: the decode step's kernel at BART's 50 265 tokens) against the
-    two-kernel path k_row_lse + k_row_topk it replaces (exactly equal picks, order and scores, ties included) and
-    against the reference's op sequence in torch (beam_search.py:244-307).  Allowed sets from 5 to 45 000 tokens per
-    row: direct LDS ranking, one histogram round, and -- on constant logits -- the further rounds and the token-order
-    tie path (more than 1024 equal keys)."""
+def test_row_pick_paths_agree_at_bart_vocabulary_and_match_torch(kind, monkeypatch):
+    """k_row_pick at BART's 50 265 tokens: its three selection paths -- bitmap walk + LDS ranking (narrow rows), the
+    thread-maxima lower bound (wide rows), the exact radix select (mass ties; forced with SEALFM_TOPK_LEGACY) -- return
+    exactly the same picks, order and scores, ties included, and agree with the reference's op sequence in torch
+    (beam_search.py:244-307).  Allowed sets from 5 to 45 000 tokens per row; constant logits put > 1024 equal keys in
+    front of the lower bound, i.e. exercise the automatic fall-through to the radix select and its token-order ties."""
     import ctypes
     from seal_amd import FMIndex
     from seal_amd._lib import check, lib
@@ -338,8 +338,8 @@ def test_row_select_at_bart_vocabulary_agrees_with_the_two_kernel_path_and_torch
         logits = logits.to(dev).contiguous()
         beam_scores = (torch.randn(rows, generator=g) * 2).to(dev)
         got = {}
-        for mode, env in (("select", {}), ("select-rounds", {"SEALFM_TOPK_NARROW": "0"}), ("two-kernel", {"SEALFM_TOPK_LEGACY": "1"}),
-                          ("two-kernel-radix", {"SEALFM_TOPK_LEGACY": "1", "SEALFM_TOPK_NARROW": "0"})):
+        for mode, env in (("select", {}), ("wide-path", {"SEALFM_TOPK_NARROW": "0"}), ("radix", {"SEALFM_TOPK_LEGACY": "1"}),
+                          ("radix-everywhere", {"SEALFM_TOPK_LEGACY": "1", "SEALFM_TOPK_NARROW": "0"})):
             for k in ("SEALFM_TOPK_NARROW", "SEALFM_TOPK_LEGACY"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
@@ -352,7 +352,7 @@ def test_row_select_at_bart_vocabulary_agrees_with_the_two_kernel_path_and_torch
                                                       top_idx.data_ptr(), top_con.data_ptr(), top_unc.data_ptr(), 0, None))
             torch.cuda.synchronize()
             got[mode] = (top_idx.cpu(), top_con.cpu(), top_unc.cpu())
-        for mode in ("select-rounds", "two-kernel", "two-kernel-radix"):
+        for mode in ("wide-path", "radix", "radix-everywhere"):
             for a, b in zip(got["select"], got[mode]):
                 assert torch.equal(a, b) or torch.equal(torch.nan_to_num(a.float(), nan=7.0), torch.nan_to_num(b.float(), nan=7.0)), (n_allowed, mode)
         if kind == "nan-row":
