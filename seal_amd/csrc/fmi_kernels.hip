@@ -605,15 +605,16 @@ __device__ __forceinline__ uint32_t float_key(float f)
 // ALLOWED tokens by processed log-prob (descending, ties to the lower token id) -> row_tok / row_lp
 // [rows, want]; row_cnt = how many exist.  The row (200 KB at BART's vocabulary) is streamed from L2 with
 // coalesced loads, a few registers per thread, so that all rows of a decode step are resident at once:
-//   sweep 1, 2   max, log(sum(exp(x - max)))                    (every row)
+//   sweep 1      max and log(sum(exp(x - max))) in one pass (running maximum), and every thread's best allowed
+//                logit on the side                                                           (every row)
 //   narrow rows  (<= 1024 allowed tokens): the allowed tokens are gathered by walking the bitmap and ranked
 //                in LDS -- nothing else is read;
-//   wide rows    sweep 3: every thread's best allowed key; the want-th largest of the 512 thread maxima is a
-//                lower bound of the want-th largest key of the row, so sweep 4 collects the keys >= it (a few
-//                dozen on any real distribution) and they are ranked in LDS.  No histogram, no atomics
-//                beyond the list counter.  Only if more than PICK_CAP keys pass (mass ties) the exact radix
-//                select runs: four 8-bit histogram passes pin the want-th largest key, one pass collects the
-//                keys above it and the lowest tokens among its ties.
+//   wide rows    a lower bound of the want-th best allowed log-prob from the threads' best logits (log-softmax
+//                is monotone in the logit): sweep 2 collects the allowed tokens that reach it -- a few dozen on
+//                any real distribution -- and they are ranked in LDS.  No histogram, no atomics beyond the
+//                list counter.  Only if more than PICK_CAP keys pass (mass ties) the exact radix select runs:
+//                four 8-bit histogram passes pin the want-th largest key, a bisection on the token id finds the
+//                lowest tokens among its ties.
 static constexpr int PICK_BLOCK = 512;
 static constexpr int PICK_WAVES = PICK_BLOCK / 64;
 static constexpr int PICK_CAP = 1024;        // candidate list in LDS; also the widest "narrow" row
@@ -636,7 +637,7 @@ __device__ __forceinline__ void row_sweep(const float *x, uint32_t vocab, F &&f)
     if (tid < head) f(tid, x[tid]);
     const float4 *x4 = reinterpret_cast<const float4 *>(x + head);
     const uint32_t n4 = (vocab - head) >> 2;
-#pragma unroll 4
+#pragma unroll 8
     for (uint32_t i = tid; i < n4; i += PICK_BLOCK) {
         const float4 v = x4[i];
         const uint32_t t = head + 4 * i;
@@ -644,6 +645,52 @@ __device__ __forceinline__ void row_sweep(const float *x, uint32_t vocab, F &&f)
     }
     const uint32_t t = head + 4 * n4 + tid;
     if (t < vocab) f(t, x[t]);
+}
+
+// r-th largest of the 64 values of a wave (r >= 1, duplicates count separately), -inf if there are fewer
+__device__ __forceinline__ float wave_rth_largest(float v, uint32_t r)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    float m = v;
+    for (uint32_t k = 0; k < r; k++) {
+        m = v;
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const uint64_t at = __ballot(v == m);
+        if (at && lane == (uint32_t)__builtin_ctzll(at)) v = -__builtin_huge_valf();     // take one holder of the maximum out
+    }
+    return m;
+}
+
+// A lower bound of the want-th largest value among the values the threads of the workgroup have seen, from
+// the threads' own maxima: every wave contributes its ceil(want / waves)-th largest thread maximum, the
+// smallest of those is returned -- at least `want` thread maxima, hence at least `want` values, are >= it.
+// (-inf when some wave has too few threads with a value: then everything passes.)
+__device__ __forceinline__ float block_lower_bound(float tmax, uint32_t want, float *s_w /* PICK_WAVES floats */)
+{
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float mine = wave_rth_largest(tmax, (want + PICK_WAVES - 1) / PICK_WAVES);
+    __syncthreads();
+    if (lane == 0) s_w[wv] = mine;
+    __syncthreads();
+    float b = s_w[0];
+    for (int i = 1; i < PICK_WAVES; i++) b = fminf(b, s_w[i]);
+    return b;
+}
+
+// the same walk with the aligned body handed over four logits at a time
+template <typename F1, typename F4>
+__device__ __forceinline__ void row_sweep_chunks(const float *x, uint32_t vocab, F1 &&f1, F4 &&f4)
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t head = (4u - (uint32_t)((reinterpret_cast<uintptr_t>(x) >> 2) & 3u)) & 3u;
+    if (head > vocab) head = vocab;
+    if (tid < head) f1(tid, x[tid]);
+    const float4 *x4 = reinterpret_cast<const float4 *>(x + head);
+    const uint32_t n4 = (vocab - head) >> 2;
+#pragma unroll 8
+    for (uint32_t i = tid; i < n4; i += PICK_BLOCK) f4(head + 4 * i, x4[i]);
+    const uint32_t t = head + 4 * n4 + tid;
+    if (t < vocab) f1(t, x[t]);
 }
 
 // the n_list candidates in s_ctok / s_cval -> their places under (value descending, token ascending); the first k_sel leave
@@ -661,61 +708,110 @@ __device__ __forceinline__ void pick_rank_and_store(const int32_t *s_ctok, const
     }
 }
 
+// n candidates in LDS (n <= PICK_CAP) -> the k_sel best written out.  Ranking is quadratic, so a long list is
+// first cut down with the same lower bound (over the list entries, two per thread) to a second, short list.
+static constexpr uint32_t PICK_DIRECT = 128;     // lists up to this length are ranked as they are
+static constexpr uint32_t PICK_SHORT = 256;      // capacity of the short list
+__device__ __forceinline__ void pick_finish(const int32_t *s_ctok, const float *s_cval, int32_t *s_tok2, float *s_val2, float *s_w,
+                                            uint32_t *s_n2, uint32_t n, uint32_t k_sel, uint32_t row, uint32_t want,
+                                            int32_t *row_tok, float *row_lp)
+{
+    const uint32_t tid = threadIdx.x;
+    if (n > PICK_DIRECT && k_sel == want) {
+        const float ninf = -__builtin_huge_valf();
+        const float a = tid < n ? s_cval[tid] : ninf, b = tid + PICK_BLOCK < n ? s_cval[tid + PICK_BLOCK] : ninf;
+        const float bound = block_lower_bound(fmaxf(a, b), want, s_w);
+        if (tid == 0) *s_n2 = 0;
+        __syncthreads();
+        if (tid < n && a >= bound) { const uint32_t o = atomicAdd(s_n2, 1u); if (o < PICK_SHORT) { s_tok2[o] = s_ctok[tid]; s_val2[o] = a; } }
+        if (tid + PICK_BLOCK < n && b >= bound) { const uint32_t o = atomicAdd(s_n2, 1u); if (o < PICK_SHORT) { s_tok2[o] = s_ctok[tid + PICK_BLOCK]; s_val2[o] = b; } }
+        __syncthreads();
+        const uint32_t n2 = *s_n2;
+        if (n2 <= PICK_SHORT) { pick_rank_and_store(s_tok2, s_val2, n2, k_sel, row, want, row_tok, row_lp); return; }
+    }
+    pick_rank_and_store(s_ctok, s_cval, n, k_sel, row, want, row_tok, row_lp);
+}
+
 __global__ __launch_bounds__(PICK_BLOCK) void k_row_pick(const float *logits, const uint32_t *bits, uint64_t words_per_row,
                                                          uint32_t row_broadcast_bits, uint64_t vocab64, uint32_t want,
                                                          float *row_max, float *row_lsum, int32_t *row_tok, float *row_lp,
                                                          uint32_t *row_cnt, uint32_t narrow_max, uint32_t flags)
 {
-    extern __shared__ uint32_t s_bm[];               // the row's bitmap, words_per_row words
+    extern __shared__ uint32_t s_bm[];               // the row's bitmap, words_per_row words + one zero word
     __shared__ int32_t s_ctok[PICK_CAP];
     __shared__ float s_cval[PICK_CAP];
-    __shared__ uint32_t s_tmax[PICK_BLOCK];
+    __shared__ int32_t s_tok2[PICK_SHORT];
+    __shared__ float s_val2[PICK_SHORT];
     __shared__ uint32_t s_hist[256];
-    __shared__ float s_a[PICK_WAVES], s_b[PICK_WAVES];
+    __shared__ float s_a[PICK_WAVES], s_b[PICK_WAVES], s_w[PICK_WAVES];
+    __shared__ uint32_t s_scan[PICK_WAVES];
     __shared__ float s_ls;
-    __shared__ uint32_t s_n, s_total, s_t0, s_prefix, s_remaining, s_tie_rank;
+    __shared__ uint32_t s_n, s_n2, s_prefix, s_remaining, s_tie_rank;
     const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t vocab = (uint32_t)vocab64, wpr = (uint32_t)words_per_row;
     const float *x = logits + (uint64_t)row * vocab64;
     const float ninf = -__builtin_huge_valf();
-    // ---- sweep 1: max (and NaN) ----
-    float mx = ninf;
-    bool nan = false;
-    row_sweep(x, vocab, [&](uint32_t, float a) { nan |= (a != a); mx = fmaxf(mx, a); });
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o));
-    const uint64_t any_nan = __ballot(nan);
-    if (lane == 0) { s_a[wv] = mx; s_b[wv] = any_nan ? 1.f : 0.f; }
-    if (tid == 0) { s_n = 0; s_total = 0; s_prefix = 0; }
-    // the row's bitmap -> LDS (tokens >= vocab do not exist), number of allowed tokens
+    // ---- the row's bitmap -> LDS (tokens >= vocab do not exist); allowed tokens per thread, scanned ----
+    uint32_t my_allowed = 0;
     {
         const uint32_t *b = bits + (row_broadcast_bits ? 0 : (uint64_t)row * words_per_row);
-        uint32_t c = 0;
         for (uint32_t w = tid; w < wpr; w += PICK_BLOCK) {
             uint32_t word = 32 * w < vocab ? b[w] : 0u;
             if (32 * w + 32 > vocab && 32 * w < vocab) word &= (1u << (vocab - 32 * w)) - 1;
             s_bm[w] = word;
-            c += (uint32_t)__popc(word);
+            my_allowed += (uint32_t)__popc(word);
         }
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-        __syncthreads();
-        if (lane == 0 && c) atomicAdd(&s_total, c);
     }
-    mx = s_a[0];
-    float nn = 0.f;
-    for (int i = 0; i < PICK_WAVES; i++) { mx = fmaxf(mx, s_a[i]); nn += s_b[i]; }
-    const bool row_nan = nn > 0.f;
-    // ---- sweep 2: sum(exp(x - max)) ----
-    float sum = 0.f;
-    row_sweep(x, vocab, [&](uint32_t, float a) { sum += expf(a - mx); });
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    if (tid == 0) { s_n = 0; s_prefix = 0; s_bm[wpr] = 0u; }
+    uint32_t incl = my_allowed;                      // inclusive scan over the workgroup (slots of the narrow-row gather)
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += v; }
+    if (lane == 63) s_scan[wv] = incl;
     __syncthreads();
-    if (lane == 0) s_a[wv] = sum;
+    uint32_t before = incl - my_allowed, total = 0;
+    for (uint32_t w = 0; w < (uint32_t)PICK_WAVES; w++) { if (w < wv) before += s_scan[w]; total += s_scan[w]; }
+    // ---- sweep 1: max and sum(exp(x - max)) in ONE pass (running maximum, the sum rescaled when it moves: once
+    // per float4 at most, rarely after the first few).  Five instructions per logit: the pass has to stay
+    // memory-bound (300 rows x 50 265 logits per decode step).  The running maximum starts at -FLT_MAX, so that
+    // a -inf logit adds exp(-inf) = 0 without a special case; NaN / +inf logits make the sum NaN, which is what
+    // marks the row (as log_softmax would).  Wide rows also track the thread's best ALLOWED logit (log-softmax
+    // is monotone in the logit); narrow rows do not need it.
+    const bool wide = total > (narrow_max > want ? narrow_max : want);
+    float mx = -3.402823466e+38f, sum = 0.f, tbest = ninf;
+    auto one = [&](uint32_t v, float a) {
+        if (a > mx) { sum *= __expf(mx - a); mx = a; }
+        sum += __expf(a - mx);
+        if (wide) tbest = bm_bit(s_bm, v) ? fmaxf(tbest, a) : tbest;
+    };
+    row_sweep_chunks(x, vocab, one,
+        [&](uint32_t v, float4 q) {
+            const float m4 = fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w));
+            if (m4 > mx) { sum *= __expf(mx - m4); mx = m4; }
+            sum += (__expf(q.x - mx) + __expf(q.y - mx)) + (__expf(q.z - mx) + __expf(q.w - mx));
+            if (wide) {
+                // the four bitmap bits of tokens v .. v+3 (they may straddle two words; s_bm has a spare zero word)
+                const uint32_t w0 = s_bm[v >> 5], w1 = s_bm[(v >> 5) + 1];
+                const uint32_t b4 = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (v & 31));
+                tbest = (b4 & 1) ? fmaxf(tbest, q.x) : tbest;
+                tbest = (b4 & 2) ? fmaxf(tbest, q.y) : tbest;
+                tbest = (b4 & 4) ? fmaxf(tbest, q.z) : tbest;
+                tbest = (b4 & 8) ? fmaxf(tbest, q.w) : tbest;
+            }
+        });
+    // (max, sum) pairs combine as  M = max(m1, m2),  S = s1 exp(m1 - M) + s2 exp(m2 - M)
+    auto combine = [&](float &m1, float &s1, float m2, float s2) {
+        const float M = fmaxf(m1, m2);
+        s1 = s1 * __expf(m1 - M) + s2 * __expf(m2 - M);
+        m1 = M;
+    };
+    for (int o = 32; o > 0; o >>= 1) { const float m2 = __shfl_xor(mx, o), s2 = __shfl_xor(sum, o); combine(mx, sum, m2, s2); }
+    if (lane == 0) { s_a[wv] = mx; s_b[wv] = sum; }
     __syncthreads();
+    mx = s_a[0]; sum = s_b[0];
+    for (int i = 1; i < PICK_WAVES; i++) combine(mx, sum, s_a[i], s_b[i]);
+    const bool row_nan = sum != sum;             // a NaN or +inf logit
     if (tid == 0) {
-        float tot = 0.f;
-        for (int i = 0; i < PICK_WAVES; i++) tot += s_a[i];
         const float qnan = __builtin_nanf("");
-        const float l = row_nan ? qnan : logf(tot);
+        const float l = row_nan ? qnan : logf(sum);
         row_max[row] = row_nan ? qnan : mx;
         row_lsum[row] = l;
         s_ls = l;
@@ -723,52 +819,54 @@ __global__ __launch_bounds__(PICK_BLOCK) void k_row_pick(const float *logits, co
     __syncthreads();
     const float ls = s_ls;
     if (row_nan) mx = __builtin_nanf("");
-    const uint32_t total = s_total;
     const uint32_t k_sel = total < want ? total : want;
     if (k_sel == 0) { if (tid == 0) row_cnt[row] = 0; return; }
-    // ---- narrow row: walk the bitmap, rank everything ----
+    // ---- narrow row: walk the bitmap into the list (slots from the scan, no atomics), then pick ----
     if (total <= (narrow_max > want ? narrow_max : want)) {
+        uint32_t o = before;
         for (uint32_t w = tid; w < wpr; w += PICK_BLOCK) {
             uint32_t word = s_bm[w];
             while (word) {
                 const uint32_t tok = 32 * w + (uint32_t)__builtin_ctz(word);
                 word &= word - 1;
-                const uint32_t o = atomicAdd(&s_n, 1u);
                 s_ctok[o] = (int32_t)tok; s_cval[o] = logp_processed(x[tok], mx, ls);
+                o++;
             }
         }
         __syncthreads();
-        pick_rank_and_store(s_ctok, s_cval, total, k_sel, row, want, row_tok, row_lp);
+        pick_finish(s_ctok, s_cval, s_tok2, s_val2, s_w, &s_n2, total, k_sel, row, want, row_tok, row_lp);
         if (tid == 0) row_cnt[row] = k_sel;
         return;
     }
-    // ---- wide row: lower bound from the thread maxima, then the few keys above it ----
+    // ---- wide row: sweep 3 collects what reaches the lower bound of the thread maxima ----
     if (!(flags & PICK_NO_PREFILTER)) {
-        uint32_t tmax = 0;                       // below every real key (float_key(-inf) = 0x007fffff)
-        row_sweep(x, vocab, [&](uint32_t v, float a) {
-            const uint32_t key = bm_bit(s_bm, v) ? float_key(logp_processed(a, mx, ls)) : 0u;
-            tmax = key > tmax ? key : tmax;
-        });
-        s_tmax[tid] = tmax;
-        __syncthreads();
-        {
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < (uint32_t)PICK_BLOCK; j++) { const uint32_t o = s_tmax[j]; rank += (o > tmax) || (o == tmax && j < tid); }
-            if (rank == want - 1) s_t0 = tmax;   // want <= 64 < PICK_BLOCK: exactly one thread
-        }
-        __syncthreads();
-        const uint32_t t0 = s_t0;               // 0 when fewer than `want` threads own an allowed token: everything passes
-        row_sweep(x, vocab, [&](uint32_t v, float a) {
+        const float xb = block_lower_bound(tbest, want, s_w);
+        const float lpb = xb == ninf ? ninf : logp_processed(xb, mx, ls);      // at least `want` allowed tokens have lp >= lpb
+        // a logit below xb can still round to lp == lpb; anything below xb - margin cannot (the margin is far above
+        // the two roundings of (x - max) - lsum), so one compare on the raw logit rejects almost everything
+        const float xcut = (xb == ninf || lpb != lpb) ? ninf : xb - (1e-3f + (fabsf(xb) + fabsf(mx) + fabsf(ls)) * 1e-6f);
+        auto take = [&](uint32_t v, float a) {
             const float lp = logp_processed(a, mx, ls);
-            if (bm_bit(s_bm, v) && float_key(lp) >= t0) {
+            if (lp >= lpb) {
                 const uint32_t o = atomicAdd(&s_n, 1u);
                 if (o < (uint32_t)PICK_CAP) { s_ctok[o] = (int32_t)v; s_cval[o] = lp; }
             }
-        });
+        };
+        row_sweep_chunks(x, vocab,
+            [&](uint32_t v, float a) { if (bm_bit(s_bm, v) && !(a < xcut)) take(v, a); },
+            [&](uint32_t v, float4 q) {
+                const uint32_t w0 = s_bm[v >> 5], w1 = s_bm[(v >> 5) + 1];
+                const uint32_t b4 = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (v & 31)) & 15u;
+                if (!b4) return;
+                if ((b4 & 1) && !(q.x < xcut)) take(v, q.x);
+                if ((b4 & 2) && !(q.y < xcut)) take(v + 1, q.y);
+                if ((b4 & 4) && !(q.z < xcut)) take(v + 2, q.z);
+                if ((b4 & 8) && !(q.w < xcut)) take(v + 3, q.w);
+            });
         __syncthreads();
         const uint32_t n = s_n;
         if (n <= (uint32_t)PICK_CAP) {
-            pick_rank_and_store(s_ctok, s_cval, n, k_sel, row, want, row_tok, row_lp);
+            pick_finish(s_ctok, s_cval, s_tok2, s_val2, s_w, &s_n2, n, k_sel, row, want, row_tok, row_lp);
             if (tid == 0) row_cnt[row] = k_sel;
             return;
         }
@@ -802,9 +900,8 @@ __global__ __launch_bounds__(PICK_BLOCK) void k_row_pick(const float *logits, co
     }
     const uint32_t T = s_prefix;
     const uint32_t need_eq = s_remaining;       // ties with T still needed: the need_eq LOWEST tokens among them
-    // ties by token order without a token-ordered sweep: the token below which exactly need_eq ties lie is found
-    // by bisection on the token id (17 counting passes over the LDS bitmap words would need the keys; the ties
-    // are re-derived from the logits instead): count(ties with token < m) is monotone in m
+    // the token below which exactly need_eq ties lie, by bisection on the token id (the count of ties below m is
+    // monotone in m; every probe is one sweep -- this path only runs on mass ties)
     uint32_t lo_t = 0, hi_t = vocab;            // smallest m with count(ties < m) >= need_eq
     while (lo_t < hi_t) {
         const uint32_t mid = lo_t + ((hi_t - lo_t) >> 1);
@@ -850,14 +947,20 @@ __global__ __launch_bounds__(MERGE_BLOCK) void k_query_merge(const float *logits
     __shared__ float s_val[32 * TOPK_MAX];
     __shared__ int32_t s_tok[32 * TOPK_MAX];
     __shared__ uint32_t s_cnt[32];
+    __shared__ uint32_t s_fill[MERGE_BLOCK / 64];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t n_all = beams * want;
+    const float qnan = __builtin_nanf("");          // padding: compares false with everything, so it is never `before` anything
     if (tid < beams) s_cnt[tid] = row_cnt[q * beams + tid];
     for (uint32_t i = tid; i < n_all; i += MERGE_BLOCK) {
         const uint32_t bm = i / want, j = i - bm * want, r = q * beams + bm;
-        const bool ok = j < row_cnt[r];
-        s_val[i] = ok ? row_lp[(uint64_t)r * want + j] + beam_scores[r] : 0.f;
-        s_tok[i] = ok ? row_tok[(uint64_t)r * want + j] : -1;
+        // every load is issued before any is needed; entries past the end of a list become NaN: they beat
+        // nothing (not even a -inf candidate), so the searches below need no list lengths
+        const uint32_t c = row_cnt[r];
+        const float lp = row_lp[(uint64_t)r * want + j], bs = beam_scores[r];
+        const int32_t tk = row_tok[(uint64_t)r * want + j];
+        s_val[i] = j < c ? lp + bs : qnan;
+        s_tok[i] = j < c ? tk : 0x7fffffff;
     }
     __syncthreads();
     uint32_t n_cand = 0;
@@ -867,17 +970,23 @@ __global__ __launch_bounds__(MERGE_BLOCK) void k_query_merge(const float *logits
         if (j >= s_cnt[bm]) continue;
         const float v = s_val[i]; const int32_t t = s_tok[i];
         uint32_t rank = j;                                   // its own list is strictly ordered
+#pragma unroll 4
         for (uint32_t ob = 0; ob < beams; ob++) {
-            if (ob == bm) continue;
-            // entries of list ob that come before (v, bm, t): value descending, then the lower flat index
-            uint32_t lo = 0, hi = s_cnt[ob];
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                const float ov = s_val[ob * want + mid];
-                const bool before = ov > v || (ov == v && (ob < bm || (ob == bm && s_tok[ob * want + mid] < t)));
-                if (before) lo = mid + 1; else hi = mid;
+            // entries of list ob that come before (v, bm, t): value descending, then the lower flat index; a
+            // branch-free lower bound over the padded list, so that the searches of several lists overlap
+            const float *lv = s_val + ob * want;
+            const int32_t *lt = s_tok + ob * want;
+            uint32_t pos = 0;
+#pragma unroll
+            for (uint32_t step = 64; step; step >>= 1) {
+                const uint32_t probe = pos + step - 1;
+                const bool in = pos + step <= want;
+                const float ov = lv[in ? probe : 0];
+                const int32_t ot = lt[in ? probe : 0];
+                const bool before = ov > v || (ov == v && (ob < bm || (ob == bm && ot < t)));
+                pos += (in && before) ? step : 0;
             }
-            rank += lo;
+            rank += ob == bm ? 0 : pos;
         }
         if (rank < want) {
             top_idx[(uint64_t)q * want + rank] = (int64_t)bm * (int64_t)vocab + t;
@@ -885,21 +994,31 @@ __global__ __launch_bounds__(MERGE_BLOCK) void k_query_merge(const float *logits
             top_unc[(uint64_t)q * want + rank] = v;          // allowed token: constrained == unconstrained
         }
     }
-    // fillers: lowest flat indices that are NOT allowed (beam 0 first); constrained -inf, real unconstrained score
-    if (tid == 0 && n_cand < want) {
-        uint32_t out = n_cand, beam = 0; uint64_t tok = 0;
-        while (out < want && beam < beams) {
+    // fillers: lowest flat indices that are NOT allowed (beam 0 first); constrained -inf, real unconstrained score.
+    // MERGE_BLOCK tokens are examined at a time (ballot + prefix count keeps the token order)
+    if (n_cand < want) {
+        const uint32_t lane = tid & 63, wv = tid >> 6;
+        uint32_t out = n_cand;
+        for (uint32_t beam = 0; beam < beams && out < want; beam++) {
             const uint32_t r = q * beams + beam;
             const uint32_t *b = bits + (row_broadcast_bits ? 0 : (uint64_t)r * words_per_row);
-            if (tok >= vocab) { beam++; tok = 0; continue; }
-            if (!((b[tok >> 5] >> (tok & 31)) & 1)) {
-                const float lp = logp_processed(logits[(uint64_t)r * vocab + tok], row_max[r], row_lsum[r]);
-                top_idx[(uint64_t)q * want + out] = (int64_t)beam * (int64_t)vocab + (int64_t)tok;
-                top_con[(uint64_t)q * want + out] = -__builtin_huge_valf();
-                top_unc[(uint64_t)q * want + out] = lp + beam_scores[r];
-                out++;
+            for (uint64_t base = 0; base < vocab && out < want; base += MERGE_BLOCK) {
+                const uint64_t tok = base + tid;
+                const bool na = tok < vocab && !((b[tok >> 5] >> (tok & 31)) & 1);
+                const uint64_t bal = __ballot(na);
+                __syncthreads();
+                if (lane == 0) s_fill[wv] = (uint32_t)__popcll(bal);
+                __syncthreads();
+                uint32_t mine = (uint32_t)__popcll(bal & ((1ull << lane) - 1)), chunk = 0;
+                for (uint32_t w = 0; w < MERGE_BLOCK / 64; w++) { if (w < wv) mine += s_fill[w]; chunk += s_fill[w]; }
+                if (na && out + mine < want) {
+                    const float lp = logp_processed(logits[(uint64_t)r * vocab + tok], row_max[r], row_lsum[r]);
+                    top_idx[(uint64_t)q * want + out + mine] = (int64_t)beam * (int64_t)vocab + (int64_t)tok;
+                    top_con[(uint64_t)q * want + out + mine] = -__builtin_huge_valf();
+                    top_unc[(uint64_t)q * want + out + mine] = lp + beam_scores[r];
+                }
+                out += chunk;
             }
-            tok++;
         }
     }
 }
@@ -1299,7 +1418,7 @@ extern "C" int fmi_dev_constrained_topk_step(fmi_t *h, void *stream, uint64_t ba
     const uint32_t narrow_max = e_narrow ? std::min<uint32_t>((uint32_t)atoi(e_narrow), TOPK_NARROW) : TOPK_NARROW;
     const char *e_legacy = getenv("SEALFM_TOPK_LEGACY");      // tests: wide rows skip the thread-maxima bound and radix-select
     const uint32_t pick_flags = (e_legacy && atoi(e_legacy)) ? (uint32_t)PICK_NO_PREFILTER : 0u;
-    hipLaunchKernelGGL(k_row_pick, dim3((unsigned)rows), dim3(PICK_BLOCK), wpr * 4, st, d_logits, bits, wpr, broadcast, vocab,
+    hipLaunchKernelGGL(k_row_pick, dim3((unsigned)rows), dim3(PICK_BLOCK), (wpr + 1) * 4, st, d_logits, bits, wpr, broadcast, vocab,
                        (uint32_t)want, row_max, row_lsum, row_tok, row_lp, row_cnt, narrow_max, pick_flags);
     hipLaunchKernelGGL(k_query_merge, dim3((unsigned)batch), dim3(MERGE_BLOCK), 0, st, d_logits, bits, wpr, broadcast, vocab, (uint32_t)beams,
                        (uint32_t)want, d_beam_scores, row_max, row_lsum, row_tok, row_lp, row_cnt, d_top_idx, d_top_con, d_top_unc);

@@ -132,7 +132,7 @@ def test_fused_step_decoder_matches_hf_cache_free_forward(S):
 def test_fused_constrained_topk_matches_unfused_step(kw, narrow, monkeypatch):
     """fmi_dev_constrained_topk against the reference's own sequence of ops on the same logits: same picks (as a set
     per query: ties/-inf fillers are unordered in torch.topk too), unconstrained scores within fp32 noise.
-    Both selection paths of k_row_topk: rows of <= 1024 allowed tokens ranked in LDS, and the radix select."""
+    Both ends of k_row_pick: rows of <= 1024 allowed tokens gathered from the bitmap, and the wide-row path."""
     monkeypatch.setenv("SEALFM_TOPK_NARROW", narrow)
     from seal_amd import FMIndex
     from seal_amd.beam_search import IndexBasedLogitsProcessor, _inf_nan_remove
@@ -263,7 +263,7 @@ def test_incremental_constraint_state_equals_full_prefix_search(kw):
 
 @pytest.mark.gpu
 def test_topk_selection_paths_agree_on_ties(monkeypatch):
-    """k_row_topk has two selection paths (LDS ranking for rows of <= 1024 allowed tokens, radix select beyond);
+    """k_row_pick has two selection paths (bitmap gather for rows of <= 1024 allowed tokens, lower bound + collect beyond);
     on heavily tied logits both must return the same picks in the same order (ties go to the lower token id)."""
     from seal_amd import FMIndex
     from seal_amd.beam_search import IndexBasedLogitsProcessor
