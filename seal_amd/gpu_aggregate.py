@@ -18,6 +18,11 @@ import numpy as np
 
 from ._lib import check, lib
 
+
+def _h2d(arr, dev):
+    from .keys import _h2d as f          # staged through pinned memory: does not block the host (seal_amd/keys.py)
+    return f(arr, dev)
+
 MAX_QUERIES_PER_PLAN = 256
 MAX_TOP = 8192
 MAX_DOC_LEN = 8192
@@ -359,8 +364,8 @@ def score_and_aggregate_on_gpu(index, jobs, params, want_ngrams=True):
     dev = torch.device("cuda", L.fmi_device(index.handle))
     if nk:
         st = torch.cuda.current_stream(dev)
-        d_off = torch.from_numpy(key_tok_off).to(dev, non_blocking=True)
-        d_tok = torch.from_numpy(key_toks).to(dev, non_blocking=True)
+        d_off = _h2d(key_tok_off, dev)
+        d_tok = _h2d(key_toks, dev)
         rng = torch.empty(2, nk, dtype=torch.int64, device=dev)
         check(L.fmi_dev_get_range(index.handle, st.cuda_stream, nk, d_off.data_ptr(), d_tok.data_ptr(), SHIFT, rng[0].data_ptr(), rng[1].data_ptr()))
         rng = rng.cpu().numpy().view(np.uint64)

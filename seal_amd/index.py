@@ -17,6 +17,11 @@ from typing import Iterable, Iterator, List, Optional, Sequence, Set, Tuple
 import numpy as np
 
 from ._lib import _p64, check, lib
+
+
+def _h2d(arr, dev):
+    from .keys import _h2d as f          # staged through pinned memory: does not block the host (seal_amd/keys.py)
+    return f(arr, dev)
 from .cpp_modules.fm_index import FMIndex as _FMIndex
 from .cpp_modules.fm_index import _arr, _ptr, default_device, load_FMIndex
 
@@ -196,8 +201,8 @@ class FMIndex(_FMIndex):
             toks[:total] = np.fromiter((t for s in sequences for t in s), dtype=np.int64, count=total)
         dev = torch.device("cuda", lib().fmi_device(self._h))
         st = torch.cuda.current_stream(dev)
-        d_off = torch.from_numpy(offs).to(dev, non_blocking=True)
-        d_tok = torch.from_numpy(toks).to(dev, non_blocking=True)
+        d_off = _h2d(offs, dev)
+        d_tok = _h2d(toks, dev)
         out = torch.empty(2, n, dtype=torch.int64, device=dev)
         check(lib().fmi_dev_get_range(self._h, st.cuda_stream, n, d_off.data_ptr(), d_tok.data_ptr(), SHIFT, out[0].data_ptr(), out[1].data_ptr()))
         res = out.cpu().numpy().view(np.uint64)
@@ -267,9 +272,9 @@ class FMIndex(_FMIndex):
         dev = torch.device("cuda", lib().fmi_device(self._h))
         st = self._side_stream(dev)
         with torch.cuda.stream(st):
-            d_lo = torch.from_numpy(lo).to(dev, non_blocking=True)
-            d_hi = torch.from_numpy(hi).to(dev, non_blocking=True)
-            d_off = torch.from_numpy(offs).to(dev, non_blocking=True)
+            d_lo = _h2d(lo, dev)
+            d_hi = _h2d(hi, dev)
+            d_off = _h2d(offs, dev)
             out = torch.empty(2, total, dtype=torch.int64, device=dev)
             check(lib().fmi_dev_locate_ranges(self._h, st.cuda_stream, len(lo), d_lo.data_ptr(), d_hi.data_ptr(),
                                               int(max_per_range), d_off.data_ptr(), total, out[0].data_ptr(), out[1].data_ptr()))
@@ -294,8 +299,8 @@ class FMIndex(_FMIndex):
         dev = torch.device("cuda", lib().fmi_device(self._h))
         st = self._side_stream(dev)
         with torch.cuda.stream(st):
-            d_docs = torch.from_numpy(docs).to(dev, non_blocking=True)
-            d_off = torch.from_numpy(offs).to(dev, non_blocking=True)
+            d_docs = _h2d(docs, dev)
+            d_off = _h2d(offs, dev)
             out = torch.empty(max(int(offs[-1]), 1), dtype=torch.int64, device=dev)
             check(lib().fmi_dev_get_docs(self._h, st.cuda_stream, len(docs), d_docs.data_ptr(), d_off.data_ptr(), SHIFT,
                                          out.data_ptr()))

@@ -50,12 +50,24 @@ def strip(seq, symbols_start, symbols_end):
     return seq[a:b]
 
 
+def _h2d(arr: np.ndarray, device) -> torch.Tensor:
+    """host array -> device WITHOUT waiting for the stream: a copy from pageable memory blocks the host until everything
+    queued before it has run (measured: ~1.2 ms per small index tensor in the middle of a search step, i.e. a pipeline
+    bubble each time), a copy from a pinned staging buffer is just another enqueued command.  The caching host allocator
+    keeps the staging buffer alive until the copy has executed."""
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    device = torch.device(device)
+    if device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def _pad_batch(seqs: Sequence[Sequence[int]], pad: int, device) -> torch.Tensor:
     width = max(len(s) for s in seqs)
     out = np.full((len(seqs), width), pad, dtype=np.int64)
     for i, s in enumerate(seqs):
         out[i, :len(s)] = s
-    return torch.from_numpy(out).to(device)
+    return _h2d(out, device)
 
 
 @torch.inference_mode()
@@ -91,7 +103,7 @@ def rescore_keys(model, inputs, list_of_decoded, batch_size=100, length_penalty=
     start = cfg.decoder_start_token_id
     for c0 in range(0, len(flat), batch_size):
         chunk = flat[c0:c0 + batch_size]
-        qidx = torch.as_tensor([qi for qi, _ in chunk], device=device)
+        qidx = _h2d(np.asarray([qi for qi, _ in chunk], dtype=np.int64), device)
         dec_in = []
         for _, key in chunk:
             d = [start] + list(prefix) + list(strip(list(key), strip_from_bos, strip_from_eos))
@@ -172,8 +184,11 @@ def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_pena
             prepared = stepdec.teacher_prepare(enc, attention_mask)
     for c, items in per_chunk.items():
         rows = [work[w] for w in order[c * chunk_rows:(c + 1) * chunk_rows]]
-        qidx = torch.as_tensor([qi for qi, _ in rows], device=device)
+        qidx = _h2d(np.asarray([qi for qi, _ in rows], dtype=np.int64), device)
         dec_ids = _pad_batch([[start] + list(p) for _, p in rows], cfg.pad_token_id, device)
+        # (row, length, last token) of every key of the chunk: one staged copy
+        key_idx = _h2d(np.asarray([[r for _, _, r, _ in items], [len(sq) for _, _, _, sq in items], [sq[-1] for _, _, _, sq in items]],
+                                  dtype=np.int64), device)
         if prepared is not None:
             logits = stepdec.teacher_logits(dec_ids, qidx, prepared)
         else:
@@ -190,9 +205,7 @@ def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_pena
                              torch.cumsum(own_lp.double(), dim=-1)], dim=1)          # cum[r, m] = first m terms
         else:
             cum = torch.zeros(len(rows), 1, dtype=torch.float64, device=device)
-        r_idx = torch.as_tensor([r for _, _, r, _ in items], device=device)
-        n_idx = torch.as_tensor([len(sq) for _, _, _, sq in items], device=device)
-        last = torch.as_tensor([sq[-1] for _, _, _, sq in items], device=device)
+        r_idx, n_idx, last = key_idx[0], key_idx[1], key_idx[2]
         last_lp = logp[r_idx, n_idx - 1, last].double()
         last_lp = torch.where(last < 2, torch.zeros_like(last_lp), last_lp)
         lo = torch.clamp(torch.full_like(n_idx, npre), max=cum.shape[1] - 1)
