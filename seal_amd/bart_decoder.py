@@ -127,7 +127,26 @@ class BartStepDecoder:
 
     @torch.no_grad()
     def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
-        return self.model.model.encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+        """``model.model.encoder(...).last_hidden_state`` through the encoder's own modules, with the padding mask built
+        here: HF's mask helper asks the device whether the mask is all ones (``padding_mask.all()``, a device -> host
+        read-back: measured 12 ms of blocked host per call once decodes are queued ahead), which stops the host from
+        enqueueing anything behind the encoder.  Same layers, same attention function, the mask always passed."""
+        enc = self.model.model.encoder
+        impl = getattr(self.model.config, "_attn_implementation", "sdpa")
+        if impl not in ("sdpa", "eager") or self.model.training:
+            return enc(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+        x = enc.embed_tokens(input_ids)
+        x = x + enc.embed_positions(x[:, :, -1]).to(x.device)
+        x = enc.layernorm_embedding(x)
+        B, S = input_ids.shape
+        keep = attention_mask.to(torch.bool)[:, None, None, :].expand(B, 1, S, S)
+        if impl == "sdpa":
+            mask = keep
+        else:
+            mask = torch.zeros(B, 1, S, S, dtype=x.dtype, device=x.device).masked_fill_(~keep, torch.finfo(x.dtype).min)
+        for layer in enc.layers:
+            x = layer(x, mask)
+        return x
 
     # ------------------------------------------------------------------
     # static-shape state: one set of buffers (and one hipGraph) per

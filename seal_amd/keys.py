@@ -18,6 +18,7 @@ of the greedy matcher) is reproduced on the host from those arrays; floating
 point is float64 ``math`` exactly where the reference uses it.
 """
 import math
+import os
 from collections import Counter
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -72,7 +73,7 @@ def _pad_batch(seqs: Sequence[Sequence[int]], pad: int, device) -> torch.Tensor:
 
 @torch.inference_mode()
 def rescore_keys(model, inputs, list_of_decoded, batch_size=100, length_penalty=0.0, progress_bar=False, prefix=[],
-                 strip_from_bos=[], strip_from_eos=[], logit_bias=None, share_prefixes=True, encoded=None):
+                 strip_from_bos=[], strip_from_eos=[], logit_bias=None, share_prefixes=True, encoded=None, pending=False):
     """Teacher-forced log-probability of every key given its query
     (reference keys.py:64-141): targets with id < 2 contribute 0 (keys.py:132),
     score divided by ``len(key) ** length_penalty``.
@@ -86,8 +87,13 @@ def rescore_keys(model, inputs, list_of_decoded, batch_size=100, length_penalty=
     summation order), ~4-5x fewer decoder positions.  ``share_prefixes=False`` is
     the reference's one-row-per-key batching."""
     if share_prefixes:
-        return _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_penalty, prefix, strip_from_bos,
-                                    strip_from_eos, logit_bias, encoded)
+        job = _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_penalty, prefix, strip_from_bos,
+                                   strip_from_eos, logit_bias, encoded)
+        # ``pending``: everything is enqueued and nothing has waited for the GPU; ``job.result()`` reads the scores back
+        # (the searcher enqueues the three rescorings of a batch back to back and reads them back afterwards)
+        return job if pending else job.result()
+    if pending:
+        raise NotImplementedError("pending=True needs share_prefixes=True")
     cfg = model.config
     device = next(model.parameters()).device
     if inputs is None:
@@ -145,7 +151,11 @@ def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_pena
     else:
         input_ids = _pad_batch(batch_in, cfg.pad_token_id, device)
         attention_mask = (input_ids != cfg.pad_token_id).to(torch.uint8)
-        enc = model.model.encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+        sd = getattr(model, "_seal_step_decoder", None)
+        if sd is None:
+            from .bart_decoder import BartStepDecoder
+            sd = model._seal_step_decoder = BartStepDecoder(model)
+        enc = sd.encode(input_ids, attention_mask)          # the encoder without HF's blocking mask check
     start, npre = cfg.decoder_start_token_id, len(prefix)
     seqs = [[tuple(list(prefix) + list(strip(list(key), strip_from_bos, strip_from_eos))) for key in keys] for keys in decoded]
     work = []           # (query, maximal parent)
@@ -164,7 +174,9 @@ def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_pena
     order = sorted(range(len(work)), key=lambda i: len(work[i][1]))     # similar lengths together: less padding
     slot = {w: j for j, w in enumerate(order)}
     # keys grouped by the chunk of their owner row
-    chunk_rows = max(batch_size, 256)
+    # rows per forward: few, large launches (an eager F.linear costs the host ~19 us whatever its size, and a batch of
+    # queries has a few hundred maximal parents); the logits of a chunk are rows x T x vocab floats -- 0.57 GB at 256 rows x 11 positions; 1024 rows measured no faster: more padding
+    chunk_rows = max(batch_size, int(os.environ.get("SEAL_RESCORE_CHUNK", 256)))
     per_chunk = {}
     for qi, ss in enumerate(seqs):
         for ki, sq in enumerate(ss):
@@ -172,6 +184,7 @@ def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_pena
                 j = slot[owner[qi][sq[:-1]]]
                 per_chunk.setdefault(j // chunk_rows, []).append((qi, ki, j % chunk_rows, sq))
     scores = [[0.0] * len(ss) for ss in seqs]
+    totals = []         # per chunk: (its keys, their scores on the device)
     # decoder forward: the fused step-decoder kernels when they apply (GPU, fp32), HF's module otherwise
     stepdec = getattr(model, "_seal_step_decoder", None)
     max_T = 1 + max((len(p) for _, p in work), default=0)
@@ -210,11 +223,28 @@ def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_pena
         last_lp = torch.where(last < 2, torch.zeros_like(last_lp), last_lp)
         lo = torch.clamp(torch.full_like(n_idx, npre), max=cum.shape[1] - 1)
         body = cum[r_idx, n_idx - 1] - cum[r_idx, torch.minimum(lo, n_idx - 1)]
-        total = torch.where(n_idx > npre, body + last_lp, torch.zeros_like(body)).float().tolist()
-        for (qi, ki, _, _), ll in zip(items, total):
-            scores[qi][ki] = ll
-    return [[(scores[qi][ki] / (len(key) ** length_penalty), list(key)) for ki, key in enumerate(keys)]
-            for qi, keys in enumerate(decoded)]
+        totals.append((items, torch.where(n_idx > npre, body + last_lp, torch.zeros_like(body)).float()))
+    return _PendingRescore(totals, scores, decoded, length_penalty)
+
+
+class _PendingRescore:
+    """the enqueued chunks of one ``rescore_keys`` call: one read-back for all of them"""
+
+    def __init__(self, totals, scores, decoded, length_penalty):
+        self._totals, self._scores, self._decoded, self._lp = totals, scores, decoded, length_penalty
+
+    def result(self):
+        scores = self._scores
+        if self._totals:
+            flat = torch.cat([t for _, t in self._totals]).tolist() if len(self._totals) > 1 else self._totals[0][1].tolist()
+            pos = 0
+            for items, _ in self._totals:
+                for (qi, ki, _, _), ll in zip(items, flat[pos:pos + len(items)]):
+                    scores[qi][ki] = ll
+                pos += len(items)
+        lp = self._lp
+        return [[(scores[qi][ki] / (len(key) ** lp), list(key)) for ki, key in enumerate(keys)]
+                for qi, keys in enumerate(self._decoded)]
 
 
 @torch.no_grad()

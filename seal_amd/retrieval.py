@@ -236,6 +236,10 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
     yield "decoded"
 
     # ---- segment 3: filters, rescoring, query n-grams, unigram scores ----
+    # The reference filters and rescores the body keys, then the query n-grams, then the title keys, each step ending in
+    # a read-back.  None of the three depends on another, so here: the candidate lists of all three are built first,
+    # ONE count launch filters them, the (up to) three rescorings are enqueued back to back, and only then are the
+    # scores read back -- in the reference's order, into the same lists.
     if s.decode_body:
         for fk in found_keys:   # retrieval.py:85-90
             fk[:] = [(sc, k[1:] if k[0] in strip_ids else k) for sc, k in fk if k]
@@ -243,12 +247,7 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
             fk[:] = [(sc, k[:-1] if k[-1] in strip_ids else k) for sc, k in fk if k]
             if s.min_length > 0:
                 fk[:] = [(sc, k) for sc, k in fk if len(k) == s.min_length]
-        found_keys = _count_filter(fm_index, found_keys)   # retrieval.py:91
-        if s.rescore and s.use_markers:
-            found_keys = rk.rescore_keys(
-                s.bart_model, base_tokens, found_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
-                strip_from_eos=[s.title_eos_token_id, s.code_eos_token_id, s.bart_model.config.eos_token_id], logit_bias=bias)
-
+    cand = None
     if s.add_query_to_keys:
         if tokenised:
             # pre-tokenised queries (an extension): the word n-grams are token n-grams (seal_amd/query_keys.py)
@@ -261,15 +260,7 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
             from .query_keys import query_ngram_keys
             cand = [query_ngram_keys(inp, s) for inp in inputs]
         cand = [[(0.0, k) for k in kk] for kk in cand]
-        cand = [[k for _, k in kk] for kk in _count_filter(fm_index, cand)]
-        _, toks = marked("body")
-        last_input_tokens = toks                # the reference re-binds `input_tokens` here (retrieval.py:139)
-        # same encoder input as the body decode (' || body || +'): its encoder states are reused where there are any
-        reuse = (body.enc, body.attention_mask) if (tokenised and body is not None and body.enc is not None) else None
-        for fk, nfk in zip(found_keys, rk.rescore_keys(s.bart_model, toks, cand, batch_size=100, length_penalty=0.0, logit_bias=bias,
-                                                       encoded=reuse)):
-            fk += nfk
-
+    title_keys = None
     if s.decode_titles:
         title_keys = [[(sc, hyp) for sc, hyp in dec_] for dec_ in decoded]
         for fk in title_keys:   # retrieval.py:180-190
@@ -281,12 +272,45 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
                 if s.min_length > 0:
                     fk[:] = [(sc, k) for sc, k in fk if len(k) == (s.min_length + 1)]
             fk[:] = [(sc, [s.title_bos_token_id] + k if k[0] != s.title_bos_token_id else k) for sc, k in fk]
-        title_keys = _count_filter(fm_index, title_keys)   # retrieval.py:191
-        if s.rescore and s.use_markers:
-            title_keys = rk.rescore_keys(
-                s.bart_title_model, title_toks, title_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
-                strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=bias,
-                encoded=(titles.enc, titles.attention_mask) if tokenised and titles.enc is not None else None)
+    # retrieval.py:91, 130, 191: get_count(k) > 0, one launch for the three lists
+    parts = [p for p in (found_keys if s.decode_body else None, cand, title_keys) if p is not None]
+    n_q = len(inputs)
+    if parts:
+        merged = _count_filter(fm_index, [fk for p in parts for fk in p])
+        parts = [merged[j * n_q:(j + 1) * n_q] for j in range(len(parts))]
+        it = iter(parts)
+        if s.decode_body:
+            found_keys = next(it)
+        if cand is not None:
+            cand = [[k for _, k in kk] for kk in next(it)]
+        if title_keys is not None:
+            title_keys = next(it)
+    marked_rescoring = s.rescore and s.use_markers
+    body_job = cand_job = title_job = None
+    if s.decode_body and marked_rescoring:
+        body_job = rk.rescore_keys(
+            s.bart_model, base_tokens, found_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
+            strip_from_eos=[s.title_eos_token_id, s.code_eos_token_id, s.bart_model.config.eos_token_id], logit_bias=bias, pending=True)
+    if cand is not None:
+        _, toks = marked("body")
+        last_input_tokens = toks                # the reference re-binds `input_tokens` here (retrieval.py:139)
+        # same encoder input as the body decode (' || body || +'): its encoder states are reused where there are any
+        reuse = (body.enc, body.attention_mask) if (tokenised and body is not None and body.enc is not None) else None
+        cand_job = rk.rescore_keys(s.bart_model, toks, cand, batch_size=100, length_penalty=0.0, logit_bias=bias, encoded=reuse,
+                                   pending=True)
+    if title_keys is not None and marked_rescoring:
+        title_job = rk.rescore_keys(
+            s.bart_title_model, title_toks, title_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
+            strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=bias,
+            encoded=(titles.enc, titles.attention_mask) if tokenised and titles.enc is not None else None, pending=True)
+    if body_job is not None:
+        found_keys = body_job.result()
+    if cand_job is not None:
+        for fk, nfk in zip(found_keys, cand_job.result()):
+            fk += nfk
+    if title_keys is not None:
+        if title_job is not None:
+            title_keys = title_job.result()
         for nfk, fk in zip(title_keys, found_keys):
             fk += nfk
 
@@ -390,6 +414,7 @@ class SEALSearcher:
         self.pipeline: int = int(params.get("pipeline", 1))
         # extension: enqueue the next batch's decodes before this batch's rescoring / aggregation (same thread, second stream)
         self.overlap: bool = bool(params.get("overlap", True))
+        self.overlap_depth: int = int(params.get("overlap_depth", 2))
         # extension (synthetic benchmarks): per-query additive bias on the model's next-token logits, [batch, vocab]
         self.logit_bias = None
         if "bart" in self.backbone:   # retrieval.py:480-491
@@ -558,7 +583,9 @@ class SEALSearcher:
         dev = self.device
         post = self.__dict__.get("_post_stream")
         if post is None:
-            post = self.__dict__["_post_stream"] = torch.cuda.Stream(device=dev)
+            # high priority: the post-processing chain is the critical path (every phase ends in a read-back the host
+            # waits for), the decodes queued ahead on the caller's stream fill whatever it leaves
+            post = self.__dict__["_post_stream"] = torch.cuda.Stream(device=dev, priority=-1)
         params = self._aggregate_params()
         constrained = not self.free_generation
         batches, offsets, off = [], [], 0
@@ -571,20 +598,43 @@ class SEALSearcher:
         post.wait_stream(torch.cuda.current_stream(dev))      # whatever the caller queued (weights, logit bias) is visible
         import os, sys, time
         tm = os.environ.get("SEAL_OVERLAP_TIMING")
-        cur = _batch_steps(self, batches[0], constrained, offsets[0])
-        next(cur)                                             # decodes of batch 0 enqueued
+        # decodes are independent of everything else and of each other: keep `overlap_depth` batches' worth of them
+        # enqueued AHEAD of the batch whose post-processing (filters, rescoring, aggregation -- phases that end in a
+        # device -> host read-back, i.e. pipeline bubbles) is running, so that the GPU never drains.  They share the
+        # decoder's static buffers and the index workspace in stream order; each keeps its own history tensors.
+        depth = max(1, int(os.environ.get("SEAL_OVERLAP_DEPTH", getattr(self, "overlap_depth", 2))))
+        ahead = []                                            # generators whose decodes are enqueued, oldest first
+        nxt_i = 0
+
+        prof = None
+        if os.environ.get("SEAL_PROFILE_ENQUEUE"):            # tools: where the host time of enqueueing a batch's decodes goes
+            import cProfile
+            prof = cProfile.Profile()
+
+        def enqueue_next():
+            nonlocal nxt_i
+            g = _batch_steps(self, batches[nxt_i], constrained, offsets[nxt_i])
+            if prof is not None and nxt_i >= 2:
+                prof.enable()
+            next(g)                                           # its decodes are enqueued behind the earlier ones
+            if prof is not None:
+                prof.disable()
+            ahead.append(g)
+            nxt_i += 1
+        enqueue_next()
         for i in range(len(batches)):
             t0 = time.perf_counter()
+            cur = ahead.pop(0)
             next(cur)                                         # hypotheses of batch i on the host
             t1 = time.perf_counter()
-            nxt = None
-            if i + 1 < len(batches):
-                nxt = _batch_steps(self, batches[i + 1], constrained, offsets[i + 1])
-                next(nxt)                                     # decodes of batch i+1 enqueued behind nothing
+            while nxt_i < len(batches) and len(ahead) < depth:
+                enqueue_next()
             t2 = time.perf_counter()
-            if tm:
-                print("[overlap] batch %d: waited %.1f ms for its decodes; enqueued the next decodes in %.1f ms" % (i, (t1 - t0) * 1e3, (t2 - t1) * 1e3),
-                      file=sys.stderr, flush=True)
+            pprof = None
+            if os.environ.get("SEAL_PROFILE_POST") and i >= 2:   # tools: where the host time of a batch's post-processing goes
+                import cProfile
+                pprof = self.__dict__.setdefault("_post_prof", cProfile.Profile())
+                pprof.enable()
             with torch.cuda.stream(post):
                 try:
                     next(cur)
@@ -594,8 +644,19 @@ class SEALSearcher:
                 jobs = [(kk[0], kk[1]) if isinstance(kk, tuple) else (kk, None) for kk in keys]
                 out = rk.aggregate_evidence_batch(jobs, self.fm_index, keep=keep, gpu_aggregate=self.gpu_aggregate, want_ngrams=False, **params)
                 post.synchronize()
+            if pprof is not None:
+                pprof.disable()
+                if i + 1 == len(batches):
+                    import pstats
+                    pstats.Stats(pprof, stream=sys.stderr).sort_stats("tottime").print_stats(45)
+                    self.__dict__.pop("_post_prof", None)
+            if tm:
+                print("[overlap] batch %d: waited %.1f ms for its decodes; enqueued further decodes in %.1f ms; filters / rescoring / "
+                      "aggregation %.1f ms" % (i, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (time.perf_counter() - t2) * 1e3), file=sys.stderr, flush=True)
+            if prof is not None and i + 1 == len(batches) and prof.getstats():
+                import pstats
+                pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(40)
             yield from out
-            cur = nxt
 
     def _pipelined(self) -> bool:
         return (int(self.pipeline) >= 2 and hasattr(self.fm_index, "view") and self.device.type == "cuda"
