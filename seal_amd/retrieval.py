@@ -414,7 +414,7 @@ class SEALSearcher:
         self.pipeline: int = int(params.get("pipeline", 1))
         # extension: enqueue the next batch's decodes before this batch's rescoring / aggregation (same thread, second stream)
         self.overlap: bool = bool(params.get("overlap", True))
-        self.overlap_depth: int = int(params.get("overlap_depth", 2))
+        self.overlap_depth: int = int(params.get("overlap_depth", 1))     # batches of decodes kept enqueued ahead (2 measured no faster)
         # extension (synthetic benchmarks): per-query additive bias on the model's next-token logits, [batch, vocab]
         self.logit_bias = None
         if "bart" in self.backbone:   # retrieval.py:480-491
@@ -579,13 +579,13 @@ class SEALSearcher:
         the next decode while the host walks through this batch's python, and the rescoring GEMMs fill the gaps.  One
         thread, one index handle (a decode uses the constraint workspace, the rest of a batch does not), no result
         depends on the schedule."""
+        import os
         import torch
         dev = self.device
         post = self.__dict__.get("_post_stream")
         if post is None:
-            # high priority: the post-processing chain is the critical path (every phase ends in a read-back the host
-            # waits for), the decodes queued ahead on the caller's stream fill whatever it leaves
-            post = self.__dict__["_post_stream"] = torch.cuda.Stream(device=dev, priority=-1)
+            # (SEAL_POST_PRIORITY=1 makes it a high-priority stream: measured no different)
+            post = self.__dict__["_post_stream"] = torch.cuda.Stream(device=dev, priority=-1 if os.environ.get("SEAL_POST_PRIORITY", "0") == "1" else 0)
         params = self._aggregate_params()
         constrained = not self.free_generation
         batches, offsets, off = [], [], 0
@@ -602,7 +602,7 @@ class SEALSearcher:
         # enqueued AHEAD of the batch whose post-processing (filters, rescoring, aggregation -- phases that end in a
         # device -> host read-back, i.e. pipeline bubbles) is running, so that the GPU never drains.  They share the
         # decoder's static buffers and the index workspace in stream order; each keeps its own history tensors.
-        depth = max(1, int(os.environ.get("SEAL_OVERLAP_DEPTH", getattr(self, "overlap_depth", 2))))
+        depth = max(1, int(os.environ.get("SEAL_OVERLAP_DEPTH", getattr(self, "overlap_depth", 1))))
         ahead = []                                            # generators whose decodes are enqueued, oldest first
         nxt_i = 0
 
