@@ -21,8 +21,11 @@ def _docs(seed, n_docs, vocab, min_len=2, max_len=30, zipf=None):
     return docs
 
 
-@pytest.fixture(scope="module", params=[(0, 40, 12, None), (1, 300, 500, None), (2, 2000, 50265, None), (2, 2000, 50265, 3)],
-                ids=["tiny", "small", "bart-vocab", "bart-vocab-superblocks"])
+# vocabularies of 1, 3, 4 and 5 hex digit levels (12 -> 4 bits ... 70 000 -> 17 bits, 32-bit text symbols): k_constrain's
+# sub-tree covers 1 / 256 / 4 096 / 65 536 symbols per wave
+@pytest.fixture(scope="module", params=[(0, 40, 12, None), (1, 300, 500, None), (2, 2000, 50265, None), (2, 2000, 50265, 3),
+                                        (3, 300, 70000, None)],
+                ids=["tiny", "small", "bart-vocab", "bart-vocab-superblocks", "17-bit-symbols"])
 def pair(request):
     import os
     from oracle.seal_oracle import OracleFMIndex
