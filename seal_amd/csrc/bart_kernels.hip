@@ -153,28 +153,38 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const float *x, const flo
     const float4 *xr = reinterpret_cast<const float4 *>(x + (uint64_t)row * d);
     const float4 *yr = reinterpret_cast<const float4 *>(y + (uint64_t)row * d);
     const uint32_t n4 = d / 4;
-    float4 v[16];
+    float4 v[16];                                    // fully unrolled below: registers, not scratch
     float sum = 0.f;
-    uint32_t c = 0;
-    for (uint32_t i = lane; i < n4; i += 64, c++) {
-        const float4 a = xr[i], b = yr[i];
-        v[c] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-        sum += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+        const uint32_t i = lane + 64 * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n4) {
+            const float4 a = xr[i], b = yr[i];
+            v[j] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
     }
     const float mean = wave_sum(sum) / (float)d;
     float var = 0.f;
-    for (uint32_t j = 0; j < c; j++) {
-        const float a = v[j].x - mean, b = v[j].y - mean, e = v[j].z - mean, f = v[j].w - mean;
-        var += (a * a + b * b) + (e * e + f * f);
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+        if (lane + 64 * j < n4) {
+            const float a = v[j].x - mean, b = v[j].y - mean, e = v[j].z - mean, f = v[j].w - mean;
+            var += (a * a + b * b) + (e * e + f * f);
+        }
     }
     const float rstd = rsqrtf(wave_sum(var) / (float)d + eps);
     const float4 *g4 = reinterpret_cast<const float4 *>(gamma), *b4 = reinterpret_cast<const float4 *>(beta);
     float4 *o4 = reinterpret_cast<float4 *>(out + (uint64_t)row * d);
-    c = 0;
-    for (uint32_t i = lane; i < n4; i += 64, c++) {
-        const float4 g = g4[i], bb = b4[i];
-        o4[i] = make_float4((v[c].x - mean) * rstd * g.x + bb.x, (v[c].y - mean) * rstd * g.y + bb.y,
-                            (v[c].z - mean) * rstd * g.z + bb.z, (v[c].w - mean) * rstd * g.w + bb.w);
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+        const uint32_t i = lane + 64 * j;
+        if (i < n4) {
+            const float4 g = g4[i], bb = b4[i];
+            o4[i] = make_float4((v[j].x - mean) * rstd * g.x + bb.x, (v[j].y - mean) * rstd * g.y + bb.y,
+                                (v[j].z - mean) * rstd * g.z + bb.z, (v[j].w - mean) * rstd * g.w + bb.w);
+        }
     }
 }
 
