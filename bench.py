@@ -43,7 +43,12 @@ def log(*a):
 # synthetic NQ-shaped corpus, generated on the GPU directly in
 # index order: per document reversed (+SHIFT), i.e. [</s>, body..., '@@', title...]
 # ---------------------------------------------------------------------------
-def synth_corpus(n_docs: int, device, seed: int = 0):
+def synth_corpus(n_docs: int, device, seed: int = 0, phrases: int = 0):
+    """``phrases`` = P > 0 (bench.py's default, P = 20 M): the token stream is a concatenation of phrases of 2..8 tokens
+    drawn Zipf(1.0) from a dictionary of P phrases (each an i.i.d. Zipf(1.07) token string), cut into documents
+    independently of the phrase boundaries: n-grams repeat as they do in real text, so a key locates ~3e5 rows per query
+    (a real NQ index: 1e5-1e6) instead of the ~1e4 of an i.i.d. corpus.
+    ``phrases`` = 0: every token drawn i.i.d. Zipf(1.07) (round 1's workload; tools/expand_bench.py keeps it)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     lens = torch.normal(137.0, 25.0, (n_docs,), generator=g, device=device).round().clamp(40, 256).long()
@@ -58,12 +63,35 @@ def synth_corpus(n_docs: int, device, seed: int = 0):
     cdf = torch.cumsum(w, 0) / w.sum()
     data = torch.empty(N, dtype=torch.int32, device=device)
     CH = 1 << 27
-    for a in range(0, N, CH):
-        b = min(N, a + CH)
-        u = torch.rand(b - a, generator=g, device=device, dtype=torch.float64)
+
+    def zipf_tokens(n):
+        u = torch.rand(n, generator=g, device=device, dtype=torch.float64)
         r = torch.searchsorted(cdf, u).clamp_(max=usable.numel() - 1)
-        data[a:b] = (ids_by_rank[r] + SHIFT).to(torch.int32)
-        del u, r
+        return (ids_by_rank[r] + SHIFT).to(torch.int32)
+    if phrases <= 0:
+        for a in range(0, N, CH):
+            b = min(N, a + CH)
+            data[a:b] = zipf_tokens(b - a)
+    else:
+        LMAX = 8
+        phrases = max(16, min(phrases, N // 100))      # a small test corpus gets a proportionally small dictionary
+        ptab = zipf_tokens(phrases * LMAX).view(phrases, LMAX)
+        plen = torch.randint(2, LMAX + 1, (phrases,), generator=g, device=device)
+        pw = 1.0 / torch.arange(1, phrases + 1, device=device, dtype=torch.float64)
+        pcdf = torch.cumsum(pw, 0) / pw.sum()
+        a = 0
+        while a < N:                                   # chunks of phrase slots; a chunk's tail phrase is cut at the chunk end
+            b = min(N, a + CH)
+            n_slots = (b - a) // 2 + 1                # enough slots even if every phrase had the minimum length
+            u = torch.rand(n_slots, generator=g, device=device, dtype=torch.float64)
+            pid = torch.searchsorted(pcdf, u).clamp_(max=phrases - 1)
+            cum = torch.cumsum(plen[pid], 0)
+            pos = torch.arange(b - a, device=device)
+            slot = torch.searchsorted(cum, pos, right=True)
+            start = torch.where(slot > 0, cum[(slot - 1).clamp_(min=0)], torch.zeros_like(pos))
+            data[a:b] = ptab[pid[slot], pos - start]
+            del u, pid, cum, pos, slot, start
+            a = b
     data[beg[:-1]] = 2 + SHIFT
     data[beg[1:] - 1 - title_len] = TITLE_EOS + SHIFT
     return data, beg, title_len, ids_by_rank
@@ -258,6 +286,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1, help="query batches in flight on worker threads (each on its own stream); 1 = none")
     ap.add_argument("--no-overlap", action="store_true", help="do not enqueue the next batch's decodes ahead of this batch's rescoring/aggregation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--corpus-phrases", type=int, default=int(os.environ.get("SEAL_BENCH_PHRASES", 20000000)),
+                    help="documents assembled from a dictionary of P repeating phrases (default 20 M: n-grams repeat as in real text, a key "
+                         "locates ~3e5 rows per query like a real NQ index); 0 = the i.i.d. Zipf corpus of round 1 (~1e4 rows per query)")
     ap.add_argument("--no-query-keys", action="store_true", help="leave out the query n-gram keys (add_query_to_keys, the reference's default)")
     ap.add_argument("--first-stage-only", action="store_true",
                     help="stop after the first retrieval stage (SURVEY.md 8d metric) instead of the reference's complete batch_search")
@@ -296,7 +327,7 @@ def main():
         dist.barrier()
 
     t0 = time.perf_counter()
-    data, beg, title_len, ids_by_rank = synth_corpus(args.docs, dev, seed=0)
+    data, beg, title_len, ids_by_rank = synth_corpus(args.docs, dev, seed=0, phrases=args.corpus_phrases)
     torch.cuda.synchronize()
     log(f"corpus: {args.docs} docs, {data.numel()} symbols in {time.perf_counter() - t0:.1f}s")
     n_batches = args.warmup + args.steps + 1
@@ -561,7 +592,7 @@ def main():
         "value": round(total_q / elapsed, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed * 1e3 / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"configs[1]: NQ-shaped synthetic FM-index ({args.docs} passages, {index.size()} symbols), random-init "
+        "config": {"workload": f"configs[1]: NQ-shaped synthetic FM-index ({args.docs} passages, {index.size()} symbols{', phrase corpus P=%d' % args.corpus_phrases if args.corpus_phrases else ''}), random-init "
                                f"BART-large fp32, beam={args.beam}, batch={args.batch} per GPU, body len 10 + title len<=15, "
                                f"{'first-stage retrieval' if args.first_stage_only else 'first stage + full-document rescoring of 1500 docs/query'}, top-{args.topk}",
                    "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated; " + ("next batch's decodes enqueued ahead of this batch's rescoring/aggregation (2 streams)" if not args.no_overlap and args.pipeline <= 1 else f"{args.pipeline} query batches in flight per GPU"), "model_arithmetic": "fp32 (as the reference runs BART)",
