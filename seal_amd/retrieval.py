@@ -163,12 +163,14 @@ def _process_batch(searcher, inputs, constrained_generation, offset=0, pipe=None
 
 
 def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
-    """``process_batch`` of the reference (retrieval.py:54-305) as a generator in three segments, so that a scheduler can
+    """``process_batch`` of the reference (retrieval.py:54-305) as a generator in segments, so that a scheduler can
     put other work between them (``SEALSearcher._overlapped_results``):
 
-    1. both constrained decodes (body, titles) are ENQUEUED -- nothing waits for the GPU -- then ``yield "decoding"``;
+    1. the body decode is ENQUEUED -- nothing waits for the GPU -- ``yield "body"``; the title decode likewise, ``yield
+       "decoding"``;
     2. the hypotheses come to the host (the one wait for the decodes), then ``yield "decoded"``;
-    3. post-filters, rescoring, query n-grams, unigram scores -> returns the keys (``StopIteration.value``).
+    3. post-filters, the rescorings enqueued, ``yield "rescoring"``; scores read back, query n-grams, unigram scores ->
+       returns the keys (``StopIteration.value``).
 
     The reference runs body decode -> body filters/rescoring -> query keys -> title decode -> title filters/rescoring;
     the two decodes do not depend on anything in between, so issuing them back to back changes no result."""
@@ -220,6 +222,7 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
             disable_fm_index=not constrained_generation, diverse_bs_groups=s.diverse_bs_groups,
             diverse_bs_penalty=s.diverse_bs_penalty, stop_at_count=s.stop_at_count, keep_history=True, topk=s.topk,
             logit_bias=bias, pending=True, **dec(s.bart_model))
+    yield "body"
     if s.decode_titles:
         strs, title_toks = marked("title")
         titles = fm_index_generate(
@@ -303,6 +306,7 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
             s.bart_title_model, title_toks, title_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
             strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=bias,
             encoded=(titles.enc, titles.attention_mask) if tokenised and titles.enc is not None else None, pending=True)
+    yield "rescoring"                            # everything of this batch up to the scores is enqueued; nothing read back yet
     if body_job is not None:
         found_keys = body_job.result()
     if cand_job is not None:
@@ -611,24 +615,34 @@ class SEALSearcher:
             import cProfile
             prof = cProfile.Profile()
 
-        def enqueue_next():
+        def enqueue_next(upto="decoding"):
+            """starts the next batch: its body decode is enqueued (``upto="body"``), or both decodes"""
             nonlocal nxt_i
             g = _batch_steps(self, batches[nxt_i], constrained, offsets[nxt_i])
             if prof is not None and nxt_i >= 2:
                 prof.enable()
-            next(g)                                           # its decodes are enqueued behind the earlier ones
+            state = next(g)                                   # "body": the body decode is enqueued behind the earlier ones
+            if upto == "decoding":
+                state = next(g)
             if prof is not None:
                 prof.disable()
-            ahead.append(g)
+            ahead.append([g, state])
             nxt_i += 1
+
+        def advance(entry, upto):
+            while entry[1] != upto:
+                entry[1] = next(entry[0])
         enqueue_next()
         for i in range(len(batches)):
             t0 = time.perf_counter()
             cur = ahead.pop(0)
-            next(cur)                                         # hypotheses of batch i on the host
+            advance(cur, "decoded")                           # (title decode enqueued if it was not;) hypotheses of batch i on the host
             t1 = time.perf_counter()
+            # The next batch's decodes go in two halves around this batch's rescoring: its body decode now, its title decode
+            # once this batch's filters and rescorings are enqueued -- so the GPU still has decode work queued while the host
+            # reads the scores back and walks through the aggregation (phases that end in a read-back).
             while nxt_i < len(batches) and len(ahead) < depth:
-                enqueue_next()
+                enqueue_next("body" if len(ahead) == 0 else "decoding")
             t2 = time.perf_counter()
             pprof = None
             if os.environ.get("SEAL_PROFILE_POST") and i >= 2:   # tools: where the host time of a batch's post-processing goes
@@ -636,9 +650,13 @@ class SEALSearcher:
                 pprof = self.__dict__.setdefault("_post_prof", cProfile.Profile())
                 pprof.enable()
             with torch.cuda.stream(post):
+                advance(cur, "rescoring")
+            if ahead:
+                advance(ahead[0], "decoding")                 # the next batch's title decode, on the caller's stream
+            with torch.cuda.stream(post):
                 try:
-                    next(cur)
-                    raise RuntimeError("_batch_steps yielded more than twice")
+                    next(cur[0])
+                    raise RuntimeError("_batch_steps yielded more often than expected")
                 except StopIteration as done:
                     keys = done.value
                 jobs = [(kk[0], kk[1]) if isinstance(kk, tuple) else (kk, None) for kk in keys]
