@@ -295,6 +295,11 @@ def main():
     ap.add_argument("--first-stage-only", action="store_true",
                     help="stop after the first retrieval stage (SURVEY.md 8d metric) instead of the reference's complete batch_search")
     args = ap.parse_args()
+    # the contract is ONE JSON line on stdout: RCCL prints a version banner there (seen with one rank: five lines after
+    # the JSON line), so file descriptor 1 is pointed at stderr for everything but the line itself
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -622,7 +627,7 @@ def main():
                   "phase_ms_one_batch": {k: round(v, 2) for k, v in phases.items()},
                   "k_constrain_ms_one_batch": round(k2.value, 3), "k_constrain_blocks_one_batch": int(p2.value)},
     }
-    print(json.dumps(out), flush=True)
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
