@@ -105,6 +105,7 @@ def test_capture_gate_gives_a_capture_the_gpu_issuing_side_to_itself():
                 note(name, "in")
                 time.sleep(0.003)
                 if captures and i in (1, 2):
+                    note(name, "want")                       # from here on it issues nothing until its capture is over
                     with gate.capturing():
                         note(name, "cap")
                         time.sleep(0.01)
@@ -124,6 +125,8 @@ def test_capture_gate_gives_a_capture_the_gpu_issuing_side_to_itself():
             inside.add(name)
         elif what == "out":
             inside.discard(name)
+        elif what == "want":
+            inside.discard(name)
         elif what == "cap":
             assert holder is None and inside <= {name}, (name, inside, holder)   # the others have left their sections
             holder = name
@@ -131,6 +134,7 @@ def test_capture_gate_gives_a_capture_the_gpu_issuing_side_to_itself():
         else:
             assert holder == name
             holder = None
+            inside.add(name)                                 # back in its section
     assert n_caps == 4
     with gate.capturing():                                   # uncontended, from a thread that holds nothing
         pass
