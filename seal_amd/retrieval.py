@@ -231,11 +231,21 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
             force_decoding_from=[s.title_bos_token_id], eos_token_id=s.title_eos_token_id,
             diverse_bs_groups=s.diverse_bs_groups, diverse_bs_penalty=s.diverse_bs_penalty, keep_history=True,
             disable_fm_index=not constrained_generation, topk=s.topk, logit_bias=bias, pending=True, **dec(s.bart_title_model))
+    codes = code_toks = None
+    if s.decode_code:           # retrieval.py:212-236
+        strs, code_toks = marked("code")
+        codes = fm_index_generate(
+            s.bart_code_model, fm_index, **encoder_batch(strs, code_toks),
+            min_length=1, max_length=15, num_beams=s.beam, length_penalty=s.length_penalty,
+            eos_token_id=s.code_eos_token_id, diverse_bs_groups=s.diverse_bs_groups, diverse_bs_penalty=s.diverse_bs_penalty,
+            keep_history=True, force_decoding_from=[s.code_bos_token_id], disable_fm_index=not constrained_generation,
+            logit_bias=bias, pending=True, **dec(s.bart_code_model))
     yield "decoding"
 
     # ---- segment 2: the hypotheses (waits for the decodes) ----
     found_keys = body.result() if body is not None else [[] for _ in inputs]
     decoded = titles.result() if titles is not None else None
+    decoded_code = codes.result() if codes is not None else None
     yield "decoded"
 
     # ---- segment 3: filters, rescoring, query n-grams, unigram scores ----
@@ -275,8 +285,18 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
                 if s.min_length > 0:
                     fk[:] = [(sc, k) for sc, k in fk if len(k) == (s.min_length + 1)]
             fk[:] = [(sc, [s.title_bos_token_id] + k if k[0] != s.title_bos_token_id else k) for sc, k in fk]
-    # retrieval.py:91, 130, 191: get_count(k) > 0, one launch for the three lists
-    parts = [p for p in (found_keys if s.decode_body else None, cand, title_keys) if p is not None]
+    code_keys = None
+    if s.decode_code:
+        code_keys = [[(sc, hyp) for sc, hyp in dec_] for dec_ in decoded_code]
+        for fk in code_keys:    # retrieval.py:240-246
+            if s.force_decoding_second_token >= 0:
+                fk[:] = [(sc, k[:1] + k[2:]) for sc, k in fk if len(k) >= 2]
+            fk[:] = [(sc, k[1:-1] if k[-1] in strip_ids else k[1:]) for sc, k in fk if k]
+            if not s.partial_code:
+                fk[:] = [(sc, k) for sc, k in fk if k and k[-1] == s.code_eos_token_id]
+            fk[:] = [(sc, [s.code_bos_token_id] + k if k[0] != s.code_bos_token_id else k) for sc, k in fk if k]
+    # retrieval.py:91, 130, 191, 247: get_count(k) > 0, one launch for all the lists
+    parts = [p for p in (found_keys if s.decode_body else None, cand, title_keys, code_keys) if p is not None]
     n_q = len(inputs)
     if parts:
         merged = _count_filter(fm_index, [fk for p in parts for fk in p])
@@ -288,8 +308,10 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
             cand = [[k for _, k in kk] for kk in next(it)]
         if title_keys is not None:
             title_keys = next(it)
+        if code_keys is not None:
+            code_keys = next(it)
     marked_rescoring = s.rescore and s.use_markers
-    body_job = cand_job = title_job = None
+    body_job = cand_job = title_job = code_job = None
     if s.decode_body and marked_rescoring:
         body_job = rk.rescore_keys(
             s.bart_model, base_tokens, found_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
@@ -306,6 +328,11 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
             s.bart_title_model, title_toks, title_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
             strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=bias,
             encoded=(titles.enc, titles.attention_mask) if tokenised and titles.enc is not None else None, pending=True)
+    if code_keys is not None and marked_rescoring:     # retrieval.py:249-263
+        code_job = rk.rescore_keys(
+            s.bart_code_model, code_toks, code_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
+            strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=bias,
+            encoded=(codes.enc, codes.attention_mask) if tokenised and codes.enc is not None else None, pending=True)
     yield "rescoring"                            # everything of this batch up to the scores is enqueued; nothing read back yet
     if body_job is not None:
         found_keys = body_job.result()
@@ -317,9 +344,11 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
             title_keys = title_job.result()
         for nfk, fk in zip(title_keys, found_keys):
             fk += nfk
-
-    if s.decode_code:
-        raise NotImplementedError("decode_code is off in the reference's defaults (retrieval.py:437) and not built here")
+    if code_keys is not None:
+        if code_job is not None:
+            code_keys = code_job.result()
+        for nfk, fk in zip(code_keys, found_keys):
+            fk += nfk
 
     if s.rescore and not s.use_markers:
         found_keys = rk.rescore_keys(s.bart_scorer_model, last_input_tokens, found_keys, batch_size=100, length_penalty=0.0,

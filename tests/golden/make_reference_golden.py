@@ -27,6 +27,13 @@ import random
 import sys
 import types
 
+# The reference keeps the query n-grams of add_query_to_keys in a python set of STRINGS (retrieval.py:115-131): their order,
+# and with it the order of the keys in ref_searcher.json, follows the interpreter's string hashing, which is randomised per
+# process.  Pin it, so that re-running this script reproduces the committed files byte for byte.
+if os.environ.get("PYTHONHASHSEED") != "0":
+    os.environ["PYTHONHASHSEED"] = "0"
+    os.execv(sys.executable, [sys.executable] + sys.argv)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REFERENCE = os.environ.get("SEAL_REFERENCE", "/root/reference")
@@ -451,7 +458,9 @@ def searcher_cases():
     out = {"vocab": vocab, "beam": K, "length": length, "title_eos": title_eos, "docs": docs, "queries": queries_ids, "runs": []}
     ref_retrieval.word_tokenizer = _split_words
     # 15 is the reference's constant; 8 is what tests/test_gpu_search.py runs both sides at
-    for title_length, query_keys in ((8, False), (15, False), (8, True)):
+    # the fourth run switches the code decode on (retrieval.py:212-264; partial_code: this corpus has no code sections, so
+    # complete code keys do not exist)
+    for title_length, query_keys, code in ((8, False, False), (15, False, False), (8, True, False), (8, False, True)):
         def generate(*a, **kw):
             if kw.get("force_decoding_from"):
                 kw = {**kw, "max_length": title_length}
@@ -459,7 +468,8 @@ def searcher_cases():
         ref_retrieval.fm_index_generate = generate
         try:
             s = SEALSearcher(index, ToyTokenizer(vocab), _ModelForTheReferenceSearcher(tiny_bart(vocab)), backbone="bart-tiny",
-                             length=length, beam=K, batch_size=2, add_query_to_keys=query_keys, detokenize=True)
+                             length=length, beam=K, batch_size=2, add_query_to_keys=query_keys, detokenize=True,
+                             **(dict(decode_code=True, partial_code=True) if code else {}))
             # (include_keys=True cannot be used with more than one query: batch_search's `for k, _ in kk` rebinds its own
             #  parameter k, the islice stop; the per-document keys are read from retrieve_from_keys below instead)
             s.title_eos_token_id, s.code_bos_token_id, s.code_eos_token_id = title_eos, title_eos, vocab - 6
@@ -470,6 +480,8 @@ def searcher_cases():
         finally:
             ref_retrieval.fm_index_generate = real_generate
         run = {"title_length": title_length, "add_query_to_keys": query_keys, "queries": []}
+        if code:
+            run["decode_code"] = True
         for (kk, us), (res, _), docs_q in zip(keys, evidence, retrieved):
             assert [d.idx for d in docs_q] == list(res)[:10] and [d.score for d in docs_q] == [res[d.idx][0] for d in docs_q]
             run["queries"].append({

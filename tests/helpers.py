@@ -167,7 +167,7 @@ class ToyTokenizer:
     reference's searcher) and the product's tests."""
 
     def __init__(self, vocab):
-        self.special = {"||": vocab - 2, "body": vocab - 3, "title": vocab - 4, "+": vocab - 5}
+        self.special = {"||": vocab - 2, "body": vocab - 3, "title": vocab - 4, "+": vocab - 5, "code": vocab - 7}
         self.back = {v: k for k, v in self.special.items()}
 
     def _ids(self, text, add_special_tokens=True):

@@ -12,14 +12,15 @@ pytestmark = pytest.mark.gpu
 TITLE_EOS = 7
 
 
-def _oracle_pipeline(model, orc, queries, K, length, vocab, first_stage_only, title_length=8, return_keys=False, query_keys=False):
+def _oracle_pipeline(model, orc, queries, K, length, vocab, first_stage_only, title_length=8, return_keys=False, query_keys=False,
+                     decode_code=False):
     from oracle.beam_oracle import oracle_fm_index_generate
     from oracle.keys_oracle import (oracle_aggregate_evidence, oracle_body_postfilter, oracle_deduplicate,
                                     oracle_title_postfilter)
     from seal_amd import keys as rk
     from tests.helpers import hf_logits_fn
     pad = model.config.pad_token_id
-    mark = {"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5]}
+    mark = {"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5], "code": [vocab - 2, vocab - 7]}
 
     def enc(kind):
         toks = [q[:-1] + mark[kind] + mark["+"] + q[-1:] for q in queries]
@@ -41,10 +42,21 @@ def _oracle_pipeline(model, orc, queries, K, length, vocab, first_stage_only, ti
                                      pad_token_id=pad, eos_token_id=TITLE_EOS, length_penalty=0.0, force_decoding_from=[2])
     title = [oracle_title_postfilter(fk, orc, title_bos=2, title_eos=TITLE_EOS) for fk in title]
     title = rk.rescore_keys(model, ttoks, title, strip_from_bos=[2, TITLE_EOS, 2], strip_from_eos=[2])
+    code = [[] for _ in queries]
+    if decode_code:      # reference retrieval.py:212-264 with partial_code=True; code_bos = TITLE_EOS, code_eos = vocab - 6 as the searchers under test
+        ctoks, ids, am = enc("code")
+        code = oracle_fm_index_generate(hf_logits_fn(model, ids, am, K), orc, len(queries), K, title_length, vocab,
+                                        pad_token_id=pad, eos_token_id=vocab - 6, length_penalty=0.0, force_decoding_from=[TITLE_EOS])
+        strip_ids = {0, 1, 2}
+        for fk in code:
+            fk[:] = [(sc, k[1:-1] if k[-1] in strip_ids else k[1:]) for sc, k in fk if k]
+            fk[:] = [(sc, [TITLE_EOS] + k if k[0] != TITLE_EOS else k) for sc, k in fk if k]
+            fk[:] = [(sc, k) for sc, k in fk if k and orc.get_count(k) > 0]
+        code = rk.rescore_keys(model, ctoks, code, strip_from_bos=[2, TITLE_EOS, 2], strip_from_eos=[2])
     out, all_keys = [], []
     uni = rk.compute_unigram_scores(model, toks)
-    for b, t, u in zip(body, title, uni):
-        keys = [(n, s) for s, n in oracle_deduplicate(b + t)]
+    for b, t, c, u in zip(body, title, code, uni):
+        keys = [(n, s) for s, n in oracle_deduplicate(b + t + c)]
         all_keys.append(keys)
         out.append(oracle_aggregate_evidence(keys, unigram_scores=u, index=orc, max_occurrences_1=1500,
                                              n_docs_complete_score=1500, alpha=2.0, beta=0.8, add_best_unigrams_to_ngrams=True,
@@ -72,7 +84,8 @@ def _tie_groups(items, rel=1e-3):
 
 
 @pytest.mark.parametrize("geom", MODEL_GEOMETRIES, ids=MODEL_IDS)
-@pytest.mark.parametrize("first_stage_only,jobs,query_keys", [(False, 1, False), (True, 1, False), (False, 2, False), (True, 2, False), (False, 1, True)])
+@pytest.mark.parametrize("first_stage_only,jobs,query_keys", [(False, 1, False), (True, 1, False), (False, 2, False), (True, 2, False), (False, 1, True),
+                                                              (False, 1, "code")])
 def test_searcher_ranks_like_the_scalar_pipeline(first_stage_only, jobs, query_keys, geom, monkeypatch):
     from oracle.seal_oracle import OracleFMIndex
     from seal_amd import FMIndex
@@ -80,6 +93,8 @@ def test_searcher_ranks_like_the_scalar_pipeline(first_stage_only, jobs, query_k
     from seal_amd.retrieval import SEALSearcher
     from tests.helpers import make_docs, tiny_bart
     vocab = 120
+    decode_code = query_keys == "code"       # the third decode of retrieval.py:212-264 (partial_code: the corpus has no code sections)
+    query_keys = False if decode_code else query_keys
     dev = torch.device("cuda:0")
     docs = make_docs(5, 200, vocab - 8, min_len=6, max_len=18, title_sep=TITLE_EOS)
     ix, orc = FMIndex(), OracleFMIndex()
@@ -95,12 +110,14 @@ def test_searcher_ranks_like_the_scalar_pipeline(first_stage_only, jobs, query_k
                         lambda *a, **kw: real(*a, **{**kw, "max_length": 8 if kw.get("force_decoding_from") else kw["max_length"]}))
     s = SEALSearcher(ix, None, tiny_bart(vocab, **geom).to(dev), backbone="bart-tiny", length=length, beam=K, batch_size=2,
                      add_query_to_keys=query_keys, detokenize=False, first_stage_only=first_stage_only, jobs=jobs,
-                     title_eos_token_id=TITLE_EOS, code_eos_token_id=vocab - 6, code_bos_token_id=TITLE_EOS,
-                     marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5]})
+                     title_eos_token_id=TITLE_EOS, code_eos_token_id=vocab - 6, code_bos_token_id=TITLE_EOS, decode_code=decode_code,
+                     partial_code=decode_code,
+                     marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5],
+                                       "code": [vocab - 2, vocab - 7]})
     got = s.batch_search(queries, k=10)
     st = s.bart_model._seal_step_decoder._st
     assert st.fused is (geom["d_model"] // geom["heads"] == 64)       # no silent fallback from the sealnn_* kernels
-    want = _oracle_pipeline(tiny_bart(vocab, **geom), orc, queries, K, length, vocab, first_stage_only, query_keys=query_keys)
+    want = _oracle_pipeline(tiny_bart(vocab, **geom), orc, queries, K, length, vocab, first_stage_only, query_keys=query_keys, decode_code=decode_code)
     for g, w in zip(got, want):
         w_all = list(w.items())
         w_items = w_all[:10]

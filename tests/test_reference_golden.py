@@ -270,7 +270,8 @@ def test_search_pipeline_equals_the_reference_searcher(run_no):
     orc = OracleFMIndex()
     orc.initialize(SEARCH["docs"])
     results, keys = _oracle_pipeline(tiny_bart(vocab), orc, SEARCH["queries"], K, length, vocab, False,
-                                     title_length=run["title_length"], return_keys=True, query_keys=run["add_query_to_keys"])
+                                     title_length=run["title_length"], return_keys=True, query_keys=run["add_query_to_keys"],
+                                     decode_code=run.get("decode_code", False))
     for got, got_keys, want in zip(results, keys, run["queries"]):
         want_keys = {tuple(n): _unhex(s) for n, s in want["keys"]}
         have_keys = {tuple(n): s for n, s in got_keys}
@@ -317,7 +318,7 @@ def test_fairseq_checkpoint_loader_equals_the_reference(tmp_path):
     assert np.allclose(logits[:, -1, :16].flatten().double().numpy(), want, atol=1e-6, rtol=0, equal_nan=True)
 
 
-@pytest.mark.parametrize("title_length,jobs,query_keys", [(8, 1, None), (15, 1, None), (8, 2, None), (8, 1, "strings"), (8, 1, "token ids")])
+@pytest.mark.parametrize("title_length,jobs,query_keys", [(8, 1, None), (15, 1, None), (8, 2, None), (8, 1, "strings"), (8, 1, "token ids"), (8, 1, "code")])
 def test_product_searcher_equals_the_reference_searcher(title_length, jobs, query_keys, monkeypatch):
     """the PRODUCT's SEALSearcher.batch_search, all of its Python (key generation recipe, batched post-filters,
     prefix-sharing rescoring, batched evidence aggregation with the native host routines, worker processes,
@@ -326,7 +327,10 @@ def test_product_searcher_equals_the_reference_searcher(title_length, jobs, quer
     from seal_amd import retrieval
     from seal_amd.retrieval import SEALSearcher
     from tests.helpers import OracleLogitsProcessor, tiny_bart
-    run = [r for r in SEARCH["runs"] if r["title_length"] == title_length and r["add_query_to_keys"] == (query_keys is not None)][0]
+    decode_code = query_keys == "code"        # the run with the code decode switched on (partial_code: the corpus has no code sections)
+    query_keys = None if decode_code else query_keys
+    run = [r for r in SEARCH["runs"] if r["title_length"] == title_length and r["add_query_to_keys"] == (query_keys is not None)
+           and bool(r.get("decode_code")) == decode_code][0]
     vocab, K, length, title_eos = SEARCH["vocab"], SEARCH["beam"], SEARCH["length"], SEARCH["title_eos"]
     orc = OracleFMIndex()
     orc.initialize(SEARCH["docs"])
@@ -366,8 +370,9 @@ def test_product_searcher_equals_the_reference_searcher(title_length, jobs, quer
         tokenizer, queries = ToyTokenizer(vocab), [" ".join(f"w{t}" for t in q[1:-1]) for q in SEARCH["queries"]]
     s = SEALSearcher(index, tokenizer, tiny_bart(vocab), backbone="bart-tiny", length=length, beam=K, batch_size=2,
                      add_query_to_keys=query_keys is not None, detokenize=False, jobs=jobs, title_eos_token_id=title_eos,
-                     code_eos_token_id=vocab - 6, code_bos_token_id=title_eos,
-                     marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5]})
+                     code_eos_token_id=vocab - 6, code_bos_token_id=title_eos, decode_code=decode_code, partial_code=decode_code,
+                     marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5],
+                                       "code": [vocab - 2, vocab - 7]})
     if query_keys is not None:       # the keys themselves: same n-grams, scores within fp32 noise (their order follows a python set's)
         for got_q, want_q in zip(s.batch_generate_keys(queries), run["queries"]):
             gk = {tuple(k): v for k, v in got_q[0]}
