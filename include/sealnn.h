@@ -38,6 +38,11 @@ int sealnn_causal_self_attn(void *stream, const float *qkv, uint32_t n_seq, uint
 int sealnn_cross_attn_rows(void *stream, const float *q, const float *ck, const float *cv, const float *bias,
                            const int32_t *row_batch, uint32_t rows, uint32_t heads, uint32_t S, float scale, float *out);
 
+/* the same when the rows come in runs of `group` consecutive rows that attend the same query (row_batch is read at the
+ * first row of every run; rows % group == 0): K/V of a (run, head) are staged in LDS once.  Bit-identical results. */
+int sealnn_cross_attn_runs(void *stream, const float *q, const float *ck, const float *cv, const float *bias,
+                           const int32_t *row_batch, uint32_t rows, uint32_t group, uint32_t heads, uint32_t S, float scale, float *out);
+
 #ifdef __cplusplus
 }
 #endif

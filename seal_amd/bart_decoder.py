@@ -231,8 +231,9 @@ class BartStepDecoder:
             q = L["cq"](x)
             c = torch.empty(N * T, self.d, dtype=x.dtype, device=dev)
             ck, cv = cross[li]
-            check(L_.sealnn_cross_attn_rows(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
-                                            N * T, self.h, S, float(self.scale), c.data_ptr()))
+            # the T positions of a sequence attend the same query: one staging of its K/V per (sequence, head)
+            check(L_.sealnn_cross_attn_runs(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
+                                            N * T, T, self.h, S, float(self.scale), c.data_ptr()))
             x = add_ln(x, L["co"](c), L["ln2"])
             x = add_ln(x, L["fc2"](L["act"](L["fc1"](x))), L["ln3"])
         return F.linear(x, self.lm_w, self.lm_b.view(-1)).view(N, T, -1)

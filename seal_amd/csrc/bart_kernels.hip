@@ -3,6 +3,8 @@
 // ~17 launch-bound PyTorch kernels per decoder layer with 3, not to reach a roofline.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "../../include/sealnn.h"
 #include "fmi_internal.h"
 
@@ -143,6 +145,46 @@ __global__ __launch_bounds__(256) void k_cross_attn_rows(const float *q, const f
     out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
 }
 
+// the same for rows that come in runs of `group` consecutive rows attending the same query (teacher forcing: the T
+// positions of a sequence): one workgroup per (run, head) stages that head's K [64, S] and V [S, 64] in LDS once and its
+// four waves walk the run's rows -- the keys and values are read from L2 once per run instead of once per row.  Same
+// arithmetic, in the same order, as k_cross_attn_rows.
+__global__ __launch_bounds__(512) void k_cross_attn_runs(const float *q, const float *ck, const float *cv, const float *bias,
+                                                         const int32_t *row_batch, uint32_t rows, uint32_t group, uint32_t heads,
+                                                         uint32_t S, float scale, float *out)
+{
+    extern __shared__ float s_kv[];                 // K [64, S] then V [S, 64]: 512 S bytes, so that several runs share a CU
+    float *s_k = s_kv, *s_v = s_kv + 64 * S;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t run = blockIdx.x / heads, head = blockIdx.x % heads;
+    const uint32_t row0 = run * group;
+    const uint32_t b = (uint32_t)row_batch[row0];
+    const float *k = ck + ((uint64_t)b * heads + head) * 64 * S;
+    const float *v = cv + ((uint64_t)b * heads + head) * S * 64;
+    for (uint32_t i = threadIdx.x; i < 64 * S; i += blockDim.x) { s_k[i] = k[i]; s_v[i] = v[i]; }
+    // this wave's rows: their queries are fetched while the staging loads are in flight
+    const float bi = lane < S ? bias[(uint64_t)b * S + lane] : 0.f;
+    __syncthreads();
+    for (uint32_t t = wv; t < group && row0 + t < rows; t += nw) {
+        const uint32_t row = row0 + t;
+        const float qd = q[((uint64_t)row * heads + head) * 64 + lane] * scale;
+        float sc = 0.f;
+#pragma unroll 16
+        for (uint32_t d = 0; d < 64; d++) {
+            const float qv = __shfl(qd, d);
+            if (lane < S) sc += qv * s_k[d * S + lane];
+        }
+        sc = lane < S ? sc + bi : -__builtin_huge_valf();
+        const float m = wave_max(sc);
+        const float e = lane < S ? expf(sc - m) : 0.f;
+        const float denom = wave_sum(e);
+        float acc = 0.f;
+#pragma unroll 8
+        for (uint32_t p = 0; p < S; p++) acc += __shfl(e, p) * s_v[p * 64 + lane];
+        out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
+    }
+}
+
 // one wavefront per row, d <= 4096 (16 float4 per lane)
 __global__ __launch_bounds__(256) void k_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta,
                                                        uint32_t rows, uint32_t d, float eps, float *out)
@@ -234,6 +276,20 @@ extern "C" int sealnn_cross_attn_rows(void *stream, const float *q, const float 
     if (S > 64) { fmi_set_error("sealnn_cross_attn_rows: encoder length %u > 64", S); return FMI_ERR_UNSUPPORTED; }
     const uint32_t items = rows * heads;
     hipLaunchKernelGGL(k_cross_attn_rows, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, ck, cv, bias, row_batch, rows, heads, S, scale, out);
+    NNCHK();
+    return FMI_OK;
+}
+
+extern "C" int sealnn_cross_attn_runs(void *stream, const float *q, const float *ck, const float *cv, const float *bias,
+                                      const int32_t *row_batch, uint32_t rows, uint32_t group, uint32_t heads, uint32_t S, float scale,
+                                      float *out)
+{
+    if (S > 64) { fmi_set_error("sealnn_cross_attn_runs: encoder length %u > 64", S); return FMI_ERR_UNSUPPORTED; }
+    if (group == 0 || rows % group) { fmi_set_error("sealnn_cross_attn_runs: %u rows are not runs of %u", rows, group); return FMI_ERR_ARG; }
+    // one wave per position of the run, up to eight
+    const unsigned threads = 64 * std::min<unsigned>(8, std::max<unsigned>(1, group));
+    hipLaunchKernelGGL(k_cross_attn_runs, dim3((rows / group) * heads), dim3(threads), (size_t)512 * S, (hipStream_t)stream, q, ck, cv, bias,
+                       row_batch, rows, group, heads, S, scale, out);
     NNCHK();
     return FMI_OK;
 }

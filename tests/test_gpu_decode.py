@@ -376,3 +376,35 @@ def test_row_pick_paths_agree_at_bart_vocabulary_and_match_torch(kind, monkeypat
                     cand = torch.nonzero(vals == v).flatten().tolist()
                     picked = sorted(i for i, s in zip(flat[q].tolist(), mine) if s == v)
                     assert picked == cand[:len(picked)], (n_allowed, q, v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,T", [(17, 11), (64, 16), (1, 1), (33, 17)])
+def test_cross_attention_over_runs_is_bit_identical_to_the_per_row_kernel(S, T):
+    """sealnn_cross_attn_runs (teacher forcing: K/V of a (sequence, head) staged once for its T positions) against
+    sealnn_cross_attn_rows (one wave per row, K/V from memory) and a torch reference"""
+    from seal_amd._lib import check, lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(S * 100 + T)
+    nq, heads, n_seq = 5, 3, 7
+    rows = n_seq * T
+    q = torch.randn(rows, heads, 64, generator=g).to(dev)
+    ck = torch.randn(nq, heads, 64, S, generator=g).to(dev)
+    cv = torch.randn(nq, heads, S, 64, generator=g).to(dev)
+    bias = torch.zeros(nq, S)
+    bias[torch.rand(nq, S, generator=g) < 0.2] = torch.finfo(torch.float32).min
+    bias[:, 0] = 0
+    bias = bias.to(dev)
+    seq_q = torch.randint(0, nq, (n_seq,), generator=g)
+    row_batch = seq_q.repeat_interleave(T).to(torch.int32).to(dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    a, b = torch.empty(rows, heads * 64, device=dev), torch.empty(rows, heads * 64, device=dev)
+    check(lib().sealnn_cross_attn_rows(st, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(), rows, heads, S,
+                                       0.125, a.data_ptr()))
+    check(lib().sealnn_cross_attn_runs(st, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(), rows, T, heads, S,
+                                       0.125, b.data_ptr()))
+    assert torch.equal(a, b)
+    rb = row_batch.long()
+    att = torch.softmax(torch.einsum("rhd,rhds->rhs", q * 0.125, ck[rb]) + bias[rb][:, None, :], -1)
+    ref = torch.einsum("rhs,rhsd->rhd", att, cv[rb]).reshape(rows, heads * 64)
+    assert torch.allclose(b, ref, atol=2e-5, rtol=1e-5)
