@@ -13,6 +13,12 @@ static __device__ __forceinline__ float wave_sum(float v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// the value lane `i` holds, for a wave-uniform i: v_readlane into a scalar register (no LDS round trip, unlike __shfl,
+// which is a ds_bpermute)
+static __device__ __forceinline__ float lane_value(float v, uint32_t i)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)i));
+}
 static __device__ __forceinline__ float wave_max(float v)
 {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(1024) void k_cross_attn_step(const float *q, const 
         const float qd = q[((uint64_t)row * heads + head) * 64 + lane] * scale;
         float sc = 0.f;
         for (uint32_t d = 0; d < 64; d++) {
-            const float qv = __shfl(qd, d);
+            const float qv = lane_value(qd, d);
             if (lane < S) sc += qv * s_k[d * S + lane];
         }
         sc = lane < S ? sc + bi : -__builtin_huge_valf();
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(1024) void k_cross_attn_step(const float *q, const 
         const float e = lane < S ? expf(sc - m) : 0.f;
         const float denom = wave_sum(e);
         float acc = 0.f;
-        for (uint32_t p = 0; p < S; p++) acc += __shfl(e, p) * s_v[p * 64 + lane];
+        for (uint32_t p = 0; p < S; p++) acc += lane_value(e, p) * s_v[p * 64 + lane];
         out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
     }
 }
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256) void k_cross_attn_rows(const float *q, const f
     const float *v = cv + ((uint64_t)b * heads + head) * S * 64;
     float sc = 0.f;
     for (uint32_t d = 0; d < 64; d++) {
-        const float qv = __shfl(qd, d);
+        const float qv = lane_value(qd, d);
         if (lane < S) sc += qv * k[(uint64_t)d * S + lane];
     }
     sc = lane < S ? sc + bias[(uint64_t)b * S + lane] : -__builtin_huge_valf();
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(256) void k_cross_attn_rows(const float *q, const f
     const float e = lane < S ? expf(sc - m) : 0.f;
     const float denom = wave_sum(e);
     float acc = 0.f;
-    for (uint32_t p = 0; p < S; p++) acc += __shfl(e, p) * v[(uint64_t)p * 64 + lane];
+    for (uint32_t p = 0; p < S; p++) acc += lane_value(e, p) * v[(uint64_t)p * 64 + lane];
     out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
 }
 
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(512) void k_cross_attn_runs(const float *q, const f
         float sc = 0.f;
 #pragma unroll 16
         for (uint32_t d = 0; d < 64; d++) {
-            const float qv = __shfl(qd, d);
+            const float qv = lane_value(qd, d);
             if (lane < S) sc += qv * s_k[d * S + lane];
         }
         sc = lane < S ? sc + bi : -__builtin_huge_valf();
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(512) void k_cross_attn_runs(const float *q, const f
         const float denom = wave_sum(e);
         float acc = 0.f;
 #pragma unroll 8
-        for (uint32_t p = 0; p < S; p++) acc += __shfl(e, p) * s_v[p * 64 + lane];
+        for (uint32_t p = 0; p < S; p++) acc += lane_value(e, p) * s_v[p * 64 + lane];
         out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
     }
 }
