@@ -72,12 +72,51 @@ def main():
             if dd == d:
                 found_own = True
         assert found_own, ("own document not among the located rows", d, pat)
+    # ---- the constraint kernel (k_constrain) at this scale: for decoder prefixes cut out of the corpus, a token is allowed
+    # iff the prefix extended by it occurs -- checked for EVERY token of the vocabulary on a few rows (50 k counts each,
+    # one launch) and for the allowed tokens plus the corpus's own continuation on all rows
+    import ctypes
+    from seal_amd._lib import check, lib
+    V = bench.VOCAB
+    mask_rows = []
+    for d, fwd, a, pat in picks[:96]:
+        if a + len(pat) < len(fwd):
+            mask_rows.append((pat, fwd[a + len(pat)]))
+    width = max(len(p) for p, _ in mask_rows)
+    by_len = {}
+    for pat, nxt in mask_rows:
+        by_len.setdefault(len(pat), []).append((pat, nxt))
+    mask_checked = mask_bad = full_rows = 0
+    for plen, group in sorted(by_len.items()):
+        ids = torch.tensor([[2] + pat for pat, _ in group], dtype=torch.long, device=dev)
+        bits = torch.zeros(len(group), (V + 31) // 32, dtype=torch.int32, device=dev)
+        check(lib().fmi_dev_allowed_bits(ix.handle, torch.cuda.current_stream(dev).cuda_stream, len(group), plen + 1, ids.data_ptr(),
+                                         bits.data_ptr(), V, bench.SHIFT, 1, 2, None, 0, 0, 0))
+        torch.cuda.synchronize()
+        words = bits.cpu().numpy().view(np.uint32)
+        allowed = np.unpackbits(words.view(np.uint8), axis=1, bitorder="little")[:, :V].astype(bool)
+        for r, (pat, nxt) in enumerate(group):
+            assert allowed[r, nxt], ("the corpus's own continuation is not allowed", pat, nxt)
+            toks = np.nonzero(allowed[r])[0].tolist()
+            if full_rows < 4 and plen <= 2:                    # the whole vocabulary, both directions
+                cand = list(range(V))
+                full_rows += 1
+            else:
+                cand = toks[:200]
+            l2, h2 = ix.get_range_batch([pat + [t] for t in cand])
+            occurs = (h2.astype(np.int64) - l2.astype(np.int64)) > 0
+            for t, oc in zip(cand, occurs.tolist()):
+                mask_checked += 1
+                if bool(allowed[r, t]) != bool(oc) and t not in (0, 1, 2, 3):
+                    mask_bad += 1
+    assert full_rows >= 1 and mask_bad == 0, (full_rows, mask_bad)
     sample_docs = [0, 1, n_docs // 2, n_docs - 1]
     for d, fwd, _, _ in picks[:20]:
         assert ix.get_doc(d) == fwd
     print(json.dumps({"docs": args.docs, "n": n, "wide_indices": n > 2**32, "hbm_gib": round(ix.device_bytes() / 2**30, 2),
                       "corpus_s": round(t_gen, 1), "build_s": round(t_build, 1), "patterns": len(picks), "rows_checked": checked_rows,
-                      "mismatching_rows": bad, "peak_torch_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
+                      "mismatching_rows": bad, "mask_rows": len(mask_rows), "mask_tokens_checked": mask_checked, "mask_rows_over_the_whole_vocabulary": full_rows,
+                      "mask_mismatches": mask_bad, "peak_torch_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
     assert bad == 0
 
 
