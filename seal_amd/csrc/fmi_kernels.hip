@@ -204,8 +204,12 @@ __device__ __forceinline__ uint32_t root_children_mask(const FmiDev &ix, uint64_
 // relative level; EMIT_BITS: s_bits8 = the wave's leaf bitmap (16^(D-root) bits, zeroed by the caller):
 // bit i = symbol (rprefix << 4 (D-root)) + i.  `counting` (wave-uniform) switches the measurement
 // bookkeeping on.
-template <int MODE, bool SB>
-__device__ __forceinline__ void expand_subtree(const FmiDev &ix, uint4 *s_node, uint32_t *s_cnt, uint8_t *s_bits8,
+// DEFER (k_constrain with several waves per workgroup, dlevels <= 4): the leaf level is NOT popped -- the
+// function returns the number of leaf-level nodes it left in array D - 1 - root (complete, because every level
+// above the leaves holds <= 32 nodes and is popped in one iteration); the workgroup's waves then serve the leaf
+// nodes of all its items together (leaf_phase).
+template <int MODE, bool SB, bool DEFER = false>
+__device__ __forceinline__ uint32_t expand_subtree(const FmiDev &ix, uint4 *s_node, uint32_t *s_cnt, uint8_t *s_bits8,
                                                const uint32_t row, const uint32_t root, const uint64_t rlo, const uint64_t rhi,
                                                const uint32_t rprefix, const EmitTarget &tgt, const bool counting, ExpCounters &ctr)
 {
@@ -218,6 +222,7 @@ __device__ __forceinline__ void expand_subtree(const FmiDev &ix, uint4 *s_node, 
     wave_sync();
     int deepest = 0;   // relative level of the deepest non-empty array (wave uniform)
     while (deepest >= 0) {
+        if (DEFER && root + (uint32_t)deepest + 1 == D) break;
         // LDS hands the counter back in a VGPR; it is the same in every lane, and the whole loop
         // (level, offsets, the per-level dbase[] loads) stays scalar only if the compiler knows
         const uint32_t cnt = __builtin_amdgcn_readfirstlane(s_cnt[deepest]);
@@ -299,6 +304,83 @@ __device__ __forceinline__ void expand_subtree(const FmiDev &ix, uint4 *s_node, 
         }
     }
     wave_sync();
+    if (DEFER) return deepest >= 0 ? (uint32_t)__builtin_amdgcn_readfirstlane(s_cnt[deepest]) : 0u;
+    return 0u;
+}
+
+// The leaf-level nodes of the W items of a workgroup, served by all its waves: chunk c (32 nodes of the
+// concatenated leaf frontiers) goes to wave c % W.  A node's eight-bit existence masks go into the LDS bitmap of
+// the item that owns it (distinct bytes for distinct nodes: no conflicts between waves).  Balances the waves of
+// a workgroup -- an item with 256 leaf-level nodes next to items with a handful costs every wave one or two
+// iterations instead of one wave eight -- and packs the lane pairs.
+template <bool SB, int W>
+__device__ __forceinline__ void leaf_phase(const FmiDev &ix, const uint4 *s_items, uint32_t stride, const uint32_t (&off)[W + 1],
+                                           const bool counting, ExpCounters &ctr)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, end = lane & 1, pair = lane >> 1;
+    const uint32_t D = ix.dlevels, k = D - 1;
+    const uint32_t pad_bits = FMI_DIGIT_BITS * D - ix.levels;
+    const uint32_t rel_mask = (1u << (FMI_DIGIT_BITS * (D - 2))) - 1;      // sub-tree roots are level-1 nodes
+    const uint32_t node0 = (uint32_t)lvl_off((int)D - 2), bits0 = (uint32_t)exp_slots((int)D - 1) + 2;   // in 16-byte slots
+    const uint32_t total = off[W];
+    for (uint32_t c0 = wave * EXP_PAIRS; c0 < total; c0 += W * EXP_PAIRS) {
+        const uint32_t g = c0 + pair;
+        const bool act = g < total;
+        uint32_t item = 0, first = 0;
+#pragma unroll
+        for (int j = 1; j < W; j++) { const bool ge = g >= off[j]; item = ge ? (uint32_t)j : item; first = ge ? off[j] : first; }
+        const uint4 *it = s_items + (size_t)item * stride;
+        uint4 nd = make_uint4(0u, 0u, 0u, 0u);
+        if (act) nd = it[node0 + (g - first)];
+        const uint64_t lo = (uint64_t)nd.x | ((uint64_t)(nd.z & 0xff) << 32);
+        const uint64_t hi = (uint64_t)nd.y | ((uint64_t)((nd.z >> 8) & 0xff) << 32);
+        const uint32_t prefix = nd.z >> 16;
+        const uint64_t p = end ? hi : lo;
+        const uint64_t blk = p >> FMI_BLOCK_SHIFT, oblk = (end ? lo : hi) >> FMI_BLOCK_SHIFT;
+        uint32_t r[16];
+#pragma unroll
+        for (uint32_t d = 0; d < 16; d++) r[d] = 0;
+        if (act) {
+            HBlock b;
+            wm_load_block(ix, k, blk, b);
+            wm_block_ranks(b, (uint32_t)p & (FMI_BLOCK_BITS - 1), r);
+        }
+        const uint64_t *rowl = nullptr, *rowh = nullptr;
+        if constexpr (SB) {
+            const uint64_t mine = ((uint64_t)k * ix.nsb + (blk >> ix.sb_shift)) * FMI_ARITY;
+            const uint64_t other = ((uint64_t)k * ix.nsb + (oblk >> ix.sb_shift)) * FMI_ARITY;
+            rowl = ix.sbase + (end ? other : mine);
+            rowh = ix.sbase + (end ? mine : other);
+        }
+        uint32_t hm = 0;
+#pragma unroll
+        for (uint32_t s = 0; s < 8; s++) {
+            const uint32_t x = dpp_xor1(r[s]), y = dpp_xor1(r[s + 8]);
+            const uint32_t cl = end ? y : r[s], ch = end ? r[s + 8] : x;
+            bool ex;
+            if constexpr (SB) {
+                const uint32_t dm = s + 8 * end;
+                ex = act && (rowh[dm] + ch) > (rowl[dm] + cl);      // !act: block 0's rows, a valid address
+            } else {
+                ex = act && ch > cl;        // both ends add the same dbase[k][digit]
+            }
+            hm |= (uint32_t)ex << s;
+        }
+        if (counting) {
+            const uint32_t other_hm = dpp_xor1(hm);
+            if (act && end == 0) {
+                ctr.model += model_nodes(hm | (other_hm << 8), k, pad_bits);
+                ctr.probes += oblk != blk ? 2 : 1;
+            }
+            const uint32_t left = total - c0;
+            ctr.iters++; ctr.nodes += left < EXP_PAIRS ? left : EXP_PAIRS;
+        }
+        if (prefix == 0 && end == 0) hm &= ~1u;          // symbol 0 is the sentinel, never a token
+        if (hm) {
+            uint8_t *bits8 = reinterpret_cast<uint8_t *>(const_cast<uint4 *>(it) + bits0);
+            bits8[((prefix & rel_mask) << 1) + end] = (uint8_t)hm;
+        }
+    }
 }
 
 // 32 bits [o, o + 32) of an LDS bit array of nw words, zeros outside it
@@ -441,6 +523,7 @@ struct ConstrainArgs {
     uint64_t *st_out;
     uint64_t *probe_counter;
     uint64_t *tstamp;              // tools only: 8 realtime stamps (100 MHz) per wave, or null
+    uint32_t groups;               // W > 1: row groups per top digit (ceil(rows / W); grid = groups * ndig0 workgroups)
 };
 
 // a special token (pad / eos) of the row: into the LDS bitmap of the wave that owns its symbol; tokens
@@ -461,100 +544,140 @@ __device__ __forceinline__ void set_special(const FmiDev &ix, const ConstrainArg
     }
 }
 
-template <bool SB>
-__global__ __launch_bounds__(64) void k_constrain(FmiDev ix, ConstrainArgs a)
+// W = waves per workgroup.  W = 1: one self-contained wave per item (any depth).  W > 1 (host: 2 <= dlevels <= 4):
+// the W waves of a workgroup take W consecutive rows of one top digit, each expands its item down to the level above
+// the leaves, then all of them serve the leaf-level nodes of the W items together (leaf_phase).
+// dynamic LDS: [32-byte header: leaf counts, W > 1 only] + W x constrain_wave_slots(D) 16-byte slots
+__host__ __device__ constexpr uint32_t constrain_wave_slots(uint32_t D)
+{
+    // frontier + 8 counters + the item's leaf bitmap (16^(D-1) bits)
+    return (uint32_t)exp_slots((int)D - 1) + 2 + ((((1u << (FMI_DIGIT_BITS * (D - 1))) + 31) / 32 + 3) / 4);
+}
+
+static constexpr int CONSTRAIN_WG = 8;       // 8 x 4.9 KB of LDS per workgroup at BART's depth, two workgroups per CU
+
+template <bool SB, int W>
+__global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, ConstrainArgs a)
 {
     extern __shared__ uint4 s_dyn[];
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t D = ix.dlevels;
     const uint32_t sub_bits = FMI_DIGIT_BITS * (D - 1);        // symbol bits below the top digit
     const uint32_t nsym = 1u << sub_bits;                       // symbols of one wave's sub-tree
     const uint32_t nw = (nsym + 31) >> 5;
-    uint4 *s_node = s_dyn;
+    const uint32_t stride = constrain_wave_slots(D);
+    uint4 *s_items = s_dyn + (W > 1 ? (W * 4 + 15) / 16 : 0);
+    uint4 *s_node = s_items + (size_t)wave * stride;
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_node + exp_slots((int)D - 1));
     uint32_t *s_bits = s_cnt + 8;
-    // rows are padded to a multiple of 8 in the grid: workgroup i runs on XCD i % 8, so every wave of a row lands on
-    // the same XCD and the row's own probes (prefix step, root) miss its L2 once instead of once per XCD
-    const uint32_t rows8 = (a.rows + 7) & ~7u;
-    const uint32_t d1 = blockIdx.x / rows8, r = blockIdx.x - d1 * rows8;
+    uint32_t d1, r;
+    if constexpr (W == 1) {
+        // rows are padded to a multiple of 8 in the grid: workgroup i runs on XCD i % 8, so every wave of a row lands on
+        // the same XCD and the row's own probes (prefix step, root) miss its L2 once instead of once per XCD
+        const uint32_t rows8 = (a.rows + 7) & ~7u;
+        d1 = blockIdx.x / rows8; r = blockIdx.x - d1 * rows8;
+    } else {
+        d1 = blockIdx.x / a.groups; r = (blockIdx.x - d1 * a.groups) * W + wave;
+    }
+    const uint32_t slot = blockIdx.x * W + wave;               // of the debug stamps
     const bool writer = d1 == 0;
     const bool counting = a.probe_counter != nullptr;
     ExpCounters ctr{0, 0, 0, 0};
-#define STAMP(i) do { if (a.tstamp && lane == 0) a.tstamp[(uint64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP(i) do { if (a.tstamp && lane == 0) a.tstamp[(uint64_t)slot * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     STAMP(0);
 
-    // housekeeping for the next call: this wave's share of the other bitmap buffer
+    // housekeeping for the next call: this workgroup's share of the other bitmap buffer
     if (a.clear) {
         const uint64_t per = (a.clear_words + gridDim.x - 1) / gridDim.x;
         const uint64_t w0 = (uint64_t)blockIdx.x * per;
-        for (uint64_t w = w0 + lane; w < w0 + per && w < a.clear_words; w += 64) a.clear[w] = 0u;
+        for (uint64_t w = w0 + threadIdx.x; w < w0 + per && w < a.clear_words; w += 64 * W) a.clear[w] = 0u;
     }
-    if (r >= a.rows) return;            // padding workgroup: its share of the clearing is all it does
+    const bool valid = r < a.rows;      // padding wave: its share of the clearing (and of a workgroup's leaf phase) is all it does
+    if (W == 1 && !valid) return;
     for (uint32_t w = lane; w < nw; w += 64) s_bits[w] = 0u;
 
     // ---- the row: prefix range, class (identical in every wave of the row) ----
-    const int64_t *sent = a.ids + (uint64_t)r * a.cur_len;
-    const int64_t last = sent[a.cur_len - 1];
-    const bool dead = last == a.eos_id || last == a.pad_id;
     uint64_t lo = 0, hi = 0, count = 0, probes = 0;
     uint32_t model = 0;      // in nodes of the binary model: one backward-search step = `levels` nodes (2 L probes)
-    if (!dead) {
-        // get_range(force_decoding_from + sent[1:]) and get_count(... sent[1:-1])
-        uint64_t l = 0, rr = ix.n;
-        if (a.st_in) {
-            // incremental: the row extends row parent[r] of the previous step, whose inclusive range
-            // [l, rr] after the same prefix was kept -- one backward-search step instead of len
-            const uint64_t pr = (uint64_t)a.parent[r];
-            l = a.st_in[2 * pr]; rr = a.st_in[2 * pr + 1];
-            count = (rr + 1) - l;
-            bs_step(ix, (uint64_t)(last + a.shift), l, rr, l, rr, &probes);
-            model += ix.levels * (uint32_t)(a.ff.n + (a.cur_len - 1));    // the reference re-searches the whole prefix
-        } else {
-            const uint64_t total = a.ff.n + (a.cur_len - 1);
-            for (uint64_t t = 0; t < total; t++) {
-                if (t + 1 == total) count = (rr + 1) - l;
-                const int64_t tok = t < a.ff.n ? a.ff.tok[t] : sent[1 + (t - a.ff.n)];
-                bs_step(ix, (uint64_t)(tok + a.shift), l, rr, l, rr, &probes);
-                model += ix.levels;
+    bool dead = true;
+    if (valid) {
+        const int64_t *sent = a.ids + (uint64_t)r * a.cur_len;
+        const int64_t last = sent[a.cur_len - 1];
+        dead = last == a.eos_id || last == a.pad_id;
+        if (!dead) {
+            // get_range(force_decoding_from + sent[1:]) and get_count(... sent[1:-1])
+            uint64_t l = 0, rr = ix.n;
+            if (a.st_in) {
+                // incremental: the row extends row parent[r] of the previous step, whose inclusive range
+                // [l, rr] after the same prefix was kept -- one backward-search step instead of len
+                const uint64_t pr = (uint64_t)a.parent[r];
+                l = a.st_in[2 * pr]; rr = a.st_in[2 * pr + 1];
+                count = (rr + 1) - l;
+                bs_step(ix, (uint64_t)(last + a.shift), l, rr, l, rr, &probes);
+                model += ix.levels * (uint32_t)(a.ff.n + (a.cur_len - 1));    // the reference re-searches the whole prefix
+            } else {
+                const uint64_t total = a.ff.n + (a.cur_len - 1);
+                for (uint64_t t = 0; t < total; t++) {
+                    if (t + 1 == total) count = (rr + 1) - l;
+                    const int64_t tok = t < a.ff.n ? a.ff.tok[t] : sent[1 + (t - a.ff.n)];
+                    bs_step(ix, (uint64_t)(tok + a.shift), l, rr, l, rr, &probes);
+                    model += ix.levels;
+                }
+                if (total == 0) count = (rr + 1) - l;
             }
-            if (total == 0) count = (rr + 1) - l;
+            if (writer && lane == 0 && a.st_out) { a.st_out[2 * r] = l; a.st_out[2 * r + 1] = rr; }
+            lo = l; hi = rr + 1;
         }
-        if (writer && lane == 0 && a.st_out) { a.st_out[2 * r] = l; a.st_out[2 * r + 1] = rr; }
-        lo = l; hi = rr + 1;
     }
     STAMP(1);
     int64_t single = -1;
     bool expand = false;
-    if (a.stop_at_count > 0 && (int64_t)count <= a.stop_at_count) single = a.eos_id;
+    if (!valid) {}
+    else if (a.stop_at_count > 0 && (int64_t)count <= a.stop_at_count) single = a.eos_id;
     else if (dead) single = a.pad_id;
     else { expand = true; if (hi > ix.n) hi = ix.n; }
     wave_sync();            // bitmap zeroed
     // ---- child d1 of the row's root node, then its sub-tree ----
+    uint32_t leaf_nodes = 0;     // W > 1: nodes this wave left in its leaf-level array
     if (expand && hi > lo) {
         uint64_t clo, chi;
         root_child(ix, lo, hi, d1, clo, chi);
-        if (a.tstamp && lane == 0) a.tstamp[(uint64_t)blockIdx.x * 8 + 2] = chi > clo ? __builtin_amdgcn_s_memrealtime() : 0;
+        if (a.tstamp && lane == 0) a.tstamp[(uint64_t)slot * 8 + 2] = chi > clo ? __builtin_amdgcn_s_memrealtime() : 0;
         if (counting && writer && lane == 0) {
             probes += (lo >> FMI_BLOCK_SHIFT) != (hi >> FMI_BLOCK_SHIFT) ? 2 : 1;
             model += model_nodes(root_children_mask(ix, lo, hi), 0, FMI_DIGIT_BITS * D - ix.levels);
         }
         if (chi > clo) {
             if (D == 1) { if (lane == 0 && d1 != 0) s_bits[0] |= 1u; }
-            else expand_subtree<EMIT_BITS, SB>(ix, s_node, s_cnt, reinterpret_cast<uint8_t *>(s_bits), r, 1, clo, chi, d1,
-                                               EmitTarget{}, counting, ctr);
+            else leaf_nodes = expand_subtree<EMIT_BITS, SB, (W > 1)>(ix, s_node, s_cnt, reinterpret_cast<uint8_t *>(s_bits), r, 1, clo, chi, d1,
+                                                                    EmitTarget{}, counting, ctr);
         }
+    }
+    if constexpr (W > 1) {
+        uint32_t *s_leaf = reinterpret_cast<uint32_t *>(s_dyn);
+        if (lane == 0) s_leaf[wave] = leaf_nodes;
+        __syncthreads();        // every item's leaf frontier and zeroed bitmap are in LDS
+        STAMP(5);
+        uint32_t off[W + 1];
+        off[0] = 0;
+#pragma unroll
+        for (int j = 0; j < W; j++) off[j + 1] = off[j] + (uint32_t)__builtin_amdgcn_readfirstlane(s_leaf[j]);
+        leaf_phase<SB, W>(ix, s_items, stride, off, counting, ctr);
+        __syncthreads();        // the leaf bits other waves found for my item
     }
     wave_sync();
     STAMP(3);
-    // pad / eos of the row's class: after the expansion, whose byte stores would overwrite them
-    if (lane == 0) {
-        if (single >= 0) set_special(ix, a, s_bits, r, d1, sub_bits, single);
-        if (a.always_allow_eos) set_special(ix, a, s_bits, r, d1, sub_bits, a.eos_id);
+    if (valid) {
+        // pad / eos of the row's class: after the expansion, whose byte stores would overwrite them
+        if (lane == 0) {
+            if (single >= 0) set_special(ix, a, s_bits, r, d1, sub_bits, single);
+            if (a.always_allow_eos) set_special(ix, a, s_bits, r, d1, sub_bits, a.eos_id);
+        }
+        wave_sync();
+        EmitTarget tgt{};
+        tgt.bits = a.bits; tgt.words_per_row = a.words_per_row; tgt.shift = a.shift; tgt.vocab = a.vocab;
+        flush_leaf_bits(tgt, r, s_bits, d1 << sub_bits, nsym);
     }
-    wave_sync();
-    EmitTarget tgt{};
-    tgt.bits = a.bits; tgt.words_per_row = a.words_per_row; tgt.shift = a.shift; tgt.vocab = a.vocab;
-    flush_leaf_bits(tgt, r, s_bits, d1 << sub_bits, nsym);
     STAMP(4);
 #undef STAMP
     if (counting) {
@@ -1288,8 +1411,13 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     for (uint64_t i = 0; i < n_force; i++) a.ff.tok[i] = force_from[i];
     a.stop_at_count = stop_at_count; a.always_allow_eos = always_allow_eos; a.vocab = vocab; a.words_per_row = wpr;
     a.probe_counter = h->probe_count_enabled ? h->d_probe_counter : nullptr;
-    const unsigned grid = (unsigned)(((rows + 7) & ~7ull) * a.ndig0);
-    a.tstamp = h->dbg_tstamp && h->dbg_tstamp_cap >= (uint64_t)grid * 8 ? h->dbg_tstamp : nullptr;
+    // waves per workgroup: CONSTRAIN_WG waves that share their leaf-level nodes when the whole sub-tree of an item fits
+    // the deferred expansion (dlevels 2..4: every real vocabulary below 2^16 symbols), else self-contained waves
+    const char *wenv = getenv("SEALFM_CONSTRAIN_WAVES");       // "1": the self-contained waves (A/B measurements, tests of both)
+    const unsigned W = (!(wenv && atoi(wenv) == 1) && h->dlevels >= 2 && h->dlevels <= 4) ? (unsigned)CONSTRAIN_WG : 1u;
+    if (W > 1) a.groups = (uint32_t)((rows + W - 1) / W);
+    const unsigned grid = W > 1 ? a.groups * a.ndig0 : (unsigned)(((rows + 7) & ~7ull) * a.ndig0);
+    a.tstamp = h->dbg_tstamp && h->dbg_tstamp_cap >= (uint64_t)grid * W * 8 ? h->dbg_tstamp : nullptr;
     if (d_bits) {
         HIPCHK(hipMemsetAsync(d_bits, 0, rows * wpr * 4, st));
         a.bits = d_bits;
@@ -1299,7 +1427,7 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
         a.bits = ws_bits(h, cur);
         // the other buffer still holds the previous call's bitmap: this launch clears it, unless that would
         // be more than a few stores per lane (a much larger previous call) -- then a memset does
-        if (h->ws_dirty[nxt] > (uint64_t)grid * 64 * 8) HIPCHK(hipMemsetAsync(ws_bits(h, nxt), 0, h->ws_dirty[nxt] * 4, st));
+        if (h->ws_dirty[nxt] > (uint64_t)grid * W * 64 * 8) HIPCHK(hipMemsetAsync(ws_bits(h, nxt), 0, h->ws_dirty[nxt] * 4, st));
         else if (h->ws_dirty[nxt]) { a.clear = ws_bits(h, nxt); a.clear_words = h->ws_dirty[nxt]; }
         h->ws_dirty[nxt] = 0;
         h->ws_dirty[cur] = rows * wpr;
@@ -1315,8 +1443,11 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     else h->state_tag = 0;
     const bool timed = h->timing_enabled && h->ev_used < MAX_TIMED_LAUNCHES;
     if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
-    auto kern = h->dev.nsb > 1 ? k_constrain<true> : k_constrain<false>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), expand_lds_bytes(h->dlevels, true), st, h->dev, a);
+    const size_t lds = (size_t)constrain_wave_slots(h->dlevels) * 16 * W + (W > 1 ? (size_t)((W * 4 + 15) / 16) * 16 : 0);
+    const bool sb = h->dev.nsb > 1;
+    void (*kern)(FmiDev, ConstrainArgs) = W > 1 ? (sb ? k_constrain<true, CONSTRAIN_WG> : k_constrain<false, CONSTRAIN_WG>)
+                                                : (sb ? k_constrain<true, 1> : k_constrain<false, 1>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds, st, h->dev, a);
     HIPCHK(hipGetLastError());
     if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
     return FMI_OK;

@@ -21,6 +21,8 @@ def _assert_decoder_path(model, geom):
     dict(max_length=8, num_beams=5, length_penalty=0.0, force_decoding_from=[2], eos_token_id=7),
     dict(max_length=5, num_beams=4, length_penalty=1.0, always_allow_eos=True),
     dict(max_length=5, num_beams=3, length_penalty=0.0, stop_at_count=2),
+    dict(max_length=5, num_beams=15, length_penalty=0.0),        # BASELINE configs[1]: beam 15
+    dict(max_length=4, num_beams=30, length_penalty=0.0),        # configs[4]: beam 30 (top-2K = 60 of the 64 k_row_pick ranks)
 ])
 def test_fm_index_generate_matches_reference_restatement(kw, geom):
     from oracle.beam_oracle import oracle_fm_index_generate

@@ -146,10 +146,14 @@ def test_save_load_round_trip_on_gpu(pair, tmp_path):
     assert ix2.get_doc(1) == docs[1]
 
 
-def test_logits_processor_matches_reference_semantics(pair):
+@pytest.mark.parametrize("waves", ["8", "1"], ids=["shared-leaf-phase", "self-contained-waves"])
+def test_logits_processor_matches_reference_semantics(pair, waves, monkeypatch):
+    """both launch shapes of k_constrain: workgroups of 8 waves that serve their leaf-level nodes together (the
+    default up to 4 digit levels) and one self-contained wave per (row, top digit)"""
     import torch
     from oracle.beam_oracle import oracle_logits_mask
     from seal_amd.beam_search import IndexBasedLogitsProcessor
+    monkeypatch.setenv("SEALFM_CONSTRAIN_WAVES", waves)
     ix, orc, docs, vocab = pair
     rng = random.Random(4)
     V = vocab + 7

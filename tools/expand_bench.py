@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--incremental", action="store_true", help="time the call of a decode step: the prefix of length L-1 was "
                     "searched by the previous call (kept ranges, workspace bitmaps), the timed call extends it by one token")
     ap.add_argument("--timestamps", action="store_true", help="per-wave realtime stamps of one call (where the time goes)")
+    ap.add_argument("--variants", default="", help="'|'-separated settings, each a space-separated list of ENV=VALUE (the launch-shape "
+                    "switches of k_constrain are read per call): the measurements are repeated for each on the same index")
     ap.add_argument("--synthetic-bwt", type=float, default=0,
                     help="N symbols: skip corpus+suffix array and load an i.i.d. Zipf 'BWT' of N symbols straight into the "
                          "wavelet matrix (rank/select-only index; bandwidth measurement only, SURVEY.md 8d tier X)")
@@ -87,86 +89,92 @@ def main():
 
     ident = torch.arange(args.rows, device=dev)
     tsbuf = torch.zeros(args.rows * 16 * 8, dtype=torch.int64, device=dev) if args.timestamps else None
-    for pl, ids in zip(plens, all_ids):
-        def call():
-            if not args.incremental:
-                check(lib().fmi_dev_allowed_bits(h, st, args.rows, ids.shape[1], ids.data_ptr(), bits.data_ptr(), V, bench.SHIFT, 1, 2,
-                                                 None, 0, 0, 0))
-                return
-            # step t-1 (untimed), then step t as the decode loop issues it
-            check(lib().fmi_dev_enable_timing(h, 0))
-            if ids.shape[1] > 2:
-                prev = ids[:, :-1].contiguous()
-                check(lib().fmi_dev_allowed_bits_step(h, st, args.rows, prev.shape[1], prev.data_ptr(), None, V, bench.SHIFT, 1, 2, None, 0, 0, 0,
-                                                      77, None, None))
-            check(lib().fmi_dev_enable_timing(h, 1))
-            if not os.environ.get("EXPAND_NO_COUNT"):
-                junk = ctypes.c_uint64()
-                check(lib().fmi_dev_read_probe_count(h, ctypes.byref(junk)))       # drop the untimed step's counts
-            out = ctypes.c_void_p()
-            check(lib().fmi_dev_allowed_bits_step(h, st, args.rows, ids.shape[1], ids.data_ptr(), None, V, bench.SHIFT, 1, 2, None, 0, 0, 0,
-                                                  77, ident.data_ptr() if ids.shape[1] > 2 else None, ctypes.byref(out)))
-            torch.cuda.synchronize()
-            l1, m1 = ctypes.c_uint64(), ctypes.c_double()
-            check(lib().fmi_dev_read_timing(h, ctypes.byref(l1), ctypes.byref(m1)))
-            acc[0] += m1.value
-            if not os.environ.get("EXPAND_NO_COUNT"):
-                xs = (ctypes.c_uint64 * 4)()
-                check(lib().fmi_dev_read_expand_stats(h, xs))                       # the timed call's own counts
-                for j in range(4):
-                    tot[j] += xs[j]
-            from bench import _CudaArray
-            ws = torch.as_tensor(_CudaArray(out.value, args.rows * ((V + 31) // 32), "<i4"), device=dev)
-            bits.copy_(ws.view(args.rows, -1))
-        acc = [0.0]
-        tot = [0, 0, 0, 0]
-        call()
-        torch.cuda.synchronize()
-        probes, launches, ms = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
-        if not os.environ.get("EXPAND_NO_COUNT"):
-            check(lib().fmi_dev_read_probe_count(h, ctypes.byref(probes)))
-        check(lib().fmi_dev_read_timing(h, ctypes.byref(launches), ctypes.byref(ms)))
-        acc[0] = 0.0
-        tot = [0, 0, 0, 0]
-        for _ in range(args.iters):
-            call()
-        stats = (ctypes.c_uint64 * 4)()
-        if not os.environ.get("EXPAND_NO_COUNT"):
-            check(lib().fmi_dev_read_expand_stats(h, stats))
-            check(lib().fmi_dev_read_probe_count(h, ctypes.byref(probes)))
-        check(lib().fmi_dev_read_timing(h, ctypes.byref(launches), ctypes.byref(ms)))
-        if args.incremental:
-            ms.value = acc[0]
-            if not os.environ.get("EXPAND_NO_COUNT"):
-                probes.value = tot[0]
-                for j in range(4):
-                    stats[j] = tot[j]
-        if args.timestamps:
-            check(lib().fmi_dev_debug_timestamps(h, tsbuf.data_ptr(), tsbuf.numel()))
-            tsbuf.zero_()
+    for variant in (args.variants.split("|") if args.variants else [""]):
+        for kv in variant.split():
+            k, v = kv.split("=", 1)
+            os.environ[k] = v
+        if args.variants:
+            print(json.dumps({"variant": variant}), flush=True)
+        for pl, ids in zip(plens, all_ids):
+            def call():
+                if not args.incremental:
+                    check(lib().fmi_dev_allowed_bits(h, st, args.rows, ids.shape[1], ids.data_ptr(), bits.data_ptr(), V, bench.SHIFT, 1, 2,
+                                                     None, 0, 0, 0))
+                    return
+                # step t-1 (untimed), then step t as the decode loop issues it
+                check(lib().fmi_dev_enable_timing(h, 0))
+                if ids.shape[1] > 2:
+                    prev = ids[:, :-1].contiguous()
+                    check(lib().fmi_dev_allowed_bits_step(h, st, args.rows, prev.shape[1], prev.data_ptr(), None, V, bench.SHIFT, 1, 2, None, 0, 0, 0,
+                                                          77, None, None))
+                check(lib().fmi_dev_enable_timing(h, 1))
+                if not os.environ.get("EXPAND_NO_COUNT"):
+                    junk = ctypes.c_uint64()
+                    check(lib().fmi_dev_read_probe_count(h, ctypes.byref(junk)))       # drop the untimed step's counts
+                out = ctypes.c_void_p()
+                check(lib().fmi_dev_allowed_bits_step(h, st, args.rows, ids.shape[1], ids.data_ptr(), None, V, bench.SHIFT, 1, 2, None, 0, 0, 0,
+                                                      77, ident.data_ptr() if ids.shape[1] > 2 else None, ctypes.byref(out)))
+                torch.cuda.synchronize()
+                l1, m1 = ctypes.c_uint64(), ctypes.c_double()
+                check(lib().fmi_dev_read_timing(h, ctypes.byref(l1), ctypes.byref(m1)))
+                acc[0] += m1.value
+                if not os.environ.get("EXPAND_NO_COUNT"):
+                    xs = (ctypes.c_uint64 * 4)()
+                    check(lib().fmi_dev_read_expand_stats(h, xs))                       # the timed call's own counts
+                    for j in range(4):
+                        tot[j] += xs[j]
+                from bench import _CudaArray
+                ws = torch.as_tensor(_CudaArray(out.value, args.rows * ((V + 31) // 32), "<i4"), device=dev)
+                bits.copy_(ws.view(args.rows, -1))
+            acc = [0.0]
+            tot = [0, 0, 0, 0]
             call()
             torch.cuda.synchronize()
-            check(lib().fmi_dev_debug_timestamps(h, None, 0))
-            t = tsbuf.view(-1, 8).cpu().numpy().astype("int64")
-            if os.environ.get("EXPAND_STAMP_DIR"):
-                __import__("numpy").save(os.path.join(os.environ["EXPAND_STAMP_DIR"], f"stamps_len{pl}.npy"), t)
-            t = t[t[:, 0] > 0]
-            t0 = t[:, 0].min()
-            def q(col, mask=None):
-                v = (t[:, col] - t0)[(t[:, col] > 0) if mask is None else mask] / 100.0        # 100 MHz -> us
-                return None if v.size == 0 else [round(float(x), 2) for x in (v.min(), float(__import__("numpy").median(v)), v.max())]
-            print(json.dumps({"prefix_len": pl, "waves": int(t.shape[0]), "us_since_first_wave_start[min,median,max]": {
-                "wave_start": q(0), "prefix_range_known": q(1), "root_child_known(non-empty only)": q(2), "subtree_done": q(3), "bitmap_stored": q(4)},
-                "waves_with_a_subtree": int((t[:, 2] > 0).sum())}), flush=True)
-        allowed = int(sum(bin(x & 0xFFFFFFFF).count("1") for x in bits[:8].flatten().tolist())) / 8.0
-        gbs = probes.value * 128 / (ms.value * 1e-3) / 1e9
-        print(json.dumps({"docs": args.docs, "n": index.size(), "rows": args.rows, "prefix_len": pl,
-                          "iters": args.iters, "blocks_per_call": probes.value / args.iters,
-                          "alg_MB_per_call": round(probes.value * 128 / args.iters / 1e6, 2),
-                          "us_per_call": round(ms.value * 1e3 / args.iters, 2), "GBps": round(gbs, 1),
-                          "frac_of_8TBps": round(gbs / 8000, 4), "wave_iters_per_call": stats[1] / args.iters,
-                          "lane_pair_util": round(stats[2] / max(1, 32 * stats[1]), 3), "model_probes_per_call": 2 * stats[3] / args.iters,
-                          "model_GBps": round(2 * stats[3] * 64 / (ms.value * 1e-3) / 1e9, 1), "avg_allowed_tokens_first8rows": allowed}), flush=True)
+            probes, launches, ms = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
+            if not os.environ.get("EXPAND_NO_COUNT"):
+                check(lib().fmi_dev_read_probe_count(h, ctypes.byref(probes)))
+            check(lib().fmi_dev_read_timing(h, ctypes.byref(launches), ctypes.byref(ms)))
+            acc[0] = 0.0
+            tot = [0, 0, 0, 0]
+            for _ in range(args.iters):
+                call()
+            stats = (ctypes.c_uint64 * 4)()
+            if not os.environ.get("EXPAND_NO_COUNT"):
+                check(lib().fmi_dev_read_expand_stats(h, stats))
+                check(lib().fmi_dev_read_probe_count(h, ctypes.byref(probes)))
+            check(lib().fmi_dev_read_timing(h, ctypes.byref(launches), ctypes.byref(ms)))
+            if args.incremental:
+                ms.value = acc[0]
+                if not os.environ.get("EXPAND_NO_COUNT"):
+                    probes.value = tot[0]
+                    for j in range(4):
+                        stats[j] = tot[j]
+            if args.timestamps:
+                check(lib().fmi_dev_debug_timestamps(h, tsbuf.data_ptr(), tsbuf.numel()))
+                tsbuf.zero_()
+                call()
+                torch.cuda.synchronize()
+                check(lib().fmi_dev_debug_timestamps(h, None, 0))
+                t = tsbuf.view(-1, 8).cpu().numpy().astype("int64")
+                if os.environ.get("EXPAND_STAMP_DIR"):
+                    __import__("numpy").save(os.path.join(os.environ["EXPAND_STAMP_DIR"], f"stamps_len{pl}.npy"), t)
+                t = t[t[:, 0] > 0]
+                t0 = t[:, 0].min()
+                def q(col, mask=None):
+                    v = (t[:, col] - t0)[(t[:, col] > 0) if mask is None else mask] / 100.0        # 100 MHz -> us
+                    return None if v.size == 0 else [round(float(x), 2) for x in (v.min(), float(__import__("numpy").median(v)), v.max())]
+                print(json.dumps({"prefix_len": pl, "waves": int(t.shape[0]), "us_since_first_wave_start[min,median,max]": {
+                    "wave_start": q(0), "prefix_range_known": q(1), "root_child_known(non-empty only)": q(2), "leaf_phase_start(workgroup)": q(5), "subtree_done": q(3), "bitmap_stored": q(4)},
+                    "waves_with_a_subtree": int((t[:, 2] > 0).sum())}), flush=True)
+            allowed = int(sum(bin(x & 0xFFFFFFFF).count("1") for x in bits[:8].flatten().tolist())) / 8.0
+            gbs = probes.value * 128 / (ms.value * 1e-3) / 1e9
+            print(json.dumps({"docs": args.docs, "n": index.size(), "rows": args.rows, "prefix_len": pl,
+                              "iters": args.iters, "blocks_per_call": probes.value / args.iters,
+                              "alg_MB_per_call": round(probes.value * 128 / args.iters / 1e6, 2),
+                              "us_per_call": round(ms.value * 1e3 / args.iters, 2), "GBps": round(gbs, 1),
+                              "frac_of_8TBps": round(gbs / 8000, 4), "wave_iters_per_call": stats[1] / args.iters,
+                              "lane_pair_util": round(stats[2] / max(1, 32 * stats[1]), 3), "model_probes_per_call": 2 * stats[3] / args.iters,
+                              "model_GBps": round(2 * stats[3] * 64 / (ms.value * 1e-3) / 1e9, 1), "avg_allowed_tokens_first8rows": allowed}), flush=True)
 
 
 if __name__ == "__main__":
