@@ -8,6 +8,14 @@
 // device primitives over the hex wavelet matrix (layout: fmi_internal.h)
 // ---------------------------------------------------------------------------
 
+// Index arrays are immutable while a query kernel runs.  Reading them through the constant address space tells
+// the compiler so: a load whose address is wave-uniform (the row's own probes in k_constrain: prefix step, root
+// child) becomes a scalar load and everything computed from it scalar ALU -- it no longer takes VALU issue slots
+// from the other three waves of the SIMD; a divergent address still compiles to the same global_load.
+template <typename T> using cptr = const T __attribute__((address_space(4))) *;
+template <typename T> __device__ __forceinline__ cptr<T> as_const(const T *p) { return (cptr<T>)(uintptr_t)p; }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 // One 128-byte block in registers: 8 x global_load_dwordx4, every byte used.
 struct HBlock {
     uint32_t rel[16];    // digits equal to d between the superblock start and the block
@@ -63,10 +71,10 @@ __device__ __forceinline__ void wm_block_ranks(const HBlock &b, uint32_t bit, ui
 __device__ __forceinline__ uint64_t wm_step(const FmiDev &ix, uint32_t k, uint64_t p, uint32_t d)
 {
     const uint64_t blk = p >> FMI_BLOCK_SHIFT;
-    const uint32_t *w = wm_block_ptr(ix, k, blk);
-    const uint64_t base = ix.sbase[((uint64_t)k * ix.nsb + (blk >> ix.sb_shift)) * FMI_ARITY + d];
-    const uint4 q0 = *reinterpret_cast<const uint4 *>(w + 16), q1 = *reinterpret_cast<const uint4 *>(w + 20);
-    const uint4 q2 = *reinterpret_cast<const uint4 *>(w + 24), q3 = *reinterpret_cast<const uint4 *>(w + 28);
+    const cptr<uint32_t> w = as_const(wm_block_ptr(ix, k, blk));
+    const uint64_t base = as_const(ix.sbase)[((uint64_t)k * ix.nsb + (blk >> ix.sb_shift)) * FMI_ARITY + d];
+    const cptr<u32x4> wq = (cptr<u32x4>)(w + 16);
+    const u32x4 q0 = wq[0], q1 = wq[1], q2 = wq[2], q3 = wq[3];
     const uint32_t rel = w[d];
     const uint32_t bit = (uint32_t)p & (FMI_BLOCK_BITS - 1);
     const uint32_t P0[4] = {q0.x, q0.y, q0.z, q0.w}, P1[4] = {q1.x, q1.y, q1.z, q1.w};
@@ -95,7 +103,7 @@ __device__ __forceinline__ uint64_t wm_rank_sym(const FmiDev &ix, uint64_t c, ui
     uint64_t p = i;
     for (uint32_t k = 0; k < ix.dlevels; k++) p = wm_step(ix, k, p, wm_digit(ix, c, k));
     if (probes) *probes += ix.dlevels;
-    return p - ix.leaf[c];
+    return p - as_const(ix.leaf)[c];
 }
 
 // rank_c at two positions at once (the two ends of a backward-search interval): the loads of both
@@ -110,7 +118,8 @@ __device__ __forceinline__ void wm_rank_sym_pair(const FmiDev &ix, uint64_t c, u
         if (probes) *probes += ((p >> FMI_BLOCK_SHIFT) == (s >> FMI_BLOCK_SHIFT)) ? 1 : 2;
         p = p2; s = s2;
     }
-    ri = p - ix.leaf[c]; rj = s - ix.leaf[c];
+    const uint64_t lf = as_const(ix.leaf)[c];
+    ri = p - lf; rj = s - lf;
 }
 
 // ---------------------------------------------------------------------------

@@ -31,7 +31,7 @@
 // is clamped to the same value here.
 __device__ __forceinline__ uint64_t rank_like_sdsl(const FmiDev &ix, uint64_t c, uint64_t i, uint64_t *probes)
 {
-    if (i > ix.n) return (ix.C[c + 1] - ix.C[c]) + ix.q1[c];
+    if (i > ix.n) return (as_const(ix.C)[c + 1] - as_const(ix.C)[c]) + as_const(ix.q1)[c];
     if (i == 0) return 0;
     return wm_rank_sym(ix, c, i, probes);
 }
@@ -40,9 +40,9 @@ __device__ __forceinline__ uint64_t rank_like_sdsl(const FmiDev &ix, uint64_t c,
 __device__ __forceinline__ void bs_step(const FmiDev &ix, uint64_t c, uint64_t l, uint64_t r,
                                         uint64_t &l_res, uint64_t &r_res, uint64_t *probes)
 {
-    const bool absent = (c > ix.max_sym) || (ix.C[c + 1] == ix.C[c]);
+    const bool absent = (c > ix.max_sym) || (as_const(ix.C)[c + 1] == as_const(ix.C)[c]);
     if (absent && c > 0) { l_res = 1; r_res = 0; return; }
-    const uint64_t cb = ix.C[c];
+    const uint64_t cb = as_const(ix.C)[c];
     uint64_t rl, rr;
     const uint64_t j = r + 1;
     // the first step of every search starts from [0, size()] (index.py:106-107): rank(0) = 0 and the
@@ -560,7 +560,8 @@ template <bool SB, int W>
 __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, ConstrainArgs a)
 {
     extern __shared__ uint4 s_dyn[];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform, and the compiler knows
     const uint32_t D = ix.dlevels;
     const uint32_t sub_bits = FMI_DIGIT_BITS * (D - 1);        // symbol bits below the top digit
     const uint32_t nsym = 1u << sub_bits;                       // symbols of one wave's sub-tree
@@ -601,7 +602,8 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
     uint32_t model = 0;      // in nodes of the binary model: one backward-search step = `levels` nodes (2 L probes)
     bool dead = true;
     if (valid) {
-        const int64_t *sent = a.ids + (uint64_t)r * a.cur_len;
+        // ids / parent / the kept ranges were written by earlier launches, not by this one: constant here
+        const cptr<int64_t> sent = as_const(a.ids) + (uint64_t)r * a.cur_len;
         const int64_t last = sent[a.cur_len - 1];
         dead = last == a.eos_id || last == a.pad_id;
         if (!dead) {
@@ -610,8 +612,8 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
             if (a.st_in) {
                 // incremental: the row extends row parent[r] of the previous step, whose inclusive range
                 // [l, rr] after the same prefix was kept -- one backward-search step instead of len
-                const uint64_t pr = (uint64_t)a.parent[r];
-                l = a.st_in[2 * pr]; rr = a.st_in[2 * pr + 1];
+                const uint64_t pr = (uint64_t)as_const(a.parent)[r];
+                l = as_const(a.st_in)[2 * pr]; rr = as_const(a.st_in)[2 * pr + 1];
                 count = (rr + 1) - l;
                 bs_step(ix, (uint64_t)(last + a.shift), l, rr, l, rr, &probes);
                 model += ix.levels * (uint32_t)(a.ff.n + (a.cur_len - 1));    // the reference re-searches the whole prefix
