@@ -147,7 +147,7 @@ __host__ __device__ constexpr int exp_slots(int nlev) { return nlev <= 0 ? 1 : l
 
 // measurement mode (fmi_dev_enable_probe_count): distinct blocks loaded, nodes of the binary model of
 // SURVEY.md 8(d), wave iterations, nodes expanded
-struct ExpCounters { uint64_t probes; uint32_t model, iters, nodes; };
+struct ExpCounters { uint32_t probes, model, iters, nodes; };      // per lane, per launch
 
 // lane <-> lane^1
 __device__ __forceinline__ uint32_t dpp_xor1(uint32_t v)
@@ -204,12 +204,8 @@ __device__ __forceinline__ uint32_t root_children_mask(const FmiDev &ix, uint64_
 // relative level; EMIT_BITS: s_bits8 = the wave's leaf bitmap (16^(D-root) bits, zeroed by the caller):
 // bit i = symbol (rprefix << 4 (D-root)) + i.  `counting` (wave-uniform) switches the measurement
 // bookkeeping on.
-// DEFER (k_constrain with several waves per workgroup, dlevels <= 4): the leaf level is NOT popped -- the
-// function returns the number of leaf-level nodes it left in array D - 1 - root (complete, because every level
-// above the leaves holds <= 32 nodes and is popped in one iteration); the workgroup's waves then serve the leaf
-// nodes of all its items together (leaf_phase).
-template <int MODE, bool SB, bool DEFER = false>
-__device__ __forceinline__ uint32_t expand_subtree(const FmiDev &ix, uint4 *s_node, uint32_t *s_cnt, uint8_t *s_bits8,
+template <int MODE, bool SB>
+__device__ __forceinline__ void expand_subtree(const FmiDev &ix, uint4 *s_node, uint32_t *s_cnt, uint8_t *s_bits8,
                                                const uint32_t row, const uint32_t root, const uint64_t rlo, const uint64_t rhi,
                                                const uint32_t rprefix, const EmitTarget &tgt, const bool counting, ExpCounters &ctr)
 {
@@ -222,7 +218,6 @@ __device__ __forceinline__ uint32_t expand_subtree(const FmiDev &ix, uint4 *s_no
     wave_sync();
     int deepest = 0;   // relative level of the deepest non-empty array (wave uniform)
     while (deepest >= 0) {
-        if (DEFER && root + (uint32_t)deepest + 1 == D) break;
         // LDS hands the counter back in a VGPR; it is the same in every lane, and the whole loop
         // (level, offsets, the per-level dbase[] loads) stays scalar only if the compiler knows
         const uint32_t cnt = __builtin_amdgcn_readfirstlane(s_cnt[deepest]);
@@ -304,67 +299,71 @@ __device__ __forceinline__ uint32_t expand_subtree(const FmiDev &ix, uint4 *s_no
         }
     }
     wave_sync();
-    if (DEFER) return deepest >= 0 ? (uint32_t)__builtin_amdgcn_readfirstlane(s_cnt[deepest]) : 0u;
-    return 0u;
 }
 
-// The leaf-level nodes of the W items of a workgroup, served by all its waves: chunk c (32 nodes of the
-// concatenated leaf frontiers) goes to wave c % W.  A node's eight-bit existence masks go into the LDS bitmap of
-// the item that owns it (distinct bytes for distinct nodes: no conflicts between waves).  Balances the waves of
-// a workgroup -- an item with 256 leaf-level nodes next to items with a handful costs every wave one or two
-// iterations instead of one wave eight -- and packs the lane pairs.
+// One level of the sub-trees of the W items of a workgroup (k_constrain, W waves per workgroup, dlevels <= 4),
+// served by all its waves together: the level's nodes -- of all W items, each slot carries its item in .w -- are
+// one array in LDS; chunk c (32 nodes, one lane pair each) goes to wave c % W.  Above the leaf level the children
+// are appended to the next level's array (space reserved with one LDS atomic per chunk: pass 1 finds which
+// children exist, pass 2 writes them); at the leaf level a node's two 8-bit existence masks go into the LDS
+// bitmap of its item (distinct bytes for distinct nodes: no conflicts between waves).  The caller puts a
+// workgroup barrier between levels.  Against one self-contained wave per item this (a) balances the waves -- an
+// item with 256 leaf-level nodes next to items with a handful costs every wave one or two iterations instead of
+// one wave eight --, (b) packs the lane pairs across items, and (c) runs the upper levels, where an item has 1
+// and <= 16 nodes, in 1/8 and <= 1/2 of the wave iterations: with four waves per SIMD in lockstep those
+// iterations are VALU time, not latency.
 template <bool SB, int W>
-__device__ __forceinline__ void leaf_phase(const FmiDev &ix, const uint4 *s_items, uint32_t stride, const uint32_t (&off)[W + 1],
-                                           const bool counting, ExpCounters &ctr)
+__device__ __forceinline__ void wg_level(const FmiDev &ix, const uint4 *s_in, const uint32_t total, uint4 *s_out, uint32_t *s_cnt_out,
+                                         const uint32_t k, uint4 *s_bitmaps, const uint32_t bm_slots, const bool counting, ExpCounters &ctr)
 {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, end = lane & 1, pair = lane >> 1;
-    const uint32_t D = ix.dlevels, k = D - 1;
+    const uint32_t lane = threadIdx.x & 63, end = lane & 1, pair = lane >> 1;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t D = ix.dlevels;
+    const bool leaf = (k + 1 == D);
     const uint32_t pad_bits = FMI_DIGIT_BITS * D - ix.levels;
     const uint32_t rel_mask = (1u << (FMI_DIGIT_BITS * (D - 2))) - 1;      // sub-tree roots are level-1 nodes
-    const uint32_t node0 = (uint32_t)lvl_off((int)D - 2), bits0 = (uint32_t)exp_slots((int)D - 1) + 2;   // in 16-byte slots
-    const uint32_t total = off[W];
     for (uint32_t c0 = wave * EXP_PAIRS; c0 < total; c0 += W * EXP_PAIRS) {
         const uint32_t g = c0 + pair;
         const bool act = g < total;
-        uint32_t item = 0, first = 0;
-#pragma unroll
-        for (int j = 1; j < W; j++) { const bool ge = g >= off[j]; item = ge ? (uint32_t)j : item; first = ge ? off[j] : first; }
-        const uint4 *it = s_items + (size_t)item * stride;
         uint4 nd = make_uint4(0u, 0u, 0u, 0u);
-        if (act) nd = it[node0 + (g - first)];
+        if (act) nd = s_in[g];               // both lanes of the pair read the same slot (LDS broadcast)
         const uint64_t lo = (uint64_t)nd.x | ((uint64_t)(nd.z & 0xff) << 32);
         const uint64_t hi = (uint64_t)nd.y | ((uint64_t)((nd.z >> 8) & 0xff) << 32);
-        const uint32_t prefix = nd.z >> 16;
-        const uint64_t p = end ? hi : lo;
+        const uint32_t prefix = nd.z >> 16, item = nd.w;
+        const uint64_t p = end ? hi : lo;                              // my end of the interval
         const uint64_t blk = p >> FMI_BLOCK_SHIFT, oblk = (end ? lo : hi) >> FMI_BLOCK_SHIFT;
         uint32_t r[16];
 #pragma unroll
         for (uint32_t d = 0; d < 16; d++) r[d] = 0;
         if (act) {
             HBlock b;
-            wm_load_block(ix, k, blk, b);
+            wm_load_block(ix, k, blk, b);        // when both ends share a block the pair asks for the same line once
             wm_block_ranks(b, (uint32_t)p & (FMI_BLOCK_BITS - 1), r);
         }
-        const uint64_t *rowl = nullptr, *rowh = nullptr;
+        const uint64_t *rowl = nullptr, *rowh = nullptr;   // superblocked index: the rows of the two ends (!act: block 0's, a valid address)
         if constexpr (SB) {
             const uint64_t mine = ((uint64_t)k * ix.nsb + (blk >> ix.sb_shift)) * FMI_ARITY;
             const uint64_t other = ((uint64_t)k * ix.nsb + (oblk >> ix.sb_shift)) * FMI_ARITY;
             rowl = ix.sbase + (end ? other : mine);
             rowh = ix.sbase + (end ? mine : other);
         }
-        uint32_t hm = 0;
+        // pass 1: which of MY eight children (digits s + 8 * end) exist
+        uint32_t hm = 0, nchild = 0;
+        uint64_t bal[8];
 #pragma unroll
         for (uint32_t s = 0; s < 8; s++) {
+            // lane `end` = 0 holds rank_lo[] and takes digit s, lane 1 holds rank_hi[] and takes digit s + 8
             const uint32_t x = dpp_xor1(r[s]), y = dpp_xor1(r[s + 8]);
             const uint32_t cl = end ? y : r[s], ch = end ? r[s + 8] : x;
             bool ex;
             if constexpr (SB) {
                 const uint32_t dm = s + 8 * end;
-                ex = act && (rowh[dm] + ch) > (rowl[dm] + cl);      // !act: block 0's rows, a valid address
+                ex = act && (rowh[dm] + ch) > (rowl[dm] + cl);
             } else {
                 ex = act && ch > cl;        // both ends add the same dbase[k][digit]
             }
             hm |= (uint32_t)ex << s;
+            if (!leaf) { bal[s] = __ballot(ex); nchild += (uint32_t)__popcll(bal[s]); }
         }
         if (counting) {
             const uint32_t other_hm = dpp_xor1(hm);
@@ -375,10 +374,33 @@ __device__ __forceinline__ void leaf_phase(const FmiDev &ix, const uint4 *s_item
             const uint32_t left = total - c0;
             ctr.iters++; ctr.nodes += left < EXP_PAIRS ? left : EXP_PAIRS;
         }
-        if (prefix == 0 && end == 0) hm &= ~1u;          // symbol 0 is the sentinel, never a token
-        if (hm) {
-            uint8_t *bits8 = reinterpret_cast<uint8_t *>(const_cast<uint4 *>(it) + bits0);
-            bits8[((prefix & rel_mask) << 1) + end] = (uint8_t)hm;
+        if (leaf) {
+            if (prefix == 0 && end == 0) hm &= ~1u;          // symbol 0 is the sentinel, never a token
+            if (hm) reinterpret_cast<uint8_t *>(s_bitmaps + (size_t)item * bm_slots)[((prefix & rel_mask) << 1) + end] = (uint8_t)hm;
+        } else if (nchild) {
+            // pass 2: reserve, then write the children (positions recomputed: cheaper than sixteen live registers)
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(s_cnt_out, nchild);
+            uint32_t run = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+            for (uint32_t s = 0; s < 8; s++) {
+                const uint32_t x = dpp_xor1(r[s]), y = dpp_xor1(r[s + 8]);
+                const uint32_t cl = end ? y : r[s], ch = end ? r[s + 8] : x;
+                const uint32_t dm = s + 8 * end;
+                uint64_t clo, chi;
+                if constexpr (SB) {
+                    clo = rowl[dm] + cl; chi = rowh[dm] + ch;
+                } else {
+                    const uint64_t bs = end ? ix.dbase[k][s + 8] : ix.dbase[k][s];
+                    clo = bs + cl; chi = bs + ch;
+                }
+                if ((hm >> s) & 1u) {
+                    uint4 c = pack_node(clo, chi, (prefix << 4) | dm);
+                    c.w = item;
+                    s_out[run + lane_rank_in(bal[s])] = c;
+                }
+                run += (uint32_t)__popcll(bal[s]);
+            }
         }
     }
 }
@@ -544,17 +566,21 @@ __device__ __forceinline__ void set_special(const FmiDev &ix, const ConstrainArg
     }
 }
 
-// W = waves per workgroup.  W = 1: one self-contained wave per item (any depth).  W > 1 (host: 2 <= dlevels <= 4):
-// the W waves of a workgroup take W consecutive rows of one top digit, each expands its item down to the level above
-// the leaves, then all of them serve the leaf-level nodes of the W items together (leaf_phase).
-// dynamic LDS: [32-byte header: leaf counts, W > 1 only] + W x constrain_wave_slots(D) 16-byte slots
-__host__ __device__ constexpr uint32_t constrain_wave_slots(uint32_t D)
+// W = waves per workgroup.  W = 1: one self-contained wave per item (any depth; dynamic LDS: exp_slots(D - 1)
+// frontier slots + 8 counters + the item's leaf bitmap).  W > 1 (host: 2 <= dlevels <= 4): the W waves of a
+// workgroup take W consecutive rows of one top digit; each finds its row's range and root child, then the
+// workgroup expands the W sub-trees level by level together (wg_level).  Dynamic LDS of that shape, in 16-byte
+// slots: [2: node counters per level] [W x bm_slots: leaf bitmaps, 16^(D-1) bits each]
+//        [level j = 0 .. D-2: W * 16^j node slots]
+__host__ __device__ constexpr uint32_t constrain_bm_slots(uint32_t D) { return (((1u << (FMI_DIGIT_BITS * (D - 1))) + 31) / 32 + 3) / 4; }
+__host__ __device__ constexpr uint32_t constrain_lvl_off(uint32_t W, uint32_t j) { return W * (((1u << (FMI_DIGIT_BITS * j)) - 1) / 15); }
+__host__ __device__ constexpr uint32_t constrain_lds_slots(uint32_t D, uint32_t W)
 {
-    // frontier + 8 counters + the item's leaf bitmap (16^(D-1) bits)
-    return (uint32_t)exp_slots((int)D - 1) + 2 + ((((1u << (FMI_DIGIT_BITS * (D - 1))) + 31) / 32 + 3) / 4);
+    return W > 1 ? 2 + W * constrain_bm_slots(D) + constrain_lvl_off(W, D - 1)
+                 : (uint32_t)exp_slots((int)D - 1) + 2 + constrain_bm_slots(D);
 }
 
-static constexpr int CONSTRAIN_WG = 8;       // 8 x 4.9 KB of LDS per workgroup at BART's depth, two workgroups per CU
+static constexpr int CONSTRAIN_WG = 8;       // 39 KB of LDS per workgroup at BART's depth, two workgroups per CU
 
 template <bool SB, int W>
 __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, ConstrainArgs a)
@@ -564,13 +590,15 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform, and the compiler knows
     const uint32_t D = ix.dlevels;
     const uint32_t sub_bits = FMI_DIGIT_BITS * (D - 1);        // symbol bits below the top digit
-    const uint32_t nsym = 1u << sub_bits;                       // symbols of one wave's sub-tree
+    const uint32_t nsym = 1u << sub_bits;                       // symbols of one item's sub-tree
     const uint32_t nw = (nsym + 31) >> 5;
-    const uint32_t stride = constrain_wave_slots(D);
-    uint4 *s_items = s_dyn + (W > 1 ? (W * 4 + 15) / 16 : 0);
-    uint4 *s_node = s_items + (size_t)wave * stride;
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_node + exp_slots((int)D - 1));
-    uint32_t *s_bits = s_cnt + 8;
+    const uint32_t bm_slots = constrain_bm_slots(D);
+    // W == 1: frontier, counters, bitmap of the wave;  W > 1: see above
+    uint4 *s_node = s_dyn;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(W > 1 ? s_dyn : s_dyn + exp_slots((int)D - 1));
+    uint4 *s_bitmaps = W > 1 ? s_dyn + 2 : s_dyn + exp_slots((int)D - 1) + 2;
+    uint4 *s_lvl = s_bitmaps + W * bm_slots;                    // W > 1 only
+    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_bitmaps + (size_t)wave * bm_slots);
     uint32_t d1, r;
     if constexpr (W == 1) {
         // rows are padded to a multiple of 8 in the grid: workgroup i runs on XCD i % 8, so every wave of a row lands on
@@ -593,9 +621,10 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
         const uint64_t w0 = (uint64_t)blockIdx.x * per;
         for (uint64_t w = w0 + threadIdx.x; w < w0 + per && w < a.clear_words; w += 64 * W) a.clear[w] = 0u;
     }
-    const bool valid = r < a.rows;      // padding wave: its share of the clearing (and of a workgroup's leaf phase) is all it does
+    const bool valid = r < a.rows;      // padding wave: its share of the clearing (and of the workgroup's levels) is all it does
     if (W == 1 && !valid) return;
     for (uint32_t w = lane; w < nw; w += 64) s_bits[w] = 0u;
+    if (W > 1 && threadIdx.x < 8) s_cnt[threadIdx.x] = 0u;
 
     // ---- the row: prefix range, class (identical in every wave of the row) ----
     uint64_t lo = 0, hi = 0, count = 0, probes = 0;
@@ -638,9 +667,8 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
     else if (a.stop_at_count > 0 && (int64_t)count <= a.stop_at_count) single = a.eos_id;
     else if (dead) single = a.pad_id;
     else { expand = true; if (hi > ix.n) hi = ix.n; }
-    wave_sync();            // bitmap zeroed
+    if constexpr (W > 1) __syncthreads(); else wave_sync();            // bitmaps and counters zeroed
     // ---- child d1 of the row's root node, then its sub-tree ----
-    uint32_t leaf_nodes = 0;     // W > 1: nodes this wave left in its leaf-level array
     if (expand && hi > lo) {
         uint64_t clo, chi;
         root_child(ix, lo, hi, d1, clo, chi);
@@ -651,21 +679,61 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
         }
         if (chi > clo) {
             if (D == 1) { if (lane == 0 && d1 != 0) s_bits[0] |= 1u; }
-            else leaf_nodes = expand_subtree<EMIT_BITS, SB, (W > 1)>(ix, s_node, s_cnt, reinterpret_cast<uint8_t *>(s_bits), r, 1, clo, chi, d1,
-                                                                    EmitTarget{}, counting, ctr);
+            else if constexpr (W > 1) {
+                if (D == 2) {
+                    // level 1 is the leaf level: the workgroup serves the W root children together
+                    if (lane == 0) {
+                        uint4 c = pack_node(clo, chi, d1);
+                        c.w = wave;
+                        s_lvl[atomicAdd(&s_cnt[0], 1u)] = c;
+                    }
+                } else {
+                    // level 1 = ONE node per item: lane (d2, end) of the first 32 takes one single-digit rank -- a
+                    // sixth of the instructions of a wave iteration that computes sixteen ranks per lane for one
+                    // node -- and no barrier in front of it; the children go to the workgroup's level-2 array
+                    const uint32_t e = lane & 1, d2 = lane >> 1;
+                    uint64_t q = 0;
+                    if (lane < 32) q = wm_step(ix, 1, e ? chi : clo, d2);
+                    const uint64_t qo = (uint64_t)dpp_xor1((uint32_t)q) | ((uint64_t)dpp_xor1((uint32_t)(q >> 32)) << 32);
+                    const uint64_t c_lo = e ? qo : q, c_hi = e ? q : qo;
+                    const bool ex = lane < 32 && e == 0 && c_hi > c_lo;
+                    const uint64_t bal = __ballot(ex);
+                    const uint32_t nch = (uint32_t)__popcll(bal);
+                    if (nch) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&s_cnt[1], nch);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        if (ex) {
+                            uint4 c = pack_node(c_lo, c_hi, (d1 << 4) | d2);
+                            c.w = wave;
+                            s_lvl[constrain_lvl_off(W, 1) + base + lane_rank_in(bal)] = c;
+                        }
+                    }
+                    if (counting && lane == 0) {
+                        uint32_t em = 0;
+#pragma unroll
+                        for (uint32_t d = 0; d < 16; d++) em |= (uint32_t)((bal >> (2 * d)) & 1ull) << d;
+                        ctr.model += model_nodes(em, 1, FMI_DIGIT_BITS * D - ix.levels);
+                        ctr.probes += (clo >> FMI_BLOCK_SHIFT) != (chi >> FMI_BLOCK_SHIFT) ? 2 : 1;
+                        ctr.iters++; ctr.nodes++;
+                    }
+                }
+            } else {
+                expand_subtree<EMIT_BITS, SB>(ix, s_node, s_cnt, reinterpret_cast<uint8_t *>(s_bits), r, 1, clo, chi, d1,
+                                              EmitTarget{}, counting, ctr);
+            }
         }
     }
     if constexpr (W > 1) {
-        uint32_t *s_leaf = reinterpret_cast<uint32_t *>(s_dyn);
-        if (lane == 0) s_leaf[wave] = leaf_nodes;
-        __syncthreads();        // every item's leaf frontier and zeroed bitmap are in LDS
-        STAMP(5);
-        uint32_t off[W + 1];
-        off[0] = 0;
-#pragma unroll
-        for (int j = 0; j < W; j++) off[j + 1] = off[j] + (uint32_t)__builtin_amdgcn_readfirstlane(s_leaf[j]);
-        leaf_phase<SB, W>(ix, s_items, stride, off, counting, ctr);
-        __syncthreads();        // the leaf bits other waves found for my item
+        // levels 2 .. D-1 (dlevels 2: level 1) of the W sub-trees, the workgroup together
+        for (uint32_t j = D == 2 ? 0 : 1; j + 1 < D; j++) {
+            __syncthreads();        // level j complete (the first one: by every wave on its own)
+            if (j == D - 2) STAMP(5);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt[j]);
+            wg_level<SB, W>(ix, s_lvl + constrain_lvl_off(W, j), total, s_lvl + constrain_lvl_off(W, j + 1), &s_cnt[j + 1], 1 + j,
+                            s_bitmaps, bm_slots, counting, ctr);
+        }
+        __syncthreads();            // the leaf bits other waves found for my item
     }
     wave_sync();
     STAMP(3);
@@ -683,7 +751,7 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
     STAMP(4);
 #undef STAMP
     if (counting) {
-        if (writer && lane == 0) { ctr.probes += probes; ctr.model += model; }
+        if (writer && lane == 0) { ctr.probes += (uint32_t)probes; ctr.model += model; }
         flush_counters(a.probe_counter, ctr);
     }
 }
@@ -1445,7 +1513,7 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     else h->state_tag = 0;
     const bool timed = h->timing_enabled && h->ev_used < MAX_TIMED_LAUNCHES;
     if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
-    const size_t lds = (size_t)constrain_wave_slots(h->dlevels) * 16 * W + (W > 1 ? (size_t)((W * 4 + 15) / 16) * 16 : 0);
+    const size_t lds = (size_t)constrain_lds_slots(h->dlevels, W) * 16;
     const bool sb = h->dev.nsb > 1;
     void (*kern)(FmiDev, ConstrainArgs) = W > 1 ? (sb ? k_constrain<true, CONSTRAIN_WG> : k_constrain<false, CONSTRAIN_WG>)
                                                 : (sb ? k_constrain<true, 1> : k_constrain<false, 1>);
