@@ -559,8 +559,8 @@ def main():
     except Exception:
         pass
     nl = max(1, launches.value)
-    roofline = {"bound": "hbm", "kernel": "k_constrain (one constraint call = one launch: prefix range, row class, root digit and sub-tree "
-                                          "expansion of every (row, top digit) in one wave)",
+    roofline = {"bound": "hbm", "kernel": "k_constrain (one constraint call = one launch: prefix range, row class and root digit per (row, top digit) "
+                                          "wave, the sub-trees level by level by workgroups of 8 waves)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic, "traffic_source": traffic_src, "launches": int(l2.value), "avg_launch_us": round(k2.value * 1e3 / n2, 2),
                 "algorithmic_bytes_per_launch": round(p2.value * 128.0 / n2, 1),

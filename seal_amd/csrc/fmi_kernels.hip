@@ -521,9 +521,13 @@ __global__ __launch_bounds__(256) void k_dense_compact(const uint64_t *dense, ui
 // a row repeats the row's own few dependent probes -- range of the prefix (one
 // backward-search step from the parent's kept range, or the full search), class of
 // the row (lines 87-105 and the branch order of 111-131), child d1 of the root node --
-// with wave-uniform addresses (one request each, L2/MALL hits for all but the first
-// wave), then expands its sub-tree into its LDS bitmap and stores it.  Only the d1 = 0
-// wave writes the row's side effects (kept range, measurement counters).
+// with wave-uniform addresses read through the constant address space: scalar loads
+// and scalar ALU (one request each, L2/MALL hits for all but the first wave), no VALU
+// issue slots.  Then the sub-tree below (row, d1) is expanded into the item's LDS
+// bitmap, which its wave stores: by the eight waves of the workgroup together, level
+// by level, for vocabularies of up to four digit levels (wg_level), by the wave alone
+// otherwise (expand_subtree).  Only the d1 = 0 wave writes the row's side effects
+// (kept range, measurement counters).
 // ---------------------------------------------------------------------------
 static constexpr int MAX_FORCE = 8;
 struct ForceFrom { int64_t tok[MAX_FORCE]; uint32_t n; };
