@@ -34,6 +34,13 @@ int sealnn_add_layernorm(void *stream, const float *x, const float *y, const flo
 /* teacher-forced causal self-attention: qkv [n_seq, T, 3, heads, 64] -> out [n_seq, T, heads*64]; T <= 17 */
 int sealnn_causal_self_attn(void *stream, const float *qkv, uint32_t n_seq, uint32_t T, uint32_t heads, float scale, float *out);
 
+/* The same attention over a prefix TREE (rescoring, reference keys.py:64-141: the keys of a query share prefixes and the
+ * decoder is causal, so every distinct prefix is ONE decoder position): node i attends the nodes anc[i][0 .. depth_i]
+ * (its ancestors from the root down, then itself; -1 beyond its depth; max_depth1 <= 17 columns).  qkv [n_nodes, 3 * heads * 64],
+ * out [n_nodes, heads * 64].  Same arithmetic, in the same order, as sealnn_causal_self_attn for a row holding that prefix. */
+int sealnn_tree_self_attn(void *stream, const float *qkv, const int32_t *anc, uint32_t n_nodes, uint32_t max_depth1, uint32_t heads,
+                          float scale, float *out);
+
 /* cross-attention of arbitrary rows: row_batch[row] = query whose encoder K/V (layouts as above) the row attends */
 int sealnn_cross_attn_rows(void *stream, const float *q, const float *ck, const float *cv, const float *bias,
                            const int32_t *row_batch, uint32_t rows, uint32_t heads, uint32_t S, float scale, float *out);

@@ -98,6 +98,7 @@ NN_SIGNATURES = {
     "sealnn_cross_attn_step": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _vp]),
     "sealnn_add_layernorm": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp]),
     "sealnn_causal_self_attn": (_int, [_vp, _vp, _u32, _u32, _u32, _f32, _vp]),
+    "sealnn_tree_self_attn": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp]),
     "sealnn_cross_attn_rows": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp]),
     "sealnn_cross_attn_runs": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _vp]),
 }

@@ -238,6 +238,68 @@ class BartStepDecoder:
             x = add_ln(x, L["fc2"](L["act"](L["fc1"](x))), L["ln3"])
         return F.linear(x, self.lm_w, self.lm_b.view(-1)).view(N, T, -1)
 
+    @torch.no_grad()
+    def tree_logits(self, tok: torch.Tensor, depth: torch.Tensor, anc: torch.Tensor, qidx: torch.Tensor, enc_hidden: torch.Tensor,
+                    attention_mask: torch.Tensor, prepared=None) -> torch.Tensor:
+        """Teacher forcing over a prefix tree: node i is one decoder position -- input token ``tok[i]`` at position
+        ``depth[i]`` of the distinct prefix whose nodes are ``anc[i, :depth[i] + 1]`` (root first, itself last, -1 beyond) --
+        of query ``qidx[i]``.  Returns the logits after every node, [N, vocab]: exactly what row-per-key teacher forcing
+        (reference keys.py:64-141) computes at that position of any row that starts with that prefix, each computed once.
+        ``prepared`` = ``teacher_prepare(...)`` runs the fused sealnn_* kernels; otherwise plain torch ops (any device / dtype)."""
+        N = tok.numel()
+        dev = tok.device
+        x = self.embed(tok) + self.pos.weight[self.pos_offset + depth]
+        x = self.ln_emb(x)
+        if prepared is not None:
+            from ._lib import check, lib
+            L_ = lib()
+            cross, bias, S = prepared
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            anc32 = anc.to(torch.int32).contiguous()
+            row_batch = qidx.to(torch.int32).contiguous()
+            A = anc32.shape[1]
+
+            def add_ln(res, y, ln):
+                out = torch.empty_like(res)
+                check(L_.sealnn_add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                              N, self.d, float(ln.eps), out.data_ptr()))
+                return out
+            for li, L in enumerate(self.layers):
+                qkv = F.linear(x, L["qkv_w"], L["qkv_b"])
+                a = torch.empty(N, self.d, dtype=x.dtype, device=dev)
+                check(L_.sealnn_tree_self_attn(stream, qkv.data_ptr(), anc32.data_ptr(), N, A, self.h, float(self.scale), a.data_ptr()))
+                x = add_ln(x, L["so"](a), L["ln1"])
+                q = L["cq"](x)
+                c = torch.empty(N, self.d, dtype=x.dtype, device=dev)
+                ck, cv = cross[li]
+                check(L_.sealnn_cross_attn_rows(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
+                                                N, self.h, S, float(self.scale), c.data_ptr()))
+                x = add_ln(x, L["co"](c), L["ln2"])
+                x = add_ln(x, L["fc2"](L["act"](L["fc1"](x))), L["ln3"])
+            return F.linear(x, self.lm_w, self.lm_b.view(-1))
+        # plain torch ops: the ancestors' keys / values gathered per node, the encoder's per query
+        B, S, _ = enc_hidden.shape
+        H, dh = self.h, self.dh
+        anc_ok = anc >= 0                                   # [N, A]
+        anc_ix = anc.clamp(min=0)
+        neg = torch.finfo(x.dtype).min
+        self_bias = torch.zeros(anc.shape, dtype=x.dtype, device=dev).masked_fill_(~anc_ok, neg)[:, None, :]      # [N, 1, A]
+        cross_bias = torch.zeros(B, S, dtype=x.dtype, device=dev).masked_fill_(attention_mask == 0, neg)[qidx][:, None, :]   # [N, 1, S]
+        for L in self.layers:
+            qkv = F.linear(x, L["qkv_w"], L["qkv_b"]).view(N, 3, H, dh)
+            q, k, v = qkv[:, 0] * self.scale, qkv[:, 1], qkv[:, 2]
+            ka, va = k[anc_ix], v[anc_ix]                   # [N, A, H, dh]
+            w = torch.softmax(torch.einsum("nhd,nahd->nha", q, ka) + self_bias, dim=-1)
+            a = torch.einsum("nha,nahd->nhd", w, va).reshape(N, self.d)
+            x = L["ln1"](x + L["so"](a))
+            kv = F.linear(enc_hidden, L["ckv_w"], L["ckv_b"]).view(B, S, 2, H, dh)
+            cq = (L["cq"](x) * self.scale).view(N, H, dh)
+            w = torch.softmax(torch.einsum("nhd,nshd->nhs", cq, kv[:, :, 0][qidx]) + cross_bias, dim=-1)
+            c = torch.einsum("nhs,nshd->nhd", w, kv[:, :, 1][qidx]).reshape(N, self.d)
+            x = L["ln2"](x + L["co"](c))
+            x = L["ln3"](x + L["fc2"](L["act"](L["fc1"](x))))
+        return F.linear(x, self.lm_w, self.lm_b.view(-1))
+
     use_fused_kernels = True      # include/sealnn.h: self-attn / cross-attn / add+LayerNorm as single HIP kernels
 
     def _step_static(self, st):

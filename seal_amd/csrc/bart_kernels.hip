@@ -125,6 +125,43 @@ __global__ __launch_bounds__(256) void k_causal_self_attn(const float *qkv, uint
     }
 }
 
+// teacher-forced self-attention over a prefix TREE: every node (one decoder position of one distinct prefix) attends
+// its ancestors and itself, anc[node][0 .. depth]: node indices from the root down, -1 beyond the node's depth.  One
+// wavefront per (node, head); lane = dim.  Same arithmetic in the same order as k_causal_self_attn does for position
+// `depth` of a row holding that prefix.
+__global__ __launch_bounds__(256) void k_tree_self_attn(const float *qkv, const int32_t *anc, uint32_t n_nodes, uint32_t A, uint32_t heads,
+                                                        float scale, float *out)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_nodes * heads) return;
+    const uint32_t node = item / heads, head = item % heads;
+    const uint64_t stride = (uint64_t)3 * heads * 64;               // per node
+    const float q = qkv[(uint64_t)node * stride + head * 64 + lane] * scale;
+    const int32_t *mine = anc + (uint64_t)node * A;
+    float s[FMI_MAX_LEVELS], vreg[FMI_MAX_LEVELS];
+    float m = -__builtin_huge_valf();
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < FMI_MAX_LEVELS; j++) {
+        s[j] = 0.f; vreg[j] = 0.f;
+        const int32_t a = j < A ? mine[j] : -1;
+        if (a >= 0 && cnt == j) {
+            const float *row = qkv + (uint64_t)a * stride + head * 64 + lane;
+            const float k = row[(uint64_t)heads * 64];
+            vreg[j] = row[(uint64_t)2 * heads * 64];
+            s[j] = wave_sum(q * k);
+            m = fmaxf(m, s[j]);
+            cnt = j + 1;
+        }
+    }
+    float denom = 0.f, acc = 0.f;
+#pragma unroll
+    for (uint32_t j = 0; j < FMI_MAX_LEVELS; j++)
+        if (j < cnt) { const float e = expf(s[j] - m); denom += e; acc += e * vreg[j]; }
+    out[(uint64_t)node * heads * 64 + head * 64 + lane] = acc / denom;
+}
+
 // cross-attention for arbitrary rows: row_batch[row] selects the query whose encoder K/V to use
 __global__ __launch_bounds__(256) void k_cross_attn_rows(const float *q, const float *ck, const float *cv, const float *bias,
                                                          const int32_t *row_batch, uint32_t rows, uint32_t heads, uint32_t S,
@@ -272,6 +309,17 @@ extern "C" int sealnn_causal_self_attn(void *stream, const float *qkv, uint32_t 
     if (T > FMI_MAX_LEVELS) { fmi_set_error("sealnn_causal_self_attn: at most %u positions", FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
     const uint32_t items = n_seq * heads;
     hipLaunchKernelGGL(k_causal_self_attn, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, n_seq, T, heads, scale, out);
+    NNCHK();
+    return FMI_OK;
+}
+
+extern "C" int sealnn_tree_self_attn(void *stream, const float *qkv, const int32_t *anc, uint32_t n_nodes, uint32_t max_depth1, uint32_t heads,
+                                     float scale, float *out)
+{
+    if (max_depth1 > FMI_MAX_LEVELS) { fmi_set_error("sealnn_tree_self_attn: at most %u positions", FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
+    const uint32_t items = n_nodes * heads;
+    if (!items) return FMI_OK;
+    hipLaunchKernelGGL(k_tree_self_attn, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, anc, n_nodes, max_depth1, heads, scale, out);
     NNCHK();
     return FMI_OK;
 }

@@ -17,6 +17,7 @@ sorts, first-come coverage, the ``[tok_end - len, tok_end)`` window, heap order
 of the greedy matcher) is reproduced on the host from those arrays; floating
 point is float64 ``math`` exactly where the reference uses it.
 """
+import itertools
 import math
 import os
 from collections import Counter
@@ -87,8 +88,9 @@ def rescore_keys(model, inputs, list_of_decoded, batch_size=100, length_penalty=
     summation order), ~4-5x fewer decoder positions.  ``share_prefixes=False`` is
     the reference's one-row-per-key batching."""
     if share_prefixes:
-        job = _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_penalty, prefix, strip_from_bos,
-                                   strip_from_eos, logit_bias, encoded)
+        # the prefix tree (every distinct prefix ONE decoder position); SEAL_RESCORE_TREE=0: maximal parents as rows
+        fn = _rescore_keys_shared if os.environ.get("SEAL_RESCORE_TREE") == "0" else _rescore_keys_tree
+        job = fn(model, inputs, list_of_decoded, batch_size, length_penalty, prefix, strip_from_bos, strip_from_eos, logit_bias, encoded)
         # ``pending``: everything is enqueued and nothing has waited for the GPU; ``job.result()`` reads the scores back
         # (the searcher enqueues the three rescorings of a batch back to back and reads them back afterwards)
         return job if pending else job.result()
@@ -171,6 +173,11 @@ def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_pena
                 work.append((qi, p))
             nxt = p
         owner.append(own)
+    if os.environ.get("SEAL_RESCORE_STATS"):
+        nodes = {(qi, p[:j]) for qi, p in work for j in range(len(p) + 1)}
+        import sys
+        print(f"[rescore] queries {len(seqs)} keys {sum(len(x) for x in seqs)} rows {len(work)} positions {sum(len(p) + 1 for _, p in work)} "
+              f"unique prefix nodes {len(nodes)} max_len {max((len(p) for _, p in work), default=0)}", file=sys.stderr)
     order = sorted(range(len(work)), key=lambda i: len(work[i][1]))     # similar lengths together: less padding
     slot = {w: j for j, w in enumerate(order)}
     # keys grouped by the chunk of their owner row
@@ -224,6 +231,121 @@ def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_pena
         lo = torch.clamp(torch.full_like(n_idx, npre), max=cum.shape[1] - 1)
         body = cum[r_idx, n_idx - 1] - cum[r_idx, torch.minimum(lo, n_idx - 1)]
         totals.append((items, torch.where(n_idx > npre, body + last_lp, torch.zeros_like(body)).float()))
+    return _PendingRescore(totals, scores, decoded, length_penalty)
+
+
+def _prefix_tree(key_query, key_seqs, npre, start):
+    """The distinct prefixes of the given keys (``key_seqs[k]``: a token tuple of query ``key_query[k]``, every one longer
+    than ``npre``) as a forest, built level by level with numpy (a node of depth j = a distinct (parent node, token j-1) pair;
+    nodes are numbered depth-major): per node its input token (``start`` for the roots), depth, query and ancestor row
+    (root first, itself last, -1 beyond); per term (key k, position j >= npre) the node of ``key[:j]``, the target
+    ``key[j]``, k and the column j - npre."""
+    nk = len(key_seqs)
+    lens = np.fromiter(map(len, key_seqs), dtype=np.int64, count=nk)
+    L = int(lens.max())
+    K = np.zeros((nk, L), dtype=np.int64)
+    flat = np.fromiter(itertools.chain.from_iterable(key_seqs), dtype=np.int64, count=int(lens.sum()))
+    K[np.repeat(np.arange(nk), lens), np.arange(len(flat)) - np.repeat(np.cumsum(lens) - lens, lens)] = flat
+    base = int(flat.max()) + 1
+    ids = np.full((nk, L), -1, dtype=np.int64)              # ids[k, j] = node of key[:j]
+    # depth 0: one root per query
+    lvl_query, ids[:, 0] = np.unique(np.asarray(key_query, dtype=np.int64), return_inverse=True)
+    lvl_anc = np.full((len(lvl_query), L), -1, dtype=np.int64)
+    lvl_anc[:, 0] = np.arange(len(lvl_query))
+    toks, depths, queries, ancs = [np.full(len(lvl_query), start, dtype=np.int64)], [np.zeros(len(lvl_query), dtype=np.int64)], [lvl_query], [lvl_anc]
+    first = 0                                               # id of the first node of the previous level
+    n_nodes = len(lvl_query)
+    for j in range(1, L):
+        live = np.nonzero(lens > j)[0]
+        if len(live) == 0:
+            break
+        up, inv = np.unique(ids[live, j - 1] * base + K[live, j - 1], return_inverse=True)
+        parent = up // base - first                         # index into the previous level
+        ids[live, j] = n_nodes + inv
+        a = lvl_anc[parent]
+        a[:, j] = n_nodes + np.arange(len(up))
+        lvl_query, lvl_anc = lvl_query[parent], a
+        toks.append(up % base); depths.append(np.full(len(up), j, dtype=np.int64)); queries.append(lvl_query); ancs.append(a)
+        first, n_nodes = n_nodes, n_nodes + len(up)
+    A = len(toks)                                           # deepest node + 1
+    jj = np.arange(L)[None, :]
+    tk, tj = np.nonzero((jj >= npre) & (jj < lens[:, None]))
+    return dict(tok=np.concatenate(toks), depth=np.concatenate(depths), query=np.concatenate(queries),
+                anc=np.ascontiguousarray(np.concatenate(ancs)[:, :A]),
+                term_node=ids[tk, tj], term_tok=K[tk, tj], term_key=tk, term_col=tj - npre, width=int(max(1, L - npre)))
+
+
+@torch.inference_mode()
+def _rescore_keys_tree(model, inputs, list_of_decoded, batch_size, length_penalty, prefix, strip_from_bos, strip_from_eos,
+                       logit_bias, encoded=None):
+    """Teacher forcing over the prefix tree.  score(key) = sum_j log p(key[j] | key[:j]) and the decoder is causal, so the
+    distribution after ``key[:j]`` is the same in every key that starts with it: every DISTINCT prefix of a query's keys is
+    one node = one decoder position (input token ``key[j-1]`` at position ``j``, attending its ancestors), run through the
+    model once (``BartStepDecoder.tree_logits``).  The keys of a batch of 20 searcher queries -- the recorded hypotheses of
+    a beam search: a few thousand keys -- have ~3 000 distinct prefixes where one row per maximal parent
+    (``_rescore_keys_shared``) runs ~10 000 positions and one row per key (reference keys.py:64-141) ~60 000."""
+    cfg = model.config
+    device = next(model.parameters()).device
+    if inputs is None:
+        batch_in = [[cfg.bos_token_id, cfg.eos_token_id]] * len(list_of_decoded)
+    else:
+        batch_in = [list(i) for i in inputs]
+    decoded = [[x[1] if isinstance(x[0], float) else x for x in xx] for xx in list_of_decoded]
+    sd = getattr(model, "_seal_step_decoder", None)
+    if sd is None or sd.layers[0]["qkv_w"].device != device:        # (the fused weights follow the model to its device)
+        from .bart_decoder import BartStepDecoder
+        sd = model._seal_step_decoder = BartStepDecoder(model)
+    if encoded is not None:
+        enc, attention_mask = encoded
+    else:
+        input_ids = _pad_batch(batch_in, cfg.pad_token_id, device)
+        attention_mask = (input_ids != cfg.pad_token_id).to(torch.uint8)
+        if device.type == "cuda":
+            enc = sd.encode(input_ids, attention_mask)          # the encoder without HF's blocking mask check
+        else:
+            enc = model.model.encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+    start, npre = cfg.decoder_start_token_id, len(prefix)
+    seqs = [[tuple(list(prefix) + list(strip(list(key), strip_from_bos, strip_from_eos))) for key in keys] for keys in decoded]
+    scores = [[0.0] * len(ss) for ss in seqs]
+    # whole queries per forward; the sum of their key lengths, an upper bound of the nodes (typically 3x), stays below `cap`
+    # (the logits are nodes x vocab floats)
+    cap = int(os.environ.get("SEAL_RESCORE_NODES", 12000))
+    totals = []
+    max_len = max((len(sq) for ss in seqs for sq in ss), default=0)
+    prepared = None
+    if enc.is_cuda and max_len > 0 and sd.can_teacher_force(enc, max_len):
+        prepared = sd.teacher_prepare(enc, attention_mask)
+
+    # chunks of whole queries: the sum of key lengths bounds a chunk's nodes from above (typically 3x)
+    groups, cur, cur_n = [], [], 0
+    for qi, ss in enumerate(seqs):
+        n = sum(len(sq) for sq in ss if len(sq) > npre)
+        if cur and cur_n + n > cap:
+            groups.append(cur); cur, cur_n = [], 0
+        cur.append(qi); cur_n += n
+    if cur:
+        groups.append(cur)
+    for group in groups:
+        items = [(qi, ki, 0, sq) for qi in group for ki, sq in enumerate(seqs[qi]) if len(sq) > npre]
+        if not items:
+            continue
+        tree = _prefix_tree([it[0] for it in items], [it[3] for it in items], npre, start)
+        packed = _h2d(np.stack([tree["tok"], tree["depth"], tree["query"]]), device)
+        anc_d = _h2d(tree["anc"], device)
+        logits = sd.tree_logits(packed[0], packed[1], anc_d, packed[2], enc, attention_mask, prepared)
+        if logit_bias is not None:
+            logits = logits + logit_bias[packed[2]]
+        logp = logits.log_softmax(-1)                                   # [nodes, V]: the distribution after the node's prefix
+        # term j of key k = logp[node(key[:j]), key[j]] (0 for targets < 2, keys.py:132), summed in position order in float64
+        t = _h2d(np.stack([tree["term_node"], tree["term_tok"], tree["term_key"], tree["term_col"]]), device)
+        lp = logp[t[0], t[1]].double()
+        lp = torch.where(t[1] < 2, torch.zeros_like(lp), lp)
+        table = torch.zeros(len(items), tree["width"], dtype=torch.float64, device=device)
+        table[t[2], t[3]] = lp
+        totals.append((items, table.sum(-1).float()))
+    if os.environ.get("SEAL_RESCORE_STATS"):
+        import sys
+        print(f"[rescore/tree] queries {len(seqs)} keys {sum(len(x) for x in seqs)} chunks {len(totals)}", file=sys.stderr)
     return _PendingRescore(totals, scores, decoded, length_penalty)
 
 

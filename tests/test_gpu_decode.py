@@ -181,10 +181,12 @@ def test_fused_constrained_topk_matches_unfused_step(kw, narrow, monkeypatch):
             assert len(set(flat[q].tolist())) == 2 * K
 
 
+@pytest.mark.parametrize("tree", ["1", "0"], ids=["prefix-tree", "maximal-parent-rows"])
 @pytest.mark.parametrize("geom", MODEL_GEOMETRIES, ids=MODEL_IDS)
-def test_rescore_keys_tree_shared_teacher_forcing_matches_one_hf_row_per_key(geom, monkeypatch):
-    """tree-shared rescoring (``share_prefixes=True``: at head_dim 64 through sealnn_causal_self_attn /
-    sealnn_cross_attn_rows / sealnn_add_layernorm, per-query cross K/V) == one row per key through HF's own
+def test_rescore_keys_tree_shared_teacher_forcing_matches_one_hf_row_per_key(geom, tree, monkeypatch):
+    """prefix-sharing rescoring (``share_prefixes=True``: one decoder position per distinct prefix through
+    sealnn_tree_self_attn, or one row per maximal parent through sealnn_causal_self_attn; at head_dim 64 both with
+    sealnn_cross_attn_* / sealnn_add_layernorm and per-query cross K/V) == one row per key through HF's own
     forward (``share_prefixes=False``, the reference's batching, keys.py:64-141).  Encoder lengths 1, 63 and 64
     in one ragged batch, keys up to 17 tokens (T = 17 decoder positions)."""
     import numpy as np
@@ -193,9 +195,12 @@ def test_rescore_keys_tree_shared_teacher_forcing_matches_one_hf_row_per_key(geo
     from tests.helpers import tiny_bart
     dev = torch.device("cuda:0")
     m = tiny_bart(120, **geom).to(dev)
+    monkeypatch.setenv("SEAL_RESCORE_TREE", tree)
     fused_calls = []
-    real = BartStepDecoder.teacher_logits
+    real, real_tree = BartStepDecoder.teacher_logits, BartStepDecoder.tree_logits
     monkeypatch.setattr(BartStepDecoder, "teacher_logits", lambda self, *a: (fused_calls.append(1), real(self, *a))[1])
+    monkeypatch.setattr(BartStepDecoder, "tree_logits",
+                        lambda self, *a: (fused_calls.append(1) if a[6] is not None else None, real_tree(self, *a))[1])
     rng = np.random.default_rng(0)
     inputs = [[0] + rng.integers(4, 118, size=n).tolist() + [2] for n in (0, 61, 62, 5)]
     inputs[0] = [2]                                      # a one-token encoder input
@@ -410,3 +415,49 @@ def test_cross_attention_over_runs_is_bit_identical_to_the_per_row_kernel(S, T):
     att = torch.softmax(torch.einsum("rhd,rhds->rhs", q * 0.125, ck[rb]) + bias[rb][:, None, :], -1)
     ref = torch.einsum("rhs,rhsd->rhd", att, cv[rb]).reshape(rows, heads * 64)
     assert torch.allclose(b, ref, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [1, 5, 17])
+def test_tree_self_attention_matches_the_row_kernel_and_torch(T):
+    """sealnn_tree_self_attn: (a) on chains -- node (n, j) = position j of sequence n, ancestors = its own row -- bit-identical
+    to sealnn_causal_self_attn; (b) on a random forest against a torch gather-softmax reference"""
+    from seal_amd._lib import check, lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(T)
+    heads, n_seq = 3, 9
+    st = torch.cuda.current_stream(dev).cuda_stream
+    qkv = torch.randn(n_seq * T, 3 * heads * 64, generator=g).to(dev)
+    a, b = torch.empty(n_seq * T, heads * 64, device=dev), torch.empty(n_seq * T, heads * 64, device=dev)
+    check(lib().sealnn_causal_self_attn(st, qkv.data_ptr(), n_seq, T, heads, 0.125, a.data_ptr()))
+    anc = torch.full((n_seq * T, T), -1, dtype=torch.int32)
+    for n in range(n_seq):
+        for j in range(T):
+            anc[n * T + j, :j + 1] = torch.arange(n * T, n * T + j + 1, dtype=torch.int32)
+    anc = anc.to(dev)
+    check(lib().sealnn_tree_self_attn(st, qkv.data_ptr(), anc.data_ptr(), n_seq * T, T, heads, 0.125, b.data_ptr()))
+    assert torch.equal(a, b)
+    # random forest: node i > 0 hangs below a random earlier node (or is a root), depth < T
+    N = 200
+    parent = [-1] * N
+    rows = [[0]]
+    for i in range(1, N):
+        p = int(torch.randint(-1, i, (1,), generator=g))
+        if p >= 0 and len(rows[p]) >= T:
+            p = -1
+        parent[i] = p
+        rows.append((rows[p] if p >= 0 else []) + [i])
+    A = max(len(r) for r in rows)
+    anc = torch.full((N, A), -1, dtype=torch.int32)
+    for i, r in enumerate(rows):
+        anc[i, :len(r)] = torch.tensor(r, dtype=torch.int32)
+    qkv = torch.randn(N, 3 * heads * 64, generator=g).to(dev)
+    out = torch.empty(N, heads * 64, device=dev)
+    anc_d = anc.to(dev)
+    check(lib().sealnn_tree_self_attn(st, qkv.data_ptr(), anc_d.data_ptr(), N, A, heads, 0.125, out.data_ptr()))
+    v = qkv.view(N, 3, heads, 64)
+    ix = anc_d.long().clamp(min=0)
+    bias = torch.zeros(N, A, device=dev).masked_fill_(anc_d < 0, torch.finfo(torch.float32).min)[:, None, :]
+    w = torch.softmax(torch.einsum("nhd,nahd->nha", v[:, 0] * 0.125, v[:, 1][ix]) + bias, -1)
+    ref = torch.einsum("nha,nahd->nhd", w, v[:, 2][ix]).reshape(N, heads * 64)
+    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-5)

@@ -57,9 +57,14 @@ def test_small_helpers():
     assert deduplicate([[1], [1], [2]]) == [[1], [2]]
 
 
-def test_rescore_keys_prefix_sharing_matches_row_per_key():
+@pytest.mark.parametrize("tree", ["1", "0"], ids=["prefix-tree", "maximal-parent-rows"])
+def test_rescore_keys_prefix_sharing_matches_row_per_key(tree, monkeypatch):
+    """both prefix-sharing forwards -- one decoder position per DISTINCT prefix (tree attention, the default) and one row
+    per maximal parent -- against the reference's one row per key (keys.py:64-141)"""
     import torch
     from seal_amd.keys import rescore_keys
+    monkeypatch.setenv("SEAL_RESCORE_TREE", tree)
+    monkeypatch.setenv("SEAL_RESCORE_NODES", "20")          # several forwards per call: chunks of whole queries
     from tests.helpers import tiny_bart
     m = tiny_bart(120)
     rng = np.random.default_rng(0)
