@@ -80,13 +80,14 @@ def rescore_keys(model, inputs, list_of_decoded, batch_size=100, length_penalty=
     score divided by ``len(key) ** length_penalty``.
 
     ``share_prefixes`` (default): the keys of a query are the nodes of the beam
-    search tree -- most are prefixes of one another -- and the decoder is causal, so
-    the log-probability of a key is a prefix sum of the token log-probabilities of
-    any longer key that extends it.  Only the maximal keys are run through the
-    model (in chunks of ``batch_size``); every other key reads its score off the
-    cumulative sums.  Same numbers as scoring each key separately (up to fp32
-    summation order), ~4-5x fewer decoder positions.  ``share_prefixes=False`` is
-    the reference's one-row-per-key batching."""
+    search tree -- most are prefixes or siblings of one another -- and the decoder is
+    causal, so the distribution after ``key[:j]`` is the same in every key that starts
+    with it.  Every DISTINCT prefix is run through the model once, as one decoder
+    position that attends its ancestors (``_rescore_keys_tree``; ``SEAL_RESCORE_TREE=0``:
+    one row per maximal key, every other key reading its score off the row's cumulative
+    sums, ``_rescore_keys_shared``).  Same numbers as scoring each key separately (up to
+    fp32 summation order), ~20x / ~6x fewer decoder positions.  ``share_prefixes=False``
+    is the reference's one-row-per-key batching."""
     if share_prefixes:
         # the prefix tree (every distinct prefix ONE decoder position); SEAL_RESCORE_TREE=0: maximal parents as rows
         fn = _rescore_keys_shared if os.environ.get("SEAL_RESCORE_TREE") == "0" else _rescore_keys_tree
