@@ -174,11 +174,6 @@ def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_pena
                 work.append((qi, p))
             nxt = p
         owner.append(own)
-    if os.environ.get("SEAL_RESCORE_STATS"):
-        nodes = {(qi, p[:j]) for qi, p in work for j in range(len(p) + 1)}
-        import sys
-        print(f"[rescore] queries {len(seqs)} keys {sum(len(x) for x in seqs)} rows {len(work)} positions {sum(len(p) + 1 for _, p in work)} "
-              f"unique prefix nodes {len(nodes)} max_len {max((len(p) for _, p in work), default=0)}", file=sys.stderr)
     order = sorted(range(len(work)), key=lambda i: len(work[i][1]))     # similar lengths together: less padding
     slot = {w: j for j, w in enumerate(order)}
     # keys grouped by the chunk of their owner row
@@ -344,9 +339,6 @@ def _rescore_keys_tree(model, inputs, list_of_decoded, batch_size, length_penalt
         table = torch.zeros(len(items), tree["width"], dtype=torch.float64, device=device)
         table[t[2], t[3]] = lp
         totals.append((items, table.sum(-1).float()))
-    if os.environ.get("SEAL_RESCORE_STATS"):
-        import sys
-        print(f"[rescore/tree] queries {len(seqs)} keys {sum(len(x) for x in seqs)} chunks {len(totals)}", file=sys.stderr)
     return _PendingRescore(totals, scores, decoded, length_penalty)
 
 
