@@ -215,3 +215,41 @@ def test_aggregate_evidence_random_option_sweep():
         _same(got, want)
         compared += len(want[0])
     assert compared > 300
+
+
+@pytest.mark.parametrize("npre", [0, 1])
+def test_prefix_tree_equals_a_dictionary_built_forest(npre):
+    """keys._prefix_tree (numpy, level by level) against the obvious construction: one node per distinct (query, prefix),
+    every term (key, position >= npre) pointing at the node of its prefix; ancestors root first, the node itself last"""
+    from seal_amd.keys import _prefix_tree
+    rng = np.random.default_rng(5 + npre)
+    key_query, key_seqs = [], []
+    for q in (0, 3, 4):                                     # query ids need not be dense
+        stems = [tuple(rng.integers(2, 9, size=rng.integers(1, 6)).tolist()) for _ in range(6)]
+        for _ in range(40):
+            s = stems[rng.integers(len(stems))]
+            k = s[:rng.integers(1, len(s) + 1)] + tuple(rng.integers(0, 9, size=rng.integers(0, 3)).tolist())
+            if len(k) > npre:
+                key_query.append(q); key_seqs.append(k)
+    key_query.append(3); key_seqs.append(key_seqs[0] if key_query[0] == 3 else key_seqs[-1])       # a duplicate key
+    t = _prefix_tree(key_query, key_seqs, npre, start=99)
+    n = len(t["tok"])
+    want = {(q, k[:j]) for q, k in zip(key_query, key_seqs) for j in range(len(k))}
+    assert n == len(want) and t["anc"].shape == (n, max(len(k) for k in key_seqs))
+    prefix_of = {}
+    for i in range(n):
+        d = int(t["depth"][i])
+        row = t["anc"][i]
+        assert row[d] == i and (row[d + 1:] == -1).all() and (row[:d + 1] >= 0).all()
+        toks = tuple(int(t["tok"][a]) for a in row[1:d + 1])
+        assert int(t["tok"][row[0]]) == 99 and all(int(t["depth"][a]) == x for x, a in enumerate(row[:d + 1]))
+        assert all(int(t["query"][a]) == int(t["query"][i]) for a in row[:d + 1])
+        prefix_of[i] = (int(t["query"][i]), toks)
+    assert set(prefix_of.values()) == want and len(set(prefix_of.values())) == n
+    terms = sorted(zip(t["term_key"].tolist(), t["term_col"].tolist(), t["term_node"].tolist(), t["term_tok"].tolist()))
+    exp = sorted((k, j - npre, None, key_seqs[k][j]) for k in range(len(key_seqs)) for j in range(npre, len(key_seqs[k])))
+    assert len(terms) == len(exp)
+    for (k, c, node, tok), (ek, ec, _, etok) in zip(terms, exp):
+        assert (k, c, tok) == (ek, ec, etok)
+        assert prefix_of[node] == (key_query[k], key_seqs[k][:c + npre])
+    assert t["width"] == max(1, max(len(k) for k in key_seqs) - npre)
