@@ -265,67 +265,118 @@ def _prefix_tree(key_query, key_seqs, npre, start):
         first, n_nodes = n_nodes, n_nodes + len(up)
     A = len(toks)                                           # deepest node + 1
     jj = np.arange(L)[None, :]
-    tk, tj = np.nonzero((jj >= npre) & (jj < lens[:, None]))
+    npre = np.broadcast_to(np.asarray(npre, dtype=np.int64), (nk,))            # one scored-from position for all keys, or one per key
+    tk, tj = np.nonzero((jj >= npre[:, None]) & (jj < lens[:, None]))
     return dict(tok=np.concatenate(toks), depth=np.concatenate(depths), query=np.concatenate(queries),
                 anc=np.ascontiguousarray(np.concatenate(ancs)[:, :A]),
-                term_node=ids[tk, tj], term_tok=K[tk, tj], term_key=tk, term_col=tj - npre, width=int(max(1, L - npre)))
+                term_node=ids[tk, tj], term_tok=K[tk, tj], term_key=tk, term_col=tj - npre[tk], width=int(max(1, (lens - npre).max())))
+
+
+def _rescore_keys_tree(model, inputs, list_of_decoded, batch_size, length_penalty, prefix, strip_from_bos, strip_from_eos,
+                       logit_bias, encoded=None):
+    return _rescore_tree_jobs(model, [dict(inputs=inputs, keys=list_of_decoded, length_penalty=length_penalty, prefix=prefix,
+                                           strip_from_bos=strip_from_bos, strip_from_eos=strip_from_eos, logit_bias=logit_bias,
+                                           encoded=encoded)])[0]
 
 
 @torch.inference_mode()
-def _rescore_keys_tree(model, inputs, list_of_decoded, batch_size, length_penalty, prefix, strip_from_bos, strip_from_eos,
-                       logit_bias, encoded=None):
+def rescore_keys_multi(jobs, pending=False):
+    """Several ``rescore_keys(share_prefixes=True)`` calls at once: ``jobs`` = [(model, inputs, list_of_decoded, kwargs)] with
+    the keyword arguments of ``rescore_keys`` (``prefix, strip_from_bos, strip_from_eos, logit_bias, encoded, length_penalty``).
+    The jobs of one model share ONE forward over the prefix forest of all their queries (the searcher's body keys / query
+    n-grams / titles of a batch: 3 x ~500 launches and three under-filled sets of GEMMs become one); each job's scores are
+    what its own ``rescore_keys`` call returns."""
+    out = [None] * len(jobs)
+    if os.environ.get("SEAL_RESCORE_TREE") == "0":                  # the maximal-parent rows, job by job (A/B, tests)
+        out = [rescore_keys(job[0], job[1], job[2], pending=True, **job[3]) for job in jobs]
+        return out if pending else [r.result() for r in out]
+    by_model = {}
+    for j, job in enumerate(jobs):
+        by_model.setdefault(id(job[0]), []).append(j)
+    for ids in by_model.values():
+        res = _rescore_tree_jobs(jobs[ids[0]][0], [dict(inputs=jobs[j][1], keys=jobs[j][2], **jobs[j][3]) for j in ids])
+        for j, r in zip(ids, res):
+            out[j] = r
+    return out if pending else [r.result() for r in out]
+
+
+@torch.inference_mode()
+def _rescore_tree_jobs(model, jobs):
     """Teacher forcing over the prefix tree.  score(key) = sum_j log p(key[j] | key[:j]) and the decoder is causal, so the
     distribution after ``key[:j]`` is the same in every key that starts with it: every DISTINCT prefix of a query's keys is
     one node = one decoder position (input token ``key[j-1]`` at position ``j``, attending its ancestors), run through the
     model once (``BartStepDecoder.tree_logits``).  The keys of a batch of 20 searcher queries -- the recorded hypotheses of
     a beam search: a few thousand keys -- have ~3 000 distinct prefixes where one row per maximal parent
-    (``_rescore_keys_shared``) runs ~10 000 positions and one row per key (reference keys.py:64-141) ~60 000."""
+    (``_rescore_keys_shared``) runs ~10 000 positions and one row per key (reference keys.py:64-141) ~60 000.
+
+    ``jobs``: dicts with inputs / keys / prefix / strip_from_bos / strip_from_eos / logit_bias / encoded / length_penalty.
+    The queries of all jobs form one forest (a job's queries keep their own encoder states: the states of the jobs are
+    padded to one length and stacked); one ``_PendingRescore`` per job."""
     cfg = model.config
     device = next(model.parameters()).device
-    if inputs is None:
-        batch_in = [[cfg.bos_token_id, cfg.eos_token_id]] * len(list_of_decoded)
-    else:
-        batch_in = [list(i) for i in inputs]
-    decoded = [[x[1] if isinstance(x[0], float) else x for x in xx] for xx in list_of_decoded]
     sd = getattr(model, "_seal_step_decoder", None)
     if sd is None or sd.layers[0]["qkv_w"].device != device:        # (the fused weights follow the model to its device)
         from .bart_decoder import BartStepDecoder
         sd = model._seal_step_decoder = BartStepDecoder(model)
-    if encoded is not None:
-        enc, attention_mask = encoded
-    else:
-        input_ids = _pad_batch(batch_in, cfg.pad_token_id, device)
-        attention_mask = (input_ids != cfg.pad_token_id).to(torch.uint8)
-        if device.type == "cuda":
-            enc = sd.encode(input_ids, attention_mask)          # the encoder without HF's blocking mask check
+    start = cfg.decoder_start_token_id
+    encs, masks, J = [], [], []
+    for job in jobs:
+        list_of_decoded = job["keys"]
+        if job.get("inputs") is None:
+            batch_in = [[cfg.bos_token_id, cfg.eos_token_id]] * len(list_of_decoded)
         else:
-            enc = model.model.encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
-    start, npre = cfg.decoder_start_token_id, len(prefix)
-    seqs = [[tuple(list(prefix) + list(strip(list(key), strip_from_bos, strip_from_eos))) for key in keys] for keys in decoded]
-    scores = [[0.0] * len(ss) for ss in seqs]
+            batch_in = [list(i) for i in job["inputs"]]
+        decoded = [[x[1] if isinstance(x[0], float) else x for x in xx] for xx in list_of_decoded]
+        if job.get("encoded") is not None:
+            # (encoder states, attention mask) of exactly these inputs from an earlier pass of the same model (the searcher's
+            # decodes encode what the rescorings would encode again, retrieval.py:157-160 vs 195)
+            enc, attention_mask = job["encoded"]
+        else:
+            input_ids = _pad_batch(batch_in, cfg.pad_token_id, device)
+            attention_mask = (input_ids != cfg.pad_token_id).to(torch.uint8)
+            if device.type == "cuda":
+                enc = sd.encode(input_ids, attention_mask)          # the encoder without HF's blocking mask check
+            else:
+                enc = model.model.encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+        prefix = list(job.get("prefix") or [])
+        sfb, sfe = job.get("strip_from_bos") or [], job.get("strip_from_eos") or []
+        seqs = [[tuple(prefix + list(strip(list(key), sfb, sfe))) for key in keys] for keys in decoded]
+        encs.append(enc); masks.append(attention_mask.to(torch.uint8))
+        J.append(dict(decoded=decoded, seqs=seqs, npre=len(prefix), scores=[[0.0] * len(ss) for ss in seqs], totals=[],
+                      lp=job.get("length_penalty", 0.0), bias=job.get("logit_bias"), first=sum(len(x["seqs"]) for x in J)))
+    if len(jobs) == 1:
+        enc, attention_mask = encs[0], masks[0]
+    else:
+        S = max(e.shape[1] for e in encs)
+        enc = torch.cat([torch.nn.functional.pad(e, (0, 0, 0, S - e.shape[1])) for e in encs])
+        attention_mask = torch.cat([torch.nn.functional.pad(m, (0, S - m.shape[1])) for m in masks])
+    logit_bias = None
+    if any(j["bias"] is not None for j in J):
+        V = next(j["bias"] for j in J if j["bias"] is not None).shape[-1]
+        logit_bias = torch.cat([j["bias"] if j["bias"] is not None else torch.zeros(len(j["seqs"]), V, dtype=enc.dtype, device=device)
+                                for j in J])
     # whole queries per forward; the sum of their key lengths, an upper bound of the nodes (typically 3x), stays below `cap`
     # (the logits are nodes x vocab floats)
     cap = int(os.environ.get("SEAL_RESCORE_NODES", 12000))
-    totals = []
-    max_len = max((len(sq) for ss in seqs for sq in ss), default=0)
+    max_len = max((len(sq) for j in J for ss in j["seqs"] for sq in ss), default=0)
     prepared = None
     if enc.is_cuda and max_len > 0 and sd.can_teacher_force(enc, max_len):
         prepared = sd.teacher_prepare(enc, attention_mask)
-
-    # chunks of whole queries: the sum of key lengths bounds a chunk's nodes from above (typically 3x)
+    units = [(ji, qi) for ji, j in enumerate(J) for qi in range(len(j["seqs"]))]          # job-major: a job's keys stay contiguous
     groups, cur, cur_n = [], [], 0
-    for qi, ss in enumerate(seqs):
-        n = sum(len(sq) for sq in ss if len(sq) > npre)
+    for ji, qi in units:
+        n = sum(len(sq) for sq in J[ji]["seqs"][qi] if len(sq) > J[ji]["npre"])
         if cur and cur_n + n > cap:
             groups.append(cur); cur, cur_n = [], 0
-        cur.append(qi); cur_n += n
+        cur.append((ji, qi)); cur_n += n
     if cur:
         groups.append(cur)
     for group in groups:
-        items = [(qi, ki, 0, sq) for qi in group for ki, sq in enumerate(seqs[qi]) if len(sq) > npre]
+        items = [(ji, qi, ki, sq) for ji, qi in group for ki, sq in enumerate(J[ji]["seqs"][qi]) if len(sq) > J[ji]["npre"]]
         if not items:
             continue
-        tree = _prefix_tree([it[0] for it in items], [it[3] for it in items], npre, start)
+        tree = _prefix_tree([J[ji]["first"] + qi for ji, qi, _, _ in items], [sq for _, _, _, sq in items],
+                            np.fromiter((J[ji]["npre"] for ji, _, _, _ in items), dtype=np.int64, count=len(items)), start)
         packed = _h2d(np.stack([tree["tok"], tree["depth"], tree["query"]]), device)
         anc_d = _h2d(tree["anc"], device)
         logits = sd.tree_logits(packed[0], packed[1], anc_d, packed[2], enc, attention_mask, prepared)
@@ -338,8 +389,15 @@ def _rescore_keys_tree(model, inputs, list_of_decoded, batch_size, length_penalt
         lp = torch.where(t[1] < 2, torch.zeros_like(lp), lp)
         table = torch.zeros(len(items), tree["width"], dtype=torch.float64, device=device)
         table[t[2], t[3]] = lp
-        totals.append((items, table.sum(-1).float()))
-    return _PendingRescore(totals, scores, decoded, length_penalty)
+        total = table.sum(-1).float()
+        a = 0
+        while a < len(items):                                           # the group's keys, job by job
+            b = a
+            while b < len(items) and items[b][0] == items[a][0]:
+                b += 1
+            J[items[a][0]]["totals"].append(([(qi, ki, 0, sq) for _, qi, ki, sq in items[a:b]], total[a:b]))
+            a = b
+    return [_PendingRescore(j["totals"], j["scores"], j["decoded"], j["lp"]) for j in J]
 
 
 class _PendingRescore:

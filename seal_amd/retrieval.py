@@ -311,28 +311,34 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
         if code_keys is not None:
             code_keys = next(it)
     marked_rescoring = s.rescore and s.use_markers
+    # the rescorings of the batch (retrieval.py:93-100, 139-149, 193-203, 249-263): the jobs of one model share one forward
     body_job = cand_job = title_job = code_job = None
+    jobs, slots = [], []
     if s.decode_body and marked_rescoring:
-        body_job = rk.rescore_keys(
-            s.bart_model, base_tokens, found_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
-            strip_from_eos=[s.title_eos_token_id, s.code_eos_token_id, s.bart_model.config.eos_token_id], logit_bias=bias, pending=True)
+        jobs.append((s.bart_model, base_tokens, found_keys, dict(
+            length_penalty=0.0, strip_from_bos=bos_strip,
+            strip_from_eos=[s.title_eos_token_id, s.code_eos_token_id, s.bart_model.config.eos_token_id], logit_bias=bias)))
+        slots.append("body")
     if cand is not None:
         _, toks = marked("body")
         last_input_tokens = toks                # the reference re-binds `input_tokens` here (retrieval.py:139)
         # same encoder input as the body decode (' || body || +'): its encoder states are reused where there are any
         reuse = (body.enc, body.attention_mask) if (tokenised and body is not None and body.enc is not None) else None
-        cand_job = rk.rescore_keys(s.bart_model, toks, cand, batch_size=100, length_penalty=0.0, logit_bias=bias, encoded=reuse,
-                                   pending=True)
+        jobs.append((s.bart_model, toks, cand, dict(length_penalty=0.0, logit_bias=bias, encoded=reuse)))
+        slots.append("cand")
     if title_keys is not None and marked_rescoring:
-        title_job = rk.rescore_keys(
-            s.bart_title_model, title_toks, title_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
-            strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=bias,
-            encoded=(titles.enc, titles.attention_mask) if tokenised and titles.enc is not None else None, pending=True)
+        jobs.append((s.bart_title_model, title_toks, title_keys, dict(
+            length_penalty=0.0, strip_from_bos=bos_strip, strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=bias,
+            encoded=(titles.enc, titles.attention_mask) if tokenised and titles.enc is not None else None)))
+        slots.append("title")
     if code_keys is not None and marked_rescoring:     # retrieval.py:249-263
-        code_job = rk.rescore_keys(
-            s.bart_code_model, code_toks, code_keys, batch_size=100, length_penalty=0.0, strip_from_bos=bos_strip,
-            strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=bias,
-            encoded=(codes.enc, codes.attention_mask) if tokenised and codes.enc is not None else None, pending=True)
+        jobs.append((s.bart_code_model, code_toks, code_keys, dict(
+            length_penalty=0.0, strip_from_bos=bos_strip, strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=bias,
+            encoded=(codes.enc, codes.attention_mask) if tokenised and codes.enc is not None else None)))
+        slots.append("code")
+    if jobs:
+        pend = dict(zip(slots, rk.rescore_keys_multi(jobs, pending=True)))
+        body_job, cand_job, title_job, code_job = pend.get("body"), pend.get("cand"), pend.get("title"), pend.get("code")
     yield "rescoring"                            # everything of this batch up to the scores is enqueued; nothing read back yet
     if body_job is not None:
         found_keys = body_job.result()

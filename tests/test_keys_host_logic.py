@@ -253,3 +253,35 @@ def test_prefix_tree_equals_a_dictionary_built_forest(npre):
         assert (k, c, tok) == (ek, ec, etok)
         assert prefix_of[node] == (key_query[k], key_seqs[k][:c + npre])
     assert t["width"] == max(1, max(len(k) for k in key_seqs) - npre)
+
+
+def test_rescore_keys_multi_equals_separate_calls():
+    """jobs with different encoder inputs (and lengths), prefixes and strip lists through ONE forest / one forward: each
+    job's scores equal its own rescore_keys call (and the reference's one row per key)"""
+    import torch
+    from seal_amd.keys import rescore_keys, rescore_keys_multi
+    from tests.helpers import tiny_bart
+    m = tiny_bart(120)
+    rng = np.random.default_rng(1)
+
+    def some_keys(nq):
+        out = []
+        for _ in range(nq):
+            base = rng.integers(4, 118, size=6).tolist()
+            other = rng.integers(4, 118, size=4).tolist()
+            kk = [base[:i] for i in range(1, 7)] + [other[:i] for i in range(1, 5)] + [[2] + base[:2], base[:3] + [2]]
+            out.append([(-1.0, k) for k in kk])
+        return out
+    jobs = [
+        (m, [[0] + rng.integers(4, 118, size=5).tolist() + [2] for _ in range(3)], some_keys(3), dict(strip_from_bos=[2], strip_from_eos=[2])),
+        (m, [[0] + rng.integers(4, 118, size=9).tolist() + [2] for _ in range(3)], some_keys(3), dict(prefix=[5])),
+        (m, [[0] + rng.integers(4, 118, size=2).tolist() + [2] for _ in range(2)], some_keys(2), dict(logit_bias=torch.randn(2, 120))),
+    ]
+    multi = rescore_keys_multi(jobs)
+    for (model, inputs, keys, kw), got in zip(jobs, multi):
+        for share in (True, False):
+            want = rescore_keys(model, inputs, keys, batch_size=4, share_prefixes=share, **kw)
+            for qa, qb in zip(got, want):
+                assert [k for _, k in qa] == [k for _, k in qb]
+                for (sa, _), (sb, _) in zip(qa, qb):
+                    assert abs(sa - sb) <= 2e-5 * max(1.0, abs(sb)), (kw, share)
