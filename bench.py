@@ -144,7 +144,7 @@ def build_cpu_oracle(index, threads):
     orc_lib().orc_set_threads(threads)
     n = index.size()
     sa = device_array(index, "sa_lo", "<i4")
-    assert device_array(index, "sa_hi", "|u1") is None
+    sa_hi = device_array(index, "sa_hi", "|u1")           # bits 32..39 of the suffix array above 2^32 rows (KILT size)
     text = device_array(index, "text", "<i2" if index_sym_bytes(index) == 2 else "<i4")
     bwt = np.empty(n, dtype=np.uint32)
     isa_s = torch.zeros(n // 64 + 1, dtype=torch.int64, device=sa.device)
@@ -152,13 +152,18 @@ def build_cpu_oracle(index, threads):
     for a in range(0, n, CH):
         b = min(n, a + CH)
         pos = sa[a:b].long() & 0xFFFFFFFF
+        if sa_hi is not None:
+            pos |= sa_hi[a:b].long() << 32
         prev = torch.where(pos == 0, torch.full_like(pos, n - 1), pos - 1)
         sym = text[prev].to(torch.int32) & (0xFFFF if text.dtype == torch.int16 else 0x7FFFFFFF)
         bwt[a:b] = sym.cpu().numpy().astype(np.uint32)
         m = (pos & 63) == 0
         isa_s[pos[m] >> 6] = torch.arange(a, b, device=sa.device)[m]
         del pos, prev, sym, m
-    sa_s = (sa[::32].long() & 0xFFFFFFFF).cpu().numpy().astype(np.uint64)
+    sa_s = sa[::32].long() & 0xFFFFFFFF
+    if sa_hi is not None:
+        sa_s |= sa_hi[::32].long() << 32
+    sa_s = sa_s.cpu().numpy().astype(np.uint64)
     orc = CppFMIndex()
     orc.initialize_from_bwt(bwt, sa_s, isa_s.cpu().numpy().astype(np.uint64))
     return orc
@@ -272,6 +277,114 @@ def parity_check(index, trace, answers, vocab=VOCAB):
             "against": "oracle/fm_oracle.c (sdsl-style wt_int + rank_support_v, SA/32, ISA/64) built from this index's BWT"}
 
 
+def _suffix_positions(index, rows):
+    """SA[rows] as int64, straight from the index's resident suffix array (32 low bits + 8 high bits above 2^32 rows)"""
+    sa_lo = device_array(index, "sa_lo", "<i4")
+    sa_hi = device_array(index, "sa_hi", "|u1")
+    pos = sa_lo[rows].long() & 0xFFFFFFFF
+    if sa_hi is not None:
+        pos |= sa_hi[rows].long() << 32
+    return pos
+
+
+def sa_audit(index, n_pairs=1 << 20, seed=7):
+    """An audit of the GPU-BUILT index that does not go through anything the builder produced except the arrays under test
+    (the NQ-scale oracle of ``build_cpu_oracle`` is fed this index's own BWT and SA samples, so it cannot see a mis-sorted
+    suffix array): (1) ``n_pairs`` random adjacent row pairs: text[SA[i]:] < text[SA[i+1]:] by direct symbol-by-symbol
+    comparison on the device; (2) sum(SA) == n(n-1)/2 (with (1): a permutation); (3) for ``n_pairs`` random rows i: one
+    backward-search step with symbol text[SA[i]-1] from [i, i] must land on the single row j with SA[j] == SA[i]-1, i.e.
+    BWT[i] == text[SA[i]-1] as the wavelet matrix sees it and LF(i) per C[] + rank are consistent with the suffix array."""
+    import ctypes
+    from seal_amd._lib import check, lib
+    n = index.size()
+    text = device_array(index, "text", "<i2" if index_sym_bytes(index) == 2 else "<i4")
+    mask = 0xFFFF if text.dtype == torch.int16 else 0x7FFFFFFF
+    dev = text.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    t0 = time.perf_counter()
+    rows = torch.randint(0, n - 1, (n_pairs,), generator=g, device=dev)
+    pa, pb = _suffix_positions(index, rows), _suffix_positions(index, rows + 1)
+    ok = torch.zeros(n_pairs, dtype=torch.bool, device=dev)
+    idx = torch.arange(n_pairs, device=dev)
+    d, max_lcp = 0, 0
+    while idx.numel():
+        inside = (pa + d < n) & (pb + d < n)               # two distinct suffixes differ before either ends (unique sentinel)
+        idx, pa, pb = idx[inside], pa[inside], pb[inside]
+        a, b = text[pa + d].long() & mask, text[pb + d].long() & mask
+        diff = a != b
+        ok[idx[diff]] = a[diff] < b[diff]
+        keep = ~diff
+        idx, pa, pb = idx[keep], pa[keep], pb[keep]
+        d += 1
+        if idx.numel():
+            max_lcp = d
+    order_bad = int((~ok).sum())
+    # (2) permutation checksum
+    sa_lo = device_array(index, "sa_lo", "<i4")
+    sa_hi = device_array(index, "sa_hi", "|u1")
+    tot = 0
+    CH = 1 << 28
+    for a0 in range(0, n, CH):
+        tot += int((sa_lo[a0:a0 + CH].long() & 0xFFFFFFFF).sum())
+        if sa_hi is not None:
+            tot += int(sa_hi[a0:a0 + CH].long().sum()) << 32
+    sum_ok = tot == n * (n - 1) // 2
+    # (3) BWT / LF consistency through the product's own backward-search step
+    rows = torch.randint(0, n, (n_pairs,), generator=g, device=dev)
+    p = _suffix_positions(index, rows)
+    prev = torch.where(p == 0, torch.full_like(p, n - 1), p - 1)
+    sym = (text[prev].long() & mask).contiguous()
+    lo_out, hi_out = torch.empty_like(rows), torch.empty_like(rows)
+    check(lib().fmi_dev_bs_step(index.handle, torch.cuda.current_stream(dev).cuda_stream, n_pairs, sym.data_ptr(), rows.data_ptr(), rows.data_ptr(),
+                                lo_out.data_ptr(), hi_out.data_ptr()))
+    torch.cuda.synchronize()
+    single = lo_out == hi_out
+    lf_bad = int((~single).sum()) + int((_suffix_positions(index, lo_out[single]) != prev[single]).sum())
+    return {"adjacent_suffix_pairs": n_pairs, "suffix_order_violations": order_bad, "longest_common_prefix_seen": max_lcp,
+            "sum_of_sa_is_n_choose_2": bool(sum_ok), "lf_rows": n_pairs, "bwt_lf_violations": lf_bad,
+            "mismatches": order_bad + lf_bad + (0 if sum_ok else 1), "seconds": round(time.perf_counter() - t0, 2),
+            "against": "direct comparison of text[SA[i]:] and text[SA[i+1]:] on the device; SA[LF(i)] == SA[i]-1 through fmi_dev_bs_step"}
+
+
+def score_parity(searcher, model, index, queries, bias, dev, n_rescore_queries=4, tol=1e-4):
+    """The float half of parity at the bench's own geometry (BART-large, beam 15, batch 20): the body and title decodes of one
+    batch are run once more exactly as the searcher issues them (retrieval.py:70-83,162-176), every hypothesis score the beam
+    loop recorded is recomputed through HF's own cache-free fp32 forward (oracle/hf_scores.py), and the prefix-tree
+    rescoring of a sample of the body keys is held to one HF row per key (reference keys.py:64-141)."""
+    from oracle.hf_scores import compare_beam_history, compare_rescoring
+    from seal_amd.beam_search import fm_index_generate
+    from seal_amd.keys import _pad_batch
+    s = searcher
+    cfg = model.config
+    mk = s.marker_token_ids
+    out = {}
+    body_hyps = body_toks = None
+    for name, kind, kw in (("beam_scores_body", "body", dict(min_length=s.length, max_length=s.length)),
+                           ("beam_scores_title", "title", dict(min_length=1, max_length=15, force_decoding_from=[s.title_bos_token_id],
+                                                               eos_token_id=s.title_eos_token_id))):
+        toks = [q[:-1] + mk[kind] + mk["+"] + q[-1:] for q in queries]
+        enc_ids = _pad_batch(toks, cfg.pad_token_id, dev)
+        enc_mask = (enc_ids != cfg.pad_token_id).long()
+        pg = fm_index_generate(model, index, enc_ids, enc_mask, length_penalty=s.length_penalty, num_beams=s.beam, keep_history=True,
+                               logit_bias=bias, pending=True, **kw)
+        steps, final, B, K, _ = pg._args
+        assert model._seal_step_decoder._st.fused, "the fused step decoder must be the one that ran"
+        out[name] = compare_beam_history(model, enc_ids, enc_mask, steps, final, B, K, logit_bias=bias, tol=tol)
+        if kind == "body":
+            body_hyps, body_toks = pg.result(), toks
+    nq = min(n_rescore_queries, len(queries))
+    strip_ids = s.strip_token_ids
+    keys = []
+    for h in body_hyps[:nq]:
+        kk = [(sc, k[1:] if k[0] in strip_ids else k) for sc, k in h if k]
+        keys.append([(sc, k) for sc, k in kk if k])
+    out["rescore_scores"] = compare_rescoring(model, [q for q in queries[:nq]], keys, tol=tol, length_penalty=0.0, logit_bias=bias[:nq],
+                                              strip_from_bos=[s.title_bos_token_id, s.code_bos_token_id, cfg.decoder_start_token_id],
+                                              strip_from_eos=[s.title_eos_token_id, s.code_eos_token_id, cfg.eos_token_id])
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -311,6 +424,10 @@ def main():
     host_threads = max(1, min(8, cores // (2 * max(world, 1))))
     os.environ.setdefault("SEAL_HOST_THREADS", str(host_threads))
     torch.set_num_threads(max(1, min(8, cores // max(world, 1))))
+    try:
+        log("host memory: " + next(l for l in open("/proc/meminfo") if l.startswith("MemTotal")).strip())
+    except Exception:
+        pass
     log(f"host: {cores} cores / {world} rank(s): {os.environ['SEAL_HOST_THREADS']} key-scoring threads, {torch.get_num_threads()} torch CPU threads per rank")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -343,7 +460,13 @@ def main():
     index = FMIndex()
     index.initialize_from_device(data, beg.tolist())
     index.labels = None
-    del data
+    # the index's resident text must be the corpus it was given (+ the sentinel): what sa_audit compares suffixes of
+    _text = device_array(index, "text", "<i2" if index_sym_bytes(index) == 2 else "<i4")
+    text_is_input = bool(_text[-1] == 0)
+    for a0 in range(0, data.numel(), 1 << 28):
+        b0 = min(data.numel(), a0 + (1 << 28))
+        text_is_input &= bool(torch.equal(_text[a0:b0].to(torch.int32) & (0xFFFF if _text.dtype == torch.int16 else 0x7FFFFFFF), data[a0:b0]))
+    del data, _text
     torch.cuda.empty_cache()
     log(f"index: n={index.size()} levels={lib().fmi_levels(index.handle)} HBM={index.device_bytes() / 2**30:.1f} GiB "
         f"built on GPU in {time.perf_counter() - t0:.1f}s")
@@ -611,6 +734,29 @@ def main():
         parity["by_kind"]["aggregated_documents_scores_and_keys"] = {"ops": len(agg_calls), "values": n_docs_cmp, "mismatches": n_bad,
                                                                       "against": "fmi_first_stage + fmi_full_score (host float64 routines) on the same keys"}
         log(f"aggregation parity: {n_docs_cmp} ranked documents vs the host routines in {time.perf_counter() - t0:.1f}s, {n_bad} mismatches")
+        # the suffix array itself, independently of the builder (the oracle above is fed this index's own BWT / SA samples)
+        audit = sa_audit(index)
+        audit["text_equals_input_corpus"] = text_is_input
+        audit["mismatches"] += 0 if text_is_input else 1
+        parity["by_kind"]["suffix_array_audit"] = audit
+        parity["ops"] += 3; parity["values_compared"] += audit["adjacent_suffix_pairs"] + audit["lf_rows"]; parity["mismatches"] += audit["mismatches"]
+        log(f"suffix array audit: {audit}")
+        # the float half: every recorded hypothesis score of this batch's two decodes, and a sample of its rescoring scores,
+        # against HF's own fp32 forward at this geometry (north_star: beam scores within 1e-4)
+        t0 = time.perf_counter()
+        lo_q = (args.warmup + args.steps) * args.batch
+        sp = score_parity(searcher, model, index, queries[lo_q:lo_q + args.batch], bias[lo_q:lo_q + args.batch], dev)
+        beam = {"values": sum(sp[k]["values"] for k in ("beam_scores_body", "beam_scores_title")),
+                "max_abs_err": max(sp[k]["max_abs_err"] for k in ("beam_scores_body", "beam_scores_title")), "tol": 1e-4,
+                "mismatches": sum(sp[k]["violations"] for k in ("beam_scores_body", "beam_scores_title")),
+                "body": sp["beam_scores_body"], "title": sp["beam_scores_title"], "against": sp["beam_scores_body"]["against"]}
+        parity["by_kind"]["beam_scores"] = beam
+        rs = sp["rescore_scores"]
+        parity["by_kind"]["rescore_scores"] = {**rs, "mismatches": rs["violations"]}
+        parity["ops"] += 3; parity["values_compared"] += beam["values"] + rs["values"]
+        parity["mismatches"] += beam["mismatches"] + rs["violations"]
+        log(f"score parity vs HF fp32 forward in {time.perf_counter() - t0:.1f}s: beam scores {beam['values']} values, max abs err "
+            f"{beam['max_abs_err']:.2e}; rescoring {rs['values']} values, max abs err {rs['max_abs_err']:.2e} (tol 1e-4)")
         log(f"parity_check: {parity['ops']} ops, {parity['values_compared']} values, {parity['mismatches']} mismatches")
         t_cpu = rep["mask_s"] + rep["ranges_s"] + rep["locate_s"] + rep["docs_s"]
         cpu = {"value": round(args.batch / t_cpu, 3), "unit": "queries/s (FM-index path only)", "cores": threads, "kind": "port",
@@ -626,7 +772,7 @@ def main():
         "value": round(total_q / elapsed, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed * 1e3 / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"configs[1]: NQ-shaped synthetic FM-index ({args.docs} passages, {index.size()} symbols{', phrase corpus P=%d' % args.corpus_phrases if args.corpus_phrases else ''}), random-init "
+        "config": {"workload": f"{'configs[3]: KILT-size' if args.docs >= 30_000_000 else 'configs[1]: NQ-shaped'} synthetic FM-index ({args.docs} passages, {index.size()} symbols{', phrase corpus P=%d' % args.corpus_phrases if args.corpus_phrases else ''}), random-init "
                                f"BART-large fp32, beam={args.beam}, batch={args.batch} per GPU, body len 10 + title len<=15, "
                                f"{'first-stage retrieval' if args.first_stage_only else 'first stage + full-document rescoring of 1500 docs/query'}, top-{args.topk}",
                    "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated; " + ("next batch's decodes enqueued ahead of this batch's rescoring/aggregation (2 streams)" if not args.no_overlap and args.pipeline <= 1 else f"{args.pipeline} query batches in flight per GPU"), "model_arithmetic": "fp32 (as the reference runs BART)",

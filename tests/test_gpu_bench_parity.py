@@ -45,3 +45,27 @@ def test_bench_parity_check_passes_on_a_real_batch_and_catches_a_corrupted_answe
     par = bench.parity_check(ix, trace, answers, vocab=vocab)
     assert par["by_kind"]["located_positions_and_doc_ids"]["mismatches"] == 1
     assert par["by_kind"]["allowed_token_sets"]["mismatches"] == 1
+
+
+def test_suffix_array_audit_passes_and_catches_a_missorted_suffix_array():
+    """bench.py's builder-independent audit (adjacent suffixes compared symbol by symbol on the device, SA checksum, one
+    backward-search step per sampled row landing on SA[i]-1) on a GPU-built index, then on the same index with two
+    suffix-array entries swapped in place"""
+    import bench
+    from seal_amd import FMIndex
+    dev = torch.device("cuda:0")
+    data, beg, _, _ = bench.synth_corpus(400, dev, seed=0, phrases=300)
+    ix = FMIndex()
+    ix.initialize_from_device(data, beg.tolist())
+    rep = bench.sa_audit(ix, n_pairs=1 << 17)
+    assert rep["mismatches"] == 0 and rep["sum_of_sa_is_n_choose_2"] and rep["longest_common_prefix_seen"] >= 2, rep
+    sa = bench.device_array(ix, "sa_lo", "<i4")
+    i = ix.size() // 2
+    a, b = int(sa[i]), int(sa[i + 1])
+    sa[i], sa[i + 1] = b, a
+    torch.cuda.synchronize()
+    bad = bench.sa_audit(ix, n_pairs=1 << 19)
+    assert bad["suffix_order_violations"] >= 1 and bad["bwt_lf_violations"] >= 1 and bad["sum_of_sa_is_n_choose_2"], bad
+    sa[i] = a                                        # a duplicated entry: the checksum must notice
+    torch.cuda.synchronize()
+    assert not bench.sa_audit(ix, n_pairs=1 << 12)["sum_of_sa_is_n_choose_2"]
