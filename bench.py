@@ -429,6 +429,17 @@ def main():
     except Exception:
         pass
     log(f"host: {cores} cores / {world} rank(s): {os.environ['SEAL_HOST_THREADS']} key-scoring threads, {torch.get_num_threads()} torch CPU threads per rank")
+    if world > 1 and hasattr(os, "sched_setaffinity"):
+        # one rank per GPU on a shared host: every rank keeps to its own contiguous share of the cores (python thread,
+        # key-scoring threads, torch CPU threads), so that 8 ranks do not migrate over each other's caches / NUMA nodes
+        avail = sorted(os.sched_getaffinity(0))
+        per = max(1, len(avail) // world)
+        mine = avail[(local % world) * per:(local % world + 1) * per] or avail
+        try:
+            os.sched_setaffinity(0, mine)
+            log(f"rank 0 of {world}: pinned to cores {mine[0]}..{mine[-1]} ({len(mine)} of {len(avail)})")
+        except OSError:
+            pass
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dist = bool(os.environ.get("SEAL_BENCH_FORCE_DIST"))     # exercise the RCCL path with one rank
@@ -551,6 +562,12 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    import resource
+    peak_rss_gib = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20        # this rank's peak host RSS so far (KiB -> GiB)
+    if use_dist:
+        t = torch.tensor([peak_rss_gib], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        peak_rss_gib = float(t.item())
     xstats = [0, 0, 0, 0]
     _p, _l, _k = read_counters(xstats)
     probes, launches, kms = ctypes.c_uint64(_p), ctypes.c_uint64(_l), ctypes.c_double(_k)
@@ -675,15 +692,24 @@ def main():
     traffic = traffic_src = None
     try:
         import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size.json")), reverse=True):
+        import hashlib
+        csrc = os.path.join(ROOT, "seal_amd", "csrc")
+        now = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("fmi_kernels.hip", "fmi_device.h", "fmi_internal.h"))).hexdigest()
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size.json")), reverse=True)
+        for f in files:
             pmc = json.load(open(f))
+            if pmc.get("_kernel_source_sha256") != now:
+                continue            # counters of another kernel generation are REFUSED (the file records the source it profiled)
             kib = sum(v["FETCH_SIZE"]["avg"] for k, v in pmc.items() if k.startswith("void k_constrain"))
             if kib:
                 traffic = round(kib * 1024.0 * 2, 1)
-                traffic_src = {"file": os.path.relpath(f, ROOT), "commit": pmc.get("_commit")}
+                traffic_src = {"file": os.path.relpath(f, ROOT), "commit": pmc.get("_commit"), "kernel_source_sha256": now[:16]}
                 break
-    except Exception:
-        pass
+        if traffic is None:
+            traffic_src = {"refused": "no profiles/r*_pmc_fetch_size.json was taken over the current fmi_kernels.hip / fmi_device.h / fmi_internal.h "
+                                      "(sha256 %s); run tools/prof_bench.sh" % now[:16], "candidates": [os.path.relpath(f, ROOT) for f in files[:3]]}
+    except Exception as e:
+        traffic_src = {"error": repr(e)}
     nl = max(1, launches.value)
     roofline = {"bound": "hbm", "kernel": "k_constrain (one constraint call = one launch: prefix range, row class and root digit per (row, top digit) "
                                           "wave, the sub-trees level by level by workgroups of 8 waves)",
@@ -785,6 +811,7 @@ def main():
         "parity_check": parity,
         "extra": {("complete_search_qps" if args.first_stage_only else "first_stage_only_qps"): None if other_qps is None else round(other_qps, 3),
                   "p50_batch_latency_ms_unpipelined": round(float(np.median(step_ms[1:] or step_ms)), 2) if step_ms else None, "docs_returned_per_query": n_found,
+                  "peak_host_rss_gib_per_rank_max": round(peak_rss_gib, 2),
                   "phase_ms_one_batch": {k: round(v, 2) for k, v in phases.items()},
                   "k_constrain_ms_one_batch": round(k2.value, 3), "k_constrain_blocks_one_batch": int(p2.value)},
     }

@@ -25,7 +25,10 @@ import torch.nn.functional as F
 
 
 import contextlib
+import logging
 import threading
+
+logger = logging.getLogger(__name__)
 
 class _CaptureGate:
     """hipGraph capture needs the GPU-issuing side of the process to itself: with two query pipelines on worker
@@ -310,6 +313,12 @@ class BartStepDecoder:
         x = self.ln_emb(x)
         fused = (self.use_fused_kernels and x.dtype == torch.float32 and dh == 64 and T <= 17 and S_pad <= 64 and x.is_cuda)
         st.fused = fused
+        if not fused and x.is_cuda and self.use_fused_kernels and not self.__dict__.get("_fallback_logged"):
+            # the limits of the fused sealnn_* step kernels, said once instead of silently running ~6x more launches
+            self._fallback_logged = True
+            logger.warning("BartStepDecoder: decode of shape (batch %d, beams %d, encoder length %d, %d positions, %s, head_dim %d) runs on the "
+                           "torch-op path: the fused step kernels need fp32, head_dim 64, <= 17 decoder positions and <= 64 encoder tokens",
+                           B, K, S_pad, T, str(x.dtype).replace("torch.", ""), dh)
         if fused:
             from ._lib import check, lib
             L_ = lib()

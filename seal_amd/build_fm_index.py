@@ -49,16 +49,30 @@ def preprocess_file(input_path: str, labels: List[str], format: str = "kilt", lo
             yield text
 
 
+_WORKER_TOKENIZE: Optional[Callable[[str], List[int]]] = None
+
+
+def _tokenize_in_worker(line: str) -> List[int]:
+    """module-level (picklable by name) entry of the tokenisation workers: the tokenizer itself -- a closure over a HF
+    tokenizer or a hub model -- is inherited through ``fork`` in ``_WORKER_TOKENIZE``, never pickled"""
+    return _WORKER_TOKENIZE(line)
+
+
 def build_index(input_path: str, tokenize: Callable[[str], List[int]], format: str = "kilt", lowercase: bool = False,
                 word_tokenize=None, include_title: bool = False, delim: str = "@@", jobs: int = 1) -> FMIndex:
+    global _WORKER_TOKENIZE
     labels: List[str] = []
     lines = preprocess_file(input_path, labels, format, lowercase, word_tokenize, include_title, delim)
     index = FMIndex()
     if jobs > 1:
         import multiprocessing
-        with multiprocessing.get_context("fork").Pool(jobs) as pool:     # tokenisation only: forked before any HIP context exists
-            sequences = pool.imap(tokenize, lines, chunksize=256)
-            index.initialize(sequences)
+        _WORKER_TOKENIZE = tokenize            # set BEFORE the fork: the children see it, nothing is pickled but the lines
+        try:
+            with multiprocessing.get_context("fork").Pool(jobs) as pool:     # tokenisation only: forked before any HIP context exists
+                sequences = pool.imap(_tokenize_in_worker, lines, chunksize=256)
+                index.initialize(sequences)
+        finally:
+            _WORKER_TOKENIZE = None
     else:
         index.initialize(tokenize(line) for line in lines)
     index.labels = labels

@@ -196,13 +196,33 @@ extern "C" int fmi_load_sdsl(fmi_t **out, const char *path, int device)
     const uint64_t sigma = c.u64();
     if (!c.ok || c.p != c.end) REFUSE("trailing or missing bytes");
     if (sigma != wt_sigma || Cv.size() != sigma + 1 || char_size == 0 || char_size > (1ull << FMI_MAX_LEVELS)) REFUSE("alphabet size");
+    // sd_vector of the occurring symbols: `wl` low bits per entry + a unary-coded high part.  Everything the decode
+    // indexes with is checked BEFORE it is used: a corrupt or crafted file must be refused, never read or written out of bounds.
+    if (wl > 63 || low.width > 63) REFUSE("alphabet low-bit width");
+    if (high.bits > 2 * (char_size + sigma) + 64) REFUSE("alphabet high-bit vector longer than its universe allows");
     std::vector<uint64_t> chars;                 // comp -> symbol
     {
+        const uint64_t n_low = wl ? low.bits / wl : 0;           // entries the low-bit vector really holds
+        const uint64_t low_words = (low.bits + 63) >> 6;
         uint64_t zeros = 0, i = 0;
         for (uint64_t b = 0; b < high.bits; b++) {
             if ((high.w[b >> 6] >> (b & 63)) & 1) {
-                const uint64_t lo = wl ? ((low.w[(i * wl) >> 6] >> ((i * wl) & 63)) | (((i * wl) & 63) + wl > 64 ? low.w[((i * wl) >> 6) + 1] << (64 - ((i * wl) & 63)) : 0)) & ((1ull << wl) - 1) : 0;
-                chars.push_back((zeros << wl) | lo);
+                if (chars.size() >= sigma) REFUSE("alphabet lists more symbols than sigma");
+                uint64_t lo = 0;
+                if (wl) {
+                    if (i >= n_low) REFUSE("alphabet high bits name more entries than the low-bit vector holds");
+                    const uint64_t bit = i * wl, w0 = bit >> 6, sh = bit & 63;
+                    lo = low.w[w0] >> sh;
+                    if (sh + wl > 64) {
+                        if (w0 + 1 >= low_words) REFUSE("alphabet low bits end inside an entry");
+                        lo |= low.w[w0 + 1] << (64 - sh);
+                    }
+                    lo &= (1ull << wl) - 1;
+                }
+                if (zeros > (char_size >> wl)) REFUSE("alphabet symbol beyond the character range");
+                const uint64_t sym = (zeros << wl) | lo;
+                if (sym >= char_size || (!chars.empty() && sym <= chars.back())) REFUSE("alphabet symbols must ascend strictly below the character range");
+                chars.push_back(sym);
                 i++;
             } else zeros++;
         }

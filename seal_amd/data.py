@@ -20,6 +20,7 @@ output   ``trec``           ``topic Q0 docid rank score tag``
 import ast
 import csv
 import json
+import re
 from enum import Enum, unique
 from typing import Dict, Iterator, List, Optional, Tuple
 
@@ -77,10 +78,14 @@ def get_query_iterator(topics_path: str, topics_format: TopicsFormat, queries_pa
                     order.append(k)
         else:
             with open(topics_path, newline="") as f:
-                for row in csv.reader(f, delimiter="\t", quoting=csv.QUOTE_NONE):
-                    if len(row) >= 2:
-                        topics[row[0]] = {"title": row[1]}
-                        order.append(row[0])
+                rows = [row for row in csv.reader(f, delimiter="\t", quoting=csv.QUOTE_NONE) if len(row) >= 2]
+            # pyserini reads .tsv topics with TsvIntTopicReader: integer topic ids (kept as strings only if some id is not one)
+            as_int = all(re.fullmatch(r"-?\d+", row[0].strip()) for row in rows)
+            for row in rows:
+                topics[int(row[0]) if as_int else row[0]] = {"title": row[1]}
+        # pyserini's QueryIterator walks sorted(topics) when the topic set has no predefined order: --debug (first 500)
+        # and --keep_samples (seed-42 shuffle of this order) then pick the same topics as the reference CLI
+        order = sorted(topics)
         return QueryIterator(topics, order, lambda t: t["title"])
     if fmt in (TopicsFormat.KILT, TopicsFormat.KILT_TEMPLATE):
         for inst in _json_lines(topics_path):

@@ -98,10 +98,13 @@ class FMIndex(_FMIndex):
         self.beginnings = [0, bwt.numel() - 1]
         self.occurring_distinct, self.occurring_counts = self.get_distinct_count(0, len(self))
         self.occurring = list(self.occurring_distinct)
+        self.__dict__.pop("_first_bits_cache", None)
 
     def _after_build(self) -> None:
         self._push_beginnings()
         self.occurring_distinct, self.occurring_counts = self.get_distinct_count(0, len(self))
+        # per-corpus caches hung on the index (the first decode step's allowed-token bitmap, beam_search.py) die with the corpus
+        self.__dict__.pop("_first_bits_cache", None)
 
     def _push_beginnings(self) -> None:
         b = np.asarray(self.beginnings, dtype=np.uint64)

@@ -17,10 +17,13 @@ class Hit:
 
 def test_topic_readers(tmp_path):
     p = tmp_path / "q.tsv"
-    p.write_text("7\twho wrote it\n9\twhen \"was\" it\n")
-    assert list(get_query_iterator(str(p), TopicsFormat.DEFAULT)) == [("7", "who wrote it"), ("9", 'when "was" it')]
+    p.write_text("9\twhen \"was\" it\n7\twho wrote it\n10\tlast\n")
+    # pyserini's default iterator: integer ids from a .tsv file, walked in sorted order (not file order, not "10" < "7")
+    assert list(get_query_iterator(str(p), TopicsFormat.DEFAULT)) == [(7, "who wrote it"), (9, 'when "was" it'), (10, "last")]
+    p.write_text("q9\tnine\nq10\tten\n")
+    assert list(get_query_iterator(str(p), TopicsFormat.DEFAULT)) == [("q10", "ten"), ("q9", "nine")]
     p = tmp_path / "q.json"
-    p.write_text(json.dumps({"a": {"title": "x y"}, "b": "z"}))
+    p.write_text(json.dumps({"b": "z", "a": {"title": "x y"}}))
     assert list(get_query_iterator(str(p), TopicsFormat("default"))) == [("a", "x y"), ("b", "z")]
     p = tmp_path / "kilt.jsonl"
     p.write_text(json.dumps({"id": "k1", "input": "q one", "meta": {"template_questions": ["tq one"]}}) + "\n\n" +
@@ -133,6 +136,27 @@ def test_corpus_preprocessing_of_the_index_builder(tmp_path):
     labels = []
     assert list(preprocess_file(str(dpr), labels, "dpr", include_title=True)) == ['Title One @@ a "quoted" passage', "Title Two @@ second passage"]
     assert labels == ["1", "2"]
+
+
+def test_index_builder_tokenises_in_worker_processes_with_a_closure_tokenizer(tmp_path, monkeypatch):
+    """``--jobs N``: make_tokenizer() returns a closure (not picklable); the workers must inherit it through fork.
+    The index itself is stubbed (no GPU here): the worker fan-out is what is under test."""
+    from seal_amd import build_fm_index as b
+
+    class Collect:
+        def initialize(self, sequences):
+            self.docs = list(sequences)
+    monkeypatch.setattr(b, "FMIndex", Collect)
+    corpus = tmp_path / "c.tsv"
+    corpus.write_text("".join(f"d{i}\tt{i}\tw{i} w{i + 1} w{i + 2}\n" for i in range(700)))
+    offset = 10
+
+    def tok(text):                                   # a local closure, like the HF / fairseq tokenizers of make_tokenizer
+        return [offset + int(w[1:]) for w in text.split() if w[0] in "tw"] + [2]
+    one = b.build_index(str(corpus), tok, include_title=True, jobs=1)
+    two = b.build_index(str(corpus), tok, include_title=True, jobs=2)
+    assert two.docs == one.docs and len(two.docs) == 700 and two.labels == one.labels == [f"d{i}" for i in range(700)]
+    assert b._WORKER_TOKENIZE is None
 
 
 @pytest.mark.gpu

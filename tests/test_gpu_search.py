@@ -211,3 +211,124 @@ def test_pipelined_batches_give_the_results_of_sequential_batches(geom, monkeypa
     assert sum(len(r) for r in base) > 30
     for key, val in out.items():
         assert val == base, key
+
+
+def _tiny_gpu_searcher(ix, model, vocab, **kw):
+    from seal_amd.retrieval import SEALSearcher
+    return SEALSearcher(ix, None, model, backbone="bart-tiny", length=6, beam=4, batch_size=2, detokenize=False,
+                        title_eos_token_id=TITLE_EOS, code_eos_token_id=vocab - 6, code_bos_token_id=TITLE_EOS,
+                        marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5]},
+                        **{"add_query_to_keys": False, **kw})
+
+
+def _short_titles(monkeypatch):
+    from seal_amd import retrieval
+    real = retrieval.fm_index_generate
+    monkeypatch.setattr(retrieval, "fm_index_generate",
+                        lambda *a, **kw: real(*a, **{**kw, "max_length": 8 if kw.get("force_decoding_from") else kw["max_length"]}))
+
+
+def test_sharded_search_over_rccl_with_one_rank_equals_the_local_search(monkeypatch):
+    """the N > 1 path as the driver's multi-GPU bench runs it -- ``sharded_batch_search``: shard, search, ONE
+    ``all_gather_into_tensor`` of [q, k, 2] float64 on the device -- on backend "nccl" (= RCCL), world size 1: the
+    collective, its device buffers and the process-group set-up are the real ones; the result must be bit-equal to the
+    plain local search"""
+    import os
+    import torch.distributed as dist
+    from seal_amd import FMIndex
+    from seal_amd.distributed import pack_topk, sharded_batch_search
+    from tests.helpers import make_docs, tiny_bart
+    from tests.test_distributed_gloo import _free_port
+    vocab = 120
+    dev = torch.device("cuda:0")
+    docs = make_docs(5, 200, vocab - 8, min_len=6, max_len=18, title_sep=TITLE_EOS)
+    ix = FMIndex()
+    ix.initialize(docs)
+    _short_titles(monkeypatch)
+    s = _tiny_gpu_searcher(ix, tiny_bart(vocab, d_model=128, heads=2).to(dev), vocab)
+    rng = np.random.default_rng(5)
+    queries = [[0] + rng.integers(4, vocab - 8, size=int(rng.integers(4, 9))).tolist() + [2] for _ in range(5)]
+    want = pack_topk(s.batch_search(queries, k=10), 10)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        got = sharded_batch_search(s, queries, k=10, device=dev)
+        assert got.is_cuda and got.shape == (5, 10, 2)
+        assert torch.equal(got.cpu(), want)
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t)                       # the bench's max-over-ranks timing collective
+        assert float(t.sum()) == 4.0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_query_longer_than_the_fused_kernels_reach_falls_back_loudly_and_ranks_the_same(monkeypatch, caplog):
+    """a query of more than 64 encoder tokens is past the fused step kernels (one lane per encoder position): the whole
+    batch then decodes through the torch-op path -- with ONE warning, not silently -- and ranks like the scalar pipeline"""
+    import logging
+    from oracle.seal_oracle import OracleFMIndex
+    from seal_amd import FMIndex
+    from tests.helpers import make_docs, tiny_bart
+    vocab = 120
+    dev = torch.device("cuda:0")
+    docs = make_docs(5, 200, vocab - 8, min_len=6, max_len=18, title_sep=TITLE_EOS)
+    ix, orc = FMIndex(), OracleFMIndex()
+    ix.initialize(docs)
+    orc.initialize(docs)
+    _short_titles(monkeypatch)
+    geom = dict(d_model=128, heads=2, max_positions=128)
+    s = _tiny_gpu_searcher(ix, tiny_bart(vocab, **geom).to(dev), vocab)
+    rng = np.random.default_rng(9)
+    queries = [[0] + rng.integers(4, vocab - 8, size=n).tolist() + [2] for n in (70, 5)]      # 76 and 11 encoder tokens with the markers
+    with caplog.at_level(logging.WARNING, logger="seal_amd.bart_decoder"):
+        got = s.batch_search(queries, k=10)
+        got2 = s.batch_search(queries, k=10)
+    assert s.bart_model._seal_step_decoder._st.fused is False
+    assert sum("torch-op path" in r.getMessage() for r in caplog.records) == 1
+    assert [[(d.idx, d.score) for d in g] for g in got] == [[(d.idx, d.score) for d in g] for g in got2]
+    want = _oracle_pipeline(tiny_bart(vocab, **geom), orc, queries, 4, 6, vocab, False)
+    for g, w in zip(got, want):
+        w_all = list(w.items())
+        groups = _tie_groups(w_all)
+        assert len(g) == min(10, len(w_all)) > 0
+        for i, d in enumerate(g):
+            assert d.idx in groups[i] and abs(d.score - w_all[i][1][0]) <= 1e-3 * max(1.0, abs(w_all[i][1][0]))
+
+
+def test_searcher_document_ids_on_a_corpus_where_ties_are_rare(monkeypatch):
+    """end-to-end document ids against the scalar pipeline at a size where equal scores are the exception: 1 500
+    documents over a 1 000-token vocabulary, the tie tolerance tightened to 1e-5 relative (fp32 model scores from two
+    devices) -- almost every rank position then admits exactly one document id"""
+    from oracle.seal_oracle import OracleFMIndex
+    from seal_amd import FMIndex
+    from tests.helpers import make_docs, tiny_bart
+    vocab = 1000
+    dev = torch.device("cuda:0")
+    docs = make_docs(21, 1500, vocab - 8, min_len=8, max_len=30, title_sep=TITLE_EOS)
+    ix, orc = FMIndex(), OracleFMIndex()
+    ix.initialize(docs)
+    orc.initialize(docs)
+    _short_titles(monkeypatch)
+    geom = dict(d_model=128, heads=2)
+    s = _tiny_gpu_searcher(ix, tiny_bart(vocab, **geom).to(dev), vocab, add_query_to_keys=True)
+    rng = np.random.default_rng(2)
+    queries = []
+    for _ in range(4):                           # queries made of corpus n-grams, so that keys are found
+        d = docs[int(rng.integers(len(docs)))]
+        a = int(rng.integers(0, max(1, len(d) - 6)))
+        queries.append([0] + d[a:a + 5] + rng.integers(4, vocab - 8, size=2).tolist() + [2])
+    got = s.batch_search(queries, k=20)
+    assert s.bart_model._seal_step_decoder._st.fused is True
+    want = _oracle_pipeline(tiny_bart(vocab, **geom), orc, queries, 4, 6, vocab, False, query_keys=True)
+    single = total = 0
+    for g, w in zip(got, want):
+        w_all = list(w.items())
+        groups = _tie_groups(w_all, rel=1e-5)
+        assert len(g) == min(20, len(w_all)) > 0
+        for i, d in enumerate(g):
+            assert d.idx in groups[i], (i, d.idx, sorted(groups[i]))
+            assert abs(d.score - w_all[i][1][0]) <= 1e-4 * max(1.0, abs(w_all[i][1][0]))
+            single += len(groups[i]) == 1
+            total += 1
+    assert single >= 0.9 * total, (single, total)

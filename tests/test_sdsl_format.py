@@ -77,6 +77,37 @@ def test_reader_refuses_files_it_cannot_vouch_for(tmp_path):
         assert b"sdsl" in lib().fmi_last_error() or b"short" in lib().fmi_last_error(), what
 
 
+def test_reader_survives_corrupted_sample_and_alphabet_sections(tmp_path):
+    """byte-level fuzz of the part of the file the reader DECODES with file-supplied sizes (SA / ISA samples, the
+    alphabet's sd_vector -- low bits, unary high bits --, C): every mutated file is either refused or loads as an index of
+    the original size; none may crash the process or index out of bounds (the alphabet decode checks every entry: strictly
+    ascending symbols below the character range, no more entries than the low-bit vector holds)"""
+    orc = OracleFMIndex()
+    orc.initialize(make_docs(2, 40, 300, min_len=3, max_len=12))
+    path = str(tmp_path / "ref.fmi")
+    orc.save_sdsl(path)
+    raw = open(path, "rb").read()
+    rng = np.random.default_rng(0)
+    tail = len(raw) * 2 // 5
+    refused = loaded = 0
+    for trial in range(400):
+        blob = bytearray(raw)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = len(raw) - 1 - int(rng.integers(0, tail))
+            blob[pos] = int(rng.integers(0, 256)) if trial % 2 else blob[pos] ^ (1 << int(rng.integers(0, 8)))
+        p = str(tmp_path / "fuzz.fmi")
+        open(p, "wb").write(bytes(blob))
+        h = ctypes.c_void_p()
+        rc = lib().fmi_load(ctypes.byref(h), p.encode(), -1)
+        if rc == 0:
+            loaded += 1
+            assert lib().fmi_size(h) == orc.size()
+            lib().fmi_free(h)
+        else:
+            refused += 1
+    assert refused > 200 and refused + loaded == 400
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [0, 1])
 def test_index_loaded_from_an_sdsl_file_answers_like_the_oracle(seed, tmp_path):

@@ -12,4 +12,10 @@ for r in rows:
 out = {}
 for k, cs in acc.items():
     out[k] = {c: {"launches": len(v), "sum": sum(v), "avg": sum(v) / len(v)} for c, v in cs.items()}
+# what the counters were taken over: bench.py only uses a traffic figure whose kernel source is the one it is running
+import hashlib
+import os
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out["_kernel_source_sha256"] = hashlib.sha256(b"".join(open(os.path.join(root, "seal_amd", "csrc", f), "rb").read()
+                                                       for f in ("fmi_kernels.hip", "fmi_device.h", "fmi_internal.h"))).hexdigest()
 json.dump(out, sys.stdout, indent=1)
