@@ -210,6 +210,23 @@ int fmi_dev_constrained_topk_step(fmi_t *h, void *stream, uint64_t batch, uint64
                                   void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc,
                                   uint64_t state_tag, const int64_t *d_parent_rows);
 
+/* The same step for SEVERAL decodes that advance in lockstep as one loop (the searcher's body decode,
+ * retrieval.py:70-83, and title decode, retrieval.py:162-176, of one batch of queries: their rows stacked,
+ * 2 * batch * beams rows per model step instead of two loops of batch * beams): group g = the next
+ * group_batch[g] queries (x beams rows) with its own end-of-sequence token group_eos[g] and forced prefix
+ * (group_force[g * 8 ..], group_n_force[g] tokens; with ONE group: group_force[0 ..]).  1 <= n_groups <= 3;
+ * pad / stop_at_count / always_allow_eos are shared.  Every row's mask is the one fmi_dev_constrained_topk_step
+ * computes for it with its group's arguments, and every query's top-2K likewise: the call is ONE constraint
+ * launch over all rows.  A later call of the same loop may hold fewer rows (finished decodes dropped):
+ * d_parent_rows[] then still names rows of the previous call. */
+int fmi_dev_constrained_topk_groups(fmi_t *h, void *stream, uint64_t n_groups, const uint64_t *group_batch,
+                                    const int64_t *group_eos, const int64_t *group_force, const uint64_t *group_n_force,
+                                    uint64_t beams, uint64_t cur_len, const int64_t *d_input_ids, const float *d_logits,
+                                    const float *d_beam_scores, uint64_t vocab, int64_t shift, int64_t pad_id,
+                                    int64_t stop_at_count, int always_allow_eos, const uint32_t *d_first_bits,
+                                    void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc,
+                                    uint64_t state_tag, const int64_t *d_parent_rows);
+
 /* fmi_dev_allowed_bits with the continuity contract of fmi_dev_constrained_topk_step (state_tag / d_parent_rows:
  * the rows extend, by one token, rows d_parent_rows[] of the previous call with the same tag, so the prefix range
  * advances by ONE backward-search step).  d_bits == NULL: the bitmap is written to the index's own workspace

@@ -55,6 +55,8 @@ SIGNATURES = {
                                         _vp, _vp, _u64, _vp, _vp, _vp]),
     "fmi_dev_constrained_topk_step": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _u64, _i64, _i64, _i64, _pi64, _u64, _i64, _int,
                                              _vp, _vp, _u64, _vp, _vp, _vp, _u64, _vp]),
+    "fmi_dev_constrained_topk_groups": (_int, [_vp, _vp, _u64, _p64, _pi64, _pi64, _p64, _u64, _u64, _vp, _vp, _vp, _u64, _i64, _i64, _i64, _int,
+                                               _vp, _vp, _u64, _vp, _vp, _vp, _u64, _vp]),
     "fmi_dev_locate": (_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "fmi_dev_locate_ranges": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp, _vp]),
     "fmi_dev_get_docs": (_int, [_vp, _vp, _u64, _vp, _vp, _i64, _vp]),

@@ -531,13 +531,19 @@ __global__ __launch_bounds__(256) void k_dense_compact(const uint64_t *dense, ui
 // ---------------------------------------------------------------------------
 static constexpr int MAX_FORCE = 8;
 struct ForceFrom { int64_t tok[MAX_FORCE]; uint32_t n; };
+// Row groups: one call may serve the rows of several decodes that run in lockstep (the searcher's body and title
+// decodes as ONE loop of batch * beams * 2 rows): group g = rows [grp_first[g], grp_first[g + 1]) with its own
+// end-of-sequence token and forced prefix (reference retrieval.py:70-83 vs 162-176).  One group = the classic call.
+static constexpr int MAX_ROW_GROUPS = 3;
 
 struct ConstrainArgs {
     uint32_t rows, ndig0;          // grid = rows * ndig0 waves
     uint64_t cur_len;
     const int64_t *ids;            // [rows, cur_len]
-    int64_t shift, pad_id, eos_id;
-    ForceFrom ff;
+    int64_t shift, pad_id;
+    uint32_t grp_first[MAX_ROW_GROUPS];   // first row of group g (grp_first[0] = 0; unused groups: 0xffffffff)
+    int64_t grp_eos[MAX_ROW_GROUPS];
+    ForceFrom grp_ff[MAX_ROW_GROUPS];
     int64_t stop_at_count;
     int always_allow_eos;
     uint64_t vocab, words_per_row;
@@ -634,11 +640,17 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
     uint64_t lo = 0, hi = 0, count = 0, probes = 0;
     uint32_t model = 0;      // in nodes of the binary model: one backward-search step = `levels` nodes (2 L probes)
     bool dead = true;
+    // the row's group (wave-uniform: scalar compares on kernel arguments)
+    uint32_t grp = 0;
+#pragma unroll
+    for (int g = 1; g < MAX_ROW_GROUPS; g++) grp += r >= a.grp_first[g] ? 1u : 0u;
+    const int64_t eos_id = a.grp_eos[grp];
+    const ForceFrom &ff = a.grp_ff[grp];
     if (valid) {
         // ids / parent / the kept ranges were written by earlier launches, not by this one: constant here
         const cptr<int64_t> sent = as_const(a.ids) + (uint64_t)r * a.cur_len;
         const int64_t last = sent[a.cur_len - 1];
-        dead = last == a.eos_id || last == a.pad_id;
+        dead = last == eos_id || last == a.pad_id;
         if (!dead) {
             // get_range(force_decoding_from + sent[1:]) and get_count(... sent[1:-1])
             uint64_t l = 0, rr = ix.n;
@@ -649,12 +661,12 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
                 l = as_const(a.st_in)[2 * pr]; rr = as_const(a.st_in)[2 * pr + 1];
                 count = (rr + 1) - l;
                 bs_step(ix, (uint64_t)(last + a.shift), l, rr, l, rr, &probes);
-                model += ix.levels * (uint32_t)(a.ff.n + (a.cur_len - 1));    // the reference re-searches the whole prefix
+                model += ix.levels * (uint32_t)(ff.n + (a.cur_len - 1));    // the reference re-searches the whole prefix
             } else {
-                const uint64_t total = a.ff.n + (a.cur_len - 1);
+                const uint64_t total = ff.n + (a.cur_len - 1);
                 for (uint64_t t = 0; t < total; t++) {
                     if (t + 1 == total) count = (rr + 1) - l;
-                    const int64_t tok = t < a.ff.n ? a.ff.tok[t] : sent[1 + (t - a.ff.n)];
+                    const int64_t tok = t < ff.n ? ff.tok[t] : sent[1 + (t - ff.n)];
                     bs_step(ix, (uint64_t)(tok + a.shift), l, rr, l, rr, &probes);
                     model += ix.levels;
                 }
@@ -668,7 +680,7 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
     int64_t single = -1;
     bool expand = false;
     if (!valid) {}
-    else if (a.stop_at_count > 0 && (int64_t)count <= a.stop_at_count) single = a.eos_id;
+    else if (a.stop_at_count > 0 && (int64_t)count <= a.stop_at_count) single = eos_id;
     else if (dead) single = a.pad_id;
     else { expand = true; if (hi > ix.n) hi = ix.n; }
     if constexpr (W > 1) __syncthreads(); else wave_sync();            // bitmaps and counters zeroed
@@ -745,7 +757,7 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
         // pad / eos of the row's class: after the expansion, whose byte stores would overwrite them
         if (lane == 0) {
             if (single >= 0) set_special(ix, a, s_bits, r, d1, sub_bits, single);
-            if (a.always_allow_eos) set_special(ix, a, s_bits, r, d1, sub_bits, a.eos_id);
+            if (a.always_allow_eos) set_special(ix, a, s_bits, r, d1, sub_bits, eos_id);
         }
         wave_sync();
         EmitTarget tgt{};
@@ -1468,21 +1480,43 @@ static int launch_expand_dense(fmi *h, hipStream_t st, const ExpandItem *items, 
 
 // One constraint call = ONE launch of k_constrain.  `d_bits` = null: the workspace bitmaps, alternating
 // between calls (the kernel clears the other one); otherwise the caller's buffer, cleared here first.
+// host view of the row groups of one call (ConstrainArgs::grp_*)
+struct RowGroups {
+    uint32_t n = 1;
+    uint64_t rows[MAX_ROW_GROUPS] = {0, 0, 0};
+    int64_t eos[MAX_ROW_GROUPS] = {0, 0, 0};
+    const int64_t *force[MAX_ROW_GROUPS] = {nullptr, nullptr, nullptr};
+    uint64_t n_force[MAX_ROW_GROUPS] = {0, 0, 0};
+    static RowGroups one(uint64_t rows, int64_t eos_id, const int64_t *force_from, uint64_t n_force)
+    {
+        RowGroups g; g.rows[0] = rows; g.eos[0] = eos_id; g.force[0] = force_from; g.n_force[0] = n_force; return g;
+    }
+};
+
 static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur_len, const int64_t *d_ids,
-                             uint32_t *d_bits, uint64_t vocab, int64_t shift, int64_t pad_id, int64_t eos_id,
-                             const int64_t *force_from, uint64_t n_force, int64_t stop_at_count, int always_allow_eos,
+                             uint32_t *d_bits, uint64_t vocab, int64_t shift, int64_t pad_id, const RowGroups &rg,
+                             int64_t stop_at_count, int always_allow_eos,
                              uint64_t state_tag = 0, const int64_t *d_parent = nullptr, const uint32_t **bits_out = nullptr)
 {
     if (cur_len < 2) { fmi_set_error("cur_len must be >= 2 (cur_len == 1 is the constant occurring_distinct mask, beam_search.py:73-77)"); return FMI_ERR_ARG; }
-    if (n_force > MAX_FORCE) { fmi_set_error("force_decoding_from longer than %d", MAX_FORCE); return FMI_ERR_UNSUPPORTED; }
+    if (rg.n < 1 || rg.n > MAX_ROW_GROUPS) { fmi_set_error("1..%d row groups per call", MAX_ROW_GROUPS); return FMI_ERR_UNSUPPORTED; }
     if (rows > h->ws_rows) { int rc = fmi_dev_reserve(h, rows); if (rc) return rc; }
     const uint64_t wpr = (vocab + 31) / 32;
     ConstrainArgs a{};
     a.rows = (uint32_t)rows; a.ndig0 = top_digits(h);
     if ((rows + 8) * a.ndig0 > 0x7fffffffull) { fmi_set_error("too many rows in one call"); return FMI_ERR_CAPACITY; }
-    a.cur_len = cur_len; a.ids = d_ids; a.shift = shift; a.pad_id = pad_id; a.eos_id = eos_id;
-    a.ff.n = (uint32_t)n_force;
-    for (uint64_t i = 0; i < n_force; i++) a.ff.tok[i] = force_from[i];
+    a.cur_len = cur_len; a.ids = d_ids; a.shift = shift; a.pad_id = pad_id;
+    uint64_t first = 0;
+    for (uint32_t g = 0; g < MAX_ROW_GROUPS; g++) {
+        a.grp_first[g] = g < rg.n ? (uint32_t)first : 0xffffffffu;
+        if (g >= rg.n) continue;
+        if (rg.n_force[g] > MAX_FORCE) { fmi_set_error("force_decoding_from longer than %d", MAX_FORCE); return FMI_ERR_UNSUPPORTED; }
+        a.grp_eos[g] = rg.eos[g];
+        a.grp_ff[g].n = (uint32_t)rg.n_force[g];
+        for (uint64_t i = 0; i < rg.n_force[g]; i++) a.grp_ff[g].tok[i] = rg.force[g][i];
+        first += rg.rows[g];
+    }
+    if (first != rows) { fmi_set_error("the row groups hold %llu rows, the call %llu", (unsigned long long)first, (unsigned long long)rows); return FMI_ERR_ARG; }
     a.stop_at_count = stop_at_count; a.always_allow_eos = always_allow_eos; a.vocab = vocab; a.words_per_row = wpr;
     a.probe_counter = h->probe_count_enabled ? h->d_probe_counter : nullptr;
     // waves per workgroup: CONSTRAIN_WG waves that share their leaf-level nodes when the whole sub-tree of an item fits
@@ -1509,7 +1543,9 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     if (bits_out) *bits_out = a.bits;
     // incremental prefix state: valid when the caller vouches (tag + parent rows) that this call extends,
     // by exactly one token, the rows of the previous call with the same tag
-    const bool inc = state_tag && d_parent && h->state_tag == state_tag && h->state_rows == rows && h->state_len + 1 == cur_len;
+    // (fewer rows than the previous call: a loop over several decodes in lockstep dropped the finished ones; the parents
+    //  still name rows of the previous call, whose kept ranges are all there)
+    const bool inc = state_tag && d_parent && h->state_tag == state_tag && rows <= h->state_rows && h->state_len + 1 == cur_len;
     a.st_in = inc ? ws_state(h, h->state_flip) : nullptr;
     a.parent = d_parent;
     a.st_out = state_tag ? ws_state(h, h->state_flip ^ 1) : nullptr;
@@ -1533,8 +1569,8 @@ extern "C" int fmi_dev_allowed_bits(fmi_t *h, void *stream, uint64_t rows, uint6
 {
     int rc = need_device(h); if (rc) return rc;
     if (rows == 0) return FMI_OK;
-    return allowed_bits_impl(h, (hipStream_t)stream, rows, cur_len, d_input_ids, d_bits, vocab, shift, pad_id, eos_id,
-                             force_from, n_force, stop_at_count, always_allow_eos);
+    return allowed_bits_impl(h, (hipStream_t)stream, rows, cur_len, d_input_ids, d_bits, vocab, shift, pad_id,
+                             RowGroups::one(rows, eos_id, force_from, n_force), stop_at_count, always_allow_eos);
 }
 
 extern "C" int fmi_dev_allowed_bits_step(fmi_t *h, void *stream, uint64_t rows, uint64_t cur_len, const int64_t *d_input_ids,
@@ -1545,8 +1581,8 @@ extern "C" int fmi_dev_allowed_bits_step(fmi_t *h, void *stream, uint64_t rows, 
     int rc = need_device(h); if (rc) return rc;
     if (rows == 0) return FMI_OK;
     if ((vocab + 31) / 32 > WS_BITS_WORDS) { fmi_set_error("vocab %llu too large", (unsigned long long)vocab); return FMI_ERR_UNSUPPORTED; }
-    return allowed_bits_impl(h, (hipStream_t)stream, rows, cur_len, d_input_ids, d_bits, vocab, shift, pad_id, eos_id,
-                             force_from, n_force, stop_at_count, always_allow_eos, state_tag, d_parent_rows, d_bits_out);
+    return allowed_bits_impl(h, (hipStream_t)stream, rows, cur_len, d_input_ids, d_bits, vocab, shift, pad_id,
+                             RowGroups::one(rows, eos_id, force_from, n_force), stop_at_count, always_allow_eos, state_tag, d_parent_rows, d_bits_out);
 }
 
 extern "C" int fmi_dev_debug_timestamps(fmi_t *h, uint64_t *d_buf, uint64_t n_words)
@@ -1567,8 +1603,8 @@ extern "C" int fmi_dev_constrain_scores(fmi_t *h, void *stream, uint64_t rows, u
     if (wpr > WS_BITS_WORDS) { fmi_set_error("vocab %llu too large", (unsigned long long)vocab); return FMI_ERR_UNSUPPORTED; }
     if (rows > h->ws_rows) { rc = fmi_dev_reserve(h, rows); if (rc) return rc; }
     const uint32_t *bits = nullptr;
-    rc = allowed_bits_impl(h, (hipStream_t)stream, rows, cur_len, d_input_ids, nullptr, vocab, shift, pad_id, eos_id,
-                           force_from, n_force, stop_at_count, always_allow_eos, 0, nullptr, &bits);
+    rc = allowed_bits_impl(h, (hipStream_t)stream, rows, cur_len, d_input_ids, nullptr, vocab, shift, pad_id,
+                           RowGroups::one(rows, eos_id, force_from, n_force), stop_at_count, always_allow_eos, 0, nullptr, &bits);
     if (rc) return rc;
     hipLaunchKernelGGL(k_apply_bits, dim3(blocks_for(vocab, 256 * 4), (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
                        d_in, d_out, bits, rows, vocab, wpr);
@@ -1594,7 +1630,33 @@ extern "C" int fmi_dev_constrained_topk_step(fmi_t *h, void *stream, uint64_t ba
                                              void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc,
                                              uint64_t state_tag, const int64_t *d_parent_rows)
 {
+    return fmi_dev_constrained_topk_groups(h, stream, 1, &batch, &eos_id, force_from, &n_force, beams, cur_len, d_input_ids, d_logits,
+                                           d_beam_scores, vocab, shift, pad_id, stop_at_count, always_allow_eos, d_first_bits, d_scratch,
+                                           scratch_bytes, d_top_idx, d_top_con, d_top_unc, state_tag, d_parent_rows);
+}
+
+extern "C" int fmi_dev_constrained_topk_groups(fmi_t *h, void *stream, uint64_t n_groups, const uint64_t *group_batch,
+                                               const int64_t *group_eos, const int64_t *group_force, const uint64_t *group_n_force,
+                                               uint64_t beams, uint64_t cur_len, const int64_t *d_input_ids, const float *d_logits,
+                                               const float *d_beam_scores, uint64_t vocab, int64_t shift, int64_t pad_id,
+                                               int64_t stop_at_count, int always_allow_eos, const uint32_t *d_first_bits,
+                                               void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc,
+                                               uint64_t state_tag, const int64_t *d_parent_rows)
+{
     int rc = need_device(h); if (rc) return rc;
+    if (n_groups < 1 || n_groups > MAX_ROW_GROUPS || !group_batch || !group_eos || !group_n_force) {
+        fmi_set_error("fmi_dev_constrained_topk_groups: 1..%d groups with batch / eos / n_force arrays", MAX_ROW_GROUPS); return FMI_ERR_ARG;
+    }
+    uint64_t batch = 0;
+    RowGroups rg;
+    rg.n = (uint32_t)n_groups;
+    for (uint64_t g = 0; g < n_groups; g++) {
+        batch += group_batch[g];
+        rg.rows[g] = group_batch[g] * beams; rg.eos[g] = group_eos[g]; rg.n_force[g] = group_n_force[g];
+        // one group: the caller's array as it is (fmi_dev_constrained_topk_step); several: MAX_FORCE slots per group
+        rg.force[g] = group_force ? group_force + (n_groups == 1 ? 0 : g * MAX_FORCE) : nullptr;
+        if (group_n_force[g] && !group_force) { fmi_set_error("group %llu: n_force without tokens", (unsigned long long)g); return FMI_ERR_ARG; }
+    }
     const uint64_t rows = batch * beams, want = 2 * beams;
     if (rows == 0) return FMI_OK;
     if (want > TOPK_MAX || beams > 64) { fmi_set_error("num_beams %llu: at most %d", (unsigned long long)beams, TOPK_MAX / 2); return FMI_ERR_UNSUPPORTED; }
@@ -1611,11 +1673,11 @@ extern "C" int fmi_dev_constrained_topk_step(fmi_t *h, void *stream, uint64_t ba
     uint32_t broadcast = 0;
     if (cur_len < 2) {
         if (!d_first_bits) { fmi_set_error("cur_len == 1 needs the occurring_distinct bitmap"); return FMI_ERR_ARG; }
-        bits = d_first_bits; broadcast = 1;      // the constant first-step mask (beam_search.py:73-77)
+        bits = d_first_bits; broadcast = 1;      // the constant first-step mask (beam_search.py:73-77), the same for every group
         h->state_tag = 0;
     } else {
         if (rows > h->ws_rows) { rc = fmi_dev_reserve(h, rows); if (rc) return rc; }
-        rc = allowed_bits_impl(h, st, rows, cur_len, d_input_ids, nullptr, vocab, shift, pad_id, eos_id, force_from, n_force,
+        rc = allowed_bits_impl(h, st, rows, cur_len, d_input_ids, nullptr, vocab, shift, pad_id, rg,
                                stop_at_count, always_allow_eos, state_tag, d_parent_rows, &bits);
         if (rc) return rc;
     }
