@@ -124,7 +124,7 @@ class BartStepDecoder:
         import copy
         c = copy.copy(self)
         c.__dict__.pop("_static_cache", None)
-        c._st = None
+        c._st = c._st_root = None
         c.logit_bias = None
         return c
 
@@ -184,6 +184,8 @@ class BartStepDecoder:
             st.logits = None
             st.graph = None
             st.shape = (B, K, S_pad, T)
+            st.dropped = 0
+            st.tails = {}       # dropped leading queries -> the static state of the rest (views of these buffers; narrow())
             cache[key] = st
         return st
 
@@ -362,18 +364,94 @@ class BartStepDecoder:
         return F.linear(x, self.lm_w, self.lm_b.view(-1)).float()
 
     @torch.no_grad()
-    def start(self, enc_hidden: torch.Tensor, attention_mask: torch.Tensor, num_beams: int, max_len: int) -> None:
+    def start(self, enc_hidden: torch.Tensor, attention_mask: torch.Tensor, num_beams: int, max_len: int, narrow_plan=()) -> None:
+        """``narrow_plan``: ascending numbers of leading queries that will have left the decode at its ``narrow`` calls
+        (a loop over several decodes in lockstep drops the ones that end first): their buffers and graphs are set up here,
+        before the decode writes anything."""
+        self._dropped = 0
         if self.use_graph and enc_hidden.is_cuda:
-            return self._start_static(enc_hidden, attention_mask, num_beams, max_len)
+            return self._start_static(enc_hidden, attention_mask, num_beams, max_len, tuple(narrow_plan))
         self._st = None
         return self._start_eager(enc_hidden, attention_mask, num_beams, max_len)
 
     @torch.no_grad()
-    def _start_static(self, enc_hidden, attention_mask, num_beams, max_len):
+    def narrow(self, nq: int) -> None:
+        """the first ``nq`` queries (``nq * beams`` rows) leave the decode; the others carry on at the same position with their
+        caches where they are"""
+        if nq <= 0:
+            return
+        K = self.beams
+        self._dropped = getattr(self, "_dropped", 0) + nq
+        if getattr(self, "_st", None) is not None:
+            cur = self._st
+            nxt = self._st_root.tails[self._dropped]
+            off = (self._dropped - cur.dropped) * K
+            # ancestry of the remaining rows, re-based to the narrower view of the same cache
+            nxt.anc.copy_(cur.anc[:, off:] - off)
+            self._st = nxt
+        else:
+            self.kv = self.kv[:, :, nq * K:]
+            self.cross = [(k[nq:], v[nq:]) for k, v in self.cross]
+            self.cross_bias = self.cross_bias[nq:]
+        self.batch -= nq
+        self.rows = self.batch * K
+        if self.logit_bias is not None:
+            self.logit_bias = self.logit_bias[nq:]
+
+    def _static_tail(self, root, dropped):
+        """the static state of the last ``B - dropped`` queries of ``root``: the same caches / cross-attention tensors /
+        position counter seen from row ``dropped * K`` on (views, nothing is copied), its own token and logits buffers,
+        ancestry table and graph"""
+        st = root.tails.get(dropped)
+        if st is None:
+            B, K, S_pad, T = root.shape
+            st = self._Static()
+            R2 = (B - dropped) * K
+            dev = root.tokens.device
+            st.tokens = torch.zeros(R2, dtype=torch.long, device=dev)
+            st.t = root.t
+            st.kv = root.kv[:, :, dropped * K:]
+            st.anc = torch.arange(R2, dtype=torch.int32, device=dev).repeat(T, 1).contiguous()
+            st.fused = False
+            st.ck, st.cv, st.cbias = root.ck[:, dropped:], root.cv[:, dropped:], root.cbias[dropped:]
+            st.pos_idx = root.pos_idx
+            st.logits = None
+            st.graph = None
+            st.shape = (B - dropped, K, S_pad, T)
+            st.dropped = dropped
+            st.tails = None
+            root.tails[dropped] = st
+        return st
+
+    def _capture(self, st, dev):
+        with CAPTURE_GATE.capturing():
+            # warm up on a side stream, then capture (standard torch recipe); the cache contents
+            # written by the warm-up steps are overwritten/masked once t is reset
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    st.t.zero_()
+                    self._step_static(st)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            st.t.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # the aggregation thread may touch the GPU meanwhile
+                st.logits = self._step_static(st)
+            st.graph = g
+            st.t.zero_()
+
+    @torch.no_grad()
+    def _start_static(self, enc_hidden, attention_mask, num_beams, max_len, narrow_plan=()):
         B, S, d = enc_hidden.shape
         self.batch, self.beams, self.rows, self.max_len = B, num_beams, B * num_beams, max_len
         S_pad = max(16, (S + 15) // 16 * 16)
         st = self._static_for(B, num_beams, S_pad, max_len, enc_hidden.dtype, enc_hidden.device)
+        self._st_root = st
+        for dropped in narrow_plan:          # graphs of the narrower continuations: captured BEFORE the decode writes its caches
+            tail = self._static_tail(st, dropped)
+            if tail.graph is None:
+                self._capture(tail, enc_hidden.device)
         for li, L in enumerate(self.layers):
             kv = F.linear(enc_hidden, L["ckv_w"], L["ckv_b"]).view(B, S, 2, self.h, self.dh)
             st.ck[li, :, :, :, :S] = kv[:, :, 0].permute(0, 2, 3, 1)
@@ -384,22 +462,7 @@ class BartStepDecoder:
         self._st = st
         self.t = 0
         if st.graph is None:
-          with CAPTURE_GATE.capturing():
-            # warm up on a side stream, then capture (standard torch recipe); the cache contents
-            # written by the warm-up steps are overwritten/masked once t is reset
-            side = torch.cuda.Stream(device=enc_hidden.device)
-            side.wait_stream(torch.cuda.current_stream(enc_hidden.device))
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    st.t.zero_()
-                    self._step_static(st)
-            torch.cuda.current_stream(enc_hidden.device).wait_stream(side)
-            st.t.zero_()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # the aggregation thread may touch the GPU meanwhile
-                st.logits = self._step_static(st)
-            st.graph = g
-            st.t.zero_()
+            self._capture(st, enc_hidden.device)
 
     @torch.no_grad()
     def _start_eager(self, enc_hidden: torch.Tensor, attention_mask: torch.Tensor, num_beams: int, max_len: int) -> None:

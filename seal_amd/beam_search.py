@@ -10,6 +10,7 @@ per row and R small H2D copies; here it is three kernels on the caller's stream
 copy), no host round trip.
 """
 import ctypes
+import itertools
 from typing import List, Optional
 
 import torch
@@ -82,43 +83,15 @@ class IndexBasedLogitsProcessor:
         return b
 
     def fused_topk(self, input_ids: torch.LongTensor, logits: torch.FloatTensor, beam_scores: torch.FloatTensor,
-                   batch: int, num_beams: int, parent_rows: Optional[torch.LongTensor] = None):
+                   batch: int, num_beams: int, parent_rows: Optional[torch.LongTensor] = None, tag: Optional[int] = None):
         """log_softmax + InfNanRemove + this constraint + beam scores + top-2K per query, fused
         (``fmi_dev_constrained_topk_step``): returns (flat indices [B, 2K], unconstrained scores [B, 2K]) -- what
         reference beam_search.py:244-307 computes through five [rows, vocab] intermediates.
 
         ``parent_rows`` (the previous step's ``beam_idx``) lets the index advance every row's prefix
         range by one backward-search step instead of re-searching the prefix (same ranges)."""
-        dev = logits.device
-        V = logits.shape[-1]
-        want = 2 * num_beams
-        rows = batch * num_beams
-        ids = input_ids.contiguous()
-        cur_len = ids.shape[1]
-        scratch = self._first_mask.get(("scratch", dev, rows, want))
-        if scratch is None:
-            scratch = torch.empty(rows * (3 + 2 * want) + 64, dtype=torch.float32, device=dev)
-            self._first_mask[("scratch", dev, rows, want)] = scratch
-        top_idx = torch.empty(batch, want, dtype=torch.int64, device=dev)
-        top_con = torch.empty(batch, want, dtype=torch.float32, device=dev)
-        top_unc = torch.empty(batch, want, dtype=torch.float32, device=dev)
-        ff = self.force_decoding_from or []
-        ff_arr = (ctypes.c_int64 * max(len(ff), 1))(*ff)
-        first = self._first_bits(V, dev) if cur_len == 1 else None
-        if getattr(self.index, "_trace", None) is not None and cur_len >= 2:
-            self.index._trace.append(("mask", ids.clone(), list(ff), dict(pad=self.pad_token_id, eos=self.eos_token_id,
-                                                                          stop_at_count=int(self.stop_at_count),
-                                                                          always_allow_eos=bool(self.always_allow_eos))))
-        lg = logits.contiguous()
-        bs = beam_scores.contiguous()
-        parent = parent_rows.contiguous() if parent_rows is not None else None
-        check(lib().fmi_dev_constrained_topk_step(
-            self.index.handle, _stream_ptr(dev), batch, num_beams, cur_len, ids.data_ptr(), lg.data_ptr(), bs.data_ptr(), V, SHIFT,
-            self.pad_token_id, self.eos_token_id, ff_arr, len(ff), int(self.stop_at_count), int(bool(self.always_allow_eos)),
-            first.data_ptr() if first is not None else None, scratch.data_ptr(), scratch.numel() * 4,
-            top_idx.data_ptr(), top_con.data_ptr(), top_unc.data_ptr(),
-            (id(self) & 0x7FFFFFFFFFFFFFFF) or 1, parent.data_ptr() if parent is not None else None))
-        return top_idx, top_unc
+        return fused_topk_groups([self], [batch], input_ids, logits, beam_scores, num_beams, parent_rows=parent_rows,
+                                 tag=tag if tag is not None else ((id(self) & 0x7FFFFFFFFFFFFFFF) or 1))
 
     def __call__(self, input_ids: torch.LongTensor, scores: torch.FloatTensor) -> torch.FloatTensor:
         if self.forced_bos_token_id is not None:   # beam_search.py:66-71
@@ -158,6 +131,69 @@ class IndexBasedLogitsProcessor:
         return out if out.dtype == scores.dtype else out.to(scores.dtype)
 
 
+MAX_FORCE = 8          # tokens of force_decoding_from the constraint kernel takes (fmi_kernels.hip)
+MAX_ROW_GROUPS = 3     # decodes one constraint call can serve in lockstep (fmi_kernels.hip)
+
+
+def can_fuse_groups(procs, logits: torch.Tensor, num_beams: int) -> bool:
+    """one fused constraint call can serve these processors' rows together: the HIP path applies to each, they constrain
+    against the same index handle and share everything but the end-of-sequence token and the forced prefix"""
+    p0 = procs[0]
+    return (0 < len(procs) <= MAX_ROW_GROUPS
+            and all(isinstance(p, IndexBasedLogitsProcessor) and p.supports_fused_topk(logits, num_beams) for p in procs)
+            and all(p.index is p0.index and p.pad_token_id == p0.pad_token_id and int(p.stop_at_count) == int(p0.stop_at_count)
+                    and bool(p.always_allow_eos) == bool(p0.always_allow_eos) and len(p.force_decoding_from or []) <= MAX_FORCE for p in procs)
+            and (len(procs) == 1 or not p0.always_allow_eos))      # (the first-step bitmap folds ONE eos in)
+
+
+def fused_topk_groups(procs, batches, input_ids: torch.LongTensor, logits: torch.FloatTensor, beam_scores: torch.FloatTensor,
+                      num_beams: int, parent_rows: Optional[torch.LongTensor] = None, tag: int = 0):
+    """``IndexBasedLogitsProcessor.fused_topk`` for the stacked rows of several decodes that advance in lockstep (group g =
+    the next ``batches[g]`` queries, constrained by ``procs[g]``): ONE ``fmi_dev_constrained_topk_groups`` call -- one
+    constraint launch, one log-softmax/top-2K launch, one merge launch -- for all of them.  Same per-row masks and per-query
+    picks as one call per processor."""
+    p0 = procs[0]
+    dev = logits.device
+    V = logits.shape[-1]
+    want = 2 * num_beams
+    batch = int(sum(batches))
+    rows = batch * num_beams
+    ids = input_ids.contiguous()
+    cur_len = ids.shape[1]
+    scratch = p0._first_mask.get(("scratch", dev, rows, want))
+    if scratch is None:
+        scratch = torch.empty(rows * (3 + 2 * want) + 64, dtype=torch.float32, device=dev)
+        p0._first_mask[("scratch", dev, rows, want)] = scratch
+    top_idx = torch.empty(batch, want, dtype=torch.int64, device=dev)
+    top_con = torch.empty(batch, want, dtype=torch.float32, device=dev)
+    top_unc = torch.empty(batch, want, dtype=torch.float32, device=dev)
+    n = len(procs)
+    g_batch = (ctypes.c_uint64 * n)(*[int(b) for b in batches])
+    g_eos = (ctypes.c_int64 * n)(*[int(p.eos_token_id) for p in procs])
+    g_nff = (ctypes.c_uint64 * n)(*[len(p.force_decoding_from or []) for p in procs])
+    g_ff = (ctypes.c_int64 * (n * MAX_FORCE))()
+    for g, p in enumerate(procs):
+        for j, t in enumerate(p.force_decoding_from or []):
+            g_ff[(g * MAX_FORCE if n > 1 else 0) + j] = int(t)
+    first = p0._first_bits(V, dev) if cur_len == 1 else None
+    if getattr(p0.index, "_trace", None) is not None and cur_len >= 2:
+        a = 0
+        for p, b in zip(procs, batches):         # one recorded operation per decode: its rows, its arguments
+            p0.index._trace.append(("mask", ids[a:a + b * num_beams].clone(), list(p.force_decoding_from or []),
+                                    dict(pad=p.pad_token_id, eos=p.eos_token_id, stop_at_count=int(p.stop_at_count),
+                                         always_allow_eos=bool(p.always_allow_eos))))
+            a += b * num_beams
+    lg = logits.contiguous()
+    bs = beam_scores.contiguous()
+    parent = parent_rows.contiguous() if parent_rows is not None else None
+    check(lib().fmi_dev_constrained_topk_groups(
+        p0.index.handle, _stream_ptr(dev), n, g_batch, g_eos, g_ff, g_nff, num_beams, cur_len, ids.data_ptr(), lg.data_ptr(), bs.data_ptr(),
+        V, SHIFT, p0.pad_token_id, int(p0.stop_at_count), int(bool(p0.always_allow_eos)),
+        first.data_ptr() if first is not None else None, scratch.data_ptr(), scratch.numel() * 4,
+        top_idx.data_ptr(), top_con.data_ptr(), top_unc.data_ptr(), int(tag), parent.data_ptr() if parent is not None else None))
+    return top_idx, top_unc
+
+
 # ---------------------------------------------------------------------------
 # beam loop (reference beam_search.py:143-389) + keep-history scorer
 # (reference beam_search.py:559-758), tensorised: no .item()/.tolist() per step,
@@ -169,6 +205,9 @@ def _inf_nan_remove(scores: torch.Tensor) -> torch.Tensor:
     +inf -> finfo.max; -inf is left alone."""
     scores = torch.where(scores != scores, torch.zeros_like(scores), scores)
     return torch.where(scores == float("inf"), torch.full_like(scores, torch.finfo(scores.dtype).max), scores)
+
+
+_LOOP_TAGS = itertools.count(1)      # one continuity tag per decode loop (fmi_dev_constrained_topk_step's state_tag)
 
 
 @torch.no_grad()
@@ -187,16 +226,34 @@ def constrained_beam_search(decoder, batch_size: int, num_beams: int, max_length
     carried on is the UNCONSTRAINED one (302-307); the first K non-eos candidates
     continue (673-685); stop when the sequence length reaches max_length (340).
     """
-    B, K = batch_size, num_beams
+    spec = dict(batch=batch_size, max_length=max_length, eos_token_id=eos_token_id, processor=constrained_decoding_processor)
+    return constrained_beam_search_groups(decoder, [spec], num_beams, decoder_start_token_id, device=device, fused=fused)[0]
+
+
+@torch.no_grad()
+def constrained_beam_search_groups(decoder, specs, num_beams: int, decoder_start_token_id: int, device=None, fused: bool = True):
+    """The loop above for SEVERAL decodes in lockstep, their rows stacked (group g = ``specs[g]["batch"]`` queries with its
+    own ``max_length`` / ``eos_token_id`` / ``processor``, max lengths ascending in row order): one model step, one
+    constraint call and one top-2K per step for all of them -- the searcher's body and title decodes of a batch are 2 x
+    batch x beams rows per step instead of two loops (reference retrieval.py:70-83 and 162-176 run one ``generate`` after
+    the other).  A group that reaches its max_length is finalised and its rows leave the loop (``decoder.narrow``); every
+    group's history is what its own loop records.  Returns [(steps, final)] per group."""
+    K = num_beams
+    assert all(a["max_length"] <= b["max_length"] for a, b in zip(specs, specs[1:])), "groups must come in ascending max_length"
+    live = list(range(len(specs)))
+    B = sum(sp["batch"] for sp in specs)
     R = B * K
     input_ids = torch.full((R, 1), decoder_start_token_id, dtype=torch.long, device=device)
     beam_scores = torch.zeros(B, K, dtype=torch.float32, device=device)
     beam_scores[:, 1:] = -1e9
     beam_scores = beam_scores.view(R)
     row_base = (torch.arange(B, device=device) * K).unsqueeze(1)
-    steps = []
+    eos_q = torch.cat([torch.full((sp["batch"],), int(sp["eos_token_id"]), dtype=torch.long, device=device) for sp in specs]).unsqueeze(1)
+    out_steps = [[] for _ in specs]
+    finals = [None] * len(specs)
     beam_idx = None     # rows of the previous step that this step's rows extend (incremental constraint state)
     first_logits = None
+    tag = next(_LOOP_TAGS)
     while True:
         logits = decoder.step(input_ids[:, -1])
         V = logits.shape[-1]
@@ -204,15 +261,24 @@ def constrained_beam_search(decoder, batch_size: int, num_beams: int, max_length
             # every beam of a query sees the same first step: the model's next-token logits after the start token,
             # i.e. what compute_unigram_scores (keys.py:145-176) runs the whole model for
             first_logits = logits.view(B, K, V)[:, 0].clone()
-        proc = constrained_decoding_processor
-        if proc is not None and fused and hasattr(proc, "fused_topk") and proc.supports_fused_topk(logits, K):
-            flat, next_scores = proc.fused_topk(input_ids, logits, beam_scores, B, K, parent_rows=beam_idx)
+        procs = [specs[g]["processor"] for g in live]
+        batches = [specs[g]["batch"] for g in live]
+        if fused and all(p is not None and hasattr(p, "fused_topk") for p in procs) and can_fuse_groups(procs, logits, K):
+            if len(procs) == 1:
+                flat, next_scores = procs[0].fused_topk(input_ids, logits, beam_scores, B, K, parent_rows=beam_idx, tag=tag)
+            else:
+                flat, next_scores = fused_topk_groups(procs, batches, input_ids, logits, beam_scores, K, parent_rows=beam_idx, tag=tag)
         else:
             logp = torch.log_softmax(logits.float(), dim=-1)
             processed = _inf_nan_remove(logp)
             unconstrained = processed + beam_scores[:, None]
-            if proc is not None:
-                constrained = proc(input_ids, processed) + beam_scores[:, None]
+            if any(p is not None for p in procs):
+                constrained = unconstrained.clone()
+                a = 0
+                for p, b in zip(procs, batches):
+                    if p is not None:
+                        constrained[a:a + b * K] = p(input_ids[a:a + b * K], processed[a:a + b * K]) + beam_scores[a:a + b * K, None]
+                    a += b * K
             else:
                 constrained = unconstrained
             _, flat = torch.topk(constrained.view(B, K * V), 2 * K, dim=1, largest=True, sorted=True)
@@ -220,9 +286,14 @@ def constrained_beam_search(decoder, batch_size: int, num_beams: int, max_length
         next_indices = flat // V                    # (next_tokens / V).long(), exact for K*V < 2^24 (309)
         next_tokens = flat % V
         src_rows = row_base + next_indices          # batch_beam_idx (661)
-        steps.append((input_ids[src_rows], next_tokens, next_scores))
+        prefix = input_ids[src_rows]
+        a = 0
+        for g in live:
+            b = a + specs[g]["batch"]
+            out_steps[g].append((prefix[a:b], next_tokens[a:b], next_scores[a:b]))
+            a = b
         # first K non-eos candidates, in rank order, become the next beams (670-685)
-        keep = next_tokens != eos_token_id
+        keep = next_tokens != eos_q
         order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)[:, :K]
         # (the reference's ValueError at 687-690 cannot trigger: each of the K rows holds
         # exactly one eos entry, so at most K of the 2K picks are eos)
@@ -231,13 +302,30 @@ def constrained_beam_search(decoder, batch_size: int, num_beams: int, max_length
         beam_idx = src_rows.gather(1, order).view(R)
         input_ids = torch.cat([input_ids[beam_idx], beam_tokens.unsqueeze(-1)], dim=-1)
         decoder.reorder(beam_idx)
-        if input_ids.shape[-1] >= max_length:       # MaxLengthCriteria (340)
-            break
+        cur = input_ids.shape[-1]
+        done = [g for g in live if cur >= specs[g]["max_length"]]       # MaxLengthCriteria (340); a prefix of `live`
+        if done:
+            a = 0
+            for g in done:
+                b = a + specs[g]["batch"] * K
+                finals[g] = (input_ids[a:b], beam_scores[a:b])
+                a = b
+            live = live[len(done):]
+            if not live:
+                break
+            nq = a // K
+            # the finished decodes' rows leave the loop; beam_idx keeps naming rows of the call before the cut, which is how
+            # the index's kept prefix ranges are addressed by the next constraint call
+            input_ids, beam_scores, beam_idx, eos_q = input_ids[a:], beam_scores[a:], beam_idx[a:], eos_q[nq:]
+            B -= nq
+            R = B * K
+            row_base = (torch.arange(B, device=device) * K).unsqueeze(1)
+            decoder.narrow(nq)
     try:
         decoder.first_logits = first_logits          # picked up by fm_index_generate(pending=True)
     except AttributeError:
         pass
-    return steps, (input_ids, beam_scores)
+    return [(out_steps[g], finals[g]) for g in range(len(specs))]
 
 
 def _history_to_hypotheses(steps, final, batch_size: int, num_beams: int, length_penalty: float):
@@ -345,6 +433,70 @@ def fm_index_generate(
         pg.first_logits = getattr(decoder, "first_logits", None)
         return pg
     return _history_to_hypotheses(steps, final, input_ids.shape[0], num_beams, length_penalty)
+
+
+@torch.no_grad()
+def fm_index_generate_joint(model, index: FMIndex, input_ids: torch.LongTensor, attention_mask: torch.LongTensor, jobs,
+                            num_beams: int = 3, length_penalty: float = 1.0, stop_at_count: int = 0, always_allow_eos: bool = False,
+                            disable_fm_index: bool = False, logit_bias=None, decoder=None, forced_bos_token_id=None):
+    """Several ``fm_index_generate(keep_history=True)`` calls of ONE model as one decode loop: ``jobs`` = dicts with
+    ``batch`` (the next ``batch`` rows of ``input_ids`` are this job's encoder inputs), ``max_length``, ``eos_token_id``,
+    ``force_decoding_from``.  The searcher's body and title decodes (reference retrieval.py:70-83, 162-176: two
+    ``generate`` calls one after the other over the same queries) become 2 x batch x beams rows per model step: one encoder
+    pass, GEMMs at twice the height, one constraint launch per step for both (``constrained_beam_search_groups``).  Every job
+    gets the hypotheses its own call would produce.  ``logit_bias`` [sum of batches, vocab].  Returns one ``PendingGenerate``
+    per job, in the order given (nothing has waited for the GPU)."""
+    from .bart_decoder import BartStepDecoder
+    if forced_bos_token_id is None:
+        forced_bos_token_id = getattr(model.config, "forced_bos_token_id", None)
+    if decoder is None:
+        decoder = getattr(model, "_seal_step_decoder", None)
+        if decoder is None or decoder.lm_w.device != input_ids.device:
+            decoder = BartStepDecoder(model)
+            model._seal_step_decoder = decoder
+    assert sum(j["batch"] for j in jobs) == input_ids.shape[0]
+    # rows in ascending max_length: the decodes that end first sit in front and are cut off when they end
+    order = sorted(range(len(jobs)), key=lambda i: jobs[i]["max_length"])
+    starts = [sum(j["batch"] for j in jobs[:i]) for i in range(len(jobs))]
+    if order != list(range(len(jobs))):
+        perm = torch.cat([torch.arange(starts[i], starts[i] + jobs[i]["batch"], device=input_ids.device) for i in order])
+        input_ids, attention_mask = input_ids[perm], attention_mask[perm]
+        if logit_bias is not None:
+            logit_bias = logit_bias[perm]
+    specs = []
+    for i in order:
+        j = jobs[i]
+        eos = j.get("eos_token_id")
+        if eos is None:
+            eos = model.config.eos_token_id
+        proc = None if disable_fm_index else IndexBasedLogitsProcessor(
+            num_beams=num_beams, index=index, pad_token_id=model.config.pad_token_id, eos_token_id=eos,
+            force_decoding_from=j.get("force_decoding_from"), stop_at_count=stop_at_count, always_allow_eos=always_allow_eos,
+            forced_bos_token_id=forced_bos_token_id)
+        specs.append(dict(batch=j["batch"], max_length=j["max_length"], eos_token_id=eos, processor=proc))
+    enc = decoder.encode(input_ids, attention_mask)
+    cuts, gone = [], 0                       # queries that have left the loop after each group but the last
+    for sp in specs[:-1]:
+        gone += sp["batch"]
+        cuts.append(gone)
+    decoder.start(enc, attention_mask, num_beams, specs[-1]["max_length"], narrow_plan=cuts)
+    saved_bias = decoder.logit_bias
+    if logit_bias is not None:
+        decoder.logit_bias = logit_bias
+    try:
+        results = constrained_beam_search_groups(decoder, specs, num_beams, model.config.decoder_start_token_id, device=input_ids.device)
+    finally:
+        decoder.logit_bias = saved_bias
+    first_logits = getattr(decoder, "first_logits", None)
+    out = [None] * len(jobs)
+    a = 0
+    for i, sp, (steps, final) in zip(order, specs, results):
+        b = a + sp["batch"]
+        pg = PendingGenerate(steps, final, sp["batch"], num_beams, length_penalty, enc=enc[a:b], attention_mask=attention_mask[a:b])
+        pg.first_logits = first_logits[a:b] if first_logits is not None else None
+        out[i] = pg
+        a = b
+    return out
 
 
 class PendingGenerate:

@@ -29,8 +29,10 @@ from typing import Dict, List, Optional, Sequence, Union
 import torch
 
 from . import keys as rk
-from .beam_search import fm_index_generate
+from .beam_search import fm_index_generate, fm_index_generate_joint
 from .index import FMIndex
+
+TITLE_MAX_LENGTH = 15     # the reference hard-wires the title / code decode length (retrieval.py:165,215); tests shorten it
 
 logger = logging.getLogger(__name__)
 
@@ -137,6 +139,9 @@ class _Pipeline:
         return d
 
 
+_FM_INDEX_GENERATE = fm_index_generate      # (a caller that swaps this module's fm_index_generate for its own gets its own: no joint loop)
+
+
 def _count_filter(index: FMIndex, per_query: List[List]) -> List[List]:
     """``[(s, k) for s, k in fk if k and index.get_count(k) > 0]`` for every query of
     the batch with one launch."""
@@ -214,7 +219,36 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
 
     # ---- segment 1: enqueue the decodes ----
     body = titles = None
-    if s.decode_body:
+    codes = code_toks = title_toks = None
+    # One loop for the decodes of this batch that share a model (the default: ``bart_title_model is bart_model``): their rows
+    # are stacked -- 2 x batch x beams per model step --, see ``fm_index_generate_joint``.  Needs the GPU index (one fused
+    # constraint call per step serves every decode's rows) and the reference's settings for those decodes.
+    joint_kinds = []
+    if (getattr(s, "joint_decode", True) and s.device.type == "cuda" and hasattr(fm_index, "handle") and s.diverse_bs_groups == 1
+            and not s.topk and fm_index_generate is _FM_INDEX_GENERATE):
+        joint_kinds = [k for k, on, m in (("body", s.decode_body, s.bart_model), ("title", s.decode_titles, s.bart_title_model),
+                                          ("code", s.decode_code, s.bart_code_model)) if on and m is s.bart_model]
+        if len(joint_kinds) < 2:
+            joint_kinds = []
+    if joint_kinds:
+        job_of = {"body": dict(max_length=s.length, eos_token_id=None, force_decoding_from=None),
+                  "title": dict(max_length=TITLE_MAX_LENGTH, eos_token_id=s.title_eos_token_id, force_decoding_from=[s.title_bos_token_id]),
+                  "code": dict(max_length=TITLE_MAX_LENGTH, eos_token_id=s.code_eos_token_id, force_decoding_from=[s.code_bos_token_id])}
+        marked_in = {k: marked(k) for k in joint_kinds}
+        if tokenised:
+            enc_in = encoder_batch(None, [t for k in joint_kinds for t in marked_in[k][1]])
+        else:
+            enc_in = encoder_batch([x for k in joint_kinds for x in marked_in[k][0]], None)
+        pend = fm_index_generate_joint(
+            s.bart_model, fm_index, enc_in["input_ids"], enc_in["attention_mask"],
+            [dict(batch=len(inputs), **job_of[k]) for k in joint_kinds], num_beams=s.beam, length_penalty=s.length_penalty,
+            stop_at_count=s.stop_at_count, disable_fm_index=not constrained_generation,
+            logit_bias=torch.cat([bias] * len(joint_kinds)) if bias is not None else None, **dec(s.bart_model))
+        got = dict(zip(joint_kinds, pend))
+        body, titles, codes = got.get("body"), got.get("title"), got.get("code")
+        title_toks = marked_in["title"][1] if "title" in got else None
+        code_toks = marked_in["code"][1] if "code" in got else None
+    if s.decode_body and body is None:
         strs, toks = marked("body")
         body = fm_index_generate(
             s.bart_model, fm_index, **encoder_batch(strs, toks),
@@ -223,20 +257,19 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
             diverse_bs_penalty=s.diverse_bs_penalty, stop_at_count=s.stop_at_count, keep_history=True, topk=s.topk,
             logit_bias=bias, pending=True, **dec(s.bart_model))
     yield "body"
-    if s.decode_titles:
+    if s.decode_titles and titles is None:
         strs, title_toks = marked("title")
         titles = fm_index_generate(
             s.bart_title_model, fm_index, **encoder_batch(strs, title_toks),
-            min_length=1, max_length=15, num_beams=s.beam, length_penalty=s.length_penalty,
+            min_length=1, max_length=TITLE_MAX_LENGTH, num_beams=s.beam, length_penalty=s.length_penalty,
             force_decoding_from=[s.title_bos_token_id], eos_token_id=s.title_eos_token_id,
             diverse_bs_groups=s.diverse_bs_groups, diverse_bs_penalty=s.diverse_bs_penalty, keep_history=True,
             disable_fm_index=not constrained_generation, topk=s.topk, logit_bias=bias, pending=True, **dec(s.bart_title_model))
-    codes = code_toks = None
-    if s.decode_code:           # retrieval.py:212-236
+    if s.decode_code and codes is None:           # retrieval.py:212-236
         strs, code_toks = marked("code")
         codes = fm_index_generate(
             s.bart_code_model, fm_index, **encoder_batch(strs, code_toks),
-            min_length=1, max_length=15, num_beams=s.beam, length_penalty=s.length_penalty,
+            min_length=1, max_length=TITLE_MAX_LENGTH, num_beams=s.beam, length_penalty=s.length_penalty,
             eos_token_id=s.code_eos_token_id, diverse_bs_groups=s.diverse_bs_groups, diverse_bs_penalty=s.diverse_bs_penalty,
             keep_history=True, force_decoding_from=[s.code_bos_token_id], disable_fm_index=not constrained_generation,
             logit_bias=bias, pending=True, **dec(s.bart_code_model))
@@ -451,6 +484,8 @@ class SEALSearcher:
         self.gpu_aggregate: bool = params.get("gpu_aggregate", True)
         # extension: query batches in flight on the GPU at a time (each batch_size queries, own stream); 1 = one after the other
         self.pipeline: int = int(params.get("pipeline", 1))
+        # extension: the decodes of a batch that share a model (body, title[, code]) run as ONE loop, rows stacked
+        self.joint_decode: bool = bool(params.get("joint_decode", True))
         # extension: enqueue the next batch's decodes before this batch's rescoring / aggregation (same thread, second stream)
         self.overlap: bool = bool(params.get("overlap", True))
         self.overlap_depth: int = int(params.get("overlap_depth", 1))     # batches of decodes kept enqueued ahead (2 measured no faster)

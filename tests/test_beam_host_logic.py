@@ -139,3 +139,51 @@ def test_capture_gate_gives_a_capture_the_gpu_issuing_side_to_itself():
     with gate.capturing():                                   # uncontended, from a thread that holds nothing
         pass
     assert gate._readers == 0 and not gate._writer and gate._writers_waiting == 0
+
+
+@pytest.mark.parametrize("lengths", [(6, 9), (7, 7), (5, 6, 8)])
+def test_lockstep_groups_record_what_separate_loops_record(lengths):
+    """``constrained_beam_search_groups``: several decodes with their own encoder inputs / end token / forced prefix /
+    length as ONE loop over stacked rows (what the searcher does with its body and title decodes), the ones that end first
+    leaving the loop (``decoder.narrow``) -- every group's history equals its own separate loop's"""
+    from seal_amd.beam_search import constrained_beam_search, constrained_beam_search_groups
+    vocab, K = 120, 3
+    m = tiny_bart(vocab)
+    docs = make_docs(3, 150, vocab, title_sep=7)
+    orc = OracleFMIndex()
+    orc.initialize(docs)
+    torch.manual_seed(5)
+    cfgs = [dict(eos_token_id=2, force_decoding_from=None), dict(eos_token_id=7, force_decoding_from=[2]),
+            dict(eos_token_id=9, force_decoding_from=[7])][:len(lengths)]
+    batches = [3, 2, 2][:len(lengths)]
+    enc_ids = [torch.randint(4, vocab, (b, 8)) for b in batches]
+    for e in enc_ids:
+        e[-1, 6:] = 1
+    bias = [torch.randn(b, vocab) for b in batches]
+
+    def proc(c):
+        return OracleLogitsProcessor(orc, K, vocab, pad_token_id=1, eos_token_id=c["eos_token_id"], force_decoding_from=c["force_decoding_from"])
+    want = []
+    for ids, c, T, lb in zip(enc_ids, cfgs, lengths, bias):
+        dec = BartStepDecoder(m)
+        mask = (ids != 1).long()
+        dec.start(dec.encode(ids, mask), mask, K, T)
+        dec.logit_bias = lb
+        want.append(constrained_beam_search(dec, ids.shape[0], K, T, 2, c["eos_token_id"], proc(c)))
+    dec = BartStepDecoder(m)
+    ids = torch.cat(enc_ids)
+    mask = (ids != 1).long()
+    cuts = [sum(batches[:i + 1]) for i in range(len(batches) - 1)]
+    dec.start(dec.encode(ids, mask), mask, K, lengths[-1], narrow_plan=cuts)
+    dec.logit_bias = torch.cat(bias)
+    specs = [dict(batch=b, max_length=T, eos_token_id=c["eos_token_id"], processor=proc(c)) for b, T, c in zip(batches, lengths, cfgs)]
+    got = constrained_beam_search_groups(dec, specs, K, 2)
+    assert len(got) == len(want)
+    for (gs, gf), (ws, wf), T in zip(got, want, lengths):
+        assert len(gs) == len(ws) == T - 1
+        for (gp, gt, gsc), (wp, wt, wsc) in zip(gs, ws):
+            fin = torch.isfinite(wsc) & (wsc > -1e8)
+            assert torch.equal(torch.isfinite(gsc), torch.isfinite(wsc))
+            assert torch.equal(gp[fin], wp[fin]) and torch.equal(gt[fin], wt[fin])
+            assert torch.allclose(gsc[fin], wsc[fin], atol=1e-5)
+        assert torch.equal(gf[0], wf[0]) and torch.allclose(gf[1], wf[1], atol=1e-5)

@@ -18,9 +18,7 @@ def test_bench_parity_check_passes_on_a_real_batch_and_catches_a_corrupted_answe
     docs = make_docs(5, 300, vocab - 8, min_len=6, max_len=18, title_sep=title_eos)
     ix = FMIndex()
     ix.initialize(docs)
-    real = retrieval.fm_index_generate
-    monkeypatch.setattr(retrieval, "fm_index_generate",
-                        lambda *a, **kw: real(*a, **{**kw, "max_length": 8 if kw.get("force_decoding_from") else kw["max_length"]}))
+    monkeypatch.setattr(retrieval, "TITLE_MAX_LENGTH", 8)      # the searcher's default path: body + title decodes as one loop
     s = SEALSearcher(ix, None, tiny_bart(vocab, d_model=128, heads=2).to(dev), backbone="bart-tiny", length=6, beam=4, batch_size=3,
                      add_query_to_keys=False, detokenize=False, title_eos_token_id=title_eos, code_eos_token_id=vocab - 6,
                      code_bos_token_id=title_eos,

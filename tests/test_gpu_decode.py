@@ -254,8 +254,8 @@ def test_incremental_constraint_state_equals_full_prefix_search(kw):
             pass
 
     class NoParents(IndexBasedLogitsProcessor):
-        def fused_topk(self, input_ids, logits, beam_scores, batch, num_beams, parent_rows=None):
-            return super().fused_topk(input_ids, logits, beam_scores, batch, num_beams, parent_rows=None)
+        def fused_topk(self, input_ids, logits, beam_scores, batch, num_beams, parent_rows=None, tag=None):
+            return super().fused_topk(input_ids, logits, beam_scores, batch, num_beams, parent_rows=None, tag=tag)
 
     out = []
     for cls in (IndexBasedLogitsProcessor, NoParents):
@@ -461,3 +461,101 @@ def test_tree_self_attention_matches_the_row_kernel_and_torch(T):
     w = torch.softmax(torch.einsum("nhd,nahd->nha", v[:, 0] * 0.125, v[:, 1][ix]) + bias, -1)
     ref = torch.einsum("nha,nahd->nhd", w, v[:, 2][ix]).reshape(N, heads * 64)
     assert torch.allclose(out, ref, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_groups", [2, 3])
+def test_lockstep_groups_on_the_gpu_equal_separate_loops_bit_for_bit(n_groups):
+    """``constrained_beam_search_groups`` over the HIP constraint (ONE ``fmi_dev_constrained_topk_groups`` call per step for
+    the stacked rows of 2 / 3 decodes with their own eos / forced prefix / length) on deterministic per-row logits: every
+    group's history must equal its own separate loop's exactly -- per-row masks, per-query picks, the incremental prefix
+    ranges across the step where the shorter decodes leave the loop (parents then name rows of the wider previous call)."""
+    from seal_amd import FMIndex
+    from seal_amd.beam_search import IndexBasedLogitsProcessor, constrained_beam_search, constrained_beam_search_groups
+    from tests.helpers import make_docs
+    vocab, K = 120, 5
+    dev = torch.device("cuda:0")
+    docs = make_docs(5, 200, vocab - 8, title_sep=7)
+    cfgs = [dict(batch=4, T=6, eos=2, ff=None), dict(batch=3, T=9, eos=7, ff=[2]), dict(batch=2, T=11, eos=9, ff=[7])][:n_groups]
+
+    class RandomDecoder:
+        """deterministic logits per (group, step, row)"""
+        def __init__(self, groups):
+            self.groups, self.t = list(groups), 0
+
+        def step(self, tokens):
+            parts = []
+            for gi, c in self.groups:
+                g = torch.Generator(device="cpu").manual_seed(1000 * gi + self.t)
+                lg = torch.randn(c["batch"] * K, vocab, generator=g) * 3
+                lg[:, 0] = float("-inf")
+                parts.append(lg)
+            self.t += 1
+            return torch.cat(parts).to(dev)
+
+        def reorder(self, beam_idx):
+            pass
+
+        def narrow(self, nq):
+            while nq > 0:
+                nq -= self.groups.pop(0)[1]["batch"]
+            assert nq == 0
+
+    def proc(ix, c):
+        return IndexBasedLogitsProcessor(ix, K, pad_token_id=1, eos_token_id=c["eos"], force_decoding_from=c["ff"])
+    want = []
+    for gi, c in enumerate(cfgs):
+        ix = FMIndex()
+        ix.initialize(docs)
+        steps, final = constrained_beam_search(RandomDecoder([(gi, c)]), c["batch"], K, c["T"], 2, c["eos"], proc(ix, c), device=dev)
+        want.append(([tuple(x.tolist() for x in s) for s in steps], final[0].tolist(), final[1].tolist()))
+    ix = FMIndex()
+    ix.initialize(docs)
+    specs = [dict(batch=c["batch"], max_length=c["T"], eos_token_id=c["eos"], processor=proc(ix, c)) for c in cfgs]
+    got = constrained_beam_search_groups(RandomDecoder(list(enumerate(cfgs))), specs, K, 2, device=dev)
+    for (steps, final), w in zip(got, want):
+        assert ([tuple(x.tolist() for x in s) for s in steps], final[0].tolist(), final[1].tolist()) == w
+
+
+@pytest.mark.gpu
+def test_joint_generate_through_the_fused_decoder_matches_separate_generates():
+    """``fm_index_generate_joint`` (body-like and title-like decode of the same queries as one loop through the graph-captured
+    fused step decoder, the title rows carrying on alone in the views ``decoder.narrow`` switches to) against two
+    ``fm_index_generate`` calls: same keys after the searcher's filters, scores within 1e-4 (GEMMs of another height)"""
+    from oracle.seal_oracle import OracleFMIndex
+    from seal_amd import FMIndex, fm_index_generate
+    from seal_amd.beam_search import fm_index_generate_joint
+    from tests.helpers import make_docs, tiny_bart, valid_set
+    vocab, K = 120, 4
+    dev = torch.device("cuda:0")
+    m = tiny_bart(vocab, d_model=128, heads=2).to(dev)
+    docs = make_docs(3, 150, vocab, title_sep=7)
+    ix, orc = FMIndex(), OracleFMIndex()
+    ix.initialize(docs)
+    orc.initialize(docs)
+    torch.manual_seed(2)
+    body_ids = torch.randint(4, vocab, (3, 9), device=dev)
+    title_ids = torch.randint(4, vocab, (3, 9), device=dev)
+    body_ids[2, 6:] = 1
+    title_ids[2, 6:] = 1
+    bias = torch.randn(3, vocab, device=dev)
+    jobs = [dict(batch=3, max_length=6, eos_token_id=None, force_decoding_from=None),
+            dict(batch=3, max_length=9, eos_token_id=7, force_decoding_from=[2])]
+    for rep in range(2):                          # the second round replays the captured graphs (wide and narrowed) over stale caches
+        ids = torch.cat([body_ids, title_ids])
+        pend = fm_index_generate_joint(m, ix, ids, (ids != 1).long(), jobs, num_beams=K, length_penalty=0.0, logit_bias=torch.cat([bias, bias]))
+        assert m._seal_step_decoder._st.fused is True and m._seal_step_decoder._st.shape[0] == 3      # ended on the narrowed state
+        got = [p.result() for p in pend]
+        assert pend[0].enc.shape[0] == 3 and pend[1].first_logits.shape == (3, vocab)
+        want = [fm_index_generate(m, ix, body_ids, (body_ids != 1).long(), min_length=1, max_length=6, num_beams=K, length_penalty=0.0,
+                                  keep_history=True, logit_bias=bias),
+                fm_index_generate(m, ix, title_ids, (title_ids != 1).long(), min_length=1, max_length=9, num_beams=K, length_penalty=0.0,
+                                  keep_history=True, force_decoding_from=[2], eos_token_id=7, logit_bias=bias)]
+        for gj, wj, te in zip(got, want, (None, 7)):
+            for g, w in zip(gj, wj):
+                gv, wv = valid_set(g, orc, te), valid_set(w, orc, te)
+                assert set(gv) == set(wv)
+                for k in gv:
+                    for a, b in zip(sorted(gv[k]), sorted(wv[k])):
+                        assert abs(a - b) <= 1e-4, (k, a, b)
+        body_ids, title_ids = torch.roll(body_ids, 1, 0), torch.roll(title_ids, 1, 0)

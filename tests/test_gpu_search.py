@@ -105,9 +105,7 @@ def test_searcher_ranks_like_the_scalar_pipeline(first_stage_only, jobs, query_k
     queries = [[0] + rng.integers(4, vocab - 8, size=int(rng.integers(4, 9))).tolist() + [2] for _ in range(3)]
     K, length = 4, 6
     # the title decode length (15) is hard-wired in the reference; shorten it for the tiny corpus on both sides
-    real = retrieval.fm_index_generate
-    monkeypatch.setattr(retrieval, "fm_index_generate",
-                        lambda *a, **kw: real(*a, **{**kw, "max_length": 8 if kw.get("force_decoding_from") else kw["max_length"]}))
+    monkeypatch.setattr(retrieval, "TITLE_MAX_LENGTH", 8)
     s = SEALSearcher(ix, None, tiny_bart(vocab, **geom).to(dev), backbone="bart-tiny", length=length, beam=K, batch_size=2,
                      add_query_to_keys=query_keys, detokenize=False, first_stage_only=first_stage_only, jobs=jobs,
                      title_eos_token_id=TITLE_EOS, code_eos_token_id=vocab - 6, code_bos_token_id=TITLE_EOS, decode_code=decode_code,
@@ -157,9 +155,7 @@ def test_search_detokenizes_title_and_body(jobs, monkeypatch):
     docs = make_docs(5, 200, vocab - 8, min_len=6, max_len=18, title_sep=TITLE_EOS)
     ix = FMIndex()
     ix.initialize(docs)
-    real = retrieval.fm_index_generate
-    monkeypatch.setattr(retrieval, "fm_index_generate",
-                        lambda *a, **kw: real(*a, **{**kw, "max_length": 8 if kw.get("force_decoding_from") else kw["max_length"]}))
+    monkeypatch.setattr(retrieval, "TITLE_MAX_LENGTH", 8)
     s = SEALSearcher(ix, _WordTokenizer(), tiny_bart(vocab).to(dev), backbone="bart-tiny", length=6, beam=4, batch_size=2,
                      add_query_to_keys=False, jobs=jobs, title_eos_token_id=TITLE_EOS, code_eos_token_id=vocab - 6,
                      code_bos_token_id=TITLE_EOS,
@@ -193,9 +189,7 @@ def test_pipelined_batches_give_the_results_of_sequential_batches(geom, monkeypa
     ix.initialize(docs)
     rng = np.random.default_rng(3)
     queries = [[0] + rng.integers(4, vocab - 8, size=int(rng.integers(4, 9))).tolist() + [2] for _ in range(11)]
-    real = retrieval.fm_index_generate
-    monkeypatch.setattr(retrieval, "fm_index_generate",
-                        lambda *a, **kw: real(*a, **{**kw, "max_length": 8 if kw.get("force_decoding_from") else kw["max_length"]}))
+    monkeypatch.setattr(retrieval, "TITLE_MAX_LENGTH", 8)
     model = tiny_bart(vocab, **geom).to(dev)
     out = {}
     for depth, overlap in ((1, False), (1, True), (2, False), (3, False)):
@@ -222,10 +216,9 @@ def _tiny_gpu_searcher(ix, model, vocab, **kw):
 
 
 def _short_titles(monkeypatch):
+    # the title decode length (15) is hard-wired in the reference; shortened for the tiny corpora on both sides
     from seal_amd import retrieval
-    real = retrieval.fm_index_generate
-    monkeypatch.setattr(retrieval, "fm_index_generate",
-                        lambda *a, **kw: real(*a, **{**kw, "max_length": 8 if kw.get("force_decoding_from") else kw["max_length"]}))
+    monkeypatch.setattr(retrieval, "TITLE_MAX_LENGTH", 8)
 
 
 def test_sharded_search_over_rccl_with_one_rank_equals_the_local_search(monkeypatch):
@@ -332,3 +325,41 @@ def test_searcher_document_ids_on_a_corpus_where_ties_are_rare(monkeypatch):
             single += len(groups[i]) == 1
             total += 1
     assert single >= 0.9 * total, (single, total)
+
+
+@pytest.mark.parametrize("decode_code", [False, True])
+def test_joint_decode_of_a_batch_returns_what_separate_decodes_return(decode_code, monkeypatch):
+    """``joint_decode`` (default): the body / title (/ code) decodes of a batch as ONE loop of stacked rows; off: one
+    ``fm_index_generate`` after the other as the reference does.  Same documents (ties at 1e-5 relative aside), scores
+    within 1e-4 relative: the GEMMs run at another height, nothing else differs."""
+    from seal_amd import FMIndex
+    from tests.helpers import make_docs, tiny_bart
+    vocab = 120
+    dev = torch.device("cuda:0")
+    docs = make_docs(5, 300, vocab - 8, min_len=6, max_len=18, title_sep=TITLE_EOS)
+    ix = FMIndex()
+    ix.initialize(docs)
+    _short_titles(monkeypatch)
+    model = tiny_bart(vocab, d_model=128, heads=2).to(dev)
+    rng = np.random.default_rng(8)
+    queries = [[0] + rng.integers(4, vocab - 8, size=int(rng.integers(4, 9))).tolist() + [2] for _ in range(5)]
+    out = {}
+    for joint in (True, False):
+        s = _tiny_gpu_searcher(ix, model, vocab, joint_decode=joint, add_query_to_keys=True, decode_code=decode_code, partial_code=decode_code,
+                               overlap=False)
+        s.marker_token_ids["code"] = [vocab - 2, vocab - 7]
+        calls = []
+        from seal_amd import beam_search
+        real = beam_search.constrained_beam_search_groups
+        monkeypatch.setattr(beam_search, "constrained_beam_search_groups", lambda dec, specs, *a, **kw: (calls.append(len(specs)), real(dec, specs, *a, **kw))[1])
+        res = s.batch_search(queries, k=10)
+        monkeypatch.setattr(beam_search, "constrained_beam_search_groups", real)
+        n_dec = 3 if decode_code else 2
+        assert calls == ([n_dec] * 3 if joint else [1] * (3 * n_dec))           # 3 batches of <= 2 queries
+        out[joint] = [[(d.idx, d.score) for d in docs_] for docs_ in res]
+    for a, b in zip(out[True], out[False]):
+        assert len(a) == len(b) > 0
+        for i, ((da, sa), (db, sb)) in enumerate(zip(a, b)):
+            assert abs(sa - sb) <= 1e-4 * max(1.0, abs(sb))
+            if da != db:                                   # a swap inside a tie group only
+                assert any(abs(sb - s2) <= 1e-5 * max(1.0, abs(sb)) and d2 == da for d2, s2 in b)
