@@ -347,32 +347,48 @@ def sa_audit(index, n_pairs=1 << 20, seed=7):
             "against": "direct comparison of text[SA[i]:] and text[SA[i+1]:] on the device; SA[LF(i)] == SA[i]-1 through fmi_dev_bs_step"}
 
 
+def retrieval_title_length():
+    from seal_amd import retrieval
+    return retrieval.TITLE_MAX_LENGTH
+
+
 def score_parity(searcher, model, index, queries, bias, dev, n_rescore_queries=4, tol=1e-4):
     """The float half of parity at the bench's own geometry (BART-large, beam 15, batch 20): the body and title decodes of one
     batch are run once more exactly as the searcher issues them (retrieval.py:70-83,162-176), every hypothesis score the beam
     loop recorded is recomputed through HF's own cache-free fp32 forward (oracle/hf_scores.py), and the prefix-tree
     rescoring of a sample of the body keys is held to one HF row per key (reference keys.py:64-141)."""
     from oracle.hf_scores import compare_beam_history, compare_rescoring
-    from seal_amd.beam_search import fm_index_generate
+    from seal_amd.beam_search import fm_index_generate, fm_index_generate_joint
     from seal_amd.keys import _pad_batch
     s = searcher
     cfg = model.config
     mk = s.marker_token_ids
     out = {}
-    body_hyps = body_toks = None
-    for name, kind, kw in (("beam_scores_body", "body", dict(min_length=s.length, max_length=s.length)),
-                           ("beam_scores_title", "title", dict(min_length=1, max_length=15, force_decoding_from=[s.title_bos_token_id],
-                                                               eos_token_id=s.title_eos_token_id))):
-        toks = [q[:-1] + mk[kind] + mk["+"] + q[-1:] for q in queries]
-        enc_ids = _pad_batch(toks, cfg.pad_token_id, dev)
+    B = len(queries)
+    kinds = (("beam_scores_body", "body", dict(max_length=s.length)),
+             ("beam_scores_title", "title", dict(max_length=retrieval_title_length(), force_decoding_from=[s.title_bos_token_id],
+                                                 eos_token_id=s.title_eos_token_id)))
+    toks = {kind: [q[:-1] + mk[kind] + mk["+"] + q[-1:] for q in queries] for _, kind, _ in kinds}
+    if s.joint_decode:
+        # what the searcher runs: both decodes as ONE loop of 2 x batch x beams rows (fm_index_generate_joint)
+        enc_ids = _pad_batch(toks["body"] + toks["title"], cfg.pad_token_id, dev)
         enc_mask = (enc_ids != cfg.pad_token_id).long()
-        pg = fm_index_generate(model, index, enc_ids, enc_mask, length_penalty=s.length_penalty, num_beams=s.beam, keep_history=True,
-                               logit_bias=bias, pending=True, **kw)
-        steps, final, B, K, _ = pg._args
-        assert model._seal_step_decoder._st.fused, "the fused step decoder must be the one that ran"
-        out[name] = compare_beam_history(model, enc_ids, enc_mask, steps, final, B, K, logit_bias=bias, tol=tol)
-        if kind == "body":
-            body_hyps, body_toks = pg.result(), toks
+        pend = fm_index_generate_joint(model, index, enc_ids, enc_mask, [dict(batch=B, **kw) for _, _, kw in kinds], num_beams=s.beam,
+                                       length_penalty=s.length_penalty, logit_bias=torch.cat([bias, bias]))
+        runs = [(name, pg, enc_ids[i * B:(i + 1) * B], enc_mask[i * B:(i + 1) * B]) for i, ((name, _, _), pg) in enumerate(zip(kinds, pend))]
+    else:
+        runs = []
+        for name, kind, kw in kinds:
+            enc_ids = _pad_batch(toks[kind], cfg.pad_token_id, dev)
+            enc_mask = (enc_ids != cfg.pad_token_id).long()
+            runs.append((name, fm_index_generate(model, index, enc_ids, enc_mask, min_length=1, length_penalty=s.length_penalty, num_beams=s.beam,
+                                                 keep_history=True, logit_bias=bias, pending=True, **kw), enc_ids, enc_mask))
+    assert model._seal_step_decoder._st.fused, "the fused step decoder must be the one that ran"
+    for name, pg, enc_ids, enc_mask in runs:
+        steps, final, nb, K, _ = pg._args
+        out[name] = compare_beam_history(model, enc_ids, enc_mask, steps, final, nb, K, logit_bias=bias, tol=tol)
+        out[name]["decoded_as"] = "one loop with the other decode (joint)" if s.joint_decode else "its own loop"
+    body_hyps = runs[0][1].result()
     nq = min(n_rescore_queries, len(queries))
     strip_ids = s.strip_token_ids
     keys = []
@@ -398,6 +414,8 @@ def main():
     ap.add_argument("--jobs", type=int, default=1, help="host worker processes (only used by the host aggregation routines)")
     ap.add_argument("--pipeline", type=int, default=1, help="query batches in flight on worker threads (each on its own stream); 1 = none")
     ap.add_argument("--no-overlap", action="store_true", help="do not enqueue the next batch's decodes ahead of this batch's rescoring/aggregation")
+    ap.add_argument("--no-joint-decode", action="store_true", help="body and title decodes as two loops of batch x beams rows (the reference's "
+                    "order) instead of one loop of 2 x batch x beams rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-other-depth", action="store_true", help="also time the same batches through the other retrieval depth "
                     "(first stage only <-> complete search); first-stage-only aggregates on the host and is slow on the phrase corpus")
@@ -496,7 +514,8 @@ def main():
     log(f"BART-large random init (fp32) in {time.perf_counter() - t0:.1f}s")
 
     searcher = SEALSearcher(index, None, model, add_query_to_keys=not args.no_query_keys, detokenize=False, first_stage_only=args.first_stage_only,
-                            beam=args.beam, batch_size=args.batch, jobs=args.jobs, pipeline=args.pipeline, overlap=not args.no_overlap)
+                            beam=args.beam, batch_size=args.batch, jobs=args.jobs, pipeline=args.pipeline, overlap=not args.no_overlap,
+                            joint_decode=not args.no_joint_decode)
     from seal_amd.bart_decoder import BartStepDecoder
     model._seal_step_decoder = BartStepDecoder(model)
     # every pipeline drives the constraint kernels through its own view of the index: count / time all of them
@@ -618,8 +637,10 @@ def main():
             return out
         return wrap
     orig = (retrieval.fm_index_generate, rk.rescore_keys, rk.compute_unigram_scores, rk.aggregate_evidence_batch, retrieval._count_filter)
-    orig_multi = rk.rescore_keys_multi
+    orig_multi, orig_joint = rk.rescore_keys_multi, retrieval.fm_index_generate_joint
     retrieval.fm_index_generate = timed("decode_ms", orig[0])
+    retrieval.fm_index_generate._joint_ok = True             # a timer, not another decoder: the searcher keeps its joint loop
+    retrieval.fm_index_generate_joint = timed("decode_ms", orig_joint)
     rk.rescore_keys = timed("rescore_ms", orig[1])
     rk.rescore_keys_multi = timed("rescore_ms", orig_multi)      # the searcher's rescorings of a batch: one forward
     rk.compute_unigram_scores = timed("unigram_ms", orig[2])
@@ -645,7 +666,7 @@ def main():
     else:
         run_batch(args.warmup + args.steps)
     retrieval.fm_index_generate, rk.rescore_keys, rk.compute_unigram_scores, rk.aggregate_evidence_batch, retrieval._count_filter = orig
-    rk.rescore_keys_multi = orig_multi
+    rk.rescore_keys_multi, retrieval.fm_index_generate_joint = orig_multi, orig_joint
     import ctypes as C
     l2, k2 = C.c_uint64(0), C.c_double(0.0)
     for hd in handles:
@@ -763,6 +784,7 @@ def main():
         # the suffix array itself, independently of the builder (the oracle above is fed this index's own BWT / SA samples)
         audit = sa_audit(index)
         audit["text_equals_input_corpus"] = text_is_input
+        audit["values"] = audit["adjacent_suffix_pairs"] + audit["lf_rows"]
         audit["mismatches"] += 0 if text_is_input else 1
         parity["by_kind"]["suffix_array_audit"] = audit
         parity["ops"] += 3; parity["values_compared"] += audit["adjacent_suffix_pairs"] + audit["lf_rows"]; parity["mismatches"] += audit["mismatches"]
@@ -802,6 +824,7 @@ def main():
                                f"BART-large fp32, beam={args.beam}, batch={args.batch} per GPU, body len 10 + title len<=15, "
                                f"{'first-stage retrieval' if args.first_stage_only else 'first stage + full-document rescoring of 1500 docs/query'}, top-{args.topk}",
                    "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated; " + ("next batch's decodes enqueued ahead of this batch's rescoring/aggregation (2 streams)" if not args.no_overlap and args.pipeline <= 1 else f"{args.pipeline} query batches in flight per GPU"), "model_arithmetic": "fp32 (as the reference runs BART)",
+                   "decodes": "body + title of a batch as two loops" if args.no_joint_decode else "body + title of a batch as ONE loop (2 x batch x beams rows per model step, one constraint launch per step)",
                    "query_ngram_keys": "off" if args.no_query_keys else "token 1..3-grams of the query ids (add_query_to_keys=True, the reference's default; "
                                                                                  "spaCy/BART tokenizer absent offline: seal_amd.query_keys.token_ngram_keys)",
                    "not_in_step": (["full-document rescoring (keys.py:366-497)"] if args.first_stage_only else []) +

@@ -1,5 +1,7 @@
 /*
- * sealnn.h -- fused fp32 decoder-step kernels for the BART step decoder (gfx950), part of libsealfm.so.
+ * sealnn.h -- fused decoder-step kernels for the BART step decoder (gfx950), part of libsealfm.so: fp32 storage (the
+ * arithmetic the reference runs BART in) and, with the suffix _bf16, bf16 storage (BASELINE.json configs[4]) -- the same
+ * kernels instantiated for 2-byte elements: loads widen to fp32, every product / sum / softmax is fp32, stores round.
  * They replace runs of small PyTorch kernels inside seal_amd/bart_decoder.py's hipGraph-captured step
  * (the reference drives HF's BartDecoderLayer through generate(); reference seal/beam_search.py:231-238).
  * Device pointers + hipStream_t (as void*), no allocation, no synchronisation: capture-safe.
@@ -49,6 +51,21 @@ int sealnn_cross_attn_rows(void *stream, const float *q, const float *ck, const 
  * first row of every run; rows % group == 0): K/V of a (run, head) are staged in LDS once.  Bit-identical results. */
 int sealnn_cross_attn_runs(void *stream, const float *q, const float *ck, const float *cv, const float *bias,
                            const int32_t *row_batch, uint32_t rows, uint32_t group, uint32_t heads, uint32_t S, float scale, float *out);
+
+/* ---- bf16 storage: same shapes and meaning, every tensor argument (incl. gamma / beta / bias) bf16 ---- */
+int sealnn_self_attn_step_bf16(void *stream, const void *qkv, void *kcache, void *vcache, const int64_t *d_t,
+                               uint32_t rows, uint32_t heads, uint32_t T, float scale, void *out, int32_t *anc);
+int sealnn_cross_attn_step_bf16(void *stream, const void *q, const void *ck, const void *cv, const void *bias,
+                                uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S, float scale, void *out);
+int sealnn_add_layernorm_bf16(void *stream, const void *x, const void *y, const void *gamma, const void *beta,
+                              uint32_t rows, uint32_t d, float eps, void *out);
+int sealnn_causal_self_attn_bf16(void *stream, const void *qkv, uint32_t n_seq, uint32_t T, uint32_t heads, float scale, void *out);
+int sealnn_tree_self_attn_bf16(void *stream, const void *qkv, const int32_t *anc, uint32_t n_nodes, uint32_t max_depth1, uint32_t heads,
+                               float scale, void *out);
+int sealnn_cross_attn_rows_bf16(void *stream, const void *q, const void *ck, const void *cv, const void *bias,
+                                const int32_t *row_batch, uint32_t rows, uint32_t heads, uint32_t S, float scale, void *out);
+int sealnn_cross_attn_runs_bf16(void *stream, const void *q, const void *ck, const void *cv, const void *bias,
+                                const int32_t *row_batch, uint32_t rows, uint32_t group, uint32_t heads, uint32_t S, float scale, void *out);
 
 #ifdef __cplusplus
 }

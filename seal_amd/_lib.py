@@ -103,6 +103,13 @@ NN_SIGNATURES = {
     "sealnn_tree_self_attn": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp]),
     "sealnn_cross_attn_rows": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp]),
     "sealnn_cross_attn_runs": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _vp]),
+    "sealnn_self_attn_step_bf16": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp, _vp]),
+    "sealnn_cross_attn_step_bf16": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _vp]),
+    "sealnn_add_layernorm_bf16": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp]),
+    "sealnn_causal_self_attn_bf16": (_int, [_vp, _vp, _u32, _u32, _u32, _f32, _vp]),
+    "sealnn_tree_self_attn_bf16": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp]),
+    "sealnn_cross_attn_rows_bf16": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp]),
+    "sealnn_cross_attn_runs_bf16": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _vp]),
 }
 
 _lib = None

@@ -117,6 +117,20 @@ class BartStepDecoder:
         # (bench.py shapes a random-init model's preferences towards corpus n-grams with it)
         self.logit_bias: Optional[torch.Tensor] = None
 
+    @staticmethod
+    def _nn(dtype):
+        """the fused kernels of include/sealnn.h for a storage dtype: ``nn.self_attn_step`` = ``sealnn_self_attn_step[_bf16]``"""
+        from ._lib import lib
+        L_ = lib()
+        suffix = "" if dtype == torch.float32 else "_bf16"
+
+        class _NN:
+            def __getattr__(self, name):
+                return getattr(L_, "sealnn_" + name + suffix)
+        return _NN()
+
+    FUSED_DTYPES = (torch.float32, torch.bfloat16)
+
     def clone_for_pipeline(self) -> "BartStepDecoder":
         """a decoder over the SAME weights with its own static buffers / captured graphs / decode position: one per
         concurrent query-batch pipeline (the buffers of a shape are reused by every decode of that shape, so two
@@ -195,7 +209,7 @@ class BartStepDecoder:
     # and every decoder row points at its query.
     # ------------------------------------------------------------------
     def can_teacher_force(self, enc_hidden: torch.Tensor, T: int) -> bool:
-        return (self.use_fused_kernels and enc_hidden.is_cuda and enc_hidden.dtype == torch.float32 and self.dh == 64
+        return (self.use_fused_kernels and enc_hidden.is_cuda and enc_hidden.dtype in self.FUSED_DTYPES and self.dh == 64
                 and T <= 17 and enc_hidden.shape[1] <= 64)
 
     @torch.no_grad()
@@ -213,9 +227,9 @@ class BartStepDecoder:
     @torch.no_grad()
     def teacher_logits(self, dec_ids: torch.Tensor, qidx: torch.Tensor, prepared) -> torch.Tensor:
         """decoder input ids [N, T] (row n belongs to query qidx[n]) -> logits [N, T, vocab]"""
-        from ._lib import check, lib
-        L_ = lib()
+        from ._lib import check
         cross, bias, S = prepared
+        L_ = self._nn(bias.dtype)
         N, T = dec_ids.shape
         dev = dec_ids.device
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -225,20 +239,20 @@ class BartStepDecoder:
 
         def add_ln(res, y, ln):
             out = torch.empty_like(res)
-            check(L_.sealnn_add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
-                                          N * T, self.d, float(ln.eps), out.data_ptr()))
+            check(L_.add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                   N * T, self.d, float(ln.eps), out.data_ptr()))
             return out
         for li, L in enumerate(self.layers):
             qkv = F.linear(x, L["qkv_w"], L["qkv_b"])
             a = torch.empty(N * T, self.d, dtype=x.dtype, device=dev)
-            check(L_.sealnn_causal_self_attn(stream, qkv.data_ptr(), N, T, self.h, float(self.scale), a.data_ptr()))
+            check(L_.causal_self_attn(stream, qkv.data_ptr(), N, T, self.h, float(self.scale), a.data_ptr()))
             x = add_ln(x, L["so"](a), L["ln1"])
             q = L["cq"](x)
             c = torch.empty(N * T, self.d, dtype=x.dtype, device=dev)
             ck, cv = cross[li]
             # the T positions of a sequence attend the same query: one staging of its K/V per (sequence, head)
-            check(L_.sealnn_cross_attn_runs(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
-                                            N * T, T, self.h, S, float(self.scale), c.data_ptr()))
+            check(L_.cross_attn_runs(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
+                                     N * T, T, self.h, S, float(self.scale), c.data_ptr()))
             x = add_ln(x, L["co"](c), L["ln2"])
             x = add_ln(x, L["fc2"](L["act"](L["fc1"](x))), L["ln3"])
         return F.linear(x, self.lm_w, self.lm_b.view(-1)).view(N, T, -1)
@@ -256,9 +270,9 @@ class BartStepDecoder:
         x = self.embed(tok) + self.pos.weight[self.pos_offset + depth]
         x = self.ln_emb(x)
         if prepared is not None:
-            from ._lib import check, lib
-            L_ = lib()
+            from ._lib import check
             cross, bias, S = prepared
+            L_ = self._nn(bias.dtype)
             stream = torch.cuda.current_stream(dev).cuda_stream
             anc32 = anc.to(torch.int32).contiguous()
             row_batch = qidx.to(torch.int32).contiguous()
@@ -266,19 +280,19 @@ class BartStepDecoder:
 
             def add_ln(res, y, ln):
                 out = torch.empty_like(res)
-                check(L_.sealnn_add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
-                                              N, self.d, float(ln.eps), out.data_ptr()))
+                check(L_.add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                       N, self.d, float(ln.eps), out.data_ptr()))
                 return out
             for li, L in enumerate(self.layers):
                 qkv = F.linear(x, L["qkv_w"], L["qkv_b"])
                 a = torch.empty(N, self.d, dtype=x.dtype, device=dev)
-                check(L_.sealnn_tree_self_attn(stream, qkv.data_ptr(), anc32.data_ptr(), N, A, self.h, float(self.scale), a.data_ptr()))
+                check(L_.tree_self_attn(stream, qkv.data_ptr(), anc32.data_ptr(), N, A, self.h, float(self.scale), a.data_ptr()))
                 x = add_ln(x, L["so"](a), L["ln1"])
                 q = L["cq"](x)
                 c = torch.empty(N, self.d, dtype=x.dtype, device=dev)
                 ck, cv = cross[li]
-                check(L_.sealnn_cross_attn_rows(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
-                                                N, self.h, S, float(self.scale), c.data_ptr()))
+                check(L_.cross_attn_rows(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
+                                         N, self.h, S, float(self.scale), c.data_ptr()))
                 x = add_ln(x, L["co"](c), L["ln2"])
                 x = add_ln(x, L["fc2"](L["act"](L["fc1"](x))), L["ln3"])
             return F.linear(x, self.lm_w, self.lm_b.view(-1))
@@ -313,35 +327,35 @@ class BartStepDecoder:
         x = self.embed(st.tokens)
         x = x + self.pos.weight.index_select(0, st.t + self.pos_offset)
         x = self.ln_emb(x)
-        fused = (self.use_fused_kernels and x.dtype == torch.float32 and dh == 64 and T <= 17 and S_pad <= 64 and x.is_cuda)
+        fused = (self.use_fused_kernels and x.dtype in self.FUSED_DTYPES and dh == 64 and T <= 17 and S_pad <= 64 and x.is_cuda)
         st.fused = fused
         if not fused and x.is_cuda and self.use_fused_kernels and not self.__dict__.get("_fallback_logged"):
             # the limits of the fused sealnn_* step kernels, said once instead of silently running ~6x more launches
             self._fallback_logged = True
             logger.warning("BartStepDecoder: decode of shape (batch %d, beams %d, encoder length %d, %d positions, %s, head_dim %d) runs on the "
-                           "torch-op path: the fused step kernels need fp32, head_dim 64, <= 17 decoder positions and <= 64 encoder tokens",
+                           "torch-op path: the fused step kernels need fp32 or bf16, head_dim 64, <= 17 decoder positions and <= 64 encoder tokens",
                            B, K, S_pad, T, str(x.dtype).replace("torch.", ""), dh)
         if fused:
-            from ._lib import check, lib
-            L_ = lib()
+            from ._lib import check
+            L_ = self._nn(x.dtype)
             stream = torch.cuda.current_stream(x.device).cuda_stream
             cbias = st.cbias.view(B, S_pad)
 
             def add_ln(res, y, ln):
                 out = torch.empty_like(res)
-                check(L_.sealnn_add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
-                                              R, self.d, float(ln.eps), out.data_ptr()))
+                check(L_.add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                       R, self.d, float(ln.eps), out.data_ptr()))
                 return out
             for li, L in enumerate(self.layers):
                 qkv = F.linear(x, L["qkv_w"], L["qkv_b"])
                 a = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
-                check(L_.sealnn_self_attn_step(stream, qkv.data_ptr(), st.kv[li, 0].data_ptr(), st.kv[li, 1].data_ptr(),
-                                               st.t.data_ptr(), R, H, T, float(self.scale), a.data_ptr(), st.anc.data_ptr()))
+                check(L_.self_attn_step(stream, qkv.data_ptr(), st.kv[li, 0].data_ptr(), st.kv[li, 1].data_ptr(),
+                                        st.t.data_ptr(), R, H, T, float(self.scale), a.data_ptr(), st.anc.data_ptr()))
                 x = add_ln(x, L["so"](a), L["ln1"])
                 q = L["cq"](x)
                 c = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
-                check(L_.sealnn_cross_attn_step(stream, q.data_ptr(), st.ck[li].data_ptr(), st.cv[li].data_ptr(), cbias.data_ptr(),
-                                                B, K, H, S_pad, float(self.scale), c.data_ptr()))
+                check(L_.cross_attn_step(stream, q.data_ptr(), st.ck[li].data_ptr(), st.cv[li].data_ptr(), cbias.data_ptr(),
+                                         B, K, H, S_pad, float(self.scale), c.data_ptr()))
                 x = add_ln(x, L["co"](c), L["ln2"])
                 x = add_ln(x, L["fc2"](L["act"](L["fc1"](x))), L["ln3"])
             st.t.add_(1)

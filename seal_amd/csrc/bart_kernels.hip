@@ -1,12 +1,38 @@
-// Fused fp32 kernels of the BART step decoder (include/sealnn.h).  Shapes are tiny (one new
+// Fused kernels of the BART step decoder (include/sealnn.h).  Shapes are tiny (one new
 // position, <= 16 cached positions, <= 64 encoder positions, head_dim 64): the point is to replace
 // ~17 launch-bound PyTorch kernels per decoder layer with 3, not to reach a roofline.
+// Every kernel is a template over the STORAGE type (fp32 as the reference runs BART; bf16 for BASELINE.json's
+// configs[4]): loads widen to fp32, all arithmetic and every accumulation is fp32, stores round to nearest even.
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
 
 #include <algorithm>
 
 #include "../../include/sealnn.h"
 #include "fmi_internal.h"
+
+typedef __hip_bfloat16 bf16;
+template <typename T> static __device__ __forceinline__ float ldf(const T *p);
+template <> __device__ __forceinline__ float ldf<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16>(const bf16 *p) { return __bfloat162float(*p); }
+template <typename T> static __device__ __forceinline__ void stf(T *p, float v);
+template <> __device__ __forceinline__ void stf<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16>(bf16 *p, float v) { *p = __float2bfloat16(v); }
+// elements 4i .. 4i+3 of a row (16-byte / 8-byte aligned): one vector load
+template <typename T> static __device__ __forceinline__ float4 ld4(const T *row, uint32_t i);
+template <> __device__ __forceinline__ float4 ld4<float>(const float *row, uint32_t i) { return reinterpret_cast<const float4 *>(row)[i]; }
+template <> __device__ __forceinline__ float4 ld4<bf16>(const bf16 *row, uint32_t i)
+{
+    const uint2 w = reinterpret_cast<const uint2 *>(row)[i];
+    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u));
+}
+template <typename T> static __device__ __forceinline__ void st4(T *row, uint32_t i, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float *row, uint32_t i, float4 v) { reinterpret_cast<float4 *>(row)[i] = v; }
+template <> __device__ __forceinline__ void st4<bf16>(bf16 *row, uint32_t i, float4 v)
+{
+    bf16 *o = row + 4 * (uint64_t)i;
+    o[0] = __float2bfloat16(v.x); o[1] = __float2bfloat16(v.y); o[2] = __float2bfloat16(v.z); o[3] = __float2bfloat16(v.w);
+}
 
 static __device__ __forceinline__ float wave_sum(float v)
 {
@@ -28,8 +54,9 @@ static __device__ __forceinline__ float wave_max(float v)
 // one wavefront per (row, head); lane = head dimension.  `anc` (optional, [T][rows]): the cache is
 // never reordered when beams are re-ranked; instead anc[p][row] names the row whose slot at position p
 // belongs to `row`'s history (the decoder permutes this 20 KB table, not the 100+ MB cache).
-__global__ __launch_bounds__(256) void k_self_attn_step(const float *qkv, float *kcache, float *vcache, const int64_t *d_t,
-                                                        uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out,
+template <typename T_>
+__global__ __launch_bounds__(256) void k_self_attn_step(const T_ *qkv, T_ *kcache, T_ *vcache, const int64_t *d_t,
+                                                        uint32_t rows, uint32_t heads, uint32_t T, float scale, T_ *out,
                                                         int32_t *anc)
 {
     const uint32_t lane = threadIdx.x & 63;
@@ -37,21 +64,21 @@ __global__ __launch_bounds__(256) void k_self_attn_step(const float *qkv, float 
     if (item >= rows * heads) return;
     const uint32_t row = item / heads, head = item % heads;
     const uint32_t t = (uint32_t)*d_t;
-    const float *base = qkv + ((uint64_t)row * 3 * heads + head) * 64;
-    const float q = base[lane] * scale;
-    const float kn = base[(uint64_t)heads * 64 + lane];
-    const float vn = base[(uint64_t)2 * heads * 64 + lane];
-    float *kc = kcache + ((uint64_t)row * heads + head) * T * 64;
-    float *vc = vcache + ((uint64_t)row * heads + head) * T * 64;
-    kc[(uint64_t)t * 64 + lane] = kn;
-    vc[(uint64_t)t * 64 + lane] = vn;
+    const T_ *base = qkv + ((uint64_t)row * 3 * heads + head) * 64;
+    const float q = ldf(base + lane) * scale;
+    const float kn = ldf(base + (uint64_t)heads * 64 + lane);       // (bf16: already the value the cache will hold)
+    const float vn = ldf(base + (uint64_t)2 * heads * 64 + lane);
+    T_ *kc = kcache + ((uint64_t)row * heads + head) * T * 64;
+    T_ *vc = vcache + ((uint64_t)row * heads + head) * T * 64;
+    stf(kc + (uint64_t)t * 64 + lane, kn);
+    stf(vc + (uint64_t)t * 64 + lane, vn);
     if (anc && head == 0 && lane == 0) anc[(uint64_t)t * rows + row] = (int32_t)row;
     // scores over positions 0..t (the new one from registers)
     float s[FMI_MAX_LEVELS];          // T <= 17 positions kept in registers
     float m = -__builtin_huge_valf();
     for (uint32_t p = 0; p <= t; p++) {
         const uint64_t src = anc ? ((uint64_t)anc[(uint64_t)p * rows + row] * heads + head) * T * 64 : ((uint64_t)row * heads + head) * T * 64;
-        const float kv = (p == t) ? kn : kcache[src + (uint64_t)p * 64 + lane];
+        const float kv = (p == t) ? kn : ldf(kcache + src + (uint64_t)p * 64 + lane);
         const float d = wave_sum(q * kv);
         s[p] = d;
         m = fmaxf(m, d);
@@ -61,29 +88,30 @@ __global__ __launch_bounds__(256) void k_self_attn_step(const float *qkv, float 
         const float e = expf(s[p] - m);
         denom += e;
         const uint64_t src = anc ? ((uint64_t)anc[(uint64_t)p * rows + row] * heads + head) * T * 64 : ((uint64_t)row * heads + head) * T * 64;
-        const float vv = (p == t) ? vn : vcache[src + (uint64_t)p * 64 + lane];
+        const float vv = (p == t) ? vn : ldf(vcache + src + (uint64_t)p * 64 + lane);
         acc += e * vv;
     }
-    out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
+    stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, acc / denom);
 }
 
 // one workgroup per (query, head): the encoder K [64, S] and V [S, 64] of that head are staged in LDS once
 // and shared by the query's beams (one wavefront per beam; scores: lane = encoder position, output: lane = dim)
-__global__ __launch_bounds__(1024) void k_cross_attn_step(const float *q, const float *ck, const float *cv, const float *bias,
+template <typename T_>
+__global__ __launch_bounds__(1024) void k_cross_attn_step(const T_ *q, const T_ *ck, const T_ *cv, const T_ *bias,
                                                           uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S, float scale,
-                                                          float *out)
+                                                          T_ *out)
 {
     __shared__ float s_k[64 * 64], s_v[64 * 64];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint32_t b = blockIdx.x / heads, head = blockIdx.x % heads;
-    const float *k = ck + ((uint64_t)b * heads + head) * 64 * S;      // [64, S]
-    const float *v = cv + ((uint64_t)b * heads + head) * S * 64;      // [S, 64]
-    for (uint32_t i = threadIdx.x; i < 64 * S; i += blockDim.x) { s_k[i] = k[i]; s_v[i] = v[i]; }
+    const T_ *k = ck + ((uint64_t)b * heads + head) * 64 * S;      // [64, S]
+    const T_ *v = cv + ((uint64_t)b * heads + head) * S * 64;      // [S, 64]
+    for (uint32_t i = threadIdx.x; i < 64 * S; i += blockDim.x) { s_k[i] = ldf(k + i); s_v[i] = ldf(v + i); }
     __syncthreads();
-    const float bi = lane < S ? bias[(uint64_t)b * S + lane] : 0.f;
+    const float bi = lane < S ? ldf(bias + (uint64_t)b * S + lane) : 0.f;
     for (uint32_t beam = wv; beam < beams; beam += nw) {
         const uint32_t row = b * beams + beam;
-        const float qd = q[((uint64_t)row * heads + head) * 64 + lane] * scale;
+        const float qd = ldf(q + ((uint64_t)row * heads + head) * 64 + lane) * scale;
         float sc = 0.f;
         for (uint32_t d = 0; d < 64; d++) {
             const float qv = lane_value(qd, d);
@@ -95,33 +123,34 @@ __global__ __launch_bounds__(1024) void k_cross_attn_step(const float *q, const 
         const float denom = wave_sum(e);
         float acc = 0.f;
         for (uint32_t p = 0; p < S; p++) acc += lane_value(e, p) * s_v[p * 64 + lane];
-        out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
+        stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, acc / denom);
     }
 }
 
 // teacher-forced causal self-attention over T positions: one wavefront per (sequence, head); lane = dim
-__global__ __launch_bounds__(256) void k_causal_self_attn(const float *qkv, uint32_t n_seq, uint32_t T, uint32_t heads, float scale,
-                                                          float *out)
+template <typename T_>
+__global__ __launch_bounds__(256) void k_causal_self_attn(const T_ *qkv, uint32_t n_seq, uint32_t T, uint32_t heads, float scale,
+                                                          T_ *out)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_seq * heads) return;
     const uint32_t n = item / heads, head = item % heads;
     const uint64_t stride = (uint64_t)3 * heads * 64;               // per position
-    const float *base = qkv + (uint64_t)n * T * stride + head * 64;
+    const T_ *base = qkv + (uint64_t)n * T * stride + head * 64;
     float kreg[FMI_MAX_LEVELS], vreg[FMI_MAX_LEVELS];
     for (uint32_t j = 0; j < T; j++) {
-        kreg[j] = base[(uint64_t)j * stride + (uint64_t)heads * 64 + lane];
-        vreg[j] = base[(uint64_t)j * stride + (uint64_t)2 * heads * 64 + lane];
+        kreg[j] = ldf(base + (uint64_t)j * stride + (uint64_t)heads * 64 + lane);
+        vreg[j] = ldf(base + (uint64_t)j * stride + (uint64_t)2 * heads * 64 + lane);
     }
     for (uint32_t i = 0; i < T; i++) {
-        const float q = base[(uint64_t)i * stride + lane] * scale;
+        const float q = ldf(base + (uint64_t)i * stride + lane) * scale;
         float s[FMI_MAX_LEVELS];
         float m = -__builtin_huge_valf();
         for (uint32_t j = 0; j <= i; j++) { s[j] = wave_sum(q * kreg[j]); m = fmaxf(m, s[j]); }
         float denom = 0.f, acc = 0.f;
         for (uint32_t j = 0; j <= i; j++) { const float e = expf(s[j] - m); denom += e; acc += e * vreg[j]; }
-        out[((uint64_t)n * T + i) * heads * 64 + head * 64 + lane] = acc / denom;
+        stf(out + ((uint64_t)n * T + i) * heads * 64 + head * 64 + lane, acc / denom);
     }
 }
 
@@ -129,15 +158,16 @@ __global__ __launch_bounds__(256) void k_causal_self_attn(const float *qkv, uint
 // its ancestors and itself, anc[node][0 .. depth]: node indices from the root down, -1 beyond the node's depth.  One
 // wavefront per (node, head); lane = dim.  Same arithmetic in the same order as k_causal_self_attn does for position
 // `depth` of a row holding that prefix.
-__global__ __launch_bounds__(256) void k_tree_self_attn(const float *qkv, const int32_t *anc, uint32_t n_nodes, uint32_t A, uint32_t heads,
-                                                        float scale, float *out)
+template <typename T_>
+__global__ __launch_bounds__(256) void k_tree_self_attn(const T_ *qkv, const int32_t *anc, uint32_t n_nodes, uint32_t A, uint32_t heads,
+                                                        float scale, T_ *out)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_nodes * heads) return;
     const uint32_t node = item / heads, head = item % heads;
     const uint64_t stride = (uint64_t)3 * heads * 64;               // per node
-    const float q = qkv[(uint64_t)node * stride + head * 64 + lane] * scale;
+    const float q = ldf(qkv + (uint64_t)node * stride + head * 64 + lane) * scale;
     const int32_t *mine = anc + (uint64_t)node * A;
     float s[FMI_MAX_LEVELS], vreg[FMI_MAX_LEVELS];
     float m = -__builtin_huge_valf();
@@ -147,9 +177,9 @@ __global__ __launch_bounds__(256) void k_tree_self_attn(const float *qkv, const 
         s[j] = 0.f; vreg[j] = 0.f;
         const int32_t a = j < A ? mine[j] : -1;
         if (a >= 0 && cnt == j) {
-            const float *row = qkv + (uint64_t)a * stride + head * 64 + lane;
-            const float k = row[(uint64_t)heads * 64];
-            vreg[j] = row[(uint64_t)2 * heads * 64];
+            const T_ *row = qkv + (uint64_t)a * stride + head * 64 + lane;
+            const float k = ldf(row + (uint64_t)heads * 64);
+            vreg[j] = ldf(row + (uint64_t)2 * heads * 64);
             s[j] = wave_sum(q * k);
             m = fmaxf(m, s[j]);
             cnt = j + 1;
@@ -159,42 +189,44 @@ __global__ __launch_bounds__(256) void k_tree_self_attn(const float *qkv, const 
 #pragma unroll
     for (uint32_t j = 0; j < FMI_MAX_LEVELS; j++)
         if (j < cnt) { const float e = expf(s[j] - m); denom += e; acc += e * vreg[j]; }
-    out[(uint64_t)node * heads * 64 + head * 64 + lane] = acc / denom;
+    stf(out + (uint64_t)node * heads * 64 + head * 64 + lane, acc / denom);
 }
 
 // cross-attention for arbitrary rows: row_batch[row] selects the query whose encoder K/V to use
-__global__ __launch_bounds__(256) void k_cross_attn_rows(const float *q, const float *ck, const float *cv, const float *bias,
+template <typename T_>
+__global__ __launch_bounds__(256) void k_cross_attn_rows(const T_ *q, const T_ *ck, const T_ *cv, const T_ *bias,
                                                          const int32_t *row_batch, uint32_t rows, uint32_t heads, uint32_t S,
-                                                         float scale, float *out)
+                                                         float scale, T_ *out)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= rows * heads) return;
     const uint32_t row = item / heads, head = item % heads, b = (uint32_t)row_batch[row];
-    const float qd = q[((uint64_t)row * heads + head) * 64 + lane] * scale;
-    const float *k = ck + ((uint64_t)b * heads + head) * 64 * S;
-    const float *v = cv + ((uint64_t)b * heads + head) * S * 64;
+    const float qd = ldf(q + ((uint64_t)row * heads + head) * 64 + lane) * scale;
+    const T_ *k = ck + ((uint64_t)b * heads + head) * 64 * S;
+    const T_ *v = cv + ((uint64_t)b * heads + head) * S * 64;
     float sc = 0.f;
     for (uint32_t d = 0; d < 64; d++) {
         const float qv = lane_value(qd, d);
-        if (lane < S) sc += qv * k[(uint64_t)d * S + lane];
+        if (lane < S) sc += qv * ldf(k + (uint64_t)d * S + lane);
     }
-    sc = lane < S ? sc + bias[(uint64_t)b * S + lane] : -__builtin_huge_valf();
+    sc = lane < S ? sc + ldf(bias + (uint64_t)b * S + lane) : -__builtin_huge_valf();
     const float m = wave_max(sc);
     const float e = lane < S ? expf(sc - m) : 0.f;
     const float denom = wave_sum(e);
     float acc = 0.f;
-    for (uint32_t p = 0; p < S; p++) acc += lane_value(e, p) * v[(uint64_t)p * 64 + lane];
-    out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
+    for (uint32_t p = 0; p < S; p++) acc += lane_value(e, p) * ldf(v + (uint64_t)p * 64 + lane);
+    stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, acc / denom);
 }
 
 // the same for rows that come in runs of `group` consecutive rows attending the same query (teacher forcing: the T
 // positions of a sequence): one workgroup per (run, head) stages that head's K [64, S] and V [S, 64] in LDS once and its
 // four waves walk the run's rows -- the keys and values are read from L2 once per run instead of once per row.  Same
 // arithmetic, in the same order, as k_cross_attn_rows.
-__global__ __launch_bounds__(512) void k_cross_attn_runs(const float *q, const float *ck, const float *cv, const float *bias,
+template <typename T_>
+__global__ __launch_bounds__(512) void k_cross_attn_runs(const T_ *q, const T_ *ck, const T_ *cv, const T_ *bias,
                                                          const int32_t *row_batch, uint32_t rows, uint32_t group, uint32_t heads,
-                                                         uint32_t S, float scale, float *out)
+                                                         uint32_t S, float scale, T_ *out)
 {
     extern __shared__ float s_kv[];                 // K [64, S] then V [S, 64]: 512 S bytes, so that several runs share a CU
     float *s_k = s_kv, *s_v = s_kv + 64 * S;
@@ -202,15 +234,15 @@ __global__ __launch_bounds__(512) void k_cross_attn_runs(const float *q, const f
     const uint32_t run = blockIdx.x / heads, head = blockIdx.x % heads;
     const uint32_t row0 = run * group;
     const uint32_t b = (uint32_t)row_batch[row0];
-    const float *k = ck + ((uint64_t)b * heads + head) * 64 * S;
-    const float *v = cv + ((uint64_t)b * heads + head) * S * 64;
-    for (uint32_t i = threadIdx.x; i < 64 * S; i += blockDim.x) { s_k[i] = k[i]; s_v[i] = v[i]; }
+    const T_ *k = ck + ((uint64_t)b * heads + head) * 64 * S;
+    const T_ *v = cv + ((uint64_t)b * heads + head) * S * 64;
+    for (uint32_t i = threadIdx.x; i < 64 * S; i += blockDim.x) { s_k[i] = ldf(k + i); s_v[i] = ldf(v + i); }
     // this wave's rows: their queries are fetched while the staging loads are in flight
-    const float bi = lane < S ? bias[(uint64_t)b * S + lane] : 0.f;
+    const float bi = lane < S ? ldf(bias + (uint64_t)b * S + lane) : 0.f;
     __syncthreads();
     for (uint32_t t = wv; t < group && row0 + t < rows; t += nw) {
         const uint32_t row = row0 + t;
-        const float qd = q[((uint64_t)row * heads + head) * 64 + lane] * scale;
+        const float qd = ldf(q + ((uint64_t)row * heads + head) * 64 + lane) * scale;
         float sc = 0.f;
 #pragma unroll 16
         for (uint32_t d = 0; d < 64; d++) {
@@ -224,19 +256,19 @@ __global__ __launch_bounds__(512) void k_cross_attn_runs(const float *q, const f
         float acc = 0.f;
 #pragma unroll 8
         for (uint32_t p = 0; p < S; p++) acc += lane_value(e, p) * s_v[p * 64 + lane];
-        out[(uint64_t)row * heads * 64 + head * 64 + lane] = acc / denom;
+        stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, acc / denom);
     }
 }
 
 // one wavefront per row, d <= 4096 (16 float4 per lane)
-__global__ __launch_bounds__(256) void k_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta,
-                                                       uint32_t rows, uint32_t d, float eps, float *out)
+template <typename T_>
+__global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y, const T_ *gamma, const T_ *beta,
+                                                       uint32_t rows, uint32_t d, float eps, T_ *out)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float4 *xr = reinterpret_cast<const float4 *>(x + (uint64_t)row * d);
-    const float4 *yr = reinterpret_cast<const float4 *>(y + (uint64_t)row * d);
+    const T_ *xr = x + (uint64_t)row * d, *yr = y + (uint64_t)row * d;
     const uint32_t n4 = d / 4;
     float4 v[16];                                    // fully unrolled below: registers, not scratch
     float sum = 0.f;
@@ -245,7 +277,7 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const float *x, const flo
         const uint32_t i = lane + 64 * j;
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < n4) {
-            const float4 a = xr[i], b = yr[i];
+            const float4 a = ld4(xr, i), b = ld4(yr, i);
             v[j] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
             sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         }
@@ -260,90 +292,150 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const float *x, const flo
         }
     }
     const float rstd = rsqrtf(wave_sum(var) / (float)d + eps);
-    const float4 *g4 = reinterpret_cast<const float4 *>(gamma), *b4 = reinterpret_cast<const float4 *>(beta);
-    float4 *o4 = reinterpret_cast<float4 *>(out + (uint64_t)row * d);
+    T_ *orow = out + (uint64_t)row * d;
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) {
         const uint32_t i = lane + 64 * j;
         if (i < n4) {
-            const float4 g = g4[i], bb = b4[i];
-            o4[i] = make_float4((v[j].x - mean) * rstd * g.x + bb.x, (v[j].y - mean) * rstd * g.y + bb.y,
-                                (v[j].z - mean) * rstd * g.z + bb.z, (v[j].w - mean) * rstd * g.w + bb.w);
+            const float4 g = ld4(gamma, i), bb = ld4(beta, i);
+            st4(orow, i, make_float4((v[j].x - mean) * rstd * g.x + bb.x, (v[j].y - mean) * rstd * g.y + bb.y,
+                                     (v[j].z - mean) * rstd * g.z + bb.z, (v[j].w - mean) * rstd * g.w + bb.w));
         }
     }
 }
 
 #define NNCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { fmi_set_error("sealnn launch failed: %s", hipGetErrorString(e_)); return FMI_ERR_HIP; } } while (0)
 
-extern "C" int sealnn_self_attn_step(void *stream, const float *qkv, float *kcache, float *vcache, const int64_t *d_t, uint32_t rows,
-                                     uint32_t heads, uint32_t T, float scale, float *out, int32_t *anc)
+template <typename T_>
+static int self_attn_step(void *stream, const void *qkv, void *kcache, void *vcache, const int64_t *d_t, uint32_t rows,
+                          uint32_t heads, uint32_t T, float scale, void *out, int32_t *anc)
 {
     if (T > FMI_MAX_LEVELS) { fmi_set_error("sealnn_self_attn_step: at most %u cached positions", FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
     const uint32_t items = rows * heads;
-    hipLaunchKernelGGL(k_self_attn_step, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, kcache, vcache, d_t, rows, heads, T, scale, out, anc);
+    hipLaunchKernelGGL(k_self_attn_step<T_>, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const T_ *)qkv, (T_ *)kcache, (T_ *)vcache,
+                       d_t, rows, heads, T, scale, (T_ *)out, anc);
     NNCHK();
     return FMI_OK;
 }
 
-extern "C" int sealnn_cross_attn_step(void *stream, const float *q, const float *ck, const float *cv, const float *bias, uint32_t batch,
-                                      uint32_t beams, uint32_t heads, uint32_t S, float scale, float *out)
+template <typename T_>
+static int cross_attn_step(void *stream, const void *q, const void *ck, const void *cv, const void *bias, uint32_t batch,
+                           uint32_t beams, uint32_t heads, uint32_t S, float scale, void *out)
 {
     if (S > 64) { fmi_set_error("sealnn_cross_attn_step: encoder length %u > 64", S); return FMI_ERR_UNSUPPORTED; }
     const uint32_t waves = beams < 16 ? beams : 16;
-    hipLaunchKernelGGL(k_cross_attn_step, dim3(batch * heads), dim3(waves * 64), 0, (hipStream_t)stream, q, ck, cv, bias, batch, beams, heads, S, scale, out);
+    hipLaunchKernelGGL(k_cross_attn_step<T_>, dim3(batch * heads), dim3(waves * 64), 0, (hipStream_t)stream, (const T_ *)q, (const T_ *)ck,
+                       (const T_ *)cv, (const T_ *)bias, batch, beams, heads, S, scale, (T_ *)out);
     NNCHK();
     return FMI_OK;
 }
 
-extern "C" int sealnn_add_layernorm(void *stream, const float *x, const float *y, const float *gamma, const float *beta, uint32_t rows,
-                                    uint32_t d, float eps, float *out)
+template <typename T_>
+static int add_layernorm(void *stream, const void *x, const void *y, const void *gamma, const void *beta, uint32_t rows,
+                         uint32_t d, float eps, void *out)
 {
     if (d % 4 || d > 4096) { fmi_set_error("sealnn_add_layernorm: d=%u unsupported", d); return FMI_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(k_add_layernorm, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta, rows, d, eps, out);
+    hipLaunchKernelGGL(k_add_layernorm<T_>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const T_ *)x, (const T_ *)y,
+                       (const T_ *)gamma, (const T_ *)beta, rows, d, eps, (T_ *)out);
     NNCHK();
     return FMI_OK;
 }
 
-extern "C" int sealnn_causal_self_attn(void *stream, const float *qkv, uint32_t n_seq, uint32_t T, uint32_t heads, float scale, float *out)
+template <typename T_>
+static int causal_self_attn(void *stream, const void *qkv, uint32_t n_seq, uint32_t T, uint32_t heads, float scale, void *out)
 {
     if (T > FMI_MAX_LEVELS) { fmi_set_error("sealnn_causal_self_attn: at most %u positions", FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
     const uint32_t items = n_seq * heads;
-    hipLaunchKernelGGL(k_causal_self_attn, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, n_seq, T, heads, scale, out);
+    hipLaunchKernelGGL(k_causal_self_attn<T_>, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const T_ *)qkv, n_seq, T, heads, scale, (T_ *)out);
     NNCHK();
     return FMI_OK;
 }
 
-extern "C" int sealnn_tree_self_attn(void *stream, const float *qkv, const int32_t *anc, uint32_t n_nodes, uint32_t max_depth1, uint32_t heads,
-                                     float scale, float *out)
+template <typename T_>
+static int tree_self_attn(void *stream, const void *qkv, const int32_t *anc, uint32_t n_nodes, uint32_t max_depth1, uint32_t heads,
+                          float scale, void *out)
 {
     if (max_depth1 > FMI_MAX_LEVELS) { fmi_set_error("sealnn_tree_self_attn: at most %u positions", FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
     const uint32_t items = n_nodes * heads;
     if (!items) return FMI_OK;
-    hipLaunchKernelGGL(k_tree_self_attn, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, anc, n_nodes, max_depth1, heads, scale, out);
+    hipLaunchKernelGGL(k_tree_self_attn<T_>, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const T_ *)qkv, anc, n_nodes, max_depth1, heads,
+                       scale, (T_ *)out);
     NNCHK();
     return FMI_OK;
 }
 
-extern "C" int sealnn_cross_attn_rows(void *stream, const float *q, const float *ck, const float *cv, const float *bias,
-                                      const int32_t *row_batch, uint32_t rows, uint32_t heads, uint32_t S, float scale, float *out)
+template <typename T_>
+static int cross_attn_rows(void *stream, const void *q, const void *ck, const void *cv, const void *bias,
+                           const int32_t *row_batch, uint32_t rows, uint32_t heads, uint32_t S, float scale, void *out)
 {
     if (S > 64) { fmi_set_error("sealnn_cross_attn_rows: encoder length %u > 64", S); return FMI_ERR_UNSUPPORTED; }
     const uint32_t items = rows * heads;
-    hipLaunchKernelGGL(k_cross_attn_rows, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, ck, cv, bias, row_batch, rows, heads, S, scale, out);
+    hipLaunchKernelGGL(k_cross_attn_rows<T_>, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const T_ *)q, (const T_ *)ck, (const T_ *)cv,
+                       (const T_ *)bias, row_batch, rows, heads, S, scale, (T_ *)out);
     NNCHK();
     return FMI_OK;
 }
 
-extern "C" int sealnn_cross_attn_runs(void *stream, const float *q, const float *ck, const float *cv, const float *bias,
-                                      const int32_t *row_batch, uint32_t rows, uint32_t group, uint32_t heads, uint32_t S, float scale,
-                                      float *out)
+template <typename T_>
+static int cross_attn_runs(void *stream, const void *q, const void *ck, const void *cv, const void *bias,
+                           const int32_t *row_batch, uint32_t rows, uint32_t group, uint32_t heads, uint32_t S, float scale, void *out)
 {
     if (S > 64) { fmi_set_error("sealnn_cross_attn_runs: encoder length %u > 64", S); return FMI_ERR_UNSUPPORTED; }
     if (group == 0 || rows % group) { fmi_set_error("sealnn_cross_attn_runs: %u rows are not runs of %u", rows, group); return FMI_ERR_ARG; }
     // one wave per position of the run, up to eight
     const unsigned threads = 64 * std::min<unsigned>(8, std::max<unsigned>(1, group));
-    hipLaunchKernelGGL(k_cross_attn_runs, dim3((rows / group) * heads), dim3(threads), (size_t)512 * S, (hipStream_t)stream, q, ck, cv, bias,
-                       row_batch, rows, group, heads, S, scale, out);
+    hipLaunchKernelGGL(k_cross_attn_runs<T_>, dim3((rows / group) * heads), dim3(threads), (size_t)512 * S, (hipStream_t)stream, (const T_ *)q,
+                       (const T_ *)ck, (const T_ *)cv, (const T_ *)bias, row_batch, rows, group, heads, S, scale, (T_ *)out);
     NNCHK();
     return FMI_OK;
 }
+
+// ---- C ABI: fp32 (the reference's arithmetic) and bf16 storage (suffix _bf16; same shapes, 2-byte elements) ----
+extern "C" int sealnn_self_attn_step(void *stream, const float *qkv, float *kcache, float *vcache, const int64_t *d_t, uint32_t rows,
+                                     uint32_t heads, uint32_t T, float scale, float *out, int32_t *anc)
+{ return self_attn_step<float>(stream, qkv, kcache, vcache, d_t, rows, heads, T, scale, out, anc); }
+extern "C" int sealnn_self_attn_step_bf16(void *stream, const void *qkv, void *kcache, void *vcache, const int64_t *d_t, uint32_t rows,
+                                          uint32_t heads, uint32_t T, float scale, void *out, int32_t *anc)
+{ return self_attn_step<bf16>(stream, qkv, kcache, vcache, d_t, rows, heads, T, scale, out, anc); }
+
+extern "C" int sealnn_cross_attn_step(void *stream, const float *q, const float *ck, const float *cv, const float *bias, uint32_t batch,
+                                      uint32_t beams, uint32_t heads, uint32_t S, float scale, float *out)
+{ return cross_attn_step<float>(stream, q, ck, cv, bias, batch, beams, heads, S, scale, out); }
+extern "C" int sealnn_cross_attn_step_bf16(void *stream, const void *q, const void *ck, const void *cv, const void *bias, uint32_t batch,
+                                           uint32_t beams, uint32_t heads, uint32_t S, float scale, void *out)
+{ return cross_attn_step<bf16>(stream, q, ck, cv, bias, batch, beams, heads, S, scale, out); }
+
+extern "C" int sealnn_add_layernorm(void *stream, const float *x, const float *y, const float *gamma, const float *beta, uint32_t rows,
+                                    uint32_t d, float eps, float *out)
+{ return add_layernorm<float>(stream, x, y, gamma, beta, rows, d, eps, out); }
+extern "C" int sealnn_add_layernorm_bf16(void *stream, const void *x, const void *y, const void *gamma, const void *beta, uint32_t rows,
+                                         uint32_t d, float eps, void *out)
+{ return add_layernorm<bf16>(stream, x, y, gamma, beta, rows, d, eps, out); }
+
+extern "C" int sealnn_causal_self_attn(void *stream, const float *qkv, uint32_t n_seq, uint32_t T, uint32_t heads, float scale, float *out)
+{ return causal_self_attn<float>(stream, qkv, n_seq, T, heads, scale, out); }
+extern "C" int sealnn_causal_self_attn_bf16(void *stream, const void *qkv, uint32_t n_seq, uint32_t T, uint32_t heads, float scale, void *out)
+{ return causal_self_attn<bf16>(stream, qkv, n_seq, T, heads, scale, out); }
+
+extern "C" int sealnn_tree_self_attn(void *stream, const float *qkv, const int32_t *anc, uint32_t n_nodes, uint32_t max_depth1, uint32_t heads,
+                                     float scale, float *out)
+{ return tree_self_attn<float>(stream, qkv, anc, n_nodes, max_depth1, heads, scale, out); }
+extern "C" int sealnn_tree_self_attn_bf16(void *stream, const void *qkv, const int32_t *anc, uint32_t n_nodes, uint32_t max_depth1, uint32_t heads,
+                                          float scale, void *out)
+{ return tree_self_attn<bf16>(stream, qkv, anc, n_nodes, max_depth1, heads, scale, out); }
+
+extern "C" int sealnn_cross_attn_rows(void *stream, const float *q, const float *ck, const float *cv, const float *bias,
+                                      const int32_t *row_batch, uint32_t rows, uint32_t heads, uint32_t S, float scale, float *out)
+{ return cross_attn_rows<float>(stream, q, ck, cv, bias, row_batch, rows, heads, S, scale, out); }
+extern "C" int sealnn_cross_attn_rows_bf16(void *stream, const void *q, const void *ck, const void *cv, const void *bias,
+                                           const int32_t *row_batch, uint32_t rows, uint32_t heads, uint32_t S, float scale, void *out)
+{ return cross_attn_rows<bf16>(stream, q, ck, cv, bias, row_batch, rows, heads, S, scale, out); }
+
+extern "C" int sealnn_cross_attn_runs(void *stream, const float *q, const float *ck, const float *cv, const float *bias,
+                                      const int32_t *row_batch, uint32_t rows, uint32_t group, uint32_t heads, uint32_t S, float scale,
+                                      float *out)
+{ return cross_attn_runs<float>(stream, q, ck, cv, bias, row_batch, rows, group, heads, S, scale, out); }
+extern "C" int sealnn_cross_attn_runs_bf16(void *stream, const void *q, const void *ck, const void *cv, const void *bias,
+                                           const int32_t *row_batch, uint32_t rows, uint32_t group, uint32_t heads, uint32_t S, float scale,
+                                           void *out)
+{ return cross_attn_runs<bf16>(stream, q, ck, cv, bias, row_batch, rows, group, heads, S, scale, out); }

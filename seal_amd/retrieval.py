@@ -139,7 +139,9 @@ class _Pipeline:
         return d
 
 
-_FM_INDEX_GENERATE = fm_index_generate      # (a caller that swaps this module's fm_index_generate for its own gets its own: no joint loop)
+# a caller that swaps this module's fm_index_generate for its own gets its own, i.e. no joint loop -- unless its stand-in
+# says ``_joint_ok`` (bench.py's phase timer wraps both entry points)
+_FM_INDEX_GENERATE = fm_index_generate
 
 
 def _count_filter(index: FMIndex, per_query: List[List]) -> List[List]:
@@ -225,7 +227,7 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
     # constraint call per step serves every decode's rows) and the reference's settings for those decodes.
     joint_kinds = []
     if (getattr(s, "joint_decode", True) and s.device.type == "cuda" and hasattr(fm_index, "handle") and s.diverse_bs_groups == 1
-            and not s.topk and fm_index_generate is _FM_INDEX_GENERATE):
+            and not s.topk and getattr(fm_index_generate, "_joint_ok", fm_index_generate is _FM_INDEX_GENERATE)):
         joint_kinds = [k for k, on, m in (("body", s.decode_body, s.bart_model), ("title", s.decode_titles, s.bart_title_model),
                                           ("code", s.decode_code, s.bart_code_model)) if on and m is s.bart_model]
         if len(joint_kinds) < 2:

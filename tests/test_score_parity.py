@@ -69,6 +69,19 @@ def test_beam_and_rescoring_scores_at_bart_large_geometry_match_hf_fp32_forward(
         for tok in (cfg.pad_token_id, cfg.bos_token_id, bench.VOCAB - 1):
             model.final_logits_bias[0, tok] = float("-inf")
     from seal_amd.keys import _pad_batch
+    from seal_amd.beam_search import fm_index_generate_joint
+    # the searcher's default: both decodes as ONE loop of 2 x batch x beams rows
+    toks2 = [q[:-1] + m + [45056, 2055] + q[-1:] for m in ([45056, 809], [45056, 1270]) for q in queries]
+    ids2 = _pad_batch(toks2, cfg.pad_token_id, dev)
+    mask2 = (ids2 != cfg.pad_token_id).long()
+    pend = fm_index_generate_joint(model, index, ids2, mask2, [dict(batch=2, max_length=10), dict(batch=2, max_length=15, force_decoding_from=[2],
+                                                                                                 eos_token_id=bench.TITLE_EOS)],
+                                   num_beams=15, length_penalty=0.0, logit_bias=torch.cat([bias, bias]))
+    assert model._seal_step_decoder._st.fused is True and model._seal_step_decoder._st.shape[0] == 2
+    for i, pg in enumerate(pend):
+        steps, final, B, K, _ = pg._args
+        rep = compare_beam_history(model, ids2[2 * i:2 * i + 2], mask2[2 * i:2 * i + 2], steps, final, B, K, logit_bias=bias)
+        assert rep["violations"] == 0 and rep["max_abs_err"] <= 1e-4 and rep["values"] >= (9, 14)[i] * B * K, rep
     for marker, kw in (([45056, 809], dict(max_length=10, num_beams=15, length_penalty=0.0)),
                        ([45056, 1270], dict(max_length=15, num_beams=15, length_penalty=0.0, force_decoding_from=[2],
                                             eos_token_id=bench.TITLE_EOS))):
