@@ -401,6 +401,157 @@ def score_parity(searcher, model, index, queries, bias, dev, n_rescore_queries=4
     return out
 
 
+def run_stress(args, dev, real_stdout):
+    """BASELINE.json configs[4]: the 100M-document stress tier -- 1.4e10 symbols, an i.i.d. Zipf "BWT" loaded straight into the
+    wavelet matrix (rank/select-only index: the suffix array of 1.4e10 symbols, 70 GB + construction workspace, is not
+    built; SURVEY.md 8d tier X) -- with beam 30 and a bf16 BART-large: one step = the key generation of a batch of queries
+    (body + title decode as one loop of 2 x batch x beams = 1200 rows, count post-filters, prefix-tree rescoring, unigram
+    scores), everything of the search that does not locate.  Parity: every constraint call and every key range of one batch
+    against the CPU oracle built from the same BWT (bit-exact), the recorded hypothesis scores against HF's own bf16 forward."""
+    import ctypes
+    import __graft_entry__ as ge
+    from seal_amd import FMIndex, retrieval
+    from seal_amd._lib import check, lib
+    from seal_amd.retrieval import SEALSearcher
+    ge.build()
+    N = int(args.stress_symbols)
+    g = torch.Generator(device=dev)
+    g.manual_seed(100)
+    t0 = time.perf_counter()
+    usable = torch.arange(4, VOCAB, device=dev)
+    usable = usable[(usable != TITLE_EOS) & (usable != CODE_EOS)]
+    ids_by_rank = usable[torch.randperm(usable.numel(), generator=g, device=dev)]
+    w = 1.0 / torch.arange(1, usable.numel() + 1, device=dev, dtype=torch.float64) ** 1.07
+    cdf = torch.cumsum(w, 0) / w.sum()
+    bwt = torch.empty(N, dtype=torch.int16, device=dev)
+    for a in range(0, N, 1 << 27):
+        b = min(N, a + (1 << 27))
+        r = torch.searchsorted(cdf, torch.rand(b - a, generator=g, device=dev, dtype=torch.float64)).clamp_(max=usable.numel() - 1)
+        bwt[a:b] = (ids_by_rank[r] + SHIFT).to(torch.int16)          # two's complement view of the u16 symbol
+    # the title markers of the searcher's title decode: every 150th symbol an end-of-sequence, '@@' a little later
+    bwt[7::150] = 2 + SHIFT
+    bwt[77::150] = (TITLE_EOS + SHIFT) - 65536 if TITLE_EOS + SHIFT >= 32768 else TITLE_EOS + SHIFT
+    bwt[N // 3] = 0
+    torch.cuda.synchronize()
+    log(f"stress BWT: {N} symbols in {time.perf_counter() - t0:.1f}s")
+    t0 = time.perf_counter()
+    index = FMIndex()
+    index.initialize_rank_only_from_bwt(bwt, VOCAB - 1 + SHIFT)
+    index.labels = None
+    log(f"rank/select-only index: n={index.size()} HBM={index.device_bytes() / 2**30:.1f} GiB in {time.perf_counter() - t0:.1f}s")
+
+    from transformers import BartConfig, BartForConditionalGeneration
+    torch.manual_seed(0)
+    cfg = BartConfig()
+    cfg.forced_bos_token_id = None
+    with torch.device(dev):
+        model = BartForConditionalGeneration(cfg)
+    model.eval()
+    with torch.no_grad():
+        for tok in (cfg.pad_token_id, cfg.bos_token_id, VOCAB - 1):
+            model.final_logits_bias[0, tok] = float("-inf")
+    model.to(torch.bfloat16)
+    searcher = SEALSearcher(index, None, model, add_query_to_keys=not args.no_query_keys, detokenize=False, beam=args.beam, batch_size=args.batch,
+                            joint_decode=not args.no_joint_decode)
+    # queries: random ids; per query +8 on 12 of the 40 most frequent tokens (frequent n-grams keep non-empty ranges for a few steps)
+    n_batches = args.warmup + args.steps + 1
+    rng = np.random.default_rng(1)
+    nq = n_batches * args.batch
+    V2 = ids_by_rank.numel()
+    queries = [[0] + ids_by_rank[torch.as_tensor(np.minimum(rng.zipf(1.3, size=int(rng.integers(8, 25))), V2) - 1, device=dev)].tolist() + [2]
+               for _ in range(nq)]
+    bias = torch.zeros(nq, VOCAB, device=dev)
+    top = ids_by_rank[:40]
+    for q in range(nq):
+        bias[q, top[torch.as_tensor(rng.choice(40, size=12, replace=False), device=dev)]] = 8.0
+    bias[:, TITLE_EOS] = 4.0
+    check(lib().fmi_dev_enable_probe_count(index.handle, 1))
+    check(lib().fmi_dev_enable_timing(index.handle, 1))
+
+    def run_batch(i):
+        lo = i * args.batch
+        searcher.logit_bias = bias[lo:lo + args.batch]
+        return list(searcher.batch_generate_keys(queries[lo:lo + args.batch]))
+    for i in range(args.warmup):
+        run_batch(i)
+    torch.cuda.synchronize()
+    pr, ln, km = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
+    check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(pr)))
+    check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(ln), ctypes.byref(km)))
+    check(lib().fmi_dev_enable_probe_count(index.handle, 0))           # the timed region runs without the in-kernel counters
+    t_start = time.perf_counter()
+    n_keys = 0
+    for i in range(args.steps):
+        n_keys += sum(len(kk[0]) if isinstance(kk, tuple) else len(kk) for kk in run_batch(args.warmup + i))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(ln), ctypes.byref(km)))
+    launches, kms = ln.value, km.value
+    # one more batch with the counters on (the bytes of the same kind of launches) and every index operation recorded
+    check(lib().fmi_dev_enable_probe_count(index.handle, 1))
+    trace = []
+    index.set_trace(trace)
+    run_batch(args.warmup + args.steps)
+    torch.cuda.synchronize()
+    index.set_trace(None)
+    check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(pr)))
+    check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(ln), ctypes.byref(km)))
+    achieved = pr.value * 128.0 / max(1, ln.value) / (kms / max(1, launches) * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_constrain<true, 8> (superblocked counters), one launch per decode step for the rows of both decodes",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                "launches": int(launches), "avg_launch_us": round(kms * 1e3 / max(1, launches), 2),
+                "algorithmic_bytes_per_launch": round(pr.value * 128.0 / max(1, ln.value), 1),
+                "measured_on": "HIP events around every k_constrain launch of the timed region (counters off); blocks counted in-kernel on one more batch"}
+    parity = cpu = None
+    if not args.no_cpu_baseline:
+        from oracle.seal_oracle import CppFMIndex, lib as orc_lib
+        threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+        orc_lib().orc_set_threads(threads)
+        t0 = time.perf_counter()
+        host = np.empty(N, dtype=np.uint32)
+        for a in range(0, N, 1 << 28):
+            host[a:a + (1 << 28)] = (bwt[a:a + (1 << 28)].to(torch.int32) & 0xFFFF).cpu().numpy().astype(np.uint32)
+        orc = CppFMIndex()
+        orc.initialize_from_bwt(host, np.zeros(N // 32 + 2, np.uint64), np.zeros(N // 64 + 2, np.uint64))
+        del host
+        log(f"cpu oracle (sdsl-style wt_int + rank_support_v) over the same BWT built in {time.perf_counter() - t0:.1f}s with {threads} threads")
+        ops = [op for op in trace if op[0] in ("mask", "ranges")]
+        rep, answers = replay_on_cpu(orc, ops, [0, N - 1], threads)
+        parity = parity_check(index, ops, answers)
+        t_cpu = rep["mask_s"] + rep["ranges_s"]
+        cpu = {"value": round(args.batch / t_cpu, 3), "unit": "queries/s (FM-index operations of the key generation only)", "cores": threads, "kind": "port",
+               "sample": f"the constraint calls ({rep['rows']} rows: get_range / get_count from scratch + distinct_count_multi) and key counts "
+                         f"({rep['sequences']} keys) of 1 batch of {args.batch} queries replayed on the oracle with the reference's call pattern",
+               "seconds": {k: round(v, 3) for k, v in rep.items() if k.endswith("_s")}}
+        del orc
+        lo_q = (args.warmup + args.steps) * args.batch
+        sp = score_parity(searcher, model, index, queries[lo_q:lo_q + args.batch], bias[lo_q:lo_q + args.batch], dev, tol=args.bf16_tol)
+        for k in ("beam_scores_body", "beam_scores_title", "rescore_scores"):
+            sp[k]["arithmetic"] = "bf16 storage, fp32 accumulation, against HF's bf16 forward of the same weights (log-softmax in fp32 on both sides)"
+        parity["by_kind"]["beam_scores"] = {"values": sp["beam_scores_body"]["values"] + sp["beam_scores_title"]["values"],
+                                            "max_abs_err": max(sp["beam_scores_body"]["max_abs_err"], sp["beam_scores_title"]["max_abs_err"]),
+                                            "tol": args.bf16_tol, "mismatches": sp["beam_scores_body"]["violations"] + sp["beam_scores_title"]["violations"],
+                                            "body": sp["beam_scores_body"], "title": sp["beam_scores_title"]}
+        parity["by_kind"]["rescore_scores"] = {**sp["rescore_scores"], "mismatches": sp["rescore_scores"]["violations"]}
+        parity["float_mismatches"] = parity["by_kind"]["beam_scores"]["mismatches"] + sp["rescore_scores"]["violations"]
+        log(f"parity_check: {parity['ops']} ops, {parity['values_compared']} integer values, {parity['mismatches']} mismatches; bf16 scores vs HF bf16: "
+            f"beam max abs err {parity['by_kind']['beam_scores']['max_abs_err']:.3g}, rescoring {sp['rescore_scores']['max_abs_err']:.3g} (tol {args.bf16_tol})")
+    del bwt
+    out = {"metric": "queries/sec of key generation, 100M-doc synthetic stress rank/select index, BART-large bf16 beam=30 batch=20",
+           "value": round(args.batch * args.steps / elapsed, 3), "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed * 1e3 / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+           "data": "synthetic",
+           "config": {"workload": f"configs[4]: synthetic 100M-doc stress tier ({N} symbols, i.i.d. Zipf BWT, rank/select-only index), random-init BART-large bf16, "
+                                  f"beam={args.beam}, batch={args.batch}, body len 10 + title len<=15 as one loop, key generation (decodes, count filters, rescoring, unigram scores)",
+                      "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "model_arithmetic": "bf16 storage, fp32 accumulation",
+                      "not_in_step": ["first-stage retrieval and full-document rescoring (locate): no suffix array at this size"]},
+           "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "extra": {"keys_per_query": round(n_keys / (args.batch * args.steps), 1)}}
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if parity is not None and parity["mismatches"]:
+        log("PARITY FAILURE", json.dumps({k: v for k, v in parity["by_kind"].items() if v.get("mismatches")}))
+        sys.exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -416,6 +567,10 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="do not enqueue the next batch's decodes ahead of this batch's rescoring/aggregation")
     ap.add_argument("--no-joint-decode", action="store_true", help="body and title decodes as two loops of batch x beams rows (the reference's "
                     "order) instead of one loop of 2 x batch x beams rows")
+    ap.add_argument("--workload", choices=["nq", "stress"], default="nq", help="nq: BASELINE configs[1] (configs[3] with --docs 36000000), the "
+                    "contract's default; stress: configs[4], the 1.4e10-symbol rank/select tier with beam 30 and bf16 BART (key generation only)")
+    ap.add_argument("--stress-symbols", type=float, default=1.4e10)
+    ap.add_argument("--bf16-tol", type=float, default=0.25, help="stress workload: tolerance of the bf16 hypothesis scores against HF's bf16 forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-other-depth", action="store_true", help="also time the same batches through the other retrieval depth "
                     "(first stage only <-> complete search); first-stage-only aggregates on the host and is slow on the phrase corpus")
@@ -460,6 +615,11 @@ def main():
             pass
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.workload == "stress":
+        assert world == 1, "the stress workload is a single-GPU measurement"
+        if "--beam" not in sys.argv:
+            args.beam = 30
+        return run_stress(args, dev, real_stdout)
     force_dist = bool(os.environ.get("SEAL_BENCH_FORCE_DIST"))     # exercise the RCCL path with one rank
     use_dist = world > 1 or force_dist
     if use_dist:
