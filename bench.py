@@ -487,6 +487,35 @@ def run_stress(args, dev, real_stdout):
     elapsed = time.perf_counter() - t_start
     check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(ln), ctypes.byref(km)))
     launches, kms = ln.value, km.value
+    # where a batch goes: one more batch with the phases serialised (synchronise before and after each)
+    from seal_amd import keys as rk
+    phases = {}
+
+    def timed(name, fn):
+        def wrap(*a, **kw):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            out = fn(*a, **kw)
+            if name == "rescore_ms" and isinstance(out, list):
+                out = [o.result() if hasattr(o, "result") else o for o in out]        # read the scores back inside the phase
+                out = [type("Done", (), {"result": (lambda self, v=v: v)})() for v in out]
+            torch.cuda.synchronize()
+            phases[name] = phases.get(name, 0.0) + (time.perf_counter() - t) * 1e3
+            return out
+        return wrap
+    saved = (retrieval.fm_index_generate_joint, retrieval.fm_index_generate, rk.rescore_keys_multi, retrieval._count_filter)
+    retrieval.fm_index_generate_joint = timed("decode_ms", saved[0])
+    retrieval.fm_index_generate = timed("decode_ms", saved[1])
+    retrieval.fm_index_generate._joint_ok = True
+    rk.rescore_keys_multi = timed("rescore_ms", saved[2])
+    retrieval._count_filter = timed("count_filter_ms", saved[3])
+    t_b = time.perf_counter()
+    run_batch(args.warmup + args.steps)
+    torch.cuda.synchronize()
+    phases["whole_batch_ms"] = (time.perf_counter() - t_b) * 1e3
+    retrieval.fm_index_generate_joint, retrieval.fm_index_generate, rk.rescore_keys_multi, retrieval._count_filter = saved
+    check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(pr)))      # (drop that batch's counts: the counters were off)
+    check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(ln), ctypes.byref(km)))
     # one more batch with the counters on (the bytes of the same kind of launches) and every index operation recorded
     check(lib().fmi_dev_enable_probe_count(index.handle, 1))
     trace = []
@@ -497,7 +526,8 @@ def run_stress(args, dev, real_stdout):
     check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(pr)))
     check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(ln), ctypes.byref(km)))
     achieved = pr.value * 128.0 / max(1, ln.value) / (kms / max(1, launches) * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_constrain<true, 8> (superblocked counters), one launch per decode step for the rows of both decodes",
+    roofline = {"bound": "hbm", "kernel": ("k_constrain<true, 8> (superblocked counters)" if N > (1 << 32) else "k_constrain<false, 8>") +
+                                          ", one launch per decode step for the rows of both decodes",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
                 "launches": int(launches), "avg_launch_us": round(kms * 1e3 / max(1, launches), 2),
                 "algorithmic_bytes_per_launch": round(pr.value * 128.0 / max(1, ln.value), 1),
@@ -545,7 +575,7 @@ def run_stress(args, dev, real_stdout):
                                   f"beam={args.beam}, batch={args.batch}, body len 10 + title len<=15 as one loop, key generation (decodes, count filters, rescoring, unigram scores)",
                       "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "model_arithmetic": "bf16 storage, fp32 accumulation",
                       "not_in_step": ["first-stage retrieval and full-document rescoring (locate): no suffix array at this size"]},
-           "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "extra": {"keys_per_query": round(n_keys / (args.batch * args.steps), 1)}}
+           "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "extra": {"keys_per_query": round(n_keys / (args.batch * args.steps), 1), "phase_ms_one_batch": {k: round(v, 2) for k, v in phases.items()}}}
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if parity is not None and parity["mismatches"]:
         log("PARITY FAILURE", json.dumps({k: v for k, v in parity["by_kind"].items() if v.get("mismatches")}))

@@ -225,7 +225,85 @@ __global__ __launch_bounds__(256) void k_entry_starts(const uint32_t *head, cons
     if (j == total - 1) { const uint32_t ne = eid[j] + head[j]; estart[ne] = (uint32_t)total; *n_entries = ne; }   // eid = heads BEFORE j
 }
 
-// one wave per document entry (persistent grid): the keys that count for the document and their discounted scores
+// Document entries (persistent grid): the keys that count for the document and their discounted scores.  A wave takes 64
+// consecutive entries at a time.  Most documents are touched by ONE located row (a few million entries per batch, two
+// thirds of them singles): such an entry is one LANE's work -- the key counts iff its occurrence is new, no discount
+// applies to a single key (keys.py:352: only from the second key on) -- and is done by all 64 lanes at once; the entries
+// with several occurrences are then walked by the whole wave, one after the other, as before.
+__device__ __forceinline__ void entry_by_wave(const AggView &v, const uint64_t *KD, const uint32_t *ID, const uint32_t *occ_rk, const uint8_t *newflag,
+                                              int allow_overlaps, double beta, double single_key, uint32_t cover_words, uint32_t *cover,
+                                              uint32_t e, uint32_t s, uint32_t t, uint32_t *ckey, double *cscore, uint32_t *ent_nkeys,
+                                              uint64_t *ent_rank, uint32_t *ent_first, uint32_t *ent_q, uint32_t *ent_doc, double *ent_score, uint32_t *ent_best)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    // ---- keys that count: first occurrence of each key that is new (or any, with allow_overlaps) ----
+    uint32_t nL = 0, carry = 0xFFFFFFFFu;          // carry = rare key of the last counting occurrence so far
+    for (uint32_t base = s; base < t; base += 64) {
+        const uint32_t j = base + lane;
+        const bool valid = j < t;
+        const uint32_t i = valid ? ID[j] : 0;
+        const uint32_t r = valid ? occ_rk[i] : 0xFFFFFFFEu;
+        const bool c = valid && (allow_overlaps || newflag[i]);
+        uint32_t prev = (uint32_t)__shfl_up((int)r, 1);
+        if (lane == 0) prev = (base > s) ? occ_rk[ID[base - 1]] : 0xFFFFFFFFu;
+        const bool runstart = valid && (r != prev);
+        const uint64_t cm = __ballot(c), rs = __ballot(runstart);
+        const uint64_t at_or_below = rs & (lanes_below(lane) | (1ull << lane));
+        bool sel;
+        if (at_or_below) {
+            const uint32_t r0 = 63 - (uint32_t)__builtin_clzll(at_or_below);
+            sel = c && !(cm & lanes_below(lane) & ~lanes_below(r0));
+        } else {
+            sel = c && !(cm & lanes_below(lane)) && (r != carry);      // run continued from the previous strip
+        }
+        const uint64_t sm = __ballot(sel);
+        if (sel) ckey[s + nL + (uint32_t)__popcll(sm & lanes_below(lane))] = r;
+        nL += (uint32_t)__popcll(sm);
+        if (cm) carry = (uint32_t)__shfl((int)r, 63 - (int)__builtin_clzll(cm));
+    }
+    __threadfence_block();
+    wave_sync();
+    // ---- repetition discount in key order (keys.py:352-364) ----
+    double current = 0.0;
+    if (nL >= 2) {
+        for (uint32_t w = lane; w < cover_words; w += 64) cover[w] = 0;
+        wave_sync();
+    }
+    bool cover_any = false;
+    for (uint32_t x = 0; x < nL; x++) {
+        const uint32_t k = v.rare_key[rfl(ckey[s + x])];
+        const double sco = v.key_score[k];
+        const uint32_t o0 = v.kset_off[k], nset = v.kset_off[k + 1] - o0;
+        double nsco = sco;
+        if (nL >= 2) {
+            if (cover_any) {
+                uint32_t covered = 0;
+                for (uint32_t u = 0; u < nset; u += 64) {
+                    const uint32_t id = (u + lane < nset) ? v.kset_ids[o0 + u + lane] : 0xFFFFFFFFu;
+                    const bool hit = id != 0xFFFFFFFFu && ((cover[id >> 5] >> (id & 31)) & 1);
+                    covered += (uint32_t)__popcll(__ballot(hit));
+                }
+                const double coeff = (1.0 - beta) + ((beta * (double)(nset - covered)) / (double)nset);
+                nsco = coeff * sco;
+            }
+            for (uint32_t u = 0; u < nset; u += 64)
+                if (u + lane < nset) { const uint32_t id = v.kset_ids[o0 + u + lane]; atomicOr(&cover[id >> 5], 1u << (id & 31)); }
+            wave_sync();
+            cover_any = cover_any || nset > 0;
+        }
+        current += nsco;
+        if (lane == 0) cscore[s + x] = nsco;
+    }
+    if (lane == 0) {
+        const uint64_t kd = KD[s];
+        const uint32_t i0 = ID[s], r0 = occ_rk[i0];
+        const double best = v.key_score[v.rare_key[r0]];     // keys arrive by descending score: the first one to touch the document
+        const double rk = (1.0 - single_key) * (-current) + single_key * (-best);
+        ent_nkeys[e] = nL; ent_score[e] = current; ent_best[e] = r0; ent_first[e] = i0;
+        ent_q[e] = (uint32_t)(kd >> 32); ent_doc[e] = (uint32_t)kd; ent_rank[e] = f64_order_key(rk);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_entries(AggView v, const uint64_t *KD, const uint32_t *ID, const uint32_t *estart, const uint32_t *n_entries_p,
                                                  const uint32_t *occ_rk, const uint8_t *newflag, int allow_overlaps, double beta, double single_key,
                                                  uint32_t cover_words, uint32_t *ckey, double *cscore, uint32_t *ent_nkeys, uint64_t *ent_rank,
@@ -235,73 +313,29 @@ __global__ __launch_bounds__(256) void k_entries(AggView v, const uint64_t *KD, 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *cover = lds + wave * cover_words;
     const uint32_t ne = *n_entries_p;
-    for (uint32_t e = blockIdx.x * 4 + wave; e < ne; e += gridDim.x * 4) {
-        const uint32_t s = estart[e], t = estart[e + 1];
-        // ---- keys that count: first occurrence of each key that is new (or any, with allow_overlaps) ----
-        uint32_t nL = 0, carry = 0xFFFFFFFFu;          // carry = rare key of the last counting occurrence so far
-        for (uint32_t base = s; base < t; base += 64) {
-            const uint32_t j = base + lane;
-            const bool valid = j < t;
-            const uint32_t i = valid ? ID[j] : 0;
-            const uint32_t r = valid ? occ_rk[i] : 0xFFFFFFFEu;
-            const bool c = valid && (allow_overlaps || newflag[i]);
-            uint32_t prev = (uint32_t)__shfl_up((int)r, 1);
-            if (lane == 0) prev = (base > s) ? occ_rk[ID[base - 1]] : 0xFFFFFFFFu;
-            const bool runstart = valid && (r != prev);
-            const uint64_t cm = __ballot(c), rs = __ballot(runstart);
-            const uint64_t at_or_below = rs & (lanes_below(lane) | (1ull << lane));
-            bool sel;
-            if (at_or_below) {
-                const uint32_t r0 = 63 - (uint32_t)__builtin_clzll(at_or_below);
-                sel = c && !(cm & lanes_below(lane) & ~lanes_below(r0));
-            } else {
-                sel = c && !(cm & lanes_below(lane)) && (r != carry);      // run continued from the previous strip
-            }
-            const uint64_t sm = __ballot(sel);
-            if (sel) ckey[s + nL + (uint32_t)__popcll(sm & lanes_below(lane))] = r;
-            nL += (uint32_t)__popcll(sm);
-            if (cm) carry = (uint32_t)__shfl((int)r, 63 - (int)__builtin_clzll(cm));
-        }
-        __threadfence_block();
-        wave_sync();
-        // ---- repetition discount in key order (keys.py:352-364) ----
-        double current = 0.0;
-        if (nL >= 2) {
-            for (uint32_t w = lane; w < cover_words; w += 64) cover[w] = 0;
-            wave_sync();
-        }
-        bool cover_any = false;
-        for (uint32_t x = 0; x < nL; x++) {
-            const uint32_t k = v.rare_key[rfl(ckey[s + x])];
-            const double sco = v.key_score[k];
-            const uint32_t o0 = v.kset_off[k], nset = v.kset_off[k + 1] - o0;
-            double nsco = sco;
-            if (nL >= 2) {
-                if (cover_any) {
-                    uint32_t covered = 0;
-                    for (uint32_t u = 0; u < nset; u += 64) {
-                        const uint32_t id = (u + lane < nset) ? v.kset_ids[o0 + u + lane] : 0xFFFFFFFFu;
-                        const bool hit = id != 0xFFFFFFFFu && ((cover[id >> 5] >> (id & 31)) & 1);
-                        covered += (uint32_t)__popcll(__ballot(hit));
-                    }
-                    const double coeff = (1.0 - beta) + ((beta * (double)(nset - covered)) / (double)nset);
-                    nsco = coeff * sco;
-                }
-                for (uint32_t u = 0; u < nset; u += 64)
-                    if (u + lane < nset) { const uint32_t id = v.kset_ids[o0 + u + lane]; atomicOr(&cover[id >> 5], 1u << (id & 31)); }
-                wave_sync();
-                cover_any = cover_any || nset > 0;
-            }
-            current += nsco;
-            if (lane == 0) cscore[s + x] = nsco;
-        }
-        if (lane == 0) {
-            const uint64_t kd = KD[s];
+    for (uint32_t e0 = (blockIdx.x * 4 + wave) * 64; e0 < ne; e0 += gridDim.x * 4 * 64) {
+        const uint32_t e = e0 + lane;
+        const bool have = e < ne;
+        const uint32_t s = have ? estart[e] : 0, t = have ? estart[e + 1] : 0;
+        if (have && t - s == 1) {
+            // one occurrence: the same values the wave path computes for it (0.0 + x == x; a single key is never discounted)
             const uint32_t i0 = ID[s], r0 = occ_rk[i0];
-            const double best = v.key_score[v.rare_key[r0]];     // keys arrive by descending score: the first one to touch the document
+            const bool c = allow_overlaps || newflag[i0];
+            const double best = v.key_score[v.rare_key[r0]];
+            double current = 0.0;
+            if (c) { ckey[s] = r0; cscore[s] = best; current += best; }
+            const uint64_t kd = KD[s];
             const double rk = (1.0 - single_key) * (-current) + single_key * (-best);
-            ent_nkeys[e] = nL; ent_score[e] = current; ent_best[e] = r0; ent_first[e] = i0;
+            ent_nkeys[e] = c ? 1u : 0u; ent_score[e] = current; ent_best[e] = r0; ent_first[e] = i0;
             ent_q[e] = (uint32_t)(kd >> 32); ent_doc[e] = (uint32_t)kd; ent_rank[e] = f64_order_key(rk);
+        }
+        uint64_t multi = __ballot(have && t - s != 1);
+        while (multi) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(multi);
+            multi &= multi - 1;
+            entry_by_wave(v, KD, ID, occ_rk, newflag, allow_overlaps, beta, single_key, cover_words, cover, e0 + l,
+                          rfl((uint32_t)__shfl((int)s, (int)l)), rfl((uint32_t)__shfl((int)t, (int)l)), ckey, cscore, ent_nkeys, ent_rank, ent_first,
+                          ent_q, ent_doc, ent_score, ent_best);
         }
     }
 }

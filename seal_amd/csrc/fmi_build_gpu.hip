@@ -449,7 +449,7 @@ int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int 
 
     // hand the resident arrays over to the index
     d.C = dC; d.leaf = dleaf; d.q1 = dq1; d.sa_lo = sa_lo_dev; d.sa_hi = sa_hi_dev; d.text = text;
-    d.doc_begin = nullptr; d.n_begin = 0;
+    d.doc_begin = nullptr; d.n_begin = 0; d.doc_hint = nullptr;
     for (void *p : {(void *)wm, (void *)d.sbase, (void *)dC, (void *)dleaf, (void *)dq1, (void *)sa_lo_dev, (void *)sa_hi_dev, (void *)text}) {
         if (!p) continue;
         pool.keep(p);

@@ -136,6 +136,12 @@ __device__ __forceinline__ uint64_t sa_at(const FmiDev &ix, uint64_t row)
 __device__ __forceinline__ uint64_t doc_of(const FmiDev &ix, uint64_t pos)
 {
     uint64_t lo = 0, hi = ix.n_begin;
+    if (ix.doc_hint && pos < ix.n) {
+        // every boundary index <= doc_hint[b] is <= pos, every one > doc_hint[b + 1] is > pos: the same search, narrowed
+        const uint64_t b = pos >> FMI_DOC_HINT_SHIFT;
+        lo = (uint64_t)ix.doc_hint[b] + 1;
+        hi = min((uint64_t)ix.doc_hint[b + 1] + 1, ix.n_begin);
+    }
     while (lo < hi) {
         uint64_t mid = (lo + hi) >> 1;
         if (pos < ix.doc_begin[mid]) hi = mid; else lo = mid + 1;

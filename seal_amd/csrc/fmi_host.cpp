@@ -377,6 +377,42 @@ extern "C" int fmi_build_from_file(fmi_t *h, const char *path, int width, int de
     return fmi_build(h, data.data(), cnt, device);
 }
 
+// device copies of the document boundaries and of the sampled position -> document table (FmiDev::doc_hint)
+static int upload_doc_tables(fmi *h)
+{
+    const std::vector<uint64_t> &b = h->doc_begin;
+    const uint64_t n_entries = b.size();
+    void *p = nullptr;
+    if (hipMalloc(&p, n_entries * 8) != hipSuccess) { fmi_set_error("hipMalloc(doc_begin) failed"); return FMI_ERR_HIP; }
+    if (hipMemcpy(p, b.data(), n_entries * 8, hipMemcpyHostToDevice) != hipSuccess) { fmi_set_error("hipMemcpy(doc_begin) failed"); return FMI_ERR_HIP; }
+    h->dev_allocs.push_back(p);
+    h->dev_bytes += n_entries * 8;
+    h->dev.doc_begin = (const uint64_t *)p;
+    h->dev.n_begin = n_entries;
+    h->dev.doc_hint = nullptr;
+    // doc_hint[blk] = bisect_right(b, blk << shift) - 1 for every block that holds a text position (+ one past): one merge
+    // pass.  Boundaries must ascend from 0 (index.py:25,50 builds them as a running sum); anything else keeps the full bisect.
+    bool ok = n_entries >= 1 && b[0] == 0 && n_entries < 0xffffffffull && h->n > 0;
+    for (uint64_t i = 1; ok && i < n_entries; i++) ok = b[i] >= b[i - 1];
+    if (ok) {
+        const uint64_t nh = ((h->n - 1) >> FMI_DOC_HINT_SHIFT) + 2;
+        std::vector<uint32_t> hint(nh);
+        uint64_t d = 0;                       // last index with b[d] <= position
+        for (uint64_t blk = 0; blk < nh; blk++) {
+            const uint64_t pos = blk << FMI_DOC_HINT_SHIFT;
+            while (d + 1 < n_entries && b[d + 1] <= pos) d++;
+            hint[blk] = (uint32_t)d;
+        }
+        void *q = nullptr;
+        if (hipMalloc(&q, nh * 4) != hipSuccess) { fmi_set_error("hipMalloc(doc_hint) failed"); return FMI_ERR_HIP; }
+        if (hipMemcpy(q, hint.data(), nh * 4, hipMemcpyHostToDevice) != hipSuccess) { fmi_set_error("hipMemcpy(doc_hint) failed"); return FMI_ERR_HIP; }
+        h->dev_allocs.push_back(q);
+        h->dev_bytes += nh * 4;
+        h->dev.doc_hint = (const uint32_t *)q;
+    }
+    return FMI_OK;
+}
+
 extern "C" int fmi_set_doc_beginnings(fmi_t *h, const uint64_t *b, uint64_t n_entries)
 {
     if (!h || !b || n_entries == 0) { fmi_set_error("fmi_set_doc_beginnings: bad argument"); return FMI_ERR_ARG; }
@@ -385,13 +421,7 @@ extern "C" int fmi_set_doc_beginnings(fmi_t *h, const uint64_t *b, uint64_t n_en
     for (uint64_t i = 1; i < n_entries; i++) h->max_doc_len = std::max<uint64_t>(h->max_doc_len, b[i] - b[i - 1]);
     if (h->device >= 0) {
         if (hipSetDevice(h->device) != hipSuccess) { fmi_set_error("hipSetDevice failed"); return FMI_ERR_HIP; }
-        void *p = nullptr;
-        if (hipMalloc(&p, n_entries * 8) != hipSuccess) { fmi_set_error("hipMalloc(doc_begin) failed"); return FMI_ERR_HIP; }
-        if (hipMemcpy(p, b, n_entries * 8, hipMemcpyHostToDevice) != hipSuccess) { fmi_set_error("hipMemcpy(doc_begin) failed"); return FMI_ERR_HIP; }
-        h->dev_allocs.push_back(p);
-        h->dev_bytes += n_entries * 8;
-        h->dev.doc_begin = (const uint64_t *)p;
-        h->dev.n_begin = n_entries;
+        return upload_doc_tables(h);
     }
     return FMI_OK;
 }
@@ -434,13 +464,14 @@ int fmi_upload(fmi *h, int device)
     const uint8_t *text8 = nullptr;
     if ((rc = up(h, h->wm, &d.wm)) || (rc = up(h, h->sbase, &d.sbase)) || (rc = up(h, h->C, &d.C)) || (rc = up(h, h->leaf, &d.leaf)) ||
         (rc = up(h, h->q1, &d.q1)) || (rc = up(h, h->sa_lo, &d.sa_lo)) || (rc = up(h, h->sa_hi, &d.sa_hi)) ||
-        (rc = up(h, h->text, &text8)) || (rc = up(h, h->doc_begin, &d.doc_begin))) {
+        (rc = up(h, h->text, &text8))) {
         fmi_release_device(h);
         return rc;
     }
     d.text = text8;
-    d.n_begin = h->doc_begin.size();
+    d.doc_begin = nullptr; d.n_begin = 0; d.doc_hint = nullptr;
     h->dev = d;
+    if (!h->doc_begin.empty() && (rc = upload_doc_tables(h))) { fmi_release_device(h); return rc; }
     return FMI_OK;
 }
 

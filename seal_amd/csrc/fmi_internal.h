@@ -53,7 +53,12 @@ struct FmiDev {
     const void *text;         // [n] the (reversed-doc) text itself, sym_bytes wide
     const uint64_t *doc_begin;// [n_begin] cumulative doc offsets (index.py beginnings)
     uint64_t n_begin;
+    // sampled position -> document table (SURVEY.md 8d "doc binning: 8 B with a sampled pos->doc table"): doc_hint[b] =
+    // bisect_right(doc_begin, b << FMI_DOC_HINT_SHIFT) - 1, so the document of a position in block b lies in
+    // [doc_hint[b], doc_hint[b + 1]] and the bisect over the 168 MB boundary array shrinks to 0..2 steps; nullptr: full bisect
+    const uint32_t *doc_hint;
 };
+static constexpr uint32_t FMI_DOC_HINT_SHIFT = 7;
 
 struct fmi {
     // geometry

@@ -28,7 +28,8 @@ def test_bf16_kernels_equal_the_fp32_kernels_rounded_to_bf16():
     o16 = torch.empty(rows, d, dtype=bf, device=dev)
     o32 = torch.empty(rows, d, device=dev)
     check(L.sealnn_add_layernorm_bf16(st, x.data_ptr(), y.data_ptr(), gam.data_ptr(), bet.data_ptr(), rows, d, 1e-5, o16.data_ptr()))
-    check(L.sealnn_add_layernorm(st, x.float().data_ptr(), y.float().data_ptr(), gam.float().data_ptr(), bet.float().data_ptr(), rows, d, 1e-5, o32.data_ptr()))
+    x32, y32, gam32, bet32 = x.float(), y.float(), gam.float(), bet.float()          # (named: a temporary's memory is reused at once)
+    check(L.sealnn_add_layernorm(st, x32.data_ptr(), y32.data_ptr(), gam32.data_ptr(), bet32.data_ptr(), rows, d, 1e-5, o32.data_ptr()))
     assert torch.equal(o16, o32.to(bf))
     # self-attention step with the ancestry-addressed cache, three positions deep
     R, H, T = 10, 3, 9
@@ -41,7 +42,8 @@ def test_bf16_kernels_equal_the_fp32_kernels_rounded_to_bf16():
         qkv = rnd(R, 3 * H * 64)
         a16, a32 = torch.empty(R, H * 64, dtype=bf, device=dev), torch.empty(R, H * 64, device=dev)
         check(L.sealnn_self_attn_step_bf16(st, qkv.data_ptr(), kc16.data_ptr(), vc16.data_ptr(), t.data_ptr(), R, H, T, 0.125, a16.data_ptr(), anc16.data_ptr()))
-        check(L.sealnn_self_attn_step(st, qkv.float().data_ptr(), kc32.data_ptr(), vc32.data_ptr(), t.data_ptr(), R, H, T, 0.125, a32.data_ptr(), anc32.data_ptr()))
+        qkv32 = qkv.float()
+        check(L.sealnn_self_attn_step(st, qkv32.data_ptr(), kc32.data_ptr(), vc32.data_ptr(), t.data_ptr(), R, H, T, 0.125, a32.data_ptr(), anc32.data_ptr()))
         assert torch.equal(a16, a32.to(bf)), step
         perm = torch.randint(0, R, (R,), generator=g).to(dev)
         anc16.copy_(anc16.index_select(1, perm))
@@ -56,12 +58,13 @@ def test_bf16_kernels_equal_the_fp32_kernels_rounded_to_bf16():
     bias = bias.to(bf).to(dev)
     c16, c32 = torch.empty(B * K, H * 64, dtype=bf, device=dev), torch.empty(B * K, H * 64, device=dev)
     check(L.sealnn_cross_attn_step_bf16(st, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), B, K, H, S, 0.125, c16.data_ptr()))
-    check(L.sealnn_cross_attn_step(st, q.float().data_ptr(), ck.float().data_ptr(), cv.float().data_ptr(), bias.float().data_ptr(), B, K, H, S, 0.125, c32.data_ptr()))
+    q32, ck32, cv32, bias32 = q.float(), ck.float(), cv.float(), bias.float()
+    check(L.sealnn_cross_attn_step(st, q32.data_ptr(), ck32.data_ptr(), cv32.data_ptr(), bias32.data_ptr(), B, K, H, S, 0.125, c32.data_ptr()))
     assert torch.equal(c16, c32.to(bf))
     rb = torch.arange(B, dtype=torch.int32).repeat_interleave(K).to(dev)
     r16, r32 = torch.empty_like(c16), torch.empty_like(c32)
     check(L.sealnn_cross_attn_rows_bf16(st, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), rb.data_ptr(), B * K, H, S, 0.125, r16.data_ptr()))
-    check(L.sealnn_cross_attn_rows(st, q.float().data_ptr(), ck.float().data_ptr(), cv.float().data_ptr(), bias.float().data_ptr(), rb.data_ptr(), B * K, H, S, 0.125, r32.data_ptr()))
+    check(L.sealnn_cross_attn_rows(st, q32.data_ptr(), ck32.data_ptr(), cv32.data_ptr(), bias32.data_ptr(), rb.data_ptr(), B * K, H, S, 0.125, r32.data_ptr()))
     assert torch.equal(r16, r32.to(bf))
     u16 = torch.empty_like(c16)
     check(L.sealnn_cross_attn_runs_bf16(st, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), rb.data_ptr(), B * K, K, H, S, 0.125, u16.data_ptr()))
@@ -71,7 +74,8 @@ def test_bf16_kernels_equal_the_fp32_kernels_rounded_to_bf16():
     qkv = rnd(n_seq * Tq, 3 * H * 64)
     s16, s32 = torch.empty(n_seq * Tq, H * 64, dtype=bf, device=dev), torch.empty(n_seq * Tq, H * 64, device=dev)
     check(L.sealnn_causal_self_attn_bf16(st, qkv.data_ptr(), n_seq, Tq, H, 0.125, s16.data_ptr()))
-    check(L.sealnn_causal_self_attn(st, qkv.float().data_ptr(), n_seq, Tq, H, 0.125, s32.data_ptr()))
+    qkv32 = qkv.float()
+    check(L.sealnn_causal_self_attn(st, qkv32.data_ptr(), n_seq, Tq, H, 0.125, s32.data_ptr()))
     assert torch.equal(s16, s32.to(bf))
     anc = torch.full((n_seq * Tq, Tq), -1, dtype=torch.int32)
     for n in range(n_seq):
