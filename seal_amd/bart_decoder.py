@@ -258,11 +258,16 @@ class BartStepDecoder:
         return F.linear(x, self.lm_w, self.lm_b.view(-1)).view(N, T, -1)
 
     @torch.no_grad()
+    def lm_head(self, x: torch.Tensor) -> torch.Tensor:
+        """decoder states [N, d] -> next-token logits [N, vocab] (``x @ shared^T + final_logits_bias``)"""
+        return F.linear(x, self.lm_w, self.lm_b.view(-1))
+
     def tree_logits(self, tok: torch.Tensor, depth: torch.Tensor, anc: torch.Tensor, qidx: torch.Tensor, enc_hidden: torch.Tensor,
-                    attention_mask: torch.Tensor, prepared=None) -> torch.Tensor:
+                    attention_mask: torch.Tensor, prepared=None, hidden_only: bool = False) -> torch.Tensor:
         """Teacher forcing over a prefix tree: node i is one decoder position -- input token ``tok[i]`` at position
         ``depth[i]`` of the distinct prefix whose nodes are ``anc[i, :depth[i] + 1]`` (root first, itself last, -1 beyond) --
-        of query ``qidx[i]``.  Returns the logits after every node, [N, vocab]: exactly what row-per-key teacher forcing
+        of query ``qidx[i]``.  Returns the logits after every node, [N, vocab] (``hidden_only``: the decoder states [N, d]
+        before the output projection, for a caller that projects them a slice at a time): exactly what row-per-key teacher forcing
         (reference keys.py:64-141) computes at that position of any row that starts with that prefix, each computed once.
         ``prepared`` = ``teacher_prepare(...)`` runs the fused sealnn_* kernels; otherwise plain torch ops (any device / dtype)."""
         N = tok.numel()
@@ -295,7 +300,7 @@ class BartStepDecoder:
                                          N, self.h, S, float(self.scale), c.data_ptr()))
                 x = add_ln(x, L["co"](c), L["ln2"])
                 x = add_ln(x, L["fc2"](L["act"](L["fc1"](x))), L["ln3"])
-            return F.linear(x, self.lm_w, self.lm_b.view(-1))
+            return x if hidden_only else self.lm_head(x)
         # plain torch ops: the ancestors' keys / values gathered per node, the encoder's per query
         B, S, _ = enc_hidden.shape
         H, dh = self.h, self.dh
@@ -317,7 +322,7 @@ class BartStepDecoder:
             c = torch.einsum("nhs,nshd->nhd", w, kv[:, :, 1][qidx]).reshape(N, self.d)
             x = L["ln2"](x + L["co"](c))
             x = L["ln3"](x + L["fc2"](L["act"](L["fc1"](x))))
-        return F.linear(x, self.lm_w, self.lm_b.view(-1))
+        return x if hidden_only else self.lm_head(x)
 
     use_fused_kernels = True      # include/sealnn.h: self-attn / cross-attn / add+LayerNorm as single HIP kernels
 

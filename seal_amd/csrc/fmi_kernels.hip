@@ -314,15 +314,16 @@ __device__ __forceinline__ void expand_subtree(const FmiDev &ix, uint4 *s_node, 
 // iterations are VALU time, not latency.
 template <bool SB, int W>
 __device__ __forceinline__ void wg_level(const FmiDev &ix, const uint4 *s_in, const uint32_t total, uint4 *s_out, uint32_t *s_cnt_out,
-                                         const uint32_t k, uint4 *s_bitmaps, const uint32_t bm_slots, const bool counting, ExpCounters &ctr)
+                                         const uint32_t k, uint4 *s_bitmaps, const uint32_t bm_slots, const bool counting, ExpCounters &ctr,
+                                         const uint32_t my_rank, const uint32_t n_live)
 {
     const uint32_t lane = threadIdx.x & 63, end = lane & 1, pair = lane >> 1;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t D = ix.dlevels;
     const bool leaf = (k + 1 == D);
     const uint32_t pad_bits = FMI_DIGIT_BITS * D - ix.levels;
     const uint32_t rel_mask = (1u << (FMI_DIGIT_BITS * (D - 2))) - 1;      // sub-tree roots are level-1 nodes
-    for (uint32_t c0 = wave * EXP_PAIRS; c0 < total; c0 += W * EXP_PAIRS) {
+    // chunk c goes to the c-th of the waves that are still in the workgroup (waves whose item is empty have left)
+    for (uint32_t c0 = my_rank * EXP_PAIRS; c0 < total; c0 += n_live * EXP_PAIRS) {
         const uint32_t g = c0 + pair;
         const bool act = g < total;
         uint4 nd = make_uint4(0u, 0u, 0u, 0u);
@@ -685,9 +686,11 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
     else { expand = true; if (hi > ix.n) hi = ix.n; }
     if constexpr (W > 1) __syncthreads(); else wave_sync();            // bitmaps and counters zeroed
     // ---- child d1 of the row's root node, then its sub-tree ----
+    bool live = false;                  // this wave's item has a sub-tree
     if (expand && hi > lo) {
         uint64_t clo, chi;
         root_child(ix, lo, hi, d1, clo, chi);
+        live = chi > clo;
         if (a.tstamp && lane == 0) a.tstamp[(uint64_t)slot * 8 + 2] = chi > clo ? __builtin_amdgcn_s_memrealtime() : 0;
         if (counting && writer && lane == 0) {
             probes += (lo >> FMI_BLOCK_SHIFT) != (hi >> FMI_BLOCK_SHIFT) ? 2 : 1;
@@ -741,13 +744,25 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
         }
     }
     if constexpr (W > 1) {
-        // levels 2 .. D-1 (dlevels 2: level 1) of the W sub-trees, the workgroup together
+        // A wave whose item is empty -- most of them once the prefixes are a few tokens long: a row's symbols then sit below
+        // one or two of the top digits -- has nothing to expand, nothing to store (the bitmap is zero) and leaves now, unless
+        // its row needs a special token set: its registers go back to the CU at once, so that the other workgroups of the
+        // launch become resident (at two workgroups of eight 126-register waves per CU a 600-row call otherwise runs in two
+        // rounds).  The barriers below count the waves that are left (s_barrier waits on the surviving waves only).
+        // Measurement modes keep every wave (the counters are flushed at the end).
+        const bool stays = live || (valid && (single >= 0 || a.always_allow_eos)) || counting || a.tstamp != nullptr;
+        if (!__builtin_amdgcn_readfirstlane((int)stays)) return;      // (a scalar condition: the whole wave branches to its end)
+        if (lane == 0) atomicOr(&s_cnt[7], 1u << wave);
+        uint32_t my_rank = 0, n_live = 1;
+        // levels 2 .. D-1 (dlevels 2: level 1) of the W sub-trees, the workgroup's remaining waves together
         for (uint32_t j = D == 2 ? 0 : 1; j + 1 < D; j++) {
             __syncthreads();        // level j complete (the first one: by every wave on its own)
             if (j == D - 2) STAMP(5);
+            const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt[7]);
+            my_rank = (uint32_t)__popc(mask & ((1u << wave) - 1)); n_live = (uint32_t)__popc(mask);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt[j]);
             wg_level<SB, W>(ix, s_lvl + constrain_lvl_off(W, j), total, s_lvl + constrain_lvl_off(W, j + 1), &s_cnt[j + 1], 1 + j,
-                            s_bitmaps, bm_slots, counting, ctr);
+                            s_bitmaps, bm_slots, counting, ctr, my_rank, n_live);
         }
         __syncthreads();            // the leaf bits other waves found for my item
     }

@@ -379,16 +379,29 @@ def _rescore_tree_jobs(model, jobs):
                             np.fromiter((J[ji]["npre"] for ji, _, _, _ in items), dtype=np.int64, count=len(items)), start)
         packed = _h2d(np.stack([tree["tok"], tree["depth"], tree["query"]]), device)
         anc_d = _h2d(tree["anc"], device)
-        logits = sd.tree_logits(packed[0], packed[1], anc_d, packed[2], enc, attention_mask, prepared)
-        if logit_bias is not None:
-            logits = logits + logit_bias[packed[2]]
-        logp = logits.log_softmax(-1)                                   # [nodes, V]: the distribution after the node's prefix
-        # term j of key k = logp[node(key[:j]), key[j]] (0 for targets < 2, keys.py:132), summed in position order in float64
-        t = _h2d(np.stack([tree["term_node"], tree["term_tok"], tree["term_key"], tree["term_col"]]), device)
-        lp = logp[t[0], t[1]].double()
-        lp = torch.where(t[1] < 2, torch.zeros_like(lp), lp)
+        hidden = sd.tree_logits(packed[0], packed[1], anc_d, packed[2], enc, attention_mask, prepared, True)      # [nodes, d]
+        # term j of key k = logp[node(key[:j]), key[j]] (0 for targets < 2, keys.py:132), summed in position order in float64.
+        # The output projection + log-softmax run over a slice of the nodes at a time (the terms sorted by node, so that a
+        # slice's terms are one run): nodes x vocab floats never exist at once -- 12 000 nodes x 50 265 x 4 B = 2.4 GB, three
+        # times with the bias add and the log-softmax -- and every row's arithmetic is what the whole-matrix form computes.
+        order = np.argsort(tree["term_node"], kind="stable")
+        t_node = tree["term_node"][order]
+        t = _h2d(np.stack([t_node, tree["term_tok"][order], tree["term_key"][order], tree["term_col"][order]]), device)
         table = torch.zeros(len(items), tree["width"], dtype=torch.float64, device=device)
-        table[t[2], t[3]] = lp
+        n_nodes = hidden.shape[0]
+        step = max(256, int(os.environ.get("SEAL_RESCORE_SLICE", 4096)))
+        for a in range(0, n_nodes, step):
+            b = min(n_nodes, a + step)
+            ta, tb = int(np.searchsorted(t_node, a, side="left")), int(np.searchsorted(t_node, b, side="left"))
+            if ta == tb:
+                continue
+            logits = sd.lm_head(hidden[a:b])
+            if logit_bias is not None:
+                logits = logits + logit_bias[packed[2][a:b]]
+            logp = logits.log_softmax(-1)                               # [slice, V]: the distribution after the node's prefix
+            lp = logp[t[0, ta:tb] - a, t[1, ta:tb]].double()
+            lp = torch.where(t[1, ta:tb] < 2, torch.zeros_like(lp), lp)
+            table[t[2, ta:tb], t[3, ta:tb]] = lp
         total = table.sum(-1).float()
         a = 0
         while a < len(items):                                           # the group's keys, job by job
