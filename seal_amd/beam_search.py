@@ -501,19 +501,71 @@ def fm_index_generate_joint(model, index: FMIndex, input_ids: torch.LongTensor, 
 
 class PendingGenerate:
     """an enqueued ``fm_index_generate``: ``result()`` waits for the GPU and builds the hypothesis lists.
-    ``enc`` = the encoder states of the call (the searcher reuses them where the reference re-encodes the same input)."""
+    ``enc`` = the encoder states of the call (the searcher reuses them where the reference re-encodes the same input).
+    ``arrays()`` is the same history as arrays (what the searcher filters before any python list exists)."""
 
     def __init__(self, steps, final, batch, beams, length_penalty, enc=None, attention_mask=None):
         self._args = (steps, final, batch, beams, length_penalty)
         self.enc, self.attention_mask = enc, attention_mask
         self.first_logits = None          # [batch, vocab]: next-token logits of the first decoder position (logit bias included)
+        self._packed = None
+        self._pack(steps, final, batch, beams)
         self._event = torch.cuda.Event() if final[0].is_cuda else None
         if self._event is not None:
             self._event.record(torch.cuda.current_stream(final[0].device))
+
+    def _pack(self, steps, final, batch, beams):
+        """the whole history in two tensors, copied to pinned host memory behind the decode (nothing waits): tokens
+        [batch, H, L] (-1 beyond a hypothesis' length; H = steps x 2K + K hypotheses per query in the reference's recording
+        order, beam_search.py:658-668 then 717-725) and their summed log-probs [batch, H]"""
+        B, K = batch, beams
+        dev = final[0].device
+        L = final[0].shape[-1]
+        H = sum(t.shape[1] for _, t, _ in steps) + K
+        tok = torch.full((B, H, L), -1, dtype=torch.int64, device=dev)
+        sc = torch.empty(B, H, dtype=torch.float32, device=dev)
+        a = 0
+        for prefix, tokens, scores in steps:
+            n, t = tokens.shape[1], prefix.shape[-1]
+            tok[:, a:a + n, :t] = prefix
+            tok[:, a:a + n, t] = tokens
+            sc[:, a:a + n] = scores
+            a += n
+        tok[:, a:a + K, :] = final[0].view(B, K, L)
+        sc[:, a:a + K] = final[1].view(B, K)
+        if dev.type == "cuda":
+            host_tok = torch.empty(tok.shape, dtype=tok.dtype, pin_memory=True)
+            host_sc = torch.empty(sc.shape, dtype=sc.dtype, pin_memory=True)
+            host_tok.copy_(tok, non_blocking=True)
+            host_sc.copy_(sc, non_blocking=True)
+        else:
+            host_tok, host_sc = tok, sc
+        lens = [p.shape[-1] + 1 for p, _, _ in steps for _ in range(p.shape[1])] + [L] * K
+        self._packed = (host_tok, host_sc, lens)
+
+    def arrays(self):
+        """(tok [B, H, L] int64, length [H] int64, score [B, H] float64, valid [B, H] bool) as numpy: hypothesis h of query b
+        is ``tok[b, h, :length[h]]`` with the score ``fm_index_generate`` would return for it (``BeamHypothesesWithMemory.add``
+        divides by ``size ** length_penalty``, the output comprehension multiplies it back, reference beam_search.py:555,752-755);
+        ``valid`` = kept by ``add`` (score > -inf)."""
+        import numpy as np
+        if self._event is not None:
+            self._event.synchronize()
+        host_tok, host_sc, lens = self._packed
+        lp = self._args[4] if self._args is not None else self._lp
+        tok = host_tok.numpy()
+        length = np.asarray(lens, dtype=np.int64)
+        s = host_sc.numpy().astype(np.float64)                      # what .tolist() / .item() hand the reference: the fp32 value as a double
+        norm = np.asarray([float(n) ** lp for n in lens], dtype=np.float64)[None, :]
+        with np.errstate(invalid="ignore"):
+            normed = s / norm
+            score = np.where(norm == 1.0, s, normed * norm)
+        return tok, length, score, normed > float("-inf")
 
     def result(self):
         if self._event is not None:
             self._event.synchronize()
         out = _history_to_hypotheses(*self._args)
+        self._lp = self._args[4]
         self._args = None
         return out

@@ -750,8 +750,11 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
         // launch become resident (at two workgroups of eight 126-register waves per CU a 600-row call otherwise runs in two
         // rounds).  The barriers below count the waves that are left (s_barrier waits on the surviving waves only).
         // Measurement modes keep every wave (the counters are flushed at the end).
-        const bool stays = live || (valid && (single >= 0 || a.always_allow_eos)) || counting || a.tstamp != nullptr;
-        if (!__builtin_amdgcn_readfirstlane((int)stays)) return;      // (a scalar condition: the whole wave branches to its end)
+        const bool stays = live || (valid && (single >= 0 || a.always_allow_eos)) || counting;
+        if (!__builtin_amdgcn_readfirstlane((int)stays)) {             // (a scalar condition: the whole wave branches to its end)
+            STAMP(3); STAMP(4);
+            return;
+        }
         if (lane == 0) atomicOr(&s_cnt[7], 1u << wave);
         uint32_t my_rank = 0, n_live = 1;
         // levels 2 .. D-1 (dlevels 2: level 1) of the W sub-trees, the workgroup's remaining waves together

@@ -191,17 +191,26 @@ class FMIndex(_FMIndex):
         """``get_range`` for many sequences in one launch -> (lo[], hi[]) uint64.  Runs on the current torch stream with
         torch-managed buffers (no hipMalloc/hipFree on the way: those synchronise the whole device, i.e. every other
         pipeline's stream)."""
-        import torch
         n = len(sequences)
         offs = np.zeros(n + 1, dtype=np.int64)
         if n:
             offs[1:] = np.cumsum([len(s) for s in sequences])
         total = int(offs[-1])
-        if n == 0:
-            return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64)
         toks = np.zeros(max(total, 1), dtype=np.int64)
         if total:
             toks[:total] = np.fromiter((t for s in sequences for t in s), dtype=np.int64, count=total)
+        return self.get_range_csr(offs, toks)
+
+    def get_range_csr(self, offsets: np.ndarray, tokens: np.ndarray):
+        """``get_range_batch`` for sequences that are already arrays: sequence i = ``tokens[offsets[i]:offsets[i + 1]]`` (int64)"""
+        import torch
+        n = len(offsets) - 1
+        if n <= 0:
+            return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64)
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        toks = np.ascontiguousarray(tokens, dtype=np.int64)
+        if toks.size == 0:
+            toks = np.zeros(1, dtype=np.int64)
         dev = torch.device("cuda", lib().fmi_device(self._h))
         st = torch.cuda.current_stream(dev)
         d_off = _h2d(offs, dev)
@@ -211,7 +220,7 @@ class FMIndex(_FMIndex):
         res = out.cpu().numpy().view(np.uint64)
         lo, hi = res[0], res[1]
         if getattr(self, "_trace", None) is not None:      # bench.py: the operation AND what the GPU answered
-            self._trace.append(("ranges", [list(s) for s in sequences], lo.copy(), hi.copy()))
+            self._trace.append(("ranges", [toks[offs[i]:offs[i + 1]].tolist() for i in range(n)], lo.copy(), hi.copy()))
         return lo, hi
 
     def get_count_batch(self, sequences: Sequence[Sequence[int]]) -> np.ndarray:

@@ -159,6 +159,72 @@ def _count_filter(index: FMIndex, per_query: List[List]) -> List[List]:
     return out
 
 
+class _HypArrays:
+    """The recorded hypotheses of one decode as arrays (``PendingGenerate.arrays``) with a window [start, end) per hypothesis:
+    the reference's list comprehensions over (score, token list) pairs (retrieval.py:85-91, 180-191) become a few numpy
+    operations over ~10^4 rows, and python lists are built for the keys that survive the filters only."""
+
+    def __init__(self, arrays):
+        import numpy as np
+        tok, length, score, valid = arrays
+        self.np = np
+        self.nq, self.nh, self.L = tok.shape
+        self.tok = tok.reshape(self.nq * self.nh, self.L)
+        self.score = score.reshape(-1)
+        self.keep = valid.reshape(-1).copy()
+        self.start = np.zeros(self.nq * self.nh, dtype=np.int64)
+        self.end = np.tile(length, self.nq)
+        self.rows = np.arange(self.nq * self.nh)
+
+    def _at(self, pos):
+        return self.tok[self.rows, np_clip(pos, 0, self.L - 1)]
+
+    def drop_empty(self):
+        self.keep &= self.end > self.start
+
+    def strip_front(self, ids):
+        hit = self.keep & (self.end > self.start) & self.np.isin(self._at(self.start), ids)
+        self.start += hit
+
+    def strip_back(self, ids):
+        hit = self.keep & (self.end > self.start) & self.np.isin(self._at(self.end - 1), ids)
+        self.end -= hit
+
+    def require_length(self, n):
+        self.keep &= (self.end - self.start) == n
+
+    def require_last(self, token):
+        self.keep &= (self.end > self.start) & (self._at(self.end - 1) == token)
+
+    def csr(self):
+        """(indices of the kept, non-empty hypotheses in list order, offsets, flat tokens) for the count filter"""
+        np = self.np
+        idx = np.nonzero(self.keep & (self.end > self.start))[0]
+        lens = (self.end - self.start)[idx]
+        pos = np.arange(self.L)[None, :]
+        m = (pos >= self.start[idx, None]) & (pos < self.end[idx, None])
+        return idx, lens, self.tok[idx][m]
+
+    def lists(self, idx, prepend=None):
+        """per query ``[(score, token list)]`` of the hypotheses ``idx`` (ascending = the reference's list order); ``prepend``:
+        a token put in front of keys that do not start with it (retrieval.py:190)"""
+        out = [[] for _ in range(self.nq)]
+        sc = self.score[idx].tolist()
+        st, en = self.start[idx].tolist(), self.end[idx].tolist()
+        rows = self.tok[idx].tolist()
+        for i, s_, a, b, row in zip((idx // self.nh).tolist(), sc, st, en, rows):
+            k = row[a:b]
+            if prepend is not None and k[0] != prepend:
+                k = [prepend] + k
+            out[i].append((s_, k))
+        return out
+
+
+def np_clip(a, lo, hi):
+    import numpy as np
+    return np.clip(a, lo, hi)
+
+
 def _process_batch(searcher, inputs, constrained_generation, offset=0, pipe=None):
     """keys of one batch of queries (reference retrieval.py:54-305)"""
     steps = _batch_steps(searcher, inputs, constrained_generation, offset, pipe)
@@ -278,8 +344,21 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
     yield "decoding"
 
     # ---- segment 2: the hypotheses (waits for the decodes) ----
-    found_keys = body.result() if body is not None else [[] for _ in inputs]
-    decoded = titles.result() if titles is not None else None
+    # On the GPU the recorded history comes back as two arrays per decode and the filters below run on them (``_HypArrays``);
+    # python lists -- what the reference's comprehensions work on -- are built for the survivors only.  Off the GPU (or with
+    # settings the array form does not cover) the lists are built first, as ever.
+    body_arr = title_arr = None
+    use_arrays = (getattr(s, "array_filters", True) and s.force_decoding_second_token < 0 and not s.decode_code
+                  and (body is None or body._packed is not None) and (titles is None or titles._packed is not None)
+                  and (body is not None or titles is not None))
+    if use_arrays:
+        body_arr = _HypArrays(body.arrays()) if body is not None else None
+        title_arr = _HypArrays(titles.arrays()) if titles is not None else None
+        found_keys = [[] for _ in inputs]
+        decoded = None
+    else:
+        found_keys = body.result() if body is not None else [[] for _ in inputs]
+        decoded = titles.result() if titles is not None else None
     decoded_code = codes.result() if codes is not None else None
     yield "decoded"
 
@@ -288,7 +367,13 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
     # a read-back.  None of the three depends on another, so here: the candidate lists of all three are built first,
     # ONE count launch filters them, the (up to) three rescorings are enqueued back to back, and only then are the
     # scores read back -- in the reference's order, into the same lists.
-    if s.decode_body:
+    if body_arr is not None:    # retrieval.py:85-90 on the arrays: empty keys dropped before each strip
+        body_arr.drop_empty(); body_arr.strip_front(strip_ids)
+        body_arr.drop_empty(); body_arr.strip_front(strip_ids)
+        body_arr.drop_empty(); body_arr.strip_back(strip_ids)
+        if s.min_length > 0:
+            body_arr.require_length(s.min_length)
+    elif s.decode_body:
         for fk in found_keys:   # retrieval.py:85-90
             fk[:] = [(sc, k[1:] if k[0] in strip_ids else k) for sc, k in fk if k]
             fk[:] = [(sc, k[1:] if k[0] in strip_ids else k) for sc, k in fk if k]
@@ -309,7 +394,13 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
             cand = [query_ngram_keys(inp, s) for inp in inputs]
         cand = [[(0.0, k) for k in kk] for kk in cand]
     title_keys = None
-    if s.decode_titles:
+    if title_arr is not None:   # retrieval.py:180-190 on the arrays
+        title_arr.strip_back(strip_ids)
+        if not s.partial_titles:
+            title_arr.require_last(s.title_eos_token_id)
+            if s.min_length > 0:
+                title_arr.require_length(s.min_length + 1)
+    elif s.decode_titles:
         title_keys = [[(sc, hyp) for sc, hyp in dec_] for dec_ in decoded]
         for fk in title_keys:   # retrieval.py:180-190
             if s.force_decoding_second_token >= 0:
@@ -331,20 +422,64 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
                 fk[:] = [(sc, k) for sc, k in fk if k and k[-1] == s.code_eos_token_id]
             fk[:] = [(sc, [s.code_bos_token_id] + k if k[0] != s.code_bos_token_id else k) for sc, k in fk if k]
     # retrieval.py:91, 130, 191, 247: get_count(k) > 0, one launch for all the lists
-    parts = [p for p in (found_keys if s.decode_body else None, cand, title_keys, code_keys) if p is not None]
     n_q = len(inputs)
-    if parts:
-        merged = _count_filter(fm_index, [fk for p in parts for fk in p])
-        parts = [merged[j * n_q:(j + 1) * n_q] for j in range(len(parts))]
-        it = iter(parts)
-        if s.decode_body:
-            found_keys = next(it)
+    if body_arr is not None or title_arr is not None:
+        import numpy as np
+        # body hypotheses, query n-grams, title hypotheses: one CSR, one launch.  A title key is counted with the title bos
+        # in front where it does not start with it (retrieval.py:190 runs before the count of :191)
+        parts_len, parts_tok, body_idx, title_idx = [], [], None, None
+        if body_arr is not None:
+            body_idx, ln, tk = body_arr.csr()
+            parts_len.append(ln); parts_tok.append(tk)
+        cand_flat = [k for kk in cand for _, k in kk if k] if cand is not None else []
+        if cand_flat:
+            parts_len.append(np.fromiter(map(len, cand_flat), dtype=np.int64, count=len(cand_flat)))
+            parts_tok.append(np.fromiter((t for k in cand_flat for t in k), dtype=np.int64))
+        title_extra = None
+        if title_arr is not None:
+            title_idx, ln, tk = title_arr.csr()
+            first = title_arr._at(title_arr.start)[title_idx]
+            title_extra = first != s.title_bos_token_id
+            if title_extra.any():                  # rare: the bos in front of those keys, in place in the flat token stream
+                offs = np.concatenate([[0], np.cumsum(ln)])[:-1]
+                tk = np.insert(tk, offs[title_extra], s.title_bos_token_id)
+                ln = ln + title_extra
+            parts_len.append(ln); parts_tok.append(tk)
+        lens = np.concatenate(parts_len) if parts_len else np.zeros(0, np.int64)
+        counts = np.zeros(0, np.int64)
+        if len(lens):
+            offsets = np.zeros(len(lens) + 1, dtype=np.int64)
+            np.cumsum(lens, out=offsets[1:])
+            flat = np.concatenate(parts_tok)
+            if hasattr(fm_index, "get_range_csr"):
+                lo, hi = fm_index.get_range_csr(offsets, flat)
+                counts = (hi - lo).astype(np.int64)
+            else:               # an index without the CSR entry point (tests: the oracle behind the batched interface)
+                counts = np.asarray(fm_index.get_count_batch([flat[offsets[i]:offsets[i + 1]].tolist() for i in range(len(lens))]), dtype=np.int64)
+        a = 0
+        if body_arr is not None:
+            found_keys = body_arr.lists(body_idx[counts[a:a + len(body_idx)] > 0])
+            a += len(body_idx)
         if cand is not None:
-            cand = [[k for _, k in kk] for kk in next(it)]
-        if title_keys is not None:
-            title_keys = next(it)
-        if code_keys is not None:
-            code_keys = next(it)
+            it = iter(counts[a:a + len(cand_flat)].tolist())
+            cand = [[k for _, k in kk if k and next(it) > 0] for kk in cand]
+            a += len(cand_flat)
+        if title_arr is not None:
+            title_keys = title_arr.lists(title_idx[counts[a:a + len(title_idx)] > 0], prepend=s.title_bos_token_id)
+    else:
+        parts = [p for p in (found_keys if s.decode_body else None, cand, title_keys, code_keys) if p is not None]
+        if parts:
+            merged = _count_filter(fm_index, [fk for p in parts for fk in p])
+            parts = [merged[j * n_q:(j + 1) * n_q] for j in range(len(parts))]
+            it = iter(parts)
+            if s.decode_body:
+                found_keys = next(it)
+            if cand is not None:
+                cand = [[k for _, k in kk] for kk in next(it)]
+            if title_keys is not None:
+                title_keys = next(it)
+            if code_keys is not None:
+                code_keys = next(it)
     marked_rescoring = s.rescore and s.use_markers
     # the rescorings of the batch (retrieval.py:93-100, 139-149, 193-203, 249-263): the jobs of one model share one forward
     body_job = cand_job = title_job = code_job = None
@@ -486,6 +621,8 @@ class SEALSearcher:
         self.gpu_aggregate: bool = params.get("gpu_aggregate", True)
         # extension: query batches in flight on the GPU at a time (each batch_size queries, own stream); 1 = one after the other
         self.pipeline: int = int(params.get("pipeline", 1))
+        # extension: the post-filters of the decodes run on the history as arrays (GPU decodes); False = on python lists
+        self.array_filters: bool = bool(params.get("array_filters", True))
         # extension: the decodes of a batch that share a model (body, title[, code]) run as ONE loop, rows stacked
         self.joint_decode: bool = bool(params.get("joint_decode", True))
         # extension: enqueue the next batch's decodes before this batch's rescoring / aggregation (same thread, second stream)

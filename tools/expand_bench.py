@@ -162,8 +162,9 @@ def main():
                 t0 = t[:, 0].min()
                 def q(col, mask=None):
                     v = (t[:, col] - t0)[(t[:, col] > 0) if mask is None else mask] / 100.0        # 100 MHz -> us
-                    return None if v.size == 0 else [round(float(x), 2) for x in (v.min(), float(__import__("numpy").median(v)), v.max())]
-                print(json.dumps({"prefix_len": pl, "waves": int(t.shape[0]), "us_since_first_wave_start[min,median,max]": {
+                    np_ = __import__("numpy")
+                    return None if v.size == 0 else [round(float(x), 2) for x in (v.min(), float(np_.median(v)), float(np_.percentile(v, 90)), v.max())]
+                print(json.dumps({"prefix_len": pl, "rows": args.rows, "waves": int(t.shape[0]), "us_since_first_wave_start[min,median,p90,max]": {
                     "wave_start": q(0), "prefix_range_known": q(1), "root_child_known(non-empty only)": q(2), "leaf_phase_start(workgroup)": q(5), "subtree_done": q(3), "bitmap_stored": q(4)},
                     "waves_with_a_subtree": int((t[:, 2] > 0).sum())}), flush=True)
             allowed = int(sum(bin(x & 0xFFFFFFFF).count("1") for x in bits[:8].flatten().tolist())) / 8.0
