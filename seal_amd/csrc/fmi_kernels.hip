@@ -537,6 +537,10 @@ struct ForceFrom { int64_t tok[MAX_FORCE]; uint32_t n; };
 // end-of-sequence token and forced prefix (reference retrieval.py:70-83 vs 162-176).  One group = the classic call.
 static constexpr int MAX_ROW_GROUPS = 3;
 
+// Row-first calls (k_constrain_rows, then k_constrain): what ONE wave per row worked out for its row -- range, class, and the
+// sixteen children of its root node -- for the (row, top digit) waves of the second launch to pick up with a single load
+struct RowPre { uint64_t lo, hi; int64_t single; uint32_t expand, child_mask; };
+
 struct ConstrainArgs {
     uint32_t rows, ndig0;          // grid = rows * ndig0 waves
     uint64_t cur_len;
@@ -557,6 +561,8 @@ struct ConstrainArgs {
     uint64_t *probe_counter;
     uint64_t *tstamp;              // tools only: 8 realtime stamps (100 MHz) per wave, or null
     uint32_t groups;               // W > 1: row groups per top digit (ceil(rows / W); grid = groups * ndig0 workgroups)
+    RowPre *pre_rows;              // row-first calls: [rows], written by k_constrain_rows, read by k_constrain (else null)
+    uint64_t *pre_child;           // [rows][16][2]: child d of the row's root node, [lo, hi) on level 1
 };
 
 // a special token (pad / eos) of the row: into the LDS bitmap of the wave that owns its symbol; tokens
@@ -592,6 +598,104 @@ __host__ __device__ constexpr uint32_t constrain_lds_slots(uint32_t D, uint32_t 
 }
 
 static constexpr int CONSTRAIN_WG = 8;       // 39 KB of LDS per workgroup at BART's depth, two workgroups per CU
+
+// the row's group (wave-uniform: scalar compares on kernel arguments)
+__device__ __forceinline__ uint32_t row_group(const ConstrainArgs &a, uint32_t r)
+{
+    uint32_t grp = 0;
+#pragma unroll
+    for (int g = 1; g < MAX_ROW_GROUPS; g++) grp += r >= a.grp_first[g] ? 1u : 0u;
+    return grp;
+}
+
+// The row's own dependent chain (beam_search.py:87-131): range of its prefix -- one backward-search step from the range kept
+// for its parent row, or the full search --, count of the prefix without its last token, and the class: `single` >= 0 = the
+// only token allowed (eos below stop_at_count, pad for a finished row), else `expand` the range [lo, hi).  Wave-uniform
+// addresses read through the constant address space: scalar loads, scalar ALU.
+__device__ __forceinline__ void row_range_and_class(const FmiDev &ix, const ConstrainArgs &a, const uint32_t r, const bool valid, const bool write_state,
+                                                    uint64_t &lo, uint64_t &hi, int64_t &single, bool &expand, int64_t &eos_id,
+                                                    uint64_t &probes, uint32_t &model)
+{
+    uint64_t count = 0;
+    bool dead = true;
+    const uint32_t grp = row_group(a, r);
+    eos_id = a.grp_eos[grp];
+    const ForceFrom &ff = a.grp_ff[grp];
+    lo = hi = 0;
+    if (valid) {
+        // ids / parent / the kept ranges were written by earlier launches, not by this one: constant here
+        const cptr<int64_t> sent = as_const(a.ids) + (uint64_t)r * a.cur_len;
+        const int64_t last = sent[a.cur_len - 1];
+        dead = last == eos_id || last == a.pad_id;
+        if (!dead) {
+            // get_range(force_decoding_from + sent[1:]) and get_count(... sent[1:-1])
+            uint64_t l = 0, rr = ix.n;
+            if (a.st_in) {
+                // incremental: the row extends row parent[r] of the previous step, whose inclusive range
+                // [l, rr] after the same prefix was kept -- one backward-search step instead of len
+                const uint64_t pr = (uint64_t)as_const(a.parent)[r];
+                l = as_const(a.st_in)[2 * pr]; rr = as_const(a.st_in)[2 * pr + 1];
+                count = (rr + 1) - l;
+                bs_step(ix, (uint64_t)(last + a.shift), l, rr, l, rr, &probes);
+                model += ix.levels * (uint32_t)(ff.n + (a.cur_len - 1));    // the reference re-searches the whole prefix
+            } else {
+                const uint64_t total = ff.n + (a.cur_len - 1);
+                for (uint64_t t = 0; t < total; t++) {
+                    if (t + 1 == total) count = (rr + 1) - l;
+                    const int64_t tok = t < ff.n ? ff.tok[t] : sent[1 + (t - ff.n)];
+                    bs_step(ix, (uint64_t)(tok + a.shift), l, rr, l, rr, &probes);
+                    model += ix.levels;
+                }
+                if (total == 0) count = (rr + 1) - l;
+            }
+            if (write_state && a.st_out) { a.st_out[2 * r] = l; a.st_out[2 * r + 1] = rr; }
+            lo = l; hi = rr + 1;
+        }
+    }
+    single = -1;
+    expand = false;
+    if (!valid) {}
+    else if (a.stop_at_count > 0 && (int64_t)count <= a.stop_at_count) single = eos_id;
+    else if (dead) single = a.pad_id;
+    else { expand = true; if (hi > ix.n) hi = ix.n; }
+}
+
+// Row-first call, first launch: ONE wave per row runs the row's chain (13 x fewer waves than when every (row, top digit) wave
+// of k_constrain repeats it) and splits the root node over all sixteen digits with one single-digit rank per lane.
+__global__ __launch_bounds__(256) void k_constrain_rows(FmiDev ix, ConstrainArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t r = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (r >= a.rows) return;
+    uint64_t lo, hi, probes = 0;
+    uint32_t model = 0;
+    int64_t single, eos_id;
+    bool expand;
+    row_range_and_class(ix, a, r, true, lane == 0, lo, hi, single, expand, eos_id, probes, model);
+    const bool split = expand && hi > lo;
+    const uint32_t e = lane & 1, d = lane >> 1;
+    uint64_t q = 0;
+    if (split && lane < 32) q = wm_step(ix, 0, e ? hi : lo, d);
+    const uint64_t qo = (uint64_t)dpp_xor1((uint32_t)q) | ((uint64_t)dpp_xor1((uint32_t)(q >> 32)) << 32);
+    const uint64_t bal = __ballot(lane < 32 && e == 0 && qo > q);
+    if (lane < 32) a.pre_child[((uint64_t)r * FMI_ARITY + d) * 2 + e] = q;
+    uint32_t em = 0;
+#pragma unroll
+    for (uint32_t x = 0; x < 16; x++) em |= (uint32_t)((bal >> (2 * x)) & 1ull) << x;
+    if (lane == 0) {
+        RowPre p;
+        p.lo = lo; p.hi = hi; p.single = single; p.expand = expand ? 1u : 0u; p.child_mask = em;
+        a.pre_rows[r] = p;
+    }
+    if (a.probe_counter) {
+        ExpCounters ctr{0, 0, 0, 0};
+        if (lane == 0) {
+            ctr.probes = (uint32_t)probes + (split ? ((lo >> FMI_BLOCK_SHIFT) != (hi >> FMI_BLOCK_SHIFT) ? 2u : 1u) : 0u);
+            ctr.model = model + (split ? model_nodes(em, 0, FMI_DIGIT_BITS * ix.dlevels - ix.levels) : 0u);
+        }
+        flush_counters(a.probe_counter, ctr);
+    }
+}
 
 template <bool SB, int W>
 __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, ConstrainArgs a)
@@ -638,61 +742,35 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
     if (W > 1 && threadIdx.x < 8) s_cnt[threadIdx.x] = 0u;
 
     // ---- the row: prefix range, class (identical in every wave of the row) ----
-    uint64_t lo = 0, hi = 0, count = 0, probes = 0;
+    uint64_t lo = 0, hi = 0, probes = 0;
     uint32_t model = 0;      // in nodes of the binary model: one backward-search step = `levels` nodes (2 L probes)
-    bool dead = true;
-    // the row's group (wave-uniform: scalar compares on kernel arguments)
-    uint32_t grp = 0;
-#pragma unroll
-    for (int g = 1; g < MAX_ROW_GROUPS; g++) grp += r >= a.grp_first[g] ? 1u : 0u;
-    const int64_t eos_id = a.grp_eos[grp];
-    const ForceFrom &ff = a.grp_ff[grp];
-    if (valid) {
-        // ids / parent / the kept ranges were written by earlier launches, not by this one: constant here
-        const cptr<int64_t> sent = as_const(a.ids) + (uint64_t)r * a.cur_len;
-        const int64_t last = sent[a.cur_len - 1];
-        dead = last == eos_id || last == a.pad_id;
-        if (!dead) {
-            // get_range(force_decoding_from + sent[1:]) and get_count(... sent[1:-1])
-            uint64_t l = 0, rr = ix.n;
-            if (a.st_in) {
-                // incremental: the row extends row parent[r] of the previous step, whose inclusive range
-                // [l, rr] after the same prefix was kept -- one backward-search step instead of len
-                const uint64_t pr = (uint64_t)as_const(a.parent)[r];
-                l = as_const(a.st_in)[2 * pr]; rr = as_const(a.st_in)[2 * pr + 1];
-                count = (rr + 1) - l;
-                bs_step(ix, (uint64_t)(last + a.shift), l, rr, l, rr, &probes);
-                model += ix.levels * (uint32_t)(ff.n + (a.cur_len - 1));    // the reference re-searches the whole prefix
-            } else {
-                const uint64_t total = ff.n + (a.cur_len - 1);
-                for (uint64_t t = 0; t < total; t++) {
-                    if (t + 1 == total) count = (rr + 1) - l;
-                    const int64_t tok = t < ff.n ? ff.tok[t] : sent[1 + (t - ff.n)];
-                    bs_step(ix, (uint64_t)(tok + a.shift), l, rr, l, rr, &probes);
-                    model += ix.levels;
-                }
-                if (total == 0) count = (rr + 1) - l;
-            }
-            if (writer && lane == 0 && a.st_out) { a.st_out[2 * r] = l; a.st_out[2 * r + 1] = rr; }
-            lo = l; hi = rr + 1;
+    int64_t single = -1, eos_id = 0;
+    bool expand = false;
+    const bool pre = W > 1 && a.pre_rows != nullptr;      // row-first call: k_constrain_rows has done the rows
+    if (pre) {
+        eos_id = a.grp_eos[row_group(a, r)];
+        if (valid) {
+            const cptr<RowPre> p = as_const(a.pre_rows) + r;
+            lo = p->lo; hi = p->hi; single = p->single; expand = p->expand != 0;
         }
+    } else {
+        row_range_and_class(ix, a, r, valid, writer && lane == 0, lo, hi, single, expand, eos_id, probes, model);
     }
     STAMP(1);
-    int64_t single = -1;
-    bool expand = false;
-    if (!valid) {}
-    else if (a.stop_at_count > 0 && (int64_t)count <= a.stop_at_count) single = eos_id;
-    else if (dead) single = a.pad_id;
-    else { expand = true; if (hi > ix.n) hi = ix.n; }
     if constexpr (W > 1) __syncthreads(); else wave_sync();            // bitmaps and counters zeroed
     // ---- child d1 of the row's root node, then its sub-tree ----
     bool live = false;                  // this wave's item has a sub-tree
     if (expand && hi > lo) {
         uint64_t clo, chi;
-        root_child(ix, lo, hi, d1, clo, chi);
+        if (pre) {
+            const cptr<uint64_t> c = as_const(a.pre_child) + ((uint64_t)r * FMI_ARITY + d1) * 2;
+            clo = c[0]; chi = c[1];
+        } else {
+            root_child(ix, lo, hi, d1, clo, chi);
+        }
         live = chi > clo;
         if (a.tstamp && lane == 0) a.tstamp[(uint64_t)slot * 8 + 2] = chi > clo ? __builtin_amdgcn_s_memrealtime() : 0;
-        if (counting && writer && lane == 0) {
+        if (counting && writer && lane == 0 && !pre) {
             probes += (lo >> FMI_BLOCK_SHIFT) != (hi >> FMI_BLOCK_SHIFT) ? 2 : 1;
             model += model_nodes(root_children_mask(ix, lo, hi), 0, FMI_DIGIT_BITS * D - ix.levels);
         }
@@ -1409,12 +1487,15 @@ extern "C" int fmi_dev_get_range(fmi_t *h, void *stream, uint64_t n_seq, const i
 static constexpr uint64_t WS_BITS_WORDS = (1ull << FMI_MAX_LEVELS) / 32;
 static inline uint32_t *ws_bits(fmi *h, int which) { return (uint32_t *)h->ws + (uint64_t)which * h->ws_rows * WS_BITS_WORDS; }
 static inline uint64_t *ws_state(fmi *h, int which) { return (uint64_t *)(ws_bits(h, 2)) + (uint64_t)which * 2 * h->ws_rows; }
+// row-first calls: per row a RowPre (32 B) and the sixteen children of its root node (256 B)
+static inline RowPre *ws_pre_rows(fmi *h) { return (RowPre *)ws_state(h, 2); }
+static inline uint64_t *ws_pre_child(fmi *h) { return (uint64_t *)(ws_pre_rows(h) + h->ws_rows); }
 extern "C" int fmi_dev_reserve(fmi_t *h, uint64_t max_rows)
 {
     int rc = need_device(h); if (rc) return rc;
     if (max_rows <= h->ws_rows) return FMI_OK;
     if (h->ws) { HIPCHK(hipFree(h->ws)); h->ws = nullptr; h->ws_rows = 0; }
-    const uint64_t bytes = max_rows * (2 * WS_BITS_WORDS * 4 + 32) + 256;
+    const uint64_t bytes = max_rows * (2 * WS_BITS_WORDS * 4 + 32 + sizeof(RowPre) + FMI_ARITY * 16) + 256;
     HIPCHK(hipMalloc(&h->ws, bytes));
     h->ws_bytes = bytes; h->ws_rows = max_rows;
     HIPCHK(hipMemset(h->ws, 0, max_rows * 2 * WS_BITS_WORDS * 4));
@@ -1573,6 +1654,23 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
     const size_t lds = (size_t)constrain_lds_slots(h->dlevels, W) * 16;
     const bool sb = h->dev.nsb > 1;
+    // Row-first: once the prefixes are a few tokens long, nine of ten (row, top digit) items are empty and a call is the chain of
+    // dependent accesses of a row (parent -> kept range -> one backward-search step -> root child), which every one of the 13 waves
+    // of a row would repeat: ONE wave per row runs it first (k_constrain_rows), the item waves pick the result up with a single load
+    // and the empty ones are gone a microsecond into the second launch.  Wide rows (the first constrained steps of a decode) gain
+    // nothing from the extra launch: the host picks by prefix length (SEALFM_ROW_FIRST=0 / 1 forces either; same results).
+    uint64_t longest = 0;
+    for (uint32_t g = 0; g < rg.n; g++) longest = std::max<uint64_t>(longest, rg.n_force[g] + (cur_len - 1));
+    const char *rfenv = getenv("SEALFM_ROW_FIRST");
+    // measured (profiles/r3_rowfirst_ab.txt): wins from 3-token prefixes on at 300 rows (29.6 -> 28.1, 26.3 -> 24.7, 18.9 -> 17.5 us at 3 / 4 / 6
+    // tokens; 2 tokens 44.5 -> 45.3), from 2 tokens on at 600 rows (81 -> 79, 52 -> 45, 40 -> 33, 33 -> 21 us at 2 / 3 / 4 / 6); a call of
+    // single-token prefixes loses 2.7 us to the extra launch (62.9 -> 65.6)
+    const uint64_t rf_from = getenv("SEALFM_ROW_FIRST_FROM") ? (uint64_t)atoll(getenv("SEALFM_ROW_FIRST_FROM")) : (rows >= 512 ? 2 : 3);
+    const bool row_first = W > 1 && (rfenv ? atoi(rfenv) != 0 : longest >= rf_from);
+    if (row_first) {
+        a.pre_rows = ws_pre_rows(h); a.pre_child = ws_pre_child(h);
+        hipLaunchKernelGGL(k_constrain_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, h->dev, a);
+    }
     void (*kern)(FmiDev, ConstrainArgs) = W > 1 ? (sb ? k_constrain<true, CONSTRAIN_WG> : k_constrain<false, CONSTRAIN_WG>)
                                                 : (sb ? k_constrain<true, 1> : k_constrain<false, 1>);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds, st, h->dev, a);
