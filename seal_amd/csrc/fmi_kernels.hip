@@ -561,6 +561,7 @@ struct ConstrainArgs {
     uint64_t *probe_counter;
     uint64_t *tstamp;              // tools only: 8 realtime stamps (100 MHz) per wave, or null
     uint32_t groups;               // W > 1: row groups per top digit (ceil(rows / W); grid = groups * ndig0 workgroups)
+    int leave_early;               // the waves of empty items leave before the level loops (see k_constrain)
     RowPre *pre_rows;              // row-first calls: [rows], written by k_constrain_rows, read by k_constrain (else null)
     uint64_t *pre_child;           // [rows][16][2]: child d of the row's root node, [lo, hi) on level 1
 };
@@ -829,7 +830,9 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
         // rounds).  The barriers below count the waves that are left (s_barrier waits on the surviving waves only).
         // Measurement modes keep every wave (the counters are flushed at the end).
         const bool stays = live || (valid && (single >= 0 || a.always_allow_eos)) || counting;
-        if (!__builtin_amdgcn_readfirstlane((int)stays)) {             // (a scalar condition: the whole wave branches to its end)
+        // (keeping the empty waves as helpers where a workgroup has much to share measured the same on the bench workload: 39.0 vs 39.4 us
+        //  per call, SEALFM_LEAVE_EARLY=0; on 600 narrow rows leaving is what lets the second launch of a row-first call finish in 12 us)
+        if (a.leave_early && !__builtin_amdgcn_readfirstlane((int)stays)) {     // (a scalar condition: the whole wave branches to its end)
             STAMP(3); STAMP(4);
             return;
         }
@@ -1661,10 +1664,13 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     // nothing from the extra launch: the host picks by prefix length (SEALFM_ROW_FIRST=0 / 1 forces either; same results).
     uint64_t longest = 0;
     for (uint32_t g = 0; g < rg.n; g++) longest = std::max<uint64_t>(longest, rg.n_force[g] + (cur_len - 1));
-    const char *rfenv = getenv("SEALFM_ROW_FIRST");
+    a.leave_early = getenv("SEALFM_LEAVE_EARLY") ? atoi(getenv("SEALFM_LEAVE_EARLY")) : 1;
+    const char *rfenv = getenv("SEALFM_ROW_FIRST");        // 0: always the single launch; 1: always row-first
     // measured (profiles/r3_rowfirst_ab.txt): wins from 3-token prefixes on at 300 rows (29.6 -> 28.1, 26.3 -> 24.7, 18.9 -> 17.5 us at 3 / 4 / 6
     // tokens; 2 tokens 44.5 -> 45.3), from 2 tokens on at 600 rows (81 -> 79, 52 -> 45, 40 -> 33, 33 -> 21 us at 2 / 3 / 4 / 6); a call of
-    // single-token prefixes loses 2.7 us to the extra launch (62.9 -> 65.6)
+    // single-token prefixes loses 2.7 us to the extra launch (62.9 -> 65.6).  (A third form -- the rows append their non-empty items to
+    // ONE list that a fixed grid walks -- measured slower everywhere, 22.1 vs 17.5 us on the narrowest call: 600 returning atomics on one
+    // counter cost more than the empty waves they save.)
     const uint64_t rf_from = getenv("SEALFM_ROW_FIRST_FROM") ? (uint64_t)atoll(getenv("SEALFM_ROW_FIRST_FROM")) : (rows >= 512 ? 2 : 3);
     const bool row_first = W > 1 && (rfenv ? atoi(rfenv) != 0 : longest >= rf_from);
     if (row_first) {
