@@ -911,7 +911,7 @@ def main():
             pmc = json.load(open(f))
             if pmc.get("_kernel_source_sha256") != now:
                 continue            # counters of another kernel generation are REFUSED (the file records the source it profiled)
-            kib = sum(v["FETCH_SIZE"]["avg"] for k, v in pmc.items() if k.startswith("void k_constrain"))
+            kib = sum(v["FETCH_SIZE"]["avg"] for k, v in pmc.items() if "k_constrain" in k)      # both launches of a row-first call
             if kib:
                 traffic = round(kib * 1024.0 * 2, 1)
                 traffic_src = {"file": os.path.relpath(f, ROOT), "commit": pmc.get("_commit"), "kernel_source_sha256": now[:16]}
@@ -922,8 +922,9 @@ def main():
     except Exception as e:
         traffic_src = {"error": repr(e)}
     nl = max(1, launches.value)
-    roofline = {"bound": "hbm", "kernel": "k_constrain (one constraint call = one launch: prefix range, row class and root digit per (row, top digit) "
-                                          "wave, the sub-trees level by level by workgroups of 8 waves)",
+    roofline = {"bound": "hbm", "kernel": "k_constrain (one constraint call for the rows of both decodes; from 2-token prefixes on as two launches: "
+                                          "k_constrain_rows -- one wave per row: prefix range, class, root node split -- then k_constrain -- one wave per "
+                                          "(row, top digit), the sub-trees level by level by workgroups of 8 waves; events bracket the call)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic, "traffic_source": traffic_src, "launches": int(l2.value), "avg_launch_us": round(k2.value * 1e3 / n2, 2),
                 "algorithmic_bytes_per_launch": round(p2.value * 128.0 / n2, 1),
