@@ -285,3 +285,61 @@ def test_rescore_keys_multi_equals_separate_calls():
                 assert [k for _, k in qa] == [k for _, k in qb]
                 for (sa, _), (sb, _) in zip(qa, qb):
                     assert abs(sa - sb) <= 2e-5 * max(1.0, abs(sb)), (kw, share)
+
+
+def test_array_post_filters_equal_the_reference_list_comprehensions():
+    """``retrieval._HypArrays`` (the searcher's post-filters on the decode history as arrays) against the reference's list
+    comprehensions (retrieval.py:85-90 body keys, 180-190 title keys) on random hypotheses that hit every edge: keys that
+    become empty after one / two / three strips, keys of strip tokens only, invalid (-inf) scores, the length filters,
+    titles that do not end with the title eos, titles that do not start with the title bos."""
+    import numpy as np
+    from seal_amd.retrieval import _HypArrays
+    rng = np.random.default_rng(0)
+    strip_ids, title_eos, title_bos = (0, 2), 7, 2
+    B, H, L = 5, 300, 6
+    length = rng.integers(1, L + 1, size=H)
+    tok = np.full((B, H, L), -1, dtype=np.int64)
+    for b in range(B):
+        for h in range(H):
+            tok[b, h, :length[h]] = rng.choice([0, 2, 2, 7, 7, 5, 9, 11], size=length[h])
+    score = rng.normal(size=(B, H))
+    valid = rng.random((B, H)) > 0.1
+
+    def lists():
+        return [[(float(score[b, h]), tok[b, h, :length[h]].tolist()) for h in range(H) if valid[b, h]] for b in range(B)]
+
+    for min_length in (0, 2):
+        # body keys
+        want = lists()
+        for fk in want:
+            fk[:] = [(sc, k[1:] if k[0] in strip_ids else k) for sc, k in fk if k]
+            fk[:] = [(sc, k[1:] if k[0] in strip_ids else k) for sc, k in fk if k]
+            fk[:] = [(sc, k[:-1] if k[-1] in strip_ids else k) for sc, k in fk if k]
+            if min_length > 0:
+                fk[:] = [(sc, k) for sc, k in fk if len(k) == min_length]
+            fk[:] = [(sc, k) for sc, k in fk if k]            # what `if k and count > 0` keeps before counting
+        arr = _HypArrays((tok, length, score, valid))
+        arr.drop_empty(); arr.strip_front(strip_ids)
+        arr.drop_empty(); arr.strip_front(strip_ids)
+        arr.drop_empty(); arr.strip_back(strip_ids)
+        if min_length > 0:
+            arr.require_length(min_length)
+        idx, lens, flat = arr.csr()
+        got = arr.lists(idx)
+        assert got == want
+        assert lens.tolist() == [len(k) for fk in want for _, k in fk] and flat.tolist() == [t for fk in want for _, k in fk for t in k]
+        # title keys (every hypothesis has at least one token, as every recorded hypothesis does)
+        want = lists()
+        for fk in want:
+            fk[:] = [(sc, k[:-1] if k[-1] in strip_ids else k) for sc, k in fk]
+            fk[:] = [(sc, k) for sc, k in fk if k and k[-1] == title_eos]
+            if min_length > 0:
+                fk[:] = [(sc, k) for sc, k in fk if len(k) == (min_length + 1)]
+            fk[:] = [(sc, [title_bos] + k if k[0] != title_bos else k) for sc, k in fk]
+        arr = _HypArrays((tok, length, score, valid))
+        arr.strip_back(strip_ids)
+        arr.require_last(title_eos)
+        if min_length > 0:
+            arr.require_length(min_length + 1)
+        idx, _, _ = arr.csr()
+        assert arr.lists(idx, prepend=title_bos) == want
