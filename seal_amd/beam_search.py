@@ -438,14 +438,16 @@ def fm_index_generate(
 @torch.no_grad()
 def fm_index_generate_joint(model, index: FMIndex, input_ids: torch.LongTensor, attention_mask: torch.LongTensor, jobs,
                             num_beams: int = 3, length_penalty: float = 1.0, stop_at_count: int = 0, always_allow_eos: bool = False,
-                            disable_fm_index: bool = False, logit_bias=None, decoder=None, forced_bos_token_id=None):
+                            disable_fm_index: bool = False, logit_bias=None, decoder=None, forced_bos_token_id=None, extra_inputs=None):
     """Several ``fm_index_generate(keep_history=True)`` calls of ONE model as one decode loop: ``jobs`` = dicts with
     ``batch`` (the next ``batch`` rows of ``input_ids`` are this job's encoder inputs), ``max_length``, ``eos_token_id``,
     ``force_decoding_from``.  The searcher's body and title decodes (reference retrieval.py:70-83, 162-176: two
     ``generate`` calls one after the other over the same queries) become 2 x batch x beams rows per model step: one encoder
     pass, GEMMs at twice the height, one constraint launch per step for both (``constrained_beam_search_groups``).  Every job
     gets the hypotheses its own call would produce.  ``logit_bias`` [sum of batches, vocab].  Returns one ``PendingGenerate``
-    per job, in the order given (nothing has waited for the GPU)."""
+    per job, in the order given (nothing has waited for the GPU).  ``extra_inputs`` = (input_ids, attention_mask) of further encoder
+    inputs of the same width that ride along in the ONE encoder pass (the searcher's bare queries, which its rescoring of the body
+    keys encodes, reference retrieval.py:93-100); their states come back as ``out[0].extra_encoded``."""
     from .bart_decoder import BartStepDecoder
     if forced_bos_token_id is None:
         forced_bos_token_id = getattr(model.config, "forced_bos_token_id", None)
@@ -474,7 +476,13 @@ def fm_index_generate_joint(model, index: FMIndex, input_ids: torch.LongTensor, 
             force_decoding_from=j.get("force_decoding_from"), stop_at_count=stop_at_count, always_allow_eos=always_allow_eos,
             forced_bos_token_id=forced_bos_token_id)
         specs.append(dict(batch=j["batch"], max_length=j["max_length"], eos_token_id=eos, processor=proc))
-    enc = decoder.encode(input_ids, attention_mask)
+    extra_encoded = None
+    if extra_inputs is not None and extra_inputs[0].shape[1] == input_ids.shape[1]:
+        n_own = input_ids.shape[0]
+        enc_all = decoder.encode(torch.cat([input_ids, extra_inputs[0]]), torch.cat([attention_mask, extra_inputs[1]]))
+        enc, extra_encoded = enc_all[:n_own], (enc_all[n_own:], extra_inputs[1])
+    else:
+        enc = decoder.encode(input_ids, attention_mask)
     cuts, gone = [], 0                       # queries that have left the loop after each group but the last
     for sp in specs[:-1]:
         gone += sp["batch"]
@@ -496,6 +504,7 @@ def fm_index_generate_joint(model, index: FMIndex, input_ids: torch.LongTensor, 
         pg.first_logits = first_logits[a:b] if first_logits is not None else None
         out[i] = pg
         a = b
+    out[0].extra_encoded = extra_encoded
     return out
 
 
@@ -508,6 +517,7 @@ class PendingGenerate:
         self._args = (steps, final, batch, beams, length_penalty)
         self.enc, self.attention_mask = enc, attention_mask
         self.first_logits = None          # [batch, vocab]: next-token logits of the first decoder position (logit bias included)
+        self.extra_encoded = None         # fm_index_generate_joint(extra_inputs=...): (encoder states, attention mask) of the inputs that rode along
         self._packed = None
         self._pack(steps, final, batch, beams)
         self._event = torch.cuda.Event() if final[0].is_cuda else None

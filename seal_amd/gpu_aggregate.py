@@ -11,6 +11,7 @@ and as the fall-back for a query that exceeds a device limit.
 """
 import ctypes
 import os
+from collections.abc import Mapping
 from itertools import chain
 from typing import List, Optional
 
@@ -225,20 +226,72 @@ def _run_plan(index, plan, nq, params):
     return out
 
 
+class _Results(Mapping):
+    """``results`` of one query from the fetched records: doc -> [score, picks, None, tokens, [best ngram, best score]] by
+    descending score, as ``aggregate_evidence`` returns it -- a read-only mapping over the fetched arrays whose entries are
+    built when somebody asks for them (the searcher reads ids, scores and token slices of the top k straight from the arrays:
+    ``top``; 2 000 five-element entries with their lazy members per batch were 9 ms of host time nobody looked at)."""
+
+    def __init__(self, out, qi, k0, ngram_of):
+        keep = out["keep"]
+        a, n = qi * keep, int(out["n_out"][qi])
+        self._out, self._a, self._n, self._k0, self._ngram_of = out, a, n, k0, ngram_of
+        self._docs = out["doc"][a:a + n].tolist()
+        self._pos = None
+        self._entries = {}
+
+    def __len__(self):
+        return self._n
+
+    def __iter__(self):
+        return iter(self._docs)
+
+    def _entry(self, x):
+        e = self._entries.get(x)
+        if e is None:
+            out, a, k0 = self._out, self._a + x, self._k0
+            po, npk, to, T = int(out["pick_off"][a]), int(out["npicks"][a]), int(out["tok_off"][a]), int(out["T"][a])
+            ids = out["pick_id"][po:po + npk]
+            ids = np.where(ids >= 0, ids - k0, ids)                 # table key id -> index into this query's table
+            bk = int(out["best_key"][a])
+            e = self._entries[x] = [float(out["score"][a]), _LazyPicks(ids, out["pick_score"][po:po + npk], self._ngram_of), None,
+                                    _LazyTokens(out["tokens"][to:to + T]),
+                                    [self._ngram_of[bk - k0] if bk >= 0 else [], float(out["best_score"][a])]]
+        return e
+
+    def __getitem__(self, doc):
+        if self._pos is None:
+            self._pos = {d: x for x, d in enumerate(self._docs)}
+        return self._entry(self._pos[doc])
+
+    def items(self):
+        return _ItemsOf(self)
+
+    def top(self, k):
+        """(doc ids, scores, token arrays) of the first ``k`` documents, no entry built"""
+        out, a = self._out, self._a
+        n = min(self._n, k)
+        to, T = out["tok_off"][a:a + n].tolist(), out["T"][a:a + n].tolist()
+        toks = out["tokens"]
+        return self._docs[:n], out["score"][a:a + n].tolist(), [_LazyTokens(toks[o:o + t]) for o, t in zip(to, T)]
+
+
+class _ItemsOf:
+    """``dict.items()`` of a ``_Results``: ordered (doc, entry) pairs, sized, iterable any number of times"""
+
+    def __init__(self, res):
+        self._res = res
+
+    def __len__(self):
+        return len(self._res)
+
+    def __iter__(self):
+        r = self._res
+        return ((d, r._entry(x)) for x, d in enumerate(r._docs))
+
+
 def _results_of(out, qi, k0, ngram_of):
-    """``results`` of query qi from the fetched records: doc -> [score, picks, None, tokens, [best ngram, best score]]"""
-    keep = out["keep"]
-    a, n = qi * keep, int(out["n_out"][qi])
-    docs, sc = out["doc"][a:a + n].tolist(), out["score"][a:a + n].tolist()
-    bk, bs = out["best_key"][a:a + n].tolist(), out["best_score"][a:a + n].tolist()
-    po, npk, to, T = out["pick_off"][a:a + n].tolist(), out["npicks"][a:a + n].tolist(), out["tok_off"][a:a + n].tolist(), out["T"][a:a + n].tolist()
-    res = {}
-    for x, d in enumerate(docs):
-        ids = out["pick_id"][po[x]:po[x] + npk[x]]
-        ids = np.where(ids >= 0, ids - k0, ids)                 # table key id -> index into this query's table
-        res[d] = [sc[x], _LazyPicks(ids, out["pick_score"][po[x]:po[x] + npk[x]], ngram_of), None,
-                  _LazyTokens(out["tokens"][to[x]:to[x] + T[x]]), [ngram_of[bk[x] - k0] if bk[x] >= 0 else [], bs[x]]]
-    return res
+    return _Results(out, qi, k0, ngram_of)
 
 
 def _aggregate_plan(index, requests, params):

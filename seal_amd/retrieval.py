@@ -66,6 +66,8 @@ class SEALDocument:
     def raw_tokens(self):
         if self._raw_tokens is None:
             self._raw_tokens = self.fm_index.get_doc(self.idx)
+        elif not isinstance(self._raw_tokens, list):
+            self._raw_tokens = list(self._raw_tokens)        # the searcher hands the fetched token array over as it is
         return self._raw_tokens
 
     def raw_text(self):
@@ -303,12 +305,17 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
                   "title": dict(max_length=TITLE_MAX_LENGTH, eos_token_id=s.title_eos_token_id, force_decoding_from=[s.title_bos_token_id]),
                   "code": dict(max_length=TITLE_MAX_LENGTH, eos_token_id=s.code_eos_token_id, force_decoding_from=[s.code_bos_token_id])}
         marked_in = {k: marked(k) for k in joint_kinds}
+        # the bare queries -- what the rescoring of the body keys encodes (retrieval.py:93-100) -- ride along in the same encoder pass
+        ride = s.decode_body and s.rescore and s.use_markers
         if tokenised:
-            enc_in = encoder_batch(None, [t for k in joint_kinds for t in marked_in[k][1]])
+            enc_in = encoder_batch(None, [t for k in joint_kinds for t in marked_in[k][1]] + (base_tokens if ride else []))
         else:
-            enc_in = encoder_batch([x for k in joint_kinds for x in marked_in[k][0]], None)
+            enc_in = encoder_batch([x for k in joint_kinds for x in marked_in[k][0]] + (list(inputs) if ride else []), None)
+        n_own = len(inputs) * len(joint_kinds)
+        extra = (enc_in["input_ids"][n_own:], enc_in["attention_mask"][n_own:]) if ride else None
+        enc_in = {k: v[:n_own] for k, v in enc_in.items()}
         pend = fm_index_generate_joint(
-            s.bart_model, fm_index, enc_in["input_ids"], enc_in["attention_mask"],
+            s.bart_model, fm_index, enc_in["input_ids"], enc_in["attention_mask"], extra_inputs=extra,
             [dict(batch=len(inputs), **job_of[k]) for k in joint_kinds], num_beams=s.beam, length_penalty=s.length_penalty,
             stop_at_count=s.stop_at_count, disable_fm_index=not constrained_generation,
             logit_bias=torch.cat([bias] * len(joint_kinds)) if bias is not None else None, **dec(s.bart_model))
@@ -487,7 +494,8 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
     if s.decode_body and marked_rescoring:
         jobs.append((s.bart_model, base_tokens, found_keys, dict(
             length_penalty=0.0, strip_from_bos=bos_strip,
-            strip_from_eos=[s.title_eos_token_id, s.code_eos_token_id, s.bart_model.config.eos_token_id], logit_bias=bias)))
+            strip_from_eos=[s.title_eos_token_id, s.code_eos_token_id, s.bart_model.config.eos_token_id], logit_bias=bias,
+            encoded=getattr(body, "extra_encoded", None))))
         slots.append("body")
     if cand is not None:
         _, toks = marked("body")
@@ -760,6 +768,16 @@ class SEALSearcher:
         # streamed: a query's (up to fully_score) ranked documents are cut to k as soon as they arrive
         for query, (res, _) in zip(queries, ranked):
             docs = []
+            if hasattr(res, "top") and not self.include_keys:
+                # the GPU aggregation's records: ids, scores and document tokens of the top k straight from the fetched arrays
+                ids, scores, toks = res.top(k)
+                for idx, score, full in zip(ids, scores, toks):
+                    doc = SEALDocument(idx, score, self.fm_index, self.bart_tokenizer, delim1=self.title_eos_token_id,
+                                       delim2=self.code_eos_token_id, keys=None, query=query)
+                    doc._raw_tokens = full            # list-like over the fetched tokens (index / slices / == as a list); a list on first use
+                    docs.append(doc)
+                retrieved.append(docs)
+                continue
             for idx, info in islice(res.items(), k):
                 score, kk, full = info[0], info[1], (info[3] if len(info) == 5 else None)
                 doc = SEALDocument(idx, score, self.fm_index, self.bart_tokenizer, delim1=self.title_eos_token_id,
@@ -944,7 +962,7 @@ class SEALSearcher:
         """reference retrieval.py:693-712"""
         for docs in retrieved:
             for d in docs:
-                title, body = d.split_tokens(d._raw_tokens if d._raw_tokens is not None else d.raw_tokens())
+                title, body = d.split_tokens(d.raw_tokens())
                 d._title, d._body = self._batch_detokenize([title, body])
         return retrieved
 
