@@ -315,8 +315,8 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
         extra = (enc_in["input_ids"][n_own:], enc_in["attention_mask"][n_own:]) if ride else None
         enc_in = {k: v[:n_own] for k, v in enc_in.items()}
         pend = fm_index_generate_joint(
-            s.bart_model, fm_index, enc_in["input_ids"], enc_in["attention_mask"], extra_inputs=extra,
-            [dict(batch=len(inputs), **job_of[k]) for k in joint_kinds], num_beams=s.beam, length_penalty=s.length_penalty,
+            s.bart_model, fm_index, enc_in["input_ids"], enc_in["attention_mask"],
+            [dict(batch=len(inputs), **job_of[k]) for k in joint_kinds], extra_inputs=extra, num_beams=s.beam, length_penalty=s.length_penalty,
             stop_at_count=s.stop_at_count, disable_fm_index=not constrained_generation,
             logit_bias=torch.cat([bias] * len(joint_kinds)) if bias is not None else None, **dec(s.bart_model))
         got = dict(zip(joint_kinds, pend))
