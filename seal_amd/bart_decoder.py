@@ -324,6 +324,71 @@ class BartStepDecoder:
             x = L["ln3"](x + L["fc2"](L["act"](L["fc1"](x))))
         return x if hidden_only else self.lm_head(x)
 
+    TREE_NODE_BUCKET = 1024      # tree_hidden_graph: node count rounded up to a multiple (few shapes, few graphs)
+
+    @torch.no_grad()
+    def tree_hidden_graph(self, tok, depth, anc, qidx, enc_hidden, attention_mask):
+        """``tree_logits(..., hidden_only=True)`` through the fused kernels as ONE hipGraph replay (the forward over a prefix tree
+        is ~160 launches that the host would otherwise issue one by one, 10 ms per batch of the searcher -- which is host-bound).
+        Shapes are made static: the node count is rounded up to ``TREE_NODE_BUCKET`` (the rows behind the real nodes keep whatever
+        valid nodes an earlier call left there; their results are ignored), the encoder length to 16, the ancestor table to 17
+        columns; one graph per (nodes, encoder length, queries) bucket, captured on first use, cross-attention K/V of the queries
+        computed inside.  Returns [N, d] (a view of the graph's output buffer, valid until the next call), or None when the fused
+        path does not apply."""
+        N = tok.numel()
+        Bq, S, d = enc_hidden.shape
+        A = anc.shape[1]
+        if not (self.use_graph and enc_hidden.is_cuda and self.can_teacher_force(enc_hidden, A) and N > 0):
+            return None
+        Np = (N + self.TREE_NODE_BUCKET - 1) // self.TREE_NODE_BUCKET * self.TREE_NODE_BUCKET
+        Sp = max(16, (S + 15) // 16 * 16)
+        if Sp > 64:
+            return None
+        dev, dt = enc_hidden.device, enc_hidden.dtype
+        cache = self.__dict__.setdefault("_static_cache", {})
+        key = ("tree", Np, Sp, Bq, dt, str(dev))
+        st = cache.get(key)
+        if st is None:
+            st = self._Static()
+            st.tok = torch.full((Np,), int(self.model.config.pad_token_id), dtype=torch.long, device=dev)
+            st.depth = torch.zeros(Np, dtype=torch.long, device=dev)
+            st.anc = torch.full((Np, 17), -1, dtype=torch.long, device=dev)
+            st.anc[:, 0] = torch.arange(Np, device=dev)                     # every row a root of its own until a real node lands on it
+            st.qidx = torch.zeros(Np, dtype=torch.long, device=dev)
+            st.enc = torch.zeros(Bq, Sp, d, dtype=dt, device=dev)
+            st.mask = torch.zeros(Bq, Sp, dtype=torch.uint8, device=dev)
+            st.hidden = None
+            st.graph = None
+            cache[key] = st
+        st.tok[:N] = tok
+        st.depth[:N] = depth
+        st.anc[:N, :A] = anc
+        if A < 17:
+            st.anc[:N, A:] = -1
+        st.qidx[:N] = qidx
+        st.enc[:, :S] = enc_hidden
+        st.mask.zero_()
+        st.mask[:, :S] = attention_mask.to(torch.uint8)
+
+        def forward():
+            prepared = self.teacher_prepare(st.enc, st.mask)
+            return self.tree_logits(st.tok, st.depth, st.anc, st.qidx, st.enc, st.mask, prepared, True)
+        if st.graph is None:
+            with CAPTURE_GATE.capturing():
+                cur = torch.cuda.current_stream(dev)
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        forward()
+                cur.wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    st.hidden = forward()
+                st.graph = g
+        st.graph.replay()
+        return st.hidden[:N]
+
     use_fused_kernels = True      # include/sealnn.h: self-attn / cross-attn / add+LayerNorm as single HIP kernels
 
     def _step_static(self, st):

@@ -360,8 +360,8 @@ def _rescore_tree_jobs(model, jobs):
     cap = int(os.environ.get("SEAL_RESCORE_NODES", 12000))
     max_len = max((len(sq) for j in J for ss in j["seqs"] for sq in ss), default=0)
     prepared = None
-    if enc.is_cuda and max_len > 0 and sd.can_teacher_force(enc, max_len):
-        prepared = sd.teacher_prepare(enc, attention_mask)
+    fused_ok = enc.is_cuda and max_len > 0 and sd.can_teacher_force(enc, max_len)
+    use_graph = fused_ok and os.environ.get("SEAL_RESCORE_GRAPH", "1") != "0"
     units = [(ji, qi) for ji, j in enumerate(J) for qi in range(len(j["seqs"]))]          # job-major: a job's keys stay contiguous
     groups, cur, cur_n = [], [], 0
     for ji, qi in units:
@@ -379,7 +379,13 @@ def _rescore_tree_jobs(model, jobs):
                             np.fromiter((J[ji]["npre"] for ji, _, _, _ in items), dtype=np.int64, count=len(items)), start)
         packed = _h2d(np.stack([tree["tok"], tree["depth"], tree["query"]]), device)
         anc_d = _h2d(tree["anc"], device)
-        hidden = sd.tree_logits(packed[0], packed[1], anc_d, packed[2], enc, attention_mask, prepared, True)      # [nodes, d]
+        hidden = None
+        if use_graph:
+            hidden = sd.tree_hidden_graph(packed[0], packed[1], anc_d, packed[2], enc, attention_mask)              # one graph replay
+        if hidden is None:
+            if fused_ok and prepared is None:
+                prepared = sd.teacher_prepare(enc, attention_mask)
+            hidden = sd.tree_logits(packed[0], packed[1], anc_d, packed[2], enc, attention_mask, prepared, True)    # [nodes, d]
         # term j of key k = logp[node(key[:j]), key[j]] (0 for targets < 2, keys.py:132), summed in position order in float64.
         # The output projection + log-softmax run over a slice of the nodes at a time (the terms sorted by node, so that a
         # slice's terms are one run): nodes x vocab floats never exist at once -- 12 000 nodes x 50 265 x 4 B = 2.4 GB, three

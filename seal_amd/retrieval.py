@@ -860,6 +860,7 @@ class SEALSearcher:
             while entry[1] != upto:
                 entry[1] = next(entry[0])
         enqueue_next()
+        held = None                                           # results of the batch before the current one, not handed out yet
         for i in range(len(batches)):
             t0 = time.perf_counter()
             cur = ahead.pop(0)
@@ -880,6 +881,11 @@ class SEALSearcher:
                 advance(cur, "rescoring")
             if ahead:
                 advance(ahead[0], "decoding")                 # the next batch's title decode, on the caller's stream
+            # this batch's rescorings are enqueued and the host is about to wait for their scores: the time to hand the
+            # PREVIOUS batch's results to the caller (who builds documents from them): its python runs under that wait
+            if held is not None:
+                yield from held
+                held = None
             with torch.cuda.stream(post):
                 try:
                     next(cur[0])
@@ -901,7 +907,9 @@ class SEALSearcher:
             if prof is not None and i + 1 == len(batches) and prof.getstats():
                 import pstats
                 pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(40)
-            yield from out
+            held = out
+        if held is not None:
+            yield from held
 
     def _pipelined(self) -> bool:
         return (int(self.pipeline) >= 2 and hasattr(self.fm_index, "view") and self.device.type == "cuda"

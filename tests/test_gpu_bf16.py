@@ -149,8 +149,9 @@ def test_bf16_searcher_runs_the_fused_paths_and_its_scores_track_hf_bf16(monkeyp
     queries = [[0] + rng.integers(4, vocab - 8, size=int(rng.integers(4, 9))).tolist() + [2] for _ in range(5)]
     from seal_amd.bart_decoder import BartStepDecoder
     tree_calls = []
-    real_tree = BartStepDecoder.tree_logits
+    real_tree, real_graph = BartStepDecoder.tree_logits, BartStepDecoder.tree_hidden_graph
     monkeypatch.setattr(BartStepDecoder, "tree_logits", lambda self, *a: (tree_calls.append(a[6] is not None), real_tree(self, *a))[1])
+    monkeypatch.setattr(BartStepDecoder, "tree_hidden_graph", lambda self, *a: (lambda out: (tree_calls.append(out is not None), out)[1])(real_graph(self, *a)))
     res = s.batch_search(queries, k=10)
     assert all(len(r) > 0 for r in res) and m._seal_step_decoder._st.fused is True and tree_calls and all(tree_calls)
     from seal_amd.keys import _pad_batch

@@ -197,10 +197,17 @@ def test_rescore_keys_tree_shared_teacher_forcing_matches_one_hf_row_per_key(geo
     m = tiny_bart(120, **geom).to(dev)
     monkeypatch.setenv("SEAL_RESCORE_TREE", tree)
     fused_calls = []
-    real, real_tree = BartStepDecoder.teacher_logits, BartStepDecoder.tree_logits
+    real, real_tree, real_graph = BartStepDecoder.teacher_logits, BartStepDecoder.tree_logits, BartStepDecoder.tree_hidden_graph
     monkeypatch.setattr(BartStepDecoder, "teacher_logits", lambda self, *a: (fused_calls.append(1), real(self, *a))[1])
     monkeypatch.setattr(BartStepDecoder, "tree_logits",
                         lambda self, *a: (fused_calls.append(1) if a[6] is not None else None, real_tree(self, *a))[1])
+
+    def graphed(self, *a):            # the tree forward as one graph replay (the fused kernels inside): None = not applicable
+        out = real_graph(self, *a)
+        if out is not None:
+            fused_calls.append(1)
+        return out
+    monkeypatch.setattr(BartStepDecoder, "tree_hidden_graph", graphed)
     rng = np.random.default_rng(0)
     inputs = [[0] + rng.integers(4, 118, size=n).tolist() + [2] for n in (0, 61, 62, 5)]
     inputs[0] = [2]                                      # a one-token encoder input
@@ -559,3 +566,29 @@ def test_joint_generate_through_the_fused_decoder_matches_separate_generates():
                     for a, b in zip(sorted(gv[k]), sorted(wv[k])):
                         assert abs(a - b) <= 1e-4, (k, a, b)
         body_ids, title_ids = torch.roll(body_ids, 1, 0), torch.roll(title_ids, 1, 0)
+
+
+@pytest.mark.gpu
+def test_graph_replayed_tree_forward_equals_the_launch_by_launch_forward(monkeypatch):
+    """``rescore_keys`` with the prefix-tree forward as ONE hipGraph replay (node count padded to a bucket, stale rows behind the
+    real nodes, encoder length padded) against the same forward issued launch by launch (``SEAL_RESCORE_GRAPH=0``): identical
+    scores, call after call with different key sets in the same bucket"""
+    import numpy as np
+    from seal_amd.keys import rescore_keys
+    from tests.helpers import tiny_bart
+    dev = torch.device("cuda:0")
+    m = tiny_bart(120, d_model=128, heads=2).to(dev)
+    rng = np.random.default_rng(3)
+    for rep in range(3):
+        inputs = [[0] + rng.integers(4, 118, size=int(rng.integers(1, 30))).tolist() + [2] for _ in range(4)]
+        keys = []
+        for _ in range(4):
+            base = rng.integers(4, 118, size=int(rng.integers(3, 17))).tolist()
+            kk = [base[:i] for i in range(1, len(base) + 1)] + [rng.integers(4, 118, size=int(rng.integers(1, 6))).tolist() for _ in range(20 - 5 * rep)]
+            keys.append([(-1.0, k) for k in kk])
+        bias = torch.randn(4, 120, device=dev)
+        monkeypatch.setenv("SEAL_RESCORE_GRAPH", "1")
+        a = rescore_keys(m, inputs, keys, logit_bias=bias)
+        monkeypatch.setenv("SEAL_RESCORE_GRAPH", "0")
+        b = rescore_keys(m, inputs, keys, logit_bias=bias)
+        assert a == b
