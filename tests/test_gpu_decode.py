@@ -571,8 +571,8 @@ def test_joint_generate_through_the_fused_decoder_matches_separate_generates():
 @pytest.mark.gpu
 def test_graph_replayed_tree_forward_equals_the_launch_by_launch_forward(monkeypatch):
     """``rescore_keys`` with the prefix-tree forward as ONE hipGraph replay (node count padded to a bucket, stale rows behind the
-    real nodes, encoder length padded) against the same forward issued launch by launch (``SEAL_RESCORE_GRAPH=0``): identical
-    scores, call after call with different key sets in the same bucket"""
+    real nodes, encoder length padded) against the same forward issued launch by launch (``SEAL_RESCORE_GRAPH=0``): the same
+    scores up to the rounding of GEMMs of another height (<= 1e-5), call after call with different key sets in the same bucket"""
     import numpy as np
     from seal_amd.keys import rescore_keys
     from tests.helpers import tiny_bart
@@ -591,4 +591,6 @@ def test_graph_replayed_tree_forward_equals_the_launch_by_launch_forward(monkeyp
         a = rescore_keys(m, inputs, keys, logit_bias=bias)
         monkeypatch.setenv("SEAL_RESCORE_GRAPH", "0")
         b = rescore_keys(m, inputs, keys, logit_bias=bias)
-        assert a == b
+        for qa, qb in zip(a, b):
+            assert [k for _, k in qa] == [k for _, k in qb]
+            assert max(abs(sa - sb) for (sa, _), (sb, _) in zip(qa, qb)) <= 1e-5
