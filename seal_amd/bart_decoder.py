@@ -329,7 +329,9 @@ class BartStepDecoder:
     @torch.no_grad()
     def tree_hidden_graph(self, tok, depth, anc, qidx, enc_hidden, attention_mask):
         """``tree_logits(..., hidden_only=True)`` through the fused kernels as ONE hipGraph replay (the forward over a prefix tree
-        is ~160 launches that the host would otherwise issue one by one, 10 ms per batch of the searcher -- which is host-bound).
+        is ~160 launches that the host would otherwise issue one by one, 10 ms per batch of the searcher).  OPT-IN
+        (``SEAL_RESCORE_GRAPH=1``): on a fast host the search is GPU-bound and the padded nodes cost more than the launches save --
+        measured on one box 247 vs 256 queries/s, rescoring 27.7 vs 23.8 ms per batch; it is there for slow hosts.
         Shapes are made static: the node count is rounded up to ``TREE_NODE_BUCKET`` (the rows behind the real nodes keep whatever
         valid nodes an earlier call left there; their results are ignored), the encoder length to 16, the ancestor table to 17
         columns; one graph per (nodes, encoder length, queries) bucket, captured on first use, cross-attention K/V of the queries

@@ -73,23 +73,41 @@ __global__ __launch_bounds__(256) void k_self_attn_step(const T_ *qkv, T_ *kcach
     stf(kc + (uint64_t)t * 64 + lane, kn);
     stf(vc + (uint64_t)t * 64 + lane, vn);
     if (anc && head == 0 && lane == 0) anc[(uint64_t)t * rows + row] = (int32_t)row;
-    // scores over positions 0..t (the new one from registers)
+    // The history of the row: position p sits in the slot of row anc[p][row].  All of it is fetched BEFORE anything is
+    // computed -- lane p reads the ancestor of position p, then every K / V load of the wave is issued back to back (their
+    // addresses no longer hang on a load inside the loop: the serial chain of <= 16 dependent round trips was the kernel's time)
+    const uint32_t my_anc = (anc && lane < t) ? (uint32_t)anc[(uint64_t)lane * rows + row] : row;
+    float kreg[FMI_MAX_LEVELS], vreg[FMI_MAX_LEVELS];
+#pragma unroll
+    for (uint32_t p = 0; p < FMI_MAX_LEVELS; p++) {
+        kreg[p] = 0.f; vreg[p] = 0.f;
+        if (p < t) {                         // wave-uniform
+            const uint32_t a_p = (uint32_t)__builtin_amdgcn_readlane((int)my_anc, (int)p);
+            const uint64_t src = ((uint64_t)a_p * heads + head) * T * 64 + (uint64_t)p * 64 + lane;
+            kreg[p] = ldf(kcache + src);
+            vreg[p] = ldf(vcache + src);
+        }
+    }
+    // scores over positions 0..t (the new one from registers), in position order as before
     float s[FMI_MAX_LEVELS];          // T <= 17 positions kept in registers
     float m = -__builtin_huge_valf();
-    for (uint32_t p = 0; p <= t; p++) {
-        const uint64_t src = anc ? ((uint64_t)anc[(uint64_t)p * rows + row] * heads + head) * T * 64 : ((uint64_t)row * heads + head) * T * 64;
-        const float kv = (p == t) ? kn : ldf(kcache + src + (uint64_t)p * 64 + lane);
-        const float d = wave_sum(q * kv);
-        s[p] = d;
-        m = fmaxf(m, d);
+#pragma unroll
+    for (uint32_t p = 0; p < FMI_MAX_LEVELS; p++) {
+        s[p] = 0.f;
+        if (p <= t) {
+            const float d = wave_sum(q * (p == t ? kn : kreg[p]));
+            s[p] = d;
+            m = fmaxf(m, d);
+        }
     }
     float denom = 0.f, acc = 0.f;
-    for (uint32_t p = 0; p <= t; p++) {
-        const float e = expf(s[p] - m);
-        denom += e;
-        const uint64_t src = anc ? ((uint64_t)anc[(uint64_t)p * rows + row] * heads + head) * T * 64 : ((uint64_t)row * heads + head) * T * 64;
-        const float vv = (p == t) ? vn : ldf(vcache + src + (uint64_t)p * 64 + lane);
-        acc += e * vv;
+#pragma unroll
+    for (uint32_t p = 0; p < FMI_MAX_LEVELS; p++) {
+        if (p <= t) {
+            const float e = expf(s[p] - m);
+            denom += e;
+            acc += e * (p == t ? vn : vreg[p]);
+        }
     }
     stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, acc / denom);
 }
@@ -323,7 +341,9 @@ static int cross_attn_step(void *stream, const void *q, const void *ck, const vo
                            uint32_t beams, uint32_t heads, uint32_t S, float scale, void *out)
 {
     if (S > 64) { fmi_set_error("sealnn_cross_attn_step: encoder length %u > 64", S); return FMI_ERR_UNSUPPORTED; }
-    const uint32_t waves = beams < 16 ? beams : 16;
+    // eight waves per workgroup (a wave takes every eighth beam): 512 threads and 32 KB of LDS let four workgroups share a CU, so the
+    // 640 workgroups of a 40-query step are resident at once (fifteen waves: two per CU, two rounds)
+    const uint32_t waves = beams < 8 ? beams : 8;
     hipLaunchKernelGGL(k_cross_attn_step<T_>, dim3(batch * heads), dim3(waves * 64), 0, (hipStream_t)stream, (const T_ *)q, (const T_ *)ck,
                        (const T_ *)cv, (const T_ *)bias, batch, beams, heads, S, scale, (T_ *)out);
     NNCHK();
