@@ -350,44 +350,48 @@ class BartStepDecoder:
         cache = self.__dict__.setdefault("_static_cache", {})
         key = ("tree", Np, Sp, Bq, dt, str(dev))
         st = cache.get(key)
-        if st is None:
-            st = self._Static()
-            st.tok = torch.full((Np,), int(self.model.config.pad_token_id), dtype=torch.long, device=dev)
-            st.depth = torch.zeros(Np, dtype=torch.long, device=dev)
-            st.anc = torch.full((Np, 17), -1, dtype=torch.long, device=dev)
-            st.anc[:, 0] = torch.arange(Np, device=dev)                     # every row a root of its own until a real node lands on it
-            st.qidx = torch.zeros(Np, dtype=torch.long, device=dev)
-            st.enc = torch.zeros(Bq, Sp, d, dtype=dt, device=dev)
-            st.mask = torch.zeros(Bq, Sp, dtype=torch.uint8, device=dev)
-            st.hidden = None
-            st.graph = None
-            cache[key] = st
-        st.tok[:N] = tok
-        st.depth[:N] = depth
-        st.anc[:N, :A] = anc
-        if A < 17:
-            st.anc[:N, A:] = -1
-        st.qidx[:N] = qidx
-        st.enc[:, :S] = enc_hidden
-        st.mask.zero_()
-        st.mask[:, :S] = attention_mask.to(torch.uint8)
+        # The caller (rescoring) runs under torch.inference_mode(); buffers and graph are made OUTSIDE it: a capture updates the
+        # CUDA generator's graph-state tensors in place, and if those were first created as inference tensors every later capture
+        # outside inference mode (the decoder's, under no_grad) raises "Inplace update to inference tensor outside InferenceMode".
+        with torch.inference_mode(False), torch.no_grad():
+            if st is None:
+                st = self._Static()
+                st.tok = torch.full((Np,), int(self.model.config.pad_token_id), dtype=torch.long, device=dev)
+                st.depth = torch.zeros(Np, dtype=torch.long, device=dev)
+                st.anc = torch.full((Np, 17), -1, dtype=torch.long, device=dev)
+                st.anc[:, 0] = torch.arange(Np, device=dev)                     # every row a root of its own until a real node lands on it
+                st.qidx = torch.zeros(Np, dtype=torch.long, device=dev)
+                st.enc = torch.zeros(Bq, Sp, d, dtype=dt, device=dev)
+                st.mask = torch.zeros(Bq, Sp, dtype=torch.uint8, device=dev)
+                st.hidden = None
+                st.graph = None
+                cache[key] = st
+            st.tok[:N] = tok
+            st.depth[:N] = depth
+            st.anc[:N, :A] = anc
+            if A < 17:
+                st.anc[:N, A:] = -1
+            st.qidx[:N] = qidx
+            st.enc[:, :S] = enc_hidden
+            st.mask.zero_()
+            st.mask[:, :S] = attention_mask.to(torch.uint8)
 
-        def forward():
-            prepared = self.teacher_prepare(st.enc, st.mask)
-            return self.tree_logits(st.tok, st.depth, st.anc, st.qidx, st.enc, st.mask, prepared, True)
-        if st.graph is None:
-            with CAPTURE_GATE.capturing():
-                cur = torch.cuda.current_stream(dev)
-                side = torch.cuda.Stream(device=dev)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    for _ in range(2):
-                        forward()
-                cur.wait_stream(side)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    st.hidden = forward()
-                st.graph = g
+            def forward():
+                prepared = self.teacher_prepare(st.enc, st.mask)
+                return self.tree_logits(st.tok, st.depth, st.anc, st.qidx, st.enc, st.mask, prepared, True)
+            if st.graph is None:
+                with CAPTURE_GATE.capturing():
+                    cur = torch.cuda.current_stream(dev)
+                    side = torch.cuda.Stream(device=dev)
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        for _ in range(2):
+                            forward()
+                    cur.wait_stream(side)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        st.hidden = forward()
+                    st.graph = g
         st.graph.replay()
         return st.hidden[:N]
 
@@ -510,7 +514,8 @@ class BartStepDecoder:
         return st
 
     def _capture(self, st, dev):
-        with CAPTURE_GATE.capturing():
+        # (never under torch.inference_mode(): see tree_hidden_graph)
+        with torch.inference_mode(False), torch.no_grad(), CAPTURE_GATE.capturing():
             # warm up on a side stream, then capture (standard torch recipe); the cache contents
             # written by the warm-up steps are overwritten/masked once t is reset
             side = torch.cuda.Stream(device=dev)
