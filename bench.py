@@ -1026,6 +1026,7 @@ def main():
         "extra": {("complete_search_qps" if args.first_stage_only else "first_stage_only_qps"): None if other_qps is None else round(other_qps, 3),
                   "p50_batch_latency_ms_unpipelined": round(float(np.median(step_ms[1:] or step_ms)), 2) if step_ms else None, "docs_returned_per_query": n_found,
                   "peak_host_rss_gib_per_rank_max": round(peak_rss_gib, 2),
+                  "decode_step_gemm_algorithms": __import__("seal_amd.tuned_gemm", fromlist=["setup"]).setup(),   # file = shipped picks, off = library default
                   "phase_ms_one_batch": {k: round(v, 2) for k, v in phases.items()},
                   "k_constrain_ms_one_batch": round(k2.value, 3), "k_constrain_blocks_one_batch": int(p2.value)},
     }

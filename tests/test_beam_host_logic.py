@@ -187,3 +187,29 @@ def test_lockstep_groups_record_what_separate_loops_record(lengths):
             assert torch.equal(gp[fin], wp[fin]) and torch.equal(gt[fin], wt[fin])
             assert torch.allclose(gsc[fin], wsc[fin], atol=1e-5)
         assert torch.equal(gf[0], wf[0]) and torch.allclose(gf[1], wf[1], atol=1e-5)
+
+
+def test_tuned_gemm_file_and_modes(tmp_path, monkeypatch):
+    """seal_amd/tuned_gemm.py: no GPU -> off; the shipped picks carry the library versions they were made with and only the
+    decode-step row counts of the default searcher; the tune-mode writer emits TunableOp's own file format"""
+    from seal_amd import tuned_gemm
+    monkeypatch.setattr(tuned_gemm, "_mode", None)
+    assert tuned_gemm.setup() == "off"
+    with tuned_gemm.tuning():
+        pass
+    lines = open(tuned_gemm.SHIPPED).read().splitlines()
+    head = [ln.split(",") for ln in lines if ln.startswith("Validator,")]
+    assert {h[1] for h in head} >= {"PT_VERSION", "HIPBLASLT_VERSION", "GCN_ARCH_NAME"} and any("gfx950" in h[2] for h in head)
+    picks = [ln.split(",") for ln in lines if not ln.startswith("Validator,")]
+    assert len(picks) == 10 and all(len(p) == 4 and p[1].split("_")[2] in ("600", "300") for p in picks)
+
+    class TN:
+        def get_validators(self):
+            return tuple((h[1], h[2]) for h in head)
+
+        def get_results(self):
+            return tuple((p[0], p[1], p[2], float(p[3])) for p in picks)
+    out = tmp_path / "picks.csv"
+    tuned_gemm._write(TN(), str(out))
+    again = out.read_text().splitlines()
+    assert [ln.split(",")[:3] for ln in again] == [ln.split(",")[:3] for ln in lines]
