@@ -199,6 +199,10 @@ class BartStepDecoder:
             st.pos_idx = torch.arange(T, device=dev).view(1, 1, 1, T)
             st.logits = None
             st.graph = None
+            # the first step of a beam search, where the K beams of a query are the same row (_step_static_first)
+            st.first_graph = None
+            st.first_logits = None
+            st.beam0 = (torch.arange(R, dtype=torch.int32, device=dev) // K * K).contiguous()
             st.shape = (B, K, S_pad, T)
             st.dropped = 0
             st.tails = {}       # dropped leading queries -> the static state of the rest (views of these buffers; narrow())
@@ -455,6 +459,49 @@ class BartStepDecoder:
         st.t.add_(1)
         return F.linear(x, self.lm_w, self.lm_b.view(-1)).float()
 
+    # A beam search starts every beam of a query from the same token (reference beam_search.py:214-216 tells them apart by
+    # the initial scores [0, -1e9, ...] only), so the first step of the K beams is ONE row of arithmetic: the model runs on
+    # `batch` rows instead of `batch x beams` (every GEMM 15 x smaller: the step is then bound by reading the weights once),
+    # position 0 of the cache is written for the first beam's row only and the ancestry table points the other beams at it,
+    # and the logits row is handed to all K beams.  Self-attention over the single position 0 is softmax([s]) = [1]:
+    # the output is V itself, as sealnn_self_attn_step computes it (1.0 * v / 1.0).
+    # OFF by default (SEAL_SHARED_FIRST_STEP=1 turns it on): correct on its own (tests/test_gpu_decode.py::test_first_step_shared_...),
+    # but the searcher's overlapped batches -- this 40-row step on the decode stream while the previous batch's rescoring GEMMs
+    # run on the other stream -- stopped making progress on the GPU twice (bench.py, round 3).  Until that is
+    # understood the full-width first step stays.
+    shared_first_step = __import__("os").environ.get("SEAL_SHARED_FIRST_STEP", "0") == "1"
+
+    def _step_static_first(self, st):
+        from ._lib import check
+        B, K, S_pad, T = st.shape
+        H, dh = self.h, self.dh
+        x = self.embed(st.tokens.view(B, K)[:, 0])
+        x = x + self.pos.weight.index_select(0, st.t + self.pos_offset)
+        x = self.ln_emb(x)
+        L_ = self._nn(x.dtype)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        cbias = st.cbias.view(B, S_pad)
+
+        def add_ln(res, y, ln):
+            out = torch.empty_like(res)
+            check(L_.add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                   B, self.d, float(ln.eps), out.data_ptr()))
+            return out
+        for li, L in enumerate(self.layers):
+            qkv = F.linear(x, L["qkv_w"], L["qkv_b"]).view(B, 3, H, dh)
+            st.kv[li, 0].view(B, K, H, T, dh)[:, 0, :, 0].copy_(qkv[:, 1])
+            st.kv[li, 1].view(B, K, H, T, dh)[:, 0, :, 0].copy_(qkv[:, 2])
+            x = add_ln(x, L["so"](qkv[:, 2].reshape(B, self.d)), L["ln1"])
+            q = L["cq"](x)
+            c = torch.empty(B, self.d, dtype=x.dtype, device=x.device)
+            check(L_.cross_attn_step(stream, q.data_ptr(), st.ck[li].data_ptr(), st.cv[li].data_ptr(), cbias.data_ptr(),
+                                     B, 1, H, S_pad, float(self.scale), c.data_ptr()))
+            x = add_ln(x, L["co"](c), L["ln2"])
+            x = add_ln(x, L["fc2"](L["act"](L["fc1"](x))), L["ln3"])
+        st.anc[0].copy_(st.beam0)
+        st.t.add_(1)
+        return F.linear(x, self.lm_w, self.lm_b.view(-1)).float()
+
     @torch.no_grad()
     def start(self, enc_hidden: torch.Tensor, attention_mask: torch.Tensor, num_beams: int, max_len: int, narrow_plan=()) -> None:
         """``narrow_plan``: ascending numbers of leading queries that will have left the decode at its ``narrow`` calls
@@ -515,7 +562,8 @@ class BartStepDecoder:
             root.tails[dropped] = st
         return st
 
-    def _capture(self, st, dev):
+    def _capture(self, st, dev, first=False):
+        forward = self._step_static_first if first else self._step_static
         # (never under torch.inference_mode(): see tree_hidden_graph)
         with torch.inference_mode(False), torch.no_grad(), CAPTURE_GATE.capturing():
             # warm up on a side stream, then capture (standard torch recipe); the cache contents
@@ -525,13 +573,16 @@ class BartStepDecoder:
             with torch.cuda.stream(side), tuned_gemm.tuning():     # the algorithm picks of this shape's GEMMs: seal_amd/tuned_gemm.py
                 for _ in range(2):
                     st.t.zero_()
-                    self._step_static(st)
+                    forward(st)
             torch.cuda.current_stream(dev).wait_stream(side)
             st.t.zero_()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):   # the aggregation thread may touch the GPU meanwhile
-                st.logits = self._step_static(st)
-            st.graph = g
+                out = forward(st)
+            if first:
+                st.first_logits, st.first_graph = out, g
+            else:
+                st.logits, st.graph = out, g
             st.t.zero_()
 
     @torch.no_grad()
@@ -556,6 +607,8 @@ class BartStepDecoder:
         self.t = 0
         if st.graph is None:
             self._capture(st, enc_hidden.device)
+        if st.first_graph is None and st.fused and self.shared_first_step and num_beams > 1:
+            self._capture(st, enc_hidden.device, first=True)
 
     @torch.no_grad()
     def _start_eager(self, enc_hidden: torch.Tensor, attention_mask: torch.Tensor, num_beams: int, max_len: int) -> None:
@@ -585,12 +638,21 @@ class BartStepDecoder:
         self.kv[:, :, :, :, :self.t] = self.kv[:, :, beam_idx, :, :self.t]
 
     @torch.no_grad()
-    def step(self, tokens: torch.Tensor) -> torch.Tensor:
-        """tokens [rows] at decoder position ``self.t`` -> next-token logits [rows, vocab] (fp32)."""
+    def step(self, tokens: torch.Tensor, beams_identical: bool = False) -> torch.Tensor:
+        """tokens [rows] at decoder position ``self.t`` -> next-token logits [rows, vocab] (fp32).  ``beams_identical``: the
+        caller's promise, at position 0, that the ``beams`` rows of every query hold the same token (the start of a beam
+        search): the model then runs once per query (``_step_static_first``)."""
         R, B, K, H, dh, t = self.rows, self.batch, self.beams, self.h, self.dh, self.t
         if getattr(self, "_st", None) is not None:
             st = self._st
             st.tokens.copy_(tokens)
+            if beams_identical and t == 0 and st.first_graph is not None:
+                st.first_graph.replay()
+                self.t += 1
+                logits = st.first_logits                                  # [B, V]
+                if self.logit_bias is not None:
+                    logits = logits + self.logit_bias
+                return logits[:, None, :].expand(B, K, logits.shape[-1]).reshape(R, -1)
             st.graph.replay()
             self.t += 1
             logits = st.logits

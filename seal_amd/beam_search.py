@@ -254,8 +254,12 @@ def constrained_beam_search_groups(decoder, specs, num_beams: int, decoder_start
     beam_idx = None     # rows of the previous step that this step's rows extend (incremental constraint state)
     first_logits = None
     tag = next(_LOOP_TAGS)
+    shared_first = bool(getattr(decoder, "shared_first_step", False))
     while True:
-        logits = decoder.step(input_ids[:, -1])
+        if first_logits is None and shared_first:
+            logits = decoder.step(input_ids[:, -1], beams_identical=True)     # every beam starts from decoder_start_token_id
+        else:
+            logits = decoder.step(input_ids[:, -1])
         V = logits.shape[-1]
         if first_logits is None:
             # every beam of a query sees the same first step: the model's next-token logits after the start token,

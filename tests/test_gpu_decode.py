@@ -128,6 +128,67 @@ def test_fused_step_decoder_matches_hf_cache_free_forward(S):
         enc_mask = torch.roll(enc_mask, 1, 0)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_first_step_shared_by_the_beams_of_a_query(dtype):
+    """``step(tokens, beams_identical=True)`` at position 0 (one row of arithmetic per query, position 0 of the cache written for
+    the first beam only, the ancestry table pointing the other beams at it): the logits of every beam == the logits of the
+    full-width step within fp32 GEMM noise, and so are the logits of the following steps -- which read that cache slot through
+    random re-rankings and through a ``narrow`` -- against HF's cache-free forward; with a logit bias; on a replayed graph."""
+    from seal_amd.bart_decoder import BartStepDecoder
+    from tests.helpers import tiny_bart
+    dev = torch.device("cuda:0")
+    vocab, B, K, T, S = 120, 4, 5, 9, 11
+    m = tiny_bart(vocab, d_model=128, heads=2, max_positions=64).to(dev)
+    tol = 2e-5 if dtype == torch.float32 else 0.15
+    run = m if dtype == torch.float32 else __import__("copy").deepcopy(m).to(dtype)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    enc_ids = torch.randint(4, vocab, (B, S), generator=g).to(dev)
+    enc_mask = torch.ones_like(enc_ids)
+    enc_mask[1, 6:] = 0
+    enc_ids[1, 6:] = 1
+    bias = torch.randn(B, vocab, generator=g).to(dev)
+    dec = BartStepDecoder(run)
+    assert dec.shared_first_step is False            # opt-in (SEAL_SHARED_FIRST_STEP=1): see the note at BartStepDecoder.shared_first_step
+    dec.shared_first_step = True
+    for rep in range(2):
+        enc = dec.encode(enc_ids, enc_mask)
+        dec.start(enc, enc_mask, K, T, narrow_plan=(2,))
+        dec.logit_bias = bias
+        assert dec._st.first_graph is not None
+        rows = torch.full((B * K, 1), 2, dtype=torch.long, device=dev)
+        ids_rep, am_rep, bias_rep = enc_ids.repeat_interleave(K, 0), enc_mask.repeat_interleave(K, 0), bias.repeat_interleave(K, 0)
+        for t in range(T - 1):
+            got = dec.step(rows[:, -1], beams_identical=(t == 0))
+            assert got.shape == (rows.shape[0], vocab) and dec._st.fused is True
+            if t == 0:
+                assert torch.equal(got.view(B, K, vocab), got.view(B, K, vocab)[:, :1].expand(B, K, vocab))
+            with torch.no_grad():
+                want = m(input_ids=ids_rep, attention_mask=am_rep, decoder_input_ids=rows).logits[:, -1, :] + bias_rep
+            finite = torch.isfinite(want)
+            assert torch.equal(finite, torch.isfinite(got))
+            err = (got[finite] - want[finite]).abs().max().item()
+            assert err <= tol, (rep, t, err)
+            n, b = rows.shape[0], rows.shape[0] // K
+            nxt = torch.randint(4, vocab, (n,), generator=g).to(dev)
+            perm = (torch.arange(n).view(b, K).gather(1, torch.randint(0, K, (b, K), generator=g))).reshape(-1).to(dev)
+            rows = torch.cat([rows[perm], nxt[:, None]], 1)
+            dec.reorder(perm)
+            if t == 3:                          # the first two queries leave: the others keep reading position 0 through the re-based table
+                dec.narrow(2)
+                rows, ids_rep, am_rep, bias_rep = rows[2 * K:], ids_rep[2 * K:], am_rep[2 * K:], bias_rep[2 * K:]
+        enc_ids, enc_mask, bias = torch.roll(enc_ids, 1, 0), torch.roll(enc_mask, 1, 0), torch.roll(bias, 1, 0)
+    # the promise is only honoured at position 0; the switch turns the path off
+    dec2 = BartStepDecoder(run)
+    dec2.start(dec2.encode(enc_ids, enc_mask), enc_mask, K, T)
+    assert dec2._st.first_graph is None
+    full = dec2.step(torch.full((B * K,), 2, dtype=torch.long, device=dev), beams_identical=True)
+    dec.start(dec.encode(enc_ids, enc_mask), enc_mask, K, T)
+    dec.logit_bias = None
+    one = dec.step(torch.full((B * K,), 2, dtype=torch.long, device=dev), beams_identical=True)
+    finite = torch.isfinite(full)
+    assert torch.equal(finite, torch.isfinite(one)) and (full[finite] - one[finite]).abs().max().item() <= tol
+
+
 @pytest.mark.parametrize("narrow", ["1024", "0"], ids=["lds-select", "radix-select"])
 @pytest.mark.parametrize("kw", [dict(), dict(force_decoding_from=[2], eos_token_id=7), dict(always_allow_eos=True),
                                 dict(stop_at_count=2)])
