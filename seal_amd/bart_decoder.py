@@ -465,9 +465,9 @@ class BartStepDecoder:
     # position 0 of the cache is written for the first beam's row only and the ancestry table points the other beams at it,
     # and the logits row is handed to all K beams.  Self-attention over the single position 0 is softmax([s]) = [1]:
     # the output is V itself, as sealnn_self_attn_step computes it (1.0 * v / 1.0).
-    # OFF by default (SEAL_SHARED_FIRST_STEP=1 turns it on): correct on its own (tests/test_gpu_decode.py::test_first_step_shared_...),
-    # but the searcher's overlapped batches -- this 40-row step on the decode stream while the previous batch's rescoring GEMMs
-    # run on the other stream -- stopped making progress on the GPU twice (bench.py, round 3).  Until that is
+    # OFF by default (SEAL_SHARED_FIRST_STEP=1 turns it on): correct on its own (tests/test_gpu_decode.py::test_first_step_shared_...)
+    # and in complete searches of overlapped batches (tools/first_step_probe.py: 8 of 9 runs), but bench.py with it on stopped making
+    # progress on the GPU three times out of three (profiles/r3_shared_first_step_hang.txt).  Until that is
     # understood the full-width first step stays.
     shared_first_step = __import__("os").environ.get("SEAL_SHARED_FIRST_STEP", "0") == "1"
 
