@@ -645,6 +645,13 @@ def main():
             pass
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # A run that stops making progress (a GPU-side stall: the host then waits in a stream synchronize for ever) ends itself
+    # with the stacks of all threads instead of sitting on the GPU until somebody's outer limit: the default run takes ~90 s,
+    # the stress tier ~6 min.  SEAL_BENCH_WATCHDOG_S=0 turns it off.
+    import faulthandler
+    limit = float(os.environ.get("SEAL_BENCH_WATCHDOG_S", 2400 if args.workload == "stress" else 900 + 20 * max(0, args.steps - 20)))
+    if limit > 0:
+        faulthandler.dump_traceback_later(limit, exit=True)
     if args.workload == "stress":
         assert world == 1, "the stress workload is a single-GPU measurement"
         if "--beam" not in sys.argv:
