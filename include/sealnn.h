@@ -67,6 +67,11 @@ int sealnn_cross_attn_rows_bf16(void *stream, const void *q, const void *ck, con
 int sealnn_cross_attn_runs_bf16(void *stream, const void *q, const void *ck, const void *cv, const void *bias,
                                 const int32_t *row_batch, uint32_t rows, uint32_t group, uint32_t heads, uint32_t S, float scale, void *out);
 
+/* ---- operands of the split GEMM (fp32-accurate linear layers on the fp16 matrix cores; seal_amd/split_gemm.py) ----
+ *   x [rows, K] fp32 -> out [rows, 3K] fp16 = [hi | hi | lo'],  hi = fp16(x), lo' = fp16((x - hi) * 2^11);  K % 4 == 0
+ *   *d_flag (may be NULL) += the number of 4-element groups holding a finite |x| > 65504 (not representable: the caller must check) */
+int sealnn_split_planes(void *stream, const float *x, uint32_t rows, uint32_t K, void *out, uint32_t *d_flag);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,6 +133,21 @@ class BartStepDecoder:
 
     FUSED_DTYPES = (torch.float32, torch.bfloat16)
 
+    # fp32 linear layers of the fused paths on the fp16 matrix cores (seal_amd/split_gemm.py; opt-in, SEAL_SPLIT_GEMM=1)
+    split_gemm = None
+
+    def _lin(self, x: torch.Tensor, w: torch.Tensor, b) -> torch.Tensor:
+        """``F.linear(x, w, b)`` of an fp32 [rows, K] activation on the GPU -- through the split GEMM when that is switched on"""
+        if self.split_gemm is None:
+            from . import split_gemm
+            BartStepDecoder.split_gemm = split_gemm.SplitLinears() if split_gemm.ENABLED else False
+        if self.split_gemm and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
+            return self.split_gemm(x, w, b)
+        return F.linear(x, w, b)
+
+    def _mod(self, x: torch.Tensor, m) -> torch.Tensor:
+        return self._lin(x, m.weight, m.bias)
+
     def clone_for_pipeline(self) -> "BartStepDecoder":
         """a decoder over the SAME weights with its own static buffers / captured graphs / decode position: one per
         concurrent query-batch pipeline (the buffers of a shape are reused by every decode of that shape, so two
@@ -266,7 +281,7 @@ class BartStepDecoder:
     @torch.no_grad()
     def lm_head(self, x: torch.Tensor) -> torch.Tensor:
         """decoder states [N, d] -> next-token logits [N, vocab] (``x @ shared^T + final_logits_bias``)"""
-        return F.linear(x, self.lm_w, self.lm_b.view(-1))
+        return self._lin(x, self.lm_w, self.lm_b.view(-1))
 
     def tree_logits(self, tok: torch.Tensor, depth: torch.Tensor, anc: torch.Tensor, qidx: torch.Tensor, enc_hidden: torch.Tensor,
                     attention_mask: torch.Tensor, prepared=None, hidden_only: bool = False) -> torch.Tensor:
@@ -295,17 +310,17 @@ class BartStepDecoder:
                                        N, self.d, float(ln.eps), out.data_ptr()))
                 return out
             for li, L in enumerate(self.layers):
-                qkv = F.linear(x, L["qkv_w"], L["qkv_b"])
+                qkv = self._lin(x, L["qkv_w"], L["qkv_b"])
                 a = torch.empty(N, self.d, dtype=x.dtype, device=dev)
                 check(L_.tree_self_attn(stream, qkv.data_ptr(), anc32.data_ptr(), N, A, self.h, float(self.scale), a.data_ptr()))
-                x = add_ln(x, L["so"](a), L["ln1"])
-                q = L["cq"](x)
+                x = add_ln(x, self._mod(a, L["so"]), L["ln1"])
+                q = self._mod(x, L["cq"])
                 c = torch.empty(N, self.d, dtype=x.dtype, device=dev)
                 ck, cv = cross[li]
                 check(L_.cross_attn_rows(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
                                          N, self.h, S, float(self.scale), c.data_ptr()))
-                x = add_ln(x, L["co"](c), L["ln2"])
-                x = add_ln(x, L["fc2"](L["act"](L["fc1"](x))), L["ln3"])
+                x = add_ln(x, self._mod(c, L["co"]), L["ln2"])
+                x = add_ln(x, self._mod(L["act"](self._mod(x, L["fc1"])), L["fc2"]), L["ln3"])
             return x if hidden_only else self.lm_head(x)
         # plain torch ops: the ancestors' keys / values gathered per node, the encoder's per query
         B, S, _ = enc_hidden.shape
@@ -429,19 +444,19 @@ class BartStepDecoder:
                                        R, self.d, float(ln.eps), out.data_ptr()))
                 return out
             for li, L in enumerate(self.layers):
-                qkv = F.linear(x, L["qkv_w"], L["qkv_b"])
+                qkv = self._lin(x, L["qkv_w"], L["qkv_b"])
                 a = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
                 check(L_.self_attn_step(stream, qkv.data_ptr(), st.kv[li, 0].data_ptr(), st.kv[li, 1].data_ptr(),
                                         st.t.data_ptr(), R, H, T, float(self.scale), a.data_ptr(), st.anc.data_ptr()))
-                x = add_ln(x, L["so"](a), L["ln1"])
-                q = L["cq"](x)
+                x = add_ln(x, self._mod(a, L["so"]), L["ln1"])
+                q = self._mod(x, L["cq"])
                 c = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
                 check(L_.cross_attn_step(stream, q.data_ptr(), st.ck[li].data_ptr(), st.cv[li].data_ptr(), cbias.data_ptr(),
                                          B, K, H, S_pad, float(self.scale), c.data_ptr()))
-                x = add_ln(x, L["co"](c), L["ln2"])
-                x = add_ln(x, L["fc2"](L["act"](L["fc1"](x))), L["ln3"])
+                x = add_ln(x, self._mod(c, L["co"]), L["ln2"])
+                x = add_ln(x, self._mod(L["act"](self._mod(x, L["fc1"])), L["fc2"]), L["ln3"])
             st.t.add_(1)
-            return F.linear(x, self.lm_w, self.lm_b.view(-1)).float()
+            return self._lin(x, self.lm_w, self.lm_b.view(-1)).float()
         future = st.pos_idx > st.t                                   # cache slots not written yet
         for li, L in enumerate(self.layers):
             qkv = F.linear(x, L["qkv_w"], L["qkv_b"]).view(R, 3, H, dh)

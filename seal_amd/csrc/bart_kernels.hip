@@ -5,6 +5,7 @@
 // configs[4]): loads widen to fp32, all arithmetic and every accumulation is fp32, stores round to nearest even.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 
 #include <algorithm>
 
@@ -424,6 +425,44 @@ extern "C" int sealnn_cross_attn_step(void *stream, const float *q, const float 
 extern "C" int sealnn_cross_attn_step_bf16(void *stream, const void *q, const void *ck, const void *cv, const void *bias, uint32_t batch,
                                            uint32_t beams, uint32_t heads, uint32_t S, float scale, void *out)
 { return cross_attn_step<bf16>(stream, q, ck, cv, bias, batch, beams, heads, S, scale, out); }
+
+// ---- split GEMM operands (seal_amd/split_gemm.py): an fp32 row -> [hi | hi | lo'] in fp16, hi = fp16(x), lo' = fp16((x - hi) * 2^11) ----
+// x = hi + lo' * 2^-11 to 22 bits; the GEMM  [hi | hi | lo'] . [W_hi | W_lo | W_hi * 2^-11]^T  on the fp16 matrix cores (fp32
+// accumulate) is then x . W to fp32 accuracy (the dropped lo . lo term is 2^-22 of the product).  The lo plane is stored SCALED so that
+// it has the magnitude of x itself: no fp16 subnormals whatever the matrix cores do with them.  A finite |x| beyond the fp16 range
+// (65504) cannot be split: it is counted in *flag, which the caller checks (never seen in BART activations).
+__global__ __launch_bounds__(256) void k_split_planes(const float *x, uint32_t rows, uint32_t K, __half *out, uint32_t *flag)
+{
+    const uint32_t per_row = K / 4;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)rows * per_row) return;
+    const uint32_t r = (uint32_t)(i / per_row), c = (uint32_t)(i % per_row) * 4;
+    const float4 v = *(const float4 *)(x + (uint64_t)r * K + c);
+    const float in[4] = {v.x, v.y, v.z, v.w};
+    __half hi[4], lo[4];
+    bool over = false;
+    for (int j = 0; j < 4; j++) {
+        const float a = fabsf(in[j]);
+        over |= a > 65504.f && a < __builtin_huge_valf();
+        hi[j] = __float2half_rn(in[j]);
+        lo[j] = __float2half_rn((in[j] - __half2float(hi[j])) * 2048.f);
+    }
+    __half *o = out + (uint64_t)r * 3 * K + c;
+    *(uint2 *)o = *(const uint2 *)hi;
+    *(uint2 *)(o + K) = *(const uint2 *)hi;
+    *(uint2 *)(o + 2 * (uint64_t)K) = *(const uint2 *)lo;
+    if (over && flag) atomicAdd(flag, 1u);
+}
+
+extern "C" int sealnn_split_planes(void *stream, const float *x, uint32_t rows, uint32_t K, void *out, uint32_t *d_flag)
+{
+    if (K % 4) { fmi_set_error("sealnn_split_planes: K=%u is not a multiple of 4", K); return FMI_ERR_UNSUPPORTED; }
+    const uint64_t n = (uint64_t)rows * (K / 4);
+    if (!n) return FMI_OK;
+    hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows, K, (__half *)out, d_flag);
+    NNCHK();
+    return FMI_OK;
+}
 
 extern "C" int sealnn_add_layernorm(void *stream, const float *x, const float *y, const float *gamma, const float *beta, uint32_t rows,
                                     uint32_t d, float eps, float *out)

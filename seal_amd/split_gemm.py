@@ -1,0 +1,117 @@
+"""fp32-accurate linear layers on the fp16 matrix cores (opt-in: ``SEAL_SPLIT_GEMM=1``; prepared in round 3, NOT yet measured).
+
+The reference runs BART in fp32 (seal/retrieval.py:560-588 loads the checkpoint as it is; beam_search.py:251 takes the
+log-softmax of fp32 logits) and north_star wants the hypothesis scores within 1e-4 of that, which rules the bf16 / fp16 model
+out (measured: 0.1).  But fp32 GEMMs are what a search step spends its GPU time on (~50 of 75 ms, at ~100
+of the 157 TF/s the fp32 MFMA path has), while the fp16 matrix cores of gfx950 do 2.5 PFLOP/s dense.  An fp32 number is two
+fp16 numbers to 22 bits,
+
+    x = hi + lo,    hi = fp16(x),    lo = fp16(x - hi)            (|lo| <= 2^-11 |hi|)
+
+and a product of two such numbers is three fp16 products up to a 2^-22 term:
+
+    x . w  =  hi_x . hi_w  +  hi_x . lo_w  +  lo_x . hi_w  (+ lo_x . lo_w, dropped)
+
+so   y = x W^T   becomes ONE fp16 GEMM with fp32 accumulation over a three times longer inner dimension,
+
+    y = alpha * [ hi_x | hi_x | lo_x * 2^11 ]  .  [ hi_w | lo_w | hi_w * 2^-11 ]^T,
+
+three times the FLOPs on units sixteen times as fast.  Emulated with numpy / torch on the CPU (tests/test_split_gemm.py) the
+representation error of the split is 4-5 times SMALLER than the rounding error of an fp32 GEMM's own accumulation (K = 1024 .. 4096,
+activations with outlier channels), i.e. the result is fp32-grade.
+
+Scaling keeps every plane in fp16's normal range whatever the matrix cores do with subnormals:
+* weights (offline): W is multiplied by a power of two ``s_w`` that puts max|W| just below 2^13; then ``lo_w`` and ``hi_w * 2^-11`` of
+  every weight that matters are normal numbers; ``alpha = 1 / s_w`` undoes it (exact);
+* activations (per call, ``sealnn_split_planes``): ``lo_x`` is stored multiplied by 2^11 -- the magnitude of x itself -- and its
+  partner plane of W carries the 2^-11.  |x| must stay below fp16's 65504 (BART activations are O(10^2) at most): the kernel counts
+  violations in a flag that ``overflowed()`` reads.
+
+``SplitLinear(weight, bias)(x)`` is ``F.linear(x, weight, bias)`` for an fp32 ``x`` [rows, K].  On the GPU the planes come from the
+HIP kernel and the product from ``torch.addmm(..., out_dtype=torch.float32)`` (hipBLASLt, fp16 in / fp32 out); on the CPU (the tests'
+checker of the arithmetic) both are emulated with torch ops.
+"""
+import math
+import os
+
+import torch
+
+ENABLED = os.environ.get("SEAL_SPLIT_GEMM", "0") == "1"
+LO_SHIFT = 11                      # bits between the planes: fp16 has an 11-bit significand
+_flags = {}                        # device -> int32 counter of unsplittable activations
+
+
+def _flag(device) -> torch.Tensor:
+    f = _flags.get(device)
+    if f is None:
+        f = _flags[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return f
+
+
+def overflowed(device) -> int:
+    """activations beyond fp16's range seen by the split kernel on ``device`` since the last call (synchronises)"""
+    f = _flags.get(torch.device(device))
+    if f is None:
+        return 0
+    n = int(f.item())
+    f.zero_()
+    return n
+
+
+def split_planes_reference(x: torch.Tensor) -> torch.Tensor:
+    """[rows, K] fp32 -> [rows, 3K] fp16 = [hi | hi | lo * 2^11]: the arithmetic of ``sealnn_split_planes`` in torch ops"""
+    hi = x.to(torch.float16)
+    lo = ((x - hi.float()) * float(2 ** LO_SHIFT)).to(torch.float16)
+    return torch.cat([hi, hi, lo], dim=1)
+
+
+def split_weight(weight: torch.Tensor):
+    """[N, K] fp32 -> ([N, 3K] fp16 = [hi | lo | hi * 2^-11] of ``weight * s_w``, alpha = 1 / s_w)"""
+    w = weight.detach().float()
+    top = float(w.abs().max())
+    s_w = 2.0 ** math.floor(math.log2(2.0 ** 13 / top)) if top > 0 and math.isfinite(top) else 1.0
+    ws = w * s_w
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    hi_s = (hi.float() * float(2.0 ** -LO_SHIFT)).to(torch.float16)
+    return torch.cat([hi, lo, hi_s], dim=1).contiguous(), 1.0 / s_w
+
+
+class SplitLinear:
+    """``F.linear(x, weight, bias)`` for fp32 ``x`` [rows, K] through one fp16 GEMM of inner dimension 3K (see the module text)."""
+
+    def __init__(self, weight: torch.Tensor, bias=None):
+        self.N, self.K = weight.shape
+        if self.K % 4:
+            raise ValueError(f"SplitLinear: K={self.K} must be a multiple of 4")
+        self.planes, self.alpha = split_weight(weight)                 # [N, 3K] fp16, row-major like the weight F.linear takes
+        self.wt = self.planes.t()                                      # the [3K, N] operand (a view)
+        b = bias.detach().float().reshape(-1) if bias is not None else torch.zeros(self.N, device=weight.device)
+        self.bias = b.contiguous()
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != self.K:
+            raise ValueError(f"SplitLinear: expected fp32 [rows, {self.K}], got {x.dtype} {tuple(x.shape)}")
+        if not x.is_cuda:
+            # the checker of the arithmetic (tests): same planes, products summed in fp32
+            return torch.addmm(self.bias, split_planes_reference(x).float(), self.wt.float(), alpha=self.alpha)
+        from ._lib import check, lib
+        x = x.contiguous()
+        a = torch.empty(x.shape[0], 3 * self.K, dtype=torch.float16, device=x.device)
+        check(lib().sealnn_split_planes(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.shape[0], self.K, a.data_ptr(),
+                                        _flag(x.device).data_ptr()))
+        return torch.addmm(self.bias, a, self.wt, alpha=self.alpha, out_dtype=torch.float32)
+
+
+class SplitLinears:
+    """the split operands of a model's weights, made on first use and kept (keyed by the weight tensor's storage)"""
+
+    def __init__(self):
+        self._by_weight = {}
+
+    def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
+        key = (weight.data_ptr(), tuple(weight.shape))
+        lin = self._by_weight.get(key)
+        if lin is None:
+            lin = self._by_weight[key] = SplitLinear(weight, bias)
+        return lin(x)

@@ -1,0 +1,137 @@
+"""seal_amd/split_gemm.py: an fp32 linear layer as ONE fp16 GEMM over three planes.  On the CPU the arithmetic itself (planes emulated
+with torch ops, products summed in fp32): the split represents x and W to 22 bits and the product lands as close to the float64 result
+as an fp32 GEMM does.  The GPU half (HIP split kernel, hipBLASLt fp16 -> fp32 product, capture in a hipGraph) is opt-in until it has run
+on an MI355X: SEAL_TEST_SPLIT_GEMM=1."""
+import os
+
+import pytest
+import torch
+
+from seal_amd.split_gemm import LO_SHIFT, SplitLinear, SplitLinears, split_planes_reference, split_weight
+
+
+def _activations(rows, K, seed, outliers=50.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, K, generator=g)
+    x[:, :4] *= outliers                      # residual streams have a few channels far above the rest
+    x[:, 7] *= 1e-4                           # and some far below
+    return x
+
+
+def test_planes_hold_22_bits_of_every_element():
+    x = _activations(64, 256, 0)
+    p = split_planes_reference(x)
+    K = x.shape[1]
+    assert p.dtype == torch.float16 and p.shape == (64, 3 * K) and torch.equal(p[:, :K], p[:, K:2 * K])
+    back = p[:, :K].double() + p[:, 2 * K:].double() * 2.0 ** -LO_SHIFT
+    err = (back - x.double()).abs()
+    normal = x.abs() >= 2.0 ** -13            # hi and the stored lo are normal fp16 numbers
+    assert normal.float().mean() > 0.98 and (~normal).any()
+    assert (err[normal] / x.double().abs()[normal]).max().item() <= 2.0 ** -21
+    assert err[~normal].max().item() <= 2.0 ** -35        # below fp16's normal range: absolute, far under anything a dot product notices
+    # the stored lo plane has the magnitude of x, not 2^-11 of it
+    lo = p[:, 2 * K:].float().abs()
+    assert (lo <= x.abs() * 1.0001 + 2.0 ** -14).all()          # (2^-14: where hi itself is subnormal)
+
+
+@pytest.mark.parametrize("top", [0.5, 1e-3, 300.0])
+def test_weight_planes_and_scale(top):
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(48, 64, generator=g) * 0.05
+    w[0, 0] = top
+    planes, alpha = split_weight(w)
+    K = w.shape[1]
+    s_w = 1.0 / alpha
+    assert 2.0 ** 12 < float(w.abs().max()) * s_w <= 2.0 ** 13 and s_w == 2.0 ** round(__import__("math").log2(s_w))
+    hi, lo, his = planes[:, :K].double(), planes[:, K:2 * K].double(), planes[:, 2 * K:].double()
+    err = ((hi + lo) * alpha - w.double()).abs().max().item()
+    assert err <= float(w.abs().max()) * 2.0 ** -21
+    big = hi.abs() >= 1.0                       # where it matters: hi * 2^-11 is exact (a normal fp16 number)
+    assert torch.equal(his[big], hi[big] * 2.0 ** -LO_SHIFT)
+    zeros, a0 = split_weight(torch.zeros(4, 8))
+    assert a0 == 1.0 and not zeros.any()
+
+
+@pytest.mark.parametrize("K,N", [(1024, 768), (4096, 256)])
+def test_split_linear_is_as_close_to_float64_as_an_fp32_gemm(K, N):
+    g = torch.Generator().manual_seed(K)
+    x = _activations(96, K, 2)
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g)
+    ref = x.double() @ w.double().t() + b.double()
+    fp32 = torch.nn.functional.linear(x, w, b)
+    got = SplitLinear(w, b)(x)
+    assert got.dtype == torch.float32 and got.shape == (96, N)
+    e_split = (got.double() - ref).pow(2).mean().sqrt().item()
+    e_fp32 = (fp32.double() - ref).pow(2).mean().sqrt().item()
+    assert e_split <= 1.5 * e_fp32 + 1e-9, (e_split, e_fp32)
+    # the split's own share of that error (products summed exactly): several times below an fp32 GEMM's rounding
+    lin = SplitLinear(w, b)
+    exact = split_planes_reference(x).double() @ lin.planes.double().t() * lin.alpha + b.double()
+    assert (exact - ref).pow(2).mean().sqrt().item() <= 0.5 * e_fp32
+    # without a bias, through the per-weight cache
+    cache = SplitLinears()
+    y1, y2 = cache(x, w), cache(x, w)
+    assert torch.equal(y1, y2) and len(cache._by_weight) == 1
+    assert (y1.double() - (ref - b.double())).pow(2).mean().sqrt().item() <= 1.5 * e_fp32 + 1e-9
+    with pytest.raises(ValueError):
+        lin(x.half())
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("SEAL_TEST_SPLIT_GEMM") != "1", reason="opt-in until measured on an MI355X (SEAL_TEST_SPLIT_GEMM=1)")
+def test_split_linear_on_the_gpu():
+    """the HIP split kernel == the torch emulation bit for bit; the hipBLASLt product is fp32-grade; out-of-range activations are
+    counted; the whole call is capturable"""
+    from seal_amd import split_gemm
+    from seal_amd._lib import check, lib
+    dev = torch.device("cuda:0")
+    x = _activations(600, 1024, 3).to(dev)
+    out = torch.empty(600, 3072, dtype=torch.float16, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib().sealnn_split_planes(torch.cuda.current_stream(dev).cuda_stream, x.data_ptr(), 600, 1024, out.data_ptr(), flag.data_ptr()))
+    assert torch.equal(out.cpu(), split_planes_reference(x.cpu())) and int(flag.item()) == 0
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(4096, 1024, generator=g) * 0.05).to(dev)
+    b = torch.randn(4096, generator=g).to(dev)
+    ref = x.double() @ w.double().t() + b.double()
+    e_fp32 = (torch.nn.functional.linear(x, w, b).double() - ref).pow(2).mean().sqrt().item()
+    lin = SplitLinear(w, b)
+    got = lin(x)
+    assert got.dtype == torch.float32
+    assert (got.double() - ref).pow(2).mean().sqrt().item() <= 2.0 * e_fp32
+    assert split_gemm.overflowed(dev) == 0
+    x2 = x.clone()
+    x2[3, 5] = 1e5
+    lin(x2)
+    assert split_gemm.overflowed(dev) == 1 and split_gemm.overflowed(dev) == 0
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        lin(x)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            y = lin(x)
+        gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, got)
+
+
+def test_decoder_linear_helpers_are_f_linear_by_default():
+    """BartStepDecoder._lin / _mod (what the fused paths call for every projection): F.linear unless SEAL_SPLIT_GEMM=1"""
+    import torch.nn.functional as F
+    from seal_amd import split_gemm
+    from seal_amd.bart_decoder import BartStepDecoder
+    from tests.helpers import tiny_bart
+    assert split_gemm.ENABLED is (os.environ.get("SEAL_SPLIT_GEMM", "0") == "1")
+    m = tiny_bart(60)
+    dec = BartStepDecoder(m)
+    x = torch.randn(5, dec.d)
+    for L in dec.layers:
+        assert torch.equal(dec._lin(x, L["qkv_w"], L["qkv_b"]), F.linear(x, L["qkv_w"], L["qkv_b"]))
+        for name in ("so", "cq", "co", "fc1"):
+            assert torch.equal(dec._mod(x, L[name]), L[name](x))
+        h = L["act"](dec._mod(x, L["fc1"]))
+        assert torch.equal(dec._mod(h, L["fc2"]), L["fc2"](h))
+    assert torch.equal(dec.lm_head(x), F.linear(x, dec.lm_w, dec.lm_b.view(-1)))
+    if not split_gemm.ENABLED:
+        assert BartStepDecoder.split_gemm is False
