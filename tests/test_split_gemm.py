@@ -135,3 +135,41 @@ def test_decoder_linear_helpers_are_f_linear_by_default():
     assert torch.equal(dec.lm_head(x), F.linear(x, dec.lm_w, dec.lm_b.view(-1)))
     if not split_gemm.ENABLED:
         assert BartStepDecoder.split_gemm is False
+
+
+def test_model_forward_through_split_linears_scores_like_fp32():
+    """every nn.Linear / lm_head product of a (tiny) BART forward through the emulated split product: the running log-probability sums of
+    teacher-forced hypotheses move by no more than fp32's own distance from float64 (tools/split_gemm_e2e_cpu.py does the same at BART-large
+    geometry: 8.4e-6 against fp32's 5.5e-6, tolerance 1e-4)"""
+    import copy
+    import torch.nn.functional as F
+    from tests.helpers import tiny_bart
+    vocab = 200
+    m = tiny_bart(vocab, d_model=128, heads=2, max_positions=64)
+    g = torch.Generator().manual_seed(3)
+    enc = torch.randint(4, vocab, (6, 9), generator=g)
+    dec = torch.randint(4, vocab, (6, 8), generator=g)
+    tgt = torch.randint(4, vocab, (6, 8), generator=g)
+
+    def sums(model):
+        with torch.no_grad():
+            lp = torch.log_softmax(model(input_ids=enc, decoder_input_ids=dec).logits, dim=-1)
+        fin = torch.isfinite(lp.gather(-1, tgt[..., None])[..., 0])
+        return torch.where(fin, lp.gather(-1, tgt[..., None])[..., 0], torch.zeros((), dtype=lp.dtype)).cumsum(-1).double()
+    a = sums(m)
+    split, orig, used = SplitLinears(), F.linear, []
+
+    def split_linear(x, w, b=None):
+        if x.dtype != torch.float32 or w.shape[1] % 4:
+            return orig(x, w, b)
+        used.append(w.shape)
+        return split(x.reshape(-1, x.shape[-1]), w, b).view(*x.shape[:-1], w.shape[0])
+    torch.nn.functional.linear = split_linear
+    try:
+        b = sums(m)
+    finally:
+        torch.nn.functional.linear = orig
+    ref = sums(copy.deepcopy(m).double())
+    assert len(used) > 20
+    e_fp32, e_split = (a - ref).abs().max().item(), (b - ref).abs().max().item()
+    assert e_split <= max(3 * e_fp32, 2e-6), (e_split, e_fp32)
