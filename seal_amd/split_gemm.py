@@ -37,6 +37,10 @@ import os
 import torch
 
 ENABLED = os.environ.get("SEAL_SPLIT_GEMM", "0") == "1"
+# which products go through the split (the rest stay F.linear): a skinny GEMM with few output columns fills a fraction of the chip in
+# either precision and has nothing to gain -- to be set from tools/split_gemm_probe.py's per-shape times
+MIN_N = int(os.environ.get("SEAL_SPLIT_GEMM_MIN_N", "0"))
+MIN_ROWS = int(os.environ.get("SEAL_SPLIT_GEMM_MIN_ROWS", "0"))
 LO_SHIFT = 11                      # bits between the planes: fp16 has an 11-bit significand
 _flags = {}                        # device -> int32 counter of unsplittable activations
 
@@ -110,6 +114,8 @@ class SplitLinears:
         self._by_weight = {}
 
     def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
+        if weight.shape[0] < MIN_N or x.shape[0] < MIN_ROWS or weight.shape[1] % 4:
+            return torch.nn.functional.linear(x, weight, bias)
         key = (weight.data_ptr(), tuple(weight.shape))
         lin = self._by_weight.get(key)
         if lin is None:

@@ -6,6 +6,7 @@ out=gpurun_out; mkdir -p $out
 timeout 200 python tools/split_gemm_probe.py > $out/${tag}_probe.txt 2>&1; echo "probe rc=$?"; grep -v "^{" $out/${tag}_probe.txt | tail -12
 SEAL_TEST_SPLIT_GEMM=1 timeout 200 python -m pytest tests/test_split_gemm.py -x -q > $out/${tag}_test.log 2>&1; echo "test rc=$?"; tail -3 $out/${tag}_test.log
 for mode in 1 0; do
+  # (SEAL_SPLIT_GEMM_MIN_N / _MIN_ROWS: set from the probe's per-shape times before this leg)
   SEAL_SPLIT_GEMM=$mode timeout -s ABRT 300 python -X faulthandler bench.py --steps 20 --warmup 5 > $out/${tag}_bench_split$mode.json 2> $out/${tag}_bench_split$mode.log
   echo "bench(split gemm $mode) rc=$?"
   python - <<'PY' $out/${tag}_bench_split$mode.json
