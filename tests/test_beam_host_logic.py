@@ -213,3 +213,32 @@ def test_tuned_gemm_file_and_modes(tmp_path, monkeypatch):
     tuned_gemm._write(TN(), str(out))
     again = out.read_text().splitlines()
     assert [ln.split(",")[:3] for ln in again] == [ln.split(",")[:3] for ln in lines]
+
+
+def test_beam_loop_promises_identical_beams_only_for_the_first_step_of_a_decoder_that_asks():
+    """``constrained_beam_search_groups`` passes ``beams_identical=True`` to ``decoder.step`` for the first position only, and only to a
+    decoder that says ``shared_first_step`` (BartStepDecoder's opt-in one-row-per-query first step); the eager decoder ignores the
+    promise and the histories are the same either way"""
+    from seal_amd.beam_search import constrained_beam_search
+    vocab, K, T = 120, 3, 5
+    m = tiny_bart(vocab)
+    torch.manual_seed(1)
+    ids = torch.randint(4, vocab, (2, 7))
+    mask = torch.ones_like(ids)
+    seen = []
+
+    class Spy(BartStepDecoder):
+        def step(self, tokens, beams_identical=False):
+            seen.append((self.t, bool(beams_identical), tokens.view(-1, K).eq(tokens.view(-1, K)[:, :1]).all().item()))
+            return super().step(tokens, beams_identical=beams_identical)
+    out = []
+    for asks in (True, False):
+        del seen[:]
+        dec = Spy(m)
+        dec.shared_first_step = asks
+        dec.start(dec.encode(ids, mask), mask, K, T)
+        out.append(constrained_beam_search(dec, 2, K, T, 2, 2, None))
+        assert [s[:2] for s in seen] == [(t, asks and t == 0) for t in range(T - 1)]
+        assert seen[0][2] is True                      # the promise holds: every beam starts from the same token
+    for (pa, ta, sa), (pb, tb, sb) in zip(out[0][0], out[1][0]):
+        assert torch.equal(pa, pb) and torch.equal(ta, tb) and torch.equal(sa, sb)
