@@ -4,6 +4,9 @@
 tag=${1:-r4s}
 out=gpurun_out; mkdir -p $out
 timeout 200 python tools/split_gemm_probe.py > $out/${tag}_probe.txt 2>&1; echo "probe rc=$?"; grep -v "^{" $out/${tag}_probe.txt | tail -12
+# the same product on hipBLASLt directly (every algorithm the heuristic offers): the route if torch's out_dtype path is missing or slow
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/blaslt_f16_probe.cpp -lhipblaslt -o /tmp/blaslt_probe > $out/${tag}_blaslt_build.log 2>&1 \
+  && timeout 200 /tmp/blaslt_probe > $out/${tag}_blaslt.txt 2>&1; echo "blaslt probe rc=$?"; tail -22 $out/${tag}_blaslt.txt
 SEAL_TEST_SPLIT_GEMM=1 timeout 200 python -m pytest tests/test_split_gemm.py -x -q > $out/${tag}_test.log 2>&1; echo "test rc=$?"; tail -3 $out/${tag}_test.log
 for mode in 1 0; do
   # (SEAL_SPLIT_GEMM_MIN_N / _MIN_ROWS: set from the probe's per-shape times before this leg)
