@@ -410,7 +410,13 @@ class BartStepDecoder:
                             forward()
                     cur.wait_stream(side)
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    # its own capture stream: torch keeps ONE BLAS workspace per (handle, stream) and captures on a process-wide
+                    # default stream otherwise -- this graph would then share the decode graphs' workspace (stream-K partial tiles
+                    # and flags of the library's GEMMs) while it replays on another stream beside them
+                    cap = self.__dict__.get("_tree_capture_stream")
+                    if cap is None:
+                        cap = self._tree_capture_stream = torch.cuda.Stream(device=dev)
+                    with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
                         st.hidden = forward()
                     st.graph = g
         st.graph.replay()
