@@ -947,6 +947,13 @@ def main():
                 "wave_iterations_per_launch": round(xstats[1] / nl, 1), "lane_pair_utilisation": round(xstats[2] / max(1, 32 * xstats[1]), 3)}
 
     cpu = parity = None
+    if args.no_cpu_baseline and world == 1 and os.environ.get("SEAL_BENCH_SCORE_PARITY") == "1":
+        # quick A/B runs of model-side changes (tools/r4_split_gemm.sh): the float half alone, no oracle
+        lo_q = (args.warmup + args.steps) * args.batch
+        sp = score_parity(searcher, model, index, queries[lo_q:lo_q + args.batch], bias[lo_q:lo_q + args.batch], dev)
+        log("score parity vs HF fp32 forward (no oracle leg): beam scores max abs err %.2e / %.2e (body / title), rescoring %.2e, violations %d (tol 1e-4)"
+            % (sp["beam_scores_body"]["max_abs_err"], sp["beam_scores_title"]["max_abs_err"], sp["rescore_scores"]["max_abs_err"],
+               sp["beam_scores_body"]["violations"] + sp["beam_scores_title"]["violations"] + sp["rescore_scores"]["violations"]))
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
         threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
         t0 = time.perf_counter()

@@ -14,7 +14,7 @@ QUICK="--docs 2000000 --corpus-phrases 2000000 --no-cpu-baseline"
 [ -n "$FULL" ] && QUICK=""
 for mode in 1 0; do
   # (SEAL_SPLIT_GEMM_MIN_N / _MIN_ROWS: set from the probe's per-shape times before this leg)
-  SEAL_SPLIT_GEMM=$mode timeout -s ABRT 300 python -X faulthandler bench.py $QUICK --steps 20 --warmup 5 > $out/${tag}_bench_split$mode.json 2> $out/${tag}_bench_split$mode.log
+  SEAL_BENCH_SCORE_PARITY=1 SEAL_SPLIT_GEMM=$mode timeout -s ABRT 300 python -X faulthandler bench.py $QUICK --steps 20 --warmup 5 > $out/${tag}_bench_split$mode.json 2> $out/${tag}_bench_split$mode.log
   echo "bench(split gemm $mode) rc=$?"
   python - <<'PY' $out/${tag}_bench_split$mode.json
 import json, sys
