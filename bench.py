@@ -717,9 +717,9 @@ def main():
     model._seal_step_decoder = BartStepDecoder(model)
     # every pipeline drives the constraint kernels through its own view of the index: count / time all of them
     handles = [index.handle] + ([p.index.handle for p in searcher._pipelines()] if searcher._pipelined() else [])
-    for hd in handles:
-        check(lib().fmi_dev_enable_probe_count(hd, 1))
-        check(lib().fmi_dev_enable_timing(hd, 1))
+    # The warm-up and the TIMED region run the product: no in-kernel probe counters, no event pairs around the constraint calls
+    # (round 3 timed the counting instantiation of k_constrain).  Launch times and block counts for the roofline come from two
+    # separate un-overlapped passes over one more batch of the same workload, after the timed region (below).
 
     def read_counters(stats=None):
         """(probes, launches, kernel ms) summed over the handles since the last read; expand stats accumulate"""
@@ -763,7 +763,6 @@ def main():
         torch.cuda.synchronize()
         step_ms.append((time.perf_counter() - t1) * 1e3)
     import ctypes
-    read_counters()                                        # drop the warm-up's counts
 
     torch.cuda.synchronize()
     if use_dist:
@@ -784,9 +783,6 @@ def main():
         t = torch.tensor([peak_rss_gib], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         peak_rss_gib = float(t.item())
-    xstats = [0, 0, 0, 0]
-    _p, _l, _k = read_counters(xstats)
-    probes, launches, kms = ctypes.c_uint64(_p), ctypes.c_uint64(_l), ctypes.c_double(_k)
     n_found = float(np.mean([len(r) for r in res]))
 
     # secondary figure: the same K batches through the other retrieval depth (first stage only <-> complete)
@@ -811,7 +807,6 @@ def main():
             t2 = float(tt.item())
         other_qps = args.batch * args.steps * world / t2
         searcher.first_stage_only = args.first_stage_only
-        read_counters()
 
     if rank != 0:
         if use_dist:
@@ -848,11 +843,11 @@ def main():
     if not os.environ.get("SEAL_BENCH_KEEP_JOBS"):
         searcher.jobs = 1                                  # inline host stages: their time shows up in aggregate_ms
     searcher.pipeline = 1                                  # one batch, on this thread: phase times are not interleaved
-    read_counters()
-    # the in-kernel counters cost the wide launches a few microseconds: this pass is TIMED with them off, the recording
-    # pass below runs the same batch once more with them on and supplies the bytes of the very same launches
+    # launch times: HIP events around every constraint call of this un-overlapped batch, in-kernel counters OFF (they cost the
+    # wide launches a few microseconds); the recording pass below runs the same batch once more with the counters on (events
+    # off) and supplies the bytes of the very same launches
     for hd in handles:
-        check(lib().fmi_dev_enable_probe_count(hd, 0))
+        check(lib().fmi_dev_enable_timing(hd, 1))
     if os.environ.get("SEAL_BENCH_PROFILE"):
         import cProfile, pstats
         pr = cProfile.Profile()
@@ -870,6 +865,7 @@ def main():
         ln, km = C.c_uint64(), C.c_double()
         check(lib().fmi_dev_read_timing(hd, C.byref(ln), C.byref(km)))
         l2.value += ln.value; k2.value += km.value
+        check(lib().fmi_dev_enable_timing(hd, 0))
         check(lib().fmi_dev_enable_probe_count(hd, 1))
     # the same batch once more, untimed, RECORDING every index operation with the GPU's answer (parity_check below)
     agg_calls = []
@@ -884,8 +880,11 @@ def main():
     run_batch(args.warmup + args.steps)
     index.set_trace(None)
     rk.aggregate_evidence_batch = orig[3]
-    _p, _l, _k = read_counters()                           # blocks loaded by the launches of that batch (the replays that
+    xstats = [0, 0, 0, 0]
+    _p, _l, _k = read_counters(xstats)                     # blocks loaded by the launches of that batch (the replays that
     p2 = ctypes.c_uint64(_p)                               # gpu_allowed_bits issues for the parity check come later)
+    for hd in handles:
+        check(lib().fmi_dev_enable_probe_count(hd, 0))
     searcher.jobs, searcher.pipeline, searcher.overlap = jobs_saved, pipeline_saved, overlap_saved
 
     # one probe = one 128-byte block of the hex wavelet matrix, counted in-kernel (distinct blocks per
@@ -895,14 +894,12 @@ def main():
     # event pair then also brackets the time its launch waits behind their dispatches -- 71 us there against 34.7 us of
     # execution in the rocprofv3 trace of the very same launches (profiles/r2_kernel_stats.csv).  The timed region's own
     # event figure is kept beside it (`timed_region_event_us`).
-    alg_bytes = probes.value * 128.0
-    timed_event_us = kms.value * 1e3 / max(1, launches.value)
     n2 = max(1, l2.value)
     achieved = (p2.value * 128.0) / (k2.value * 1e-3) / 1e9 if k2.value > 0 else 0.0
     # SURVEY.md §8(d) prices the same work on the reference-shaped structure (binary wavelet tree, one
     # 64-byte level-probe per node end): counted exactly in-kernel as well, reported beside it
     model_bytes = 2.0 * xstats[3] * 64.0
-    model_gbps = (model_bytes / max(1, launches.value)) / (k2.value / n2 * 1e-3) / 1e9 if k2.value > 0 else 0.0
+    model_gbps = model_bytes / (k2.value * 1e-3) / 1e9 if k2.value > 0 else 0.0
     # memory-side traffic comes from a SEPARATE rocprofv3 --pmc FETCH_SIZE pass of this same command over the
     # CURRENT kernel (tools/prof_bench.sh -> profiles/r*_pmc_fetch_size.json, which names the commit it was taken
     # at); a profile of another kernel generation is not used.  Per launch = per constraint call = one k_constrain.
@@ -928,19 +925,16 @@ def main():
                                       "(sha256 %s); run tools/prof_bench.sh" % now[:16], "candidates": [os.path.relpath(f, ROOT) for f in files[:3]]}
     except Exception as e:
         traffic_src = {"error": repr(e)}
-    nl = max(1, launches.value)
+    nl = n2
     roofline = {"bound": "hbm", "kernel": "k_constrain (one constraint call for the rows of both decodes; from 2-token prefixes on as two launches: "
                                           "k_constrain_rows -- one wave per row: prefix range, class, root node split -- then k_constrain -- one wave per "
                                           "(row, top digit), the sub-trees level by level by workgroups of 8 waves; events bracket the call)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic, "traffic_source": traffic_src, "launches": int(l2.value), "avg_launch_us": round(k2.value * 1e3 / n2, 2),
                 "algorithmic_bytes_per_launch": round(p2.value * 128.0 / n2, 1),
-                "measured_on": "one batch of the same workload with the launches alone on the GPU: HIP events around each with the in-kernel counters off, "
-                               "the blocks counted in a second pass over the same batch",
-                "timed_region": {"launches": int(launches.value), "event_us_per_launch": round(timed_event_us, 2),
-                                 "algorithmic_bytes_per_launch": round(alg_bytes / nl, 1),
-                                 "note": "a second stream shares the GPU here: the event pair also sees its launch queueing behind the other "
-                                         "stream's dispatches (rocprofv3 shows the same execution time for these launches as for the un-overlapped ones)"},
+                "measured_on": "one batch of the same workload AFTER the timed region, launches alone on the GPU: HIP events around each constraint call with the "
+                               "in-kernel counters off, the blocks counted in a second pass over the same batch with the events off; the timed region "
+                               "itself runs the product kernels, uninstrumented",
                 "survey_8d_model": {"bytes_per_launch": round(model_bytes / nl, 1), "achieved": round(model_gbps, 2),
                                     "frac": round(model_gbps / HBM_PEAK_GBPS, 5),
                                     "note": "binary 16-level wavelet tree, 64 B per level-probe, same symbols emitted"},
@@ -1040,7 +1034,9 @@ def main():
         "extra": {("complete_search_qps" if args.first_stage_only else "first_stage_only_qps"): None if other_qps is None else round(other_qps, 3),
                   "p50_batch_latency_ms_unpipelined": round(float(np.median(step_ms[1:] or step_ms)), 2) if step_ms else None, "docs_returned_per_query": n_found,
                   "peak_host_rss_gib_per_rank_max": round(peak_rss_gib, 2),
-                  "decode_step_gemm_algorithms": __import__("seal_amd.tuned_gemm", fromlist=["setup"]).setup(),   # file = shipped picks, off = library default
+                  "timed_region_instrumentation": "none: probe counters and constraint-call event pairs are off during warm-up and the timed call; "
+                                                  "roofline figures come from separate un-overlapped passes after it",
+                  "decode_step_gemm_algorithms": "library default (hipBLASLt heuristic); round 3's TunableOp picks are gone: one of them stalled the search (DESIGN.md 9)",
                   "phase_ms_one_batch": {k: round(v, 2) for k, v in phases.items()},
                   "k_constrain_ms_one_batch": round(k2.value, 3), "k_constrain_blocks_one_batch": int(p2.value)},
     }

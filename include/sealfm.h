@@ -215,7 +215,9 @@ int fmi_dev_constrained_topk_step(fmi_t *h, void *stream, uint64_t batch, uint64
  * 2 * batch * beams rows per model step instead of two loops of batch * beams): group g = the next
  * group_batch[g] queries (x beams rows) with its own end-of-sequence token group_eos[g] and forced prefix
  * (group_force[g * 8 ..], group_n_force[g] tokens; with ONE group: group_force[0 ..]).  1 <= n_groups <= 3;
- * pad / stop_at_count / always_allow_eos are shared.  Every row's mask is the one fmi_dev_constrained_topk_step
+ * pad / always_allow_eos are shared; group_stop_at_count[g] (NULL: stop_at_count for every group) is the group's own
+ * stop_at_count -- the reference passes it to the body decode only (retrieval.py:70-83; titles / codes run with 0,
+ * retrieval.py:162-176, 212-236).  Every row's mask is the one fmi_dev_constrained_topk_step
  * computes for it with its group's arguments, and every query's top-2K likewise: the call is ONE constraint
  * launch over all rows.  A later call of the same loop may hold fewer rows (finished decodes dropped):
  * d_parent_rows[] then still names rows of the previous call. */
@@ -225,7 +227,7 @@ int fmi_dev_constrained_topk_groups(fmi_t *h, void *stream, uint64_t n_groups, c
                                     const float *d_beam_scores, uint64_t vocab, int64_t shift, int64_t pad_id,
                                     int64_t stop_at_count, int always_allow_eos, const uint32_t *d_first_bits,
                                     void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc,
-                                    uint64_t state_tag, const int64_t *d_parent_rows);
+                                    uint64_t state_tag, const int64_t *d_parent_rows, const int64_t *group_stop_at_count);
 
 /* fmi_dev_allowed_bits with the continuity contract of fmi_dev_constrained_topk_step (state_tag / d_parent_rows:
  * the rows extend, by one token, rows d_parent_rows[] of the previous call with the same tag, so the prefix range
@@ -241,6 +243,21 @@ int fmi_dev_allowed_bits_step(fmi_t *h, void *stream, uint64_t rows, uint64_t cu
  * k_constrain stores realtime stamps (100 MHz) at {start, prefix range known, root child known (0: none),
  * sub-tree expanded, bitmap stored}.  NULL switches it off. */
 int fmi_dev_debug_timestamps(fmi_t *h, uint64_t *d_buf, uint64_t n_words);
+
+/* Launch-shape switches of the constraint / top-2K calls, for A/B measurements and for the tests that force every kernel path.
+ * Each is read from the environment ONCE when the handle is created (SEALFM_<NAME in capitals>) and can be changed afterwards
+ * here; value -1 restores the built-in choice.  Names: "constrain_waves" (1: one self-contained wave per (row, top digit)),
+ * "leave_early" (0: the waves of empty items stay), "row_first" (0 / 1: never / always the row-first pair of launches),
+ * "row_first_from", "rows_only_from" (prefix length in tokens from which the form is used; rows_only_from 0: never),
+ * "topk_narrow" (rows with more allowed tokens take the wide-row path of the top-2K kernel), "topk_legacy" (1: exact radix
+ * select on wide rows).  Results are identical for every setting (tests/test_gpu_fmindex.py, tests/test_gpu_decode.py). */
+int fmi_dev_set_option(fmi_t *h, const char *name, int64_t value);
+
+/* tools only (tools/soak.py: which launch of a stalled stream never completed): while `marks` (>= 16 uint32 of
+ * host-visible memory, e.g. pinned) is set, fmi_dev_aggregate writes marks[1] = 100 * call number + stage after every
+ * launch of its sequence, in stream order.  NULL switches it off.  fmi_dev_mark: one such write on any stream. */
+int fmi_dev_debug_marks(fmi_t *h, uint32_t *marks);
+int fmi_dev_mark(void *stream, uint32_t *word, uint32_t value);
 
 /* locate + doc binning for n rows (seal/keys.py:320-324) */
 int fmi_dev_locate(fmi_t *h, void *stream, uint64_t n, const uint64_t *d_rows,

@@ -51,12 +51,15 @@ SIGNATURES = {
     "fmi_dev_allowed_bits": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, _i64, _i64, _i64, _pi64, _u64, _i64, _int]),
     "fmi_dev_allowed_bits_step": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, _i64, _i64, _i64, _pi64, _u64, _i64, _int, _u64, _vp, _vp]),
     "fmi_dev_debug_timestamps": (_int, [_vp, _vp, _u64]),
+    "fmi_dev_set_option": (_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
+    "fmi_dev_debug_marks": (_int, [_vp, _vp]),
+    "fmi_dev_mark": (_int, [_vp, _vp, ctypes.c_uint32]),
     "fmi_dev_constrained_topk": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _u64, _i64, _i64, _i64, _pi64, _u64, _i64, _int,
                                         _vp, _vp, _u64, _vp, _vp, _vp]),
     "fmi_dev_constrained_topk_step": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _u64, _i64, _i64, _i64, _pi64, _u64, _i64, _int,
                                              _vp, _vp, _u64, _vp, _vp, _vp, _u64, _vp]),
     "fmi_dev_constrained_topk_groups": (_int, [_vp, _vp, _u64, _p64, _pi64, _pi64, _p64, _u64, _u64, _vp, _vp, _vp, _u64, _i64, _i64, _i64, _int,
-                                               _vp, _vp, _u64, _vp, _vp, _vp, _u64, _vp]),
+                                               _vp, _vp, _u64, _vp, _vp, _vp, _u64, _vp, _pi64]),
     "fmi_dev_locate": (_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "fmi_dev_locate_ranges": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp, _vp]),
     "fmi_dev_get_docs": (_int, [_vp, _vp, _u64, _vp, _vp, _i64, _vp]),

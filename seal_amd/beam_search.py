@@ -64,7 +64,7 @@ class IndexBasedLogitsProcessor:
     # -- fused decode step ----------------------------------------------------
     def supports_fused_topk(self, logits: torch.Tensor, num_beams: int) -> bool:
         return (logits.is_cuda and logits.dtype == torch.float32 and self.forced_bos_token_id is None
-                and 2 * num_beams <= 64)
+                and 2 * num_beams <= 64 and len(self.force_decoding_from or []) <= MAX_FORCE)    # longer forced prefixes: the unfused path
 
     def _first_bits(self, vocab: int, device) -> torch.Tensor:
         """allowed-token bitmap of the first step (``occurring_distinct``, beam_search.py:73-77), cached on the index"""
@@ -141,7 +141,7 @@ def can_fuse_groups(procs, logits: torch.Tensor, num_beams: int) -> bool:
     p0 = procs[0]
     return (0 < len(procs) <= MAX_ROW_GROUPS
             and all(isinstance(p, IndexBasedLogitsProcessor) and p.supports_fused_topk(logits, num_beams) for p in procs)
-            and all(p.index is p0.index and p.pad_token_id == p0.pad_token_id and int(p.stop_at_count) == int(p0.stop_at_count)
+            and all(p.index is p0.index and p.pad_token_id == p0.pad_token_id
                     and bool(p.always_allow_eos) == bool(p0.always_allow_eos) and len(p.force_decoding_from or []) <= MAX_FORCE for p in procs)
             and (len(procs) == 1 or not p0.always_allow_eos))      # (the first-step bitmap folds ONE eos in)
 
@@ -171,6 +171,7 @@ def fused_topk_groups(procs, batches, input_ids: torch.LongTensor, logits: torch
     g_batch = (ctypes.c_uint64 * n)(*[int(b) for b in batches])
     g_eos = (ctypes.c_int64 * n)(*[int(p.eos_token_id) for p in procs])
     g_nff = (ctypes.c_uint64 * n)(*[len(p.force_decoding_from or []) for p in procs])
+    g_stop = (ctypes.c_int64 * n)(*[max(0, int(p.stop_at_count)) for p in procs])      # per decode: the reference gives it to the body decode only
     g_ff = (ctypes.c_int64 * (n * MAX_FORCE))()
     for g, p in enumerate(procs):
         for j, t in enumerate(p.force_decoding_from or []):
@@ -190,7 +191,7 @@ def fused_topk_groups(procs, batches, input_ids: torch.LongTensor, logits: torch
         p0.index.handle, _stream_ptr(dev), n, g_batch, g_eos, g_ff, g_nff, num_beams, cur_len, ids.data_ptr(), lg.data_ptr(), bs.data_ptr(),
         V, SHIFT, p0.pad_token_id, int(p0.stop_at_count), int(bool(p0.always_allow_eos)),
         first.data_ptr() if first is not None else None, scratch.data_ptr(), scratch.numel() * 4,
-        top_idx.data_ptr(), top_con.data_ptr(), top_unc.data_ptr(), int(tag), parent.data_ptr() if parent is not None else None))
+        top_idx.data_ptr(), top_con.data_ptr(), top_unc.data_ptr(), int(tag), parent.data_ptr() if parent is not None else None, g_stop))
     return top_idx, top_unc
 
 
@@ -208,6 +209,7 @@ def _inf_nan_remove(scores: torch.Tensor) -> torch.Tensor:
 
 
 _LOOP_TAGS = itertools.count(1)      # one continuity tag per decode loop (fmi_dev_constrained_topk_step's state_tag)
+_DEBUG_MARK = None                   # tools/soak.py: callable(code) that writes a progress word in stream order (which launch of a stalled decode never completed)
 
 
 @torch.no_grad()
@@ -260,6 +262,8 @@ def constrained_beam_search_groups(decoder, specs, num_beams: int, decoder_start
             logits = decoder.step(input_ids[:, -1], beams_identical=True)     # every beam starts from decoder_start_token_id
         else:
             logits = decoder.step(input_ids[:, -1])
+        if _DEBUG_MARK is not None:
+            _DEBUG_MARK(1000 * tag + 10 * input_ids.shape[-1] + 1)       # the model step of this position is behind us
         V = logits.shape[-1]
         if first_logits is None:
             # every beam of a query sees the same first step: the model's next-token logits after the start token,
@@ -287,6 +291,8 @@ def constrained_beam_search_groups(decoder, specs, num_beams: int, decoder_start
                 constrained = unconstrained
             _, flat = torch.topk(constrained.view(B, K * V), 2 * K, dim=1, largest=True, sorted=True)
             next_scores = unconstrained.view(B, K * V).gather(-1, flat)
+        if _DEBUG_MARK is not None:
+            _DEBUG_MARK(1000 * tag + 10 * input_ids.shape[-1] + 2)       # constraint + top-2K
         next_indices = flat // V                    # (next_tokens / V).long(), exact for K*V < 2^24 (309)
         next_tokens = flat % V
         src_rows = row_base + next_indices          # batch_beam_idx (661)
@@ -306,6 +312,8 @@ def constrained_beam_search_groups(decoder, specs, num_beams: int, decoder_start
         beam_idx = src_rows.gather(1, order).view(R)
         input_ids = torch.cat([input_ids[beam_idx], beam_tokens.unsqueeze(-1)], dim=-1)
         decoder.reorder(beam_idx)
+        if _DEBUG_MARK is not None:
+            _DEBUG_MARK(1000 * tag + 10 * (input_ids.shape[-1] - 1) + 3)  # the loop's own torch ops + the ancestry table
         cur = input_ids.shape[-1]
         done = [g for g in live if cur >= specs[g]["max_length"]]       # MaxLengthCriteria (340); a prefix of `live`
         if done:
@@ -445,7 +453,7 @@ def fm_index_generate_joint(model, index: FMIndex, input_ids: torch.LongTensor, 
                             disable_fm_index: bool = False, logit_bias=None, decoder=None, forced_bos_token_id=None, extra_inputs=None):
     """Several ``fm_index_generate(keep_history=True)`` calls of ONE model as one decode loop: ``jobs`` = dicts with
     ``batch`` (the next ``batch`` rows of ``input_ids`` are this job's encoder inputs), ``max_length``, ``eos_token_id``,
-    ``force_decoding_from``.  The searcher's body and title decodes (reference retrieval.py:70-83, 162-176: two
+    ``force_decoding_from``, optionally its own ``stop_at_count`` (default: the call's).  The searcher's body and title decodes (reference retrieval.py:70-83, 162-176: two
     ``generate`` calls one after the other over the same queries) become 2 x batch x beams rows per model step: one encoder
     pass, GEMMs at twice the height, one constraint launch per step for both (``constrained_beam_search_groups``).  Every job
     gets the hypotheses its own call would produce.  ``logit_bias`` [sum of batches, vocab].  Returns one ``PendingGenerate``
@@ -477,7 +485,7 @@ def fm_index_generate_joint(model, index: FMIndex, input_ids: torch.LongTensor, 
             eos = model.config.eos_token_id
         proc = None if disable_fm_index else IndexBasedLogitsProcessor(
             num_beams=num_beams, index=index, pad_token_id=model.config.pad_token_id, eos_token_id=eos,
-            force_decoding_from=j.get("force_decoding_from"), stop_at_count=stop_at_count, always_allow_eos=always_allow_eos,
+            force_decoding_from=j.get("force_decoding_from"), stop_at_count=j.get("stop_at_count", stop_at_count), always_allow_eos=always_allow_eos,
             forced_bos_token_id=forced_bos_token_id)
         specs.append(dict(batch=j["batch"], max_length=j["max_length"], eos_token_id=eos, processor=proc))
     extra_encoded = None

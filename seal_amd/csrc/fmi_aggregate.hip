@@ -857,6 +857,11 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
     const AggView v = make_view(H, (const uint8_t *)d_plan_blob);
     const uint64_t N = H.total_occ;
     const uint32_t nq = (uint32_t)H.nq;
+    // tools (fmi_dev_debug_marks): marks[1] = 100 * call + stage after every launch, so that a stalled stream names its launch
+    static uint32_t call_no = 0;
+    const uint32_t call_base = 100u * (++call_no);
+    auto mark = [&](uint32_t stage) { if (h->dbg_marks) hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, st, h->dbg_marks + 1, call_base + stage); };
+    mark(1);
     HIPCHK(hipMemsetAsync(d_out, 0, L.fixed_bytes, st));
     HIPCHK(hipMemsetAsync(w.top_cnt, 0, nq * 4, st));
     HIPCHK(hipMemsetAsync(w.pool_cursor, 0, 32, st));          // [0]: pool cursor, [4]: error word of the first stage
@@ -864,34 +869,45 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
         // ---- first stage ----
         uint64_t *ka = w.k0, *kb = w.k1;
         uint32_t *va = w.v0, *vb = w.v1;
+        mark(2);
         hipLaunchKernelGGL(k_agg_locate, dim3(blocks_for(N, 256)), dim3(256), 0, st, h->dev, v, w.occ_rk, w.doc, ka, va);
+        mark(3);
         if ((rc = sort_pairs(w, ka, kb, va, vb, N, FMI_AGG_POS_BITS + bits_for(nq - 1), st))) return rc;
+        mark(4);
         hipLaunchKernelGGL(k_mis_prepare, dim3(blocks_for(N, 256)), dim3(256), 0, st, v, va, w.occ_rk, w.M, w.state);
         hipLaunchKernelGGL(k_mis, dim3(blocks_for(N, MIS_CHUNK)), dim3(256), 0, st, ka, w.M, va, w.state, w.newflag, (uint32_t)N, (uint32_t)H.max_key_len,
                            w.pool_cursor + 4);
+        mark(5);
         hipLaunchKernelGGL(k_doc_keys, dim3(blocks_for(N, 256)), dim3(256), 0, st, v, w.occ_rk, w.doc, ka, va);
         if ((rc = sort_pairs(w, ka, kb, va, vb, N, 32 + bits_for(nq - 1), st))) return rc;
+        mark(6);
         hipLaunchKernelGGL(k_heads, dim3(blocks_for(N, 256)), dim3(256), 0, st, ka, w.head, N);
         size_t tb = w.rp_bytes;
         HIPCHK(rocprim::exclusive_scan(w.rp_tmp, tb, w.head, w.eid, 0u, N, rocprim::plus<uint32_t>(), st));
+        mark(7);
         hipLaunchKernelGGL(k_entry_starts, dim3(blocks_for(N, 256)), dim3(256), 0, st, w.head, w.eid, w.estart, w.n_entries, N);
         const uint32_t cover_words = (uint32_t)((H.max_u + 31) / 32) + 1;
         hipLaunchKernelGGL(k_entries, dim3((unsigned)std::min<uint64_t>(blocks_for(N, 4), 4096)), dim3(256), 4 * cover_words * 4, st, v, ka, va,
                            w.estart, w.n_entries, w.occ_rk, w.newflag, allow_overlaps, beta, single_key, cover_words, w.ckey, w.cscore,
                            w.ent_nkeys, w.ent_rank, w.ent_first, w.ent_q, w.ent_doc, w.ent_score, w.ent_best);
+        mark(8);
         // ---- ranking: stable sorts by first touch, then rank key, then query = sorted(first_stage.items(), key=...) ----
         uint32_t *fa = w.ent_first, *fb = w.tmp32;
         va = w.v0; vb = w.v1;
         hipLaunchKernelGGL(k_pad_entries, dim3(blocks_for(N, 256)), dim3(256), 0, st, w.n_entries, w.ent_first, w.ent_rank, w.ent_q, nq, va, N);
         if ((rc = sort_pairs(w, fa, fb, va, vb, N, 32, st))) return rc;
+        mark(9);
         ka = w.k0; kb = w.k1;
         hipLaunchKernelGGL(k_gather<uint64_t>, dim3(blocks_for(N, 256)), dim3(256), 0, st, w.ent_rank, va, ka, N);
         if ((rc = sort_pairs(w, ka, kb, va, vb, N, 64, st))) return rc;
+        mark(10);
         uint32_t *qa = w.head, *qb = w.eid;                   // head/eid are free by now
         hipLaunchKernelGGL(k_gather<uint32_t>, dim3(blocks_for(N, 256)), dim3(256), 0, st, w.ent_q, va, qa, N);
         if ((rc = sort_pairs(w, qa, qb, va, vb, N, bits_for(nq), st))) return rc;
+        mark(11);
         hipLaunchKernelGGL(k_top_docs, dim3(nq), dim3(256), 0, st, qa, va, w.ent_doc, N, nq, (uint32_t)n_top, w.ent_score, w.top_doc, w.top_ent, w.top_cnt,
                            L.o.fs_doc, L.o.fs_score, L.o.fs_cnt);
+        mark(12);
     }
     // ---- full scoring ----
     HIPCHK(hipMemsetAsync(w.type_dense, 0, (uint64_t)nq * H.vocab * 8, st));
@@ -916,12 +932,15 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
     p.per_q = (uint32_t)n_top;
     hipLaunchKernelGGL(k_full_score<false>, dim3(blocks_for((uint64_t)nq * n_top, 4)), dim3(256), lds_bytes, st, h->dev, v, p, w.top_doc, w.top_cnt,
                        (const uint32_t *)nullptr, w.type_dense, w.tok2local, w.scores, so, pool);
+    mark(13);
     if (n_top * 8 > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)k_rank_docs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(n_top * 8)));
     hipLaunchKernelGGL(k_rank_docs, dim3(nq), dim3(1024), n_top * 8, st, w.scores, w.top_cnt, (uint32_t)n_top, w.order);
+    mark(14);
     p.per_q = (uint32_t)keep;
     hipLaunchKernelGGL(k_full_score<true>, dim3(blocks_for((uint64_t)nq * keep, 4)), dim3(256), lds_bytes, st, h->dev, v, p, w.top_doc, w.top_cnt,
                        w.order, w.type_dense, w.tok2local, w.scores, so, pool);
+    mark(15);
     HIPCHK(hipGetLastError());
     return FMI_OK;
 }

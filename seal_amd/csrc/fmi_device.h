@@ -16,6 +16,9 @@ template <typename T> using cptr = const T __attribute__((address_space(4))) *;
 template <typename T> __device__ __forceinline__ cptr<T> as_const(const T *p) { return (cptr<T>)(uintptr_t)p; }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// tools (fmi_dev_debug_marks / fmi_dev_mark): a progress word in host-visible memory, written in stream order
+static __global__ void k_mark(volatile uint32_t *p, uint32_t v) { *p = v; __threadfence_system(); }
+
 // One 128-byte block in registers: 8 x global_load_dwordx4, every byte used.
 struct HBlock {
     uint32_t rel[16];    // digits equal to d between the superblock start and the block

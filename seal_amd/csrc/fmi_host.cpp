@@ -33,6 +33,45 @@ uint32_t fmi_sb_shift_for(uint64_t n)
 }
 extern "C" uint32_t fmi_abi_version(void) { return 1; }
 
+// ---- launch-shape switches: the environment is read here, once per handle (fmi_internal.h) ----
+static int64_t env_i64(const char *name, int64_t dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? (int64_t)atoll(e) : dflt;
+}
+
+FmiOptions::FmiOptions()
+{
+    constrain_waves = env_i64("SEALFM_CONSTRAIN_WAVES", constrain_waves);
+    leave_early = env_i64("SEALFM_LEAVE_EARLY", leave_early);
+    row_first = env_i64("SEALFM_ROW_FIRST", row_first);
+    row_first_from = env_i64("SEALFM_ROW_FIRST_FROM", row_first_from);
+    rows_only_from = env_i64("SEALFM_ROWS_ONLY_FROM", rows_only_from);
+    topk_narrow = env_i64("SEALFM_TOPK_NARROW", topk_narrow);
+    topk_legacy = env_i64("SEALFM_TOPK_LEGACY", topk_legacy);
+}
+
+int FmiOptions::set(const char *name, int64_t value)
+{
+    const std::string s(name ? name : "");
+    if (s == "constrain_waves") constrain_waves = value;
+    else if (s == "leave_early") leave_early = value < 0 ? 1 : value;
+    else if (s == "row_first") row_first = value;
+    else if (s == "row_first_from") row_first_from = value;
+    else if (s == "rows_only_from") rows_only_from = value;
+    else if (s == "topk_narrow") topk_narrow = value;
+    else if (s == "topk_legacy") topk_legacy = value < 0 ? 0 : value;
+    else return -1;
+    return 0;
+}
+
+extern "C" int fmi_dev_set_option(fmi_t *h, const char *name, int64_t value)
+{
+    if (!h || !name) { fmi_set_error("null argument"); return FMI_ERR_ARG; }
+    if (h->opt.set(name, value)) { fmi_set_error("fmi_dev_set_option: unknown option '%s'", name); return FMI_ERR_ARG; }
+    return FMI_OK;
+}
+
 extern "C" int fmi_create(fmi_t **out)
 {
     if (!out) { fmi_set_error("fmi_create: null out"); return FMI_ERR_ARG; }

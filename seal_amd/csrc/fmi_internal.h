@@ -60,7 +60,23 @@ struct FmiDev {
 };
 static constexpr uint32_t FMI_DOC_HINT_SHIFT = 7;
 
+// Launch-shape switches of the fmi_dev_* constraint / top-2K calls (A/B measurements, tests of every kernel path).  Read from the
+// environment ONCE, when the handle is created -- not per launch on a 40 us path -- and changed afterwards with
+// fmi_dev_set_option(h, name, value); -1 = the built-in choice.
+struct FmiOptions {
+    int64_t constrain_waves = -1;   // SEALFM_CONSTRAIN_WAVES=1: one self-contained wave per (row, top digit) instead of workgroups of 8 waves
+    int64_t leave_early = 1;        // SEALFM_LEAVE_EARLY=0: the waves of empty items stay in their workgroup
+    int64_t row_first = -1;         // SEALFM_ROW_FIRST=0 / 1: never / always the row-first pair of launches (default: by prefix length)
+    int64_t row_first_from = -1;    // SEALFM_ROW_FIRST_FROM=<tokens>: prefix length from which a call goes row-first (default 3; 2 from 512 rows on)
+    int64_t rows_only_from = -1;    // SEALFM_ROWS_ONLY_FROM=<tokens>: prefix length from which ONE wave per row does the whole row (0: never)
+    int64_t topk_narrow = -1;       // SEALFM_TOPK_NARROW=<n>: rows of more than n allowed tokens take the wide-row path of k_row_pick
+    int64_t topk_legacy = 0;        // SEALFM_TOPK_LEGACY=1: wide rows skip the thread-maxima bound (exact radix select)
+    FmiOptions();
+    int set(const char *name, int64_t value);      // 0, or -1 for an unknown name
+};
+
 struct fmi {
+    FmiOptions opt;
     // geometry
     uint64_t n = 0, max_sym = 0, sigma = 0, nblk = 0;
     uint32_t levels = 0, dlevels = 0, sym_bytes = 2, sb_shift = FMI_SB_NONE;
@@ -90,6 +106,7 @@ struct fmi {
     uint64_t *d_probe_counter = nullptr;
     uint64_t *dbg_tstamp = nullptr;   // tools: per-wave realtime stamps of k_constrain (fmi_dev_debug_timestamps)
     uint64_t dbg_tstamp_cap = 0;
+    uint32_t *dbg_marks = nullptr;    // tools: host-visible progress words (fmi_dev_debug_marks); [1] = last finished stage of fmi_dev_aggregate
     int probe_count_enabled = 0;
     // optional event timing of k_constrain launches
     int timing_enabled = 0;

@@ -549,7 +549,7 @@ struct ConstrainArgs {
     uint32_t grp_first[MAX_ROW_GROUPS];   // first row of group g (grp_first[0] = 0; unused groups: 0xffffffff)
     int64_t grp_eos[MAX_ROW_GROUPS];
     ForceFrom grp_ff[MAX_ROW_GROUPS];
-    int64_t stop_at_count;
+    int64_t grp_stop[MAX_ROW_GROUPS];     // stop_at_count of the group's decode (reference retrieval.py:70-83: the body decode's only; titles / codes 0)
     int always_allow_eos;
     uint64_t vocab, words_per_row;
     uint32_t *bits;                // [rows][words_per_row], zero on entry
@@ -598,6 +598,7 @@ __host__ __device__ constexpr uint32_t constrain_lds_slots(uint32_t D, uint32_t 
                  : (uint32_t)exp_slots((int)D - 1) + 2 + constrain_bm_slots(D);
 }
 
+static constexpr uint64_t ROWS_ONLY_FROM_DEFAULT = 0;   // prefix length from which a call takes the rows-only form (0: never; FmiOptions::rows_only_from)
 static constexpr int CONSTRAIN_WG = 8;       // 39 KB of LDS per workgroup at BART's depth, two workgroups per CU
 
 // the row's group (wave-uniform: scalar compares on kernel arguments)
@@ -656,7 +657,7 @@ __device__ __forceinline__ void row_range_and_class(const FmiDev &ix, const Cons
     single = -1;
     expand = false;
     if (!valid) {}
-    else if (a.stop_at_count > 0 && (int64_t)count <= a.stop_at_count) single = eos_id;
+    else if (a.grp_stop[grp] > 0 && (int64_t)count <= a.grp_stop[grp]) single = eos_id;
     else if (dead) single = a.pad_id;
     else { expand = true; if (hi > ix.n) hi = ix.n; }
 }
@@ -697,6 +698,94 @@ __global__ __launch_bounds__(256) void k_constrain_rows(FmiDev ix, ConstrainArgs
         flush_counters(a.probe_counter, ctr);
     }
 }
+
+// Rows-only call: ONE wave per row does the whole row -- chain, root split, then the sub-tree of every non-empty top digit in turn
+// (expand_subtree, the self-contained single-wave expansion) -- and there is no second launch.  For calls whose rows are narrow (long
+// prefixes: a handful of symbols below one or two top digits) that is one kernel of rows / 4 workgroups instead of two kernels and
+// thirteen waves per row; a wide row met here is still expanded correctly, digit after digit, only slowly: the host chooses the form by
+// prefix length (SEALFM_ROWS_ONLY_FROM).  Dynamic LDS: 4 x constrain_lds_slots(D, 1) slots (frontier, counters, leaf bitmap per wave).
+template <bool SB>
+__global__ __launch_bounds__(256) void k_constrain_rows_only(FmiDev ix, ConstrainArgs a)
+{
+    extern __shared__ uint4 s_dyn[];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t D = ix.dlevels;
+    const uint32_t sub_bits = FMI_DIGIT_BITS * (D - 1);
+    const uint32_t nsym = 1u << sub_bits;
+    const uint32_t nw = (nsym + 31) >> 5;
+    uint4 *s_node = s_dyn + (size_t)wave * constrain_lds_slots(D, 1);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_node + exp_slots((int)D - 1));
+    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_node + exp_slots((int)D - 1) + 2);
+    // housekeeping for the next call: this workgroup's share of the other bitmap buffer
+    if (a.clear) {
+        const uint64_t per = (a.clear_words + gridDim.x - 1) / gridDim.x;
+        const uint64_t w0 = (uint64_t)blockIdx.x * per;
+        for (uint64_t w = w0 + threadIdx.x; w < w0 + per && w < a.clear_words; w += 256) a.clear[w] = 0u;
+    }
+    const uint32_t r = blockIdx.x * 4 + wave;
+    if (r >= a.rows) return;
+    const bool counting = a.probe_counter != nullptr;
+    ExpCounters ctr{0, 0, 0, 0};
+    uint64_t lo, hi, probes = 0;
+    uint32_t model = 0;
+    int64_t single, eos_id;
+    bool expand;
+    row_range_and_class(ix, a, r, true, lane == 0, lo, hi, single, expand, eos_id, probes, model);
+    // the root node over all sixteen digits: lane (d, end) of the first 32 takes one single-digit rank (as k_constrain_rows)
+    const bool split = expand && hi > lo;
+    const uint32_t e = lane & 1, d = lane >> 1;
+    uint64_t q = 0;
+    if (split && lane < 32) q = wm_step(ix, 0, e ? hi : lo, d);
+    const uint64_t qo = (uint64_t)dpp_xor1((uint32_t)q) | ((uint64_t)dpp_xor1((uint32_t)(q >> 32)) << 32);
+    const uint64_t bal = __ballot(lane < 32 && e == 0 && qo > q);
+    uint32_t em = 0;
+#pragma unroll
+    for (uint32_t x = 0; x < 16; x++) em |= (uint32_t)((bal >> (2 * x)) & 1ull) << x;
+    // the special tokens of the row's class (pad / eos): the digit that owns each must be visited even if it has no child
+    const int64_t special[2] = {single, a.always_allow_eos ? eos_id : (int64_t)-1};
+    uint32_t need = em;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int64_t tok = special[i];
+        if (tok < 0 || (uint64_t)tok >= a.vocab) continue;
+        const int64_t sym = tok + a.shift;
+        if (sym >= 0 && (uint64_t)(sym >> sub_bits) < a.ndig0) need |= 1u << (uint32_t)(sym >> sub_bits);
+        else if (lane == 0) atomicOr(&a.bits[(uint64_t)r * a.words_per_row + ((uint64_t)tok >> 5)], 1u << (tok & 31));
+    }
+    EmitTarget tgt{};
+    tgt.bits = a.bits; tgt.words_per_row = a.words_per_row; tgt.shift = a.shift; tgt.vocab = a.vocab;
+    while (need) {
+        const uint32_t d1 = (uint32_t)__builtin_ctz(need);
+        need &= need - 1;
+        for (uint32_t w = lane; w < nw; w += 64) s_bits[w] = 0u;
+        wave_sync();
+        if ((em >> d1) & 1u) {
+            const uint64_t clo = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q, (int)(2 * d1)) |
+                                 ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q >> 32), (int)(2 * d1)) << 32);
+            const uint64_t chi = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q, (int)(2 * d1 + 1)) |
+                                 ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q >> 32), (int)(2 * d1 + 1)) << 32);
+            if (D == 1) { if (lane == 0 && d1 != 0) s_bits[0] |= 1u; }
+            else expand_subtree<EMIT_BITS, SB>(ix, s_node, s_cnt, reinterpret_cast<uint8_t *>(s_bits), r, 1, clo, chi, d1, EmitTarget{}, counting, ctr);
+            wave_sync();
+        }
+        if (lane == 0) {
+            if (single >= 0) set_special(ix, a, s_bits, r, d1, sub_bits, single);
+            if (a.always_allow_eos) set_special(ix, a, s_bits, r, d1, sub_bits, eos_id);
+        }
+        wave_sync();
+        flush_leaf_bits(tgt, r, s_bits, d1 << sub_bits, nsym);
+        wave_sync();
+    }
+    if (counting) {
+        if (lane == 0) {
+            ctr.probes += (uint32_t)probes + (split ? ((lo >> FMI_BLOCK_SHIFT) != (hi >> FMI_BLOCK_SHIFT) ? 2u : 1u) : 0u);
+            ctr.model += model + (split ? model_nodes(em, 0, FMI_DIGIT_BITS * D - ix.levels) : 0u);
+        }
+        flush_counters(a.probe_counter, ctr);
+    }
+}
+
 
 template <bool SB, int W>
 __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, ConstrainArgs a)
@@ -1589,6 +1678,7 @@ struct RowGroups {
     int64_t eos[MAX_ROW_GROUPS] = {0, 0, 0};
     const int64_t *force[MAX_ROW_GROUPS] = {nullptr, nullptr, nullptr};
     uint64_t n_force[MAX_ROW_GROUPS] = {0, 0, 0};
+    int64_t stop[MAX_ROW_GROUPS] = {-1, -1, -1};      // per-group stop_at_count; -1: the call's
     static RowGroups one(uint64_t rows, int64_t eos_id, const int64_t *force_from, uint64_t n_force)
     {
         RowGroups g; g.rows[0] = rows; g.eos[0] = eos_id; g.force[0] = force_from; g.n_force[0] = n_force; return g;
@@ -1614,17 +1704,18 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
         if (g >= rg.n) continue;
         if (rg.n_force[g] > MAX_FORCE) { fmi_set_error("force_decoding_from longer than %d", MAX_FORCE); return FMI_ERR_UNSUPPORTED; }
         a.grp_eos[g] = rg.eos[g];
+        a.grp_stop[g] = rg.stop[g] >= 0 ? rg.stop[g] : stop_at_count;
         a.grp_ff[g].n = (uint32_t)rg.n_force[g];
         for (uint64_t i = 0; i < rg.n_force[g]; i++) a.grp_ff[g].tok[i] = rg.force[g][i];
         first += rg.rows[g];
     }
     if (first != rows) { fmi_set_error("the row groups hold %llu rows, the call %llu", (unsigned long long)first, (unsigned long long)rows); return FMI_ERR_ARG; }
-    a.stop_at_count = stop_at_count; a.always_allow_eos = always_allow_eos; a.vocab = vocab; a.words_per_row = wpr;
+    a.always_allow_eos = always_allow_eos; a.vocab = vocab; a.words_per_row = wpr;
     a.probe_counter = h->probe_count_enabled ? h->d_probe_counter : nullptr;
     // waves per workgroup: CONSTRAIN_WG waves that share their leaf-level nodes when the whole sub-tree of an item fits
     // the deferred expansion (dlevels 2..4: every real vocabulary below 2^16 symbols), else self-contained waves
-    const char *wenv = getenv("SEALFM_CONSTRAIN_WAVES");       // "1": the self-contained waves (A/B measurements, tests of both)
-    const unsigned W = (!(wenv && atoi(wenv) == 1) && h->dlevels >= 2 && h->dlevels <= 4) ? (unsigned)CONSTRAIN_WG : 1u;
+    // (FmiOptions: the environment was read when the handle was created; "constrain_waves" 1 = the self-contained waves)
+    const unsigned W = (h->opt.constrain_waves != 1 && h->dlevels >= 2 && h->dlevels <= 4) ? (unsigned)CONSTRAIN_WG : 1u;
     if (W > 1) a.groups = (uint32_t)((rows + W - 1) / W);
     const unsigned grid = W > 1 ? a.groups * a.ndig0 : (unsigned)(((rows + 7) & ~7ull) * a.ndig0);
     a.tstamp = h->dbg_tstamp && h->dbg_tstamp_cap >= (uint64_t)grid * W * 8 ? h->dbg_tstamp : nullptr;
@@ -1664,15 +1755,27 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     // nothing from the extra launch: the host picks by prefix length (SEALFM_ROW_FIRST=0 / 1 forces either; same results).
     uint64_t longest = 0;
     for (uint32_t g = 0; g < rg.n; g++) longest = std::max<uint64_t>(longest, rg.n_force[g] + (cur_len - 1));
-    a.leave_early = getenv("SEALFM_LEAVE_EARLY") ? atoi(getenv("SEALFM_LEAVE_EARLY")) : 1;
-    const char *rfenv = getenv("SEALFM_ROW_FIRST");        // 0: always the single launch; 1: always row-first
+    a.leave_early = (int)h->opt.leave_early;
     // measured (profiles/r3_rowfirst_ab.txt): wins from 3-token prefixes on at 300 rows (29.6 -> 28.1, 26.3 -> 24.7, 18.9 -> 17.5 us at 3 / 4 / 6
     // tokens; 2 tokens 44.5 -> 45.3), from 2 tokens on at 600 rows (81 -> 79, 52 -> 45, 40 -> 33, 33 -> 21 us at 2 / 3 / 4 / 6); a call of
     // single-token prefixes loses 2.7 us to the extra launch (62.9 -> 65.6).  (A third form -- the rows append their non-empty items to
     // ONE list that a fixed grid walks -- measured slower everywhere, 22.1 vs 17.5 us on the narrowest call: 600 returning atomics on one
     // counter cost more than the empty waves they save.)
-    const uint64_t rf_from = getenv("SEALFM_ROW_FIRST_FROM") ? (uint64_t)atoll(getenv("SEALFM_ROW_FIRST_FROM")) : (rows >= 512 ? 2 : 3);
-    const bool row_first = W > 1 && (rfenv ? atoi(rfenv) != 0 : longest >= rf_from);
+    const uint64_t rf_from = h->opt.row_first_from >= 0 ? (uint64_t)h->opt.row_first_from : (rows >= 512 ? 2 : 3);
+    // Rows-only (k_constrain_rows_only): when every row's prefix is long the rows are narrow and one wave per row is the whole call
+    uint64_t shortest = ~0ull;
+    for (uint32_t g = 0; g < rg.n; g++) shortest = std::min<uint64_t>(shortest, rg.n_force[g] + (cur_len - 1));
+    const uint64_t ro_from = h->opt.rows_only_from >= 0 ? (uint64_t)h->opt.rows_only_from : ROWS_ONLY_FROM_DEFAULT;
+    if (W > 1 && ro_from > 0 && shortest >= ro_from && !a.tstamp) {
+        a.pre_rows = nullptr; a.pre_child = nullptr;
+        const size_t lds_ro = (size_t)4 * constrain_lds_slots(h->dlevels, 1) * 16;
+        void (*kro)(FmiDev, ConstrainArgs) = sb ? k_constrain_rows_only<true> : k_constrain_rows_only<false>;
+        hipLaunchKernelGGL(kro, dim3((unsigned)((rows + 3) / 4)), dim3(256), lds_ro, st, h->dev, a);
+        HIPCHK(hipGetLastError());
+        if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
+        return FMI_OK;
+    }
+    const bool row_first = W > 1 && (h->opt.row_first >= 0 ? h->opt.row_first != 0 : longest >= rf_from);
     if (row_first) {
         a.pre_rows = ws_pre_rows(h); a.pre_child = ws_pre_child(h);
         hipLaunchKernelGGL(k_constrain_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, h->dev, a);
@@ -1711,6 +1814,21 @@ extern "C" int fmi_dev_debug_timestamps(fmi_t *h, uint64_t *d_buf, uint64_t n_wo
 {
     if (!h) { fmi_set_error("null handle"); return FMI_ERR_ARG; }
     h->dbg_tstamp = d_buf; h->dbg_tstamp_cap = d_buf ? n_words : 0;
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_debug_marks(fmi_t *h, uint32_t *marks)
+{
+    if (!h) { fmi_set_error("null handle"); return FMI_ERR_ARG; }
+    h->dbg_marks = marks;
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_mark(void *stream, uint32_t *word, uint32_t value)
+{
+    if (!word) { fmi_set_error("null argument"); return FMI_ERR_ARG; }
+    hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, (hipStream_t)stream, word, value);
+    HIPCHK(hipGetLastError());
     return FMI_OK;
 }
 
@@ -1754,7 +1872,7 @@ extern "C" int fmi_dev_constrained_topk_step(fmi_t *h, void *stream, uint64_t ba
 {
     return fmi_dev_constrained_topk_groups(h, stream, 1, &batch, &eos_id, force_from, &n_force, beams, cur_len, d_input_ids, d_logits,
                                            d_beam_scores, vocab, shift, pad_id, stop_at_count, always_allow_eos, d_first_bits, d_scratch,
-                                           scratch_bytes, d_top_idx, d_top_con, d_top_unc, state_tag, d_parent_rows);
+                                           scratch_bytes, d_top_idx, d_top_con, d_top_unc, state_tag, d_parent_rows, nullptr);
 }
 
 extern "C" int fmi_dev_constrained_topk_groups(fmi_t *h, void *stream, uint64_t n_groups, const uint64_t *group_batch,
@@ -1763,7 +1881,7 @@ extern "C" int fmi_dev_constrained_topk_groups(fmi_t *h, void *stream, uint64_t 
                                                const float *d_beam_scores, uint64_t vocab, int64_t shift, int64_t pad_id,
                                                int64_t stop_at_count, int always_allow_eos, const uint32_t *d_first_bits,
                                                void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc,
-                                               uint64_t state_tag, const int64_t *d_parent_rows)
+                                               uint64_t state_tag, const int64_t *d_parent_rows, const int64_t *group_stop_at_count)
 {
     int rc = need_device(h); if (rc) return rc;
     if (n_groups < 1 || n_groups > MAX_ROW_GROUPS || !group_batch || !group_eos || !group_n_force) {
@@ -1775,6 +1893,7 @@ extern "C" int fmi_dev_constrained_topk_groups(fmi_t *h, void *stream, uint64_t 
     for (uint64_t g = 0; g < n_groups; g++) {
         batch += group_batch[g];
         rg.rows[g] = group_batch[g] * beams; rg.eos[g] = group_eos[g]; rg.n_force[g] = group_n_force[g];
+        if (group_stop_at_count) rg.stop[g] = group_stop_at_count[g] < 0 ? 0 : group_stop_at_count[g];
         // one group: the caller's array as it is (fmi_dev_constrained_topk_step); several: MAX_FORCE slots per group
         rg.force[g] = group_force ? group_force + (n_groups == 1 ? 0 : g * MAX_FORCE) : nullptr;
         if (group_n_force[g] && !group_force) { fmi_set_error("group %llu: n_force without tokens", (unsigned long long)g); return FMI_ERR_ARG; }
@@ -1803,10 +1922,9 @@ extern "C" int fmi_dev_constrained_topk_groups(fmi_t *h, void *stream, uint64_t 
                                stop_at_count, always_allow_eos, state_tag, d_parent_rows, &bits);
         if (rc) return rc;
     }
-    const char *e_narrow = getenv("SEALFM_TOPK_NARROW");      // tests: 0 sends every row down the wide-row path
-    const uint32_t narrow_max = e_narrow ? std::min<uint32_t>((uint32_t)atoi(e_narrow), TOPK_NARROW) : TOPK_NARROW;
-    const char *e_legacy = getenv("SEALFM_TOPK_LEGACY");      // tests: wide rows skip the thread-maxima bound and radix-select
-    const uint32_t pick_flags = (e_legacy && atoi(e_legacy)) ? (uint32_t)PICK_NO_PREFILTER : 0u;
+    // (FmiOptions) tests: topk_narrow 0 sends every row down the wide-row path; topk_legacy: wide rows skip the thread-maxima bound
+    const uint32_t narrow_max = h->opt.topk_narrow >= 0 ? std::min<uint32_t>((uint32_t)h->opt.topk_narrow, TOPK_NARROW) : TOPK_NARROW;
+    const uint32_t pick_flags = h->opt.topk_legacy ? (uint32_t)PICK_NO_PREFILTER : 0u;
     hipLaunchKernelGGL(k_row_pick, dim3((unsigned)rows), dim3(PICK_BLOCK), (wpr + 1) * 4, st, d_logits, bits, wpr, broadcast, vocab,
                        (uint32_t)want, row_max, row_lsum, row_tok, row_lp, row_cnt, narrow_max, pick_flags);
     hipLaunchKernelGGL(k_query_merge, dim3((unsigned)batch), dim3(MERGE_BLOCK), 0, st, d_logits, bits, wpr, broadcast, vocab, (uint32_t)beams,

@@ -301,9 +301,13 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
         if len(joint_kinds) < 2:
             joint_kinds = []
     if joint_kinds:
-        job_of = {"body": dict(max_length=s.length, eos_token_id=None, force_decoding_from=None),
-                  "title": dict(max_length=TITLE_MAX_LENGTH, eos_token_id=s.title_eos_token_id, force_decoding_from=[s.title_bos_token_id]),
-                  "code": dict(max_length=TITLE_MAX_LENGTH, eos_token_id=s.code_eos_token_id, force_decoding_from=[s.code_bos_token_id])}
+        # stop_at_count is the body decode's alone (reference retrieval.py:70-83 passes it; the title / code decodes, :162-176 and
+        # :212-236, run with the default 0)
+        job_of = {"body": dict(max_length=s.length, eos_token_id=None, force_decoding_from=None, stop_at_count=s.stop_at_count),
+                  "title": dict(max_length=TITLE_MAX_LENGTH, eos_token_id=s.title_eos_token_id, force_decoding_from=[s.title_bos_token_id],
+                                stop_at_count=0),
+                  "code": dict(max_length=TITLE_MAX_LENGTH, eos_token_id=s.code_eos_token_id, force_decoding_from=[s.code_bos_token_id],
+                               stop_at_count=0)}
         marked_in = {k: marked(k) for k in joint_kinds}
         # the bare queries -- what the rescoring of the body keys encodes (retrieval.py:93-100) -- ride along in the same encoder pass
         ride = s.decode_body and s.rescore and s.use_markers

@@ -207,3 +207,21 @@ class Word:
 def split_words(query):
     """stands in for spaCy's English tokenizer (absent offline): whitespace words as objects with .text"""
     return [Word(w) for w in query.split()]
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def kernel_options(index, **opts):
+    """forces launch-shape switches of the constraint / top-2K calls on ``index``'s handle (include/sealfm.h
+    ``fmi_dev_set_option``: the environment is only read when a handle is created) and restores the built-in choices"""
+    from seal_amd._lib import check, lib
+    handle = getattr(index, "handle", index)
+    for k, v in opts.items():
+        check(lib().fmi_dev_set_option(handle, k.encode(), int(v)))
+    try:
+        yield
+    finally:
+        for k in opts:
+            check(lib().fmi_dev_set_option(handle, k.encode(), -1))

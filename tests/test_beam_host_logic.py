@@ -189,30 +189,27 @@ def test_lockstep_groups_record_what_separate_loops_record(lengths):
         assert torch.equal(gf[0], wf[0]) and torch.allclose(gf[1], wf[1], atol=1e-5)
 
 
-def test_tuned_gemm_file_and_modes(tmp_path, monkeypatch):
-    """seal_amd/tuned_gemm.py: no GPU -> off; the shipped picks carry the library versions they were made with and only the
-    decode-step row counts of the default searcher; the tune-mode writer emits TunableOp's own file format"""
-    from seal_amd import tuned_gemm
-    monkeypatch.setattr(tuned_gemm, "_mode", None)
-    assert tuned_gemm.setup() == "off"
-    with tuned_gemm.tuning():
-        pass
-    lines = open(tuned_gemm.SHIPPED).read().splitlines()
-    head = [ln.split(",") for ln in lines if ln.startswith("Validator,")]
-    assert {h[1] for h in head} >= {"PT_VERSION", "HIPBLASLT_VERSION", "GCN_ARCH_NAME"} and any("gfx950" in h[2] for h in head)
-    picks = [ln.split(",") for ln in lines if not ln.startswith("Validator,")]
-    assert len(picks) == 10 and all(len(p) == 4 and p[1].split("_")[2] in ("600", "300") for p in picks)
+def test_joint_generate_gives_every_job_its_own_stop_at_count(monkeypatch):
+    """``fm_index_generate_joint``: a job's ``stop_at_count`` wins over the call's (the searcher passes the body decode's
+    value to the body job and 0 to the title / code jobs, as the reference's separate ``fm_index_generate`` calls do,
+    retrieval.py:70-83 vs 162-176)"""
+    from seal_amd import beam_search as bs
+    vocab, K = 120, 2
+    m = tiny_bart(vocab)
+    seen = []
 
-    class TN:
-        def get_validators(self):
-            return tuple((h[1], h[2]) for h in head)
-
-        def get_results(self):
-            return tuple((p[0], p[1], p[2], float(p[3])) for p in picks)
-    out = tmp_path / "picks.csv"
-    tuned_gemm._write(TN(), str(out))
-    again = out.read_text().splitlines()
-    assert [ln.split(",")[:3] for ln in again] == [ln.split(",")[:3] for ln in lines]
+    def fake_groups(decoder, specs, num_beams, start, device=None, fused=True):
+        seen.extend((sp["processor"].stop_at_count, sp["eos_token_id"]) for sp in specs)
+        raise StopIteration
+    monkeypatch.setattr(bs, "constrained_beam_search_groups", fake_groups)
+    orc = OracleFMIndex()
+    orc.initialize(make_docs(3, 40, vocab, title_sep=7))
+    ids = torch.randint(4, vocab, (4, 6))
+    jobs = [dict(batch=2, max_length=5, eos_token_id=None, force_decoding_from=None, stop_at_count=3),
+            dict(batch=2, max_length=8, eos_token_id=7, force_decoding_from=[2], stop_at_count=0)]
+    with pytest.raises(StopIteration):
+        bs.fm_index_generate_joint(m, orc, ids, torch.ones_like(ids), jobs, num_beams=K, stop_at_count=9)
+    assert seen == [(3, m.config.eos_token_id), (0, 7)]
 
 
 def test_beam_loop_promises_identical_beams_only_for_the_first_step_of_a_decoder_that_asks():

@@ -199,7 +199,7 @@ def test_fused_constrained_topk_matches_unfused_step(kw, narrow, monkeypatch):
     monkeypatch.setenv("SEALFM_TOPK_NARROW", narrow)
     from seal_amd import FMIndex
     from seal_amd.beam_search import IndexBasedLogitsProcessor, _inf_nan_remove
-    from tests.helpers import make_docs
+    from tests.helpers import kernel_options, make_docs
     vocab, B, K = 120, 5, 4
     dev = torch.device("cuda:0")
     docs = make_docs(3, 150, vocab - 8, title_sep=7)
@@ -299,7 +299,7 @@ def test_incremental_constraint_state_equals_full_prefix_search(kw):
     loops must produce identical histories, bit for bit."""
     from seal_amd import FMIndex
     from seal_amd.beam_search import IndexBasedLogitsProcessor, constrained_beam_search
-    from tests.helpers import make_docs
+    from tests.helpers import kernel_options, make_docs
     vocab, B, K, T = 120, 6, 5, 9
     dev = torch.device("cuda:0")
     docs = make_docs(5, 200, vocab - 8, title_sep=7)
@@ -342,7 +342,7 @@ def test_topk_selection_paths_agree_on_ties(monkeypatch):
     on heavily tied logits both must return the same picks in the same order (ties go to the lower token id)."""
     from seal_amd import FMIndex
     from seal_amd.beam_search import IndexBasedLogitsProcessor
-    from tests.helpers import make_docs
+    from tests.helpers import kernel_options, make_docs
     vocab, B, K = 300, 4, 6
     dev = torch.device("cuda:0")
     docs = make_docs(11, 400, vocab - 8, title_sep=7)
@@ -362,9 +362,9 @@ def test_topk_selection_paths_agree_on_ties(monkeypatch):
         logits = torch.randint(-2, 3, (B * K, vocab), generator=g).float().to(dev)     # five distinct values: ties everywhere
         beam_scores = torch.randint(-2, 2, (B * K,), generator=g).float().to(dev)
         got = []
-        for narrow in ("1024", "0"):
-            monkeypatch.setenv("SEALFM_TOPK_NARROW", narrow)
-            flat, unc = proc.fused_topk(ids, logits, beam_scores, B, K)
+        for narrow in (1024, 0):
+            with kernel_options(ix, topk_narrow=narrow):
+                flat, unc = proc.fused_topk(ids, logits, beam_scores, B, K)
             got.append((flat.tolist(), unc.tolist()))
         assert got[0] == got[1], cur_len
 
@@ -381,7 +381,7 @@ def test_row_pick_paths_agree_at_bart_vocabulary_and_match_torch(kind, monkeypat
     from seal_amd import FMIndex
     from seal_amd._lib import check, lib
     from seal_amd.beam_search import _inf_nan_remove
-    from tests.helpers import make_docs
+    from tests.helpers import kernel_options, make_docs
     V, B, K = 50265, 3, 5
     want, rows = 2 * K, B * K
     dev = torch.device("cuda:0")
@@ -413,18 +413,15 @@ def test_row_pick_paths_agree_at_bart_vocabulary_and_match_torch(kind, monkeypat
         logits = logits.to(dev).contiguous()
         beam_scores = (torch.randn(rows, generator=g) * 2).to(dev)
         got = {}
-        for mode, env in (("select", {}), ("wide-path", {"SEALFM_TOPK_NARROW": "0"}), ("radix", {"SEALFM_TOPK_LEGACY": "1"}),
-                          ("radix-everywhere", {"SEALFM_TOPK_LEGACY": "1", "SEALFM_TOPK_NARROW": "0"})):
-            for k in ("SEALFM_TOPK_NARROW", "SEALFM_TOPK_LEGACY"):
-                monkeypatch.delenv(k, raising=False)
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
+        for mode, opts in (("select", {}), ("wide-path", dict(topk_narrow=0)), ("radix", dict(topk_legacy=1)),
+                           ("radix-everywhere", dict(topk_legacy=1, topk_narrow=0))):
             top_idx = torch.empty(B, want, dtype=torch.int64, device=dev)
             top_con = torch.empty(B, want, dtype=torch.float32, device=dev)
             top_unc = torch.empty(B, want, dtype=torch.float32, device=dev)
-            check(lib().fmi_dev_constrained_topk_step(ix.handle, st, B, K, 1, ids.data_ptr(), logits.data_ptr(), beam_scores.data_ptr(), V, 0,
-                                                      1, 2, ff, 0, 0, 0, bits.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,
-                                                      top_idx.data_ptr(), top_con.data_ptr(), top_unc.data_ptr(), 0, None))
+            with kernel_options(ix, **opts):
+                check(lib().fmi_dev_constrained_topk_step(ix.handle, st, B, K, 1, ids.data_ptr(), logits.data_ptr(), beam_scores.data_ptr(), V, 0,
+                                                          1, 2, ff, 0, 0, 0, bits.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,
+                                                          top_idx.data_ptr(), top_con.data_ptr(), top_unc.data_ptr(), 0, None))
             torch.cuda.synchronize()
             got[mode] = (top_idx.cpu(), top_con.cpu(), top_unc.cpu())
         for mode in ("wide-path", "radix", "radix-everywhere"):
@@ -532,19 +529,23 @@ def test_tree_self_attention_matches_the_row_kernel_and_torch(T):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_groups", [2, 3])
-def test_lockstep_groups_on_the_gpu_equal_separate_loops_bit_for_bit(n_groups):
+@pytest.mark.parametrize("n_groups,stops", [(2, (0, 0, 0)), (3, (0, 0, 0)), (2, (3, 0, 0)), (3, (2, 0, 4))],
+                         ids=["2", "3", "2-body-stop_at_count", "3-mixed-stop_at_count"])
+def test_lockstep_groups_on_the_gpu_equal_separate_loops_bit_for_bit(n_groups, stops):
     """``constrained_beam_search_groups`` over the HIP constraint (ONE ``fmi_dev_constrained_topk_groups`` call per step for
     the stacked rows of 2 / 3 decodes with their own eos / forced prefix / length) on deterministic per-row logits: every
     group's history must equal its own separate loop's exactly -- per-row masks, per-query picks, the incremental prefix
-    ranges across the step where the shorter decodes leave the loop (parents then name rows of the wider previous call)."""
+    ranges across the step where the shorter decodes leave the loop (parents then name rows of the wider previous call).
+    ``stops``: every decode keeps its OWN stop_at_count in the joint call (the reference gives it to the body decode only,
+    retrieval.py:70-83 vs 162-176; round-3 advisor finding: the joint path applied the body's to the title rows as well)."""
     from seal_amd import FMIndex
     from seal_amd.beam_search import IndexBasedLogitsProcessor, constrained_beam_search, constrained_beam_search_groups
-    from tests.helpers import make_docs
+    from tests.helpers import kernel_options, make_docs
     vocab, K = 120, 5
     dev = torch.device("cuda:0")
     docs = make_docs(5, 200, vocab - 8, title_sep=7)
-    cfgs = [dict(batch=4, T=6, eos=2, ff=None), dict(batch=3, T=9, eos=7, ff=[2]), dict(batch=2, T=11, eos=9, ff=[7])][:n_groups]
+    cfgs = [dict(batch=4, T=6, eos=2, ff=None, stop=stops[0]), dict(batch=3, T=9, eos=7, ff=[2], stop=stops[1]),
+            dict(batch=2, T=11, eos=9, ff=[7], stop=stops[2])][:n_groups]
 
     class RandomDecoder:
         """deterministic logits per (group, step, row)"""
@@ -570,7 +571,7 @@ def test_lockstep_groups_on_the_gpu_equal_separate_loops_bit_for_bit(n_groups):
             assert nq == 0
 
     def proc(ix, c):
-        return IndexBasedLogitsProcessor(ix, K, pad_token_id=1, eos_token_id=c["eos"], force_decoding_from=c["ff"])
+        return IndexBasedLogitsProcessor(ix, K, pad_token_id=1, eos_token_id=c["eos"], force_decoding_from=c["ff"], stop_at_count=c["stop"])
     want = []
     for gi, c in enumerate(cfgs):
         ix = FMIndex()

@@ -146,15 +146,24 @@ def test_save_load_round_trip_on_gpu(pair, tmp_path):
     assert ix2.get_doc(1) == docs[1]
 
 
-@pytest.mark.parametrize("waves", ["8", "1"], ids=["shared-leaf-phase", "self-contained-waves"])
-def test_logits_processor_matches_reference_semantics(pair, waves, monkeypatch):
-    """both launch shapes of k_constrain: workgroups of 8 waves that serve their leaf-level nodes together (the
-    default up to 4 digit levels) and one self-contained wave per (row, top digit)"""
+@pytest.mark.parametrize("form", [dict(constrain_waves=8), dict(constrain_waves=1), dict(row_first=0), dict(row_first=1), dict(rows_only_from=1),
+                                  dict(leave_early=0)],
+                         ids=["shared-leaf-phase", "self-contained-waves", "single-launch", "row-first", "rows-only", "empty-waves-stay"])
+def test_logits_processor_matches_reference_semantics(pair, form):
+    """every launch form of a constraint call gives the reference's masks: workgroups of 8 waves that serve their leaf-level
+    nodes together (the default up to 4 digit levels) / one self-contained wave per (row, top digit); the single launch / the
+    row-first pair (k_constrain_rows, then k_constrain) / ONE wave per row for the whole row (k_constrain_rows_only) whatever the
+    prefix length; the waves of empty items leaving early or staying"""
+    from tests.helpers import kernel_options
+    ix, orc, docs, vocab = pair
+    with kernel_options(ix, **form):
+        _logits_processor_cases(ix, orc, docs, vocab)
+
+
+def _logits_processor_cases(ix, orc, docs, vocab):
     import torch
     from oracle.beam_oracle import oracle_logits_mask
     from seal_amd.beam_search import IndexBasedLogitsProcessor
-    monkeypatch.setenv("SEALFM_CONSTRAIN_WAVES", waves)
-    ix, orc, docs, vocab = pair
     rng = random.Random(4)
     V = vocab + 7
     beams = 3

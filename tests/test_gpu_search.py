@@ -327,11 +327,13 @@ def test_searcher_document_ids_on_a_corpus_where_ties_are_rare(monkeypatch):
     assert single >= 0.9 * total, (single, total)
 
 
-@pytest.mark.parametrize("decode_code", [False, True])
-def test_joint_decode_of_a_batch_returns_what_separate_decodes_return(decode_code, monkeypatch):
+@pytest.mark.parametrize("decode_code,stop_at_count", [(False, 0), (True, 0), (False, 4), (True, 3)],
+                         ids=["body+title", "body+title+code", "body+title-stop_at_count", "body+title+code-stop_at_count"])
+def test_joint_decode_of_a_batch_returns_what_separate_decodes_return(decode_code, stop_at_count, monkeypatch):
     """``joint_decode`` (default): the body / title (/ code) decodes of a batch as ONE loop of stacked rows; off: one
     ``fm_index_generate`` after the other as the reference does.  Same documents (ties at 1e-5 relative aside), scores
-    within 1e-4 relative: the GEMMs run at another height, nothing else differs."""
+    within 1e-4 relative: the GEMMs run at another height, nothing else differs.  With ``stop_at_count`` > 0 the value is the
+    body decode's alone on both paths (reference retrieval.py:70-83; titles / codes run with 0)."""
     from seal_amd import FMIndex
     from tests.helpers import make_docs, tiny_bart
     vocab = 120
@@ -346,7 +348,7 @@ def test_joint_decode_of_a_batch_returns_what_separate_decodes_return(decode_cod
     out = {}
     for joint in (True, False):
         s = _tiny_gpu_searcher(ix, model, vocab, joint_decode=joint, add_query_to_keys=True, decode_code=decode_code, partial_code=decode_code,
-                               overlap=False)
+                               overlap=False, stop_at_count=stop_at_count)
         s.marker_token_ids["code"] = [vocab - 2, vocab - 7]
         calls = []
         from seal_amd import beam_search
