@@ -71,6 +71,11 @@ int sealnn_cross_attn_runs_bf16(void *stream, const void *q, const void *ck, con
  *   x [rows, K] fp32 -> out [rows, 3K] fp16 = [hi | hi | lo'],  hi = fp16(x), lo' = fp16((x - hi) * 2^11);  K % 4 == 0
  *   *d_flag (may be NULL) += the number of 4-element groups holding a finite |x| > 65504 (not representable: the caller must check) */
 int sealnn_split_planes(void *stream, const float *x, uint32_t rows, uint32_t K, void *out, uint32_t *d_flag);
+/* the same planes written by the kernel that PRODUCES the activation (no separate pass): LayerNorm(x + y) as fp32 `out` (the residual
+ * stream) and as `planes` [rows, 3d] (the next projection's operand);  gelu(x) (erf form, torch's arithmetic) as planes only (fc2's operand) */
+int sealnn_add_layernorm_planes(void *stream, const float *x, const float *y, const float *gamma, const float *beta, uint32_t rows,
+                                uint32_t d, float eps, float *out, void *planes, uint32_t *d_flag);
+int sealnn_gelu_planes(void *stream, const float *x, uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag);
 
 #ifdef __cplusplus
 }

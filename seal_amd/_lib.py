@@ -114,6 +114,8 @@ NN_SIGNATURES = {
     "sealnn_cross_attn_rows_bf16": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp]),
     "sealnn_cross_attn_runs_bf16": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _vp]),
     "sealnn_split_planes": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    "sealnn_add_layernorm_planes": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp]),
+    "sealnn_gelu_planes": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
 }
 
 _lib = None

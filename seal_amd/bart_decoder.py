@@ -147,6 +147,40 @@ class BartStepDecoder:
     def _mod(self, x: torch.Tensor, m) -> torch.Tensor:
         return self._lin(x, m.weight, m.bias)
 
+    # -- split GEMM with the operand planes written by the kernels that produce the activations (split_gemm.FUSED) --
+    def _planes_on(self, x: torch.Tensor) -> bool:
+        from . import split_gemm
+        if self.split_gemm is None:
+            BartStepDecoder.split_gemm = split_gemm.SplitLinears() if split_gemm.ENABLED else False
+        return bool(self.split_gemm) and split_gemm.FUSED and x.is_cuda and x.dtype == torch.float32
+
+    def _lin_p(self, x: torch.Tensor, xp, w: torch.Tensor, b) -> torch.Tensor:
+        """``F.linear(x, w, b)`` where ``xp`` (or None) holds x's split planes already"""
+        if xp is not None and self.split_gemm and self.split_gemm.wants(w, x.shape[0]):
+            return self.split_gemm.from_planes(xp, w, b)
+        return self._lin(x, w, b)
+
+    def _planes_of(self, x: torch.Tensor) -> torch.Tensor:
+        from . import split_gemm
+        from ._lib import check, lib
+        p = torch.empty(x.shape[0], 3 * x.shape[1], dtype=torch.float16, device=x.device)
+        check(lib().sealnn_split_planes(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.shape[0], x.shape[1], p.data_ptr(),
+                                        split_gemm._flag(x.device).data_ptr()))
+        return p
+
+    def _ffn(self, x: torch.Tensor, xp, L) -> torch.Tensor:
+        """fc2(gelu(fc1(x))): with planes, gelu's output exists as fc2's operand only"""
+        h = self._lin_p(x, xp, L["fc1"].weight, L["fc1"].bias)
+        w2 = L["fc2"].weight
+        if xp is not None and self.split_gemm.wants(w2, x.shape[0]) and getattr(L["act"], "__class__", type(None)).__name__ in ("GELUActivation", "GELU"):
+            from . import split_gemm
+            from ._lib import check, lib
+            hp = torch.empty(h.shape[0], 3 * h.shape[1], dtype=torch.float16, device=h.device)
+            check(lib().sealnn_gelu_planes(torch.cuda.current_stream(h.device).cuda_stream, h.data_ptr(), h.shape[0], h.shape[1], hp.data_ptr(),
+                                           split_gemm._flag(h.device).data_ptr()))
+            return self.split_gemm.from_planes(hp, w2, L["fc2"].bias)
+        return self._mod(L["act"](h), L["fc2"])
+
     def clone_for_pipeline(self) -> "BartStepDecoder":
         """a decoder over the SAME weights with its own static buffers / captured graphs / decode position: one per
         concurrent query-batch pipeline (the buffers of a shape are reused by every decode of that shape, so two
@@ -303,24 +337,37 @@ class BartStepDecoder:
             row_batch = qidx.to(torch.int32).contiguous()
             A = anc32.shape[1]
 
+            planes = self._planes_on(x)
+
             def add_ln(res, y, ln):
                 out = torch.empty_like(res)
+                if planes:
+                    from . import split_gemm
+                    from ._lib import lib
+                    p = torch.empty(N, 3 * self.d, dtype=torch.float16, device=dev)
+                    check(lib().sealnn_add_layernorm_planes(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                                            N, self.d, float(ln.eps), out.data_ptr(), p.data_ptr(),
+                                                            split_gemm._flag(dev).data_ptr()))
+                    return out, p
                 check(L_.add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
                                        N, self.d, float(ln.eps), out.data_ptr()))
-                return out
+                return out, None
+            xp = self._planes_of(x) if planes else None
             for li, L in enumerate(self.layers):
-                qkv = self._lin(x, L["qkv_w"], L["qkv_b"])
+                qkv = self._lin_p(x, xp, L["qkv_w"], L["qkv_b"])
                 a = torch.empty(N, self.d, dtype=x.dtype, device=dev)
                 check(L_.tree_self_attn(stream, qkv.data_ptr(), anc32.data_ptr(), N, A, self.h, float(self.scale), a.data_ptr()))
-                x = add_ln(x, self._mod(a, L["so"]), L["ln1"])
-                q = self._mod(x, L["cq"])
+                x, xp = add_ln(x, self._mod(a, L["so"]), L["ln1"])
+                q = self._lin_p(x, xp, L["cq"].weight, L["cq"].bias)
                 c = torch.empty(N, self.d, dtype=x.dtype, device=dev)
                 ck, cv = cross[li]
                 check(L_.cross_attn_rows(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
                                          N, self.h, S, float(self.scale), c.data_ptr()))
-                x = add_ln(x, self._mod(c, L["co"]), L["ln2"])
-                x = add_ln(x, self._mod(L["act"](self._mod(x, L["fc1"])), L["fc2"]), L["ln3"])
-            return x if hidden_only else self.lm_head(x)
+                x, xp = add_ln(x, self._mod(c, L["co"]), L["ln2"])
+                x, xp = add_ln(x, self._ffn(x, xp, L), L["ln3"])
+            if hidden_only:
+                return x            # (the caller projects slices of x: lm_head -> _lin -> the split kernel per slice)
+            return self._lin_p(x, xp, self.lm_w, self.lm_b.view(-1))
         # plain torch ops: the ancestors' keys / values gathered per node, the encoder's per query
         B, S, _ = enc_hidden.shape
         H, dh = self.h, self.dh
@@ -438,30 +485,41 @@ class BartStepDecoder:
                            "torch-op path: the fused step kernels need fp32 or bf16, head_dim 64, <= 17 decoder positions and <= 64 encoder tokens",
                            B, K, S_pad, T, str(x.dtype).replace("torch.", ""), dh)
         if fused:
-            from ._lib import check
+            from ._lib import check, lib
             L_ = self._nn(x.dtype)
             stream = torch.cuda.current_stream(x.device).cuda_stream
             cbias = st.cbias.view(B, S_pad)
 
+            planes = self._planes_on(x)
+
             def add_ln(res, y, ln):
+                """LayerNorm(res + y) -> (fp32, its split planes or None)"""
                 out = torch.empty_like(res)
+                if planes:
+                    from . import split_gemm
+                    p = torch.empty(R, 3 * self.d, dtype=torch.float16, device=res.device)
+                    check(lib().sealnn_add_layernorm_planes(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                                            R, self.d, float(ln.eps), out.data_ptr(), p.data_ptr(),
+                                                            split_gemm._flag(res.device).data_ptr()))
+                    return out, p
                 check(L_.add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
                                        R, self.d, float(ln.eps), out.data_ptr()))
-                return out
+                return out, None
+            xp = self._planes_of(x) if planes else None
             for li, L in enumerate(self.layers):
-                qkv = self._lin(x, L["qkv_w"], L["qkv_b"])
+                qkv = self._lin_p(x, xp, L["qkv_w"], L["qkv_b"])
                 a = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
                 check(L_.self_attn_step(stream, qkv.data_ptr(), st.kv[li, 0].data_ptr(), st.kv[li, 1].data_ptr(),
                                         st.t.data_ptr(), R, H, T, float(self.scale), a.data_ptr(), st.anc.data_ptr()))
-                x = add_ln(x, self._mod(a, L["so"]), L["ln1"])
-                q = self._mod(x, L["cq"])
+                x, xp = add_ln(x, self._mod(a, L["so"]), L["ln1"])
+                q = self._lin_p(x, xp, L["cq"].weight, L["cq"].bias)
                 c = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
                 check(L_.cross_attn_step(stream, q.data_ptr(), st.ck[li].data_ptr(), st.cv[li].data_ptr(), cbias.data_ptr(),
                                          B, K, H, S_pad, float(self.scale), c.data_ptr()))
-                x = add_ln(x, self._mod(c, L["co"]), L["ln2"])
-                x = add_ln(x, self._mod(L["act"](self._mod(x, L["fc1"])), L["fc2"]), L["ln3"])
+                x, xp = add_ln(x, self._mod(c, L["co"]), L["ln2"])
+                x, xp = add_ln(x, self._ffn(x, xp, L), L["ln3"])
             st.t.add_(1)
-            return self._lin(x, self.lm_w, self.lm_b.view(-1)).float()
+            return self._lin_p(x, xp, self.lm_w, self.lm_b.view(-1)).float()
         future = st.pos_idx > st.t                                   # cache slots not written yet
         for li, L in enumerate(self.layers):
             qkv = F.linear(x, L["qkv_w"], L["qkv_b"]).view(R, 3, H, dh)

@@ -35,6 +35,27 @@ template <> __device__ __forceinline__ void st4<bf16>(bf16 *row, uint32_t i, flo
     o[0] = __float2bfloat16(v.x); o[1] = __float2bfloat16(v.y); o[2] = __float2bfloat16(v.z); o[3] = __float2bfloat16(v.w);
 }
 
+// the split-GEMM operand planes of four consecutive elements of a row ([hi | hi | lo * 2^11] in fp16, row length d; see k_split_planes):
+// returns whether one of them is finite and beyond fp16's range
+static __device__ __forceinline__ bool store_planes4(__half *prow, uint32_t d, uint32_t i, float4 v)
+{
+    const float in[4] = {v.x, v.y, v.z, v.w};
+    __half hi[4], lo[4];
+    bool over = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float a = fabsf(in[j]);
+        over |= a > 65504.f && a < __builtin_huge_valf();
+        hi[j] = __float2half_rn(in[j]);
+        lo[j] = __float2half_rn((in[j] - __half2float(hi[j])) * 2048.f);
+    }
+    __half *o = prow + 4 * (uint64_t)i;
+    *(uint2 *)o = *(const uint2 *)hi;
+    *(uint2 *)(o + d) = *(const uint2 *)hi;
+    *(uint2 *)(o + 2 * (uint64_t)d) = *(const uint2 *)lo;
+    return over;
+}
+
 static __device__ __forceinline__ float wave_sum(float v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -282,7 +303,7 @@ __global__ __launch_bounds__(512) void k_cross_attn_runs(const T_ *q, const T_ *
 // one wavefront per row, d <= 4096 (16 float4 per lane)
 template <typename T_>
 __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y, const T_ *gamma, const T_ *beta,
-                                                       uint32_t rows, uint32_t d, float eps, T_ *out)
+                                                       uint32_t rows, uint32_t d, float eps, T_ *out, __half *planes, uint32_t *flag)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -312,15 +333,34 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y,
     }
     const float rstd = rsqrtf(wave_sum(var) / (float)d + eps);
     T_ *orow = out + (uint64_t)row * d;
+    __half *prow = planes ? planes + (uint64_t)row * 3 * d : nullptr;      // (fp32 only) the same values as the next GEMM's split operand
+    bool over = false;
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) {
         const uint32_t i = lane + 64 * j;
         if (i < n4) {
             const float4 g = ld4(gamma, i), bb = ld4(beta, i);
-            st4(orow, i, make_float4((v[j].x - mean) * rstd * g.x + bb.x, (v[j].y - mean) * rstd * g.y + bb.y,
-                                     (v[j].z - mean) * rstd * g.z + bb.z, (v[j].w - mean) * rstd * g.w + bb.w));
+            const float4 r = make_float4((v[j].x - mean) * rstd * g.x + bb.x, (v[j].y - mean) * rstd * g.y + bb.y,
+                                         (v[j].z - mean) * rstd * g.z + bb.z, (v[j].w - mean) * rstd * g.w + bb.w);
+            st4(orow, i, r);
+            if (prow) over |= store_planes4(prow, d, i, r);
         }
     }
+    if (over && flag) atomicAdd(flag, 1u);
+}
+
+// fc2's operand: planes of gelu(x) (the erf form, the arithmetic of torch's GeluCUDAKernelImpl: 0.5 * x * (1 + erf(x * M_SQRT1_2)))
+__global__ __launch_bounds__(256) void k_gelu_planes(const float *x, uint32_t rows, uint32_t d, __half *planes, uint32_t *flag)
+{
+    const uint32_t per_row = d / 4;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)rows * per_row) return;
+    const uint32_t r = (uint32_t)(i / per_row), c = (uint32_t)(i % per_row);
+    const float4 v = reinterpret_cast<const float4 *>(x + (uint64_t)r * d)[c];
+    const float kAlpha = 0.70710678118654752440f;
+    const float4 g = make_float4(0.5f * v.x * (1.f + erff(v.x * kAlpha)), 0.5f * v.y * (1.f + erff(v.y * kAlpha)),
+                                 0.5f * v.z * (1.f + erff(v.z * kAlpha)), 0.5f * v.w * (1.f + erff(v.w * kAlpha)));
+    if (store_planes4(planes + (uint64_t)r * 3 * d, d, c, g) && flag) atomicAdd(flag, 1u);
 }
 
 #define NNCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { fmi_set_error("sealnn launch failed: %s", hipGetErrorString(e_)); return FMI_ERR_HIP; } } while (0)
@@ -353,11 +393,11 @@ static int cross_attn_step(void *stream, const void *q, const void *ck, const vo
 
 template <typename T_>
 static int add_layernorm(void *stream, const void *x, const void *y, const void *gamma, const void *beta, uint32_t rows,
-                         uint32_t d, float eps, void *out)
+                         uint32_t d, float eps, void *out, void *planes = nullptr, uint32_t *flag = nullptr)
 {
     if (d % 4 || d > 4096) { fmi_set_error("sealnn_add_layernorm: d=%u unsupported", d); return FMI_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_add_layernorm<T_>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const T_ *)x, (const T_ *)y,
-                       (const T_ *)gamma, (const T_ *)beta, rows, d, eps, (T_ *)out);
+                       (const T_ *)gamma, (const T_ *)beta, rows, d, eps, (T_ *)out, (__half *)planes, flag);
     NNCHK();
     return FMI_OK;
 }
@@ -467,6 +507,21 @@ extern "C" int sealnn_split_planes(void *stream, const float *x, uint32_t rows, 
 extern "C" int sealnn_add_layernorm(void *stream, const float *x, const float *y, const float *gamma, const float *beta, uint32_t rows,
                                     uint32_t d, float eps, float *out)
 { return add_layernorm<float>(stream, x, y, gamma, beta, rows, d, eps, out); }
+extern "C" int sealnn_add_layernorm_planes(void *stream, const float *x, const float *y, const float *gamma, const float *beta, uint32_t rows,
+                                           uint32_t d, float eps, float *out, void *planes, uint32_t *d_flag)
+{
+    if (!planes) { fmi_set_error("sealnn_add_layernorm_planes: no plane buffer"); return FMI_ERR_ARG; }
+    return add_layernorm<float>(stream, x, y, gamma, beta, rows, d, eps, out, planes, d_flag);
+}
+extern "C" int sealnn_gelu_planes(void *stream, const float *x, uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag)
+{
+    if (d % 4 || !planes) { fmi_set_error("sealnn_gelu_planes: d=%u must be a multiple of 4 (and a plane buffer given)", d); return FMI_ERR_UNSUPPORTED; }
+    const uint64_t n = (uint64_t)rows * (d / 4);
+    if (!n) return FMI_OK;
+    hipLaunchKernelGGL(k_gelu_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows, d, (__half *)planes, d_flag);
+    NNCHK();
+    return FMI_OK;
+}
 extern "C" int sealnn_add_layernorm_bf16(void *stream, const void *x, const void *y, const void *gamma, const void *beta, uint32_t rows,
                                          uint32_t d, float eps, void *out)
 { return add_layernorm<bf16>(stream, x, y, gamma, beta, rows, d, eps, out); }

@@ -41,6 +41,9 @@ ENABLED = os.environ.get("SEAL_SPLIT_GEMM", "0") == "1"
 # either precision and has nothing to gain -- to be set from tools/split_gemm_probe.py's per-shape times
 MIN_N = int(os.environ.get("SEAL_SPLIT_GEMM_MIN_N", "0"))
 MIN_ROWS = int(os.environ.get("SEAL_SPLIT_GEMM_MIN_ROWS", "0"))
+# the planes written by the kernels that produce the activations (sealnn_add_layernorm_planes, sealnn_gelu_planes) instead of a pass of
+# sealnn_split_planes in front of every product
+FUSED = os.environ.get("SEAL_SPLIT_FUSED", "1") == "1"
 LO_SHIFT = 11                      # bits between the planes: fp16 has an 11-bit significand
 _flags = {}                        # device -> int32 counter of unsplittable activations
 
@@ -104,7 +107,13 @@ class SplitLinear:
         a = torch.empty(x.shape[0], 3 * self.K, dtype=torch.float16, device=x.device)
         check(lib().sealnn_split_planes(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.shape[0], self.K, a.data_ptr(),
                                         _flag(x.device).data_ptr()))
-        return torch.addmm(self.bias, a, self.wt, alpha=self.alpha, out_dtype=torch.float32)
+        return self.from_planes(a)
+
+    def from_planes(self, planes: torch.Tensor) -> torch.Tensor:
+        """the product for an activation whose planes [rows, 3K] fp16 exist already"""
+        if not planes.is_cuda:
+            return torch.addmm(self.bias, planes.float(), self.wt.float(), alpha=self.alpha)
+        return torch.addmm(self.bias, planes, self.wt, alpha=self.alpha, out_dtype=torch.float32)
 
 
 class SplitLinears:
@@ -113,11 +122,21 @@ class SplitLinears:
     def __init__(self):
         self._by_weight = {}
 
-    def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
-        if weight.shape[0] < MIN_N or x.shape[0] < MIN_ROWS or weight.shape[1] % 4:
-            return torch.nn.functional.linear(x, weight, bias)
+    @staticmethod
+    def wants(weight: torch.Tensor, rows: int) -> bool:
+        return weight.shape[0] >= MIN_N and rows >= MIN_ROWS and weight.shape[1] % 4 == 0
+
+    def _of(self, weight, bias) -> SplitLinear:
         key = (weight.data_ptr(), tuple(weight.shape))
         lin = self._by_weight.get(key)
         if lin is None:
             lin = self._by_weight[key] = SplitLinear(weight, bias)
-        return lin(x)
+        return lin
+
+    def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
+        if not self.wants(weight, x.shape[0]):
+            return torch.nn.functional.linear(x, weight, bias)
+        return self._of(weight, bias)(x)
+
+    def from_planes(self, planes: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
+        return self._of(weight, bias).from_planes(planes)

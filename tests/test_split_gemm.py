@@ -173,3 +173,33 @@ def test_model_forward_through_split_linears_scores_like_fp32():
     assert len(used) > 20
     e_fp32, e_split = (a - ref).abs().max().item(), (b - ref).abs().max().item()
     assert e_split <= max(3 * e_fp32, 2e-6), (e_split, e_fp32)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("SEAL_TEST_SPLIT_GEMM") != "1", reason="opt-in until measured on an MI355X (SEAL_TEST_SPLIT_GEMM=1)")
+def test_planes_from_the_producing_kernels_on_the_gpu():
+    """sealnn_add_layernorm_planes: fp32 output == sealnn_add_layernorm's, planes == the split of that output, bit for bit;
+    sealnn_gelu_planes == the split of torch's gelu (erf form) to the last bit of the hi plane (erff may differ by an ulp: lo within 2^-10 of hi's ulp)"""
+    from seal_amd._lib import check, lib
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    g = torch.Generator().manual_seed(9)
+    rows, d = 77, 1024
+    x, y = torch.randn(rows, d, generator=g).to(dev), (torch.randn(rows, d, generator=g) * 3).to(dev)
+    gamma, beta = (torch.rand(d, generator=g) + 0.5).to(dev), torch.randn(d, generator=g).to(dev)
+    want = torch.empty_like(x)
+    check(lib().sealnn_add_layernorm(st, x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, d, 1e-5, want.data_ptr()))
+    out, planes = torch.empty_like(x), torch.empty(rows, 3 * d, dtype=torch.float16, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib().sealnn_add_layernorm_planes(st, x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, d, 1e-5, out.data_ptr(),
+                                            planes.data_ptr(), flag.data_ptr()))
+    assert torch.equal(out, want) and torch.equal(planes.cpu(), split_planes_reference(want.cpu())) and int(flag.item()) == 0
+    h = (torch.randn(rows, 4096, generator=g) * 2).to(dev)
+    hp = torch.empty(rows, 3 * 4096, dtype=torch.float16, device=dev)
+    check(lib().sealnn_gelu_planes(st, h.data_ptr(), rows, 4096, hp.data_ptr(), flag.data_ptr()))
+    ref = split_planes_reference(torch.nn.functional.gelu(h).cpu())
+    got = hp.cpu()
+    assert torch.equal(got[:, :4096], got[:, 4096:8192])
+    back = got[:, :4096].double() + got[:, 8192:].double() * 2.0 ** -LO_SHIFT
+    want_back = ref[:, :4096].double() + ref[:, 8192:].double() * 2.0 ** -LO_SHIFT
+    assert (back - want_back).abs().max().item() <= 1e-6 and int(flag.item()) == 0
