@@ -560,6 +560,8 @@ class PendingGenerate:
             host_sc = torch.empty(sc.shape, dtype=sc.dtype, pin_memory=True)
             host_tok.copy_(tok, non_blocking=True)
             host_sc.copy_(sc, non_blocking=True)
+            from . import split_gemm
+            self._split_flag = split_gemm.flag_snapshot(dev)          # activations beyond fp16's range in this decode's split GEMMs?
         else:
             host_tok, host_sc = tok, sc
         lens = [p.shape[-1] + 1 for p, _, _ in steps for _ in range(p.shape[1])] + [L] * K
@@ -571,8 +573,7 @@ class PendingGenerate:
         divides by ``size ** length_penalty``, the output comprehension multiplies it back, reference beam_search.py:555,752-755);
         ``valid`` = kept by ``add`` (score > -inf)."""
         import numpy as np
-        if self._event is not None:
-            self._event.synchronize()
+        self._wait()
         host_tok, host_sc, lens = self._packed
         lp = self._args[4] if self._args is not None else self._lp
         tok = host_tok.numpy()
@@ -584,9 +585,16 @@ class PendingGenerate:
             score = np.where(norm == 1.0, s, normed * norm)
         return tok, length, score, normed > float("-inf")
 
-    def result(self):
+    def _wait(self):
         if self._event is not None:
             self._event.synchronize()
+            flag, self._split_flag = getattr(self, "_split_flag", None), None
+            if flag is not None:
+                from . import split_gemm
+                split_gemm.check_snapshot(flag, self.enc.device if self.enc is not None else None)
+
+    def result(self):
+        self._wait()
         out = _history_to_hypotheses(*self._args)
         self._lp = self._args[4]
         self._args = None

@@ -416,19 +416,26 @@ def _rescore_tree_jobs(model, jobs):
                 b += 1
             J[items[a][0]]["totals"].append(([(qi, ki, 0, sq) for _, qi, ki, sq in items[a:b]], total[a:b]))
             a = b
-    return [_PendingRescore(j["totals"], j["scores"], j["decoded"], j["lp"]) for j in J]
+    from . import split_gemm
+    flag = split_gemm.flag_snapshot(device) if device.type == "cuda" else None     # read with the scores: activations beyond fp16's range?
+    return [_PendingRescore(j["totals"], j["scores"], j["decoded"], j["lp"], flag if ji == 0 else None, device) for ji, j in enumerate(J)]
 
 
 class _PendingRescore:
     """the enqueued chunks of one ``rescore_keys`` call: one read-back for all of them"""
 
-    def __init__(self, totals, scores, decoded, length_penalty):
+    def __init__(self, totals, scores, decoded, length_penalty, split_flag=None, device=None):
         self._totals, self._scores, self._decoded, self._lp = totals, scores, decoded, length_penalty
+        self._split_flag, self._device = split_flag, device
 
     def result(self):
         scores = self._scores
         if self._totals:
             flat = torch.cat([t for _, t in self._totals]).tolist() if len(self._totals) > 1 else self._totals[0][1].tolist()
+            if self._split_flag is not None:          # (the read-back above waited for the stream the snapshot was enqueued on)
+                from . import split_gemm
+                flag, self._split_flag = self._split_flag, None
+                split_gemm.check_snapshot(flag, self._device)
             pos = 0
             for items, _ in self._totals:
                 for (qi, ki, _, _), ll in zip(items, flat[pos:pos + len(items)]):

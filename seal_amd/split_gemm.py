@@ -1,4 +1,4 @@
-"""fp32-accurate linear layers on the fp16 matrix cores (opt-in: ``SEAL_SPLIT_GEMM=1``; prepared in round 3, NOT yet measured).
+"""fp32-accurate linear layers on the fp16 matrix cores (on by default; ``SEAL_SPLIT_GEMM=0`` = plain fp32 GEMMs).
 
 The reference runs BART in fp32 (seal/retrieval.py:560-588 loads the checkpoint as it is; beam_search.py:251 takes the
 log-softmax of fp32 logits) and north_star wants the hypothesis scores within 1e-4 of that, which rules the bf16 / fp16 model
@@ -36,14 +36,23 @@ import os
 
 import torch
 
-ENABLED = os.environ.get("SEAL_SPLIT_GEMM", "0") == "1"
-# which products go through the split (the rest stay F.linear): a skinny GEMM with few output columns fills a fraction of the chip in
-# either precision and has nothing to gain -- to be set from tools/split_gemm_probe.py's per-shape times
-MIN_N = int(os.environ.get("SEAL_SPLIT_GEMM_MIN_N", "0"))
-MIN_ROWS = int(os.environ.get("SEAL_SPLIT_GEMM_MIN_ROWS", "0"))
+# ON by default since round 4 (measured on an MI355X, profiles/r4_split_gemm_probe.txt: the products below run 1.3 - 2.2 x faster than the
+# library's fp32 GEMM, the hypothesis scores stay within 1e-4 of HF's fp32 forward); SEAL_SPLIT_GEMM=0 runs every product as F.linear.
+ENABLED = os.environ.get("SEAL_SPLIT_GEMM", "1") == "1"
+# Which products go through the split: three times the FLOPs on the fp16 matrix cores only pays once the product fills the chip
+# (tools/split_gemm_probe.py, us per call fp32 -> split GEMM alone / with the sealnn_split_planes pass in front of it):
+#   600 x 3072 x 1024 (qkv)  39.6 -> 28.4 / 32.9     600 x 4096 x 1024 (fc1) 60.8 -> 31.1 / 35.6    600 x 1024 x 4096 (fc2) 56.9 -> 48.6 / 55.8
+#   600 x 1024 x 1024        17.2 -> 18.1 / 24.1     600 x 50265 x 1024 (lm_head) 518 -> 275 / 282   300 x 50265 x 1024      274 -> 146 / 149
+#   300 x 3072 x 1024        21.2 -> 19.9 / 23.8     300 x 4096 x 1024       27.5 -> 23.1 / 26.6    300 x 1024 x 4096       36.8 -> 36.1 / 41.5
+#    40 x 50265 x 1024       56.8 -> 66.1 / 69.3     3200 rows (the rescoring forward): every product 1.9 - 2.4 x faster
+# i.e. from ~0.9 GFLOP (rows x N x K multiply-adds) on when the operand planes exist already (written by the kernel that produced
+# the activation), from ~1.8 GFLOP when a split pass has to run first, and never below 128 rows.
+MIN_ROWS = 128
+MIN_MACS_WITH_PLANES = 0.9e9
+MIN_MACS_WITH_SPLIT_PASS = 1.8e9
 # the planes written by the kernels that produce the activations (sealnn_add_layernorm_planes, sealnn_gelu_planes) instead of a pass of
 # sealnn_split_planes in front of every product
-FUSED = os.environ.get("SEAL_SPLIT_FUSED", "1") == "1"
+FUSED = True
 LO_SHIFT = 11                      # bits between the planes: fp16 has an 11-bit significand
 _flags = {}                        # device -> int32 counter of unsplittable activations
 
@@ -53,6 +62,32 @@ def _flag(device) -> torch.Tensor:
     if f is None:
         f = _flags[device] = torch.zeros(1, dtype=torch.int32, device=device)
     return f
+
+
+_seen = {}                         # device -> violations already reported
+
+
+def flag_snapshot(device):
+    """the violation counter of ``device`` on its way to pinned host memory behind what the current stream holds (nothing waits);
+    ``check_snapshot`` reads it once that work is known to be complete.  None when no split product ever ran on the device."""
+    f = _flags.get(torch.device(device))
+    if f is None:
+        return None
+    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    host.copy_(f, non_blocking=True)
+    return host
+
+
+def check_snapshot(host, device=None) -> None:
+    """raises when activations left fp16's range since the last check: the products that saw them are wrong"""
+    if host is None:
+        return
+    n = int(host[0])
+    key = str(device)
+    if n > _seen.get(key, 0):
+        _seen[key] = n
+        raise RuntimeError(f"split GEMM: {n} groups of activations beyond fp16's range (|x| > 65504) were seen; the scores of this call are "
+                           f"unreliable -- run with SEAL_SPLIT_GEMM=0 (plain fp32 GEMMs) for this model")
 
 
 def overflowed(device) -> int:
@@ -123,8 +158,11 @@ class SplitLinears:
         self._by_weight = {}
 
     @staticmethod
-    def wants(weight: torch.Tensor, rows: int) -> bool:
-        return weight.shape[0] >= MIN_N and rows >= MIN_ROWS and weight.shape[1] % 4 == 0
+    def wants(weight: torch.Tensor, rows: int, have_planes: bool = True) -> bool:
+        """does ``F.linear(x[rows, K], weight[N, K])`` gain from the split?  (``have_planes``: x's operand planes exist already)"""
+        n, k = weight.shape
+        macs = float(rows) * n * k
+        return rows >= MIN_ROWS and k % 4 == 0 and macs >= (MIN_MACS_WITH_PLANES if have_planes else MIN_MACS_WITH_SPLIT_PASS)
 
     def _of(self, weight, bias) -> SplitLinear:
         key = (weight.data_ptr(), tuple(weight.shape))
@@ -134,7 +172,7 @@ class SplitLinears:
         return lin
 
     def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
-        if not self.wants(weight, x.shape[0]):
+        if not self.wants(weight, x.shape[0], have_planes=False):
             return torch.nn.functional.linear(x, weight, bias)
         return self._of(weight, bias)(x)
 

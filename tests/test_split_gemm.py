@@ -1,7 +1,7 @@
 """seal_amd/split_gemm.py: an fp32 linear layer as ONE fp16 GEMM over three planes.  On the CPU the arithmetic itself (planes emulated
 with torch ops, products summed in fp32): the split represents x and W to 22 bits and the product lands as close to the float64 result
-as an fp32 GEMM does.  The GPU half (HIP split kernel, hipBLASLt fp16 -> fp32 product, capture in a hipGraph) is opt-in until it has run
-on an MI355X: SEAL_TEST_SPLIT_GEMM=1."""
+as an fp32 GEMM does.  The GPU half: the HIP split kernels (stand-alone and fused into add+LayerNorm / GELU), the hipBLASLt fp16 -> fp32
+product, capture in a hipGraph, and the size policy of ``SplitLinears.wants`` (measured on an MI355X, profiles/r4_split_gemm_probe.txt)."""
 import os
 
 import pytest
@@ -53,7 +53,10 @@ def test_weight_planes_and_scale(top):
 
 
 @pytest.mark.parametrize("K,N", [(1024, 768), (4096, 256)])
-def test_split_linear_is_as_close_to_float64_as_an_fp32_gemm(K, N):
+def test_split_linear_is_as_close_to_float64_as_an_fp32_gemm(K, N, monkeypatch):
+    from seal_amd import split_gemm
+    monkeypatch.setattr(split_gemm, "MIN_ROWS", 0)
+    monkeypatch.setattr(split_gemm, "MIN_MACS_WITH_SPLIT_PASS", 0.0)          # the size policy aside: every product through the split
     g = torch.Generator().manual_seed(K)
     x = _activations(96, K, 2)
     w = torch.randn(N, K, generator=g) * 0.05
@@ -79,7 +82,6 @@ def test_split_linear_is_as_close_to_float64_as_an_fp32_gemm(K, N):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("SEAL_TEST_SPLIT_GEMM") != "1", reason="opt-in until measured on an MI355X (SEAL_TEST_SPLIT_GEMM=1)")
 def test_split_linear_on_the_gpu():
     """the HIP split kernel == the torch emulation bit for bit; the hipBLASLt product is fp32-grade; out-of-range activations are
     counted; the whole call is capturable"""
@@ -116,13 +118,14 @@ def test_split_linear_on_the_gpu():
     assert torch.equal(y, got)
 
 
-def test_decoder_linear_helpers_are_f_linear_by_default():
-    """BartStepDecoder._lin / _mod (what the fused paths call for every projection): F.linear unless SEAL_SPLIT_GEMM=1"""
+def test_decoder_linear_helpers_are_f_linear_off_the_gpu():
+    """BartStepDecoder._lin / _mod (what the fused paths call for every projection): plain F.linear for anything that is not an fp32
+    activation on the GPU, whatever SEAL_SPLIT_GEMM says (default: on)"""
     import torch.nn.functional as F
     from seal_amd import split_gemm
     from seal_amd.bart_decoder import BartStepDecoder
     from tests.helpers import tiny_bart
-    assert split_gemm.ENABLED is (os.environ.get("SEAL_SPLIT_GEMM", "0") == "1")
+    assert split_gemm.ENABLED is (os.environ.get("SEAL_SPLIT_GEMM", "1") == "1")
     m = tiny_bart(60)
     dec = BartStepDecoder(m)
     x = torch.randn(5, dec.d)
@@ -137,7 +140,23 @@ def test_decoder_linear_helpers_are_f_linear_by_default():
         assert BartStepDecoder.split_gemm is False
 
 
-def test_model_forward_through_split_linears_scores_like_fp32():
+def test_split_policy_follows_the_measured_shapes():
+    """``SplitLinears.wants``: the products that measured faster through the split on an MI355X (module text of seal_amd/split_gemm.py)"""
+    w = lambda n, k: torch.empty(n, k, device="meta")
+    yes = [(600, 3072, 1024, True), (600, 4096, 1024, True), (600, 1024, 4096, True), (600, 50265, 1024, True), (300, 50265, 1024, False),
+           (300, 4096, 1024, True), (300, 3072, 1024, True), (3200, 1024, 1024, False), (600, 3072, 1024, False), (4096, 50265, 1024, False)]
+    no = [(600, 1024, 1024, True), (300, 1024, 1024, True), (40, 50265, 1024, True), (40, 4096, 1024, True), (300, 4096, 1024, False),
+          (300, 3072, 1024, False), (600, 1024, 1024, False), (600, 1022, 1022, True)]
+    for rows, n, k, planes in yes:
+        assert SplitLinears.wants(w(n, k), rows, planes), (rows, n, k, planes)
+    for rows, n, k, planes in no:
+        assert not SplitLinears.wants(w(n, k), rows, planes), (rows, n, k, planes)
+
+
+def test_model_forward_through_split_linears_scores_like_fp32(monkeypatch):
+    from seal_amd import split_gemm
+    monkeypatch.setattr(split_gemm, "MIN_ROWS", 0)
+    monkeypatch.setattr(split_gemm, "MIN_MACS_WITH_SPLIT_PASS", 0.0)
     """every nn.Linear / lm_head product of a (tiny) BART forward through the emulated split product: the running log-probability sums of
     teacher-forced hypotheses move by no more than fp32's own distance from float64 (tools/split_gemm_e2e_cpu.py does the same at BART-large
     geometry: 8.4e-6 against fp32's 5.5e-6, tolerance 1e-4)"""
@@ -176,7 +195,6 @@ def test_model_forward_through_split_linears_scores_like_fp32():
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("SEAL_TEST_SPLIT_GEMM") != "1", reason="opt-in until measured on an MI355X (SEAL_TEST_SPLIT_GEMM=1)")
 def test_planes_from_the_producing_kernels_on_the_gpu():
     """sealnn_add_layernorm_planes: fp32 output == sealnn_add_layernorm's, planes == the split of that output, bit for bit;
     sealnn_gelu_planes == the split of torch's gelu (erf form) to the last bit of the hi plane (erff may differ by an ulp: lo within 2^-10 of hi's ulp)"""

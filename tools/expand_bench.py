@@ -33,8 +33,8 @@ def main():
     ap.add_argument("--incremental", action="store_true", help="time the call of a decode step: the prefix of length L-1 was "
                     "searched by the previous call (kept ranges, workspace bitmaps), the timed call extends it by one token")
     ap.add_argument("--timestamps", action="store_true", help="per-wave realtime stamps of one call (where the time goes)")
-    ap.add_argument("--variants", default="", help="'|'-separated settings, each a space-separated list of ENV=VALUE (the launch-shape "
-                    "switches of k_constrain are read per call): the measurements are repeated for each on the same index")
+    ap.add_argument("--variants", default="", help="'|'-separated settings, each a space-separated list of SEALFM_<OPTION>=VALUE (fmi_dev_set_option: the "
+                    "launch-shape switches of the constraint call): the measurements are repeated for each on the same index")
     ap.add_argument("--synthetic-bwt", type=float, default=0,
                     help="N symbols: skip corpus+suffix array and load an i.i.d. Zipf 'BWT' of N symbols straight into the "
                          "wavelet matrix (rank/select-only index; bandwidth measurement only, SURVEY.md 8d tier X)")
@@ -92,7 +92,10 @@ def main():
     for variant in (args.variants.split("|") if args.variants else [""]):
         for kv in variant.split():
             k, v = kv.split("=", 1)
-            os.environ[k] = v
+            if k.startswith("SEALFM_"):        # launch-shape switches: per handle since round 4 (the environment is read at handle creation)
+                check(lib().fmi_dev_set_option(h, k[len("SEALFM_"):].lower().encode(), int(v)))
+            else:
+                os.environ[k] = v
         if args.variants:
             print(json.dumps({"variant": variant}), flush=True)
         for pl, ids in zip(plens, all_ids):
