@@ -837,9 +837,31 @@ class SEALSearcher:
         # enqueued AHEAD of the batch whose post-processing (filters, rescoring, aggregation -- phases that end in a
         # device -> host read-back, i.e. pipeline bubbles) is running, so that the GPU never drains.  They share the
         # decoder's static buffers and the index workspace in stream order; each keeps its own history tensors.
-        depth = max(1, int(os.environ.get("SEAL_OVERLAP_DEPTH", getattr(self, "overlap_depth", 1))))
+        # ONE library GEMM stream at a time (round 4).  The decodes (caller's stream) and the rescoring forward (post stream) both run
+        # hipBLASLt GEMMs, all stream-K kernels whose workgroups wait for partner workgroups through flags; two of them in flight at
+        # once on one GPU stalled for ever -- reproducibly with some algorithm picks (round 3's TunableOp pick for lm_head, every fp16
+        # pick of the split GEMM: profiles/r4_hang_*.txt, r4_split_gemm_two_gemm_streams_stalls.txt), never with launches serialised.
+        # So the two GEMM-bearing phases ALTERNATE on the GPU, enforced with events: a batch's rescoring waits for the decodes enqueued
+        # before it, the next decode waits for that rescoring; the aggregation (index kernels, rocPRIM sorts: no library GEMM) still
+        # overlaps both on the index's own stream.  The host keeps one more batch of decodes enqueued ahead (depth 2), so that the GPU
+        # has the next decode queued while the host waits for a batch's scores: throughput is bound by the host loop or by
+        # decode + rescoring, whichever is longer, as before.
+        exclusive = bool(getattr(self, "exclusive_gemm_streams", True)) and os.environ.get("SEAL_EXCLUSIVE_GEMM_STREAMS", "1") != "0"
+        depth = max(1, int(os.environ.get("SEAL_OVERLAP_DEPTH", getattr(self, "overlap_depth", 2 if exclusive else 1))))
         ahead = []                                            # generators whose decodes are enqueued, oldest first
         nxt_i = 0
+        main = torch.cuda.current_stream(dev)
+        fence = {"decode": None, "rescore": None}             # events behind the newest enqueued decode / rescoring
+
+        def after(kind, stream):
+            if exclusive:
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                fence[kind] = ev
+
+        def wait_for(kind, stream):
+            if exclusive and fence[kind] is not None:
+                stream.wait_event(fence[kind])
 
         prof = None
         if os.environ.get("SEAL_PROFILE_ENQUEUE"):            # tools: where the host time of enqueueing a batch's decodes goes
@@ -852,17 +874,24 @@ class SEALSearcher:
             g = _batch_steps(self, batches[nxt_i], constrained, offsets[nxt_i])
             if prof is not None and nxt_i >= 2:
                 prof.enable()
+            wait_for("rescore", main)
             state = next(g)                                   # "body": the body decode is enqueued behind the earlier ones
             if upto == "decoding":
                 state = next(g)
+            after("decode", main)
             if prof is not None:
                 prof.disable()
             ahead.append([g, state])
             nxt_i += 1
 
         def advance(entry, upto):
+            decodes = entry[1] in ("body",) and upto in ("decoding", "decoded", "rescoring")     # a title decode still to be enqueued
+            if decodes:
+                wait_for("rescore", main)
             while entry[1] != upto:
                 entry[1] = next(entry[0])
+                if decodes and entry[1] == "decoding":
+                    after("decode", main)
         enqueue_next()
         held = None                                           # results of the batch before the current one, not handed out yet
         for i in range(len(batches)):
@@ -881,8 +910,10 @@ class SEALSearcher:
                 import cProfile
                 pprof = self.__dict__.setdefault("_post_prof", cProfile.Profile())
                 pprof.enable()
+            wait_for("decode", post)
             with torch.cuda.stream(post):
                 advance(cur, "rescoring")
+            after("rescore", post)
             if ahead:
                 advance(ahead[0], "decoding")                 # the next batch's title decode, on the caller's stream
             # this batch's rescorings are enqueued and the host is about to wait for their scores: the time to hand the

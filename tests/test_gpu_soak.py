@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 DOCS = 3_200_000            # x ~137 tokens: 4.4e8 symbols, ~4.2 GiB resident (matrix + suffix array + text)
 BATCHES = 36
 CALLS = 3
-WALL_S = 240                # a stalled GPU ends the test process with every thread's stack instead of hanging the suite
+WALL_S = 180                # a stalled GPU ends the test process with every thread's stack instead of hanging the suite
 
 
 def test_overlapped_batches_complete_and_equal_the_sequential_path():
@@ -33,7 +33,10 @@ def test_overlapped_batches_complete_and_equal_the_sequential_path():
     from seal_amd.retrieval import SEALSearcher
     from transformers import BartConfig, BartForConditionalGeneration
     dev = torch.device("cuda:0")
-    faulthandler.dump_traceback_later(WALL_S, exit=True, file=sys.stderr)
+    # (pytest captures fd 2: the stacks of a stall go to a file that survives the process)
+    log_dir = "gpurun_out" if os.path.isdir("gpurun_out") else "/tmp"
+    stall_log = open(os.path.join(log_dir, "test_gpu_soak_stall.txt"), "w")
+    faulthandler.dump_traceback_later(WALL_S, exit=True, file=stall_log)
     try:
         data, beg, title_len, ids_by_rank = bench.synth_corpus(DOCS, dev, seed=0, phrases=3_000_000)
         queries, bias = bench.synth_queries(BATCHES * 20, data, beg, title_len, ids_by_rank, dev, seed=1)
@@ -71,3 +74,6 @@ def test_overlapped_batches_complete_and_equal_the_sequential_path():
               file=sys.stderr)
     finally:
         faulthandler.cancel_dump_traceback_later()
+        stall_log.close()
+        if os.path.getsize(stall_log.name) == 0:
+            os.remove(stall_log.name)
