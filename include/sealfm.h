@@ -83,6 +83,15 @@ int fmi_build_device(fmi_t *h, const uint32_t *d_data, uint64_t n_data, int devi
  * whose suffix array cannot be built on one GPU (SURVEY.md 8d tier X: ~1.4e10 symbols). */
 int fmi_build_from_bwt_device(fmi_t *h, const void *d_bwt, uint64_t n, int sym_bytes, uint64_t max_sym, int device);
 
+/* The same index as fmi_build_device for texts whose construction workspace there (prefix doubling: ~42 B per symbol) does not fit the
+ * GPU next to the index -- BASELINE configs[4], 1.4e10 symbols: the suffix array is sorted in slices of ~slice_rows suffixes
+ * (0: 2^30), cut by the value of their leading symbols and refined a few symbols at a time (seal_amd/csrc/fmi_build_gpu.hip,
+ * build_sliced_impl; ~60 B of workspace per suffix of ONE slice).  d_text: the n symbols of the text in index order INCLUDING the
+ * final 0 sentinel, sym_bytes (2 or 4) each, in device memory that the caller owns and keeps alive as long as the index lives: it
+ * becomes the index's resident text, nothing is copied.  Replaces what sdsl's construct() does on disk for such sizes
+ * (seal/cpp_modules/fm_index.cpp:43-48, seal/index.py:55-66). */
+int fmi_build_device_sliced(fmi_t *h, const void *d_text, uint64_t n, int sym_bytes, int device, uint64_t slice_rows);
+
 /* FMIndex::save(path)  (fm_index.cpp:186-189).  Own documented format
  * (DESIGN.md "on-disk layout"), not sdsl's. */
 int fmi_save(const fmi_t *h, const char *path);

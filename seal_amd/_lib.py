@@ -26,6 +26,7 @@ SIGNATURES = {
     "fmi_build_from_file": (_int, [_vp, ctypes.c_char_p, _int, _int]),
     "fmi_build_device": (_int, [_vp, _vp, _u64, _int, _int]),
     "fmi_build_from_bwt_device": (_int, [_vp, _vp, _u64, _int, _u64, _int]),
+    "fmi_build_device_sliced": (_int, [_vp, _vp, _u64, _int, _int, _u64]),
     "fmi_save": (_int, [_vp, ctypes.c_char_p]),
     "fmi_load": (_int, [ctypes.POINTER(_vp), ctypes.c_char_p, _int]),
     "fmi_load_sdsl": (_int, [ctypes.POINTER(_vp), ctypes.c_char_p, _int]),

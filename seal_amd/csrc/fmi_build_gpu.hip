@@ -239,11 +239,21 @@ __global__ void k_widen(const SymT *in, uint64_t n, uint32_t *out) { GRID_STRIDE
 // fields of `h` and `d`.  Shared by the full builder and by fmi_build_from_bwt_device.
 template <typename SymT>
 int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64_t n, uint64_t max_sym, uint32_t L, FmiDev &d,
-                     uint64_t **wm_out, uint64_t **dC_out, uint64_t **dleaf_out, uint8_t **dq1_out)
+                     uint64_t **wm_out, uint64_t **dC_out, uint64_t **dleaf_out, uint8_t **dq1_out, SymT *consume_bwt = nullptr)
 {
+    // (consume_bwt: the pool-owned BWT buffer itself becomes the first level's input instead of a copy of it -- 2 B per symbol
+    //  less at the peak of a build that is sized to the GPU; it is gone afterwards)
+    unsigned long long *first_pos = nullptr;
+    HIPCHK(pool.alloc(&first_pos, max_sym + 1));
+    HIPCHK(hipMemsetAsync(first_pos, 0xff, (max_sym + 1) * 8, st));
+    hipLaunchKernelGGL((k_first_pos<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, bwt, n, first_pos);
     SymT *cur = nullptr, *nxt = nullptr;
-    HIPCHK(pool.alloc(&cur, n)); HIPCHK(pool.alloc(&nxt, n));
-    HIPCHK(hipMemcpyAsync(cur, bwt, n * sizeof(SymT), hipMemcpyDeviceToDevice, st));
+    if (consume_bwt) cur = consume_bwt;
+    else {
+        HIPCHK(pool.alloc(&cur, n));
+        HIPCHK(hipMemcpyAsync(cur, bwt, n * sizeof(SymT), hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHK(pool.alloc(&nxt, n));
     const uint64_t nblk = n / FMI_BLOCK_BITS + 2;
     const uint32_t D = (L + FMI_DIGIT_BITS - 1) / FMI_DIGIT_BITS;
     const uint32_t sb_shift = fmi_sb_shift_for(n);
@@ -290,13 +300,10 @@ int wavelet_from_bwt(fmi *h, Pool &pool, hipStream_t st, const SymT *bwt, uint64
 
     // ---- per-symbol tables --------------------------------------------------
     uint64_t *leaf = nullptr, *occ_end = nullptr;
-    unsigned long long *first_pos = nullptr;
-    HIPCHK(pool.alloc(&leaf, max_sym + 1)); HIPCHK(pool.alloc(&occ_end, max_sym + 1)); HIPCHK(pool.alloc(&first_pos, max_sym + 1));
+    HIPCHK(pool.alloc(&leaf, max_sym + 1)); HIPCHK(pool.alloc(&occ_end, max_sym + 1));
     HIPCHK(hipMemsetAsync(leaf, 0, (max_sym + 1) * 8, st));
     HIPCHK(hipMemsetAsync(occ_end, 0, (max_sym + 1) * 8, st));
-    HIPCHK(hipMemsetAsync(first_pos, 0xff, (max_sym + 1) * 8, st));
     hipLaunchKernelGGL((k_runs<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, cur, n, leaf, occ_end);
-    hipLaunchKernelGGL((k_first_pos<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, bwt, n, first_pos);
     std::vector<uint64_t> h_leaf(max_sym + 1), h_end(max_sym + 1), h_first(max_sym + 1);
     HIPCHK(hipMemcpyAsync(h_leaf.data(), leaf, (max_sym + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(h_end.data(), occ_end, (max_sym + 1) * 8, hipMemcpyDeviceToHost, st));
@@ -465,6 +472,304 @@ int build_impl(fmi *h, const uint32_t *d_data, uint64_t n_data, int device, int 
     return FMI_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// Suffix array in SLICES, for texts whose prefix-doubling workspace (ranks + double-buffered keys and indices: ~42 B per symbol)
+// does not fit the GPU next to the index itself -- BASELINE configs[4]: 1.4e10 symbols = 28 GB of text, 70 GB of suffix array,
+// 56 GB of wavelet matrix; prefix doubling would need 590 GB.
+//
+// The suffixes are cut into slices by the VALUE of their first `per` symbols (splitters = quantiles of a sample of those keys, so
+// every slice holds about `slice_rows` suffixes and slice s precedes slice s + 1 in suffix order).  A slice is sorted on its own:
+// its positions are collected (one pass over the text per slice), sorted by the key of their first `per` symbols, and then
+// refined -- the groups of suffixes that still agree are sorted by their NEXT `per` symbols (stable LSD: by the new key, then
+// by the group), `per` symbols deeper every round, until every group is a single suffix.  The text has exactly one sentinel (its
+// last symbol, smaller than every other), so two suffixes always differ before either runs off the end: the result is the suffix
+// array, byte-identical to the prefix-doubling builder's (tests force small slices on test corpora).  Workspace: ~60 B per
+// suffix OF ONE SLICE; rounds = longest repeat / per, two radix sorts each.
+// ---------------------------------------------------------------------------
+template <typename SymT>
+__device__ __forceinline__ uint64_t key_at(const SymT *text, uint64_t n, uint64_t p, uint32_t bits, uint32_t per)
+{
+    uint64_t key = 0;
+    for (uint32_t j = 0; j < per; j++) {
+        const uint64_t s = (p + j < n) ? (uint64_t)text[p + j] : 0;
+        key = (key << bits) | s;
+    }
+    return key;
+}
+
+template <typename SymT>
+__global__ void k_sample_keys(const SymT *text, uint64_t n, uint32_t bits, uint32_t per, uint64_t stride, uint64_t n_samples, uint64_t *keys)
+{
+    GRID_STRIDE(i, n_samples) keys[i] = key_at(text, n, std::min<uint64_t>(i * stride, n - 1), bits, per);
+}
+
+// slice of a key: the number of splitters <= key (splitters ascending, n_split <= 1023)
+__device__ __forceinline__ uint32_t slice_of(const uint64_t *split, uint32_t n_split, uint64_t key)
+{
+    uint32_t a = 0, b = n_split;
+    while (a < b) { const uint32_t mid = (a + b) >> 1; if (split[mid] <= key) a = mid + 1; else b = mid; }
+    return a;
+}
+
+template <typename SymT>
+__global__ __launch_bounds__(256) void k_count_slices(const SymT *text, uint64_t n, uint32_t bits, uint32_t per, const uint64_t *split, uint32_t n_split,
+                                                      unsigned long long *counts)
+{
+    __shared__ unsigned int local[1024];
+    for (uint32_t i = threadIdx.x; i <= n_split; i += blockDim.x) local[i] = 0;
+    __syncthreads();
+    GRID_STRIDE(p, n) atomicAdd(&local[slice_of(split, n_split, key_at(text, n, p, bits, per))], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= n_split; i += blockDim.x) if (local[i]) atomicAdd(&counts[i], (unsigned long long)local[i]);
+}
+
+// the positions of one slice (key in [lo_key, hi_key), hi_key = 0 with `last`: no upper bound), in any order, with their keys
+template <typename SymT>
+__global__ __launch_bounds__(256) void k_collect_slice(const SymT *text, uint64_t n, uint32_t bits, uint32_t per, uint64_t lo_key, uint64_t hi_key, int first,
+                                                       int last, uint64_t *pos, uint64_t *keys, unsigned long long *cursor)
+{
+    GRID_STRIDE(p, n) {
+        const uint64_t k = key_at(text, n, p, bits, per);
+        const bool mine = (first || k >= lo_key) && (last || k < hi_key);
+        const uint64_t bal = __ballot(mine);
+        if (!bal) continue;
+        unsigned long long base = 0;
+        const uint32_t lane = threadIdx.x & 63;
+        if (lane == (uint32_t)__builtin_ctzll(bal)) base = atomicAdd(cursor, (unsigned long long)__popcll(bal));
+        base = __shfl(base, __builtin_ctzll(bal));
+        if (mine) {
+            const uint64_t at = base + (uint64_t)__popcll(bal & ((1ull << lane) - 1));
+            pos[at] = p; keys[at] = k;
+        }
+    }
+}
+
+__global__ void k_iota32(uint32_t *v, uint64_t m) { GRID_STRIDE(j, m) v[j] = (uint32_t)j; }
+
+// group starts after the first sort: head where the key changes
+__global__ void k_slice_heads0(const uint64_t *keys, uint64_t m, uint32_t *gs)
+{
+    GRID_STRIDE(j, m) gs[j] = (j == 0 || keys[j] != keys[j - 1]) ? (uint32_t)j : 0u;
+}
+
+// ... after a refinement round: head where the old group or the new key changes
+__global__ void k_slice_heads(const uint32_t *gid, const uint64_t *keys, uint64_t m, uint32_t *gs)
+{
+    GRID_STRIDE(j, m) gs[j] = (j == 0 || gid[j] != gid[j - 1] || keys[j] != keys[j - 1]) ? (uint32_t)j : 0u;
+}
+
+__global__ void k_count_group_heads(const uint32_t *gid, uint64_t m, unsigned long long *n_groups)
+{
+    unsigned long long local = 0;
+    GRID_STRIDE(j, m) local += (gid[j] == (uint32_t)j);
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(n_groups, local);
+}
+
+// key of the next `per` symbols of every suffix of the slice; a suffix that is alone in its group keeps key 0 (nothing left to decide)
+template <typename SymT>
+__global__ void k_slice_next_keys(const SymT *text, uint64_t n, uint32_t bits, uint32_t per, uint64_t depth, const uint64_t *pos, const uint32_t *gid,
+                                  uint64_t m, uint64_t *keys)
+{
+    GRID_STRIDE(j, m) {
+        const bool alone = gid[j] == (uint32_t)j && (j + 1 == m || gid[j + 1] == (uint32_t)(j + 1));
+        keys[j] = alone ? 0ull : key_at(text, n, pos[j] + depth, bits, per);
+    }
+}
+
+template <typename T>
+__global__ void k_gather_by(const T *src, const uint32_t *idx, T *dst, uint64_t m) { GRID_STRIDE(j, m) dst[j] = src[idx[j]]; }
+
+__global__ void k_store_sa(const uint64_t *pos, uint64_t m, uint64_t base, uint32_t *sa_lo, uint8_t *sa_hi)
+{
+    GRID_STRIDE(j, m) { sa_lo[base + j] = (uint32_t)pos[j]; if (sa_hi) sa_hi[base + j] = (uint8_t)(pos[j] >> 32); }
+}
+
+template <typename SymT>
+__global__ void k_bwt_split(const SymT *text, const uint32_t *sa_lo, const uint8_t *sa_hi, uint64_t n, SymT *bwt)
+{
+    GRID_STRIDE(j, n) { const uint64_t p = (uint64_t)sa_lo[j] | (sa_hi ? (uint64_t)sa_hi[j] << 32 : 0ull); bwt[j] = text[p ? p - 1 : n - 1]; }
+}
+
+template <typename SymT>
+__global__ void k_max_sym(const SymT *text, uint64_t n, unsigned int *out)
+{
+    unsigned int local = 0;
+    GRID_STRIDE(i, n) local = max(local, (unsigned int)text[i]);
+    for (int o = 32; o > 0; o >>= 1) local = max(local, (unsigned int)__shfl_down((int)local, o));
+    if ((threadIdx.x & 63) == 0 && local) atomicMax(out, local);
+}
+
+template <typename SymT>
+int build_sliced_impl(fmi *h, const SymT *text, uint64_t n, int device, uint64_t max_sym, uint32_t L, uint64_t slice_rows, bool text_owned)
+{
+    Pool pool;
+    hipStream_t st = 0;
+    const uint32_t per = std::max<uint32_t>(1, 64 / L);
+    const bool wide = n > (1ull << 32);
+    uint32_t *sa_lo = nullptr;
+    uint8_t *sa_hi = nullptr;
+    HIPCHK(pool.alloc(&sa_lo, n));
+    if (wide) HIPCHK(pool.alloc(&sa_hi, n));
+    // ---- splitters: quantiles of the leading keys of ~2^20 evenly spaced suffixes ----
+    slice_rows = std::max<uint64_t>(slice_rows, 64);
+    uint32_t n_slices = (uint32_t)std::min<uint64_t>((n + slice_rows - 1) / slice_rows, 1000);
+    std::vector<uint64_t> split;                     // ascending, distinct
+    std::vector<unsigned long long> counts;
+    unsigned long long *d_counts = nullptr, *d_cursor = nullptr;
+    uint64_t *d_split = nullptr;
+    HIPCHK(pool.alloc(&d_counts, 1024)); HIPCHK(pool.alloc(&d_cursor, 1)); HIPCHK(pool.alloc(&d_split, 1024));
+    for (int attempt = 0;; attempt++) {
+        split.clear();
+        if (n_slices > 1) {
+            const uint64_t n_samples = std::min<uint64_t>(n, 1ull << 20);
+            const uint64_t stride = std::max<uint64_t>(1, n / n_samples);
+            uint64_t *sk = nullptr, *sk2 = nullptr;
+            HIPCHK(pool.alloc(&sk, n_samples)); HIPCHK(pool.alloc(&sk2, n_samples));
+            hipLaunchKernelGGL((k_sample_keys<SymT>), dim3(grid_for(n_samples)), dim3(TB), 0, st, text, n, L, per, stride, n_samples, sk);
+            rocprim::double_buffer<uint64_t> db(sk, sk2);
+            size_t tb = 0;
+            HIPCHK(rocprim::radix_sort_keys(nullptr, tb, db, n_samples, 0u, 64u, st));
+            void *tmp = nullptr;
+            HIPCHK(pool.alloc((char **)&tmp, tb + 256));
+            HIPCHK(rocprim::radix_sort_keys(tmp, tb, db, n_samples, 0u, 64u, st));
+            std::vector<uint64_t> hs(n_samples);
+            HIPCHK(hipMemcpy(hs.data(), db.current(), n_samples * 8, hipMemcpyDeviceToHost));
+            pool.release(sk); pool.release(sk2); pool.release(tmp);
+            for (uint32_t q = 1; q < n_slices; q++) {
+                const uint64_t v = hs[(uint64_t)q * n_samples / n_slices];
+                if (split.empty() || v > split.back()) split.push_back(v);
+            }
+        }
+        counts.assign(split.size() + 1, 0);
+        HIPCHK(hipMemsetAsync(d_counts, 0, 1024 * 8, st));
+        if (!split.empty()) HIPCHK(hipMemcpyAsync(d_split, split.data(), split.size() * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL((k_count_slices<SymT>), dim3(grid_for(n)), dim3(256), 0, st, text, n, L, per, (const uint64_t *)d_split, (uint32_t)split.size(), d_counts);
+        HIPCHK(hipMemcpy(counts.data(), d_counts, counts.size() * 8, hipMemcpyDeviceToHost));
+        const unsigned long long biggest = *std::max_element(counts.begin(), counts.end());
+        if (biggest <= 2 * slice_rows || n_slices >= 1000 || attempt >= 3) {
+            if (biggest >= (1ull << 32)) { fmi_set_error("fmi_build_device_sliced: one leading key holds %llu suffixes; a slice is limited to 2^32", biggest); return FMI_ERR_CAPACITY; }
+            break;
+        }
+        n_slices = std::min<uint32_t>(n_slices * 2, 1000);          // skewed keys: cut finer and look again
+    }
+    const uint64_t cap = *std::max_element(counts.begin(), counts.end());
+    // ---- slice workspace ----
+    uint64_t *posA = nullptr, *posB = nullptr, *keyA = nullptr, *keyB = nullptr;
+    uint32_t *gid = nullptr, *gid2 = nullptr, *permA = nullptr, *permB = nullptr;
+    HIPCHK(pool.alloc(&posA, cap)); HIPCHK(pool.alloc(&posB, cap)); HIPCHK(pool.alloc(&keyA, cap)); HIPCHK(pool.alloc(&keyB, cap));
+    HIPCHK(pool.alloc(&gid, cap)); HIPCHK(pool.alloc(&gid2, cap)); HIPCHK(pool.alloc(&permA, cap)); HIPCHK(pool.alloc(&permB, cap));
+    size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    {
+        rocprim::double_buffer<uint64_t> k64(keyA, keyB), v64(posA, posB);
+        rocprim::double_buffer<uint32_t> k32(gid, gid2), v32(permA, permB);
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, t1, k64, v64, cap, 0u, 64u, st));
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, t2, k64, v32, cap, 0u, 64u, st));
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, t3, k32, v32, cap, 0u, 32u, st));
+        HIPCHK(rocprim::inclusive_scan(nullptr, t4, (uint32_t *)nullptr, (uint32_t *)nullptr, cap, rocprim::maximum<uint32_t>(), st));
+    }
+    const size_t tmp_bytes = std::max(std::max(t1, t2), std::max(t3, t4)) + 256;
+    void *tmp = nullptr;
+    HIPCHK(pool.alloc((char **)&tmp, tmp_bytes));
+    const uint32_t key_bits = std::min<uint32_t>(64u, per * L);
+    uint64_t base = 0;
+    for (size_t sl = 0; sl < counts.size(); sl++) {
+        const uint64_t m = counts[sl];
+        if (m == 0) continue;
+        HIPCHK(hipMemsetAsync(d_cursor, 0, 8, st));
+        hipLaunchKernelGGL((k_collect_slice<SymT>), dim3(grid_for(n)), dim3(256), 0, st, text, n, L, per, sl ? split[sl - 1] : 0ull,
+                           sl < split.size() ? split[sl] : 0ull, (int)(sl == 0), (int)(sl == split.size()), posA, keyA, d_cursor);
+        uint64_t *pos = posA, *pos_alt = posB, *key = keyA, *key_alt = keyB;
+        {
+            rocprim::double_buffer<uint64_t> dk(key, key_alt), dv(pos, pos_alt);
+            size_t tb = tmp_bytes;
+            HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, m, 0u, key_bits, st));
+            key = dk.current(); key_alt = dk.alternate(); pos = dv.current(); pos_alt = dv.alternate();
+        }
+        uint32_t *g = gid, *g_other = gid2;           // g: group ids in the current order; g_other: free
+        hipLaunchKernelGGL(k_slice_heads0, dim3(grid_for(m)), dim3(TB), 0, st, (const uint64_t *)key, m, g);
+        uint32_t gbits = 1;
+        while (gbits < 32 && (m >> gbits)) gbits++;
+        uint64_t depth = 0;
+        for (int round = 0;; round++) {
+            size_t sb = tmp_bytes;
+            HIPCHK(rocprim::inclusive_scan(tmp, sb, g, g, m, rocprim::maximum<uint32_t>(), st));         // g[j] = index of j's group head
+            unsigned long long groups = 0;
+            HIPCHK(hipMemsetAsync(d_cursor, 0, 8, st));
+            hipLaunchKernelGGL(k_count_group_heads, dim3(grid_for(m)), dim3(TB), 0, st, (const uint32_t *)g, m, d_cursor);
+            HIPCHK(hipMemcpy(&groups, d_cursor, 8, hipMemcpyDeviceToHost));
+            if (groups == m) break;
+            depth += per;
+            if (depth > n || round > 1000000) { fmi_set_error("fmi_build_device_sliced: the suffixes of slice %zu did not separate", sl); return FMI_ERR_STATE; }
+            // stable LSD over (group, next key): by the next key first ...
+            hipLaunchKernelGGL((k_slice_next_keys<SymT>), dim3(grid_for(m)), dim3(TB), 0, st, text, n, L, per, depth, (const uint64_t *)pos,
+                               (const uint32_t *)g, m, key);
+            hipLaunchKernelGGL(k_iota32, dim3(grid_for(m)), dim3(TB), 0, st, permA, m);
+            uint32_t *perm = permA, *perm_alt = permB;
+            {
+                rocprim::double_buffer<uint64_t> dk(key, key_alt);
+                rocprim::double_buffer<uint32_t> dv(perm, perm_alt);
+                size_t tb = tmp_bytes;
+                HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, m, 0u, key_bits, st));
+                key = dk.current(); key_alt = dk.alternate(); perm = dv.current(); perm_alt = dv.alternate();
+            }
+            // ... then by the group: every group is back in its own index range [head, head + size), now in (next key) order inside.
+            // The values carried through both sorts are the indices the round started with.
+            hipLaunchKernelGGL(k_gather_by<uint32_t>, dim3(grid_for(m)), dim3(TB), 0, st, (const uint32_t *)g, (const uint32_t *)perm, g_other, m);
+            {
+                rocprim::double_buffer<uint32_t> dk(g_other, g), dv(perm, perm_alt);       // (g, the ids in the old order, is free now: the sort's alternate)
+                size_t tb = tmp_bytes;
+                HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, m, 0u, gbits, st));
+                g = dk.current(); g_other = dk.alternate(); perm = dv.current(); perm_alt = dv.alternate();
+            }
+            hipLaunchKernelGGL(k_gather_by<uint64_t>, dim3(grid_for(m)), dim3(TB), 0, st, (const uint64_t *)pos, (const uint32_t *)perm, pos_alt, m);
+            std::swap(pos, pos_alt);
+            // the next keys once more, in the new order (cheaper than carrying 8 more bytes through the second sort), then the finer groups
+            hipLaunchKernelGGL((k_slice_next_keys<SymT>), dim3(grid_for(m)), dim3(TB), 0, st, text, n, L, per, depth, (const uint64_t *)pos,
+                               (const uint32_t *)g, m, key);
+            hipLaunchKernelGGL(k_slice_heads, dim3(grid_for(m)), dim3(TB), 0, st, (const uint32_t *)g, (const uint64_t *)key, m, g_other);
+            std::swap(g, g_other);
+        }
+        hipLaunchKernelGGL(k_store_sa, dim3(grid_for(m)), dim3(TB), 0, st, (const uint64_t *)pos, m, base, sa_lo, sa_hi);
+        HIPCHK(hipStreamSynchronize(st));
+        base += m;
+    }
+    if (base != n) { fmi_set_error("fmi_build_device_sliced: %llu of %llu suffixes placed", (unsigned long long)base, (unsigned long long)n); return FMI_ERR_STATE; }
+    for (void *p : {(void *)posA, (void *)posB, (void *)keyA, (void *)keyB, (void *)gid, (void *)gid2, (void *)permA, (void *)permB, tmp}) pool.release(p);
+
+    // ---- BWT, wavelet matrix, tables ----
+    SymT *bwt = nullptr;
+    HIPCHK(pool.alloc(&bwt, n));
+    hipLaunchKernelGGL((k_bwt_split<SymT>), dim3(grid_for(n)), dim3(TB), 0, st, text, (const uint32_t *)sa_lo, (const uint8_t *)sa_hi, n, bwt);
+    FmiDev d{};
+    uint64_t *wm = nullptr, *dC = nullptr, *dleaf = nullptr;
+    uint8_t *dq1 = nullptr;
+    {
+        int rc = wavelet_from_bwt<SymT>(h, pool, st, bwt, n, max_sym, L, d, &wm, &dC, &dleaf, &dq1, bwt);
+        if (rc) return rc;
+    }
+    h->wm.clear(); h->sa_lo.clear(); h->sa_hi.clear(); h->text.clear(); h->bwt.clear();
+    h->host_resident = false;
+    d.C = dC; d.leaf = dleaf; d.q1 = dq1; d.sa_lo = sa_lo; d.sa_hi = sa_hi; d.text = text;
+    d.doc_begin = nullptr; d.n_begin = 0; d.doc_hint = nullptr;
+    for (void *p : {(void *)wm, (void *)d.sbase, (void *)dC, (void *)dleaf, (void *)dq1, (void *)sa_lo, (void *)sa_hi}) {
+        if (!p) continue;
+        pool.keep(p);
+        h->dev_allocs.push_back(p);
+    }
+    if (text_owned) h->dev_allocs.push_back((void *)text);
+    h->dev_bytes = (uint64_t)h->dlevels * d.nblk * FMI_BLOCK_BYTES + (max_sym + 2) * 8 + (max_sym + 1) * 9 + (uint64_t)h->dlevels * d.nsb * FMI_ARITY * 8 +
+                   n * (wide ? 5 : 4) + n * sizeof(SymT);
+    h->device = device;
+    h->dev = d;
+    if (!h->doc_begin.empty()) {
+        std::vector<uint64_t> b = h->doc_begin;
+        return fmi_set_doc_beginnings(h, b.data(), b.size());
+    }
+    return FMI_OK;
+}
+
 }  // namespace
 
 template <typename SymT>
@@ -542,4 +847,37 @@ extern "C" int fmi_build_device(fmi_t *h, const uint32_t *d_data, uint64_t n_dat
                     : build_impl<uint16_t, uint32_t>(h, d_data, n_data, device, keep_host, max_sym32, L);
     return wide ? build_impl<uint32_t, uint64_t>(h, d_data, n_data, device, keep_host, max_sym32, L)
                 : build_impl<uint32_t, uint32_t>(h, d_data, n_data, device, keep_host, max_sym32, L);
+}
+
+// Index construction with the suffix array sorted in slices (see build_sliced_impl): for texts whose prefix-doubling workspace does not
+// fit the GPU.  `d_text`: the n symbols of the text INCLUDING the final 0 sentinel, 2 or 4 bytes each, in device memory that the CALLER
+// owns and keeps alive for the life of the index (it becomes the index's resident text: nothing is copied).  slice_rows: suffixes per
+// slice (0: 2^30).
+extern "C" int fmi_build_device_sliced(fmi_t *h, const void *d_text, uint64_t n, int sym_bytes, int device, uint64_t slice_rows)
+{
+    if (!h || !d_text || n < 2 || !(sym_bytes == 2 || sym_bytes == 4)) { fmi_set_error("fmi_build_device_sliced: bad argument"); return FMI_ERR_ARG; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= device || device < 0) { fmi_set_error("no HIP device %d visible", device); return FMI_ERR_NO_DEVICE; }
+    if (n >= (1ull << 40)) { fmi_set_error("fmi_build_device_sliced: %llu symbols; positions are 40-bit", (unsigned long long)n); return FMI_ERR_UNSUPPORTED; }
+    fmi_release_device(h);
+    HIPCHK(hipSetDevice(device));
+    uint32_t last = 1;
+    HIPCHK(hipMemcpy(&last, (const uint8_t *)d_text + (n - 1) * sym_bytes, sym_bytes, hipMemcpyDeviceToHost));
+    if (sym_bytes == 2) last &= 0xffffu;
+    if (last != 0) { fmi_set_error("fmi_build_device_sliced: the text must end with the 0 sentinel"); return FMI_ERR_ARG; }
+    unsigned int *d_max = nullptr, max_sym32 = 0;
+    HIPCHK(hipMalloc((void **)&d_max, 4));
+    HIPCHK(hipMemset(d_max, 0, 4));
+    if (sym_bytes == 2) hipLaunchKernelGGL((k_max_sym<uint16_t>), dim3(grid_for(n)), dim3(TB), 0, 0, (const uint16_t *)d_text, n, d_max);
+    else hipLaunchKernelGGL((k_max_sym<uint32_t>), dim3(grid_for(n)), dim3(TB), 0, 0, (const uint32_t *)d_text, n, d_max);
+    HIPCHK(hipMemcpy(&max_sym32, d_max, 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_max);
+    uint32_t L = 0;
+    while (((uint64_t)max_sym32 >> L) > 0) L++;
+    if (L == 0) L = 1;
+    if (L > FMI_MAX_LEVELS) { fmi_set_error("alphabet needs %u bits per symbol; this build supports <= %u", L, FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
+    if (sym_bytes == 2 && max_sym32 >= 65536) { fmi_set_error("internal: 16-bit symbols above 65535"); return FMI_ERR_STATE; }
+    if (slice_rows == 0) slice_rows = 1ull << 30;
+    return sym_bytes == 2 ? build_sliced_impl<uint16_t>(h, (const uint16_t *)d_text, n, device, max_sym32, L, slice_rows, false)
+                          : build_sliced_impl<uint32_t>(h, (const uint32_t *)d_text, n, device, max_sym32, L, slice_rows, false);
 }

@@ -86,6 +86,29 @@ class FMIndex(_FMIndex):
         check(lib().fmi_build_device(self._h, data.data_ptr(), data.numel(), data.device.index or 0, int(keep_host)))
         self._after_build()
 
+    def initialize_from_device_text(self, text, beginnings, occurring=None, slice_rows: int = 0) -> None:
+        """``initialize_from_device`` for texts whose construction workspace there does not fit the GPU (BASELINE configs[4],
+        1.4e10 symbols): the suffix array is sorted in slices (``fmi_build_device_sliced``).  ``text``: the symbols in index order
+        -- per-document reversed, +SHIFT -- INCLUDING the final 0 sentinel, as an int16 / uint16 (two's-complement view of the
+        16-bit symbol) or int32 tensor on the target GPU; it becomes the index's resident text (nothing is copied) and is kept
+        alive by this object.  ``slice_rows``: suffixes per slice (0: 2^30)."""
+        import torch
+        assert text.is_cuda and text.is_contiguous() and text.element_size() in (2, 4) and text.dim() == 1
+        self.beginnings = [int(x) for x in beginnings]
+        wide = text.element_size() == 4
+        if occurring is None:
+            present = torch.zeros(1 << 17 if wide else 1 << 16, dtype=torch.bool, device=text.device)
+            for a in range(0, text.numel(), 1 << 28):      # chunked: torch refuses index tensors beyond 2^31 elements
+                chunk = text[a:a + (1 << 28)].long()
+                present[chunk if wide else chunk & 0xFFFF] = True
+            present[0] = False                              # the sentinel
+            occurring = (torch.nonzero(present).flatten() - SHIFT).tolist()
+        self.occurring = list(occurring)
+        self._text_tensor = text                            # the library reads it for as long as the index lives
+        torch.cuda.synchronize(text.device)
+        check(lib().fmi_build_device_sliced(self._h, text.data_ptr(), text.numel(), text.element_size(), text.device.index or 0, int(slice_rows)))
+        self._after_build()
+
     def initialize_rank_only_from_bwt(self, bwt, max_symbol: int) -> None:
         """Rank/select-only index from a BWT already on the GPU (int16/uint16 or int32 tensor with exactly
         one 0): backward search, ranges, counts and continuations work; ``locate``/``get_doc`` raise.

@@ -893,6 +893,8 @@ class SEALSearcher:
                 if decodes and entry[1] == "decoding":
                     after("decode", main)
         enqueue_next()
+        if exclusive and len(batches) > 1 and depth > 1:
+            enqueue_next()                                    # one decode ahead of the batch the loop starts with
         held = None                                           # results of the batch before the current one, not handed out yet
         for i in range(len(batches)):
             t0 = time.perf_counter()
@@ -902,8 +904,9 @@ class SEALSearcher:
             # The next batch's decodes go in two halves around this batch's rescoring: its body decode now, its title decode
             # once this batch's filters and rescorings are enqueued -- so the GPU still has decode work queued while the host
             # reads the scores back and walks through the aggregation (phases that end in a read-back).
-            while nxt_i < len(batches) and len(ahead) < depth:
-                enqueue_next("body" if len(ahead) == 0 else "decoding")
+            if not exclusive:
+                while nxt_i < len(batches) and len(ahead) < depth:
+                    enqueue_next("body" if len(ahead) == 0 else "decoding")
             t2 = time.perf_counter()
             pprof = None
             if os.environ.get("SEAL_PROFILE_POST") and i >= 2:   # tools: where the host time of a batch's post-processing goes
@@ -914,7 +917,15 @@ class SEALSearcher:
             with torch.cuda.stream(post):
                 advance(cur, "rescoring")
             after("rescore", post)
-            if ahead:
+            if exclusive:
+                # GPU order: decode(i+1) [enqueued one iteration ago] -> rescoring(i) [just enqueued: it waits for that decode only] ->
+                # decode(i+2) [enqueued now: it waits for the rescoring] -- the scores of batch i are back after ONE decode and the
+                # GPU has the next decode queued while the host aggregates batch i
+                for entry in ahead:
+                    advance(entry, "decoding")
+                while nxt_i < len(batches) and len(ahead) < depth:
+                    enqueue_next("decoding")
+            elif ahead:
                 advance(ahead[0], "decoding")                 # the next batch's title decode, on the caller's stream
             # this batch's rescorings are enqueued and the host is about to wait for their scores: the time to hand the
             # PREVIOUS batch's results to the caller (who builds documents from them): its python runs under that wait

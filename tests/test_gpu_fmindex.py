@@ -237,6 +237,51 @@ def test_gpu_builder_is_byte_identical_to_host_builder(seed, n_docs, vocab, wide
     assert np.array_equal(pa, pb) and np.array_equal(da, db)
 
 
+@pytest.mark.parametrize("slice_rows", [64, 700, 0], ids=["slices-of-64", "slices-of-700", "one-slice"])
+@pytest.mark.parametrize("seed,n_docs,vocab,wide", [(0, 30, 6, False), (1, 400, 300, False), (2, 3000, 50265, False), (2, 3000, 50265, True),
+                                                     (3, 500, 70000, False)])
+def test_sliced_builder_equals_the_prefix_doubling_builder(seed, n_docs, vocab, wide, slice_rows, monkeypatch):
+    """``fmi_build_device_sliced`` (BASELINE configs[4]: suffix array sorted in slices cut by the leading symbols, refined a few
+    symbols deeper per round) builds byte for byte the index ``fmi_build_device`` builds: suffix array, text, wavelet matrix,
+    tables -- on corpora with long repeats, with slices far smaller than the groups of equal leading keys and with one slice;
+    16- and 32-bit symbols; with the superblocked wavelet layout of the large tiers forced"""
+    import ctypes
+    import torch
+    if wide:
+        monkeypatch.setenv("SEALFM_FORCE_SB", "2")
+    from seal_amd import FMIndex
+    from seal_amd._lib import lib
+    docs = _docs(seed, n_docs, vocab, zipf=1.2 if vocab > 1000 else None)
+    if seed == 1:
+        docs = docs + docs[:50] + [docs[0] * 3] + [docs[1] * 2] * 3      # long repeats: many refinement rounds
+    data = np.concatenate([np.asarray(d[::-1], dtype=np.int64) + 10 for d in docs])
+    beginnings = np.concatenate([[0], np.cumsum([len(d) for d in docs])]).tolist()
+    a = FMIndex()
+    a.initialize_from_device(torch.from_numpy(data.astype(np.int32)).cuda(), beginnings)
+    text = np.concatenate([data, [0]])
+    t = torch.from_numpy(text.astype(np.int32)).cuda() if vocab + 10 >= 65536 else torch.from_numpy(text.astype(np.uint16).view(np.int16)).cuda()
+    b = FMIndex()
+    b.initialize_from_device_text(t, beginnings, slice_rows=slice_rows)
+
+    def arr(ix, name):
+        n, e = ctypes.c_uint64(), ctypes.c_uint32()
+        p = lib().fmi_dev_array(ix.handle, name.encode(), ctypes.byref(n), ctypes.byref(e))
+        if not p:
+            return None
+        from bench import _CudaArray
+        return torch.as_tensor(_CudaArray(p, n.value * e.value, "|u1"), device="cuda:0").cpu().numpy().tobytes()
+
+    for name in ("sa_lo", "sa_hi", "text", "wm", "C", "leaf", "q1"):
+        assert arr(a, name) == arr(b, name), name
+    assert b.size() == a.size() and b.occurring_distinct == a.occurring_distinct and b.occurring_counts == a.occurring_counts
+    assert sorted(b.occurring) == sorted(a.occurring)
+    assert b.get_doc(3) == docs[3] and b.get_range(docs[5][:2]) == a.get_range(docs[5][:2])
+    rows = np.arange(0, a.size(), max(1, a.size() // 97), dtype=np.uint64)
+    pa, da = a.locate_batch(rows)
+    pb, db = b.locate_batch(rows)
+    assert np.array_equal(pa, pb) and np.array_equal(da, db)
+
+
 def test_scale_check_properties_small():
     """the size-independent properties of tools/scale_check.py (run there at NQ / KILT size) at CI size"""
     import subprocess
