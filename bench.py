@@ -43,8 +43,15 @@ def log(*a):
 # synthetic NQ-shaped corpus, generated on the GPU directly in
 # index order: per document reversed (+SHIFT), i.e. [</s>, body..., '@@', title...]
 # ---------------------------------------------------------------------------
-def synth_corpus(n_docs: int, device, seed: int = 0, phrases: int = 0):
-    """``phrases`` = P > 0 (bench.py's default, P = 20 M): the token stream is a concatenation of phrases of 2..8 tokens
+def _sym(v: int, dtype):
+    """symbol value as `dtype` stores it (int16 = the two's-complement view of the 16-bit symbol)"""
+    return v - 65536 if dtype == torch.int16 and v >= 32768 else v
+
+
+def synth_corpus(n_docs: int, device, seed: int = 0, phrases: int = 0, text16: bool = False):
+    """``text16``: the corpus as the index's resident text itself -- int16 (two's-complement view of the 16-bit symbols), one element
+    longer, ending with the 0 sentinel -- for the tier whose int32 form (56 GB at 1.4e10 symbols) has no room next to the build.
+    ``phrases`` = P > 0 (bench.py's default, P = 20 M): the token stream is a concatenation of phrases of 2..8 tokens
     drawn Zipf(1.0) from a dictionary of P phrases (each an i.i.d. Zipf(1.07) token string), cut into documents
     independently of the phrase boundaries: n-grams repeat as they do in real text, so a key locates ~3e5 rows per query
     (a real NQ index: 1e5-1e6) instead of the ~1e4 of an i.i.d. corpus.
@@ -61,7 +68,10 @@ def synth_corpus(n_docs: int, device, seed: int = 0, phrases: int = 0):
     ids_by_rank = usable[torch.randperm(usable.numel(), generator=g, device=device)]
     w = 1.0 / torch.arange(1, usable.numel() + 1, device=device, dtype=torch.float64) ** 1.07
     cdf = torch.cumsum(w, 0) / w.sum()
-    data = torch.empty(N, dtype=torch.int32, device=device)
+    dt = torch.int16 if text16 else torch.int32
+    data = torch.empty(N + (1 if text16 else 0), dtype=dt, device=device)
+    if text16:
+        data[N] = 0
     CH = 1 << 27
 
     def zipf_tokens(n):
@@ -92,8 +102,8 @@ def synth_corpus(n_docs: int, device, seed: int = 0, phrases: int = 0):
             data[a:b] = ptab[pid[slot], pos - start]
             del u, pid, cum, pos, slot, start
             a = b
-    data[beg[:-1]] = 2 + SHIFT
-    data[beg[1:] - 1 - title_len] = TITLE_EOS + SHIFT
+    data[beg[:-1]] = _sym(2 + SHIFT, dt)
+    data[beg[1:] - 1 - title_len] = _sym(TITLE_EOS + SHIFT, dt)
     return data, beg, title_len, ids_by_rank
 
 
@@ -111,7 +121,7 @@ def synth_queries(n, data, beg, title_len, ids_by_rank, device, seed: int = 1):
         queries.append([0] + ids_by_rank[torch.as_tensor(ranks, device=device)].tolist() + [2])
         d = int(rng.integers(0, n_docs))
         b, e, tl = int(beg[d]), int(beg[d + 1]), int(title_len[d])
-        rev = (data[b:e].long() - SHIFT)
+        rev = ((data[b:e].long() & 0xFFFFF) - SHIFT) if data.dtype != torch.int16 else ((data[b:e].long() & 0xFFFF) - SHIFT)
         fwd = torch.flip(rev, [0])                       # title..., '@@', body..., </s>
         body0 = tl + 1
         s = int(rng.integers(body0, max(body0 + 1, (e - b) - 11)))
@@ -174,7 +184,7 @@ def index_sym_bytes(index):
     return 2 if lib().fmi_max_symbol(index.handle) < 65536 else 4
 
 
-def replay_on_cpu(orc, trace, beginnings, threads, vocab=VOCAB):
+def replay_on_cpu(orc, trace, beginnings, threads, vocab=VOCAB, locate_stride=1):
     """reference call pattern: per decode step and row, get_range(prefix) and
     get_count(prefix[:-1]) from scratch (beam_search.py:96-101), one task per row for
     distinct_count_multi (fm_index.cpp:117-121); get_count per key; locate + bisect per row;
@@ -207,12 +217,13 @@ def replay_on_cpu(orc, trace, beginnings, threads, vocab=VOCAB):
         elif op[0] == "locate":
             lo, hi, mx = op[1], op[2], op[3]
             rows = np.concatenate([np.arange(a, min(c, a + mx), dtype=np.uint64) for a, c in zip(lo, hi) if c > a] or [np.zeros(0, np.uint64)])
+            rows = rows[::locate_stride]           # (a sample where the host's LF walks would take minutes: parity_check strides the GPU's answers alike)
             t0 = time.perf_counter()
             answers.append(orc.locate_bin_batch(rows, b, threads=threads))
             t_loc += time.perf_counter() - t0
             n_loc += len(rows)
         elif op[0] == "docs":
-            d = op[1]
+            d = op[1][::locate_stride]
             t0 = time.perf_counter()
             answers.append(orc.extract_batch_tokens(b[d], b[d + 1], threads=threads))    # get_doc = extract_text per document (index.py:68-75)
             t_doc += time.perf_counter() - t0
@@ -236,7 +247,7 @@ def gpu_allowed_bits(index, ids, ff, kw, vocab=VOCAB):
     return bits.cpu().numpy().view(np.uint32)
 
 
-def parity_check(index, trace, answers, vocab=VOCAB):
+def parity_check(index, trace, answers, vocab=VOCAB, locate_stride=1):
     """every recorded FM-index operation of one batch at BASELINE scale: what the GPU answered vs what the CPU oracle
     answers for the same operation on the same index -- bit-exact (ranges and counts of every key, the allowed-token
     set of every decode row = its distinct symbols, located positions + doc ids, extracted documents)"""
@@ -267,12 +278,19 @@ def parity_check(index, trace, answers, vocab=VOCAB):
             tally("ranges_and_counts", 2 * len(lo), int((lo != op[2]).sum() + (hi != op[3]).sum()))
         elif op[0] == "locate":
             pos, doc = ans
-            tally("located_positions_and_doc_ids", 2 * len(pos), int((pos.astype(np.int64) != op[4]).sum() + (doc.astype(np.int64) != op[5]).sum())
-                  if len(pos) == len(op[4]) else max(len(pos), len(op[4])))
+            g_pos, g_doc = op[4][::locate_stride], op[5][::locate_stride]
+            tally("located_positions_and_doc_ids", 2 * len(pos), int((pos.astype(np.int64) != g_pos).sum() + (doc.astype(np.int64) != g_doc).sum())
+                  if len(pos) == len(g_pos) else max(len(pos), len(g_pos)))
         elif op[0] == "docs":
             flat, offs = ans
-            same_shape = len(flat) == len(op[2]) and np.array_equal(offs, op[3])
-            tally("extracted_document_tokens", len(flat), int((flat != op[2]).sum()) if same_shape else max(len(flat), len(op[2])))
+            g_flat, g_offs = op[2], op[3]
+            if locate_stride > 1:              # the GPU's documents of the same sample: re-packed from its flat array
+                o = np.asarray(op[3], dtype=np.int64)
+                pick = np.arange(0, len(o) - 1, locate_stride)
+                g_flat = np.concatenate([op[2][o[i]:o[i + 1]] for i in pick] or [np.zeros(0, dtype=np.asarray(op[2]).dtype)])
+                g_offs = np.concatenate([[0], np.cumsum(o[pick + 1] - o[pick])])
+            same_shape = len(flat) == len(g_flat) and np.array_equal(np.asarray(offs, dtype=np.int64), np.asarray(g_offs, dtype=np.int64))
+            tally("extracted_document_tokens", len(flat), int((flat != g_flat).sum()) if same_shape else max(len(flat), len(g_flat)))
     return {"ops": ops, "values_compared": vals, "mismatches": bad, "by_kind": detail,
             "against": "oracle/fm_oracle.c (sdsl-style wt_int + rank_support_v, SA/32, ISA/64) built from this index's BWT"}
 
@@ -401,187 +419,6 @@ def score_parity(searcher, model, index, queries, bias, dev, n_rescore_queries=4
     return out
 
 
-def run_stress(args, dev, real_stdout):
-    """BASELINE.json configs[4]: the 100M-document stress tier -- 1.4e10 symbols, an i.i.d. Zipf "BWT" loaded straight into the
-    wavelet matrix (rank/select-only index: the suffix array of 1.4e10 symbols, 70 GB + construction workspace, is not
-    built; SURVEY.md 8d tier X) -- with beam 30 and a bf16 BART-large: one step = the key generation of a batch of queries
-    (body + title decode as one loop of 2 x batch x beams = 1200 rows, count post-filters, prefix-tree rescoring, unigram
-    scores), everything of the search that does not locate.  Parity: every constraint call and every key range of one batch
-    against the CPU oracle built from the same BWT (bit-exact), the recorded hypothesis scores against HF's own bf16 forward."""
-    import ctypes
-    import __graft_entry__ as ge
-    from seal_amd import FMIndex, retrieval
-    from seal_amd._lib import check, lib
-    from seal_amd.retrieval import SEALSearcher
-    ge.build()
-    N = int(args.stress_symbols)
-    g = torch.Generator(device=dev)
-    g.manual_seed(100)
-    t0 = time.perf_counter()
-    usable = torch.arange(4, VOCAB, device=dev)
-    usable = usable[(usable != TITLE_EOS) & (usable != CODE_EOS)]
-    ids_by_rank = usable[torch.randperm(usable.numel(), generator=g, device=dev)]
-    w = 1.0 / torch.arange(1, usable.numel() + 1, device=dev, dtype=torch.float64) ** 1.07
-    cdf = torch.cumsum(w, 0) / w.sum()
-    bwt = torch.empty(N, dtype=torch.int16, device=dev)
-    for a in range(0, N, 1 << 27):
-        b = min(N, a + (1 << 27))
-        r = torch.searchsorted(cdf, torch.rand(b - a, generator=g, device=dev, dtype=torch.float64)).clamp_(max=usable.numel() - 1)
-        bwt[a:b] = (ids_by_rank[r] + SHIFT).to(torch.int16)          # two's complement view of the u16 symbol
-    # the title markers of the searcher's title decode: every 150th symbol an end-of-sequence, '@@' a little later
-    bwt[7::150] = 2 + SHIFT
-    bwt[77::150] = (TITLE_EOS + SHIFT) - 65536 if TITLE_EOS + SHIFT >= 32768 else TITLE_EOS + SHIFT
-    bwt[N // 3] = 0
-    torch.cuda.synchronize()
-    log(f"stress BWT: {N} symbols in {time.perf_counter() - t0:.1f}s")
-    t0 = time.perf_counter()
-    index = FMIndex()
-    index.initialize_rank_only_from_bwt(bwt, VOCAB - 1 + SHIFT)
-    index.labels = None
-    log(f"rank/select-only index: n={index.size()} HBM={index.device_bytes() / 2**30:.1f} GiB in {time.perf_counter() - t0:.1f}s")
-
-    from transformers import BartConfig, BartForConditionalGeneration
-    torch.manual_seed(0)
-    cfg = BartConfig()
-    cfg.forced_bos_token_id = None
-    with torch.device(dev):
-        model = BartForConditionalGeneration(cfg)
-    model.eval()
-    with torch.no_grad():
-        for tok in (cfg.pad_token_id, cfg.bos_token_id, VOCAB - 1):
-            model.final_logits_bias[0, tok] = float("-inf")
-    model.to(torch.bfloat16)
-    searcher = SEALSearcher(index, None, model, add_query_to_keys=not args.no_query_keys, detokenize=False, beam=args.beam, batch_size=args.batch,
-                            joint_decode=not args.no_joint_decode)
-    # queries: random ids; per query +8 on 12 of the 40 most frequent tokens (frequent n-grams keep non-empty ranges for a few steps)
-    n_batches = args.warmup + args.steps + 1
-    rng = np.random.default_rng(1)
-    nq = n_batches * args.batch
-    V2 = ids_by_rank.numel()
-    queries = [[0] + ids_by_rank[torch.as_tensor(np.minimum(rng.zipf(1.3, size=int(rng.integers(8, 25))), V2) - 1, device=dev)].tolist() + [2]
-               for _ in range(nq)]
-    bias = torch.zeros(nq, VOCAB, device=dev)
-    top = ids_by_rank[:40]
-    for q in range(nq):
-        bias[q, top[torch.as_tensor(rng.choice(40, size=12, replace=False), device=dev)]] = 8.0
-    bias[:, TITLE_EOS] = 4.0
-    check(lib().fmi_dev_enable_probe_count(index.handle, 1))
-    check(lib().fmi_dev_enable_timing(index.handle, 1))
-
-    def run_batch(i):
-        lo = i * args.batch
-        searcher.logit_bias = bias[lo:lo + args.batch]
-        return list(searcher.batch_generate_keys(queries[lo:lo + args.batch]))
-    for i in range(args.warmup):
-        run_batch(i)
-    torch.cuda.synchronize()
-    pr, ln, km = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
-    check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(pr)))
-    check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(ln), ctypes.byref(km)))
-    check(lib().fmi_dev_enable_probe_count(index.handle, 0))           # the timed region runs without the in-kernel counters
-    t_start = time.perf_counter()
-    n_keys = 0
-    for i in range(args.steps):
-        n_keys += sum(len(kk[0]) if isinstance(kk, tuple) else len(kk) for kk in run_batch(args.warmup + i))
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-    check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(ln), ctypes.byref(km)))
-    launches, kms = ln.value, km.value
-    # where a batch goes: one more batch with the phases serialised (synchronise before and after each)
-    from seal_amd import keys as rk
-    phases = {}
-
-    def timed(name, fn):
-        def wrap(*a, **kw):
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            out = fn(*a, **kw)
-            if name == "rescore_ms" and isinstance(out, list):
-                out = [o.result() if hasattr(o, "result") else o for o in out]        # read the scores back inside the phase
-                out = [type("Done", (), {"result": (lambda self, v=v: v)})() for v in out]
-            torch.cuda.synchronize()
-            phases[name] = phases.get(name, 0.0) + (time.perf_counter() - t) * 1e3
-            return out
-        return wrap
-    saved = (retrieval.fm_index_generate_joint, retrieval.fm_index_generate, rk.rescore_keys_multi, retrieval._count_filter)
-    retrieval.fm_index_generate_joint = timed("decode_ms", saved[0])
-    retrieval.fm_index_generate = timed("decode_ms", saved[1])
-    retrieval.fm_index_generate._joint_ok = True
-    rk.rescore_keys_multi = timed("rescore_ms", saved[2])
-    retrieval._count_filter = timed("count_filter_ms", saved[3])
-    t_b = time.perf_counter()
-    run_batch(args.warmup + args.steps)
-    torch.cuda.synchronize()
-    phases["whole_batch_ms"] = (time.perf_counter() - t_b) * 1e3
-    retrieval.fm_index_generate_joint, retrieval.fm_index_generate, rk.rescore_keys_multi, retrieval._count_filter = saved
-    check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(pr)))      # (drop that batch's counts: the counters were off)
-    check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(ln), ctypes.byref(km)))
-    # one more batch with the counters on (the bytes of the same kind of launches) and every index operation recorded
-    check(lib().fmi_dev_enable_probe_count(index.handle, 1))
-    trace = []
-    index.set_trace(trace)
-    run_batch(args.warmup + args.steps)
-    torch.cuda.synchronize()
-    index.set_trace(None)
-    check(lib().fmi_dev_read_probe_count(index.handle, ctypes.byref(pr)))
-    check(lib().fmi_dev_read_timing(index.handle, ctypes.byref(ln), ctypes.byref(km)))
-    achieved = pr.value * 128.0 / max(1, ln.value) / (kms / max(1, launches) * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": ("k_constrain<true, 8> (superblocked counters)" if N > (1 << 32) else "k_constrain<false, 8>") +
-                                          ", one launch per decode step for the rows of both decodes",
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
-                "launches": int(launches), "avg_launch_us": round(kms * 1e3 / max(1, launches), 2),
-                "algorithmic_bytes_per_launch": round(pr.value * 128.0 / max(1, ln.value), 1),
-                "measured_on": "HIP events around every k_constrain launch of the timed region (counters off); blocks counted in-kernel on one more batch"}
-    parity = cpu = None
-    if not args.no_cpu_baseline:
-        from oracle.seal_oracle import CppFMIndex, lib as orc_lib
-        threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-        orc_lib().orc_set_threads(threads)
-        t0 = time.perf_counter()
-        host = np.empty(N, dtype=np.uint32)
-        for a in range(0, N, 1 << 28):
-            host[a:a + (1 << 28)] = (bwt[a:a + (1 << 28)].to(torch.int32) & 0xFFFF).cpu().numpy().astype(np.uint32)
-        orc = CppFMIndex()
-        orc.initialize_from_bwt(host, np.zeros(N // 32 + 2, np.uint64), np.zeros(N // 64 + 2, np.uint64))
-        del host
-        log(f"cpu oracle (sdsl-style wt_int + rank_support_v) over the same BWT built in {time.perf_counter() - t0:.1f}s with {threads} threads")
-        ops = [op for op in trace if op[0] in ("mask", "ranges")]
-        rep, answers = replay_on_cpu(orc, ops, [0, N - 1], threads)
-        parity = parity_check(index, ops, answers)
-        t_cpu = rep["mask_s"] + rep["ranges_s"]
-        cpu = {"value": round(args.batch / t_cpu, 3), "unit": "queries/s (FM-index operations of the key generation only)", "cores": threads, "kind": "port",
-               "sample": f"the constraint calls ({rep['rows']} rows: get_range / get_count from scratch + distinct_count_multi) and key counts "
-                         f"({rep['sequences']} keys) of 1 batch of {args.batch} queries replayed on the oracle with the reference's call pattern",
-               "seconds": {k: round(v, 3) for k, v in rep.items() if k.endswith("_s")}}
-        del orc
-        lo_q = (args.warmup + args.steps) * args.batch
-        sp = score_parity(searcher, model, index, queries[lo_q:lo_q + args.batch], bias[lo_q:lo_q + args.batch], dev, tol=args.bf16_tol)
-        for k in ("beam_scores_body", "beam_scores_title", "rescore_scores"):
-            sp[k]["arithmetic"] = "bf16 storage, fp32 accumulation, against HF's bf16 forward of the same weights (log-softmax in fp32 on both sides)"
-        parity["by_kind"]["beam_scores"] = {"values": sp["beam_scores_body"]["values"] + sp["beam_scores_title"]["values"],
-                                            "max_abs_err": max(sp["beam_scores_body"]["max_abs_err"], sp["beam_scores_title"]["max_abs_err"]),
-                                            "tol": args.bf16_tol, "mismatches": sp["beam_scores_body"]["violations"] + sp["beam_scores_title"]["violations"],
-                                            "body": sp["beam_scores_body"], "title": sp["beam_scores_title"]}
-        parity["by_kind"]["rescore_scores"] = {**sp["rescore_scores"], "mismatches": sp["rescore_scores"]["violations"]}
-        parity["float_mismatches"] = parity["by_kind"]["beam_scores"]["mismatches"] + sp["rescore_scores"]["violations"]
-        log(f"parity_check: {parity['ops']} ops, {parity['values_compared']} integer values, {parity['mismatches']} mismatches; bf16 scores vs HF bf16: "
-            f"beam max abs err {parity['by_kind']['beam_scores']['max_abs_err']:.3g}, rescoring {sp['rescore_scores']['max_abs_err']:.3g} (tol {args.bf16_tol})")
-    del bwt
-    out = {"metric": "queries/sec of key generation, 100M-doc synthetic stress rank/select index, BART-large bf16 beam=30 batch=20",
-           "value": round(args.batch * args.steps / elapsed, 3), "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(elapsed * 1e3 / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
-           "data": "synthetic",
-           "config": {"workload": f"configs[4]: synthetic 100M-doc stress tier ({N} symbols, i.i.d. Zipf BWT, rank/select-only index), random-init BART-large bf16, "
-                                  f"beam={args.beam}, batch={args.batch}, body len 10 + title len<=15 as one loop, key generation (decodes, count filters, rescoring, unigram scores)",
-                      "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "model_arithmetic": "bf16 storage, fp32 accumulation",
-                      "not_in_step": ["first-stage retrieval and full-document rescoring (locate): no suffix array at this size"]},
-           "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "extra": {"keys_per_query": round(n_keys / (args.batch * args.steps), 1), "phase_ms_one_batch": {k: round(v, 2) for k, v in phases.items()}}}
-    os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if parity is not None and parity["mismatches"]:
-        log("PARITY FAILURE", json.dumps({k: v for k, v in parity["by_kind"].items() if v.get("mismatches")}))
-        sys.exit(3)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -598,9 +435,12 @@ def main():
     ap.add_argument("--no-joint-decode", action="store_true", help="body and title decodes as two loops of batch x beams rows (the reference's "
                     "order) instead of one loop of 2 x batch x beams rows")
     ap.add_argument("--workload", choices=["nq", "stress"], default="nq", help="nq: BASELINE configs[1] (configs[3] with --docs 36000000), the "
-                    "contract's default; stress: configs[4], the 1.4e10-symbol rank/select tier with beam 30 and bf16 BART (key generation only)")
-    ap.add_argument("--stress-symbols", type=float, default=1.4e10)
+                    "contract's default; stress: configs[4], the same complete search over 100 M synthetic passages (1.4e10 symbols: 40-bit suffix "
+                    "array sorted in slices, fmi_build_device_sliced) with beam 30 and a bf16 BART-large")
+    ap.add_argument("--slice-rows", type=int, default=1 << 29, help="stress workload: suffixes per slice of the suffix-array construction")
     ap.add_argument("--bf16-tol", type=float, default=0.25, help="stress workload: tolerance of the bf16 hypothesis scores against HF's bf16 forward")
+    ap.add_argument("--cpu-locate-sample", type=int, default=0, help="CPU oracle replay: every k-th located row / every k-th document only "
+                    "(0: all at nq, 64 at stress: sdsl's sampled suffix array costs ~31 LF steps per row on the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-other-depth", action="store_true", help="also time the same batches through the other retrieval depth "
                     "(first stage only <-> complete search); first-stage-only aggregates on the host and is slow on the phrase corpus")
@@ -649,14 +489,18 @@ def main():
     # with the stacks of all threads instead of sitting on the GPU until somebody's outer limit: the default run takes ~90 s,
     # the stress tier ~6 min.  SEAL_BENCH_WATCHDOG_S=0 turns it off.
     import faulthandler
-    limit = float(os.environ.get("SEAL_BENCH_WATCHDOG_S", 2400 if args.workload == "stress" else 900 + 20 * max(0, args.steps - 20)))
+    stress = args.workload == "stress"
+    limit = float(os.environ.get("SEAL_BENCH_WATCHDOG_S", 2400 if stress else 900 + 20 * max(0, args.steps - 20)))
     if limit > 0:
         faulthandler.dump_traceback_later(limit, exit=True)
-    if args.workload == "stress":
+    if stress:
         assert world == 1, "the stress workload is a single-GPU measurement"
         if "--beam" not in sys.argv:
             args.beam = 30
-        return run_stress(args, dev, real_stdout)
+        if "--docs" not in sys.argv and "SEAL_BENCH_DOCS" not in os.environ:
+            args.docs = 100_000_000
+        if not args.cpu_locate_sample:
+            args.cpu_locate_sample = 64
     force_dist = bool(os.environ.get("SEAL_BENCH_FORCE_DIST"))     # exercise the RCCL path with one rank
     use_dist = world > 1 or force_dist
     if use_dist:
@@ -677,21 +521,28 @@ def main():
         dist.barrier()
 
     t0 = time.perf_counter()
-    data, beg, title_len, ids_by_rank = synth_corpus(args.docs, dev, seed=0, phrases=args.corpus_phrases)
+    data, beg, title_len, ids_by_rank = synth_corpus(args.docs, dev, seed=0, phrases=args.corpus_phrases, text16=stress)
     torch.cuda.synchronize()
-    log(f"corpus: {args.docs} docs, {data.numel()} symbols in {time.perf_counter() - t0:.1f}s")
+    log(f"corpus: {args.docs} docs, {data.numel() - (1 if stress else 0)} symbols in {time.perf_counter() - t0:.1f}s")
     n_batches = args.warmup + args.steps + 1
     queries, bias = synth_queries(n_batches * args.batch, data, beg, title_len, ids_by_rank, dev, seed=1 + rank)
     t0 = time.perf_counter()
     index = FMIndex()
-    index.initialize_from_device(data, beg.tolist())
+    if stress:
+        # the corpus IS the resident text (nothing copied: no room for a second 28 GB); the suffix array is sorted in slices
+        torch.cuda.empty_cache()
+        index.initialize_from_device_text(data, beg.tolist(), slice_rows=args.slice_rows)
+        _text = device_array(index, "text", "<i2")
+        text_is_input = _text.data_ptr() == data.data_ptr() and bool(_text[-1] == 0)
+    else:
+        index.initialize_from_device(data, beg.tolist())
+        # the index's resident text must be the corpus it was given (+ the sentinel): what sa_audit compares suffixes of
+        _text = device_array(index, "text", "<i2" if index_sym_bytes(index) == 2 else "<i4")
+        text_is_input = bool(_text[-1] == 0)
+        for a0 in range(0, data.numel(), 1 << 28):
+            b0 = min(data.numel(), a0 + (1 << 28))
+            text_is_input &= bool(torch.equal(_text[a0:b0].to(torch.int32) & (0xFFFF if _text.dtype == torch.int16 else 0x7FFFFFFF), data[a0:b0]))
     index.labels = None
-    # the index's resident text must be the corpus it was given (+ the sentinel): what sa_audit compares suffixes of
-    _text = device_array(index, "text", "<i2" if index_sym_bytes(index) == 2 else "<i4")
-    text_is_input = bool(_text[-1] == 0)
-    for a0 in range(0, data.numel(), 1 << 28):
-        b0 = min(data.numel(), a0 + (1 << 28))
-        text_is_input &= bool(torch.equal(_text[a0:b0].to(torch.int32) & (0xFFFF if _text.dtype == torch.int16 else 0x7FFFFFFF), data[a0:b0]))
     del data, _text
     torch.cuda.empty_cache()
     log(f"index: n={index.size()} levels={lib().fmi_levels(index.handle)} HBM={index.device_bytes() / 2**30:.1f} GiB "
@@ -708,7 +559,9 @@ def main():
     with torch.no_grad():
         for tok in (cfg.pad_token_id, cfg.bos_token_id, VOCAB - 1):      # reference retrieval.py:584-588
             model.final_logits_bias[0, tok] = float("-inf")
-    log(f"BART-large random init (fp32) in {time.perf_counter() - t0:.1f}s")
+    if stress:
+        model.to(torch.bfloat16)          # BASELINE configs[4]: bf16 BART decode (fused kernels: bf16 storage, fp32 accumulation)
+    log(f"BART-large random init ({'bf16' if stress else 'fp32'}) in {time.perf_counter() - t0:.1f}s")
 
     searcher = SEALSearcher(index, None, model, add_query_to_keys=not args.no_query_keys, detokenize=False, first_stage_only=args.first_stage_only,
                             beam=args.beam, batch_size=args.batch, jobs=args.jobs, pipeline=args.pipeline, overlap=not args.no_overlap,
@@ -959,8 +812,11 @@ def main():
         occ = np.asarray(index.occurring_distinct)
         trace.append(("ranges", [[int(t)] for t in rng.choice(occ, size=5000 * args.batch)], None, None))
         n_real_ops = len(trace) - 1
-        rep, answers = replay_on_cpu(orc, trace, index.beginnings, threads)
-        parity = parity_check(index, trace[:n_real_ops], answers[:n_real_ops])
+        stride = max(1, int(args.cpu_locate_sample))
+        rep, answers = replay_on_cpu(orc, trace, index.beginnings, threads, locate_stride=stride)
+        parity = parity_check(index, trace[:n_real_ops], answers[:n_real_ops], locate_stride=stride)
+        if stride > 1:
+            parity["locate_and_document_sample"] = f"every {stride}th located row / fully scored document (the host walks ~31 LF steps per row)"
         # the evidence aggregation itself (first stage + full-document scoring on the GPU) against the bit-exact host
         # routines (fmi_first_stage / fmi_full_score) on the same keys: ranked documents, float64 scores, accepted keys
         t0 = time.perf_counter()
@@ -992,9 +848,13 @@ def main():
         # against HF's own fp32 forward at this geometry (north_star: beam scores within 1e-4)
         t0 = time.perf_counter()
         lo_q = (args.warmup + args.steps) * args.batch
-        sp = score_parity(searcher, model, index, queries[lo_q:lo_q + args.batch], bias[lo_q:lo_q + args.batch], dev)
+        score_tol = args.bf16_tol if stress else 1e-4
+        sp = score_parity(searcher, model, index, queries[lo_q:lo_q + args.batch], bias[lo_q:lo_q + args.batch], dev, tol=score_tol)
+        if stress:
+            for k in ("beam_scores_body", "beam_scores_title", "rescore_scores"):
+                sp[k]["arithmetic"] = "bf16 storage, fp32 accumulation, against HF's bf16 forward of the same weights (log-softmax in fp32 on both sides)"
         beam = {"values": sum(sp[k]["values"] for k in ("beam_scores_body", "beam_scores_title")),
-                "max_abs_err": max(sp[k]["max_abs_err"] for k in ("beam_scores_body", "beam_scores_title")), "tol": 1e-4,
+                "max_abs_err": max(sp[k]["max_abs_err"] for k in ("beam_scores_body", "beam_scores_title")), "tol": score_tol,
                 "mismatches": sum(sp[k]["violations"] for k in ("beam_scores_body", "beam_scores_title")),
                 "body": sp["beam_scores_body"], "title": sp["beam_scores_title"], "against": sp["beam_scores_body"]["against"]}
         parity["by_kind"]["beam_scores"] = beam
@@ -1003,7 +863,7 @@ def main():
         parity["ops"] += 3; parity["values_compared"] += beam["values"] + rs["values"]
         parity["mismatches"] += beam["mismatches"] + rs["violations"]
         log(f"score parity vs HF fp32 forward in {time.perf_counter() - t0:.1f}s: beam scores {beam['values']} values, max abs err "
-            f"{beam['max_abs_err']:.2e}; rescoring {rs['values']} values, max abs err {rs['max_abs_err']:.2e} (tol 1e-4)")
+            f"{beam['max_abs_err']:.2e}; rescoring {rs['values']} values, max abs err {rs['max_abs_err']:.2e} (tol {score_tol:g})")
         log(f"parity_check: {parity['ops']} ops, {parity['values_compared']} values, {parity['mismatches']} mismatches")
         t_cpu = rep["mask_s"] + rep["ranges_s"] + rep["locate_s"] + rep["docs_s"]
         cpu = {"value": round(args.batch / t_cpu, 3), "unit": "queries/s (FM-index path only)", "cores": threads, "kind": "port",
@@ -1015,14 +875,15 @@ def main():
 
     total_q = args.batch * args.steps * world
     out = {
-        "metric": "queries/sec, NQ-shaped FM-index, BART-large beam=15 batch=20 (p50 batch latency in extra)",
+        "metric": (f"queries/sec, 100M-passage synthetic stress FM-index, BART-large bf16 beam={args.beam} batch={args.batch} (complete search)" if stress else
+                   "queries/sec, NQ-shaped FM-index, BART-large beam=15 batch=20 (p50 batch latency in extra)"),
         "value": round(total_q / elapsed, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed * 1e3 / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"{'configs[3]: KILT-size' if args.docs >= 30_000_000 else 'configs[1]: NQ-shaped'} synthetic FM-index ({args.docs} passages, {index.size()} symbols{', phrase corpus P=%d' % args.corpus_phrases if args.corpus_phrases else ''}), random-init "
-                               f"BART-large fp32, beam={args.beam}, batch={args.batch} per GPU, body len 10 + title len<=15, "
+        "config": {"workload": f"{'configs[4]: 100M-document stress tier, suffix array sorted in slices,' if stress else 'configs[3]: KILT-size' if args.docs >= 30_000_000 else 'configs[1]: NQ-shaped'} synthetic FM-index ({args.docs} passages, {index.size()} symbols{', phrase corpus P=%d' % args.corpus_phrases if args.corpus_phrases else ''}), random-init "
+                               f"BART-large {'bf16' if stress else 'fp32'}, beam={args.beam}, batch={args.batch} per GPU, body len 10 + title len<=15, "
                                f"{'first-stage retrieval' if args.first_stage_only else 'first stage + full-document rescoring of 1500 docs/query'}, top-{args.topk}",
-                   "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated; " + ("next batch's decodes enqueued ahead of this batch's rescoring/aggregation (2 streams)" if not args.no_overlap and args.pipeline <= 1 else f"{args.pipeline} query batches in flight per GPU"), "model_arithmetic": "fp32 (as the reference runs BART)",
+                   "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated; " + ("decodes of the next two batches enqueued ahead of this batch's rescoring / aggregation; the two GEMM-bearing phases (decode, rescoring) alternate on the GPU, the aggregation overlaps both on the index's stream" if not args.no_overlap and args.pipeline <= 1 else f"{args.pipeline} query batches in flight per GPU"), "model_arithmetic": "bf16 storage, fp32 accumulation (BASELINE configs[4])" if stress else "fp32 (as the reference runs BART); linear layers of >= 0.9 GFLOP as one fp16 GEMM over three planes with fp32 accumulation (seal_amd/split_gemm.py), scores within 1e-4 of HF's fp32 forward",
                    "decodes": "body + title of a batch as two loops" if args.no_joint_decode else "body + title of a batch as ONE loop (2 x batch x beams rows per model step, one constraint launch per step)",
                    "query_ngram_keys": "off" if args.no_query_keys else "token 1..3-grams of the query ids (add_query_to_keys=True, the reference's default; "
                                                                                  "spaCy/BART tokenizer absent offline: seal_amd.query_keys.token_ngram_keys)",

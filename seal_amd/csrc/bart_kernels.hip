@@ -47,7 +47,12 @@ static __device__ __forceinline__ bool store_planes4(__half *prow, uint32_t d, u
         const float a = fabsf(in[j]);
         over |= a > 65504.f && a < __builtin_huge_valf();
         hi[j] = __float2half_rn(in[j]);
-        lo[j] = __float2half_rn((in[j] - __half2float(hi[j])) * 2048.f);
+        // lo is the remainder against the hi that is STORED: its bits go through an opaque register move, so that the compiler cannot
+        // derive the subtrahend from `in` by another route (seen on gfx950 inside k_gelu_planes: at exact ties between two fp16 values
+        // the stored hi was rounded to even, the one subtracted toward zero -- lo came out with the wrong sign, 8 of 315 392 elements)
+        unsigned short hb = __half_as_ushort(hi[j]);
+        asm volatile("" : "+v"(hb));
+        lo[j] = __float2half_rn((in[j] - __half2float(__ushort_as_half(hb))) * 2048.f);
     }
     __half *o = prow + 4 * (uint64_t)i;
     *(uint2 *)o = *(const uint2 *)hi;
@@ -485,7 +490,9 @@ __global__ __launch_bounds__(256) void k_split_planes(const float *x, uint32_t r
         const float a = fabsf(in[j]);
         over |= a > 65504.f && a < __builtin_huge_valf();
         hi[j] = __float2half_rn(in[j]);
-        lo[j] = __float2half_rn((in[j] - __half2float(hi[j])) * 2048.f);
+        unsigned short hb = __half_as_ushort(hi[j]);      // (see store_planes4: the remainder against the STORED hi)
+        asm volatile("" : "+v"(hb));
+        lo[j] = __float2half_rn((in[j] - __half2float(__ushort_as_half(hb))) * 2048.f);
     }
     __half *o = out + (uint64_t)r * 3 * K + c;
     *(uint2 *)o = *(const uint2 *)hi;

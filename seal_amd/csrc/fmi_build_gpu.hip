@@ -19,6 +19,8 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_reduce.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/functional.hpp>
 
 #include <algorithm>
@@ -553,28 +555,28 @@ __global__ void k_slice_heads0(const uint64_t *keys, uint64_t m, uint32_t *gs)
     GRID_STRIDE(j, m) gs[j] = (j == 0 || keys[j] != keys[j - 1]) ? (uint32_t)j : 0u;
 }
 
-// ... after a refinement round: head where the old group or the new key changes
-__global__ void k_slice_heads(const uint32_t *gid, const uint64_t *keys, uint64_t m, uint32_t *gs)
+// a suffix is unresolved while it shares its group with another one
+__global__ void k_slice_unresolved(const uint32_t *gid, uint64_t m, uint8_t *flags)
 {
-    GRID_STRIDE(j, m) gs[j] = (j == 0 || gid[j] != gid[j - 1] || keys[j] != keys[j - 1]) ? (uint32_t)j : 0u;
+    GRID_STRIDE(j, m) flags[j] = !(gid[j] == (uint32_t)j && (j + 1 == m || gid[j + 1] == (uint32_t)(j + 1)));
 }
 
-__global__ void k_count_group_heads(const uint32_t *gid, uint64_t m, unsigned long long *n_groups)
-{
-    unsigned long long local = 0;
-    GRID_STRIDE(j, m) local += (gid[j] == (uint32_t)j);
-    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(n_groups, local);
-}
-
-// key of the next `per` symbols of every suffix of the slice; a suffix that is alone in its group keeps key 0 (nothing left to decide)
+// key of the `per` symbols at depth `depth` of the given suffixes
 template <typename SymT>
-__global__ void k_slice_next_keys(const SymT *text, uint64_t n, uint32_t bits, uint32_t per, uint64_t depth, const uint64_t *pos, const uint32_t *gid,
-                                  uint64_t m, uint64_t *keys)
+__global__ void k_keys_at(const SymT *text, uint64_t n, uint32_t bits, uint32_t per, uint64_t depth, const uint64_t *pos, uint64_t m, uint64_t *keys)
 {
-    GRID_STRIDE(j, m) {
-        const bool alone = gid[j] == (uint32_t)j && (j + 1 == m || gid[j + 1] == (uint32_t)(j + 1));
-        keys[j] = alone ? 0ull : key_at(text, n, pos[j] + depth, bits, per);
+    GRID_STRIDE(j, m) keys[j] = key_at(text, n, pos[j] + depth, bits, per);
+}
+
+// the re-ordered unresolved suffixes go back to the unresolved slots (ascending: group after group); a slot starts a group where the
+// old group or the new key changes (group heads carry their own slot number, the rest 0: the next max-scan fills them in)
+__global__ void k_slice_write_back(const uint32_t *act_slot, const uint64_t *apos, const uint32_t *sg, const uint64_t *akey, uint64_t A, uint64_t *pos,
+                                   uint32_t *gid)
+{
+    GRID_STRIDE(j, A) {
+        const uint32_t slot = act_slot[j];
+        pos[slot] = apos[j];
+        gid[slot] = (j == 0 || sg[j] != sg[j - 1] || akey[j] != akey[j - 1]) ? slot : 0u;
     }
 }
 
@@ -655,21 +657,24 @@ int build_sliced_impl(fmi *h, const SymT *text, uint64_t n, int device, uint64_t
         n_slices = std::min<uint32_t>(n_slices * 2, 1000);          // skewed keys: cut finer and look again
     }
     const uint64_t cap = *std::max_element(counts.begin(), counts.end());
-    // ---- slice workspace ----
-    uint64_t *posA = nullptr, *posB = nullptr, *keyA = nullptr, *keyB = nullptr;
-    uint32_t *gid = nullptr, *gid2 = nullptr, *permA = nullptr, *permB = nullptr;
-    HIPCHK(pool.alloc(&posA, cap)); HIPCHK(pool.alloc(&posB, cap)); HIPCHK(pool.alloc(&keyA, cap)); HIPCHK(pool.alloc(&keyB, cap));
-    HIPCHK(pool.alloc(&gid, cap)); HIPCHK(pool.alloc(&gid2, cap)); HIPCHK(pool.alloc(&permA, cap)); HIPCHK(pool.alloc(&permB, cap));
-    size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    // ---- slice workspace (~65 B per suffix of the largest slice) ----
+    uint64_t *pos = nullptr, *aposA = nullptr, *aposB = nullptr, *akeyA = nullptr, *akeyB = nullptr;
+    uint32_t *gid = nullptr, *act_slot = nullptr, *agidA = nullptr, *agidB = nullptr, *permA = nullptr, *permB = nullptr;
+    uint8_t *flags = nullptr;
+    HIPCHK(pool.alloc(&pos, cap)); HIPCHK(pool.alloc(&aposA, cap)); HIPCHK(pool.alloc(&aposB, cap)); HIPCHK(pool.alloc(&akeyA, cap)); HIPCHK(pool.alloc(&akeyB, cap));
+    HIPCHK(pool.alloc(&gid, cap)); HIPCHK(pool.alloc(&act_slot, cap)); HIPCHK(pool.alloc(&agidA, cap)); HIPCHK(pool.alloc(&agidB, cap));
+    HIPCHK(pool.alloc(&permA, cap)); HIPCHK(pool.alloc(&permB, cap)); HIPCHK(pool.alloc(&flags, cap));
+    size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
     {
-        rocprim::double_buffer<uint64_t> k64(keyA, keyB), v64(posA, posB);
-        rocprim::double_buffer<uint32_t> k32(gid, gid2), v32(permA, permB);
+        rocprim::double_buffer<uint64_t> k64(akeyA, akeyB), v64(aposA, aposB);
+        rocprim::double_buffer<uint32_t> k32(agidA, agidB), v32(permA, permB);
         HIPCHK(rocprim::radix_sort_pairs(nullptr, t1, k64, v64, cap, 0u, 64u, st));
         HIPCHK(rocprim::radix_sort_pairs(nullptr, t2, k64, v32, cap, 0u, 64u, st));
         HIPCHK(rocprim::radix_sort_pairs(nullptr, t3, k32, v32, cap, 0u, 32u, st));
         HIPCHK(rocprim::inclusive_scan(nullptr, t4, (uint32_t *)nullptr, (uint32_t *)nullptr, cap, rocprim::maximum<uint32_t>(), st));
+        HIPCHK(rocprim::select(nullptr, t5, rocprim::counting_iterator<uint32_t>(0), (uint8_t *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr, cap, st));
     }
-    const size_t tmp_bytes = std::max(std::max(t1, t2), std::max(t3, t4)) + 256;
+    const size_t tmp_bytes = std::max(std::max(std::max(t1, t2), std::max(t3, t4)), t5) + 256;
     void *tmp = nullptr;
     HIPCHK(pool.alloc((char **)&tmp, tmp_bytes));
     const uint32_t key_bits = std::min<uint32_t>(64u, per * L);
@@ -677,66 +682,66 @@ int build_sliced_impl(fmi *h, const SymT *text, uint64_t n, int device, uint64_t
     for (size_t sl = 0; sl < counts.size(); sl++) {
         const uint64_t m = counts[sl];
         if (m == 0) continue;
+        // ---- the slice's suffixes, sorted by their first `per` symbols ----
         HIPCHK(hipMemsetAsync(d_cursor, 0, 8, st));
         hipLaunchKernelGGL((k_collect_slice<SymT>), dim3(grid_for(n)), dim3(256), 0, st, text, n, L, per, sl ? split[sl - 1] : 0ull,
-                           sl < split.size() ? split[sl] : 0ull, (int)(sl == 0), (int)(sl == split.size()), posA, keyA, d_cursor);
-        uint64_t *pos = posA, *pos_alt = posB, *key = keyA, *key_alt = keyB;
+                           sl < split.size() ? split[sl] : 0ull, (int)(sl == 0), (int)(sl == split.size()), aposA, akeyA, d_cursor);
         {
-            rocprim::double_buffer<uint64_t> dk(key, key_alt), dv(pos, pos_alt);
+            rocprim::double_buffer<uint64_t> dk(akeyA, akeyB), dv(aposA, aposB);
             size_t tb = tmp_bytes;
             HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, m, 0u, key_bits, st));
-            key = dk.current(); key_alt = dk.alternate(); pos = dv.current(); pos_alt = dv.alternate();
+            HIPCHK(hipMemcpyAsync(pos, dv.current(), m * 8, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_slice_heads0, dim3(grid_for(m)), dim3(TB), 0, st, (const uint64_t *)dk.current(), m, gid);
         }
-        uint32_t *g = gid, *g_other = gid2;           // g: group ids in the current order; g_other: free
-        hipLaunchKernelGGL(k_slice_heads0, dim3(grid_for(m)), dim3(TB), 0, st, (const uint64_t *)key, m, g);
         uint32_t gbits = 1;
         while (gbits < 32 && (m >> gbits)) gbits++;
+        // ---- refinement: the suffixes that still share a group, `per` symbols deeper per round ----
         uint64_t depth = 0;
         for (int round = 0;; round++) {
             size_t sb = tmp_bytes;
-            HIPCHK(rocprim::inclusive_scan(tmp, sb, g, g, m, rocprim::maximum<uint32_t>(), st));         // g[j] = index of j's group head
-            unsigned long long groups = 0;
-            HIPCHK(hipMemsetAsync(d_cursor, 0, 8, st));
-            hipLaunchKernelGGL(k_count_group_heads, dim3(grid_for(m)), dim3(TB), 0, st, (const uint32_t *)g, m, d_cursor);
-            HIPCHK(hipMemcpy(&groups, d_cursor, 8, hipMemcpyDeviceToHost));
-            if (groups == m) break;
+            HIPCHK(rocprim::inclusive_scan(tmp, sb, gid, gid, m, rocprim::maximum<uint32_t>(), st));       // gid[j] = slot of j's group head
+            hipLaunchKernelGGL(k_slice_unresolved, dim3(grid_for(m)), dim3(TB), 0, st, (const uint32_t *)gid, m, flags);
+            sb = tmp_bytes;
+            HIPCHK(rocprim::select(tmp, sb, rocprim::counting_iterator<uint32_t>(0), flags, act_slot, d_cursor, m, st));
+            unsigned long long A = 0;
+            HIPCHK(hipMemcpy(&A, d_cursor, 8, hipMemcpyDeviceToHost));
+            if (A == 0) break;
             depth += per;
             if (depth > n || round > 1000000) { fmi_set_error("fmi_build_device_sliced: the suffixes of slice %zu did not separate", sl); return FMI_ERR_STATE; }
-            // stable LSD over (group, next key): by the next key first ...
-            hipLaunchKernelGGL((k_slice_next_keys<SymT>), dim3(grid_for(m)), dim3(TB), 0, st, text, n, L, per, depth, (const uint64_t *)pos,
-                               (const uint32_t *)g, m, key);
-            hipLaunchKernelGGL(k_iota32, dim3(grid_for(m)), dim3(TB), 0, st, permA, m);
+            hipLaunchKernelGGL(k_gather_by<uint64_t>, dim3(grid_for(A)), dim3(TB), 0, st, (const uint64_t *)pos, (const uint32_t *)act_slot, aposA, A);
+            hipLaunchKernelGGL(k_gather_by<uint32_t>, dim3(grid_for(A)), dim3(TB), 0, st, (const uint32_t *)gid, (const uint32_t *)act_slot, agidA, A);
+            hipLaunchKernelGGL((k_keys_at<SymT>), dim3(grid_for(A)), dim3(TB), 0, st, text, n, L, per, depth, (const uint64_t *)aposA, A, akeyA);
+            hipLaunchKernelGGL(k_iota32, dim3(grid_for(A)), dim3(TB), 0, st, permA, A);
+            // stable LSD over (group, next key): by the next key ...
             uint32_t *perm = permA, *perm_alt = permB;
             {
-                rocprim::double_buffer<uint64_t> dk(key, key_alt);
+                rocprim::double_buffer<uint64_t> dk(akeyA, akeyB);
                 rocprim::double_buffer<uint32_t> dv(perm, perm_alt);
                 size_t tb = tmp_bytes;
-                HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, m, 0u, key_bits, st));
-                key = dk.current(); key_alt = dk.alternate(); perm = dv.current(); perm_alt = dv.alternate();
+                HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, A, 0u, key_bits, st));
+                perm = dv.current(); perm_alt = dv.alternate();
             }
-            // ... then by the group: every group is back in its own index range [head, head + size), now in (next key) order inside.
-            // The values carried through both sorts are the indices the round started with.
-            hipLaunchKernelGGL(k_gather_by<uint32_t>, dim3(grid_for(m)), dim3(TB), 0, st, (const uint32_t *)g, (const uint32_t *)perm, g_other, m);
+            // ... then by the group: the unresolved suffixes of a group are back in the group's own slots, in (next key) order
+            hipLaunchKernelGGL(k_gather_by<uint32_t>, dim3(grid_for(A)), dim3(TB), 0, st, (const uint32_t *)agidA, (const uint32_t *)perm, agidB, A);
+            uint32_t *sg = nullptr;
             {
-                rocprim::double_buffer<uint32_t> dk(g_other, g), dv(perm, perm_alt);       // (g, the ids in the old order, is free now: the sort's alternate)
+                rocprim::double_buffer<uint32_t> dk(agidB, agidA), dv(perm, perm_alt);       // (agidA, the ids in the old order, is free now)
                 size_t tb = tmp_bytes;
-                HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, m, 0u, gbits, st));
-                g = dk.current(); g_other = dk.alternate(); perm = dv.current(); perm_alt = dv.alternate();
+                HIPCHK(rocprim::radix_sort_pairs(tmp, tb, dk, dv, A, 0u, gbits, st));
+                sg = dk.current(); perm = dv.current();
             }
-            hipLaunchKernelGGL(k_gather_by<uint64_t>, dim3(grid_for(m)), dim3(TB), 0, st, (const uint64_t *)pos, (const uint32_t *)perm, pos_alt, m);
-            std::swap(pos, pos_alt);
-            // the next keys once more, in the new order (cheaper than carrying 8 more bytes through the second sort), then the finer groups
-            hipLaunchKernelGGL((k_slice_next_keys<SymT>), dim3(grid_for(m)), dim3(TB), 0, st, text, n, L, per, depth, (const uint64_t *)pos,
-                               (const uint32_t *)g, m, key);
-            hipLaunchKernelGGL(k_slice_heads, dim3(grid_for(m)), dim3(TB), 0, st, (const uint32_t *)g, (const uint64_t *)key, m, g_other);
-            std::swap(g, g_other);
+            hipLaunchKernelGGL(k_gather_by<uint64_t>, dim3(grid_for(A)), dim3(TB), 0, st, (const uint64_t *)aposA, (const uint32_t *)perm, aposB, A);
+            hipLaunchKernelGGL((k_keys_at<SymT>), dim3(grid_for(A)), dim3(TB), 0, st, text, n, L, per, depth, (const uint64_t *)aposB, A, akeyA);
+            hipLaunchKernelGGL(k_slice_write_back, dim3(grid_for(A)), dim3(TB), 0, st, (const uint32_t *)act_slot, (const uint64_t *)aposB, (const uint32_t *)sg,
+                               (const uint64_t *)akeyA, (uint64_t)A, pos, gid);
         }
         hipLaunchKernelGGL(k_store_sa, dim3(grid_for(m)), dim3(TB), 0, st, (const uint64_t *)pos, m, base, sa_lo, sa_hi);
         HIPCHK(hipStreamSynchronize(st));
         base += m;
     }
     if (base != n) { fmi_set_error("fmi_build_device_sliced: %llu of %llu suffixes placed", (unsigned long long)base, (unsigned long long)n); return FMI_ERR_STATE; }
-    for (void *p : {(void *)posA, (void *)posB, (void *)keyA, (void *)keyB, (void *)gid, (void *)gid2, (void *)permA, (void *)permB, tmp}) pool.release(p);
+    for (void *p : {(void *)pos, (void *)aposA, (void *)aposB, (void *)akeyA, (void *)akeyB, (void *)gid, (void *)act_slot, (void *)agidA, (void *)agidB, (void *)permA,
+                    (void *)permB, (void *)flags, tmp}) pool.release(p);
 
     // ---- BWT, wavelet matrix, tables ----
     SymT *bwt = nullptr;

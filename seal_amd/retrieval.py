@@ -519,6 +519,9 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
             encoded=(codes.enc, codes.attention_mask) if tokenised and codes.enc is not None else None)))
         slots.append("code")
     if jobs:
+        gate = s.__dict__.get("_gemm_gate")
+        if gate is not None:
+            gate()              # the overlapped search: the rescoring forward (library GEMMs) waits for the decodes enqueued so far
         pend = dict(zip(slots, rk.rescore_keys_multi(jobs, pending=True)))
         body_job, cand_job, title_job, code_job = pend.get("body"), pend.get("cand"), pend.get("title"), pend.get("code")
     yield "rescoring"                            # everything of this batch up to the scores is enqueued; nothing read back yet
@@ -913,9 +916,13 @@ class SEALSearcher:
                 import cProfile
                 pprof = self.__dict__.setdefault("_post_prof", cProfile.Profile())
                 pprof.enable()
-            wait_for("decode", post)
-            with torch.cuda.stream(post):
-                advance(cur, "rescoring")
+            # (the filters' count launch and copies run beside the decodes; only the rescoring forward is fenced, from inside the step)
+            self.__dict__["_gemm_gate"] = lambda: wait_for("decode", post)
+            try:
+                with torch.cuda.stream(post):
+                    advance(cur, "rescoring")
+            finally:
+                self.__dict__.pop("_gemm_gate", None)
             after("rescore", post)
             if exclusive:
                 # GPU order: decode(i+1) [enqueued one iteration ago] -> rescoring(i) [just enqueued: it waits for that decode only] ->
