@@ -396,9 +396,10 @@ class BartStepDecoder:
     @torch.no_grad()
     def tree_hidden_graph(self, tok, depth, anc, qidx, enc_hidden, attention_mask):
         """``tree_logits(..., hidden_only=True)`` through the fused kernels as ONE hipGraph replay (the forward over a prefix tree
-        is ~160 launches that the host would otherwise issue one by one, 10 ms per batch of the searcher).  OPT-IN
-        (``SEAL_RESCORE_GRAPH=1``): on a fast host the search is GPU-bound and the padded nodes cost more than the launches save --
-        measured on one box 247 vs 256 queries/s, rescoring 27.7 vs 23.8 ms per batch; it is there for slow hosts.
+        is ~160 launches that the host would otherwise issue one by one, 10 ms per batch of the searcher).  On by default since
+        round 4 (``SEAL_RESCORE_GRAPH=0``: launch by launch): with the split GEMM the search is bound by its one python thread,
+        and the launches saved are worth more than the padded nodes cost -- 217 -> 236 queries/s (profiles/r4_soak_ab.txt; round 3,
+        GPU-bound on fp32 GEMMs, measured the opposite: 256 -> 247).
         Shapes are made static: the node count is rounded up to ``TREE_NODE_BUCKET`` (the rows behind the real nodes keep whatever
         valid nodes an earlier call left there; their results are ignored), the encoder length to 16, the ancestor table to 17
         columns; one graph per (nodes, encoder length, queries) bucket, captured on first use, cross-attention K/V of the queries
@@ -543,11 +544,11 @@ class BartStepDecoder:
     # position 0 of the cache is written for the first beam's row only and the ancestry table points the other beams at it,
     # and the logits row is handed to all K beams.  Self-attention over the single position 0 is softmax([s]) = [1]:
     # the output is V itself, as sealnn_self_attn_step computes it (1.0 * v / 1.0).
-    # OFF by default (SEAL_SHARED_FIRST_STEP=1 turns it on): correct on its own (tests/test_gpu_decode.py::test_first_step_shared_...)
-    # and in complete searches of overlapped batches (tools/first_step_probe.py: 8 of 9 runs), but bench.py with it on stopped making
-    # progress on the GPU three times out of three (profiles/r3_shared_first_step_hang.txt).  Until that is
-    # understood the full-width first step stays.
-    shared_first_step = __import__("os").environ.get("SEAL_SHARED_FIRST_STEP", "0") == "1"
+    # ON by default since round 4 (SEAL_SHARED_FIRST_STEP=0: the full-width first step).  Round 3 kept it off because bench.py stalled
+    # with it on; the stall was never this path's -- it was two library GEMM streams in flight at once (a TunableOp pick of the lm_head
+    # GEMM then), which the searcher no longer allows.  Clean in every soak run of round 4
+    # (profiles/r4_soak_*.txt), +2..6 % queries/s.
+    shared_first_step = __import__("os").environ.get("SEAL_SHARED_FIRST_STEP", "1") == "1"
 
     def _step_static_first(self, st):
         from ._lib import check

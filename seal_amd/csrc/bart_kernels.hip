@@ -39,25 +39,29 @@ template <> __device__ __forceinline__ void st4<bf16>(bf16 *row, uint32_t i, flo
 // returns whether one of them is finite and beyond fp16's range
 static __device__ __forceinline__ bool store_planes4(__half *prow, uint32_t d, uint32_t i, float4 v)
 {
-    const float in[4] = {v.x, v.y, v.z, v.w};
-    __half hi[4], lo[4];
+    float in[4] = {v.x, v.y, v.z, v.w};
+    unsigned short hi[4], lo[4];
     bool over = false;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
+        // ONE value of the element and ONE conversion of it feed both planes: the element and the 16 bits of hi go through opaque
+        // register moves, so that the stored hi and the hi that lo is the remainder against cannot come from two evaluations (seen on
+        // gfx950 inside k_gelu_planes: where gelu(x) sits on a tie between two fp16 values the stored hi was the even neighbour, the
+        // subtracted one the other -- lo came out with the wrong sign on 8 of 315 392 elements)
+        asm volatile("" : "+v"(in[j]));
         const float a = fabsf(in[j]);
         over |= a > 65504.f && a < __builtin_huge_valf();
-        hi[j] = __float2half_rn(in[j]);
-        // lo is the remainder against the hi that is STORED: its bits go through an opaque register move, so that the compiler cannot
-        // derive the subtrahend from `in` by another route (seen on gfx950 inside k_gelu_planes: at exact ties between two fp16 values
-        // the stored hi was rounded to even, the one subtracted toward zero -- lo came out with the wrong sign, 8 of 315 392 elements)
-        unsigned short hb = __half_as_ushort(hi[j]);
+        unsigned short hb = __half_as_ushort(__float2half_rn(in[j]));
         asm volatile("" : "+v"(hb));
-        lo[j] = __float2half_rn((in[j] - __half2float(__ushort_as_half(hb))) * 2048.f);
+        hi[j] = hb;
+        lo[j] = __half_as_ushort(__float2half_rn((in[j] - __half2float(__ushort_as_half(hb))) * 2048.f));
     }
     __half *o = prow + 4 * (uint64_t)i;
-    *(uint2 *)o = *(const uint2 *)hi;
-    *(uint2 *)(o + d) = *(const uint2 *)hi;
-    *(uint2 *)(o + 2 * (uint64_t)d) = *(const uint2 *)lo;
+    const uint2 hw = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+    const uint2 lw = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+    *(uint2 *)o = hw;
+    *(uint2 *)(o + d) = hw;
+    *(uint2 *)(o + 2 * (uint64_t)d) = lw;
     return over;
 }
 
@@ -483,21 +487,7 @@ __global__ __launch_bounds__(256) void k_split_planes(const float *x, uint32_t r
     if (i >= (uint64_t)rows * per_row) return;
     const uint32_t r = (uint32_t)(i / per_row), c = (uint32_t)(i % per_row) * 4;
     const float4 v = *(const float4 *)(x + (uint64_t)r * K + c);
-    const float in[4] = {v.x, v.y, v.z, v.w};
-    __half hi[4], lo[4];
-    bool over = false;
-    for (int j = 0; j < 4; j++) {
-        const float a = fabsf(in[j]);
-        over |= a > 65504.f && a < __builtin_huge_valf();
-        hi[j] = __float2half_rn(in[j]);
-        unsigned short hb = __half_as_ushort(hi[j]);      // (see store_planes4: the remainder against the STORED hi)
-        asm volatile("" : "+v"(hb));
-        lo[j] = __float2half_rn((in[j] - __half2float(__ushort_as_half(hb))) * 2048.f);
-    }
-    __half *o = out + (uint64_t)r * 3 * K + c;
-    *(uint2 *)o = *(const uint2 *)hi;
-    *(uint2 *)(o + K) = *(const uint2 *)hi;
-    *(uint2 *)(o + 2 * (uint64_t)K) = *(const uint2 *)lo;
+    const bool over = store_planes4(out + (uint64_t)r * 3 * K, K, c / 4, v);
     if (over && flag) atomicAdd(flag, 1u);
 }
 

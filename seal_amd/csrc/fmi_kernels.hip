@@ -600,6 +600,10 @@ __host__ __device__ constexpr uint32_t constrain_lds_slots(uint32_t D, uint32_t 
 }
 
 static constexpr uint64_t ROWS_ONLY_FROM_DEFAULT = 0;   // prefix length from which a call takes the rows-only form (0: never; FmiOptions::rows_only_from)
+// k_constrain<.., W > 1> keeps the per-level node counters in s_cnt[0 .. dlevels - 2] and the mask of the waves that stay in
+// s_cnt[7]; waves of empty items END before the workgroup's level barriers (gfx9 s_barrier waits for the waves that have not
+// terminated: CDNA ISA "S_BARRIER ... waves that have ended are not counted"; leave_early = 0 keeps them, and a GPU test runs both)
+static_assert(FMI_MAX_DLEVELS < 7, "s_cnt[7] holds the live-wave mask: the level counters must end below it");
 static constexpr int CONSTRAIN_WG = 8;       // 39 KB of LDS per workgroup at BART's depth, two workgroups per CU
 
 // the row's group (wave-uniform: scalar compares on kernel arguments)

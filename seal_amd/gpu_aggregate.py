@@ -230,7 +230,11 @@ class _Results(Mapping):
     """``results`` of one query from the fetched records: doc -> [score, picks, None, tokens, [best ngram, best score]] by
     descending score, as ``aggregate_evidence`` returns it -- a read-only mapping over the fetched arrays whose entries are
     built when somebody asks for them (the searcher reads ids, scores and token slices of the top k straight from the arrays:
-    ``top``; 2 000 five-element entries with their lazy members per batch were 9 ms of host time nobody looked at)."""
+    ``top``; 2 000 five-element entries with their lazy members per batch were 9 ms of host time nobody looked at).
+
+    Contract (both aggregation paths): ``results`` is a ``collections.abc.Mapping`` in ranked order -- ``len``, iteration,
+    ``items()`` / ``keys()`` / ``values()``, ``[doc]``, ``in``, ``itertools.islice(results.items(), k)`` work on the host path's
+    ``dict`` and on this object alike; code that wants to mutate or serialise takes ``to_dict()`` (here) / the dict itself (host)."""
 
     def __init__(self, out, qi, k0, ngram_of):
         keep = out["keep"]
@@ -266,6 +270,10 @@ class _Results(Mapping):
 
     def items(self):
         return _ItemsOf(self)
+
+    def to_dict(self) -> dict:
+        """a plain ``dict`` (doc -> entry, ranked order) with lists for the picks and the tokens: what the host path returns"""
+        return {d: [e[0], list(e[1]), e[2], list(e[3]), list(e[4])] for d, e in ((d, self._entry(x)) for x, d in enumerate(self._docs))}
 
     def top(self, k):
         """(doc ids, scores, token arrays) of the first ``k`` documents, no entry built"""

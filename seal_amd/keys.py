@@ -361,7 +361,7 @@ def _rescore_tree_jobs(model, jobs):
     max_len = max((len(sq) for j in J for ss in j["seqs"] for sq in ss), default=0)
     prepared = None
     fused_ok = enc.is_cuda and max_len > 0 and sd.can_teacher_force(enc, max_len)
-    use_graph = fused_ok and os.environ.get("SEAL_RESCORE_GRAPH", "0") == "1"      # opt-in: see BartStepDecoder.tree_hidden_graph
+    use_graph = fused_ok and os.environ.get("SEAL_RESCORE_GRAPH", "1") == "1"      # (on by default: see BartStepDecoder.tree_hidden_graph)
     units = [(ji, qi) for ji, j in enumerate(J) for qi in range(len(j["seqs"]))]          # job-major: a job's keys stay contiguous
     groups, cur, cur_n = [], [], 0
     for ji, qi in units:

@@ -143,6 +143,18 @@ def test_gpu_aggregation_equals_the_host_routines(seed, kw, python_scoring, monk
         assert sum(len(w[0]) for w in want) > 20
         for g, w in zip(got, want):
             _same(g, w, keep)
+        # the GPU path's result object answers what callers ask of the host path's dict (Mapping contract, gpu_aggregate._Results)
+        from collections.abc import Mapping
+        from itertools import islice
+        res, host = got[0][0], want[0][0]
+        res = res.result() if hasattr(res, "result") else res
+        assert isinstance(res, Mapping) and isinstance(host, Mapping) and hasattr(res, "to_dict"), type(res)
+        n = len(res)
+        assert list(res) == list(res.keys()) == list(host)[:n] and len(res.items()) == n and len(list(res.values())) == n
+        first = next(iter(res))
+        assert first in res and res[first][0] == host[first][0] and list(islice(res.items(), 2)) == list(res.items())[:2]
+        as_dict = res.to_dict()
+        assert type(as_dict) is dict and list(as_dict) == list(res) and as_dict[first][0] == host[first][0] and as_dict[first][3] == list(host[first][3])
         # the first-stage ranking itself (keys.py:366) against the host routine
         monkeypatch.setenv("SEAL_HOST_AGGREGATE", "1")
         for (fd, fsc), (k, u) in zip(fs, jobs):

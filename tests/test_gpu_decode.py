@@ -148,8 +148,7 @@ def test_first_step_shared_by_the_beams_of_a_query(dtype):
     enc_ids[1, 6:] = 1
     bias = torch.randn(B, vocab, generator=g).to(dev)
     dec = BartStepDecoder(run)
-    assert dec.shared_first_step is False            # opt-in (SEAL_SHARED_FIRST_STEP=1): see the note at BartStepDecoder.shared_first_step
-    dec.shared_first_step = True
+    assert dec.shared_first_step is True             # the default (SEAL_SHARED_FIRST_STEP=0 turns it off)
     for rep in range(2):
         enc = dec.encode(enc_ids, enc_mask)
         dec.start(enc, enc_mask, K, T, narrow_plan=(2,))
