@@ -430,7 +430,6 @@ def main():
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--cpu-threads", type=int, default=64)
     ap.add_argument("--jobs", type=int, default=1, help="host worker processes (only used by the host aggregation routines)")
-    ap.add_argument("--pipeline", type=int, default=1, help="query batches in flight on worker threads (each on its own stream); 1 = none")
     ap.add_argument("--no-overlap", action="store_true", help="do not enqueue the next batch's decodes ahead of this batch's rescoring/aggregation")
     ap.add_argument("--no-joint-decode", action="store_true", help="body and title decodes as two loops of batch x beams rows (the reference's "
                     "order) instead of one loop of 2 x batch x beams rows")
@@ -564,12 +563,11 @@ def main():
     log(f"BART-large random init ({'bf16' if stress else 'fp32'}) in {time.perf_counter() - t0:.1f}s")
 
     searcher = SEALSearcher(index, None, model, add_query_to_keys=not args.no_query_keys, detokenize=False, first_stage_only=args.first_stage_only,
-                            beam=args.beam, batch_size=args.batch, jobs=args.jobs, pipeline=args.pipeline, overlap=not args.no_overlap,
+                            beam=args.beam, batch_size=args.batch, jobs=args.jobs, overlap=not args.no_overlap,
                             joint_decode=not args.no_joint_decode)
     from seal_amd.bart_decoder import BartStepDecoder
     model._seal_step_decoder = BartStepDecoder(model)
-    # every pipeline drives the constraint kernels through its own view of the index: count / time all of them
-    handles = [index.handle] + ([p.index.handle for p in searcher._pipelines()] if searcher._pipelined() else [])
+    handles = [index.handle]
     # The warm-up and the TIMED region run the product: no in-kernel probe counters, no event pairs around the constraint calls
     # (round 3 timed the counting instantiation of k_constrain).  Launch times and block counts for the roofline come from two
     # separate un-overlapped passes over one more batch of the same workload, after the timed region (below).
@@ -691,11 +689,10 @@ def main():
     rk.compute_unigram_scores = timed("unigram_ms", orig[2])
     rk.aggregate_evidence_batch = timed("aggregate_ms", orig[3])
     retrieval._count_filter = timed("count_filter_ms", orig[4])
-    jobs_saved, pipeline_saved, overlap_saved = searcher.jobs, searcher.pipeline, searcher.overlap
+    jobs_saved, overlap_saved = searcher.jobs, searcher.overlap
     searcher.overlap = False
     if not os.environ.get("SEAL_BENCH_KEEP_JOBS"):
         searcher.jobs = 1                                  # inline host stages: their time shows up in aggregate_ms
-    searcher.pipeline = 1                                  # one batch, on this thread: phase times are not interleaved
     # launch times: HIP events around every constraint call of this un-overlapped batch, in-kernel counters OFF (they cost the
     # wide launches a few microseconds); the recording pass below runs the same batch once more with the counters on (events
     # off) and supplies the bytes of the very same launches
@@ -738,7 +735,7 @@ def main():
     p2 = ctypes.c_uint64(_p)                               # gpu_allowed_bits issues for the parity check come later)
     for hd in handles:
         check(lib().fmi_dev_enable_probe_count(hd, 0))
-    searcher.jobs, searcher.pipeline, searcher.overlap = jobs_saved, pipeline_saved, overlap_saved
+    searcher.jobs, searcher.overlap = jobs_saved, overlap_saved
 
     # one probe = one 128-byte block of the hex wavelet matrix, counted in-kernel (distinct blocks per
     # node): the bytes THIS data structure has to read for the work
@@ -883,7 +880,7 @@ def main():
         "config": {"workload": f"{'configs[4]: 100M-document stress tier, suffix array sorted in slices,' if stress else 'configs[3]: KILT-size' if args.docs >= 30_000_000 else 'configs[1]: NQ-shaped'} synthetic FM-index ({args.docs} passages, {index.size()} symbols{', phrase corpus P=%d' % args.corpus_phrases if args.corpus_phrases else ''}), random-init "
                                f"BART-large {'bf16' if stress else 'fp32'}, beam={args.beam}, batch={args.batch} per GPU, body len 10 + title len<=15, "
                                f"{'first-stage retrieval' if args.first_stage_only else 'first stage + full-document rescoring of 1500 docs/query'}, top-{args.topk}",
-                   "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated; " + ("decodes of the next two batches enqueued ahead of this batch's rescoring / aggregation; the two GEMM-bearing phases (decode, rescoring) alternate on the GPU, the aggregation overlaps both on the index's stream" if not args.no_overlap and args.pipeline <= 1 else f"{args.pipeline} query batches in flight per GPU"), "model_arithmetic": "bf16 storage, fp32 accumulation (BASELINE configs[4])" if stress else "fp32 (as the reference runs BART); linear layers of >= 0.9 GFLOP as one fp16 GEMM over three planes with fp32 accumulation (seal_amd/split_gemm.py), scores within 1e-4 of HF's fp32 forward",
+                   "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated; " + ("decodes of the next two batches enqueued ahead of this batch's rescoring / aggregation; the two GEMM-bearing phases (decode, rescoring) alternate on the GPU, the aggregation overlaps both on the index's stream" if not args.no_overlap else "one batch after the other"), "model_arithmetic": "bf16 storage, fp32 accumulation (BASELINE configs[4])" if stress else "fp32 (as the reference runs BART); linear layers of >= 0.9 GFLOP as one fp16 GEMM over three planes with fp32 accumulation (seal_amd/split_gemm.py), scores within 1e-4 of HF's fp32 forward",
                    "decodes": "body + title of a batch as two loops" if args.no_joint_decode else "body + title of a batch as ONE loop (2 x batch x beams rows per model step, one constraint launch per step)",
                    "query_ngram_keys": "off" if args.no_query_keys else "token 1..3-grams of the query ids (add_query_to_keys=True, the reference's default; "
                                                                                  "spaCy/BART tokenizer absent offline: seal_amd.query_keys.token_ngram_keys)",

@@ -24,66 +24,10 @@ import torch
 import torch.nn.functional as F
 
 
-import contextlib
 import logging
-import threading
 
 
 logger = logging.getLogger(__name__)
-
-class _CaptureGate:
-    """hipGraph capture needs the GPU-issuing side of the process to itself: with two query pipelines on worker
-    threads a capture on one thread aborted (inside hipBLASLt) every few runs while the other thread was launching.
-    Pipeline workers hold the gate SHARED while they issue a batch (``issuing()``); a capture takes it EXCLUSIVELY
-    (``capturing()``: gives up the caller's own shared hold, waits until nobody else holds one, blocks newcomers,
-    takes the shared hold back afterwards).  Captures are rare (one per (batch, beams, S_pad, T) shape), so the
-    stall is a one-off.  Threads that never entered ``issuing()`` (the single-threaded default) pay one uncontended
-    lock."""
-
-    def __init__(self):
-        self._cond = threading.Condition()
-        self._readers = 0
-        self._writer = False
-        self._writers_waiting = 0
-        self._local = threading.local()
-
-    @contextlib.contextmanager
-    def issuing(self):
-        with self._cond:
-            while self._writer or self._writers_waiting:
-                self._cond.wait()
-            self._readers += 1
-        self._local.depth = getattr(self._local, "depth", 0) + 1
-        try:
-            yield
-        finally:
-            self._local.depth -= 1
-            with self._cond:
-                self._readers -= 1
-                self._cond.notify_all()
-
-    @contextlib.contextmanager
-    def capturing(self):
-        mine = getattr(self._local, "depth", 0)
-        with self._cond:
-            self._readers -= mine
-            self._writers_waiting += 1
-            self._cond.notify_all()
-            while self._writer or self._readers:
-                self._cond.wait()
-            self._writers_waiting -= 1
-            self._writer = True
-        try:
-            yield
-        finally:
-            with self._cond:
-                self._writer = False
-                self._readers += mine
-                self._cond.notify_all()
-
-
-CAPTURE_GATE = _CaptureGate()
-
 
 class BartStepDecoder:
     def __init__(self, model):
@@ -180,17 +124,6 @@ class BartStepDecoder:
                                            split_gemm._flag(h.device).data_ptr()))
             return self.split_gemm.from_planes(hp, w2, L["fc2"].bias)
         return self._mod(L["act"](h), L["fc2"])
-
-    def clone_for_pipeline(self) -> "BartStepDecoder":
-        """a decoder over the SAME weights with its own static buffers / captured graphs / decode position: one per
-        concurrent query-batch pipeline (the buffers of a shape are reused by every decode of that shape, so two
-        decodes in flight need two sets)"""
-        import copy
-        c = copy.copy(self)
-        c.__dict__.pop("_static_cache", None)
-        c._st = c._st_root = None
-        c.logit_bias = None
-        return c
 
     @torch.no_grad()
     def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
@@ -448,24 +381,23 @@ class BartStepDecoder:
                 prepared = self.teacher_prepare(st.enc, st.mask)
                 return self.tree_logits(st.tok, st.depth, st.anc, st.qidx, st.enc, st.mask, prepared, True)
             if st.graph is None:
-                with CAPTURE_GATE.capturing():
-                    cur = torch.cuda.current_stream(dev)
-                    side = torch.cuda.Stream(device=dev)
-                    side.wait_stream(cur)
-                    with torch.cuda.stream(side):
-                        for _ in range(2):
-                            forward()
-                    cur.wait_stream(side)
-                    g = torch.cuda.CUDAGraph()
-                    # its own capture stream: torch keeps ONE BLAS workspace per (handle, stream) and captures on a process-wide
-                    # default stream otherwise -- this graph would then share the decode graphs' workspace (stream-K partial tiles
-                    # and flags of the library's GEMMs) while it replays on another stream beside them
-                    cap = self.__dict__.get("_tree_capture_stream")
-                    if cap is None:
-                        cap = self._tree_capture_stream = torch.cuda.Stream(device=dev)
-                    with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
-                        st.hidden = forward()
-                    st.graph = g
+                cur = torch.cuda.current_stream(dev)
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        forward()
+                cur.wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                # its own capture stream: torch keeps ONE BLAS workspace per (handle, stream) and captures on a process-wide
+                # default stream otherwise -- this graph would then share the decode graphs' workspace (stream-K partial tiles
+                # and flags of the library's GEMMs) while it replays on another stream beside them
+                cap = self.__dict__.get("_tree_capture_stream")
+                if cap is None:
+                    cap = self._tree_capture_stream = torch.cuda.Stream(device=dev)
+                with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
+                    st.hidden = forward()
+                st.graph = g
         st.graph.replay()
         return st.hidden[:N]
 
@@ -644,7 +576,7 @@ class BartStepDecoder:
     def _capture(self, st, dev, first=False):
         forward = self._step_static_first if first else self._step_static
         # (never under torch.inference_mode(): see tree_hidden_graph)
-        with torch.inference_mode(False), torch.no_grad(), CAPTURE_GATE.capturing():
+        with torch.inference_mode(False), torch.no_grad():
             # warm up on a side stream, then capture (standard torch recipe); the cache contents
             # written by the warm-up steps are overwritten/masked once t is reset
             side = torch.cuda.Stream(device=dev)

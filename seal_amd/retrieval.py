@@ -118,29 +118,6 @@ def batch_generate_keys(searcher, queries, constrained_generation=True):
         offset += len(batch)
 
 
-class _Pipeline:
-    """what one of the searcher's concurrent query-batch pipelines owns: a stream, a view of the index (its own
-    constraint workspace and aggregation buffers over the shared device arrays) and step decoders with their own
-    static buffers over the shared weights"""
-
-    def __init__(self, searcher):
-        import torch
-        self.device = searcher.device
-        self.stream = torch.cuda.Stream(device=self.device)
-        self.index = searcher.fm_index.view()
-        self._decoders = {}
-
-    def decoder(self, model):
-        d = self._decoders.get(id(model))
-        if d is None:
-            from .bart_decoder import BartStepDecoder
-            base = getattr(model, "_seal_step_decoder", None)
-            if base is None:
-                base = model._seal_step_decoder = BartStepDecoder(model)
-            d = self._decoders[id(model)] = base.clone_for_pipeline()
-        return d
-
-
 # a caller that swaps this module's fm_index_generate for its own gets its own, i.e. no joint loop -- unless its stand-in
 # says ``_joint_ok`` (bench.py's phase timer wraps both entry points)
 _FM_INDEX_GENERATE = fm_index_generate
@@ -227,9 +204,9 @@ def np_clip(a, lo, hi):
     return np.clip(a, lo, hi)
 
 
-def _process_batch(searcher, inputs, constrained_generation, offset=0, pipe=None):
+def _process_batch(searcher, inputs, constrained_generation, offset=0):
     """keys of one batch of queries (reference retrieval.py:54-305)"""
-    steps = _batch_steps(searcher, inputs, constrained_generation, offset, pipe)
+    steps = _batch_steps(searcher, inputs, constrained_generation, offset)
     try:
         while True:
             next(steps)
@@ -237,7 +214,7 @@ def _process_batch(searcher, inputs, constrained_generation, offset=0, pipe=None
         return done.value
 
 
-def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
+def _batch_steps(searcher, inputs, constrained_generation, offset=0):
     """``process_batch`` of the reference (retrieval.py:54-305) as a generator in segments, so that a scheduler can
     put other work between them (``SEALSearcher._overlapped_results``):
 
@@ -250,8 +227,8 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0, pipe=None):
     The reference runs body decode -> body filters/rescoring -> query keys -> title decode -> title filters/rescoring;
     the two decodes do not depend on anything in between, so issuing them back to back changes no result."""
     s = searcher
-    fm_index = pipe.index if pipe is not None else s.fm_index
-    dec = (lambda model: dict(decoder=pipe.decoder(model))) if pipe is not None else (lambda model: {})
+    fm_index = s.fm_index
+    dec = lambda model: {}
     bias = s.logit_bias
     if bias is not None and bias.shape[0] != len(inputs):
         bias = bias[offset:offset + len(inputs)]      # one row per query of the whole call
@@ -634,15 +611,16 @@ class SEALSearcher:
         self.first_stage_only: bool = params.get("first_stage_only", False)
         # extension: False = evidence aggregation through the host checker routines instead of the GPU kernels
         self.gpu_aggregate: bool = params.get("gpu_aggregate", True)
-        # extension: query batches in flight on the GPU at a time (each batch_size queries, own stream); 1 = one after the other
-        self.pipeline: int = int(params.get("pipeline", 1))
         # extension: the post-filters of the decodes run on the history as arrays (GPU decodes); False = on python lists
         self.array_filters: bool = bool(params.get("array_filters", True))
         # extension: the decodes of a batch that share a model (body, title[, code]) run as ONE loop, rows stacked
         self.joint_decode: bool = bool(params.get("joint_decode", True))
         # extension: enqueue the next batch's decodes before this batch's rescoring / aggregation (same thread, second stream)
         self.overlap: bool = bool(params.get("overlap", True))
-        self.overlap_depth: int = int(params.get("overlap_depth", 1))     # batches of decodes kept enqueued ahead (2 measured no faster)
+        self.overlap_depth: int = int(params.get("overlap_depth", 2))     # batches of decodes kept enqueued ahead
+        # the decode and the rescoring phase (the two that run library GEMMs) ALTERNATE on the GPU instead of sharing it: two stream-K
+        # GEMM streams in flight at once stalled the GPU for ever.  False restores round 3's behaviour.
+        self.exclusive_gemm_streams: bool = bool(params.get("exclusive_gemm_streams", True))
         # extension (synthetic benchmarks): per-query additive bias on the model's next-token logits, [batch, vocab]
         self.logit_bias = None
         if "bart" in self.backbone:   # retrieval.py:480-491
@@ -758,10 +736,6 @@ class SEALSearcher:
         if self._overlapped() and added_documents is None:
             # the next batch's decodes are enqueued before this batch's rescoring / aggregation start (second stream)
             ranked = self._overlapped_results(queries, keep=k)
-        elif self._pipelined() and added_documents is None:
-            # `pipeline` query batches in flight, each on its own stream (key generation + aggregation of one batch
-            # overlap the other batches' GPU and host work)
-            ranked = self._pipelined_results(queries, keep=k)
         else:
             keys = self.batch_generate_keys(queries)
             if added_documents is not None:
@@ -805,10 +779,10 @@ class SEALSearcher:
         return retrieved
 
     # ------------------------------------------------------------------
-    # concurrent query-batch pipelines on one GPU
+    # the next batches' decodes enqueued ahead of a batch's rescoring / aggregation
     # ------------------------------------------------------------------
     def _overlapped(self) -> bool:
-        return bool(self.overlap) and int(self.pipeline) <= 1 and self.device.type == "cuda" and hasattr(self.fm_index, "handle")
+        return bool(self.overlap) and self.device.type == "cuda" and hasattr(self.fm_index, "handle")
 
     def _overlapped_results(self, queries, keep=None):
         """``(results, all_ngrams)`` per query, in query order, one batch after the other as always -- but the decodes of
@@ -850,7 +824,7 @@ class SEALSearcher:
         # has the next decode queued while the host waits for a batch's scores: throughput is bound by the host loop or by
         # decode + rescoring, whichever is longer, as before.
         exclusive = bool(getattr(self, "exclusive_gemm_streams", True)) and os.environ.get("SEAL_EXCLUSIVE_GEMM_STREAMS", "1") != "0"
-        depth = max(1, int(os.environ.get("SEAL_OVERLAP_DEPTH", getattr(self, "overlap_depth", 2 if exclusive else 1))))
+        depth = max(1, int(os.environ.get("SEAL_OVERLAP_DEPTH", self.overlap_depth if exclusive else 1)))
         ahead = []                                            # generators whose decodes are enqueued, oldest first
         nxt_i = 0
         main = torch.cuda.current_stream(dev)
@@ -963,61 +937,6 @@ class SEALSearcher:
             held = out
         if held is not None:
             yield from held
-
-    def _pipelined(self) -> bool:
-        return (int(self.pipeline) >= 2 and hasattr(self.fm_index, "view") and self.device.type == "cuda"
-                and self.gpu_aggregate and rk.gpu_aggregation_applies(self.fm_index, self._aggregate_params()))
-
-    def _pipelines(self):
-        pipes = self.__dict__.get("_pipes")
-        if pipes is None or len(pipes) != int(self.pipeline):
-            pipes = self.__dict__["_pipes"] = [_Pipeline(self) for _ in range(int(self.pipeline))]
-        return pipes
-
-    def _pipelined_results(self, queries, keep=None):
-        """``(results, all_ngrams)`` per query, in query order: the queries are cut into batches of ``batch_size`` as
-        always; up to ``pipeline`` batches are in flight, each through the whole path (decode -> filters -> rescoring
-        -> unigram scores -> evidence aggregation) on its own stream, index view and decoder buffers.  A batch gives
-        the same results whichever pipeline runs it."""
-        import queue
-        import sys
-        from concurrent.futures import ThreadPoolExecutor
-        import torch
-        pipes = self._pipelines()
-        free = queue.SimpleQueue()
-        for p in pipes:
-            free.put(p)
-        params = self._aggregate_params()
-        constrained = not self.free_generation
-        dev = self.device
-        if sys.getswitchinterval() > 1e-3:
-            sys.setswitchinterval(1e-3)         # the pipelines hand the interpreter to each other at every GPU wait
-
-        def run(batch, offset):
-            pipe = free.get()
-            try:
-                torch.cuda.set_device(dev)
-                from .bart_decoder import CAPTURE_GATE
-                with CAPTURE_GATE.issuing(), torch.cuda.stream(pipe.stream):
-                    keys = _process_batch(self, batch, constrained, offset, pipe)
-                    jobs = [(kk[0], kk[1]) if isinstance(kk, tuple) else (kk, None) for kk in keys]
-                    out = rk.aggregate_evidence_batch(jobs, pipe.index, keep=keep, gpu_aggregate=True, want_ngrams=False, **params)
-                    pipe.stream.synchronize()
-                return out
-            finally:
-                free.put(pipe)
-        pool = self.__dict__.get("_pipe_pool")
-        if pool is None or pool._max_workers != len(pipes):
-            pool = self.__dict__["_pipe_pool"] = ThreadPoolExecutor(max_workers=len(pipes), thread_name_prefix="seal-pipeline")
-        main = torch.cuda.current_stream(dev)
-        for p in pipes:
-            p.stream.wait_stream(main)          # whatever the caller queued (model weights, logit bias) is visible
-        futures, offset = [], 0
-        for batch in _chunks(queries, self.batch_size):
-            futures.append(pool.submit(run, batch, offset))
-            offset += len(batch)
-        for fut in futures:
-            yield from fut.result()
 
     def detokenize_retrieved(self, retrieved):
         """reference retrieval.py:693-712"""

@@ -85,62 +85,6 @@ def test_unsupported_modes_say_so():
                           keep_history=False)
 
 
-def test_capture_gate_gives_a_capture_the_gpu_issuing_side_to_itself():
-    """seal_amd.bart_decoder.CAPTURE_GATE: pipeline workers hold it shared while they issue a batch; a hipGraph capture on
-    one of them runs only when no other worker is inside its section, newcomers wait until it is over, two workers that
-    both want to capture do not deadlock, and a thread that never entered a section can capture right away."""
-    import threading
-    import time
-    from seal_amd.bart_decoder import _CaptureGate
-    gate = _CaptureGate()
-    log, lock = [], threading.Lock()
-
-    def note(*e):
-        with lock:
-            log.append(e)
-
-    def worker(name, captures):
-        for i in range(4):
-            with gate.issuing():
-                note(name, "in")
-                time.sleep(0.003)
-                if captures and i in (1, 2):
-                    note(name, "want")                       # from here on it issues nothing until its capture is over
-                    with gate.capturing():
-                        note(name, "cap")
-                        time.sleep(0.01)
-                        note(name, "cap-end")
-                time.sleep(0.003)
-                note(name, "out")
-    threads = [threading.Thread(target=worker, args=(n, c)) for n, c in (("a", True), ("b", True), ("c", False), ("d", False))]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(20)
-    assert not any(t.is_alive() for t in threads), "deadlock"
-    inside, holder, n_caps = set(), None, 0
-    for name, what in log:
-        if what == "in":
-            assert holder is None, (name, holder)            # nobody enters while a capture is open
-            inside.add(name)
-        elif what == "out":
-            inside.discard(name)
-        elif what == "want":
-            inside.discard(name)
-        elif what == "cap":
-            assert holder is None and inside <= {name}, (name, inside, holder)   # the others have left their sections
-            holder = name
-            n_caps += 1
-        else:
-            assert holder == name
-            holder = None
-            inside.add(name)                                 # back in its section
-    assert n_caps == 4
-    with gate.capturing():                                   # uncontended, from a thread that holds nothing
-        pass
-    assert gate._readers == 0 and not gate._writer and gate._writers_waiting == 0
-
-
 @pytest.mark.parametrize("lengths", [(6, 9), (7, 7), (5, 6, 8)])
 def test_lockstep_groups_record_what_separate_loops_record(lengths):
     """``constrained_beam_search_groups``: several decodes with their own encoder inputs / end token / forced prefix /

@@ -173,11 +173,10 @@ def test_search_detokenizes_title_and_body(jobs, monkeypatch):
 
 
 @pytest.mark.parametrize("geom", MODEL_GEOMETRIES, ids=MODEL_IDS)
-def test_pipelined_batches_give_the_results_of_sequential_batches(geom, monkeypatch):
-    """the two ways of keeping the GPU busy across batches -- ``overlap`` (next batch's decodes enqueued before this
-    batch's rescoring / aggregation, second stream) and ``pipeline`` query batches in flight on worker threads (own
-    stream, index view -- constraint workspace, incremental ranges, aggregation buffers -- and decoder buffers each)
-    -- return exactly what one batch after the other returns: same documents, bit-equal scores, same keys, in order"""
+def test_overlapped_batches_give_the_results_of_sequential_batches(geom, monkeypatch):
+    """``overlap`` (the default: the next batches' decodes enqueued ahead of this batch's rescoring / aggregation; the decode and
+    the rescoring phase alternating on the GPU -- ``exclusive_gemm_streams`` -- or sharing it as in round 3; one or two batches
+    of decodes ahead) returns exactly what one batch after the other returns: same documents, bit-equal scores, same keys, in order"""
     from seal_amd import FMIndex
     from seal_amd import retrieval
     from seal_amd.retrieval import SEALSearcher
@@ -192,16 +191,16 @@ def test_pipelined_batches_give_the_results_of_sequential_batches(geom, monkeypa
     monkeypatch.setattr(retrieval, "TITLE_MAX_LENGTH", 8)
     model = tiny_bart(vocab, **geom).to(dev)
     out = {}
-    for depth, overlap in ((1, False), (1, True), (2, False), (3, False)):
+    for depth, overlap, exclusive in ((1, False, True), (2, True, True), (1, True, True), (3, True, True), (1, True, False), (2, True, False)):
         s = SEALSearcher(ix, None, model, backbone="bart-tiny", length=6, beam=4, batch_size=2, add_query_to_keys=False,
-                         detokenize=False, pipeline=depth, overlap=overlap, include_keys=True, title_eos_token_id=TITLE_EOS,
-                         code_eos_token_id=vocab - 6, code_bos_token_id=TITLE_EOS,
+                         detokenize=False, overlap_depth=depth, overlap=overlap, exclusive_gemm_streams=exclusive, include_keys=True,
+                         title_eos_token_id=TITLE_EOS, code_eos_token_id=vocab - 6, code_bos_token_id=TITLE_EOS,
                          marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5]})
-        assert s._pipelined() is (depth > 1) and s._overlapped() is (overlap and depth == 1)
+        assert s._overlapped() is overlap
         for rep in range(2):           # the second call reuses the captured graphs and buffers
             res = s.batch_search(queries, k=10)
-            out[(depth, overlap, rep)] = [[(d.idx, d.score, list(d.raw_tokens()), d.keys) for d in docs_] for docs_ in res]
-    base = out[(1, False, 0)]
+            out[(depth, overlap, exclusive, rep)] = [[(d.idx, d.score, list(d.raw_tokens()), d.keys) for d in docs_] for docs_ in res]
+    base = out[(1, False, True, 0)]
     assert sum(len(r) for r in base) > 30
     for key, val in out.items():
         assert val == base, key
