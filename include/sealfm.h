@@ -257,8 +257,7 @@ int fmi_dev_debug_timestamps(fmi_t *h, uint64_t *d_buf, uint64_t n_words);
  * Each is read from the environment ONCE when the handle is created (SEALFM_<NAME in capitals>) and can be changed afterwards
  * here; value -1 restores the built-in choice.  Names: "constrain_waves" (1: one self-contained wave per (row, top digit)),
  * "leave_early" (0: the waves of empty items stay), "row_first" (0 / 1: never / always the row-first pair of launches),
- * "row_first_from", "rows_only_from" (prefix length in tokens from which the form is used; rows_only_from 0: never),
- * "small_row_max" (0..64: intervals of at most this many BWT rows are expanded by their row's own wave in those two forms),
+ * "row_first_from" (prefix length in tokens from which a call goes row-first),
  * "topk_narrow" (rows with more allowed tokens take the wide-row path of the top-2K kernel), "topk_legacy" (1: exact radix
  * select on wide rows).  Results are identical for every setting (tests/test_gpu_fmindex.py, tests/test_gpu_decode.py). */
 int fmi_dev_set_option(fmi_t *h, const char *name, int64_t value);

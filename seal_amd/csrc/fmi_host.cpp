@@ -46,8 +46,6 @@ FmiOptions::FmiOptions()
     leave_early = env_i64("SEALFM_LEAVE_EARLY", leave_early);
     row_first = env_i64("SEALFM_ROW_FIRST", row_first);
     row_first_from = env_i64("SEALFM_ROW_FIRST_FROM", row_first_from);
-    rows_only_from = env_i64("SEALFM_ROWS_ONLY_FROM", rows_only_from);
-    small_row_max = env_i64("SEALFM_SMALL_ROW_MAX", small_row_max);
     topk_narrow = env_i64("SEALFM_TOPK_NARROW", topk_narrow);
     topk_legacy = env_i64("SEALFM_TOPK_LEGACY", topk_legacy);
 }
@@ -59,8 +57,6 @@ int FmiOptions::set(const char *name, int64_t value)
     else if (s == "leave_early") leave_early = value < 0 ? 1 : value;
     else if (s == "row_first") row_first = value;
     else if (s == "row_first_from") row_first_from = value;
-    else if (s == "rows_only_from") rows_only_from = value;
-    else if (s == "small_row_max") small_row_max = value;
     else if (s == "topk_narrow") topk_narrow = value;
     else if (s == "topk_legacy") topk_legacy = value < 0 ? 0 : value;
     else return -1;

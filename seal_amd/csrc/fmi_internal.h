@@ -68,8 +68,6 @@ struct FmiOptions {
     int64_t leave_early = 1;        // SEALFM_LEAVE_EARLY=0: the waves of empty items stay in their workgroup
     int64_t row_first = -1;         // SEALFM_ROW_FIRST=0 / 1: never / always the row-first pair of launches (default: by prefix length)
     int64_t row_first_from = -1;    // SEALFM_ROW_FIRST_FROM=<tokens>: prefix length from which a call goes row-first (default 3; 2 from 512 rows on)
-    int64_t small_row_max = -1;     // SEALFM_SMALL_ROW_MAX=<rows>: intervals of at most this many rows are expanded by their row's own wave (default / cap 64; 0: none)
-    int64_t rows_only_from = -1;    // SEALFM_ROWS_ONLY_FROM=<tokens>: prefix length from which ONE wave per row does the whole row (0: never)
     int64_t topk_narrow = -1;       // SEALFM_TOPK_NARROW=<n>: rows of more than n allowed tokens take the wide-row path of k_row_pick
     int64_t topk_legacy = 0;        // SEALFM_TOPK_LEGACY=1: wide rows skip the thread-maxima bound (exact radix select)
     FmiOptions();

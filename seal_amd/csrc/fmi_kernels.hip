@@ -562,7 +562,6 @@ struct ConstrainArgs {
     uint64_t *tstamp;              // tools only: 8 realtime stamps (100 MHz) per wave, or null
     uint32_t groups;               // W > 1: row groups per top digit (ceil(rows / W); grid = groups * ndig0 workgroups)
     int leave_early;               // the waves of empty items leave before the level loops (see k_constrain)
-    uint64_t small_max;            // k_constrain_rows: intervals of at most this many rows are expanded by the row's own wave (<= 64; 0: none)
     RowPre *pre_rows;              // row-first calls: [rows], written by k_constrain_rows, read by k_constrain (else null)
     uint64_t *pre_child;           // [rows][16][2]: child d of the row's root node, [lo, hi) on level 1
 };
@@ -599,7 +598,6 @@ __host__ __device__ constexpr uint32_t constrain_lds_slots(uint32_t D, uint32_t 
                  : (uint32_t)exp_slots((int)D - 1) + 2 + constrain_bm_slots(D);
 }
 
-static constexpr uint64_t ROWS_ONLY_FROM_DEFAULT = 0;   // prefix length from which a call takes the rows-only form (0: never; FmiOptions::rows_only_from)
 // k_constrain<.., W > 1> keeps the per-level node counters in s_cnt[0 .. dlevels - 2] and the mask of the waves that stay in
 // s_cnt[7]; waves of empty items END before the workgroup's level barriers (gfx9 s_barrier waits for the waves that have not
 // terminated: CDNA ISA "S_BARRIER ... waves that have ended are not counted"; leave_early = 0 keeps them, and a GPU test runs both)
@@ -667,218 +665,38 @@ __device__ __forceinline__ void row_range_and_class(const FmiDev &ix, const Cons
     else { expand = true; if (hi > ix.n) hi = ix.n; }
 }
 
-// ---- rows whose interval is small: the whole tree by ONE wave, one lane per node ----
-// An interval of at most 64 rows of the BWT holds at most 64 distinct symbols, and the nodes of a level are disjoint non-empty
-// sub-intervals of it: no level of its tree has more than 64 nodes.  So the frontier of a level is one node per LANE -- both ends'
-// blocks loaded by the lane (one line when they share it, the rule for such rows), sixteen ranks per end, the children compacted into
-// the wave's 64 LDS slots by a prefix sum over the lanes -- and a row costs `dlevels` dependent accesses after its chain, whatever the
-// number of top digits its symbols spread over; the leaves go straight into the row's token bitmap (<= 64 bits: one or two atomicOr
-// per leaf-level node, no LDS bitmap, no flush).  This is what decode steps look like once the prefixes are a few tokens long.
-static constexpr uint32_t SMALL_ROW_MAX = 64;
-
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
-{
-    const uint32_t lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)v, o);
-        if (lane >= (uint32_t)o) v += y;
-    }
-    return v;
-}
-
-// one allowed token of row r (pad / eos of the row's class; symbol = token + shift)
-__device__ __forceinline__ void set_token_bit(const ConstrainArgs &a, uint32_t r, int64_t tok)
-{
-    if (tok < 0 || (uint64_t)tok >= a.vocab) return;
-    atomicOr(&a.bits[(uint64_t)r * a.words_per_row + ((uint64_t)tok >> 5)], 1u << (tok & 31));
-}
-
-template <bool SB>
-__device__ __forceinline__ void expand_small_row(const FmiDev &ix, const ConstrainArgs &a, const uint32_t r, const uint64_t lo, const uint64_t hi,
-                                                 uint4 *s_front, const bool counting, ExpCounters &ctr)
-{
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t D = ix.dlevels;
-    const uint32_t pad_bits = FMI_DIGIT_BITS * D - ix.levels;
-    uint32_t *rowbits = a.bits + (uint64_t)r * a.words_per_row;
-    uint32_t cnt = 1;                               // nodes of the level (wave-uniform)
-    uint64_t nlo = lo, nhi = hi;
-    uint32_t pre = 0;
-    for (uint32_t k = 0; k < D; k++) {
-        const bool act = lane < cnt;
-        const bool leaf = k + 1 == D;
-        const uint64_t bl = act ? nlo >> FMI_BLOCK_SHIFT : 0, bh = act ? nhi >> FMI_BLOCK_SHIFT : 0;
-        uint32_t rl[16], rh[16];
-#pragma unroll
-        for (uint32_t d = 0; d < 16; d++) { rl[d] = 0; rh[d] = 0; }
-        if (act) {
-            HBlock b;
-            wm_load_block(ix, k, bl, b);
-            wm_block_ranks(b, (uint32_t)nlo & (FMI_BLOCK_BITS - 1), rl);
-            if (bh != bl) wm_load_block(ix, k, bh, b);
-            wm_block_ranks(b, (uint32_t)nhi & (FMI_BLOCK_BITS - 1), rh);
-        }
-        // superblocked index: the rows of the two ends (L2-resident table); else both ends add the same dbase[k][d] (kernel arguments)
-        const uint64_t *rwl = nullptr, *rwh = nullptr;
-        if constexpr (SB) {
-            rwl = ix.sbase + ((uint64_t)k * ix.nsb + (bl >> ix.sb_shift)) * FMI_ARITY;
-            rwh = ix.sbase + ((uint64_t)k * ix.nsb + (bh >> ix.sb_shift)) * FMI_ARITY;
-        }
-        uint32_t em = 0;
-#pragma unroll
-        for (uint32_t d = 0; d < 16; d++) {
-            bool ex;
-            if constexpr (SB) ex = act && (rwh[d] + rh[d]) > (rwl[d] + rl[d]);
-            else ex = act && rh[d] > rl[d];
-            em |= (uint32_t)ex << d;
-        }
-        if (counting) {
-            if (act) { ctr.probes += bh != bl ? 2 : 1; ctr.model += model_nodes(em, k, pad_bits); }
-            ctr.iters++; ctr.nodes += (cnt + 1) / 2;                 // in lane pairs, the unit of the other expansions
-        }
-        if (leaf) {
-            // symbols (pre << 4) + d -> tokens: the 16-bit field starts at token base (may be negative: symbols below `shift`)
-            if (pre == 0) em &= ~1u;                                  // symbol 0 is the sentinel, never a token
-            int64_t base = (int64_t)((uint64_t)pre << FMI_DIGIT_BITS) - a.shift;
-            uint64_t m = em;
-            if (base < 0) { m = base > -16 ? m >> (uint32_t)(-base) : 0; base = 0; }
-            if ((uint64_t)base + 16 > a.vocab) m &= (uint64_t)base >= a.vocab ? 0ull : ((1ull << (a.vocab - (uint64_t)base)) - 1);
-            if (m) {
-                const uint64_t w = (uint64_t)base >> 5;
-                const uint64_t mm = m << ((uint32_t)base & 31);
-                if ((uint32_t)mm) atomicOr(&rowbits[w], (uint32_t)mm);
-                if ((uint32_t)(mm >> 32)) atomicOr(&rowbits[w + 1], (uint32_t)(mm >> 32));
-            }
-        } else {
-            const uint32_t nch = (uint32_t)__popc(em);
-            const uint32_t incl = wave_incl_scan(nch);
-            const uint32_t off = incl - nch;
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-#pragma unroll
-            for (uint32_t d = 0; d < 16; d++)
-                if ((em >> d) & 1u) {
-                    uint64_t clo, chi;
-                    if constexpr (SB) { clo = rwl[d] + rl[d]; chi = rwh[d] + rh[d]; }
-                    else { const uint64_t bs = ix.dbase[k][d]; clo = bs + rl[d]; chi = bs + rh[d]; }
-                    s_front[off + (uint32_t)__popc(em & ((1u << d) - 1))] = pack_node(clo, chi, (pre << 4) | d);
-                }
-            wave_sync();
-            cnt = total;                            // <= hi - lo <= 64
-            if (lane < cnt) {
-                const uint4 nd = s_front[lane];
-                nlo = (uint64_t)nd.x | ((uint64_t)(nd.z & 0xff) << 32);
-                nhi = (uint64_t)nd.y | ((uint64_t)((nd.z >> 8) & 0xff) << 32);
-                pre = nd.z >> 16;
-            }
-            wave_sync();
-            if (cnt == 0) break;
-        }
-    }
-}
-
-// ONE wave per row.  It runs the row's chain (13 x fewer waves than when every (row, top digit) wave of k_constrain repeats it), and then
-//  * finishes the row itself when that is cheap: a row whose class is a single token (pad / eos), an empty range, or a SMALL interval
-//    (expand_small_row) -- bits and special tokens set, the row marked done;
-//  * ROWS_ONLY = false (row-first call, first launch): splits the root node of a wide row over all sixteen digits with one single-digit
-//    rank per lane and leaves range, class and the sixteen child intervals in the workspace for the (row, top digit) waves of the
-//    second launch (k_constrain), which skip the rows that are done;
-//  * ROWS_ONLY = true (the whole call; the host picks it by prefix length, when rows are narrow): expands a wide row met here all the
-//    same, one top digit after the other (expand_subtree, the self-contained single-wave expansion) -- correct, only slow.
-// Dynamic LDS per wave: 64 frontier slots (ROWS_ONLY: at least constrain_lds_slots(D, 1)).
-__host__ __device__ constexpr uint32_t rows_lds_slots(uint32_t D, bool rows_only)
-{
-    return rows_only && constrain_lds_slots(D, 1) > SMALL_ROW_MAX ? constrain_lds_slots(D, 1) : SMALL_ROW_MAX;
-}
-
-template <bool SB, bool ROWS_ONLY>
+// Row-first call, first launch: ONE wave per row runs the row's chain (13 x fewer waves than when every (row, top digit) wave
+// of k_constrain repeats it) and splits the root node over all sixteen digits with one single-digit rank per lane.
 __global__ __launch_bounds__(256) void k_constrain_rows(FmiDev ix, ConstrainArgs a)
 {
-    extern __shared__ uint4 s_dyn[];
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t D = ix.dlevels;
-    uint4 *s_mine = s_dyn + (size_t)wave * rows_lds_slots(D, ROWS_ONLY);
-    if (ROWS_ONLY && a.clear) {
-        // housekeeping for the next call: this workgroup's share of the other bitmap buffer (k_constrain does it in a row-first call)
-        const uint64_t per = (a.clear_words + gridDim.x - 1) / gridDim.x;
-        const uint64_t w0 = (uint64_t)blockIdx.x * per;
-        for (uint64_t w = w0 + threadIdx.x; w < w0 + per && w < a.clear_words; w += 256) a.clear[w] = 0u;
-    }
-    const uint32_t r = blockIdx.x * 4 + wave;
+    const uint32_t r = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (r >= a.rows) return;
-    const bool counting = a.probe_counter != nullptr;
-    ExpCounters ctr{0, 0, 0, 0};
     uint64_t lo, hi, probes = 0;
     uint32_t model = 0;
     int64_t single, eos_id;
     bool expand;
     row_range_and_class(ix, a, r, true, lane == 0, lo, hi, single, expand, eos_id, probes, model);
     const bool split = expand && hi > lo;
-    const bool small = split && hi - lo <= a.small_max;
-    const bool done = !split || small;               // the row is finished in this kernel
-    if (small) expand_small_row<SB>(ix, a, r, lo, hi, s_mine, counting, ctr);
-    if (done && lane == 0) {
-        if (single >= 0) set_token_bit(a, r, single);
-        if (a.always_allow_eos) set_token_bit(a, r, eos_id);
-    }
+    const uint32_t e = lane & 1, d = lane >> 1;
+    uint64_t q = 0;
+    if (split && lane < 32) q = wm_step(ix, 0, e ? hi : lo, d);
+    const uint64_t qo = (uint64_t)dpp_xor1((uint32_t)q) | ((uint64_t)dpp_xor1((uint32_t)(q >> 32)) << 32);
+    const uint64_t bal = __ballot(lane < 32 && e == 0 && qo > q);
+    if (lane < 32) a.pre_child[((uint64_t)r * FMI_ARITY + d) * 2 + e] = q;
     uint32_t em = 0;
-    if (!done) {
-        // the root node over all sixteen digits: lane (d, end) of the first 32 takes one single-digit rank
-        const uint32_t e = lane & 1, d = lane >> 1;
-        uint64_t q = 0;
-        if (lane < 32) q = wm_step(ix, 0, e ? hi : lo, d);
-        const uint64_t qo = (uint64_t)dpp_xor1((uint32_t)q) | ((uint64_t)dpp_xor1((uint32_t)(q >> 32)) << 32);
-        const uint64_t bal = __ballot(lane < 32 && e == 0 && qo > q);
 #pragma unroll
-        for (uint32_t x = 0; x < 16; x++) em |= (uint32_t)((bal >> (2 * x)) & 1ull) << x;
-        if constexpr (!ROWS_ONLY) {
-            if (lane < 32) a.pre_child[((uint64_t)r * FMI_ARITY + d) * 2 + e] = q;
-        } else {
-            // a wide row in a rows-only call: one top digit after the other; the digit that owns a special token is visited even if empty
-            const uint32_t sub_bits = FMI_DIGIT_BITS * (D - 1);
-            const uint32_t nsym = 1u << sub_bits, nw = (nsym + 31) >> 5;
-            uint4 *s_node = s_mine;
-            uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_node + exp_slots((int)D - 1));
-            uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_node + exp_slots((int)D - 1) + 2);
-            uint32_t need = em;
-            if (a.always_allow_eos && eos_id >= 0 && (uint64_t)eos_id < a.vocab) {
-                const int64_t sym = eos_id + a.shift;
-                if (sym >= 0 && (uint64_t)(sym >> sub_bits) < a.ndig0) need |= 1u << (uint32_t)(sym >> sub_bits);
-                else if (lane == 0) set_token_bit(a, r, eos_id);
-            }
-            EmitTarget tgt{};
-            tgt.bits = a.bits; tgt.words_per_row = a.words_per_row; tgt.shift = a.shift; tgt.vocab = a.vocab;
-            while (need) {
-                const uint32_t d1 = (uint32_t)__builtin_ctz(need);
-                need &= need - 1;
-                for (uint32_t w = lane; w < nw; w += 64) s_bits[w] = 0u;
-                wave_sync();
-                if ((em >> d1) & 1u) {
-                    const uint64_t clo = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q, (int)(2 * d1)) |
-                                         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q >> 32), (int)(2 * d1)) << 32);
-                    const uint64_t chi = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q, (int)(2 * d1 + 1)) |
-                                         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q >> 32), (int)(2 * d1 + 1)) << 32);
-                    if (D == 1) { if (lane == 0 && d1 != 0) s_bits[0] |= 1u; }
-                    else expand_subtree<EMIT_BITS, SB>(ix, s_node, s_cnt, reinterpret_cast<uint8_t *>(s_bits), r, 1, clo, chi, d1, EmitTarget{}, counting, ctr);
-                    wave_sync();
-                }
-                if (lane == 0 && a.always_allow_eos) set_special(ix, a, s_bits, r, d1, sub_bits, eos_id);
-                wave_sync();
-                flush_leaf_bits(tgt, r, s_bits, d1 << sub_bits, nsym);
-                wave_sync();
-            }
-        }
-    }
-    if (!ROWS_ONLY && lane == 0) {
+    for (uint32_t x = 0; x < 16; x++) em |= (uint32_t)((bal >> (2 * x)) & 1ull) << x;
+    if (lane == 0) {
         RowPre p;
-        p.lo = lo; p.hi = hi; p.single = single; p.expand = done ? 2u : 1u; p.child_mask = em;      // expand == 2: nothing left to do for this row
+        p.lo = lo; p.hi = hi; p.single = single; p.expand = expand ? 1u : 0u; p.child_mask = em;
         a.pre_rows[r] = p;
     }
-    if (counting) {
+    if (a.probe_counter) {
+        ExpCounters ctr{0, 0, 0, 0};
         if (lane == 0) {
-            ctr.probes += (uint32_t)probes + (!done ? ((lo >> FMI_BLOCK_SHIFT) != (hi >> FMI_BLOCK_SHIFT) ? 2u : 1u) : 0u);
-            ctr.model += model + (!done ? model_nodes(em, 0, FMI_DIGIT_BITS * D - ix.levels) : 0u);
+            ctr.probes = (uint32_t)probes + (split ? ((lo >> FMI_BLOCK_SHIFT) != (hi >> FMI_BLOCK_SHIFT) ? 2u : 1u) : 0u);
+            ctr.model = model + (split ? model_nodes(em, 0, FMI_DIGIT_BITS * ix.dlevels - ix.levels) : 0u);
         }
         flush_counters(a.probe_counter, ctr);
     }
@@ -934,12 +752,11 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
     int64_t single = -1, eos_id = 0;
     bool expand = false;
     const bool pre = W > 1 && a.pre_rows != nullptr;      // row-first call: k_constrain_rows has done the rows
-    bool done_row = false;                                 // ... and finished this one altogether (single token / empty / small interval)
     if (pre) {
         eos_id = a.grp_eos[row_group(a, r)];
         if (valid) {
             const cptr<RowPre> p = as_const(a.pre_rows) + r;
-            lo = p->lo; hi = p->hi; single = p->single; expand = p->expand == 1; done_row = p->expand == 2;
+            lo = p->lo; hi = p->hi; single = p->single; expand = p->expand != 0;
         }
     } else {
         row_range_and_class(ix, a, r, valid, writer && lane == 0, lo, hi, single, expand, eos_id, probes, model);
@@ -1016,7 +833,7 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
         // launch become resident (at two workgroups of eight 126-register waves per CU a 600-row call otherwise runs in two
         // rounds).  The barriers below count the waves that are left (s_barrier waits on the surviving waves only).
         // Measurement modes keep every wave (the counters are flushed at the end).
-        const bool stays = live || (valid && !done_row && (single >= 0 || a.always_allow_eos)) || counting;
+        const bool stays = live || (valid && (single >= 0 || a.always_allow_eos)) || counting;
         // (keeping the empty waves as helpers where a workgroup has much to share measured the same on the bench workload: 39.0 vs 39.4 us
         //  per call, SEALFM_LEAVE_EARLY=0; on 600 narrow rows leaving is what lets the second launch of a row-first call finish in 12 us)
         if (a.leave_early && !__builtin_amdgcn_readfirstlane((int)stays)) {     // (a scalar condition: the whole wave branches to its end)
@@ -1039,7 +856,7 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
     }
     wave_sync();
     STAMP(3);
-    if (valid && !done_row) {
+    if (valid) {
         // pad / eos of the row's class: after the expansion, whose byte stores would overwrite them
         if (lane == 0) {
             if (single >= 0) set_special(ix, a, s_bits, r, d1, sub_bits, single);
@@ -1860,25 +1677,10 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     // ONE list that a fixed grid walks -- measured slower everywhere, 22.1 vs 17.5 us on the narrowest call: 600 returning atomics on one
     // counter cost more than the empty waves they save.)
     const uint64_t rf_from = h->opt.row_first_from >= 0 ? (uint64_t)h->opt.row_first_from : (rows >= 512 ? 2 : 3);
-    // Rows-only (k_constrain_rows_only): when every row's prefix is long the rows are narrow and one wave per row is the whole call
-    uint64_t shortest = ~0ull;
-    for (uint32_t g = 0; g < rg.n; g++) shortest = std::min<uint64_t>(shortest, rg.n_force[g] + (cur_len - 1));
-    const uint64_t ro_from = h->opt.rows_only_from >= 0 ? (uint64_t)h->opt.rows_only_from : ROWS_ONLY_FROM_DEFAULT;
-    a.small_max = h->opt.small_row_max >= 0 ? std::min<uint64_t>((uint64_t)h->opt.small_row_max, SMALL_ROW_MAX) : SMALL_ROW_MAX;
-    if (W > 1 && ro_from > 0 && shortest >= ro_from && !a.tstamp) {
-        a.pre_rows = nullptr; a.pre_child = nullptr;
-        const size_t lds_ro = (size_t)4 * rows_lds_slots(h->dlevels, true) * 16;
-        void (*kro)(FmiDev, ConstrainArgs) = sb ? k_constrain_rows<true, true> : k_constrain_rows<false, true>;
-        hipLaunchKernelGGL(kro, dim3((unsigned)((rows + 3) / 4)), dim3(256), lds_ro, st, h->dev, a);
-        HIPCHK(hipGetLastError());
-        if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
-        return FMI_OK;
-    }
     const bool row_first = W > 1 && (h->opt.row_first >= 0 ? h->opt.row_first != 0 : longest >= rf_from);
     if (row_first) {
         a.pre_rows = ws_pre_rows(h); a.pre_child = ws_pre_child(h);
-        void (*krf)(FmiDev, ConstrainArgs) = sb ? k_constrain_rows<true, false> : k_constrain_rows<false, false>;
-        hipLaunchKernelGGL(krf, dim3((unsigned)((rows + 3) / 4)), dim3(256), (size_t)4 * rows_lds_slots(h->dlevels, false) * 16, st, h->dev, a);
+        hipLaunchKernelGGL(k_constrain_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, h->dev, a);
     }
     void (*kern)(FmiDev, ConstrainArgs) = W > 1 ? (sb ? k_constrain<true, CONSTRAIN_WG> : k_constrain<false, CONSTRAIN_WG>)
                                                 : (sb ? k_constrain<true, 1> : k_constrain<false, 1>);

@@ -178,6 +178,7 @@ def test_first_step_shared_by_the_beams_of_a_query(dtype):
         enc_ids, enc_mask, bias = torch.roll(enc_ids, 1, 0), torch.roll(enc_mask, 1, 0), torch.roll(bias, 1, 0)
     # the promise is only honoured at position 0; the switch turns the path off
     dec2 = BartStepDecoder(run)
+    dec2.shared_first_step = False
     dec2.start(dec2.encode(enc_ids, enc_mask), enc_mask, K, T)
     assert dec2._st.first_graph is None
     full = dec2.step(torch.full((B * K,), 2, dtype=torch.long, device=dev), beams_identical=True)

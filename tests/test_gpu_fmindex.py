@@ -146,18 +146,15 @@ def test_save_load_round_trip_on_gpu(pair, tmp_path):
     assert ix2.get_doc(1) == docs[1]
 
 
-@pytest.mark.parametrize("form", [dict(constrain_waves=8), dict(constrain_waves=1), dict(row_first=0), dict(row_first=1), dict(rows_only_from=1),
-                                  dict(leave_early=0), dict(row_first=1, small_row_max=0), dict(rows_only_from=1, small_row_max=0),
-                                  dict(row_first=1, small_row_max=3), dict(rows_only_from=1, small_row_max=3)],
-                         ids=["shared-leaf-phase", "self-contained-waves", "single-launch", "row-first", "rows-only", "empty-waves-stay",
-                              "row-first-no-small-rows", "rows-only-every-row-wide", "row-first-small<=3", "rows-only-small<=3"])
+@pytest.mark.parametrize("form", [dict(constrain_waves=8), dict(constrain_waves=1), dict(row_first=0), dict(row_first=1), dict(leave_early=0),
+                                  dict(row_first=1, leave_early=0)],
+                         ids=["shared-leaf-phase", "self-contained-waves", "single-launch", "row-first", "empty-waves-stay", "row-first-empty-waves-stay"])
 def test_logits_processor_matches_reference_semantics(pair, form):
     """every launch form of a constraint call gives the reference's masks: workgroups of 8 waves that serve their leaf-level
     nodes together (the default up to 4 digit levels) / one self-contained wave per (row, top digit); the single launch / the
-    row-first pair (k_constrain_rows, then k_constrain) / ONE wave per row for the whole row (k_constrain_rows<.., true>) whatever the
-    prefix length -- each with the rows of small intervals finished by their own wave (expand_small_row: the default, <= 64 rows of
-    the BWT), with none, and with a threshold that splits the test rows between the two ways; the waves of empty items leaving early
-    or staying"""
+    row-first pair (k_constrain_rows, then k_constrain) whatever the prefix length; the waves of empty items leaving early or
+    staying.  (Two more forms were measured in round 4 and dropped -- one wave per row for the whole row, and rows of small
+    intervals finished by their own wave: profiles/r4_rows_forms_ab_*.txt.)"""
     from tests.helpers import kernel_options
     ix, orc, docs, vocab = pair
     with kernel_options(ix, **form):
