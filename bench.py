@@ -523,6 +523,8 @@ def main():
     data, beg, title_len, ids_by_rank = synth_corpus(args.docs, dev, seed=0, phrases=args.corpus_phrases, text16=stress)
     torch.cuda.synchronize()
     log(f"corpus: {args.docs} docs, {data.numel() - (1 if stress else 0)} symbols in {time.perf_counter() - t0:.1f}s")
+    workload_tag = f"{args.workload}-{args.docs}"          # a PMC traffic file is only cited by lines of the workload it was taken on
+    log(f"workload_tag={workload_tag}")
     n_batches = args.warmup + args.steps + 1
     queries, bias = synth_queries(n_batches * args.batch, data, beg, title_len, ids_by_rank, dev, seed=1 + rank)
     t0 = time.perf_counter()
@@ -760,19 +762,21 @@ def main():
         import hashlib
         csrc = os.path.join(ROOT, "seal_amd", "csrc")
         now = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("fmi_kernels.hip", "fmi_device.h", "fmi_internal.h"))).hexdigest()
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size.json")), reverse=True)
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size*.json")), reverse=True)
         for f in files:
             pmc = json.load(open(f))
             if pmc.get("_kernel_source_sha256") != now:
                 continue            # counters of another kernel generation are REFUSED (the file records the source it profiled)
+            if pmc.get("_workload") != workload_tag:
+                continue            # ... and so are counters taken on another workload (index size, beam): per-workload files
             kib = sum(v["FETCH_SIZE"]["avg"] for k, v in pmc.items() if "k_constrain" in k)      # both launches of a row-first call
             if kib:
                 traffic = round(kib * 1024.0 * 2, 1)
-                traffic_src = {"file": os.path.relpath(f, ROOT), "commit": pmc.get("_commit"), "kernel_source_sha256": now[:16]}
+                traffic_src = {"file": os.path.relpath(f, ROOT), "commit": pmc.get("_commit"), "kernel_source_sha256": now[:16], "workload": workload_tag}
                 break
         if traffic is None:
-            traffic_src = {"refused": "no profiles/r*_pmc_fetch_size.json was taken over the current fmi_kernels.hip / fmi_device.h / fmi_internal.h "
-                                      "(sha256 %s); run tools/prof_bench.sh" % now[:16], "candidates": [os.path.relpath(f, ROOT) for f in files[:3]]}
+            traffic_src = {"refused": "no profiles/r*_pmc_fetch_size*.json was taken over the current fmi_kernels.hip / fmi_device.h / fmi_internal.h "
+                                      "(sha256 %s) on this workload (%s); run tools/prof_bench.sh" % (now[:16], workload_tag), "candidates": [os.path.relpath(f, ROOT) for f in files[:3]]}
     except Exception as e:
         traffic_src = {"error": repr(e)}
     nl = n2

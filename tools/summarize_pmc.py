@@ -18,4 +18,6 @@ import os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out["_kernel_source_sha256"] = hashlib.sha256(b"".join(open(os.path.join(root, "seal_amd", "csrc", f), "rb").read()
                                                        for f in ("fmi_kernels.hip", "fmi_device.h", "fmi_internal.h"))).hexdigest()
+if len(sys.argv) > 2:
+    out["_workload"] = sys.argv[2]          # bench.py's workload_tag: a line only cites counters of its own workload
 json.dump(out, sys.stdout, indent=1)
