@@ -866,8 +866,10 @@ def main():
         log(f"score parity vs HF fp32 forward in {time.perf_counter() - t0:.1f}s: beam scores {beam['values']} values, max abs err "
             f"{beam['max_abs_err']:.2e}; rescoring {rs['values']} values, max abs err {rs['max_abs_err']:.2e} (tol {score_tol:g})")
         log(f"parity_check: {parity['ops']} ops, {parity['values_compared']} values, {parity['mismatches']} mismatches")
-        t_cpu = rep["mask_s"] + rep["ranges_s"] + rep["locate_s"] + rep["docs_s"]
+        # (with a sampled replay the located rows / documents stand for `stride` times as many: their time is scaled up, and said so)
+        t_cpu = rep["mask_s"] + rep["ranges_s"] + stride * (rep["locate_s"] + rep["docs_s"])
         cpu = {"value": round(args.batch / t_cpu, 3), "unit": "queries/s (FM-index path only)", "cores": threads, "kind": "port",
+               **({"extrapolated": f"locate and document time of every {stride}th row / document, times {stride}"} if stride > 1 else {}),
                "sample": f"FM-index operations of 1 batch of {args.batch} queries (decode-step get_range/get_count from scratch + "
                          f"distinct_count_multi for {rep['rows']} rows, get_count for {rep['sequences']} keys, locate+bisect for "
                          f"{rep['located']} rows, get_doc for {rep['docs']} documents) replayed on the oracle with the reference's call pattern; the model forward is not "

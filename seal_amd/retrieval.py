@@ -796,8 +796,7 @@ class SEALSearcher:
         dev = self.device
         post = self.__dict__.get("_post_stream")
         if post is None:
-            # (SEAL_POST_PRIORITY=1 makes it a high-priority stream: measured no different)
-            post = self.__dict__["_post_stream"] = torch.cuda.Stream(device=dev, priority=-1 if os.environ.get("SEAL_POST_PRIORITY", "0") == "1" else 0)
+            post = self.__dict__["_post_stream"] = torch.cuda.Stream(device=dev)
         params = self._aggregate_params()
         constrained = not self.free_generation
         batches, offsets, off = [], [], 0
@@ -840,24 +839,15 @@ class SEALSearcher:
             if exclusive and fence[kind] is not None:
                 stream.wait_event(fence[kind])
 
-        prof = None
-        if os.environ.get("SEAL_PROFILE_ENQUEUE"):            # tools: where the host time of enqueueing a batch's decodes goes
-            import cProfile
-            prof = cProfile.Profile()
-
         def enqueue_next(upto="decoding"):
             """starts the next batch: its body decode is enqueued (``upto="body"``), or both decodes"""
             nonlocal nxt_i
             g = _batch_steps(self, batches[nxt_i], constrained, offsets[nxt_i])
-            if prof is not None and nxt_i >= 2:
-                prof.enable()
             wait_for("rescore", main)
             state = next(g)                                   # "body": the body decode is enqueued behind the earlier ones
             if upto == "decoding":
                 state = next(g)
             after("decode", main)
-            if prof is not None:
-                prof.disable()
             ahead.append([g, state])
             nxt_i += 1
 
@@ -885,11 +875,6 @@ class SEALSearcher:
                 while nxt_i < len(batches) and len(ahead) < depth:
                     enqueue_next("body" if len(ahead) == 0 else "decoding")
             t2 = time.perf_counter()
-            pprof = None
-            if os.environ.get("SEAL_PROFILE_POST") and i >= 2:   # tools: where the host time of a batch's post-processing goes
-                import cProfile
-                pprof = self.__dict__.setdefault("_post_prof", cProfile.Profile())
-                pprof.enable()
             # (the filters' count launch and copies run beside the decodes; only the rescoring forward is fenced, from inside the step)
             self.__dict__["_gemm_gate"] = lambda: wait_for("decode", post)
             try:
@@ -922,18 +907,9 @@ class SEALSearcher:
                 jobs = [(kk[0], kk[1]) if isinstance(kk, tuple) else (kk, None) for kk in keys]
                 out = rk.aggregate_evidence_batch(jobs, self.fm_index, keep=keep, gpu_aggregate=self.gpu_aggregate, want_ngrams=False, **params)
                 post.synchronize()
-            if pprof is not None:
-                pprof.disable()
-                if i + 1 == len(batches):
-                    import pstats
-                    pstats.Stats(pprof, stream=sys.stderr).sort_stats("tottime").print_stats(45)
-                    self.__dict__.pop("_post_prof", None)
             if tm:
                 print("[overlap] batch %d: waited %.1f ms for its decodes; enqueued further decodes in %.1f ms; filters / rescoring / "
                       "aggregation %.1f ms" % (i, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (time.perf_counter() - t2) * 1e3), file=sys.stderr, flush=True)
-            if prof is not None and i + 1 == len(batches) and prof.getstats():
-                import pstats
-                pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(40)
             held = out
         if held is not None:
             yield from held
