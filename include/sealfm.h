@@ -258,6 +258,7 @@ int fmi_dev_debug_timestamps(fmi_t *h, uint64_t *d_buf, uint64_t n_words);
  * here; value -1 restores the built-in choice.  Names: "constrain_waves" (1: one self-contained wave per (row, top digit)),
  * "leave_early" (0: the waves of empty items stay), "row_first" (0 / 1: never / always the row-first pair of launches),
  * "row_first_from" (prefix length in tokens from which a call goes row-first),
+ * "prefix_tables" (0: the first constrained step of a decode through the generic expansion instead of the per-token node tables),
  * "topk_narrow" (rows with more allowed tokens take the wide-row path of the top-2K kernel), "topk_legacy" (1: exact radix
  * select on wide rows).  Results are identical for every setting (tests/test_gpu_fmindex.py, tests/test_gpu_decode.py). */
 int fmi_dev_set_option(fmi_t *h, const char *name, int64_t value);

@@ -46,6 +46,8 @@ FmiOptions::FmiOptions()
     leave_early = env_i64("SEALFM_LEAVE_EARLY", leave_early);
     row_first = env_i64("SEALFM_ROW_FIRST", row_first);
     row_first_from = env_i64("SEALFM_ROW_FIRST_FROM", row_first_from);
+    prefix_tables = env_i64("SEALFM_PREFIX_TABLES", prefix_tables);
+    table_grid = env_i64("SEALFM_TABLE_GRID", table_grid);
     topk_narrow = env_i64("SEALFM_TOPK_NARROW", topk_narrow);
     topk_legacy = env_i64("SEALFM_TOPK_LEGACY", topk_legacy);
 }
@@ -57,6 +59,8 @@ int FmiOptions::set(const char *name, int64_t value)
     else if (s == "leave_early") leave_early = value < 0 ? 1 : value;
     else if (s == "row_first") row_first = value;
     else if (s == "row_first_from") row_first_from = value;
+    else if (s == "prefix_tables") prefix_tables = value < 0 ? 1 : value;
+    else if (s == "table_grid") table_grid = value;
     else if (s == "topk_narrow") topk_narrow = value;
     else if (s == "topk_legacy") topk_legacy = value < 0 ? 0 : value;
     else return -1;
@@ -83,6 +87,12 @@ void fmi_release_device(fmi *h)
         (void)hipSetDevice(h->device);
         for (void *p : h->dev_allocs) (void)hipFree(p);
         if (h->ws) (void)hipFree(h->ws);
+        for (FmiPrefixTable &t : h->prefix_tables) {
+            if (t.d_off) (void)hipFree(t.d_off);
+            if (t.d_root) (void)hipFree(t.d_root);
+            if (t.d_nodes) (void)hipFree(t.d_nodes);
+        }
+        if (h->sym_bits) (void)hipFree(h->sym_bits);
         if (h->d_probe_counter) (void)hipFree(h->d_probe_counter);
         if (h->service_stream) (void)hipStreamDestroy((hipStream_t)h->service_stream);
         for (void *e : h->ev_start) (void)hipEventDestroy((hipEvent_t)e);
@@ -91,7 +101,9 @@ void fmi_release_device(fmi *h)
     h->service_stream = nullptr;
     h->ev_start.clear(); h->ev_stop.clear(); h->ev_used = 0; h->timing_enabled = 0;
     h->dev_allocs.clear();
+    h->prefix_tables.clear();
     h->ws = nullptr; h->ws_bytes = 0; h->ws_rows = 0;
+    h->sym_bits = nullptr; h->sym_rows = 0; h->sym_row_words = 0;
     h->d_probe_counter = nullptr;
     h->dev = FmiDev{};
     h->device = -1;

@@ -68,14 +68,32 @@ struct FmiOptions {
     int64_t leave_early = 1;        // SEALFM_LEAVE_EARLY=0: the waves of empty items stay in their workgroup
     int64_t row_first = -1;         // SEALFM_ROW_FIRST=0 / 1: never / always the row-first pair of launches (default: by prefix length)
     int64_t row_first_from = -1;    // SEALFM_ROW_FIRST_FROM=<tokens>: prefix length from which a call goes row-first (default 3; 2 from 512 rows on)
+    int64_t prefix_tables = 1;      // SEALFM_PREFIX_TABLES=0: the first constrained step of a decode through the generic expansion
+    int64_t table_grid = -1;        // SEALFM_TABLE_GRID=<n>: workgroups of k_constrain_table (default 1024: one resident round)
     int64_t topk_narrow = -1;       // SEALFM_TOPK_NARROW=<n>: rows of more than n allowed tokens take the wide-row path of k_row_pick
     int64_t topk_legacy = 0;        // SEALFM_TOPK_LEGACY=1: wide rows skip the thread-maxima bound (exact radix select)
     FmiOptions();
     int set(const char *name, int64_t value);      // 0, or -1 for an unknown name
 };
 
+// Leaf-level node table of one forced prefix P: for every token t, the nodes of the LAST digit level of the
+// wavelet matrix below the interval of P + [t] (what the expansion of that interval reaches after its dependent upper levels), and the
+// interval itself.  The first constrained step of a decode -- every row's prefix is P + one token -- then reads its rows' node lists
+// (contiguous) and streams the leaf level from one flat, evenly cut list: no ramp, no tail (k_constrain_table).
+struct FmiPrefixTable {
+    std::vector<int64_t> force;
+    int64_t shift = 0;
+    uint64_t vocab = 0;
+    uint64_t *d_off = nullptr;    // [vocab + 1] first node of token t
+    uint64_t *d_root = nullptr;   // [vocab][2]   inclusive range (l, r) of P + [t]; (1, 0): empty
+    void *d_nodes = nullptr;      // uint4[n_nodes]: two 40-bit positions + 16-bit symbol prefix (pack_node), grouped by token
+    uint64_t n_nodes = 0;
+    bool ok = false;              // false: not built (too large): the generic path serves such rows
+};
+
 struct fmi {
     FmiOptions opt;
+    std::vector<FmiPrefixTable> prefix_tables;
     // geometry
     uint64_t n = 0, max_sym = 0, sigma = 0, nblk = 0;
     uint32_t levels = 0, dlevels = 0, sym_bytes = 2, sb_shift = FMI_SB_NONE;
@@ -97,6 +115,10 @@ struct fmi {
     uint64_t ws_rows = 0;
     uint64_t ws_seq = 0;      // parity picks the workspace bitmap of the next constraint call
     uint64_t ws_dirty[2] = {0, 0};   // words of each workspace bitmap that its last use may have left non-zero
+    // the two symbol-space bitmaps of the table calls (k_constrain_table / k_table_bits, fmi_kernels.hip), one allocation
+    void *sym_bits = nullptr;
+    uint64_t sym_rows = 0, sym_row_words = 0, sym_dirty_rows[2] = {0, 0};
+    int sym_flip = 0;
     // incremental constraint state of fmi_dev_constrained_topk_step (per-row prefix ranges of the last call)
     uint64_t state_tag = 0, state_rows = 0, state_len = 0;
     int state_flip = 0;

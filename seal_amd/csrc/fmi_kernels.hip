@@ -7,6 +7,9 @@
 // Wave size is 64 throughout.
 #include <hip/hip_runtime.h>
 
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -582,6 +585,13 @@ __device__ __forceinline__ void set_special(const FmiDev &ix, const ConstrainArg
     } else if (d1 == 0) {
         atomicOr(&a.bits[(uint64_t)row * a.words_per_row + ((uint64_t)tok >> 5)], 1u << (tok & 31));
     }
+}
+
+// one allowed token of row r straight into the row's bitmap in global memory
+__device__ __forceinline__ void set_bit_global(const ConstrainArgs &a, uint32_t r, int64_t tok)
+{
+    if (tok < 0 || (uint64_t)tok >= a.vocab) return;
+    atomicOr(&a.bits[(uint64_t)r * a.words_per_row + ((uint64_t)tok >> 5)], 1u << (tok & 31));
 }
 
 // W = waves per workgroup.  W = 1: one self-contained wave per item (any depth; dynamic LDS: exp_slots(D - 1)
@@ -1600,6 +1610,373 @@ struct RowGroups {
     }
 };
 
+// ---------------------------------------------------------------------------
+// The first constrained step of a decode (cur_len == 2: every row's prefix is the forced prefix P of its decode + ONE token) from
+// per-token tables (FmiPrefixTable, fmi_internal.h).  The expansion of such a row starts from [C[c], C[c + 1]) -- a static property of
+// the index -- and is the widest of the decode (10^3..10^4 distinct continuations): in k_constrain its leaf level, 95 % of the bytes,
+// streams at the chip's random-request rate, but only after a ramp of dependent upper levels (~10 us) and with a tail of workgroups that
+// finish alone (~12 us of a 70 us call).  With the leaf-level nodes of every token tabulated once per index (a few hundred MB at NQ
+// size, built in milliseconds by the level-by-level expansion below), the call is ONE flat list -- the rows' node lists back to back,
+// found through a prefix sum over the rows in LDS -- cut evenly over the grid: every lane pair loads the one or two blocks of its node,
+// takes the sixteen child-exists bits and ORs them into the row's token bitmap.  No ramp, no tail.
+// ---------------------------------------------------------------------------
+struct PtNode { uint64_t lo, hi; uint32_t prefix, owner; };
+
+// level-0 nodes: the interval of P + [t] for every token t (the same backward-search steps as row_range_and_class, quirk Q1 included)
+__global__ void k_pt_roots(FmiDev ix, ForceFrom ff, int64_t shift, uint64_t vocab, uint64_t *root, uint32_t *flag)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= vocab) return;
+    uint64_t l = 0, rr = ix.n;
+    for (uint32_t j = 0; j <= ff.n; j++) {
+        const int64_t tok = j < ff.n ? ff.tok[j] : (int64_t)t;
+        bs_step(ix, (uint64_t)(tok + shift), l, rr, l, rr, nullptr);
+    }
+    uint64_t lo = l, hi = rr + 1;
+    if (hi > ix.n) hi = ix.n;
+    root[2 * t] = l; root[2 * t + 1] = rr;
+    flag[t] = hi > lo ? 1u : 0u;
+}
+
+__global__ void k_pt_root_nodes(const uint64_t *root, const uint32_t *flag, const uint64_t *offs, uint64_t vocab, uint64_t n, PtNode *out)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= vocab || !flag[t]) return;
+    PtNode nd;
+    nd.lo = root[2 * t]; nd.hi = min(root[2 * t + 1] + 1, n); nd.prefix = 0; nd.owner = (uint32_t)t;
+    out[offs[t]] = nd;
+}
+
+// children of every node of level k: count, then (after an exclusive scan) write; one thread per node, sixteen digits each
+__global__ void k_pt_children(FmiDev ix, uint32_t k, const PtNode *nodes, uint64_t n, const uint64_t *offs, uint32_t *cnt, PtNode *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PtNode nd = nodes[i];
+    uint64_t at = out ? offs[i] : 0;
+    uint32_t c = 0;
+    for (uint32_t d = 0; d < FMI_ARITY; d++) {
+        const uint64_t clo = wm_step(ix, k, nd.lo, d), chi = wm_step(ix, k, nd.hi, d);
+        if (chi > clo) {
+            c++;
+            if (out) { PtNode ch; ch.lo = clo; ch.hi = chi; ch.prefix = (nd.prefix << FMI_DIGIT_BITS) | d; ch.owner = nd.owner; out[at++] = ch; }
+        }
+    }
+    if (!out) cnt[i] = c;
+}
+
+__global__ void k_pt_pack(const PtNode *nodes, uint64_t n, uint4 *packed, uint32_t *owner)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    packed[i] = pack_node(nodes[i].lo, nodes[i].hi, nodes[i].prefix);
+    owner[i] = nodes[i].owner;
+}
+
+// off[t] = first node whose owner is >= t (the nodes are grouped by owner, ascending)
+__global__ void k_pt_offsets(const uint32_t *owner, uint64_t n, uint64_t vocab, uint64_t *off)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > vocab) return;
+    uint64_t a = 0, b = n;
+    while (a < b) { const uint64_t mid = (a + b) >> 1; if (owner[mid] < t) a = mid + 1; else b = mid; }
+    off[t] = a;
+}
+
+static constexpr uint64_t PT_MAX_NODES = 1ull << 28;      // 4 GiB of packed nodes: beyond that the generic path serves the prefix
+
+static int build_prefix_table(fmi *h, FmiPrefixTable &T)
+{
+    // (runs once per index and forced prefix, on the null stream, synchronously: allocation + a few passes; milliseconds at NQ size)
+    const uint64_t V = T.vocab;
+    ForceFrom ff{};
+    ff.n = (uint32_t)T.force.size();
+    for (uint32_t i = 0; i < ff.n; i++) ff.tok[i] = T.force[i];
+    DevBuf flag, offs, tmp;
+    int rc;
+    HIPCHK(hipMalloc((void **)&T.d_root, V * 16));
+    if ((rc = flag.alloc((V + 1) * 4)) || (rc = offs.alloc((V + 1) * 8))) return rc;
+    HIPCHK(hipMemsetAsync(flag.p, 0, (V + 1) * 4, 0));             // (the scan runs over V + 1 flags: the last one stays 0)
+    hipLaunchKernelGGL(k_pt_roots, dim3(blocks_for(V, 256)), dim3(256), 0, 0, h->dev, ff, T.shift, V, T.d_root, flag.as<uint32_t>());
+    size_t tb = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, tb, flag.as<uint32_t>(), offs.as<uint64_t>(), (uint64_t)0, V + 1, rocprim::plus<uint64_t>(), (hipStream_t)0));
+    if ((rc = tmp.alloc(tb + 256))) return rc;
+    HIPCHK(rocprim::exclusive_scan(tmp.p, tb, flag.as<uint32_t>(), offs.as<uint64_t>(), (uint64_t)0, V + 1, rocprim::plus<uint64_t>(), (hipStream_t)0));
+    uint64_t n = 0;
+    HIPCHK(hipMemcpy(&n, offs.as<uint64_t>() + V, 8, hipMemcpyDeviceToHost));
+    PtNode *cur = nullptr, *nxt = nullptr;
+    HIPCHK(hipMalloc((void **)&cur, std::max<uint64_t>(n, 1) * sizeof(PtNode)));
+    hipLaunchKernelGGL(k_pt_root_nodes, dim3(blocks_for(V, 256)), dim3(256), 0, 0, (const uint64_t *)T.d_root, flag.as<uint32_t>(), offs.as<uint64_t>(), V, h->n, cur);
+    auto fail = [&](int code) { if (cur) (void)hipFree(cur); if (nxt) (void)hipFree(nxt); return code; };
+    for (uint32_t k = 0; k + 1 < h->dlevels && n; k++) {
+        DevBuf cnt, off2, tmp2;
+        if ((rc = cnt.alloc((n + 1) * 4)) || (rc = off2.alloc((n + 1) * 8))) return fail(rc);
+        if (hipMemsetAsync(cnt.p, 0, (n + 1) * 4, 0) != hipSuccess) return fail(FMI_ERR_HIP);
+        hipLaunchKernelGGL(k_pt_children, dim3(blocks_for(n, 256)), dim3(256), 0, 0, h->dev, k, (const PtNode *)cur, n, (const uint64_t *)nullptr, cnt.as<uint32_t>(), (PtNode *)nullptr);
+        size_t t2 = 0;
+        if (rocprim::exclusive_scan(nullptr, t2, cnt.as<uint32_t>(), off2.as<uint64_t>(), (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), (hipStream_t)0) != hipSuccess) return fail(FMI_ERR_HIP);
+        if ((rc = tmp2.alloc(t2 + 256))) return fail(rc);
+        if (rocprim::exclusive_scan(tmp2.p, t2, cnt.as<uint32_t>(), off2.as<uint64_t>(), (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), (hipStream_t)0) != hipSuccess) return fail(FMI_ERR_HIP);
+        uint64_t m = 0;
+        if (hipMemcpy(&m, off2.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(FMI_ERR_HIP);
+        if (m > PT_MAX_NODES) { (void)fail(0); T.ok = false; return FMI_OK; }        // too large for a table: not an error
+        if (hipMalloc((void **)&nxt, std::max<uint64_t>(m, 1) * sizeof(PtNode)) != hipSuccess) { (void)fail(0); (void)hipGetLastError(); T.ok = false; return FMI_OK; }
+        hipLaunchKernelGGL(k_pt_children, dim3(blocks_for(n, 256)), dim3(256), 0, 0, h->dev, k, (const PtNode *)cur, n, (const uint64_t *)off2.as<uint64_t>(), (uint32_t *)nullptr, nxt);
+        if (hipDeviceSynchronize() != hipSuccess) return fail(FMI_ERR_HIP);
+        (void)hipFree(cur); cur = nxt; nxt = nullptr; n = m;
+    }
+    DevBuf owner;
+    if ((rc = owner.alloc(std::max<uint64_t>(n, 1) * 4))) return fail(rc);
+    if (hipMalloc(&T.d_nodes, std::max<uint64_t>(n, 1) * 16) != hipSuccess || hipMalloc((void **)&T.d_off, (V + 1) * 8) != hipSuccess) { (void)hipGetLastError(); (void)fail(0); T.ok = false; return FMI_OK; }
+    if (n) hipLaunchKernelGGL(k_pt_pack, dim3(blocks_for(n, 256)), dim3(256), 0, 0, (const PtNode *)cur, n, (uint4 *)T.d_nodes, owner.as<uint32_t>());
+    hipLaunchKernelGGL(k_pt_offsets, dim3(blocks_for(V + 1, 256)), dim3(256), 0, 0, (const uint32_t *)owner.as<uint32_t>(), n, V, T.d_off);
+    if (hipDeviceSynchronize() != hipSuccess) return fail(FMI_ERR_HIP);
+    (void)fail(0);
+    T.n_nodes = n;
+    T.ok = true;
+    return FMI_OK;
+}
+
+// the table of forced prefix `force` for this (shift, vocab), built on first use; nullptr: none (too large / switched off)
+static const FmiPrefixTable *prefix_table_for(fmi *h, const int64_t *force, uint64_t n_force, int64_t shift, uint64_t vocab, int *rc_out)
+{
+    *rc_out = FMI_OK;
+    for (const FmiPrefixTable &t : h->prefix_tables)
+        if (t.shift == shift && t.vocab == vocab && t.force.size() == n_force && std::equal(t.force.begin(), t.force.end(), force)) return t.ok ? &t : nullptr;
+    if (h->prefix_tables.size() >= 8) return nullptr;          // a handful of decodes per searcher: anything beyond takes the generic path
+    h->prefix_tables.emplace_back();
+    FmiPrefixTable &T = h->prefix_tables.back();
+    T.force.assign(force, force + n_force); T.shift = shift; T.vocab = vocab;
+    *rc_out = build_prefix_table(h, T);
+    if (*rc_out != FMI_OK) { T.ok = false; return nullptr; }
+    return T.ok ? &T : nullptr;
+}
+
+struct TableArgs {
+    const uint64_t *off[MAX_ROW_GROUPS];
+    const uint64_t *root[MAX_ROW_GROUPS];
+    const uint4 *nodes[MAX_ROW_GROUPS];
+    uint8_t *sym;                  // [rows][sym_row_words * 4]: bit s of a row = symbol s follows its prefix; zero on entry
+    uint64_t sym_row_words;
+};
+
+// entry g of a per-group kernel argument for a per-lane g: selects between scalar registers (indexing the array with a vector would
+// be a load from the kernel-argument segment, and one more dependent access in front of what it addresses)
+template <class T>
+__device__ __forceinline__ T of_group(const T (&v)[MAX_ROW_GROUPS], uint32_t g)
+{
+    static_assert(MAX_ROW_GROUPS == 3, "of_group selects between three entries");
+    return g == 0 ? v[0] : (g == 1 ? v[1] : v[2]);
+}
+
+static constexpr uint32_t TABLE_WG = 256;
+static constexpr uint32_t TABLE_GRID = 1024;      // workgroups of the flat leaf-level pass: the 4 x 4 waves a CU holds at ~100 registers, ONE round
+__host__ __device__ constexpr size_t table_lds_bytes(uint32_t rows) { return (size_t)(rows + 1) * 4 + (size_t)rows * 8 + 264 * 4; }
+
+template <bool SB>
+__global__ __launch_bounds__(TABLE_WG) void k_constrain_table(FmiDev ix, ConstrainArgs a, TableArgs tb)
+{
+    extern __shared__ uint64_t s_dyn64[];
+    uint64_t *s_base = s_dyn64;                                           // [rows]   first table node of the row
+    uint32_t *s_start = reinterpret_cast<uint32_t *>(s_base + a.rows);   // [rows+1] first flat node index of the row
+    uint32_t *s_part = s_start + a.rows + 1;                              // [256 + 8] scan scratch
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t D = ix.dlevels, kl = D - 1;                            // the leaf level
+    const bool counting = a.probe_counter != nullptr;
+    ExpCounters ctr{0, 0, 0, 0};
+    if (a.clear) {      // housekeeping for the next call: this workgroup's share of the other bitmap buffer
+        const uint64_t per = (a.clear_words + gridDim.x - 1) / gridDim.x;
+        const uint64_t w0 = (uint64_t)blockIdx.x * per;
+        for (uint64_t w = w0 + tid; w < w0 + per && w < a.clear_words; w += TABLE_WG) a.clear[w] = 0u;
+    }
+    // ---- every workgroup: the rows' node counts (two dependent loads: last token, its table offsets) and their prefix sum ----
+    // (rows strided over the threads, four per thread in flight: the loads of a batch are independent of one another)
+    for (uint32_t r0 = 0; r0 < a.rows; r0 += 4 * TABLE_WG) {
+        int64_t tok[4];
+        uint64_t base[4], next[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t r = r0 + u * TABLE_WG + tid;
+            tok[u] = r < a.rows ? a.ids[(uint64_t)r * a.cur_len + (a.cur_len - 1)] : a.pad_id;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t r = r0 + u * TABLE_WG + tid;
+            const uint32_t grp = row_group(a, r < a.rows ? r : 0);
+            const bool dead = tok[u] == of_group(a.grp_eos, grp) || tok[u] == a.pad_id;
+            const bool in_table = !dead && tok[u] >= 0 && (uint64_t)tok[u] < a.vocab;
+            base[u] = in_table ? of_group(tb.off, grp)[tok[u]] : 0;
+            next[u] = in_table ? of_group(tb.off, grp)[tok[u] + 1] : 0;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t r = r0 + u * TABLE_WG + tid;
+            if (r >= a.rows) continue;
+            s_base[r] = base[u];
+            s_start[r] = (uint32_t)(next[u] - base[u]);
+            if (blockIdx.x == 0) {
+                // the row's side effects, once: its kept range for the next step's one-step advance, the special tokens of its class
+                const uint32_t grp = row_group(a, r);
+                const bool dead = tok[u] == of_group(a.grp_eos, grp) || tok[u] == a.pad_id;
+                if (a.st_out && !dead) {               // (inclusive range; a token outside the vocabulary: the empty one)
+                    const bool in_table = tok[u] >= 0 && (uint64_t)tok[u] < a.vocab;
+                    a.st_out[2 * (uint64_t)r] = in_table ? of_group(tb.root, grp)[2 * tok[u]] : 1;
+                    a.st_out[2 * (uint64_t)r + 1] = in_table ? of_group(tb.root, grp)[2 * tok[u] + 1] : 0;
+                }
+                if (dead) set_bit_global(a, r, a.pad_id);
+                if (a.always_allow_eos) set_bit_global(a, r, of_group(a.grp_eos, grp));
+            }
+        }
+    }
+    __syncthreads();
+    // thread t sums its per_thread consecutive rows; then the scan over the threads
+    const uint32_t per_thread = (a.rows + TABLE_WG - 1) / TABLE_WG;
+    uint32_t mine = 0;
+    for (uint32_t j = 0; j < per_thread; j++) {
+        const uint32_t r = tid * per_thread + j;
+        if (r < a.rows) mine += s_start[r];
+    }
+    s_part[tid] = mine;
+    __syncthreads();
+    if (wave == 0) {                       // exclusive scan of the 256 partial sums by one wave: four per lane
+        uint32_t v[4], sum = 0;
+        for (int j = 0; j < 4; j++) { v[j] = s_part[4 * lane + j]; sum += v[j]; }
+        uint32_t incl = sum;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += y; }
+        uint32_t run = incl - sum;
+        for (int j = 0; j < 4; j++) { s_part[4 * lane + j] = run; run += v[j]; }
+        if (lane == 63) s_part[256] = incl;
+    }
+    __syncthreads();
+    const uint32_t T = s_part[256];
+    {
+        uint32_t run = s_part[tid];
+        for (uint32_t j = 0; j < per_thread; j++) {
+            const uint32_t r = tid * per_thread + j;
+            if (r >= a.rows) break;
+            const uint32_t c = s_start[r];
+            s_start[r] = run;
+            run += c;
+        }
+        if (tid == 0) s_start[a.rows] = T;
+    }
+    __syncthreads();
+    // ---- the flat node list, cut evenly: workgroup w takes [w * per, (w + 1) * per), 32 nodes (lane pairs) per wave iteration ----
+    const uint32_t per = ((T + gridDim.x - 1) / gridDim.x + EXP_PAIRS - 1) / EXP_PAIRS * EXP_PAIRS;
+    const uint32_t lo_i = blockIdx.x * per, hi_i = min(T, lo_i + per);
+    const uint32_t end = lane & 1, pair = lane >> 1;
+    const uint32_t pad_bits = FMI_DIGIT_BITS * D - ix.levels;
+    // (a wave's iteration = a row lookup in LDS, the node's table slot, then its block: two dependent global loads.  The lookup and the
+    //  slot of the NEXT iteration are issued behind this iteration's block load, so that a wave waits for one latency per 32 nodes, not two)
+    const uint32_t step = (TABLE_WG / 64) * EXP_PAIRS;
+    auto fetch = [&](uint32_t at, uint32_t &r, uint4 &nd) -> bool {
+        const uint32_t i = at + pair;
+        r = 0;
+        nd = make_uint4(0u, 0u, 0u, 0u);
+        if (i >= hi_i) return false;
+        uint32_t x = 0, y = a.rows;           // last row with s_start[row] <= i
+        while (y - x > 1) { const uint32_t mid = (x + y) >> 1; if (s_start[mid] <= i) x = mid; else y = mid; }
+        r = x;
+        nd = of_group(tb.nodes, row_group(a, r))[s_base[r] + (i - s_start[r])];
+        return true;
+    };
+    uint32_t c0 = lo_i + wave * EXP_PAIRS;
+    uint32_t r_next = 0;
+    uint4 nd_next = make_uint4(0u, 0u, 0u, 0u);
+    bool act_next = c0 < hi_i && fetch(c0, r_next, nd_next);
+    for (; c0 < hi_i; c0 += step) {
+        const uint32_t r = r_next;
+        const uint4 nd = nd_next;
+        const bool act = act_next;
+        const uint64_t nlo = (uint64_t)nd.x | ((uint64_t)(nd.z & 0xff) << 32);
+        const uint64_t nhi = (uint64_t)nd.y | ((uint64_t)((nd.z >> 8) & 0xff) << 32);
+        const uint32_t prefix = nd.z >> 16;
+        const uint64_t p = end ? nhi : nlo;
+        const uint64_t blk = p >> FMI_BLOCK_SHIFT, oblk = (end ? nlo : nhi) >> FMI_BLOCK_SHIFT;
+        HBlock b;
+        if (act) wm_load_block(ix, kl, blk, b);
+        act_next = c0 + step < hi_i && fetch(c0 + step, r_next, nd_next);
+        uint32_t rk[16];
+#pragma unroll
+        for (uint32_t d = 0; d < 16; d++) rk[d] = 0;
+        if (act) wm_block_ranks(b, (uint32_t)p & (FMI_BLOCK_BITS - 1), rk);
+        // superblocked index: the ends' rows of counts matter only when the ends lie in different superblocks (2^20 positions: rare at the
+        // leaf level) -- then digit d has (rowh[d] - rowl[d]) occurrences between the two superblock starts, which is all an existence
+        // test needs of them (saturated to 32 bits: the in-superblock counters are smaller).  Sixteen loads for the lanes that need them.
+        uint32_t between[8];
+#pragma unroll
+        for (uint32_t s = 0; s < 8; s++) between[s] = 0u;
+        if constexpr (SB) {
+            const uint64_t sb_mine = blk >> ix.sb_shift, sb_other = oblk >> ix.sb_shift;
+            if (act && sb_mine != sb_other) {
+                const uint64_t *rowl = ix.sbase + ((uint64_t)kl * ix.nsb + (end ? sb_other : sb_mine)) * FMI_ARITY + 8 * end;
+                const uint64_t *rowh = ix.sbase + ((uint64_t)kl * ix.nsb + (end ? sb_mine : sb_other)) * FMI_ARITY + 8 * end;
+#pragma unroll
+                for (uint32_t s = 0; s < 8; s++) {
+                    const uint64_t d = rowh[s] - rowl[s];
+                    between[s] = d > 0xffffffffull ? 0xffffffffu : (uint32_t)d;
+                }
+            }
+        }
+        uint32_t hm = 0;                     // which of MY eight children (digits s + 8 * end) exist
+#pragma unroll
+        for (uint32_t s = 0; s < 8; s++) {
+            // lane `end` = 0 holds rank_lo[] and takes digit s, lane 1 holds rank_hi[] and takes digit s + 8
+            const uint32_t x = dpp_xor1(rk[s]), y = dpp_xor1(rk[s + 8]);
+            const uint32_t cl = end ? y : rk[s], ch = end ? rk[s + 8] : x;
+            hm |= (uint32_t)(act && (uint64_t)between[s] + ch > cl) << s;
+        }
+        if (counting) {
+            const uint32_t other_hm = dpp_xor1(hm);
+            if (act && end == 0) { ctr.model += model_nodes(hm | (other_hm << 8), kl, pad_bits); ctr.probes += oblk != blk ? 2 : 1; }
+            if (lane == 0) ctr.probes += 4;                  // the 32 table slots of the iteration: four 128-byte lines
+            const uint32_t left = hi_i - c0;
+            ctr.iters++; ctr.nodes += left < EXP_PAIRS ? left : EXP_PAIRS;
+        }
+        if (act) {
+            // my eight child bits = byte (2 * prefix + end) of the row's SYMBOL bitmap: one owner per byte, plain stores (8-bit masks
+            // ORed into the token bitmap with atomics -- tokens = symbols - shift straddle bytes -- ran at half the speed: 5 M atomics)
+            if (prefix == 0 && end == 0) hm &= ~1u;          // symbol 0 is the sentinel, never a token
+            if (hm) tb.sym[(uint64_t)r * (tb.sym_row_words * 4) + ((uint64_t)prefix << 1) + end] = (uint8_t)hm;
+        }
+    }
+    if (counting) flush_counters(a.probe_counter, ctr);
+}
+
+// second launch of a table call: the rows' symbol bitmaps -> token bitmaps (token = symbol - shift, clipped to the vocabulary; ORed:
+// k_constrain_table has set the special tokens), and the OTHER symbol buffer -- the previous table call's -- zeroed for the next one
+__global__ __launch_bounds__(256) void k_table_bits(ConstrainArgs a, const uint32_t *sym, uint64_t sym_row_words, uint32_t *other, uint32_t other_rows)
+{
+    const uint32_t r = blockIdx.y;
+    const uint64_t W = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < other_rows && W < sym_row_words) other[(uint64_t)r * sym_row_words + W] = 0u;
+    if (r >= a.rows || W >= a.words_per_row) return;
+    const int64_t s0 = (int64_t)(32 * W) + a.shift;          // the symbol of the word's first token
+    const int64_t i = s0 >> 5;                               // (arithmetic shift: floor)
+    const uint32_t sh = (uint32_t)s0 & 31;
+    const uint32_t *row = sym + (uint64_t)r * sym_row_words;
+    const uint32_t w0 = (i >= 0 && (uint64_t)i < sym_row_words) ? row[i] : 0u;
+    const uint32_t w1 = (i + 1 >= 0 && (uint64_t)(i + 1) < sym_row_words) ? row[i + 1] : 0u;
+    uint32_t v = sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
+    if (32 * W + 32 > a.vocab) v &= (1u << (uint32_t)(a.vocab - 32 * W)) - 1;
+    if (v) a.bits[(uint64_t)r * a.words_per_row + W] |= v;
+}
+
+// the two symbol bitmaps of the table calls (they alternate: each call's second launch zeroes the other one), grown on demand
+static int reserve_sym_bits(fmi *h, uint64_t rows, hipStream_t st)
+{
+    const uint64_t words = ((uint64_t)top_digits(h) << (FMI_DIGIT_BITS * (h->dlevels - 1))) / 32 + 1;
+    if (h->sym_bits && rows <= h->sym_rows && words == h->sym_row_words) return FMI_OK;
+    const uint64_t cap = std::max<uint64_t>(rows, h->ws_rows);
+    if (cap * words * 8 > (1ull << 30)) return FMI_ERR_CAPACITY;       // (the caller takes the generic path)
+    HIPCHK(hipStreamSynchronize(st));
+    if (h->sym_bits) { HIPCHK(hipFree(h->sym_bits)); h->sym_bits = nullptr; }
+    HIPCHK(hipMalloc(&h->sym_bits, cap * words * 8));
+    HIPCHK(hipMemsetAsync(h->sym_bits, 0, cap * words * 8, st));
+    h->sym_rows = cap; h->sym_row_words = words; h->sym_dirty_rows[0] = h->sym_dirty_rows[1] = 0;
+    return FMI_OK;
+}
+
 static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur_len, const int64_t *d_ids,
                              uint32_t *d_bits, uint64_t vocab, int64_t shift, int64_t pad_id, const RowGroups &rg,
                              int64_t stop_at_count, int always_allow_eos,
@@ -1663,6 +2040,40 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
     const size_t lds = (size_t)constrain_lds_slots(h->dlevels, W) * 16;
     const bool sb = h->dev.nsb > 1;
+    // The first constrained step of a decode (every prefix = its decode's forced prefix + one token) from the per-token node tables:
+    // one flat, evenly cut leaf-level pass (k_constrain_table) instead of the expansion from the root.  Tables are built on first use
+    // (once per index and forced prefix, synchronously: a few ms); a prefix whose table would be too large takes the generic path.
+    // (a packed node carries 16 bits of symbol prefix: leaf-level nodes of up to five digit levels)
+    if (h->opt.prefix_tables && cur_len == 2 && !inc && !a.tstamp && h->dlevels <= 5 && table_lds_bytes((uint32_t)rows) <= 64 * 1024) {
+        TableArgs tb{};
+        bool all = true;
+        for (uint32_t g = 0; g < rg.n; g++) {
+            if (a.grp_stop[g] > 0) { all = false; break; }      // (the count of the prefix without its last token: not tabulated)
+            int trc = FMI_OK;
+            const FmiPrefixTable *T = prefix_table_for(h, rg.force[g], rg.n_force[g], shift, vocab, &trc);
+            if (trc) return trc;
+            if (!T) { all = false; break; }
+            tb.off[g] = T->d_off; tb.root[g] = T->d_root; tb.nodes[g] = (const uint4 *)T->d_nodes;
+        }
+        if (all && reserve_sym_bits(h, rows, st) != FMI_OK) { all = false; (void)hipGetLastError(); }
+        if (all) {
+            const int cur = h->sym_flip, oth = cur ^ 1;
+            h->sym_flip = oth;
+            uint32_t *buf[2] = {(uint32_t *)h->sym_bits, (uint32_t *)h->sym_bits + h->sym_rows * h->sym_row_words};
+            tb.sym = (uint8_t *)buf[cur]; tb.sym_row_words = h->sym_row_words;
+            void (*kt)(FmiDev, ConstrainArgs, TableArgs) = sb ? k_constrain_table<true> : k_constrain_table<false>;
+            const unsigned tgrid = h->opt.table_grid > 0 ? (unsigned)std::min<int64_t>(h->opt.table_grid, 1 << 16) : TABLE_GRID;
+            hipLaunchKernelGGL(kt, dim3(tgrid), dim3(TABLE_WG), table_lds_bytes((uint32_t)rows), st, h->dev, a, tb);
+            const uint64_t oth_rows = h->sym_dirty_rows[oth];
+            const uint64_t per_row = std::max<uint64_t>(wpr, h->sym_row_words);
+            hipLaunchKernelGGL(k_table_bits, dim3((unsigned)blocks_for(per_row, 256), (unsigned)std::max<uint64_t>(rows, oth_rows)), dim3(256), 0, st,
+                               a, (const uint32_t *)buf[cur], h->sym_row_words, buf[oth], (uint32_t)oth_rows);
+            h->sym_dirty_rows[cur] = rows; h->sym_dirty_rows[oth] = 0;
+            HIPCHK(hipGetLastError());
+            if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
+            return FMI_OK;
+        }
+    }
     // Row-first: once the prefixes are a few tokens long, nine of ten (row, top digit) items are empty and a call is the chain of
     // dependent accesses of a row (parent -> kept range -> one backward-search step -> root child), which every one of the 13 waves
     // of a row would repeat: ONE wave per row runs it first (k_constrain_rows), the item waves pick the result up with a single load

@@ -147,13 +147,15 @@ def test_save_load_round_trip_on_gpu(pair, tmp_path):
 
 
 @pytest.mark.parametrize("form", [dict(constrain_waves=8), dict(constrain_waves=1), dict(row_first=0), dict(row_first=1), dict(leave_early=0),
-                                  dict(row_first=1, leave_early=0)],
-                         ids=["shared-leaf-phase", "self-contained-waves", "single-launch", "row-first", "empty-waves-stay", "row-first-empty-waves-stay"])
+                                  dict(row_first=1, leave_early=0), dict(prefix_tables=0), dict(prefix_tables=0, constrain_waves=1)],
+                         ids=["shared-leaf-phase", "self-contained-waves", "single-launch", "row-first", "empty-waves-stay", "row-first-empty-waves-stay",
+                              "no-prefix-tables", "no-prefix-tables-self-contained-waves"])
 def test_logits_processor_matches_reference_semantics(pair, form):
     """every launch form of a constraint call gives the reference's masks: workgroups of 8 waves that serve their leaf-level
     nodes together (the default up to 4 digit levels) / one self-contained wave per (row, top digit); the single launch / the
     row-first pair (k_constrain_rows, then k_constrain) whatever the prefix length; the waves of empty items leaving early or
-    staying.  (Two more forms were measured in round 4 and dropped -- one wave per row for the whole row, and rows of small
+    staying; the first constrained step (prefix = forced prefix + one token) from the per-token node tables (k_constrain_table, the
+    default) or through the generic expansion.  (Two more forms were measured in round 4 and dropped -- one wave per row for the whole row, and rows of small
     intervals finished by their own wave: profiles/r4_rows_forms_ab_*.txt.)"""
     from tests.helpers import kernel_options
     ix, orc, docs, vocab = pair
@@ -169,7 +171,8 @@ def _logits_processor_cases(ix, orc, docs, vocab):
     V = vocab + 7
     beams = 3
     dev = torch.device("cuda:0")
-    for cur_len, kw in [(1, {}), (2, {}), (3, {}), (5, {}), (4, dict(force_decoding_from=[2])),
+    for cur_len, kw in [(1, {}), (2, {}), (3, {}), (5, {}), (4, dict(force_decoding_from=[2])), (2, dict(force_decoding_from=[2])),
+                        (2, dict(always_allow_eos=True)), (2, dict(stop_at_count=2)), (2, dict(force_decoding_from=[2, 7])),
                         (3, dict(stop_at_count=3)), (3, dict(always_allow_eos=True)), (1, dict(always_allow_eos=True)),
                         (2, dict(forced_bos_token_id=0)), (1, dict(forced_bos_token_id=0))]:
         rows = []

@@ -178,7 +178,8 @@ def main():
                               "us_per_call": round(ms.value * 1e3 / args.iters, 2), "GBps": round(gbs, 1),
                               "frac_of_8TBps": round(gbs / 8000, 4), "wave_iters_per_call": stats[1] / args.iters,
                               "lane_pair_util": round(stats[2] / max(1, 32 * stats[1]), 3), "model_probes_per_call": 2 * stats[3] / args.iters,
-                              "model_GBps": round(2 * stats[3] * 64 / (ms.value * 1e-3) / 1e9, 1), "avg_allowed_tokens_first8rows": allowed}), flush=True)
+                              "model_GBps": round(2 * stats[3] * 64 / (ms.value * 1e-3) / 1e9, 1), "avg_allowed_tokens_first8rows": allowed,
+                              "bitmap_checksum": int((bits.long() * (1 + torch.arange(bits.numel(), device=dev).view_as(bits) % 8191)).sum())}), flush=True)
 
 
 if __name__ == "__main__":
