@@ -754,7 +754,7 @@ def main():
     model_gbps = model_bytes / (k2.value * 1e-3) / 1e9 if k2.value > 0 else 0.0
     # memory-side traffic comes from a SEPARATE rocprofv3 --pmc FETCH_SIZE pass of this same command over the
     # CURRENT kernel (tools/prof_bench.sh -> profiles/r*_pmc_fetch_size.json, which names the commit it was taken
-    # at); a profile of another kernel generation is not used.  Per launch = per constraint call = one k_constrain.
+    # at); a profile of another kernel generation is not used.  Per launch = per constraint call = one k_constrain / k_constrain_table.
     # FETCH_SIZE counts 128-byte requests at 64 bytes on gfx950 (MI355X guide; tools/gather_calib.hip): x 2.
     traffic = traffic_src = None
     try:
@@ -769,7 +769,11 @@ def main():
                 continue            # counters of another kernel generation are REFUSED (the file records the source it profiled)
             if pmc.get("_workload") != workload_tag:
                 continue            # ... and so are counters taken on another workload (index size, beam): per-workload files
-            kib = sum(v["FETCH_SIZE"]["avg"] for k, v in pmc.items() if "k_constrain" in k)      # both launches of a row-first call
+            # every launch of the constraint calls (k_constrain_rows + k_constrain of a row-first call; k_constrain_table + k_table_bits of a
+            # decode's first step), summed over the run and divided by the CALLS (one k_constrain or one k_constrain_table each)
+            mine = {k: v["FETCH_SIZE"] for k, v in pmc.items() if isinstance(v, dict) and ("k_constrain" in k or "k_table_bits" in k)}
+            calls = sum(c["launches"] for k, c in mine.items() if "k_constrain<" in k or "k_constrain_table" in k)
+            kib = sum(c["sum"] for c in mine.values()) / calls if calls else 0
             if kib:
                 traffic = round(kib * 1024.0 * 2, 1)
                 traffic_src = {"file": os.path.relpath(f, ROOT), "commit": pmc.get("_commit"), "kernel_source_sha256": now[:16], "workload": workload_tag}
@@ -780,9 +784,10 @@ def main():
     except Exception as e:
         traffic_src = {"error": repr(e)}
     nl = n2
-    roofline = {"bound": "hbm", "kernel": "k_constrain (one constraint call for the rows of both decodes; from 2-token prefixes on as two launches: "
-                                          "k_constrain_rows -- one wave per row: prefix range, class, root node split -- then k_constrain -- one wave per "
-                                          "(row, top digit), the sub-trees level by level by workgroups of 8 waves; events bracket the call)",
+    roofline = {"bound": "hbm", "kernel": "k_constrain (one constraint call for the rows of both decodes: k_constrain_rows -- one wave per row: prefix "
+                                          "range, class, root node split -- then k_constrain -- one wave per (row, top digit), the sub-trees level by level "
+                                          "by workgroups of 8 waves; the FIRST call of a decode instead k_constrain_table -- the leaf-level nodes of every row "
+                                          "from the per-token tables as one evenly cut list -- then k_table_bits; events bracket the call)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic, "traffic_source": traffic_src, "launches": int(l2.value), "avg_launch_us": round(k2.value * 1e3 / n2, 2),
                 "algorithmic_bytes_per_launch": round(p2.value * 128.0 / n2, 1),
