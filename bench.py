@@ -419,6 +419,15 @@ def score_parity(searcher, model, index, queries, bias, dev, n_rescore_queries=4
     return out
 
 
+def _prefix_table_stats(index):
+    """the per-token node tables the index handle built for the first constrained step of the decodes"""
+    import ctypes
+    from seal_amd._lib import check, lib
+    t, n, b = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    check(lib().fmi_dev_prefix_table_stats(index.handle, ctypes.byref(t), ctypes.byref(n), ctypes.byref(b)))
+    return {"tables": t.value, "leaf_level_nodes": n.value, "hbm_mib": round(b.value / 2**20, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -907,7 +916,8 @@ def main():
                                                   "roofline figures come from separate un-overlapped passes after it",
                   "decode_step_gemm_algorithms": "library default (hipBLASLt heuristic); round 3's TunableOp picks are gone: one of them stalled the search (DESIGN.md 9)",
                   "phase_ms_one_batch": {k: round(v, 2) for k, v in phases.items()},
-                  "k_constrain_ms_one_batch": round(k2.value, 3), "k_constrain_blocks_one_batch": int(p2.value)},
+                  "k_constrain_ms_one_batch": round(k2.value, 3), "k_constrain_blocks_one_batch": int(p2.value),
+                  "prefix_tables": _prefix_table_stats(index)},
     }
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:

@@ -259,9 +259,14 @@ int fmi_dev_debug_timestamps(fmi_t *h, uint64_t *d_buf, uint64_t n_words);
  * "leave_early" (0: the waves of empty items stay), "row_first" (0 / 1: never / always the row-first pair of launches),
  * "row_first_from" (prefix length in tokens from which a call goes row-first),
  * "prefix_tables" (0: the first constrained step of a decode through the generic expansion instead of the per-token node tables),
+ * "table_grid" (workgroups of the table call's flat pass),
  * "topk_narrow" (rows with more allowed tokens take the wide-row path of the top-2K kernel), "topk_legacy" (1: exact radix
  * select on wide rows).  Results are identical for every setting (tests/test_gpu_fmindex.py, tests/test_gpu_decode.py). */
 int fmi_dev_set_option(fmi_t *h, const char *name, int64_t value);
+
+/* The per-token node tables this handle has built so far (one per forced prefix of a decode; the first constrained step of a decode
+ * reads them instead of expanding from the root): how many, their leaf-level nodes in total, the HBM they hold. */
+int fmi_dev_prefix_table_stats(fmi_t *h, uint64_t *n_tables, uint64_t *n_nodes, uint64_t *n_bytes);
 
 /* tools only (tools/soak.py: which launch of a stalled stream never completed): while `marks` (>= 16 uint32 of
  * host-visible memory, e.g. pinned) is set, fmi_dev_aggregate writes marks[1] = 100 * call number + stage after every

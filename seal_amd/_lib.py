@@ -53,6 +53,7 @@ SIGNATURES = {
     "fmi_dev_allowed_bits_step": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, _i64, _i64, _i64, _pi64, _u64, _i64, _int, _u64, _vp, _vp]),
     "fmi_dev_debug_timestamps": (_int, [_vp, _vp, _u64]),
     "fmi_dev_set_option": (_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
+    "fmi_dev_prefix_table_stats": (_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "fmi_dev_debug_marks": (_int, [_vp, _vp]),
     "fmi_dev_mark": (_int, [_vp, _vp, ctypes.c_uint32]),
     "fmi_dev_constrained_topk": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _u64, _i64, _i64, _i64, _pi64, _u64, _i64, _int,

@@ -74,6 +74,21 @@ extern "C" int fmi_dev_set_option(fmi_t *h, const char *name, int64_t value)
     return FMI_OK;
 }
 
+extern "C" int fmi_dev_prefix_table_stats(fmi_t *h, uint64_t *n_tables, uint64_t *n_nodes, uint64_t *n_bytes)
+{
+    if (!h) { fmi_set_error("null handle"); return FMI_ERR_ARG; }
+    uint64_t t = 0, n = 0, b = 0;
+    for (const FmiPrefixTable &T : h->prefix_tables) {
+        if (!T.ok) continue;
+        t++; n += T.n_nodes;
+        b += T.n_nodes * 16 + (T.vocab + 1) * 8 + T.vocab * 16;
+    }
+    if (n_tables) *n_tables = t;
+    if (n_nodes) *n_nodes = n;
+    if (n_bytes) *n_bytes = b;
+    return FMI_OK;
+}
+
 extern "C" int fmi_create(fmi_t **out)
 {
     if (!out) { fmi_set_error("fmi_create: null out"); return FMI_ERR_ARG; }
