@@ -76,6 +76,19 @@ int sealnn_split_planes(void *stream, const float *x, uint32_t rows, uint32_t K,
 int sealnn_add_layernorm_planes(void *stream, const float *x, const float *y, const float *gamma, const float *beta, uint32_t rows,
                                 uint32_t d, float eps, float *out, void *planes, uint32_t *d_flag);
 int sealnn_gelu_planes(void *stream, const float *x, uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag);
+/* The same kernels reading the RAW fp32 accumulators of a split GEMM (torch.mm(planes, W^T, out_dtype=float32)): the projection's output is
+ * alpha * acc + bias -- the GEMM's epilogue, applied on read by the kernel that consumes it instead of as a pass over the output (which is
+ * what torch.addmm(out_dtype=float32) costs: a copy of the broadcast bias in front of every product).  bias: [3 * heads * 64] for the qkv
+ * projections, [d] otherwise; alpha a power of two (split_gemm.split_weight), so alpha * acc is exact and the result is bit for bit the
+ * epilogue's.  `planes` of sealnn_add_layernorm_acc may be NULL. */
+int sealnn_self_attn_step_acc(void *stream, const float *qkv_acc, const float *qkv_bias, float alpha, float *kcache, float *vcache,
+                              const int64_t *d_t, uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out, int32_t *anc);
+int sealnn_tree_self_attn_acc(void *stream, const float *qkv_acc, const float *qkv_bias, float alpha, const int32_t *anc, uint32_t n_nodes,
+                              uint32_t max_depth1, uint32_t heads, float scale, float *out);
+int sealnn_add_layernorm_acc(void *stream, const float *x, const float *y_acc, const float *y_bias, float alpha, const float *gamma,
+                             const float *beta, uint32_t rows, uint32_t d, float eps, float *out, void *planes, uint32_t *d_flag);
+int sealnn_gelu_planes_acc(void *stream, const float *x_acc, const float *x_bias, float alpha, uint32_t rows, uint32_t d, void *planes,
+                           uint32_t *d_flag);
 
 #ifdef __cplusplus
 }

@@ -118,6 +118,10 @@ NN_SIGNATURES = {
     "sealnn_split_planes": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "sealnn_add_layernorm_planes": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp]),
     "sealnn_gelu_planes": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    "sealnn_self_attn_step_acc": (_int, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp, _vp]),
+    "sealnn_tree_self_attn_acc": (_int, [_vp, _vp, _vp, _f32, _vp, _u32, _u32, _u32, _f32, _vp]),
+    "sealnn_add_layernorm_acc": (_int, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp]),
+    "sealnn_gelu_planes_acc": (_int, [_vp, _vp, _vp, _f32, _u32, _u32, _vp, _vp]),
 }
 
 _lib = None

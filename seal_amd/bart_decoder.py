@@ -76,20 +76,42 @@ class BartStepDecoder:
 
     FUSED_DTYPES = (torch.float32, torch.bfloat16)
 
-    # fp32 linear layers of the fused paths on the fp16 matrix cores (seal_amd/split_gemm.py; opt-in, SEAL_SPLIT_GEMM=1)
+    # fp32 linear layers of the fused paths on the fp16 matrix cores (seal_amd/split_gemm.py; SEAL_SPLIT_GEMM=0: plain fp32 GEMMs)
     split_gemm = None
 
-    def _lin(self, x: torch.Tensor, w: torch.Tensor, b) -> torch.Tensor:
-        """``F.linear(x, w, b)`` of an fp32 [rows, K] activation on the GPU -- through the split GEMM when that is switched on"""
+    def _lin(self, x: torch.Tensor, w: torch.Tensor, b, defer: bool = False):
+        """``F.linear(x, w, b)`` of an fp32 [rows, K] activation on the GPU -- through the split GEMM when that is switched on.
+        ``defer``: the caller hands the result to a sealnn_*_acc kernel, which applies the epilogue of a split product itself
+        (``split_gemm.Deferred``; a product that does not go through the split comes back finished)"""
         if self.split_gemm is None:
             from . import split_gemm
             BartStepDecoder.split_gemm = split_gemm.SplitLinears() if split_gemm.ENABLED else False
         if self.split_gemm and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
-            return self.split_gemm(x, w, b)
+            return self.split_gemm(x, w, b, defer)
         return F.linear(x, w, b)
 
-    def _mod(self, x: torch.Tensor, m) -> torch.Tensor:
-        return self._lin(x, m.weight, m.bias)
+    def _mod(self, x: torch.Tensor, m, defer: bool = False):
+        return self._lin(x, m.weight, m.bias, defer)
+
+    # -- the consumers of a product: the finished tensor through the plain kernel, a Deferred one through its _acc twin --
+    def _add_ln(self, L_, stream, res, y, ln, rows, planes):
+        """LayerNorm(res + y) -> (fp32, its split planes or None); ``y``: a tensor or a ``split_gemm.Deferred``"""
+        from . import split_gemm
+        from ._lib import check, lib
+        out = torch.empty_like(res)
+        p = torch.empty(rows, 3 * self.d, dtype=torch.float16, device=res.device) if planes else None
+        flag = split_gemm._flag(res.device).data_ptr() if planes else None
+        if isinstance(y, split_gemm.Deferred):
+            check(lib().sealnn_add_layernorm_acc(stream, res.data_ptr(), y.acc.data_ptr(), y.bias.data_ptr(), float(y.alpha), ln.weight.data_ptr(),
+                                                 ln.bias.data_ptr(), rows, self.d, float(ln.eps), out.data_ptr(),
+                                                 p.data_ptr() if planes else None, flag))
+        elif planes:
+            check(lib().sealnn_add_layernorm_planes(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                                    rows, self.d, float(ln.eps), out.data_ptr(), p.data_ptr(), flag))
+        else:
+            check(L_.add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                   rows, self.d, float(ln.eps), out.data_ptr()))
+        return out, p
 
     # -- split GEMM with the operand planes written by the kernels that produce the activations (split_gemm.FUSED) --
     def _planes_on(self, x: torch.Tensor) -> bool:
@@ -98,11 +120,11 @@ class BartStepDecoder:
             BartStepDecoder.split_gemm = split_gemm.SplitLinears() if split_gemm.ENABLED else False
         return bool(self.split_gemm) and split_gemm.FUSED and x.is_cuda and x.dtype == torch.float32
 
-    def _lin_p(self, x: torch.Tensor, xp, w: torch.Tensor, b) -> torch.Tensor:
-        """``F.linear(x, w, b)`` where ``xp`` (or None) holds x's split planes already"""
+    def _lin_p(self, x: torch.Tensor, xp, w: torch.Tensor, b, defer: bool = False):
+        """``F.linear(x, w, b)`` where ``xp`` (or None) holds x's split planes already (``defer``: see ``_lin``)"""
         if xp is not None and self.split_gemm and self.split_gemm.wants(w, x.shape[0]):
-            return self.split_gemm.from_planes(xp, w, b)
-        return self._lin(x, w, b)
+            return self.split_gemm.from_planes(xp, w, b, defer)
+        return self._lin(x, w, b, defer)
 
     def _planes_of(self, x: torch.Tensor) -> torch.Tensor:
         from . import split_gemm
@@ -112,18 +134,25 @@ class BartStepDecoder:
                                         split_gemm._flag(x.device).data_ptr()))
         return p
 
-    def _ffn(self, x: torch.Tensor, xp, L) -> torch.Tensor:
-        """fc2(gelu(fc1(x))): with planes, gelu's output exists as fc2's operand only"""
-        h = self._lin_p(x, xp, L["fc1"].weight, L["fc1"].bias)
+    def _ffn(self, x: torch.Tensor, xp, L, defer: bool = False):
+        """fc2(gelu(fc1(x))): with planes, gelu's output exists as fc2's operand only (``defer``: see ``_lin``; fc1's own epilogue is
+        always gelu's to apply)"""
         w2 = L["fc2"].weight
         if xp is not None and self.split_gemm.wants(w2, x.shape[0]) and getattr(L["act"], "__class__", type(None)).__name__ in ("GELUActivation", "GELU"):
             from . import split_gemm
             from ._lib import check, lib
-            hp = torch.empty(h.shape[0], 3 * h.shape[1], dtype=torch.float16, device=h.device)
-            check(lib().sealnn_gelu_planes(torch.cuda.current_stream(h.device).cuda_stream, h.data_ptr(), h.shape[0], h.shape[1], hp.data_ptr(),
-                                           split_gemm._flag(h.device).data_ptr()))
-            return self.split_gemm.from_planes(hp, w2, L["fc2"].bias)
-        return self._mod(L["act"](h), L["fc2"])
+            h = self._lin_p(x, xp, L["fc1"].weight, L["fc1"].bias, defer=True)
+            acc = h.acc if isinstance(h, split_gemm.Deferred) else h
+            hp = torch.empty(acc.shape[0], 3 * acc.shape[1], dtype=torch.float16, device=acc.device)
+            stream = torch.cuda.current_stream(acc.device).cuda_stream
+            flag = split_gemm._flag(acc.device).data_ptr()
+            if isinstance(h, split_gemm.Deferred):
+                check(lib().sealnn_gelu_planes_acc(stream, acc.data_ptr(), h.bias.data_ptr(), float(h.alpha), acc.shape[0], acc.shape[1], hp.data_ptr(), flag))
+            else:
+                check(lib().sealnn_gelu_planes(stream, acc.data_ptr(), acc.shape[0], acc.shape[1], hp.data_ptr(), flag))
+            return self.split_gemm.from_planes(hp, w2, L["fc2"].bias, defer)
+        h = self._lin_p(x, xp, L["fc1"].weight, L["fc1"].bias)
+        return self._mod(L["act"](h), L["fc2"], defer)
 
     @torch.no_grad()
     def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
@@ -270,34 +299,29 @@ class BartStepDecoder:
             row_batch = qidx.to(torch.int32).contiguous()
             A = anc32.shape[1]
 
+            from . import split_gemm
+            from ._lib import lib
             planes = self._planes_on(x)
 
             def add_ln(res, y, ln):
-                out = torch.empty_like(res)
-                if planes:
-                    from . import split_gemm
-                    from ._lib import lib
-                    p = torch.empty(N, 3 * self.d, dtype=torch.float16, device=dev)
-                    check(lib().sealnn_add_layernorm_planes(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
-                                                            N, self.d, float(ln.eps), out.data_ptr(), p.data_ptr(),
-                                                            split_gemm._flag(dev).data_ptr()))
-                    return out, p
-                check(L_.add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
-                                       N, self.d, float(ln.eps), out.data_ptr()))
-                return out, None
+                return self._add_ln(L_, stream, res, y, ln, N, planes)
             xp = self._planes_of(x) if planes else None
             for li, L in enumerate(self.layers):
-                qkv = self._lin_p(x, xp, L["qkv_w"], L["qkv_b"])
+                qkv = self._lin_p(x, xp, L["qkv_w"], L["qkv_b"], defer=True)
                 a = torch.empty(N, self.d, dtype=x.dtype, device=dev)
-                check(L_.tree_self_attn(stream, qkv.data_ptr(), anc32.data_ptr(), N, A, self.h, float(self.scale), a.data_ptr()))
-                x, xp = add_ln(x, self._mod(a, L["so"]), L["ln1"])
+                if isinstance(qkv, split_gemm.Deferred):
+                    check(lib().sealnn_tree_self_attn_acc(stream, qkv.acc.data_ptr(), qkv.bias.data_ptr(), float(qkv.alpha), anc32.data_ptr(), N, A,
+                                                          self.h, float(self.scale), a.data_ptr()))
+                else:
+                    check(L_.tree_self_attn(stream, qkv.data_ptr(), anc32.data_ptr(), N, A, self.h, float(self.scale), a.data_ptr()))
+                x, xp = add_ln(x, self._mod(a, L["so"], defer=True), L["ln1"])
                 q = self._lin_p(x, xp, L["cq"].weight, L["cq"].bias)
                 c = torch.empty(N, self.d, dtype=x.dtype, device=dev)
                 ck, cv = cross[li]
                 check(L_.cross_attn_rows(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
                                          N, self.h, S, float(self.scale), c.data_ptr()))
-                x, xp = add_ln(x, self._mod(c, L["co"]), L["ln2"])
-                x, xp = add_ln(x, self._ffn(x, xp, L), L["ln3"])
+                x, xp = add_ln(x, self._mod(c, L["co"], defer=True), L["ln2"])
+                x, xp = add_ln(x, self._ffn(x, xp, L, defer=True), L["ln3"])
             if hidden_only:
                 return x            # (the caller projects slices of x: lm_head -> _lin -> the split kernel per slice)
             return self._lin_p(x, xp, self.lm_w, self.lm_b.view(-1))
@@ -423,34 +447,30 @@ class BartStepDecoder:
             stream = torch.cuda.current_stream(x.device).cuda_stream
             cbias = st.cbias.view(B, S_pad)
 
+            from . import split_gemm
             planes = self._planes_on(x)
 
             def add_ln(res, y, ln):
                 """LayerNorm(res + y) -> (fp32, its split planes or None)"""
-                out = torch.empty_like(res)
-                if planes:
-                    from . import split_gemm
-                    p = torch.empty(R, 3 * self.d, dtype=torch.float16, device=res.device)
-                    check(lib().sealnn_add_layernorm_planes(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
-                                                            R, self.d, float(ln.eps), out.data_ptr(), p.data_ptr(),
-                                                            split_gemm._flag(res.device).data_ptr()))
-                    return out, p
-                check(L_.add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
-                                       R, self.d, float(ln.eps), out.data_ptr()))
-                return out, None
+                return self._add_ln(L_, stream, res, y, ln, R, planes)
             xp = self._planes_of(x) if planes else None
             for li, L in enumerate(self.layers):
-                qkv = self._lin_p(x, xp, L["qkv_w"], L["qkv_b"])
+                qkv = self._lin_p(x, xp, L["qkv_w"], L["qkv_b"], defer=True)
                 a = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
-                check(L_.self_attn_step(stream, qkv.data_ptr(), st.kv[li, 0].data_ptr(), st.kv[li, 1].data_ptr(),
-                                        st.t.data_ptr(), R, H, T, float(self.scale), a.data_ptr(), st.anc.data_ptr()))
-                x, xp = add_ln(x, self._mod(a, L["so"]), L["ln1"])
+                if isinstance(qkv, split_gemm.Deferred):
+                    check(lib().sealnn_self_attn_step_acc(stream, qkv.acc.data_ptr(), qkv.bias.data_ptr(), float(qkv.alpha), st.kv[li, 0].data_ptr(),
+                                                          st.kv[li, 1].data_ptr(), st.t.data_ptr(), R, H, T, float(self.scale), a.data_ptr(),
+                                                          st.anc.data_ptr()))
+                else:
+                    check(L_.self_attn_step(stream, qkv.data_ptr(), st.kv[li, 0].data_ptr(), st.kv[li, 1].data_ptr(),
+                                            st.t.data_ptr(), R, H, T, float(self.scale), a.data_ptr(), st.anc.data_ptr()))
+                x, xp = add_ln(x, self._mod(a, L["so"], defer=True), L["ln1"])
                 q = self._lin_p(x, xp, L["cq"].weight, L["cq"].bias)
                 c = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
                 check(L_.cross_attn_step(stream, q.data_ptr(), st.ck[li].data_ptr(), st.cv[li].data_ptr(), cbias.data_ptr(),
                                          B, K, H, S_pad, float(self.scale), c.data_ptr()))
-                x, xp = add_ln(x, self._mod(c, L["co"]), L["ln2"])
-                x, xp = add_ln(x, self._ffn(x, xp, L), L["ln3"])
+                x, xp = add_ln(x, self._mod(c, L["co"], defer=True), L["ln2"])
+                x, xp = add_ln(x, self._ffn(x, xp, L, defer=True), L["ln3"])
             st.t.add_(1)
             return self._lin_p(x, xp, self.lm_w, self.lm_b.view(-1)).float()
         future = st.pos_idx > st.t                                   # cache slots not written yet

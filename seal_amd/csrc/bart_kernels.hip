@@ -85,10 +85,12 @@ static __device__ __forceinline__ float wave_max(float v)
 // one wavefront per (row, head); lane = head dimension.  `anc` (optional, [T][rows]): the cache is
 // never reordered when beams are re-ranked; instead anc[p][row] names the row whose slot at position p
 // belongs to `row`'s history (the decoder permutes this 20 KB table, not the 100+ MB cache).
+// `pb` (optional, [3 * heads * 64]) / `pa`: qkv holds the raw accumulators of a split GEMM (seal_amd/split_gemm.py: Deferred) and the
+// projection's output is pa * qkv + pb -- the GEMM's own epilogue, applied here on read instead of in a pass over qkv
 template <typename T_>
 __global__ __launch_bounds__(256) void k_self_attn_step(const T_ *qkv, T_ *kcache, T_ *vcache, const int64_t *d_t,
                                                         uint32_t rows, uint32_t heads, uint32_t T, float scale, T_ *out,
-                                                        int32_t *anc)
+                                                        int32_t *anc, const T_ *pb, float pa)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -96,9 +98,14 @@ __global__ __launch_bounds__(256) void k_self_attn_step(const T_ *qkv, T_ *kcach
     const uint32_t row = item / heads, head = item % heads;
     const uint32_t t = (uint32_t)*d_t;
     const T_ *base = qkv + ((uint64_t)row * 3 * heads + head) * 64;
-    const float q = ldf(base + lane) * scale;
-    const float kn = ldf(base + (uint64_t)heads * 64 + lane);       // (bf16: already the value the cache will hold)
-    const float vn = ldf(base + (uint64_t)2 * heads * 64 + lane);
+    float q = ldf(base + lane);
+    float kn = ldf(base + (uint64_t)heads * 64 + lane);       // (bf16: already the value the cache will hold)
+    float vn = ldf(base + (uint64_t)2 * heads * 64 + lane);
+    if (pb) {
+        const T_ *b = pb + head * 64 + lane;
+        q = pa * q + ldf(b); kn = pa * kn + ldf(b + (uint64_t)heads * 64); vn = pa * vn + ldf(b + (uint64_t)2 * heads * 64);
+    }
+    q *= scale;
     T_ *kc = kcache + ((uint64_t)row * heads + head) * T * 64;
     T_ *vc = vcache + ((uint64_t)row * heads + head) * T * 64;
     stf(kc + (uint64_t)t * 64 + lane, kn);
@@ -209,14 +216,21 @@ __global__ __launch_bounds__(256) void k_causal_self_attn(const T_ *qkv, uint32_
 // `depth` of a row holding that prefix.
 template <typename T_>
 __global__ __launch_bounds__(256) void k_tree_self_attn(const T_ *qkv, const int32_t *anc, uint32_t n_nodes, uint32_t A, uint32_t heads,
-                                                        float scale, T_ *out)
+                                                        float scale, T_ *out, const T_ *pb, float pa)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_nodes * heads) return;
     const uint32_t node = item / heads, head = item % heads;
     const uint64_t stride = (uint64_t)3 * heads * 64;               // per node
-    const float q = ldf(qkv + (uint64_t)node * stride + head * 64 + lane) * scale;
+    // (pb / pa: qkv = raw split-GEMM accumulators, the projection is pa * qkv + pb; see k_self_attn_step)
+    float q = ldf(qkv + (uint64_t)node * stride + head * 64 + lane);
+    float bk = 0.f, bv = 0.f;
+    if (pb) {
+        const T_ *b = pb + head * 64 + lane;
+        q = pa * q + ldf(b); bk = ldf(b + (uint64_t)heads * 64); bv = ldf(b + (uint64_t)2 * heads * 64);
+    }
+    q *= scale;
     const int32_t *mine = anc + (uint64_t)node * A;
     float s[FMI_MAX_LEVELS], vreg[FMI_MAX_LEVELS];
     float m = -__builtin_huge_valf();
@@ -227,8 +241,9 @@ __global__ __launch_bounds__(256) void k_tree_self_attn(const T_ *qkv, const int
         const int32_t a = j < A ? mine[j] : -1;
         if (a >= 0 && cnt == j) {
             const T_ *row = qkv + (uint64_t)a * stride + head * 64 + lane;
-            const float k = ldf(row + (uint64_t)heads * 64);
+            float k = ldf(row + (uint64_t)heads * 64);
             vreg[j] = ldf(row + (uint64_t)2 * heads * 64);
+            if (pb) { k = pa * k + bk; vreg[j] = pa * vreg[j] + bv; }
             s[j] = wave_sum(q * k);
             m = fmaxf(m, s[j]);
             cnt = j + 1;
@@ -311,8 +326,10 @@ __global__ __launch_bounds__(512) void k_cross_attn_runs(const T_ *q, const T_ *
 
 // one wavefront per row, d <= 4096 (16 float4 per lane)
 template <typename T_>
+// (yb / ya: y = raw split-GEMM accumulators, the addend is ya * y + yb; see k_self_attn_step)
 __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y, const T_ *gamma, const T_ *beta,
-                                                       uint32_t rows, uint32_t d, float eps, T_ *out, __half *planes, uint32_t *flag)
+                                                       uint32_t rows, uint32_t d, float eps, T_ *out, __half *planes, uint32_t *flag,
+                                                       const T_ *yb, float ya)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -326,7 +343,9 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y,
         const uint32_t i = lane + 64 * j;
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < n4) {
-            const float4 a = ld4(xr, i), b = ld4(yr, i);
+            const float4 a = ld4(xr, i);
+            float4 b = ld4(yr, i);
+            if (yb) { const float4 c = ld4(yb, i); b = make_float4(ya * b.x + c.x, ya * b.y + c.y, ya * b.z + c.z, ya * b.w + c.w); }
             v[j] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
             sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         }
@@ -359,13 +378,15 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y,
 }
 
 // fc2's operand: planes of gelu(x) (the erf form, the arithmetic of torch's GeluCUDAKernelImpl: 0.5 * x * (1 + erf(x * M_SQRT1_2)))
-__global__ __launch_bounds__(256) void k_gelu_planes(const float *x, uint32_t rows, uint32_t d, __half *planes, uint32_t *flag)
+// (xb / xa: x = raw split-GEMM accumulators, gelu's argument is xa * x + xb; see k_self_attn_step)
+__global__ __launch_bounds__(256) void k_gelu_planes(const float *x, uint32_t rows, uint32_t d, __half *planes, uint32_t *flag, const float *xb, float xa)
 {
     const uint32_t per_row = d / 4;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)rows * per_row) return;
     const uint32_t r = (uint32_t)(i / per_row), c = (uint32_t)(i % per_row);
-    const float4 v = reinterpret_cast<const float4 *>(x + (uint64_t)r * d)[c];
+    float4 v = reinterpret_cast<const float4 *>(x + (uint64_t)r * d)[c];
+    if (xb) { const float4 b = reinterpret_cast<const float4 *>(xb)[c]; v = make_float4(xa * v.x + b.x, xa * v.y + b.y, xa * v.z + b.z, xa * v.w + b.w); }
     const float kAlpha = 0.70710678118654752440f;
     const float4 g = make_float4(0.5f * v.x * (1.f + erff(v.x * kAlpha)), 0.5f * v.y * (1.f + erff(v.y * kAlpha)),
                                  0.5f * v.z * (1.f + erff(v.z * kAlpha)), 0.5f * v.w * (1.f + erff(v.w * kAlpha)));
@@ -376,12 +397,12 @@ __global__ __launch_bounds__(256) void k_gelu_planes(const float *x, uint32_t ro
 
 template <typename T_>
 static int self_attn_step(void *stream, const void *qkv, void *kcache, void *vcache, const int64_t *d_t, uint32_t rows,
-                          uint32_t heads, uint32_t T, float scale, void *out, int32_t *anc)
+                          uint32_t heads, uint32_t T, float scale, void *out, int32_t *anc, const void *pb = nullptr, float pa = 1.f)
 {
     if (T > FMI_MAX_LEVELS) { fmi_set_error("sealnn_self_attn_step: at most %u cached positions", FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
     const uint32_t items = rows * heads;
     hipLaunchKernelGGL(k_self_attn_step<T_>, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const T_ *)qkv, (T_ *)kcache, (T_ *)vcache,
-                       d_t, rows, heads, T, scale, (T_ *)out, anc);
+                       d_t, rows, heads, T, scale, (T_ *)out, anc, (const T_ *)pb, pa);
     NNCHK();
     return FMI_OK;
 }
@@ -402,11 +423,11 @@ static int cross_attn_step(void *stream, const void *q, const void *ck, const vo
 
 template <typename T_>
 static int add_layernorm(void *stream, const void *x, const void *y, const void *gamma, const void *beta, uint32_t rows,
-                         uint32_t d, float eps, void *out, void *planes = nullptr, uint32_t *flag = nullptr)
+                         uint32_t d, float eps, void *out, void *planes = nullptr, uint32_t *flag = nullptr, const void *yb = nullptr, float ya = 1.f)
 {
     if (d % 4 || d > 4096) { fmi_set_error("sealnn_add_layernorm: d=%u unsupported", d); return FMI_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_add_layernorm<T_>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const T_ *)x, (const T_ *)y,
-                       (const T_ *)gamma, (const T_ *)beta, rows, d, eps, (T_ *)out, (__half *)planes, flag);
+                       (const T_ *)gamma, (const T_ *)beta, rows, d, eps, (T_ *)out, (__half *)planes, flag, (const T_ *)yb, ya);
     NNCHK();
     return FMI_OK;
 }
@@ -423,13 +444,13 @@ static int causal_self_attn(void *stream, const void *qkv, uint32_t n_seq, uint3
 
 template <typename T_>
 static int tree_self_attn(void *stream, const void *qkv, const int32_t *anc, uint32_t n_nodes, uint32_t max_depth1, uint32_t heads,
-                          float scale, void *out)
+                          float scale, void *out, const void *pb = nullptr, float pa = 1.f)
 {
     if (max_depth1 > FMI_MAX_LEVELS) { fmi_set_error("sealnn_tree_self_attn: at most %u positions", FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
     const uint32_t items = n_nodes * heads;
     if (!items) return FMI_OK;
     hipLaunchKernelGGL(k_tree_self_attn<T_>, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const T_ *)qkv, anc, n_nodes, max_depth1, heads,
-                       scale, (T_ *)out);
+                       scale, (T_ *)out, (const T_ *)pb, pa);
     NNCHK();
     return FMI_OK;
 }
@@ -510,14 +531,43 @@ extern "C" int sealnn_add_layernorm_planes(void *stream, const float *x, const f
     if (!planes) { fmi_set_error("sealnn_add_layernorm_planes: no plane buffer"); return FMI_ERR_ARG; }
     return add_layernorm<float>(stream, x, y, gamma, beta, rows, d, eps, out, planes, d_flag);
 }
-extern "C" int sealnn_gelu_planes(void *stream, const float *x, uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag)
+static int gelu_planes(void *stream, const float *x, uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag, const float *xb, float xa)
 {
     if (d % 4 || !planes) { fmi_set_error("sealnn_gelu_planes: d=%u must be a multiple of 4 (and a plane buffer given)", d); return FMI_ERR_UNSUPPORTED; }
     const uint64_t n = (uint64_t)rows * (d / 4);
     if (!n) return FMI_OK;
-    hipLaunchKernelGGL(k_gelu_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows, d, (__half *)planes, d_flag);
+    hipLaunchKernelGGL(k_gelu_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows, d, (__half *)planes, d_flag, xb, xa);
     NNCHK();
     return FMI_OK;
+}
+extern "C" int sealnn_gelu_planes(void *stream, const float *x, uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag)
+{ return gelu_planes(stream, x, rows, d, planes, d_flag, nullptr, 1.f); }
+
+// ---- the same kernels reading the RAW accumulators of a split GEMM: the projection's output is alpha * acc + bias (the GEMM's epilogue,
+// which torch.addmm(out_dtype=float32) runs as a separate pass over the output: a copy of the broadcast bias in front of every product) ----
+extern "C" int sealnn_self_attn_step_acc(void *stream, const float *qkv_acc, const float *qkv_bias, float alpha, float *kcache, float *vcache,
+                                         const int64_t *d_t, uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out, int32_t *anc)
+{
+    if (!qkv_bias) { fmi_set_error("sealnn_self_attn_step_acc: no bias"); return FMI_ERR_ARG; }
+    return self_attn_step<float>(stream, qkv_acc, kcache, vcache, d_t, rows, heads, T, scale, out, anc, qkv_bias, alpha);
+}
+extern "C" int sealnn_tree_self_attn_acc(void *stream, const float *qkv_acc, const float *qkv_bias, float alpha, const int32_t *anc, uint32_t n_nodes,
+                                         uint32_t max_depth1, uint32_t heads, float scale, float *out)
+{
+    if (!qkv_bias) { fmi_set_error("sealnn_tree_self_attn_acc: no bias"); return FMI_ERR_ARG; }
+    return tree_self_attn<float>(stream, qkv_acc, anc, n_nodes, max_depth1, heads, scale, out, qkv_bias, alpha);
+}
+extern "C" int sealnn_add_layernorm_acc(void *stream, const float *x, const float *y_acc, const float *y_bias, float alpha, const float *gamma,
+                                        const float *beta, uint32_t rows, uint32_t d, float eps, float *out, void *planes, uint32_t *d_flag)
+{
+    if (!y_bias) { fmi_set_error("sealnn_add_layernorm_acc: no bias"); return FMI_ERR_ARG; }
+    return add_layernorm<float>(stream, x, y_acc, gamma, beta, rows, d, eps, out, planes, d_flag, y_bias, alpha);
+}
+extern "C" int sealnn_gelu_planes_acc(void *stream, const float *x_acc, const float *x_bias, float alpha, uint32_t rows, uint32_t d, void *planes,
+                                      uint32_t *d_flag)
+{
+    if (!x_bias) { fmi_set_error("sealnn_gelu_planes_acc: no bias"); return FMI_ERR_ARG; }
+    return gelu_planes(stream, x_acc, rows, d, planes, d_flag, x_bias, alpha);
 }
 extern "C" int sealnn_add_layernorm_bf16(void *stream, const void *x, const void *y, const void *gamma, const void *beta, uint32_t rows,
                                          uint32_t d, float eps, void *out)

@@ -53,6 +53,10 @@ MIN_MACS_WITH_SPLIT_PASS = 1.8e9
 # the planes written by the kernels that produce the activations (sealnn_add_layernorm_planes, sealnn_gelu_planes) instead of a pass of
 # sealnn_split_planes in front of every product
 FUSED = True
+# the GEMM's epilogue (alpha * acc + bias) applied by the kernel that READS the product (sealnn_*_acc) instead of by the library call:
+# torch.addmm(out_dtype=float32) does not use hipBLASLt's bias epilogue but copies the broadcast bias into the output first -- one
+# [rows, N] strided copy in front of every product, 5 ms of a 72 ms search step (rocprofv3 trace of round 4: 817 copies per batch)
+DEFER_EPILOGUE = True
 LO_SHIFT = 11                      # bits between the planes: fp16 has an 11-bit significand
 _flags = {}                        # device -> int32 counter of unsplittable activations
 
@@ -119,6 +123,18 @@ def split_weight(weight: torch.Tensor):
     return torch.cat([hi, lo, hi_s], dim=1).contiguous(), 1.0 / s_w
 
 
+class Deferred:
+    """a product whose epilogue is left to the kernel that reads it: the value is ``alpha * acc + bias`` (bias over the last dimension)"""
+    __slots__ = ("acc", "bias", "alpha")
+
+    def __init__(self, acc, bias, alpha):
+        self.acc, self.bias, self.alpha = acc, bias, alpha
+
+    def value(self) -> torch.Tensor:
+        """materialised (what the library's own epilogue computes: alpha a power of two, one rounding in the add)"""
+        return self.acc * self.alpha + self.bias
+
+
 class SplitLinear:
     """``F.linear(x, weight, bias)`` for fp32 ``x`` [rows, K] through one fp16 GEMM of inner dimension 3K (see the module text)."""
 
@@ -131,21 +147,24 @@ class SplitLinear:
         b = bias.detach().float().reshape(-1) if bias is not None else torch.zeros(self.N, device=weight.device)
         self.bias = b.contiguous()
 
-    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, defer: bool = False):
         if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != self.K:
             raise ValueError(f"SplitLinear: expected fp32 [rows, {self.K}], got {x.dtype} {tuple(x.shape)}")
         if not x.is_cuda:
             # the checker of the arithmetic (tests): same planes, products summed in fp32
-            return torch.addmm(self.bias, split_planes_reference(x).float(), self.wt.float(), alpha=self.alpha)
+            return self.from_planes(split_planes_reference(x), defer)
         from ._lib import check, lib
         x = x.contiguous()
         a = torch.empty(x.shape[0], 3 * self.K, dtype=torch.float16, device=x.device)
         check(lib().sealnn_split_planes(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.shape[0], self.K, a.data_ptr(),
                                         _flag(x.device).data_ptr()))
-        return self.from_planes(a)
+        return self.from_planes(a, defer)
 
-    def from_planes(self, planes: torch.Tensor) -> torch.Tensor:
-        """the product for an activation whose planes [rows, 3K] fp16 exist already"""
+    def from_planes(self, planes: torch.Tensor, defer: bool = False):
+        """the product for an activation whose planes [rows, 3K] fp16 exist already (``defer``: as ``Deferred`` raw accumulators)"""
+        if defer:
+            acc = torch.mm(planes, self.wt, out_dtype=torch.float32) if planes.is_cuda else torch.mm(planes.float(), self.wt.float())
+            return Deferred(acc, self.bias, self.alpha)
         if not planes.is_cuda:
             return torch.addmm(self.bias, planes.float(), self.wt.float(), alpha=self.alpha)
         return torch.addmm(self.bias, planes, self.wt, alpha=self.alpha, out_dtype=torch.float32)
@@ -171,10 +190,11 @@ class SplitLinears:
             lin = self._by_weight[key] = SplitLinear(weight, bias)
         return lin
 
-    def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias=None, defer: bool = False):
+        """``defer``: a product that goes through the split comes back as ``Deferred`` (one that does not, as the finished tensor)"""
         if not self.wants(weight, x.shape[0], have_planes=False):
             return torch.nn.functional.linear(x, weight, bias)
-        return self._of(weight, bias)(x)
+        return self._of(weight, bias)(x, defer and DEFER_EPILOGUE)
 
-    def from_planes(self, planes: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
-        return self._of(weight, bias).from_planes(planes)
+    def from_planes(self, planes: torch.Tensor, weight: torch.Tensor, bias=None, defer: bool = False):
+        return self._of(weight, bias).from_planes(planes, defer and DEFER_EPILOGUE)

@@ -221,3 +221,111 @@ def test_planes_from_the_producing_kernels_on_the_gpu():
     back = got[:, :4096].double() + got[:, 8192:].double() * 2.0 ** -LO_SHIFT
     want_back = ref[:, :4096].double() + ref[:, 8192:].double() * 2.0 ** -LO_SHIFT
     assert (back - want_back).abs().max().item() <= 1e-6 and int(flag.item()) == 0
+
+
+def test_deferred_product_is_the_finished_one():
+    """``SplitLinear(...)(x, defer=True)`` hands back the raw accumulators + (alpha, bias); alpha is a power of two, so alpha * acc is exact
+    and ``value()`` is the product with its epilogue applied (CPU emulation of both)"""
+    import math
+    g = torch.Generator().manual_seed(11)
+    x = _activations(33, 256, 2)
+    w, b = torch.randn(96, 256, generator=g) * 0.05, torch.randn(96, generator=g)
+    lin = SplitLinear(w, b)
+    d = lin(x, defer=True)
+    assert math.log2(d.alpha) == int(math.log2(d.alpha)) and d.acc.dtype == torch.float32 and d.bias is lin.bias
+    assert torch.allclose(d.value(), lin(x), rtol=1e-6, atol=1e-6)
+    assert torch.equal(lin.from_planes(split_planes_reference(x), defer=True).acc, d.acc)
+
+
+@pytest.mark.gpu
+def test_kernels_that_apply_the_epilogue_themselves_on_the_gpu(monkeypatch):
+    """sealnn_*_acc(raw accumulators, bias, alpha) == the plain kernel on alpha * acc + bias, bit for bit -- outputs, caches, planes; and a
+    tree forward of the decoder with the epilogues deferred == the same with torch.addmm's (split_gemm.DEFER_EPILOGUE off) to 1e-4"""
+    from seal_amd import split_gemm
+    from seal_amd._lib import check, lib
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    g = torch.Generator().manual_seed(13)
+    alpha = 2.0 ** -13
+    rows, H, T, d = 45, 16, 9, 1024
+    # self-attention step: q / k / v read from the accumulators, k / v written to the caches
+    acc = (torch.randn(rows, 3 * d, generator=g) * 3000).to(dev)
+    bias = torch.randn(3 * d, generator=g).to(dev)
+    qkv = acc * alpha + bias
+    t = torch.tensor([4], dtype=torch.int64, device=dev)
+    caches = [(torch.randn(rows, H, T, 64, generator=g)).to(dev) for _ in range(2)]
+    anc = torch.randint(0, rows, (T, rows), generator=g, dtype=torch.int32).to(dev)
+    outs = []
+    for use_acc in (False, True):
+        kc, vc, an, out = caches[0].clone(), caches[1].clone(), anc.clone(), torch.empty(rows, d, device=dev)
+        if use_acc:
+            check(lib().sealnn_self_attn_step_acc(st, acc.data_ptr(), bias.data_ptr(), alpha, kc.data_ptr(), vc.data_ptr(), t.data_ptr(), rows, H, T,
+                                                  0.125, out.data_ptr(), an.data_ptr()))
+        else:
+            check(lib().sealnn_self_attn_step(st, qkv.data_ptr(), kc.data_ptr(), vc.data_ptr(), t.data_ptr(), rows, H, T, 0.125, out.data_ptr(),
+                                              an.data_ptr()))
+        outs.append((out, kc, vc, an))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    # tree self-attention
+    n, A = 60, 5
+    tacc = (torch.randn(n, 3 * d, generator=g) * 3000).to(dev)
+    tqkv = tacc * alpha + bias
+    depth = torch.randint(0, A, (n,), generator=g)
+    tanc = torch.full((n, A), -1, dtype=torch.int32)
+    for i in range(n):
+        for j in range(int(depth[i])):
+            tanc[i, j] = int(torch.randint(0, n, (1,), generator=g))
+        tanc[i, int(depth[i])] = i
+    tanc = tanc.to(dev)
+    o1, o2 = torch.empty(n, d, device=dev), torch.empty(n, d, device=dev)
+    check(lib().sealnn_tree_self_attn(st, tqkv.data_ptr(), tanc.data_ptr(), n, A, H, 0.125, o1.data_ptr()))
+    check(lib().sealnn_tree_self_attn_acc(st, tacc.data_ptr(), bias.data_ptr(), alpha, tanc.data_ptr(), n, A, H, 0.125, o2.data_ptr()))
+    assert torch.equal(o1, o2)
+    # add + LayerNorm (+ planes), gelu planes
+    x = torch.randn(rows, d, generator=g).to(dev)
+    yacc, yb = (torch.randn(rows, d, generator=g) * 20000).to(dev), torch.randn(d, generator=g).to(dev)
+    y = yacc * alpha + yb
+    gamma, beta = (torch.rand(d, generator=g) + 0.5).to(dev), torch.randn(d, generator=g).to(dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    w1, p1, w2, p2 = torch.empty_like(x), torch.empty(rows, 3 * d, dtype=torch.float16, device=dev), torch.empty_like(x), torch.empty(rows, 3 * d, dtype=torch.float16, device=dev)
+    check(lib().sealnn_add_layernorm_planes(st, x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, d, 1e-5, w1.data_ptr(), p1.data_ptr(), flag.data_ptr()))
+    check(lib().sealnn_add_layernorm_acc(st, x.data_ptr(), yacc.data_ptr(), yb.data_ptr(), alpha, gamma.data_ptr(), beta.data_ptr(), rows, d, 1e-5, w2.data_ptr(),
+                                         p2.data_ptr(), flag.data_ptr()))
+    assert torch.equal(w1, w2) and torch.equal(p1, p2)
+    w3 = torch.empty_like(x)
+    check(lib().sealnn_add_layernorm_acc(st, x.data_ptr(), yacc.data_ptr(), yb.data_ptr(), alpha, gamma.data_ptr(), beta.data_ptr(), rows, d, 1e-5, w3.data_ptr(),
+                                         None, None))
+    assert torch.equal(w1, w3)
+    hacc, hb = (torch.randn(rows, 4096, generator=g) * 15000).to(dev), torch.randn(4096, generator=g).to(dev)
+    h = hacc * alpha + hb
+    g1, g2 = torch.empty(rows, 3 * 4096, dtype=torch.float16, device=dev), torch.empty(rows, 3 * 4096, dtype=torch.float16, device=dev)
+    check(lib().sealnn_gelu_planes(st, h.data_ptr(), rows, 4096, g1.data_ptr(), flag.data_ptr()))
+    check(lib().sealnn_gelu_planes_acc(st, hacc.data_ptr(), hb.data_ptr(), alpha, rows, 4096, g2.data_ptr(), flag.data_ptr()))
+    assert torch.equal(g1, g2) and int(flag.item()) == 0
+    # the decoder's tree forward at a size where every projection goes through the split: deferred against addmm's epilogue
+    from transformers import BartConfig, BartForConditionalGeneration
+    from seal_amd.bart_decoder import BartStepDecoder
+    torch.manual_seed(0)
+    cfg = BartConfig(vocab_size=4000, d_model=1024, encoder_layers=1, decoder_layers=2, encoder_attention_heads=16, decoder_attention_heads=16,
+                     encoder_ffn_dim=4096, decoder_ffn_dim=4096, max_position_embeddings=64)
+    with torch.device(dev):
+        model = BartForConditionalGeneration(cfg).eval()
+    dec = BartStepDecoder(model)
+    B, S, N, A = 4, 12, 3200, 6
+    ids = torch.randint(3, 4000, (B, S), generator=g).to(dev)
+    mask = torch.ones(B, S, dtype=torch.long, device=dev)
+    enc = dec.encode(ids, mask)
+    prepared = dec.teacher_prepare(enc, mask)
+    tok = torch.randint(3, 4000, (N,), generator=g).to(dev)
+    depth = (torch.arange(N) % A)
+    anc = torch.full((N, A), -1, dtype=torch.long)
+    for i in range(N):
+        k = int(depth[i])
+        anc[i, :k + 1] = torch.arange(i - k, i + 1)
+    qidx = (torch.arange(N) // (N // B)).clamp(max=B - 1).to(dev)
+    res = []
+    for defer in (True, False):
+        monkeypatch.setattr(split_gemm, "DEFER_EPILOGUE", defer)
+        res.append(dec.tree_logits(tok, depth.to(dev), anc.to(dev), qidx, enc, mask, prepared=prepared))
+    # (the library may pick another GEMM kernel for a product without an epilogue: same arithmetic, another summation order)
+    assert torch.isfinite(res[0]).all() and (res[0] - res[1]).abs().max().item() <= 1e-4 and split_gemm.overflowed(dev) == 0
