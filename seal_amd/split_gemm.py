@@ -29,7 +29,8 @@ Scaling keeps every plane in fp16's normal range whatever the matrix cores do wi
 
 ``SplitLinear(weight, bias)(x)`` is ``F.linear(x, weight, bias)`` for an fp32 ``x`` [rows, K].  On the GPU the planes come from the
 HIP kernel and the product from ``torch.addmm(..., out_dtype=torch.float32)`` (hipBLASLt, fp16 in / fp32 out); on the CPU (the tests'
-checker of the arithmetic) both are emulated with torch ops.
+checker of the arithmetic) both are emulated with torch ops.  ``defer=True`` hands back the raw accumulators (``torch.mm``) with
+``(alpha, bias)`` for a consumer that applies the epilogue as it reads (``Deferred``, ``DEFER_EPILOGUE``; the sealnn_*_acc kernels).
 """
 import math
 import os
