@@ -47,8 +47,10 @@ int sealnn_tree_self_attn(void *stream, const float *qkv, const int32_t *anc, ui
 int sealnn_cross_attn_rows(void *stream, const float *q, const float *ck, const float *cv, const float *bias,
                            const int32_t *row_batch, uint32_t rows, uint32_t heads, uint32_t S, float scale, float *out);
 
-/* the same when the rows come in runs of `group` consecutive rows that attend the same query (row_batch is read at the
- * first row of every run; rows % group == 0): K/V of a (run, head) are staged in LDS once.  Bit-identical results. */
+/* the same, one workgroup per (`group` consecutive rows, head): the K/V of the run's FIRST row's query are staged in LDS once and every
+ * row of that query reads them there; a row of another query reads its own from memory (so any row_batch is served; rows that come in
+ * runs per query -- teacher forcing, the nodes of a query's prefix tree -- are served fast); the last run may be short.  Bit-identical
+ * results. */
 int sealnn_cross_attn_runs(void *stream, const float *q, const float *ck, const float *cv, const float *bias,
                            const int32_t *row_batch, uint32_t rows, uint32_t group, uint32_t heads, uint32_t S, float scale, float *out);
 

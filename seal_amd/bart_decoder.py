@@ -318,8 +318,10 @@ class BartStepDecoder:
                 q = self._lin_p(x, xp, L["cq"].weight, L["cq"].bias)
                 c = torch.empty(N, self.d, dtype=x.dtype, device=dev)
                 ck, cv = cross[li]
-                check(L_.cross_attn_rows(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
-                                         N, self.h, S, float(self.scale), c.data_ptr()))
+                # (a query's nodes are consecutive: sixteen rows per workgroup share its K / V through LDS; a row of another query than its
+                #  run's first reads its own from memory -- the same arithmetic as sealnn_cross_attn_rows on either path)
+                check(L_.cross_attn_runs(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
+                                         N, 16, self.h, S, float(self.scale), c.data_ptr()))
                 x, xp = add_ln(x, self._mod(c, L["co"], defer=True), L["ln2"])
                 x, xp = add_ln(x, self._ffn(x, xp, L, defer=True), L["ln3"])
             if hidden_only:

@@ -8,6 +8,7 @@
 #include <hip/hip_fp16.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "../../include/sealnn.h"
 #include "fmi_internal.h"
@@ -150,6 +151,55 @@ __global__ __launch_bounds__(256) void k_self_attn_step(const T_ *qkv, T_ *kcach
     stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, acc / denom);
 }
 
+// K [64, S] and V [S, 64] of one (query, head) into LDS (s_k, s_v: 16-byte aligned, n = 64 * S elements each).  Every load of a thread is
+// issued before its first store: as a plain copy loop the compiler waited for each pair of loads before storing it, eight memory round
+// trips in a row at the head of a 17 us kernel.
+template <typename T_>
+static __device__ __forceinline__ void stage_kv(const T_ *k, const T_ *v, float *s_k, float *s_v, uint32_t n)
+{
+    if constexpr (std::is_same<T_, float>::value) {
+        const uint32_t n4 = n / 4;
+        const float4 *k4 = reinterpret_cast<const float4 *>(k), *v4 = reinterpret_cast<const float4 *>(v);
+        float4 *sk4 = reinterpret_cast<float4 *>(s_k), *sv4 = reinterpret_cast<float4 *>(s_v);
+        for (uint32_t i0 = threadIdx.x; i0 < n4; i0 += 4 * blockDim.x) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t i = i0 + j * blockDim.x;
+                a[j] = b[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < n4) { a[j] = k4[i]; b[j] = v4[i]; }
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t i = i0 + j * blockDim.x;
+                if (i < n4) { sk4[i] = a[j]; sv4[i] = b[j]; }
+            }
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { s_k[i] = ldf(k + i); s_v[i] = ldf(v + i); }
+    }
+}
+
+// one row's attention over the S encoder positions of its (query, head): scores with lane = encoder position, output with lane = dim.
+// K / V through any pointer (LDS or global).  The lanes beyond S read position 0 and are masked afterwards: no branch inside the loops,
+// so the reads of a loop are issued together (with `if (lane < S)` around each, every one of the 128 reads was waited for on its own).
+template <typename KV>
+static __device__ __forceinline__ float cross_attn_row(float qd, const KV *k, const KV *v, float bi, uint32_t S, uint32_t lane)
+{
+    const uint32_t l = lane < S ? lane : 0;
+    float sc = 0.f;
+#pragma unroll 16
+    for (uint32_t d = 0; d < 64; d++) sc += lane_value(qd, d) * ldf(k + d * S + l);
+    sc = lane < S ? sc + bi : -__builtin_huge_valf();
+    const float m = wave_max(sc);
+    const float e = lane < S ? expf(sc - m) : 0.f;
+    const float denom = wave_sum(e);
+    float acc = 0.f;
+#pragma unroll 8
+    for (uint32_t p = 0; p < S; p++) acc += lane_value(e, p) * ldf(v + p * 64 + lane);
+    return acc / denom;
+}
+
 // one workgroup per (query, head): the encoder K [64, S] and V [S, 64] of that head are staged in LDS once
 // and shared by the query's beams (one wavefront per beam; scores: lane = encoder position, output: lane = dim)
 template <typename T_>
@@ -157,29 +207,19 @@ __global__ __launch_bounds__(1024) void k_cross_attn_step(const T_ *q, const T_ 
                                                           uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S, float scale,
                                                           T_ *out)
 {
-    __shared__ float s_k[64 * 64], s_v[64 * 64];
+    __shared__ __attribute__((aligned(16))) float s_k[64 * 64];
+    __shared__ __attribute__((aligned(16))) float s_v[64 * 64];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint32_t b = blockIdx.x / heads, head = blockIdx.x % heads;
     const T_ *k = ck + ((uint64_t)b * heads + head) * 64 * S;      // [64, S]
     const T_ *v = cv + ((uint64_t)b * heads + head) * S * 64;      // [S, 64]
-    for (uint32_t i = threadIdx.x; i < 64 * S; i += blockDim.x) { s_k[i] = ldf(k + i); s_v[i] = ldf(v + i); }
-    __syncthreads();
+    stage_kv(k, v, s_k, s_v, 64 * S);
     const float bi = lane < S ? ldf(bias + (uint64_t)b * S + lane) : 0.f;
+    __syncthreads();
     for (uint32_t beam = wv; beam < beams; beam += nw) {
         const uint32_t row = b * beams + beam;
         const float qd = ldf(q + ((uint64_t)row * heads + head) * 64 + lane) * scale;
-        float sc = 0.f;
-        for (uint32_t d = 0; d < 64; d++) {
-            const float qv = lane_value(qd, d);
-            if (lane < S) sc += qv * s_k[d * S + lane];
-        }
-        sc = lane < S ? sc + bi : -__builtin_huge_valf();
-        const float m = wave_max(sc);
-        const float e = lane < S ? expf(sc - m) : 0.f;
-        const float denom = wave_sum(e);
-        float acc = 0.f;
-        for (uint32_t p = 0; p < S; p++) acc += lane_value(e, p) * s_v[p * 64 + lane];
-        stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, acc / denom);
+        stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, cross_attn_row(qd, s_k, s_v, bi, S, lane));
     }
 }
 
@@ -269,58 +309,41 @@ __global__ __launch_bounds__(256) void k_cross_attn_rows(const T_ *q, const T_ *
     const float qd = ldf(q + ((uint64_t)row * heads + head) * 64 + lane) * scale;
     const T_ *k = ck + ((uint64_t)b * heads + head) * 64 * S;
     const T_ *v = cv + ((uint64_t)b * heads + head) * S * 64;
-    float sc = 0.f;
-    for (uint32_t d = 0; d < 64; d++) {
-        const float qv = lane_value(qd, d);
-        if (lane < S) sc += qv * ldf(k + (uint64_t)d * S + lane);
-    }
-    sc = lane < S ? sc + ldf(bias + (uint64_t)b * S + lane) : -__builtin_huge_valf();
-    const float m = wave_max(sc);
-    const float e = lane < S ? expf(sc - m) : 0.f;
-    const float denom = wave_sum(e);
-    float acc = 0.f;
-    for (uint32_t p = 0; p < S; p++) acc += lane_value(e, p) * ldf(v + (uint64_t)p * 64 + lane);
-    stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, acc / denom);
+    const float bi = lane < S ? ldf(bias + (uint64_t)b * S + lane) : 0.f;
+    stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, cross_attn_row(qd, k, v, bi, S, lane));
 }
 
-// the same for rows that come in runs of `group` consecutive rows attending the same query (teacher forcing: the T
-// positions of a sequence): one workgroup per (run, head) stages that head's K [64, S] and V [S, 64] in LDS once and its
-// four waves walk the run's rows -- the keys and values are read from L2 once per run instead of once per row.  Same
-// arithmetic, in the same order, as k_cross_attn_rows.
+// the same for rows that come in runs: one workgroup per (`group` consecutive rows, head) stages the K [64, S] and V [S, 64] of the FIRST
+// row's query in LDS once and its waves walk the rows -- a row of that query (teacher forcing: the T positions of a sequence; the nodes of a
+// query's prefix tree, which are consecutive: all of them but at the borders between queries) reads LDS, a row of another query reads
+// its own K / V from global memory as k_cross_attn_rows does: 16 x fewer bytes out of L2 for the 3 200-row rescoring forward, whose
+// one-wave-per-(row, head) form spent 84 us per launch re-reading 32 KB per wave.  Same arithmetic, in the same order, on every path.
 template <typename T_>
 __global__ __launch_bounds__(512) void k_cross_attn_runs(const T_ *q, const T_ *ck, const T_ *cv, const T_ *bias,
                                                          const int32_t *row_batch, uint32_t rows, uint32_t group, uint32_t heads,
                                                          uint32_t S, float scale, T_ *out)
 {
-    extern __shared__ float s_kv[];                 // K [64, S] then V [S, 64]: 512 S bytes, so that several runs share a CU
-    float *s_k = s_kv, *s_v = s_kv + 64 * S;
+    extern __shared__ float4 s_kv4[];               // K [64, S] then V [S, 64]: 512 S bytes, so that several runs share a CU
+    float *s_k = reinterpret_cast<float *>(s_kv4), *s_v = s_k + 64 * S;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint32_t run = blockIdx.x / heads, head = blockIdx.x % heads;
     const uint32_t row0 = run * group;
     const uint32_t b = (uint32_t)row_batch[row0];
-    const T_ *k = ck + ((uint64_t)b * heads + head) * 64 * S;
-    const T_ *v = cv + ((uint64_t)b * heads + head) * S * 64;
-    for (uint32_t i = threadIdx.x; i < 64 * S; i += blockDim.x) { s_k[i] = ldf(k + i); s_v[i] = ldf(v + i); }
-    // this wave's rows: their queries are fetched while the staging loads are in flight
+    stage_kv(ck + ((uint64_t)b * heads + head) * 64 * S, cv + ((uint64_t)b * heads + head) * S * 64, s_k, s_v, 64 * S);
     const float bi = lane < S ? ldf(bias + (uint64_t)b * S + lane) : 0.f;
     __syncthreads();
     for (uint32_t t = wv; t < group && row0 + t < rows; t += nw) {
         const uint32_t row = row0 + t;
+        const uint32_t rb = (uint32_t)row_batch[row];
         const float qd = ldf(q + ((uint64_t)row * heads + head) * 64 + lane) * scale;
-        float sc = 0.f;
-#pragma unroll 16
-        for (uint32_t d = 0; d < 64; d++) {
-            const float qv = lane_value(qd, d);
-            if (lane < S) sc += qv * s_k[d * S + lane];
+        float o;
+        if (rb == b) {
+            o = cross_attn_row(qd, s_k, s_v, bi, S, lane);
+        } else {
+            const float bo = lane < S ? ldf(bias + (uint64_t)rb * S + lane) : 0.f;
+            o = cross_attn_row(qd, ck + ((uint64_t)rb * heads + head) * 64 * S, cv + ((uint64_t)rb * heads + head) * S * 64, bo, S, lane);
         }
-        sc = lane < S ? sc + bi : -__builtin_huge_valf();
-        const float m = wave_max(sc);
-        const float e = lane < S ? expf(sc - m) : 0.f;
-        const float denom = wave_sum(e);
-        float acc = 0.f;
-#pragma unroll 8
-        for (uint32_t p = 0; p < S; p++) acc += lane_value(e, p) * s_v[p * 64 + lane];
-        stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, acc / denom);
+        stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, o);
     }
 }
 
@@ -472,10 +495,11 @@ static int cross_attn_runs(void *stream, const void *q, const void *ck, const vo
                            const int32_t *row_batch, uint32_t rows, uint32_t group, uint32_t heads, uint32_t S, float scale, void *out)
 {
     if (S > 64) { fmi_set_error("sealnn_cross_attn_runs: encoder length %u > 64", S); return FMI_ERR_UNSUPPORTED; }
-    if (group == 0 || rows % group) { fmi_set_error("sealnn_cross_attn_runs: %u rows are not runs of %u", rows, group); return FMI_ERR_ARG; }
-    // one wave per position of the run, up to eight
+    if (group == 0) { fmi_set_error("sealnn_cross_attn_runs: runs of 0 rows"); return FMI_ERR_ARG; }
+    if (!rows) return FMI_OK;
+    // one wave per position of the run, up to eight; the last run may be short
     const unsigned threads = 64 * std::min<unsigned>(8, std::max<unsigned>(1, group));
-    hipLaunchKernelGGL(k_cross_attn_runs<T_>, dim3((rows / group) * heads), dim3(threads), (size_t)512 * S, (hipStream_t)stream, (const T_ *)q,
+    hipLaunchKernelGGL(k_cross_attn_runs<T_>, dim3(((rows + group - 1) / group) * heads), dim3(threads), (size_t)512 * S, (hipStream_t)stream, (const T_ *)q,
                        (const T_ *)ck, (const T_ *)cv, (const T_ *)bias, row_batch, rows, group, heads, S, scale, (T_ *)out);
     NNCHK();
     return FMI_OK;

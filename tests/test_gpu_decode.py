@@ -476,6 +476,13 @@ def test_cross_attention_over_runs_is_bit_identical_to_the_per_row_kernel(S, T):
     check(lib().sealnn_cross_attn_runs(st, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(), rows, T, heads, S,
                                        0.125, b.data_ptr()))
     assert torch.equal(a, b)
+    # runs that do NOT line up with the queries (the rescoring tree: a query's nodes are consecutive, 16 rows per workgroup; a row of another
+    # query than its run's first reads its own K / V from memory), the last run short
+    for group in (16, 5, 64):
+        c = torch.empty(rows, heads * 64, device=dev)
+        check(lib().sealnn_cross_attn_runs(st, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(), rows, group, heads, S,
+                                           0.125, c.data_ptr()))
+        assert torch.equal(a, c), group
     rb = row_batch.long()
     att = torch.softmax(torch.einsum("rhd,rhds->rhs", q * 0.125, ck[rb]) + bias[rb][:, None, :], -1)
     ref = torch.einsum("rhs,rhsd->rhd", att, cv[rb]).reshape(rows, heads * 64)
