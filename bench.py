@@ -419,6 +419,44 @@ def score_parity(searcher, model, index, queries, bias, dev, n_rescore_queries=4
     return out
 
 
+def kernel_source_sha256(root=ROOT) -> str:
+    """what a PMC file must have been taken over to be cited (tools/summarize_pmc.py records the same digest)"""
+    import hashlib
+    csrc = os.path.join(root, "seal_amd", "csrc")
+    return hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("fmi_kernels.hip", "fmi_device.h", "fmi_internal.h"))).hexdigest()
+
+
+def cite_traffic(workload_tag, root=ROOT, now=None):
+    """(HBM bytes per constraint call, where the figure comes from) from the newest profiles/r*_pmc_fetch_size*.json taken over the CURRENT
+    kernel sources on THIS workload; (None, why not) otherwise -- counters of another kernel generation or workload are refused"""
+    import glob
+    traffic = traffic_src = None
+    try:
+        now = now or kernel_source_sha256(root)
+        files = sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_fetch_size*.json")), reverse=True)
+        for f in files:
+            pmc = json.load(open(f))
+            if pmc.get("_kernel_source_sha256") != now:
+                continue            # counters of another kernel generation are REFUSED (the file records the source it profiled)
+            if pmc.get("_workload") != workload_tag:
+                continue            # ... and so are counters taken on another workload (index size, beam): per-workload files
+            # every launch of the constraint calls (k_constrain_rows + k_constrain of a row-first call; k_constrain_table + k_table_bits of a
+            # decode's first step), summed over the run and divided by the CALLS (one k_constrain or one k_constrain_table each)
+            mine = {k: v["FETCH_SIZE"] for k, v in pmc.items() if isinstance(v, dict) and ("k_constrain" in k or "k_table_bits" in k)}
+            calls = sum(c["launches"] for k, c in mine.items() if "k_constrain<" in k or "k_constrain_table" in k)
+            kib = sum(c["sum"] for c in mine.values()) / calls if calls else 0
+            if kib:
+                traffic = round(kib * 1024.0 * 2, 1)
+                traffic_src = {"file": os.path.relpath(f, root), "commit": pmc.get("_commit"), "kernel_source_sha256": now[:16], "workload": workload_tag}
+                break
+        if traffic is None:
+            traffic_src = {"refused": "no profiles/r*_pmc_fetch_size*.json was taken over the current fmi_kernels.hip / fmi_device.h / fmi_internal.h "
+                                      "(sha256 %s) on this workload (%s); run tools/prof_bench.sh" % (now[:16], workload_tag), "candidates": [os.path.relpath(f, root) for f in files[:3]]}
+    except Exception as e:
+        traffic_src = {"error": repr(e)}
+    return traffic, traffic_src
+
+
 def _prefix_table_stats(index):
     """the per-token node tables the index handle built for the first constrained step of the decodes"""
     import ctypes
@@ -765,33 +803,7 @@ def main():
     # CURRENT kernel (tools/prof_bench.sh -> profiles/r*_pmc_fetch_size.json, which names the commit it was taken
     # at); a profile of another kernel generation is not used.  Per launch = per constraint call = one k_constrain / k_constrain_table.
     # FETCH_SIZE counts 128-byte requests at 64 bytes on gfx950 (MI355X guide; tools/gather_calib.hip): x 2.
-    traffic = traffic_src = None
-    try:
-        import glob
-        import hashlib
-        csrc = os.path.join(ROOT, "seal_amd", "csrc")
-        now = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("fmi_kernels.hip", "fmi_device.h", "fmi_internal.h"))).hexdigest()
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size*.json")), reverse=True)
-        for f in files:
-            pmc = json.load(open(f))
-            if pmc.get("_kernel_source_sha256") != now:
-                continue            # counters of another kernel generation are REFUSED (the file records the source it profiled)
-            if pmc.get("_workload") != workload_tag:
-                continue            # ... and so are counters taken on another workload (index size, beam): per-workload files
-            # every launch of the constraint calls (k_constrain_rows + k_constrain of a row-first call; k_constrain_table + k_table_bits of a
-            # decode's first step), summed over the run and divided by the CALLS (one k_constrain or one k_constrain_table each)
-            mine = {k: v["FETCH_SIZE"] for k, v in pmc.items() if isinstance(v, dict) and ("k_constrain" in k or "k_table_bits" in k)}
-            calls = sum(c["launches"] for k, c in mine.items() if "k_constrain<" in k or "k_constrain_table" in k)
-            kib = sum(c["sum"] for c in mine.values()) / calls if calls else 0
-            if kib:
-                traffic = round(kib * 1024.0 * 2, 1)
-                traffic_src = {"file": os.path.relpath(f, ROOT), "commit": pmc.get("_commit"), "kernel_source_sha256": now[:16], "workload": workload_tag}
-                break
-        if traffic is None:
-            traffic_src = {"refused": "no profiles/r*_pmc_fetch_size*.json was taken over the current fmi_kernels.hip / fmi_device.h / fmi_internal.h "
-                                      "(sha256 %s) on this workload (%s); run tools/prof_bench.sh" % (now[:16], workload_tag), "candidates": [os.path.relpath(f, ROOT) for f in files[:3]]}
-    except Exception as e:
-        traffic_src = {"error": repr(e)}
+    traffic, traffic_src = cite_traffic(workload_tag)
     nl = n2
     roofline = {"bound": "hbm", "kernel": "k_constrain (one constraint call for the rows of both decodes: k_constrain_rows -- one wave per row: prefix "
                                           "range, class, root node split -- then k_constrain -- one wave per (row, top digit), the sub-trees level by level "
