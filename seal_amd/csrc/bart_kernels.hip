@@ -115,17 +115,19 @@ __global__ __launch_bounds__(256) void k_self_attn_step(const T_ *qkv, T_ *kcach
     // The history of the row: position p sits in the slot of row anc[p][row].  All of it is fetched BEFORE anything is
     // computed -- lane p reads the ancestor of position p, then every K / V load of the wave is issued back to back (their
     // addresses no longer hang on a load inside the loop: the serial chain of <= 16 dependent round trips was the kernel's time)
+    // (no branch around the loads: with `if (p < t)` the compiler waited for every position's pair before issuing the next one, up to
+    //  sixteen round trips in a row.  A position beyond the history re-reads the last one -- a line the wave has just asked for -- and is
+    //  never used below.)
     const uint32_t my_anc = (anc && lane < t) ? (uint32_t)anc[(uint64_t)lane * rows + row] : row;
+    const uint32_t last = t ? t - 1 : 0;
     float kreg[FMI_MAX_LEVELS], vreg[FMI_MAX_LEVELS];
 #pragma unroll
     for (uint32_t p = 0; p < FMI_MAX_LEVELS; p++) {
-        kreg[p] = 0.f; vreg[p] = 0.f;
-        if (p < t) {                         // wave-uniform
-            const uint32_t a_p = (uint32_t)__builtin_amdgcn_readlane((int)my_anc, (int)p);
-            const uint64_t src = ((uint64_t)a_p * heads + head) * T * 64 + (uint64_t)p * 64 + lane;
-            kreg[p] = ldf(kcache + src);
-            vreg[p] = ldf(vcache + src);
-        }
+        const uint32_t pc = p < t ? p : last;                         // wave-uniform
+        const uint32_t a_p = (uint32_t)__builtin_amdgcn_readlane((int)my_anc, (int)pc);
+        const uint64_t src = ((uint64_t)a_p * heads + head) * T * 64 + (uint64_t)pc * 64 + lane;
+        kreg[p] = ldf(kcache + src);
+        vreg[p] = ldf(vcache + src);
     }
     // scores over positions 0..t (the new one from registers), in position order as before
     float s[FMI_MAX_LEVELS];          // T <= 17 positions kept in registers
@@ -359,18 +361,36 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y,
     if (row >= rows) return;
     const T_ *xr = x + (uint64_t)row * d, *yr = y + (uint64_t)row * d;
     const uint32_t n4 = d / 4;
+    // The row in chunks of four float4 per lane (d = 1024: one chunk).  The loads of a chunk are issued together, unconditionally -- a lane
+    // beyond the row reads element 0 and its value is dropped: with `if (i < n4)` around each, every pair of loads was waited for before the
+    // next was issued, one memory round trip per 256 columns -- and gamma / beta of the first chunk are asked for BEFORE the reductions.
+    const T_ *ybp = yb ? yb : gamma;                  // (a valid address when there is no epilogue to apply: loaded, not used)
     float4 v[16];                                    // fully unrolled below: registers, not scratch
+    float4 g0[4], b0[4];
     float sum = 0.f;
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) {
-        const uint32_t i = lane + 64 * j;
-        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < n4) {
-            const float4 a = ld4(xr, i);
-            float4 b = ld4(yr, i);
-            if (yb) { const float4 c = ld4(yb, i); b = make_float4(ya * b.x + c.x, ya * b.y + c.y, ya * b.z + c.z, ya * b.w + c.w); }
-            v[j] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-            sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    for (uint32_t j0 = 0; j0 < 16; j0 += 4) {
+        if (64 * j0 >= n4) {                         // (wave-uniform) chunks beyond the row
+#pragma unroll
+            for (uint32_t jj = 0; jj < 4; jj++) v[j0 + jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        float4 a[4], b[4], c[4];
+#pragma unroll
+        for (uint32_t jj = 0; jj < 4; jj++) {
+            const uint32_t i = lane + 64 * (j0 + jj), ic = i < n4 ? i : 0;
+            a[jj] = ld4(xr, ic); b[jj] = ld4(yr, ic); c[jj] = ld4(ybp, ic);
+            if (j0 == 0) { g0[jj] = ld4(gamma, ic); b0[jj] = ld4(beta, ic); }
+        }
+#pragma unroll
+        for (uint32_t jj = 0; jj < 4; jj++) {
+            const uint32_t i = lane + 64 * (j0 + jj);
+            float4 bb = b[jj];
+            if (yb) bb = make_float4(ya * bb.x + c[jj].x, ya * bb.y + c[jj].y, ya * bb.z + c[jj].z, ya * bb.w + c[jj].w);
+            const float4 w = make_float4(a[jj].x + bb.x, a[jj].y + bb.y, a[jj].z + bb.z, a[jj].w + bb.w);
+            const bool in = i < n4;
+            v[j0 + jj] = in ? w : make_float4(0.f, 0.f, 0.f, 0.f);
+            sum += in ? (w.x + w.y) + (w.z + w.w) : 0.f;
         }
     }
     const float mean = wave_sum(sum) / (float)d;
@@ -387,14 +407,24 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y,
     __half *prow = planes ? planes + (uint64_t)row * 3 * d : nullptr;      // (fp32 only) the same values as the next GEMM's split operand
     bool over = false;
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) {
-        const uint32_t i = lane + 64 * j;
-        if (i < n4) {
-            const float4 g = ld4(gamma, i), bb = ld4(beta, i);
-            const float4 r = make_float4((v[j].x - mean) * rstd * g.x + bb.x, (v[j].y - mean) * rstd * g.y + bb.y,
-                                         (v[j].z - mean) * rstd * g.z + bb.z, (v[j].w - mean) * rstd * g.w + bb.w);
-            st4(orow, i, r);
-            if (prow) over |= store_planes4(prow, d, i, r);
+    for (uint32_t j0 = 0; j0 < 16; j0 += 4) {
+        if (64 * j0 >= n4) continue;
+        float4 g[4], bb[4];
+#pragma unroll
+        for (uint32_t jj = 0; jj < 4; jj++) {
+            const uint32_t i = lane + 64 * (j0 + jj), ic = i < n4 ? i : 0;
+            if (j0 == 0) { g[jj] = g0[jj]; bb[jj] = b0[jj]; }
+            else { g[jj] = ld4(gamma, ic); bb[jj] = ld4(beta, ic); }
+        }
+#pragma unroll
+        for (uint32_t jj = 0; jj < 4; jj++) {
+            const uint32_t j = j0 + jj, i = lane + 64 * j;
+            if (i < n4) {
+                const float4 r = make_float4((v[j].x - mean) * rstd * g[jj].x + bb[jj].x, (v[j].y - mean) * rstd * g[jj].y + bb[jj].y,
+                                             (v[j].z - mean) * rstd * g[jj].z + bb[jj].z, (v[j].w - mean) * rstd * g[jj].w + bb[jj].w);
+                st4(orow, i, r);
+                if (prow) over |= store_planes4(prow, d, i, r);
+            }
         }
     }
     if (over && flag) atomicAdd(flag, 1u);
