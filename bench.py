@@ -466,6 +466,55 @@ def _prefix_table_stats(index):
     return {"tables": t.value, "leaf_level_nodes": n.value, "hbm_mib": round(b.value / 2**20, 1)}
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(n_gpus: int, argv, port: int = None, script: str = None):
+    """the command line `python bench.py --gpus N ...` turns itself into when no launcher set RANK / WORLD_SIZE: one rank per GPU of
+    this node under torch.distributed.run (rendezvous on 127.0.0.1: the container's hostname may not resolve)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port or _free_port()), script or os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n_gpus: int, argv) -> int:
+    """start the N ranks and wait for them; rank 0's JSON line goes to this process's stdout, every rank's log to stderr"""
+    import subprocess
+    cmd = launch_command(n_gpus, argv)
+    print("[bench] --gpus %d without RANK/WORLD_SIZE in the environment: launching %s" % (n_gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # RCCL over dmabuf IPC (the host driver supports nothing else)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run_launch(args) -> int:
+    """--dry-run-launch: every rank joins the process group (nccl = RCCL when it has a GPU, gloo otherwise), all-reduces a one, and rank 0
+    prints the launch fields of the line.  No index, no model: what it proves is that `--gpus N` yields N ranks and one line."""
+    import torch.distributed as dist
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    gpu = torch.cuda.is_available()
+    if gpu:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local) if gpu else torch.device("cpu")
+    backend = "nccl" if gpu else "gloo"
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if gpu else {}))
+    t = torch.ones(1, device=dev, dtype=torch.float64)
+    dist.all_reduce(t)
+    print(f"[bench] rank {rank} of {dist.get_world_size()} up (backend {dist.get_backend()}, device {dev})", file=sys.stderr, flush=True)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "launch dry run", "n_gpus": dist.get_world_size(), "ranks_reduced": int(t.item()), "requested_gpus": args.gpus,
+                          "config": {"parallelism": f"query-sharded x{dist.get_world_size()}, backend {dist.get_backend()}"}, "dry_run": True}), flush=True)
+    dist.destroy_process_group()
+    return 0 if int(t.item()) == world else 4
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -496,7 +545,14 @@ def main():
     ap.add_argument("--no-query-keys", action="store_true", help="leave out the query n-gram keys (add_query_to_keys, the reference's default)")
     ap.add_argument("--first-stage-only", action="store_true",
                     help="stop after the first retrieval stage (SURVEY.md 8d metric) instead of the reference's complete batch_search")
+    ap.add_argument("--dry-run-launch", action="store_true", help="start the ranks, form the process group (nccl = RCCL with a GPU, gloo without), "
+                    "all-reduce a one per rank and print the line's launch fields only: checks the N-rank launch without building an index")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver types it: nobody started the ranks yet -> this process becomes the launcher
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_run_launch:
+        sys.exit(dry_run_launch(args))
     # the contract is ONE JSON line on stdout: RCCL prints a version banner there (seen with one rank: five lines after
     # the JSON line), so file descriptor 1 is pointed at stderr for everything but the line itself
     sys.stdout.flush()
@@ -506,7 +562,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if world != args.gpus:
+        print(f"[bench] rank {rank}: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is what runs", file=sys.stderr, flush=True)
+    if not torch.cuda.is_available():
+        print(f"[bench] bench.py needs a GPU (rank {rank} of {world})", file=sys.stderr, flush=True)
+        if world > 1:
+            # the launcher tears the other ranks down as soon as one fails: linger so that every rank's own diagnosis reaches the log
+            time.sleep(float(os.environ.get("SEAL_BENCH_FAIL_LINGER_S", "2")))
+        sys.exit(5)
     # host budget of a rank: the search step is one python thread + the key-scoring threads of fmi_agg_score_pack; all
     # ranks of a node share its cores (the CPU baseline leg alone uses --cpu-threads, on rank 0 at N=1 only)
     cores = os.cpu_count() or 1
@@ -912,7 +975,7 @@ def main():
         "config": {"workload": f"{'configs[4]: 100M-document stress tier, suffix array sorted in slices,' if stress else 'configs[3]: KILT-size' if args.docs >= 30_000_000 else 'configs[1]: NQ-shaped'} synthetic FM-index ({args.docs} passages, {index.size()} symbols{', phrase corpus P=%d' % args.corpus_phrases if args.corpus_phrases else ''}), random-init "
                                f"BART-large {'bf16' if stress else 'fp32'}, beam={args.beam}, batch={args.batch} per GPU, body len 10 + title len<=15, "
                                f"{'first-stage retrieval' if args.first_stage_only else 'first stage + full-document rescoring of 1500 docs/query'}, top-{args.topk}",
-                   "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world}, index+model replicated; " + ("decodes of the next two batches enqueued ahead of this batch's rescoring / aggregation; the two GEMM-bearing phases (decode, rescoring) alternate on the GPU, the aggregation overlaps both on the index's stream" if not args.no_overlap else "one batch after the other"), "model_arithmetic": "bf16 storage, fp32 accumulation (BASELINE configs[4])" if stress else "fp32 (as the reference runs BART); linear layers of >= 0.9 GFLOP as one fp16 GEMM over three planes with fp32 accumulation (seal_amd/split_gemm.py), scores within 1e-4 of HF's fp32 forward",
+                   "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world} ({'torch.distributed backend ' + dist.get_backend() + ' = RCCL, world_size ' + str(dist.get_world_size()) + ', one all_gather of the top-k per timed call' if use_dist else 'one rank, no process group'}), index+model replicated; " + ("decodes of the next two batches enqueued ahead of this batch's rescoring / aggregation; the two GEMM-bearing phases (decode, rescoring) alternate on the GPU, the aggregation overlaps both on the index's stream" if not args.no_overlap else "one batch after the other"), "model_arithmetic": "bf16 storage, fp32 accumulation (BASELINE configs[4])" if stress else "fp32 (as the reference runs BART); linear layers of >= 0.9 GFLOP as one fp16 GEMM over three planes with fp32 accumulation (seal_amd/split_gemm.py), scores within 1e-4 of HF's fp32 forward",
                    "decodes": "body + title of a batch as two loops" if args.no_joint_decode else "body + title of a batch as ONE loop (2 x batch x beams rows per model step, one constraint launch per step)",
                    "query_ngram_keys": "off" if args.no_query_keys else "token 1..3-grams of the query ids (add_query_to_keys=True, the reference's default; "
                                                                                  "spaCy/BART tokenizer absent offline: seal_amd.query_keys.token_ngram_keys)",

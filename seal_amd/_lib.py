@@ -140,6 +140,11 @@ def lib():
             raise ImportError(
                 f"{_build.LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  seal_amd has no pure-Python or CPU fallback.")
+        if _build.stale() and os.environ.get("SEALFM_ALLOW_STALE_LIB") != "1":
+            # a binary built from other sources than the ones present (it is git-ignored and travels with snapshots): never run it silently
+            raise ImportError(
+                f"{_build.LIB} was built from other sources (stamp {_build.built_digest()[:16] or 'missing'}, sources "
+                f"{_build.source_digest()[:16]}): rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
         L = ctypes.CDLL(_build.LIB)
         for name, (res, args) in list(SIGNATURES.items()) + list(NN_SIGNATURES.items()):
             fn = getattr(L, name)   # AttributeError here = ABI drift, fail loudly

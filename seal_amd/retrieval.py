@@ -518,7 +518,14 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0):
         for nfk, fk in zip(code_keys, found_keys):
             fk += nfk
 
+    def gemm_gate():
+        # (overlapped search) a forward AFTER the "rescoring" yield -- the un-marked rescoring, a separate scorer model's unigram scores, a
+        # forced second token -- is a library-GEMM phase too: it waits for the decodes released meanwhile, and the caller fences behind it
+        g = s.__dict__.get("_gemm_gate")
+        if g is not None:
+            g()
     if s.rescore and not s.use_markers:
+        gemm_gate()
         found_keys = rk.rescore_keys(s.bart_scorer_model, last_input_tokens, found_keys, batch_size=100, length_penalty=0.0,
                                      strip_from_bos=bos_strip, strip_from_eos=[s.bart_model.config.eos_token_id])
 
@@ -533,6 +540,7 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0):
         return list(zip(found_keys, unigram))
     if s.unigram_scores:
         _, toks = marked("body")
+        gemm_gate()
         unigram = rk.compute_unigram_scores(
             s.bart_scorer_model, toks, fm_index,
             prefix=[s.force_decoding_second_token] if s.force_decoding_second_token >= 0 else [], logit_bias=bias,
@@ -823,6 +831,17 @@ class SEALSearcher:
         # has the next decode queued while the host waits for a batch's scores: throughput is bound by the host loop or by
         # decode + rescoring, whichever is longer, as before.
         exclusive = bool(getattr(self, "exclusive_gemm_streams", True)) and os.environ.get("SEAL_EXCLUSIVE_GEMM_STREAMS", "1") != "0"
+        if not exclusive:
+            # two library-GEMM streams at once is the configuration that stalled the GPU for ever: it is for
+            # reproducing that stall (tools/soak.py), never something a caller gets by flipping one switch
+            if os.environ.get("SEAL_I_KNOW_TWO_GEMM_STREAMS_CAN_STALL") != "1":
+                raise RuntimeError("exclusive_gemm_streams=False / SEAL_EXCLUSIVE_GEMM_STREAMS=0 lets the decode and the rescoring forward run "
+                                   "hipBLASLt stream-K GEMMs on two streams at once, which has stalled the GPU for ever (DESIGN.md section 9); "
+                                   "set SEAL_I_KNOW_TWO_GEMM_STREAMS_CAN_STALL=1 to do it anyway")
+            if not self.__dict__.get("_warned_two_gemm_streams"):
+                self.__dict__["_warned_two_gemm_streams"] = True
+                print("[seal_amd] WARNING: decode and rescoring share the GPU (two library-GEMM streams): this configuration can stall",
+                      file=sys.stderr, flush=True)
         depth = max(1, int(os.environ.get("SEAL_OVERLAP_DEPTH", self.overlap_depth if exclusive else 1)))
         ahead = []                                            # generators whose decodes are enqueued, oldest first
         nxt_i = 0
@@ -876,12 +895,18 @@ class SEALSearcher:
                     enqueue_next("body" if len(ahead) == 0 else "decoding")
             t2 = time.perf_counter()
             # (the filters' count launch and copies run beside the decodes; only the rescoring forward is fenced, from inside the step)
-            self.__dict__["_gemm_gate"] = lambda: wait_for("decode", post)
+            gated = [0]
+
+            def gate():
+                gated[0] += 1
+                wait_for("decode", post)
+            self.__dict__["_gemm_gate"] = gate                # stays installed until this batch's keys are back (forwards after the yield)
             try:
                 with torch.cuda.stream(post):
                     advance(cur, "rescoring")
-            finally:
+            except BaseException:
                 self.__dict__.pop("_gemm_gate", None)
+                raise
             after("rescore", post)
             if exclusive:
                 # GPU order: decode(i+1) [enqueued one iteration ago] -> rescoring(i) [just enqueued: it waits for that decode only] ->
@@ -899,11 +924,17 @@ class SEALSearcher:
                 yield from held
                 held = None
             with torch.cuda.stream(post):
+                late = gated[0]
                 try:
                     next(cur[0])
                     raise RuntimeError("_batch_steps yielded more often than expected")
                 except StopIteration as done:
                     keys = done.value
+                finally:
+                    self.__dict__.pop("_gemm_gate", None)
+                if gated[0] != late:
+                    # a forward ran after the yield (non-default configurations): the decodes enqueued from here on wait for it as well
+                    after("rescore", post)
                 jobs = [(kk[0], kk[1]) if isinstance(kk, tuple) else (kk, None) for kk in keys]
                 out = rk.aggregate_evidence_batch(jobs, self.fm_index, keep=keep, gpu_aggregate=self.gpu_aggregate, want_ngrams=False, **params)
                 post.synchronize()

@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """the library under test is the one built from the sources present: rebuild it (hipcc cross-compiles without a GPU) when its stamp
+    says otherwise, instead of testing a stale git-ignored binary that travelled with a snapshot"""
+    from seal_amd import _build
+    if _build.stale():
+        _build.build(verbose=True)
+    from oracle import seal_oracle
+    seal_oracle.build_oracle_lib()
+
+
 def _has_gpu():
     try:
         import torch

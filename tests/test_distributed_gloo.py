@@ -27,8 +27,8 @@ def _worker(rank, world, port, n_queries, k, q):
     # a deterministic fake "search": query i returns docs i*100+j with scores 1000-i-j/10, fewer hits for odd i
     results = [[(i * 100 + j, 1000.0 - i - j / 10.0) for j in range(k if i % 2 == 0 else k // 2)] for i in mine]
     full = gather_topk(pack_topk(results, k), n_queries)
-    q.put((rank, mine, full.clone()))
-    dist.barrier()
+    q.put((rank, mine, full.numpy().tobytes(), tuple(full.shape)))     # by value: a tensor on a spawn queue travels as a file descriptor
+    dist.barrier()                                                     # of a process that may be gone when the parent reads it
     dist.destroy_process_group()
 
 
@@ -44,7 +44,8 @@ def test_two_rank_shard_and_gather():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    got.sort(key=lambda x: x[0])
+    import numpy as np
+    got = sorted((r, mine, torch.from_numpy(np.frombuffer(raw, dtype=np.float64).reshape(shape).copy())) for r, mine, raw, shape in got)
     assert got[0][1] == [0, 1, 2, 3] and got[1][1] == [4, 5, 6]
     for _, _, full in got:            # every rank ends up with the whole, query-ordered result
         assert full.shape == (n_queries, k, 2)

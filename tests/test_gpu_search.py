@@ -197,6 +197,12 @@ def test_overlapped_batches_give_the_results_of_sequential_batches(geom, monkeyp
                          title_eos_token_id=TITLE_EOS, code_eos_token_id=vocab - 6, code_bos_token_id=TITLE_EOS,
                          marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5]})
         assert s._overlapped() is overlap
+        if not exclusive:
+            # two library-GEMM streams at once re-arm round 3's stall: refused without the explicit switch (tiny GEMMs here: safe to run)
+            monkeypatch.delenv("SEAL_I_KNOW_TWO_GEMM_STREAMS_CAN_STALL", raising=False)
+            with pytest.raises(RuntimeError, match="SEAL_I_KNOW_TWO_GEMM_STREAMS_CAN_STALL"):
+                s.batch_search(queries, k=10)
+            monkeypatch.setenv("SEAL_I_KNOW_TWO_GEMM_STREAMS_CAN_STALL", "1")
         for rep in range(2):           # the second call reuses the captured graphs and buffers
             res = s.batch_search(queries, k=10)
             out[(depth, overlap, exclusive, rep)] = [[(d.idx, d.score, list(d.raw_tokens()), d.keys) for d in docs_] for docs_ in res]
@@ -204,6 +210,51 @@ def test_overlapped_batches_give_the_results_of_sequential_batches(geom, monkeyp
     assert sum(len(r) for r in base) > 30
     for key, val in out.items():
         assert val == base, key
+
+
+@pytest.mark.parametrize("variant", ["unmarked_rescoring", "separate_scorer", "forced_second_token"])
+def test_overlapped_search_with_a_forward_after_the_rescoring_yield(variant, monkeypatch):
+    """configurations whose model forwards run AFTER the batch's marked rescoring is enqueued (reference retrieval.py:265-281 un-marked
+    rescoring; keys.py:145-176 unigram scores from a separate scorer model or behind a forced second token): the overlapped search
+    fences those forwards like the rescoring itself (one library-GEMM stream at a time) and returns what the sequential search returns"""
+    from seal_amd import FMIndex
+    from seal_amd import retrieval
+    from seal_amd.retrieval import SEALSearcher
+    from tests.helpers import make_docs, tiny_bart
+    vocab = 120
+    dev = torch.device("cuda:0")
+    docs = make_docs(5, 300, vocab - 8, min_len=6, max_len=18, title_sep=TITLE_EOS)
+    ix = FMIndex()
+    ix.initialize(docs)
+    rng = np.random.default_rng(5)
+    queries = [[0] + rng.integers(4, vocab - 8, size=int(rng.integers(4, 9))).tolist() + [2] for _ in range(7)]
+    monkeypatch.setattr(retrieval, "TITLE_MAX_LENGTH", 8)
+    model = tiny_bart(vocab).to(dev)
+    extra, scorer = {}, None
+    if variant == "unmarked_rescoring":
+        extra = dict(use_markers=False)
+    elif variant == "separate_scorer":
+        scorer = tiny_bart(vocab, seed=11).to(dev)
+    else:
+        extra = dict(force_decoding_second_token=int(docs[0][0]))
+    gates = []
+    out = {}
+    for overlap in (False, True):
+        s = SEALSearcher(ix, None, model, bart_scorer_model=scorer, backbone="bart-tiny", length=6, beam=4, batch_size=2, add_query_to_keys=False,
+                         detokenize=False, overlap=overlap, title_eos_token_id=TITLE_EOS, code_eos_token_id=vocab - 6, code_bos_token_id=TITLE_EOS,
+                         marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5]}, **extra)
+        if overlap:
+            real = retrieval.rk.compute_unigram_scores if variant != "unmarked_rescoring" else retrieval.rk.rescore_keys
+            name = "compute_unigram_scores" if variant != "unmarked_rescoring" else "rescore_keys"
+
+            def spy(*a, _real=real, **kw):
+                gates.append(s.__dict__.get("_gemm_gate") is not None)      # the gate is still installed when the late forward runs
+                return _real(*a, **kw)
+            monkeypatch.setattr(retrieval.rk, name, spy)
+        res = s.batch_search(queries, k=10)
+        out[overlap] = [[(d.idx, d.score) for d in docs_] for docs_ in res]
+    assert gates and all(gates)
+    assert out[True] == out[False] and sum(len(r) for r in out[True]) > 10
 
 
 def _tiny_gpu_searcher(ix, model, vocab, **kw):
