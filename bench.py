@@ -447,7 +447,7 @@ def cite_traffic(workload_tag, root=ROOT, now=None):
             kib = sum(c["sum"] for c in mine.values()) / calls if calls else 0
             if kib:
                 traffic = round(kib * 1024.0 * 2, 1)
-                traffic_src = {"file": os.path.relpath(f, root), "commit": pmc.get("_commit"), "kernel_source_sha256": now[:16], "workload": workload_tag}
+                traffic_src = {"file": os.path.relpath(f, root), "builder_run": True, "commit": pmc.get("_commit"), "kernel_source_sha256": now[:16], "workload": workload_tag}
                 break
         if traffic is None:
             traffic_src = {"refused": "no profiles/r*_pmc_fetch_size*.json was taken over the current fmi_kernels.hip / fmi_device.h / fmi_internal.h "
@@ -455,6 +455,96 @@ def cite_traffic(workload_tag, root=ROOT, now=None):
     except Exception as e:
         traffic_src = {"error": repr(e)}
     return traffic, traffic_src
+
+
+CALL_FORMS = {0: "generic", 1: "row_first", 2: "table", 3: "chained"}
+
+
+def read_call_log(handle, cap=4096):
+    """the library's per-call log (fmi_dev_call_log): [{cur_len, rows, form, us, blocks}] in launch order; clears it"""
+    import ctypes as C
+    from seal_amd._lib import check, lib
+    cl, rw, kd = (C.c_uint32 * cap)(), (C.c_uint32 * cap)(), (C.c_uint32 * cap)()
+    us, bl, n = (C.c_float * cap)(), (C.c_uint64 * cap)(), C.c_uint64()
+    check(lib().fmi_dev_read_call_log(handle, cap, cl, rw, kd, us, bl, C.byref(n)))
+    return [{"cur_len": cl[i], "rows": rw[i], "form": CALL_FORMS.get(kd[i], str(kd[i])), "us": float(us[i]), "blocks": int(bl[i])} for i in range(min(cap, n.value))]
+
+
+def merge_call_logs(timed, counted):
+    """the timing pass and the counting pass ran the same batch: the same calls in the same order.  One record per call with both figures;
+    [] when the two passes disagree about what was launched (then neither is attributed)"""
+    if not timed or len(timed) != len(counted) or any((a["cur_len"], a["rows"], a["form"]) != (b["cur_len"], b["rows"], b["form"]) for a, b in zip(timed, counted)):
+        return []
+    out = []
+    for a, b in zip(timed, counted):
+        mb = b["blocks"] * 128.0 / 1e6
+        us = a["us"]
+        out.append({"cur_len": a["cur_len"], "rows": a["rows"], "form": a["form"], "MB": round(mb, 3), "us": round(us, 2),
+                    "GBps": round(mb * 1e6 / (us * 1e-6) / 1e9, 1) if us > 0 else None, "frac": round(mb * 1e6 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if us > 0 else None})
+    return out
+
+
+AGG_STAGES = ["k_agg_locate", "sort_by_position(rocprim)", "coverage(k_mis_prepare+k_mis)", "k_doc_keys+sort_by_document(rocprim)",
+              "entry_boundaries(k_heads+scan+k_entry_starts)", "k_entries", "ranking(3 rocprim sorts+k_top_docs)", "token_tables(memsets+scatters)",
+              "k_full_score(ranked documents)", "k_rank_docs", "k_full_score(top-k records)"]
+
+
+def read_agg_timing(handle):
+    import ctypes as C
+    from seal_amd._lib import check, lib
+    ms, cnt, calls = (C.c_double * len(AGG_STAGES))(), (C.c_uint64 * 5)(), C.c_uint64()
+    check(lib().fmi_dev_read_agg_timing(handle, ms, cnt, C.byref(calls)))
+    return {"stage_ms": list(ms), "counts": list(cnt), "calls": calls.value}
+
+
+def aggregate_roofline(t, index):
+    """`roofline_aggregate`: the locate + doc-binning + evidence kernels of ONE un-overlapped batch (north_star: "then locate() + doc-id
+    binning for scoring"; reference keys.py:314-350, index.py:77-82), HIP events after every stage of fmi_dev_aggregate.  Algorithmic bytes
+    = the arrays a stage must read and write once for the rows / entries / documents it processed (DESIGN.md 5.4 derives each figure)."""
+    if not t or not t["calls"]:
+        return None
+    rows, entries, docs, kept, doc_tok = t["counts"]
+    wide_sa = index.size() > (1 << 32)
+    per = {
+        # row -> SA[row] (4 B, +1 B above 2^32 rows) -> doc_hint[pos >> 7] (4 B) -> 0..2 boundaries (8 B each, ~1) ; writes occ_rk 4 + doc 4 + key_pos 8 + val 4
+        "k_agg_locate": rows * ((5 if wide_sa else 4) + 4 + 8 + 20),
+        # k_mis_prepare: sorted_val 4 + occ_rk[val] 4 -> M 2 + state 1; k_mis: E 8 + M 2 + PRI 4 + state 1 -> newflag 1
+        "coverage(k_mis_prepare+k_mis)": rows * (4 + 4 + 2 + 1 + 8 + 2 + 4 + 1 + 1),
+        # per located row KD 8 + ID 4 + occ_rk 4 + newflag 1; per (query, document) entry: nkeys 4 + rank 8 + first 4 + q 4 + doc 4 + score 8 + best 4 + one key (4 + 8)
+        "k_entries": rows * 17 + entries * 48,
+        # the document's tokens from the resident text (2 B each) + its score (8 B); everything else lives in LDS
+        "k_full_score(ranked documents)": doc_tok * 2 + docs * 8,
+    }
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "calls": t["calls"], "located_rows": rows, "document_entries": entries,
+           "documents_scored": docs, "documents_kept": kept, "document_tokens": doc_tok, "stages": []}
+    for name, ms in zip(AGG_STAGES, t["stage_ms"]):
+        rec = {"stage": name, "us": round(ms * 1e3, 1)}
+        if name in per and ms > 0:
+            gbps = per[name] / (ms * 1e-3) / 1e9
+            rec.update({"algorithmic_MB": round(per[name] / 1e6, 2), "achieved": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)})
+        out["stages"].append(rec)
+    loc = out["stages"][0]
+    out.update({"kernel": "k_agg_locate", "achieved": loc.get("achieved"), "frac": loc.get("frac"), "total_us": round(sum(t["stage_ms"]) * 1e3, 1),
+                "measured_on": "the un-overlapped batch after the timed region that also times the constraint calls",
+                "note": "k_full_score is an LDS / ALU kernel (hash-trie matching, rank sort and greedy cover in LDS): its HBM bytes are the documents' tokens; "
+                        "the radix sorts are rocPRIM's"})
+    out["traffic"], out["traffic_source"] = cite_traffic_agg(index)
+    return out
+
+
+def cite_traffic_agg(index=None, root=ROOT):
+    """FETCH_SIZE + WRITE_SIZE of the aggregation kernels from the newest builder-run profiles/r*_pmc_agg*.json taken over the current
+    fmi_aggregate.hip (same refusal rule as cite_traffic)"""
+    import glob, hashlib
+    try:
+        sha = hashlib.sha256(open(os.path.join(root, "seal_amd", "csrc", "fmi_aggregate.hip"), "rb").read()).hexdigest()
+        for f in sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_agg*.json")), reverse=True):
+            pmc = json.load(open(f))
+            if pmc.get("_aggregate_source_sha256") == sha:
+                return pmc.get("per_batch_MB"), {"file": os.path.relpath(f, root), "builder_run": True, "aggregate_source_sha256": sha[:16]}
+        return None, {"refused": "no profiles/r*_pmc_agg*.json taken over the current fmi_aggregate.hip (sha256 %s)" % sha[:16]}
+    except Exception as e:
+        return None, {"error": repr(e)}
 
 
 def _prefix_table_stats(index):
@@ -524,7 +614,7 @@ def main():
     ap.add_argument("--batch", type=int, default=20)
     ap.add_argument("--beam", type=int, default=15)
     ap.add_argument("--topk", type=int, default=100)
-    ap.add_argument("--cpu-threads", type=int, default=64)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline leg (0 = all the cores this process may run on, SURVEY.md 8(d))")
     ap.add_argument("--jobs", type=int, default=1, help="host worker processes (only used by the host aggregation routines)")
     ap.add_argument("--no-overlap", action="store_true", help="do not enqueue the next batch's decodes ahead of this batch's rescoring/aggregation")
     ap.add_argument("--no-joint-decode", action="store_true", help="body and title decodes as two loops of batch x beams rows (the reference's "
@@ -810,6 +900,8 @@ def main():
     # off) and supplies the bytes of the very same launches
     for hd in handles:
         check(lib().fmi_dev_enable_timing(hd, 1))
+        check(lib().fmi_dev_call_log(hd, 1))              # which call each event pair belongs to (prefix length, rows, launch form)
+        check(lib().fmi_dev_agg_timing(hd, 1))            # events after every stage of fmi_dev_aggregate (roofline_aggregate)
     if os.environ.get("SEAL_BENCH_PROFILE"):
         import cProfile, pstats
         pr = cProfile.Profile()
@@ -822,6 +914,9 @@ def main():
     retrieval.fm_index_generate, rk.rescore_keys, rk.compute_unigram_scores, rk.aggregate_evidence_batch, retrieval._count_filter = orig
     rk.rescore_keys_multi, retrieval.fm_index_generate_joint = orig_multi, orig_joint
     import ctypes as C
+    calls_timed = read_call_log(handles[0])               # (before fmi_dev_read_timing hands the event pairs back)
+    agg_timing = read_agg_timing(handles[0])
+    check(lib().fmi_dev_agg_timing(handles[0], 0))
     l2, k2 = C.c_uint64(0), C.c_double(0.0)
     for hd in handles:
         ln, km = C.c_uint64(), C.c_double()
@@ -842,6 +937,8 @@ def main():
     run_batch(args.warmup + args.steps)
     index.set_trace(None)
     rk.aggregate_evidence_batch = orig[3]
+    calls_counted = read_call_log(handles[0])             # blocks per call, drained call by call in this pass
+    check(lib().fmi_dev_call_log(handles[0], 0))
     xstats = [0, 0, 0, 0]
     _p, _l, _k = read_counters(xstats)                     # blocks loaded by the launches of that batch (the replays that
     p2 = ctypes.c_uint64(_p)                               # gpu_allowed_bits issues for the parity check come later)
@@ -883,6 +980,15 @@ def main():
                                     "note": "binary 16-level wavelet tree, 64 B per level-probe, same symbols emitted"},
                 "wave_iterations_per_launch": round(xstats[1] / nl, 1), "lane_pair_utilisation": round(xstats[2] / max(1, 32 * xstats[1]), 3)}
 
+    by_call = merge_call_logs(calls_timed, calls_counted)
+    if by_call:
+        roofline["by_call"] = by_call
+        roofline["widest_call"] = max(by_call, key=lambda c: c["MB"])
+        roofline["by_call_note"] = ("one record per constraint call of ONE batch, in launch order: us = HIP events around the call in the un-overlapped timing "
+                                    "pass, MB = 128-byte blocks its launches loaded in the counting pass of the same batch; frac = MB / us / 8 TB/s; "
+                                    "form: table = k_constrain_table + k_table_bits, row_first = k_constrain_rows + k_constrain, generic = k_constrain")
+    roofline_aggregate = aggregate_roofline(agg_timing, index)
+
     cpu = parity = None
     if args.no_cpu_baseline and world == 1 and os.environ.get("SEAL_BENCH_SCORE_PARITY") == "1":
         # quick A/B runs of model-side changes (tools/r4_split_gemm.sh): the float half alone, no oracle
@@ -892,7 +998,8 @@ def main():
             % (sp["beam_scores_body"]["max_abs_err"], sp["beam_scores_title"]["max_abs_err"], sp["rescore_scores"]["max_abs_err"],
                sp["beam_scores_body"]["violations"] + sp["beam_scores_title"]["violations"] + sp["rescore_scores"]["violations"]))
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
-        threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = max(1, min(args.cpu_threads or avail, avail))
         t0 = time.perf_counter()
         orc = build_cpu_oracle(index, threads)
         log(f"cpu oracle index (sdsl-style wt_int + rank_support_v, SA/32, ISA/64) built in {time.perf_counter() - t0:.1f}s with {threads} threads")
@@ -982,6 +1089,7 @@ def main():
                    "not_in_step": (["full-document rescoring (keys.py:366-497)"] if args.first_stage_only else []) +
                                   (["query n-gram keys (add_query_to_keys)"] if args.no_query_keys else [])},
         "roofline": roofline,
+        "roofline_aggregate": roofline_aggregate,
         "cpu_baseline": cpu,
         "parity_check": parity,
         "extra": {("complete_search_qps" if args.first_stage_only else "first_stage_only_qps"): None if other_qps is None else round(other_qps, 3),

@@ -310,6 +310,33 @@ int fmi_dev_read_expand_stats(fmi_t *h, uint64_t *out4);
 int fmi_dev_enable_timing(fmi_t *h, int enable);
 int fmi_dev_read_timing(fmi_t *h, uint64_t *launches_out, double *total_ms_out);
 
+/* Per-call log of the constraint calls (bench.py's `roofline.by_call`): while enabled, every call of the
+ * fmi_dev_allowed_bits* / fmi_dev_constrain_scores / fmi_dev_constrained_topk* family appends one record -- prefix length
+ * (cur_len), rows, launch form (FMI_CALL_*) -- which names its HIP-event pair when fmi_dev_enable_timing is on, and, when
+ * fmi_dev_enable_probe_count is on, holds the 128-byte blocks its launches loaded (the stream is drained after the call:
+ * a measurement pass).  read = synchronise, copy up to `cap` records out (us = -1 without timing), report how many there
+ * were, clear.  The reference has no counterpart: one IndexBasedLogitsProcessor.__call__ (beam_search.py:62-140) = one record. */
+#define FMI_CALL_GENERIC 0   /* k_constrain alone */
+#define FMI_CALL_ROW_FIRST 1 /* k_constrain_rows + k_constrain */
+#define FMI_CALL_TABLE 2     /* k_constrain_table + k_table_bits (first constrained step of a decode) */
+int fmi_dev_call_log(fmi_t *h, int enable);
+int fmi_dev_read_call_log(fmi_t *h, uint64_t cap, uint32_t *cur_len, uint32_t *rows, uint32_t *kind, float *us, uint64_t *blocks,
+                          uint64_t *n_out);
+
+/* Stage timing of fmi_dev_aggregate (bench.py's `roofline_aggregate`; a measurement pass: every call then ends with a stream
+ * synchronise and a read-back of what it processed).  While enabled every call (up to 64) brackets its stages with HIP events:
+ *   0 k_agg_locate (row -> text position -> document: keys.py:322-324, index.py:77-82)   1 radix sort by (query, position)
+ *   2 coverage (k_mis_prepare + k_mis: keys.py:320-341)   3 k_doc_keys + radix sort by (query, document)
+ *   4 entry boundaries (k_heads, scan, k_entry_starts)     5 k_entries (keys.py:343-364)
+ *   6 ranking (three stable radix sorts + k_top_docs = sorted(first_stage.items()), keys.py:366-375)
+ *   7 per-query token tables (memsets + scatters)          8 k_full_score over the ranked documents (keys.py:377-497)
+ *   9 k_rank_docs                                          10 k_full_score over the caller's top-k (the records that go back)
+ * read: stage_ms[11] summed over the calls; counts[5] = {located rows, (query, document) entries, documents scored in stage 8,
+ * documents re-scored in stage 10, tokens of the documents of stage 8}; clears. */
+#define FMI_AGG_STAGES 11
+int fmi_dev_agg_timing(fmi_t *h, int enable);
+int fmi_dev_read_agg_timing(fmi_t *h, double *stage_ms, uint64_t *counts, uint64_t *calls_out);
+
 /* Device pointer of a resident array, for zero-copy hand-over (e.g. to build the
  * CPU baseline's samples).  name in {"sa_lo","sa_hi","text","wm","C","leaf","q1","doc_begin"}. */
 const void *fmi_dev_array(const fmi_t *h, const char *name, uint64_t *n_out, uint32_t *elem_out);

@@ -70,6 +70,11 @@ SIGNATURES = {
     "fmi_dev_read_expand_stats": (_int, [_vp, _p64]),
     "fmi_dev_enable_timing": (_int, [_vp, _int]),
     "fmi_dev_read_timing": (_int, [_vp, _p64, ctypes.POINTER(ctypes.c_double)]),
+    "fmi_dev_agg_timing": (_int, [_vp, _int]),
+    "fmi_dev_read_agg_timing": (_int, [_vp, ctypes.POINTER(ctypes.c_double), _p64, _p64]),
+    "fmi_dev_call_log": (_int, [_vp, _int]),
+    "fmi_dev_read_call_log": (_int, [_vp, _u64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
+                                     ctypes.POINTER(ctypes.c_float), _p64, _p64]),
     "fmi_dev_array": (_vp, [_vp, ctypes.c_char_p, _p64, ctypes.POINTER(ctypes.c_uint32)]),
     "fmi_first_stage": (_int, [_u64, _vp, _vp, _vp, _vp, _vp, _vp, _int, ctypes.c_double, ctypes.c_double, _u64,
                                ctypes.POINTER(_vp)]),

@@ -118,7 +118,8 @@ class BartStepDecoder:
         from . import split_gemm
         if self.split_gemm is None:
             BartStepDecoder.split_gemm = split_gemm.SplitLinears() if split_gemm.ENABLED else False
-        return bool(self.split_gemm) and split_gemm.FUSED and x.is_cuda and x.dtype == torch.float32
+        # (no product of fewer than MIN_ROWS rows takes the split: nobody would read the planes of such an activation)
+        return bool(self.split_gemm) and split_gemm.FUSED and x.is_cuda and x.dtype == torch.float32 and x.shape[0] >= split_gemm.MIN_ROWS
 
     def _lin_p(self, x: torch.Tensor, xp, w: torch.Tensor, b, defer: bool = False):
         """``F.linear(x, w, b)`` where ``xp`` (or None) holds x's split planes already (``defer``: see ``_lin``)"""
@@ -138,7 +139,10 @@ class BartStepDecoder:
         """fc2(gelu(fc1(x))): with planes, gelu's output exists as fc2's operand only (``defer``: see ``_lin``; fc1's own epilogue is
         always gelu's to apply)"""
         w2 = L["fc2"].weight
-        if xp is not None and self.split_gemm.wants(w2, x.shape[0]) and getattr(L["act"], "__class__", type(None)).__name__ in ("GELUActivation", "GELU"):
+        # (the fused kernel computes the erf form: nn.GELU(approximate="tanh") shares the class name and must not take it)
+        erf_gelu = (getattr(L["act"], "__class__", type(None)).__name__ in ("GELUActivation", "GELU")
+                    and getattr(L["act"], "approximate", "none") == "none")
+        if xp is not None and self.split_gemm.wants(w2, x.shape[0]) and erf_gelu:
             from . import split_gemm
             from ._lib import check, lib
             h = self._lin_p(x, xp, L["fc1"].weight, L["fc1"].bias, defer=True)

@@ -861,6 +861,15 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
     static uint32_t call_no = 0;
     const uint32_t call_base = 100u * (++call_no);
     auto mark = [&](uint32_t stage) { if (h->dbg_marks) hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, st, h->dbg_marks + 1, call_base + stage); };
+    // stage timing (fmi_dev_agg_timing; measurement passes only): an event after every stage of this call
+    const bool timing = h->agg_timing_enabled && h->agg_calls.size() < 64;
+    size_t ev_base = 0;
+    int ev_next = 0;
+    if (timing) {
+        ev_base = h->agg_events.size();
+        for (int i = 0; i <= FMI_AGG_STAGES; i++) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->agg_events.push_back((void *)e); }
+    }
+    auto stage_done = [&]() { if (timing && ev_next <= FMI_AGG_STAGES) (void)hipEventRecord((hipEvent_t)h->agg_events[ev_base + ev_next++], st); };
     mark(1);
     HIPCHK(hipMemsetAsync(d_out, 0, L.fixed_bytes, st));
     HIPCHK(hipMemsetAsync(w.top_cnt, 0, nq * 4, st));
@@ -870,27 +879,34 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
         uint64_t *ka = w.k0, *kb = w.k1;
         uint32_t *va = w.v0, *vb = w.v1;
         mark(2);
+        stage_done();                    // [start]
         hipLaunchKernelGGL(k_agg_locate, dim3(blocks_for(N, 256)), dim3(256), 0, st, h->dev, v, w.occ_rk, w.doc, ka, va);
         mark(3);
+        stage_done();                    // 0: k_agg_locate
         if ((rc = sort_pairs(w, ka, kb, va, vb, N, FMI_AGG_POS_BITS + bits_for(nq - 1), st))) return rc;
         mark(4);
+        stage_done();                    // 1: sort by (query, position)
         hipLaunchKernelGGL(k_mis_prepare, dim3(blocks_for(N, 256)), dim3(256), 0, st, v, va, w.occ_rk, w.M, w.state);
         hipLaunchKernelGGL(k_mis, dim3(blocks_for(N, MIS_CHUNK)), dim3(256), 0, st, ka, w.M, va, w.state, w.newflag, (uint32_t)N, (uint32_t)H.max_key_len,
                            w.pool_cursor + 4);
         mark(5);
+        stage_done();                    // 2: coverage (k_mis_prepare + k_mis)
         hipLaunchKernelGGL(k_doc_keys, dim3(blocks_for(N, 256)), dim3(256), 0, st, v, w.occ_rk, w.doc, ka, va);
         if ((rc = sort_pairs(w, ka, kb, va, vb, N, 32 + bits_for(nq - 1), st))) return rc;
         mark(6);
+        stage_done();                    // 3: k_doc_keys + sort by (query, document)
         hipLaunchKernelGGL(k_heads, dim3(blocks_for(N, 256)), dim3(256), 0, st, ka, w.head, N);
         size_t tb = w.rp_bytes;
         HIPCHK(rocprim::exclusive_scan(w.rp_tmp, tb, w.head, w.eid, 0u, N, rocprim::plus<uint32_t>(), st));
         mark(7);
         hipLaunchKernelGGL(k_entry_starts, dim3(blocks_for(N, 256)), dim3(256), 0, st, w.head, w.eid, w.estart, w.n_entries, N);
         const uint32_t cover_words = (uint32_t)((H.max_u + 31) / 32) + 1;
+        stage_done();                    // 4: entry boundaries (k_heads, scan, k_entry_starts)
         hipLaunchKernelGGL(k_entries, dim3((unsigned)std::min<uint64_t>(blocks_for(N, 4), 4096)), dim3(256), 4 * cover_words * 4, st, v, ka, va,
                            w.estart, w.n_entries, w.occ_rk, w.newflag, allow_overlaps, beta, single_key, cover_words, w.ckey, w.cscore,
                            w.ent_nkeys, w.ent_rank, w.ent_first, w.ent_q, w.ent_doc, w.ent_score, w.ent_best);
         mark(8);
+        stage_done();                    // 5: k_entries
         // ---- ranking: stable sorts by first touch, then rank key, then query = sorted(first_stage.items(), key=...) ----
         uint32_t *fa = w.ent_first, *fb = w.tmp32;
         va = w.v0; vb = w.v1;
@@ -908,6 +924,9 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
         hipLaunchKernelGGL(k_top_docs, dim3(nq), dim3(256), 0, st, qa, va, w.ent_doc, N, nq, (uint32_t)n_top, w.ent_score, w.top_doc, w.top_ent, w.top_cnt,
                            L.o.fs_doc, L.o.fs_score, L.o.fs_cnt);
         mark(12);
+        stage_done();                    // 6: ranking (three stable sorts + k_top_docs)
+    } else if (timing) {
+        for (int i = 0; i < 8; i++) stage_done();
     }
     // ---- full scoring ----
     HIPCHK(hipMemsetAsync(w.type_dense, 0, (uint64_t)nq * H.vocab * 8, st));
@@ -930,17 +949,72 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
     ScoreOut so = L.o;
     so.stage_id = w.stage_id; so.stage_score = w.stage_score;
     p.per_q = (uint32_t)n_top;
+    stage_done();                        // 7: per-query token tables (memsets + scatters)
     hipLaunchKernelGGL(k_full_score<false>, dim3(blocks_for((uint64_t)nq * n_top, 4)), dim3(256), lds_bytes, st, h->dev, v, p, w.top_doc, w.top_cnt,
                        (const uint32_t *)nullptr, w.type_dense, w.tok2local, w.scores, so, pool);
     mark(13);
+    stage_done();                        // 8: k_full_score over the ranked documents
     if (n_top * 8 > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)k_rank_docs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(n_top * 8)));
     hipLaunchKernelGGL(k_rank_docs, dim3(nq), dim3(1024), n_top * 8, st, w.scores, w.top_cnt, (uint32_t)n_top, w.order);
     mark(14);
+    stage_done();                        // 9: k_rank_docs
     p.per_q = (uint32_t)keep;
     hipLaunchKernelGGL(k_full_score<true>, dim3(blocks_for((uint64_t)nq * keep, 4)), dim3(256), lds_bytes, st, h->dev, v, p, w.top_doc, w.top_cnt,
                        w.order, w.type_dense, w.tok2local, w.scores, so, pool);
     mark(15);
+    stage_done();                        // 10: k_full_score again over the caller's top-k (records what goes back)
     HIPCHK(hipGetLastError());
+    if (timing) {
+        // what the stages processed (read back: this is a measurement pass)
+        HIPCHK(hipStreamSynchronize(st));
+        uint32_t ne = 0;
+        std::vector<uint32_t> cnt(nq);
+        if (N) HIPCHK(hipMemcpy(&ne, w.n_entries, 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(cnt.data(), w.top_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost));
+        fmi::AggCall c{N, ne, 0, 0, 0};
+        std::vector<uint32_t> docs((size_t)nq * n_top);
+        HIPCHK(hipMemcpy(docs.data(), w.top_doc, docs.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t q = 0; q < nq; q++) {
+            const uint32_t m = std::min<uint32_t>(cnt[q], (uint32_t)n_top);
+            c.docs_scored += m; c.docs_kept += std::min<uint64_t>(m, keep);
+            for (uint32_t j = 0; j < m; j++) {
+                const uint32_t d = docs[(size_t)q * n_top + j];
+                if ((uint64_t)d + 1 < h->doc_begin.size()) c.doc_tokens += h->doc_begin[d + 1] - h->doc_begin[d];
+            }
+        }
+        h->agg_calls.push_back(c);
+    }
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_agg_timing(fmi_t *h, int enable)
+{
+    if (!h) { fmi_set_error("null handle"); return FMI_ERR_ARG; }
+    for (void *e : h->agg_events) (void)hipEventDestroy((hipEvent_t)e);
+    h->agg_events.clear(); h->agg_calls.clear();
+    h->agg_timing_enabled = enable;
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_read_agg_timing(fmi_t *h, double *stage_ms, uint64_t *counts, uint64_t *calls_out)
+{
+    if (!h || !stage_ms || !counts || !calls_out) { fmi_set_error("null argument"); return FMI_ERR_ARG; }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    for (int i = 0; i < FMI_AGG_STAGES; i++) stage_ms[i] = 0.0;
+    for (int i = 0; i < 5; i++) counts[i] = 0;
+    for (size_t c = 0; c < h->agg_calls.size(); c++) {
+        for (int i = 0; i < FMI_AGG_STAGES; i++) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, (hipEvent_t)h->agg_events[c * (FMI_AGG_STAGES + 1) + i], (hipEvent_t)h->agg_events[c * (FMI_AGG_STAGES + 1) + i + 1]));
+            stage_ms[i] += ms;
+        }
+        const fmi::AggCall &a = h->agg_calls[c];
+        counts[0] += a.rows; counts[1] += a.entries; counts[2] += a.docs_scored; counts[3] += a.docs_kept; counts[4] += a.doc_tokens;
+    }
+    *calls_out = h->agg_calls.size();
+    for (void *e : h->agg_events) (void)hipEventDestroy((hipEvent_t)e);
+    h->agg_events.clear(); h->agg_calls.clear();
     return FMI_OK;
 }

@@ -63,6 +63,7 @@ int FmiOptions::set(const char *name, int64_t value)
     else if (s == "table_grid") table_grid = value;
     else if (s == "topk_narrow") topk_narrow = value;
     else if (s == "topk_legacy") topk_legacy = value < 0 ? 0 : value;
+    else if (s == "pt_inject_failure") pt_inject_failure = value < 0 ? 0 : value;
     else return -1;
     return 0;
 }
@@ -112,7 +113,9 @@ void fmi_release_device(fmi *h)
         if (h->service_stream) (void)hipStreamDestroy((hipStream_t)h->service_stream);
         for (void *e : h->ev_start) (void)hipEventDestroy((hipEvent_t)e);
         for (void *e : h->ev_stop) (void)hipEventDestroy((hipEvent_t)e);
+        for (void *e : h->agg_events) (void)hipEventDestroy((hipEvent_t)e);
     }
+    h->agg_events.clear(); h->agg_calls.clear(); h->call_log.clear();
     h->service_stream = nullptr;
     h->ev_start.clear(); h->ev_stop.clear(); h->ev_used = 0; h->timing_enabled = 0;
     h->dev_allocs.clear();

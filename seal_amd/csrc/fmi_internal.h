@@ -72,6 +72,7 @@ struct FmiOptions {
     int64_t table_grid = -1;        // SEALFM_TABLE_GRID=<n>: workgroups of k_constrain_table (default 1024: one resident round)
     int64_t topk_narrow = -1;       // SEALFM_TOPK_NARROW=<n>: rows of more than n allowed tokens take the wide-row path of k_row_pick
     int64_t topk_legacy = 0;        // SEALFM_TOPK_LEGACY=1: wide rows skip the thread-maxima bound (exact radix select)
+    int64_t pt_inject_failure = 0;  // tests: building a prefix table fails after its first allocation (the call must take the generic path)
     FmiOptions();
     int set(const char *name, int64_t value);      // 0, or -1 for an unknown name
 };
@@ -133,6 +134,18 @@ struct fmi {
     int timing_enabled = 0;
     std::vector<void *> ev_start, ev_stop;   // hipEvent_t
     uint64_t ev_used = 0;
+    // per-call log of the constraint calls (fmi_dev_call_log): which call (prefix length, rows, launch form), its event time
+    // (timing mode) or the blocks its launches loaded (counting mode: read back after every call)
+    struct CallRec { uint32_t cur_len, rows, kind; int64_t ev; uint64_t blocks; };
+    std::vector<CallRec> call_log;
+    int call_log_enabled = 0;
+    uint64_t probe_accum[4] = {0, 0, 0, 0};      // counters drained per call, not yet handed to fmi_dev_read_probe_count / _expand_stats
+    // stage timing of fmi_dev_aggregate (fmi_dev_agg_timing): per call FMI_AGG_STAGES + 1 events on the call's stream, the located
+    // rows / document entries / scored documents of the call (a measurement pass: the entry count is read back after the call)
+    int agg_timing_enabled = 0;
+    std::vector<void *> agg_events;             // hipEvent_t, (FMI_AGG_STAGES + 1) per logged call
+    struct AggCall { uint64_t rows, entries, docs_scored, docs_kept, doc_tokens; };
+    std::vector<AggCall> agg_calls;
     // non-blocking stream of the host-buffer API (fmi_<op>): its copies/kernels neither wait for nor
     // stall the caller's (torch's) streams; index arrays are immutable so there is nothing to order
     void *service_stream = nullptr;

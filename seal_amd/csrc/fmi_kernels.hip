@@ -1449,10 +1449,71 @@ static int read_probe_slots(fmi *h, uint64_t out3[4], bool reset)
     HIPCHK(hipDeviceSynchronize());
     std::vector<uint64_t> slots(PROBE_SLOTS * 8);
     HIPCHK(hipMemcpy(slots.data(), h->d_probe_counter, PROBE_SLOTS * 64, hipMemcpyDeviceToHost));
-    out3[0] = out3[1] = out3[2] = out3[3] = 0;
+    for (int e = 0; e < 4; e++) out3[e] = h->probe_accum[e];      // what the per-call log drained since the last read
     for (uint32_t i = 0; i < PROBE_SLOTS; i++)
         for (int e = 0; e < 4; e++) out3[e] += slots[i * 8 + e];
-    if (reset) HIPCHK(hipMemset(h->d_probe_counter, 0, PROBE_SLOTS * 64));
+    if (reset) {
+        HIPCHK(hipMemset(h->d_probe_counter, 0, PROBE_SLOTS * 64));
+        for (int e = 0; e < 4; e++) h->probe_accum[e] = 0;
+    }
+    return FMI_OK;
+}
+
+// the per-call log: one record per constraint call since it was switched on.  Timing mode (fmi_dev_enable_timing): the record names
+// the call's event pair; counting mode (fmi_dev_enable_probe_count): the stream is drained after the call and the blocks its launches
+// loaded are read back (a measurement pass: it serialises the calls)
+static void call_log_begin(fmi *h, uint32_t kind, uint64_t cur_len, uint64_t rows, bool timed)
+{
+    if (!h->call_log_enabled) return;
+    fmi::CallRec r{(uint32_t)cur_len, (uint32_t)rows, kind, timed ? (int64_t)h->ev_used : -1, 0};
+    h->call_log.push_back(r);
+}
+
+static int call_log_end(fmi *h, hipStream_t st)
+{
+    if (!h->call_log_enabled || !h->probe_count_enabled || !h->d_probe_counter || h->call_log.empty()) return FMI_OK;
+    HIPCHK(hipStreamSynchronize(st));
+    uint64_t slots[PROBE_SLOTS * 8];
+    HIPCHK(hipMemcpy(slots, h->d_probe_counter, PROBE_SLOTS * 64, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->d_probe_counter, 0, PROBE_SLOTS * 64));
+    uint64_t v[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < PROBE_SLOTS; i++)
+        for (int e = 0; e < 4; e++) v[e] += slots[i * 8 + e];
+    for (int e = 0; e < 4; e++) h->probe_accum[e] += v[e];
+    h->call_log.back().blocks = v[0];
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_call_log(fmi_t *h, int enable)
+{
+    if (!h) { fmi_set_error("null handle"); return FMI_ERR_ARG; }
+    h->call_log_enabled = enable;
+    h->call_log.clear();
+    return FMI_OK;
+}
+
+extern "C" int fmi_dev_read_call_log(fmi_t *h, uint64_t cap, uint32_t *cur_len, uint32_t *rows, uint32_t *kind, float *us, uint64_t *blocks,
+                                     uint64_t *n_out)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (!n_out) { fmi_set_error("null n_out"); return FMI_ERR_ARG; }
+    HIPCHK(hipDeviceSynchronize());
+    const uint64_t n = std::min<uint64_t>(cap, h->call_log.size());
+    for (uint64_t i = 0; i < n; i++) {
+        const fmi::CallRec &r = h->call_log[i];
+        if (cur_len) cur_len[i] = r.cur_len;
+        if (rows) rows[i] = r.rows;
+        if (kind) kind[i] = r.kind;
+        if (blocks) blocks[i] = r.blocks;
+        if (us) {
+            float ms = -1.0f;
+            if (r.ev >= 0 && (uint64_t)r.ev < h->ev_start.size() && (uint64_t)r.ev < h->ev_used)
+                HIPCHK(hipEventElapsedTime(&ms, (hipEvent_t)h->ev_start[r.ev], (hipEvent_t)h->ev_stop[r.ev]));
+            us[i] = ms < 0 ? -1.0f : ms * 1000.0f;
+        }
+    }
+    *n_out = h->call_log.size();
+    h->call_log.clear();
     return FMI_OK;
 }
 
@@ -1685,7 +1746,26 @@ __global__ void k_pt_offsets(const uint32_t *owner, uint64_t n, uint64_t vocab, 
 
 static constexpr uint64_t PT_MAX_NODES = 1ull << 28;      // 4 GiB of packed nodes: beyond that the generic path serves the prefix
 
+static int build_prefix_table_impl(fmi *h, FmiPrefixTable &T);
+
+// A table is an optimisation: the generic expansion serves every prefix without one and needs no extra memory.  So whatever goes wrong
+// while building -- an allocation on an index sized to HBM, a scan -- leaves "no table" (T.ok = false, partial buffers freed, the HIP
+// error state cleared), never a failed constraint call.
 static int build_prefix_table(fmi *h, FmiPrefixTable &T)
+{
+    const int rc = build_prefix_table_impl(h, T);
+    if (rc != FMI_OK || !T.ok) {
+        (void)hipDeviceSynchronize();
+        if (T.d_root) (void)hipFree(T.d_root);
+        if (T.d_nodes) (void)hipFree(T.d_nodes);
+        if (T.d_off) (void)hipFree(T.d_off);
+        T.d_root = nullptr; T.d_nodes = nullptr; T.d_off = nullptr; T.n_nodes = 0; T.ok = false;
+        (void)hipGetLastError();
+    }
+    return FMI_OK;
+}
+
+static int build_prefix_table_impl(fmi *h, FmiPrefixTable &T)
 {
     // (runs once per index and forced prefix, on the null stream, synchronously: allocation + a few passes; milliseconds at NQ size)
     const uint64_t V = T.vocab;
@@ -1695,6 +1775,7 @@ static int build_prefix_table(fmi *h, FmiPrefixTable &T)
     DevBuf flag, offs, tmp;
     int rc;
     HIPCHK(hipMalloc((void **)&T.d_root, V * 16));
+    if (h->opt.pt_inject_failure) { fmi_set_error("prefix table: injected failure"); return FMI_ERR_HIP; }
     if ((rc = flag.alloc((V + 1) * 4)) || (rc = offs.alloc((V + 1) * 8))) return rc;
     HIPCHK(hipMemsetAsync(flag.p, 0, (V + 1) * 4, 0));             // (the scan runs over V + 1 flags: the last one stays 0)
     hipLaunchKernelGGL(k_pt_roots, dim3(blocks_for(V, 256)), dim3(256), 0, 0, h->dev, ff, T.shift, V, T.d_root, flag.as<uint32_t>());
@@ -1705,9 +1786,9 @@ static int build_prefix_table(fmi *h, FmiPrefixTable &T)
     uint64_t n = 0;
     HIPCHK(hipMemcpy(&n, offs.as<uint64_t>() + V, 8, hipMemcpyDeviceToHost));
     PtNode *cur = nullptr, *nxt = nullptr;
-    HIPCHK(hipMalloc((void **)&cur, std::max<uint64_t>(n, 1) * sizeof(PtNode)));
+    if (hipMalloc((void **)&cur, std::max<uint64_t>(n, 1) * sizeof(PtNode)) != hipSuccess) { fmi_set_error("prefix table: hipMalloc failed"); return FMI_ERR_HIP; }
     hipLaunchKernelGGL(k_pt_root_nodes, dim3(blocks_for(V, 256)), dim3(256), 0, 0, (const uint64_t *)T.d_root, flag.as<uint32_t>(), offs.as<uint64_t>(), V, h->n, cur);
-    auto fail = [&](int code) { if (cur) (void)hipFree(cur); if (nxt) (void)hipFree(nxt); return code; };
+    auto fail = [&](int code) { if (cur) (void)hipFree(cur); if (nxt) (void)hipFree(nxt); cur = nxt = nullptr; return code; };
     for (uint32_t k = 0; k + 1 < h->dlevels && n; k++) {
         DevBuf cnt, off2, tmp2;
         if ((rc = cnt.alloc((n + 1) * 4)) || (rc = off2.alloc((n + 1) * 8))) return fail(rc);
@@ -2070,8 +2151,9 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
                                a, (const uint32_t *)buf[cur], h->sym_row_words, buf[oth], (uint32_t)oth_rows);
             h->sym_dirty_rows[cur] = rows; h->sym_dirty_rows[oth] = 0;
             HIPCHK(hipGetLastError());
+            call_log_begin(h, FMI_CALL_TABLE, cur_len, rows, timed);
             if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
-            return FMI_OK;
+            return call_log_end(h, st);
         }
     }
     // Row-first: once the prefixes are a few tokens long, nine of ten (row, top digit) items are empty and a call is the chain of
@@ -2097,8 +2179,9 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
                                                 : (sb ? k_constrain<true, 1> : k_constrain<false, 1>);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds, st, h->dev, a);
     HIPCHK(hipGetLastError());
+    call_log_begin(h, row_first ? FMI_CALL_ROW_FIRST : FMI_CALL_GENERIC, cur_len, rows, timed);
     if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
-    return FMI_OK;
+    return call_log_end(h, st);
 }
 
 extern "C" int fmi_dev_allowed_bits(fmi_t *h, void *stream, uint64_t rows, uint64_t cur_len, const int64_t *d_input_ids,

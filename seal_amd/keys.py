@@ -418,7 +418,9 @@ def _rescore_tree_jobs(model, jobs):
             a = b
     from . import split_gemm
     flag = split_gemm.flag_snapshot(device) if device.type == "cuda" else None     # read with the scores: activations beyond fp16's range?
-    return [_PendingRescore(j["totals"], j["scores"], j["decoded"], j["lp"], flag if ji == 0 else None, device) for ji, j in enumerate(J)]
+    # the snapshot rides with the FIRST job that has scores to read back (a job without totals never looks at it)
+    first = next((ji for ji, j in enumerate(J) if j["totals"]), None)
+    return [_PendingRescore(j["totals"], j["scores"], j["decoded"], j["lp"], flag if ji == first else None, device) for ji, j in enumerate(J)]
 
 
 class _PendingRescore:

@@ -626,6 +626,11 @@ class SEALSearcher:
         # extension: enqueue the next batch's decodes before this batch's rescoring / aggregation (same thread, second stream)
         self.overlap: bool = bool(params.get("overlap", True))
         self.overlap_depth: int = int(params.get("overlap_depth", 2))     # batches of decodes kept enqueued ahead
+        if params.get("pipeline"):
+            # round 3's `pipeline=N` (N batches in flight on worker threads, one stream each) is gone: several GEMM streams at once are what
+            # stalled the GPU; it must not be ignored silently
+            raise ValueError("SEALSearcher(pipeline=N) was removed in round 4 (several library-GEMM streams at once can stall the GPU): "
+                             "use overlap=True / overlap_depth (the default) instead")
         # the decode and the rescoring phase (the two that run library GEMMs) ALTERNATE on the GPU instead of sharing it: two stream-K
         # GEMM streams in flight at once stalled the GPU for ever.  False restores round 3's behaviour.
         self.exclusive_gemm_streams: bool = bool(params.get("exclusive_gemm_streams", True))

@@ -88,7 +88,9 @@ def check_snapshot(host, device=None) -> None:
     if host is None:
         return
     n = int(host[0])
-    key = str(device)
+    key = str(torch.device(device)) if device is not None else "None"
+    if n < _seen.get(key, 0):
+        _seen[key] = 0                                # the device counter was reset behind our back (overflowed())
     if n > _seen.get(key, 0):
         _seen[key] = n
         raise RuntimeError(f"split GEMM: {n} groups of activations beyond fp16's range (|x| > 65504) were seen; the scores of this call are "
@@ -102,6 +104,7 @@ def overflowed(device) -> int:
         return 0
     n = int(f.item())
     f.zero_()
+    _seen.pop(str(torch.device(device)), None)      # the counter restarts: so does what check_snapshot has reported already
     return n
 
 

@@ -163,6 +163,32 @@ def test_logits_processor_matches_reference_semantics(pair, form):
         _logits_processor_cases(ix, orc, docs, vocab)
 
 
+def test_a_prefix_table_that_cannot_be_built_leaves_the_generic_path():
+    """building a per-token node table (lazily, inside the first constrained step of a decode) may fail -- an allocation on an index
+    sized to HBM: the call is then served by the generic expansion, which needs no extra memory, not failed (round-4 advisor finding)"""
+    import ctypes
+    from oracle.seal_oracle import OracleFMIndex
+    from seal_amd import FMIndex
+    from seal_amd._lib import check, lib
+    from tests.helpers import kernel_options, make_docs
+    vocab = 90
+    docs = make_docs(21, 120, vocab)
+    ix, orc = FMIndex(), OracleFMIndex()
+    ix.initialize(docs)
+    orc.initialize(docs)
+    with kernel_options(ix, pt_inject_failure=1):
+        _logits_processor_cases(ix, orc, docs, vocab)
+        t, n, b = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        check(lib().fmi_dev_prefix_table_stats(ix.handle, ctypes.byref(t), ctypes.byref(n), ctypes.byref(b)))
+        assert t.value == 0
+    ix2 = FMIndex()
+    ix2.initialize(docs)
+    _logits_processor_cases(ix2, orc, docs, vocab)          # (and with the tables: the same masks)
+    t = ctypes.c_uint64()
+    check(lib().fmi_dev_prefix_table_stats(ix2.handle, ctypes.byref(t), None, None))
+    assert t.value > 0
+
+
 def _logits_processor_cases(ix, orc, docs, vocab):
     import torch
     from oracle.beam_oracle import oracle_logits_mask
