@@ -265,7 +265,13 @@ def parity_check(index, trace, answers, vocab=VOCAB, locate_stride=1):
         if op[0] == "mask":
             ids, ff, kw = op[1], op[2], op[3]
             assert kw["stop_at_count"] == 0 and not kw["always_allow_eos"]
-            got = gpu_allowed_bits(index, ids, ff, kw, vocab)
+            if len(op) > 4 and op[4] is not None:
+                # the bitmap the decode step ACTUALLY applied (fmi_dev_last_constraint_bits: table / chained / generic form alike)
+                got = op[4].cpu().numpy().view(np.uint32)
+                applied = detail.setdefault("allowed_token_sets", {"ops": 0, "values": 0, "mismatches": 0})
+                applied["source"] = "the bitmaps the timed path's constraint calls filled (captured per step), not a recomputation"
+            else:
+                got = gpu_allowed_bits(index, ids, ff, kw, vocab)
             live, bits, k = ans
             want = np.zeros_like(got)
             want[:, kw["pad"] >> 5] |= np.uint32(1 << (kw["pad"] & 31))       # finished rows: only pad (beam_search.py:119-127)
@@ -457,7 +463,7 @@ def cite_traffic(workload_tag, root=ROOT, now=None):
     return traffic, traffic_src
 
 
-CALL_FORMS = {0: "generic", 1: "row_first", 2: "table", 3: "chained"}
+CALL_FORMS = {0: "generic", 1: "row_first", 2: "table", 3: "chained", 4: "advance", 5: "advance+chains"}
 
 
 def read_call_log(handle, cap=4096):
@@ -471,17 +477,35 @@ def read_call_log(handle, cap=4096):
 
 
 def merge_call_logs(timed, counted):
-    """the timing pass and the counting pass ran the same batch: the same calls in the same order.  One record per call with both figures;
-    [] when the two passes disagree about what was launched (then neither is attributed)"""
+    """the timing pass and the counting pass ran the same batch: the same launches in the same order.  One record per CONSTRAINT call with
+    both figures; the k_beam_advance launch that ran the rows' chains of a call a model step ahead of it ("advance+chains", logged under
+    that call's cur_len) is added to the call -- its whole duration, the beam bookkeeping that shares the launch included -- and its blocks
+    too; a k_beam_advance without chains is not index work and is listed apart.  [] when the two passes disagree about what was launched."""
     if not timed or len(timed) != len(counted) or any((a["cur_len"], a["rows"], a["form"]) != (b["cur_len"], b["rows"], b["form"]) for a, b in zip(timed, counted)):
-        return []
-    out = []
+        return [], []
+    calls, other = [], []
+    pending = None                       # the advance record waiting for the call it prepared
     for a, b in zip(timed, counted):
-        mb = b["blocks"] * 128.0 / 1e6
-        us = a["us"]
-        out.append({"cur_len": a["cur_len"], "rows": a["rows"], "form": a["form"], "MB": round(mb, 3), "us": round(us, 2),
-                    "GBps": round(mb * 1e6 / (us * 1e-6) / 1e9, 1) if us > 0 else None, "frac": round(mb * 1e6 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if us > 0 else None})
-    return out
+        rec = {"cur_len": a["cur_len"], "rows": a["rows"], "form": a["form"], "MB": b["blocks"] * 128.0 / 1e6, "us": a["us"]}
+        if a["form"] == "advance+chains":
+            pending = rec
+            continue
+        if a["form"] == "advance":
+            other.append({"cur_len": a["cur_len"], "rows": a["rows"], "form": a["form"], "us": round(a["us"], 2)})
+            continue
+        if pending is not None and pending["cur_len"] == rec["cur_len"]:
+            rec["chains_us"] = round(pending["us"], 2)
+            rec["chains_MB"] = round(pending["MB"], 3)
+            rec["us"] += pending["us"]
+            rec["MB"] += pending["MB"]
+        pending = None
+        calls.append(rec)
+    for c in calls:
+        us, mb = c["us"], c["MB"]
+        c["MB"], c["us"] = round(mb, 3), round(us, 2)
+        c["GBps"] = round(mb * 1e6 / (us * 1e-6) / 1e9, 1) if us > 0 else None
+        c["frac"] = round(mb * 1e6 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if us > 0 else None
+    return calls, other
 
 
 AGG_STAGES = ["k_agg_locate", "sort_by_position(rocprim)", "coverage(k_mis_prepare+k_mis)", "k_doc_keys+sort_by_document(rocprim)",
@@ -953,6 +977,12 @@ def main():
     # event pair then also brackets the time its launch waits behind their dispatches -- 71 us there against 34.7 us of
     # execution in the rocprofv3 trace of the very same launches (profiles/r2_kernel_stats.csv).  The timed region's own
     # event figure is kept beside it (`timed_region_event_us`).
+    by_call, other_launches = merge_call_logs(calls_timed, calls_counted)
+    if by_call:
+        # a constraint call = its own launches + the chains k_beam_advance ran for it a model step earlier (by_call adds them); the
+        # advance launches without chains (the steps in front of a table call) are the beam loop's bookkeeping, not index work
+        k2 = C.c_double(sum(c["us"] for c in by_call) * 1e-3)
+        l2 = C.c_uint64(len(by_call))
     n2 = max(1, l2.value)
     achieved = (p2.value * 128.0) / (k2.value * 1e-3) / 1e9 if k2.value > 0 else 0.0
     # SURVEY.md §8(d) prices the same work on the reference-shaped structure (binary wavelet tree, one
@@ -965,10 +995,10 @@ def main():
     # FETCH_SIZE counts 128-byte requests at 64 bytes on gfx950 (MI355X guide; tools/gather_calib.hip): x 2.
     traffic, traffic_src = cite_traffic(workload_tag)
     nl = n2
-    roofline = {"bound": "hbm", "kernel": "k_constrain (one constraint call for the rows of both decodes: k_constrain_rows -- one wave per row: prefix "
-                                          "range, class, root node split -- then k_constrain -- one wave per (row, top digit), the sub-trees level by level "
-                                          "by workgroups of 8 waves; the FIRST call of a decode instead k_constrain_table -- the leaf-level nodes of every row "
-                                          "from the per-token tables as one evenly cut list -- then k_table_bits; events bracket the call)",
+    roofline = {"bound": "hbm", "kernel": "k_constrain (one constraint call for the rows of both decodes: the rows' chains -- kept range -> one backward-search step -> class "
+                                          "-> root node split -- run by the previous step's k_beam_advance, one wave per row, then k_constrain -- one wave per (row, top digit), "
+                                          "the sub-trees level by level by workgroups of 8 waves; the FIRST call of a decode instead k_constrain_table -- the leaf-level nodes "
+                                          "of every row from the per-token tables as one evenly cut list -- then k_table_bits; events bracket every launch)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic, "traffic_source": traffic_src, "launches": int(l2.value), "avg_launch_us": round(k2.value * 1e3 / n2, 2),
                 "algorithmic_bytes_per_launch": round(p2.value * 128.0 / n2, 1),
@@ -980,13 +1010,15 @@ def main():
                                     "note": "binary 16-level wavelet tree, 64 B per level-probe, same symbols emitted"},
                 "wave_iterations_per_launch": round(xstats[1] / nl, 1), "lane_pair_utilisation": round(xstats[2] / max(1, 32 * xstats[1]), 3)}
 
-    by_call = merge_call_logs(calls_timed, calls_counted)
     if by_call:
         roofline["by_call"] = by_call
+        roofline["advance_launches_without_chains"] = other_launches
         roofline["widest_call"] = max(by_call, key=lambda c: c["MB"])
         roofline["by_call_note"] = ("one record per constraint call of ONE batch, in launch order: us = HIP events around the call in the un-overlapped timing "
                                     "pass, MB = 128-byte blocks its launches loaded in the counting pass of the same batch; frac = MB / us / 8 TB/s; "
-                                    "form: table = k_constrain_table + k_table_bits, row_first = k_constrain_rows + k_constrain, generic = k_constrain")
+                                    "form: table = k_constrain_table + k_table_bits, row_first = k_constrain_rows + k_constrain, generic = k_constrain, chained = "
+                                    "k_constrain started from the chains that the previous step's k_beam_advance ran (chains_us / chains_MB: that launch, whole, "
+                                    "added to the call)")
     roofline_aggregate = aggregate_roofline(agg_timing, index)
 
     cpu = parity = None

@@ -310,6 +310,57 @@ int fmi_dev_read_expand_stats(fmi_t *h, uint64_t *out4);
 int fmi_dev_enable_timing(fmi_t *h, int enable);
 int fmi_dev_read_timing(fmi_t *h, uint64_t *launches_out, double *total_ms_out);
 
+/* ---- one decode step of the beam loop behind the model's forward -----------------------------------------------
+ * reference seal/beam_search.py:244-332 (log-softmax, processors, top-2K on the constrained scores carrying the unconstrained
+ * ones, next_indices / next_tokens) + BeamSearchScorerWithMemory.process (:614-700: every ranked candidate recorded, the
+ * first num_beams non-eos candidates continue) + input_ids = cat(input_ids[beam_idx], beam_next_tokens) + _reorder_cache,
+ * for the stacked rows of up to three decodes in lockstep (group g = the next group_batch[g] queries: own eos, forced prefix,
+ * stop_at_count), as fmi_dev_constrained_topk_groups + ONE more launch (k_beam_advance) that also runs, for every NEW row,
+ * the dependent chain of the NEXT step's constraint (kept range of its source row -> one backward-search step with its token
+ * -> class -> root node split; `chain_next`), so that the next call of the same `state_tag` starts at the sub-trees.
+ * All pointers are device pointers; nothing is allocated or synchronised.
+ *   d_ids          [rows][ids_stride] int64: the rows' tokens, cur_len of each used; rewritten in place to cur_len + 1
+ *   d_beam_scores  [rows] in: of the rows; out: of the new rows        d_beam_idx [rows] out: source row of every new row
+ *   d_tokens_out   [rows] or null: the new rows' last tokens (the decoder's next input)
+ *   d_anc          null, or the decoder's ancestry table [anc_positions][anc_rows] int32: column r' := column source(r')
+ *   d_hist_tok[g]  null, or [group_batch[g]][hist_H[g]][hist_L[g]] int64 (-1-filled by the caller): candidate c of the step is
+ *                  written at hypothesis slot hist_off + c (its source row's tokens, then its token); d_hist_sc[g] [batch][H] f32
+ *   d_top_*        [batch][2 * beams] scratch outputs of the merge (kept: tests)
+ *   dropped_rows   rows that left the FRONT of the loop since the previous step of this state_tag (a decode that ended)      */
+typedef struct fmi_beam_step {
+    uint64_t struct_bytes;           /* sizeof(fmi_beam_step_t) */
+    uint64_t n_groups;
+    uint64_t group_batch[3];
+    int64_t group_eos[3];
+    int64_t group_force[3][8];
+    uint64_t group_n_force[3];
+    int64_t group_stop[3];
+    uint64_t beams, cur_len, vocab;
+    int64_t shift, pad_id;
+    int32_t always_allow_eos, chain_next;
+    int64_t *d_ids;
+    uint64_t ids_stride;
+    const float *d_logits;
+    float *d_beam_scores;
+    const uint32_t *d_first_bits;
+    void *d_scratch;
+    uint64_t scratch_bytes;
+    int64_t *d_top_idx;
+    float *d_top_con, *d_top_unc;
+    int64_t *d_beam_idx, *d_tokens_out;
+    int32_t *d_anc;
+    uint64_t anc_rows, anc_positions;
+    int64_t *d_hist_tok[3];
+    float *d_hist_sc[3];
+    uint64_t hist_H[3], hist_L[3], hist_off;
+    uint64_t state_tag, dropped_rows;
+} fmi_beam_step_t;
+int fmi_dev_beam_step(fmi_t *h, void *stream, const fmi_beam_step_t *step);
+/* the allowed-token bitmap the last constraint call of this handle filled ([rows][words_per_row] uint32, device memory owned by the
+ * handle, valid until the next call; null after a cur_len == 1 step): tests and bench.py's parity check read the masks that were
+ * actually applied (table / chained / generic form alike) instead of recomputing them */
+const uint32_t *fmi_dev_last_constraint_bits(fmi_t *h, uint64_t *rows_out, uint64_t *words_per_row_out);
+
 /* Per-call log of the constraint calls (bench.py's `roofline.by_call`): while enabled, every call of the
  * fmi_dev_allowed_bits* / fmi_dev_constrain_scores / fmi_dev_constrained_topk* family appends one record -- prefix length
  * (cur_len), rows, launch form (FMI_CALL_*) -- which names its HIP-event pair when fmi_dev_enable_timing is on, and, when
@@ -319,6 +370,9 @@ int fmi_dev_read_timing(fmi_t *h, uint64_t *launches_out, double *total_ms_out);
 #define FMI_CALL_GENERIC 0   /* k_constrain alone */
 #define FMI_CALL_ROW_FIRST 1 /* k_constrain_rows + k_constrain */
 #define FMI_CALL_TABLE 2     /* k_constrain_table + k_table_bits (first constrained step of a decode) */
+#define FMI_CALL_CHAINED 3   /* k_constrain alone, started from what the previous step's k_beam_advance left (fmi_dev_beam_step) */
+#define FMI_CALL_ADVANCE 4   /* k_beam_advance without / with (5) the chains of the call it precedes; cur_len = that call's */
+#define FMI_CALL_ADVANCE_CHAIN 5
 int fmi_dev_call_log(fmi_t *h, int enable);
 int fmi_dev_read_call_log(fmi_t *h, uint64_t cap, uint32_t *cur_len, uint32_t *rows, uint32_t *kind, float *us, uint64_t *blocks,
                           uint64_t *n_out);

@@ -15,6 +15,34 @@ _pi64 = ctypes.POINTER(ctypes.c_int64)
 _vp = ctypes.c_void_p
 _int = ctypes.c_int
 
+class FmiBeamStep(ctypes.Structure):
+    """``fmi_beam_step_t`` of include/sealfm.h (one decode step of the beam loop, fmi_dev_beam_step), field for field"""
+    _fields_ = [
+        ("struct_bytes", _u64), ("n_groups", _u64), ("group_batch", _u64 * 3), ("group_eos", _i64 * 3), ("group_force", (_i64 * 8) * 3),
+        ("group_n_force", _u64 * 3), ("group_stop", _i64 * 3), ("beams", _u64), ("cur_len", _u64), ("vocab", _u64), ("shift", _i64), ("pad_id", _i64),
+        ("always_allow_eos", ctypes.c_int32), ("chain_next", ctypes.c_int32), ("d_ids", _vp), ("ids_stride", _u64), ("d_logits", _vp),
+        ("d_beam_scores", _vp), ("d_first_bits", _vp), ("d_scratch", _vp), ("scratch_bytes", _u64), ("d_top_idx", _vp), ("d_top_con", _vp),
+        ("d_top_unc", _vp), ("d_beam_idx", _vp), ("d_tokens_out", _vp), ("d_anc", _vp), ("anc_rows", _u64), ("anc_positions", _u64),
+        ("d_hist_tok", _vp * 3), ("d_hist_sc", _vp * 3), ("hist_H", _u64 * 3), ("hist_L", _u64 * 3), ("hist_off", _u64),
+        ("state_tag", _u64), ("dropped_rows", _u64)]
+
+
+class _DeviceWords:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, True), "version": 2}
+
+
+def last_constraint_bits(handle, device):
+    """the allowed-token bitmap the handle's last constraint call filled, as an int32 tensor [rows, words_per_row] that ALIASES the
+    handle's workspace (clone it before the next call), or None (after a cur_len == 1 step: the constant first-step mask)"""
+    import torch
+    rows, wpr = _u64(), _u64()
+    p = lib().fmi_dev_last_constraint_bits(handle, ctypes.byref(rows), ctypes.byref(wpr))
+    if not p or not rows.value:
+        return None
+    return torch.as_tensor(_DeviceWords(p, rows.value * wpr.value), device=device).view(rows.value, wpr.value)
+
+
 # name -> (restype, argtypes); the list mirrors include/sealfm.h one to one
 SIGNATURES = {
     "fmi_last_error": (ctypes.c_char_p, []),
@@ -70,6 +98,8 @@ SIGNATURES = {
     "fmi_dev_read_expand_stats": (_int, [_vp, _p64]),
     "fmi_dev_enable_timing": (_int, [_vp, _int]),
     "fmi_dev_read_timing": (_int, [_vp, _p64, ctypes.POINTER(ctypes.c_double)]),
+    "fmi_dev_beam_step": (_int, [_vp, _vp, ctypes.POINTER(FmiBeamStep)]),
+    "fmi_dev_last_constraint_bits": (_vp, [_vp, _p64, _p64]),
     "fmi_dev_agg_timing": (_int, [_vp, _int]),
     "fmi_dev_read_agg_timing": (_int, [_vp, ctypes.POINTER(ctypes.c_double), _p64, _p64]),
     "fmi_dev_call_log": (_int, [_vp, _int]),

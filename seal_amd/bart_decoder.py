@@ -674,6 +674,16 @@ class BartStepDecoder:
             return
         self.kv[:, :, :, :, :self.t] = self.kv[:, :, beam_idx, :, :self.t]
 
+    def step_buffers(self):
+        """(token buffer, ancestry table) of the static fused decode state, for a caller that advances the beams on the device
+        (``fmi_dev_beam_step``): the next step's input tokens are written straight into the buffer ``step`` reads, and re-ranking the
+        beams permutes the columns of the table in the same launch.  (None, None) off the fused static path: ``step(tokens)`` +
+        ``reorder(beam_idx)`` as before."""
+        st = getattr(self, "_st", None)
+        if st is None or not st.fused:
+            return None, None
+        return st.tokens, st.anc
+
     @torch.no_grad()
     def step(self, tokens: torch.Tensor, beams_identical: bool = False) -> torch.Tensor:
         """tokens [rows] at decoder position ``self.t`` -> next-token logits [rows, vocab] (fp32).  ``beams_identical``: the
@@ -682,7 +692,8 @@ class BartStepDecoder:
         R, B, K, H, dh, t = self.rows, self.batch, self.beams, self.h, self.dh, self.t
         if getattr(self, "_st", None) is not None:
             st = self._st
-            st.tokens.copy_(tokens)
+            if tokens.data_ptr() != st.tokens.data_ptr():          # (fmi_dev_beam_step writes the next input where this step reads it)
+                st.tokens.copy_(tokens)
             if beams_identical and t == 0 and st.first_graph is not None:
                 st.first_graph.replay()
                 self.t += 1

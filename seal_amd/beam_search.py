@@ -131,6 +131,9 @@ class IndexBasedLogitsProcessor:
         return out if out.dtype == scores.dtype else out.to(scores.dtype)
 
 
+# the beam loop's bookkeeping between two model steps as ONE library call (fmi_dev_beam_step: _BeamStepper); SEAL_FUSED_BEAM_STEP=0 keeps
+# round 4's form (fmi_dev_constrained_topk_groups + ~15 torch launches per step): same histories, the GPU tests run both
+FUSED_BEAM_STEP = __import__("os").environ.get("SEAL_FUSED_BEAM_STEP", "1") == "1"
 MAX_FORCE = 8          # tokens of force_decoding_from the constraint kernel takes (fmi_kernels.hip)
 MAX_ROW_GROUPS = 3     # decodes one constraint call can serve in lockstep (fmi_kernels.hip)
 
@@ -208,6 +211,135 @@ def _inf_nan_remove(scores: torch.Tensor) -> torch.Tensor:
     return torch.where(scores == float("inf"), torch.full_like(scores, torch.finfo(scores.dtype).max), scores)
 
 
+class _Steps(list):
+    """the recorded steps of one decode; ``packed`` = (tokens [batch, H, L], scores [batch, H]) when the steps are views of the packed
+    history that ``fmi_dev_beam_step`` wrote in place (``PendingGenerate`` then has nothing to copy together)"""
+    packed = None
+
+
+class _BeamStepper:
+    """The beam loop's state as device buffers that ``fmi_dev_beam_step`` advances in place -- ONE library call per decode step:
+    constraint (started from the chains the previous step's ``k_beam_advance`` ran) + log-softmax + top-2K + merge, then
+    ``k_beam_advance``: the keep-history scorer's bookkeeping (reference beam_search.py:658-685), ``input_ids`` = cat(input_ids[beam_idx],
+    tokens) (:313), the decoder's ancestry table, and the chains of the NEXT constraint call.  Replaces ~15 torch launches per step.
+    Rows are the stacked rows of the live groups; a group that ends leaves at the front (``drop``)."""
+
+    def __init__(self, specs, num_beams: int, decoder_start_token_id: int, device):
+        from ._lib import FmiBeamStep
+        K = self.K = num_beams
+        self.specs = specs
+        B = sum(sp["batch"] for sp in specs)
+        R = B * K
+        t_max = max(sp["max_length"] for sp in specs)
+        p0 = specs[0]["processor"]
+        self.index = p0.index
+        self.ids = torch.full((R, t_max + 1), int(p0.pad_token_id), dtype=torch.long, device=device)
+        self.ids[:, 0] = decoder_start_token_id
+        bs = torch.zeros(B, K, dtype=torch.float32, device=device)
+        bs[:, 1:] = -1e9
+        self.beam_scores = bs.view(R)
+        self.beam_idx = torch.empty(R, dtype=torch.long, device=device)
+        self.tokens = torch.empty(R, dtype=torch.long, device=device)
+        want = 2 * K
+        self.top_idx = torch.empty(B, want, dtype=torch.int64, device=device)
+        self.top_con = torch.empty(B, want, dtype=torch.float32, device=device)
+        self.top_unc = torch.empty(B, want, dtype=torch.float32, device=device)
+        self.scratch = torch.empty(R * (3 + 2 * want) + 64, dtype=torch.float32, device=device)
+        # the decodes' histories, packed as PendingGenerate hands them to the host: tokens [batch, H, L] (-1 beyond a hypothesis), scores [batch, H]
+        self.hist = []
+        for sp in specs:
+            L = sp["max_length"]
+            H = (L - 1) * want + K
+            self.hist.append((torch.full((sp["batch"], H, L), -1, dtype=torch.int64, device=device), torch.empty(sp["batch"], H, dtype=torch.float32, device=device)))
+        self.row0 = 0                 # rows of the groups that have left
+        self.dropped = 0              # ... since the previous step
+        self.step_no = 0
+        self.st = FmiBeamStep()
+        self.st.struct_bytes = ctypes.sizeof(FmiBeamStep)
+
+    def input_ids(self, cur_len: int) -> torch.Tensor:
+        return self.ids[self.row0:, :cur_len]
+
+    def drop(self, rows: int) -> None:
+        self.row0 += rows
+        self.dropped += rows
+
+    def step(self, live, logits: torch.Tensor, cur_len: int, tag: int, chain_next: bool, tokens_out, anc):
+        """one decode step for the live groups; returns the (prefix, tokens, scores) views of each live group's history"""
+        K, st, dev = self.K, self.st, logits.device
+        want = 2 * K
+        procs = [self.specs[g]["processor"] for g in live]
+        p0 = procs[0]
+        V = logits.shape[-1]
+        n = len(live)
+        batch = 0
+        for i, g in enumerate(live):
+            p, sp = procs[i], self.specs[g]
+            st.group_batch[i] = sp["batch"]
+            st.group_eos[i] = int(p.eos_token_id)
+            ff = p.force_decoding_from or []
+            st.group_n_force[i] = len(ff)
+            for j, tk in enumerate(ff):
+                st.group_force[i][j] = int(tk)
+            st.group_stop[i] = max(0, int(p.stop_at_count))
+            tok, sc = self.hist[g]
+            st.d_hist_tok[i], st.d_hist_sc[i] = tok.data_ptr(), sc.data_ptr()
+            st.hist_H[i], st.hist_L[i] = tok.shape[1], tok.shape[2]
+            batch += sp["batch"]
+        for i in range(n, 3):
+            st.group_batch[i] = 0
+            st.d_hist_tok[i] = st.d_hist_sc[i] = None
+        rows = batch * K
+        st.n_groups, st.beams, st.cur_len, st.vocab = n, K, cur_len, V
+        st.shift, st.pad_id = SHIFT, int(p0.pad_token_id)
+        st.always_allow_eos, st.chain_next = int(bool(p0.always_allow_eos)), int(bool(chain_next))
+        ids = self.ids[self.row0:]
+        st.d_ids, st.ids_stride = ids.data_ptr(), self.ids.stride(0)
+        lg = logits.contiguous()
+        st.d_logits = lg.data_ptr()
+        st.d_beam_scores = self.beam_scores[self.row0:].data_ptr()
+        first = p0._first_bits(V, dev) if cur_len == 1 else None
+        st.d_first_bits = first.data_ptr() if first is not None else None
+        st.d_scratch, st.scratch_bytes = self.scratch.data_ptr(), self.scratch.numel() * 4
+        q0 = self.row0 // K
+        st.d_top_idx, st.d_top_con, st.d_top_unc = self.top_idx[q0:].data_ptr(), self.top_con[q0:].data_ptr(), self.top_unc[q0:].data_ptr()
+        st.d_beam_idx = self.beam_idx[self.row0:].data_ptr()
+        out_tok = tokens_out if tokens_out is not None else self.tokens[self.row0:]
+        assert out_tok.numel() == rows and out_tok.is_contiguous() and out_tok.dtype == torch.long
+        st.d_tokens_out = out_tok.data_ptr()
+        if anc is not None:
+            assert anc.dtype == torch.int32 and anc.is_contiguous() and anc.shape[1] == rows
+            st.d_anc, st.anc_rows, st.anc_positions = anc.data_ptr(), anc.shape[1], anc.shape[0]
+        else:
+            st.d_anc, st.anc_rows, st.anc_positions = None, 0, 0
+        off = self.step_no * want
+        st.hist_off = off
+        st.state_tag, st.dropped_rows = int(tag), self.dropped
+        trace = getattr(self.index, "_trace", None)
+        ids_before = self.ids[self.row0:, :cur_len].clone() if (trace is not None and cur_len >= 2) else None
+        check(lib().fmi_dev_beam_step(self.index.handle, _stream_ptr(dev), ctypes.byref(st)))
+        if ids_before is not None:
+            # one recorded operation per decode: its rows, its arguments, and the bitmap the step ACTUALLY applied (table / chained /
+            # generic form alike): bench.py's parity check holds that bitmap, not a recomputation, to the CPU oracle
+            from ._lib import last_constraint_bits
+            bits = last_constraint_bits(self.index.handle, dev)
+            bits = bits[:rows].clone() if bits is not None else None
+            a = 0
+            for p, g in zip(procs, live):
+                b = self.specs[g]["batch"] * K
+                trace.append(("mask", ids_before[a:a + b], list(p.force_decoding_from or []),
+                              dict(pad=p.pad_token_id, eos=p.eos_token_id, stop_at_count=int(p.stop_at_count), always_allow_eos=bool(p.always_allow_eos)),
+                              bits[a:a + b] if bits is not None else None))
+                a += b
+        self.dropped = 0
+        self.step_no += 1
+        views = []
+        for g in live:
+            tok, sc = self.hist[g]
+            views.append((tok[:, off:off + want, :cur_len], tok[:, off:off + want, cur_len], sc[:, off:off + want]))
+        return views, out_tok
+
+
 _LOOP_TAGS = itertools.count(1)      # one continuity tag per decode loop (fmi_dev_constrained_topk_step's state_tag)
 _DEBUG_MARK = None                   # tools/soak.py: callable(code) that writes a progress word in stream order (which launch of a stalled decode never completed)
 
@@ -251,15 +383,19 @@ def constrained_beam_search_groups(decoder, specs, num_beams: int, decoder_start
     beam_scores = beam_scores.view(R)
     row_base = (torch.arange(B, device=device) * K).unsqueeze(1)
     eos_q = torch.cat([torch.full((sp["batch"],), int(sp["eos_token_id"]), dtype=torch.long, device=device) for sp in specs]).unsqueeze(1)
-    out_steps = [[] for _ in specs]
+    out_steps = [_Steps() for _ in specs]
     finals = [None] * len(specs)
     beam_idx = None     # rows of the previous step that this step's rows extend (incremental constraint state)
     first_logits = None
     tag = next(_LOOP_TAGS)
     shared_first = bool(getattr(decoder, "shared_first_step", False))
+    stepper = None                 # the fused beam step (fmi_dev_beam_step): the loop's state lives in its buffers
+    next_tokens_in = None          # ... and the decoder's next input is already where the decoder reads it
     while True:
         if first_logits is None and shared_first:
             logits = decoder.step(input_ids[:, -1], beams_identical=True)     # every beam starts from decoder_start_token_id
+        elif next_tokens_in is not None:
+            logits = decoder.step(next_tokens_in)
         else:
             logits = decoder.step(input_ids[:, -1])
         if _DEBUG_MARK is not None:
@@ -271,6 +407,47 @@ def constrained_beam_search_groups(decoder, specs, num_beams: int, decoder_start
             first_logits = logits.view(B, K, V)[:, 0].clone()
         procs = [specs[g]["processor"] for g in live]
         batches = [specs[g]["batch"] for g in live]
+        if (fused and FUSED_BEAM_STEP and K <= 32 and all(isinstance(p, IndexBasedLogitsProcessor) for p in procs) and can_fuse_groups(procs, logits, K)
+                and max(sp["max_length"] for sp in specs) < 62 and (stepper is not None or input_ids.shape[-1] == 1)):
+            # ---- ONE library call for everything between two model steps (the torch ops below are its specification) ----
+            if stepper is None:
+                stepper = _BeamStepper(specs, K, decoder_start_token_id, device)
+                for g in range(len(specs)):
+                    out_steps[g].packed = stepper.hist[g]
+            cur = input_ids.shape[-1]
+            tok_buf, anc = decoder.step_buffers() if hasattr(decoder, "step_buffers") else (None, None)
+            n_live_after = [g for g in live if cur + 1 < specs[g]["max_length"]]
+            views, next_tokens_in = stepper.step(live, logits, cur, tag, chain_next=bool(n_live_after) and cur >= 2, tokens_out=tok_buf, anc=anc)
+            for g, v in zip(live, views):
+                out_steps[g].append(v)
+            if anc is None:
+                decoder.reorder(stepper.beam_idx[stepper.row0:])
+            if _DEBUG_MARK is not None:
+                _DEBUG_MARK(1000 * tag + 10 * cur + 3)
+            cur += 1
+            input_ids = stepper.input_ids(cur)
+            done = [g for g in live if cur >= specs[g]["max_length"]]
+            if done:
+                a = 0
+                for g in done:
+                    b = a + specs[g]["batch"] * K
+                    finals[g] = (input_ids[a:b].contiguous(), stepper.beam_scores[stepper.row0 + a:stepper.row0 + b].clone())
+                    a = b
+                live = live[len(done):]
+                if not live:
+                    break
+                nq = a // K
+                stepper.drop(a)
+                input_ids = stepper.input_ids(cur)
+                B -= nq
+                R = B * K
+                decoder.narrow(nq)
+                next_tokens_in = None if next_tokens_in is None else next_tokens_in[a:]
+                if hasattr(decoder, "step_buffers") and decoder.step_buffers()[0] is not None:
+                    # the narrower decode state has its own token buffer: the survivors' tokens move there (once per dropped group)
+                    decoder.step_buffers()[0].copy_(next_tokens_in)
+                    next_tokens_in = decoder.step_buffers()[0]
+            continue
         if fused and all(p is not None and hasattr(p, "fused_topk") for p in procs) and can_fuse_groups(procs, logits, K):
             if len(procs) == 1:
                 flat, next_scores = procs[0].fused_topk(input_ids, logits, beam_scores, B, K, parent_rows=beam_idx, tag=tag)
@@ -544,15 +721,20 @@ class PendingGenerate:
         dev = final[0].device
         L = final[0].shape[-1]
         H = sum(t.shape[1] for _, t, _ in steps) + K
-        tok = torch.full((B, H, L), -1, dtype=torch.int64, device=dev)
-        sc = torch.empty(B, H, dtype=torch.float32, device=dev)
-        a = 0
-        for prefix, tokens, scores in steps:
-            n, t = tokens.shape[1], prefix.shape[-1]
-            tok[:, a:a + n, :t] = prefix
-            tok[:, a:a + n, t] = tokens
-            sc[:, a:a + n] = scores
-            a += n
+        packed = getattr(steps, "packed", None)
+        if packed is not None and tuple(packed[0].shape) == (B, H, L):
+            tok, sc = packed                      # written in place, step by step, by fmi_dev_beam_step: only the final beams are missing
+            a = H - K
+        else:
+            tok = torch.full((B, H, L), -1, dtype=torch.int64, device=dev)
+            sc = torch.empty(B, H, dtype=torch.float32, device=dev)
+            a = 0
+            for prefix, tokens, scores in steps:
+                n, t = tokens.shape[1], prefix.shape[-1]
+                tok[:, a:a + n, :t] = prefix
+                tok[:, a:a + n, t] = tokens
+                sc[:, a:a + n] = scores
+                a += n
         tok[:, a:a + K, :] = final[0].view(B, K, L)
         sc[:, a:a + K] = final[1].view(B, K)
         if dev.type == "cuda":

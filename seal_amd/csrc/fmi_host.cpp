@@ -50,6 +50,7 @@ FmiOptions::FmiOptions()
     table_grid = env_i64("SEALFM_TABLE_GRID", table_grid);
     topk_narrow = env_i64("SEALFM_TOPK_NARROW", topk_narrow);
     topk_legacy = env_i64("SEALFM_TOPK_LEGACY", topk_legacy);
+    chain_steps = env_i64("SEALFM_CHAIN_STEPS", chain_steps);
 }
 
 int FmiOptions::set(const char *name, int64_t value)
@@ -63,6 +64,7 @@ int FmiOptions::set(const char *name, int64_t value)
     else if (s == "table_grid") table_grid = value;
     else if (s == "topk_narrow") topk_narrow = value;
     else if (s == "topk_legacy") topk_legacy = value < 0 ? 0 : value;
+    else if (s == "chain_steps") chain_steps = value < 0 ? 1 : value;
     else if (s == "pt_inject_failure") pt_inject_failure = value < 0 ? 0 : value;
     else return -1;
     return 0;

@@ -72,6 +72,7 @@ struct FmiOptions {
     int64_t table_grid = -1;        // SEALFM_TABLE_GRID=<n>: workgroups of k_constrain_table (default 1024: one resident round)
     int64_t topk_narrow = -1;       // SEALFM_TOPK_NARROW=<n>: rows of more than n allowed tokens take the wide-row path of k_row_pick
     int64_t topk_legacy = 0;        // SEALFM_TOPK_LEGACY=1: wide rows skip the thread-maxima bound (exact radix select)
+    int64_t chain_steps = 1;        // SEALFM_CHAIN_STEPS=0: fmi_dev_beam_step leaves the rows' chains to the next call (k_constrain_rows) instead of k_beam_advance
     int64_t pt_inject_failure = 0;  // tests: building a prefix table fails after its first allocation (the call must take the generic path)
     FmiOptions();
     int set(const char *name, int64_t value);      // 0, or -1 for an unknown name
@@ -123,6 +124,11 @@ struct fmi {
     // incremental constraint state of fmi_dev_constrained_topk_step (per-row prefix ranges of the last call)
     uint64_t state_tag = 0, state_rows = 0, state_len = 0;
     int state_flip = 0;
+    // chained constraint calls (fmi_dev_beam_step): k_beam_advance of step t leaves the ranges / classes / root splits of the rows of
+    // step t + 1 in the workspace; chain_* say for which call they are valid, state_base = index of the current call's row 0 in them
+    uint64_t chain_tag = 0, chain_len = 0, chain_rows = 0, state_base = 0;
+    const uint32_t *last_bits = nullptr;      // the bitmap the last constraint call filled (fmi_dev_last_constraint_bits)
+    uint64_t last_bits_rows = 0, last_bits_wpr = 0;
     void *ws = nullptr;
     uint64_t ws_bytes = 0;
     uint64_t *d_probe_counter = nullptr;

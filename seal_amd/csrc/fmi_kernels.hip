@@ -547,7 +547,8 @@ struct RowPre { uint64_t lo, hi; int64_t single; uint32_t expand, child_mask; };
 struct ConstrainArgs {
     uint32_t rows, ndig0;          // grid = rows * ndig0 waves
     uint64_t cur_len;
-    const int64_t *ids;            // [rows, cur_len]
+    const int64_t *ids;            // [rows][ids_stride], the first cur_len of each row used
+    uint64_t ids_stride;
     int64_t shift, pad_id;
     uint32_t grp_first[MAX_ROW_GROUPS];   // first row of group g (grp_first[0] = 0; unused groups: 0xffffffff)
     int64_t grp_eos[MAX_ROW_GROUPS];
@@ -639,7 +640,7 @@ __device__ __forceinline__ void row_range_and_class(const FmiDev &ix, const Cons
     lo = hi = 0;
     if (valid) {
         // ids / parent / the kept ranges were written by earlier launches, not by this one: constant here
-        const cptr<int64_t> sent = as_const(a.ids) + (uint64_t)r * a.cur_len;
+        const cptr<int64_t> sent = as_const(a.ids) + (uint64_t)r * a.ids_stride;
         const int64_t last = sent[a.cur_len - 1];
         dead = last == eos_id || last == a.pad_id;
         if (!dead) {
@@ -1878,7 +1879,7 @@ __global__ __launch_bounds__(TABLE_WG) void k_constrain_table(FmiDev ix, Constra
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
             const uint32_t r = r0 + u * TABLE_WG + tid;
-            tok[u] = r < a.rows ? a.ids[(uint64_t)r * a.cur_len + (a.cur_len - 1)] : a.pad_id;
+            tok[u] = r < a.rows ? a.ids[(uint64_t)r * a.ids_stride + (a.cur_len - 1)] : a.pad_id;
         }
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
@@ -2043,6 +2044,161 @@ __global__ __launch_bounds__(256) void k_table_bits(ConstrainArgs a, const uint3
     if (v) a.bits[(uint64_t)r * a.words_per_row + W] |= v;
 }
 
+// ---------------------------------------------------------------------------
+// k_beam_advance -- what the beam loop does between two model steps, as ONE launch (reference beam_search.py:309-332 + the
+// keep-history scorer's process(), 658-685; seal_amd/beam_search.py ran it as ~15 torch launches per step: //, %, index, argsort,
+// gathers, cat, the ancestry-table permutation), AND the rows' chains of the NEXT constraint call.
+// One workgroup per query, one wave per new beam:
+//   * the 2K ranked candidates of the query (k_query_merge's output) are read by every wave (lane = candidate); the first K that are not
+//     the decode's eos continue, in rank order (stable; the same order torch.argsort(stable=True) of the eos flags gives);
+//   * history: candidate c -> its hypothesis (prefix of its source row + its token) and score into the decode's packed history;
+//   * new beam j (wave j): ids row = its source row + its token (in place: all loads of a query's rows come before its stores),
+//     beam score, parent row, the decoder's next input token, and column j of the decoder's ancestry table = its source's column;
+//   * chain (`chain`): the new row's prefix range = ONE backward-search step with its token from the range kept for its source row, its
+//     class (beam_search.py:87-131), and the split of its root node over the sixteen top digits -- exactly what k_constrain_rows computes in
+//     front of a row-first call, but here, a model step ahead of the call that needs it, from values this kernel holds in registers.
+//     The next call's k_constrain starts from the results (RowPre / pre_child) with a single load per wave.
+// ---------------------------------------------------------------------------
+static constexpr uint32_t ADV_MAX_WAVES = 16;
+static constexpr uint32_t ADV_ITERS = 2;          // new beams per wave (two explicit register sets in the kernel): num_beams <= 32, the top-2K kernels' own limit
+
+struct AdvanceArgs {
+    uint32_t batch, beams;
+    uint64_t cur_len;                 // tokens per row before the advance
+    int64_t *ids; uint64_t ids_stride;
+    uint64_t vocab; int64_t shift, pad_id;
+    const int64_t *top_idx; const float *top_unc;          // [batch][2 * beams]
+    float *beam_scores; int64_t *beam_idx; int64_t *tokens_out;   // [batch * beams]
+    int32_t *anc; uint64_t anc_rows; uint32_t anc_T;       // the decoder's ancestry table [anc_T][anc_rows], or null
+    int64_t *hist_tok[MAX_ROW_GROUPS]; float *hist_sc[MAX_ROW_GROUPS];
+    uint32_t hist_H[MAX_ROW_GROUPS], hist_L[MAX_ROW_GROUPS], hist_off;
+    uint32_t grp_first_q[MAX_ROW_GROUPS];                  // first query of group g (unused groups: 0xffffffff)
+    int64_t grp_eos[MAX_ROW_GROUPS], grp_stop[MAX_ROW_GROUPS];
+    uint32_t grp_nff[MAX_ROW_GROUPS];                      // tokens of the group's forced prefix (measurement mode: the binary model's count)
+    int chain;
+    const uint64_t *st_in; uint64_t st_base; uint64_t *st_out;
+    RowPre *pre_rows; uint64_t *pre_child;
+    uint64_t *probe_counter;
+};
+
+__device__ __forceinline__ uint32_t rl_u32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+__global__ __launch_bounds__(64 * ADV_MAX_WAVES) void k_beam_advance(FmiDev ix, AdvanceArgs a)
+{
+    const uint32_t q = blockIdx.x, lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+    const uint32_t K = a.beams, W2 = 2 * K, t = (uint32_t)a.cur_len;
+    uint32_t grp = 0;
+#pragma unroll
+    for (int g = 1; g < MAX_ROW_GROUPS; g++) grp += q >= a.grp_first_q[g] ? 1u : 0u;
+    const int64_t eos = of_group(a.grp_eos, grp);
+    const uint32_t q_in_grp = q - of_group(a.grp_first_q, grp);
+    // ---- the query's 2K ranked candidates, in every wave (lane = candidate) ----
+    const bool valid = lane < W2;
+    const uint64_t flat = valid ? (uint64_t)a.top_idx[(uint64_t)q * W2 + lane] : 0ull;
+    const float csc = valid ? a.top_unc[(uint64_t)q * W2 + lane] : 0.f;
+    const uint32_t cbeam = (uint32_t)(flat / a.vocab);                                  // next_indices = flat // V (beam_search.py:309)
+    const uint32_t ctok = (uint32_t)(flat - (uint64_t)cbeam * a.vocab);                // next_tokens = flat % V
+    const bool keep = valid && (int64_t)ctok != eos;
+    const uint64_t vb = __ballot(valid), kb = __ballot(keep);
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    // position in the stable order "not eos first" (beam_search.py:670-685: the first K non-eos candidates, in rank order, continue)
+    const uint32_t rank = keep ? (uint32_t)__popcll(kb & below) : (uint32_t)__popcll(kb) + (uint32_t)__popcll(vb & ~kb & below);
+    // ---- history of the step: candidate c = (its source row's tokens, its token) with its summed log-prob (beam_search.py:658-668) ----
+    int64_t *htok = of_group(a.hist_tok, grp);
+    if (htok) {
+        float *hsc = of_group(a.hist_sc, grp);
+        const uint32_t H = of_group(a.hist_H, grp), L = of_group(a.hist_L, grp);
+        for (uint32_t c = wave; c < W2; c += nw) {
+            const uint32_t sb = rl_u32(cbeam, c), tk = rl_u32(ctok, c);
+            const float sc = __uint_as_float(rl_u32(__float_as_uint(csc), c));
+            const uint64_t src = (uint64_t)q * K + sb;
+            const uint64_t slot = (uint64_t)q_in_grp * H + a.hist_off + c;
+            int64_t *dst = htok + slot * L;
+            if (lane < t && lane < L) dst[lane] = a.ids[src * a.ids_stride + lane];
+            if (lane == 0) { if (t < L) dst[t] = (int64_t)tk; hsc[slot] = sc; }
+        }
+    }
+    // ---- the new beams: everything that is read from the query's old rows, then a barrier, then the stores ----
+    // (wave w takes new beams w and w + nw: two explicit sets of registers, no indexed arrays)
+    struct NewBeam { uint32_t par, tok; float sc; int64_t id; int32_t anc; };
+    auto pick = [&](uint32_t j, NewBeam &b) {
+        b.par = 0; b.tok = 0; b.sc = 0.f; b.id = 0; b.anc = 0;
+        if (j >= K) return;
+        const uint64_t m = __ballot(valid && rank == j);
+        const uint32_t c = m ? (uint32_t)__ffsll((unsigned long long)m) - 1u : 0u;
+        b.par = rl_u32(cbeam, c); b.tok = rl_u32(ctok, c);
+        b.sc = __uint_as_float(rl_u32(__float_as_uint(csc), c));
+        const uint64_t src = (uint64_t)q * K + b.par;
+        if (lane < t) b.id = a.ids[src * a.ids_stride + lane];
+        if (a.anc && lane < a.anc_T) b.anc = a.anc[(uint64_t)lane * a.anc_rows + src];
+    };
+    auto put = [&](uint32_t j, const NewBeam &b) {
+        if (j >= K) return;
+        const uint64_t r = (uint64_t)q * K + j;
+        if (lane < t) a.ids[r * a.ids_stride + lane] = b.id;
+        if (a.anc && lane < a.anc_T) a.anc[(uint64_t)lane * a.anc_rows + r] = b.anc;
+        if (lane == 0) {
+            a.ids[r * a.ids_stride + t] = (int64_t)b.tok;
+            a.beam_scores[r] = b.sc;
+            a.beam_idx[r] = (int64_t)((uint64_t)q * K + b.par);
+            if (a.tokens_out) a.tokens_out[r] = (int64_t)b.tok;
+        }
+    };
+    NewBeam b0, b1;
+    pick(wave, b0);
+    pick(wave + nw, b1);
+    __syncthreads();
+    put(wave, b0);
+    put(wave + nw, b1);
+    if (!a.chain) return;
+    // ---- the chains of the next constraint call ----
+    const int64_t stop = of_group(a.grp_stop, grp);
+    ExpCounters ctr{0, 0, 0, 0};
+    auto chain = [&](uint32_t j, const NewBeam &b) {
+        if (j >= K) return;
+        const uint64_t r = (uint64_t)q * K + j, prow = (uint64_t)q * K + b.par;
+        const int64_t tok = (int64_t)b.tok;
+        const bool dead = tok == eos || tok == a.pad_id;
+        uint64_t lo = 0, hi = 0, count = 0, probes = 0;
+        if (!dead) {
+            // (the kept ranges were written by an earlier launch: constant here, scalar loads)
+            uint64_t l = as_const(a.st_in)[2 * (a.st_base + prow)], rr = as_const(a.st_in)[2 * (a.st_base + prow) + 1];
+            count = (rr + 1) - l;
+            bs_step(ix, (uint64_t)(tok + a.shift), l, rr, l, rr, &probes);
+            if (lane == 0) { a.st_out[2 * r] = l; a.st_out[2 * r + 1] = rr; }
+            lo = l; hi = rr + 1;
+        }
+        int64_t single = -1;
+        bool expand = false;
+        if (stop > 0 && (int64_t)count <= stop) single = eos;
+        else if (dead) single = a.pad_id;
+        else { expand = true; if (hi > ix.n) hi = ix.n; }
+        const bool split = expand && hi > lo;
+        const uint32_t e = lane & 1, d = lane >> 1;
+        uint64_t qv = 0;
+        if (split && lane < 32) qv = wm_step(ix, 0, e ? hi : lo, d);
+        const uint64_t qo = (uint64_t)dpp_xor1((uint32_t)qv) | ((uint64_t)dpp_xor1((uint32_t)(qv >> 32)) << 32);
+        const uint64_t bal = __ballot(lane < 32 && e == 0 && qo > qv);
+        if (lane < 32) a.pre_child[(r * FMI_ARITY + d) * 2 + e] = qv;
+        uint32_t em = 0;
+#pragma unroll
+        for (uint32_t x = 0; x < 16; x++) em |= (uint32_t)((bal >> (2 * x)) & 1ull) << x;
+        if (lane == 0) {
+            RowPre p;
+            p.lo = lo; p.hi = hi; p.single = single; p.expand = expand ? 1u : 0u; p.child_mask = em;
+            a.pre_rows[r] = p;
+            if (a.probe_counter) {
+                ctr.probes += (uint32_t)probes + (split ? ((lo >> FMI_BLOCK_SHIFT) != (hi >> FMI_BLOCK_SHIFT) ? 2u : 1u) : 0u);
+                ctr.model += (dead ? 0u : ix.levels * (of_group(a.grp_nff, grp) + (uint32_t)a.cur_len)) + (split ? model_nodes(em, 0, FMI_DIGIT_BITS * ix.dlevels - ix.levels) : 0u);
+            }
+        }
+    };
+    chain(wave, b0);
+    chain(wave + nw, b1);
+    if (a.probe_counter) flush_counters(a.probe_counter, ctr);
+}
+
 // the two symbol bitmaps of the table calls (they alternate: each call's second launch zeroes the other one), grown on demand
 static int reserve_sym_bits(fmi *h, uint64_t rows, hipStream_t st)
 {
@@ -2061,7 +2217,8 @@ static int reserve_sym_bits(fmi *h, uint64_t rows, hipStream_t st)
 static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur_len, const int64_t *d_ids,
                              uint32_t *d_bits, uint64_t vocab, int64_t shift, int64_t pad_id, const RowGroups &rg,
                              int64_t stop_at_count, int always_allow_eos,
-                             uint64_t state_tag = 0, const int64_t *d_parent = nullptr, const uint32_t **bits_out = nullptr)
+                             uint64_t state_tag = 0, const int64_t *d_parent = nullptr, const uint32_t **bits_out = nullptr,
+                             uint64_t ids_stride = 0, bool allow_chain = false, uint64_t dropped_rows = 0)
 {
     if (cur_len < 2) { fmi_set_error("cur_len must be >= 2 (cur_len == 1 is the constant occurring_distinct mask, beam_search.py:73-77)"); return FMI_ERR_ARG; }
     if (rg.n < 1 || rg.n > MAX_ROW_GROUPS) { fmi_set_error("1..%d row groups per call", MAX_ROW_GROUPS); return FMI_ERR_UNSUPPORTED; }
@@ -2070,7 +2227,7 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     ConstrainArgs a{};
     a.rows = (uint32_t)rows; a.ndig0 = top_digits(h);
     if ((rows + 8) * a.ndig0 > 0x7fffffffull) { fmi_set_error("too many rows in one call"); return FMI_ERR_CAPACITY; }
-    a.cur_len = cur_len; a.ids = d_ids; a.shift = shift; a.pad_id = pad_id;
+    a.cur_len = cur_len; a.ids = d_ids; a.ids_stride = ids_stride ? ids_stride : cur_len; a.shift = shift; a.pad_id = pad_id;
     uint64_t first = 0;
     for (uint32_t g = 0; g < MAX_ROW_GROUPS; g++) {
         a.grp_first[g] = g < rg.n ? (uint32_t)first : 0xffffffffu;
@@ -2107,6 +2264,32 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
         h->ws_dirty[cur] = rows * wpr;
     }
     if (bits_out) *bits_out = a.bits;
+    h->last_bits = a.bits; h->last_bits_rows = rows; h->last_bits_wpr = wpr;
+    // Chained call (fmi_dev_beam_step): the previous step's k_beam_advance has run every row's chain already -- kept range of its parent
+    // -> one backward-search step with the token it was given -> class -> root node split -- and left the results where the
+    // (row, top digit) waves of k_constrain pick them up.  This call is then ONE launch with no dependent access in front of the sub-trees,
+    // and reads neither ids nor parents.  `dropped_rows`: rows that left the front of the loop since that step (their decode ended).
+    const bool chained = allow_chain && state_tag && !d_bits && h->chain_tag == state_tag && h->chain_len == cur_len &&
+                         rows + dropped_rows + h->state_base == h->chain_rows && h->opt.constrain_waves != 1 && h->dlevels >= 2 && h->dlevels <= 4 &&
+                         !(h->dbg_tstamp);
+    if (chained) {
+        h->state_base += dropped_rows;
+        h->state_len = cur_len; h->state_rows = rows;
+        a.pre_rows = ws_pre_rows(h) + h->state_base; a.pre_child = ws_pre_child(h) + h->state_base * FMI_ARITY * 2;
+        a.groups = (uint32_t)((rows + CONSTRAIN_WG - 1) / CONSTRAIN_WG);
+        a.leave_early = (int)h->opt.leave_early;
+        const unsigned cgrid = a.groups * a.ndig0;
+        const bool ctimed = h->timing_enabled && h->ev_used < MAX_TIMED_LAUNCHES;
+        if (ctimed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
+        void (*ck)(FmiDev, ConstrainArgs) = h->dev.nsb > 1 ? k_constrain<true, CONSTRAIN_WG> : k_constrain<false, CONSTRAIN_WG>;
+        hipLaunchKernelGGL(ck, dim3(cgrid), dim3(64 * CONSTRAIN_WG), (size_t)constrain_lds_slots(h->dlevels, CONSTRAIN_WG) * 16, st, h->dev, a);
+        HIPCHK(hipGetLastError());
+        call_log_begin(h, FMI_CALL_CHAINED, cur_len, rows, ctimed);
+        if (ctimed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
+        return call_log_end(h, st);
+    }
+    h->chain_tag = 0;
+    h->state_base = 0;
     // incremental prefix state: valid when the caller vouches (tag + parent rows) that this call extends,
     // by exactly one token, the rows of the previous call with the same tag
     // (fewer rows than the previous call: a loop over several decodes in lockstep dropped the finished ones; the parents
@@ -2271,6 +2454,15 @@ extern "C" int fmi_dev_constrained_topk_step(fmi_t *h, void *stream, uint64_t ba
                                            scratch_bytes, d_top_idx, d_top_con, d_top_unc, state_tag, d_parent_rows, nullptr);
 }
 
+static int topk_groups_impl(fmi_t *h, void *stream, uint64_t n_groups, const uint64_t *group_batch,
+                            const int64_t *group_eos, const int64_t *group_force, const uint64_t *group_n_force,
+                            uint64_t beams, uint64_t cur_len, const int64_t *d_input_ids, const float *d_logits,
+                            const float *d_beam_scores, uint64_t vocab, int64_t shift, int64_t pad_id,
+                            int64_t stop_at_count, int always_allow_eos, const uint32_t *d_first_bits,
+                            void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc,
+                            uint64_t state_tag, const int64_t *d_parent_rows, const int64_t *group_stop_at_count,
+                            uint64_t ids_stride, bool allow_chain, uint64_t dropped_rows, uint64_t force_slots);
+
 extern "C" int fmi_dev_constrained_topk_groups(fmi_t *h, void *stream, uint64_t n_groups, const uint64_t *group_batch,
                                                const int64_t *group_eos, const int64_t *group_force, const uint64_t *group_n_force,
                                                uint64_t beams, uint64_t cur_len, const int64_t *d_input_ids, const float *d_logits,
@@ -2278,6 +2470,21 @@ extern "C" int fmi_dev_constrained_topk_groups(fmi_t *h, void *stream, uint64_t 
                                                int64_t stop_at_count, int always_allow_eos, const uint32_t *d_first_bits,
                                                void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc,
                                                uint64_t state_tag, const int64_t *d_parent_rows, const int64_t *group_stop_at_count)
+{
+    // one group: the caller's forced-prefix array as it is (fmi_dev_constrained_topk_step); several: MAX_FORCE slots per group
+    return topk_groups_impl(h, stream, n_groups, group_batch, group_eos, group_force, group_n_force, beams, cur_len, d_input_ids, d_logits,
+                            d_beam_scores, vocab, shift, pad_id, stop_at_count, always_allow_eos, d_first_bits, d_scratch, scratch_bytes,
+                            d_top_idx, d_top_con, d_top_unc, state_tag, d_parent_rows, group_stop_at_count, 0, false, 0, n_groups == 1 ? 0 : MAX_FORCE);
+}
+
+static int topk_groups_impl(fmi_t *h, void *stream, uint64_t n_groups, const uint64_t *group_batch,
+                            const int64_t *group_eos, const int64_t *group_force, const uint64_t *group_n_force,
+                            uint64_t beams, uint64_t cur_len, const int64_t *d_input_ids, const float *d_logits,
+                            const float *d_beam_scores, uint64_t vocab, int64_t shift, int64_t pad_id,
+                            int64_t stop_at_count, int always_allow_eos, const uint32_t *d_first_bits,
+                            void *d_scratch, uint64_t scratch_bytes, int64_t *d_top_idx, float *d_top_con, float *d_top_unc,
+                            uint64_t state_tag, const int64_t *d_parent_rows, const int64_t *group_stop_at_count,
+                            uint64_t ids_stride, bool allow_chain, uint64_t dropped_rows, uint64_t force_slots)
 {
     int rc = need_device(h); if (rc) return rc;
     if (n_groups < 1 || n_groups > MAX_ROW_GROUPS || !group_batch || !group_eos || !group_n_force) {
@@ -2290,8 +2497,7 @@ extern "C" int fmi_dev_constrained_topk_groups(fmi_t *h, void *stream, uint64_t 
         batch += group_batch[g];
         rg.rows[g] = group_batch[g] * beams; rg.eos[g] = group_eos[g]; rg.n_force[g] = group_n_force[g];
         if (group_stop_at_count) rg.stop[g] = group_stop_at_count[g] < 0 ? 0 : group_stop_at_count[g];
-        // one group: the caller's array as it is (fmi_dev_constrained_topk_step); several: MAX_FORCE slots per group
-        rg.force[g] = group_force ? group_force + (n_groups == 1 ? 0 : g * MAX_FORCE) : nullptr;
+        rg.force[g] = group_force ? group_force + g * force_slots : nullptr;
         if (group_n_force[g] && !group_force) { fmi_set_error("group %llu: n_force without tokens", (unsigned long long)g); return FMI_ERR_ARG; }
     }
     const uint64_t rows = batch * beams, want = 2 * beams;
@@ -2311,11 +2517,12 @@ extern "C" int fmi_dev_constrained_topk_groups(fmi_t *h, void *stream, uint64_t 
     if (cur_len < 2) {
         if (!d_first_bits) { fmi_set_error("cur_len == 1 needs the occurring_distinct bitmap"); return FMI_ERR_ARG; }
         bits = d_first_bits; broadcast = 1;      // the constant first-step mask (beam_search.py:73-77), the same for every group
-        h->state_tag = 0;
+        h->state_tag = 0; h->chain_tag = 0; h->state_base = 0;
+        h->last_bits = nullptr; h->last_bits_rows = 0;
     } else {
         if (rows > h->ws_rows) { rc = fmi_dev_reserve(h, rows); if (rc) return rc; }
         rc = allowed_bits_impl(h, st, rows, cur_len, d_input_ids, nullptr, vocab, shift, pad_id, rg,
-                               stop_at_count, always_allow_eos, state_tag, d_parent_rows, &bits);
+                               stop_at_count, always_allow_eos, state_tag, d_parent_rows, &bits, ids_stride, allow_chain, dropped_rows);
         if (rc) return rc;
     }
     // (FmiOptions) tests: topk_narrow 0 sends every row down the wide-row path; topk_legacy: wide rows skip the thread-maxima bound
@@ -2327,6 +2534,73 @@ extern "C" int fmi_dev_constrained_topk_groups(fmi_t *h, void *stream, uint64_t 
                        (uint32_t)want, d_beam_scores, row_max, row_lsum, row_tok, row_lp, row_cnt, d_top_idx, d_top_con, d_top_unc);
     HIPCHK(hipGetLastError());
     return FMI_OK;
+}
+
+// One decode step of the beam loop behind the model's forward (sealfm.h: fmi_beam_step_t): constraint + log-softmax + top-2K + merge
+// (fmi_dev_constrained_topk_groups), then k_beam_advance.
+extern "C" int fmi_dev_beam_step(fmi_t *h, void *stream, const fmi_beam_step_t *s)
+{
+    int rc = need_device(h); if (rc) return rc;
+    if (!s || s->struct_bytes != sizeof(fmi_beam_step_t)) { fmi_set_error("fmi_dev_beam_step: struct_bytes must be sizeof(fmi_beam_step_t)"); return FMI_ERR_ARG; }
+    if (s->n_groups < 1 || s->n_groups > MAX_ROW_GROUPS) { fmi_set_error("fmi_dev_beam_step: 1..%d groups", MAX_ROW_GROUPS); return FMI_ERR_ARG; }
+    if (s->beams < 1 || s->beams > ADV_MAX_WAVES * ADV_ITERS || 2 * s->beams > TOPK_MAX) { fmi_set_error("fmi_dev_beam_step: num_beams %llu: at most %d", (unsigned long long)s->beams, TOPK_MAX / 2); return FMI_ERR_UNSUPPORTED; }
+    if (s->cur_len < 1 || s->cur_len >= 63 || s->ids_stride < s->cur_len + 1) { fmi_set_error("fmi_dev_beam_step: cur_len %llu needs an ids row of cur_len + 1 <= 63 slots", (unsigned long long)s->cur_len); return FMI_ERR_ARG; }
+    if (!s->d_ids || !s->d_logits || !s->d_beam_scores || !s->d_top_idx || !s->d_top_con || !s->d_top_unc || !s->d_beam_idx) { fmi_set_error("fmi_dev_beam_step: null buffer"); return FMI_ERR_ARG; }
+    if (s->d_anc && s->anc_positions > 64) { fmi_set_error("fmi_dev_beam_step: at most 64 decoder positions in the ancestry table"); return FMI_ERR_UNSUPPORTED; }
+    uint64_t batch = 0;
+    for (uint64_t g = 0; g < s->n_groups; g++) batch += s->group_batch[g];
+    if (batch == 0) return FMI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    rc = topk_groups_impl(h, stream, s->n_groups, s->group_batch, s->group_eos, &s->group_force[0][0], s->group_n_force, s->beams, s->cur_len, s->d_ids,
+                          s->d_logits, s->d_beam_scores, s->vocab, s->shift, s->pad_id, 0, s->always_allow_eos, s->d_first_bits, s->d_scratch, s->scratch_bytes,
+                          s->d_top_idx, s->d_top_con, s->d_top_unc, s->state_tag, nullptr, s->group_stop, s->ids_stride, true, s->dropped_rows, MAX_FORCE);
+    if (rc) return rc;
+    const uint64_t rows = batch * s->beams;
+    AdvanceArgs a{};
+    a.batch = (uint32_t)batch; a.beams = (uint32_t)s->beams; a.cur_len = s->cur_len; a.ids = s->d_ids; a.ids_stride = s->ids_stride;
+    a.vocab = s->vocab; a.shift = s->shift; a.pad_id = s->pad_id;
+    a.top_idx = s->d_top_idx; a.top_unc = s->d_top_unc; a.beam_scores = s->d_beam_scores; a.beam_idx = s->d_beam_idx; a.tokens_out = s->d_tokens_out;
+    a.anc = s->d_anc; a.anc_rows = s->anc_rows; a.anc_T = (uint32_t)s->anc_positions;
+    uint64_t first_q = 0;
+    for (uint32_t g = 0; g < MAX_ROW_GROUPS; g++) {
+        a.grp_first_q[g] = g < s->n_groups ? (uint32_t)first_q : 0xffffffffu;
+        if (g >= s->n_groups) continue;
+        a.grp_eos[g] = s->group_eos[g]; a.grp_stop[g] = s->group_stop[g] < 0 ? 0 : s->group_stop[g]; a.grp_nff[g] = (uint32_t)s->group_n_force[g];
+        a.hist_tok[g] = s->d_hist_tok[g]; a.hist_sc[g] = s->d_hist_sc[g]; a.hist_H[g] = (uint32_t)s->hist_H[g]; a.hist_L[g] = (uint32_t)s->hist_L[g];
+        if (a.hist_tok[g] && (!a.hist_sc[g] || s->hist_off + 2 * s->beams > s->hist_H[g])) { fmi_set_error("fmi_dev_beam_step: history of group %u too small", g); return FMI_ERR_ARG; }
+        first_q += s->group_batch[g];
+    }
+    a.hist_off = (uint32_t)s->hist_off;
+    // the chains of the next call: only behind a constraint call of this decode whose kept ranges are in the workspace (cur_len >= 2)
+    const bool chain = s->chain_next && s->state_tag && s->cur_len >= 2 && h->state_tag == s->state_tag && h->state_len == s->cur_len &&
+                       h->state_rows == rows && h->opt.chain_steps && h->opt.constrain_waves != 1 && h->dlevels >= 2 && h->dlevels <= 4;
+    if (chain) {
+        a.chain = 1;
+        a.st_in = ws_state(h, h->state_flip); a.st_base = h->state_base; a.st_out = ws_state(h, h->state_flip ^ 1);
+        a.pre_rows = ws_pre_rows(h); a.pre_child = ws_pre_child(h);
+        a.probe_counter = h->probe_count_enabled ? h->d_probe_counter : nullptr;
+        h->state_flip ^= 1; h->state_base = 0; h->state_len = s->cur_len + 1;
+        h->chain_tag = s->state_tag; h->chain_len = s->cur_len + 1; h->chain_rows = rows;
+    } else {
+        h->chain_tag = 0;
+    }
+    const bool timed = h->timing_enabled && h->ev_used < MAX_TIMED_LAUNCHES;
+    if (timed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
+    const unsigned nw = (unsigned)std::min<uint64_t>(s->beams, ADV_MAX_WAVES);
+    hipLaunchKernelGGL(k_beam_advance, dim3((unsigned)batch), dim3(64 * nw), 0, st, h->dev, a);
+    HIPCHK(hipGetLastError());
+    // (its own record of the per-call log: cur_len = the call it prepares; bench.py adds it to that call)
+    call_log_begin(h, chain ? FMI_CALL_ADVANCE_CHAIN : FMI_CALL_ADVANCE, s->cur_len + 1, rows, timed);
+    if (timed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }
+    return call_log_end(h, st);
+}
+
+extern "C" const uint32_t *fmi_dev_last_constraint_bits(fmi_t *h, uint64_t *rows_out, uint64_t *words_per_row_out)
+{
+    if (!h) return nullptr;
+    if (rows_out) *rows_out = h->last_bits_rows;
+    if (words_per_row_out) *words_per_row_out = h->last_bits_wpr;
+    return h->last_bits;
 }
 
 extern "C" int fmi_dev_locate(fmi_t *h, void *stream, uint64_t n, const uint64_t *d_rows, uint64_t *d_pos_out, uint64_t *d_doc_out)

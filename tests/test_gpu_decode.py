@@ -536,16 +536,23 @@ def test_tree_self_attention_matches_the_row_kernel_and_torch(T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["torch-ops", "beam-step", "beam-step-unchained"])
 @pytest.mark.parametrize("n_groups,stops", [(2, (0, 0, 0)), (3, (0, 0, 0)), (2, (3, 0, 0)), (3, (2, 0, 4))],
                          ids=["2", "3", "2-body-stop_at_count", "3-mixed-stop_at_count"])
-def test_lockstep_groups_on_the_gpu_equal_separate_loops_bit_for_bit(n_groups, stops):
+def test_lockstep_groups_on_the_gpu_equal_separate_loops_bit_for_bit(n_groups, stops, mode, monkeypatch):
     """``constrained_beam_search_groups`` over the HIP constraint (ONE ``fmi_dev_constrained_topk_groups`` call per step for
     the stacked rows of 2 / 3 decodes with their own eos / forced prefix / length) on deterministic per-row logits: every
     group's history must equal its own separate loop's exactly -- per-row masks, per-query picks, the incremental prefix
     ranges across the step where the shorter decodes leave the loop (parents then name rows of the wider previous call).
     ``stops``: every decode keeps its OWN stop_at_count in the joint call (the reference gives it to the body decode only,
-    retrieval.py:70-83 vs 162-176; round-3 advisor finding: the joint path applied the body's to the title rows as well)."""
+    retrieval.py:70-83 vs 162-176; round-3 advisor finding: the joint path applied the body's to the title rows as well).
+    ``mode``: the separate loops always run round 4's form (the constraint + top-2K call, then the loop's own torch ops: the
+    specification); the joint loop runs that form too, or round 5's ONE call per step (``fmi_dev_beam_step``: k_beam_advance does the
+    scorer's bookkeeping, rewrites the ids in place and runs the chains of the next constraint call, whose rows are numbered from the
+    rows that left), or the same with the chains left to the next call (``chain_steps=0``)."""
+    import contextlib
     from seal_amd import FMIndex
+    from seal_amd import beam_search as bs_mod
     from seal_amd.beam_search import IndexBasedLogitsProcessor, constrained_beam_search, constrained_beam_search_groups
     from tests.helpers import kernel_options, make_docs
     vocab, K = 120, 5
@@ -580,6 +587,7 @@ def test_lockstep_groups_on_the_gpu_equal_separate_loops_bit_for_bit(n_groups, s
     def proc(ix, c):
         return IndexBasedLogitsProcessor(ix, K, pad_token_id=1, eos_token_id=c["eos"], force_decoding_from=c["ff"], stop_at_count=c["stop"])
     want = []
+    monkeypatch.setattr(bs_mod, "FUSED_BEAM_STEP", False)
     for gi, c in enumerate(cfgs):
         ix = FMIndex()
         ix.initialize(docs)
@@ -588,9 +596,13 @@ def test_lockstep_groups_on_the_gpu_equal_separate_loops_bit_for_bit(n_groups, s
     ix = FMIndex()
     ix.initialize(docs)
     specs = [dict(batch=c["batch"], max_length=c["T"], eos_token_id=c["eos"], processor=proc(ix, c)) for c in cfgs]
-    got = constrained_beam_search_groups(RandomDecoder(list(enumerate(cfgs))), specs, K, 2, device=dev)
+    monkeypatch.setattr(bs_mod, "FUSED_BEAM_STEP", mode != "torch-ops")
+    with (kernel_options(ix, chain_steps=0) if mode == "beam-step-unchained" else contextlib.nullcontext()):
+        got = constrained_beam_search_groups(RandomDecoder(list(enumerate(cfgs))), specs, K, 2, device=dev)
     for (steps, final), w in zip(got, want):
         assert ([tuple(x.tolist() for x in s) for s in steps], final[0].tolist(), final[1].tolist()) == w
+    if mode != "torch-ops":
+        assert got[0][0].packed is not None          # the history was written in place by fmi_dev_beam_step
 
 
 @pytest.mark.gpu

@@ -218,3 +218,21 @@ def test_lightning_loader_accepts_both_layouts_and_rejects_a_wrong_checkpoint(tm
     torch.save(other.state_dict(), bad)
     with pytest.raises(RuntimeError, match="does not match"):
         load_state_dict_from_lightning_checkpoint(tiny_bart(120, seed=9), bad)
+
+
+def test_beam_step_struct_matches_the_header_field_for_field(tmp_path):
+    """``_lib.FmiBeamStep`` (ctypes) against ``fmi_beam_step_t`` as a C compiler lays it out from include/sealfm.h"""
+    import ctypes
+    import os
+    import subprocess
+    from seal_amd._lib import FmiBeamStep
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = [f[0] for f in FmiBeamStep._fields_]
+    src = tmp_path / "offs.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s/include/sealfm.h"\nint main(void) {\n%s\n  printf("%%zu\\n", sizeof(fmi_beam_step_t));\n  return 0;\n}\n'
+                   % (root, "\n".join('  printf("%%zu\\n", offsetof(fmi_beam_step_t, %s));' % n for n in names)))
+    exe = tmp_path / "offs"
+    subprocess.check_call(["gcc", str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got[:-1] == [getattr(FmiBeamStep, n).offset for n in names]
+    assert got[-1] == ctypes.sizeof(FmiBeamStep)
