@@ -276,7 +276,15 @@ def parity_check(index, trace, answers, vocab=VOCAB, locate_stride=1):
             want = np.zeros_like(got)
             want[:, kw["pad"] >> 5] |= np.uint32(1 << (kw["pad"] & 31))       # finished rows: only pad (beam_search.py:119-127)
             want[live] = bits
-            tally("allowed_token_sets", got.shape[0], int((got != want).any(axis=1).sum()))
+            bad_rows = np.nonzero((got != want).any(axis=1))[0]
+            tally("allowed_token_sets", got.shape[0], len(bad_rows))
+            for r in bad_rows[:4]:          # what differs, for the log (a mismatch fails the run)
+                x = np.unpackbits((got[r] ^ want[r]).view(np.uint8), bitorder="little")
+                toks = np.nonzero(x)[0][:8].tolist()
+                detail.setdefault("allowed_token_set_mismatch_samples", []).append(
+                    {"cur_len": int(ids.shape[1]), "row": int(r), "ids": ids[r].tolist(), "forced": list(ff), "n_got": int(np.unpackbits(got[r].view(np.uint8)).sum()),
+                     "n_want": int(np.unpackbits(want[r].view(np.uint8)).sum()), "differing_tokens": toks,
+                     "in_got": [bool((got[r][t >> 5] >> (t & 31)) & 1) for t in toks]})
             pop = np.unpackbits(got[live].view(np.uint8), axis=1).sum(axis=1)
             tally("distinct_symbol_counts", len(live), int((pop != k.astype(np.int64)).sum()))
         elif op[0] == "ranges":

@@ -29,7 +29,7 @@ class FmiBeamStep(ctypes.Structure):
 
 class _DeviceWords:
     def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, True), "version": 2}
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
 
 def last_constraint_bits(handle, device):

@@ -407,7 +407,7 @@ def constrained_beam_search_groups(decoder, specs, num_beams: int, decoder_start
             first_logits = logits.view(B, K, V)[:, 0].clone()
         procs = [specs[g]["processor"] for g in live]
         batches = [specs[g]["batch"] for g in live]
-        if (fused and FUSED_BEAM_STEP and K <= 32 and all(isinstance(p, IndexBasedLogitsProcessor) for p in procs) and can_fuse_groups(procs, logits, K)
+        if (fused and FUSED_BEAM_STEP and K <= 32 and all(type(p) is IndexBasedLogitsProcessor for p in procs) and can_fuse_groups(procs, logits, K)
                 and max(sp["max_length"] for sp in specs) < 62 and (stepper is not None or input_ids.shape[-1] == 1)):
             # ---- ONE library call for everything between two model steps (the torch ops below are its specification) ----
             if stepper is None:

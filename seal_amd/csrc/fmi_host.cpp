@@ -105,6 +105,7 @@ void fmi_release_device(fmi *h)
         (void)hipSetDevice(h->device);
         for (void *p : h->dev_allocs) (void)hipFree(p);
         if (h->ws) (void)hipFree(h->ws);
+        if (h->ws_list) (void)hipFree(h->ws_list);
         for (FmiPrefixTable &t : h->prefix_tables) {
             if (t.d_off) (void)hipFree(t.d_off);
             if (t.d_root) (void)hipFree(t.d_root);
@@ -122,7 +123,7 @@ void fmi_release_device(fmi *h)
     h->ev_start.clear(); h->ev_stop.clear(); h->ev_used = 0; h->timing_enabled = 0;
     h->dev_allocs.clear();
     h->prefix_tables.clear();
-    h->ws = nullptr; h->ws_bytes = 0; h->ws_rows = 0;
+    h->ws = nullptr; h->ws_bytes = 0; h->ws_rows = 0; h->ws_list = nullptr;
     h->sym_bits = nullptr; h->sym_rows = 0; h->sym_row_words = 0;
     h->d_probe_counter = nullptr;
     h->dev = FmiDev{};

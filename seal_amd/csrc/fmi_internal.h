@@ -131,6 +131,8 @@ struct fmi {
     uint64_t last_bits_rows = 0, last_bits_wpr = 0;
     void *ws = nullptr;
     uint64_t ws_bytes = 0;
+    void *ws_list = nullptr;          // list mode of the chained steps: [2][rows][64] positions, [2][rows][64] symbols, [2][rows] lengths
+    int bits_prefilled = 0;           // k_beam_advance has put list rows' tokens into the workspace bitmap the next call will fill
     uint64_t *d_probe_counter = nullptr;
     uint64_t *dbg_tstamp = nullptr;   // tools: per-wave realtime stamps of k_constrain (fmi_dev_debug_timestamps)
     uint64_t dbg_tstamp_cap = 0;

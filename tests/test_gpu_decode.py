@@ -337,6 +337,62 @@ def test_incremental_constraint_state_equals_full_prefix_search(kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chain", [1, 0], ids=["chained", "unchained"])
+@pytest.mark.parametrize("kw", [dict(), dict(force_decoding_from=[2], eos_token_id=7), dict(stop_at_count=2), dict(always_allow_eos=True)])
+def test_masks_the_beam_step_applies_equal_the_oracle_masks_row_by_row(kw, chain):
+    """every allowed-token bitmap a decode through ``fmi_dev_beam_step`` actually applies (captured per step: table call, chained calls with
+    rows in interval and in list mode, finished rows) equals the reference's mask for the same ``input_ids`` (IndexBasedLogitsProcessor.__call__
+    restated over the oracle).  A tiny corpus under a wide beam: queries run out of finite candidates, the beam fills up with not-allowed
+    tokens (quirk Q4) and rows CONTINUE finished rows -- the case in which the kept ranges of rounds 2-4 went stale."""
+    import numpy as np
+    from oracle.beam_oracle import oracle_logits_mask
+    from oracle.seal_oracle import OracleFMIndex
+    from seal_amd import FMIndex
+    from seal_amd.beam_search import IndexBasedLogitsProcessor, constrained_beam_search
+    from tests.helpers import kernel_options, make_docs
+    vocab, B, K, T = 40, 4, 7, 9
+    dev = torch.device("cuda:0")
+    docs = make_docs(13, 12, vocab - 8, min_len=3, max_len=7, title_sep=7)
+    eos = kw.get("eos_token_id", 2)
+    ix, orc = FMIndex(), OracleFMIndex()
+    ix.initialize(docs)
+    orc.initialize(docs)
+
+    class RandomDecoder:
+        def __init__(self):
+            self.t = 0
+
+        def step(self, tokens):
+            g = torch.Generator(device="cpu").manual_seed(300 + self.t)
+            self.t += 1
+            lg = torch.randn(B * K, vocab, generator=g) * 3
+            lg[:, 0] = float("-inf")
+            return lg.to(dev)
+
+        def reorder(self, beam_idx):
+            pass
+
+    trace = []
+    ix.set_trace(trace)
+    proc = IndexBasedLogitsProcessor(ix, K, pad_token_id=1, eos_token_id=eos, force_decoding_from=kw.get("force_decoding_from"),
+                                     stop_at_count=kw.get("stop_at_count", 0), always_allow_eos=kw.get("always_allow_eos", False))
+    with kernel_options(ix, chain_steps=chain):
+        steps, final = constrained_beam_search(RandomDecoder(), B, K, T, 2, eos, proc, device=dev)
+    ix.set_trace(None)
+    masks = [op for op in trace if op[0] == "mask"]
+    assert len(masks) == T - 2 and all(len(op) == 5 and op[4] is not None for op in masks)
+    continued_finished = 0
+    for op in masks:
+        ids, bits = op[1].tolist(), op[4].cpu().numpy().view(np.uint32)
+        got = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, :vocab].astype(bool)
+        want = oracle_logits_mask(orc, ids, vocab, K, pad_token_id=1, eos_token_id=eos, force_decoding_from=kw.get("force_decoding_from"),
+                                  stop_at_count=kw.get("stop_at_count", 0), always_allow_eos=kw.get("always_allow_eos", False))
+        assert np.array_equal(got, np.asarray(want, dtype=bool)), (len(ids[0]), np.nonzero((got != want).any(axis=1))[0][:5])
+        continued_finished += sum(1 for r in ids if any(t in (eos, 1) for t in r[1:-1]) and r[-1] not in (eos, 1))
+    assert continued_finished > 0, "the case under test must occur: a live row whose prefix runs through an eos / pad"
+
+
+@pytest.mark.gpu
 def test_topk_selection_paths_agree_on_ties(monkeypatch):
     """k_row_pick has two selection paths (bitmap gather for rows of <= 1024 allowed tokens, lower bound + collect beyond);
     on heavily tied logits both must return the same picks in the same order (ties go to the lower token id)."""

@@ -171,3 +171,43 @@ def test_batched_drivers_match_scalar_calls():
     for a, b, kk in zip(lo, hi, k):
         if b > a:
             assert len(ix.distinct_count(int(a), int(b))) // 2 == int(kk)
+
+
+def test_position_lists_step_like_the_intervals_they_come_from():
+    """the invariant behind the list mode of the chained decode steps (k_beam_advance, fmi_kernels.hip): for the suffix-array rows
+    [lo, hi) of a prefix X, with text positions P[k] = SA[lo + k] and BWT symbols S[k] = T[P[k] - 1], the rows of X + [c] are -- in the
+    same order -- the positions {P[k] - 1 : S[k] == c}, and the distinct symbols of its rows (the allowed continuations,
+    fm_index.cpp:91-109) are the symbols in front of those.  Checked against the oracle's interval arithmetic (sdsl's backward_search)
+    on every prefix of a few random walks through a small corpus, finished rows (eos inside the prefix) and quirk-Q1 first steps included."""
+    import random
+    from oracle.seal_oracle import SHIFT, OracleFMIndex, brute_bwt, brute_sa, brute_text
+    from tests.helpers import make_docs
+    rng = random.Random(7)
+    docs = make_docs(9, 60, 30, min_len=4, max_len=12)
+    orc = OracleFMIndex()
+    orc.initialize(docs)
+    text, _ = brute_text(docs)
+    sa = brute_sa(text)
+    n = len(text)
+    assert [orc.locate(i) for i in range(n)] == sa
+    checked = 0
+    for _ in range(300):
+        d = rng.choice(docs)
+        a = rng.randrange(len(d))
+        seq = d[a:a + rng.randrange(2, 7)]
+        if rng.random() < 0.3:
+            seq = seq[:1] + [2] + seq[1:]                       # an eos inside the prefix: a continued finished row
+        lo, hi = orc.get_range(seq[:1])
+        hi = min(hi, n)                                         # (quirk Q1 may hand out one row past the end: the kernel keeps such a row an interval)
+        P = [sa[i] for i in range(lo, hi)]
+        for t in range(1, len(seq)):
+            S = [text[p - 1] if p else text[n - 1] for p in P]
+            lo2, hi2 = orc.get_range(seq[:t + 1])
+            if orc.get_range(seq[:t])[1] > n:
+                break                                           # its parent reached past the end: not a list row
+            P = [p - 1 for p, s in zip(P, S) if s == seq[t] + SHIFT and p > 0]
+            assert P == [sa[i] for i in range(lo2, min(hi2, n))], (seq, t)
+            S2 = sorted({text[p - 1] for p in P if p})
+            assert [s - SHIFT for s in S2 if s] == orc.get_distinct(lo2, min(hi2, n)), (seq, t)
+            checked += 1
+    assert checked > 500
