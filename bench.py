@@ -484,27 +484,45 @@ def read_call_log(handle, cap=4096):
     return [{"cur_len": cl[i], "rows": rw[i], "form": CALL_FORMS.get(kd[i], str(kd[i])), "us": float(us[i]), "blocks": int(bl[i])} for i in range(min(cap, n.value))]
 
 
-def merge_call_logs(timed, counted):
-    """the timing pass and the counting pass ran the same batch: the same launches in the same order.  One record per CONSTRAINT call with
-    both figures; the k_beam_advance launch that ran the rows' chains of a call a model step ahead of it ("advance+chains", logged under
-    that call's cur_len) is added to the call -- its whole duration, the beam bookkeeping that shares the launch included -- and its blocks
-    too; a k_beam_advance without chains is not index work and is listed apart.  [] when the two passes disagree about what was launched."""
-    if not timed or len(timed) != len(counted) or any((a["cur_len"], a["rows"], a["form"]) != (b["cur_len"], b["rows"], b["form"]) for a, b in zip(timed, counted)):
+def merge_call_logs(timed, counted, fused=None):
+    """One record per CONSTRAINT call of one un-overlapped batch, in launch order.  Three passes over the same batch supply it:
+    `timed` -- events around every launch, k_beam_advance run as two launches (its bookkeeping, then the rows' chains of the next call:
+    "advance" / "advance+chains" records, logged under the cur_len of the call they precede); `counted` -- the same launches with the
+    in-kernel block counters, drained call by call; `fused` -- the product's launch shape, k_beam_advance ONE launch, events around it.
+    A call's `us` = its own launches + `chains_us`, what its chains ADD to the k_beam_advance launch they ride in (fused duration minus
+    the bookkeeping launch's duration; never below zero); `chains_alone_us` = the chains as a launch of their own, an upper bound that
+    pays for a launch the product does not make.  `MB` = the call's blocks + the chains'.  [] when the passes disagree about what ran."""
+    def shape(log):
+        return [(a["cur_len"], a["rows"], a["form"]) for a in log]
+    if not timed or shape(timed) != shape(counted):
         return [], []
+    fused_adv = {}
+    if fused:
+        for a in fused:
+            if a["form"] in ("advance", "advance+chains"):
+                fused_adv[a["cur_len"]] = a["us"]
     calls, other = [], []
-    pending = None                       # the advance record waiting for the call it prepared
+    pending, book = None, {}
     for a, b in zip(timed, counted):
         rec = {"cur_len": a["cur_len"], "rows": a["rows"], "form": a["form"], "MB": b["blocks"] * 128.0 / 1e6, "us": a["us"]}
         if a["form"] == "advance+chains":
             pending = rec
             continue
         if a["form"] == "advance":
-            other.append({"cur_len": a["cur_len"], "rows": a["rows"], "form": a["form"], "us": round(a["us"], 2)})
+            book[a["cur_len"]] = a["us"]
+            other.append({"cur_len": a["cur_len"], "rows": a["rows"], "form": a["form"], "us": round(a["us"], 2),
+                          **({"fused_with_chains_us": round(fused_adv[a["cur_len"]], 2)} if a["cur_len"] in fused_adv else {})})
             continue
         if pending is not None and pending["cur_len"] == rec["cur_len"]:
-            rec["chains_us"] = round(pending["us"], 2)
+            alone = pending["us"]
+            cl = rec["cur_len"]
+            added = max(0.0, fused_adv[cl] - book[cl]) if (cl in fused_adv and cl in book) else alone
+            rec["own_launches_us"] = round(rec["us"], 2)
+            rec["chains_us"] = round(added, 2)
+            rec["chains_alone_us"] = round(alone, 2)
             rec["chains_MB"] = round(pending["MB"], 3)
-            rec["us"] += pending["us"]
+            rec["us"] += added
+            rec["us_upper_bound"] = round(rec["own_launches_us"] + alone, 2)
             rec["MB"] += pending["MB"]
         pending = None
         calls.append(rec)
@@ -930,6 +948,24 @@ def main():
     # launch times: HIP events around every constraint call of this un-overlapped batch, in-kernel counters OFF (they cost the
     # wide launches a few microseconds); the recording pass below runs the same batch once more with the counters on (events
     # off) and supplies the bytes of the very same launches
+    # (first the same batch with the product's launch shape -- k_beam_advance ONE launch, bookkeeping and chains together -- events around
+    #  every launch: what the chains add to that launch is its duration minus the bookkeeping's, which the next pass times on its own)
+    for hd in handles:
+        check(lib().fmi_dev_set_option(hd, b"advance_apart", 0))
+        check(lib().fmi_dev_enable_timing(hd, 1))
+        check(lib().fmi_dev_call_log(hd, 1))
+    saved_wrappers = (retrieval.fm_index_generate, retrieval.fm_index_generate_joint, rk.rescore_keys, rk.rescore_keys_multi, rk.compute_unigram_scores,
+                      rk.aggregate_evidence_batch, retrieval._count_filter)
+    (retrieval.fm_index_generate, retrieval.fm_index_generate_joint, rk.rescore_keys, rk.rescore_keys_multi, rk.compute_unigram_scores,
+     rk.aggregate_evidence_batch, retrieval._count_filter) = (orig[0], orig_joint, orig[1], orig_multi, orig[2], orig[3], orig[4])
+    run_batch(args.warmup + args.steps)
+    (retrieval.fm_index_generate, retrieval.fm_index_generate_joint, rk.rescore_keys, rk.rescore_keys_multi, rk.compute_unigram_scores,
+     rk.aggregate_evidence_batch, retrieval._count_filter) = saved_wrappers
+    calls_fused = read_call_log(handles[0])
+    for hd in handles:
+        _ln, _km = ctypes.c_uint64(), ctypes.c_double()
+        check(lib().fmi_dev_read_timing(hd, ctypes.byref(_ln), ctypes.byref(_km)))
+        check(lib().fmi_dev_set_option(hd, b"advance_apart", 1))
     for hd in handles:
         check(lib().fmi_dev_enable_timing(hd, 1))
         check(lib().fmi_dev_call_log(hd, 1))              # which call each event pair belongs to (prefix length, rows, launch form)
@@ -985,12 +1021,13 @@ def main():
     # event pair then also brackets the time its launch waits behind their dispatches -- 71 us there against 34.7 us of
     # execution in the rocprofv3 trace of the very same launches (profiles/r2_kernel_stats.csv).  The timed region's own
     # event figure is kept beside it (`timed_region_event_us`).
-    by_call, other_launches = merge_call_logs(calls_timed, calls_counted)
+    by_call, other_launches = merge_call_logs(calls_timed, calls_counted, calls_fused)
     if by_call:
         # a constraint call = its own launches + the chains k_beam_advance ran for it a model step earlier (by_call adds them); the
         # advance launches without chains (the steps in front of a table call) are the beam loop's bookkeeping, not index work
         k2 = C.c_double(sum(c["us"] for c in by_call) * 1e-3)
         l2 = C.c_uint64(len(by_call))
+        k2_upper = sum(c.get("us_upper_bound", c["us"]) for c in by_call) * 1e-3
     n2 = max(1, l2.value)
     achieved = (p2.value * 128.0) / (k2.value * 1e-3) / 1e9 if k2.value > 0 else 0.0
     # SURVEY.md §8(d) prices the same work on the reference-shaped structure (binary wavelet tree, one
@@ -1020,13 +1057,16 @@ def main():
 
     if by_call:
         roofline["by_call"] = by_call
-        roofline["advance_launches_without_chains"] = other_launches
+        roofline["k_beam_advance_bookkeeping_launches"] = other_launches
+        roofline["frac_with_chains_as_own_launches"] = round((p2.value * 128.0) / (k2_upper * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if k2_upper > 0 else None
         roofline["widest_call"] = max(by_call, key=lambda c: c["MB"])
         roofline["by_call_note"] = ("one record per constraint call of ONE batch, in launch order: us = HIP events around the call in the un-overlapped timing "
                                     "pass, MB = 128-byte blocks its launches loaded in the counting pass of the same batch; frac = MB / us / 8 TB/s; "
                                     "form: table = k_constrain_table + k_table_bits, row_first = k_constrain_rows + k_constrain, generic = k_constrain, chained = "
-                                    "k_constrain started from the chains that the previous step's k_beam_advance ran (chains_us / chains_MB: that launch, whole, "
-                                    "added to the call)")
+                                    "k_constrain started from what the previous step's k_beam_advance left -- the rows' chains, and for rows of <= 64 suffix-array "
+                                    "rows the allowed tokens themselves (list mode); chains_us = what the chains add to that launch (its duration as ONE "
+                                    "launch minus its bookkeeping's), chains_alone_us = the chains as a launch of their own (upper bound), both included "
+                                    "in us / us_upper_bound; chains_MB = their blocks")
     roofline_aggregate = aggregate_roofline(agg_timing, index)
 
     cpu = parity = None

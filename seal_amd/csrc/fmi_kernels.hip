@@ -760,8 +760,31 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
     }
     const bool valid = r < a.rows;      // padding wave: its share of the clearing (and of the workgroup's levels) is all it does
     if (W == 1 && !valid) return;
+    if constexpr (W > 1) {
+        // A row-first / chained call knows whether this (row, top digit) item has any work before it touches anything: the row's record
+        // says what the row needs (a special token, an expansion, nothing: ROW_DONE) and which of its root node's children exist.  Most
+        // items of a decode step are empty -- all of them once every row is in list mode -- and such a wave ends HERE, before the LDS
+        // initialisation and the workgroup's first barrier (round 5: an all-empty 600-row call cost 21 us of workgroups that zeroed
+        // their bitmaps and met at a barrier only to leave).  Measurement modes keep every wave.
+        if (a.pre_rows != nullptr && a.leave_early && a.probe_counter == nullptr && a.tstamp == nullptr) {
+            bool work = false;
+            if (valid) {
+                const cptr<RowPre> p = as_const(a.pre_rows) + r;
+                const int64_t sg = p->single;
+                // (a special token is set by the wave that owns its symbol, or by the top digit 0 wave when no wave does: set_special)
+                auto sets = [&](int64_t tok) {
+                    const int64_t sym = tok + a.shift;
+                    const bool owned = sym >= 0 && (uint64_t)(sym >> sub_bits) < a.ndig0;
+                    return tok >= 0 && (uint64_t)tok < a.vocab && (owned ? (uint32_t)(sym >> sub_bits) == d1 : d1 == 0);
+                };
+                work = (sg >= 0 && sets(sg)) || (a.always_allow_eos && sg != -2 && sets(a.grp_eos[row_group(a, r)]));
+                if (p->expand != 0 && p->hi > p->lo) work = work || ((p->child_mask >> d1) & 1u) != 0;
+            }
+            if (!__builtin_amdgcn_readfirstlane((int)work)) return;
+        }
+    }
     for (uint32_t w = lane; w < nw; w += 64) s_bits[w] = 0u;
-    if (W > 1 && threadIdx.x < 8) s_cnt[threadIdx.x] = 0u;
+    if (W > 1 && lane < 8) s_cnt[lane] = 0u;       // (by every wave that stays: the one that used to do it may have left)
 
     // ---- the row: prefix range, class (identical in every wave of the row) ----
     uint64_t lo = 0, hi = 0, probes = 0;
@@ -2147,7 +2170,7 @@ __global__ __launch_bounds__(64 * ADV_MAX_WAVES) void k_beam_advance(FmiDev ix, 
     const int64_t eos = of_group(a.grp_eos, grp);
     const uint32_t q_in_grp = q - of_group(a.grp_first_q, grp);
     // ---- the query's 2K ranked candidates, in every wave (lane = candidate) ----
-    const bool valid = lane < W2;
+    const bool valid = lane < W2 && a.phase != 2;            // (a chains-only launch reads what the bookkeeping launch left instead)
     const uint64_t flat = valid ? (uint64_t)a.top_idx[(uint64_t)q * W2 + lane] : 0ull;
     const float csc = valid ? a.top_unc[(uint64_t)q * W2 + lane] : 0.f;
     const uint32_t cbeam = (uint32_t)(flat / a.vocab);                                  // next_indices = flat // V (beam_search.py:309)
@@ -2741,7 +2764,7 @@ extern "C" int fmi_dev_beam_step(fmi_t *h, void *stream, const fmi_beam_step_t *
     // The product runs ONE launch.  Measurement passes (fmi_dev_enable_timing / fmi_dev_call_log) run the bookkeeping and the chains as two
     // launches of the same kernel, so that an event pair / a counter read-out brackets exactly the index work (the chains, the list
     // steps): that costs the chains a launch of their own -- the figure they are charged with is an upper bound of what they cost the product.
-    const bool apart = chain && (h->timing_enabled || h->call_log_enabled);
+    const bool apart = chain && (h->timing_enabled || h->call_log_enabled) && h->opt.advance_apart;
     for (int phase = apart ? 1 : 0; phase <= (apart ? 2 : 0); phase++) {
         a.phase = phase;
         const bool timed = h->timing_enabled && h->ev_used < MAX_TIMED_LAUNCHES;

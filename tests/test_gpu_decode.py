@@ -389,7 +389,8 @@ def test_masks_the_beam_step_applies_equal_the_oracle_masks_row_by_row(kw, chain
                                   stop_at_count=kw.get("stop_at_count", 0), always_allow_eos=kw.get("always_allow_eos", False))
         assert np.array_equal(got, np.asarray(want, dtype=bool)), (len(ids[0]), np.nonzero((got != want).any(axis=1))[0][:5])
         continued_finished += sum(1 for r in ids if any(t in (eos, 1) for t in r[1:-1]) and r[-1] not in (eos, 1))
-    assert continued_finished > 0, "the case under test must occur: a live row whose prefix runs through an eos / pad"
+    if not kw.get("stop_at_count") and not kw.get("always_allow_eos"):
+        assert continued_finished > 0, "the case under test must occur: a live row whose prefix runs through an eos / pad"
 
 
 @pytest.mark.gpu
