@@ -1600,7 +1600,7 @@ static inline uint64_t *ws_state(fmi *h, int which) { return (uint64_t *)(ws_bit
 static inline RowPre *ws_pre_rows(fmi *h) { return (RowPre *)ws_state(h, 2); }
 static inline uint64_t *ws_pre_child(fmi *h) { return (uint64_t *)(ws_pre_rows(h) + h->ws_rows); }
 // list mode of the chained steps (k_beam_advance), two buffers each like the kept ranges: lengths, text positions, BWT symbols
-static constexpr uint64_t WS_LIST_MAX = 64;
+static constexpr uint64_t WS_LIST_MAX = 1024;      // = LIST_MAX of k_beam_advance (static_assert there)
 static inline uint64_t *ws_list_pos(fmi *h, int which) { return (uint64_t *)h->ws_list + (uint64_t)which * h->ws_rows * WS_LIST_MAX; }
 static inline uint32_t *ws_list_sym(fmi *h, int which) { return (uint32_t *)ws_list_pos(h, 2) + (uint64_t)which * h->ws_rows * WS_LIST_MAX; }
 static inline uint32_t *ws_list_len(fmi *h, int which) { return ws_list_sym(h, 2) + (uint64_t)which * h->ws_rows; }
@@ -2134,26 +2134,20 @@ struct AdvanceArgs {
 // step, then root + 3 levels of the expansion in a second launch: ~9 dependent accesses) that is 2 (the parent's list, the gather), in the
 // launch that advances the beams.  Same sets, same counts: both are functions of the same suffix-array rows.  Lists only ever shrink, so
 // a row in list mode stays there.  lm[row] = its length, or LIST_RANGE_MODE while the row still carries an interval.
-static constexpr uint32_t LIST_MAX = 64;
+static constexpr uint32_t LIST_PER_LANE = 16;                   // entries of a row's list per lane of its wave
+static constexpr uint32_t LIST_MAX = 64 * LIST_PER_LANE;        // 1024 suffix-array rows: 12 KB of positions + symbols per row and buffer
 static constexpr uint32_t LIST_RANGE_MODE = 0xffffffffu;
+static_assert(LIST_MAX == WS_LIST_MAX, "the workspace holds LIST_MAX entries per row");
 static constexpr int64_t ROW_DONE = -2;            // RowPre::single: the row's bits are in the bitmap already, k_constrain has nothing to do for it
 
 __device__ __forceinline__ uint32_t rl_u32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
-// nodes the binary 16-level model visits to emit the distinct symbols held by the first m lanes (measurement mode only)
-__device__ __forceinline__ uint32_t model_nodes_of_symbols(uint32_t sym, uint32_t m, uint32_t levels)
+// nodes the binary 16-level model visits to emit k distinct symbols: N(k) = sum over the levels of min(2^level, k),
+// the survey's own formula (measurement mode only; k = the bits the wave has just set in the row's bitmap)
+__device__ __forceinline__ uint32_t model_nodes_of_k(uint32_t k, uint32_t levels)
 {
-    const uint32_t lane = threadIdx.x & 63;
     uint32_t nodes = 0;
-    for (uint32_t d = 0; d < levels; d++) {                      // depth d: distinct d-bit prefixes
-        const uint32_t mine = d ? sym >> (levels - d) : 0u;
-        bool first = lane < m;
-        for (uint32_t j = 0; j < (uint32_t)__builtin_amdgcn_readfirstlane((int)m); j++) {
-            const uint32_t o = rl_u32(d ? sym >> (levels - d) : 0u, j);
-            if (j < lane && o == mine) first = false;
-        }
-        nodes += (uint32_t)__popcll(__ballot(first));
-    }
+    for (uint32_t l = 0; l < levels; l++) nodes += (l < 31 && (1u << l) < k) ? (1u << l) : k;
     return nodes;
 }
 
@@ -2257,30 +2251,44 @@ __global__ __launch_bounds__(64 * ADV_MAX_WAVES) void k_beam_advance(FmiDev ix, 
         const uint32_t pm = as_const(a.lm_in)[prow];
         uint64_t count = 0, probes = 0;
         uint32_t m = LIST_RANGE_MODE;            // this row's list length, if it has (or gets) one
-        uint64_t p = 0;                          // lane k: position / symbol k of the list
-        uint32_t sv = 0;
         uint64_t lo = 0, hi = 0;
-        bool have = false;                       // lane holds an entry of the new list
+        // lane k holds entries k, k + 64, ... of the list: positions, then the symbols in front of them (0: no entry)
+        uint64_t pp[LIST_PER_LANE];
+        uint32_t sv[LIST_PER_LANE];
+#pragma unroll
+        for (uint32_t i = 0; i < LIST_PER_LANE; i++) { pp[i] = 0; sv[i] = 0; }
+        uint32_t slot[LIST_PER_LANE];
+        uint64_t sel = 0;                        // bit i: entry i of this lane belongs to the new list
         if (pm != LIST_RANGE_MODE) {
             // ---- list mode: filter the source row's list by the token, step the survivors one position back ----
             count = pm;
-            const bool mine = lane < pm;
-            const uint64_t pp = mine ? a.lp_in[prow * LIST_MAX + lane] : 0;
-            const uint32_t ps = mine ? a.ls_in[prow * LIST_MAX + lane] : 0;
-            const bool match = mine && (uint64_t)ps == sym && pp > 0;
-            const uint64_t bal = __ballot(match);
-            m = (uint32_t)__popcll(bal);
-            const uint32_t slot = lane_rank_in(bal);
-            // compact through the output array itself: survivor -> slot; then lane k reads slot k back? no need: each survivor gathers
-            // its own new symbol and stores both at its slot
-            if (match) {
-                p = pp - 1;
-                sv = p ? (uint32_t)text_at(ix, p - 1) : 0u;                  // position 0: the BWT symbol is the sentinel
-                a.lp_out[r * LIST_MAX + slot] = p;
-                a.ls_out[r * LIST_MAX + slot] = sv;
-                have = true;
+            uint32_t ps[LIST_PER_LANE];
+#pragma unroll
+            for (uint32_t i = 0; i < LIST_PER_LANE; i++) {          // every load of the list is issued before any is looked at
+                ps[i] = 0;
+                if (64 * i < pm) {                                  // (uniform: whole chunks beyond the list are skipped)
+                    const uint32_t idx = lane + 64 * i;
+                    if (idx < pm) { pp[i] = a.lp_in[prow * LIST_MAX + idx]; ps[i] = a.ls_in[prow * LIST_MAX + idx]; }
+                }
             }
-            if (a.probe_counter && lane == 0) probes += (pm * 8 + 127) / 128 + (pm * 4 + 127) / 128 + m;
+            uint32_t base = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < LIST_PER_LANE; i++) {
+                slot[i] = 0;
+                if (64 * i < pm) {
+                    const bool match = lane + 64 * i < pm && (uint64_t)ps[i] == sym && pp[i] > 0;
+                    const uint64_t bal = __ballot(match);
+                    slot[i] = base + lane_rank_in(bal);
+                    base += (uint32_t)__popcll(bal);
+                    sel |= (uint64_t)match << i;
+                }
+            }
+            m = base;
+#pragma unroll
+            for (uint32_t i = 0; i < LIST_PER_LANE; i++) {          // ONE dependent access: the survivors' new symbols, gathered together
+                if ((sel >> i) & 1) { pp[i] -= 1; sv[i] = pp[i] ? (uint32_t)text_at(ix, pp[i] - 1) : 0u; }     // position 0: the sentinel is in front
+            }
+            if (a.probe_counter && lane == 0) probes += ((uint64_t)pm * 8 + 127) / 128 + ((uint64_t)pm * 4 + 127) / 128 + m;
         } else {
             // ---- range mode: one backward-search step from the source row's kept interval ----
             uint64_t l = as_const(a.st_in)[2 * prow], rr = as_const(a.st_in)[2 * prow + 1];
@@ -2293,15 +2301,21 @@ __global__ __launch_bounds__(64 * ADV_MAX_WAVES) void k_beam_advance(FmiDev ix, 
             if (cnt <= LIST_MAX && rr + 1 <= ix.n) {        // (an interval that reaches past the last row -- quirk Q1 -- keeps its exact count as an interval)
                 // the interval has become small: from here on the row carries its suffix-array rows' text positions
                 m = (uint32_t)cnt;
-                if (lane < m) {
-                    p = sa_at(ix, lo + lane);
-                    sv = p ? (uint32_t)text_at(ix, p - 1) : (uint32_t)text_at(ix, ix.n - 1);
-                    a.lp_out[r * LIST_MAX + lane] = p;
-                    a.ls_out[r * LIST_MAX + lane] = sv;
-                    have = true;
+#pragma unroll
+                for (uint32_t i = 0; i < LIST_PER_LANE; i++) {
+                    slot[i] = lane + 64 * i;
+                    if (64 * i < m && lane + 64 * i < m) { pp[i] = sa_at(ix, lo + lane + 64 * i); sel |= 1ull << i; }
                 }
-                if (a.probe_counter && lane == 0) probes += (m * 4 + 127) / 128 + m;
+#pragma unroll
+                for (uint32_t i = 0; i < LIST_PER_LANE; i++)
+                    if ((sel >> i) & 1) sv[i] = pp[i] ? (uint32_t)text_at(ix, pp[i] - 1) : (uint32_t)text_at(ix, ix.n - 1);
+                if (a.probe_counter && lane == 0) probes += ((uint64_t)m * 4 + 127) / 128 + m;
             }
+        }
+        if (m != LIST_RANGE_MODE) {
+#pragma unroll
+            for (uint32_t i = 0; i < LIST_PER_LANE; i++)
+                if ((sel >> i) & 1) { a.lp_out[r * LIST_MAX + slot[i]] = pp[i]; a.ls_out[r * LIST_MAX + slot[i]] = sv[i]; }
         }
         if (lane == 0) a.lm_out[r] = m;
         // ---- class (beam_search.py:87-131): a finished row counts 0 ----
@@ -2318,8 +2332,17 @@ __global__ __launch_bounds__(64 * ADV_MAX_WAVES) void k_beam_advance(FmiDev ix, 
         if (!expand || m != LIST_RANGE_MODE) {
             // nothing is left for k_constrain: the row's tokens go into the next call's bitmap here
             if (expand) {
-                if (have && sv != 0) set_next_bit(r, (int64_t)sv - a.shift);
-                if (a.probe_counter) model += model_nodes_of_symbols(sv, m, ix.levels);
+#pragma unroll
+                for (uint32_t i = 0; i < LIST_PER_LANE; i++)
+                    if (((sel >> i) & 1) && sv[i] != 0) set_next_bit(r, (int64_t)sv[i] - a.shift);
+                if (a.probe_counter) {
+                    // (measurement mode: the distinct tokens of the row = the bits this wave has just set in the row's words)
+                    __threadfence();
+                    uint32_t k = 0;
+                    for (uint64_t w = lane; w < a.words_per_row; w += 64) k += (uint32_t)__popc(__hip_atomic_load(&a.bits_next[r * a.words_per_row + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    for (uint32_t o = 32; o; o >>= 1) k += __shfl_xor(k, o);
+                    model += model_nodes_of_k(k, ix.levels);
+                }
             } else if (lane == 0) {
                 set_next_bit(r, single);
             }
