@@ -1600,7 +1600,7 @@ static inline uint64_t *ws_state(fmi *h, int which) { return (uint64_t *)(ws_bit
 static inline RowPre *ws_pre_rows(fmi *h) { return (RowPre *)ws_state(h, 2); }
 static inline uint64_t *ws_pre_child(fmi *h) { return (uint64_t *)(ws_pre_rows(h) + h->ws_rows); }
 // list mode of the chained steps (k_beam_advance), two buffers each like the kept ranges: lengths, text positions, BWT symbols
-static constexpr uint64_t WS_LIST_MAX = 1024;      // = LIST_MAX of k_beam_advance (static_assert there)
+static constexpr uint64_t WS_LIST_MAX = 64;        // = LIST_MAX of k_beam_advance (static_assert there)
 static inline uint64_t *ws_list_pos(fmi *h, int which) { return (uint64_t *)h->ws_list + (uint64_t)which * h->ws_rows * WS_LIST_MAX; }
 static inline uint32_t *ws_list_sym(fmi *h, int which) { return (uint32_t *)ws_list_pos(h, 2) + (uint64_t)which * h->ws_rows * WS_LIST_MAX; }
 static inline uint32_t *ws_list_len(fmi *h, int which) { return ws_list_sym(h, 2) + (uint64_t)which * h->ws_rows; }
@@ -2134,8 +2134,12 @@ struct AdvanceArgs {
 // step, then root + 3 levels of the expansion in a second launch: ~9 dependent accesses) that is 2 (the parent's list, the gather), in the
 // launch that advances the beams.  Same sets, same counts: both are functions of the same suffix-array rows.  Lists only ever shrink, so
 // a row in list mode stays there.  lm[row] = its length, or LIST_RANGE_MODE while the row still carries an interval.
-static constexpr uint32_t LIST_PER_LANE = 16;                   // entries of a row's list per lane of its wave
-static constexpr uint32_t LIST_MAX = 64 * LIST_PER_LANE;        // 1024 suffix-array rows: 12 KB of positions + symbols per row and buffer
+// entries of a row's list per lane of its wave.  Measured on the bench workload (profiles/r5_list_length_ab.txt): 1 (lists of <= 64 rows)
+// adds 10 us of chains to a step's k_beam_advance and leaves k_constrain 16 us at the 8th / 9th token; 16 (<= 1024 rows: k_constrain is idle
+// from the 8th token on, 9 -> 7 us) makes the chains themselves 25 - 55 us -- a thousand gathers and as many atomics on a handful of words by
+// ONE wave per row.  The code is written for any value; 1 is what runs.
+static constexpr uint32_t LIST_PER_LANE = 1;
+static constexpr uint32_t LIST_MAX = 64 * LIST_PER_LANE;
 static constexpr uint32_t LIST_RANGE_MODE = 0xffffffffu;
 static_assert(LIST_MAX == WS_LIST_MAX, "the workspace holds LIST_MAX entries per row");
 static constexpr int64_t ROW_DONE = -2;            // RowPre::single: the row's bits are in the bitmap already, k_constrain has nothing to do for it
