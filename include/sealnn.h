@@ -91,13 +91,18 @@ int sealnn_add_layernorm_acc(void *stream, const float *x, const float *y_acc, c
                              const float *beta, uint32_t rows, uint32_t d, float eps, float *out, void *planes, uint32_t *d_flag);
 int sealnn_gelu_planes_acc(void *stream, const float *x_acc, const float *x_bias, float alpha, uint32_t rows, uint32_t d, void *planes,
                            uint32_t *d_flag);
+/* sealnn_add_layernorm_acc whose addend arrives as the n_slabs slabs of a split-K product (sealnn_hgemm_nt with slices > 1: slab s at
+ * y_acc + s * slab_stride floats): y = alpha * (slab 0 + slab 1 + ...) + bias, the slabs added in slab order as they are read. */
+int sealnn_add_layernorm_acc_slabs(void *stream, const float *x, const float *y_acc, uint32_t n_slabs, uint64_t slab_stride, const float *y_bias,
+                                   float alpha, const float *gamma, const float *beta, uint32_t rows, uint32_t d, float eps, float *out,
+                                   void *planes, uint32_t *d_flag);
 
 /* C[M][N] (fp32, row stride ldc) = A[M][K] (fp16, K contiguous) x W[N][K]^T (fp16, K contiguous), fp32 accumulation on the fp16 matrix cores
  * of gfx950: the linear layers of a decode step (reference seal/beam_search.py:231-253 runs them through torch.nn.Linear) as ONE product over
  * the three split planes of an fp32 operand (K = 3 x in_features; sealnn_*_planes write A, seal_amd/split_gemm.py W).  A hand-written kernel
  * for the decode's heights (M = 300 .. 640 rows, a few hundred workgroups): LDS-DMA staging, no stream-K hand-off between workgroups.
  * K % 64 == 0, operands 16-byte aligned.  config: 0 = tile picked by shape; probes / tests: tile (1: 128 x 128, 2: 64 x 64, 3: 128 x 64,
- * 4: 64 x 128) | 0x100 (one LDS stage, not pipelined) | slices << 16 (split-K: slab s at C + s * M * ldc, the caller sums the slabs). */
+ * 4: 64 x 128) | stages << 8 (LDS stages 1..4, 0: three) | slices << 16 (split-K: slab s at C + s * M * ldc, the caller sums the slabs). */
 int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float *c, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t config);
 
 #ifdef __cplusplus

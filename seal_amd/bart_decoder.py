@@ -101,7 +101,11 @@ class BartStepDecoder:
         out = torch.empty_like(res)
         p = torch.empty(rows, 3 * self.d, dtype=torch.float16, device=res.device) if planes else None
         flag = split_gemm._flag(res.device).data_ptr() if planes else None
-        if isinstance(y, split_gemm.Deferred):
+        if isinstance(y, split_gemm.Deferred) and y.slabs > 1:
+            check(lib().sealnn_add_layernorm_acc_slabs(stream, res.data_ptr(), y.acc.data_ptr(), y.slabs, y.acc.stride(0), y.bias.data_ptr(), float(y.alpha),
+                                                       ln.weight.data_ptr(), ln.bias.data_ptr(), rows, self.d, float(ln.eps), out.data_ptr(),
+                                                       p.data_ptr() if planes else None, flag))
+        elif isinstance(y, split_gemm.Deferred):
             check(lib().sealnn_add_layernorm_acc(stream, res.data_ptr(), y.acc.data_ptr(), y.bias.data_ptr(), float(y.alpha), ln.weight.data_ptr(),
                                                  ln.bias.data_ptr(), rows, self.d, float(ln.eps), out.data_ptr(),
                                                  p.data_ptr() if planes else None, flag))
@@ -154,7 +158,7 @@ class BartStepDecoder:
                 check(lib().sealnn_gelu_planes_acc(stream, acc.data_ptr(), h.bias.data_ptr(), float(h.alpha), acc.shape[0], acc.shape[1], hp.data_ptr(), flag))
             else:
                 check(lib().sealnn_gelu_planes(stream, acc.data_ptr(), acc.shape[0], acc.shape[1], hp.data_ptr(), flag))
-            return self.split_gemm.from_planes(hp, w2, L["fc2"].bias, defer)
+            return self.split_gemm.from_planes(hp, w2, L["fc2"].bias, defer, slabs_ok=defer)      # (its consumer, add + LayerNorm, adds split-K slabs)
         h = self._lin_p(x, xp, L["fc1"].weight, L["fc1"].bias)
         return self._mod(L["act"](h), L["fc2"], defer)
 

@@ -354,7 +354,7 @@ template <typename T_>
 // (yb / ya: y = raw split-GEMM accumulators, the addend is ya * y + yb; see k_self_attn_step)
 __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y, const T_ *gamma, const T_ *beta,
                                                        uint32_t rows, uint32_t d, float eps, T_ *out, __half *planes, uint32_t *flag,
-                                                       const T_ *yb, float ya)
+                                                       const T_ *yb, float ya, uint32_t y_slabs, uint64_t y_slab_stride)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -381,6 +381,17 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y,
             const uint32_t i = lane + 64 * (j0 + jj), ic = i < n4 ? i : 0;
             a[jj] = ld4(xr, ic); b[jj] = ld4(yr, ic); c[jj] = ld4(ybp, ic);
             if (j0 == 0) { g0[jj] = ld4(gamma, ic); b0[jj] = ld4(beta, ic); }
+        }
+        // (y_slabs > 1: y holds the slabs of a split-K product, sealnn_hgemm_nt -- summed here, in slab order, as they are read)
+        for (uint32_t sl = 1; sl < y_slabs; sl++) {
+            float4 e[4];
+#pragma unroll
+            for (uint32_t jj = 0; jj < 4; jj++) {
+                const uint32_t i = lane + 64 * (j0 + jj), ic = i < n4 ? i : 0;
+                e[jj] = ld4(yr + (uint64_t)sl * y_slab_stride, ic);
+            }
+#pragma unroll
+            for (uint32_t jj = 0; jj < 4; jj++) b[jj] = make_float4(b[jj].x + e[jj].x, b[jj].y + e[jj].y, b[jj].z + e[jj].z, b[jj].w + e[jj].w);
         }
 #pragma unroll
         for (uint32_t jj = 0; jj < 4; jj++) {
@@ -476,11 +487,12 @@ static int cross_attn_step(void *stream, const void *q, const void *ck, const vo
 
 template <typename T_>
 static int add_layernorm(void *stream, const void *x, const void *y, const void *gamma, const void *beta, uint32_t rows,
-                         uint32_t d, float eps, void *out, void *planes = nullptr, uint32_t *flag = nullptr, const void *yb = nullptr, float ya = 1.f)
+                         uint32_t d, float eps, void *out, void *planes = nullptr, uint32_t *flag = nullptr, const void *yb = nullptr, float ya = 1.f,
+                         uint32_t y_slabs = 1, uint64_t y_slab_stride = 0)
 {
     if (d % 4 || d > 4096) { fmi_set_error("sealnn_add_layernorm: d=%u unsupported", d); return FMI_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_add_layernorm<T_>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const T_ *)x, (const T_ *)y,
-                       (const T_ *)gamma, (const T_ *)beta, rows, d, eps, (T_ *)out, (__half *)planes, flag, (const T_ *)yb, ya);
+                       (const T_ *)gamma, (const T_ *)beta, rows, d, eps, (T_ *)out, (__half *)planes, flag, (const T_ *)yb, ya, y_slabs, y_slab_stride);
     NNCHK();
     return FMI_OK;
 }
@@ -617,6 +629,15 @@ extern "C" int sealnn_add_layernorm_acc(void *stream, const float *x, const floa
     if (!y_bias) { fmi_set_error("sealnn_add_layernorm_acc: no bias"); return FMI_ERR_ARG; }
     return add_layernorm<float>(stream, x, y_acc, gamma, beta, rows, d, eps, out, planes, d_flag, y_bias, alpha);
 }
+extern "C" int sealnn_add_layernorm_acc_slabs(void *stream, const float *x, const float *y_acc, uint32_t n_slabs, uint64_t slab_stride, const float *y_bias,
+                                              float alpha, const float *gamma, const float *beta, uint32_t rows, uint32_t d, float eps, float *out,
+                                              void *planes, uint32_t *d_flag)
+{
+    if (!y_bias) { fmi_set_error("sealnn_add_layernorm_acc_slabs: no bias"); return FMI_ERR_ARG; }
+    if (n_slabs < 1 || n_slabs > 16) { fmi_set_error("sealnn_add_layernorm_acc_slabs: 1..16 slabs"); return FMI_ERR_ARG; }
+    return add_layernorm<float>(stream, x, y_acc, gamma, beta, rows, d, eps, out, planes, d_flag, y_bias, alpha, n_slabs, slab_stride);
+}
+
 extern "C" int sealnn_gelu_planes_acc(void *stream, const float *x_acc, const float *x_bias, float alpha, uint32_t rows, uint32_t d, void *planes,
                                       uint32_t *d_flag)
 {

@@ -14,8 +14,9 @@
 //     global_load_lds_dwordx4 (16 B per lane, no staging registers), 8 rows per wave instruction, the 16-byte chunks of a row XOR-swizzled
 //     with bits 1..3 of the row ON THE SOURCE ADDRESS (the LDS image of an LDS-DMA is lane-linear), so that the sixteen lanes of every
 //     ds_read_b128 lane group hit sixteen different 16-byte slots of the 256-byte bank row;
-//   * two LDS stages: the loads of stage t + 1 are issued before stage t is computed and waited for with a COUNTED s_waitcnt vmcnt -- raw
-//     s_barrier, never __syncthreads() while an LDS-DMA is in flight (it would drain the prefetch); ALL of the LDS is one array;
+//   * NS LDS stages (2 by default; 3 measured no faster): NS - 1 K steps are in flight while one is computed -- at these heights a workgroup is bound by the latency
+//     of its loads, not by their bandwidth --, waited for with a COUNTED s_waitcnt vmcnt and ONE raw s_barrier per K step (never
+//     __syncthreads() while an LDS-DMA is in flight: it would drain the prefetch); ALL of the LDS is one array;
 //   * rows beyond M / N are clamped on load (they read a valid row) and not stored.
 // K must be a multiple of 64 and the operands 16-byte aligned.
 #include <hip/hip_runtime.h>
@@ -58,20 +59,35 @@ __device__ __forceinline__ half8 read_frag(const unsigned char *lds_tile, uint32
     return *reinterpret_cast<const half8 *>(lds_tile + row * ROW_BYTES + swz(row, chunk) * 16);
 }
 
-template <uint32_t BM, uint32_t BN, bool PIPE>
-__global__ __launch_bounds__(256) void k_hgemm_nt(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, float *__restrict__ C,
+template <uint32_t N>
+__device__ __forceinline__ void wait_all_but()      // all LDS-DMA but the newest N have landed (vmcnt is an immediate)
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NS = LDS stages: NS - 1 K steps are in flight while one is computed.  NS = 1: one stage, __syncthreads() (the reference form of the tests).
+// KG = K groups: KG x 4 waves per workgroup; group g takes the K steps g, g + KG, ... of the tile through LDS stages of its own, and the
+// groups' accumulators are summed through the LDS at the end, in group order (deterministic).  A skinny product (a few hundred rows, a
+// long K) has too few C tiles for 256 CUs and a 4-wave workgroup waits for the latency of every K step alone: K groups put 8 or 16 waves
+// on the CU that overlap one another's waits -- split-K without slabs in memory or a second kernel.
+template <uint32_t BM, uint32_t BN, uint32_t NS, uint32_t KG>
+__global__ __launch_bounds__(256 * KG) void k_hgemm_nt(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, float *__restrict__ C,
                                                   uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t k_per_slice, uint64_t slab_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr uint32_t TM = BM / 2, TN = BN / 2, FM = TM / 16, FN = TN / 16;
     constexpr uint32_t STAGE = (BM + BN) * ROW_BYTES;
     constexpr uint32_t NL = (BM + BN) / 32;                    // LDS-DMA instructions per wave and stage
+    static_assert((NS - 1) * NL <= 48, "vmcnt holds 6 bits");
+    static_assert(KG == 1 || (KG - 1) * BM * BN * 4 <= KG * NS * STAGE, "the groups' partial tiles are summed through the stage buffers");
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wave_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t grp = wave_all >> 2, wave = wave_all & 3;
     const uint32_t wm = wave >> 1, wn = wave & 1;
     const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const uint32_t kbeg = blockIdx.z * k_per_slice;
-    const uint32_t nk = k_per_slice / BK;
+    const uint32_t kbeg = blockIdx.z * k_per_slice + grp * BK;       // this group's first K step; its steps are KG * BK apart
+    const uint32_t nk = k_per_slice / (BK * KG);
+    unsigned char *const lds_grp = lds + grp * NS * STAGE;
     C += (uint64_t)blockIdx.z * slab_stride;
 
     float4v acc[FM][FN];
@@ -81,41 +97,50 @@ __global__ __launch_bounds__(256) void k_hgemm_nt(const _Float16 *__restrict__ A
         for (uint32_t j = 0; j < FN; j++) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
     auto issue = [&](uint32_t kt, uint32_t buf) {
-        unsigned char *st = lds + buf * STAGE;
-        load_tile<BM>(A, m0, M, K, kbeg + kt * BK, st, wave, lane);
-        load_tile<BN>(W, n0, N, K, kbeg + kt * BK, st + BM * ROW_BYTES, wave, lane);
+        unsigned char *st = lds_grp + buf * STAGE;
+        load_tile<BM>(A, m0, M, K, kbeg + kt * BK * KG, st, wave, lane);
+        load_tile<BN>(W, n0, N, K, kbeg + kt * BK * KG, st + BM * ROW_BYTES, wave, lane);
     };
     auto compute = [&](uint32_t buf) {
-        const unsigned char *ta = lds + buf * STAGE, *tb = ta + BM * ROW_BYTES;
+        const unsigned char *ta = lds_grp + buf * STAGE, *tb = ta + BM * ROW_BYTES;
+        // the fragments of BOTH halves of the K step are asked for before the first MFMA: the second half's reads land behind the first's math
+        half8 fa[2][FM], fb[2][FN];
 #pragma unroll
         for (uint32_t ks = 0; ks < 2; ks++) {
-            half8 fa[FM], fb[FN];
 #pragma unroll
-            for (uint32_t i = 0; i < FM; i++) fa[i] = read_frag(ta, wm * TM + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+            for (uint32_t i = 0; i < FM; i++) fa[ks][i] = read_frag(ta, wm * TM + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
 #pragma unroll
-            for (uint32_t j = 0; j < FN; j++) fb[j] = read_frag(tb, wn * TN + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+            for (uint32_t j = 0; j < FN; j++) fb[ks][j] = read_frag(tb, wn * TN + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+        }
+#pragma unroll
+        for (uint32_t ks = 0; ks < 2; ks++)
 #pragma unroll
             for (uint32_t i = 0; i < FM; i++)
 #pragma unroll
-                for (uint32_t j = 0; j < FN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
+                for (uint32_t j = 0; j < FN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
     };
 
-    if constexpr (PIPE) {
-        issue(0, 0);
+    if constexpr (NS >= 2) {
+        // prologue: NS - 1 stages in flight
+#pragma unroll
+        for (uint32_t s = 0; s + 1 < NS; s++)
+            if (s < nk) issue(s, s);
+        uint32_t buf = 0;                                    // kt % NS
         for (uint32_t kt = 0; kt < nk; kt++) {
-            if (kt + 1 < nk) {
-                issue(kt + 1, (kt + 1) & 1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");      // all but the newest NL: stage kt has landed (this wave's share)
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();                                        // ... and everybody else's
+            // stage kt has landed once all but the stages issued after it have: min(NS - 2, nk - 1 - kt) of them
+            const uint32_t newer = nk - 1 - kt < NS - 2 ? nk - 1 - kt : NS - 2;
+            if (newer == 0) wait_all_but<0>();
+            else if (newer == 1) wait_all_but<NL>();
+            else if (newer == 2) wait_all_but<2 * NL>();
+            else wait_all_but<3 * NL>();
+            // ONE barrier per K step: every wave's share of stage kt is in the LDS, and every wave is done reading stage kt - 1 (its
+            // ds_reads completed before its last MFMAs were issued), whose buffer the next LDS-DMA refills
+            __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            compute(kt & 1);
+            if (kt + NS - 1 < nk) issue(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+            compute(buf);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                        // stage kt is read: iteration kt + 1 may refill its buffer
-            asm volatile("" ::: "memory");
+            buf = buf + 1 == NS ? 0 : buf + 1;
         }
     } else {
         for (uint32_t kt = 0; kt < nk; kt++) {
@@ -126,61 +151,111 @@ __global__ __launch_bounds__(256) void k_hgemm_nt(const _Float16 *__restrict__ A
         }
     }
 
+    if constexpr (KG > 1) {
+        // the groups' partial tiles -> group 0, through the (now idle) stage buffers: group g > 0 parks its accumulators as [fragment][lane]
+        // float4 (conflict-free 16-byte stores), group 0 adds them in group order
+        __syncthreads();
+        float4v *park = reinterpret_cast<float4v *>(lds);
+        constexpr uint32_t PER_GROUP = 4 * FM * FN * 64;                 // float4 slots of one group: 4 waves x fragments x lanes
+        if (grp > 0) {
+#pragma unroll
+            for (uint32_t i = 0; i < FM; i++)
+#pragma unroll
+                for (uint32_t j = 0; j < FN; j++) park[(grp - 1) * PER_GROUP + ((wave * FM + i) * FN + j) * 64 + lane] = acc[i][j];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (uint32_t g = 1; g < KG; g++)
+#pragma unroll
+            for (uint32_t i = 0; i < FM; i++)
+#pragma unroll
+                for (uint32_t j = 0; j < FN; j++) acc[i][j] += park[(g - 1) * PER_GROUP + ((wave * FM + i) * FN + j) * 64 + lane];
+    }
     // D fragment: column lane & 15, rows 4 (lane >> 4) .. + 3
+    const bool inside = m0 + BM <= M && n0 + BN <= N;       // (uniform: interior tiles store without bounds tests)
 #pragma unroll
     for (uint32_t i = 0; i < FM; i++) {
 #pragma unroll
         for (uint32_t j = 0; j < FN; j++) {
             const uint32_t col = n0 + wn * TN + j * 16 + (lane & 15);
             const uint32_t rbase = m0 + wm * TM + i * 16 + (lane >> 4) * 4;
+            float *dst = C + (uint64_t)rbase * ldc + col;
+            if (inside) {
 #pragma unroll
-            for (uint32_t r = 0; r < 4; r++) {
-                const uint32_t row = rbase + r;
-                if (row < M && col < N) C[(uint64_t)row * ldc + col] = acc[i][j][r];
+                for (uint32_t r = 0; r < 4; r++) dst[(uint64_t)r * ldc] = acc[i][j][r];
+            } else {
+#pragma unroll
+                for (uint32_t r = 0; r < 4; r++)
+                    if (rbase + r < M && col < N) dst[(uint64_t)r * ldc] = acc[i][j][r];
             }
         }
     }
 }
 
-template <uint32_t BM, uint32_t BN>
-int launch(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t slices, bool pipe)
+template <uint32_t BM, uint32_t BN, uint32_t NS, uint32_t KG>
+int launch_cfg(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t slices)
 {
     const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, slices);
-    const uint32_t kps = K / slices;
-    const size_t lds = (size_t)(pipe ? 2 : 1) * (BM + BN) * ROW_BYTES;
-    const uint64_t slab = (uint64_t)M * ldc;
-    if (pipe) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_hgemm_nt<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_hgemm_nt<BM, BN, true>), grid, dim3(256), lds, st, (const _Float16 *)A, (const _Float16 *)W, C, M, N, K, ldc, kps, slab);
-    } else {
-        hipLaunchKernelGGL((k_hgemm_nt<BM, BN, false>), grid, dim3(256), lds, st, (const _Float16 *)A, (const _Float16 *)W, C, M, N, K, ldc, kps, slab);
-    }
+    const size_t lds = (size_t)KG * NS * (BM + BN) * ROW_BYTES;
+    if ((K / slices) % (BK * KG)) { fmi_set_error("sealnn_hgemm_nt: %u K steps per slice do not split over %u K groups", K / slices / BK, KG); return FMI_ERR_ARG; }
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_hgemm_nt<BM, BN, NS, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_hgemm_nt<BM, BN, NS, KG>), grid, dim3(256 * KG), lds, st, (const _Float16 *)A, (const _Float16 *)W, C, M, N, K, ldc, K / slices,
+                       (uint64_t)M * ldc);
     return hipGetLastError() == hipSuccess ? FMI_OK : FMI_ERR_HIP;
+}
+
+// (the configurations that are instantiated: every tile with 1..3 stages and one K group; the skinny-product forms -- 2 and 4 K groups --
+//  for the two small tiles, two stages)
+template <uint32_t BM, uint32_t BN>
+int launch(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t slices, uint32_t stages,
+           uint32_t kgroups)
+{
+    if (kgroups == 1) {
+        switch (stages) {
+        case 1: return launch_cfg<BM, BN, 1, 1>(st, A, W, C, M, N, K, ldc, slices);
+        case 2: return launch_cfg<BM, BN, 2, 1>(st, A, W, C, M, N, K, ldc, slices);
+        case 3: return launch_cfg<BM, BN, 3, 1>(st, A, W, C, M, N, K, ldc, slices);
+        default: break;
+        }
+    } else if constexpr (BM * BN <= 128 * 64) {
+        if (stages == 2 && kgroups == 2) return launch_cfg<BM, BN, 2, 2>(st, A, W, C, M, N, K, ldc, slices);
+        if constexpr (BM * BN <= 64 * 64) {
+            if (stages == 2 && kgroups == 4) return launch_cfg<BM, BN, 2, 4>(st, A, W, C, M, N, K, ldc, slices);
+        }
+    }
+    fmi_set_error("sealnn_hgemm_nt: no kernel for %u x %u tiles with %u stages and %u K groups", BM, BN, stages, kgroups);
+    return FMI_ERR_ARG;
 }
 
 }   // namespace
 
-// config: 0 = pick by shape; else (tile: 1 = 128 x 128, 2 = 64 x 64, 3 = 128 x 64, 4 = 64 x 128) | 0x100: not pipelined (one LDS stage,
-// __syncthreads) | slices << 16 (split-K: slab s of C at C + s * M * ldc; the caller sums the slabs).  Probes and tests pass it explicitly.
+// config: 0 = pick by shape; else tile (1 = 128 x 128, 2 = 64 x 64, 3 = 128 x 64, 4 = 64 x 128) | stages << 8 (LDS stages 1..3; 0: two) |
+// kgroups << 12 (K groups of 4 waves per workgroup: 1, 2 (tiles 2..4), 4 (tile 2); 0: one) | slices << 16 (split-K over workgroups: slab s of C
+// at C + s * M * ldc, the caller sums the slabs).  Probes and tests pass it explicitly.
 extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float *c, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t config)
 {
     if (!a || !w || !c || M == 0 || N == 0) { fmi_set_error("sealnn_hgemm_nt: null / empty operand"); return FMI_ERR_ARG; }
     if (K == 0 || K % BK) { fmi_set_error("sealnn_hgemm_nt: K = %u must be a multiple of %u", K, BK); return FMI_ERR_UNSUPPORTED; }
     if (((uintptr_t)a | (uintptr_t)w) & 15) { fmi_set_error("sealnn_hgemm_nt: operands must be 16-byte aligned"); return FMI_ERR_ARG; }
-    uint32_t tile = config & 0xff, slices = (config >> 16) ? (config >> 16) : 1;
-    const bool pipe = !(config & 0x100);
+    uint32_t tile = config & 0xff, stages = (config >> 8) & 0xf, kgroups = (config >> 12) & 0xf, slices = (config >> 16) ? (config >> 16) : 1;
+    if (stages == 0) stages = 2;
+    if (kgroups == 0) kgroups = 1;
     if ((K / BK) % slices) { fmi_set_error("sealnn_hgemm_nt: %u K steps do not split into %u slices", K / BK, slices); return FMI_ERR_ARG; }
     if (tile == 0) {
-        // enough workgroups for 256 CUs first, large tiles (less operand traffic per flop) second
-        const uint64_t big = (uint64_t)((M + 127) / 128) * ((N + 127) / 128);
-        tile = big >= 120 ? 1 : ((uint64_t)((M + 127) / 128) * ((N + 63) / 64) >= 120 ? 3 : 2);
+        // by shape (profiles/r5_hgemm_probe.txt): C tiles of 64 x 64; as many K groups as keep a CU's worth of waves busy when the tiles alone
+        // do not fill the chip
+        const uint64_t tiles = (uint64_t)((M + 63) / 64) * ((N + 63) / 64);
+        tile = 2; stages = 2;
+        kgroups = tiles >= 512 ? 1 : (tiles >= 256 ? 2 : 4);
+        while (kgroups > 1 && (K / BK) % kgroups) kgroups >>= 1;
     }
     hipStream_t st = (hipStream_t)stream;
     switch (tile) {
-    case 1: return launch<128, 128>(st, a, w, c, M, N, K, ldc, slices, pipe);
-    case 2: return launch<64, 64>(st, a, w, c, M, N, K, ldc, slices, pipe);
-    case 3: return launch<128, 64>(st, a, w, c, M, N, K, ldc, slices, pipe);
-    case 4: return launch<64, 128>(st, a, w, c, M, N, K, ldc, slices, pipe);
+    case 1: return launch<128, 128>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups);
+    case 2: return launch<64, 64>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups);
+    case 3: return launch<128, 64>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups);
+    case 4: return launch<64, 128>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups);
     default: fmi_set_error("sealnn_hgemm_nt: unknown tile %u", tile); return FMI_ERR_ARG;
     }
 }

@@ -128,15 +128,43 @@ def split_weight(weight: torch.Tensor):
 
 
 class Deferred:
-    """a product whose epilogue is left to the kernel that reads it: the value is ``alpha * acc + bias`` (bias over the last dimension)"""
-    __slots__ = ("acc", "bias", "alpha")
+    """a product whose epilogue is left to the kernel that reads it: the value is ``alpha * acc + bias`` (bias over the last dimension).
+    ``slabs`` > 1: ``acc`` is [slabs, rows, N], the slabs of a split-K product (``sealnn_hgemm_nt``), to be added in slab order."""
+    __slots__ = ("acc", "bias", "alpha", "slabs")
 
-    def __init__(self, acc, bias, alpha):
-        self.acc, self.bias, self.alpha = acc, bias, alpha
+    def __init__(self, acc, bias, alpha, slabs=1):
+        self.acc, self.bias, self.alpha, self.slabs = acc, bias, alpha, slabs
 
     def value(self) -> torch.Tensor:
         """materialised (what the library's own epilogue computes: alpha a power of two, one rounding in the add)"""
-        return self.acc * self.alpha + self.bias
+        acc = self.acc
+        if self.slabs > 1:
+            tot = acc[0]
+            for s in range(1, self.slabs):
+                tot = tot + acc[s]
+            acc = tot
+        return acc * self.alpha + self.bias
+
+
+# The hand-written fp16 product (sealnn_hgemm_nt, seal_amd/csrc/hgemm_kernels.hip) for the decode step's skinny products whose consumer can add
+# split-K slabs as it reads them (sealnn_add_layernorm_acc_slabs): measured on an MI355X (profiles/r5_hgemm_probe.txt, us per call, library ->
+# hand-written with 4 slabs): fc2 [rows, 3 x 4096] x [1024]: 600 rows 43.2 -> 32.2, 300 rows 31.5 -> 21.3.  (N, K') -> {max rows: config};
+# config = tile | stages << 8 | K groups << 12 | slices << 16 (sealnn.h).  SEAL_HAND_GEMM=0: the library for everything.
+HAND_GEMM = os.environ.get("SEAL_HAND_GEMM", "1") == "1"
+HAND_CONFIGS = {
+    (1024, 12288): ((320, 2 | (2 << 8) | (2 << 12) | (4 << 16)), (640, 2 | (2 << 8) | (1 << 12) | (4 << 16))),
+    (1024, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (4 << 16)), (640, 2 | (2 << 8) | (1 << 12) | (4 << 16))),
+}
+
+
+def hand_config(rows: int, n: int, k3: int):
+    """the sealnn_hgemm_nt configuration for a [rows, k3] x [n, k3]^T product, or None: the library's GEMM serves it"""
+    if not HAND_GEMM:
+        return None
+    for max_rows, cfg in HAND_CONFIGS.get((n, k3), ()):
+        if rows <= max_rows:
+            return cfg
+    return None
 
 
 class SplitLinear:
@@ -164,9 +192,19 @@ class SplitLinear:
                                         _flag(x.device).data_ptr()))
         return self.from_planes(a, defer)
 
-    def from_planes(self, planes: torch.Tensor, defer: bool = False):
-        """the product for an activation whose planes [rows, 3K] fp16 exist already (``defer``: as ``Deferred`` raw accumulators)"""
+    def from_planes(self, planes: torch.Tensor, defer: bool = False, slabs_ok: bool = False):
+        """the product for an activation whose planes [rows, 3K] fp16 exist already (``defer``: as ``Deferred`` raw accumulators;
+        ``slabs_ok``: the consumer adds split-K slabs itself, so the hand-written kernel may serve the product)"""
         if defer:
+            if planes.is_cuda and slabs_ok:
+                cfg = hand_config(planes.shape[0], self.N, planes.shape[1])
+                if cfg is not None and planes.is_contiguous():
+                    from ._lib import check, lib
+                    slices = max(1, cfg >> 16)
+                    acc = torch.empty(slices, planes.shape[0], self.N, dtype=torch.float32, device=planes.device)
+                    check(lib().sealnn_hgemm_nt(torch.cuda.current_stream(planes.device).cuda_stream, planes.data_ptr(), self.planes.data_ptr(), acc.data_ptr(),
+                                                planes.shape[0], self.N, planes.shape[1], self.N, cfg))
+                    return Deferred(acc, self.bias, self.alpha, slabs=slices)
             acc = torch.mm(planes, self.wt, out_dtype=torch.float32) if planes.is_cuda else torch.mm(planes.float(), self.wt.float())
             return Deferred(acc, self.bias, self.alpha)
         if not planes.is_cuda:
@@ -200,5 +238,5 @@ class SplitLinears:
             return torch.nn.functional.linear(x, weight, bias)
         return self._of(weight, bias)(x, defer and DEFER_EPILOGUE)
 
-    def from_planes(self, planes: torch.Tensor, weight: torch.Tensor, bias=None, defer: bool = False):
-        return self._of(weight, bias).from_planes(planes, defer and DEFER_EPILOGUE)
+    def from_planes(self, planes: torch.Tensor, weight: torch.Tensor, bias=None, defer: bool = False, slabs_ok: bool = False):
+        return self._of(weight, bias).from_planes(planes, defer and DEFER_EPILOGUE, slabs_ok)

@@ -329,3 +329,99 @@ def test_kernels_that_apply_the_epilogue_themselves_on_the_gpu(monkeypatch):
         res.append(dec.tree_logits(tok, depth.to(dev), anc.to(dev), qidx, enc, mask, prepared=prepared))
     # (the library may pick another GEMM kernel for a product without an epilogue: same arithmetic, another summation order)
     assert torch.isfinite(res[0]).all() and (res[0] - res[1]).abs().max().item() <= 1e-4 and split_gemm.overflowed(dev) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(600, 1024, 3072), (300, 1024, 12288), (37, 200, 192), (640, 192, 256)])
+def test_hand_written_gemm_against_torch(M, N, K):
+    """``sealnn_hgemm_nt`` (hgemm_kernels.hip: LDS-DMA staging, swizzled LDS, MFMA 16x16x32 f16) in every instantiated configuration -- tiles,
+    LDS stages, K groups, split-K slabs: EXACT on one-hot operands (a permuted fragment or a transposed tile cannot pass), within fp32
+    accumulation noise of torch's product on random ones; ragged heights / widths (rows beyond M, N are clamped on load, not stored)."""
+    from seal_amd._lib import check, lib
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(M, K, generator=g).half().to(dev)
+    w = torch.randn(N, K, generator=g).half().to(dev)
+    ref = torch.mm(a.float(), w.float().t())
+    a1 = torch.zeros(M, K, dtype=torch.float16, device=dev)
+    a1[torch.arange(M, device=dev), (torch.arange(M, device=dev) * 7 + 3) % K] = 1.0
+    ref1 = torch.mm(a1.float(), w.float().t())
+    n_cfg = 0
+    for tile in (1, 2, 3, 4):
+        for stages, kg in ((1, 1), (2, 1), (3, 1), (2, 2), (2, 4)):
+            if kg > {1: 1, 2: 4, 3: 2, 4: 2}[tile]:
+                continue
+            for slices in (1, 2, 4):
+                if (K // 64) % slices or (K // 64 // slices) % kg:
+                    continue
+                cfg = tile | (stages << 8) | (kg << 12) | (slices << 16)
+                for x, want, exact in ((a, ref, False), (a1, ref1, True)):
+                    c = torch.full((slices, M, N), float("nan"), device=dev)
+                    check(lib().sealnn_hgemm_nt(st, x.data_ptr(), w.data_ptr(), c.data_ptr(), M, N, K, N, cfg))
+                    got = c.sum(0)
+                    if exact:
+                        assert torch.equal(got, want), (tile, stages, kg, slices)
+                    else:
+                        assert float((got - want).abs().max() / want.abs().max()) < 1e-4, (tile, stages, kg, slices)
+                n_cfg += 1
+    c = torch.empty(M, N, device=dev)
+    check(lib().sealnn_hgemm_nt(st, a.data_ptr(), w.data_ptr(), c.data_ptr(), M, N, K, N, 0))          # the shape-picked configuration
+    assert float((c - ref).abs().max() / ref.abs().max()) < 1e-4 and n_cfg >= 8
+    with pytest.raises(Exception):
+        check(lib().sealnn_hgemm_nt(st, a.data_ptr(), w.data_ptr(), c.data_ptr(), M, N, 100, N, 0))     # K not a multiple of 64
+
+
+@pytest.mark.gpu
+def test_split_k_slabs_are_summed_by_the_kernel_that_reads_them(monkeypatch):
+    """the decode step's fc2 product through the hand-written kernel: 4 split-K slabs that ``sealnn_add_layernorm_acc_slabs`` adds in slab
+    order as it reads them == ``sealnn_add_layernorm_acc`` on the slabs summed beforehand in the same order, bit for bit (outputs and planes);
+    and the graph-captured step decoder with the hand-written product == the same with the library's (``SEAL_HAND_GEMM`` off) to 1e-5"""
+    from seal_amd import split_gemm
+    from seal_amd._lib import check, lib
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    g = torch.Generator().manual_seed(17)
+    rows, d, S = 77, 1024, 4
+    alpha = 2.0 ** -12
+    x = torch.randn(rows, d, generator=g).to(dev)
+    slabs = (torch.randn(S, rows, d, generator=g) * 9000).to(dev)
+    tot = slabs[0]
+    for s in range(1, S):
+        tot = tot + slabs[s]
+    yb = torch.randn(d, generator=g).to(dev)
+    gamma, beta = (torch.rand(d, generator=g) + 0.5).to(dev), torch.randn(d, generator=g).to(dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    o1, p1, o2, p2 = torch.empty_like(x), torch.empty(rows, 3 * d, dtype=torch.float16, device=dev), torch.empty_like(x), torch.empty(rows, 3 * d, dtype=torch.float16, device=dev)
+    check(lib().sealnn_add_layernorm_acc(st, x.data_ptr(), tot.contiguous().data_ptr(), yb.data_ptr(), alpha, gamma.data_ptr(), beta.data_ptr(), rows, d, 1e-5,
+                                         o1.data_ptr(), p1.data_ptr(), flag.data_ptr()))
+    check(lib().sealnn_add_layernorm_acc_slabs(st, x.data_ptr(), slabs.data_ptr(), S, rows * d, yb.data_ptr(), alpha, gamma.data_ptr(), beta.data_ptr(), rows, d,
+                                               1e-5, o2.data_ptr(), p2.data_ptr(), flag.data_ptr()))
+    assert torch.equal(o1, o2) and torch.equal(p1, p2)
+    # the step decoder: hand-written fc2 against the library's
+    from transformers import BartConfig, BartForConditionalGeneration
+    from seal_amd.bart_decoder import BartStepDecoder
+    torch.manual_seed(0)
+    cfg = BartConfig(vocab_size=3000, d_model=1024, encoder_layers=1, decoder_layers=2, encoder_attention_heads=16, decoder_attention_heads=16,
+                     encoder_ffn_dim=4096, decoder_ffn_dim=4096, max_position_embeddings=64)
+    with torch.device(dev):
+        model = BartForConditionalGeneration(cfg).eval()
+    B, K, S_in, T = 10, 15, 12, 4
+    ids = torch.randint(3, 3000, (B, S_in), generator=g).to(dev)
+    mask = torch.ones(B, S_in, dtype=torch.long, device=dev)
+    outs, used = [], []
+    for hand in (True, False):
+        monkeypatch.setattr(split_gemm, "HAND_GEMM", hand)
+        dec = BartStepDecoder(model)
+        enc = dec.encode(ids, mask)
+        dec.start(enc, mask, K, T)
+        tok = torch.full((B * K,), 2, dtype=torch.long, device=dev)
+        steps = []
+        for t in range(T - 1):
+            lg = dec.step(tok).clone()
+            steps.append(lg)
+            tok = lg.argmax(-1)
+        outs.append(torch.stack(steps))
+        used.append(split_gemm.hand_config(B * K, 1024, 3 * 4096) is not None)
+    assert used == [True, False]
+    assert torch.isfinite(outs[0]).all() and (outs[0] - outs[1]).abs().max().item() <= 2e-4 and split_gemm.overflowed(dev) == 0

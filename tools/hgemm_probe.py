@@ -48,11 +48,13 @@ def main():
         a1[torch.arange(M, device=dev), (torch.arange(M, device=dev) * 7 + 3) % K] = 1.0
         ref1 = torch.mm(a1.float(), w.float().t())
         for tile in (1, 2, 3, 4):
-            for nopipe in (0, 0x100):
+            for stages, kg in ((1, 1), (2, 1), (3, 1), (2, 2), (2, 4)):
+                if kg > {1: 1, 2: 4, 3: 2, 4: 2}[tile]:
+                    continue
                 for slices in (1, 2, 3):
-                    if (K // 64) % slices:
+                    if (K // 64) % slices or (K // 64 // slices) % kg:
                         continue
-                    cfg = tile | nopipe | (slices << 16)
+                    cfg = tile | (stages << 8) | (kg << 12) | (slices << 16)
                     c = hgemm(a, w, cfg).sum(0)
                     c1 = hgemm(a1, w, cfg).sum(0)
                     torch.cuda.synchronize()
@@ -60,8 +62,8 @@ def main():
                     e1 = float((c1 - ref1).abs().max())
                     ok = e < 2e-3 and e1 == 0.0
                     bad += 0 if ok else 1
-                    if not ok or (tile == 1 and not nopipe and slices == 1):
-                        print(f"M={M} N={N} K={K} tile={tile} pipelined={not nopipe} slices={slices}: random {e:.2e}  one-hot {e1:.2e}  {'ok' if ok else 'WRONG'}")
+                    if not ok or (tile == 2 and stages == 2 and slices == 1):
+                        print(f"M={M} N={N} K={K} tile={tile} stages={stages} kgroups={kg} slices={slices}: random {e:.2e}  one-hot {e1:.2e}  {'ok' if ok else 'WRONG'}")
     print(f"# {bad} wrong configurations")
     print("# us per call: library fp16 GEMM (torch.mm out fp32) vs sealnn_hgemm_nt per configuration (tile/pipelined/slices)")
     for M in (600, 300, 3200):
@@ -72,17 +74,19 @@ def main():
             t_lib = gtime(lambda: torch.mm(a, wt, out_dtype=torch.float32))
             res = []
             for tile in (1, 2, 3, 4):
-                for slices in (1, 2, 4):
-                    if (K // 64) % slices:
+                for stages, kg in ((2, 1), (3, 1), (2, 2), (2, 4)):
+                    if kg > {1: 1, 2: 4, 3: 2, 4: 2}[tile]:
                         continue
-                    for nopipe in (0, 0x100):
-                        cfg = tile | nopipe | (slices << 16)
+                    for slices in (1, 2, 4):
+                        if (K // 64) % slices or (K // 64 // slices) % kg:
+                            continue
+                        cfg = tile | (stages << 8) | (kg << 12) | (slices << 16)
                         out = torch.empty(slices, M, N, dtype=torch.float32, device=dev)
-                        res.append((gtime(lambda: hgemm(a, w, cfg, out)), tile, not nopipe, slices))
+                        res.append((gtime(lambda: hgemm(a, w, cfg, out)), tile, stages, kg, slices))
             res.sort()
             auto = gtime(lambda: hgemm(a, w, 0))
-            best = ", ".join(f"{t:.1f} (tile {tl}{'' if p else ' unpipelined'}{'' if s == 1 else ' x%d slices' % s})" for t, tl, p, s in res[:4])
-            print(f"M={M:5d} {name:5s} N={N:5d} K={K:5d}: library {t_lib:6.1f}   auto {auto:6.1f}   best: {best}")
+            fmt = lambda r: f"{r[0]:.1f} (tile {r[1]} stages {r[2]} kgroups {r[3]}{'' if r[4] == 1 else ' x%d slices' % r[4]})"
+            print(f"M={M:5d} {name:5s} N={N:5d} K={K:5d}: library {t_lib:6.1f}   auto {auto:6.1f}   best: {', '.join(fmt(r) for r in res[:3])}   | one slab: {', '.join(fmt(r) for r in [r for r in res if r[4] == 1][:3])}")
     sys.exit(1 if bad else 0)
 
 
