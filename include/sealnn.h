@@ -91,6 +91,17 @@ int sealnn_add_layernorm_acc(void *stream, const float *x, const float *y_acc, c
                              const float *beta, uint32_t rows, uint32_t d, float eps, float *out, void *planes, uint32_t *d_flag);
 int sealnn_gelu_planes_acc(void *stream, const float *x_acc, const float *x_bias, float alpha, uint32_t rows, uint32_t d, void *planes,
                            uint32_t *d_flag);
+/* sealnn_self_attn_step / sealnn_cross_attn_step BETWEEN two hand-written products (sealnn_hgemm_nt): the projection in front arrives as raw
+ * accumulators -- n_slabs split-K slabs, slab s at acc + s * slab_stride floats, the projection = alpha * (slab 0 + slab 1 + ...) + bias
+ * (q_bias of the cross form may be NULL: q_acc is then the finished projection) -- and the result leaves as the split planes of the projection
+ * that follows ([rows][3 * heads * 64] fp16 = [hi | hi | lo * 2^11], as sealnn_split_planes writes them; d_flag counts rows beyond fp16's range)
+ * and / or as fp32 `out` (either may be NULL, not both).  Same arithmetic, in the same order, as the plain kernels on the finished operand. */
+int sealnn_self_attn_step_x(void *stream, const float *qkv_acc, uint32_t n_slabs, uint64_t slab_stride, const float *qkv_bias, float alpha,
+                            float *kcache, float *vcache, const int64_t *d_t, uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out,
+                            void *out_planes, uint32_t *d_flag, int32_t *anc);
+int sealnn_cross_attn_step_x(void *stream, const float *q_acc, uint32_t n_slabs, uint64_t slab_stride, const float *q_bias, float alpha,
+                             const float *ck, const float *cv, const float *bias, uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S,
+                             float scale, float *out, void *out_planes, uint32_t *d_flag);
 /* sealnn_add_layernorm_acc whose addend arrives as the n_slabs slabs of a split-K product (sealnn_hgemm_nt with slices > 1: slab s at
  * y_acc + s * slab_stride floats): y = alpha * (slab 0 + slab 1 + ...) + bias, the slabs added in slab order as they are read. */
 int sealnn_add_layernorm_acc_slabs(void *stream, const float *x, const float *y_acc, uint32_t n_slabs, uint64_t slab_stride, const float *y_bias,

@@ -125,10 +125,11 @@ class BartStepDecoder:
         # (no product of fewer than MIN_ROWS rows takes the split: nobody would read the planes of such an activation)
         return bool(self.split_gemm) and split_gemm.FUSED and x.is_cuda and x.dtype == torch.float32 and x.shape[0] >= split_gemm.MIN_ROWS
 
-    def _lin_p(self, x: torch.Tensor, xp, w: torch.Tensor, b, defer: bool = False):
-        """``F.linear(x, w, b)`` where ``xp`` (or None) holds x's split planes already (``defer``: see ``_lin``)"""
+    def _lin_p(self, x: torch.Tensor, xp, w: torch.Tensor, b, defer: bool = False, slabs_ok: bool = False):
+        """``F.linear(x, w, b)`` where ``xp`` (or None) holds x's split planes already (``defer``: see ``_lin``; ``slabs_ok``: the consumer
+        adds split-K slabs, so the hand-written kernel may serve the product)"""
         if xp is not None and self.split_gemm and self.split_gemm.wants(w, x.shape[0]):
-            return self.split_gemm.from_planes(xp, w, b, defer)
+            return self.split_gemm.from_planes(xp, w, b, defer, slabs_ok=slabs_ok)
         return self._lin(x, w, b, defer)
 
     def _planes_of(self, x: torch.Tensor) -> torch.Tensor:
@@ -464,22 +465,45 @@ class BartStepDecoder:
                 """LayerNorm(res + y) -> (fp32, its split planes or None)"""
                 return self._add_ln(L_, stream, res, y, ln, R, planes)
             xp = self._planes_of(x) if planes else None
+            # The hand-written product (sealnn_hgemm_nt) between kernels of this repository: at the decode step's heights the d x d projections
+            # (self-attention output, cross-attention query and output) run as 4 split-K slabs that the consumer adds as it reads them, and
+            # the attention kernels hand their result over as the next projection's split planes -- the library's fp32 GEMM of 17 us (600 rows)
+            # / 12 us (300) becomes 11 / 7 us (profiles/r5_hgemm_probe.txt), with no pass over the activations in between.
+            hand = bool(planes and x.dtype == torch.float32 and split_gemm.hand_config(R, self.d, 3 * self.d) is not None)
+            flag = split_gemm._flag(x.device).data_ptr() if hand else None
             for li, L in enumerate(self.layers):
-                qkv = self._lin_p(x, xp, L["qkv_w"], L["qkv_b"], defer=True)
-                a = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
-                if isinstance(qkv, split_gemm.Deferred):
-                    check(lib().sealnn_self_attn_step_acc(stream, qkv.acc.data_ptr(), qkv.bias.data_ptr(), float(qkv.alpha), st.kv[li, 0].data_ptr(),
-                                                          st.kv[li, 1].data_ptr(), st.t.data_ptr(), R, H, T, float(self.scale), a.data_ptr(),
-                                                          st.anc.data_ptr()))
+                qkv = self._lin_p(x, xp, L["qkv_w"], L["qkv_b"], defer=True, slabs_ok=hand)
+                if hand and isinstance(qkv, split_gemm.Deferred):
+                    ap = torch.empty(R, 3 * self.d, dtype=torch.float16, device=x.device)
+                    check(lib().sealnn_self_attn_step_x(stream, qkv.acc.data_ptr(), qkv.slabs, qkv.acc.stride(0) if qkv.slabs > 1 else 0, qkv.bias.data_ptr(),
+                                                        float(qkv.alpha), st.kv[li, 0].data_ptr(), st.kv[li, 1].data_ptr(), st.t.data_ptr(), R, H, T,
+                                                        float(self.scale), None, ap.data_ptr(), flag, st.anc.data_ptr()))
+                    y = self.split_gemm.from_planes(ap, L["so"].weight, L["so"].bias, defer=True, slabs_ok=True)
                 else:
-                    check(L_.self_attn_step(stream, qkv.data_ptr(), st.kv[li, 0].data_ptr(), st.kv[li, 1].data_ptr(),
-                                            st.t.data_ptr(), R, H, T, float(self.scale), a.data_ptr(), st.anc.data_ptr()))
-                x, xp = add_ln(x, self._mod(a, L["so"], defer=True), L["ln1"])
-                q = self._lin_p(x, xp, L["cq"].weight, L["cq"].bias)
-                c = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
-                check(L_.cross_attn_step(stream, q.data_ptr(), st.ck[li].data_ptr(), st.cv[li].data_ptr(), cbias.data_ptr(),
-                                         B, K, H, S_pad, float(self.scale), c.data_ptr()))
-                x, xp = add_ln(x, self._mod(c, L["co"], defer=True), L["ln2"])
+                    a = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
+                    if isinstance(qkv, split_gemm.Deferred):
+                        check(lib().sealnn_self_attn_step_acc(stream, qkv.acc.data_ptr(), qkv.bias.data_ptr(), float(qkv.alpha), st.kv[li, 0].data_ptr(),
+                                                              st.kv[li, 1].data_ptr(), st.t.data_ptr(), R, H, T, float(self.scale), a.data_ptr(),
+                                                              st.anc.data_ptr()))
+                    else:
+                        check(L_.self_attn_step(stream, qkv.data_ptr(), st.kv[li, 0].data_ptr(), st.kv[li, 1].data_ptr(),
+                                                st.t.data_ptr(), R, H, T, float(self.scale), a.data_ptr(), st.anc.data_ptr()))
+                    y = self._mod(a, L["so"], defer=True)
+                x, xp = add_ln(x, y, L["ln1"])
+                if hand:
+                    qd = self.split_gemm.from_planes(xp, L["cq"].weight, L["cq"].bias, defer=True, slabs_ok=True)
+                    cp = torch.empty(R, 3 * self.d, dtype=torch.float16, device=x.device)
+                    check(lib().sealnn_cross_attn_step_x(stream, qd.acc.data_ptr(), qd.slabs, qd.acc.stride(0) if qd.slabs > 1 else 0, qd.bias.data_ptr(),
+                                                         float(qd.alpha), st.ck[li].data_ptr(), st.cv[li].data_ptr(), cbias.data_ptr(), B, K, H, S_pad,
+                                                         float(self.scale), None, cp.data_ptr(), flag))
+                    y = self.split_gemm.from_planes(cp, L["co"].weight, L["co"].bias, defer=True, slabs_ok=True)
+                else:
+                    q = self._lin_p(x, xp, L["cq"].weight, L["cq"].bias)
+                    c = torch.empty(R, self.d, dtype=x.dtype, device=x.device)
+                    check(L_.cross_attn_step(stream, q.data_ptr(), st.ck[li].data_ptr(), st.cv[li].data_ptr(), cbias.data_ptr(),
+                                             B, K, H, S_pad, float(self.scale), c.data_ptr()))
+                    y = self._mod(c, L["co"], defer=True)
+                x, xp = add_ln(x, y, L["ln2"])
                 x, xp = add_ln(x, self._ffn(x, xp, L, defer=True), L["ln3"])
             st.t.add_(1)
             return self._lin_p(x, xp, self.lm_w, self.lm_b.view(-1)).float()

@@ -66,6 +66,20 @@ static __device__ __forceinline__ bool store_planes4(__half *prow, uint32_t d, u
     return over;
 }
 
+// the same for ONE element (lane = column: the wave's three stores are 128 contiguous bytes each)
+static __device__ __forceinline__ bool store_planes1(__half *prow, uint32_t d, uint32_t col, float v)
+{
+    asm volatile("" : "+v"(v));
+    const float a = fabsf(v);
+    const bool over = a > 65504.f && a < __builtin_huge_valf();
+    unsigned short hb = __half_as_ushort(__float2half_rn(v));
+    asm volatile("" : "+v"(hb));
+    const unsigned short lb = __half_as_ushort(__float2half_rn((v - __half2float(__ushort_as_half(hb))) * 2048.f));
+    unsigned short *o = reinterpret_cast<unsigned short *>(prow);
+    o[col] = hb; o[(uint64_t)d + col] = hb; o[2 * (uint64_t)d + col] = lb;
+    return over;
+}
+
 static __device__ __forceinline__ float wave_sum(float v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -91,7 +105,8 @@ static __device__ __forceinline__ float wave_max(float v)
 template <typename T_>
 __global__ __launch_bounds__(256) void k_self_attn_step(const T_ *qkv, T_ *kcache, T_ *vcache, const int64_t *d_t,
                                                         uint32_t rows, uint32_t heads, uint32_t T, float scale, T_ *out,
-                                                        int32_t *anc, const T_ *pb, float pa)
+                                                        int32_t *anc, const T_ *pb, float pa, uint32_t n_slabs = 1, uint64_t slab_stride = 0,
+                                                        __half *oplanes = nullptr, uint32_t *flag = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -102,6 +117,11 @@ __global__ __launch_bounds__(256) void k_self_attn_step(const T_ *qkv, T_ *kcach
     float q = ldf(base + lane);
     float kn = ldf(base + (uint64_t)heads * 64 + lane);       // (bf16: already the value the cache will hold)
     float vn = ldf(base + (uint64_t)2 * heads * 64 + lane);
+    // (n_slabs > 1: qkv holds the slabs of a split-K product, sealnn_hgemm_nt: added here, in slab order)
+    for (uint32_t sl = 1; sl < n_slabs; sl++) {
+        const T_ *bs = base + (uint64_t)sl * slab_stride;
+        q += ldf(bs + lane); kn += ldf(bs + (uint64_t)heads * 64 + lane); vn += ldf(bs + (uint64_t)2 * heads * 64 + lane);
+    }
     if (pb) {
         const T_ *b = pb + head * 64 + lane;
         q = pa * q + ldf(b); kn = pa * kn + ldf(b + (uint64_t)heads * 64); vn = pa * vn + ldf(b + (uint64_t)2 * heads * 64);
@@ -150,7 +170,11 @@ __global__ __launch_bounds__(256) void k_self_attn_step(const T_ *qkv, T_ *kcach
             acc += e * (p == t ? vn : vreg[p]);
         }
     }
-    stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, acc / denom);
+    const float o = acc / denom;
+    if (out) stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, o);
+    // (oplanes: the output as the split operand of the projection that follows -- [hi | hi | lo * 2^11] in fp16 --, written here instead of by a
+    //  pass of k_split_planes over `out`)
+    if (oplanes && __any((int)store_planes1(oplanes + (uint64_t)row * 3 * heads * 64, heads * 64, head * 64 + lane, o)) && lane == 0 && flag) atomicAdd(flag, 1u);
 }
 
 // K [64, S] and V [S, 64] of one (query, head) into LDS (s_k, s_v: 16-byte aligned, n = 64 * S elements each).  Every load of a thread is
@@ -207,7 +231,8 @@ static __device__ __forceinline__ float cross_attn_row(float qd, const KV *k, co
 template <typename T_>
 __global__ __launch_bounds__(1024) void k_cross_attn_step(const T_ *q, const T_ *ck, const T_ *cv, const T_ *bias,
                                                           uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S, float scale,
-                                                          T_ *out)
+                                                          T_ *out, const T_ *qb = nullptr, float qa = 1.f, uint32_t n_slabs = 1, uint64_t slab_stride = 0,
+                                                          __half *oplanes = nullptr, uint32_t *flag = nullptr)
 {
     __shared__ __attribute__((aligned(16))) float s_k[64 * 64];
     __shared__ __attribute__((aligned(16))) float s_v[64 * 64];
@@ -220,8 +245,13 @@ __global__ __launch_bounds__(1024) void k_cross_attn_step(const T_ *q, const T_ 
     __syncthreads();
     for (uint32_t beam = wv; beam < beams; beam += nw) {
         const uint32_t row = b * beams + beam;
-        const float qd = ldf(q + ((uint64_t)row * heads + head) * 64 + lane) * scale;
-        stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, cross_attn_row(qd, s_k, s_v, bi, S, lane));
+        // (qb / qa / slabs: q = the raw accumulators of the query projection, possibly as split-K slabs: the projection is qa * sum + qb)
+        float qv = ldf(q + ((uint64_t)row * heads + head) * 64 + lane);
+        for (uint32_t sl = 1; sl < n_slabs; sl++) qv += ldf(q + (uint64_t)sl * slab_stride + ((uint64_t)row * heads + head) * 64 + lane);
+        if (qb) qv = qa * qv + ldf(qb + head * 64 + lane);
+        const float o = cross_attn_row(qv * scale, s_k, s_v, bi, S, lane);
+        if (out) stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, o);
+        if (oplanes && __any((int)store_planes1(oplanes + (uint64_t)row * 3 * heads * 64, heads * 64, head * 64 + lane, o)) && lane == 0 && flag) atomicAdd(flag, 1u);
     }
 }
 
@@ -561,6 +591,33 @@ extern "C" int sealnn_cross_attn_step(void *stream, const float *q, const float 
 extern "C" int sealnn_cross_attn_step_bf16(void *stream, const void *q, const void *ck, const void *cv, const void *bias, uint32_t batch,
                                            uint32_t beams, uint32_t heads, uint32_t S, float scale, void *out)
 { return cross_attn_step<bf16>(stream, q, ck, cv, bias, batch, beams, heads, S, scale, out); }
+
+// the two step kernels between hand-written products: operands as raw (split-K) accumulators with their epilogue, results as split planes
+extern "C" int sealnn_self_attn_step_x(void *stream, const float *qkv_acc, uint32_t n_slabs, uint64_t slab_stride, const float *qkv_bias, float alpha,
+                                       float *kcache, float *vcache, const int64_t *d_t, uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out,
+                                       void *out_planes, uint32_t *d_flag, int32_t *anc)
+{
+    if (T > FMI_MAX_LEVELS) { fmi_set_error("sealnn_self_attn_step_x: at most %u positions", FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
+    if (!qkv_bias || (!out && !out_planes) || n_slabs < 1 || n_slabs > 16) { fmi_set_error("sealnn_self_attn_step_x: bad argument"); return FMI_ERR_ARG; }
+    const uint32_t items = rows * heads;
+    hipLaunchKernelGGL(k_self_attn_step<float>, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv_acc, kcache, vcache, d_t, rows, heads, T, scale,
+                       out, anc, qkv_bias, alpha, n_slabs, slab_stride, (__half *)out_planes, d_flag);
+    NNCHK();
+    return FMI_OK;
+}
+
+extern "C" int sealnn_cross_attn_step_x(void *stream, const float *q_acc, uint32_t n_slabs, uint64_t slab_stride, const float *q_bias, float alpha,
+                                        const float *ck, const float *cv, const float *bias, uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S,
+                                        float scale, float *out, void *out_planes, uint32_t *d_flag)
+{
+    if (S > 64) { fmi_set_error("sealnn_cross_attn_step_x: encoder length %u > 64", S); return FMI_ERR_UNSUPPORTED; }
+    if ((!out && !out_planes) || n_slabs < 1 || n_slabs > 16) { fmi_set_error("sealnn_cross_attn_step_x: bad argument"); return FMI_ERR_ARG; }
+    const uint32_t waves = beams < 8 ? beams : 8;
+    hipLaunchKernelGGL(k_cross_attn_step<float>, dim3(batch * heads), dim3(waves * 64), 0, (hipStream_t)stream, q_acc, ck, cv, bias, batch, beams, heads, S,
+                       scale, out, q_bias, alpha, n_slabs, slab_stride, (__half *)out_planes, d_flag);
+    NNCHK();
+    return FMI_OK;
+}
 
 // ---- split GEMM operands (seal_amd/split_gemm.py): an fp32 row -> [hi | hi | lo'] in fp16, hi = fp16(x), lo' = fp16((x - hi) * 2^11) ----
 // x = hi + lo' * 2^-11 to 22 bits; the GEMM  [hi | hi | lo'] . [W_hi | W_lo | W_hi * 2^-11]^T  on the fp16 matrix cores (fp32

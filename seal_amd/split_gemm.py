@@ -152,8 +152,9 @@ class Deferred:
 # config = tile | stages << 8 | K groups << 12 | slices << 16 (sealnn.h).  SEAL_HAND_GEMM=0: the library for everything.
 HAND_GEMM = os.environ.get("SEAL_HAND_GEMM", "1") == "1"
 HAND_CONFIGS = {
-    (1024, 12288): ((320, 2 | (2 << 8) | (2 << 12) | (4 << 16)), (640, 2 | (2 << 8) | (1 << 12) | (4 << 16))),
-    (1024, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (4 << 16)), (640, 2 | (2 << 8) | (1 << 12) | (4 << 16))),
+    (1024, 12288): ((320, 2 | (2 << 8) | (2 << 12) | (4 << 16)), (640, 2 | (2 << 8) | (1 << 12) | (4 << 16))),      # fc2
+    (1024, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (4 << 16)), (640, 2 | (2 << 8) | (1 << 12) | (4 << 16))),       # the d x d projections: 14.3 -> 10.7, 11.1 -> 6.6
+    (3072, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (2 << 16)),),                                                    # qkv at 300 rows: 15.2 -> 11.9 (600: no gain)
 }
 
 

@@ -398,7 +398,44 @@ def test_split_k_slabs_are_summed_by_the_kernel_that_reads_them(monkeypatch):
     check(lib().sealnn_add_layernorm_acc_slabs(st, x.data_ptr(), slabs.data_ptr(), S, rows * d, yb.data_ptr(), alpha, gamma.data_ptr(), beta.data_ptr(), rows, d,
                                                1e-5, o2.data_ptr(), p2.data_ptr(), flag.data_ptr()))
     assert torch.equal(o1, o2) and torch.equal(p1, p2)
-    # the step decoder: hand-written fc2 against the library's
+    # the attention step kernels between two hand-written products: slabs in, split planes out == the plain kernel on the finished operand,
+    # then sealnn_split_planes over its output
+    H, T, Bq, Kb, S_enc = 16, 9, 5, 9, 24
+    R = Bq * Kb
+    qs = (torch.randn(S, R, 3 * d, generator=g) * 3000).to(dev)
+    qb = torch.randn(3 * d, generator=g).to(dev)
+    qtot = qs[0]
+    for s in range(1, S):
+        qtot = qtot + qs[s]
+    qkv = qtot * alpha + qb
+    t = torch.tensor([4], dtype=torch.int64, device=dev)
+    caches = [(torch.randn(R, H, T, 64, generator=g)).to(dev) for _ in range(2)]
+    anc = torch.randint(0, R, (T, R), generator=g, dtype=torch.int32).to(dev)
+    k1, v1, a1, o1 = caches[0].clone(), caches[1].clone(), anc.clone(), torch.empty(R, d, device=dev)
+    check(lib().sealnn_self_attn_step(st, qkv.data_ptr(), k1.data_ptr(), v1.data_ptr(), t.data_ptr(), R, H, T, 0.125, o1.data_ptr(), a1.data_ptr()))
+    pl1 = torch.empty(R, 3 * d, dtype=torch.float16, device=dev)
+    check(lib().sealnn_split_planes(st, o1.data_ptr(), R, d, pl1.data_ptr(), flag.data_ptr()))
+    k2, v2, a2, o2, pl2 = caches[0].clone(), caches[1].clone(), anc.clone(), torch.empty(R, d, device=dev), torch.empty(R, 3 * d, dtype=torch.float16, device=dev)
+    check(lib().sealnn_self_attn_step_x(st, qs.data_ptr(), S, R * 3 * d, qb.data_ptr(), alpha, k2.data_ptr(), v2.data_ptr(), t.data_ptr(), R, H, T, 0.125,
+                                        o2.data_ptr(), pl2.data_ptr(), flag.data_ptr(), a2.data_ptr()))
+    assert torch.equal(o1, o2) and torch.equal(pl1, pl2) and torch.equal(k1, k2) and torch.equal(v1, v2) and torch.equal(a1, a2)
+    ck = torch.randn(Bq, H, 64, S_enc, generator=g).to(dev)
+    cv = torch.randn(Bq, H, S_enc, 64, generator=g).to(dev)
+    cb = torch.zeros(Bq, S_enc, device=dev)
+    cb[:, -3:] = torch.finfo(torch.float32).min
+    cq_s = (torch.randn(S, R, d, generator=g) * 3000).to(dev)
+    cqb = torch.randn(d, generator=g).to(dev)
+    ctot = cq_s[0]
+    for s in range(1, S):
+        ctot = ctot + cq_s[s]
+    cqv = (ctot * alpha + cqb).contiguous()
+    c1, c2, cp1, cp2 = torch.empty(R, d, device=dev), torch.empty(R, d, device=dev), torch.empty(R, 3 * d, dtype=torch.float16, device=dev), torch.empty(R, 3 * d, dtype=torch.float16, device=dev)
+    check(lib().sealnn_cross_attn_step(st, cqv.data_ptr(), ck.data_ptr(), cv.data_ptr(), cb.data_ptr(), Bq, Kb, H, S_enc, 0.125, c1.data_ptr()))
+    check(lib().sealnn_split_planes(st, c1.data_ptr(), R, d, cp1.data_ptr(), flag.data_ptr()))
+    check(lib().sealnn_cross_attn_step_x(st, cq_s.data_ptr(), S, R * d, cqb.data_ptr(), alpha, ck.data_ptr(), cv.data_ptr(), cb.data_ptr(), Bq, Kb, H, S_enc, 0.125,
+                                         c2.data_ptr(), cp2.data_ptr(), flag.data_ptr()))
+    assert torch.equal(c1, c2) and torch.equal(cp1, cp2) and int(flag.item()) == 0
+    # the step decoder: the hand-written products (d x d projections, qkv, fc2) against the library's
     from transformers import BartConfig, BartForConditionalGeneration
     from seal_amd.bart_decoder import BartStepDecoder
     torch.manual_seed(0)
