@@ -456,7 +456,8 @@ def cite_traffic(workload_tag, root=ROOT, now=None):
                 continue            # ... and so are counters taken on another workload (index size, beam): per-workload files
             # every launch of the constraint calls (k_constrain_rows + k_constrain of a row-first call; k_constrain_table + k_table_bits of a
             # decode's first step), summed over the run and divided by the CALLS (one k_constrain or one k_constrain_table each)
-            mine = {k: v["FETCH_SIZE"] for k, v in pmc.items() if isinstance(v, dict) and ("k_constrain" in k or "k_table_bits" in k)}
+            # (+ k_beam_advance: the rows' chains and list steps of the chained calls ride in that launch; its bookkeeping traffic comes along)
+            mine = {k: v["FETCH_SIZE"] for k, v in pmc.items() if isinstance(v, dict) and "FETCH_SIZE" in v and ("k_constrain" in k or "k_table_bits" in k or "k_beam_advance" in k)}
             calls = sum(c["launches"] for k, c in mine.items() if "k_constrain<" in k or "k_constrain_table" in k)
             kib = sum(c["sum"] for c in mine.values()) / calls if calls else 0
             if kib:

@@ -8,7 +8,7 @@ import csv
 import re
 import sys
 
-FAMILIES = ["k_constrain", "k_table_bits", "k_row_pick", "k_query_merge", "k_self_attn", "k_tree_self", "k_cross_attn", "k_add_layernorm", "k_gelu",
+FAMILIES = ["k_constrain", "k_table_bits", "k_beam_advance", "k_hgemm", "k_row_pick", "k_query_merge", "k_self_attn", "k_tree_self", "k_cross_attn", "k_add_layernorm", "k_gelu",
             "k_split_planes", "k_entries", "k_agg", "k_full_score", "k_mis", "rocprim"]
 TORCH = r"(direct_copy|CUDAFunctor_add|index_elementwise|_scatter_gather|vectorized_elementwise_kernel|layer_norm|gather|indexSelect|reduce_kernel|SoftMax|sort|topk|fill|cat|where|masked|arange|cumsum)"
 
