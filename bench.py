@@ -384,7 +384,7 @@ def retrieval_title_length():
     return retrieval.TITLE_MAX_LENGTH
 
 
-def score_parity(searcher, model, index, queries, bias, dev, n_rescore_queries=4, tol=1e-4):
+def score_parity(searcher, model, index, queries, bias, dev, n_rescore_queries=4, tol=1e-4, fp32_model=None):
     """The float half of parity at the bench's own geometry (BART-large, beam 15, batch 20): the body and title decodes of one
     batch are run once more exactly as the searcher issues them (retrieval.py:70-83,162-176), every hypothesis score the beam
     loop recorded is recomputed through HF's own cache-free fp32 forward (oracle/hf_scores.py), and the prefix-tree
@@ -420,6 +420,10 @@ def score_parity(searcher, model, index, queries, bias, dev, n_rescore_queries=4
         steps, final, nb, K, _ = pg._args
         out[name] = compare_beam_history(model, enc_ids, enc_mask, steps, final, nb, K, logit_bias=bias, tol=tol)
         out[name]["decoded_as"] = "one loop with the other decode (joint)" if s.joint_decode else "its own loop"
+        if fp32_model is not None:
+            # a reduced-precision decode (configs[4]) against the FP32 answer as well: distance, HF's own low-precision distance, rank changes
+            from oracle.hf_scores import compare_with_fp32_forward
+            out[name]["vs_fp32"] = compare_with_fp32_forward(model, fp32_model, enc_ids, enc_mask, steps, final, nb, K, logit_bias=bias)
     body_hyps = runs[0][1].result()
     nq = min(n_rescore_queries, len(queries))
     strip_ids = s.strip_token_ids
@@ -1127,10 +1131,25 @@ def main():
         t0 = time.perf_counter()
         lo_q = (args.warmup + args.steps) * args.batch
         score_tol = args.bf16_tol if stress else 1e-4
-        sp = score_parity(searcher, model, index, queries[lo_q:lo_q + args.batch], bias[lo_q:lo_q + args.batch], dev, tol=score_tol)
+        fp32_model = None
+        if stress:
+            # the same (bf16-representable) weights, computed in fp32: the FP32 answer  (a fresh module: the bf16 one carries captured graphs)
+            with torch.device(dev):
+                fp32_model = BartForConditionalGeneration(cfg)
+            fp32_model.load_state_dict({k: v.float() for k, v in model.state_dict().items()})
+            fp32_model.eval()
+        sp = score_parity(searcher, model, index, queries[lo_q:lo_q + args.batch], bias[lo_q:lo_q + args.batch], dev, tol=score_tol, fp32_model=fp32_model)
         if stress:
             for k in ("beam_scores_body", "beam_scores_title", "rescore_scores"):
                 sp[k]["arithmetic"] = "bf16 storage, fp32 accumulation, against HF's bf16 forward of the same weights (log-softmax in fp32 on both sides)"
+            # the criterion that means something: the recorded scores may be no further from the FP32 forward than 1.5 x what HF's own bf16
+            # forward is (floor 0.05) -- instead of a fixed 0.25 against HF's bf16 numbers
+            for k in ("beam_scores_body", "beam_scores_title"):
+                v = sp[k]["vs_fp32"]
+                v["tol_vs_fp32"] = max(0.05, 1.5 * v["hf_lowp_vs_hf_fp32_max_abs_err"])
+                v["violation"] = bool(v["max_abs_err_vs_hf_fp32"] > v["tol_vs_fp32"])
+                sp[k]["violations"] += int(v["violation"])
+            del fp32_model
         beam = {"values": sum(sp[k]["values"] for k in ("beam_scores_body", "beam_scores_title")),
                 "max_abs_err": max(sp[k]["max_abs_err"] for k in ("beam_scores_body", "beam_scores_title")), "tol": score_tol,
                 "mismatches": sum(sp[k]["violations"] for k in ("beam_scores_body", "beam_scores_title")),

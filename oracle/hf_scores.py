@@ -99,3 +99,54 @@ def compare_rescoring(model, inputs, keys, tol: float = 1e-4, **kw):
             viol += int(not err <= tol)
     return {"values": vals, "max_abs_err": worst, "violations": viol, "tol": tol,
             "against": "one decoder row per key through HF's forward (reference keys.py:64-141)"}
+
+
+@torch.no_grad()
+def recompute_beam_history(model, enc_ids, enc_mask, steps, final, batch: int, num_beams: int, logit_bias: Optional[torch.Tensor] = None):
+    """the recorded history's scores recomputed through ``model``'s cache-free forward: [(scores [B, 2K]) per step], final [B * K]"""
+    dev = enc_ids.device
+    B, K = batch, num_beams
+    out = []
+    for prefix, tokens, scores in steps:
+        n = prefix.shape[1]
+        seqs = torch.cat([prefix, tokens.unsqueeze(-1)], dim=-1).view(B * n, -1)
+        q = torch.arange(B, device=dev).repeat_interleave(n)
+        out.append(hf_path_logprob_sums(model, enc_ids, enc_mask, seqs, q, logit_bias).view(B, n))
+    ids, _ = final
+    q = torch.arange(B, device=dev).repeat_interleave(K)
+    return out, hf_path_logprob_sums(model, enc_ids, enc_mask, ids, q, logit_bias)
+
+
+@torch.no_grad()
+def compare_with_fp32_forward(model_lowp, model_fp32, enc_ids, enc_mask, steps, final, batch: int, num_beams: int,
+                              logit_bias: Optional[torch.Tensor] = None):
+    """A reduced-precision decode (configs[4]: bf16 storage) against the FP32 answer: the recorded scores vs HF's fp32 forward of the same
+    weights widened to fp32, HF's own reduced-precision forward vs the same (what the storage type costs by itself), and how many
+    recorded candidates would sit at another rank within their step's 2K if the fp32 scores ordered them (a reordered beam is what an
+    error of this size can do; a bound on the summed log-probs alone does not say)."""
+    B, K = batch, num_beams
+    ref_steps, ref_final = recompute_beam_history(model_fp32, enc_ids, enc_mask, steps, final, B, K, logit_bias.float() if logit_bias is not None else None)
+    low_steps, low_final = recompute_beam_history(model_lowp, enc_ids, enc_mask, steps, final, B, K, logit_bias)
+    worst_prod = worst_hf = 0.0
+    ranked = moved = 0
+    for (prefix, tokens, scores), ref, low in zip(steps, ref_steps, low_steps):
+        got = scores.float()
+        m = torch.isfinite(got) & torch.isfinite(ref) & (got > -1e8)
+        if bool(m.any()):
+            worst_prod = max(worst_prod, float((got[m] - ref[m]).abs().max()))
+            worst_hf = max(worst_hf, float((low.float()[m] - ref[m]).abs().max()))
+        # rank within the step's 2K candidates of a query, by the recorded scores and by the fp32 ones (stable: ties keep the recorded order)
+        g = torch.where(m, got, torch.full_like(got, -1e30))
+        r = torch.where(m, ref, torch.full_like(ref, -1e30))
+        rg = torch.argsort(torch.argsort(-g, dim=1, stable=True), dim=1)
+        rr = torch.argsort(torch.argsort(-r, dim=1, stable=True), dim=1)
+        ranked += int(m.sum())
+        moved += int(((rg != rr) & m).sum())
+    gf = final[1].float()
+    mf = torch.isfinite(gf) & torch.isfinite(ref_final) & (gf > -1e8)
+    if bool(mf.any()):
+        worst_prod = max(worst_prod, float((gf[mf] - ref_final[mf]).abs().max()))
+        worst_hf = max(worst_hf, float((low_final.float()[mf] - ref_final[mf]).abs().max()))
+    return {"max_abs_err_vs_hf_fp32": worst_prod, "hf_lowp_vs_hf_fp32_max_abs_err": worst_hf, "candidates_ranked": ranked,
+            "candidates_at_another_rank_under_fp32_scores": moved, "rank_changed_fraction": (moved / ranked) if ranked else 0.0,
+            "against": "HF BartForConditionalGeneration, the same weights widened to fp32, cache-free forward"}

@@ -11,10 +11,15 @@ KERNELS = ("k_agg_locate", "k_mis_prepare", "k_mis", "k_doc_keys", "k_heads", "k
 
 
 def reduce(path, counter):
+    """per kernel family [launches, sum] -- of the dispatches from the first k_agg_locate on: the index BUILD in front of it launches kernels
+    of the same names (k_heads, k_scatter_*, rocPRIM sorts over 2.9 G suffixes) that are not the aggregation's"""
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    key = "Dispatch_Id" if rows and "Dispatch_Id" in rows[0] else None
+    if key:
+        rows.sort(key=lambda r: int(r[key]))
+    first = next((i for i, r in enumerate(rows) if "k_agg_locate" in r["Kernel_Name"]), 0)
     acc = defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
-            continue
+    for r in rows[first:]:
         name = r["Kernel_Name"]
         fam = next((k for k in KERNELS if k in name), None)
         if fam is None:
