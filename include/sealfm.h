@@ -261,7 +261,16 @@ int fmi_dev_debug_timestamps(fmi_t *h, uint64_t *d_buf, uint64_t n_words);
  * "prefix_tables" (0: the first constrained step of a decode through the generic expansion instead of the per-token node tables),
  * "table_grid" (workgroups of the table call's flat pass),
  * "topk_narrow" (rows with more allowed tokens take the wide-row path of the top-2K kernel), "topk_legacy" (1: exact radix
- * select on wide rows).  Results are identical for every setting (tests/test_gpu_fmindex.py, tests/test_gpu_decode.py). */
+ * select on wide rows), "chain_steps" (0: fmi_dev_beam_step leaves the rows' chains to the next constraint call),
+ * "advance_apart" (measurement passes: 0 = k_beam_advance as the product's one launch, timed whole), "pt_inject_failure"
+ * (tests: building a prefix table fails).  Results are identical for every setting (tests/test_gpu_fmindex.py, tests/test_gpu_decode.py).
+ *
+ * "leave_early" = 1 (the default): a wave of k_constrain whose (row, top digit) item is empty ENDS before its workgroup's barriers.
+ * That relies on the documented behaviour of the gfx9 / CDNA barrier -- "S_BARRIER: Synchronize waves within a threadgroup. [...] If
+ * some waves in the threadgroup have already terminated, this waits on only the surviving waves" (AMD Instinct MI300 / CDNA3 ISA
+ * reference guide, SOPP instructions, S_BARRIER; the barrier counts a workgroup's waves that have not executed s_endpgm) -- not on
+ * the HIP programming model, which leaves __syncthreads() in divergent code undefined: the kernels are gfx950-only, the condition is
+ * wave-uniform (a scalar branch: a whole wave leaves or stays), and the GPU tests run every constraint form with 0 and 1. */
 int fmi_dev_set_option(fmi_t *h, const char *name, int64_t value);
 
 /* The per-token node tables this handle has built so far (one per forced prefix of a decode; the first constrained step of a decode

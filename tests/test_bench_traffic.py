@@ -50,3 +50,45 @@ def test_counters_of_other_kernels_or_workloads_are_refused(tmp_path):
     with open(os.path.join(root, "seal_amd", "csrc", "fmi_kernels.hip"), "ab") as f:
         f.write(b"// edit")
     assert bench.cite_traffic("nq-36", root)[0] is None
+
+
+def test_by_call_adds_the_chains_to_the_call_they_precede():
+    """``bench.merge_call_logs``: three passes over one batch -> one record per constraint call.  The chains that k_beam_advance ran for a
+    call a model step ahead are charged to that call: what they add to the launch they ride in (fused duration - bookkeeping duration, never
+    below zero), with the chains as a launch of their own as the upper bound; a pass that launched something else voids the attribution."""
+    import bench
+    def rec(cur_len, rows, form, us=-1.0, blocks=0):
+        return {"cur_len": cur_len, "rows": rows, "form": form, "us": us, "blocks": blocks}
+    timed = [rec(2, 600, "table", 60.0), rec(3, 600, "advance", 8.0), rec(3, 600, "advance+chains", 15.0), rec(3, 600, "chained", 50.0),
+             rec(4, 600, "advance", 9.0), rec(4, 600, "advance+chains", 14.0), rec(4, 600, "chained", 20.0), rec(5, 300, "advance", 8.5)]
+    counted = [rec(2, 600, "table", blocks=1000000), rec(3, 600, "advance"), rec(3, 600, "advance+chains", blocks=8000), rec(3, 600, "chained", blocks=500000),
+               rec(4, 600, "advance"), rec(4, 600, "advance+chains", blocks=4000), rec(4, 600, "chained", blocks=100000), rec(5, 300, "advance")]
+    fused = [rec(2, 600, "table", 61.0), rec(3, 600, "advance+chains", 18.0), rec(3, 600, "chained", 50.0), rec(4, 600, "advance+chains", 8.0),
+             rec(4, 600, "chained", 20.0), rec(5, 300, "advance", 8.4)]
+    calls, other = bench.merge_call_logs(timed, counted, fused)
+    assert [(c["cur_len"], c["form"]) for c in calls] == [(2, "table"), (3, "chained"), (4, "chained")]
+    assert calls[0]["us"] == 60.0 and calls[0]["MB"] == 128.0 and "chains_us" not in calls[0]
+    assert calls[1]["chains_us"] == 10.0 and calls[1]["chains_alone_us"] == 15.0 and calls[1]["us"] == 60.0 and calls[1]["us_upper_bound"] == 65.0
+    assert abs(calls[1]["MB"] - (500000 + 8000) * 128 / 1e6) < 1e-3 and abs(calls[1]["frac"] - calls[1]["MB"] / 60.0 / 8000 * 1e3) < 1e-3
+    assert calls[2]["chains_us"] == 0.0 and calls[2]["us"] == 20.0                       # (fused < bookkeeping on that step: nothing is subtracted)
+    assert [o["cur_len"] for o in other] == [3, 4, 5] and other[0]["fused_with_chains_us"] == 18.0
+    # without the fused pass the chains are charged as their own launch
+    calls2, _ = bench.merge_call_logs(timed, counted, None)
+    assert calls2[1]["chains_us"] == 15.0 and calls2[1]["us"] == 65.0
+    # the counting pass launched another sequence: no attribution at all
+    assert bench.merge_call_logs(timed, counted[:-1], fused) == ([], [])
+
+
+def test_aggregate_roofline_prices_the_stages_from_what_they_processed():
+    import bench
+
+    class Ix:
+        def size(self):
+            return 2_879_038_742
+    t = {"stage_ms": [0.2332, 0.4552, 0.1637, 0.3962, 0.0666, 0.2348, 1.1196, 0.0175, 0.3592, 0.0933, 0.0936], "counts": [5775748, 5699723, 30000, 2000, 4250343], "calls": 1}
+    r = bench.aggregate_roofline(t, Ix())
+    loc = r["stages"][0]
+    assert loc["stage"] == "k_agg_locate" and abs(loc["algorithmic_MB"] - 5775748 * 36 / 1e6) < 0.01       # SA 4 + hint 4 + boundary 8 + 20 B written
+    assert abs(loc["achieved"] - 5775748 * 36 / 233.2e-6 / 1e9) < 1.0 and r["frac"] == loc["frac"] and r["kernel"] == "k_agg_locate"
+    assert "algorithmic_MB" not in r["stages"][1] and r["located_rows"] == 5775748 and abs(r["total_us"] - sum(t["stage_ms"]) * 1e3) < 0.1
+    assert bench.aggregate_roofline({"stage_ms": [0] * 11, "counts": [0] * 5, "calls": 0}, Ix()) is None
