@@ -28,6 +28,8 @@ import logging
 
 
 logger = logging.getLogger(__name__)
+# the encoder's linear layers through the split GEMM as well (SEAL_ENCODER_SPLIT=0: HF's own encoder layers, fp32 library GEMMs)
+ENCODER_SPLIT = __import__("os").environ.get("SEAL_ENCODER_SPLIT", "1") == "1"
 
 class BartStepDecoder:
     def __init__(self, model):
@@ -182,9 +184,38 @@ class BartStepDecoder:
             mask = keep
         else:
             mask = torch.zeros(B, 1, S, S, dtype=x.dtype, device=x.device).masked_fill_(~keep, torch.finfo(x.dtype).min)
+        if (x.is_cuda and x.dtype == torch.float32 and self._planes_on(x.view(B * S, -1)) and ENCODER_SPLIT
+                and all(getattr(l.activation_fn, "__class__", type(None)).__name__ in ("GELUActivation", "GELU")
+                        and getattr(l.activation_fn, "approximate", "none") == "none" for l in enc.layers)):
+            # The encoder's linear layers through the split GEMM too (round 5: they were 72 fp32 library launches of ~41 us per batch of 60
+            # inputs, 5 ms of a 63 ms step): the layer written out with this module's `_lin` (q, k, v as one product), torch's fused attention
+            # and LayerNorm in between -- the same arithmetic as BartEncoderLayer.forward (post-LN), products at fp32 accuracy (split_gemm.py).
+            x2 = x.reshape(B * S, -1)
+            H, dh = enc.layers[0].self_attn.num_heads, enc.layers[0].self_attn.head_dim
+            for layer in enc.layers:
+                sa = layer.self_attn
+                w, b = self._encoder_qkv(layer)
+                qkv = self._lin(x2, w, b).view(B, S, 3, H, dh)
+                q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+                a = F.scaled_dot_product_attention(q, k, v, attn_mask=keep, scale=float(sa.scaling))
+                y = self._lin(a.transpose(1, 2).reshape(B * S, H * dh), sa.out_proj.weight, sa.out_proj.bias)
+                x2 = layer.self_attn_layer_norm(x2 + y)
+                h = layer.activation_fn(self._lin(x2, layer.fc1.weight, layer.fc1.bias))
+                x2 = layer.final_layer_norm(x2 + self._lin(h, layer.fc2.weight, layer.fc2.bias))
+            return x2.view(B, S, -1)
         for layer in enc.layers:
             x = layer(x, mask)
         return x
+
+    def _encoder_qkv(self, layer):
+        """(weight [3d, d], bias [3d]) of an encoder layer's q / k / v projections as one product, made once"""
+        cache = self.__dict__.setdefault("_enc_qkv", {})
+        wb = cache.get(id(layer))
+        if wb is None:
+            sa = layer.self_attn
+            wb = cache[id(layer)] = (torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0).detach().contiguous(),
+                                     torch.cat([sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias], 0).detach().contiguous())
+        return wb
 
     # ------------------------------------------------------------------
     # static-shape state: one set of buffers (and one hipGraph) per
