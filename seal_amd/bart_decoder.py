@@ -207,6 +207,14 @@ class BartStepDecoder:
             x = layer(x, mask)
         return x
 
+    def _ckv(self, enc_hidden: torch.Tensor, L) -> torch.Tensor:
+        """the cross-attention K / V projection of the encoder states, one product per layer ([B, S, d] -> [B, S, 2d]); through the split GEMM
+        where that pays (fp32 on the GPU, enough rows), F.linear otherwise"""
+        if enc_hidden.is_cuda and enc_hidden.dtype == torch.float32 and enc_hidden.dim() == 3 and ENCODER_SPLIT:
+            B, S, d = enc_hidden.shape
+            return self._lin(enc_hidden.reshape(B * S, d), L["ckv_w"], L["ckv_b"]).view(B, S, -1)
+        return F.linear(enc_hidden, L["ckv_w"], L["ckv_b"])
+
     def _encoder_qkv(self, layer):
         """(weight [3d, d], bias [3d]) of an encoder layer's q / k / v projections as one product, made once"""
         cache = self.__dict__.setdefault("_enc_qkv", {})
@@ -274,7 +282,7 @@ class BartStepDecoder:
         B, S, _ = enc_hidden.shape
         cross = []
         for L in self.layers:
-            kv = F.linear(enc_hidden, L["ckv_w"], L["ckv_b"]).view(B, S, 2, self.h, self.dh)
+            kv = self._ckv(enc_hidden, L).view(B, S, 2, self.h, self.dh)
             cross.append((kv[:, :, 0].permute(0, 2, 3, 1).contiguous(), kv[:, :, 1].permute(0, 2, 1, 3).contiguous()))
         bias = torch.zeros(B, S, dtype=enc_hidden.dtype, device=enc_hidden.device)
         bias.masked_fill_(attention_mask == 0, torch.finfo(enc_hidden.dtype).min)
@@ -382,7 +390,7 @@ class BartStepDecoder:
             w = torch.softmax(torch.einsum("nhd,nahd->nha", q, ka) + self_bias, dim=-1)
             a = torch.einsum("nha,nahd->nhd", w, va).reshape(N, self.d)
             x = L["ln1"](x + L["so"](a))
-            kv = F.linear(enc_hidden, L["ckv_w"], L["ckv_b"]).view(B, S, 2, H, dh)
+            kv = self._ckv(enc_hidden, L).view(B, S, 2, H, dh)
             cq = (L["cq"](x) * self.scale).view(N, H, dh)
             w = torch.softmax(torch.einsum("nhd,nshd->nhs", cq, kv[:, :, 0][qidx]) + cross_bias, dim=-1)
             c = torch.einsum("nhs,nshd->nhd", w, kv[:, :, 1][qidx]).reshape(N, self.d)
@@ -693,7 +701,7 @@ class BartStepDecoder:
             if tail.graph is None:
                 self._capture(tail, enc_hidden.device)
         for li, L in enumerate(self.layers):
-            kv = F.linear(enc_hidden, L["ckv_w"], L["ckv_b"]).view(B, S, 2, self.h, self.dh)
+            kv = self._ckv(enc_hidden, L).view(B, S, 2, self.h, self.dh)
             st.ck[li, :, :, :, :S] = kv[:, :, 0].permute(0, 2, 3, 1)
             st.cv[li, :, :, :S] = kv[:, :, 1].permute(0, 2, 1, 3)
         st.cbias.fill_(torch.finfo(enc_hidden.dtype).min)
@@ -713,7 +721,7 @@ class BartStepDecoder:
         dt, dev = enc_hidden.dtype, enc_hidden.device
         self.cross = []
         for L in self.layers:
-            kv = F.linear(enc_hidden, L["ckv_w"], L["ckv_b"]).view(B, S, 2, self.h, self.dh)
+            kv = self._ckv(enc_hidden, L).view(B, S, 2, self.h, self.dh)
             k = kv[:, :, 0].permute(0, 2, 3, 1).contiguous()      # [B, H, dh, S]
             v = kv[:, :, 1].permute(0, 2, 1, 3).contiguous()      # [B, H, S, dh]
             self.cross.append((k, v))

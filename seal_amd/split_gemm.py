@@ -227,10 +227,18 @@ class SplitLinears:
         return rows >= MIN_ROWS and k % 4 == 0 and macs >= (MIN_MACS_WITH_PLANES if have_planes else MIN_MACS_WITH_SPLIT_PASS)
 
     def _of(self, weight, bias) -> SplitLinear:
+        # keyed by the weight's storage address, VALIDATED by the tensor object itself and its version counter: an address is reused once a
+        # model is freed (a second model loaded into the same process got the first one's planes: found by a test that builds two models)
+        # and a checkpoint loaded in place keeps its address
+        import weakref
         key = (weight.data_ptr(), tuple(weight.shape))
-        lin = self._by_weight.get(key)
-        if lin is None:
-            lin = self._by_weight[key] = SplitLinear(weight, bias)
+        hit = self._by_weight.get(key)
+        if hit is not None:
+            ref, version, lin = hit
+            if ref() is weight and version == weight._version:
+                return lin
+        lin = SplitLinear(weight, bias)
+        self._by_weight[key] = (weakref.ref(weight), weight._version, lin)
         return lin
 
     def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias=None, defer: bool = False):
