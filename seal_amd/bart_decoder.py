@@ -184,24 +184,30 @@ class BartStepDecoder:
             mask = keep
         else:
             mask = torch.zeros(B, 1, S, S, dtype=x.dtype, device=x.device).masked_fill_(~keep, torch.finfo(x.dtype).min)
-        if (x.is_cuda and x.dtype == torch.float32 and self._planes_on(x.view(B * S, -1)) and ENCODER_SPLIT
+        if (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == self.d and self._planes_on(x.view(B * S, -1)) and ENCODER_SPLIT
                 and all(getattr(l.activation_fn, "__class__", type(None)).__name__ in ("GELUActivation", "GELU")
                         and getattr(l.activation_fn, "approximate", "none") == "none" for l in enc.layers)):
             # The encoder's linear layers through the split GEMM too (round 5: they were 72 fp32 library launches of ~41 us per batch of 60
             # inputs, 5 ms of a 63 ms step): the layer written out with this module's `_lin` (q, k, v as one product), torch's fused attention
             # and LayerNorm in between -- the same arithmetic as BartEncoderLayer.forward (post-LN), products at fp32 accuracy (split_gemm.py).
-            x2 = x.reshape(B * S, -1)
+            # (residual + LayerNorm and GELU through the decoder's fused kernels: they apply the products' epilogues as they read them and
+            #  write the next product's operand planes -- no bias copy, no split pass, no separate GELU between the products)
+            x2 = x.reshape(B * S, -1).contiguous()
+            rows = B * S
             H, dh = enc.layers[0].self_attn.num_heads, enc.layers[0].self_attn.head_dim
+            L_ = self._nn(x2.dtype)
+            stream = torch.cuda.current_stream(x2.device).cuda_stream
+            xp = self._planes_of(x2)
             for layer in enc.layers:
                 sa = layer.self_attn
                 w, b = self._encoder_qkv(layer)
-                qkv = self._lin(x2, w, b).view(B, S, 3, H, dh)
+                qkv = self._lin_p(x2, xp, w, b).view(B, S, 3, H, dh)
                 q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
                 a = F.scaled_dot_product_attention(q, k, v, attn_mask=keep, scale=float(sa.scaling))
-                y = self._lin(a.transpose(1, 2).reshape(B * S, H * dh), sa.out_proj.weight, sa.out_proj.bias)
-                x2 = layer.self_attn_layer_norm(x2 + y)
-                h = layer.activation_fn(self._lin(x2, layer.fc1.weight, layer.fc1.bias))
-                x2 = layer.final_layer_norm(x2 + self._lin(h, layer.fc2.weight, layer.fc2.bias))
+                y = self._lin(a.transpose(1, 2).reshape(rows, H * dh), sa.out_proj.weight, sa.out_proj.bias, defer=True)
+                x2, xp = self._add_ln(L_, stream, x2, y, layer.self_attn_layer_norm, rows, True)
+                ffn = self._ffn(x2, xp, {"fc1": layer.fc1, "fc2": layer.fc2, "act": layer.activation_fn}, defer=True)
+                x2, xp = self._add_ln(L_, stream, x2, ffn, layer.final_layer_norm, rows, True)
             return x2.view(B, S, -1)
         for layer in enc.layers:
             x = layer(x, mask)
