@@ -398,6 +398,69 @@ def test_masks_the_beam_step_applies_equal_the_oracle_masks_row_by_row(kw, chain
 
 
 @pytest.mark.gpu
+def test_chains_run_for_a_call_that_never_comes_do_not_leak_into_the_next_one():
+    """``k_beam_advance`` writes list rows' tokens into the workspace bitmap the NEXT constraint call will fill.  If that call never comes --
+    the loop is abandoned, or another kind of call uses the handle next -- the pre-filled bits must not show up in it: a protocol call
+    (``IndexBasedLogitsProcessor.__call__`` -> ``fmi_dev_constrain_scores``, which takes its bitmap from the same workspace) right after a
+    chained step still gives the oracle's mask, and so does a fresh decode loop on the same handle afterwards."""
+    import numpy as np
+    from oracle.beam_oracle import oracle_logits_mask
+    from oracle.seal_oracle import OracleFMIndex
+    from seal_amd import FMIndex
+    from seal_amd.beam_search import IndexBasedLogitsProcessor, _BeamStepper, constrained_beam_search
+    from tests.helpers import make_docs
+    vocab, B, K = 60, 3, 5
+    dev = torch.device("cuda:0")
+    docs = make_docs(21, 80, vocab - 8, min_len=4, max_len=9, title_sep=7)
+    ix, orc = FMIndex(), OracleFMIndex()
+    ix.initialize(docs)
+    orc.initialize(docs)
+    proc = IndexBasedLogitsProcessor(ix, K, pad_token_id=1, eos_token_id=2)
+    spec = [dict(batch=B, max_length=8, eos_token_id=2, processor=proc)]
+    stepper = _BeamStepper(spec, K, 2, dev)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for cur in (1, 2, 3):                                     # the last of them runs chains (and pre-fills bits) for a 4th call ...
+        lg = (torch.randn(B * K, vocab, generator=g) * 3).to(dev)
+        lg[:, 0] = float("-inf")
+        stepper.step([0], lg, cur, tag=777, chain_next=cur >= 2, tokens_out=None, anc=None)
+    # ... that never comes: a protocol call on arbitrary rows instead
+    rng = np.random.default_rng(3)
+    rows = []
+    for _ in range(B * K):
+        d = docs[int(rng.integers(len(docs)))]
+        a = int(rng.integers(len(d) - 2))
+        rows.append([2] + d[a:a + 2])
+    scores = torch.randn(len(rows), vocab, device=dev)
+    out = proc(torch.tensor(rows, device=dev), scores)
+    allowed = torch.from_numpy(oracle_logits_mask(orc, rows, vocab, K, pad_token_id=1, eos_token_id=2)).to(dev)
+    assert torch.equal(out, torch.where(allowed, scores, torch.full_like(scores, float("-inf"))))
+    # and a whole new loop on the same handle: every applied mask is the oracle's
+
+    class Logits:
+        t = 0
+
+        def step(self, tokens):
+            gg = torch.Generator(device="cpu").manual_seed(500 + self.t)
+            self.t += 1
+            lg = torch.randn(B * K, vocab, generator=gg) * 3
+            lg[:, 0] = float("-inf")
+            return lg.to(dev)
+
+        def reorder(self, beam_idx):
+            pass
+    trace = []
+    ix.set_trace(trace)
+    constrained_beam_search(Logits(), B, K, 7, 2, 2, proc, device=dev)
+    ix.set_trace(None)
+    masks = [op for op in trace if op[0] == "mask"]
+    assert len(masks) == 5
+    for op in masks:
+        got = np.unpackbits(op[4].cpu().numpy().view(np.uint8), axis=1, bitorder="little")[:, :vocab].astype(bool)
+        want = oracle_logits_mask(orc, op[1].tolist(), vocab, K, pad_token_id=1, eos_token_id=2)
+        assert np.array_equal(got, np.asarray(want, dtype=bool)), len(op[1][0])
+
+
+@pytest.mark.gpu
 def test_topk_selection_paths_agree_on_ties(monkeypatch):
     """k_row_pick has two selection paths (bitmap gather for rows of <= 1024 allowed tokens, lower bound + collect beyond);
     on heavily tied logits both must return the same picks in the same order (ties go to the lower token id)."""
