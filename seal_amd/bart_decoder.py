@@ -551,7 +551,16 @@ class BartStepDecoder:
                 x, xp = add_ln(x, y, L["ln2"])
                 x, xp = add_ln(x, self._ffn(x, xp, L, defer=True), L["ln3"])
             st.t.add_(1)
-            return self._lin_p(x, xp, self.lm_w, self.lm_b.view(-1)).float()
+            # The output projection leaves the graph as RAW accumulators when it goes through the split GEMM: its epilogue (alpha * acc +
+            # final_logits_bias) is applied by `step` in the same pass that adds a per-query logit bias, if there is one -- torch.addmm would
+            # first copy the broadcast bias into the [rows, vocab] output (120 MB at 600 rows) and have the GEMM read it back.
+            y = self._lin_p(x, xp, self.lm_w, self.lm_b.view(-1), defer=True)
+            if isinstance(y, split_gemm.Deferred) and y.slabs == 1:
+                st.lm_epilogue = (float(y.alpha), y.bias)
+                return y.acc
+            st.lm_epilogue = None
+            return (y.value() if isinstance(y, split_gemm.Deferred) else y).float()
+        st.lm_epilogue = None
         future = st.pos_idx > st.t                                   # cache slots not written yet
         for li, L in enumerate(self.layers):
             qkv = F.linear(x, L["qkv_w"], L["qkv_b"]).view(R, 3, H, dh)
@@ -747,6 +756,15 @@ class BartStepDecoder:
             return
         self.kv[:, :, :, :, :self.t] = self.kv[:, :, beam_idx, :, :self.t]
 
+    def _bias_per_query(self, bias: torch.Tensor) -> torch.Tensor:
+        """final_logits_bias + the per-query logit bias, [batch, vocab]; made once per (bias tensor) and reused by the steps of a decode"""
+        import weakref
+        lb = self.logit_bias
+        hit = self.__dict__.get("_bias_q")           # (validated by the tensor OBJECTS and the version: an address alone is reused)
+        if hit is None or hit[0]() is not lb or hit[1] != lb._version or hit[2]() is not bias:
+            hit = self.__dict__["_bias_q"] = (weakref.ref(lb), lb._version, weakref.ref(bias), bias[None, :] + lb)
+        return hit[3]
+
     def step_buffers(self):
         """(token buffer, ancestry table) of the static fused decode state, for a caller that advances the beams on the device
         (``fmi_dev_beam_step``): the next step's input tokens are written straight into the buffer ``step`` reads, and re-ranking the
@@ -777,6 +795,12 @@ class BartStepDecoder:
             st.graph.replay()
             self.t += 1
             logits = st.logits
+            ep = getattr(st, "lm_epilogue", None)
+            if ep is not None:
+                alpha, bias = ep                                       # (alpha a power of two: alpha * acc is exact, one rounding in the add)
+                if self.logit_bias is not None:
+                    return torch.add(self._bias_per_query(bias)[:, None, :], logits.view(B, K, -1), alpha=alpha).view(R, -1)
+                return torch.add(bias, logits, alpha=alpha)
             if self.logit_bias is not None:
                 logits = (logits.view(B, K, -1) + self.logit_bias[:, None, :]).view(R, -1)
             return logits
