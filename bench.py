@@ -916,6 +916,27 @@ def main():
         other_qps = args.batch * args.steps * world / t2
         searcher.first_stage_only = args.first_stage_only
 
+    # same-box A/B of an environment switch the product reads per call (SEAL_BENCH_AB=SEAL_RESCORE_AHEAD): the same K batches with the switch
+    # at 0 and at 1, alternating, after the timed run -- boxes differ by +-15 %, two runs on two boxes say nothing about a 3 % change
+    ab = None
+    if os.environ.get("SEAL_BENCH_AB") and not use_dist:
+        var, ab = os.environ["SEAL_BENCH_AB"], {"switch": os.environ["SEAL_BENCH_AB"], "0": [], "1": []}
+        saved = os.environ.get(var)
+        for rep in range(int(os.environ.get("SEAL_BENCH_AB_REPS", 3))):
+            for val in ("0", "1"):
+                os.environ[var] = val
+                run_batch(0)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                run_batches(args.warmup, args.steps)
+                torch.cuda.synchronize()
+                ab[val].append(round(args.batch * args.steps / (time.perf_counter() - t2), 1))
+        if saved is None:
+            os.environ.pop(var, None)
+        else:
+            os.environ[var] = saved
+        print("[bench] A/B %s: queries/s with 0: %s, with 1: %s" % (var, ab["0"], ab["1"]), file=sys.stderr, flush=True)
+
     if rank != 0:
         if use_dist:
             dist.barrier()
@@ -1200,7 +1221,7 @@ def main():
                   "decode_step_gemm_algorithms": "library default (hipBLASLt heuristic); round 3's TunableOp picks are gone: one of them stalled the search (DESIGN.md 9)",
                   "phase_ms_one_batch": {k: round(v, 2) for k, v in phases.items()},
                   "k_constrain_ms_one_batch": round(k2.value, 3), "k_constrain_blocks_one_batch": int(p2.value),
-                  "prefix_tables": _prefix_table_stats(index)},
+                  "prefix_tables": _prefix_table_stats(index), **({"same_box_ab_qps": ab} if ab else {})},
     }
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:

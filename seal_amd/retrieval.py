@@ -848,6 +848,7 @@ class SEALSearcher:
                 print("[seal_amd] WARNING: decode and rescoring share the GPU (two library-GEMM streams): this configuration can stall",
                       file=sys.stderr, flush=True)
         depth = max(1, int(os.environ.get("SEAL_OVERLAP_DEPTH", self.overlap_depth if exclusive else 1)))
+        rescore_ahead = os.environ.get("SEAL_RESCORE_AHEAD", "1") != "0"   # (the round-4 order, for same-box comparisons: bench.py SEAL_BENCH_AB)
         ahead = []                                            # generators whose decodes are enqueued, oldest first
         nxt_i = 0
         main = torch.cuda.current_stream(dev)
@@ -875,7 +876,11 @@ class SEALSearcher:
             ahead.append([g, state])
             nxt_i += 1
 
+        ORDER = {"body": 0, "decoding": 1, "decoded": 2, "rescoring": 3}
+
         def advance(entry, upto):
+            if ORDER[entry[1]] >= ORDER[upto]:
+                return                                        # (already there: a batch's rescoring may have been enqueued one iteration early)
             decodes = entry[1] in ("body",) and upto in ("decoding", "decoded", "rescoring")     # a title decode still to be enqueued
             if decodes:
                 wait_for("rescore", main)
@@ -883,6 +888,32 @@ class SEALSearcher:
                 entry[1] = next(entry[0])
                 if decodes and entry[1] == "decoding":
                     after("decode", main)
+
+        def to_rescoring(entry):
+            """the batch's hypotheses on the host, its filters run, its rescoring forward enqueued on the post stream (fenced behind the decodes
+            enqueued so far); entry[2] = how often its gate was called"""
+            if ORDER[entry[1]] >= ORDER["rescoring"]:
+                return
+            advance(entry, "decoded")
+            gated = [0]
+            entry.append(gated)
+
+            def gate():
+                gated[0] += 1
+                wait_for("decode", post)
+            entry.append(gate)
+            self.__dict__["_gemm_gate"] = gate                # (read by _batch_steps when it reaches a forward)
+            try:
+                with torch.cuda.stream(post):
+                    advance(entry, "rescoring")
+            finally:
+                self.__dict__.pop("_gemm_gate", None)
+            after("rescore", post)
+        # the aggregation's own launches (key counts, locate, evidence kernels) and the host's waits for them: the index's retrieval stream,
+        # NOT the post stream -- a count read-back there would queue behind the next batch's rescoring forward (round 5)
+        agg_stream = self.__dict__.get("_agg_stream")
+        if agg_stream is None or agg_stream.device != dev:
+            agg_stream = self.__dict__["_agg_stream"] = torch.cuda.Stream(device=dev)
         enqueue_next()
         if exclusive and len(batches) > 1 and depth > 1:
             enqueue_next()                                    # one decode ahead of the batch the loop starts with
@@ -900,21 +931,9 @@ class SEALSearcher:
                     enqueue_next("body" if len(ahead) == 0 else "decoding")
             t2 = time.perf_counter()
             # (the filters' count launch and copies run beside the decodes; only the rescoring forward is fenced, from inside the step)
-            gated = [0]
-
-            def gate():
-                gated[0] += 1
-                wait_for("decode", post)
-            self.__dict__["_gemm_gate"] = gate                # stays installed until this batch's keys are back (forwards after the yield)
-            try:
-                with torch.cuda.stream(post):
-                    advance(cur, "rescoring")
-            except BaseException:
-                self.__dict__.pop("_gemm_gate", None)
-                raise
-            after("rescore", post)
+            to_rescoring(cur)                                 # (a no-op when the previous iteration did it already, below)
             if exclusive:
-                # GPU order: decode(i+1) [enqueued one iteration ago] -> rescoring(i) [just enqueued: it waits for that decode only] ->
+                # GPU order: decode(i+1) [enqueued one iteration ago] -> rescoring(i) [it waits for that decode only] ->
                 # decode(i+2) [enqueued now: it waits for the rescoring] -- the scores of batch i are back after ONE decode and the
                 # GPU has the next decode queued while the host aggregates batch i
                 for entry in ahead:
@@ -929,7 +948,9 @@ class SEALSearcher:
                 yield from held
                 held = None
             with torch.cuda.stream(post):
+                gated, gate = cur[2], cur[3]
                 late = gated[0]
+                self.__dict__["_gemm_gate"] = gate            # (forwards after the "rescoring" yield: non-default configurations)
                 try:
                     next(cur[0])
                     raise RuntimeError("_batch_steps yielded more often than expected")
@@ -940,12 +961,21 @@ class SEALSearcher:
                 if gated[0] != late:
                     # a forward ran after the yield (non-default configurations): the decodes enqueued from here on wait for it as well
                     after("rescore", post)
-                jobs = [(kk[0], kk[1]) if isinstance(kk, tuple) else (kk, None) for kk in keys]
+            t3 = time.perf_counter()
+            if exclusive and ahead and rescore_ahead:
+                # The NEXT batch's filters and rescoring forward are enqueued BEFORE this batch's aggregation (round 5): its decode finished
+                # before this batch's rescoring did, so its hypotheses are on the host already; the forward waits (event) for the decode
+                # enqueued above.  The GPU then holds decode(i+2) -> rescoring(i+1) while the host walks through ~20 ms of deduplication,
+                # key scoring and aggregation of batch i -- which used to sit between "scores of batch i" and "rescoring(i+1) enqueued" and
+                # left the GPU idle once decode + rescoring had become shorter than that stretch of host work.
+                to_rescoring(ahead[0])
+            jobs = [(kk[0], kk[1]) if isinstance(kk, tuple) else (kk, None) for kk in keys]
+            with torch.cuda.stream(agg_stream):
                 out = rk.aggregate_evidence_batch(jobs, self.fm_index, keep=keep, gpu_aggregate=self.gpu_aggregate, want_ngrams=False, **params)
-                post.synchronize()
+                agg_stream.synchronize()
             if tm:
-                print("[overlap] batch %d: waited %.1f ms for its decodes; enqueued further decodes in %.1f ms; filters / rescoring / "
-                      "aggregation %.1f ms" % (i, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (time.perf_counter() - t2) * 1e3), file=sys.stderr, flush=True)
+                print("[overlap] batch %d: waited %.1f ms for its decodes; enqueued further decodes in %.1f ms; filters / rescoring %.1f ms; next batch's rescoring + "
+                      "aggregation %.1f ms" % (i, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (time.perf_counter() - t3) * 1e3), file=sys.stderr, flush=True)
             held = out
         if held is not None:
             yield from held
