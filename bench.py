@@ -916,15 +916,21 @@ def main():
         other_qps = args.batch * args.steps * world / t2
         searcher.first_stage_only = args.first_stage_only
 
-    # same-box A/B of an environment switch the product reads per call (SEAL_BENCH_AB=SEAL_RESCORE_AHEAD): the same K batches with the switch
-    # at 0 and at 1, alternating, after the timed run -- boxes differ by +-15 %, two runs on two boxes say nothing about a 3 % change
+    # same-box comparison of an environment switch the product reads per call (SEAL_BENCH_AB="SEAL_RESCORE_AHEAD=0,1,auto"): the same K batches
+    # with each value in turn, several rounds, after the timed run -- boxes differ by +-15 %, two runs on two boxes say nothing about a 3 %
+    # change.  SEAL_BENCH_AB_GARBAGE=1: the legs' results stay with the collector (a host slowed by collections) instead of being frozen.
     ab = None
     if os.environ.get("SEAL_BENCH_AB") and not use_dist:
-        var, ab = os.environ["SEAL_BENCH_AB"], {"switch": os.environ["SEAL_BENCH_AB"], "0": [], "1": []}
+        var, _, vals = os.environ["SEAL_BENCH_AB"].partition("=")
+        vals = vals.split(",") if vals else ["0", "1"]
+        ab = {"switch": var, "garbage": bool(os.environ.get("SEAL_BENCH_AB_GARBAGE")), **{v: [] for v in vals}}
         saved = os.environ.get(var)
         for rep in range(int(os.environ.get("SEAL_BENCH_AB_REPS", 3))):
-            for val in ("0", "1"):
+            for val in vals:
                 os.environ[var] = val
+                if not ab["garbage"]:
+                    gc.collect()
+                    gc.freeze()                               # (as before the timed run: earlier legs' results out of later collections)
                 run_batch(0)
                 torch.cuda.synchronize()
                 t2 = time.perf_counter()
@@ -935,7 +941,8 @@ def main():
             os.environ.pop(var, None)
         else:
             os.environ[var] = saved
-        print("[bench] A/B %s: queries/s with 0: %s, with 1: %s" % (var, ab["0"], ab["1"]), file=sys.stderr, flush=True)
+        print("[bench] same box, %s (queries/s over %d batches per leg%s): %s" % (var, args.steps, ", results left to the collector" if ab["garbage"] else "",
+              "; ".join("%s: %s" % (v, ab[v]) for v in vals)), file=sys.stderr, flush=True)
 
     if rank != 0:
         if use_dist:

@@ -400,6 +400,12 @@ int fmi_dev_read_call_log(fmi_t *h, uint64_t cap, uint32_t *cur_len, uint32_t *r
 int fmi_dev_agg_timing(fmi_t *h, int enable);
 int fmi_dev_read_agg_timing(fmi_t *h, double *stage_ms, uint64_t *counts, uint64_t *calls_out);
 
+/* A copy between device memory and PINNED (device-visible) host memory, either way, done by a kernel: ordered by `stream` alone, where a
+ * hipMemcpyAsync waits in the DMA engine's queue behind copies other streams have enqueued (the plan and the results of
+ * fmi_dev_aggregate behind the pending copy-back of a decode enqueued ahead: seal_amd/csrc/fmi_upload.hip).  dst, src and bytes are
+ * multiples of 4 (16: wider accesses); the host sees a download once the stream has been waited for. */
+int fmi_dev_kernel_copy(void *stream, void *dst, const void *src, uint64_t bytes);
+
 /* Device pointer of a resident array, for zero-copy hand-over (e.g. to build the
  * CPU baseline's samples).  name in {"sa_lo","sa_hi","text","wm","C","leaf","q1","doc_begin"}. */
 const void *fmi_dev_array(const fmi_t *h, const char *name, uint64_t *n_out, uint32_t *elem_out);

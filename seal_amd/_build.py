@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libsealfm.so")
 SOURCES = ["fmi_host.cpp", "fmi_evidence.cpp", "fmi_agg_pack.cpp", "fmi_sdsl.cpp", "fmi_kernels.hip", "fmi_aggregate.hip", "fmi_build_gpu.hip",
-           "bart_kernels.hip", "hgemm_kernels.hip"]
+           "bart_kernels.hip", "hgemm_kernels.hip", "fmi_upload.hip"]
 HEADERS = ["fmi_internal.h", "fmi_device.h", "fmi_agg.h", os.path.join("..", "..", "include", "sealfm.h"),
            os.path.join("..", "..", "include", "sealnn.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]

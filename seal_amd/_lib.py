@@ -101,6 +101,7 @@ SIGNATURES = {
     "fmi_dev_beam_step": (_int, [_vp, _vp, ctypes.POINTER(FmiBeamStep)]),
     "fmi_dev_last_constraint_bits": (_vp, [_vp, _p64, _p64]),
     "fmi_dev_agg_timing": (_int, [_vp, _int]),
+    "fmi_dev_kernel_copy": (_int, [_vp, _vp, _vp, _u64]),
     "fmi_dev_read_agg_timing": (_int, [_vp, ctypes.POINTER(ctypes.c_double), _p64, _p64]),
     "fmi_dev_call_log": (_int, [_vp, _int]),
     "fmi_dev_read_call_log": (_int, [_vp, _u64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),

@@ -149,9 +149,11 @@ def _plan_header(blob_ptr):
     return dict(zip(names, struct.unpack("<%dQ" % len(names), raw)))
 
 
-def _run_plan(index, plan, nq, params):
+def _run_plan(index, plan, nq, params, two_phase=False):
     """copies the plan to the GPU, runs ``fmi_dev_aggregate`` on the index's retrieval stream and fetches the records of
-    the top documents.  Returns (keep, n_out, flags, records..., pools...) as numpy arrays."""
+    the top documents.  Returns (keep, n_out, flags, records..., pools...) as numpy arrays.  ``two_phase``: returns once the
+    launches and the first copy back are ENQUEUED -- a callable that waits for them and fetches the rest (the plan and the
+    index's aggregation buffers belong to this call until it has run)."""
     import torch
     from .index import SHIFT
     L = lib()
@@ -172,57 +174,74 @@ def _run_plan(index, plan, nq, params):
     if bufs is None:
         bufs = index.__dict__["_agg_buffers"] = _Buffers()
     R = nq * keep
-    bufs.fit(dev, ws_bytes.value, out_bytes, blob_bytes, max(fixed_bytes, 1 << 20))
+    up_bytes = (blob_bytes + 15) & ~15
+    bufs.fit(dev, ws_bytes.value, out_bytes, up_bytes, max(fixed_bytes, 1 << 20))
     st = index._side_stream(dev)
     with torch.cuda.stream(st):
         ctypes.memmove(bufs.pin_in.data_ptr(), blob_ptr, blob_bytes)
-        bufs.blob[:blob_bytes].copy_(bufs.pin_in[:blob_bytes], non_blocking=True)
+        # (by a kernel, not hipMemcpyAsync: the DMA queue holds the pending copy-back of a decode enqueued ahead, and a copy of this size
+        # waited behind it until that decode had ended -- fmi_upload.hip)
+        check(L.fmi_dev_kernel_copy(st.cuda_stream, bufs.blob.data_ptr(), bufs.pin_in.data_ptr(), up_bytes))
+        mk = index.__dict__.get("_agg_mark")                  # (SEAL_OVERLAP_TIMING=2: events on this stream, retrieval.py)
+        if mk is not None:
+            mk("  index stream: plan of %d bytes on the GPU" % blob_bytes, st)
         check(L.fmi_dev_aggregate(
             index.handle, st.cuda_stream, plan, bufs.blob.data_ptr(), n_top, keep, allow, float(params.get("beta", 0.8)),
             float(params.get("single_key", 0.0)), int(bool(params.get("single_key_add_unigrams", False))),
             int(bool(params.get("unigrams_ignore_free_places", False))), SHIFT, bufs.ws.data_ptr(), bufs.ws.numel(),
             bufs.out.data_ptr(), bufs.out.numel()))
-        bufs.pin_out[:fixed_bytes].copy_(bufs.out[:fixed_bytes], non_blocking=True)
-        st.synchronize()
-        fixed = bufs.pin_out[:fixed_bytes].numpy().copy()
-        view = lambda slot, dt, n: fixed[off[slot]:off[slot] + n * np.dtype(dt).itemsize].view(dt)
-        cursor = view(2, np.uint32, 2)
-        n_picks, n_toks = int(cursor[0]), int(cursor[1])
-        # the used prefixes of the pick and token pools, one more round trip
-        need = 4 * n_picks + 8 * n_picks + 4 * n_toks + 64
-        bufs.pin_out = bufs._fit(bufs.pin_out, need, pin_memory=True)
-        a0, a1, a2 = 0, (4 * n_picks + 15) & ~15, ((4 * n_picks + 15) & ~15) + 8 * n_picks
-        if n_picks:
-            bufs.pin_out[a0:a0 + 4 * n_picks].copy_(bufs.out[off[12]:off[12] + 4 * n_picks], non_blocking=True)
-            bufs.pin_out[a1:a1 + 8 * n_picks].copy_(bufs.out[off[13]:off[13] + 8 * n_picks], non_blocking=True)
-        if n_toks:
-            bufs.pin_out[a2:a2 + 4 * n_toks].copy_(bufs.out[off[14]:off[14] + 4 * n_toks], non_blocking=True)
-        st.synchronize()
-        host = bufs.pin_out.numpy()
-        out = dict(keep=keep, n_out=view(0, np.uint32, nq), flags=view(1, np.uint32, nq),
-                   pick_id=host[a0:a0 + 4 * n_picks].view(np.int32).copy(), pick_score=host[a1:a1 + 8 * n_picks].view(np.float64).copy(),
-                   tokens=host[a2:a2 + 4 * n_toks].view(np.int32).copy(),
-                   doc=view(3, np.uint64, R), score=view(4, np.float64, R), best_score=view(5, np.float64, R),
-                   best_key=view(6, np.int32, R), T=view(7, np.uint32, R), npicks=view(8, np.uint32, R),
-                   pick_off=view(9, np.uint32, R), tok_off=view(10, np.uint32, R))
-        tracing = getattr(index, "_trace", None) is not None
-        if index.__dict__.get("_agg_debug") is not None or tracing:       # tests / bench.py parity: the first-stage ranking as well
-            fs_cnt = view(11, np.uint32, nq).copy()
-            fs_doc = bufs.out[off[15]:off[15] + 4 * nq * n_top].cpu().numpy().view(np.uint32).reshape(nq, n_top)
-            fs_score = bufs.out[off[16]:off[16] + 8 * nq * n_top].cpu().numpy().view(np.float64).reshape(nq, n_top)
-            if index.__dict__.get("_agg_debug") is not None:
-                index.__dict__["_agg_debug"].append([(fs_doc[q, :fs_cnt[q]].copy(), fs_score[q, :fs_cnt[q]].copy()) for q in range(nq)])
-            if tracing:
-                # bench.py records every index operation of a batch with the GPU's answer to compare them with the CPU
-                # oracle's: the located rows and the candidate documents never reach the host on this path, so the same
-                # rows / documents are fetched once more through the host-visible calls (which record)
-                H = _plan_header(blob_ptr)
-                rare_key = np.frombuffer(ctypes.string_at(blob_ptr + H["o_rare_key"], 4 * H["n_rare"]), dtype=np.uint32)
-                occ = np.frombuffer(ctypes.string_at(blob_ptr + H["o_rare_occ_off"], 8 * (H["n_rare"] + 1)), dtype=np.uint64).astype(np.int64)
-                key_lo = np.frombuffer(ctypes.string_at(blob_ptr + H["o_key_lo"], 8 * max(H["n_keys"], 1)), dtype=np.uint64).astype(np.int64)
-                lo = key_lo[rare_key.astype(np.int64)] if H["n_rare"] else np.zeros(0, np.int64)
-                index.locate_ranges(lo, lo + np.diff(occ), int(params.get("max_occurrences_1", 1500)))
-                index.get_docs_batch(np.concatenate([fs_doc[q, :fs_cnt[q]] for q in range(nq)]).astype(np.int64), as_arrays="flat")
+        check(L.fmi_dev_kernel_copy(st.cuda_stream, bufs.pin_out.data_ptr(), bufs.out.data_ptr(), (fixed_bytes + 3) & ~3))   # (likewise)
+
+    def fetch():
+        with torch.cuda.stream(st):
+            return _fetch_records(index, plan, nq, params, bufs, st, off, fixed_bytes, keep, n_top, R, blob_ptr)
+    return fetch if two_phase else fetch()
+
+
+def _fetch_records(index, plan, nq, params, bufs, st, off, fixed_bytes, keep, n_top, R, blob_ptr):
+    """the second half of ``_run_plan``: waits for the launches, reads the fixed records, then the used prefixes of the pools"""
+    st.synchronize()
+    fixed = bufs.pin_out[:fixed_bytes].numpy().copy()
+    view = lambda slot, dt, n: fixed[off[slot]:off[slot] + n * np.dtype(dt).itemsize].view(dt)
+    cursor = view(2, np.uint32, 2)
+    n_picks, n_toks = int(cursor[0]), int(cursor[1])
+    # the used prefixes of the pick and token pools, one more round trip
+    need = 4 * n_picks + 8 * n_picks + 4 * n_toks + 64
+    bufs.pin_out = bufs._fit(bufs.pin_out, need, pin_memory=True)
+    a0, a1, a2 = 0, (4 * n_picks + 15) & ~15, ((4 * n_picks + 15) & ~15) + 8 * n_picks
+    L = lib()
+    po, do = bufs.pin_out.data_ptr(), bufs.out.data_ptr()
+    if n_picks:
+        check(L.fmi_dev_kernel_copy(st.cuda_stream, po + a0, do + off[12], 4 * n_picks))
+        check(L.fmi_dev_kernel_copy(st.cuda_stream, po + a1, do + off[13], 8 * n_picks))
+    if n_toks:
+        check(L.fmi_dev_kernel_copy(st.cuda_stream, po + a2, do + off[14], 4 * n_toks))
+    st.synchronize()
+    host = bufs.pin_out.numpy()
+    out = dict(keep=keep, n_out=view(0, np.uint32, nq), flags=view(1, np.uint32, nq),
+               pick_id=host[a0:a0 + 4 * n_picks].view(np.int32).copy(), pick_score=host[a1:a1 + 8 * n_picks].view(np.float64).copy(),
+               tokens=host[a2:a2 + 4 * n_toks].view(np.int32).copy(),
+               doc=view(3, np.uint64, R), score=view(4, np.float64, R), best_score=view(5, np.float64, R),
+               best_key=view(6, np.int32, R), T=view(7, np.uint32, R), npicks=view(8, np.uint32, R),
+               pick_off=view(9, np.uint32, R), tok_off=view(10, np.uint32, R))
+    tracing = getattr(index, "_trace", None) is not None
+    if index.__dict__.get("_agg_debug") is not None or tracing:       # tests / bench.py parity: the first-stage ranking as well
+        fs_cnt = view(11, np.uint32, nq).copy()
+        fs_doc = bufs.out[off[15]:off[15] + 4 * nq * n_top].cpu().numpy().view(np.uint32).reshape(nq, n_top)
+        fs_score = bufs.out[off[16]:off[16] + 8 * nq * n_top].cpu().numpy().view(np.float64).reshape(nq, n_top)
+        if index.__dict__.get("_agg_debug") is not None:
+            index.__dict__["_agg_debug"].append([(fs_doc[q, :fs_cnt[q]].copy(), fs_score[q, :fs_cnt[q]].copy()) for q in range(nq)])
+        if tracing:
+            # bench.py records every index operation of a batch with the GPU's answer to compare them with the CPU
+            # oracle's: the located rows and the candidate documents never reach the host on this path, so the same
+            # rows / documents are fetched once more through the host-visible calls (which record)
+            H = _plan_header(blob_ptr)
+            rare_key = np.frombuffer(ctypes.string_at(blob_ptr + H["o_rare_key"], 4 * H["n_rare"]), dtype=np.uint32)
+            occ = np.frombuffer(ctypes.string_at(blob_ptr + H["o_rare_occ_off"], 8 * (H["n_rare"] + 1)), dtype=np.uint64).astype(np.int64)
+            key_lo = np.frombuffer(ctypes.string_at(blob_ptr + H["o_key_lo"], 8 * max(H["n_keys"], 1)), dtype=np.uint64).astype(np.int64)
+            lo = key_lo[rare_key.astype(np.int64)] if H["n_rare"] else np.zeros(0, np.int64)
+            index.locate_ranges(lo, lo + np.diff(occ), int(params.get("max_occurrences_1", 1500)))
+            index.get_docs_batch(np.concatenate([fs_doc[q, :fs_cnt[q]] for q in range(nq)]).astype(np.int64), as_arrays="flat")
     return out
 
 
@@ -374,25 +393,33 @@ class _NgramTable:
         return tuple(self._keys[s]) if s >= 0 else (-s - 1,)
 
 
-def score_and_aggregate_on_gpu(index, jobs, params, want_ngrams=True):
+def score_and_aggregate_on_gpu(index, jobs, params, want_ngrams=True, two_phase=False):
     """``aggregate_evidence`` for the queries of a chunk with the key scoring (keys.py:207-309) in C++
     (``fmi_agg_score_pack``) and everything after it on the GPU.  ``jobs`` = [(ngrams_and_scores, unigram_scores)].
     Returns a list of ``(results, all_ngrams)`` -- ``all_ngrams`` None unless ``want_ngrams`` -- with ``None`` in place of
     a pair where the query must take the python route (device limit exceeded), or None for the whole chunk when the
-    input is outside what the C++ scorer takes (an empty key)."""
+    input is outside what the C++ scorer takes (an empty key).
+
+    ``two_phase``: returns a callable instead, as soon as the key scoring is done and the aggregation's launches are ENQUEUED; calling it
+    waits for them and returns the above.  The searcher's overlapped loop enqueues the next batch's rescoring forward between the two
+    (the index kernels run beside the decode that is on the GPU at that time; the host does not sit waiting for them)."""
     import torch
     from .index import SHIFT
     from .keys import _unigram_ranges
     L = lib()
     nq = len(jobs)
+    if two_phase:
+        now = lambda value: (lambda: value)
+    else:
+        now = lambda value: value
     if nq > MAX_QUERIES_PER_PLAN:
         out = []
         for a in range(0, nq, MAX_QUERIES_PER_PLAN):
             part = score_and_aggregate_on_gpu(index, jobs[a:a + MAX_QUERIES_PER_PLAN], params, want_ngrams)
             if part is None:
-                return None
+                return now(None)
             out += part
-        return out
+        return now(out)
     key_lists, lens, lm, type_ptrs, keep_alive = [], [], [], [], []
     q_key_off = np.zeros(nq + 1, dtype=np.int64)
     vocab = 1
@@ -401,7 +428,7 @@ def score_and_aggregate_on_gpu(index, jobs, params, want_ngrams=True):
         key_lists.append(keys)
         ln = [len(k) for k in keys]
         if ln and (min(ln) < 1 or max(ln) > MAX_KEY_LEN):
-            return None
+            return now(None)
         lens += ln
         lm += [sr for _, sr in nas]
         q_key_off[qi + 1] = q_key_off[qi] + len(keys)
@@ -413,7 +440,7 @@ def score_and_aggregate_on_gpu(index, jobs, params, want_ngrams=True):
         else:
             type_ptrs.append(None)
     if len({u.shape[0] for u in keep_alive}) > 1 or (not params.get("use_fm_index_frequency", True) and any(len(k) == 0 for k in key_lists)):
-        return None
+        return now(None)
     nk = int(q_key_off[-1])
     key_tok_off = np.zeros(nk + 1, dtype=np.int64)
     if nk:
@@ -445,6 +472,7 @@ def score_and_aggregate_on_gpu(index, jobs, params, want_ngrams=True):
         float(params.get("length_penalty", 0.0)), float(params.get("smoothing", 5.0)), int(bool(params.get("use_fm_index_frequency", True))),
         int(bool(params.get("add_best_unigrams_to_ngrams", False))), int(params.get("use_top_k_unigrams", 1000)),
         int(params.get("max_occurrences_1", 1500)), int(params.get("max_occurrences_2", 10_000_000)), int(index.size()), ctypes.byref(plan)))
+    fetch = None
     try:
         nt = int(L.fmi_agg_plan_table_src(plan, None))
         table_src = np.zeros(max(nt, 1), dtype=np.int64)
@@ -462,16 +490,24 @@ def score_and_aggregate_on_gpu(index, jobs, params, want_ngrams=True):
                 ngrams.append({(tuple(keys[s]) if s >= 0 else (-s - 1,)): v for s, v in zip(src[:n].tolist(), sc[:n].tolist())})
         if H["total_occ"] == 0 and not H["n_rare"]:
             # no query has a rare key: nothing to locate, every result is empty (keys.py:311 never iterates)
-            return [({}, None if ngrams is None else ngrams[qi]) for qi in range(nq)]
-        out = _run_plan(index, plan, nq, params)
+            return now([({}, None if ngrams is None else ngrams[qi]) for qi in range(nq)])
+        fetch = _run_plan(index, plan, nq, params, two_phase=True)
     finally:
-        L.fmi_agg_plan_free(plan)
-    res = []
-    for qi in range(nq):
-        if out["flags"][qi] & 1:
-            res.append(None)
-            continue
-        k0 = int(q_tab[qi])
-        table = _NgramTable(table_src[k0:int(q_tab[qi + 1])], key_lists[qi])
-        res.append((_results_of(out, qi, k0, table), None if ngrams is None else ngrams[qi]))
-    return res
+        if fetch is None:
+            L.fmi_agg_plan_free(plan)
+
+    def finish():
+        try:
+            out = fetch()
+        finally:
+            L.fmi_agg_plan_free(plan)
+        res = []
+        for qi in range(nq):
+            if out["flags"][qi] & 1:
+                res.append(None)
+                continue
+            k0 = int(q_tab[qi])
+            table = _NgramTable(table_src[k0:int(q_tab[qi + 1])], key_lists[qi])
+            res.append((_results_of(out, qi, k0, table), None if ngrams is None else ngrams[qi]))
+        return res
+    return finish if two_phase else finish()

@@ -11,6 +11,7 @@ GPU decode and retrieval paths use to avoid one launch per Python call.
 """
 import bisect
 import ctypes
+import os
 import pickle
 from typing import Iterable, Iterator, List, Optional, Sequence, Set, Tuple
 
@@ -265,9 +266,17 @@ class FMIndex(_FMIndex):
         import torch
         if self.__dict__.get("_is_view"):
             return torch.cuda.current_stream(dev)
+        # a HIGH-PRIORITY stream (SEAL_INDEX_STREAM_PRIORITY, default -1).  Not for the priority itself: HIP maps streams onto a few
+        # hardware queues per priority level, round robin, and at the default priority this stream has shared its hardware queue with
+        # the searcher's rescoring stream (rocprofv3: stream 10 and stream 1 both on queue 2) -- the index kernels then ran in the
+        # rescoring's queue order, behind its event waits.  Streams of another priority level get queues of their own
+        # (tools/stream_overlap_probe.py, profiles/r5_stream_overlap_probe.txt: a side chain beside graph replays ends after 4.6 ms on a
+        # high-priority stream, after the 35 ms of replays on a default-priority one that landed on the replays' queue).
+        prio = int(os.environ.get("SEAL_INDEX_STREAM_PRIORITY", "-1"))
         st = self.__dict__.get("_svc_stream")
-        if st is None:
-            st = self.__dict__["_svc_stream"] = torch.cuda.Stream(device=dev)
+        if st is None or self.__dict__.get("_svc_stream_priority") != prio:
+            st = self.__dict__["_svc_stream"] = torch.cuda.Stream(device=dev, priority=prio)
+            self.__dict__["_svc_stream_priority"] = prio
         return st
 
     def set_trace(self, trace) -> None:

@@ -896,8 +896,33 @@ def aggregate_evidence_batch(jobs, index, **params):
     """``aggregate_evidence`` for several queries with the GPU work batched ACROSS them: one
     backward-search launch for every key of every query, one locate launch for every rare key of
     every query (and one document fetch when fully scoring).  ``jobs`` = list of
-    ``(ngrams_and_scores, unigram_scores)``; returns the list of ``(results, all_ngrams)``."""
+    ``(ngrams_and_scores, unigram_scores)``; returns the list of ``(results, all_ngrams)``.
+
+    ``two_phase=True``: returns a callable that returns that list.  On the GPU route the call itself scores the keys and ENQUEUES the index
+    kernels, and the callable waits for them and builds the results (``score_and_aggregate_on_gpu``); everywhere else the callable does
+    all the work."""
     import os, time, sys
+    if params.pop("two_phase", False):
+        use_gpu = params.get("gpu_aggregate", True)
+        if (use_gpu and not params.get("python_scoring", os.environ.get("SEAL_PYTHON_SCORING") == "1")
+                and gpu_aggregation_applies(index, {k: v for k, v in params.items() if k not in ("gpu_aggregate", "want_ngrams", "python_scoring")})):
+            from .gpu_aggregate import score_and_aggregate_on_gpu
+            rest = {k: v for k, v in params.items() if k not in ("gpu_aggregate", "want_ngrams", "python_scoring")}
+            fetch = score_and_aggregate_on_gpu(index, jobs, rest, params.get("want_ngrams", True), two_phase=True)
+
+            def finish():
+                done = fetch()
+                if done is not None and all(r is not None for r in done):
+                    return done
+                if done is None:
+                    return aggregate_evidence_batch(jobs, index, **{**params, "python_scoring": True})
+                left = [i for i, r in enumerate(done) if r is None]
+                some = aggregate_evidence_batch([jobs[i] for i in left], index, **{**params, "gpu_aggregate": False})
+                for i, r in zip(left, some):
+                    done[i] = r
+                return done
+            return finish
+        return lambda: aggregate_evidence_batch(jobs, index, **params)
     use_gpu = params.pop("gpu_aggregate", True)          # False: the host routines (fmi_first_stage / fmi_full_score) for every query
     want_ngrams = params.pop("want_ngrams", True)        # False: the caller ignores `all_ngrams` (the searcher does)
     python_scoring = params.pop("python_scoring", os.environ.get("SEAL_PYTHON_SCORING") == "1")

@@ -221,8 +221,8 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0):
     1. the body decode is ENQUEUED -- nothing waits for the GPU -- ``yield "body"``; the title decode likewise, ``yield
        "decoding"``;
     2. the hypotheses come to the host (the one wait for the decodes), then ``yield "decoded"``;
-    3. post-filters, the rescorings enqueued, ``yield "rescoring"``; scores read back, query n-grams, unigram scores ->
-       returns the keys (``StopIteration.value``).
+    3. post-filters (one count launch and its read-back, no GEMM), ``yield "filtered"``; the rescorings enqueued, ``yield
+       "rescoring"``; scores read back, query n-grams, unigram scores -> returns the keys (``StopIteration.value``).
 
     The reference runs body decode -> body filters/rescoring -> query keys -> title decode -> title filters/rescoring;
     the two decodes do not depend on anything in between, so issuing them back to back changes no result."""
@@ -495,6 +495,7 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0):
             length_penalty=0.0, strip_from_bos=bos_strip, strip_from_eos=[s.bart_model.config.eos_token_id], logit_bias=bias,
             encoded=(codes.enc, codes.attention_mask) if tokenised and codes.enc is not None else None)))
         slots.append("code")
+    yield "filtered"                             # the candidate lists are final; what follows launches GEMMs
     if jobs:
         gate = s.__dict__.get("_gemm_gate")
         if gate is not None:
@@ -848,7 +849,10 @@ class SEALSearcher:
                 print("[seal_amd] WARNING: decode and rescoring share the GPU (two library-GEMM streams): this configuration can stall",
                       file=sys.stderr, flush=True)
         depth = max(1, int(os.environ.get("SEAL_OVERLAP_DEPTH", self.overlap_depth if exclusive else 1)))
-        rescore_ahead = os.environ.get("SEAL_RESCORE_AHEAD", "1") != "0"   # (the round-4 order, for same-box comparisons: bench.py SEAL_BENCH_AB)
+        # What the host does between "the scores of batch i are back" and "the rescoring of batch i+1 is enqueued" decides whether the GPU
+        # runs dry after decode(i+2) (see the loop).  2 (default) = interleaved: the aggregation's launches, the rescoring, the aggregation's
+        # read-back; 0 = the whole aggregation first (round 4); 1 = the rescoring first.  (bench.py SEAL_BENCH_AB compares them on one box.)
+        ahead_mode = os.environ.get("SEAL_RESCORE_AHEAD", "2")
         ahead = []                                            # generators whose decodes are enqueued, oldest first
         nxt_i = 0
         main = torch.cuda.current_stream(dev)
@@ -863,25 +867,34 @@ class SEALSearcher:
         def wait_for(kind, stream):
             if exclusive and fence[kind] is not None:
                 stream.wait_event(fence[kind])
+        marks = []                                            # SEAL_OVERLAP_TIMING=2: (label, event) at the phase boundaries, in GPU time
+
+        def mark(label, stream):
+            if tm == "2":
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(stream)
+                marks.append((label, ev))
 
         def enqueue_next(upto="decoding"):
             """starts the next batch: its body decode is enqueued (``upto="body"``), or both decodes"""
             nonlocal nxt_i
             g = _batch_steps(self, batches[nxt_i], constrained, offsets[nxt_i])
             wait_for("rescore", main)
+            mark("decode %d begins" % nxt_i, main)
             state = next(g)                                   # "body": the body decode is enqueued behind the earlier ones
             if upto == "decoding":
                 state = next(g)
             after("decode", main)
+            mark("decode %d ends" % nxt_i, main)
             ahead.append([g, state])
             nxt_i += 1
 
-        ORDER = {"body": 0, "decoding": 1, "decoded": 2, "rescoring": 3}
+        ORDER = {"body": 0, "decoding": 1, "decoded": 2, "filtered": 3, "rescoring": 4}
 
         def advance(entry, upto):
             if ORDER[entry[1]] >= ORDER[upto]:
-                return                                        # (already there: a batch's rescoring may have been enqueued one iteration early)
-            decodes = entry[1] in ("body",) and upto in ("decoding", "decoded", "rescoring")     # a title decode still to be enqueued
+                return                                        # (already there: a batch's filters / rescoring may have been run one iteration early)
+            decodes = entry[1] == "body"                      # a title decode still to be enqueued
             if decodes:
                 wait_for("rescore", main)
             while entry[1] != upto:
@@ -901,6 +914,7 @@ class SEALSearcher:
             def gate():
                 gated[0] += 1
                 wait_for("decode", post)
+                mark("rescoring begins", post)
             entry.append(gate)
             self.__dict__["_gemm_gate"] = gate                # (read by _batch_steps when it reaches a forward)
             try:
@@ -909,11 +923,22 @@ class SEALSearcher:
             finally:
                 self.__dict__.pop("_gemm_gate", None)
             after("rescore", post)
+            mark("rescoring ends", post)
+
+        def to_filtered(entry):
+            """the batch's hypotheses on the host and its post-filters run (one count launch and its read-back, on the aggregation's stream:
+            the post stream may be busy with the previous batch's rescoring) -- everything of "rescoring" that needs no GEMM"""
+            advance(entry, "decoded")
+            with torch.cuda.stream(agg_stream):
+                advance(entry, "filtered")
         # the aggregation's own launches (key counts, locate, evidence kernels) and the host's waits for them: the index's retrieval stream,
         # NOT the post stream -- a count read-back there would queue behind the next batch's rescoring forward (round 5)
+        # (high priority, as the index's own stream: index.py _side_stream)
+        prio = int(os.environ.get("SEAL_INDEX_STREAM_PRIORITY", "-1"))
         agg_stream = self.__dict__.get("_agg_stream")
-        if agg_stream is None or agg_stream.device != dev:
-            agg_stream = self.__dict__["_agg_stream"] = torch.cuda.Stream(device=dev)
+        if agg_stream is None or agg_stream.device != dev or self.__dict__.get("_agg_stream_priority") != prio:
+            agg_stream = self.__dict__["_agg_stream"] = torch.cuda.Stream(device=dev, priority=prio)
+            self.__dict__["_agg_stream_priority"] = prio
         enqueue_next()
         if exclusive and len(batches) > 1 and depth > 1:
             enqueue_next()                                    # one decode ahead of the batch the loop starts with
@@ -947,6 +972,11 @@ class SEALSearcher:
             if held is not None:
                 yield from held
                 held = None
+            interleave = exclusive and bool(ahead) and ahead_mode == "2"
+            if interleave:
+                # the host is about to wait for this batch's scores (the GPU is in its rescoring): the time for the NEXT batch's filters -- its
+                # decode finished before this rescoring began, so its hypotheses are there; nothing of it needs the busy streams
+                to_filtered(ahead[0])
             with torch.cuda.stream(post):
                 gated, gate = cur[2], cur[3]
                 late = gated[0]
@@ -962,21 +992,52 @@ class SEALSearcher:
                     # a forward ran after the yield (non-default configurations): the decodes enqueued from here on wait for it as well
                     after("rescore", post)
             t3 = time.perf_counter()
-            if exclusive and ahead and rescore_ahead:
-                # The NEXT batch's filters and rescoring forward are enqueued BEFORE this batch's aggregation (round 5): its decode finished
-                # before this batch's rescoring did, so its hypotheses are on the host already; the forward waits (event) for the decode
-                # enqueued above.  The GPU then holds decode(i+2) -> rescoring(i+1) while the host walks through ~20 ms of deduplication,
-                # key scoring and aggregation of batch i -- which used to sit between "scores of batch i" and "rescoring(i+1) enqueued" and
-                # left the GPU idle once decode + rescoring had become shorter than that stretch of host work.
-                to_rescoring(ahead[0])
+            mark("  host: scores of batch %d are back" % i, agg_stream)      # (an idle stream: the event's GPU time is the host's "now")
+            # The scores of batch i are back: the GPU is in decode(i+2) (~38 ms), and rescoring(i+1) has to be in its queue before that decode
+            # ends or the GPU idles for the difference.  The host has two things to do: the aggregation of batch i (~11 ms: key lists, one
+            # count launch, key scoring in C++, fmi_dev_aggregate = 3.5 ms of index kernels, two read-backs) and the rescoring enqueue of batch
+            # i+1 (~16 ms: filters, prefix tree, graph replay).  Round 4's order -- the whole aggregation, then (next iteration) filters and
+            # rescoring -- has the rescoring in the queue ~33 ms into the decode: in time on a fast host, late on a slower one (a box at
+            # 294 queries/s where others gave 337; 299 vs 318 with the collector walking earlier results).  Rescoring first is never late, but
+            # then the index kernels land beside the rescoring's chip-filling GEMMs instead of beside the decode's small ones, which leave
+            # CUs idle: 326 vs 340 queries/s on a fast host (profiles/r5_rescore_ahead_ab.txt).  So the two are interleaved: the aggregation's
+            # host half and its launches first (kernels beside the decode), the rescoring enqueue while they run, then the read-back; and
+            # the filters of batch i+1 (no GEMM) have moved in front of the wait for the scores above.
             jobs = [(kk[0], kk[1]) if isinstance(kk, tuple) else (kk, None) for kk in keys]
+            if exclusive and ahead and ahead_mode == "1":
+                to_rescoring(ahead[0])
+            if tm == "2":
+                self.fm_index.__dict__["_agg_mark"] = mark
             with torch.cuda.stream(agg_stream):
-                out = rk.aggregate_evidence_batch(jobs, self.fm_index, keep=keep, gpu_aggregate=self.gpu_aggregate, want_ngrams=False, **params)
-                agg_stream.synchronize()
+                fetch = rk.aggregate_evidence_batch(jobs, self.fm_index, two_phase=interleave, keep=keep, gpu_aggregate=self.gpu_aggregate,
+                                                    want_ngrams=False, **params)
+            t4 = time.perf_counter()
+            mark("  host: aggregation of batch %d launched" % i, agg_stream)
+            if tm == "2" and hasattr(self.fm_index, "_side_stream"):
+                mark("  index stream: aggregation kernels of batch %d done" % i, self.fm_index._side_stream(dev))
+            if interleave:
+                to_rescoring(ahead[0])
+                mark("  host: next rescoring enqueued", agg_stream)
+                t5 = time.perf_counter()
+                with torch.cuda.stream(agg_stream):
+                    out = fetch()
+            else:
+                t5, out = t4, fetch
+            agg_stream.synchronize()
+            mark("  host: aggregation of batch %d fetched" % i, agg_stream)
             if tm:
-                print("[overlap] batch %d: waited %.1f ms for its decodes; enqueued further decodes in %.1f ms; filters / rescoring %.1f ms; next batch's rescoring + "
-                      "aggregation %.1f ms" % (i, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (time.perf_counter() - t3) * 1e3), file=sys.stderr, flush=True)
+                print("[overlap] batch %d: waited %.1f ms for its decodes; enqueued further decodes in %.1f ms; filters / rescoring / next filters / scores %.1f ms; "
+                      "aggregation %.1f ms + %.1f ms around the next batch's rescoring enqueue %.1f ms" %
+                      (i, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (time.perf_counter() - t5) * 1e3, (t5 - t4) * 1e3), file=sys.stderr, flush=True)
             held = out
+        if marks:
+            self.fm_index.__dict__.pop("_agg_mark", None)
+            torch.cuda.synchronize(dev)
+            t_first, prev = marks[0][1], None
+            for label, ev in sorted(marks, key=lambda m: t_first.elapsed_time(m[1])):
+                at = t_first.elapsed_time(ev)
+                print("[overlap] GPU time %9.2f ms (+%6.2f)  %s" % (at, at - (prev if prev is not None else at), label), file=sys.stderr, flush=True)
+                prev = at
         if held is not None:
             yield from held
 

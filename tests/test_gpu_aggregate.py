@@ -46,7 +46,7 @@ def test_gpu_aggregation_equals_the_reference(case_no, monkeypatch):
     us = None if case["unigram_scores"] is None else [_unhex(x) for x in case["unigram_scores"]]
     calls = []
     real = gpu_aggregate._run_plan
-    monkeypatch.setattr(gpu_aggregate, "_run_plan", lambda *a: (calls.append(1), real(*a))[1])
+    monkeypatch.setattr(gpu_aggregate, "_run_plan", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
     results, all_ngrams = aggregate_evidence(keys, unigram_scores=us, index=ix, **kw)
     on_gpu = not (kw.get("sort_by_length") or kw.get("sort_by_freq") or kw.get("first_stage_only"))
     if on_gpu and len(case["results"]) > 0:
@@ -142,6 +142,12 @@ def test_gpu_aggregation_equals_the_host_routines(seed, kw, python_scoring, monk
         ix._agg_debug = None
         assert sum(len(w[0]) for w in want) > 20
         for g, w in zip(got, want):
+            _same(g, w, keep)
+        # two phases (the overlapped search puts the next batch's rescoring enqueue between them): the same results
+        fetch = aggregate_evidence_batch(jobs, ix, keep=keep, python_scoring=python_scoring, two_phase=True,
+                                         **{**dict(n_docs_complete_score=500, max_occurrences_1=1500), **kw})
+        assert callable(fetch)
+        for g, w in zip(fetch(), want):
             _same(g, w, keep)
         # the GPU path's result object answers what callers ask of the host path's dict (Mapping contract, gpu_aggregate._Results)
         from collections.abc import Mapping

@@ -125,9 +125,12 @@ def test_aggregate_evidence_batch_equals_per_query_calls(first_stage_only):
     params = dict(first_stage_only=first_stage_only, add_best_unigrams_to_ngrams=True, use_top_k_unigrams=25,
                   n_docs_complete_score=30, max_occurrences_1=40)
     got = aggregate_evidence_batch(jobs, OracleBatchIndex(orc), **params)
-    for (keys, us), g in zip(jobs, got):
+    later = aggregate_evidence_batch(jobs, OracleBatchIndex(orc), two_phase=True, **params)       # (host route: the callable does all the work)
+    assert callable(later)
+    for (keys, us), g, g2 in zip(jobs, got, later()):
         want = oracle_aggregate_evidence(keys, unigram_scores=None if us is None else us.tolist(), index=orc, **params)
         _same(g, want)
+        _same(g2, want)
 
 
 @pytest.mark.parametrize("seed", range(12))
