@@ -196,3 +196,28 @@ def test_gpu_aggregation_long_documents_and_overflowing_candidate_lists():
     got = aggregate_evidence(keys, unigram_scores=us, index=ix, **kw)
     assert len(want[0]) == 72
     _same(got, want)
+
+
+@pytest.mark.parametrize("nbytes", [16, 4096, 3_000_016, 20, 1_000_004])
+def test_kernel_copy_moves_bytes_both_ways_and_refuses_pageable_memory(nbytes):
+    """``fmi_dev_kernel_copy`` (the aggregation's plan goes up and its records come back through it, not through the DMA queue every
+    stream of the process shares): pinned -> device and device -> pinned, 16-byte and 4-byte granular, by value"""
+    import torch
+    from seal_amd._lib import SealFMError, check, lib
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev, priority=-1)
+    src = torch.randint(0, 256, (nbytes,), dtype=torch.uint8).pin_memory()
+    mid = torch.zeros(nbytes + 64, dtype=torch.uint8, device=dev)
+    back = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+    with torch.cuda.stream(st):
+        check(lib().fmi_dev_kernel_copy(st.cuda_stream, mid.data_ptr(), src.data_ptr(), nbytes))
+        check(lib().fmi_dev_kernel_copy(st.cuda_stream, back.data_ptr(), mid.data_ptr(), nbytes))
+    st.synchronize()
+    assert torch.equal(back, src)
+    assert torch.equal(mid[:nbytes].cpu(), src) and int(mid[nbytes:].sum()) == 0
+    if nbytes == 4096:
+        pageable = torch.zeros(nbytes, dtype=torch.uint8)
+        with pytest.raises(SealFMError):
+            check(lib().fmi_dev_kernel_copy(st.cuda_stream, mid.data_ptr(), pageable.data_ptr(), nbytes))
+        with pytest.raises(SealFMError):
+            check(lib().fmi_dev_kernel_copy(st.cuda_stream, mid.data_ptr() + 2, src.data_ptr(), 8))
