@@ -20,6 +20,8 @@ scaled by ``head_dim ** -0.5``, logits = ``x @ shared^T + final_logits_bias``.
 """
 from typing import Optional
 
+import os
+import sys
 import torch
 import torch.nn.functional as F
 
@@ -424,6 +426,8 @@ class BartStepDecoder:
         if not (self.use_graph and enc_hidden.is_cuda and self.can_teacher_force(enc_hidden, A) and N > 0):
             return None
         Np = (N + self.TREE_NODE_BUCKET - 1) // self.TREE_NODE_BUCKET * self.TREE_NODE_BUCKET
+        if os.environ.get("SEAL_RESCORE_SHAPES"):           # (measurement: how many of a replay's rows are padding)
+            print("[rescore] tree of %d nodes in a graph of %d rows, %d queries, encoder length %d" % (N, Np, Bq, S), file=sys.stderr, flush=True)
         Sp = max(16, (S + 15) // 16 * 16)
         if Sp > 64:
             return None

@@ -355,9 +355,12 @@ def _rescore_tree_jobs(model, jobs):
         V = next(j["bias"] for j in J if j["bias"] is not None).shape[-1]
         logit_bias = torch.cat([j["bias"] if j["bias"] is not None else torch.zeros(len(j["seqs"]), V, dtype=enc.dtype, device=device)
                                 for j in J])
-    # whole queries per forward; the sum of their key lengths, an upper bound of the nodes (typically 3x), stays below `cap`
-    # (the logits are nodes x vocab floats)
-    cap = int(os.environ.get("SEAL_RESCORE_NODES", 12000))
+    # whole queries per forward; the sum of their key lengths, an upper bound of the nodes (3x to 10x: title keys share long prefixes),
+    # stays below `cap`.  The cap dates from when nodes x vocab logits existed at once; they are projected a slice at a time now, and a
+    # cap of 12 000 cut a searcher batch (20 queries x 3 jobs, ~3 300 nodes) into forests of ~2 000 + 700 + 650 nodes = graphs of 2 048 +
+    # 1 024 + 1 024 rows, three forwards of launch-bound height.  One forest of 4 096 rows is the same padded rows in a third of the
+    # launches at twice the GEMM efficiency: 332 -> 367 queries/s on one box (profiles/r5_rescore_one_forest_ab.txt).
+    cap = int(os.environ.get("SEAL_RESCORE_NODES", 48000))
     max_len = max((len(sq) for j in J for ss in j["seqs"] for sq in ss), default=0)
     prepared = None
     fused_ok = enc.is_cuda and max_len > 0 and sd.can_teacher_force(enc, max_len)
