@@ -425,7 +425,8 @@ class BartStepDecoder:
         A = anc.shape[1]
         if not (self.use_graph and enc_hidden.is_cuda and self.can_teacher_force(enc_hidden, A) and N > 0):
             return None
-        Np = (N + self.TREE_NODE_BUCKET - 1) // self.TREE_NODE_BUCKET * self.TREE_NODE_BUCKET
+        bucket = max(64, int(os.environ.get("SEAL_TREE_NODE_BUCKET", self.TREE_NODE_BUCKET)))
+        Np = (N + bucket - 1) // bucket * bucket
         if os.environ.get("SEAL_RESCORE_SHAPES"):           # (measurement: how many of a replay's rows are padding)
             print("[rescore] tree of %d nodes in a graph of %d rows, %d queries, encoder length %d" % (N, Np, Bq, S), file=sys.stderr, flush=True)
         Sp = max(16, (S + 15) // 16 * 16)
