@@ -1016,7 +1016,14 @@ class SEALSearcher:
             if tm == "2" and hasattr(self.fm_index, "_side_stream"):
                 mark("  index stream: aggregation kernels of batch %d done" % i, self.fm_index._side_stream(dev))
             if interleave:
-                to_rescoring(ahead[0])
+                try:
+                    to_rescoring(ahead[0])
+                except BaseException:
+                    try:
+                        fetch()                               # (the plan and the index's aggregation buffers belong to the pending call)
+                    except Exception:
+                        pass
+                    raise
                 mark("  host: next rescoring enqueued", agg_stream)
                 t5 = time.perf_counter()
                 with torch.cuda.stream(agg_stream):
