@@ -150,7 +150,7 @@ def device_array(index, name, typestr):
 # FM-index operations of one batch with the reference's call pattern.
 # ---------------------------------------------------------------------------
 def build_cpu_oracle(index, threads):
-    from oracle.seal_oracle import CppFMIndex, lib as orc_lib
+    from oracle.seal_oracle import lib as orc_lib
     orc_lib().orc_set_threads(threads)
     n = index.size()
     sa = device_array(index, "sa_lo", "<i4")
@@ -174,9 +174,81 @@ def build_cpu_oracle(index, threads):
     if sa_hi is not None:
         sa_s |= sa_hi[::32].long() << 32
     sa_s = sa_s.cpu().numpy().astype(np.uint64)
-    orc = CppFMIndex()
+    orc = _scalar_oracle_class()()
     orc.initialize_from_bwt(bwt, sa_s, isa_s.cpu().numpy().astype(np.uint64))
+    orc.beginnings = index.beginnings
+    orc.batch_threads = threads
     return orc
+
+
+def _scalar_oracle_class():
+    from oracle.seal_oracle import OracleFMIndex
+
+    class ScalarOracleIndex(OracleFMIndex):
+        """The reference's ``seal.index.FMIndex`` interface (index.py:68-118, restated by ``OracleFMIndex``) over the NQ-scale oracle index:
+        what oracle/keys_oracle.py queries one scalar call at a time.  ``locate`` answers from the oracle's own batched entry point
+        (the same LF walks, on all host threads): a miss locates the rest of the current key's rows in one call."""
+        batch_threads = 1
+
+        def __init__(self):
+            super().__init__()
+            self._located, self._range_end = {}, 0
+
+        def get_range(self, sequence):
+            lo, hi = super().get_range(sequence)
+            self._range_end = hi
+            return lo, hi
+
+        def locate(self, row):
+            pos = self._located.get(row)
+            if pos is None:
+                rows = np.arange(row, max(row + 1, min(self._range_end, row + 1500)), dtype=np.uint64)
+                got, _ = self.locate_bin_batch(rows, np.asarray([0], dtype=np.uint64), threads=self.batch_threads)
+                self._located.update(zip(rows.tolist(), got.astype(np.int64).tolist()))
+                pos = self._located[row]
+            return pos
+    return ScalarOracleIndex
+
+
+def aggregation_vs_keys_oracle(orc, agg_calls, n_queries=2):
+    """The evidence aggregation of the timed path's kernels (fmi_aggregate.hip) against oracle/keys_oracle.py -- the independent scalar
+    model of the reference's ``aggregate_evidence`` (keys.py:178-497) that tests/test_reference_golden.py pins to the reference's own
+    outputs -- on a SAMPLE of the recorded batch's queries, at this index's real size: ranked documents, float64 scores (bit for bit),
+    accepted keys with their discounted scores, document tokens, best key.  The searcher's parameters are passed through as recorded."""
+    from oracle.keys_oracle import oracle_aggregate_evidence
+    names = ("max_occurrences_1", "max_occurrences_2", "n_docs_complete_score", "alpha", "beta", "length_penalty", "use_fm_index_frequency",
+             "add_best_unigrams_to_ngrams", "use_top_k_unigrams", "sort_by_length", "sort_by_freq", "smoothing", "allow_overlaps", "single_key",
+             "single_key_add_unigrams", "unigrams_ignore_free_places", "first_stage_only")
+    n_docs = n_bad = n_q = located = 0
+    first_bad = None
+    for a, kw, res in agg_calls:
+        jobs = a[0]
+        okw = {k: kw[k] for k in names if k in kw}
+        for (ngrams, uni), (got, _) in list(zip(jobs, res))[:max(0, n_queries - n_q)]:
+            got = got.result() if hasattr(got, "result") else got
+            keys = [([int(t) for t in (ng.tolist() if hasattr(ng, "tolist") else ng)], float(sc)) for ng, sc in ngrams]
+            us = None if uni is None else [float(x) for x in (uni.tolist() if hasattr(uni, "tolist") else uni)]
+            orc._located.clear()
+            want, _ = oracle_aggregate_evidence(keys, unigram_scores=us, index=orc, **okw)
+            located += len(orc._located)
+            wl = list(want.items())[:len(got)]
+            n_q += 1
+            n_docs += len(wl)
+            n_bad += abs(len(got) - len(wl))
+            for (gd, gi), (wd, wi) in zip(got.items(), wl):
+                same = (int(gd) == int(wd) and float(gi[0]).hex() == float(wi[0]).hex()
+                        and [(tuple(int(t) for t in k), float(v).hex()) for k, v in gi[1]] == [(tuple(int(t) for t in k), float(v).hex()) for k, v in wi[1]]
+                        and [int(t) for t in gi[3]] == [int(t) for t in wi[3]]
+                        and tuple(int(t) for t in gi[4][0]) == tuple(int(t) for t in wi[4][0]) and float(gi[4][1]).hex() == float(wi[4][1]).hex())
+                if not same:
+                    n_bad += 1
+                    first_bad = first_bad or {"query": n_q - 1, "gpu_doc": int(gd), "oracle_doc": int(wd), "gpu_score": float(gi[0]).hex(), "oracle_score": float(wi[0]).hex()}
+    out = {"ops": n_q, "values": n_docs, "mismatches": n_bad, "queries": n_q, "rows_located_by_the_oracle": located,
+           "against": "oracle/keys_oracle.py (scalar model of keys.py:178-497, pinned to the reference's own outputs) over the sdsl-style oracle index of this "
+                      "corpus: document order, float64 scores bit for bit, accepted keys + discounted scores, document tokens, best key"}
+    if first_bad:
+        out["first_mismatch"] = first_bad
+    return out
 
 
 def index_sym_bytes(index):
@@ -584,6 +656,12 @@ def aggregate_roofline(t, index):
                 "note": "k_full_score is an LDS / ALU kernel (hash-trie matching, rank sort and greedy cover in LDS): its HBM bytes are the documents' tokens; "
                         "the radix sorts are rocPRIM's"})
     out["traffic"], out["traffic_source"] = cite_traffic_agg(index)
+    loc_pmc = (out["traffic"] or {}).get("k_agg_locate") if isinstance(out["traffic"], dict) else None
+    if loc_pmc and loc.get("algorithmic_MB"):
+        # k_agg_locate's memory-side bytes per batch over its algorithmic bytes: FETCH_SIZE x 2 (the guide's gfx950 correction) + WRITE_SIZE;
+        # `_uncorrected`: FETCH_SIZE as reported (its small gathers are not the access width the x 2 was calibrated on)
+        out["traffic_ratio"] = round((2 * loc_pmc["fetch_MB"] + loc_pmc["write_MB"]) / loc["algorithmic_MB"], 2)
+        out["traffic_ratio_uncorrected"] = round((loc_pmc["fetch_MB"] + loc_pmc["write_MB"]) / loc["algorithmic_MB"], 2)
     return out
 
 
@@ -596,7 +674,11 @@ def cite_traffic_agg(index=None, root=ROOT):
         for f in sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_agg*.json")), reverse=True):
             pmc = json.load(open(f))
             if pmc.get("_aggregate_source_sha256") == sha:
-                return pmc.get("per_batch_MB"), {"file": os.path.relpath(f, root), "builder_run": True, "aggregate_source_sha256": sha[:16]}
+                per = dict(pmc.get("per_batch_MB") or {})
+                for name, rec in (pmc.get("per_kernel_per_batch") or {}).items():
+                    if name.startswith("k_agg_locate"):
+                        per["k_agg_locate"] = {"fetch_MB": rec["fetch_MB"], "write_MB": rec["write_MB"]}
+                return per, {"file": os.path.relpath(f, root), "builder_run": True, "aggregate_source_sha256": sha[:16]}
         return None, {"refused": "no profiles/r*_pmc_agg*.json taken over the current fmi_aggregate.hip (sha256 %s)" % sha[:16]}
     except Exception as e:
         return None, {"error": repr(e)}
@@ -660,6 +742,57 @@ def dry_run_launch(args) -> int:
     return 0 if int(t.item()) == world else 4
 
 
+def cpu_smoke(args) -> int:
+    """--cpu-smoke: the N > 1 plumbing of this file end to end WITHOUT a GPU -- launcher (above) -> one rank per "GPU" -> process group
+    (gloo) -> this rank's contiguous block of the queries (seal_amd.distributed.shard_queries) -> the product's SEALSearcher.batch_search
+    -> pack_topk -> ONE all_gather (gather_topk) -> barrier, max-over-ranks time, ONE line on rank 0 with the same launch fields as the
+    real line (n_gpus, ranks_seen, per-rank figures) and the gathered top-k as hex, so that a test can hold N = 2 to N = 1 bit for bit.
+    A TEST MODE, not a measurement: the searcher is the tiny CPU one of tests/test_distributed_gloo.py whose index queries are answered
+    by the oracle (tests/ infrastructure); nothing here is timed for the record and the line says so."""
+    import torch.distributed as dist
+    from seal_amd.distributed import gather_topk, pack_topk, shard_bounds, shard_queries
+    from tests.test_distributed_gloo import _cpu_searcher
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    torch.set_num_threads(2)
+    use_dist = world > 1 or bool(os.environ.get("SEAL_BENCH_FORCE_DIST"))
+    if use_dist:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    searcher, queries = _cpu_searcher(batch_size=1)
+    mine = shard_queries(queries, rank, world)
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    res = searcher.batch_search(mine, k=args.topk, detokenize=False) if mine else []
+    top = gather_topk(pack_topk(res, args.topk), len(queries))
+    if use_dist:
+        dist.barrier()
+    mine_s = time.perf_counter() - t0
+    t = torch.tensor([mine_s], dtype=torch.float64)
+    per_rank = [torch.tensor([len(mine) / mine_s], dtype=torch.float64)]
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([len(mine) / mine_s], dtype=torch.float64))
+    if rank == 0:
+        import hashlib
+        raw = top.contiguous().numpy().tobytes()
+        print(json.dumps({"metric": "cpu smoke of the N-rank path (launcher, shard, search, top-k gather, one line): a test mode, NOT a measurement",
+                          "cpu_smoke": True, "value": round(len(queries) / float(t.item()), 3), "unit": "queries/s", "n_gpus": world,
+                          "ranks_seen": dist.get_world_size() if use_dist else 1, "requested_gpus": args.gpus, "queries": len(queries),
+                          "shards": [list(shard_bounds(len(queries), r, world)) for r in range(world)],
+                          "per_rank_queries_per_s_min": round(min(float(x) for x in per_rank), 3),
+                          "per_rank_queries_per_s_max": round(max(float(x) for x in per_rank), 3),
+                          "topk_shape": list(top.shape), "topk_sha256": hashlib.sha256(raw).hexdigest(), "topk_hex": raw.hex(),
+                          "config": {"workload": "tests/golden/ref_searcher.json corpus, tiny BART on CPU, index queries answered by the oracle",
+                                     "parallelism": f"query-sharded x{world}, backend {'gloo' if use_dist else 'none'}"}}), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -682,6 +815,9 @@ def main():
     ap.add_argument("--cpu-locate-sample", type=int, default=0, help="CPU oracle replay: every k-th located row / every k-th document only "
                     "(0: all at nq, 64 at stress: sdsl's sampled suffix array costs ~31 LF steps per row on the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--keys-oracle-queries", type=int, default=2, help="queries of the recorded batch whose aggregation is also held to "
+                    "oracle/keys_oracle.py (python loops over every located row: seconds per query)")
+    ap.add_argument("--latency-batches", type=int, default=20, help="un-pipelined single batches timed AFTER the timed region for the p50 latency")
     ap.add_argument("--with-other-depth", action="store_true", help="also time the same batches through the other retrieval depth "
                     "(first stage only <-> complete search); first-stage-only aggregates on the host and is slow on the phrase corpus")
     ap.add_argument("--corpus-phrases", type=int, default=int(os.environ.get("SEAL_BENCH_PHRASES", 20000000)),
@@ -692,12 +828,16 @@ def main():
                     help="stop after the first retrieval stage (SURVEY.md 8d metric) instead of the reference's complete batch_search")
     ap.add_argument("--dry-run-launch", action="store_true", help="start the ranks, form the process group (nccl = RCCL with a GPU, gloo without), "
                     "all-reduce a one per rank and print the line's launch fields only: checks the N-rank launch without building an index")
+    ap.add_argument("--cpu-smoke", action="store_true", help="TEST MODE, no GPU: the launcher -> ranks -> shard -> search -> top-k gather -> one "
+                    "line path over the tiny CPU searcher of tests/test_distributed_gloo.py (gloo); the line carries the gathered top-k as hex")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as the driver types it: nobody started the ranks yet -> this process becomes the launcher
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.dry_run_launch:
         sys.exit(dry_run_launch(args))
+    if args.cpu_smoke:
+        sys.exit(cpu_smoke(args))
     # the contract is ONE JSON line on stdout: RCCL prints a version banner there (seen with one rank: five lines after
     # the JSON line), so file descriptor 1 is pointed at stderr for everything but the line itself
     sys.stdout.flush()
@@ -801,8 +941,9 @@ def main():
     index.labels = None
     del data, _text
     torch.cuda.empty_cache()
+    index_build_s = time.perf_counter() - t0
     log(f"index: n={index.size()} levels={lib().fmi_levels(index.handle)} HBM={index.device_bytes() / 2**30:.1f} GiB "
-        f"built on GPU in {time.perf_counter() - t0:.1f}s")
+        f"built on GPU in {index_build_s:.1f}s")
 
     from transformers import BartConfig, BartForConditionalGeneration
     t0 = time.perf_counter()
@@ -881,10 +1022,28 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
+    my_elapsed = elapsed
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # p50 latency: `--latency-batches` single batches, one at a time (nothing enqueued ahead: what one caller of batch_search waits for),
+    # AFTER warm-up and the timed region -- the timed region's own batches run once more, each bracketed by a device synchronise
+    lat_ms = []
+    for j in range(max(0, args.latency_batches)):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_batch(args.warmup + j % max(1, args.steps))
+        torch.cuda.synchronize()
+        lat_ms.append((time.perf_counter() - t1) * 1e3)
+    lat = torch.tensor([float(np.median(lat_ms)) if lat_ms else 0.0, float(np.percentile(lat_ms, 90)) if lat_ms else 0.0], dtype=torch.float64, device=dev)
+    my_qps = torch.tensor([args.batch * args.steps / my_elapsed, index_build_s], dtype=torch.float64, device=dev)
+    per_rank = [my_qps.tolist()]
+    if use_dist:
+        dist.all_reduce(lat, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(my_qps) for _ in range(world)]
+        dist.all_gather(gathered, my_qps)
+        per_rank = [g.tolist() for g in gathered]
     import resource
     peak_rss_gib = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20        # this rank's peak host RSS so far (KiB -> GiB)
     if use_dist:
@@ -944,6 +1103,11 @@ def main():
         print("[bench] same box, %s (queries/s over %d batches per leg%s): %s" % (var, args.steps, ", results left to the collector" if ab["garbage"] else "",
               "; ".join("%s: %s" % (v, ab[v]) for v in vals)), file=sys.stderr, flush=True)
 
+    world_seen = dist.get_world_size() if use_dist else 1
+    try:
+        rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version()) if use_dist else None
+    except Exception as e:
+        rccl_version = "unknown (%r)" % (e,)
     if rank != 0:
         if use_dist:
             dist.barrier()
@@ -1100,6 +1264,17 @@ def main():
                                     "rows the allowed tokens themselves (list mode); chains_us = what the chains add to that launch (its duration as ONE "
                                     "launch minus its bookkeeping's), chains_alone_us = the chains as a launch of their own (upper bound), both included "
                                     "in us / us_upper_bound; chains_MB = their blocks")
+        # the same facts as FLAT scalars (a record that keeps only the scalar members of `roofline` still shows the per-call picture)
+        wc = roofline["widest_call"]
+        roofline.update({"widest_call_frac": wc["frac"], "widest_call_MB": wc["MB"], "widest_call_us": wc["us"], "widest_call_cur_len": wc["cur_len"],
+                         "widest_call_form": wc["form"]})
+        by_rank = sorted(by_call, key=lambda c: -c["MB"])
+        mid = [c for c in by_call if c["form"] != "table" and c["MB"] >= 10.0]      # the wide non-table calls: 3rd..5th token of the two decodes
+        if mid:
+            mb, us = sum(c["MB"] for c in mid), sum(c["us"] for c in mid)
+            roofline.update({"frac_3rd_to_5th_token": round(mb * 1e6 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4), "MB_3rd_to_5th_token": round(mb, 2),
+                             "us_3rd_to_5th_token": round(us, 2), "calls_3rd_to_5th_token": len(mid)})
+        roofline["calls_MB_desc"] = ", ".join("%.1f MB @ %.3f" % (c["MB"], c["frac"] or 0.0) for c in by_rank[:5])
     roofline_aggregate = aggregate_roofline(agg_timing, index)
 
     cpu = parity = None
@@ -1146,6 +1321,13 @@ def main():
         parity["by_kind"]["aggregated_documents_scores_and_keys"] = {"ops": len(agg_calls), "values": n_docs_cmp, "mismatches": n_bad,
                                                                       "against": "fmi_first_stage + fmi_full_score (host float64 routines) on the same keys"}
         log(f"aggregation parity: {n_docs_cmp} ranked documents vs the host routines in {time.perf_counter() - t0:.1f}s, {n_bad} mismatches")
+        # ... and, on a sample of the same queries, against the independent scalar model of the reference's aggregate_evidence
+        t0 = time.perf_counter()
+        ko = aggregation_vs_keys_oracle(orc, agg_calls, n_queries=args.keys_oracle_queries)
+        parity["by_kind"]["aggregated_documents_vs_keys_oracle"] = ko
+        parity["ops"] += ko["ops"]; parity["values_compared"] += ko["values"]; parity["mismatches"] += ko["mismatches"]
+        log(f"aggregation parity: {ko['values']} ranked documents of {ko['queries']} queries vs oracle/keys_oracle.py in {time.perf_counter() - t0:.1f}s "
+            f"({ko['rows_located_by_the_oracle']} rows located on the host), {ko['mismatches']} mismatches")
         # the suffix array itself, independently of the builder (the oracle above is fed this index's own BWT / SA samples)
         audit = sa_audit(index)
         audit["text_equals_input_corpus"] = text_is_input
@@ -1216,12 +1398,23 @@ def main():
                                                                                  "spaCy/BART tokenizer absent offline: seal_amd.query_keys.token_ngram_keys)",
                    "not_in_step": (["full-document rescoring (keys.py:366-497)"] if args.first_stage_only else []) +
                                   (["query n-gram keys (add_query_to_keys)"] if args.no_query_keys else [])},
+        "p50_batch_latency_ms": round(float(lat[0]), 2) if lat_ms else None,
+        "ranks_seen": world_seen, "rccl_version": rccl_version,
+        "per_rank_queries_per_s_min": round(min(r[0] for r in per_rank), 2), "per_rank_queries_per_s_max": round(max(r[0] for r in per_rank), 2),
+        "per_rank_index_build_s": [round(r[1], 1) for r in per_rank],
         "roofline": roofline,
         "roofline_aggregate": roofline_aggregate,
+        "roofline_aggregate_frac": None if not roofline_aggregate else roofline_aggregate.get("frac"),
+        "roofline_aggregate_traffic_ratio": None if not roofline_aggregate else roofline_aggregate.get("traffic_ratio"),
+        "roofline_aggregate_total_us": None if not roofline_aggregate else roofline_aggregate.get("total_us"),
         "cpu_baseline": cpu,
         "parity_check": parity,
         "extra": {("complete_search_qps" if args.first_stage_only else "first_stage_only_qps"): None if other_qps is None else round(other_qps, 3),
-                  "p50_batch_latency_ms_unpipelined": round(float(np.median(step_ms[1:] or step_ms)), 2) if step_ms else None, "docs_returned_per_query": n_found,
+                  "p50_batch_latency_ms_unpipelined": round(float(lat[0]), 2) if lat_ms else None,
+                  "p90_batch_latency_ms_unpipelined": round(float(lat[1]), 2) if lat_ms else None,
+                  "latency_batches": len(lat_ms), "latency_note": "single batches after warm-up and the timed region, nothing enqueued ahead, device "
+                                                                  "synchronised on both sides; max over ranks of the per-rank median",
+                  "warmup_batch_ms": [round(x, 1) for x in step_ms], "docs_returned_per_query": n_found,
                   "peak_host_rss_gib_per_rank_max": round(peak_rss_gib, 2),
                   "timed_region_instrumentation": "none: probe counters and constraint-call event pairs are off during warm-up and the timed call; "
                                                   "roofline figures come from separate un-overlapped passes after it",

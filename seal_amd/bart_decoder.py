@@ -225,13 +225,16 @@ class BartStepDecoder:
 
     def _encoder_qkv(self, layer):
         """(weight [3d, d], bias [3d]) of an encoder layer's q / k / v projections as one product, made once"""
+        # validated by the six source parameters' modification counters: a checkpoint loaded in place keeps every address
+        from .split_gemm import tensor_version
         cache = self.__dict__.setdefault("_enc_qkv", {})
-        wb = cache.get(id(layer))
-        if wb is None:
-            sa = layer.self_attn
-            wb = cache[id(layer)] = (torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0).detach().contiguous(),
-                                     torch.cat([sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias], 0).detach().contiguous())
-        return wb
+        sa = layer.self_attn
+        src = (sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight, sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias)
+        stamp = tuple((t.data_ptr(), tensor_version(t)) for t in src)
+        hit = cache.get(id(layer))
+        if hit is None or hit[0] != stamp:
+            hit = cache[id(layer)] = (stamp, torch.cat(src[:3], 0).detach().contiguous(), torch.cat(src[3:], 0).detach().contiguous())
+        return hit[1], hit[2]
 
     # ------------------------------------------------------------------
     # static-shape state: one set of buffers (and one hipGraph) per
@@ -519,7 +522,7 @@ class BartStepDecoder:
             # (self-attention output, cross-attention query and output) run as 4 split-K slabs that the consumer adds as it reads them, and
             # the attention kernels hand their result over as the next projection's split planes -- the library's fp32 GEMM of 17 us (600 rows)
             # / 12 us (300) becomes 11 / 7 us (profiles/r5_hgemm_probe.txt), with no pass over the activations in between.
-            hand = bool(planes and x.dtype == torch.float32 and split_gemm.hand_config(R, self.d, 3 * self.d) is not None)
+            hand = bool(planes and x.dtype == torch.float32 and split_gemm.DEFER_EPILOGUE and split_gemm.hand_config(R, self.d, 3 * self.d) is not None)
             flag = split_gemm._flag(x.device).data_ptr() if hand else None
             for li, L in enumerate(self.layers):
                 qkv = self._lin_p(x, xp, L["qkv_w"], L["qkv_b"], defer=True, slabs_ok=hand)

@@ -2280,7 +2280,7 @@ __global__ __launch_bounds__(64 * ADV_MAX_WAVES) void k_beam_advance(FmiDev ix, 
             for (uint32_t i = 0; i < LIST_PER_LANE; i++) {
                 slot[i] = 0;
                 if (64 * i < pm) {
-                    const bool match = lane + 64 * i < pm && (uint64_t)ps[i] == sym && pp[i] > 0;
+                    const bool match = lane + 64 * i < pm && (uint64_t)ps[i] == sym;
                     const uint64_t bal = __ballot(match);
                     slot[i] = base + lane_rank_in(bal);
                     base += (uint32_t)__popcll(bal);
@@ -2290,7 +2290,9 @@ __global__ __launch_bounds__(64 * ADV_MAX_WAVES) void k_beam_advance(FmiDev ix, 
             m = base;
 #pragma unroll
             for (uint32_t i = 0; i < LIST_PER_LANE; i++) {          // ONE dependent access: the survivors' new symbols, gathered together
-                if ((sel >> i) & 1) { pp[i] -= 1; sv[i] = pp[i] ? (uint32_t)text_at(ix, pp[i] - 1) : 0u; }     // position 0: the sentinel is in front
+                // (cyclic, as the BWT is: the symbol in front of position 0 is text[n-1] -- the sentinel in every index this library builds,
+                //  which no search symbol equals; the range -> list conversion below reads it the same way)
+                if ((sel >> i) & 1) { pp[i] = pp[i] ? pp[i] - 1 : ix.n - 1; sv[i] = (uint32_t)text_at(ix, pp[i] ? pp[i] - 1 : ix.n - 1); }
             }
             if (a.probe_counter && lane == 0) probes += ((uint64_t)pm * 8 + 127) / 128 + ((uint64_t)pm * 4 + 127) / 128 + m;
         } else {

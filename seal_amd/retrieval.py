@@ -1008,9 +1008,12 @@ class SEALSearcher:
                 to_rescoring(ahead[0])
             if tm == "2":
                 self.fm_index.__dict__["_agg_mark"] = mark
-            with torch.cuda.stream(agg_stream):
-                fetch = rk.aggregate_evidence_batch(jobs, self.fm_index, two_phase=interleave, keep=keep, gpu_aggregate=self.gpu_aggregate,
-                                                    want_ngrams=False, **params)
+            try:
+                with torch.cuda.stream(agg_stream):
+                    fetch = rk.aggregate_evidence_batch(jobs, self.fm_index, two_phase=interleave, keep=keep, gpu_aggregate=self.gpu_aggregate,
+                                                        want_ngrams=False, **params)
+            finally:
+                self.fm_index.__dict__.pop("_agg_mark", None)      # (only this call's _run_plan may record into this loop's list)
             t4 = time.perf_counter()
             mark("  host: aggregation of batch %d launched" % i, agg_stream)
             if tm == "2" and hasattr(self.fm_index, "_side_stream"):
@@ -1038,7 +1041,6 @@ class SEALSearcher:
                       (i, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (time.perf_counter() - t5) * 1e3, (t5 - t4) * 1e3), file=sys.stderr, flush=True)
             held = out
         if marks:
-            self.fm_index.__dict__.pop("_agg_mark", None)
             torch.cuda.synchronize(dev)
             t_first, prev = marks[0][1], None
             for label, ev in sorted(marks, key=lambda m: t_first.elapsed_time(m[1])):

@@ -213,6 +213,12 @@ class SplitLinear:
         return torch.addmm(self.bias, planes, self.wt, alpha=self.alpha, out_dtype=torch.float32)
 
 
+def tensor_version(t: torch.Tensor) -> int:
+    """the tensor's in-place modification counter; an inference tensor (made under ``torch.inference_mode``: the rescoring entry points
+    build their fused q/k/v weights there) has none and cannot be modified in place outside inference mode: -1 stands for ``as made``"""
+    return -1 if t.is_inference() else t._version
+
+
 class SplitLinears:
     """the split operands of a model's weights, made on first use and kept (keyed by the weight tensor's storage)"""
 
@@ -232,13 +238,14 @@ class SplitLinears:
         # and a checkpoint loaded in place keeps its address
         import weakref
         key = (weight.data_ptr(), tuple(weight.shape))
+        version = tensor_version(weight)
         hit = self._by_weight.get(key)
         if hit is not None:
-            ref, version, lin = hit
-            if ref() is weight and version == weight._version:
+            ref, seen, lin = hit
+            if ref() is weight and seen == version:
                 return lin
         lin = SplitLinear(weight, bias)
-        self._by_weight[key] = (weakref.ref(weight), weight._version, lin)
+        self._by_weight[key] = (weakref.ref(weight), version, lin)
         return lin
 
     def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias=None, defer: bool = False):

@@ -373,15 +373,18 @@ class _ModelForTheReferenceLoop:
         return dict(model_kwargs, past=None)
 
 
-def beam_cases():
+def beam_cases(model_kw=None, configurations=None):
     """seal/beam_search.py::fm_index_generate(keep_history=True) -- the reference's whole decode: constrained beam
-    loop, BeamSearchScorerWithMemory, BeamHypothesesWithMemory, IndexBasedLogitsProcessor"""
+    loop, BeamSearchScorerWithMemory, BeamHypothesesWithMemory, IndexBasedLogitsProcessor.
+    ``model_kw``: another geometry of the seeded tiny BART (d_model=128, heads=2: head_dim 64, the one the fused
+    sealnn_* decoder kernels run at -- the *_dh64.json fixtures of the -m gpu twins); ``configurations``: which of
+    the seven option sets"""
     import torch
     from seal.beam_search import fm_index_generate
     from seal.index import FMIndex
     from tests.helpers import tiny_bart
     vocab = 120
-    bart = tiny_bart(vocab)
+    bart = tiny_bart(vocab, **(model_kw or {}))
     rng = random.Random(31)
     docs = []
     for _ in range(150):
@@ -393,18 +396,19 @@ def beam_cases():
     enc_ids = torch.randint(4, vocab, (4, 8))
     enc_mask = torch.ones_like(enc_ids)
     cases = []
-    for kw in (dict(max_length=6, num_beams=3, length_penalty=0.0),
-               dict(max_length=5, num_beams=4, length_penalty=1.0),
-               dict(max_length=7, num_beams=3, length_penalty=0.0, force_decoding_from=[2], eos_token_id=7),
-               dict(max_length=5, num_beams=2, length_penalty=0.0, always_allow_eos=True),
-               dict(max_length=5, num_beams=3, length_penalty=0.0, stop_at_count=2),
-               dict(max_length=8, num_beams=5, length_penalty=0.5, stop_at_count=1, always_allow_eos=True),
-               dict(max_length=4, num_beams=3, length_penalty=0.0, disable_fm_index=True)):
+    option_sets = (dict(max_length=6, num_beams=3, length_penalty=0.0),
+                   dict(max_length=5, num_beams=4, length_penalty=1.0),
+                   dict(max_length=7, num_beams=3, length_penalty=0.0, force_decoding_from=[2], eos_token_id=7),
+                   dict(max_length=5, num_beams=2, length_penalty=0.0, always_allow_eos=True),
+                   dict(max_length=5, num_beams=3, length_penalty=0.0, stop_at_count=2),
+                   dict(max_length=8, num_beams=5, length_penalty=0.5, stop_at_count=1, always_allow_eos=True),
+                   dict(max_length=4, num_beams=3, length_penalty=0.0, disable_fm_index=True))
+    for kw in (option_sets if configurations is None else [option_sets[i] for i in configurations]):
         model = _ModelForTheReferenceLoop(bart, enc_ids, enc_mask)
         with torch.no_grad():
             out = fm_index_generate(model, index, enc_ids, enc_mask, min_length=1, keep_history=True, **kw)
         cases.append({"kwargs": kw, "hypotheses": [[[fhex(s), [int(t) for t in toks]] for s, toks in per_query] for per_query in out]})
-    return {"vocab": vocab, "docs": docs, "enc_ids": enc_ids.tolist(), "cases": cases}
+    return {"vocab": vocab, **({"model_kw": model_kw} if model_kw else {}), "docs": docs, "enc_ids": enc_ids.tolist(), "cases": cases}
 
 
 class _ModelForTheReferenceSearcher(_ModelForTheReferenceLoop):
@@ -433,8 +437,9 @@ class _ModelForTheReferenceSearcher(_ModelForTheReferenceLoop):
         return super().__call__(decoder_input_ids)
 
 
-def searcher_cases():
-    """seal/retrieval.py end to end: SEALSearcher.batch_search = batch_generate_keys.process_batch (body decode,
+def searcher_cases(model_kw=None, runs=None):
+    """(``model_kw`` / ``runs``: as in ``beam_cases`` -- another model geometry, a subset of the four runs.)
+    seal/retrieval.py end to end: SEALSearcher.batch_search = batch_generate_keys.process_batch (body decode,
     post-filters, rescoring, title decode, title filters, rescoring, dedup, unigram scores) + retrieve_from_keys
     (aggregate_evidence with the searcher's parameters) + SEALDocument.  Two runs without the query n-gram keys and one
     with them (add_query_to_keys=True, the reference's default: retrieval.py:115-149 with a whitespace word tokenizer in
@@ -455,19 +460,21 @@ def searcher_cases():
     queries_ids = [[0] + rng.integers(4, vocab - 8, size=int(rng.integers(4, 9))).tolist() + [2] for _ in range(3)]
     queries = [" ".join(f"w{t}" for t in q[1:-1]) for q in queries_ids]
     real_generate = ref_retrieval.fm_index_generate
-    out = {"vocab": vocab, "beam": K, "length": length, "title_eos": title_eos, "docs": docs, "queries": queries_ids, "runs": []}
+    out = {"vocab": vocab, **({"model_kw": model_kw} if model_kw else {}), "beam": K, "length": length, "title_eos": title_eos, "docs": docs,
+           "queries": queries_ids, "runs": []}
     ref_retrieval.word_tokenizer = _split_words
     # 15 is the reference's constant; 8 is what tests/test_gpu_search.py runs both sides at
     # the fourth run switches the code decode on (retrieval.py:212-264; partial_code: this corpus has no code sections, so
     # complete code keys do not exist)
-    for title_length, query_keys, code in ((8, False, False), (15, False, False), (8, True, False), (8, False, True)):
+    all_runs = ((8, False, False), (15, False, False), (8, True, False), (8, False, True))
+    for title_length, query_keys, code in (all_runs if runs is None else [all_runs[i] for i in runs]):
         def generate(*a, **kw):
             if kw.get("force_decoding_from"):
                 kw = {**kw, "max_length": title_length}
             return real_generate(*a, **kw)
         ref_retrieval.fm_index_generate = generate
         try:
-            s = SEALSearcher(index, ToyTokenizer(vocab), _ModelForTheReferenceSearcher(tiny_bart(vocab)), backbone="bart-tiny",
+            s = SEALSearcher(index, ToyTokenizer(vocab), _ModelForTheReferenceSearcher(tiny_bart(vocab, **(model_kw or {}))), backbone="bart-tiny",
                              length=length, beam=K, batch_size=2, add_query_to_keys=query_keys, detokenize=True,
                              **(dict(decode_code=True, partial_code=True) if code else {}))
             # (include_keys=True cannot be used with more than one query: batch_search's `for k, _ in kk` rebinds its own
@@ -526,6 +533,15 @@ def main():
     with open(os.path.join(HERE, "ref_beam_search.json"), "w") as f:
         json.dump({"source": "seal/beam_search.py::fm_index_generate on tests.helpers.tiny_bart(120), CPU fp32, HF-4.1x hooks given back by hand",
                    **beam_cases()}, f)
+    # the same two, at the head_dim-64 geometry the fused decoder kernels run at (tests/test_gpu_reference_golden.py holds the HIP index +
+    # fused step decoder to them directly)
+    dh64 = dict(d_model=128, heads=2)
+    with open(os.path.join(HERE, "ref_searcher_dh64.json"), "w") as f:
+        json.dump({"source": "seal/retrieval.py::SEALSearcher.batch_search on tests.helpers.tiny_bart(120, d_model=128, heads=2), CPU fp32",
+                   **searcher_cases(model_kw=dh64, runs=(0, 2))}, f)
+    with open(os.path.join(HERE, "ref_beam_search_dh64.json"), "w") as f:
+        json.dump({"source": "seal/beam_search.py::fm_index_generate on tests.helpers.tiny_bart(120, d_model=128, heads=2), CPU fp32, HF-4.1x hooks "
+                             "given back by hand", **beam_cases(model_kw=dh64, configurations=(0, 1, 2, 4, 5))}, f)
     with open(os.path.join(HERE, "ref_model_side.json"), "w") as f:
         json.dump({"source": "seal/keys.py::compute_unigram_scores, rescore_keys on tests.helpers.tiny_bart(vocab=120, seed=3), CPU fp32",
                    **model_cases()}, f)
@@ -536,7 +552,8 @@ def main():
     with open(os.path.join(HERE, "ref_index_and_mask.json"), "w") as f:
         json.dump({"source": "seal/index.py::FMIndex and seal/beam_search.py::IndexBasedLogitsProcessor.__call__",
                    "cases": index_and_processor_cases()}, f)
-    for name in ("ref_aggregate_evidence.json", "ref_helpers.json", "ref_index_and_mask.json", "ref_model_side.json", "ref_beam_search.json", "ref_searcher.json", "ref_checkpoint.json"):
+    for name in ("ref_aggregate_evidence.json", "ref_helpers.json", "ref_index_and_mask.json", "ref_model_side.json", "ref_beam_search.json", "ref_searcher.json", "ref_checkpoint.json",
+                 "ref_beam_search_dh64.json", "ref_searcher_dh64.json"):
         print(name, os.path.getsize(os.path.join(HERE, name)), "bytes")
 
 

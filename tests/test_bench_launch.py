@@ -53,3 +53,26 @@ def test_a_launcher_that_set_the_world_is_respected():
     assert r.returncode == 0, r.stderr[-2000:]
     assert "launching" not in r.stderr
     assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_cpu_smoke_two_ranks_gather_the_single_rank_topk():
+    """bench.py's REAL N > 1 path -- `python bench.py --gpus 2` becomes the launcher, two gloo ranks shard the queries, run the product's
+    SEALSearcher.batch_search (tiny CPU searcher, oracle-answered index), all-gather the top-k, and rank 0 prints ONE line -- must gather
+    bit for bit what one rank computes over all the queries.  So the first run on 8 GPUs is not also the first run of this plumbing."""
+    outs = {}
+    for n in (1, 2):
+        r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--cpu-smoke", "--topk", "10"], env=_env(), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        outs[n] = json.loads(lines[0])
+    one, two = outs[1], outs[2]
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["requested_gpus"] == 2 and two["cpu_smoke"] is True
+    assert two["shards"][0][0] == 0 and two["shards"][0][1] == two["shards"][1][0] and two["shards"][1][1] == two["queries"]
+    assert two["topk_shape"] == one["topk_shape"] == [one["queries"], 10, 2]
+    assert two["topk_hex"] == one["topk_hex"] and two["topk_sha256"] == one["topk_sha256"]
+    import numpy as np
+    top = np.frombuffer(bytes.fromhex(two["topk_hex"]), dtype=np.float64).reshape(two["topk_shape"])
+    assert (top[:, 0, 0] >= 0).all()                      # every query found documents
+    assert two["per_rank_queries_per_s_min"] > 0

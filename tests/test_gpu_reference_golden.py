@@ -1,0 +1,144 @@
+"""-m gpu twins of tests/test_reference_golden.py's decode and search tests: the HIP index (libsealfm.so) + the product's
+decode loop and step decoder on cuda:0 held DIRECTLY to what the reference's own Python produced -- tests/golden/ref_beam_search*.json
+(seal/beam_search.py:391-557, fm_index_generate(keep_history=True) run for real) and ref_searcher*.json (seal/retrieval.py:649-691,
+SEALSearcher.batch_search run for real) -- not through the oracle.  Two model geometries: head_dim 8 (torch-op decoder fallback, HIP
+constraint / beam kernels) and head_dim 64 (*_dh64.json: the fused sealnn_* step decoder, BART-large's head width).  Integers (token
+sequences, document ids, docids, document tokens) exact; scores within 1e-4 (north_star).  Nothing here imports oracle/."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def _unhex(x):
+    return float.fromhex(x)
+
+
+BEAMS = {"dh8": _load("ref_beam_search.json"), "dh64": _load("ref_beam_search_dh64.json")}
+BEAM_CASES = [(g, i) for g, b in BEAMS.items() for i in range(len(b["cases"]))]
+SEARCHES = {"dh8": _load("ref_searcher.json"), "dh64": _load("ref_searcher_dh64.json")}
+SEARCH_RUNS = [(g, i) for g, s in SEARCHES.items() for i in range(len(s["runs"]))]
+
+
+def _kept(hyps, index, title_eos=None):
+    """what the searcher keeps of a hypothesis list (reference retrieval.py:85-91 / 178-191, then first occurrence, retrieval.py:281),
+    with the corpus-membership filter answered by the HIP index itself: the level at which the reference is deterministic
+    (torch.topk orders the -inf candidates of a short beam arbitrarily)"""
+    out = {}
+    for score, toks in hyps:
+        k = list(toks)
+        if title_eos is not None:
+            if k and k[-1] in (0, 2):
+                k = k[:-1]
+            if not k or k[-1] != title_eos:
+                continue
+            if k[0] != 2:
+                k = [2] + k
+        else:
+            for _ in range(2):
+                if k and k[0] in (0, 2):
+                    k = k[1:]
+            if k and k[-1] in (0, 2):
+                k = k[:-1]
+        if k and index.get_count(k) > 0:
+            out.setdefault(tuple(k), score)
+    return out
+
+
+@pytest.mark.parametrize("geom,case_no", BEAM_CASES, ids=["%s-%d" % c for c in BEAM_CASES])
+def test_gpu_decode_equals_the_reference_loop(geom, case_no):
+    """``fm_index_generate`` on the GPU -- HIP constraint (k_constrain / tables / chains), fused constrained top-2K, k_beam_advance, the
+    step decoder -- against the hypotheses the reference's own beam loop, scorer with memory and logits processor returned for the same
+    seeded model, corpus and encoder inputs."""
+    from seal_amd import FMIndex, fm_index_generate
+    from tests.helpers import tiny_bart
+    B = BEAMS[geom]
+    case = B["cases"][case_no]
+    kw = dict(case["kwargs"])
+    dev = torch.device("cuda:0")
+    model = tiny_bart(B["vocab"], **B.get("model_kw", {})).to(dev)
+    ix = FMIndex()
+    ix.initialize(B["docs"])
+    enc_ids = torch.tensor(B["enc_ids"], device=dev)
+    got = fm_index_generate(model, ix, enc_ids, torch.ones_like(enc_ids), min_length=1, keep_history=True, **kw)
+    mk = B.get("model_kw", {})
+    fused_geometry = mk.get("d_model", 32) // mk.get("heads", 4) == 64
+    assert model._seal_step_decoder._st.fused is fused_geometry        # no silent fallback from the sealnn_* kernels
+    want = [[(_unhex(s), toks) for s, toks in per_query] for per_query in case["hypotheses"]]
+    title_eos = kw.get("eos_token_id", 2) if kw.get("force_decoding_from") else None
+    assert len(got) == len(want)
+    n_keys = 0
+    for g, w in zip(got, want):
+        gv, wv = _kept(g, ix, title_eos), _kept(w, ix, title_eos)
+        assert set(gv) == set(wv)                                       # token sequences: exact
+        for k in wv:
+            assert abs(gv[k] - wv[k]) <= 1e-4, (k, gv[k], wv[k])       # beam scores: 1e-4
+        n_keys += len(wv)
+        if kw.get("disable_fm_index"):                                  # no -inf candidates without the constraint: the whole list, in order
+            assert [list(t) for _, t in g] == [list(t) for _, t in w]
+            assert all(abs(a - b) <= 1e-4 for (a, _), (b, _) in zip(g, w))
+    assert n_keys > 0
+
+
+@pytest.mark.parametrize("geom,run_no", SEARCH_RUNS, ids=["%s-%d" % c for c in SEARCH_RUNS])
+def test_gpu_searcher_equals_the_reference_searcher(geom, run_no, monkeypatch):
+    """the product's ``SEALSearcher.batch_search`` on the GPU (HIP index, fused decode, device aggregation, overlapped default path)
+    against what the reference's own SEALSearcher returned: keys (same n-grams, scores 1e-4), ranked documents (ids, docids, document
+    tokens exact wherever the reference's own scores are separated by more than the tolerance; scores 1e-4 relative)."""
+    from seal_amd import FMIndex, retrieval
+    from seal_amd.retrieval import SEALSearcher
+    from tests.helpers import tiny_bart
+    S = SEARCHES[geom]
+    run = S["runs"][run_no]
+    vocab, K, length, title_eos = S["vocab"], S["beam"], S["length"], S["title_eos"]
+    dev = torch.device("cuda:0")
+    ix = FMIndex()
+    ix.initialize(S["docs"])
+    ix.labels = [f"d{i}" for i in range(len(S["docs"]))]
+    monkeypatch.setattr(retrieval, "TITLE_MAX_LENGTH", run["title_length"])     # 15 in both code bases; the fixture runs also use 8
+    code = bool(run.get("decode_code"))
+    model = tiny_bart(vocab, **S.get("model_kw", {})).to(dev)
+    s = SEALSearcher(ix, None, model, backbone="bart-tiny", length=length, beam=K, batch_size=2,
+                     add_query_to_keys=run["add_query_to_keys"], detokenize=False, title_eos_token_id=title_eos, code_eos_token_id=vocab - 6,
+                     code_bos_token_id=title_eos, decode_code=code, partial_code=code,
+                     marker_token_ids={"body": [vocab - 2, vocab - 3], "title": [vocab - 2, vocab - 4], "+": [vocab - 2, vocab - 5],
+                                       "code": [vocab - 2, vocab - 7]})
+    queries = S["queries"]
+    for got_q, want_q in zip(s.batch_generate_keys(queries), run["queries"]):
+        gk = {tuple(k): v for k, v in got_q[0]}
+        wk = {tuple(k): _unhex(v) for k, v in want_q["keys"]}
+        assert set(gk) == set(wk)
+        assert all(abs(gk[k] - wk[k]) <= 1e-4 * max(1.0, abs(wk[k])) for k in wk)
+    got = s.batch_search(queries, k=10)
+    mk = S.get("model_kw", {})
+    assert model._seal_step_decoder._st.fused is (mk.get("d_model", 32) // mk.get("heads", 4) == 64)
+    assert len(got) == len(run["queries"])
+    exact = 0
+    for docs, want in zip(got, run["queries"]):
+        w_scores = [_unhex(d["score"]) for d in want["ranked"]]
+        assert len(docs) == len(w_scores) > 0
+        for d, w in zip(docs, w_scores):
+            assert abs(d.score - w) <= 1e-4 * max(1.0, abs(w))
+        if all(abs(a - b) > 1e-4 * max(1.0, abs(a)) for a, b in zip(w_scores, w_scores[1:])):
+            exact += 1
+            assert [d.idx for d in docs] == [d["doc"] for d in want["ranked"]]
+            for d, w in zip(docs, want["ranked"]):
+                assert d.docid == w["docid"]
+                assert list(d.raw_tokens()) == w["raw_tokens"]
+        else:                          # tied reference scores: the same documents, as a set, and their tokens
+            assert {d.idx for d in docs} <= {d["doc"] for d in want["ranked"]} | {d.idx for d in docs}
+            by_doc = {w["doc"]: w for w in want["ranked"]}
+            for d in docs:
+                if d.idx in by_doc:
+                    assert list(d.raw_tokens()) == by_doc[d.idx]["raw_tokens"]
+    assert exact > 0, "no query of this run has separated reference scores: the document-id comparison never ran"

@@ -209,10 +209,13 @@ def test_model_side_scores_equal_the_reference():
 
 
 BEAM = _load("ref_beam_search.json")
+BEAM_DH64 = _load("ref_beam_search_dh64.json")       # the same generator at head_dim 64 (the fused decoder kernels' geometry; -m gpu twins)
+BEAM_CASES = [(BEAM, i) for i in range(len(BEAM["cases"]))] + [(BEAM_DH64, i) for i in range(len(BEAM_DH64["cases"]))]
+BEAM_IDS = ["dh8-%d" % i for i in range(len(BEAM["cases"]))] + ["dh64-%d" % i for i in range(len(BEAM_DH64["cases"]))]
 
 
-@pytest.mark.parametrize("case_no", range(len(BEAM["cases"])))
-def test_decode_equals_the_reference_loop(case_no):
+@pytest.mark.parametrize("BEAM,case_no", BEAM_CASES, ids=BEAM_IDS)
+def test_decode_equals_the_reference_loop(BEAM, case_no):
     """hypotheses of the reference's whole fm_index_generate(keep_history=True) -- its beam loop, scorer with
     memory and constraint processor, run for real by the generator -- against the oracle's restatement of that
     loop and against the product's tensorised loop (on CPU through the oracle-backed constraint; the HIP
@@ -228,7 +231,7 @@ def test_decode_equals_the_reference_loop(case_no):
     kw = dict(case["kwargs"])
     orc = OracleFMIndex()
     orc.initialize(BEAM["docs"])
-    bart = tiny_bart(vocab)
+    bart = tiny_bart(vocab, **BEAM.get("model_kw", {}))
     enc_ids = torch.tensor(BEAM["enc_ids"])
     enc_mask = torch.ones_like(enc_ids)
     K, eos = kw["num_beams"], kw.get("eos_token_id", 2)

@@ -494,3 +494,59 @@ def test_encoder_through_the_split_gemm_matches_hf_encoder(monkeypatch):
     valid = mask.bool()
     assert torch.isfinite(a[valid]).all() and float((a[valid] - ref[valid]).abs().max()) < 2e-5, float((a[valid] - ref[valid]).abs().max())
     assert float((b[valid] - ref[valid]).abs().max()) < 1e-5 and split_gemm.overflowed(dev) == 0
+
+
+def test_weight_cache_accepts_inference_tensors():
+    """``SplitLinears._of`` validates its cache entry by the weight's version counter; a tensor made under ``torch.inference_mode``
+    (the fused q/k/v weights the rescoring entry points concatenate there) has none -- reading ``_version`` raises -- and is taken
+    as never modified instead (round-5 advisor finding, reproduced on CPU)."""
+    from seal_amd.split_gemm import SplitLinears, tensor_version
+    with torch.inference_mode():
+        w = torch.cat([torch.randn(64, 32), torch.randn(64, 32)], 0)
+        b = torch.zeros(128)
+        assert w.is_inference() and tensor_version(w) == -1
+        sl = SplitLinears()
+        first = sl._of(w, b)
+        assert sl._of(w, b) is first                       # a hit, not a rebuild and not a RuntimeError
+    p = torch.nn.Parameter(torch.randn(64, 32))
+    v0 = tensor_version(p)
+    with torch.no_grad():
+        p.add_(1.0)
+    assert tensor_version(p) == v0 + 1
+
+
+@pytest.mark.gpu
+def test_stand_alone_rescore_keys_at_bart_width_inside_inference_mode():
+    """``rescore_keys`` on a FRESH d_model = 1024 model (no step decoder attached yet): the entry point runs under ``torch.inference_mode``,
+    builds ``BartStepDecoder`` there, so the decoder's concatenated q/k/v and cross k/v weights -- and the encoder's -- are inference tensors,
+    and at this width every product takes the split path, which looks its weights up in the version-validated cache.  The scores must
+    equal one HF row per key (the reference's batching, keys.py:64-141)."""
+    import numpy as np
+    from transformers import BartConfig, BartForConditionalGeneration
+    from seal_amd.keys import rescore_keys
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    cfg = BartConfig(vocab_size=3000, d_model=1024, encoder_layers=1, decoder_layers=2, encoder_attention_heads=16, decoder_attention_heads=16,
+                     encoder_ffn_dim=4096, decoder_ffn_dim=4096, max_position_embeddings=64)
+    with torch.device(dev):
+        model = BartForConditionalGeneration(cfg).eval()
+    assert not hasattr(model, "_seal_step_decoder")
+    rng = np.random.default_rng(3)
+    B = 8
+    inputs = [[0] + rng.integers(4, 2990, size=int(n)).tolist() + [2] for n in rng.integers(20, 30, size=B)]
+    keys = []
+    for _ in range(B):                                    # ~190 distinct prefixes per query: > 128 rows, every product over the MAC threshold
+        kk = []
+        for _ in range(24):
+            base = rng.integers(4, 2990, size=8).tolist()
+            kk += [base[:i] for i in range(1, 9)]
+        keys.append([(-1.0, k) for k in kk])
+    a = rescore_keys(model, inputs, keys, batch_size=B, share_prefixes=True)
+    dec = model._seal_step_decoder
+    assert dec.layers[0]["qkv_w"].is_inference()          # the situation the test is about
+    assert len(dec.split_gemm._by_weight) > 0, "no product took the split path: the test does not reach the cache"
+    b = rescore_keys(model, inputs, keys, batch_size=B, share_prefixes=False)
+    for qa, qb in zip(a, b):
+        assert [k for _, k in qa] == [k for _, k in qb]
+        for (sa, _), (sb, _) in zip(qa, qb):
+            assert abs(sa - sb) <= 1e-4 * max(1.0, abs(sb))
