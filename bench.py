@@ -193,6 +193,13 @@ def _scalar_oracle_class():
         def __init__(self):
             super().__init__()
             self._located, self._range_end = {}, 0
+            self.seconds = {"locate_batches": 0.0, "get_doc": 0.0}
+
+        def get_doc(self, doc_index):
+            t0 = time.perf_counter()
+            out = super().get_doc(doc_index)
+            self.seconds["get_doc"] += time.perf_counter() - t0
+            return out
 
         def get_range(self, sequence):
             lo, hi = super().get_range(sequence)
@@ -202,8 +209,10 @@ def _scalar_oracle_class():
         def locate(self, row):
             pos = self._located.get(row)
             if pos is None:
+                t0 = time.perf_counter()
                 rows = np.arange(row, max(row + 1, min(self._range_end, row + 1500)), dtype=np.uint64)
-                got, _ = self.locate_bin_batch(rows, np.asarray([0], dtype=np.uint64), threads=self.batch_threads)
+                got, _ = self.locate_bin_batch(rows, np.asarray([0], dtype=np.uint64), threads=min(16, self.batch_threads))
+                self.seconds["locate_batches"] += time.perf_counter() - t0
                 self._located.update(zip(rows.tolist(), got.astype(np.int64).tolist()))
                 pos = self._located[row]
             return pos
@@ -244,6 +253,7 @@ def aggregation_vs_keys_oracle(orc, agg_calls, n_queries=2):
                     n_bad += 1
                     first_bad = first_bad or {"query": n_q - 1, "gpu_doc": int(gd), "oracle_doc": int(wd), "gpu_score": float(gi[0]).hex(), "oracle_score": float(wi[0]).hex()}
     out = {"ops": n_q, "values": n_docs, "mismatches": n_bad, "queries": n_q, "rows_located_by_the_oracle": located,
+           "oracle_seconds": {k: round(v, 1) for k, v in orc.seconds.items()},
            "against": "oracle/keys_oracle.py (scalar model of keys.py:178-497, pinned to the reference's own outputs) over the sdsl-style oracle index of this "
                       "corpus: document order, float64 scores bit for bit, accepted keys + discounted scores, document tokens, best key"}
     if first_bad:
@@ -612,7 +622,7 @@ def merge_call_logs(timed, counted, fused=None):
 
 
 AGG_STAGES = ["k_agg_locate", "sort_by_position(rocprim)", "coverage(k_mis_prepare+k_mis)", "k_doc_keys+sort_by_document(rocprim)",
-              "entry_boundaries(k_heads+scan+k_entry_starts)", "k_entries", "ranking(3 rocprim sorts+k_top_docs)", "token_tables(memsets+scatters)",
+              "entry_boundaries(k_heads+scan+k_entry_starts)", "k_entries", "ranking(k_sel_minmax+k_sel_hist x2+k_sel_compact+k_sel_final)", "token_tables(memsets+scatters)",
               "k_full_score(ranked documents)", "k_rank_docs", "k_full_score(top-k records)"]
 
 

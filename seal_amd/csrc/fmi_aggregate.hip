@@ -58,6 +58,7 @@ namespace {
 // device view of the packed plan
 struct AggView {
     uint32_t nq, n_keys, n_rare, max_key_len;
+    uint32_t pos_bits, doc_bits;       // widths of the position / document fields of the two sort keys: this index's, not the format's maximum
     uint64_t total, vocab;
     const uint32_t *q_key_off, *q_rare_off, *rare_key, *key_len, *key_q, *key_rank, *kset_off, *kset_ids, *q_tok_off, *tok_list, *q_trie_off;
     const uint64_t *rare_occ_off, *key_lo, *uni_flat;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void k_agg_locate(FmiDev ix, AggView v, uint32
     const uint64_t pos = sa_at(ix, row);
     occ_rk[i] = a;
     doc[i] = (uint32_t)doc_of(ix, pos);
-    key_pos[i] = ((uint64_t)v.key_q[k] << FMI_AGG_POS_BITS) + pos + 256;      // window [pos - len, pos) never goes below 0 after the offset
+    key_pos[i] = ((uint64_t)v.key_q[k] << v.pos_bits) + pos + 256;      // window [pos - len, pos) never goes below 0 after the offset
     val[i] = (uint32_t)i;
 }
 
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void k_doc_keys(AggView v, const uint32_t *occ
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.total) return;
-    key_doc[i] = ((uint64_t)v.key_q[v.rare_key[occ_rk[i]]] << 32) | doc[i];
+    key_doc[i] = ((uint64_t)v.key_q[v.rare_key[occ_rk[i]]] << v.doc_bits) | doc[i];
     val[i] = (uint32_t)i;
 }
 
@@ -300,7 +301,7 @@ __device__ __forceinline__ void entry_by_wave(const AggView &v, const uint64_t *
         const double best = v.key_score[v.rare_key[r0]];     // keys arrive by descending score: the first one to touch the document
         const double rk = (1.0 - single_key) * (-current) + single_key * (-best);
         ent_nkeys[e] = nL; ent_score[e] = current; ent_best[e] = r0; ent_first[e] = i0;
-        ent_q[e] = (uint32_t)(kd >> 32); ent_doc[e] = (uint32_t)kd; ent_rank[e] = f64_order_key(rk);
+        ent_q[e] = (uint32_t)(kd >> v.doc_bits); ent_doc[e] = (uint32_t)(kd & ((1ull << v.doc_bits) - 1)); ent_rank[e] = f64_order_key(rk);
     }
 }
 
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void k_entries(AggView v, const uint64_t *KD, 
             const uint64_t kd = KD[s];
             const double rk = (1.0 - single_key) * (-current) + single_key * (-best);
             ent_nkeys[e] = c ? 1u : 0u; ent_score[e] = current; ent_best[e] = r0; ent_first[e] = i0;
-            ent_q[e] = (uint32_t)(kd >> 32); ent_doc[e] = (uint32_t)kd; ent_rank[e] = f64_order_key(rk);
+            ent_q[e] = (uint32_t)(kd >> v.doc_bits); ent_doc[e] = (uint32_t)(kd & ((1ull << v.doc_bits) - 1)); ent_rank[e] = f64_order_key(rk);
         }
         uint64_t multi = __ballot(have && t - s != 1);
         while (multi) {
@@ -345,6 +346,522 @@ __global__ __launch_bounds__(256) void k_gather(const T *src, const uint32_t *id
 {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x < n) dst[x] = src[idx[x]];
+}
+
+// The ranking of the first stage, sorted(first_stage.items(), key=...)[:n_docs_complete_score] (keys.py:366-375): per query the n_top
+// entries with the smallest (rank key, first touch) -- Python's sort is stable and the dict is in first-touch order, and a first touch (the
+// index of an occurrence) is unique, so the composite 96-bit key K = rank key << 32 | first touch is a total order.  Rounds 2-5 ran three full
+// stable radix sorts over every (query, document) entry slot of the batch (first touch, rank key, query: 1.1 ms for 5.7 M slots) to read
+// 1 500 per query off the front; this is a SELECTION, one workgroup per query over its entries (contiguous: they were built from the
+// (query, document) sort):
+//   1. min / max of the rank keys: the bits all entries share are skipped (scores of one query share sign and most of the exponent);
+//   2. MSD radix select from the first differing bit, 8 bits a pass: histogram of the digit among the entries that match the bits decided so
+//      far, the bin that holds the n_top-th, descend -- it ends when a bin boundary coincides with n_top, at the latest when all 96 bits are
+//      decided.  Once the candidates of the boundary bin fit the LDS (SEL_CACHE entries) they are copied there and the remaining passes never
+//      touch memory again: a typical query streams its entries four times (min/max, one histogram, the copy, the final collection);
+//   3. the entries at or below the threshold are collected and ordered by counting (each one's rank = how many of them are smaller).
+// Streaming loops keep SEL_U loads per thread in flight (one workgroup has to pull ~2 MB per pass on its own); histograms are per wave, and a
+// wave whose 64 entries share the digit adds once (tie groups: thousands of documents with the same score).
+static constexpr uint32_t SEL_WG = 1024, SEL_WAVES = SEL_WG / 64, SEL_U = 8, SEL_CACHE_MAX = 4096;
+__host__ __device__ constexpr size_t select_lds_bytes(uint32_t n_top, uint32_t cache)
+{
+    return (size_t)n_top * 16 + (size_t)cache * 12 + SEL_WAVES * 256 * 4 + 256 * 4 + 2 * SEL_WAVES * 8 + 64;
+}
+// candidates the LDS can hold beside the n_top selected entries (160 KB per workgroup)
+__host__ constexpr uint32_t select_cache_for(uint32_t n_top)
+{
+    const size_t fixed = select_lds_bytes(n_top, 0), room = 160 * 1024 > fixed ? 160 * 1024 - fixed : 0;
+    return (uint32_t)(room / 12 < SEL_CACHE_MAX ? (room / 12) & ~(size_t)7 : SEL_CACHE_MAX);
+}
+typedef unsigned __int128 u128;
+__device__ __forceinline__ u128 key96(uint64_t hi, uint32_t lo) { return ((u128)hi << 32) | lo; }
+// bits [pos, pos + width) of a 96-bit key, counted from its most significant bit
+__device__ __forceinline__ uint32_t key96_bits(u128 k, uint32_t pos, uint32_t width) { return (uint32_t)(k >> (96 - pos - width)) & ((1u << width) - 1); }
+__device__ __forceinline__ bool key96_same_prefix(u128 k, u128 p, uint32_t pos) { return pos == 0 || (k >> (96 - pos)) == (p >> (96 - pos)); }
+
+__device__ __forceinline__ void select_by_one_workgroup(uint64_t *sel_lds, const uint32_t *n_entries_p, const uint32_t *ent_q, const uint64_t *ent_rank,
+                                                        const uint32_t *ent_first, const uint32_t *ent_doc, const double *ent_score, uint32_t n_top,
+                                                        uint32_t SEL_CACHE, uint32_t *top_doc, uint32_t *top_ent, uint32_t *top_cnt, uint32_t *fs_doc,
+                                                        double *fs_score, uint32_t *fs_cnt)
+{
+    uint64_t *s_hi = sel_lds;                                             // [n_top] the selected entries' rank keys
+    uint64_t *c_hi = s_hi + n_top;                                        // [SEL_CACHE] the cached candidates' rank keys
+    uint64_t *s_red = c_hi + SEL_CACHE;                                   // [2 * SEL_WAVES] min / max per wave
+    uint32_t *s_lo = reinterpret_cast<uint32_t *>(s_red + 2 * SEL_WAVES); // [n_top] ... first touches
+    uint32_t *s_e = s_lo + n_top;                                         // [n_top] ... entry numbers
+    uint32_t *c_lo = s_e + n_top;                                         // [SEL_CACHE]
+    uint32_t *s_hist = c_lo + SEL_CACHE;                                  // [SEL_WAVES][256]
+    uint32_t *s_cnt = s_hist + SEL_WAVES * 256;                           // [256] bins summed over the waves
+    uint32_t *s_misc = s_cnt + 256;                                       // [0..1] segment, [2] bin, [3] below, [4] done, [5] collected, [6] bin count, [7] cached
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t ne = *n_entries_p;
+    if (tid < 2) {
+        const uint32_t want_q = q + tid;                                  // first entry with ent_q >= want_q
+        uint32_t a = 0, b = ne;
+        while (a < b) { const uint32_t mid = (a + b) >> 1; if (ent_q[mid] < want_q) a = mid + 1; else b = mid; }
+        s_misc[tid] = a;
+    }
+    __syncthreads();
+    const uint32_t e0 = s_misc[0], e1 = s_misc[1];
+    const uint32_t want = min(e1 - e0, n_top);
+    if (tid == 0) { top_cnt[q] = want; fs_cnt[q] = want; }
+    if (want == 0) return;
+    // ---- the threshold T: the want-th smallest key (all ones when every entry is taken) ----
+    u128 T = ~(u128)0;
+    if (want < e1 - e0) {
+        // 1. the bits every rank key of the query shares (min / max over the segment; equal keys throughout: the first touches decide)
+        uint64_t mn = ~0ull, mx = 0;
+        for (uint32_t base = e0; base < e1; base += SEL_WG * SEL_U) {
+            uint64_t v[SEL_U];
+#pragma unroll
+            for (uint32_t u = 0; u < SEL_U; u++) { const uint32_t e = base + u * SEL_WG + tid; v[u] = e < e1 ? ent_rank[e] : ent_rank[e0]; }
+#pragma unroll
+            for (uint32_t u = 0; u < SEL_U; u++) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
+        }
+        for (int o = 32; o; o >>= 1) {
+            const uint64_t a = ((uint64_t)(uint32_t)__shfl_xor((int)(mn >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)mn, o);
+            const uint64_t b = ((uint64_t)(uint32_t)__shfl_xor((int)(mx >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)mx, o);
+            mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+        }
+        if (lane == 0) { s_red[wave] = mn; s_red[SEL_WAVES + wave] = mx; }
+        __syncthreads();
+        mn = s_red[0]; mx = s_red[SEL_WAVES];
+        for (uint32_t w = 1; w < SEL_WAVES; w++) { mn = s_red[w] < mn ? s_red[w] : mn; mx = s_red[SEL_WAVES + w] > mx ? s_red[SEL_WAVES + w] : mx; }
+        uint32_t pos = mn == mx ? 64u : (uint32_t)__builtin_clzll(mn ^ mx);       // bits decided so far
+        u128 P = pos ? ((key96(mn, 0) >> (96 - pos)) << (96 - pos)) : (u128)0;      // ... and their values
+        uint32_t need = want, cached = 0;          // cached > 0: the candidates (same first `pos` bits as P) are c_hi / c_lo [0, cached)
+        if (tid == 0) s_misc[7] = 0;
+        for (;;) {
+            const uint32_t width = min(8u, 96u - pos);
+            const bool use_lo = pos + width > 64;
+            for (uint32_t i = tid; i < SEL_WAVES * 256; i += SEL_WG) s_hist[i] = 0;
+            __syncthreads();
+            auto tally = [&](bool cand, uint32_t d) {
+                const uint64_t cm = __ballot(cand);
+                if (!cm) return;
+                const uint32_t d0 = (uint32_t)__shfl((int)d, (int)__builtin_ctzll(cm));
+                if (__ballot(cand && d == d0) == cm) { if (lane == 0) s_hist[wave * 256 + d0] += (uint32_t)__popcll(cm); }      // one digit in the whole wave
+                else if (cand) atomicAdd(&s_hist[wave * 256 + d], 1u);
+            };
+            if (cached) {
+                for (uint32_t base = 0; base < cached; base += SEL_WG) {
+                    const uint32_t i = base + tid;
+                    const u128 k = i < cached ? key96(c_hi[i], c_lo[i]) : (u128)0;
+                    tally(i < cached && key96_same_prefix(k, P, pos), key96_bits(k, pos, width));
+                }
+            } else {
+                for (uint32_t base = e0; base < e1; base += SEL_WG * SEL_U) {
+                    uint64_t hi[SEL_U];
+                    uint32_t lo[SEL_U];
+#pragma unroll
+                    for (uint32_t u = 0; u < SEL_U; u++) {
+                        const uint32_t e = base + u * SEL_WG + tid;
+                        hi[u] = e < e1 ? ent_rank[e] : 0ull;
+                        lo[u] = (use_lo && e < e1) ? ent_first[e] : 0u;
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < SEL_U; u++) {
+                        const uint32_t e = base + u * SEL_WG + tid;
+                        const u128 k = key96(hi[u], lo[u]);
+                        tally(e < e1 && key96_same_prefix(k, P, pos < 64 ? pos : 64) && (pos <= 64 || key96_same_prefix(k, P, pos)), key96_bits(k, pos, width));
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < 256) { uint32_t c = 0; for (uint32_t w = 0; w < SEL_WAVES; w++) c += s_hist[w * 256 + tid]; s_cnt[tid] = c; }
+            __syncthreads();
+            if (wave == 0) {                      // the bin that holds the need-th candidate: scan of 256 counts, four per lane
+                uint32_t c[4], sum = 0;
+                for (int j = 0; j < 4; j++) { c[j] = s_cnt[4 * lane + j]; sum += c[j]; }
+                uint32_t incl = sum;
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += y; }
+                uint32_t run = incl - sum;
+                for (int j = 0; j < 4; j++) {
+                    if (run < need && need <= run + c[j]) { s_misc[2] = 4 * lane + j; s_misc[3] = run; s_misc[4] = (run + c[j] == need) ? 1u : 0u; s_misc[6] = c[j]; }
+                    run += c[j];
+                }
+            }
+            __syncthreads();
+            const uint32_t bin = s_misc[2], below = s_misc[3], done = s_misc[4], in_bin = s_misc[6];
+            P |= (u128)bin << (96 - pos - width);
+            pos += width;
+            if (done || pos == 96) { T = pos < 96 ? (P | (((u128)1 << (96 - pos)) - 1)) : P; break; }
+            need -= below;
+            if (!cached && in_bin <= SEL_CACHE) {
+                // 2b. the boundary bin's candidates into the LDS: every later pass reads them there
+                __syncthreads();
+                for (uint32_t base = e0; base < e1; base += SEL_WG * SEL_U) {
+                    uint64_t hi[SEL_U];
+#pragma unroll
+                    for (uint32_t u = 0; u < SEL_U; u++) { const uint32_t e = base + u * SEL_WG + tid; hi[u] = e < e1 ? ent_rank[e] : 0ull; }
+#pragma unroll
+                    for (uint32_t u = 0; u < SEL_U; u++) {
+                        const uint32_t e = base + u * SEL_WG + tid;
+                        if (e >= e1 || !key96_same_prefix(key96(hi[u], 0), P, pos < 64 ? pos : 64)) continue;
+                        const uint32_t lo = ent_first[e];
+                        if (pos > 64 && !key96_same_prefix(key96(hi[u], lo), P, pos)) continue;
+                        const uint32_t slot = atomicAdd(&s_misc[7], 1u);
+                        if (slot < SEL_CACHE) { c_hi[slot] = hi[u]; c_lo[slot] = lo; }
+                    }
+                }
+                __syncthreads();
+                cached = min(s_misc[7], SEL_CACHE);
+            }
+        }
+    }
+    // ---- 3. collect, then order by counting ----
+    __syncthreads();
+    if (tid == 0) s_misc[5] = 0;
+    __syncthreads();
+    const uint64_t thi = (uint64_t)(T >> 32);
+    const uint32_t tlo = (uint32_t)T;
+    for (uint32_t base = e0; base < e1; base += SEL_WG * SEL_U) {
+        uint64_t hi[SEL_U];
+#pragma unroll
+        for (uint32_t u = 0; u < SEL_U; u++) { const uint32_t e = base + u * SEL_WG + tid; hi[u] = e < e1 ? ent_rank[e] : ~0ull; }
+#pragma unroll
+        for (uint32_t u = 0; u < SEL_U; u++) {
+            const uint32_t e = base + u * SEL_WG + tid;
+            if (e >= e1 || hi[u] > thi) continue;
+            const uint32_t lo = ent_first[e];
+            if (hi[u] == thi && lo > tlo) continue;
+            const uint32_t slot = atomicAdd(&s_misc[5], 1u);
+            if (slot < n_top) { s_hi[slot] = hi[u]; s_lo[slot] = lo; s_e[slot] = e; }
+        }
+    }
+    __syncthreads();
+    const uint32_t got = min(s_misc[5], n_top);        // (== want: the composite keys are distinct)
+    for (uint32_t x = tid; x < got; x += SEL_WG) {
+        const uint64_t hi = s_hi[x];
+        const uint32_t lo = s_lo[x];
+        uint32_t r = 0;
+        for (uint32_t y = 0; y < got; y++) { const uint64_t h2 = s_hi[y]; r += (h2 < hi || (h2 == hi && s_lo[y] < lo)) ? 1u : 0u; }
+        const uint32_t e = s_e[x];
+        top_doc[(uint64_t)q * n_top + r] = ent_doc[e];
+        top_ent[(uint64_t)q * n_top + r] = e;
+        fs_doc[(uint64_t)q * n_top + r] = ent_doc[e];
+        fs_score[(uint64_t)q * n_top + r] = ent_score[e];
+    }
+}
+
+__global__ __launch_bounds__(SEL_WG) void k_select_top(const uint32_t *n_entries_p, const uint32_t *ent_q, const uint64_t *ent_rank, const uint32_t *ent_first,
+                                                       const uint32_t *ent_doc, const double *ent_score, uint32_t n_top, uint32_t cache,
+                                                       uint32_t *top_doc, uint32_t *top_ent, uint32_t *top_cnt, uint32_t *fs_doc, double *fs_score,
+                                                       uint32_t *fs_cnt)
+{
+    extern __shared__ uint64_t sel_lds[];
+    select_by_one_workgroup(sel_lds, n_entries_p, ent_q, ent_rank, ent_first, ent_doc, ent_score, n_top, cache, top_doc, top_ent, top_cnt, fs_doc, fs_score, fs_cnt);
+}
+
+// ---- the same selection with the streaming spread over the chip ------------------------------------------------------------------------------
+// One workgroup pulls ~15 GB/s on its own (64 KB in flight against ~3 us of latency): the single-workgroup form above spends ~130 us per pass over a
+// query's ~200 k entries, 0.9 ms for a typical query -- no better than the sorts it replaces.  So the passes over the ENTRIES run on SEL_G
+// workgroups per query, one launch per pass, through per-query records in global memory:
+//   k_sel_minmax    segment bounds of the queries (once), min / max of the rank keys (atomicMin / atomicMax)
+//   k_sel_hist x 2  histogram of the next 11 bits behind the bits decided so far (every workgroup re-derives the state of its query from the
+//                   min / max and the histograms of the passes before: a scan of 2 048 counters; nothing is handed from launch to launch but
+//                   counters)
+//   k_sel_compact   entries below the boundary bin -> the query's `sure` list (fewer than n_top by construction), entries inside it -> its
+//                   `maybe` list (a few, or one tie group)
+//   k_sel_final     one workgroup per query: the n_top-th among the `maybe` entries by the remaining bits (in the LDS), sure + chosen ordered by
+//                   counting, written out.  A `maybe` list that overflows its buffer (a tie group of more than SEL_MAYBE_CAP documents after
+//                   22 more bits) sends the query through the single-workgroup routine instead.
+static constexpr uint32_t SEL_G = 12, SEL_GT = 256, SEL_BITS = 11, SEL_BINS = 1u << SEL_BITS, SEL_PASSES = 2, SEL_MAYBE_CAP = 16384;
+struct SelWork {
+    uint64_t *mm;        // [2][nq] min (memset to ones), max (zero) of the rank keys
+    uint32_t *hist;      // [SEL_PASSES][nq][SEL_BINS]
+    uint32_t *cnt;       // [nq][4]: sure, maybe, -, -
+    uint32_t *qstart;    // [nq + 1]
+    uint32_t *sure;      // [nq][n_top] entry numbers
+    uint32_t *maybe;     // [nq][SEL_MAYBE_CAP]
+    uint32_t n_top, nq;
+};
+struct SelState { u128 P; uint32_t pos, need, done, in_bin; };
+
+// the state of query q's selection after `passes` histogram passes; by the whole workgroup (s_scr: 8 words of LDS)
+__device__ __forceinline__ SelState sel_state(const SelWork &w, uint32_t q, uint32_t passes, uint32_t count, uint32_t want, uint32_t *s_scr)
+{
+    SelState st;
+    st.P = 0; st.pos = 0; st.need = want; st.done = 0; st.in_bin = count;
+    if (want >= count) { st.done = 1; return st; }                 // every entry is taken: the threshold is all ones
+    const uint64_t mn = w.mm[q], mx = w.mm[w.nq + q];
+    st.pos = mn == mx ? 64u : (uint32_t)__builtin_clzll(mn ^ mx);
+    st.P = st.pos ? ((key96(mn, 0) >> (96 - st.pos)) << (96 - st.pos)) : (u128)0;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t k = 0; k < passes && !st.done && st.pos < 96; k++) {
+        const uint32_t width = min(SEL_BITS, 96u - st.pos), bins = 1u << width;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint32_t *h = w.hist + ((uint64_t)k * w.nq + q) * SEL_BINS;
+            const uint32_t per = (bins + 63) / 64, b0 = lane * per;
+            uint32_t sum = 0;
+            for (uint32_t j = 0; j < per; j++) sum += b0 + j < bins ? h[b0 + j] : 0u;
+            uint32_t incl = sum;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += y; }
+            uint32_t run = incl - sum;
+            if (run < st.need && st.need <= incl) {
+                for (uint32_t j = 0; j < per; j++) {
+                    const uint32_t c = b0 + j < bins ? h[b0 + j] : 0u;
+                    if (run < st.need && st.need <= run + c) { s_scr[0] = b0 + j; s_scr[1] = run; s_scr[2] = (run + c == st.need) ? 1u : 0u; s_scr[3] = c; }
+                    run += c;
+                }
+            }
+        }
+        __syncthreads();
+        st.P |= (u128)s_scr[0] << (96 - st.pos - width);
+        st.pos += width;
+        st.done = s_scr[2] | (st.pos == 96 ? 1u : 0u);
+        st.in_bin = s_scr[3];
+        if (!st.done) st.need -= s_scr[1];
+    }
+    __syncthreads();
+    return st;
+}
+
+// this workgroup's share [a, b) of query q's entries
+__device__ __forceinline__ void sel_share(const SelWork &w, uint32_t &q, uint32_t &a, uint32_t &b, uint32_t &count)
+{
+    q = blockIdx.x / SEL_G;
+    const uint32_t g = blockIdx.x - q * SEL_G, e0 = w.qstart[q], e1 = w.qstart[q + 1];
+    count = e1 - e0;
+    const uint32_t per = ((count + SEL_G - 1) / SEL_G + 63) & ~63u;
+    a = min(e1, e0 + g * per); b = min(e1, a + per);
+}
+
+__global__ __launch_bounds__(SEL_GT) void k_sel_minmax(const uint32_t *n_entries_p, const uint32_t *ent_q, const uint64_t *ent_rank, SelWork w)
+{
+    __shared__ uint32_t s_seg[2];
+    const uint32_t q = blockIdx.x / SEL_G, g = blockIdx.x - q * SEL_G, tid = threadIdx.x, lane = tid & 63;
+    const uint32_t ne = *n_entries_p;
+    if (tid < 2) {
+        const uint32_t want_q = q + tid;
+        uint32_t a = 0, b = ne;
+        while (a < b) { const uint32_t mid = (a + b) >> 1; if (ent_q[mid] < want_q) a = mid + 1; else b = mid; }
+        s_seg[tid] = a;
+        if (g == 0 && (tid == 0 || q + 1 == w.nq)) w.qstart[q + tid] = a;
+    }
+    __syncthreads();
+    const uint32_t e0 = s_seg[0], e1 = s_seg[1], count = e1 - e0;
+    if (count <= w.n_top) return;                              // every entry is taken: no threshold to look for
+    const uint32_t per = ((count + SEL_G - 1) / SEL_G + 63) & ~63u;
+    const uint32_t a = min(e1, e0 + g * per), b = min(e1, a + per);
+    if (a >= b) return;
+    uint64_t mn = ~0ull, mx = 0;
+    for (uint32_t base = a; base < b; base += SEL_GT * SEL_U) {
+        uint64_t v[SEL_U];
+#pragma unroll
+        for (uint32_t u = 0; u < SEL_U; u++) { const uint32_t e = base + u * SEL_GT + tid; v[u] = e < b ? ent_rank[e] : ent_rank[a]; }
+#pragma unroll
+        for (uint32_t u = 0; u < SEL_U; u++) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
+    }
+    for (int o = 32; o; o >>= 1) {
+        const uint64_t x = ((uint64_t)(uint32_t)__shfl_xor((int)(mn >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)mn, o);
+        const uint64_t y = ((uint64_t)(uint32_t)__shfl_xor((int)(mx >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)mx, o);
+        mn = x < mn ? x : mn; mx = y > mx ? y : mx;
+    }
+    if (lane == 0) { atomicMin((unsigned long long *)&w.mm[q], (unsigned long long)mn); atomicMax((unsigned long long *)&w.mm[w.nq + q], (unsigned long long)mx); }
+}
+
+__global__ __launch_bounds__(SEL_GT) void k_sel_hist(uint32_t pass, const uint64_t *ent_rank, const uint32_t *ent_first, SelWork w)
+{
+    __shared__ uint32_t s_hist[SEL_BINS];
+    __shared__ uint32_t s_scr[8];
+    uint32_t q, a, b, count;
+    sel_share(w, q, a, b, count);
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const SelState st = sel_state(w, q, pass, count, min(count, w.n_top), s_scr);
+    if (st.done || a >= b) return;
+    const uint32_t pos = st.pos, width = min(SEL_BITS, 96u - pos);
+    const bool use_lo = pos + width > 64;
+    for (uint32_t i = tid; i < SEL_BINS; i += SEL_GT) s_hist[i] = 0;
+    __syncthreads();
+    for (uint32_t base = a; base < b; base += SEL_GT * SEL_U) {
+        uint64_t hi[SEL_U];
+        uint32_t lo[SEL_U];
+#pragma unroll
+        for (uint32_t u = 0; u < SEL_U; u++) {
+            const uint32_t e = base + u * SEL_GT + tid;
+            hi[u] = e < b ? ent_rank[e] : 0ull;
+            lo[u] = (use_lo && e < b) ? ent_first[e] : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < SEL_U; u++) {
+            const uint32_t e = base + u * SEL_GT + tid;
+            const u128 k = key96(hi[u], lo[u]);
+            const bool cand = e < b && key96_same_prefix(k, st.P, pos);
+            const uint32_t d = key96_bits(k, pos, width);
+            const uint64_t cm = __ballot(cand);
+            if (cm) {
+                const uint32_t d0 = (uint32_t)__shfl((int)d, (int)__builtin_ctzll(cm));
+                if (__ballot(cand && d == d0) == cm) { if (lane == 0) atomicAdd(&s_hist[d0], (uint32_t)__popcll(cm)); }
+                else if (cand) atomicAdd(&s_hist[d], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *h = w.hist + ((uint64_t)pass * w.nq + q) * SEL_BINS;
+    for (uint32_t i = tid; i < SEL_BINS; i += SEL_GT) { const uint32_t c = s_hist[i]; if (c) atomicAdd(&h[i], c); }
+}
+
+__global__ __launch_bounds__(SEL_GT) void k_sel_compact(const uint64_t *ent_rank, const uint32_t *ent_first, SelWork w)
+{
+    __shared__ uint32_t s_scr[8];
+    __shared__ uint32_t s_n[2], s_base[2];
+    uint32_t q, a, b, count;
+    sel_share(w, q, a, b, count);
+    const uint32_t tid = threadIdx.x;
+    const SelState st = sel_state(w, q, SEL_PASSES, count, min(count, w.n_top), s_scr);
+    if (a >= b) return;
+    const uint32_t pos = st.pos;
+    const bool use_lo = pos > 64;
+    // two sweeps over the share: count, reserve with ONE atomic per list, write (the entries are re-read from the L2)
+    for (uint32_t sweep = 0; sweep < 2; sweep++) {
+        if (tid < 2) s_n[tid] = 0;
+        __syncthreads();
+        for (uint32_t base = a; base < b; base += SEL_GT * SEL_U) {
+            uint64_t hi[SEL_U];
+            uint32_t lo[SEL_U];
+#pragma unroll
+            for (uint32_t u = 0; u < SEL_U; u++) {
+                const uint32_t e = base + u * SEL_GT + tid;
+                hi[u] = e < b ? ent_rank[e] : 0ull;
+                lo[u] = (use_lo && e < b) ? ent_first[e] : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < SEL_U; u++) {
+                const uint32_t e = base + u * SEL_GT + tid;
+                if (e >= b) continue;
+                const u128 kp = pos ? key96(hi[u], lo[u]) >> (96 - pos) : (u128)0, pp = pos ? st.P >> (96 - pos) : (u128)0;
+                const bool sure = kp < pp || (st.done && kp == pp), maybe = !st.done && kp == pp;
+                if (!sure && !maybe) continue;
+                const uint32_t slot = atomicAdd(&s_n[sure ? 0 : 1], 1u);
+                if (sweep == 1) {
+                    const uint32_t at = s_base[sure ? 0 : 1] + slot;
+                    if (sure) { if (at < w.n_top) w.sure[(uint64_t)q * w.n_top + at] = e; }
+                    else if (at < SEL_MAYBE_CAP) w.maybe[(uint64_t)q * SEL_MAYBE_CAP + at] = e;
+                }
+            }
+        }
+        __syncthreads();
+        if (sweep == 0 && tid < 2) s_base[tid] = s_n[tid] ? atomicAdd(&w.cnt[4 * q + tid], s_n[tid]) : 0u;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(SEL_WG) void k_sel_final(const uint32_t *n_entries_p, const uint32_t *ent_q, const uint64_t *ent_rank, const uint32_t *ent_first,
+                                                      const uint32_t *ent_doc, const double *ent_score, SelWork w, uint32_t cache, uint32_t p2,
+                                                      uint32_t *top_doc, uint32_t *top_ent, uint32_t *top_cnt, uint32_t *fs_doc, double *fs_score,
+                                                      uint32_t *fs_cnt)
+{
+    extern __shared__ uint64_t sel_lds[];
+    const uint32_t n_top = w.n_top;                                       // (p2 = the power of two at or above it: the sort's array length)
+    uint64_t *s_hi = sel_lds;                                             // [p2] selected: rank keys
+    uint64_t *c_hi = s_hi + p2;                                           // [cache] the `maybe` entries' rank keys
+    uint32_t *s_lo = reinterpret_cast<uint32_t *>(c_hi + cache);          // [p2]
+    uint32_t *s_e = s_lo + p2;                                            // [p2]
+    uint32_t *c_lo = s_e + p2;                                            // [cache]
+    uint32_t *c_e = c_lo + cache;                                         // [cache]
+    uint32_t *s_hist = c_e + cache;                                       // [SEL_WAVES][256]
+    uint32_t *s_cnt = s_hist + SEL_WAVES * 256;                           // [256]
+    uint32_t *s_misc = s_cnt + 256;                                       // [0..7] scratch of sel_state, [8] bin, [9] below, [10] done, [11] taken
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t e0 = w.qstart[q], e1 = w.qstart[q + 1], count = e1 - e0, want = min(count, n_top);
+    const uint32_t n_sure = w.cnt[4 * q], n_maybe = w.cnt[4 * q + 1];
+    if (want == 0) { if (tid == 0) { top_cnt[q] = 0; fs_cnt[q] = 0; } return; }
+    SelState st = sel_state(w, q, SEL_PASSES, count, want, s_misc);
+    if (!st.done && (n_maybe > SEL_MAYBE_CAP || n_maybe > cache)) {
+        // a tie group that does not fit: this query through the single-workgroup routine, over its entries
+        __syncthreads();
+        select_by_one_workgroup(sel_lds, n_entries_p, ent_q, ent_rank, ent_first, ent_doc, ent_score, n_top, 0u, top_doc, top_ent, top_cnt, fs_doc, fs_score, fs_cnt);
+        return;
+    }
+    if (tid == 0) { top_cnt[q] = want; fs_cnt[q] = want; }
+    // the sure entries, and the maybe entries with their keys
+    for (uint32_t i = tid; i < n_sure && i < n_top; i += SEL_WG) {
+        const uint32_t e = w.sure[(uint64_t)q * n_top + i];
+        s_e[i] = e; s_hi[i] = ent_rank[e]; s_lo[i] = ent_first[e];
+    }
+    uint32_t taken = min(n_sure, n_top);
+    if (!st.done) {
+        for (uint32_t i = tid; i < n_maybe; i += SEL_WG) {
+            const uint32_t e = w.maybe[(uint64_t)q * SEL_MAYBE_CAP + i];
+            c_e[i] = e; c_hi[i] = ent_rank[e]; c_lo[i] = ent_first[e];
+        }
+        __syncthreads();
+        // the need-th smallest of the maybe entries by the bits behind st.pos, 8 at a time, in the LDS
+        u128 P = st.P;
+        uint32_t pos = st.pos, need = st.need;
+        u128 T = ~(u128)0;
+        for (;;) {
+            const uint32_t width = min(8u, 96u - pos);
+            for (uint32_t i = tid; i < SEL_WAVES * 256; i += SEL_WG) s_hist[i] = 0;
+            __syncthreads();
+            for (uint32_t base = 0; base < n_maybe; base += SEL_WG) {
+                const uint32_t i = base + tid;
+                const u128 k = i < n_maybe ? key96(c_hi[i], c_lo[i]) : (u128)0;
+                if (i < n_maybe && key96_same_prefix(k, P, pos)) atomicAdd(&s_hist[wave * 256 + key96_bits(k, pos, width)], 1u);
+            }
+            __syncthreads();
+            if (tid < 256) { uint32_t c = 0; for (uint32_t x = 0; x < SEL_WAVES; x++) c += s_hist[x * 256 + tid]; s_cnt[tid] = c; }
+            __syncthreads();
+            if (wave == 0) {
+                uint32_t c[4], sum = 0;
+                for (int j = 0; j < 4; j++) { c[j] = s_cnt[4 * lane + j]; sum += c[j]; }
+                uint32_t incl = sum;
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += y; }
+                uint32_t run = incl - sum;
+                for (int j = 0; j < 4; j++) {
+                    if (run < need && need <= run + c[j]) { s_misc[8] = 4 * lane + j; s_misc[9] = run; s_misc[10] = (run + c[j] == need) ? 1u : 0u; }
+                    run += c[j];
+                }
+            }
+            __syncthreads();
+            P |= (u128)s_misc[8] << (96 - pos - width);
+            pos += width;
+            if (s_misc[10] || pos == 96) { T = pos < 96 ? (P | (((u128)1 << (96 - pos)) - 1)) : P; break; }
+            need -= s_misc[9];
+        }
+        if (tid == 0) s_misc[11] = taken;
+        __syncthreads();
+        for (uint32_t base = 0; base < n_maybe; base += SEL_WG) {
+            const uint32_t i = base + tid;
+            if (i < n_maybe && key96(c_hi[i], c_lo[i]) <= T) {
+                const uint32_t slot = atomicAdd(&s_misc[11], 1u);
+                if (slot < n_top) { s_hi[slot] = c_hi[i]; s_lo[slot] = c_lo[i]; s_e[slot] = c_e[i]; }
+            }
+        }
+        __syncthreads();
+        taken = min(s_misc[11], n_top);
+    }
+    __syncthreads();
+    // order: bitonic sort of the p2 slots by (rank key, first touch) (counting every entry's rank against all others is 2 M key compares on
+    // ONE compute unit: 180 us for 1 500 entries; this is 66 passes over 2 048 slots)
+    for (uint32_t x = taken + tid; x < p2; x += SEL_WG) { s_hi[x] = ~0ull; s_lo[x] = ~0u; s_e[x] = 0; }
+    __syncthreads();
+    for (uint32_t k = 2; k <= p2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < p2; i += SEL_WG) {
+                const uint32_t o = i ^ j;
+                if (o > i) {
+                    const uint64_t h1 = s_hi[i], h2 = s_hi[o];
+                    const uint32_t l1 = s_lo[i], l2 = s_lo[o];
+                    const bool gt = h1 > h2 || (h1 == h2 && l1 > l2);
+                    if (gt == ((i & k) == 0)) {
+                        s_hi[i] = h2; s_hi[o] = h1; s_lo[i] = l2; s_lo[o] = l1;
+                        const uint32_t t = s_e[i]; s_e[i] = s_e[o]; s_e[o] = t;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t r = tid; r < taken; r += SEL_WG) {
+        const uint32_t e = s_e[r];
+        top_doc[(uint64_t)q * n_top + r] = ent_doc[e];
+        top_ent[(uint64_t)q * n_top + r] = e;
+        fs_doc[(uint64_t)q * n_top + r] = ent_doc[e];
+        fs_score[(uint64_t)q * n_top + r] = ent_score[e];
+    }
 }
 
 // entry slots beyond the number of documents are padding: they sort behind everything and belong to "query nq"
@@ -673,19 +1190,31 @@ __global__ __launch_bounds__(256) void k_full_score(FmiDev ix, AggView v, ScoreP
     }
 }
 
-// sorted(results.items(), key=lambda x: -x[1][0]) (keys.py:496): stable, one workgroup per query
-__global__ __launch_bounds__(1024) void k_rank_docs(const double *scores, const uint32_t *top_cnt, uint32_t n_top, uint32_t *order)
+// sorted(results.items(), key=lambda x: -x[1][0]) (keys.py:496): stable, one workgroup per query: bitonic sort of (key, position) pairs over the
+// p2 slots of the LDS (p2 = the power of two at or above n_top; the position breaks ties, which is what stability means here).  Round 5
+// counted every document's rank against all others: 2 M compares on one compute unit, 92 us.
+__global__ __launch_bounds__(1024) void k_rank_docs(const double *scores, const uint32_t *top_cnt, uint32_t n_top, uint32_t p2, uint32_t *order)
 {
     extern __shared__ uint64_t keys[];
+    uint32_t *idx = reinterpret_cast<uint32_t *>(keys + p2);
     const uint32_t q = blockIdx.x, cnt = top_cnt[q];
-    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) keys[i] = f64_order_key(-scores[(uint64_t)q * n_top + i]);
+    for (uint32_t i = threadIdx.x; i < p2; i += blockDim.x) { keys[i] = i < cnt ? f64_order_key(-scores[(uint64_t)q * n_top + i]) : ~0ull; idx[i] = i; }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const uint64_t my = keys[i];
-        uint32_t rank = 0;
-        for (uint32_t y = 0; y < cnt; y++) { const uint64_t o = keys[y]; rank += (o < my) || (o == my && y < i); }
-        order[(uint64_t)q * n_top + rank] = i;
+    for (uint32_t k = 2; k <= p2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < p2; i += blockDim.x) {
+                const uint32_t o = i ^ j;
+                if (o > i) {
+                    const uint64_t k1 = keys[i], k2 = keys[o];
+                    const uint32_t i1 = idx[i], i2 = idx[o];
+                    const bool gt = k1 > k2 || (k1 == k2 && i1 > i2);
+                    if (gt == ((i & k) == 0)) { keys[i] = k2; keys[o] = k1; idx[i] = i2; idx[o] = i1; }
+                }
+            }
+            __syncthreads();
+        }
     }
+    for (uint32_t r = threadIdx.x; r < cnt; r += blockDim.x) order[(uint64_t)q * n_top + r] = idx[r];
 }
 
 // ---------------------------------------------------------------------------
@@ -714,6 +1243,9 @@ struct Work {          // workspace layout; base == nullptr: sizes only
     uint64_t *pool_sk;
     int32_t *stage_id;
     double *stage_score;
+    uint64_t *sel_mm;                                  // k_sel_*: [2][nq] min / max, then (contiguous, zeroed together) the histograms and counters
+    uint32_t *sel_hist, *sel_cnt, *sel_qstart, *sel_sure, *sel_maybe;
+    uint64_t sel_zero_bytes;
     void *rp_tmp;
     uint64_t rp_bytes, pool_cap, bytes;
 };
@@ -747,6 +1279,10 @@ Work carve(void *base, const FmiAggHeader &H, uint32_t n_top, uint32_t keep, uin
     w.pool_cap = 1ull << 23;                                   // 8 M candidate slots (96 MB) for documents that overflow the LDS list
     w.pool_sk = c.take<uint64_t>(w.pool_cap); w.pool_key = c.take<uint32_t>(w.pool_cap); w.pool_cursor = c.take<uint32_t>(8);
     w.stage_id = c.take<int32_t>(nq * (uint64_t)keep * pick_cap); w.stage_score = c.take<double>(nq * (uint64_t)keep * pick_cap);
+    w.sel_mm = c.take<uint64_t>(2 * nq);
+    w.sel_hist = c.take<uint32_t>((uint64_t)SEL_PASSES * nq * SEL_BINS); w.sel_cnt = c.take<uint32_t>(nq * 4);
+    w.sel_zero_bytes = base ? (uint64_t)((uint8_t *)(w.sel_cnt + nq * 4) - (uint8_t *)(w.sel_mm + nq)) : 0;       // [max | histograms | counters]
+    w.sel_qstart = c.take<uint32_t>(nq + 1); w.sel_sure = c.take<uint32_t>(nq * n_top); w.sel_maybe = c.take<uint32_t>(nq * (uint64_t)SEL_MAYBE_CAP);
     w.rp_bytes = rocprim_temp_bytes(N);
     w.rp_tmp = c.take<uint8_t>(w.rp_bytes);
     w.bytes = c.off + 256;
@@ -828,6 +1364,8 @@ extern "C" int fmi_dev_aggregate_sizes(fmi_t *h, const fmi_agg_plan *plan, uint6
     return FMI_OK;
 }
 
+static unsigned bits_for(uint64_t max_value) { unsigned b = 1; while (b < 64 && (max_value >> b)) b++; return b; }
+
 template <class K>
 static int sort_pairs(Work &w, K *&ka, K *&kb, uint32_t *&va, uint32_t *&vb, uint64_t n, unsigned bits, hipStream_t st)
 {
@@ -838,8 +1376,6 @@ static int sort_pairs(Work &w, K *&ka, K *&kb, uint32_t *&va, uint32_t *&vb, uin
     ka = dk.current(); kb = dk.alternate(); va = dv.current(); vb = dv.alternate();
     return FMI_OK;
 }
-
-static unsigned bits_for(uint64_t max_value) { unsigned b = 1; while (b < 64 && (max_value >> b)) b++; return b; }
 
 extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *plan, const void *d_plan_blob, uint64_t n_top, uint64_t keep,
                                  int allow_overlaps, double beta, double single_key, int single_key_add_unigrams,
@@ -854,7 +1390,10 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
     Work w = carve(d_ws, H, (uint32_t)n_top, (uint32_t)keep, pc);
     OutLayout L = carve_out(d_out, H.nq, (uint32_t)n_top, (uint32_t)keep, pc, h->max_doc_len);
     if (w.bytes > ws_bytes || L.bytes > out_bytes) { fmi_set_error("fmi_dev_aggregate: workspace/output too small (see fmi_dev_aggregate_sizes)"); return FMI_ERR_ARG; }
-    const AggView v = make_view(H, (const uint8_t *)d_plan_blob);
+    AggView v = make_view(H, (const uint8_t *)d_plan_blob);
+    // the sort keys are as wide as THIS index needs (a radix pass per 8 bits: NQ size sorts 37 / 30 bits where the format's maxima are 46 / 37)
+    v.pos_bits = bits_for(h->n + 256 + H.max_key_len);
+    v.doc_bits = bits_for(h->dev.n_begin);
     const uint64_t N = H.total_occ;
     const uint32_t nq = (uint32_t)H.nq;
     // tools (fmi_dev_debug_marks): marks[1] = 100 * call + stage after every launch, so that a stalled stream names its launch
@@ -883,7 +1422,7 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
         hipLaunchKernelGGL(k_agg_locate, dim3(blocks_for(N, 256)), dim3(256), 0, st, h->dev, v, w.occ_rk, w.doc, ka, va);
         mark(3);
         stage_done();                    // 0: k_agg_locate
-        if ((rc = sort_pairs(w, ka, kb, va, vb, N, FMI_AGG_POS_BITS + bits_for(nq - 1), st))) return rc;
+        if ((rc = sort_pairs(w, ka, kb, va, vb, N, v.pos_bits + bits_for(nq - 1), st))) return rc;
         mark(4);
         stage_done();                    // 1: sort by (query, position)
         hipLaunchKernelGGL(k_mis_prepare, dim3(blocks_for(N, 256)), dim3(256), 0, st, v, va, w.occ_rk, w.M, w.state);
@@ -892,7 +1431,7 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
         mark(5);
         stage_done();                    // 2: coverage (k_mis_prepare + k_mis)
         hipLaunchKernelGGL(k_doc_keys, dim3(blocks_for(N, 256)), dim3(256), 0, st, v, w.occ_rk, w.doc, ka, va);
-        if ((rc = sort_pairs(w, ka, kb, va, vb, N, 32 + bits_for(nq - 1), st))) return rc;
+        if ((rc = sort_pairs(w, ka, kb, va, vb, N, v.doc_bits + bits_for(nq - 1), st))) return rc;
         mark(6);
         stage_done();                    // 3: k_doc_keys + sort by (query, document)
         hipLaunchKernelGGL(k_heads, dim3(blocks_for(N, 256)), dim3(256), 0, st, ka, w.head, N);
@@ -907,7 +1446,37 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
                            w.ent_nkeys, w.ent_rank, w.ent_first, w.ent_q, w.ent_doc, w.ent_score, w.ent_best);
         mark(8);
         stage_done();                    // 5: k_entries
-        // ---- ranking: stable sorts by first touch, then rank key, then query = sorted(first_stage.items(), key=...) ----
+        // ---- ranking: sorted(first_stage.items(), key=...)[:n_top] per query, as a selection (k_select_top) ----
+        if (h->opt.agg_rank_by_sorts == 0) {
+            // the streaming passes on SEL_G workgroups per query, the end game on one (k_sel_*)
+            SelWork sw{w.sel_mm, w.sel_hist, w.sel_cnt, w.sel_qstart, w.sel_sure, w.sel_maybe, (uint32_t)n_top, nq};
+            HIPCHK(hipMemsetAsync(w.sel_mm, 0xFF, (size_t)nq * 8, st));
+            HIPCHK(hipMemsetAsync(w.sel_mm + nq, 0, w.sel_zero_bytes, st));
+            uint32_t p2 = 1;
+            while (p2 < n_top) p2 <<= 1;
+            const size_t fixed = (size_t)p2 * 16 + SEL_WAVES * 256 * 4 + 256 * 4 + 64;
+            const uint32_t fcache = (uint32_t)std::min<size_t>(SEL_MAYBE_CAP, (160 * 1024 > fixed ? 160 * 1024 - fixed : 0) / 16);
+            const size_t flds = std::max(fixed + (size_t)fcache * 16, select_lds_bytes((uint32_t)n_top, 0));
+            if (flds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_sel_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+            hipLaunchKernelGGL(k_sel_minmax, dim3(nq * SEL_G), dim3(SEL_GT), 0, st, w.n_entries, w.ent_q, w.ent_rank, sw);
+            for (uint32_t pass = 0; pass < SEL_PASSES; pass++)
+                hipLaunchKernelGGL(k_sel_hist, dim3(nq * SEL_G), dim3(SEL_GT), 0, st, pass, w.ent_rank, w.ent_first, sw);
+            hipLaunchKernelGGL(k_sel_compact, dim3(nq * SEL_G), dim3(SEL_GT), 0, st, w.ent_rank, w.ent_first, sw);
+            hipLaunchKernelGGL(k_sel_final, dim3(nq), dim3(SEL_WG), flds, st, w.n_entries, w.ent_q, w.ent_rank, w.ent_first, w.ent_doc, w.ent_score, sw, fcache, p2,
+                               w.top_doc, w.top_ent, w.top_cnt, L.o.fs_doc, L.o.fs_score, L.o.fs_cnt);
+            mark(12);
+            stage_done();                    // 6: ranking (k_sel_minmax, k_sel_hist x 2, k_sel_compact, k_sel_final)
+        } else if (h->opt.agg_rank_by_sorts == 2) {
+            // (the whole selection by ONE workgroup per query: what k_sel_final falls back to for a tie group that overflows; tests run it on its own)
+            const uint32_t sel_cache = select_cache_for((uint32_t)n_top);
+            const size_t sel_lds = select_lds_bytes((uint32_t)n_top, sel_cache);
+            if (sel_lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_select_top, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+            hipLaunchKernelGGL(k_select_top, dim3(nq), dim3(SEL_WG), sel_lds, st, w.n_entries, w.ent_q, w.ent_rank, w.ent_first, w.ent_doc, w.ent_score,
+                               (uint32_t)n_top, sel_cache, w.top_doc, w.top_ent, w.top_cnt, L.o.fs_doc, L.o.fs_score, L.o.fs_cnt);
+            mark(12);
+            stage_done();                    // 6: ranking (k_select_top)
+        } else {
+        // (the form of rounds 2-5, kept as the checker of the selection: three stable sorts -- first touch, rank key, query -- over every entry slot)
         uint32_t *fa = w.ent_first, *fb = w.tmp32;
         va = w.v0; vb = w.v1;
         hipLaunchKernelGGL(k_pad_entries, dim3(blocks_for(N, 256)), dim3(256), 0, st, w.n_entries, w.ent_first, w.ent_rank, w.ent_q, nq, va, N);
@@ -925,6 +1494,7 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
                            L.o.fs_doc, L.o.fs_score, L.o.fs_cnt);
         mark(12);
         stage_done();                    // 6: ranking (three stable sorts + k_top_docs)
+        }
     } else if (timing) {
         for (int i = 0; i < 8; i++) stage_done();
     }
@@ -954,9 +1524,11 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
                        (const uint32_t *)nullptr, w.type_dense, w.tok2local, w.scores, so, pool);
     mark(13);
     stage_done();                        // 8: k_full_score over the ranked documents
-    if (n_top * 8 > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void *)k_rank_docs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(n_top * 8)));
-    hipLaunchKernelGGL(k_rank_docs, dim3(nq), dim3(1024), n_top * 8, st, w.scores, w.top_cnt, (uint32_t)n_top, w.order);
+    uint32_t rank_p2 = 1;
+    while (rank_p2 < n_top) rank_p2 <<= 1;
+    if ((size_t)rank_p2 * 12 > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)k_rank_docs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rank_p2 * 12)));
+    hipLaunchKernelGGL(k_rank_docs, dim3(nq), dim3(1024), (size_t)rank_p2 * 12, st, w.scores, w.top_cnt, (uint32_t)n_top, rank_p2, w.order);
     mark(14);
     stage_done();                        // 9: k_rank_docs
     p.per_q = (uint32_t)keep;

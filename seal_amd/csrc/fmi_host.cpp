@@ -66,6 +66,7 @@ int FmiOptions::set(const char *name, int64_t value)
     else if (s == "topk_legacy") topk_legacy = value < 0 ? 0 : value;
     else if (s == "chain_steps") chain_steps = value < 0 ? 1 : value;
     else if (s == "advance_apart") advance_apart = value < 0 ? 1 : value;
+    else if (s == "agg_rank_by_sorts") agg_rank_by_sorts = value < 0 ? 0 : value;
     else if (s == "pt_inject_failure") pt_inject_failure = value < 0 ? 0 : value;
     else return -1;
     return 0;

@@ -74,6 +74,7 @@ struct FmiOptions {
     int64_t topk_legacy = 0;        // SEALFM_TOPK_LEGACY=1: wide rows skip the thread-maxima bound (exact radix select)
     int64_t chain_steps = 1;        // SEALFM_CHAIN_STEPS=0: fmi_dev_beam_step leaves the rows' chains to the next call (k_constrain_rows) instead of k_beam_advance
     int64_t advance_apart = 1;      // measurement passes: k_beam_advance as two launches (bookkeeping, chains); 0: the product's one launch, timed whole
+    int64_t agg_rank_by_sorts = 0;  // tests: fmi_dev_aggregate ranks the first stage 1: with the three full stable sorts of rounds 2-5 (the checker of the selection), 2: with the single-workgroup selection (k_select_top)
     int64_t pt_inject_failure = 0;  // tests: building a prefix table fails after its first allocation (the call must take the generic path)
     FmiOptions();
     int set(const char *name, int64_t value);      // 0, or -1 for an unknown name

@@ -614,6 +614,12 @@ __host__ __device__ constexpr uint32_t constrain_lds_slots(uint32_t D, uint32_t 
 // terminated: CDNA ISA "S_BARRIER ... waves that have ended are not counted"; leave_early = 0 keeps them, and a GPU test runs both)
 static_assert(FMI_MAX_DLEVELS < 7, "s_cnt[7] holds the live-wave mask: the level counters must end below it");
 static constexpr int CONSTRAIN_WG = 8;       // 39 KB of LDS per workgroup at BART's depth, two workgroups per CU
+// Chained calls (the decode loop's calls from the 3rd token on: the rows' chains are done, most items are empty, a few hundred are wide):
+// workgroups of FOUR waves.  Measured on the bench workload with 2 / 4 / 8 / 16 waves (profiles/r6_constrain_ab_workgroup_width.txt, us per
+// batch): 313 / 317 / 329 / 335 -- the level barriers of a workgroup wait for its slowest dependent access, and fewer waves wait less;
+// packing the live items densely into 8-wave workgroups (a list written by k_beam_advance) lost for the same reason
+// (profiles/r6_constrain_ab_item_list_lost.txt: 365 vs 346).  4 rather than 2: a wide row still shares its leaf level with three helpers.
+static constexpr int CONSTRAIN_WG_CHAINED = 4;
 
 // the row's group (wave-uniform: scalar compares on kernel arguments)
 __device__ __forceinline__ uint32_t row_group(const ConstrainArgs &a, uint32_t r)
@@ -743,7 +749,11 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
         const uint32_t rows8 = (a.rows + 7) & ~7u;
         d1 = blockIdx.x / rows8; r = blockIdx.x - d1 * rows8;
     } else {
-        d1 = blockIdx.x / a.groups; r = (blockIdx.x - d1 * a.groups) * W + wave;
+        // workgroups in row-group-major order -- the top digits of one group of W rows follow each other in the grid (round 6; top-digit-major
+        // before): a batch's calls 344 -> 322 us on one box (profiles/r6_constrain_ab_item_order.txt); striding a workgroup's rows over the
+        // call instead of taking W consecutive ones changed nothing
+        const uint32_t g = blockIdx.x / a.ndig0;
+        d1 = blockIdx.x - g * a.ndig0; r = g * W + wave;
     }
     const uint32_t slot = blockIdx.x * W + wave;               // of the debug stamps
     const bool writer = d1 == 0;
@@ -2467,13 +2477,13 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
         h->bits_prefilled = 0;
         if (bits_out) *bits_out = a.bits;
         h->last_bits = a.bits;
-        a.groups = (uint32_t)((rows + CONSTRAIN_WG - 1) / CONSTRAIN_WG);
+        a.groups = (uint32_t)((rows + CONSTRAIN_WG_CHAINED - 1) / CONSTRAIN_WG_CHAINED);
         a.leave_early = (int)h->opt.leave_early;
         const unsigned cgrid = a.groups * a.ndig0;
         const bool ctimed = h->timing_enabled && h->ev_used < MAX_TIMED_LAUNCHES;
         if (ctimed) HIPCHK(hipEventRecord((hipEvent_t)h->ev_start[h->ev_used], st));
-        void (*ck)(FmiDev, ConstrainArgs) = h->dev.nsb > 1 ? k_constrain<true, CONSTRAIN_WG> : k_constrain<false, CONSTRAIN_WG>;
-        hipLaunchKernelGGL(ck, dim3(cgrid), dim3(64 * CONSTRAIN_WG), (size_t)constrain_lds_slots(h->dlevels, CONSTRAIN_WG) * 16, st, h->dev, a);
+        void (*ck)(FmiDev, ConstrainArgs) = h->dev.nsb > 1 ? k_constrain<true, CONSTRAIN_WG_CHAINED> : k_constrain<false, CONSTRAIN_WG_CHAINED>;
+        hipLaunchKernelGGL(ck, dim3(cgrid), dim3(64 * CONSTRAIN_WG_CHAINED), (size_t)constrain_lds_slots(h->dlevels, CONSTRAIN_WG_CHAINED) * 16, st, h->dev, a);
         HIPCHK(hipGetLastError());
         call_log_begin(h, FMI_CALL_CHAINED, cur_len, rows, ctimed);
         if (ctimed) { HIPCHK(hipEventRecord((hipEvent_t)h->ev_stop[h->ev_used], st)); h->ev_used++; }

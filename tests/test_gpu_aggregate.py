@@ -221,3 +221,38 @@ def test_kernel_copy_moves_bytes_both_ways_and_refuses_pageable_memory(nbytes):
             check(lib().fmi_dev_kernel_copy(st.cuda_stream, mid.data_ptr(), pageable.data_ptr(), nbytes))
         with pytest.raises(SealFMError):
             check(lib().fmi_dev_kernel_copy(st.cuda_stream, mid.data_ptr() + 2, src.data_ptr(), 8))
+
+
+@pytest.mark.parametrize("n_docs,n_top", [(3000, 1), (3000, 100), (3000, 257), (3000, 2999), (3000, 3000), (3000, 4000), (15000, 6000)])
+def test_first_stage_ranking_by_selection_equals_the_three_stable_sorts_under_mass_ties(n_docs, n_top):
+    """``k_select_top`` (round 6: per query the n_docs_complete_score best entries by an MSD radix select on (rank key, first touch)) against the
+    three full stable sorts of rounds 2-5 (``agg_rank_by_sorts``) and against the host routine, on the case the selection has to work hardest
+    for: thousands of documents with the SAME score (one occurrence of one key each), the cut falling inside the tie group -- the order among
+    them is the order of first touch (Python's stable sort over the dict's insertion order, keys.py:366-375) --, plus groups above and below.
+    (15 000 documents, 6 000 wanted: the cut falls into a tie group of 10 000, more than k_sel_final can hold beside 6 000 selected entries -- the
+    query takes the single-workgroup fallback inside the default pipeline.)"""
+    from seal_amd.keys import aggregate_evidence
+    from tests.helpers import kernel_options
+    rng = np.random.default_rng(11)
+    docs = []
+    for d in range(n_docs):
+        filler = rng.integers(20, 60, size=int(rng.integers(2, 6))).tolist()
+        docs.append(filler[:1] + [7] + filler[1:] + [10 + (d % 3 == 0)] + [2])          # token 10 or 11 once per document
+    ix = _hip_index(docs)
+    keys = [([10], -1.0), ([11], -1.0), ([11, 2], -0.5)]                              # [11, 2]: the same documents as [11], a better score
+    keys += [(docs[d][:2], -0.25) for d in (5, 17, 1500)]                               # a few documents on top
+    kw = dict(max_occurrences_1=20000, n_docs_complete_score=n_top, use_fm_index_frequency=False)
+    os.environ["SEAL_HOST_AGGREGATE"] = "1"
+    try:
+        want = aggregate_evidence(keys, unigram_scores=None, index=ix, **kw)
+    finally:
+        del os.environ["SEAL_HOST_AGGREGATE"]
+    by_selection = aggregate_evidence(keys, unigram_scores=None, index=ix, **kw)
+    with kernel_options(ix, agg_rank_by_sorts=1):
+        by_sorts = aggregate_evidence(keys, unigram_scores=None, index=ix, **kw)
+    with kernel_options(ix, agg_rank_by_sorts=2):          # the single-workgroup form (what a tie group beyond the `maybe` buffer falls back to)
+        by_one_workgroup = aggregate_evidence(keys, unigram_scores=None, index=ix, **kw)
+    assert len(want[0]) == min(n_top, n_docs)
+    _same(by_selection, want)
+    _same(by_sorts, want)
+    _same(by_one_workgroup, want)

