@@ -92,6 +92,9 @@ class BartStepDecoder:
             BartStepDecoder.split_gemm = split_gemm.SplitLinears() if split_gemm.ENABLED else False
         if self.split_gemm and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
             return self.split_gemm(x, w, b, defer)
+        if x.is_cuda:
+            from . import split_gemm
+            split_gemm.LIBRARY_GEMMS[0] += 1
         return F.linear(x, w, b)
 
     def _mod(self, x: torch.Tensor, m, defer: bool = False):
@@ -144,9 +147,9 @@ class BartStepDecoder:
                                         split_gemm._flag(x.device).data_ptr()))
         return p
 
-    def _ffn(self, x: torch.Tensor, xp, L, defer: bool = False):
+    def _ffn(self, x: torch.Tensor, xp, L, defer: bool = False, hand: bool = False):
         """fc2(gelu(fc1(x))): with planes, gelu's output exists as fc2's operand only (``defer``: see ``_lin``; fc1's own epilogue is
-        always gelu's to apply)"""
+        always gelu's to apply; ``hand``: fc1 may run in the hand-written kernel too -- one slab, GELU reads it)"""
         w2 = L["fc2"].weight
         # (the fused kernel computes the erf form: nn.GELU(approximate="tanh") shares the class name and must not take it)
         erf_gelu = (getattr(L["act"], "__class__", type(None)).__name__ in ("GELUActivation", "GELU")
@@ -154,7 +157,9 @@ class BartStepDecoder:
         if xp is not None and self.split_gemm.wants(w2, x.shape[0]) and erf_gelu:
             from . import split_gemm
             from ._lib import check, lib
-            h = self._lin_p(x, xp, L["fc1"].weight, L["fc1"].bias, defer=True)
+            h = self._lin_p(x, xp, L["fc1"].weight, L["fc1"].bias, defer=True, slabs_ok=hand)
+            if isinstance(h, split_gemm.Deferred) and h.slabs > 1:        # (no configuration of fc1 asks for slabs; summed here if one ever does)
+                h = split_gemm.Deferred(h.acc.sum(0), h.bias, h.alpha)
             acc = h.acc if isinstance(h, split_gemm.Deferred) else h
             hp = torch.empty(acc.shape[0], 3 * acc.shape[1], dtype=torch.float16, device=acc.device)
             stream = torch.cuda.current_stream(acc.device).cuda_stream
@@ -262,6 +267,7 @@ class BartStepDecoder:
             # by permuting the columns of this table, the cache itself never moves
             st.anc = torch.arange(R, dtype=torch.int32, device=dev).repeat(T, 1).contiguous()
             st.fused = False
+            st.library_free = False
             st.ck = torch.zeros(nl, B, H, dh, S_pad, dtype=dtype, device=dev)
             st.cv = torch.zeros(nl, B, H, S_pad, dh, dtype=dtype, device=dev)
             st.cbias = torch.zeros(B, 1, 1, S_pad, dtype=dtype, device=dev)
@@ -524,6 +530,7 @@ class BartStepDecoder:
             # / 12 us (300) becomes 11 / 7 us (profiles/r5_hgemm_probe.txt), with no pass over the activations in between.
             hand = bool(planes and x.dtype == torch.float32 and split_gemm.DEFER_EPILOGUE and split_gemm.hand_config(R, self.d, 3 * self.d) is not None)
             flag = split_gemm._flag(x.device).data_ptr() if hand else None
+            library_before = split_gemm.LIBRARY_GEMMS[0]
             for li, L in enumerate(self.layers):
                 qkv = self._lin_p(x, xp, L["qkv_w"], L["qkv_b"], defer=True, slabs_ok=hand)
                 if hand and isinstance(qkv, split_gemm.Deferred):
@@ -557,12 +564,15 @@ class BartStepDecoder:
                                              B, K, H, S_pad, float(self.scale), c.data_ptr()))
                     y = self._mod(c, L["co"], defer=True)
                 x, xp = add_ln(x, y, L["ln2"])
-                x, xp = add_ln(x, self._ffn(x, xp, L, defer=True), L["ln3"])
+                x, xp = add_ln(x, self._ffn(x, xp, L, defer=True, hand=hand), L["ln3"])
             st.t.add_(1)
             # The output projection leaves the graph as RAW accumulators when it goes through the split GEMM: its epilogue (alpha * acc +
             # final_logits_bias) is applied by `step` in the same pass that adds a per-query logit bias, if there is one -- torch.addmm would
             # first copy the broadcast bias into the [rows, vocab] output (120 MB at 600 rows) and have the GEMM read it back.
-            y = self._lin_p(x, xp, self.lm_w, self.lm_b.view(-1), defer=True)
+            y = self._lin_p(x, xp, self.lm_w, self.lm_b.view(-1), defer=True, slabs_ok=hand)
+            # no library GEMM in this step: nothing in it waits for partner workgroups (hipBLASLt's kernels are stream-K), so another stream's
+            # library GEMMs may run beside it (retrieval.py: the rescoring forward overlaps the decode steps)
+            st.library_free = hand and split_gemm.LIBRARY_GEMMS[0] == library_before
             if isinstance(y, split_gemm.Deferred) and y.slabs == 1:
                 st.lm_epilogue = (float(y.alpha), y.bias)
                 return y.acc
@@ -679,6 +689,7 @@ class BartStepDecoder:
             st.kv = root.kv[:, :, dropped * K:]
             st.anc = torch.arange(R2, dtype=torch.int32, device=dev).repeat(T, 1).contiguous()
             st.fused = False
+            st.library_free = False
             st.ck, st.cv, st.cbias = root.ck[:, dropped:], root.cv[:, dropped:], root.cbias[dropped:]
             st.pos_idx = root.pos_idx
             st.logits = None
@@ -773,6 +784,22 @@ class BartStepDecoder:
             hit = self.__dict__["_bias_q"] = (weakref.ref(lb), lb._version, weakref.ref(bias), bias[None, :] + lb)
         return hit[3]
 
+    def steps_are_library_free(self) -> bool:
+        """do the remaining model steps of the running decode (its static state and the narrower continuations set up for it) hold no library
+        GEMM?  (The encoder, the cross-attention K / V and the shared first step do: the decode's PREFIX.)"""
+        root = getattr(self, "_st_root", None)
+        if root is None or getattr(self, "_st", None) is None:
+            return False
+        states = [root] + [t for t in (root.tails or {}).values() if t.graph is not None]
+        return all(getattr(s, "library_free", False) for s in states)
+
+    def _library_prefix_done(self):
+        """called once the first model step of a decode is enqueued: tells whoever asked (``model._seal_after_library_prefix``, set by the
+        overlapped searcher around its decode enqueues) that everything this decode still has to run is free of library GEMMs"""
+        cb = getattr(self.model, "_seal_after_library_prefix", None)
+        if cb is not None and self.steps_are_library_free():
+            cb()
+
     def step_buffers(self):
         """(token buffer, ancestry table) of the static fused decode state, for a caller that advances the beams on the device
         (``fmi_dev_beam_step``): the next step's input tokens are written straight into the buffer ``step`` reads, and re-ranking the
@@ -796,12 +823,15 @@ class BartStepDecoder:
             if beams_identical and t == 0 and st.first_graph is not None:
                 st.first_graph.replay()
                 self.t += 1
+                self._library_prefix_done()
                 logits = st.first_logits                                  # [B, V]
                 if self.logit_bias is not None:
                     logits = logits + self.logit_bias
                 return logits[:, None, :].expand(B, K, logits.shape[-1]).reshape(R, -1)
             st.graph.replay()
             self.t += 1
+            if t == 0:
+                self._library_prefix_done()
             logits = st.logits
             ep = getattr(st, "lm_epilogue", None)
             if ep is not None:

@@ -72,7 +72,8 @@ __device__ __forceinline__ void wait_all_but()      // all LDS-DMA but the newes
 // on the CU that overlap one another's waits -- split-K without slabs in memory or a second kernel.
 template <uint32_t BM, uint32_t BN, uint32_t NS, uint32_t KG>
 __global__ __launch_bounds__(256 * KG) void k_hgemm_nt(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, float *__restrict__ C,
-                                                  uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t k_per_slice, uint64_t slab_stride)
+                                                  uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t k_per_slice, uint64_t slab_stride,
+                                                  uint32_t m_fastest)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr uint32_t TM = BM / 2, TN = BN / 2, FM = TM / 16, FN = TN / 16;
@@ -84,7 +85,18 @@ __global__ __launch_bounds__(256 * KG) void k_hgemm_nt(const _Float16 *__restric
     const uint32_t wave_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t grp = wave_all >> 2, wave = wave_all & 3;
     const uint32_t wm = wave >> 1, wn = wave & 1;
-    const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    uint32_t tile_m = blockIdx.y, tile_n = blockIdx.x;
+    if (m_fastest) {
+        // A wide-N product (lm_head: 393 column tiles x 5 row tiles) reads each W tile once per ROW tile; with the column tile as the fastest
+        // grid index those five workgroups are 393 launches apart and W comes from memory five times (1.5 GB for a 309 MB matrix).  Here the
+        // grid is one-dimensional, the row tile runs fastest, and the index is first remapped so that consecutive logical tiles land on ONE XCD
+        // (workgroup i runs on XCD i % 8): the row tiles of a column tile then share that XCD's L2 copy of the W tile.
+        const uint32_t tiles_m = (M + BM - 1) / BM, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7u;
+        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        const uint32_t logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        tile_n = logical / tiles_m; tile_m = logical - tile_n * tiles_m;
+    }
+    const uint32_t m0 = tile_m * BM, n0 = tile_n * BN;
     const uint32_t kbeg = blockIdx.z * k_per_slice + grp * BK;       // this group's first K step; its steps are KG * BK apart
     const uint32_t nk = k_per_slice / (BK * KG);
     unsigned char *const lds_grp = lds + grp * NS * STAGE;
@@ -194,14 +206,14 @@ __global__ __launch_bounds__(256 * KG) void k_hgemm_nt(const _Float16 *__restric
 }
 
 template <uint32_t BM, uint32_t BN, uint32_t NS, uint32_t KG>
-int launch_cfg(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t slices)
+int launch_cfg(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t slices, uint32_t m_fastest)
 {
-    const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, slices);
+    const dim3 grid = m_fastest ? dim3(((N + BN - 1) / BN) * ((M + BM - 1) / BM), 1, slices) : dim3((N + BN - 1) / BN, (M + BM - 1) / BM, slices);
     const size_t lds = (size_t)KG * NS * (BM + BN) * ROW_BYTES;
     if ((K / slices) % (BK * KG)) { fmi_set_error("sealnn_hgemm_nt: %u K steps per slice do not split over %u K groups", K / slices / BK, KG); return FMI_ERR_ARG; }
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_hgemm_nt<BM, BN, NS, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_hgemm_nt<BM, BN, NS, KG>), grid, dim3(256 * KG), lds, st, (const _Float16 *)A, (const _Float16 *)W, C, M, N, K, ldc, K / slices,
-                       (uint64_t)M * ldc);
+                       (uint64_t)M * ldc, m_fastest);
     return hipGetLastError() == hipSuccess ? FMI_OK : FMI_ERR_HIP;
 }
 
@@ -209,19 +221,19 @@ int launch_cfg(hipStream_t st, const void *A, const void *W, float *C, uint32_t 
 //  for the two small tiles, two stages)
 template <uint32_t BM, uint32_t BN>
 int launch(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t slices, uint32_t stages,
-           uint32_t kgroups)
+           uint32_t kgroups, uint32_t mf)
 {
     if (kgroups == 1) {
         switch (stages) {
-        case 1: return launch_cfg<BM, BN, 1, 1>(st, A, W, C, M, N, K, ldc, slices);
-        case 2: return launch_cfg<BM, BN, 2, 1>(st, A, W, C, M, N, K, ldc, slices);
-        case 3: return launch_cfg<BM, BN, 3, 1>(st, A, W, C, M, N, K, ldc, slices);
+        case 1: return launch_cfg<BM, BN, 1, 1>(st, A, W, C, M, N, K, ldc, slices, mf);
+        case 2: return launch_cfg<BM, BN, 2, 1>(st, A, W, C, M, N, K, ldc, slices, mf);
+        case 3: return launch_cfg<BM, BN, 3, 1>(st, A, W, C, M, N, K, ldc, slices, mf);
         default: break;
         }
     } else if constexpr (BM * BN <= 128 * 64) {
-        if (stages == 2 && kgroups == 2) return launch_cfg<BM, BN, 2, 2>(st, A, W, C, M, N, K, ldc, slices);
+        if (stages == 2 && kgroups == 2) return launch_cfg<BM, BN, 2, 2>(st, A, W, C, M, N, K, ldc, slices, mf);
         if constexpr (BM * BN <= 64 * 64) {
-            if (stages == 2 && kgroups == 4) return launch_cfg<BM, BN, 2, 4>(st, A, W, C, M, N, K, ldc, slices);
+            if (stages == 2 && kgroups == 4) return launch_cfg<BM, BN, 2, 4>(st, A, W, C, M, N, K, ldc, slices, mf);
         }
     }
     fmi_set_error("sealnn_hgemm_nt: no kernel for %u x %u tiles with %u stages and %u K groups", BM, BN, stages, kgroups);
@@ -230,7 +242,7 @@ int launch(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, u
 
 }   // namespace
 
-// config: 0 = pick by shape; else tile (1 = 128 x 128, 2 = 64 x 64, 3 = 128 x 64, 4 = 64 x 128) | stages << 8 (LDS stages 1..3; 0: two) |
+// config: 0 = pick by shape; else tile (1 = 128 x 128, 2 = 64 x 64, 3 = 128 x 64, 4 = 64 x 128; + 128: row tiles fastest, XCD-grouped) | stages << 8 (LDS stages 1..3; 0: two) |
 // kgroups << 12 (K groups of 4 waves per workgroup: 1, 2 (tiles 2..4), 4 (tile 2); 0: one) | slices << 16 (split-K over workgroups: slab s of C
 // at C + s * M * ldc, the caller sums the slabs).  Probes and tests pass it explicitly.
 extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float *c, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t config)
@@ -238,7 +250,8 @@ extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float
     if (!a || !w || !c || M == 0 || N == 0) { fmi_set_error("sealnn_hgemm_nt: null / empty operand"); return FMI_ERR_ARG; }
     if (K == 0 || K % BK) { fmi_set_error("sealnn_hgemm_nt: K = %u must be a multiple of %u", K, BK); return FMI_ERR_UNSUPPORTED; }
     if (((uintptr_t)a | (uintptr_t)w) & 15) { fmi_set_error("sealnn_hgemm_nt: operands must be 16-byte aligned"); return FMI_ERR_ARG; }
-    uint32_t tile = config & 0xff, stages = (config >> 8) & 0xf, kgroups = (config >> 12) & 0xf, slices = (config >> 16) ? (config >> 16) : 1;
+    const uint32_t mf = (config >> 7) & 1u;          // bit 7 of the tile byte: row tile fastest + XCD remap (wide-N products)
+    uint32_t tile = config & 0x7f, stages = (config >> 8) & 0xf, kgroups = (config >> 12) & 0xf, slices = (config >> 16) ? (config >> 16) : 1;
     if (stages == 0) stages = 2;
     if (kgroups == 0) kgroups = 1;
     if ((K / BK) % slices) { fmi_set_error("sealnn_hgemm_nt: %u K steps do not split into %u slices", K / BK, slices); return FMI_ERR_ARG; }
@@ -252,10 +265,10 @@ extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float
     }
     hipStream_t st = (hipStream_t)stream;
     switch (tile) {
-    case 1: return launch<128, 128>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups);
-    case 2: return launch<64, 64>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups);
-    case 3: return launch<128, 64>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups);
-    case 4: return launch<64, 128>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups);
+    case 1: return launch<128, 128>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
+    case 2: return launch<64, 64>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
+    case 3: return launch<128, 64>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
+    case 4: return launch<64, 128>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
     default: fmi_set_error("sealnn_hgemm_nt: unknown tile %u", tile); return FMI_ERR_ARG;
     }
 }

@@ -635,6 +635,9 @@ class SEALSearcher:
         # the decode and the rescoring phase (the two that run library GEMMs) ALTERNATE on the GPU instead of sharing it: two stream-K
         # GEMM streams in flight at once stalled the GPU for ever.  False restores round 3's behaviour.
         self.exclusive_gemm_streams: bool = bool(params.get("exclusive_gemm_streams", True))
+        # ... where "the decode" means the part of it that runs library GEMMs: its model steps do not (round 6: every product of a step is the
+        # hand-written kernel), so a batch's rescoring runs BESIDE the next batch's decode steps.  False: rescoring after the whole decode (round 5).
+        self.rescore_beside_decode: bool = bool(params.get("rescore_beside_decode", True))
         # extension (synthetic benchmarks): per-query additive bias on the model's next-token logits, [batch, vocab]
         self.logit_bias = None
         if "bart" in self.backbone:   # retrieval.py:480-491
@@ -875,16 +878,52 @@ class SEALSearcher:
                 ev.record(stream)
                 marks.append((label, ev))
 
+        # Round 6: the decode's model STEPS hold no library GEMM (every product of a step runs in sealnn_hgemm_nt, which has no inter-workgroup
+        # hand-off: split_gemm.HAND_CONFIGS); what does is the decode's PREFIX -- encoder, cross-attention K / V, the shared first step.  So the
+        # fence a rescoring waits for is recorded right behind that prefix (the step decoder calls back once its first step is enqueued and
+        # everything after it is library-free), not behind the whole decode: GPU order  prefix(i+1) -> [steps(i+1)  ||  rescoring(i)] ->
+        # prefix(i+2) [waits for rescoring(i)] -> ...  -- still at most ONE stream of stream-K kernels at any time, and no phase boundary at
+        # which the GPU drains: 380 -> 398 queries/s (profiles/r6_overlap_timeline.txt).  The two phases SHARE the chip rather than hide in each
+        # other: beside the rescoring's chip-filling GEMMs a decode takes 48 ms instead of 38.5 and the rescoring 20 instead of 10.9 (a decode
+        # kernel's few hundred workgroups wait for compute units the rescoring's hold); a high-priority decode stream changed nothing.
+        # A decoder whose steps are not library-free (bf16 storage, SEAL_HAND_GEMM=0, other geometries) never calls back: the fence then sits
+        # behind the whole decode, as in round 5.
+        overlap_steps = exclusive and bool(getattr(self, "rescore_beside_decode", True))
+
+        class _PrefixFence:
+            """while active, the step decoders of this searcher's models record the "decode" fence behind their library-GEMM prefix"""
+            def __init__(self_f):
+                self_f.called = False
+                self_f.models = [m for m in {id(m): m for m in (self.bart_model, getattr(self, "bart_title_model", None),
+                                                                  getattr(self, "bart_code_model", None)) if m is not None}.values()]
+
+            def __enter__(self_f):
+                if overlap_steps:
+                    def done():
+                        self_f.called = True
+                        after("decode", main)
+                        mark("decode prefix ends", main)
+                    for m in self_f.models:
+                        m._seal_after_library_prefix = done
+                return self_f
+
+            def __exit__(self_f, *exc):
+                for m in self_f.models:
+                    m.__dict__.pop("_seal_after_library_prefix", None)
+                return False
+
         def enqueue_next(upto="decoding"):
             """starts the next batch: its body decode is enqueued (``upto="body"``), or both decodes"""
             nonlocal nxt_i
             g = _batch_steps(self, batches[nxt_i], constrained, offsets[nxt_i])
             wait_for("rescore", main)
             mark("decode %d begins" % nxt_i, main)
-            state = next(g)                                   # "body": the body decode is enqueued behind the earlier ones
-            if upto == "decoding":
-                state = next(g)
-            after("decode", main)
+            with _PrefixFence() as pf:
+                state = next(g)                               # "body": the body decode is enqueued behind the earlier ones
+                if upto == "decoding":
+                    state = next(g)
+            if not pf.called:
+                after("decode", main)
             mark("decode %d ends" % nxt_i, main)
             ahead.append([g, state])
             nxt_i += 1
@@ -898,9 +937,13 @@ class SEALSearcher:
             if decodes:
                 wait_for("rescore", main)
             while entry[1] != upto:
+                if decodes and entry[1] == "body":
+                    with _PrefixFence() as pf:
+                        entry[1] = next(entry[0])
+                    if entry[1] == "decoding" and not pf.called:
+                        after("decode", main)
+                    continue
                 entry[1] = next(entry[0])
-                if decodes and entry[1] == "decoding":
-                    after("decode", main)
 
         def to_rescoring(entry):
             """the batch's hypotheses on the host, its filters run, its rescoring forward enqueued on the post stream (fenced behind the decodes

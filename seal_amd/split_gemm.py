@@ -151,11 +151,23 @@ class Deferred:
 # hand-written with 4 slabs): fc2 [rows, 3 x 4096] x [1024]: 600 rows 43.2 -> 32.2, 300 rows 31.5 -> 21.3.  (N, K') -> {max rows: config};
 # config = tile | stages << 8 | K groups << 12 | slices << 16 (sealnn.h).  SEAL_HAND_GEMM=0: the library for everything.
 HAND_GEMM = os.environ.get("SEAL_HAND_GEMM", "1") == "1"
+# Round 6: EVERY product of a decode step (fused path, fp32, 129 .. 640 rows) runs in the hand-written kernel -- also the three that round 5 left to
+# the library (profiles/r6_hgemm_probe_decode.txt, us, library -> hand): qkv at 600 rows 23.8 -> 19.5; fc1 25.2 -> 27.9 (600), 18.3 -> 18.5 (300);
+# lm_head 237.9 -> 229.6 (600), 126.4 -> 157.7 (300) with the row tile as the fastest grid index and the workgroups grouped by XCD (tile + 128:
+# each 128-column tile of the 309 MB matrix is read from memory once, by the XCD whose five row tiles share it; column-major order: 305 us).
+# Not for the microseconds -- they roughly cancel -- but because a step without a library GEMM has no stream-K kernel in it, so the rescoring
+# forward (the library's GEMMs, on another stream) may run BESIDE the decode steps (retrieval.py; DESIGN.md section 9: at most one stream of
+# stream-K kernels at a time).
 HAND_CONFIGS = {
     (1024, 12288): ((320, 2 | (2 << 8) | (2 << 12) | (4 << 16)), (640, 2 | (2 << 8) | (1 << 12) | (4 << 16))),      # fc2
     (1024, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (4 << 16)), (640, 2 | (2 << 8) | (1 << 12) | (4 << 16))),       # the d x d projections: 14.3 -> 10.7, 11.1 -> 6.6
-    (3072, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (2 << 16)),),                                                    # qkv at 300 rows: 15.2 -> 11.9 (600: no gain)
+    (3072, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (2 << 16)), (640, 4 | (3 << 8) | (1 << 12) | (2 << 16))),       # qkv: 15.2 -> 11.9, 23.8 -> 19.5
+    (4096, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (1 << 16)), (640, (4 + 128) | (3 << 8) | (1 << 12) | (1 << 16))),   # fc1 (ONE slab: GELU reads it)
+    (50265, 3072): ((640, (1 + 128) | (2 << 8) | (1 << 12) | (1 << 16)),),                                           # lm_head (one slab)
 }
+# library GEMMs issued through this module and BartStepDecoder._lin since the process started: a step decoder that captures its graph reads it
+# before and after to learn whether the step is free of them (BartStepDecoder._step_static)
+LIBRARY_GEMMS = [0]
 
 
 def hand_config(rows: int, n: int, k3: int):
@@ -205,11 +217,13 @@ class SplitLinear:
                     acc = torch.empty(slices, planes.shape[0], self.N, dtype=torch.float32, device=planes.device)
                     check(lib().sealnn_hgemm_nt(torch.cuda.current_stream(planes.device).cuda_stream, planes.data_ptr(), self.planes.data_ptr(), acc.data_ptr(),
                                                 planes.shape[0], self.N, planes.shape[1], self.N, cfg))
-                    return Deferred(acc, self.bias, self.alpha, slabs=slices)
+                    return Deferred(acc if slices > 1 else acc[0], self.bias, self.alpha, slabs=slices)
+            LIBRARY_GEMMS[0] += 1 if planes.is_cuda else 0
             acc = torch.mm(planes, self.wt, out_dtype=torch.float32) if planes.is_cuda else torch.mm(planes.float(), self.wt.float())
             return Deferred(acc, self.bias, self.alpha)
         if not planes.is_cuda:
             return torch.addmm(self.bias, planes.float(), self.wt.float(), alpha=self.alpha)
+        LIBRARY_GEMMS[0] += 1
         return torch.addmm(self.bias, planes, self.wt, alpha=self.alpha, out_dtype=torch.float32)
 
 
@@ -251,6 +265,7 @@ class SplitLinears:
     def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias=None, defer: bool = False):
         """``defer``: a product that goes through the split comes back as ``Deferred`` (one that does not, as the finished tensor)"""
         if not self.wants(weight, x.shape[0], have_planes=False):
+            LIBRARY_GEMMS[0] += 1 if x.is_cuda else 0
             return torch.nn.functional.linear(x, weight, bias)
         return self._of(weight, bias)(x, defer and DEFER_EPILOGUE)
 
