@@ -1085,7 +1085,7 @@ def main():
         other_qps = args.batch * args.steps * world / t2
         searcher.first_stage_only = args.first_stage_only
 
-    # same-box comparison of an environment switch the product reads per call (SEAL_BENCH_AB="SEAL_RESCORE_AHEAD=0,1,auto"): the same K batches
+    # same-box comparison of an environment switch the product reads per call (SEAL_BENCH_AB="SEAL_SPLIT_GEMM=1,0"): the same K batches
     # with each value in turn, several rounds, after the timed run -- boxes differ by +-15 %, two runs on two boxes say nothing about a 3 %
     # change.  SEAL_BENCH_AB_GARBAGE=1: the legs' results stay with the collector (a host slowed by collections) instead of being frozen.
     ab = None
@@ -1402,7 +1402,7 @@ def main():
         "config": {"workload": f"{'configs[4]: 100M-document stress tier, suffix array sorted in slices,' if stress else 'configs[3]: KILT-size' if args.docs >= 30_000_000 else 'configs[1]: NQ-shaped'} synthetic FM-index ({args.docs} passages, {index.size()} symbols{', phrase corpus P=%d' % args.corpus_phrases if args.corpus_phrases else ''}), random-init "
                                f"BART-large {'bf16' if stress else 'fp32'}, beam={args.beam}, batch={args.batch} per GPU, body len 10 + title len<=15, "
                                f"{'first-stage retrieval' if args.first_stage_only else 'first stage + full-document rescoring of 1500 docs/query'}, top-{args.topk}",
-                   "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world} ({'torch.distributed backend ' + dist.get_backend() + ' = RCCL, world_size ' + str(dist.get_world_size()) + ', one all_gather of the top-k per timed call' if use_dist else 'one rank, no process group'}), index+model replicated; " + ("decodes of the next two batches enqueued ahead of this batch's rescoring / aggregation; the two GEMM-bearing phases (decode, rescoring) alternate on the GPU, the aggregation overlaps both on the index's stream" if not args.no_overlap else "one batch after the other"), "model_arithmetic": "bf16 storage, fp32 accumulation (BASELINE configs[4])" if stress else "fp32 (as the reference runs BART); linear layers of >= 0.9 GFLOP as one fp16 GEMM over three planes with fp32 accumulation (seal_amd/split_gemm.py), scores within 1e-4 of HF's fp32 forward",
+                   "index_hbm_gib": round(index.device_bytes() / 2**30, 2), "parallelism": f"query-sharded x{world} ({'torch.distributed backend ' + dist.get_backend() + ' = RCCL, world_size ' + str(dist.get_world_size()) + ', one all_gather of the top-k per timed call' if use_dist else 'one rank, no process group'}), index+model replicated; " + ("decodes of the next two batches enqueued ahead of this batch's rescoring / aggregation; a batch's rescoring forward (library GEMMs) runs beside the next batch's decode steps (hand-written GEMMs only) behind a fence at that decode's library-GEMM prefix, the aggregation overlaps both on the index's stream" if not args.no_overlap else "one batch after the other"), "model_arithmetic": "bf16 storage, fp32 accumulation (BASELINE configs[4])" if stress else "fp32 (as the reference runs BART); linear layers of >= 0.9 GFLOP as one fp16 GEMM over three planes with fp32 accumulation (seal_amd/split_gemm.py; every product of a decode step in sealnn_hgemm_nt), scores within 1e-4 of HF's fp32 forward",
                    "decodes": "body + title of a batch as two loops" if args.no_joint_decode else "body + title of a batch as ONE loop (2 x batch x beams rows per model step, one constraint launch per step)",
                    "query_ngram_keys": "off" if args.no_query_keys else "token 1..3-grams of the query ids (add_query_to_keys=True, the reference's default; "
                                                                                  "spaCy/BART tokenizer absent offline: seal_amd.query_keys.token_ngram_keys)",
@@ -1428,7 +1428,7 @@ def main():
                   "peak_host_rss_gib_per_rank_max": round(peak_rss_gib, 2),
                   "timed_region_instrumentation": "none: probe counters and constraint-call event pairs are off during warm-up and the timed call; "
                                                   "roofline figures come from separate un-overlapped passes after it",
-                  "decode_step_gemm_algorithms": "library default (hipBLASLt heuristic); round 3's TunableOp picks are gone: one of them stalled the search (DESIGN.md 9)",
+                  "decode_step_gemm_algorithms": "sealnn_hgemm_nt for every product of a decode step (split_gemm.HAND_CONFIGS); the library's default picks (hipBLASLt heuristic) for the encoder, the first step and the rescoring forward",
                   "phase_ms_one_batch": {k: round(v, 2) for k, v in phases.items()},
                   "k_constrain_ms_one_batch": round(k2.value, 3), "k_constrain_blocks_one_batch": int(p2.value),
                   "prefix_tables": _prefix_table_stats(index), **({"same_box_ab_qps": ab} if ab else {})},

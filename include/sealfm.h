@@ -51,6 +51,9 @@ enum {
 const char *fmi_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 uint32_t fmi_abi_version(void);
+/* sha256 (64 hex digits) of the sources, headers and compiler flags this binary was built from; seal_amd/_lib.py refuses a library whose digest
+ * is not that of the sources beside it (the binary is git-ignored and travels with snapshots of the tree) */
+const char *fmi_source_digest(void);
 
 /* ---- lifecycle / construction ------------------------------------------- */
 

@@ -47,6 +47,7 @@ def last_constraint_bits(handle, device):
 SIGNATURES = {
     "fmi_last_error": (ctypes.c_char_p, []),
     "fmi_abi_version": (ctypes.c_uint32, []),
+    "fmi_source_digest": (ctypes.c_char_p, []),
     "fmi_create": (_int, [ctypes.POINTER(_vp)]),
     "fmi_free": (None, [_vp]),
     "fmi_view_create": (_int, [_vp, ctypes.POINTER(_vp)]),
@@ -183,13 +184,17 @@ def lib():
         if _build.stale() and os.environ.get("SEALFM_ALLOW_STALE_LIB") != "1":
             # a binary built from other sources than the ones present (it is git-ignored and travels with snapshots): never run it silently
             raise ImportError(
-                f"{_build.LIB} was built from other sources (stamp {_build.built_digest()[:16] or 'missing'}, sources "
+                f"{_build.LIB} was built from other sources (its digest {_build.built_digest()[:16] or 'missing'}, sources "
                 f"{_build.source_digest()[:16]}): rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
         L = ctypes.CDLL(_build.LIB)
         for name, (res, args) in list(SIGNATURES.items()) + list(NN_SIGNATURES.items()):
             fn = getattr(L, name)   # AttributeError here = ABI drift, fail loudly
             fn.restype = res
             fn.argtypes = args
+        # the digest the LOADED library reports about itself (the check above read the file; this is the mapped image)
+        inside = (L.fmi_source_digest() or b"").decode("ascii", "replace")
+        if inside != _build.source_digest() and os.environ.get("SEALFM_ALLOW_STALE_LIB") != "1":
+            raise ImportError(f"{_build.LIB}: fmi_source_digest() = {inside[:16]}, the sources present are {_build.source_digest()[:16]}: rebuild")
         _lib = L
     return _lib
 

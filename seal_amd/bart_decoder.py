@@ -30,8 +30,8 @@ import logging
 
 
 logger = logging.getLogger(__name__)
-# the encoder's linear layers through the split GEMM as well (SEAL_ENCODER_SPLIT=0: HF's own encoder layers, fp32 library GEMMs)
-ENCODER_SPLIT = __import__("os").environ.get("SEAL_ENCODER_SPLIT", "1") == "1"
+# the encoder's linear layers through the split GEMM as well (False: HF's own encoder layers, fp32 library GEMMs; the tests flip it)
+ENCODER_SPLIT = True
 
 class BartStepDecoder:
     def __init__(self, model):
@@ -421,7 +421,7 @@ class BartStepDecoder:
     def tree_hidden_graph(self, tok, depth, anc, qidx, enc_hidden, attention_mask):
         """``tree_logits(..., hidden_only=True)`` through the fused kernels as ONE hipGraph replay (the forward over a prefix tree
         is ~160 launches that the host would otherwise issue one by one, 10 ms per batch of the searcher).  On by default since
-        round 4 (``SEAL_RESCORE_GRAPH=0``: launch by launch): with the split GEMM the search is bound by its one python thread,
+        round 4 (``keys.RESCORE_GRAPH = False``: launch by launch): with the split GEMM the search is bound by its one python thread,
         and the launches saved are worth more than the padded nodes cost -- 217 -> 236 queries/s (profiles/r4_soak_ab.txt; round 3,
         GPU-bound on fp32 GEMMs, measured the opposite: 256 -> 247).
         Shapes are made static: the node count is rounded up to ``TREE_NODE_BUCKET`` (the rows behind the real nodes keep whatever
@@ -434,10 +434,8 @@ class BartStepDecoder:
         A = anc.shape[1]
         if not (self.use_graph and enc_hidden.is_cuda and self.can_teacher_force(enc_hidden, A) and N > 0):
             return None
-        bucket = max(64, int(os.environ.get("SEAL_TREE_NODE_BUCKET", self.TREE_NODE_BUCKET)))
+        bucket = max(64, int(self.TREE_NODE_BUCKET))
         Np = (N + bucket - 1) // bucket * bucket
-        if os.environ.get("SEAL_RESCORE_SHAPES"):           # (measurement: how many of a replay's rows are padding)
-            print("[rescore] tree of %d nodes in a graph of %d rows, %d queries, encoder length %d" % (N, Np, Bq, S), file=sys.stderr, flush=True)
         Sp = max(16, (S + 15) // 16 * 16)
         if Sp > 64:
             return None
@@ -602,11 +600,11 @@ class BartStepDecoder:
     # position 0 of the cache is written for the first beam's row only and the ancestry table points the other beams at it,
     # and the logits row is handed to all K beams.  Self-attention over the single position 0 is softmax([s]) = [1]:
     # the output is V itself, as sealnn_self_attn_step computes it (1.0 * v / 1.0).
-    # ON by default since round 4 (SEAL_SHARED_FIRST_STEP=0: the full-width first step).  Round 3 kept it off because bench.py stalled
+    # ON by default since round 4 (``shared_first_step = False``: the full-width first step).  Round 3 kept it off because bench.py stalled
     # with it on; the stall was never this path's -- it was two library GEMM streams in flight at once (a TunableOp pick of the lm_head
     # GEMM then), which the searcher no longer allows.  Clean in every soak run of round 4
     # (profiles/r4_soak_*.txt), +2..6 % queries/s.
-    shared_first_step = __import__("os").environ.get("SEAL_SHARED_FIRST_STEP", "1") == "1"
+    shared_first_step = True
 
     def _step_static_first(self, st):
         from ._lib import check

@@ -131,9 +131,9 @@ class IndexBasedLogitsProcessor:
         return out if out.dtype == scores.dtype else out.to(scores.dtype)
 
 
-# the beam loop's bookkeeping between two model steps as ONE library call (fmi_dev_beam_step: _BeamStepper); SEAL_FUSED_BEAM_STEP=0 keeps
+# the beam loop's bookkeeping between two model steps as ONE library call (fmi_dev_beam_step: _BeamStepper); ``FUSED_BEAM_STEP = False`` keeps
 # round 4's form (fmi_dev_constrained_topk_groups + ~15 torch launches per step): same histories, the GPU tests run both
-FUSED_BEAM_STEP = __import__("os").environ.get("SEAL_FUSED_BEAM_STEP", "1") == "1"
+FUSED_BEAM_STEP = True
 MAX_FORCE = 8          # tokens of force_decoding_from the constraint kernel takes (fmi_kernels.hip)
 MAX_ROW_GROUPS = 3     # decodes one constraint call can serve in lockstep (fmi_kernels.hip)
 

@@ -33,25 +33,10 @@ uint32_t fmi_sb_shift_for(uint64_t n)
 }
 extern "C" uint32_t fmi_abi_version(void) { return 1; }
 
-// ---- launch-shape switches: the environment is read here, once per handle (fmi_internal.h) ----
-static int64_t env_i64(const char *name, int64_t dflt)
-{
-    const char *e = getenv(name);
-    return (e && *e) ? (int64_t)atoll(e) : dflt;
-}
-
-FmiOptions::FmiOptions()
-{
-    constrain_waves = env_i64("SEALFM_CONSTRAIN_WAVES", constrain_waves);
-    leave_early = env_i64("SEALFM_LEAVE_EARLY", leave_early);
-    row_first = env_i64("SEALFM_ROW_FIRST", row_first);
-    row_first_from = env_i64("SEALFM_ROW_FIRST_FROM", row_first_from);
-    prefix_tables = env_i64("SEALFM_PREFIX_TABLES", prefix_tables);
-    table_grid = env_i64("SEALFM_TABLE_GRID", table_grid);
-    topk_narrow = env_i64("SEALFM_TOPK_NARROW", topk_narrow);
-    topk_legacy = env_i64("SEALFM_TOPK_LEGACY", topk_legacy);
-    chain_steps = env_i64("SEALFM_CHAIN_STEPS", chain_steps);
-}
+// ---- launch-shape options (fmi_internal.h): built-in choices; fmi_dev_set_option changes one on a handle (tests, tools).  Round 6: the nine
+// SEALFM_* environment variables that used to seed them are gone -- every alternative they selected is either a test of a kernel path
+// (set through fmi_dev_set_option) or lost its A/B (profiles/ keeps the records) ----
+FmiOptions::FmiOptions() {}
 
 int FmiOptions::set(const char *name, int64_t value)
 {

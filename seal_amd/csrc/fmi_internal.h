@@ -60,19 +60,19 @@ struct FmiDev {
 };
 static constexpr uint32_t FMI_DOC_HINT_SHIFT = 7;
 
-// Launch-shape switches of the fmi_dev_* constraint / top-2K calls (A/B measurements, tests of every kernel path).  Read from the
-// environment ONCE, when the handle is created -- not per launch on a 40 us path -- and changed afterwards with
-// fmi_dev_set_option(h, name, value); -1 = the built-in choice.
+// Launch-shape options of the fmi_dev_* constraint / top-2K / aggregation calls: the built-in choice of each, changed per handle with
+// fmi_dev_set_option(h, name, value) (-1 = back to the built-in choice) -- how the GPU tests run every kernel path on the same index and how
+// tools/ compares two forms on one box.  Not read from the environment (round 6).
 struct FmiOptions {
-    int64_t constrain_waves = -1;   // SEALFM_CONSTRAIN_WAVES=1: one self-contained wave per (row, top digit) instead of workgroups of 8 waves
-    int64_t leave_early = 1;        // SEALFM_LEAVE_EARLY=0: the waves of empty items stay in their workgroup
-    int64_t row_first = -1;         // SEALFM_ROW_FIRST=0 / 1: never / always the row-first pair of launches (default: by prefix length)
-    int64_t row_first_from = -1;    // SEALFM_ROW_FIRST_FROM=<tokens>: prefix length from which a call goes row-first (default 3; 2 from 512 rows on)
-    int64_t prefix_tables = 1;      // SEALFM_PREFIX_TABLES=0: the first constrained step of a decode through the generic expansion
-    int64_t table_grid = -1;        // SEALFM_TABLE_GRID=<n>: workgroups of k_constrain_table (default 1024: one resident round)
-    int64_t topk_narrow = -1;       // SEALFM_TOPK_NARROW=<n>: rows of more than n allowed tokens take the wide-row path of k_row_pick
-    int64_t topk_legacy = 0;        // SEALFM_TOPK_LEGACY=1: wide rows skip the thread-maxima bound (exact radix select)
-    int64_t chain_steps = 1;        // SEALFM_CHAIN_STEPS=0: fmi_dev_beam_step leaves the rows' chains to the next call (k_constrain_rows) instead of k_beam_advance
+    int64_t constrain_waves = -1;   // 1: one self-contained wave per (row, top digit) instead of workgroups of 8 waves (any alphabet depth takes this form)
+    int64_t leave_early = 1;        // 0: the waves of empty items stay in their workgroup
+    int64_t row_first = -1;         // 0 / 1: never / always the row-first pair of launches (default: by prefix length)
+    int64_t row_first_from = -1;    // prefix length from which a call goes row-first (default 3; 2 from 512 rows on)
+    int64_t prefix_tables = 1;      // 0: the first constrained step of a decode through the generic expansion
+    int64_t table_grid = -1;        // workgroups of k_constrain_table (default 1024: one resident round)
+    int64_t topk_narrow = -1;       // rows of more than this many allowed tokens take the wide-row path of k_row_pick (default 1024)
+    int64_t topk_legacy = 0;        // 1: wide rows skip the thread-maxima bound (the exact radix select: the tests' third path)
+    int64_t chain_steps = 1;        // 0: fmi_dev_beam_step leaves the rows' chains to the next call (k_constrain_rows) instead of k_beam_advance
     int64_t advance_apart = 1;      // measurement passes: k_beam_advance as two launches (bookkeeping, chains); 0: the product's one launch, timed whole
     int64_t agg_rank_by_sorts = 0;  // tests: fmi_dev_aggregate ranks the first stage 1: with the three full stable sorts of rounds 2-5 (the checker of the selection), 2: with the single-workgroup selection (k_select_top)
     int64_t pt_inject_failure = 0;  // tests: building a prefix table fails after its first allocation (the call must take the generic path)

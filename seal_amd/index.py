@@ -266,13 +266,13 @@ class FMIndex(_FMIndex):
         import torch
         if self.__dict__.get("_is_view"):
             return torch.cuda.current_stream(dev)
-        # a HIGH-PRIORITY stream (SEAL_INDEX_STREAM_PRIORITY, default -1).  Not for the priority itself: HIP maps streams onto a few
+        # a HIGH-PRIORITY stream.  Not for the priority itself: HIP maps streams onto a few
         # hardware queues per priority level, round robin, and at the default priority this stream has shared its hardware queue with
         # the searcher's rescoring stream (rocprofv3: stream 10 and stream 1 both on queue 2) -- the index kernels then ran in the
         # rescoring's queue order, behind its event waits.  Streams of another priority level get queues of their own
         # (tools/stream_overlap_probe.py, profiles/r5_stream_overlap_probe.txt: a side chain beside graph replays ends after 4.6 ms on a
         # high-priority stream, after the 35 ms of replays on a default-priority one that landed on the replays' queue).
-        prio = int(os.environ.get("SEAL_INDEX_STREAM_PRIORITY", "-1"))
+        prio = -1
         st = self.__dict__.get("_svc_stream")
         if st is None or self.__dict__.get("_svc_stream_priority") != prio:
             st = self.__dict__["_svc_stream"] = torch.cuda.Stream(device=dev, priority=prio)

@@ -27,6 +27,14 @@ import numpy as np
 import torch
 
 
+# Rescoring forms.  Module attributes, not environment switches (round 6): the tests flip them to run the other path.
+RESCORE_TREE = True        # teacher forcing over the prefix TREE of a query's keys (every distinct prefix one decoder position); False: one row per maximal parent
+RESCORE_GRAPH = True       # the tree forward as one hipGraph replay (BartStepDecoder.tree_hidden_graph)
+RESCORE_CHUNK_ROWS = 256   # rows per forward of the maximal-parent form
+RESCORE_MAX_NODES = 48000  # nodes of one forest (a searcher batch's rescorings are ONE forward up to here)
+RESCORE_LM_HEAD_SLICE = 4096   # nodes per slice of the output projection (the logits of all nodes never exist at once)
+AGG_TIMING = False         # tools: aggregate_evidence_batch prints where its host time goes
+
 def deduplicate(list_of_lists):
     """First occurrence wins; elements are token lists or (score, tokens) pairs
     (reference keys.py:19-35)."""
@@ -83,14 +91,14 @@ def rescore_keys(model, inputs, list_of_decoded, batch_size=100, length_penalty=
     search tree -- most are prefixes or siblings of one another -- and the decoder is
     causal, so the distribution after ``key[:j]`` is the same in every key that starts
     with it.  Every DISTINCT prefix is run through the model once, as one decoder
-    position that attends its ancestors (``_rescore_keys_tree``; ``SEAL_RESCORE_TREE=0``:
+    position that attends its ancestors (``_rescore_keys_tree``; ``keys.RESCORE_TREE = False``:
     one row per maximal key, every other key reading its score off the row's cumulative
     sums, ``_rescore_keys_shared``).  Same numbers as scoring each key separately (up to
     fp32 summation order), ~20x / ~6x fewer decoder positions.  ``share_prefixes=False``
     is the reference's one-row-per-key batching."""
     if share_prefixes:
-        # the prefix tree (every distinct prefix ONE decoder position); SEAL_RESCORE_TREE=0: maximal parents as rows
-        fn = _rescore_keys_shared if os.environ.get("SEAL_RESCORE_TREE") == "0" else _rescore_keys_tree
+        # the prefix tree (every distinct prefix ONE decoder position); RESCORE_TREE = False: maximal parents as rows
+        fn = _rescore_keys_tree if RESCORE_TREE else _rescore_keys_shared
         job = fn(model, inputs, list_of_decoded, batch_size, length_penalty, prefix, strip_from_bos, strip_from_eos, logit_bias, encoded)
         # ``pending``: everything is enqueued and nothing has waited for the GPU; ``job.result()`` reads the scores back
         # (the searcher enqueues the three rescorings of a batch back to back and reads them back afterwards)
@@ -179,7 +187,7 @@ def _rescore_keys_shared(model, inputs, list_of_decoded, batch_size, length_pena
     # keys grouped by the chunk of their owner row
     # rows per forward: few, large launches (an eager F.linear costs the host ~19 us whatever its size, and a batch of
     # queries has a few hundred maximal parents); the logits of a chunk are rows x T x vocab floats -- 0.57 GB at 256 rows x 11 positions; 1024 rows measured no faster: more padding
-    chunk_rows = max(batch_size, int(os.environ.get("SEAL_RESCORE_CHUNK", 256)))
+    chunk_rows = max(batch_size, RESCORE_CHUNK_ROWS)
     per_chunk = {}
     for qi, ss in enumerate(seqs):
         for ki, sq in enumerate(ss):
@@ -287,7 +295,7 @@ def rescore_keys_multi(jobs, pending=False):
     n-grams / titles of a batch: 3 x ~500 launches and three under-filled sets of GEMMs become one); each job's scores are
     what its own ``rescore_keys`` call returns."""
     out = [None] * len(jobs)
-    if os.environ.get("SEAL_RESCORE_TREE") == "0":                  # the maximal-parent rows, job by job (A/B, tests)
+    if not RESCORE_TREE:                  # the maximal-parent rows, job by job (A/B, tests)
         out = [rescore_keys(job[0], job[1], job[2], pending=True, **job[3]) for job in jobs]
         return out if pending else [r.result() for r in out]
     by_model = {}
@@ -360,11 +368,11 @@ def _rescore_tree_jobs(model, jobs):
     # cap of 12 000 cut a searcher batch (20 queries x 3 jobs, ~3 300 nodes) into forests of ~2 000 + 700 + 650 nodes = graphs of 2 048 +
     # 1 024 + 1 024 rows, three forwards of launch-bound height.  One forest of 4 096 rows is the same padded rows in a third of the
     # launches at twice the GEMM efficiency: 332 -> 367 queries/s on one box (profiles/r5_rescore_one_forest_ab.txt).
-    cap = int(os.environ.get("SEAL_RESCORE_NODES", 48000))
+    cap = RESCORE_MAX_NODES
     max_len = max((len(sq) for j in J for ss in j["seqs"] for sq in ss), default=0)
     prepared = None
     fused_ok = enc.is_cuda and max_len > 0 and sd.can_teacher_force(enc, max_len)
-    use_graph = fused_ok and os.environ.get("SEAL_RESCORE_GRAPH", "1") == "1"      # (on by default: see BartStepDecoder.tree_hidden_graph)
+    use_graph = fused_ok and RESCORE_GRAPH      # (on by default: see BartStepDecoder.tree_hidden_graph)
     units = [(ji, qi) for ji, j in enumerate(J) for qi in range(len(j["seqs"]))]          # job-major: a job's keys stay contiguous
     groups, cur, cur_n = [], [], 0
     for ji, qi in units:
@@ -398,7 +406,7 @@ def _rescore_tree_jobs(model, jobs):
         t = _h2d(np.stack([t_node, tree["term_tok"][order], tree["term_key"][order], tree["term_col"][order]]), device)
         table = torch.zeros(len(items), tree["width"], dtype=torch.float64, device=device)
         n_nodes = hidden.shape[0]
-        step = max(256, int(os.environ.get("SEAL_RESCORE_SLICE", 4096)))
+        step = max(256, RESCORE_LM_HEAD_SLICE)
         for a in range(0, n_nodes, step):
             b = min(n_nodes, a + step)
             ta, tb = int(np.searchsorted(t_node, a, side="left")), int(np.searchsorted(t_node, b, side="left"))
@@ -907,7 +915,7 @@ def aggregate_evidence_batch(jobs, index, **params):
     import os, time, sys
     if params.pop("two_phase", False):
         use_gpu = params.get("gpu_aggregate", True)
-        if (use_gpu and not params.get("python_scoring", os.environ.get("SEAL_PYTHON_SCORING") == "1")
+        if (use_gpu and not params.get("python_scoring", False)
                 and gpu_aggregation_applies(index, {k: v for k, v in params.items() if k not in ("gpu_aggregate", "want_ngrams", "python_scoring")})):
             from .gpu_aggregate import score_and_aggregate_on_gpu
             rest = {k: v for k, v in params.items() if k not in ("gpu_aggregate", "want_ngrams", "python_scoring")}
@@ -928,8 +936,8 @@ def aggregate_evidence_batch(jobs, index, **params):
         return lambda: aggregate_evidence_batch(jobs, index, **params)
     use_gpu = params.pop("gpu_aggregate", True)          # False: the host routines (fmi_first_stage / fmi_full_score) for every query
     want_ngrams = params.pop("want_ngrams", True)        # False: the caller ignores `all_ngrams` (the searcher does)
-    python_scoring = params.pop("python_scoring", os.environ.get("SEAL_PYTHON_SCORING") == "1")
-    _tm = os.environ.get("SEAL_AGG_TIMING")
+    python_scoring = params.pop("python_scoring", False)
+    _tm = AGG_TIMING
     _t = {"t0": time.perf_counter()}
     def _mark(name):
         if _tm:

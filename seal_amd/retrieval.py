@@ -635,6 +635,7 @@ class SEALSearcher:
         # the decode and the rescoring phase (the two that run library GEMMs) ALTERNATE on the GPU instead of sharing it: two stream-K
         # GEMM streams in flight at once stalled the GPU for ever.  False restores round 3's behaviour.
         self.exclusive_gemm_streams: bool = bool(params.get("exclusive_gemm_streams", True))
+        self.i_know_two_gemm_streams_can_stall: bool = bool(params.get("i_know_two_gemm_streams_can_stall", False))
         # ... where "the decode" means the part of it that runs library GEMMs: its model steps do not (round 6: every product of a step is the
         # hand-written kernel), so a batch's rescoring runs BESIDE the next batch's decode steps.  False: rescoring after the whole decode (round 5).
         self.rescore_beside_decode: bool = bool(params.get("rescore_beside_decode", True))
@@ -839,23 +840,22 @@ class SEALSearcher:
         # overlaps both on the index's own stream.  The host keeps one more batch of decodes enqueued ahead (depth 2), so that the GPU
         # has the next decode queued while the host waits for a batch's scores: throughput is bound by the host loop or by
         # decode + rescoring, whichever is longer, as before.
-        exclusive = bool(getattr(self, "exclusive_gemm_streams", True)) and os.environ.get("SEAL_EXCLUSIVE_GEMM_STREAMS", "1") != "0"
+        exclusive = bool(getattr(self, "exclusive_gemm_streams", True))
         if not exclusive:
             # two library-GEMM streams at once is the configuration that stalled the GPU for ever: it is for
             # reproducing that stall (tools/soak.py), never something a caller gets by flipping one switch
-            if os.environ.get("SEAL_I_KNOW_TWO_GEMM_STREAMS_CAN_STALL") != "1":
-                raise RuntimeError("exclusive_gemm_streams=False / SEAL_EXCLUSIVE_GEMM_STREAMS=0 lets the decode and the rescoring forward run "
-                                   "hipBLASLt stream-K GEMMs on two streams at once, which has stalled the GPU for ever (DESIGN.md section 9); "
-                                   "set SEAL_I_KNOW_TWO_GEMM_STREAMS_CAN_STALL=1 to do it anyway")
+            if not getattr(self, "i_know_two_gemm_streams_can_stall", False):
+                raise RuntimeError("exclusive_gemm_streams=False lets the decode and the rescoring forward run hipBLASLt stream-K GEMMs on two "
+                                   "streams at once, which has stalled the GPU for ever (DESIGN.md section 9); pass "
+                                   "i_know_two_gemm_streams_can_stall=True as well to do it anyway")
             if not self.__dict__.get("_warned_two_gemm_streams"):
                 self.__dict__["_warned_two_gemm_streams"] = True
                 print("[seal_amd] WARNING: decode and rescoring share the GPU (two library-GEMM streams): this configuration can stall",
                       file=sys.stderr, flush=True)
-        depth = max(1, int(os.environ.get("SEAL_OVERLAP_DEPTH", self.overlap_depth if exclusive else 1)))
+        depth = max(1, int(self.overlap_depth if exclusive else 1))
         # What the host does between "the scores of batch i are back" and "the rescoring of batch i+1 is enqueued" decides whether the GPU
-        # runs dry after decode(i+2) (see the loop).  2 (default) = interleaved: the aggregation's launches, the rescoring, the aggregation's
-        # read-back; 0 = the whole aggregation first (round 4); 1 = the rescoring first.  (bench.py SEAL_BENCH_AB compares them on one box.)
-        ahead_mode = os.environ.get("SEAL_RESCORE_AHEAD", "2")
+        # runs dry after decode(i+2) (see the loop): interleaved -- the aggregation's launches, the rescoring enqueue, the aggregation's
+        # read-back.  (The whole aggregation first, round 4's order, and the rescoring first lost on one box: profiles/r5_rescore_ahead_ab.txt.)
         ahead = []                                            # generators whose decodes are enqueued, oldest first
         nxt_i = 0
         main = torch.cuda.current_stream(dev)
@@ -886,7 +886,7 @@ class SEALSearcher:
         # which the GPU drains: 380 -> 398 queries/s (profiles/r6_overlap_timeline.txt).  The two phases SHARE the chip rather than hide in each
         # other: beside the rescoring's chip-filling GEMMs a decode takes 48 ms instead of 38.5 and the rescoring 20 instead of 10.9 (a decode
         # kernel's few hundred workgroups wait for compute units the rescoring's hold); a high-priority decode stream changed nothing.
-        # A decoder whose steps are not library-free (bf16 storage, SEAL_HAND_GEMM=0, other geometries) never calls back: the fence then sits
+        # A decoder whose steps are not library-free (bf16 storage, split_gemm.HAND_GEMM off, other geometries) never calls back: the fence then sits
         # behind the whole decode, as in round 5.
         overlap_steps = exclusive and bool(getattr(self, "rescore_beside_decode", True))
 
@@ -977,7 +977,7 @@ class SEALSearcher:
         # the aggregation's own launches (key counts, locate, evidence kernels) and the host's waits for them: the index's retrieval stream,
         # NOT the post stream -- a count read-back there would queue behind the next batch's rescoring forward (round 5)
         # (high priority, as the index's own stream: index.py _side_stream)
-        prio = int(os.environ.get("SEAL_INDEX_STREAM_PRIORITY", "-1"))
+        prio = -1
         agg_stream = self.__dict__.get("_agg_stream")
         if agg_stream is None or agg_stream.device != dev or self.__dict__.get("_agg_stream_priority") != prio:
             agg_stream = self.__dict__["_agg_stream"] = torch.cuda.Stream(device=dev, priority=prio)
@@ -1015,7 +1015,7 @@ class SEALSearcher:
             if held is not None:
                 yield from held
                 held = None
-            interleave = exclusive and bool(ahead) and ahead_mode == "2"
+            interleave = exclusive and bool(ahead)
             if interleave:
                 # the host is about to wait for this batch's scores (the GPU is in its rescoring): the time for the NEXT batch's filters -- its
                 # decode finished before this rescoring began, so its hypotheses are there; nothing of it needs the busy streams
@@ -1047,8 +1047,6 @@ class SEALSearcher:
             # host half and its launches first (kernels beside the decode), the rescoring enqueue while they run, then the read-back; and
             # the filters of batch i+1 (no GEMM) have moved in front of the wait for the scores above.
             jobs = [(kk[0], kk[1]) if isinstance(kk, tuple) else (kk, None) for kk in keys]
-            if exclusive and ahead and ahead_mode == "1":
-                to_rescoring(ahead[0])
             if tm == "2":
                 self.fm_index.__dict__["_agg_mark"] = mark
             try:
@@ -1120,11 +1118,7 @@ class SEALSearcher:
             import multiprocessing
             import os
             from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
-            if os.environ.get("SEAL_HOST_WORKERS", "process") == "thread":
-                # the native routines release the GIL: threads avoid pickling the documents
-                pool = ThreadPoolExecutor(max_workers=int(self.jobs))
-            else:
-                pool = ProcessPoolExecutor(max_workers=int(self.jobs), mp_context=multiprocessing.get_context("spawn"))
+            pool = ProcessPoolExecutor(max_workers=int(self.jobs), mp_context=multiprocessing.get_context("spawn"))
             self.__dict__["_pool"] = pool
         return pool
 
@@ -1191,7 +1185,7 @@ class SEALSearcher:
             yield from rk.aggregate_evidence_batch(jobs, self.fm_index, defer=defer, keep=keep, gpu_aggregate=self.gpu_aggregate,
                                                    want_ngrams=False, **params)
         import os, sys, time
-        tm = os.environ.get("SEAL_AGG_TIMING")
+        tm = rk.AGG_TIMING
         t_end = time.perf_counter()
         for fut in pending:
             t0 = time.perf_counter()

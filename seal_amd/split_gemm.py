@@ -149,8 +149,8 @@ class Deferred:
 # The hand-written fp16 product (sealnn_hgemm_nt, seal_amd/csrc/hgemm_kernels.hip) for the decode step's skinny products whose consumer can add
 # split-K slabs as it reads them (sealnn_add_layernorm_acc_slabs): measured on an MI355X (profiles/r5_hgemm_probe.txt, us per call, library ->
 # hand-written with 4 slabs): fc2 [rows, 3 x 4096] x [1024]: 600 rows 43.2 -> 32.2, 300 rows 31.5 -> 21.3.  (N, K') -> {max rows: config};
-# config = tile | stages << 8 | K groups << 12 | slices << 16 (sealnn.h).  SEAL_HAND_GEMM=0: the library for everything.
-HAND_GEMM = os.environ.get("SEAL_HAND_GEMM", "1") == "1"
+# config = tile | stages << 8 | K groups << 12 | slices << 16 (sealnn.h).  ``HAND_GEMM = False``: the library for everything.
+HAND_GEMM = True
 # Round 6: EVERY product of a decode step (fused path, fp32, 129 .. 640 rows) runs in the hand-written kernel -- also the three that round 5 left to
 # the library (profiles/r6_hgemm_probe_decode.txt, us, library -> hand): qkv at 600 rows 23.8 -> 19.5; fc1 25.2 -> 27.9 (600), 18.3 -> 18.5 (300);
 # lm_head 237.9 -> 229.6 (600), 126.4 -> 157.7 (300) with the row tile as the fastest grid index and the workgroups grouped by XCD (tile + 128:

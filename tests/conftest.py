@@ -13,7 +13,7 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """the library under test is the one built from the sources present: rebuild it (hipcc cross-compiles without a GPU) when its stamp
+    """the library under test is the one built from the sources present: rebuild it (hipcc cross-compiles without a GPU) when the digest inside it
     says otherwise, instead of testing a stale git-ignored binary that travelled with a snapshot"""
     from seal_amd import _build
     if _build.stale():

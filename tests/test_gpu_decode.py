@@ -148,7 +148,7 @@ def test_first_step_shared_by_the_beams_of_a_query(dtype):
     enc_ids[1, 6:] = 1
     bias = torch.randn(B, vocab, generator=g).to(dev)
     dec = BartStepDecoder(run)
-    assert dec.shared_first_step is True             # the default (SEAL_SHARED_FIRST_STEP=0 turns it off)
+    assert dec.shared_first_step is True             # the default (a class attribute of BartStepDecoder)
     for rep in range(2):
         enc = dec.encode(enc_ids, enc_mask)
         dec.start(enc, enc_mask, K, T, narrow_plan=(2,))
@@ -196,7 +196,6 @@ def test_fused_constrained_topk_matches_unfused_step(kw, narrow, monkeypatch):
     """fmi_dev_constrained_topk against the reference's own sequence of ops on the same logits: same picks (as a set
     per query: ties/-inf fillers are unordered in torch.topk too), unconstrained scores within fp32 noise.
     Both ends of k_row_pick: rows of <= 1024 allowed tokens gathered from the bitmap, and the wide-row path."""
-    monkeypatch.setenv("SEALFM_TOPK_NARROW", narrow)
     from seal_amd import FMIndex
     from seal_amd.beam_search import IndexBasedLogitsProcessor, _inf_nan_remove
     from tests.helpers import kernel_options, make_docs
@@ -205,6 +204,8 @@ def test_fused_constrained_topk_matches_unfused_step(kw, narrow, monkeypatch):
     docs = make_docs(3, 150, vocab - 8, title_sep=7)
     ix = FMIndex()
     ix.initialize(docs)
+    from seal_amd._lib import check, lib
+    check(lib().fmi_dev_set_option(ix.handle, b"topk_narrow", int(narrow)))      # (the index is this test's own: nothing to restore)
     eos = kw.get("eos_token_id", 2)
     proc = IndexBasedLogitsProcessor(ix, K, pad_token_id=1, eos_token_id=eos, force_decoding_from=kw.get("force_decoding_from"),
                                      stop_at_count=kw.get("stop_at_count", 0), always_allow_eos=kw.get("always_allow_eos", False))
@@ -256,7 +257,8 @@ def test_rescore_keys_tree_shared_teacher_forcing_matches_one_hf_row_per_key(geo
     from tests.helpers import tiny_bart
     dev = torch.device("cuda:0")
     m = tiny_bart(120, **geom).to(dev)
-    monkeypatch.setenv("SEAL_RESCORE_TREE", tree)
+    from seal_amd import keys as keys_mod
+    monkeypatch.setattr(keys_mod, "RESCORE_TREE", tree == "1")
     fused_calls = []
     real, real_tree, real_graph = BartStepDecoder.teacher_logits, BartStepDecoder.tree_logits, BartStepDecoder.tree_hidden_graph
     monkeypatch.setattr(BartStepDecoder, "teacher_logits", lambda self, *a: (fused_calls.append(1), real(self, *a))[1])
@@ -776,9 +778,10 @@ def test_joint_generate_through_the_fused_decoder_matches_separate_generates():
 @pytest.mark.gpu
 def test_graph_replayed_tree_forward_equals_the_launch_by_launch_forward(monkeypatch):
     """``rescore_keys`` with the prefix-tree forward as ONE hipGraph replay (node count padded to a bucket, stale rows behind the
-    real nodes, encoder length padded) against the same forward issued launch by launch (``SEAL_RESCORE_GRAPH=0``): the same
+    real nodes, encoder length padded) against the same forward issued launch by launch (``keys.RESCORE_GRAPH = False``): the same
     scores up to the rounding of GEMMs of another height (<= 1e-5), call after call with different key sets in the same bucket"""
     import numpy as np
+    from seal_amd import keys as keys_mod
     from seal_amd.keys import rescore_keys
     from tests.helpers import tiny_bart
     dev = torch.device("cuda:0")
@@ -792,9 +795,9 @@ def test_graph_replayed_tree_forward_equals_the_launch_by_launch_forward(monkeyp
             kk = [base[:i] for i in range(1, len(base) + 1)] + [rng.integers(4, 118, size=int(rng.integers(1, 6))).tolist() for _ in range(20 - 5 * rep)]
             keys.append([(-1.0, k) for k in kk])
         bias = torch.randn(4, 120, device=dev)
-        monkeypatch.setenv("SEAL_RESCORE_GRAPH", "1")
+        monkeypatch.setattr(keys_mod, "RESCORE_GRAPH", True)
         a = rescore_keys(m, inputs, keys, logit_bias=bias)
-        monkeypatch.setenv("SEAL_RESCORE_GRAPH", "0")
+        monkeypatch.setattr(keys_mod, "RESCORE_GRAPH", False)
         b = rescore_keys(m, inputs, keys, logit_bias=bias)
         for qa, qb in zip(a, b):
             assert [k for _, k in qa] == [k for _, k in qb]

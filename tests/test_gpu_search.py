@@ -199,10 +199,9 @@ def test_overlapped_batches_give_the_results_of_sequential_batches(geom, monkeyp
         assert s._overlapped() is overlap
         if not exclusive:
             # two library-GEMM streams at once re-arm round 3's stall: refused without the explicit switch (tiny GEMMs here: safe to run)
-            monkeypatch.delenv("SEAL_I_KNOW_TWO_GEMM_STREAMS_CAN_STALL", raising=False)
-            with pytest.raises(RuntimeError, match="SEAL_I_KNOW_TWO_GEMM_STREAMS_CAN_STALL"):
+            with pytest.raises(RuntimeError, match="i_know_two_gemm_streams_can_stall"):
                 s.batch_search(queries, k=10)
-            monkeypatch.setenv("SEAL_I_KNOW_TWO_GEMM_STREAMS_CAN_STALL", "1")
+            s.i_know_two_gemm_streams_can_stall = True
         for rep in range(2):           # the second call reuses the captured graphs and buffers
             res = s.batch_search(queries, k=10)
             out[(depth, overlap, exclusive, rep)] = [[(d.idx, d.score, list(d.raw_tokens()), d.keys) for d in docs_] for docs_ in res]

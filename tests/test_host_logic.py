@@ -28,6 +28,33 @@ def test_library_exports_every_declared_symbol():
     assert nn == set(NN_SIGNATURES) and all(hasattr(L, n) for n in nn)
 
 
+def test_the_library_carries_the_digest_of_its_sources_and_another_one_is_refused(tmp_path, monkeypatch):
+    """the digest of the sources, headers and flags lives INSIDE libsealfm.so (``fmi_source_digest()``): read from the file without loading it
+    (``_build.built_digest``) and from the mapped image at load; a binary built from other sources -- here: the same file with one digit of its
+    digest changed, dropped in place of the real one, no sidecar to forge -- is refused before anything is called in it"""
+    import shutil
+    from seal_amd import _build, _lib
+    want = _build.source_digest()
+    assert len(want) == 64 and _build.built_digest() == want and not _build.stale()
+    assert lib().fmi_source_digest().decode() == want
+    forged = tmp_path / "libsealfm.so"
+    blob = open(_build.LIB, "rb").read()
+    at = blob.find(_build.MARKER) + len(_build.MARKER)
+    assert at > len(_build.MARKER) and blob.count(_build.MARKER) == 1
+    other = b"0" if blob[at:at + 1] != b"0" else b"1"
+    forged.write_bytes(blob[:at] + other + blob[at + 1:])
+    monkeypatch.setattr(_build, "LIB", str(forged))
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.delenv("SEALFM_ALLOW_STALE_LIB", raising=False)
+    _build._digest_cache.clear()
+    try:
+        assert _build.stale() and _build.built_digest() != want
+        with pytest.raises(ImportError, match="built from other sources"):
+            _lib.lib()
+    finally:
+        _build._digest_cache.clear()
+
+
 def _host_index(data):
     h = ctypes.c_void_p()
     check(lib().fmi_create(ctypes.byref(h)))

@@ -63,8 +63,9 @@ def test_rescore_keys_prefix_sharing_matches_row_per_key(tree, monkeypatch):
     per maximal parent -- against the reference's one row per key (keys.py:64-141)"""
     import torch
     from seal_amd.keys import rescore_keys
-    monkeypatch.setenv("SEAL_RESCORE_TREE", tree)
-    monkeypatch.setenv("SEAL_RESCORE_NODES", "20")          # several forwards per call: chunks of whole queries
+    from seal_amd import keys as keys_mod
+    monkeypatch.setattr(keys_mod, "RESCORE_TREE", tree == "1")
+    monkeypatch.setattr(keys_mod, "RESCORE_MAX_NODES", 20)          # several forwards per call: chunks of whole queries
     from tests.helpers import tiny_bart
     m = tiny_bart(120)
     rng = np.random.default_rng(0)

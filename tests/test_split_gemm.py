@@ -376,7 +376,7 @@ def test_hand_written_gemm_against_torch(M, N, K):
 def test_split_k_slabs_are_summed_by_the_kernel_that_reads_them(monkeypatch):
     """the decode step's fc2 product through the hand-written kernel: 4 split-K slabs that ``sealnn_add_layernorm_acc_slabs`` adds in slab
     order as it reads them == ``sealnn_add_layernorm_acc`` on the slabs summed beforehand in the same order, bit for bit (outputs and planes);
-    and the graph-captured step decoder with the hand-written product == the same with the library's (``SEAL_HAND_GEMM`` off) to 1e-5"""
+    and the graph-captured step decoder with the hand-written product == the same with the library's (``split_gemm.HAND_GEMM`` off) to 1e-5"""
     from seal_amd import split_gemm
     from seal_amd._lib import check, lib
     dev = torch.device("cuda:0")
