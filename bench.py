@@ -621,7 +621,7 @@ def merge_call_logs(timed, counted, fused=None):
     return calls, other
 
 
-AGG_STAGES = ["k_agg_locate", "sort_by_position(rocprim)", "coverage(k_mis_prepare+k_mis)", "k_doc_keys+sort_by_document(rocprim)",
+AGG_STAGES = ["k_agg_locate", "sort_by_position(rocprim)", "documents+coverage(k_occ_prepare+k_mis)", "(sort_by_document: gone)",
               "entry_boundaries(k_heads+scan+k_entry_starts)", "k_entries", "ranking(k_sel_minmax+k_sel_hist x2+k_sel_compact+k_sel_final)", "token_tables(memsets+scatters)",
               "k_full_score(ranked documents)", "k_rank_docs", "k_full_score(top-k records)"]
 
@@ -634,7 +634,7 @@ def read_agg_timing(handle):
     return {"stage_ms": list(ms), "counts": list(cnt), "calls": calls.value}
 
 
-def aggregate_roofline(t, index):
+def aggregate_roofline(t, index, workload_tag=None):
     """`roofline_aggregate`: the locate + doc-binning + evidence kernels of ONE un-overlapped batch (north_star: "then locate() + doc-id
     binning for scoring"; reference keys.py:314-350, index.py:77-82), HIP events after every stage of fmi_dev_aggregate.  Algorithmic bytes
     = the arrays a stage must read and write once for the rows / entries / documents it processed (DESIGN.md 5.4 derives each figure)."""
@@ -643,12 +643,14 @@ def aggregate_roofline(t, index):
     rows, entries, docs, kept, doc_tok = t["counts"]
     wide_sa = index.size() > (1 << 32)
     per = {
-        # row -> SA[row] (4 B, +1 B above 2^32 rows) -> doc_hint[pos >> 7] (4 B) -> 0..2 boundaries (8 B each, ~1) ; writes occ_rk 4 + doc 4 + key_pos 8 + val 4
-        "k_agg_locate": rows * ((5 if wide_sa else 4) + 4 + 8 + 20),
-        # k_mis_prepare: sorted_val 4 + occ_rk[val] 4 -> M 2 + state 1; k_mis: E 8 + M 2 + PRI 4 + state 1 -> newflag 1
-        "coverage(k_mis_prepare+k_mis)": rows * (4 + 4 + 2 + 1 + 8 + 2 + 4 + 1 + 1),
-        # per located row KD 8 + ID 4 + occ_rk 4 + newflag 1; per (query, document) entry: nkeys 4 + rank 8 + first 4 + q 4 + doc 4 + score 8 + best 4 + one key (4 + 8)
-        "k_entries": rows * 17 + entries * 48,
+        # row -> SA[row] (4 B, +1 B above 2^32 rows); writes the sort key 8 + the occurrence number 4 + its rare key 4
+        "k_agg_locate": rows * ((5 if wide_sa else 4) + 16),
+        # k_occ_prepare, in position order: key 8 + occurrence number 4 -> rare key 4 + document 4 (sampled table 4 + boundary 8, shared by
+        # neighbours: counted once per row all the same) + window 2 + state 1; k_mis: E 8 + M 2 + PRI 4 + state 1 -> newflag 1
+        "documents+coverage(k_occ_prepare+k_mis)": rows * (8 + 4 + 4 + 4 + 8 + 4 + 4 + 2 + 1 + 8 + 2 + 4 + 1 + 1),
+        # per located row: occurrence number 4 + rare key 4 + newflag 1, read once, written once in processing order, read again (x 3);
+        # per (query, document) entry: key 8 + document 4 + nkeys 4 + rank 8 + first 4 + q 4 + doc 4 + score 8 + best 4 + one key (4 + 8)
+        "k_entries": rows * 27 + entries * 60,
         # the document's tokens from the resident text (2 B each) + its score (8 B); everything else lives in LDS
         "k_full_score(ranked documents)": doc_tok * 2 + docs * 8,
     }
@@ -665,7 +667,7 @@ def aggregate_roofline(t, index):
                 "measured_on": "the un-overlapped batch after the timed region that also times the constraint calls",
                 "note": "k_full_score is an LDS / ALU kernel (hash-trie matching, rank sort and greedy cover in LDS): its HBM bytes are the documents' tokens; "
                         "the radix sorts are rocPRIM's"})
-    out["traffic"], out["traffic_source"] = cite_traffic_agg(index)
+    out["traffic"], out["traffic_source"] = cite_traffic_agg(index, workload_tag=workload_tag)
     loc_pmc = (out["traffic"] or {}).get("k_agg_locate") if isinstance(out["traffic"], dict) else None
     if loc_pmc and loc.get("algorithmic_MB"):
         # k_agg_locate's memory-side bytes per batch over its algorithmic bytes: FETCH_SIZE x 2 (the guide's gfx950 correction) + WRITE_SIZE;
@@ -675,7 +677,7 @@ def aggregate_roofline(t, index):
     return out
 
 
-def cite_traffic_agg(index=None, root=ROOT):
+def cite_traffic_agg(index=None, root=ROOT, workload_tag=None):
     """FETCH_SIZE + WRITE_SIZE of the aggregation kernels from the newest builder-run profiles/r*_pmc_agg*.json taken over the current
     fmi_aggregate.hip (same refusal rule as cite_traffic)"""
     import glob, hashlib
@@ -683,13 +685,13 @@ def cite_traffic_agg(index=None, root=ROOT):
         sha = hashlib.sha256(open(os.path.join(root, "seal_amd", "csrc", "fmi_aggregate.hip"), "rb").read()).hexdigest()
         for f in sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_agg*.json")), reverse=True):
             pmc = json.load(open(f))
-            if pmc.get("_aggregate_source_sha256") == sha:
+            if pmc.get("_aggregate_source_sha256") == sha and (workload_tag is None or pmc.get("_workload") == workload_tag):
                 per = dict(pmc.get("per_batch_MB") or {})
                 for name, rec in (pmc.get("per_kernel_per_batch") or {}).items():
                     if name.startswith("k_agg_locate"):
                         per["k_agg_locate"] = {"fetch_MB": rec["fetch_MB"], "write_MB": rec["write_MB"]}
                 return per, {"file": os.path.relpath(f, root), "builder_run": True, "aggregate_source_sha256": sha[:16]}
-        return None, {"refused": "no profiles/r*_pmc_agg*.json taken over the current fmi_aggregate.hip (sha256 %s)" % sha[:16]}
+        return None, {"refused": "no profiles/r*_pmc_agg*.json taken over the current fmi_aggregate.hip (sha256 %s) on this workload (%s)" % (sha[:16], workload_tag)}
     except Exception as e:
         return None, {"error": repr(e)}
 
@@ -1022,6 +1024,10 @@ def main():
         torch.cuda.synchronize()
         step_ms.append((time.perf_counter() - t1) * 1e3)
     import ctypes
+    # (the warm-up batches' results are garbage by now: collected and the survivors frozen, like the index's lists above, so that no full
+    #  collection of theirs falls into the timed call)
+    gc.collect()
+    gc.freeze()
 
     torch.cuda.synchronize()
     if use_dist:
@@ -1285,7 +1291,7 @@ def main():
             roofline.update({"frac_3rd_to_5th_token": round(mb * 1e6 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4), "MB_3rd_to_5th_token": round(mb, 2),
                              "us_3rd_to_5th_token": round(us, 2), "calls_3rd_to_5th_token": len(mid)})
         roofline["calls_MB_desc"] = ", ".join("%.1f MB @ %.3f" % (c["MB"], c["frac"] or 0.0) for c in by_rank[:5])
-    roofline_aggregate = aggregate_roofline(agg_timing, index)
+    roofline_aggregate = aggregate_roofline(agg_timing, index, workload_tag)
 
     cpu = parity = None
     if args.no_cpu_baseline and world == 1 and os.environ.get("SEAL_BENCH_SCORE_PARITY") == "1":

@@ -8,15 +8,20 @@
 // restructured so that the ORDER is carried by sort keys and every sum runs in the reference's order:
 //
 //  first stage (keys.py:311-367)
-//   k_agg_locate        row -> (text position, document) for every occurrence i (i = the reference's processing
-//                       order: keys by descending score, rows ascending); suffix array + boundaries are resident
-//   radix sort by (query, position); k_mis: an occurrence is "new" iff no EARLIER-processed new occurrence overlaps
+//   k_agg_locate        row -> text position for every occurrence i (i = the reference's processing order: keys by
+//                       descending score, rows ascending); the suffix array is resident
+//   radix sort by (query, position); k_occ_prepare: in that order, where neighbours share cache lines, the occurrence's
+//                       key (a search over the plan's offsets) and its DOCUMENT (sampled position -> document table +
+//                       boundaries: round 6 -- in processing order these were two random sectors per row, 4 x the bytes
+//                       the kernel needs); k_mis: an occurrence is "new" iff no EARLIER-processed new occurrence overlaps
 //                       its window [pos - len, pos) -- the greedy maximal independent set of the interval graph in
 //                       priority order, resolved cluster by cluster (clusters = connected runs of overlapping
 //                       windows, independent of each other) with a parallel fixed point: a vertex is decided once
 //                       all its higher-priority neighbours are
-//   radix sort by (query, document) (stable: occurrences of a document stay in processing order); k_entries: one
-//                       wave per document: first touch, best key, the keys that count once per document
+//   (no second sort: the document of a position is monotone in the position, so the order by (query, position) already
+//                       groups the occurrences by (query, document); rounds 2-5 sorted them once more, 0.34 ms)
+//   k_entries           one wave per document: its occurrences put back into PROCESSING order (the order their keys arrive
+//                       in the reference; a handful per document), first touch, best key, the keys that count once per document
 //                       (keys.py:343-350), the repetition discount in key order with the covered token set as an
 //                       LDS bitmap over query-local token ids (keys.py:352-364), float64 in the reference's order
 //   three stable radix sorts (first touch, rank key, query) = sorted(first_stage.items(), key=...) (keys.py:366)
@@ -103,28 +108,40 @@ __device__ __forceinline__ uint64_t f64_order_key(double x)
 // ---------------------------------------------------------------------------
 // first stage
 // ---------------------------------------------------------------------------
-// occurrence i -> rare key (binary search over the occurrence offsets), row, text position, document
-__global__ __launch_bounds__(256) void k_agg_locate(FmiDev ix, AggView v, uint32_t *occ_rk, uint32_t *doc, uint64_t *key_pos, uint32_t *val)
+// last rare key r with rare_occ_off[r] <= i: the key occurrence i belongs to (the offsets: a few thousand words, cache-resident)
+__device__ __forceinline__ uint32_t rare_of_occurrence(const AggView &v, uint64_t i)
+{
+    uint32_t a = 0, b = v.n_rare;
+    while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (v.rare_occ_off[mid] <= i) a = mid; else b = mid; }
+    return a;
+}
+
+// occurrence i -> suffix-array row -> text position, as the sort key (query, position).  The rows of a key are consecutive: the suffix
+// array is read in runs, 4 B per row, and nothing else is touched here (the document comes later, in position order: k_occ_prepare).
+__global__ __launch_bounds__(256) void k_agg_locate(FmiDev ix, AggView v, uint64_t *key_pos, uint32_t *val, uint32_t *occ_i)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.total) return;
-    uint32_t a = 0, b = v.n_rare;          // last r with rare_occ_off[r] <= i
-    while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (v.rare_occ_off[mid] <= i) a = mid; else b = mid; }
+    const uint32_t a = rare_of_occurrence(v, i);
+    occ_i[i] = a;                                  // (k_occ_prepare gathers it in position order: cheaper than the search again, 13 dependent steps per row)
     const uint32_t k = v.rare_key[a];
     const uint64_t row = v.key_lo[k] + (i - v.rare_occ_off[a]);
     const uint64_t pos = sa_at(ix, row);
-    occ_rk[i] = a;
-    doc[i] = (uint32_t)doc_of(ix, pos);
     key_pos[i] = ((uint64_t)v.key_q[k] << v.pos_bits) + pos + 256;      // window [pos - len, pos) never goes below 0 after the offset
     val[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(256) void k_mis_prepare(AggView v, const uint32_t *sorted_val, const uint32_t *occ_rk, uint16_t *M, uint8_t *state)
+// in the order of the sort by (query, position): the occurrence's rare key, its window length, and its document -- neighbours in this
+// order are neighbours in the text, so the sampled position -> document table and the boundary array are read in runs
+__global__ __launch_bounds__(256) void k_occ_prepare(FmiDev ix, AggView v, const uint64_t *E, const uint32_t *sorted_val, const uint32_t *occ_i,
+                                                     uint32_t *occ_s, uint32_t *doc_s, uint16_t *M, uint8_t *state)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= v.total) return;
-    const uint32_t m = v.key_len[v.rare_key[occ_rk[sorted_val[j]]]];
-    M[j] = (uint16_t)m;
+    const uint32_t a = occ_i[sorted_val[j]];
+    occ_s[j] = a;
+    M[j] = (uint16_t)v.key_len[v.rare_key[a]];
+    doc_s[j] = (uint32_t)doc_of(ix, (E[j] & ((1ull << v.pos_bits) - 1)) - 256);
     state[j] = 0;
 }
 
@@ -200,22 +217,15 @@ __global__ __launch_bounds__(256) void k_mis(const uint64_t *E, const uint16_t *
         __syncthreads();
         if (!s_pending) break;
     }
-    for (uint32_t j = a + threadIdx.x; j < b; j += blockDim.x) newflag[PRI[j]] = state[j] == ST_NEW;
+    for (uint32_t j = a + threadIdx.x; j < b; j += blockDim.x) newflag[j] = state[j] == ST_NEW;      // (in the sorted order: k_entries reads it there)
 }
 
-__global__ __launch_bounds__(256) void k_doc_keys(AggView v, const uint32_t *occ_rk, const uint32_t *doc, uint64_t *key_doc, uint32_t *val)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= v.total) return;
-    key_doc[i] = ((uint64_t)v.key_q[v.rare_key[occ_rk[i]]] << v.doc_bits) | doc[i];
-    val[i] = (uint32_t)i;
-}
-
-__global__ __launch_bounds__(256) void k_heads(const uint64_t *KD, uint32_t *head, uint64_t total)
+// entry boundaries: where (query, document) changes in the order by (query, position)
+__global__ __launch_bounds__(256) void k_heads(const uint64_t *E, const uint32_t *doc_s, uint32_t pos_bits, uint32_t *head, uint64_t total)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= total) return;
-    head[j] = (j == 0 || KD[j] != KD[j - 1]) ? 1u : 0u;
+    head[j] = (j == 0 || doc_s[j] != doc_s[j - 1] || (E[j] >> pos_bits) != (E[j - 1] >> pos_bits)) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void k_entry_starts(const uint32_t *head, const uint32_t *eid, uint32_t *estart, uint32_t *n_entries, uint64_t total)
@@ -231,22 +241,48 @@ __global__ __launch_bounds__(256) void k_entry_starts(const uint32_t *head, cons
 // thirds of them singles): such an entry is one LANE's work -- the key counts iff its occurrence is new, no discount
 // applies to a single key (keys.py:352: only from the second key on) -- and is done by all 64 lanes at once; the entries
 // with several occurrences are then walked by the whole wave, one after the other, as before.
-__device__ __forceinline__ void entry_by_wave(const AggView &v, const uint64_t *KD, const uint32_t *ID, const uint32_t *occ_rk, const uint8_t *newflag,
-                                              int allow_overlaps, double beta, double single_key, uint32_t cover_words, uint32_t *cover,
+// The occurrences [s, t) of one (query, document) entry arrive in POSITION order (the sort's); the reference meets them in processing order
+// (keys by descending score, rows ascending: the occurrence number i), and everything below depends on that order (which key touches the
+// document first, which occurrence of a key counts).  So the wave first puts the entry's (i, rare key, new flag) triples in ascending i, into
+// scratch arrays at the same offsets: every member's rank = how many members have a smaller i, counted strip by strip (a handful of members
+// in nearly every entry: one strip, as many readlanes as members).  Rounds 2-5 got this order from a second, stable radix sort over all rows.
+__device__ __forceinline__ void entry_in_processing_order(const uint32_t *ID, const uint32_t *occ_s, const uint8_t *new_s, uint32_t s, uint32_t t,
+                                                          uint32_t *ID2, uint32_t *occ2, uint8_t *new2)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t base = s; base < t; base += 64) {
+        const uint32_t j = base + lane;
+        const bool valid = j < t;
+        const uint32_t mine = valid ? ID[j] : 0xFFFFFFFFu;
+        uint32_t rank = 0;
+        for (uint32_t ob = s; ob < t; ob += 64) {
+            const uint32_t oj = ob + lane;
+            const uint32_t other = oj < t ? ID[oj] : 0xFFFFFFFFu;
+            const uint32_t n = min(64u, t - ob);
+            for (uint32_t m = 0; m < n; m++) rank += rfl((uint32_t)__shfl((int)other, (int)m)) < mine ? 1u : 0u;
+        }
+        if (valid) { ID2[s + rank] = mine; occ2[s + rank] = occ_s[j]; new2[s + rank] = new_s[j]; }
+    }
+    __threadfence_block();
+    wave_sync();
+}
+
+__device__ __forceinline__ void entry_by_wave(const AggView &v, const uint64_t *E, const uint32_t *doc_s, const uint32_t *ID, const uint32_t *occ_rk,
+                                              const uint8_t *newflag, int allow_overlaps, double beta, double single_key, uint32_t cover_words, uint32_t *cover,
                                               uint32_t e, uint32_t s, uint32_t t, uint32_t *ckey, double *cscore, uint32_t *ent_nkeys,
                                               uint64_t *ent_rank, uint32_t *ent_first, uint32_t *ent_q, uint32_t *ent_doc, double *ent_score, uint32_t *ent_best)
 {
+    // (ID / occ_rk / newflag: the entry's members in processing order -- entry_in_processing_order's output --, indexed by slot)
     const uint32_t lane = threadIdx.x & 63;
     // ---- keys that count: first occurrence of each key that is new (or any, with allow_overlaps) ----
     uint32_t nL = 0, carry = 0xFFFFFFFFu;          // carry = rare key of the last counting occurrence so far
     for (uint32_t base = s; base < t; base += 64) {
         const uint32_t j = base + lane;
         const bool valid = j < t;
-        const uint32_t i = valid ? ID[j] : 0;
-        const uint32_t r = valid ? occ_rk[i] : 0xFFFFFFFEu;
-        const bool c = valid && (allow_overlaps || newflag[i]);
+        const uint32_t r = valid ? occ_rk[j] : 0xFFFFFFFEu;
+        const bool c = valid && (allow_overlaps || newflag[j]);
         uint32_t prev = (uint32_t)__shfl_up((int)r, 1);
-        if (lane == 0) prev = (base > s) ? occ_rk[ID[base - 1]] : 0xFFFFFFFFu;
+        if (lane == 0) prev = (base > s) ? occ_rk[base - 1] : 0xFFFFFFFFu;
         const bool runstart = valid && (r != prev);
         const uint64_t cm = __ballot(c), rs = __ballot(runstart);
         const uint64_t at_or_below = rs & (lanes_below(lane) | (1ull << lane));
@@ -296,17 +332,17 @@ __device__ __forceinline__ void entry_by_wave(const AggView &v, const uint64_t *
         if (lane == 0) cscore[s + x] = nsco;
     }
     if (lane == 0) {
-        const uint64_t kd = KD[s];
-        const uint32_t i0 = ID[s], r0 = occ_rk[i0];
+        const uint32_t i0 = ID[s], r0 = occ_rk[s];
         const double best = v.key_score[v.rare_key[r0]];     // keys arrive by descending score: the first one to touch the document
         const double rk = (1.0 - single_key) * (-current) + single_key * (-best);
         ent_nkeys[e] = nL; ent_score[e] = current; ent_best[e] = r0; ent_first[e] = i0;
-        ent_q[e] = (uint32_t)(kd >> v.doc_bits); ent_doc[e] = (uint32_t)(kd & ((1ull << v.doc_bits) - 1)); ent_rank[e] = f64_order_key(rk);
+        ent_q[e] = (uint32_t)(E[s] >> v.pos_bits); ent_doc[e] = doc_s[s]; ent_rank[e] = f64_order_key(rk);
     }
 }
 
-__global__ __launch_bounds__(256) void k_entries(AggView v, const uint64_t *KD, const uint32_t *ID, const uint32_t *estart, const uint32_t *n_entries_p,
-                                                 const uint32_t *occ_rk, const uint8_t *newflag, int allow_overlaps, double beta, double single_key,
+__global__ __launch_bounds__(256) void k_entries(AggView v, const uint64_t *E, const uint32_t *ID, const uint32_t *doc_s, const uint32_t *estart,
+                                                 const uint32_t *n_entries_p, const uint32_t *occ_s, const uint8_t *new_s, uint32_t *ID2, uint32_t *occ2,
+                                                 uint8_t *new2, int allow_overlaps, double beta, double single_key,
                                                  uint32_t cover_words, uint32_t *ckey, double *cscore, uint32_t *ent_nkeys, uint64_t *ent_rank,
                                                  uint32_t *ent_first, uint32_t *ent_q, uint32_t *ent_doc, double *ent_score, uint32_t *ent_best)
 {
@@ -320,23 +356,23 @@ __global__ __launch_bounds__(256) void k_entries(AggView v, const uint64_t *KD, 
         const uint32_t s = have ? estart[e] : 0, t = have ? estart[e + 1] : 0;
         if (have && t - s == 1) {
             // one occurrence: the same values the wave path computes for it (0.0 + x == x; a single key is never discounted)
-            const uint32_t i0 = ID[s], r0 = occ_rk[i0];
-            const bool c = allow_overlaps || newflag[i0];
+            const uint32_t i0 = ID[s], r0 = occ_s[s];
+            const bool c = allow_overlaps || new_s[s];
             const double best = v.key_score[v.rare_key[r0]];
             double current = 0.0;
             if (c) { ckey[s] = r0; cscore[s] = best; current += best; }
-            const uint64_t kd = KD[s];
             const double rk = (1.0 - single_key) * (-current) + single_key * (-best);
             ent_nkeys[e] = c ? 1u : 0u; ent_score[e] = current; ent_best[e] = r0; ent_first[e] = i0;
-            ent_q[e] = (uint32_t)(kd >> v.doc_bits); ent_doc[e] = (uint32_t)(kd & ((1ull << v.doc_bits) - 1)); ent_rank[e] = f64_order_key(rk);
+            ent_q[e] = (uint32_t)(E[s] >> v.pos_bits); ent_doc[e] = doc_s[s]; ent_rank[e] = f64_order_key(rk);
         }
         uint64_t multi = __ballot(have && t - s != 1);
         while (multi) {
             const uint32_t l = (uint32_t)__builtin_ctzll(multi);
             multi &= multi - 1;
-            entry_by_wave(v, KD, ID, occ_rk, newflag, allow_overlaps, beta, single_key, cover_words, cover, e0 + l,
-                          rfl((uint32_t)__shfl((int)s, (int)l)), rfl((uint32_t)__shfl((int)t, (int)l)), ckey, cscore, ent_nkeys, ent_rank, ent_first,
-                          ent_q, ent_doc, ent_score, ent_best);
+            const uint32_t ms = rfl((uint32_t)__shfl((int)s, (int)l)), mt = rfl((uint32_t)__shfl((int)t, (int)l));
+            entry_in_processing_order(ID, occ_s, new_s, ms, mt, ID2, occ2, new2);
+            entry_by_wave(v, E, doc_s, ID2, occ2, new2, allow_overlaps, beta, single_key, cover_words, cover, e0 + l, ms, mt, ckey, cscore, ent_nkeys,
+                          ent_rank, ent_first, ent_q, ent_doc, ent_score, ent_best);
         }
     }
 }
@@ -1234,7 +1270,7 @@ struct Carver {
 };
 
 struct Work {          // workspace layout; base == nullptr: sizes only
-    uint32_t *occ_rk, *doc, *v0, *v1, *head, *eid, *estart, *n_entries, *ckey, *ent_nkeys, *ent_first, *ent_q, *ent_doc, *ent_best, *tmp32;
+    uint32_t *occ_rk, *occ_i, *doc, *v0, *v1, *head, *eid, *estart, *n_entries, *ckey, *ent_nkeys, *ent_first, *ent_q, *ent_doc, *ent_best, *tmp32;
     uint64_t *k0, *k1, *ent_rank;
     uint16_t *M;
     uint8_t *state, *newflag;
@@ -1266,7 +1302,7 @@ Work carve(void *base, const FmiAggHeader &H, uint32_t n_top, uint32_t keep, uin
     Work w{};
     Carver c(base);
     const uint64_t N = std::max<uint64_t>(H.total_occ, 1), nq = H.nq;
-    w.occ_rk = c.take<uint32_t>(N); w.doc = c.take<uint32_t>(N);
+    w.occ_rk = c.take<uint32_t>(N); w.occ_i = c.take<uint32_t>(N); w.doc = c.take<uint32_t>(N);
     w.k0 = c.take<uint64_t>(N); w.k1 = c.take<uint64_t>(N); w.v0 = c.take<uint32_t>(N); w.v1 = c.take<uint32_t>(N);
     w.M = c.take<uint16_t>(N); w.state = c.take<uint8_t>(N); w.newflag = c.take<uint8_t>(N);
     w.head = c.take<uint32_t>(N); w.eid = c.take<uint32_t>(N); w.estart = c.take<uint32_t>(N + 1); w.n_entries = c.take<uint32_t>(4);
@@ -1419,30 +1455,30 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
         uint32_t *va = w.v0, *vb = w.v1;
         mark(2);
         stage_done();                    // [start]
-        hipLaunchKernelGGL(k_agg_locate, dim3(blocks_for(N, 256)), dim3(256), 0, st, h->dev, v, w.occ_rk, w.doc, ka, va);
+        hipLaunchKernelGGL(k_agg_locate, dim3(blocks_for(N, 256)), dim3(256), 0, st, h->dev, v, ka, va, w.occ_i);
         mark(3);
         stage_done();                    // 0: k_agg_locate
         if ((rc = sort_pairs(w, ka, kb, va, vb, N, v.pos_bits + bits_for(nq - 1), st))) return rc;
         mark(4);
         stage_done();                    // 1: sort by (query, position)
-        hipLaunchKernelGGL(k_mis_prepare, dim3(blocks_for(N, 256)), dim3(256), 0, st, v, va, w.occ_rk, w.M, w.state);
+        // (from here on everything is in that order: w.occ_rk = the occurrences' rare keys, w.doc = their documents, w.newflag = their new flags)
+        hipLaunchKernelGGL(k_occ_prepare, dim3(blocks_for(N, 256)), dim3(256), 0, st, h->dev, v, ka, va, w.occ_i, w.occ_rk, w.doc, w.M, w.state);
         hipLaunchKernelGGL(k_mis, dim3(blocks_for(N, MIS_CHUNK)), dim3(256), 0, st, ka, w.M, va, w.state, w.newflag, (uint32_t)N, (uint32_t)H.max_key_len,
                            w.pool_cursor + 4);
         mark(5);
-        stage_done();                    // 2: coverage (k_mis_prepare + k_mis)
-        hipLaunchKernelGGL(k_doc_keys, dim3(blocks_for(N, 256)), dim3(256), 0, st, v, w.occ_rk, w.doc, ka, va);
-        if ((rc = sort_pairs(w, ka, kb, va, vb, N, v.doc_bits + bits_for(nq - 1), st))) return rc;
+        stage_done();                    // 2: documents + coverage (k_occ_prepare + k_mis)
         mark(6);
-        stage_done();                    // 3: k_doc_keys + sort by (query, document)
-        hipLaunchKernelGGL(k_heads, dim3(blocks_for(N, 256)), dim3(256), 0, st, ka, w.head, N);
+        stage_done();                    // 3: (the sort by (query, document) of rounds 2-5: gone -- the order by position groups by document)
+        hipLaunchKernelGGL(k_heads, dim3(blocks_for(N, 256)), dim3(256), 0, st, ka, w.doc, v.pos_bits, w.head, N);
         size_t tb = w.rp_bytes;
         HIPCHK(rocprim::exclusive_scan(w.rp_tmp, tb, w.head, w.eid, 0u, N, rocprim::plus<uint32_t>(), st));
         mark(7);
         hipLaunchKernelGGL(k_entry_starts, dim3(blocks_for(N, 256)), dim3(256), 0, st, w.head, w.eid, w.estart, w.n_entries, N);
         const uint32_t cover_words = (uint32_t)((H.max_u + 31) / 32) + 1;
         stage_done();                    // 4: entry boundaries (k_heads, scan, k_entry_starts)
-        hipLaunchKernelGGL(k_entries, dim3((unsigned)std::min<uint64_t>(blocks_for(N, 4), 4096)), dim3(256), 4 * cover_words * 4, st, v, ka, va,
-                           w.estart, w.n_entries, w.occ_rk, w.newflag, allow_overlaps, beta, single_key, cover_words, w.ckey, w.cscore,
+        // (scratch of the entries' members in processing order: w.tmp32 / w.head / w.state are free here)
+        hipLaunchKernelGGL(k_entries, dim3((unsigned)std::min<uint64_t>(blocks_for(N, 4), 4096)), dim3(256), 4 * cover_words * 4, st, v, ka, va, w.doc,
+                           w.estart, w.n_entries, w.occ_rk, w.newflag, w.tmp32, w.head, w.state, allow_overlaps, beta, single_key, cover_words, w.ckey, w.cscore,
                            w.ent_nkeys, w.ent_rank, w.ent_first, w.ent_q, w.ent_doc, w.ent_score, w.ent_best);
         mark(8);
         stage_done();                    // 5: k_entries

@@ -552,6 +552,28 @@ def _batch_steps(searcher, inputs, constrained_generation, offset=0):
     return found_keys
 
 
+def _low_priority_stream(dev):
+    """A stream of the LOWEST priority for the searcher's rescoring phase (filters, rescoring forward, unigram scores).  Not for the priority
+    as such: HIP maps streams onto a few hardware queues per priority level, and at the default priority the rescoring stream has -- in four
+    runs of seven -- landed on the hardware queue of the caller's stream, where the decodes of the next two batches are already queued: the
+    first rescoring of a call then ran ~120 ms late, behind them (363 instead of 405 queries/s over 20 batches; bimodal from run to run).  A stream
+    of another priority level gets a queue of that level: the index's service stream took the high one for the same reason in round 5 (index.py),
+    the rescoring -- the phase nothing on the GPU waits for -- takes the low one (8 of 8 runs at 399-412 queries/s).  torch.cuda.Stream offers
+    only the levels -1 and 0 (HIP: -1 .. 1), so the stream is made by the runtime and wrapped."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        raw = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            lo, hi = ctypes.c_int(), ctypes.c_int()
+            if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(lo), ctypes.byref(hi)) == 0 and lo.value > 0 \
+                    and hip.hipStreamCreateWithPriority(ctypes.byref(raw), ctypes.c_uint(1), ctypes.c_int(lo.value)) == 0 and raw.value:   # 1 = hipStreamNonBlocking
+                return torch.cuda.ExternalStream(raw.value, device=dev)
+    except (OSError, AttributeError):
+        pass
+    return torch.cuda.Stream(device=dev)
+
+
 class SEALSearcher:
     """Drop-in for ``seal.retrieval.SEALSearcher`` (reference retrieval.py:399-811)."""
 
@@ -814,7 +836,7 @@ class SEALSearcher:
         dev = self.device
         post = self.__dict__.get("_post_stream")
         if post is None:
-            post = self.__dict__["_post_stream"] = torch.cuda.Stream(device=dev)
+            post = self.__dict__["_post_stream"] = _low_priority_stream(dev)
         params = self._aggregate_params()
         constrained = not self.free_generation
         batches, offsets, off = [], [], 0
