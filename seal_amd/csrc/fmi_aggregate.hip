@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256) void k_occ_prepare(FmiDev ix, AggView v, const
     const uint32_t a = occ_i[sorted_val[j]];
     occ_s[j] = a;
     M[j] = (uint16_t)v.key_len[v.rare_key[a]];
-    doc_s[j] = (uint32_t)doc_of(ix, (E[j] & ((1ull << v.pos_bits) - 1)) - 256);
     state[j] = 0;
+    doc_s[j] = (uint32_t)doc_of(ix, (E[j] & ((1ull << v.pos_bits) - 1)) - 256);
 }
 
 enum : uint8_t { ST_UNKNOWN = 0, ST_NEW = 1, ST_OLD = 2 };
@@ -1373,7 +1373,7 @@ extern "C" const void *fmi_agg_plan_blob(const fmi_agg_plan *p, uint64_t *bytes_
 
 static constexpr uint32_t AGG_MAX_DOC_LEN = 8192;      // LDS budget of the scoring kernel (4 waves per workgroup)
 static constexpr uint32_t AGG_MAX_TOP = 8192;
-static constexpr uint32_t AGG_CAND_CAP = 384;          // occurrences of keys per document held in LDS before the pool is used
+static constexpr uint32_t AGG_CAND_CAP = 128;          // occurrences of keys per document held in LDS before the pool is used
 
 static int agg_check(fmi *h, const FmiAggHeader &H, uint64_t n_top, uint64_t keep)
 {
