@@ -415,7 +415,8 @@ class BartStepDecoder:
             x = L["ln3"](x + L["fc2"](L["act"](L["fc1"](x))))
         return x if hidden_only else self.lm_head(x)
 
-    TREE_NODE_BUCKET = 1024      # tree_hidden_graph: node count rounded up to a multiple (few shapes, few graphs)
+    TREE_NODE_BUCKET = 256       # tree_hidden_graph: node count rounded up to a multiple (round 6: 1 024 before; the neighbours of the first bucket are captured with it)
+    tree_capture_neighbours = True
 
     @torch.no_grad()
     def tree_hidden_graph(self, tok, depth, anc, qidx, enc_hidden, attention_mask):
@@ -447,32 +448,23 @@ class BartStepDecoder:
         # CUDA generator's graph-state tensors in place, and if those were first created as inference tensors every later capture
         # outside inference mode (the decoder's, under no_grad) raises "Inplace update to inference tensor outside InferenceMode".
         with torch.inference_mode(False), torch.no_grad():
-            if st is None:
-                st = self._Static()
-                st.tok = torch.full((Np,), int(self.model.config.pad_token_id), dtype=torch.long, device=dev)
-                st.depth = torch.zeros(Np, dtype=torch.long, device=dev)
-                st.anc = torch.full((Np, 17), -1, dtype=torch.long, device=dev)
-                st.anc[:, 0] = torch.arange(Np, device=dev)                     # every row a root of its own until a real node lands on it
-                st.qidx = torch.zeros(Np, dtype=torch.long, device=dev)
-                st.enc = torch.zeros(Bq, Sp, d, dtype=dt, device=dev)
-                st.mask = torch.zeros(Bq, Sp, dtype=torch.uint8, device=dev)
-                st.hidden = None
-                st.graph = None
-                cache[key] = st
-            st.tok[:N] = tok
-            st.depth[:N] = depth
-            st.anc[:N, :A] = anc
-            if A < 17:
-                st.anc[:N, A:] = -1
-            st.qidx[:N] = qidx
-            st.enc[:, :S] = enc_hidden
-            st.mask.zero_()
-            st.mask[:, :S] = attention_mask.to(torch.uint8)
+            def make(n_rows):
+                z = self._Static()
+                z.tok = torch.full((n_rows,), int(self.model.config.pad_token_id), dtype=torch.long, device=dev)
+                z.depth = torch.zeros(n_rows, dtype=torch.long, device=dev)
+                z.anc = torch.full((n_rows, 17), -1, dtype=torch.long, device=dev)
+                z.anc[:, 0] = torch.arange(n_rows, device=dev)                  # every row a root of its own until a real node lands on it
+                z.qidx = torch.zeros(n_rows, dtype=torch.long, device=dev)
+                z.enc = torch.zeros(Bq, Sp, d, dtype=dt, device=dev)
+                z.mask = torch.zeros(Bq, Sp, dtype=torch.uint8, device=dev)
+                z.hidden = None
+                z.graph = None
+                return z
 
-            def forward():
-                prepared = self.teacher_prepare(st.enc, st.mask)
-                return self.tree_logits(st.tok, st.depth, st.anc, st.qidx, st.enc, st.mask, prepared, True)
-            if st.graph is None:
+            def capture(z):
+                def forward():
+                    prepared = self.teacher_prepare(z.enc, z.mask)
+                    return self.tree_logits(z.tok, z.depth, z.anc, z.qidx, z.enc, z.mask, prepared, True)
                 cur = torch.cuda.current_stream(dev)
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(cur)
@@ -488,8 +480,34 @@ class BartStepDecoder:
                 if cap is None:
                     cap = self._tree_capture_stream = torch.cuda.Stream(device=dev)
                 with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
-                    st.hidden = forward()
-                st.graph = g
+                    z.hidden = forward()
+                z.graph = g
+            first_of_family = st is None and not any(k[0] == "tree" and k[2:] == key[2:] for k in cache if isinstance(k, tuple))
+            if st is None:
+                st = cache[key] = make(Np)
+            st.tok[:N] = tok
+            st.depth[:N] = depth
+            st.anc[:N, :A] = anc
+            if A < 17:
+                st.anc[:N, A:] = -1
+            st.qidx[:N] = qidx
+            st.enc[:, :S] = enc_hidden
+            st.mask.zero_()
+            st.mask[:, :S] = attention_mask.to(torch.uint8)
+            if st.graph is None:
+                capture(st)
+                if first_of_family and self.tree_capture_neighbours:
+                    # The first forest of a searcher decides where its node counts live (a batch of the bench: 2 900 .. 3 400 nodes); the buckets
+                    # next to it are captured right away, behind this one -- a capture costs ~0.1 s of a stalled search whenever it happens,
+                    # and it is better spent while the searcher warms up than in the middle of a run.  (What this buys: buckets of 256 rows
+                    # instead of 1 024 -- a forest of 3 130 nodes no longer runs as 4 096 rows, a quarter of the rescoring's GEMM work.)
+                    for n_rows in (Np + bucket, Np - bucket, Np + 2 * bucket):
+                        k2 = ("tree", n_rows) + key[2:]
+                        if n_rows >= bucket and k2 not in cache:
+                            z = cache[k2] = make(n_rows)
+                            z.enc.copy_(st.enc)
+                            z.mask.copy_(st.mask)
+                            capture(z)
         st.graph.replay()
         return st.hidden[:N]
 
