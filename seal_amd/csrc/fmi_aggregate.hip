@@ -10,10 +10,10 @@
 //  first stage (keys.py:311-367)
 //   k_agg_locate        row -> text position for every occurrence i (i = the reference's processing order: keys by
 //                       descending score, rows ascending); the suffix array is resident
-//   radix sort by (query, position); k_occ_prepare: in that order, where neighbours share cache lines, the occurrence's
-//                       key (a search over the plan's offsets) and its DOCUMENT (sampled position -> document table +
-//                       boundaries: round 6 -- in processing order these were two random sectors per row, 4 x the bytes
-//                       the kernel needs); k_mis: an occurrence is "new" iff no EARLIER-processed new occurrence overlaps
+//   radix sort by (query, position); k_occ_prepare: in that order, the occurrence's key and its DOCUMENT (sampled
+//                       position -> document table + boundaries: still two random sectors per row -- a query's positions
+//                       are 10^4 symbols apart --, but in this order the documents come out GROUPED, see below);
+//                       k_mis: an occurrence is "new" iff no EARLIER-processed new occurrence overlaps
 //                       its window [pos - len, pos) -- the greedy maximal independent set of the interval graph in
 //                       priority order, resolved cluster by cluster (clusters = connected runs of overlapping
 //                       windows, independent of each other) with a parallel fixed point: a vertex is decided once
@@ -118,12 +118,11 @@ __device__ __forceinline__ uint32_t rare_of_occurrence(const AggView &v, uint64_
 
 // occurrence i -> suffix-array row -> text position, as the sort key (query, position).  The rows of a key are consecutive: the suffix
 // array is read in runs, 4 B per row, and nothing else is touched here (the document comes later, in position order: k_occ_prepare).
-__global__ __launch_bounds__(256) void k_agg_locate(FmiDev ix, AggView v, uint64_t *key_pos, uint32_t *val, uint32_t *occ_i)
+__global__ __launch_bounds__(256) void k_agg_locate(FmiDev ix, AggView v, uint64_t *key_pos, uint32_t *val)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.total) return;
     const uint32_t a = rare_of_occurrence(v, i);
-    occ_i[i] = a;                                  // (k_occ_prepare gathers it in position order: cheaper than the search again, 13 dependent steps per row)
     const uint32_t k = v.rare_key[a];
     const uint64_t row = v.key_lo[k] + (i - v.rare_occ_off[a]);
     const uint64_t pos = sa_at(ix, row);
@@ -131,14 +130,16 @@ __global__ __launch_bounds__(256) void k_agg_locate(FmiDev ix, AggView v, uint64
     val[i] = (uint32_t)i;
 }
 
-// in the order of the sort by (query, position): the occurrence's rare key, its window length, and its document -- neighbours in this
-// order are neighbours in the text, so the sampled position -> document table and the boundary array are read in runs
-__global__ __launch_bounds__(256) void k_occ_prepare(FmiDev ix, AggView v, const uint64_t *E, const uint32_t *sorted_val, const uint32_t *occ_i,
-                                                     uint32_t *occ_s, uint32_t *doc_s, uint16_t *M, uint8_t *state)
+// in the order of the sort by (query, position): the occurrence's rare key, its window length, and its document (two random sectors per
+// row: the sampled position -> document table and a boundary; neighbours in this order are ~10^4 positions apart at NQ size)
+__global__ __launch_bounds__(256) void k_occ_prepare(FmiDev ix, AggView v, const uint64_t *E, const uint32_t *sorted_val, uint32_t *occ_s, uint32_t *doc_s,
+                                                     uint16_t *M, uint8_t *state)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= v.total) return;
-    const uint32_t a = occ_i[sorted_val[j]];
+    // (the search again -- 13 steps through a cache-resident array -- rather than a gather of what k_agg_locate found: one random sector per row less,
+    //  measured 294 against 316 us for this kernel + k_mis)
+    const uint32_t a = rare_of_occurrence(v, sorted_val[j]);
     occ_s[j] = a;
     M[j] = (uint16_t)v.key_len[v.rare_key[a]];
     state[j] = 0;
@@ -1270,7 +1271,7 @@ struct Carver {
 };
 
 struct Work {          // workspace layout; base == nullptr: sizes only
-    uint32_t *occ_rk, *occ_i, *doc, *v0, *v1, *head, *eid, *estart, *n_entries, *ckey, *ent_nkeys, *ent_first, *ent_q, *ent_doc, *ent_best, *tmp32;
+    uint32_t *occ_rk, *doc, *v0, *v1, *head, *eid, *estart, *n_entries, *ckey, *ent_nkeys, *ent_first, *ent_q, *ent_doc, *ent_best, *tmp32;
     uint64_t *k0, *k1, *ent_rank;
     uint16_t *M;
     uint8_t *state, *newflag;
@@ -1302,7 +1303,7 @@ Work carve(void *base, const FmiAggHeader &H, uint32_t n_top, uint32_t keep, uin
     Work w{};
     Carver c(base);
     const uint64_t N = std::max<uint64_t>(H.total_occ, 1), nq = H.nq;
-    w.occ_rk = c.take<uint32_t>(N); w.occ_i = c.take<uint32_t>(N); w.doc = c.take<uint32_t>(N);
+    w.occ_rk = c.take<uint32_t>(N); w.doc = c.take<uint32_t>(N);
     w.k0 = c.take<uint64_t>(N); w.k1 = c.take<uint64_t>(N); w.v0 = c.take<uint32_t>(N); w.v1 = c.take<uint32_t>(N);
     w.M = c.take<uint16_t>(N); w.state = c.take<uint8_t>(N); w.newflag = c.take<uint8_t>(N);
     w.head = c.take<uint32_t>(N); w.eid = c.take<uint32_t>(N); w.estart = c.take<uint32_t>(N + 1); w.n_entries = c.take<uint32_t>(4);
@@ -1455,14 +1456,14 @@ extern "C" int fmi_dev_aggregate(fmi_t *h, void *stream, const fmi_agg_plan *pla
         uint32_t *va = w.v0, *vb = w.v1;
         mark(2);
         stage_done();                    // [start]
-        hipLaunchKernelGGL(k_agg_locate, dim3(blocks_for(N, 256)), dim3(256), 0, st, h->dev, v, ka, va, w.occ_i);
+        hipLaunchKernelGGL(k_agg_locate, dim3(blocks_for(N, 256)), dim3(256), 0, st, h->dev, v, ka, va);
         mark(3);
         stage_done();                    // 0: k_agg_locate
         if ((rc = sort_pairs(w, ka, kb, va, vb, N, v.pos_bits + bits_for(nq - 1), st))) return rc;
         mark(4);
         stage_done();                    // 1: sort by (query, position)
         // (from here on everything is in that order: w.occ_rk = the occurrences' rare keys, w.doc = their documents, w.newflag = their new flags)
-        hipLaunchKernelGGL(k_occ_prepare, dim3(blocks_for(N, 256)), dim3(256), 0, st, h->dev, v, ka, va, w.occ_i, w.occ_rk, w.doc, w.M, w.state);
+        hipLaunchKernelGGL(k_occ_prepare, dim3(blocks_for(N, 256)), dim3(256), 0, st, h->dev, v, ka, va, w.occ_rk, w.doc, w.M, w.state);
         hipLaunchKernelGGL(k_mis, dim3(blocks_for(N, MIS_CHUNK)), dim3(256), 0, st, ka, w.M, va, w.state, w.newflag, (uint32_t)N, (uint32_t)H.max_key_len,
                            w.pool_cursor + 4);
         mark(5);

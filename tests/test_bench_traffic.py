@@ -88,8 +88,8 @@ def test_aggregate_roofline_prices_the_stages_from_what_they_processed():
     t = {"stage_ms": [0.2332, 0.4552, 0.1637, 0.3962, 0.0666, 0.2348, 1.1196, 0.0175, 0.3592, 0.0933, 0.0936], "counts": [5775748, 5699723, 30000, 2000, 4250343], "calls": 1}
     r = bench.aggregate_roofline(t, Ix())
     loc = r["stages"][0]
-    assert loc["stage"] == "k_agg_locate" and abs(loc["algorithmic_MB"] - 5775748 * 20 / 1e6) < 0.01       # SA 4 + 16 B written (round 6: the document comes later, in position order)
-    assert abs(loc["achieved"] - 5775748 * 20 / 233.2e-6 / 1e9) < 1.0 and r["frac"] == loc["frac"] and r["kernel"] == "k_agg_locate"
-    assert r["stages"][2]["stage"].startswith("documents+coverage") and abs(r["stages"][2]["algorithmic_MB"] - 5775748 * 55 / 1e6) < 0.01
+    assert loc["stage"] == "k_agg_locate" and abs(loc["algorithmic_MB"] - 5775748 * 16 / 1e6) < 0.01       # SA 4 + 12 B written (round 6: the document comes later, in position order)
+    assert abs(loc["achieved"] - 5775748 * 16 / 233.2e-6 / 1e9) < 1.0 and r["frac"] == loc["frac"] and r["kernel"] == "k_agg_locate"
+    assert r["stages"][2]["stage"].startswith("documents+coverage") and abs(r["stages"][2]["algorithmic_MB"] - 5775748 * 51 / 1e6) < 0.01
     assert "algorithmic_MB" not in r["stages"][1] and r["located_rows"] == 5775748 and abs(r["total_us"] - sum(t["stage_ms"]) * 1e3) < 0.1
     assert bench.aggregate_roofline({"stage_ms": [0] * 11, "counts": [0] * 5, "calls": 0}, Ix()) is None

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/prof_kt /tmp/prof_pmc /tmp/prof_aggf /tmp/prof_aggw
 B="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-AGG="k_agg_locate|k_mis|k_doc_keys|k_heads|k_entry_starts|k_entries|k_sel_|k_select_top|k_pad_entries|k_gather|k_top_docs|k_scatter|k_full_score|k_rank_docs|rocprim"
+AGG="k_agg_locate|k_occ_prepare|k_mis|k_doc_keys|k_heads|k_entry_starts|k_entries|k_sel_|k_select_top|k_pad_entries|k_gather|k_top_docs|k_scatter|k_full_score|k_rank_docs|rocprim"
 SEAL_BENCH_SKIP_OTHER=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $B "$@" > $GRAFT_REPO_ROOT/$out/${tag}_bench_under_rocprof.log 2>&1
 f=$(find /tmp/prof_kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $GRAFT_REPO_ROOT/$out/${tag}_kernel_stats.csv
 # (the full trace -- 30-60 MB -- stays on the box: gpurun_out/ travels back only below 64 MiB; KEEP_TRACE=1 copies it)

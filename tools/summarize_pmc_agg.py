@@ -6,7 +6,7 @@ usage: python tools/summarize_pmc_agg.py <fetch.csv> <write.csv> <workload_tag>"
 import csv, hashlib, json, os, sys
 from collections import defaultdict
 
-KERNELS = ("k_agg_locate", "k_mis_prepare", "k_mis", "k_doc_keys", "k_heads", "k_entry_starts", "k_entries", "k_sel_minmax", "k_sel_hist", "k_sel_compact", "k_sel_final",
+KERNELS = ("k_agg_locate", "k_occ_prepare", "k_mis_prepare", "k_mis", "k_doc_keys", "k_heads", "k_entry_starts", "k_entries", "k_sel_minmax", "k_sel_hist", "k_sel_compact", "k_sel_final",
            "k_select_top", "k_pad_entries", "k_gather", "k_top_docs",
            "k_scatter", "k_full_score", "k_rank_docs", "rocprim")
 
