@@ -256,17 +256,18 @@ int fmi_dev_allowed_bits_step(fmi_t *h, void *stream, uint64_t rows, uint64_t cu
  * sub-tree expanded, bitmap stored}.  NULL switches it off. */
 int fmi_dev_debug_timestamps(fmi_t *h, uint64_t *d_buf, uint64_t n_words);
 
-/* Launch-shape switches of the constraint / top-2K calls, for A/B measurements and for the tests that force every kernel path.
- * Each is read from the environment ONCE when the handle is created (SEALFM_<NAME in capitals>) and can be changed afterwards
- * here; value -1 restores the built-in choice.  Names: "constrain_waves" (1: one self-contained wave per (row, top digit)),
+/* Launch-shape options of the constraint / top-2K / aggregation calls, for A/B measurements and for the tests that force every kernel path.
+ * A handle starts with the built-in choices (nothing is read from the environment: round 6); this call changes one, value -1 restores the
+ * built-in choice.  Names: "constrain_waves" (1: one self-contained wave per (row, top digit)),
  * "leave_early" (0: the waves of empty items stay), "row_first" (0 / 1: never / always the row-first pair of launches),
  * "row_first_from" (prefix length in tokens from which a call goes row-first),
  * "prefix_tables" (0: the first constrained step of a decode through the generic expansion instead of the per-token node tables),
  * "table_grid" (workgroups of the table call's flat pass),
  * "topk_narrow" (rows with more allowed tokens take the wide-row path of the top-2K kernel), "topk_legacy" (1: exact radix
  * select on wide rows), "chain_steps" (0: fmi_dev_beam_step leaves the rows' chains to the next constraint call),
- * "advance_apart" (measurement passes: 0 = k_beam_advance as the product's one launch, timed whole), "pt_inject_failure"
- * (tests: building a prefix table fails).  Results are identical for every setting (tests/test_gpu_fmindex.py, tests/test_gpu_decode.py).
+ * "advance_apart" (measurement passes: 0 = k_beam_advance as the product's one launch, timed whole), "agg_rank_by_sorts"
+ * (fmi_dev_aggregate's first-stage ranking: 1 = the three full stable sorts of rounds 2-5, 2 = the single-workgroup selection; 0 = the
+ * selection on twelve workgroups per query), "pt_inject_failure" (tests: building a prefix table fails).  Results are identical for every setting (tests/test_gpu_fmindex.py, tests/test_gpu_decode.py).
  *
  * "leave_early" = 1 (the default): a wave of k_constrain whose (row, top digit) item is empty ENDS before its workgroup's barriers.
  * That relies on the documented behaviour of the gfx9 / CDNA barrier -- "S_BARRIER: Synchronize waves within a threadgroup. [...] If

@@ -886,7 +886,7 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 4 : 1) void k_constrain(FmiDev ix, 
         // (single == ROW_DONE: k_beam_advance has put the row's tokens into the bitmap already)
         const bool stays = live || (valid && (single >= 0 || (a.always_allow_eos && single != -2))) || counting;
         // (keeping the empty waves as helpers where a workgroup has much to share measured the same on the bench workload: 39.0 vs 39.4 us
-        //  per call, SEALFM_LEAVE_EARLY=0; on 600 narrow rows leaving is what lets the second launch of a row-first call finish in 12 us)
+        //  per call, option leave_early = 0; on 600 narrow rows leaving is what lets the second launch of a row-first call finish in 12 us)
         if (a.leave_early && !__builtin_amdgcn_readfirstlane((int)stays)) {     // (a scalar condition: the whole wave branches to its end)
             STAMP(3); STAMP(4);
             return;
@@ -2551,7 +2551,7 @@ static int allowed_bits_impl(fmi *h, hipStream_t st, uint64_t rows, uint64_t cur
     // dependent accesses of a row (parent -> kept range -> one backward-search step -> root child), which every one of the 13 waves
     // of a row would repeat: ONE wave per row runs it first (k_constrain_rows), the item waves pick the result up with a single load
     // and the empty ones are gone a microsecond into the second launch.  Wide rows (the first constrained steps of a decode) gain
-    // nothing from the extra launch: the host picks by prefix length (SEALFM_ROW_FIRST=0 / 1 forces either; same results).
+    // nothing from the extra launch: the host picks by prefix length (option row_first = 0 / 1 forces either; same results).
     uint64_t longest = 0;
     for (uint32_t g = 0; g < rg.n; g++) longest = std::max<uint64_t>(longest, rg.n_force[g] + (cur_len - 1));
     a.leave_early = (int)h->opt.leave_early;
