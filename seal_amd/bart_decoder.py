@@ -435,7 +435,11 @@ class BartStepDecoder:
         A = anc.shape[1]
         if not (self.use_graph and enc_hidden.is_cuda and self.can_teacher_force(enc_hidden, A) and N > 0):
             return None
+        # (the bucket grows with the forest: 1/16 of the power of two at or above N -- 256 rows for the ~3 100 nodes of a beam-15 batch, 512 for
+        #  the ~6 200 of beam 30 -- so that the forests of one workload fall into three or four buckets whatever their size)
         bucket = max(64, int(self.TREE_NODE_BUCKET))
+        while bucket * 16 < N:
+            bucket *= 2
         Np = (N + bucket - 1) // bucket * bucket
         Sp = max(16, (S + 15) // 16 * 16)
         if Sp > 64:
@@ -501,7 +505,7 @@ class BartStepDecoder:
                     # next to it are captured right away, behind this one -- a capture costs ~0.1 s of a stalled search whenever it happens,
                     # and it is better spent while the searcher warms up than in the middle of a run.  (What this buys: buckets of 256 rows
                     # instead of 1 024 -- a forest of 3 130 nodes no longer runs as 4 096 rows, a quarter of the rescoring's GEMM work.)
-                    for n_rows in (Np + bucket, Np - bucket, Np + 2 * bucket):
+                    for n_rows in (Np + bucket, Np - bucket, Np + 2 * bucket, Np - 2 * bucket):
                         k2 = ("tree", n_rows) + key[2:]
                         if n_rows >= bucket and k2 not in cache:
                             z = cache[k2] = make(n_rows)
