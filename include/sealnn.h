@@ -102,6 +102,9 @@ int sealnn_self_attn_step_x(void *stream, const float *qkv_acc, uint32_t n_slabs
 int sealnn_cross_attn_step_x(void *stream, const float *q_acc, uint32_t n_slabs, uint64_t slab_stride, const float *q_bias, float alpha,
                              const float *ck, const float *cv, const float *bias, uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S,
                              float scale, float *out, void *out_planes, uint32_t *d_flag);
+/* sealnn_gelu_planes_acc over the n_slabs slabs of fc1 as a split-K product: x = alpha * (slab 0 + slab 1 + ...) + bias, added in slab order. */
+int sealnn_gelu_planes_acc_slabs(void *stream, const float *x_acc, uint32_t n_slabs, uint64_t slab_stride, const float *x_bias, float alpha,
+                                 uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag);
 /* sealnn_add_layernorm_acc whose addend arrives as the n_slabs slabs of a split-K product (sealnn_hgemm_nt with slices > 1: slab s at
  * y_acc + s * slab_stride floats): y = alpha * (slab 0 + slab 1 + ...) + bias, the slabs added in slab order as they are read. */
 int sealnn_add_layernorm_acc_slabs(void *stream, const float *x, const float *y_acc, uint32_t n_slabs, uint64_t slab_stride, const float *y_bias,
@@ -113,7 +116,7 @@ int sealnn_add_layernorm_acc_slabs(void *stream, const float *x, const float *y_
  * the three split planes of an fp32 operand (K = 3 x in_features; sealnn_*_planes write A, seal_amd/split_gemm.py W).  A hand-written kernel
  * for the decode's heights (M = 300 .. 640 rows, a few hundred workgroups): LDS-DMA staging, no stream-K hand-off between workgroups.
  * K % 64 == 0, operands 16-byte aligned.  config: 0 = tile picked by shape; probes / tests: tile (1: 128 x 128, 2: 64 x 64, 3: 128 x 64,
- * 4: 64 x 128) | stages << 8 (LDS stages 1..4, 0: three) | slices << 16 (split-K: slab s at C + s * M * ldc, the caller sums the slabs). */
+ * 4: 64 x 128; 5: 320 x 128, 6: 320 x 64 -- the tall tiles of 8 waves, for 300 / 600 rows) | stages << 8 (LDS stages 1..3, 0: two) | slices << 16 (split-K: slab s at C + s * M * ldc, the caller sums the slabs). */
 int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float *c, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t config);
 
 #ifdef __cplusplus

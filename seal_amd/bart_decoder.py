@@ -149,7 +149,7 @@ class BartStepDecoder:
 
     def _ffn(self, x: torch.Tensor, xp, L, defer: bool = False, hand: bool = False):
         """fc2(gelu(fc1(x))): with planes, gelu's output exists as fc2's operand only (``defer``: see ``_lin``; fc1's own epilogue is
-        always gelu's to apply; ``hand``: fc1 may run in the hand-written kernel too -- one slab, GELU reads it)"""
+        always gelu's to apply; ``hand``: fc1 may run in the hand-written kernel too, split-K slabs and all -- GELU adds them)"""
         w2 = L["fc2"].weight
         # (the fused kernel computes the erf form: nn.GELU(approximate="tanh") shares the class name and must not take it)
         erf_gelu = (getattr(L["act"], "__class__", type(None)).__name__ in ("GELUActivation", "GELU")
@@ -158,16 +158,18 @@ class BartStepDecoder:
             from . import split_gemm
             from ._lib import check, lib
             h = self._lin_p(x, xp, L["fc1"].weight, L["fc1"].bias, defer=True, slabs_ok=hand)
-            if isinstance(h, split_gemm.Deferred) and h.slabs > 1:        # (no configuration of fc1 asks for slabs; summed here if one ever does)
-                h = split_gemm.Deferred(h.acc.sum(0), h.bias, h.alpha)
             acc = h.acc if isinstance(h, split_gemm.Deferred) else h
-            hp = torch.empty(acc.shape[0], 3 * acc.shape[1], dtype=torch.float16, device=acc.device)
+            rows, d1 = acc.shape[-2], acc.shape[-1]
+            hp = torch.empty(rows, 3 * d1, dtype=torch.float16, device=acc.device)
             stream = torch.cuda.current_stream(acc.device).cuda_stream
             flag = split_gemm._flag(acc.device).data_ptr()
-            if isinstance(h, split_gemm.Deferred):
-                check(lib().sealnn_gelu_planes_acc(stream, acc.data_ptr(), h.bias.data_ptr(), float(h.alpha), acc.shape[0], acc.shape[1], hp.data_ptr(), flag))
+            if isinstance(h, split_gemm.Deferred) and h.slabs > 1:        # (fc1 as a split-K product: GELU adds the slabs as it reads them)
+                check(lib().sealnn_gelu_planes_acc_slabs(stream, acc.data_ptr(), h.slabs, acc.stride(0), h.bias.data_ptr(), float(h.alpha), rows, d1,
+                                                         hp.data_ptr(), flag))
+            elif isinstance(h, split_gemm.Deferred):
+                check(lib().sealnn_gelu_planes_acc(stream, acc.data_ptr(), h.bias.data_ptr(), float(h.alpha), rows, d1, hp.data_ptr(), flag))
             else:
-                check(lib().sealnn_gelu_planes(stream, acc.data_ptr(), acc.shape[0], acc.shape[1], hp.data_ptr(), flag))
+                check(lib().sealnn_gelu_planes(stream, acc.data_ptr(), rows, d1, hp.data_ptr(), flag))
             return self.split_gemm.from_planes(hp, w2, L["fc2"].bias, defer, slabs_ok=defer)      # (its consumer, add + LayerNorm, adds split-K slabs)
         h = self._lin_p(x, xp, L["fc1"].weight, L["fc1"].bias)
         return self._mod(L["act"](h), L["fc2"], defer)

@@ -473,13 +473,19 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y,
 
 // fc2's operand: planes of gelu(x) (the erf form, the arithmetic of torch's GeluCUDAKernelImpl: 0.5 * x * (1 + erf(x * M_SQRT1_2)))
 // (xb / xa: x = raw split-GEMM accumulators, gelu's argument is xa * x + xb; see k_self_attn_step)
-__global__ __launch_bounds__(256) void k_gelu_planes(const float *x, uint32_t rows, uint32_t d, __half *planes, uint32_t *flag, const float *xb, float xa)
+__global__ __launch_bounds__(256) void k_gelu_planes(const float *x, uint32_t rows, uint32_t d, __half *planes, uint32_t *flag, const float *xb, float xa,
+                                                     uint32_t n_slabs, uint64_t slab_stride)
 {
     const uint32_t per_row = d / 4;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)rows * per_row) return;
     const uint32_t r = (uint32_t)(i / per_row), c = (uint32_t)(i % per_row);
     float4 v = reinterpret_cast<const float4 *>(x + (uint64_t)r * d)[c];
+    // (n_slabs > 1: x holds the slabs of a split-K product, sealnn_hgemm_nt -- added here, in slab order)
+    for (uint32_t sl = 1; sl < n_slabs; sl++) {
+        const float4 e = reinterpret_cast<const float4 *>(x + (uint64_t)sl * slab_stride + (uint64_t)r * d)[c];
+        v = make_float4(v.x + e.x, v.y + e.y, v.z + e.z, v.w + e.w);
+    }
     if (xb) { const float4 b = reinterpret_cast<const float4 *>(xb)[c]; v = make_float4(xa * v.x + b.x, xa * v.y + b.y, xa * v.z + b.z, xa * v.w + b.w); }
     const float kAlpha = 0.70710678118654752440f;
     const float4 g = make_float4(0.5f * v.x * (1.f + erff(v.x * kAlpha)), 0.5f * v.y * (1.f + erff(v.y * kAlpha)),
@@ -654,12 +660,13 @@ extern "C" int sealnn_add_layernorm_planes(void *stream, const float *x, const f
     if (!planes) { fmi_set_error("sealnn_add_layernorm_planes: no plane buffer"); return FMI_ERR_ARG; }
     return add_layernorm<float>(stream, x, y, gamma, beta, rows, d, eps, out, planes, d_flag);
 }
-static int gelu_planes(void *stream, const float *x, uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag, const float *xb, float xa)
+static int gelu_planes(void *stream, const float *x, uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag, const float *xb, float xa,
+                       uint32_t n_slabs = 1, uint64_t slab_stride = 0)
 {
     if (d % 4 || !planes) { fmi_set_error("sealnn_gelu_planes: d=%u must be a multiple of 4 (and a plane buffer given)", d); return FMI_ERR_UNSUPPORTED; }
     const uint64_t n = (uint64_t)rows * (d / 4);
     if (!n) return FMI_OK;
-    hipLaunchKernelGGL(k_gelu_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows, d, (__half *)planes, d_flag, xb, xa);
+    hipLaunchKernelGGL(k_gelu_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows, d, (__half *)planes, d_flag, xb, xa, n_slabs, slab_stride);
     NNCHK();
     return FMI_OK;
 }
@@ -700,6 +707,12 @@ extern "C" int sealnn_gelu_planes_acc(void *stream, const float *x_acc, const fl
 {
     if (!x_bias) { fmi_set_error("sealnn_gelu_planes_acc: no bias"); return FMI_ERR_ARG; }
     return gelu_planes(stream, x_acc, rows, d, planes, d_flag, x_bias, alpha);
+}
+extern "C" int sealnn_gelu_planes_acc_slabs(void *stream, const float *x_acc, uint32_t n_slabs, uint64_t slab_stride, const float *x_bias, float alpha,
+                                           uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag)
+{
+    if (!x_bias || n_slabs < 1 || n_slabs > 16) { fmi_set_error("sealnn_gelu_planes_acc_slabs: a bias and 1..16 slabs"); return FMI_ERR_ARG; }
+    return gelu_planes(stream, x_acc, rows, d, planes, d_flag, x_bias, alpha, n_slabs, slab_stride);
 }
 extern "C" int sealnn_add_layernorm_bf16(void *stream, const void *x, const void *y, const void *gamma, const void *beta, uint32_t rows,
                                          uint32_t d, float eps, void *out)

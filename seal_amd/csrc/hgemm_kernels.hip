@@ -23,6 +23,8 @@
 
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/sealnn.h"
 #include "fmi_internal.h"
 
@@ -205,6 +207,216 @@ __global__ __launch_bounds__(256 * KG) void k_hgemm_nt(const _Float16 *__restric
     }
 }
 
+// ---- the tall tile: BM = 320 rows (a decode step's 600 rows are TWO row tiles, its 300 rows one) x BN columns, 8 waves ----
+// What bounds the 4-wave kernel above at these heights is the CU's load path, not the matrix cores and not HBM: one CU takes ~92 GB/s from the L2
+// into its LDS (38 B/clk) whatever the depth of the prefetch, the number of CUs pulling or the form of the load (LDS-DMA or registers:
+// tools/glds_rate.hip, profiles/r6_glds_rate.txt), and the part of a stage that comes from HBM -- W, which a decode step streams once -- at
+// about a third of that, with everything the wave issued behind it waiting (loads return in order).  Every product of a step fits
+// time = bytes through that path / CUs: qkv as 64 x 128 tiles moves 265 MB, the d x d projections as 64 x 64 126 MB, lm_head as 128 x 128 3.1 GB.
+// So the tile grows in the only direction these products have left: BM = 320 cuts the bytes per flop to (1/320 + 1/BN) / (1/64 + 1/BN), eight
+// waves (4 along M x 2 along N, 80 x BN/2 each: 5 x BN/32 accumulator fragments) put two waves on every SIMD, and the pieces of the K step after
+// next are issued between the MFMA rows of this one.  One workgroup per CU; the stages decide BN: 3 stages of (320 + 96) x 128 B are 156 KB of the
+// 160, 3 of 320 + 128 do not fit and 2 are not enough (profiles/r6_hgemm_probe_tall.txt).  The grid is one-dimensional, XCD-grouped (consecutive
+// logical tiles on one XCD), row tile fastest, then column tile, then K slice: the two row tiles of a W tile share its L2 copy.
+// Where a step's cycles go (DBG = 3, s_memtime: profiles/r6_hgemm_tall_step_timeline.txt): the vmcnt wait at its top is 20 - 200 cycles -- the
+// stages ARE there in time --, the waves need 1000 - 1550 cycles for 14 fragment reads, 20 MFMAs (340 cycles) and 6 pieces because each piece
+// waits for the queue of the load path, and wave 0 then waits 500 cycles at the barrier for wave 7.  Without LDS-DMA a step takes 1200 cycles,
+// without reads and MFMAs 1630 (profiles/r6_hgemm_tall_decomposition.txt): the two overlap, and it is the load path that is left.
+constexpr uint32_t TALL_BM = 320;
+
+template <uint32_t BN, uint32_t NS, uint32_t DBG = 0>      // DBG (probes only): 1 = no LDS-DMA after the prologue, 2 = no fragment reads / MFMAs
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_hgemm_tall(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, float *__restrict__ C,
+                                                    uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t k_per_slice, uint64_t slab_stride,
+                                                    uint32_t tiles_m, uint32_t tiles_n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr uint32_t BM = TALL_BM, TM = BM / 4, TN = BN / 2, FM = TM / 16, FN = TN / 16;
+    constexpr uint32_t STAGE = (BM + BN) * ROW_BYTES;
+    constexpr uint32_t PA = BM / 64, PW = (BN / 8 + 7) / 8, NL = PA + PW;       // LDS-DMA pieces (8 rows x 128 B) per wave and stage: A's, W's
+    constexpr uint32_t LAST_W = (BN / 8) % 8;                  // != 0: only waves < LAST_W have a last W piece (BN = 96: twelve pieces over eight waves)
+    static_assert(NS >= 2 && NS * STAGE <= 160 * 1024, "the stages must fit the LDS of one CU");
+    static_assert((NS - 1) * NL <= 48, "vmcnt holds 6 bits");
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wm = wave >> 1, wn = wave & 1;
+    // logical tile of this workgroup: XCD x owns a contiguous range of logical indices (workgroup i runs on XCD i % 8)
+    const uint32_t nwg = gridDim.x, q = nwg >> 3, r8 = nwg & 7u;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    uint32_t logical = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
+    const uint32_t tile_m = logical % tiles_m;
+    logical /= tiles_m;
+    const uint32_t tile_n = logical % tiles_n, slice = logical / tiles_n;
+    const uint32_t m0 = tile_m * BM, n0 = tile_n * BN;
+    const uint32_t nk = k_per_slice / BK;
+    float *const dbg_out = C;
+    const uint64_t t_begin = DBG == 3 ? __builtin_amdgcn_s_memtime() : 0;
+    C += (uint64_t)slice * slab_stride;
+
+    // source of every piece this lane issues, at the slice's first K step (a K step later: + 128 bytes).  Piece p of a tile = its rows
+    // 8 p .. 8 p + 7; wave w issues pieces w, w + 8, ...; lane l fills row 8 p + (l >> 3), physical 16-byte slot l & 7 = logical chunk
+    // (l & 7) ^ ((row >> 1) & 7).  Rows beyond M / N read the last valid row (and are not stored).
+    const _Float16 *src[NL];
+#pragma unroll
+    for (uint32_t i = 0; i < PA; i++) {
+        const uint32_t row = (i * 8 + wave) * 8 + (lane >> 3);
+        uint32_t gr = m0 + row;
+        gr = gr < M ? gr : M - 1;
+        src[PW + i] = A + (uint64_t)gr * K + (uint64_t)slice * k_per_slice + swz(row, lane & 7u) * 8;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < PW; i++) {
+        const uint32_t row = ((i * 8 + wave) * 8 + (lane >> 3)) % BN;         // (% BN: the piece a wave >= LAST_W does not have; never issued)
+        uint32_t gr = n0 + row;
+        gr = gr < N ? gr : N - 1;
+        src[i] = W + (uint64_t)gr * K + (uint64_t)slice * k_per_slice + swz(row, lane & 7u) * 8;
+    }
+    // piece x (0 .. NL - 1; W's first: they come from memory, A's from the L2) of K step kt into stage buffer buf
+    auto piece = [&](uint32_t x, uint32_t kt, uint32_t buf) {
+        unsigned char *st = lds + buf * STAGE;
+        unsigned char *dst = x < PW ? st + BM * ROW_BYTES + (x * 8 + wave) * 8 * ROW_BYTES : st + ((x - PW) * 8 + wave) * 8 * ROW_BYTES;
+        if (LAST_W != 0 && x == PW - 1 && wave >= LAST_W) return;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[x] + (uint64_t)kt * BK),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+
+    float4v acc[FM][FN];
+#pragma unroll
+    for (uint32_t i = 0; i < FM; i++)
+#pragma unroll
+        for (uint32_t j = 0; j < FN; j++) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: NS - 1 stages in flight
+#pragma unroll
+    for (uint32_t s = 0; s + 1 < NS; s++)
+        if (s < nk) {
+#pragma unroll
+            for (uint32_t x = 0; x < NL; x++) piece(x, s, s);
+        }
+    // one K step: MORE = a further stage (kt + NS - 1) exists and is issued between the MFMA rows; NEWER = stages issued after kt and still in flight.
+    // The fragment reads are inline assembly with waits counted by hand: left to itself the compiler (which must assume that an LDS-DMA and a
+    // ds_read alias) delays the reads to save registers and with them every piece of the next stage, to the END of the step, where the DMA
+    // has no MFMAs left to hide behind and the next step waits for it.  Here all 2 (FM + FN) reads go out behind the barrier, the first half's
+    // MFMA rows start when lgkmcnt says its fragments are in, and a piece goes out in front of each row.
+    uint32_t buf = 0;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)lds);
+    const uint32_t frag_swz = (lane >> 4) ^ ((lane >> 1) & 7u);               // chunk (lane >> 4) of K half 0 at row lane & 15; K half 1: ^ 4
+    const uint32_t a_off0 = lds_base + (wm * TM + (lane & 15)) * ROW_BYTES + frag_swz * 16, a_off1 = a_off0 ^ 64u;
+    const uint32_t b_off0 = lds_base + (BM + wn * TN + (lane & 15)) * ROW_BYTES + frag_swz * 16, b_off1 = b_off0 ^ 64u;
+    auto step = [&](uint32_t kt, auto more_tag, auto newer_tag) {
+        constexpr bool MORE = decltype(more_tag)::value && DBG != 1;
+        constexpr uint32_t NEWER = decltype(newer_tag)::value;
+        uint64_t t0 = 0, t1 = 0;
+        if constexpr (DBG == 3) t0 = __builtin_amdgcn_s_memtime();
+        if (LAST_W != 0 && NEWER != 0 && wave >= LAST_W) wait_all_but<NEWER * (NL - 1)>();
+        else wait_all_but<NEWER * NL>();
+        if constexpr (DBG == 3) t1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (DBG == 3) {
+            // (probe) waves 0 and 7 of every workgroup: cycles since the kernel began at the top of the step, after its wait, after the barrier
+            const uint64_t t2 = __builtin_amdgcn_s_memtime();
+            if ((wave == 0 || wave == 7) && lane == 0 && kt < 60) {
+                float *o = dbg_out + ((uint64_t)blockIdx.x * 2 + (wave == 7)) * 192 + kt * 3;
+                o[0] = (float)(t0 - t_begin); o[1] = (float)(t1 - t_begin); o[2] = (float)(t2 - t_begin);
+            }
+        }
+        const uint32_t nxt = kt + NS - 1, nbuf = buf == 0 ? NS - 1 : buf - 1;
+        const uint32_t va0 = a_off0 + buf * STAGE, va1 = a_off1 + buf * STAGE, vb0 = b_off0 + buf * STAGE, vb1 = b_off1 + buf * STAGE;
+        auto issue_all = [&]() {
+            if constexpr (MORE) {
+#pragma unroll
+                for (uint32_t x = 0; x < NL; x++) piece(x, nxt, nbuf);
+            }
+        };
+        auto compute = [&](auto interleave_tag) {
+            constexpr bool INTERLEAVE = decltype(interleave_tag)::value;
+            half8 fa[2][FM], fb[2][FN];
+#pragma unroll
+            for (uint32_t j = 0; j < FN; j++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0][j]) : "v"(vb0), "n"(j * 16 * ROW_BYTES) : "memory");
+#pragma unroll
+            for (uint32_t i = 0; i < FM; i++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[0][i]) : "v"(va0), "n"(i * 16 * ROW_BYTES) : "memory");
+#pragma unroll
+            for (uint32_t j = 0; j < FN; j++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1][j]) : "v"(vb1), "n"(j * 16 * ROW_BYTES) : "memory");
+#pragma unroll
+            for (uint32_t i = 0; i < FM; i++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[1][i]) : "v"(va1), "n"(i * 16 * ROW_BYTES) : "memory");
+            static_assert(NL <= 2 * FM, "a piece per MFMA row");
+#pragma unroll
+            for (uint32_t ks = 0; ks < 2; ks++) {
+                // the K half's fragments are in: all reads but the other half's (ks = 0) / all (ks = 1); tied to the registers the MFMAs read
+                if (ks == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM + FN) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (uint32_t j = 0; j < FN; j++) asm volatile("" : "+v"(fb[ks][j]));
+#pragma unroll
+                for (uint32_t i = 0; i < FM; i++) asm volatile("" : "+v"(fa[ks][i]));
+#pragma unroll
+                for (uint32_t i = 0; i < FM; i++) {
+                    if constexpr (MORE && INTERLEAVE) {
+                        if (ks * FM + i < NL) piece(ks * FM + i, nxt, nbuf);
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < FN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+                }
+            }
+        };
+        if constexpr (DBG == 2) issue_all();
+        else compute(std::true_type{});
+        // (tried and dropped, profiles/r6_hgemm_tall_step_timeline_skewed.txt: the two waves of a SIMD taking turns -- waves 0..3 issue all their
+        //  pieces first and compute after, waves 4..7 the other way round -- instead of a piece between everybody's MFMA rows: no faster)
+        buf = buf + 1 == NS ? 0 : buf + 1;
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    uint32_t kt = 0;
+    for (; kt + NS - 1 < nk; kt++) step(kt, T{}, std::integral_constant<uint32_t, NS - 2>{});
+    if constexpr (NS == 3) {
+        if (kt + 1 < nk) { step(kt, F{}, std::integral_constant<uint32_t, 1>{}); kt++; }
+    }
+    if (kt < nk) step(kt, F{}, std::integral_constant<uint32_t, 0>{});
+
+    if constexpr (DBG == 3) {
+        float keep = 0.f;
+#pragma unroll
+        for (uint32_t i = 0; i < FM; i++)
+#pragma unroll
+            for (uint32_t j = 0; j < FN; j++) keep += acc[i][j][0];
+        if ((wave == 0 || wave == 7) && lane == 0) {
+            float *o = dbg_out + ((uint64_t)blockIdx.x * 2 + (wave == 7)) * 192;
+            o[180] = (float)(__builtin_amdgcn_s_memtime() - t_begin); o[181] = keep; o[182] = (float)nk;
+        }
+        return;
+    }
+    const bool inside = m0 + BM <= M && n0 + BN <= N;
+#pragma unroll
+    for (uint32_t i = 0; i < FM; i++) {
+#pragma unroll
+        for (uint32_t j = 0; j < FN; j++) {
+            const uint32_t col = n0 + wn * TN + j * 16 + (lane & 15);
+            const uint32_t rbase = m0 + wm * TM + i * 16 + (lane >> 4) * 4;
+            float *dst = C + (uint64_t)rbase * ldc + col;
+            if (inside) {
+#pragma unroll
+                for (uint32_t r = 0; r < 4; r++) dst[(uint64_t)r * ldc] = acc[i][j][r];
+            } else {
+#pragma unroll
+                for (uint32_t r = 0; r < 4; r++)
+                    if (rbase + r < M && col < N) dst[(uint64_t)r * ldc] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+template <uint32_t BN, uint32_t NS, uint32_t DBG = 0>
+int launch_tall(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t slices)
+{
+    const uint32_t tiles_m = (M + TALL_BM - 1) / TALL_BM, tiles_n = (N + BN - 1) / BN;
+    const size_t lds = (size_t)NS * (TALL_BM + BN) * ROW_BYTES;
+    (void)hipFuncSetAttribute((const void *)k_hgemm_tall<BN, NS, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_hgemm_tall<BN, NS, DBG>), dim3(tiles_m * tiles_n * slices), dim3(512), lds, st, (const _Float16 *)A, (const _Float16 *)W, C, M, N, K, ldc,
+                       K / slices, (uint64_t)M * ldc, tiles_m, tiles_n);
+    return hipGetLastError() == hipSuccess ? FMI_OK : FMI_ERR_HIP;
+}
+
 template <uint32_t BM, uint32_t BN, uint32_t NS, uint32_t KG>
 int launch_cfg(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t slices, uint32_t m_fastest)
 {
@@ -242,7 +454,8 @@ int launch(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, u
 
 }   // namespace
 
-// config: 0 = pick by shape; else tile (1 = 128 x 128, 2 = 64 x 64, 3 = 128 x 64, 4 = 64 x 128; + 128: row tiles fastest, XCD-grouped) | stages << 8 (LDS stages 1..3; 0: two) |
+// config: 0 = pick by shape; else tile (1 = 128 x 128, 2 = 64 x 64, 3 = 128 x 64, 4 = 64 x 128; + 128: row tiles fastest, XCD-grouped; 5 = 320 x 128,
+// 6 = 320 x 64: the tall tiles of 8 waves) | stages << 8 (LDS stages 1..3; 0: two) |
 // kgroups << 12 (K groups of 4 waves per workgroup: 1, 2 (tiles 2..4), 4 (tile 2); 0: one) | slices << 16 (split-K over workgroups: slab s of C
 // at C + s * M * ldc, the caller sums the slabs).  Probes and tests pass it explicitly.
 extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float *c, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t config)
@@ -251,7 +464,7 @@ extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float
     if (K == 0 || K % BK) { fmi_set_error("sealnn_hgemm_nt: K = %u must be a multiple of %u", K, BK); return FMI_ERR_UNSUPPORTED; }
     if (((uintptr_t)a | (uintptr_t)w) & 15) { fmi_set_error("sealnn_hgemm_nt: operands must be 16-byte aligned"); return FMI_ERR_ARG; }
     const uint32_t mf = (config >> 7) & 1u;          // bit 7 of the tile byte: row tile fastest + XCD remap (wide-N products)
-    uint32_t tile = config & 0x7f, stages = (config >> 8) & 0xf, kgroups = (config >> 12) & 0xf, slices = (config >> 16) ? (config >> 16) : 1;
+    uint32_t tile = config & 0x7f, stages = (config >> 8) & 0xf, kgroups = (config >> 12) & 0xf, slices = ((config >> 16) & 0x3fff) ? ((config >> 16) & 0x3fff) : 1;
     if (stages == 0) stages = 2;
     if (kgroups == 0) kgroups = 1;
     if ((K / BK) % slices) { fmi_set_error("sealnn_hgemm_nt: %u K steps do not split into %u slices", K / BK, slices); return FMI_ERR_ARG; }
@@ -264,6 +477,20 @@ extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float
         while (kgroups > 1 && (K / BK) % kgroups) kgroups >>= 1;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (tile >= 5 && tile <= 7) {
+        // the tall tile (320 x 128 / 64 / 96, 8 waves, always XCD-grouped); 2 stages, 3 where they fit the LDS (320 x 64 and 320 x 96)
+        if (kgroups != 1 || stages < 2 || stages > (tile == 5 ? 2u : 3u)) {
+            fmi_set_error("sealnn_hgemm_nt: no tall-tile kernel with %u stages and %u K groups", stages, kgroups);
+            return FMI_ERR_ARG;
+        }
+        if (tile == 5) return launch_tall<128, 2>(st, a, w, c, M, N, K, ldc, slices);
+        // (config >> 30, probes only: 1 / 2 = the 320 x 64 kernel without its LDS-DMA / without its reads and MFMAs, 3 = step timestamps instead of C)
+        if (tile == 7 && (config >> 30) == 3) return launch_tall<96, 3, 3>(st, a, w, c, M, N, K, ldc, slices);
+        if (tile == 6 && (config >> 30) == 3) return launch_tall<64, 3, 3>(st, a, w, c, M, N, K, ldc, slices);
+        if (tile == 7) return stages == 2 ? launch_tall<96, 2>(st, a, w, c, M, N, K, ldc, slices) : launch_tall<96, 3>(st, a, w, c, M, N, K, ldc, slices);
+        if (config >> 30) return (config >> 30) == 1 ? launch_tall<64, 3, 1>(st, a, w, c, M, N, K, ldc, slices) : launch_tall<64, 3, 2>(st, a, w, c, M, N, K, ldc, slices);
+        return stages == 2 ? launch_tall<64, 2>(st, a, w, c, M, N, K, ldc, slices) : launch_tall<64, 3>(st, a, w, c, M, N, K, ldc, slices);
+    }
     switch (tile) {
     case 1: return launch<128, 128>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
     case 2: return launch<64, 64>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);

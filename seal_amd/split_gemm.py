@@ -158,11 +158,16 @@ HAND_GEMM = True
 # Not for the microseconds -- they roughly cancel -- but because a step without a library GEMM has no stream-K kernel in it, so the rescoring
 # forward (the library's GEMMs, on another stream) may run BESIDE the decode steps (retrieval.py; DESIGN.md section 9: at most one stream of
 # stream-K kernels at a time).
+# The tall tile (tile codes 5..7: 320 rows x 128 / 64 / 96 columns, eight waves, one workgroup per CU) where it wins with W streamed from memory as a
+# decode step streams it (profiles/r6_hgemm_probe_tall.txt, us, 4-wave tile -> tall): fc2 38.9 -> 24.2 (600 rows, 8 slabs), 25.7 -> 16.8 (300, 16
+# slabs); fc1 28.9 -> 25.0 (600, 2 slabs that GELU adds), 24.8 -> 17.0 (300, 4 slabs); qkv 24.8 -> 18.9 (600 rows, 320 x 96, 4 slabs).  The d x d
+# projections stay (11.6 / 7.4 against 10.7 / 8.9 with twice the slabs), so does lm_head (234 against 248: 786 tall tiles are 3.07 rounds of 256 CUs).
+_TALL = lambda tile, stages, slices: tile | (stages << 8) | (1 << 12) | (slices << 16)
 HAND_CONFIGS = {
-    (1024, 12288): ((320, 2 | (2 << 8) | (2 << 12) | (4 << 16)), (640, 2 | (2 << 8) | (1 << 12) | (4 << 16))),      # fc2
+    (1024, 12288): ((320, _TALL(6, 3, 16)), (640, _TALL(6, 3, 8))),                                                  # fc2
     (1024, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (4 << 16)), (640, 2 | (2 << 8) | (1 << 12) | (4 << 16))),       # the d x d projections: 14.3 -> 10.7, 11.1 -> 6.6
-    (3072, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (2 << 16)), (640, 4 | (3 << 8) | (1 << 12) | (2 << 16))),       # qkv: 15.2 -> 11.9, 23.8 -> 19.5
-    (4096, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (1 << 16)), (640, (4 + 128) | (3 << 8) | (1 << 12) | (1 << 16))),   # fc1 (ONE slab: GELU reads it)
+    (3072, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (2 << 16)), (640, _TALL(7, 3, 4))),                             # qkv
+    (4096, 3072): ((320, _TALL(6, 3, 4)), (640, _TALL(6, 3, 2))),                                                    # fc1 (GELU adds the slabs)
     (50265, 3072): ((640, (1 + 128) | (2 << 8) | (1 << 12) | (1 << 16)),),                                           # lm_head (one slab)
 }
 # library GEMMs issued through this module and BartStepDecoder._lin since the process started: a step decoder that captures its graph reads it

@@ -332,7 +332,7 @@ def test_kernels_that_apply_the_epilogue_themselves_on_the_gpu(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(600, 1024, 3072), (300, 1024, 12288), (37, 200, 192), (640, 192, 256)])
+@pytest.mark.parametrize("M,N,K", [(600, 1024, 3072), (300, 1024, 12288), (37, 200, 192), (640, 192, 256), (321, 4096 + 40, 512)])
 def test_hand_written_gemm_against_torch(M, N, K):
     """``sealnn_hgemm_nt`` (hgemm_kernels.hip: LDS-DMA staging, swizzled LDS, MFMA 16x16x32 f16) in every instantiated configuration -- tiles,
     LDS stages, K groups, split-K slabs: EXACT on one-hot operands (a permuted fragment or a transposed tile cannot pass), within fp32
@@ -365,11 +365,55 @@ def test_hand_written_gemm_against_torch(M, N, K):
                     else:
                         assert float((got - want).abs().max() / want.abs().max()) < 1e-4, (tile, stages, kg, slices)
                 n_cfg += 1
+    # the tall tiles (320 x 128 / 64 / 96, eight waves, hand-counted waits on inline-assembly fragment reads; 96: a ragged last piece per stage)
+    for tile, stage_opts in ((5, (2,)), (6, (2, 3)), (7, (2, 3))):
+        for stages in stage_opts:
+            for slices in (1, 2, 4):
+                if (K // 64) % slices:
+                    continue
+                cfg = tile | (stages << 8) | (1 << 12) | (slices << 16)
+                for x, want, exact in ((a, ref, False), (a1, ref1, True)):
+                    c = torch.full((slices, M, N), float("nan"), device=dev)
+                    check(lib().sealnn_hgemm_nt(st, x.data_ptr(), w.data_ptr(), c.data_ptr(), M, N, K, N, cfg))
+                    got = c.sum(0)
+                    if exact:
+                        assert torch.equal(got, want), (tile, stages, slices)
+                    else:
+                        assert float((got - want).abs().max() / want.abs().max()) < 1e-4, (tile, stages, slices)
+                n_cfg += 1
+    with pytest.raises(Exception):
+        check(lib().sealnn_hgemm_nt(st, a.data_ptr(), w.data_ptr(), c.data_ptr(), M, N, K, N, 5 | (3 << 8) | (1 << 12) | (1 << 16)))    # 3 stages of 320 x 128 do not fit the LDS
     c = torch.empty(M, N, device=dev)
     check(lib().sealnn_hgemm_nt(st, a.data_ptr(), w.data_ptr(), c.data_ptr(), M, N, K, N, 0))          # the shape-picked configuration
     assert float((c - ref).abs().max() / ref.abs().max()) < 1e-4 and n_cfg >= 8
     with pytest.raises(Exception):
         check(lib().sealnn_hgemm_nt(st, a.data_ptr(), w.data_ptr(), c.data_ptr(), M, N, 100, N, 0))     # K not a multiple of 64
+
+
+@pytest.mark.gpu
+def test_gelu_adds_the_slabs_of_a_split_k_fc1():
+    """``sealnn_gelu_planes_acc_slabs`` (fc1 as a split-K product of the tall tile: GELU adds the slabs as it reads them) == ``sealnn_gelu_planes_acc``
+    on the slabs summed beforehand in the same order, bit for bit"""
+    from seal_amd._lib import check, lib
+    from seal_amd import split_gemm
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    g = torch.Generator().manual_seed(5)
+    rows, d = 77, 4096
+    for n_slabs in (1, 2, 3, 16):
+        slabs = (torch.randn(n_slabs, rows, d, generator=g) * 3).to(dev)
+        bias = torch.randn(d, generator=g).to(dev)
+        tot = slabs[0].clone()
+        for s_ in range(1, n_slabs):
+            tot = tot + slabs[s_]
+        want = torch.empty(rows, 3 * d, dtype=torch.float16, device=dev)
+        got = torch.empty_like(want)
+        flag = split_gemm._flag(dev).data_ptr()
+        check(lib().sealnn_gelu_planes_acc(st, tot.data_ptr(), bias.data_ptr(), 0.5, rows, d, want.data_ptr(), flag))
+        check(lib().sealnn_gelu_planes_acc_slabs(st, slabs.data_ptr(), n_slabs, slabs.stride(0), bias.data_ptr(), 0.5, rows, d, got.data_ptr(), flag))
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), n_slabs
+    with pytest.raises(Exception):
+        check(lib().sealnn_gelu_planes_acc_slabs(st, slabs.data_ptr(), 17, slabs.stride(0), bias.data_ptr(), 0.5, rows, d, got.data_ptr(), flag))
 
 
 @pytest.mark.gpu
