@@ -105,6 +105,10 @@ int sealnn_cross_attn_step_x(void *stream, const float *q_acc, uint32_t n_slabs,
 /* sealnn_gelu_planes_acc over the n_slabs slabs of fc1 as a split-K product: x = alpha * (slab 0 + slab 1 + ...) + bias, added in slab order. */
 int sealnn_gelu_planes_acc_slabs(void *stream, const float *x_acc, uint32_t n_slabs, uint64_t slab_stride, const float *x_bias, float alpha,
                                  uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag);
+/* out[rows][n] = alpha * (slab 0 + slab 1 + ...) + bias: a product of sealnn_hgemm_nt finished for a consumer that is not one of these kernels
+ * (torch's fused attention in the encoder; reference: the bias add of every nn.Linear of modeling_bart). */
+int sealnn_finish_product(void *stream, const float *acc, uint32_t n_slabs, uint64_t slab_stride, const float *bias, float alpha, uint32_t rows,
+                          uint32_t n, float *out);
 /* sealnn_add_layernorm_acc whose addend arrives as the n_slabs slabs of a split-K product (sealnn_hgemm_nt with slices > 1: slab s at
  * y_acc + s * slab_stride floats): y = alpha * (slab 0 + slab 1 + ...) + bias, the slabs added in slab order as they are read. */
 int sealnn_add_layernorm_acc_slabs(void *stream, const float *x, const float *y_acc, uint32_t n_slabs, uint64_t slab_stride, const float *y_bias,

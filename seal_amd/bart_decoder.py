@@ -83,7 +83,7 @@ class BartStepDecoder:
     # fp32 linear layers of the fused paths on the fp16 matrix cores (seal_amd/split_gemm.py; SEAL_SPLIT_GEMM=0: plain fp32 GEMMs)
     split_gemm = None
 
-    def _lin(self, x: torch.Tensor, w: torch.Tensor, b, defer: bool = False):
+    def _lin(self, x: torch.Tensor, w: torch.Tensor, b, defer: bool = False, slabs_ok: bool = False):
         """``F.linear(x, w, b)`` of an fp32 [rows, K] activation on the GPU -- through the split GEMM when that is switched on.
         ``defer``: the caller hands the result to a sealnn_*_acc kernel, which applies the epilogue of a split product itself
         (``split_gemm.Deferred``; a product that does not go through the split comes back finished)"""
@@ -91,14 +91,14 @@ class BartStepDecoder:
             from . import split_gemm
             BartStepDecoder.split_gemm = split_gemm.SplitLinears() if split_gemm.ENABLED else False
         if self.split_gemm and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
-            return self.split_gemm(x, w, b, defer)
+            return self.split_gemm(x, w, b, defer, slabs_ok)
         if x.is_cuda:
             from . import split_gemm
             split_gemm.LIBRARY_GEMMS[0] += 1
         return F.linear(x, w, b)
 
-    def _mod(self, x: torch.Tensor, m, defer: bool = False):
-        return self._lin(x, m.weight, m.bias, defer)
+    def _mod(self, x: torch.Tensor, m, defer: bool = False, slabs_ok: bool = False):
+        return self._lin(x, m.weight, m.bias, defer, slabs_ok)
 
     # -- the consumers of a product: the finished tensor through the plain kernel, a Deferred one through its _acc twin --
     def _add_ln(self, L_, stream, res, y, ln, rows, planes):
@@ -213,9 +213,9 @@ class BartStepDecoder:
                 qkv = self._lin_p(x2, xp, w, b).view(B, S, 3, H, dh)
                 q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
                 a = F.scaled_dot_product_attention(q, k, v, attn_mask=keep, scale=float(sa.scaling))
-                y = self._lin(a.transpose(1, 2).reshape(rows, H * dh), sa.out_proj.weight, sa.out_proj.bias, defer=True)
+                y = self._lin(a.transpose(1, 2).reshape(rows, H * dh), sa.out_proj.weight, sa.out_proj.bias, defer=True, slabs_ok=True)
                 x2, xp = self._add_ln(L_, stream, x2, y, layer.self_attn_layer_norm, rows, True)
-                ffn = self._ffn(x2, xp, {"fc1": layer.fc1, "fc2": layer.fc2, "act": layer.activation_fn}, defer=True)
+                ffn = self._ffn(x2, xp, {"fc1": layer.fc1, "fc2": layer.fc2, "act": layer.activation_fn}, defer=True, hand=True)
                 x2, xp = self._add_ln(L_, stream, x2, ffn, layer.final_layer_norm, rows, True)
             return x2.view(B, S, -1)
         for layer in enc.layers:
@@ -381,7 +381,7 @@ class BartStepDecoder:
                                                           self.h, float(self.scale), a.data_ptr()))
                 else:
                     check(L_.tree_self_attn(stream, qkv.data_ptr(), anc32.data_ptr(), N, A, self.h, float(self.scale), a.data_ptr()))
-                x, xp = add_ln(x, self._mod(a, L["so"], defer=True), L["ln1"])
+                x, xp = add_ln(x, self._mod(a, L["so"], defer=True, slabs_ok=True), L["ln1"])
                 q = self._lin_p(x, xp, L["cq"].weight, L["cq"].bias)
                 c = torch.empty(N, self.d, dtype=x.dtype, device=dev)
                 ck, cv = cross[li]
@@ -389,7 +389,7 @@ class BartStepDecoder:
                 #  run's first reads its own from memory -- the same arithmetic as sealnn_cross_attn_rows on either path)
                 check(L_.cross_attn_runs(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
                                          N, 16, self.h, S, float(self.scale), c.data_ptr()))
-                x, xp = add_ln(x, self._mod(c, L["co"], defer=True), L["ln2"])
+                x, xp = add_ln(x, self._mod(c, L["co"], defer=True, slabs_ok=True), L["ln2"])
                 x, xp = add_ln(x, self._ffn(x, xp, L, defer=True), L["ln3"])
             if hidden_only:
                 return x            # (the caller projects slices of x: lm_head -> _lin -> the split kernel per slice)

@@ -118,9 +118,18 @@ __global__ __launch_bounds__(256) void k_self_attn_step(const T_ *qkv, T_ *kcach
     float kn = ldf(base + (uint64_t)heads * 64 + lane);       // (bf16: already the value the cache will hold)
     float vn = ldf(base + (uint64_t)2 * heads * 64 + lane);
     // (n_slabs > 1: qkv holds the slabs of a split-K product, sealnn_hgemm_nt: added here, in slab order)
-    for (uint32_t sl = 1; sl < n_slabs; sl++) {
-        const T_ *bs = base + (uint64_t)sl * slab_stride;
-        q += ldf(bs + lane); kn += ldf(bs + (uint64_t)heads * 64 + lane); vn += ldf(bs + (uint64_t)2 * heads * 64 + lane);
+    // (four slabs' loads are in flight together -- a loop of load, add, load, ... is one memory round trip per slab --; a slab beyond the last
+    //  reads slab 0 again and is not added)
+    for (uint32_t sl = 1; sl < n_slabs; sl += 4) {
+        float eq[4], ek[4], ev[4];
+#pragma unroll
+        for (uint32_t s = 0; s < 4; s++) {
+            const T_ *bs = base + (uint64_t)(sl + s < n_slabs ? sl + s : 0) * slab_stride;
+            eq[s] = ldf(bs + lane); ek[s] = ldf(bs + (uint64_t)heads * 64 + lane); ev[s] = ldf(bs + (uint64_t)2 * heads * 64 + lane);
+        }
+#pragma unroll
+        for (uint32_t s = 0; s < 4; s++)
+            if (sl + s < n_slabs) { q += eq[s]; kn += ek[s]; vn += ev[s]; }
     }
     if (pb) {
         const T_ *b = pb + head * 64 + lane;
@@ -247,7 +256,14 @@ __global__ __launch_bounds__(1024) void k_cross_attn_step(const T_ *q, const T_ 
         const uint32_t row = b * beams + beam;
         // (qb / qa / slabs: q = the raw accumulators of the query projection, possibly as split-K slabs: the projection is qa * sum + qb)
         float qv = ldf(q + ((uint64_t)row * heads + head) * 64 + lane);
-        for (uint32_t sl = 1; sl < n_slabs; sl++) qv += ldf(q + (uint64_t)sl * slab_stride + ((uint64_t)row * heads + head) * 64 + lane);
+        for (uint32_t sl = 1; sl < n_slabs; sl += 4) {       // (four slabs' loads in flight together: k_self_attn_step)
+            float e[4];
+#pragma unroll
+            for (uint32_t s = 0; s < 4; s++) e[s] = ldf(q + (uint64_t)(sl + s < n_slabs ? sl + s : 0) * slab_stride + ((uint64_t)row * heads + head) * 64 + lane);
+#pragma unroll
+            for (uint32_t s = 0; s < 4; s++)
+                if (sl + s < n_slabs) qv += e[s];
+        }
         if (qb) qv = qa * qv + ldf(qb + head * 64 + lane);
         const float o = cross_attn_row(qv * scale, s_k, s_v, bi, S, lane);
         if (out) stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, o);
@@ -413,15 +429,25 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y,
             if (j0 == 0) { g0[jj] = ld4(gamma, ic); b0[jj] = ld4(beta, ic); }
         }
         // (y_slabs > 1: y holds the slabs of a split-K product, sealnn_hgemm_nt -- summed here, in slab order, as they are read)
-        for (uint32_t sl = 1; sl < y_slabs; sl++) {
-            float4 e[4];
+        // (four slabs' loads are in flight together; a slab beyond the last reads slab 0 again and is not added)
+        for (uint32_t sl = 1; sl < y_slabs; sl += 4) {
+            float4 e[4][4];
 #pragma unroll
-            for (uint32_t jj = 0; jj < 4; jj++) {
-                const uint32_t i = lane + 64 * (j0 + jj), ic = i < n4 ? i : 0;
-                e[jj] = ld4(yr + (uint64_t)sl * y_slab_stride, ic);
+            for (uint32_t s = 0; s < 4; s++) {
+                const T_ *ys = yr + (uint64_t)(sl + s < y_slabs ? sl + s : 0) * y_slab_stride;
+#pragma unroll
+                for (uint32_t jj = 0; jj < 4; jj++) {
+                    const uint32_t i = lane + 64 * (j0 + jj), ic = i < n4 ? i : 0;
+                    e[s][jj] = ld4(ys, ic);
+                }
             }
 #pragma unroll
-            for (uint32_t jj = 0; jj < 4; jj++) b[jj] = make_float4(b[jj].x + e[jj].x, b[jj].y + e[jj].y, b[jj].z + e[jj].z, b[jj].w + e[jj].w);
+            for (uint32_t s = 0; s < 4; s++) {
+                if (sl + s >= y_slabs) continue;
+#pragma unroll
+                for (uint32_t jj = 0; jj < 4; jj++)
+                    b[jj] = make_float4(b[jj].x + e[s][jj].x, b[jj].y + e[s][jj].y, b[jj].z + e[s][jj].z, b[jj].w + e[s][jj].w);
+            }
         }
 #pragma unroll
         for (uint32_t jj = 0; jj < 4; jj++) {
@@ -482,15 +508,39 @@ __global__ __launch_bounds__(256) void k_gelu_planes(const float *x, uint32_t ro
     const uint32_t r = (uint32_t)(i / per_row), c = (uint32_t)(i % per_row);
     float4 v = reinterpret_cast<const float4 *>(x + (uint64_t)r * d)[c];
     // (n_slabs > 1: x holds the slabs of a split-K product, sealnn_hgemm_nt -- added here, in slab order)
-    for (uint32_t sl = 1; sl < n_slabs; sl++) {
-        const float4 e = reinterpret_cast<const float4 *>(x + (uint64_t)sl * slab_stride + (uint64_t)r * d)[c];
-        v = make_float4(v.x + e.x, v.y + e.y, v.z + e.z, v.w + e.w);
+    for (uint32_t sl = 1; sl < n_slabs; sl += 4) {           // (four slabs' loads in flight together: k_self_attn_step)
+        float4 e[4];
+#pragma unroll
+        for (uint32_t s = 0; s < 4; s++) e[s] = reinterpret_cast<const float4 *>(x + (uint64_t)(sl + s < n_slabs ? sl + s : 0) * slab_stride + (uint64_t)r * d)[c];
+#pragma unroll
+        for (uint32_t s = 0; s < 4; s++)
+            if (sl + s < n_slabs) v = make_float4(v.x + e[s].x, v.y + e[s].y, v.z + e[s].z, v.w + e[s].w);
     }
     if (xb) { const float4 b = reinterpret_cast<const float4 *>(xb)[c]; v = make_float4(xa * v.x + b.x, xa * v.y + b.y, xa * v.z + b.z, xa * v.w + b.w); }
     const float kAlpha = 0.70710678118654752440f;
     const float4 g = make_float4(0.5f * v.x * (1.f + erff(v.x * kAlpha)), 0.5f * v.y * (1.f + erff(v.y * kAlpha)),
                                  0.5f * v.z * (1.f + erff(v.z * kAlpha)), 0.5f * v.w * (1.f + erff(v.w * kAlpha)));
     if (store_planes4(planes + (uint64_t)r * 3 * d, d, c, g) && flag) atomicAdd(flag, 1u);
+}
+
+// alpha * (slab 0 + slab 1 + ...) + bias -> a finished fp32 product: for the consumers that are not kernels of this file (torch's fused attention in
+// the encoder, the permutes of the cross-attention K / V), so that the hand-written product serves them too
+__global__ __launch_bounds__(256) void k_finish_product(const float *acc, uint32_t n_slabs, uint64_t slab_stride, const float *bias, float alpha, uint64_t n4,
+                                                        uint32_t per_row, float *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = reinterpret_cast<const float4 *>(acc)[i];
+    for (uint32_t sl = 1; sl < n_slabs; sl += 4) {           // (four slabs' loads in flight together: k_self_attn_step)
+        float4 e[4];
+#pragma unroll
+        for (uint32_t s = 0; s < 4; s++) e[s] = reinterpret_cast<const float4 *>(acc + (uint64_t)(sl + s < n_slabs ? sl + s : 0) * slab_stride)[i];
+#pragma unroll
+        for (uint32_t s = 0; s < 4; s++)
+            if (sl + s < n_slabs) v = make_float4(v.x + e[s].x, v.y + e[s].y, v.z + e[s].z, v.w + e[s].w);
+    }
+    const float4 b = reinterpret_cast<const float4 *>(bias)[i % per_row];
+    reinterpret_cast<float4 *>(out)[i] = make_float4(alpha * v.x + b.x, alpha * v.y + b.y, alpha * v.z + b.z, alpha * v.w + b.w);
 }
 
 #define NNCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { fmi_set_error("sealnn launch failed: %s", hipGetErrorString(e_)); return FMI_ERR_HIP; } } while (0)
@@ -713,6 +763,19 @@ extern "C" int sealnn_gelu_planes_acc_slabs(void *stream, const float *x_acc, ui
 {
     if (!x_bias || n_slabs < 1 || n_slabs > 16) { fmi_set_error("sealnn_gelu_planes_acc_slabs: a bias and 1..16 slabs"); return FMI_ERR_ARG; }
     return gelu_planes(stream, x_acc, rows, d, planes, d_flag, x_bias, alpha, n_slabs, slab_stride);
+}
+extern "C" int sealnn_finish_product(void *stream, const float *acc, uint32_t n_slabs, uint64_t slab_stride, const float *bias, float alpha, uint32_t rows,
+                                     uint32_t n, float *out)
+{
+    if (!acc || !bias || !out || n % 4 || n_slabs < 1 || n_slabs > 16 || (n_slabs > 1 && slab_stride % 4)) {
+        fmi_set_error("sealnn_finish_product: n = %u must be a multiple of 4, 1..16 slabs, a bias", n);
+        return FMI_ERR_ARG;
+    }
+    const uint64_t n4 = (uint64_t)rows * (n / 4);
+    if (!n4) return FMI_OK;
+    hipLaunchKernelGGL(k_finish_product, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc, n_slabs, slab_stride, bias, alpha, n4, n / 4, out);
+    NNCHK();
+    return FMI_OK;
 }
 extern "C" int sealnn_add_layernorm_bf16(void *stream, const void *x, const void *y, const void *gamma, const void *beta, uint32_t rows,
                                          uint32_t d, float eps, void *out)

@@ -162,11 +162,15 @@ HAND_GEMM = True
 # decode step streams it (profiles/r6_hgemm_probe_tall.txt, us, 4-wave tile -> tall): fc2 38.9 -> 24.2 (600 rows, 8 slabs), 25.7 -> 16.8 (300, 16
 # slabs); fc1 28.9 -> 25.0 (600, 2 slabs that GELU adds), 24.8 -> 17.0 (300, 4 slabs); qkv 24.8 -> 18.9 (600 rows, 320 x 96, 4 slabs).  The d x d
 # projections stay (11.6 / 7.4 against 10.7 / 8.9 with twice the slabs), so does lm_head (234 against 248: 786 tall tiles are 3.07 rounds of 256 CUs).
+# At the heights of the rescoring forest (~3 300 rows) the library stays: it runs qkv, fc1 and the K / V of the encoder states at 0.9 PFLOP/s, and the two
+# products of 1 024 columns that the tall tile wins alone (112 -> 90, 33 -> 28 us: profiles/r6_hgemm_probe_rescoring.txt) do not win beside a decode
+# whose own tall tiles want the same whole-CU LDS (430.9 against 433 .. 436 queries/s).
 _TALL = lambda tile, stages, slices: tile | (stages << 8) | (1 << 12) | (slices << 16)
 HAND_CONFIGS = {
     (1024, 12288): ((320, _TALL(6, 3, 16)), (640, _TALL(6, 3, 8))),                                                  # fc2
     (1024, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (4 << 16)), (640, 2 | (2 << 8) | (1 << 12) | (4 << 16))),       # the d x d projections: 14.3 -> 10.7, 11.1 -> 6.6
     (3072, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (2 << 16)), (640, _TALL(7, 3, 4))),                             # qkv
+    (2048, 3072): ((320, 2 | (2 << 8) | (2 << 12) | (2 << 16)), (640, _TALL(6, 3, 4))),                             # the cross-attention K / V of a batch's encoder states
     (4096, 3072): ((320, _TALL(6, 3, 4)), (640, _TALL(6, 3, 2))),                                                    # fc1 (GELU adds the slabs)
     (50265, 3072): ((640, (1 + 128) | (2 << 8) | (1 << 12) | (1 << 16)),),                                           # lm_head (one slab)
 }
@@ -197,7 +201,7 @@ class SplitLinear:
         b = bias.detach().float().reshape(-1) if bias is not None else torch.zeros(self.N, device=weight.device)
         self.bias = b.contiguous()
 
-    def __call__(self, x: torch.Tensor, defer: bool = False):
+    def __call__(self, x: torch.Tensor, defer: bool = False, slabs_ok: bool = False):
         if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != self.K:
             raise ValueError(f"SplitLinear: expected fp32 [rows, {self.K}], got {x.dtype} {tuple(x.shape)}")
         if not x.is_cuda:
@@ -208,26 +212,42 @@ class SplitLinear:
         a = torch.empty(x.shape[0], 3 * self.K, dtype=torch.float16, device=x.device)
         check(lib().sealnn_split_planes(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.shape[0], self.K, a.data_ptr(),
                                         _flag(x.device).data_ptr()))
-        return self.from_planes(a, defer)
+        return self.from_planes(a, defer, slabs_ok)
+
+    def _hand(self, planes: torch.Tensor):
+        """the product's raw accumulators [slices, rows, N] from sealnn_hgemm_nt, or None where the library serves it"""
+        if not planes.is_cuda or not planes.is_contiguous():
+            return None
+        cfg = hand_config(planes.shape[0], self.N, planes.shape[1])
+        if cfg is None:
+            return None
+        from ._lib import check, lib
+        slices = max(1, cfg >> 16)
+        acc = torch.empty(slices, planes.shape[0], self.N, dtype=torch.float32, device=planes.device)
+        check(lib().sealnn_hgemm_nt(torch.cuda.current_stream(planes.device).cuda_stream, planes.data_ptr(), self.planes.data_ptr(), acc.data_ptr(),
+                                    planes.shape[0], self.N, planes.shape[1], self.N, cfg))
+        return acc
 
     def from_planes(self, planes: torch.Tensor, defer: bool = False, slabs_ok: bool = False):
         """the product for an activation whose planes [rows, 3K] fp16 exist already (``defer``: as ``Deferred`` raw accumulators;
-        ``slabs_ok``: the consumer adds split-K slabs itself, so the hand-written kernel may serve the product)"""
+        ``slabs_ok``: the consumer adds split-K slabs itself, so the hand-written kernel may serve the product).  A FINISHED product
+        (``defer`` off) of a shape the hand-written kernel has a configuration for runs there too, with ``sealnn_finish_product`` behind it."""
         if defer:
-            if planes.is_cuda and slabs_ok:
-                cfg = hand_config(planes.shape[0], self.N, planes.shape[1])
-                if cfg is not None and planes.is_contiguous():
-                    from ._lib import check, lib
-                    slices = max(1, cfg >> 16)
-                    acc = torch.empty(slices, planes.shape[0], self.N, dtype=torch.float32, device=planes.device)
-                    check(lib().sealnn_hgemm_nt(torch.cuda.current_stream(planes.device).cuda_stream, planes.data_ptr(), self.planes.data_ptr(), acc.data_ptr(),
-                                                planes.shape[0], self.N, planes.shape[1], self.N, cfg))
-                    return Deferred(acc if slices > 1 else acc[0], self.bias, self.alpha, slabs=slices)
+            acc = self._hand(planes) if slabs_ok else None
+            if acc is not None:
+                return Deferred(acc if acc.shape[0] > 1 else acc[0], self.bias, self.alpha, slabs=acc.shape[0])
             LIBRARY_GEMMS[0] += 1 if planes.is_cuda else 0
             acc = torch.mm(planes, self.wt, out_dtype=torch.float32) if planes.is_cuda else torch.mm(planes.float(), self.wt.float())
             return Deferred(acc, self.bias, self.alpha)
         if not planes.is_cuda:
             return torch.addmm(self.bias, planes.float(), self.wt.float(), alpha=self.alpha)
+        acc = self._hand(planes) if self.N % 4 == 0 else None
+        if acc is not None:
+            from ._lib import check, lib
+            out = torch.empty(planes.shape[0], self.N, dtype=torch.float32, device=planes.device)
+            check(lib().sealnn_finish_product(torch.cuda.current_stream(planes.device).cuda_stream, acc.data_ptr(), acc.shape[0], acc.stride(0),
+                                              self.bias.data_ptr(), float(self.alpha), planes.shape[0], self.N, out.data_ptr()))
+            return out
         LIBRARY_GEMMS[0] += 1
         return torch.addmm(self.bias, planes, self.wt, alpha=self.alpha, out_dtype=torch.float32)
 
@@ -267,12 +287,12 @@ class SplitLinears:
         self._by_weight[key] = (weakref.ref(weight), version, lin)
         return lin
 
-    def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias=None, defer: bool = False):
+    def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias=None, defer: bool = False, slabs_ok: bool = False):
         """``defer``: a product that goes through the split comes back as ``Deferred`` (one that does not, as the finished tensor)"""
         if not self.wants(weight, x.shape[0], have_planes=False):
             LIBRARY_GEMMS[0] += 1 if x.is_cuda else 0
             return torch.nn.functional.linear(x, weight, bias)
-        return self._of(weight, bias)(x, defer and DEFER_EPILOGUE)
+        return self._of(weight, bias)(x, defer and DEFER_EPILOGUE, slabs_ok)
 
     def from_planes(self, planes: torch.Tensor, weight: torch.Tensor, bias=None, defer: bool = False, slabs_ok: bool = False):
         return self._of(weight, bias).from_planes(planes, defer and DEFER_EPILOGUE, slabs_ok)

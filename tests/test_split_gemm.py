@@ -417,6 +417,38 @@ def test_gelu_adds_the_slabs_of_a_split_k_fc1():
 
 
 @pytest.mark.gpu
+def test_a_finished_product_through_the_hand_written_kernel():
+    """a product nobody defers (the encoder's q / k / v for torch's attention, the cross-attention K / V) at a height the hand-written kernel has a
+    configuration for: ``sealnn_hgemm_nt`` + ``sealnn_finish_product`` == ``Deferred.value()`` of the same slabs bit for bit, no library GEMM is
+    issued, and the result is the fp32 ``F.linear`` to split-GEMM accuracy; ``HAND_GEMM`` off: the library's addmm, same accuracy"""
+    from seal_amd import split_gemm
+    from seal_amd._lib import check, lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    for rows, n, k in ((320, 3072, 1024), (300, 2048, 1024), (600, 2048, 1024), (77, 4096, 1024)):
+        w = (torch.randn(n, k, generator=g) * 0.05).to(dev)
+        b = torch.randn(n, generator=g).to(dev)
+        x = torch.randn(rows, k, generator=g).to(dev)
+        lin = split_gemm.SplitLinear(w, b)
+        ref = torch.nn.functional.linear(x.double(), w.double(), b.double()).float()
+        before = split_gemm.LIBRARY_GEMMS[0]
+        got = lin(x)
+        assert split_gemm.LIBRARY_GEMMS[0] == before and split_gemm.hand_config(rows, n, 3 * k) is not None
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+        d = lin(x, defer=True, slabs_ok=True)
+        assert isinstance(d, split_gemm.Deferred) and torch.equal(d.value(), got)
+        try:
+            split_gemm.HAND_GEMM = False
+            lib_out = lin(x)
+        finally:
+            split_gemm.HAND_GEMM = True
+        assert split_gemm.LIBRARY_GEMMS[0] == before + 1 and float((lib_out - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    st = torch.cuda.current_stream(dev).cuda_stream
+    with pytest.raises(Exception):
+        check(lib().sealnn_finish_product(st, got.data_ptr(), 1, 0, b.data_ptr(), 1.0, 4, 6, got.data_ptr()))       # n not a multiple of 4
+
+
+@pytest.mark.gpu
 def test_split_k_slabs_are_summed_by_the_kernel_that_reads_them(monkeypatch):
     """the decode step's fc2 product through the hand-written kernel: 4 split-K slabs that ``sealnn_add_layernorm_acc_slabs`` adds in slab
     order as it reads them == ``sealnn_add_layernorm_acc`` on the slabs summed beforehand in the same order, bit for bit (outputs and planes);

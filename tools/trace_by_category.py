@@ -2,6 +2,8 @@
 """Where a batch's GPU time goes, from a rocprofv3 kernel trace of bench.py (tools/prof_bench.sh keeps it as gpurun_out/<tag>_kernel_trace_full.csv):
 busy time and launches per batch by kernel family over the TIMED batches (from the second k_constrain_table launch -- the first belongs to the
 warm-up -- to the first one after them), and the strided fp32 copies torch puts in front of GEMMs (what a copy precedes).
+Then the same for a decode's PREFIX alone (encoder, cross-attention K / V, first step): the kernels on the decode queue between the last k_beam_advance of
+the first and the last library GEMM a batch has on the decode queue (a decode's later steps hold none), extended to the bookkeeping launches either side.
 usage: python tools/trace_by_category.py <kernel_trace.csv> [timed batches, default 3]"""
 import collections
 import csv
@@ -58,6 +60,34 @@ def main():
             cp[key][1] += 1
     for k, v in sorted(cp.items(), key=lambda x: -x[1][0])[:12]:
         print("  %-90s %7.3f ms/batch %6.1f/batch" % (str(k), v[0] / batches / 1e6, v[1] / batches))
+    # the decode prefix of every timed batch but the first
+    dq = rows[first[1]][4]
+    on_q = [r for r in rows if r[4] == dq]
+    tables = [i for i, r in enumerate(on_q) if "k_constrain_table" in r[2]]
+    pacc, walls, n = collections.defaultdict(lambda: [0, 0]), [], 0
+    for t_prev, ti in zip(tables[1:1 + batches], tables[2:2 + batches]):
+        # (a decode's steps hold no library GEMM: the prefix is where the queue's Cijk kernels are, up to the bookkeeping launch behind the first step)
+        lib_ix = [i for i in range(t_prev, ti) if "Cijk" in on_q[i][2]]
+        if not lib_ix:
+            continue
+        j0 = lib_ix[0]
+        while j0 > t_prev and not any(k in on_q[j0 - 1][2] for k in ("k_beam_advance", "k_row_pick", "k_query_merge", "k_hgemm")):
+            j0 -= 1
+        j1 = lib_ix[-1]
+        while j1 + 1 < ti and "k_beam_advance" not in on_q[j1][2]:
+            j1 += 1
+        seg = on_q[j0:j1 + 1]
+        n += 1
+        walls.append((seg[-1][1] - seg[0][0]) / 1e6)
+        for r in seg:
+            a = pacc[family(r[2])]
+            a[0] += r[1] - r[0]
+            a[1] += 1
+    if n:
+        print("decode prefix (encoder, cross K / V, first step up to its table call) on queue %s: wall %.2f ms, busy %.2f ms, %.0f kernels per batch" %
+              (dq, sum(walls) / n, sum(v[0] for v in pacc.values()) / n / 1e6, sum(v[1] for v in pacc.values()) / n))
+        for k, v in sorted(pacc.items(), key=lambda x: -x[1][0])[:16]:
+            print("  %-55s %8.3f ms/batch %8.1f launches/batch %7.1f us each" % (k, v[0] / n / 1e6, v[1] / n, v[0] / v[1] / 1e3))
 
 
 if __name__ == "__main__":
