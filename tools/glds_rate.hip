@@ -4,6 +4,7 @@
 //   mode 0: global_load_lds_dwordx4 (LDS-DMA, 1 KB per wave instruction)
 //   mode 1: global_load_dwordx4 into registers, nothing else (the load path alone)
 //   mode 2: global_load_dwordx4 into registers + ds_write_b128 (register staging)
+//   mode 3: LDS-DMA of HALF lines: a piece = 16 rows x 64 bytes, a K step = 64 bytes of every row (the two halves of a 128-byte line in two steps)
 // build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -o /tmp/glds_rate tools/glds_rate.hip && /tmp/glds_rate
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,20 +30,24 @@ __global__ __launch_bounds__(512) void k_stream(const unsigned char *__restrict_
     for (int i = 0; i < PIECES; i++) {
         const uint32_t row = ((blockIdx.x % 24) * 64 + (i * 8 + wave) * 8 + (lane >> 3)) % rows_total;
         p[i] = src + (uint64_t)row * pitch + (lane & 7u) * 16;
+        if constexpr (MODE == 3) {
+            const uint32_t row2 = ((blockIdx.x % 24) * 64 + (i * 8 + wave) * 16 + (lane >> 2)) % rows_total;
+            p[i] = src + (uint64_t)row2 * pitch + (lane & 3u) * 16;
+        }
     }
     u32x4 acc = {0, 0, 0, 0};
     auto issue = [&](uint32_t kt, uint32_t buf, u32x4 (&regs)[PIECES]) {
 #pragma unroll
         for (int i = 0; i < PIECES; i++) {
-            const unsigned char *g = p[i] + (uint64_t)kt * 128;
-            if constexpr (MODE == 0)
+            const unsigned char *g = p[i] + (uint64_t)kt * (MODE == 3 ? 64 : 128);
+            if constexpr (MODE == 0 || MODE == 3)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                                  (__attribute__((address_space(3))) void *)(lds + buf * STAGE + (i * 8 + wave) * 1024), 16, 0, 0);
             else
                 regs[i] = *reinterpret_cast<const u32x4 *>(g);
         }
     };
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 0 || MODE == 3) {
         u32x4 dummy[PIECES];
         for (uint32_t s = 0; s < DEPTH; s++) issue(s, s, dummy);
         uint32_t buf = 0;
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(512) void k_stream(const unsigned char *__restrict_
 template <int MODE, int PIECES, int DEPTH>
 static int run(const char *what, const unsigned char *src, uint64_t pitch, uint32_t rows, uint32_t iters, uint32_t *sink, int wgs)
 {
-    const size_t lds = MODE == 0 ? (size_t)DEPTH * PIECES * 8192 : (size_t)2 * PIECES * 8192;
+    const size_t lds = (MODE == 0 || MODE == 3) ? (size_t)DEPTH * PIECES * 8192 : (size_t)2 * PIECES * 8192;
     CHECK(hipFuncSetAttribute((const void *)k_stream<MODE, PIECES, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     hipEvent_t a, b;
     CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -95,7 +100,7 @@ static int run(const char *what, const unsigned char *src, uint64_t pitch, uint3
     float ms = 0; CHECK(hipEventElapsedTime(&ms, a, b));
     const double us = ms * 1e3 / reps, bytes = (double)wgs * iters * PIECES * 8192;
     printf("%-28s pieces/wave/step %d depth %d (%3zu KB in flight): %7.1f us  %6.2f TB/s  %5.1f GB/s per CU  = %4.1f B/clk/CU at 2.4 GHz\n", what, PIECES, DEPTH,
-           MODE == 0 ? lds / 1024 : (size_t)PIECES * 8, us, bytes / us / 1e6, bytes / us / 1e3 / wgs, bytes / us / 1e3 / wgs / 2.4);
+           (MODE == 0 || MODE == 3) ? lds / 1024 : (size_t)PIECES * 8, us, bytes / us / 1e6, bytes / us / 1e3 / wgs, bytes / us / 1e3 / wgs / 2.4);
     return 0;
 }
 
@@ -114,6 +119,8 @@ int main()
         if (run<0, 3, 6>("LDS-DMA", src, pitch, rows, iters, sink, wgs)) return 1;
         if (run<0, 2, 8>("LDS-DMA", src, pitch, rows, iters, sink, wgs)) return 1;
         if (run<0, 1, 16>("LDS-DMA", src, pitch, rows, iters, sink, wgs)) return 1;
+        if (run<3, 3, 4>("LDS-DMA, half lines", src, pitch, rows, 2 * iters, sink, wgs)) return 1;
+        if (run<3, 3, 6>("LDS-DMA, half lines", src, pitch, rows, 2 * iters, sink, wgs)) return 1;
         if (run<1, 6, 1>("registers, no LDS write", src, pitch, rows, iters, sink, wgs)) return 1;
         if (run<1, 12, 1>("registers, no LDS write", src, pitch, rows, iters, sink, wgs)) return 1;
         if (run<2, 6, 1>("registers + ds_write_b128", src, pitch, rows, iters, sink, wgs)) return 1;

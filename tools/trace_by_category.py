@@ -84,8 +84,9 @@ def main():
             a[0] += r[1] - r[0]
             a[1] += 1
     if n:
-        print("decode prefix (encoder, cross K / V, first step up to its table call) on queue %s: wall %.2f ms, busy %.2f ms, %.0f kernels per batch" %
-              (dq, sum(walls) / n, sum(v[0] for v in pacc.values()) / n / 1e6, sum(v[1] for v in pacc.values()) / n))
+        print("decode prefix (encoder, cross K / V, first step) on queue %s: busy %.2f ms, %.0f kernels per batch; first to last kernel %.1f ms (a batch's encoder is "
+              "enqueued ahead of its first step: the two are not contiguous on the queue)" %
+              (dq, sum(v[0] for v in pacc.values()) / n / 1e6, sum(v[1] for v in pacc.values()) / n, sum(walls) / n))
         for k, v in sorted(pacc.items(), key=lambda x: -x[1][0])[:16]:
             print("  %-55s %8.3f ms/batch %8.1f launches/batch %7.1f us each" % (k, v[0] / n / 1e6, v[1] / n, v[0] / v[1] / 1e3))
 
