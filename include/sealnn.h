@@ -105,6 +105,21 @@ int sealnn_cross_attn_step_x(void *stream, const float *q_acc, uint32_t n_slabs,
 /* sealnn_gelu_planes_acc over the n_slabs slabs of fc1 as a split-K product: x = alpha * (slab 0 + slab 1 + ...) + bias, added in slab order. */
 int sealnn_gelu_planes_acc_slabs(void *stream, const float *x_acc, uint32_t n_slabs, uint64_t slab_stride, const float *x_bias, float alpha,
                                  uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag);
+/* The PAIRS operand (round 6): the planes of an activation as [hi of 32 columns | lo * 2^11 of the same 32 columns] per 128-byte line, rows of 2 d halves --
+ * two thirds of the three-block operand, for sealnn_hgemm_nt's PAIRS products (config bit 29: three products per K step from four tiles instead of six, of
+ * which two were copies).  The same kernels as their namesakes, only the layout of `planes` / `out_planes` differs (d a multiple of 32). */
+int sealnn_split_planes_pairs(void *stream, const float *x, uint32_t rows, uint32_t K, void *out, uint32_t *d_flag);
+int sealnn_add_layernorm_acc_slabs_pairs(void *stream, const float *x, const float *y_acc, uint32_t n_slabs, uint64_t slab_stride, const float *y_bias,
+                                         float alpha, const float *gamma, const float *beta, uint32_t rows, uint32_t d, float eps, float *out,
+                                         void *planes, uint32_t *d_flag);
+int sealnn_gelu_planes_acc_slabs_pairs(void *stream, const float *x_acc, uint32_t n_slabs, uint64_t slab_stride, const float *x_bias, float alpha,
+                                       uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag);
+int sealnn_self_attn_step_x_pairs(void *stream, const float *qkv_acc, uint32_t n_slabs, uint64_t slab_stride, const float *qkv_bias, float alpha,
+                                  float *kcache, float *vcache, const int64_t *d_t, uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out,
+                                  void *out_planes, uint32_t *d_flag, int32_t *anc);
+int sealnn_cross_attn_step_x_pairs(void *stream, const float *q_acc, uint32_t n_slabs, uint64_t slab_stride, const float *q_bias, float alpha,
+                                   const float *ck, const float *cv, const float *bias, uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S,
+                                   float scale, float *out, void *out_planes, uint32_t *d_flag);
 /* out[rows][n] = alpha * (slab 0 + slab 1 + ...) + bias: a product of sealnn_hgemm_nt finished for a consumer that is not one of these kernels
  * (torch's fused attention in the encoder; reference: the bias add of every nn.Linear of modeling_bart). */
 int sealnn_finish_product(void *stream, const float *acc, uint32_t n_slabs, uint64_t slab_stride, const float *bias, float alpha, uint32_t rows,
@@ -120,7 +135,7 @@ int sealnn_add_layernorm_acc_slabs(void *stream, const float *x, const float *y_
  * the three split planes of an fp32 operand (K = 3 x in_features; sealnn_*_planes write A, seal_amd/split_gemm.py W).  A hand-written kernel
  * for the decode's heights (M = 300 .. 640 rows, a few hundred workgroups): LDS-DMA staging, no stream-K hand-off between workgroups.
  * K % 64 == 0, operands 16-byte aligned.  config: 0 = tile picked by shape; probes / tests: tile (1: 128 x 128, 2: 64 x 64, 3: 128 x 64,
- * 4: 64 x 128; 5: 320 x 128, 6: 320 x 64 -- the tall tiles of 8 waves, for 300 / 600 rows) | stages << 8 (LDS stages 1..3, 0: two) | slices << 16 (split-K: slab s at C + s * M * ldc, the caller sums the slabs). */
+ * 4: 64 x 128; 5: 320 x 128, 6: 320 x 64 -- the tall tiles of 8 waves, for 300 / 600 rows) | stages << 8 (LDS stages 1..3, 0: two) | 1 << 29 (the operands are PAIRS planes, K = 2 x in_features) | slices << 16 (split-K: slab s at C + s * M * ldc, the caller sums the slabs). */
 int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float *c, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t config);
 
 #ifdef __cplusplus

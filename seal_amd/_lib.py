@@ -159,6 +159,11 @@ NN_SIGNATURES = {
     "sealnn_tree_self_attn_acc": (_int, [_vp, _vp, _vp, _f32, _vp, _u32, _u32, _u32, _f32, _vp]),
     "sealnn_add_layernorm_acc": (_int, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp]),
     "sealnn_gelu_planes_acc": (_int, [_vp, _vp, _vp, _f32, _u32, _u32, _vp, _vp]),
+    "sealnn_split_planes_pairs": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    "sealnn_add_layernorm_acc_slabs_pairs": (_int, [_vp, _vp, _vp, _u32, _u64, _vp, _f32, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp]),
+    "sealnn_gelu_planes_acc_slabs_pairs": (_int, [_vp, _vp, _u32, _u64, _vp, _f32, _u32, _u32, _vp, _vp]),
+    "sealnn_self_attn_step_x_pairs": (_int, [_vp, _vp, _u32, _u64, _vp, _f32, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp, _vp, _vp, _vp]),
+    "sealnn_cross_attn_step_x_pairs": (_int, [_vp, _vp, _u32, _u64, _vp, _f32, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _vp, _vp, _vp]),
     "sealnn_finish_product": (_int, [_vp, _vp, _u32, _u64, _vp, _f32, _u32, _u32, _vp]),
     "sealnn_gelu_planes_acc_slabs": (_int, [_vp, _vp, _u32, _u64, _vp, _f32, _u32, _u32, _vp, _vp]),
     "sealnn_self_attn_step_x": (_int, [_vp, _vp, _u32, _u64, _vp, _f32, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp, _vp, _vp, _vp]),

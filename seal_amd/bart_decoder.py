@@ -101,14 +101,21 @@ class BartStepDecoder:
         return self._lin(x, m.weight, m.bias, defer, slabs_ok)
 
     # -- the consumers of a product: the finished tensor through the plain kernel, a Deferred one through its _acc twin --
-    def _add_ln(self, L_, stream, res, y, ln, rows, planes):
-        """LayerNorm(res + y) -> (fp32, its split planes or None); ``y``: a tensor or a ``split_gemm.Deferred``"""
+    def _add_ln(self, L_, stream, res, y, ln, rows, planes, pairs=False):
+        """LayerNorm(res + y) -> (fp32, its split planes or None); ``y``: a tensor or a ``split_gemm.Deferred``; ``pairs``: the planes as
+        hi / lo pairs per 32 columns ([rows, 2d]: the operand of the hand-written product's PAIRS form) -- ``y`` is then a ``Deferred``"""
         from . import split_gemm
         from ._lib import check, lib
         out = torch.empty_like(res)
-        p = torch.empty(rows, 3 * self.d, dtype=torch.float16, device=res.device) if planes else None
+        p = torch.empty(rows, (2 if pairs else 3) * self.d, dtype=torch.float16, device=res.device) if planes else None
         flag = split_gemm._flag(res.device).data_ptr() if planes else None
-        if isinstance(y, split_gemm.Deferred) and y.slabs > 1:
+        if pairs:
+            if not (planes and isinstance(y, split_gemm.Deferred)):
+                raise RuntimeError("BartStepDecoder: pair planes are written behind a deferred product only")
+            check(lib().sealnn_add_layernorm_acc_slabs_pairs(stream, res.data_ptr(), y.acc.data_ptr(), y.slabs, y.acc.stride(0) if y.slabs > 1 else 0,
+                                                             y.bias.data_ptr(), float(y.alpha), ln.weight.data_ptr(), ln.bias.data_ptr(), rows, self.d,
+                                                             float(ln.eps), out.data_ptr(), p.data_ptr(), flag))
+        elif isinstance(y, split_gemm.Deferred) and y.slabs > 1:
             check(lib().sealnn_add_layernorm_acc_slabs(stream, res.data_ptr(), y.acc.data_ptr(), y.slabs, y.acc.stride(0), y.bias.data_ptr(), float(y.alpha),
                                                        ln.weight.data_ptr(), ln.bias.data_ptr(), rows, self.d, float(ln.eps), out.data_ptr(),
                                                        p.data_ptr() if planes else None, flag))
@@ -135,19 +142,24 @@ class BartStepDecoder:
     def _lin_p(self, x: torch.Tensor, xp, w: torch.Tensor, b, defer: bool = False, slabs_ok: bool = False):
         """``F.linear(x, w, b)`` where ``xp`` (or None) holds x's split planes already (``defer``: see ``_lin``; ``slabs_ok``: the consumer
         adds split-K slabs, so the hand-written kernel may serve the product)"""
+        if xp is not None and xp.shape[1] == 2 * x.shape[1]:
+            # pair planes (a hand step's): only the hand-written kernel reads them; a product it has no configuration for splits x itself
+            from . import split_gemm
+            if split_gemm.hand_config(x.shape[0], w.shape[0], 3 * w.shape[1], True) is None:
+                xp = None
         if xp is not None and self.split_gemm and self.split_gemm.wants(w, x.shape[0]):
             return self.split_gemm.from_planes(xp, w, b, defer, slabs_ok=slabs_ok)
         return self._lin(x, w, b, defer)
 
-    def _planes_of(self, x: torch.Tensor) -> torch.Tensor:
+    def _planes_of(self, x: torch.Tensor, pairs: bool = False) -> torch.Tensor:
         from . import split_gemm
         from ._lib import check, lib
-        p = torch.empty(x.shape[0], 3 * x.shape[1], dtype=torch.float16, device=x.device)
-        check(lib().sealnn_split_planes(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.shape[0], x.shape[1], p.data_ptr(),
-                                        split_gemm._flag(x.device).data_ptr()))
+        p = torch.empty(x.shape[0], (2 if pairs else 3) * x.shape[1], dtype=torch.float16, device=x.device)
+        fn = lib().sealnn_split_planes_pairs if pairs else lib().sealnn_split_planes
+        check(fn(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.shape[0], x.shape[1], p.data_ptr(), split_gemm._flag(x.device).data_ptr()))
         return p
 
-    def _ffn(self, x: torch.Tensor, xp, L, defer: bool = False, hand: bool = False):
+    def _ffn(self, x: torch.Tensor, xp, L, defer: bool = False, hand: bool = False, pairs: bool = False):
         """fc2(gelu(fc1(x))): with planes, gelu's output exists as fc2's operand only (``defer``: see ``_lin``; fc1's own epilogue is
         always gelu's to apply; ``hand``: fc1 may run in the hand-written kernel too, split-K slabs and all -- GELU adds them)"""
         w2 = L["fc2"].weight
@@ -160,10 +172,15 @@ class BartStepDecoder:
             h = self._lin_p(x, xp, L["fc1"].weight, L["fc1"].bias, defer=True, slabs_ok=hand)
             acc = h.acc if isinstance(h, split_gemm.Deferred) else h
             rows, d1 = acc.shape[-2], acc.shape[-1]
-            hp = torch.empty(rows, 3 * d1, dtype=torch.float16, device=acc.device)
+            hp = torch.empty(rows, (2 if pairs else 3) * d1, dtype=torch.float16, device=acc.device)
             stream = torch.cuda.current_stream(acc.device).cuda_stream
             flag = split_gemm._flag(acc.device).data_ptr()
-            if isinstance(h, split_gemm.Deferred) and h.slabs > 1:        # (fc1 as a split-K product: GELU adds the slabs as it reads them)
+            if pairs:                                                      # (fc2's operand as hi / lo pairs: the hand-written product's PAIRS form)
+                if not isinstance(h, split_gemm.Deferred):
+                    raise RuntimeError("BartStepDecoder: pair planes are written behind a deferred product only")
+                check(lib().sealnn_gelu_planes_acc_slabs_pairs(stream, acc.data_ptr(), h.slabs, acc.stride(0) if h.slabs > 1 else 0, h.bias.data_ptr(),
+                                                               float(h.alpha), rows, d1, hp.data_ptr(), flag))
+            elif isinstance(h, split_gemm.Deferred) and h.slabs > 1:        # (fc1 as a split-K product: GELU adds the slabs as it reads them)
                 check(lib().sealnn_gelu_planes_acc_slabs(stream, acc.data_ptr(), h.slabs, acc.stride(0), h.bias.data_ptr(), float(h.alpha), rows, d1,
                                                          hp.data_ptr(), flag))
             elif isinstance(h, split_gemm.Deferred):
@@ -544,20 +561,31 @@ class BartStepDecoder:
 
             def add_ln(res, y, ln):
                 """LayerNorm(res + y) -> (fp32, its split planes or None)"""
-                return self._add_ln(L_, stream, res, y, ln, R, planes)
-            xp = self._planes_of(x) if planes else None
+                return self._add_ln(L_, stream, res, y, ln, R, planes, pairs)
             # The hand-written product (sealnn_hgemm_nt) between kernels of this repository: at the decode step's heights the d x d projections
             # (self-attention output, cross-attention query and output) run as 4 split-K slabs that the consumer adds as it reads them, and
             # the attention kernels hand their result over as the next projection's split planes -- the library's fp32 GEMM of 17 us (600 rows)
             # / 12 us (300) becomes 11 / 7 us (profiles/r5_hgemm_probe.txt), with no pass over the activations in between.
             hand = bool(planes and x.dtype == torch.float32 and split_gemm.DEFER_EPILOGUE and split_gemm.hand_config(R, self.d, 3 * self.d) is not None)
+            # every plane of a hand step as hi / lo PAIRS ([rows, 2d]): the products then move four tiles per K step instead of six (split_gemm.PAIRS)
+            ffn = int(self.model.config.decoder_ffn_dim)
+            L0 = self.layers[0]
+            pairs = bool(hand and split_gemm.PAIRS and self.d % 32 == 0 and ffn % 32 == 0 and
+                         all(split_gemm.hand_config(R, n, 3 * k, True) is not None for n, k in ((3 * self.d, self.d), (self.d, self.d), (ffn, self.d), (self.d, ffn))) and
+                         # (every product of the step must BE a split product: nothing else reads pair planes)
+                         all(self.split_gemm.wants(w, R) for w in (L0["qkv_w"], L0["fc1"].weight, L0["fc2"].weight)))
+            st.pairs = pairs
+            xp = self._planes_of(x, pairs) if planes else None
+            pw = 2 if pairs else 3
+            attn_self = lib().sealnn_self_attn_step_x_pairs if pairs else lib().sealnn_self_attn_step_x
+            attn_cross = lib().sealnn_cross_attn_step_x_pairs if pairs else lib().sealnn_cross_attn_step_x
             flag = split_gemm._flag(x.device).data_ptr() if hand else None
             library_before = split_gemm.LIBRARY_GEMMS[0]
             for li, L in enumerate(self.layers):
                 qkv = self._lin_p(x, xp, L["qkv_w"], L["qkv_b"], defer=True, slabs_ok=hand)
                 if hand and isinstance(qkv, split_gemm.Deferred):
-                    ap = torch.empty(R, 3 * self.d, dtype=torch.float16, device=x.device)
-                    check(lib().sealnn_self_attn_step_x(stream, qkv.acc.data_ptr(), qkv.slabs, qkv.acc.stride(0) if qkv.slabs > 1 else 0, qkv.bias.data_ptr(),
+                    ap = torch.empty(R, pw * self.d, dtype=torch.float16, device=x.device)
+                    check(attn_self(stream, qkv.acc.data_ptr(), qkv.slabs, qkv.acc.stride(0) if qkv.slabs > 1 else 0, qkv.bias.data_ptr(),
                                                         float(qkv.alpha), st.kv[li, 0].data_ptr(), st.kv[li, 1].data_ptr(), st.t.data_ptr(), R, H, T,
                                                         float(self.scale), None, ap.data_ptr(), flag, st.anc.data_ptr()))
                     y = self.split_gemm.from_planes(ap, L["so"].weight, L["so"].bias, defer=True, slabs_ok=True)
@@ -574,8 +602,8 @@ class BartStepDecoder:
                 x, xp = add_ln(x, y, L["ln1"])
                 if hand:
                     qd = self.split_gemm.from_planes(xp, L["cq"].weight, L["cq"].bias, defer=True, slabs_ok=True)
-                    cp = torch.empty(R, 3 * self.d, dtype=torch.float16, device=x.device)
-                    check(lib().sealnn_cross_attn_step_x(stream, qd.acc.data_ptr(), qd.slabs, qd.acc.stride(0) if qd.slabs > 1 else 0, qd.bias.data_ptr(),
+                    cp = torch.empty(R, pw * self.d, dtype=torch.float16, device=x.device)
+                    check(attn_cross(stream, qd.acc.data_ptr(), qd.slabs, qd.acc.stride(0) if qd.slabs > 1 else 0, qd.bias.data_ptr(),
                                                          float(qd.alpha), st.ck[li].data_ptr(), st.cv[li].data_ptr(), cbias.data_ptr(), B, K, H, S_pad,
                                                          float(self.scale), None, cp.data_ptr(), flag))
                     y = self.split_gemm.from_planes(cp, L["co"].weight, L["co"].bias, defer=True, slabs_ok=True)
@@ -586,7 +614,7 @@ class BartStepDecoder:
                                              B, K, H, S_pad, float(self.scale), c.data_ptr()))
                     y = self._mod(c, L["co"], defer=True)
                 x, xp = add_ln(x, y, L["ln2"])
-                x, xp = add_ln(x, self._ffn(x, xp, L, defer=True, hand=hand), L["ln3"])
+                x, xp = add_ln(x, self._ffn(x, xp, L, defer=True, hand=hand, pairs=pairs), L["ln3"])
             st.t.add_(1)
             # The output projection leaves the graph as RAW accumulators when it goes through the split GEMM: its epilogue (alpha * acc +
             # final_logits_bias) is applied by `step` in the same pass that adds a per-query logit bias, if there is one -- torch.addmm would

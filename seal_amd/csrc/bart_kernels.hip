@@ -38,7 +38,8 @@ template <> __device__ __forceinline__ void st4<bf16>(bf16 *row, uint32_t i, flo
 
 // the split-GEMM operand planes of four consecutive elements of a row ([hi | hi | lo * 2^11] in fp16, row length d; see k_split_planes):
 // returns whether one of them is finite and beyond fp16's range
-static __device__ __forceinline__ bool store_planes4(__half *prow, uint32_t d, uint32_t i, float4 v)
+// pairs != 0: the row is [hi of 32 columns | lo * 2^11 of the same 32 columns] per 128-byte line, 2 d halves long (k_hgemm_nt's PAIRS operand)
+static __device__ __forceinline__ bool store_planes4(__half *prow, uint32_t d, uint32_t i, float4 v, uint32_t pairs = 0)
 {
     float in[4] = {v.x, v.y, v.z, v.w};
     unsigned short hi[4], lo[4];
@@ -60,6 +61,12 @@ static __device__ __forceinline__ bool store_planes4(__half *prow, uint32_t d, u
     __half *o = prow + 4 * (uint64_t)i;
     const uint2 hw = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
     const uint2 lw = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+    if (pairs) {
+        __half *q = prow + ((4 * i) >> 5) * 64 + ((4 * i) & 31u);
+        *(uint2 *)q = hw;
+        *(uint2 *)(q + 32) = lw;
+        return over;
+    }
     *(uint2 *)o = hw;
     *(uint2 *)(o + d) = hw;
     *(uint2 *)(o + 2 * (uint64_t)d) = lw;
@@ -67,7 +74,7 @@ static __device__ __forceinline__ bool store_planes4(__half *prow, uint32_t d, u
 }
 
 // the same for ONE element (lane = column: the wave's three stores are 128 contiguous bytes each)
-static __device__ __forceinline__ bool store_planes1(__half *prow, uint32_t d, uint32_t col, float v)
+static __device__ __forceinline__ bool store_planes1(__half *prow, uint32_t d, uint32_t col, float v, uint32_t pairs = 0)
 {
     asm volatile("" : "+v"(v));
     const float a = fabsf(v);
@@ -76,6 +83,7 @@ static __device__ __forceinline__ bool store_planes1(__half *prow, uint32_t d, u
     asm volatile("" : "+v"(hb));
     const unsigned short lb = __half_as_ushort(__float2half_rn((v - __half2float(__ushort_as_half(hb))) * 2048.f));
     unsigned short *o = reinterpret_cast<unsigned short *>(prow);
+    if (pairs) { o[(col >> 5) * 64 + (col & 31u)] = hb; o[(col >> 5) * 64 + 32 + (col & 31u)] = lb; return over; }
     o[col] = hb; o[(uint64_t)d + col] = hb; o[2 * (uint64_t)d + col] = lb;
     return over;
 }
@@ -106,7 +114,7 @@ template <typename T_>
 __global__ __launch_bounds__(256) void k_self_attn_step(const T_ *qkv, T_ *kcache, T_ *vcache, const int64_t *d_t,
                                                         uint32_t rows, uint32_t heads, uint32_t T, float scale, T_ *out,
                                                         int32_t *anc, const T_ *pb, float pa, uint32_t n_slabs = 1, uint64_t slab_stride = 0,
-                                                        __half *oplanes = nullptr, uint32_t *flag = nullptr)
+                                                        __half *oplanes = nullptr, uint32_t *flag = nullptr, uint32_t pairs = 0)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256) void k_self_attn_step(const T_ *qkv, T_ *kcach
     if (out) stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, o);
     // (oplanes: the output as the split operand of the projection that follows -- [hi | hi | lo * 2^11] in fp16 --, written here instead of by a
     //  pass of k_split_planes over `out`)
-    if (oplanes && __any((int)store_planes1(oplanes + (uint64_t)row * 3 * heads * 64, heads * 64, head * 64 + lane, o)) && lane == 0 && flag) atomicAdd(flag, 1u);
+    if (oplanes && __any((int)store_planes1(oplanes + (uint64_t)row * (pairs ? 2 : 3) * heads * 64, heads * 64, head * 64 + lane, o, pairs)) && lane == 0 && flag) atomicAdd(flag, 1u);
 }
 
 // K [64, S] and V [S, 64] of one (query, head) into LDS (s_k, s_v: 16-byte aligned, n = 64 * S elements each).  Every load of a thread is
@@ -241,7 +249,7 @@ template <typename T_>
 __global__ __launch_bounds__(1024) void k_cross_attn_step(const T_ *q, const T_ *ck, const T_ *cv, const T_ *bias,
                                                           uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S, float scale,
                                                           T_ *out, const T_ *qb = nullptr, float qa = 1.f, uint32_t n_slabs = 1, uint64_t slab_stride = 0,
-                                                          __half *oplanes = nullptr, uint32_t *flag = nullptr)
+                                                          __half *oplanes = nullptr, uint32_t *flag = nullptr, uint32_t pairs = 0)
 {
     __shared__ __attribute__((aligned(16))) float s_k[64 * 64];
     __shared__ __attribute__((aligned(16))) float s_v[64 * 64];
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(1024) void k_cross_attn_step(const T_ *q, const T_ 
         if (qb) qv = qa * qv + ldf(qb + head * 64 + lane);
         const float o = cross_attn_row(qv * scale, s_k, s_v, bi, S, lane);
         if (out) stf(out + (uint64_t)row * heads * 64 + head * 64 + lane, o);
-        if (oplanes && __any((int)store_planes1(oplanes + (uint64_t)row * 3 * heads * 64, heads * 64, head * 64 + lane, o)) && lane == 0 && flag) atomicAdd(flag, 1u);
+        if (oplanes && __any((int)store_planes1(oplanes + (uint64_t)row * (pairs ? 2 : 3) * heads * 64, heads * 64, head * 64 + lane, o, pairs)) && lane == 0 && flag) atomicAdd(flag, 1u);
     }
 }
 
@@ -400,7 +408,7 @@ template <typename T_>
 // (yb / ya: y = raw split-GEMM accumulators, the addend is ya * y + yb; see k_self_attn_step)
 __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y, const T_ *gamma, const T_ *beta,
                                                        uint32_t rows, uint32_t d, float eps, T_ *out, __half *planes, uint32_t *flag,
-                                                       const T_ *yb, float ya, uint32_t y_slabs, uint64_t y_slab_stride)
+                                                       const T_ *yb, float ya, uint32_t y_slabs, uint64_t y_slab_stride, uint32_t pairs)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y,
     }
     const float rstd = rsqrtf(wave_sum(var) / (float)d + eps);
     T_ *orow = out + (uint64_t)row * d;
-    __half *prow = planes ? planes + (uint64_t)row * 3 * d : nullptr;      // (fp32 only) the same values as the next GEMM's split operand
+    __half *prow = planes ? planes + (uint64_t)row * (pairs ? 2 : 3) * d : nullptr;      // (fp32 only) the same values as the next GEMM's split operand
     bool over = false;
 #pragma unroll
     for (uint32_t j0 = 0; j0 < 16; j0 += 4) {
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y,
                 const float4 r = make_float4((v[j].x - mean) * rstd * g[jj].x + bb[jj].x, (v[j].y - mean) * rstd * g[jj].y + bb[jj].y,
                                              (v[j].z - mean) * rstd * g[jj].z + bb[jj].z, (v[j].w - mean) * rstd * g[jj].w + bb[jj].w);
                 st4(orow, i, r);
-                if (prow) over |= store_planes4(prow, d, i, r);
+                if (prow) over |= store_planes4(prow, d, i, r, pairs);
             }
         }
     }
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const T_ *x, const T_ *y,
 // fc2's operand: planes of gelu(x) (the erf form, the arithmetic of torch's GeluCUDAKernelImpl: 0.5 * x * (1 + erf(x * M_SQRT1_2)))
 // (xb / xa: x = raw split-GEMM accumulators, gelu's argument is xa * x + xb; see k_self_attn_step)
 __global__ __launch_bounds__(256) void k_gelu_planes(const float *x, uint32_t rows, uint32_t d, __half *planes, uint32_t *flag, const float *xb, float xa,
-                                                     uint32_t n_slabs, uint64_t slab_stride)
+                                                     uint32_t n_slabs, uint64_t slab_stride, uint32_t pairs)
 {
     const uint32_t per_row = d / 4;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -520,7 +528,7 @@ __global__ __launch_bounds__(256) void k_gelu_planes(const float *x, uint32_t ro
     const float kAlpha = 0.70710678118654752440f;
     const float4 g = make_float4(0.5f * v.x * (1.f + erff(v.x * kAlpha)), 0.5f * v.y * (1.f + erff(v.y * kAlpha)),
                                  0.5f * v.z * (1.f + erff(v.z * kAlpha)), 0.5f * v.w * (1.f + erff(v.w * kAlpha)));
-    if (store_planes4(planes + (uint64_t)r * 3 * d, d, c, g) && flag) atomicAdd(flag, 1u);
+    if (store_planes4(planes + (uint64_t)r * (pairs ? 2 : 3) * d, d, c, g, pairs) && flag) atomicAdd(flag, 1u);
 }
 
 // alpha * (slab 0 + slab 1 + ...) + bias -> a finished fp32 product: for the consumers that are not kernels of this file (torch's fused attention in
@@ -574,11 +582,11 @@ static int cross_attn_step(void *stream, const void *q, const void *ck, const vo
 template <typename T_>
 static int add_layernorm(void *stream, const void *x, const void *y, const void *gamma, const void *beta, uint32_t rows,
                          uint32_t d, float eps, void *out, void *planes = nullptr, uint32_t *flag = nullptr, const void *yb = nullptr, float ya = 1.f,
-                         uint32_t y_slabs = 1, uint64_t y_slab_stride = 0)
+                         uint32_t y_slabs = 1, uint64_t y_slab_stride = 0, uint32_t pairs = 0)
 {
-    if (d % 4 || d > 4096) { fmi_set_error("sealnn_add_layernorm: d=%u unsupported", d); return FMI_ERR_UNSUPPORTED; }
+    if (d % 4 || d > 4096 || (pairs && d % 32)) { fmi_set_error("sealnn_add_layernorm: d=%u unsupported", d); return FMI_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_add_layernorm<T_>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const T_ *)x, (const T_ *)y,
-                       (const T_ *)gamma, (const T_ *)beta, rows, d, eps, (T_ *)out, (__half *)planes, flag, (const T_ *)yb, ya, y_slabs, y_slab_stride);
+                       (const T_ *)gamma, (const T_ *)beta, rows, d, eps, (T_ *)out, (__half *)planes, flag, (const T_ *)yb, ya, y_slabs, y_slab_stride, pairs);
     NNCHK();
     return FMI_OK;
 }
@@ -649,57 +657,81 @@ extern "C" int sealnn_cross_attn_step_bf16(void *stream, const void *q, const vo
 { return cross_attn_step<bf16>(stream, q, ck, cv, bias, batch, beams, heads, S, scale, out); }
 
 // the two step kernels between hand-written products: operands as raw (split-K) accumulators with their epilogue, results as split planes
-extern "C" int sealnn_self_attn_step_x(void *stream, const float *qkv_acc, uint32_t n_slabs, uint64_t slab_stride, const float *qkv_bias, float alpha,
+static int self_attn_step_x(void *stream, const float *qkv_acc, uint32_t n_slabs, uint64_t slab_stride, const float *qkv_bias, float alpha,
                                        float *kcache, float *vcache, const int64_t *d_t, uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out,
-                                       void *out_planes, uint32_t *d_flag, int32_t *anc)
+                                       void *out_planes, uint32_t *d_flag, int32_t *anc, uint32_t pairs)
 {
     if (T > FMI_MAX_LEVELS) { fmi_set_error("sealnn_self_attn_step_x: at most %u positions", FMI_MAX_LEVELS); return FMI_ERR_UNSUPPORTED; }
     if (!qkv_bias || (!out && !out_planes) || n_slabs < 1 || n_slabs > 16) { fmi_set_error("sealnn_self_attn_step_x: bad argument"); return FMI_ERR_ARG; }
     const uint32_t items = rows * heads;
     hipLaunchKernelGGL(k_self_attn_step<float>, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv_acc, kcache, vcache, d_t, rows, heads, T, scale,
-                       out, anc, qkv_bias, alpha, n_slabs, slab_stride, (__half *)out_planes, d_flag);
+                       out, anc, qkv_bias, alpha, n_slabs, slab_stride, (__half *)out_planes, d_flag, pairs);
     NNCHK();
     return FMI_OK;
 }
 
-extern "C" int sealnn_cross_attn_step_x(void *stream, const float *q_acc, uint32_t n_slabs, uint64_t slab_stride, const float *q_bias, float alpha,
+extern "C" int sealnn_self_attn_step_x(void *stream, const float *qkv_acc, uint32_t n_slabs, uint64_t slab_stride, const float *qkv_bias, float alpha,
+                                       float *kcache, float *vcache, const int64_t *d_t, uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out,
+                                       void *out_planes, uint32_t *d_flag, int32_t *anc)
+{ return self_attn_step_x(stream, qkv_acc, n_slabs, slab_stride, qkv_bias, alpha, kcache, vcache, d_t, rows, heads, T, scale, out, out_planes, d_flag, anc, 0); }
+extern "C" int sealnn_self_attn_step_x_pairs(void *stream, const float *qkv_acc, uint32_t n_slabs, uint64_t slab_stride, const float *qkv_bias, float alpha,
+                                             float *kcache, float *vcache, const int64_t *d_t, uint32_t rows, uint32_t heads, uint32_t T, float scale, float *out,
+                                             void *out_planes, uint32_t *d_flag, int32_t *anc)
+{ return self_attn_step_x(stream, qkv_acc, n_slabs, slab_stride, qkv_bias, alpha, kcache, vcache, d_t, rows, heads, T, scale, out, out_planes, d_flag, anc, 1); }
+
+static int cross_attn_step_x(void *stream, const float *q_acc, uint32_t n_slabs, uint64_t slab_stride, const float *q_bias, float alpha,
                                         const float *ck, const float *cv, const float *bias, uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S,
-                                        float scale, float *out, void *out_planes, uint32_t *d_flag)
+                                        float scale, float *out, void *out_planes, uint32_t *d_flag, uint32_t pairs)
 {
     if (S > 64) { fmi_set_error("sealnn_cross_attn_step_x: encoder length %u > 64", S); return FMI_ERR_UNSUPPORTED; }
     if ((!out && !out_planes) || n_slabs < 1 || n_slabs > 16) { fmi_set_error("sealnn_cross_attn_step_x: bad argument"); return FMI_ERR_ARG; }
     const uint32_t waves = beams < 8 ? beams : 8;
     hipLaunchKernelGGL(k_cross_attn_step<float>, dim3(batch * heads), dim3(waves * 64), 0, (hipStream_t)stream, q_acc, ck, cv, bias, batch, beams, heads, S,
-                       scale, out, q_bias, alpha, n_slabs, slab_stride, (__half *)out_planes, d_flag);
+                       scale, out, q_bias, alpha, n_slabs, slab_stride, (__half *)out_planes, d_flag, pairs);
     NNCHK();
     return FMI_OK;
 }
+extern "C" int sealnn_cross_attn_step_x(void *stream, const float *q_acc, uint32_t n_slabs, uint64_t slab_stride, const float *q_bias, float alpha,
+                                        const float *ck, const float *cv, const float *bias, uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S,
+                                        float scale, float *out, void *out_planes, uint32_t *d_flag)
+{ return cross_attn_step_x(stream, q_acc, n_slabs, slab_stride, q_bias, alpha, ck, cv, bias, batch, beams, heads, S, scale, out, out_planes, d_flag, 0); }
+extern "C" int sealnn_cross_attn_step_x_pairs(void *stream, const float *q_acc, uint32_t n_slabs, uint64_t slab_stride, const float *q_bias, float alpha,
+                                              const float *ck, const float *cv, const float *bias, uint32_t batch, uint32_t beams, uint32_t heads, uint32_t S,
+                                              float scale, float *out, void *out_planes, uint32_t *d_flag)
+{ return cross_attn_step_x(stream, q_acc, n_slabs, slab_stride, q_bias, alpha, ck, cv, bias, batch, beams, heads, S, scale, out, out_planes, d_flag, 1); }
 
 // ---- split GEMM operands (seal_amd/split_gemm.py): an fp32 row -> [hi | hi | lo'] in fp16, hi = fp16(x), lo' = fp16((x - hi) * 2^11) ----
 // x = hi + lo' * 2^-11 to 22 bits; the GEMM  [hi | hi | lo'] . [W_hi | W_lo | W_hi * 2^-11]^T  on the fp16 matrix cores (fp32
 // accumulate) is then x . W to fp32 accuracy (the dropped lo . lo term is 2^-22 of the product).  The lo plane is stored SCALED so that
 // it has the magnitude of x itself: no fp16 subnormals whatever the matrix cores do with them.  A finite |x| beyond the fp16 range
 // (65504) cannot be split: it is counted in *flag, which the caller checks (never seen in BART activations).
-__global__ __launch_bounds__(256) void k_split_planes(const float *x, uint32_t rows, uint32_t K, __half *out, uint32_t *flag)
+__global__ __launch_bounds__(256) void k_split_planes(const float *x, uint32_t rows, uint32_t K, __half *out, uint32_t *flag, uint32_t pairs)
 {
     const uint32_t per_row = K / 4;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)rows * per_row) return;
     const uint32_t r = (uint32_t)(i / per_row), c = (uint32_t)(i % per_row) * 4;
     const float4 v = *(const float4 *)(x + (uint64_t)r * K + c);
-    const bool over = store_planes4(out + (uint64_t)r * 3 * K, K, c / 4, v);
+    const bool over = store_planes4(out + (uint64_t)r * (pairs ? 2 : 3) * K, K, c / 4, v, pairs);
     if (over && flag) atomicAdd(flag, 1u);
 }
 
-extern "C" int sealnn_split_planes(void *stream, const float *x, uint32_t rows, uint32_t K, void *out, uint32_t *d_flag)
+static int split_planes(void *stream, const float *x, uint32_t rows, uint32_t K, void *out, uint32_t *d_flag, uint32_t pairs)
 {
-    if (K % 4) { fmi_set_error("sealnn_split_planes: K=%u is not a multiple of 4", K); return FMI_ERR_UNSUPPORTED; }
+    if (K % 4 || (pairs && K % 32)) { fmi_set_error("sealnn_split_planes: K=%u is not a multiple of %u", K, pairs ? 32 : 4); return FMI_ERR_UNSUPPORTED; }
     const uint64_t n = (uint64_t)rows * (K / 4);
     if (!n) return FMI_OK;
-    hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows, K, (__half *)out, d_flag);
+    hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows, K, (__half *)out, d_flag, pairs);
     NNCHK();
     return FMI_OK;
 }
+extern "C" int sealnn_split_planes(void *stream, const float *x, uint32_t rows, uint32_t K, void *out, uint32_t *d_flag)
+{ return split_planes(stream, x, rows, K, out, d_flag, 0); }
+
+// ---- the PAIRS forms: the same kernels writing their planes as [hi of 32 columns | lo * 2^11 of the same 32 columns] per 128-byte line, rows of 2 d halves:
+// the operand of sealnn_hgemm_nt's PAIRS products (config bit 29; hgemm_kernels.hip), two thirds of the three-block operand ----
+extern "C" int sealnn_split_planes_pairs(void *stream, const float *x, uint32_t rows, uint32_t K, void *out, uint32_t *d_flag)
+{ return split_planes(stream, x, rows, K, out, d_flag, 1); }
 
 extern "C" int sealnn_add_layernorm(void *stream, const float *x, const float *y, const float *gamma, const float *beta, uint32_t rows,
                                     uint32_t d, float eps, float *out)
@@ -711,12 +743,12 @@ extern "C" int sealnn_add_layernorm_planes(void *stream, const float *x, const f
     return add_layernorm<float>(stream, x, y, gamma, beta, rows, d, eps, out, planes, d_flag);
 }
 static int gelu_planes(void *stream, const float *x, uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag, const float *xb, float xa,
-                       uint32_t n_slabs = 1, uint64_t slab_stride = 0)
+                       uint32_t n_slabs = 1, uint64_t slab_stride = 0, uint32_t pairs = 0)
 {
-    if (d % 4 || !planes) { fmi_set_error("sealnn_gelu_planes: d=%u must be a multiple of 4 (and a plane buffer given)", d); return FMI_ERR_UNSUPPORTED; }
+    if (d % 4 || !planes || (pairs && d % 32)) { fmi_set_error("sealnn_gelu_planes: d=%u must be a multiple of 4 (and a plane buffer given)", d); return FMI_ERR_UNSUPPORTED; }
     const uint64_t n = (uint64_t)rows * (d / 4);
     if (!n) return FMI_OK;
-    hipLaunchKernelGGL(k_gelu_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows, d, (__half *)planes, d_flag, xb, xa, n_slabs, slab_stride);
+    hipLaunchKernelGGL(k_gelu_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows, d, (__half *)planes, d_flag, xb, xa, n_slabs, slab_stride, pairs);
     NNCHK();
     return FMI_OK;
 }
@@ -763,6 +795,19 @@ extern "C" int sealnn_gelu_planes_acc_slabs(void *stream, const float *x_acc, ui
 {
     if (!x_bias || n_slabs < 1 || n_slabs > 16) { fmi_set_error("sealnn_gelu_planes_acc_slabs: a bias and 1..16 slabs"); return FMI_ERR_ARG; }
     return gelu_planes(stream, x_acc, rows, d, planes, d_flag, x_bias, alpha, n_slabs, slab_stride);
+}
+extern "C" int sealnn_add_layernorm_acc_slabs_pairs(void *stream, const float *x, const float *y_acc, uint32_t n_slabs, uint64_t slab_stride, const float *y_bias,
+                                                    float alpha, const float *gamma, const float *beta, uint32_t rows, uint32_t d, float eps, float *out,
+                                                    void *planes, uint32_t *d_flag)
+{
+    if (!y_bias || !planes || n_slabs < 1 || n_slabs > 16) { fmi_set_error("sealnn_add_layernorm_acc_slabs_pairs: a bias, a plane buffer and 1..16 slabs"); return FMI_ERR_ARG; }
+    return add_layernorm<float>(stream, x, y_acc, gamma, beta, rows, d, eps, out, planes, d_flag, y_bias, alpha, n_slabs, slab_stride, 1);
+}
+extern "C" int sealnn_gelu_planes_acc_slabs_pairs(void *stream, const float *x_acc, uint32_t n_slabs, uint64_t slab_stride, const float *x_bias, float alpha,
+                                                  uint32_t rows, uint32_t d, void *planes, uint32_t *d_flag)
+{
+    if (!x_bias || n_slabs < 1 || n_slabs > 16) { fmi_set_error("sealnn_gelu_planes_acc_slabs_pairs: a bias and 1..16 slabs"); return FMI_ERR_ARG; }
+    return gelu_planes(stream, x_acc, rows, d, planes, d_flag, x_bias, alpha, n_slabs, slab_stride, 1);
 }
 extern "C" int sealnn_finish_product(void *stream, const float *acc, uint32_t n_slabs, uint64_t slab_stride, const float *bias, float alpha, uint32_t rows,
                                      uint32_t n, float *out)

@@ -72,7 +72,12 @@ __device__ __forceinline__ void wait_all_but()      // all LDS-DMA but the newes
 // groups' accumulators are summed through the LDS at the end, in group order (deterministic).  A skinny product (a few hundred rows, a
 // long K) has too few C tiles for 256 CUs and a 4-wave workgroup waits for the latency of every K step alone: K groups put 8 or 16 waves
 // on the CU that overlap one another's waits -- split-K without slabs in memory or a second kernel.
-template <uint32_t BM, uint32_t BN, uint32_t NS, uint32_t KG>
+// PAIRS: the operands are the hi / lo planes of a split fp32 operand INTERLEAVED per 32 columns -- a 128-byte line of a row = [hi of 32 columns | lo * 2^11
+// (A) resp. lo (W) of the same 32 columns] (sealnn_*_pairs write A, seal_amd/split_gemm.py W) -- and a K step of 64 halves is the three products of
+// those 32 columns: hi.hi + hi.lo into one accumulator, (lo 2^11).hi into a second one that joins the first times 2^-11 at the end.  The three-block
+// layout [hi | hi | lo 2^11] x [hi | lo | hi 2^-11] feeds the matrix cores the same three products from six tiles of which two are copies: here four
+// tiles travel, two thirds of the bytes through the load path that bounds these products (and of the LDS reads), for the same MFMAs.
+template <uint32_t BM, uint32_t BN, uint32_t NS, uint32_t KG, bool PAIRS = false>
 __global__ __launch_bounds__(256 * KG) void k_hgemm_nt(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, float *__restrict__ C,
                                                   uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t k_per_slice, uint64_t slab_stride,
                                                   uint32_t m_fastest)
@@ -105,10 +110,14 @@ __global__ __launch_bounds__(256 * KG) void k_hgemm_nt(const _Float16 *__restric
     C += (uint64_t)blockIdx.z * slab_stride;
 
     float4v acc[FM][FN];
+    float4v acc2[PAIRS ? FM : 1][PAIRS ? FN : 1];             // (PAIRS) the (lo 2^11) . hi products
 #pragma unroll
     for (uint32_t i = 0; i < FM; i++)
 #pragma unroll
-        for (uint32_t j = 0; j < FN; j++) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+        for (uint32_t j = 0; j < FN; j++) {
+            acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+            if constexpr (PAIRS) acc2[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+        }
 
     auto issue = [&](uint32_t kt, uint32_t buf) {
         unsigned char *st = lds_grp + buf * STAGE;
@@ -126,12 +135,23 @@ __global__ __launch_bounds__(256 * KG) void k_hgemm_nt(const _Float16 *__restric
 #pragma unroll
             for (uint32_t j = 0; j < FN; j++) fb[ks][j] = read_frag(tb, wn * TN + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
         }
-#pragma unroll
-        for (uint32_t ks = 0; ks < 2; ks++)
+        if constexpr (PAIRS) {
 #pragma unroll
             for (uint32_t i = 0; i < FM; i++)
 #pragma unroll
-                for (uint32_t j = 0; j < FN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+                for (uint32_t j = 0; j < FN; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[1][j], acc[i][j], 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1][i], fb[0][j], acc2[i][j], 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (uint32_t ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (uint32_t i = 0; i < FM; i++)
+#pragma unroll
+                    for (uint32_t j = 0; j < FN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+        }
     };
 
     if constexpr (NS >= 2) {
@@ -165,6 +185,12 @@ __global__ __launch_bounds__(256 * KG) void k_hgemm_nt(const _Float16 *__restric
         }
     }
 
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (uint32_t i = 0; i < FM; i++)
+#pragma unroll
+            for (uint32_t j = 0; j < FN; j++) acc[i][j] += acc2[i][j] * 0x1p-11f;
+    }
     if constexpr (KG > 1) {
         // the groups' partial tiles -> group 0, through the (now idle) stage buffers: group g > 0 parks its accumulators as [fragment][lane]
         // float4 (conflict-free 16-byte stores), group 0 adds them in group order
@@ -224,7 +250,7 @@ __global__ __launch_bounds__(256 * KG) void k_hgemm_nt(const _Float16 *__restric
 // without reads and MFMAs 1630 (profiles/r6_hgemm_tall_decomposition.txt): the two overlap, and it is the load path that is left.
 constexpr uint32_t TALL_BM = 320;
 
-template <uint32_t BN, uint32_t NS, uint32_t DBG = 0>      // DBG (probes only): 1 = no LDS-DMA after the prologue, 2 = no fragment reads / MFMAs
+template <uint32_t BN, uint32_t NS, uint32_t DBG = 0, bool PAIRS = false>      // PAIRS: see k_hgemm_nt;  DBG (probes only): 1 = no LDS-DMA after the prologue, 2 = no fragment reads / MFMAs
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_hgemm_tall(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, float *__restrict__ C,
                                                     uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t k_per_slice, uint64_t slab_stride,
                                                     uint32_t tiles_m, uint32_t tiles_n)
@@ -280,10 +306,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
 
     float4v acc[FM][FN];
+    float4v acc2[PAIRS ? FM : 1][PAIRS ? FN : 1];             // (PAIRS) the (lo 2^11) . hi products
 #pragma unroll
     for (uint32_t i = 0; i < FM; i++)
 #pragma unroll
-        for (uint32_t j = 0; j < FN; j++) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+        for (uint32_t j = 0; j < FN; j++) {
+            acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+            if constexpr (PAIRS) acc2[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+        }
 
     // prologue: NS - 1 stages in flight
 #pragma unroll
@@ -340,6 +370,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (uint32_t i = 0; i < FM; i++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[1][i]) : "v"(va1), "n"(i * 16 * ROW_BYTES) : "memory");
             static_assert(NL <= 2 * FM, "a piece per MFMA row");
+            if constexpr (PAIRS) {
+                // three products of the step's 32 columns: hi . hi as soon as the hi fragments are in, then hi . lo and (lo 2^11) . hi
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM + FN) : "memory");
+#pragma unroll
+                for (uint32_t j = 0; j < FN; j++) asm volatile("" : "+v"(fb[0][j]));
+#pragma unroll
+                for (uint32_t i = 0; i < FM; i++) asm volatile("" : "+v"(fa[0][i]));
+#pragma unroll
+                for (uint32_t i = 0; i < FM; i++) {
+                    if constexpr (MORE && INTERLEAVE) {
+                        if (i < NL) piece(i, nxt, nbuf);
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < FN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (uint32_t j = 0; j < FN; j++) asm volatile("" : "+v"(fb[1][j]));
+#pragma unroll
+                for (uint32_t i = 0; i < FM; i++) asm volatile("" : "+v"(fa[1][i]));
+#pragma unroll
+                for (uint32_t i = 0; i < FM; i++) {
+                    if constexpr (MORE && INTERLEAVE) {
+                        if (FM + i < NL) piece(FM + i, nxt, nbuf);
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < FN; j++) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[1][j], acc[i][j], 0, 0, 0);
+                        acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1][i], fb[0][j], acc2[i][j], 0, 0, 0);
+                    }
+                }
+            } else {
 #pragma unroll
             for (uint32_t ks = 0; ks < 2; ks++) {
                 // the K half's fragments are in: all reads but the other half's (ks = 0) / all (ks = 1); tied to the registers the MFMAs read
@@ -358,6 +420,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (uint32_t j = 0; j < FN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
                 }
             }
+            }
         };
         if constexpr (DBG == 2) issue_all();
         else compute(std::true_type{});
@@ -374,6 +437,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if (kt < nk) step(kt, F{}, std::integral_constant<uint32_t, 0>{});
 
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (uint32_t i = 0; i < FM; i++)
+#pragma unroll
+            for (uint32_t j = 0; j < FN; j++) acc[i][j] += acc2[i][j] * 0x1p-11f;
+    }
     if constexpr (DBG == 3) {
         float keep = 0.f;
 #pragma unroll
@@ -406,46 +475,46 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <uint32_t BN, uint32_t NS, uint32_t DBG = 0>
+template <uint32_t BN, uint32_t NS, uint32_t DBG = 0, bool PAIRS = false>
 int launch_tall(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t slices)
 {
     const uint32_t tiles_m = (M + TALL_BM - 1) / TALL_BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds = (size_t)NS * (TALL_BM + BN) * ROW_BYTES;
-    (void)hipFuncSetAttribute((const void *)k_hgemm_tall<BN, NS, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_hgemm_tall<BN, NS, DBG>), dim3(tiles_m * tiles_n * slices), dim3(512), lds, st, (const _Float16 *)A, (const _Float16 *)W, C, M, N, K, ldc,
+    (void)hipFuncSetAttribute((const void *)k_hgemm_tall<BN, NS, DBG, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_hgemm_tall<BN, NS, DBG, PAIRS>), dim3(tiles_m * tiles_n * slices), dim3(512), lds, st, (const _Float16 *)A, (const _Float16 *)W, C, M, N, K, ldc,
                        K / slices, (uint64_t)M * ldc, tiles_m, tiles_n);
     return hipGetLastError() == hipSuccess ? FMI_OK : FMI_ERR_HIP;
 }
 
-template <uint32_t BM, uint32_t BN, uint32_t NS, uint32_t KG>
+template <uint32_t BM, uint32_t BN, uint32_t NS, uint32_t KG, bool PAIRS>
 int launch_cfg(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t slices, uint32_t m_fastest)
 {
     const dim3 grid = m_fastest ? dim3(((N + BN - 1) / BN) * ((M + BM - 1) / BM), 1, slices) : dim3((N + BN - 1) / BN, (M + BM - 1) / BM, slices);
     const size_t lds = (size_t)KG * NS * (BM + BN) * ROW_BYTES;
     if ((K / slices) % (BK * KG)) { fmi_set_error("sealnn_hgemm_nt: %u K steps per slice do not split over %u K groups", K / slices / BK, KG); return FMI_ERR_ARG; }
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_hgemm_nt<BM, BN, NS, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_hgemm_nt<BM, BN, NS, KG>), grid, dim3(256 * KG), lds, st, (const _Float16 *)A, (const _Float16 *)W, C, M, N, K, ldc, K / slices,
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_hgemm_nt<BM, BN, NS, KG, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_hgemm_nt<BM, BN, NS, KG, PAIRS>), grid, dim3(256 * KG), lds, st, (const _Float16 *)A, (const _Float16 *)W, C, M, N, K, ldc, K / slices,
                        (uint64_t)M * ldc, m_fastest);
     return hipGetLastError() == hipSuccess ? FMI_OK : FMI_ERR_HIP;
 }
 
 // (the configurations that are instantiated: every tile with 1..3 stages and one K group; the skinny-product forms -- 2 and 4 K groups --
 //  for the two small tiles, two stages)
-template <uint32_t BM, uint32_t BN>
+template <uint32_t BM, uint32_t BN, bool PAIRS>
 int launch(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t slices, uint32_t stages,
            uint32_t kgroups, uint32_t mf)
 {
     if (kgroups == 1) {
         switch (stages) {
-        case 1: return launch_cfg<BM, BN, 1, 1>(st, A, W, C, M, N, K, ldc, slices, mf);
-        case 2: return launch_cfg<BM, BN, 2, 1>(st, A, W, C, M, N, K, ldc, slices, mf);
-        case 3: return launch_cfg<BM, BN, 3, 1>(st, A, W, C, M, N, K, ldc, slices, mf);
+        case 1: return launch_cfg<BM, BN, 1, 1, PAIRS>(st, A, W, C, M, N, K, ldc, slices, mf);
+        case 2: return launch_cfg<BM, BN, 2, 1, PAIRS>(st, A, W, C, M, N, K, ldc, slices, mf);
+        case 3: return launch_cfg<BM, BN, 3, 1, PAIRS>(st, A, W, C, M, N, K, ldc, slices, mf);
         default: break;
         }
     } else if constexpr (BM * BN <= 128 * 64) {
-        if (stages == 2 && kgroups == 2) return launch_cfg<BM, BN, 2, 2>(st, A, W, C, M, N, K, ldc, slices, mf);
+        if (stages == 2 && kgroups == 2) return launch_cfg<BM, BN, 2, 2, PAIRS>(st, A, W, C, M, N, K, ldc, slices, mf);
         if constexpr (BM * BN <= 64 * 64) {
-            if (stages == 2 && kgroups == 4) return launch_cfg<BM, BN, 2, 4>(st, A, W, C, M, N, K, ldc, slices, mf);
+            if (stages == 2 && kgroups == 4) return launch_cfg<BM, BN, 2, 4, PAIRS>(st, A, W, C, M, N, K, ldc, slices, mf);
         }
     }
     fmi_set_error("sealnn_hgemm_nt: no kernel for %u x %u tiles with %u stages and %u K groups", BM, BN, stages, kgroups);
@@ -456,7 +525,8 @@ int launch(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, u
 
 // config: 0 = pick by shape; else tile (1 = 128 x 128, 2 = 64 x 64, 3 = 128 x 64, 4 = 64 x 128; + 128: row tiles fastest, XCD-grouped; 5 = 320 x 128,
 // 6 = 320 x 64: the tall tiles of 8 waves) | stages << 8 (LDS stages 1..3; 0: two) |
-// kgroups << 12 (K groups of 4 waves per workgroup: 1, 2 (tiles 2..4), 4 (tile 2); 0: one) | slices << 16 (split-K over workgroups: slab s of C
+// kgroups << 12 (K groups of 4 waves per workgroup: 1, 2 (tiles 2..4), 4 (tile 2); 0: one) | 1 << 29: the operands are hi / lo PAIRS (k_hgemm_nt) |
+// slices << 16 (up to 8191; split-K over workgroups: slab s of C
 // at C + s * M * ldc, the caller sums the slabs).  Probes and tests pass it explicitly.
 extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float *c, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t config)
 {
@@ -464,7 +534,8 @@ extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float
     if (K == 0 || K % BK) { fmi_set_error("sealnn_hgemm_nt: K = %u must be a multiple of %u", K, BK); return FMI_ERR_UNSUPPORTED; }
     if (((uintptr_t)a | (uintptr_t)w) & 15) { fmi_set_error("sealnn_hgemm_nt: operands must be 16-byte aligned"); return FMI_ERR_ARG; }
     const uint32_t mf = (config >> 7) & 1u;          // bit 7 of the tile byte: row tile fastest + XCD remap (wide-N products)
-    uint32_t tile = config & 0x7f, stages = (config >> 8) & 0xf, kgroups = (config >> 12) & 0xf, slices = ((config >> 16) & 0x3fff) ? ((config >> 16) & 0x3fff) : 1;
+    const bool pairs = (config >> 29) & 1u;          // the operands are hi / lo PAIRS per 32 columns (K = 2 x in_features): three products per K step
+    uint32_t tile = config & 0x7f, stages = (config >> 8) & 0xf, kgroups = (config >> 12) & 0xf, slices = ((config >> 16) & 0x1fff) ? ((config >> 16) & 0x1fff) : 1;
     if (stages == 0) stages = 2;
     if (kgroups == 0) kgroups = 1;
     if ((K / BK) % slices) { fmi_set_error("sealnn_hgemm_nt: %u K steps do not split into %u slices", K / BK, slices); return FMI_ERR_ARG; }
@@ -483,6 +554,11 @@ extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float
             fmi_set_error("sealnn_hgemm_nt: no tall-tile kernel with %u stages and %u K groups", stages, kgroups);
             return FMI_ERR_ARG;
         }
+        if (pairs) {
+            if (tile == 5) return launch_tall<128, 2, 0, true>(st, a, w, c, M, N, K, ldc, slices);
+            if (tile == 7) return stages == 2 ? launch_tall<96, 2, 0, true>(st, a, w, c, M, N, K, ldc, slices) : launch_tall<96, 3, 0, true>(st, a, w, c, M, N, K, ldc, slices);
+            return stages == 2 ? launch_tall<64, 2, 0, true>(st, a, w, c, M, N, K, ldc, slices) : launch_tall<64, 3, 0, true>(st, a, w, c, M, N, K, ldc, slices);
+        }
         if (tile == 5) return launch_tall<128, 2>(st, a, w, c, M, N, K, ldc, slices);
         // (config >> 30, probes only: 1 / 2 = the 320 x 64 kernel without its LDS-DMA / without its reads and MFMAs, 3 = step timestamps instead of C)
         if (tile == 7 && (config >> 30) == 3) return launch_tall<96, 3, 3>(st, a, w, c, M, N, K, ldc, slices);
@@ -491,11 +567,20 @@ extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float
         if (config >> 30) return (config >> 30) == 1 ? launch_tall<64, 3, 1>(st, a, w, c, M, N, K, ldc, slices) : launch_tall<64, 3, 2>(st, a, w, c, M, N, K, ldc, slices);
         return stages == 2 ? launch_tall<64, 2>(st, a, w, c, M, N, K, ldc, slices) : launch_tall<64, 3>(st, a, w, c, M, N, K, ldc, slices);
     }
+    if (pairs) {
+        switch (tile) {
+        case 1: return launch<128, 128, true>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
+        case 2: return launch<64, 64, true>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
+        case 3: return launch<128, 64, true>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
+        case 4: return launch<64, 128, true>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
+        default: fmi_set_error("sealnn_hgemm_nt: unknown tile %u", tile); return FMI_ERR_ARG;
+        }
+    }
     switch (tile) {
-    case 1: return launch<128, 128>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
-    case 2: return launch<64, 64>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
-    case 3: return launch<128, 64>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
-    case 4: return launch<64, 128>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
+    case 1: return launch<128, 128, false>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
+    case 2: return launch<64, 64, false>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
+    case 3: return launch<128, 64, false>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
+    case 4: return launch<64, 128, false>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
     default: fmi_set_error("sealnn_hgemm_nt: unknown tile %u", tile); return FMI_ERR_ARG;
     }
 }

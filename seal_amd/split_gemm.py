@@ -174,16 +174,36 @@ HAND_CONFIGS = {
     (4096, 3072): ((320, _TALL(6, 3, 4)), (640, _TALL(6, 3, 2))),                                                    # fc1 (GELU adds the slabs)
     (50265, 3072): ((640, (1 + 128) | (2 << 8) | (1 << 12) | (1 << 16)),),                                           # lm_head (one slab)
 }
+# PAIRS (round 6): inside a decode step whose every product is the hand-written kernel's, the operand planes are hi / lo PAIRS per 32 columns -- a 128-byte
+# line of a row = [hi of 32 columns | lo * 2^11 (activations) resp. lo (weights) of the same 32] -- and a K step is the three products of those columns
+# (hi.hi + hi.lo into one accumulator, (lo 2^11).hi into a second that joins it times 2^-11).  The three-block operand [hi | hi | lo 2^11] x [hi | lo | hi 2^-11]
+# feeds the matrix cores the same three products from six tiles of which two are copies; here four tiles travel: two thirds of the bytes through the CU's
+# load path, which is what bounds these products (hgemm_kernels.hip).  The kernels that write the planes have _pairs twins (include/sealnn.h), the weights'
+# pairs are made from their planes on first use.  Same terms, another order of the fp32 additions.  ``PAIRS = False``: three blocks everywhere.
+PAIRS = True
+PAIRS_BIT = 1 << 29
+# (N, 3K) -> {max rows: config} for the PAIRS form (2K / 64 K steps); profiles/r6_hgemm_probe_pairs.txt, us, three blocks -> pairs, W from memory:
+# 600 rows: d x d 11.5 -> 8.7, qkv 21.2 -> 18.2, fc1 28.1 -> 21.3, fc2 26.0 -> 21.3, lm_head 249 -> 209; 300 rows: 7.8 -> 6.6, 16.9 -> 10.5, 17.2 -> 14.7,
+# 17.3 -> 16.1, 163 -> 114 (a third fewer bytes buys 14 .. 38 %: with the load path relieved the reads-and-MFMA phase of a step shows)
+_T4 = lambda tile, stages, kgroups, slices: tile | (stages << 8) | (kgroups << 12) | (slices << 16)
+HAND_CONFIGS_PAIRS = {
+    (1024, 12288): ((320, _TALL(6, 3, 16)), (640, _TALL(6, 3, 8))),
+    (1024, 3072): ((320, _T4(2, 2, 2, 4)), (640, _T4(2, 2, 1, 4))),
+    (3072, 3072): ((320, _T4(2, 2, 2, 2)), (640, _TALL(6, 3, 2))),
+    (4096, 3072): ((320, _T4(4, 2, 1, 4)), (640, _TALL(6, 3, 2))),
+    (50265, 3072): ((320, _TALL(5, 2, 1)), (640, _TALL(7, 3, 1))),
+}
 # library GEMMs issued through this module and BartStepDecoder._lin since the process started: a step decoder that captures its graph reads it
 # before and after to learn whether the step is free of them (BartStepDecoder._step_static)
 LIBRARY_GEMMS = [0]
 
 
-def hand_config(rows: int, n: int, k3: int):
-    """the sealnn_hgemm_nt configuration for a [rows, k3] x [n, k3]^T product, or None: the library's GEMM serves it"""
+def hand_config(rows: int, n: int, k3: int, pairs: bool = False):
+    """the sealnn_hgemm_nt configuration for a [rows, k3] x [n, k3]^T product (``pairs``: as [rows, 2 k3 / 3] pair planes), or None: the
+    library's GEMM serves it"""
     if not HAND_GEMM:
         return None
-    for max_rows, cfg in HAND_CONFIGS.get((n, k3), ()):
+    for max_rows, cfg in (HAND_CONFIGS_PAIRS if pairs else HAND_CONFIGS).get((n, k3), ()):
         if rows <= max_rows:
             return cfg
     return None
@@ -214,18 +234,31 @@ class SplitLinear:
                                         _flag(x.device).data_ptr()))
         return self.from_planes(a, defer, slabs_ok)
 
+    def pair_planes(self) -> torch.Tensor:
+        """the weight as hi / lo pairs per 32 columns, [N, 2K] fp16 (made from the planes on first use)"""
+        p = self.__dict__.get("_pairs")
+        if p is None:
+            if self.K % 32:
+                raise ValueError(f"SplitLinear: pair planes need K={self.K} to be a multiple of 32")
+            hi, lo = self.planes[:, :self.K].reshape(self.N, -1, 32), self.planes[:, self.K:2 * self.K].reshape(self.N, -1, 32)
+            p = self._pairs = torch.stack((hi, lo), 2).reshape(self.N, 2 * self.K).contiguous()
+        return p
+
     def _hand(self, planes: torch.Tensor):
-        """the product's raw accumulators [slices, rows, N] from sealnn_hgemm_nt, or None where the library serves it"""
-        if not planes.is_cuda or not planes.is_contiguous():
-            return None
-        cfg = hand_config(planes.shape[0], self.N, planes.shape[1])
+        """the product's raw accumulators [slices, rows, N] from sealnn_hgemm_nt, or None where the library serves it (pair planes -- [rows, 2K]
+        -- have no other server: an error then)"""
+        pairs = planes.shape[1] == 2 * self.K
+        cfg = hand_config(planes.shape[0], self.N, 3 * self.K, pairs) if planes.is_cuda and planes.is_contiguous() else None
         if cfg is None:
+            if pairs:
+                raise RuntimeError(f"SplitLinear: no hand-written configuration for pair planes of a [{planes.shape[0]}, {self.K}] x [{self.N}, {self.K}]^T product")
             return None
         from ._lib import check, lib
-        slices = max(1, cfg >> 16)
+        slices = max(1, (cfg >> 16) & 0x1fff)
         acc = torch.empty(slices, planes.shape[0], self.N, dtype=torch.float32, device=planes.device)
-        check(lib().sealnn_hgemm_nt(torch.cuda.current_stream(planes.device).cuda_stream, planes.data_ptr(), self.planes.data_ptr(), acc.data_ptr(),
-                                    planes.shape[0], self.N, planes.shape[1], self.N, cfg))
+        w = self.pair_planes() if pairs else self.planes
+        check(lib().sealnn_hgemm_nt(torch.cuda.current_stream(planes.device).cuda_stream, planes.data_ptr(), w.data_ptr(), acc.data_ptr(),
+                                    planes.shape[0], self.N, planes.shape[1], self.N, cfg | (PAIRS_BIT if pairs else 0)))
         return acc
 
     def from_planes(self, planes: torch.Tensor, defer: bool = False, slabs_ok: bool = False):
@@ -233,7 +266,7 @@ class SplitLinear:
         ``slabs_ok``: the consumer adds split-K slabs itself, so the hand-written kernel may serve the product).  A FINISHED product
         (``defer`` off) of a shape the hand-written kernel has a configuration for runs there too, with ``sealnn_finish_product`` behind it."""
         if defer:
-            acc = self._hand(planes) if slabs_ok else None
+            acc = self._hand(planes) if slabs_ok or planes.shape[1] == 2 * self.K else None
             if acc is not None:
                 return Deferred(acc if acc.shape[0] > 1 else acc[0], self.bias, self.alpha, slabs=acc.shape[0])
             LIBRARY_GEMMS[0] += 1 if planes.is_cuda else 0

@@ -417,6 +417,76 @@ def test_gelu_adds_the_slabs_of_a_split_k_fc1():
 
 
 @pytest.mark.gpu
+def test_pair_planes_and_the_three_products_of_a_k_step():
+    """the PAIRS operand (hi / lo per 32 columns, [rows, 2K]): every kernel that writes planes writes the same 16-bit values in its _pairs form as in the
+    three-block form; ``sealnn_hgemm_nt`` with the PAIRS bit on those operands == the three-block product -- EXACTLY on one-hot activations (a misplaced
+    column or plane cannot pass), to fp32 summation noise on random ones, in 4-wave and tall tiles, with split-K slabs -- and == fp64 ``F.linear`` to
+    split-GEMM accuracy"""
+    from seal_amd import split_gemm
+    from seal_amd._lib import check, lib
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    g = torch.Generator().manual_seed(21)
+    flag = split_gemm._flag(dev).data_ptr()
+
+    def as_pairs(three, k):
+        hi, lo = three[:, :k].reshape(three.shape[0], -1, 32), three[:, 2 * k:].reshape(three.shape[0], -1, 32)
+        assert torch.equal(three[:, :k], three[:, k:2 * k])
+        return torch.stack((hi, lo), 2).reshape(three.shape[0], 2 * k)
+    # the writers: split_planes, gelu, add + LayerNorm (behind slabs)
+    rows, d = 77, 1024
+    x = (torch.randn(rows, d, generator=g) * 3).to(dev)
+    three, two = torch.empty(rows, 3 * d, dtype=torch.float16, device=dev), torch.empty(rows, 2 * d, dtype=torch.float16, device=dev)
+    check(lib().sealnn_split_planes(st, x.data_ptr(), rows, d, three.data_ptr(), flag))
+    check(lib().sealnn_split_planes_pairs(st, x.data_ptr(), rows, d, two.data_ptr(), flag))
+    assert torch.equal(as_pairs(three, d).view(torch.int16), two.view(torch.int16))
+    slabs, bias = (torch.randn(3, rows, d, generator=g)).to(dev), torch.randn(d, generator=g).to(dev)
+    check(lib().sealnn_gelu_planes_acc_slabs(st, slabs.data_ptr(), 3, slabs.stride(0), bias.data_ptr(), 0.5, rows, d, three.data_ptr(), flag))
+    check(lib().sealnn_gelu_planes_acc_slabs_pairs(st, slabs.data_ptr(), 3, slabs.stride(0), bias.data_ptr(), 0.5, rows, d, two.data_ptr(), flag))
+    assert torch.equal(as_pairs(three, d).view(torch.int16), two.view(torch.int16))
+    gamma, beta = torch.randn(d, generator=g).to(dev), torch.randn(d, generator=g).to(dev)
+    o3, o2 = torch.empty(rows, d, device=dev), torch.empty(rows, d, device=dev)
+    check(lib().sealnn_add_layernorm_acc_slabs(st, x.data_ptr(), slabs.data_ptr(), 3, slabs.stride(0), bias.data_ptr(), 0.5, gamma.data_ptr(), beta.data_ptr(),
+                                               rows, d, 1e-5, o3.data_ptr(), three.data_ptr(), flag))
+    check(lib().sealnn_add_layernorm_acc_slabs_pairs(st, x.data_ptr(), slabs.data_ptr(), 3, slabs.stride(0), bias.data_ptr(), 0.5, gamma.data_ptr(),
+                                                     beta.data_ptr(), rows, d, 1e-5, o2.data_ptr(), two.data_ptr(), flag))
+    assert torch.equal(o3, o2) and torch.equal(as_pairs(three, d).view(torch.int16), two.view(torch.int16))
+    # the product
+    for rows, n, k in ((600, 1024, 1024), (300, 4096, 1024), (37, 200, 256), (321, 1024, 4096)):
+        w = (torch.randn(n, k, generator=g) * 0.05).to(dev)
+        lin = split_gemm.SplitLinear(w, torch.zeros(n, device=dev))
+        wp = lin.pair_planes()
+        assert torch.equal(wp.view(n, -1, 2, 32)[:, :, 0].reshape(n, k), lin.planes[:, :k]) and torch.equal(wp.view(n, -1, 2, 32)[:, :, 1].reshape(n, k), lin.planes[:, k:2 * k])
+        x = torch.randn(rows, k, generator=g).to(dev)
+        x1 = torch.zeros(rows, k, device=dev)
+        x1[torch.arange(rows, device=dev), (torch.arange(rows, device=dev) * 7 + 3) % k] = 1.0
+        ref = torch.nn.functional.linear(x.double(), w.double()).float()
+        n_cfg = 0
+        for xx, exact in ((x, False), (x1, True)):
+            a3, a2 = torch.empty(rows, 3 * k, dtype=torch.float16, device=dev), torch.empty(rows, 2 * k, dtype=torch.float16, device=dev)
+            check(lib().sealnn_split_planes(st, xx.data_ptr(), rows, k, a3.data_ptr(), flag))
+            check(lib().sealnn_split_planes_pairs(st, xx.data_ptr(), rows, k, a2.data_ptr(), flag))
+            c3 = torch.empty(rows, n, device=dev)
+            check(lib().sealnn_hgemm_nt(st, a3.data_ptr(), lin.planes.data_ptr(), c3.data_ptr(), rows, n, 3 * k, n, 2 | (2 << 8) | (1 << 12) | (1 << 16)))
+            for tile, stages, kg in ((1, 2, 1), (2, 2, 1), (2, 2, 2), (2, 2, 4), (3, 3, 1), (4, 2, 2), (129, 2, 1), (5, 2, 1), (6, 3, 1), (7, 3, 1), (7, 2, 1)):
+                for slices in (1, 2, 4):
+                    if (2 * k // 64) % slices or (2 * k // 64 // slices) % kg:
+                        continue
+                    c = torch.full((slices, rows, n), float("nan"), device=dev)
+                    check(lib().sealnn_hgemm_nt(st, a2.data_ptr(), wp.data_ptr(), c.data_ptr(), rows, n, 2 * k, n,
+                                                tile | (stages << 8) | (kg << 12) | (slices << 16) | split_gemm.PAIRS_BIT))
+                    got = c.sum(0)
+                    if exact:
+                        assert torch.equal(got, c3), (tile, stages, kg, slices)
+                    else:
+                        assert float((got - c3).abs().max()) <= 6e-6 * float(c3.abs().max()), (tile, stages, kg, slices)
+                        assert float((got * lin.alpha - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+                    n_cfg += 1
+        assert n_cfg >= 16
+    assert split_gemm.overflowed(dev) == 0
+
+
+@pytest.mark.gpu
 def test_a_finished_product_through_the_hand_written_kernel():
     """a product nobody defers (the encoder's q / k / v for torch's attention, the cross-attention K / V) at a height the hand-written kernel has a
     configuration for: ``sealnn_hgemm_nt`` + ``sealnn_finish_product`` == ``Deferred.value()`` of the same slabs bit for bit, no library GEMM is
@@ -519,12 +589,13 @@ def test_split_k_slabs_are_summed_by_the_kernel_that_reads_them(monkeypatch):
                      encoder_ffn_dim=4096, decoder_ffn_dim=4096, max_position_embeddings=64)
     with torch.device(dev):
         model = BartForConditionalGeneration(cfg).eval()
-    B, K, S_in, T = 10, 15, 12, 4
+    B, K, S_in, T = 20, 15, 12, 4            # (300 rows: every product of the step is a split product, so the PAIRS form applies)
     ids = torch.randint(3, 3000, (B, S_in), generator=g).to(dev)
     mask = torch.ones(B, S_in, dtype=torch.long, device=dev)
-    outs, used = [], []
-    for hand in (True, False):
+    outs, used, paired = [], [], []
+    for hand, pairs in ((True, True), (True, False), (False, False)):         # (pairs: every plane of the step as hi / lo pairs, three products per K step)
         monkeypatch.setattr(split_gemm, "HAND_GEMM", hand)
+        monkeypatch.setattr(split_gemm, "PAIRS", pairs)
         dec = BartStepDecoder(model)
         enc = dec.encode(ids, mask)
         dec.start(enc, mask, K, T)
@@ -533,11 +604,13 @@ def test_split_k_slabs_are_summed_by_the_kernel_that_reads_them(monkeypatch):
         for t in range(T - 1):
             lg = dec.step(tok).clone()
             steps.append(lg)
-            tok = lg.argmax(-1)
+            tok = lg.argmax(-1) if not outs else outs[0][t].argmax(-1)            # (the same tokens in every arm)
         outs.append(torch.stack(steps))
         used.append(split_gemm.hand_config(B * K, 1024, 3 * 4096) is not None)
-    assert used == [True, False]
-    assert torch.isfinite(outs[0]).all() and (outs[0] - outs[1]).abs().max().item() <= 2e-4 and split_gemm.overflowed(dev) == 0
+        paired.append(any(getattr(z, "pairs", False) for z in dec._static_cache.values()))
+    assert used == [True, True, False] and paired == [True, False, False]
+    assert torch.isfinite(outs[0]).all() and split_gemm.overflowed(dev) == 0
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-4 and (outs[0] - outs[2]).abs().max().item() <= 2e-4
 
 
 @pytest.mark.gpu
