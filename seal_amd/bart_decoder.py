@@ -83,7 +83,7 @@ class BartStepDecoder:
     # fp32 linear layers of the fused paths on the fp16 matrix cores (seal_amd/split_gemm.py; SEAL_SPLIT_GEMM=0: plain fp32 GEMMs)
     split_gemm = None
 
-    def _lin(self, x: torch.Tensor, w: torch.Tensor, b, defer: bool = False, slabs_ok: bool = False):
+    def _lin(self, x: torch.Tensor, w: torch.Tensor, b, defer: bool = False, slabs_ok: bool = False, pairs: bool = False):
         """``F.linear(x, w, b)`` of an fp32 [rows, K] activation on the GPU -- through the split GEMM when that is switched on.
         ``defer``: the caller hands the result to a sealnn_*_acc kernel, which applies the epilogue of a split product itself
         (``split_gemm.Deferred``; a product that does not go through the split comes back finished)"""
@@ -91,14 +91,22 @@ class BartStepDecoder:
             from . import split_gemm
             BartStepDecoder.split_gemm = split_gemm.SplitLinears() if split_gemm.ENABLED else False
         if self.split_gemm and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
-            return self.split_gemm(x, w, b, defer, slabs_ok)
+            return self.split_gemm(x, w, b, defer, slabs_ok, pairs)
         if x.is_cuda:
             from . import split_gemm
             split_gemm.LIBRARY_GEMMS[0] += 1
         return F.linear(x, w, b)
 
-    def _mod(self, x: torch.Tensor, m, defer: bool = False, slabs_ok: bool = False):
-        return self._lin(x, m.weight, m.bias, defer, slabs_ok)
+    def _mod(self, x: torch.Tensor, m, defer: bool = False, slabs_ok: bool = False, pairs: bool = False):
+        return self._lin(x, m.weight, m.bias, defer, slabs_ok, pairs)
+
+    def _pairs_ok(self, rows: int, ffn: int, w_qkv, w_fc1, w_fc2) -> bool:
+        """may the planes of a layer stack at this height be hi / lo PAIRS?  Only the hand-written kernel reads them, so every product must have a
+        PAIRS configuration and be a split product at all (split_gemm.PAIRS, HAND_CONFIGS_PAIRS)"""
+        from . import split_gemm
+        return bool(self.split_gemm and split_gemm.PAIRS and split_gemm.HAND_GEMM and split_gemm.DEFER_EPILOGUE and self.d % 32 == 0 and ffn % 32 == 0 and
+                    all(split_gemm.hand_config(rows, n, 3 * k, True) is not None for n, k in ((3 * self.d, self.d), (self.d, self.d), (ffn, self.d), (self.d, ffn))) and
+                    all(self.split_gemm.wants(w, rows) for w in (w_qkv, w_fc1, w_fc2)))
 
     # -- the consumers of a product: the finished tensor through the plain kernel, a Deferred one through its _acc twin --
     def _add_ln(self, L_, stream, res, y, ln, rows, planes, pairs=False):
@@ -110,8 +118,14 @@ class BartStepDecoder:
         p = torch.empty(rows, (2 if pairs else 3) * self.d, dtype=torch.float16, device=res.device) if planes else None
         flag = split_gemm._flag(res.device).data_ptr() if planes else None
         if pairs:
-            if not (planes and isinstance(y, split_gemm.Deferred)):
-                raise RuntimeError("BartStepDecoder: pair planes are written behind a deferred product only")
+            if not planes:
+                raise RuntimeError("BartStepDecoder: pair planes asked for where no planes are written")
+            if not isinstance(y, split_gemm.Deferred):
+                # (a finished addend -- a product too small for the split -- as the trivial deferred one: 1.0 * y + 0)
+                zero = self.__dict__.get("_zero_bias")
+                if zero is None or zero.device != y.device:
+                    zero = self._zero_bias = torch.zeros(self.d, dtype=torch.float32, device=y.device)
+                y = split_gemm.Deferred(y.contiguous(), zero, 1.0)
             check(lib().sealnn_add_layernorm_acc_slabs_pairs(stream, res.data_ptr(), y.acc.data_ptr(), y.slabs, y.acc.stride(0) if y.slabs > 1 else 0,
                                                              y.bias.data_ptr(), float(y.alpha), ln.weight.data_ptr(), ln.bias.data_ptr(), rows, self.d,
                                                              float(ln.eps), out.data_ptr(), p.data_ptr(), flag))
@@ -223,17 +237,25 @@ class BartStepDecoder:
             H, dh = enc.layers[0].self_attn.num_heads, enc.layers[0].self_attn.head_dim
             L_ = self._nn(x2.dtype)
             stream = torch.cuda.current_stream(x2.device).cuda_stream
-            xp = self._planes_of(x2)
+            # (round 6: the planes as hi / lo PAIRS where every product of the stack has a hand-written configuration at this height -- the library's 37 / 44 /
+            #  68 us for qkv / fc1 / fc2 at 1 280 rows become 26 / 33 / 44: split_gemm.HAND_CONFIGS_PAIRS)
+            l0 = enc.layers[0]
+            pairs = self._pairs_ok(rows, int(l0.fc1.weight.shape[0]), self._encoder_qkv(l0)[0], l0.fc1.weight, l0.fc2.weight)
+            xp = self._planes_of(x2, pairs)
             for layer in enc.layers:
                 sa = layer.self_attn
                 w, b = self._encoder_qkv(layer)
                 qkv = self._lin_p(x2, xp, w, b).view(B, S, 3, H, dh)
                 q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
                 a = F.scaled_dot_product_attention(q, k, v, attn_mask=keep, scale=float(sa.scaling))
-                y = self._lin(a.transpose(1, 2).reshape(rows, H * dh), sa.out_proj.weight, sa.out_proj.bias, defer=True, slabs_ok=True)
-                x2, xp = self._add_ln(L_, stream, x2, y, layer.self_attn_layer_norm, rows, True)
-                ffn = self._ffn(x2, xp, {"fc1": layer.fc1, "fc2": layer.fc2, "act": layer.activation_fn}, defer=True, hand=True)
-                x2, xp = self._add_ln(L_, stream, x2, ffn, layer.final_layer_norm, rows, True)
+                a = a.transpose(1, 2).reshape(rows, H * dh)
+                if pairs:       # (the d x d product is below the split's own threshold at these heights; as pairs it is the hand-written kernel's)
+                    y = self.split_gemm._of(sa.out_proj.weight, sa.out_proj.bias)(a, True, True, True)
+                else:
+                    y = self._lin(a, sa.out_proj.weight, sa.out_proj.bias, defer=True, slabs_ok=True)
+                x2, xp = self._add_ln(L_, stream, x2, y, layer.self_attn_layer_norm, rows, True, pairs)
+                ffn = self._ffn(x2, xp, {"fc1": layer.fc1, "fc2": layer.fc2, "act": layer.activation_fn}, defer=True, hand=True, pairs=pairs)
+                x2, xp = self._add_ln(L_, stream, x2, ffn, layer.final_layer_norm, rows, True, pairs)
             return x2.view(B, S, -1)
         for layer in enc.layers:
             x = layer(x, mask)
@@ -244,7 +266,7 @@ class BartStepDecoder:
         where that pays (fp32 on the GPU, enough rows), F.linear otherwise"""
         if enc_hidden.is_cuda and enc_hidden.dtype == torch.float32 and enc_hidden.dim() == 3 and ENCODER_SPLIT:
             B, S, d = enc_hidden.shape
-            return self._lin(enc_hidden.reshape(B * S, d), L["ckv_w"], L["ckv_b"]).view(B, S, -1)
+            return self._lin(enc_hidden.reshape(B * S, d), L["ckv_w"], L["ckv_b"], pairs=True).view(B, S, -1)      # (pairs where this height has a configuration)
         return F.linear(enc_hidden, L["ckv_w"], L["ckv_b"])
 
     def _encoder_qkv(self, layer):
@@ -387,18 +409,24 @@ class BartStepDecoder:
             from ._lib import lib
             planes = self._planes_on(x)
 
+            L0 = self.layers[0]
+            # (round 6: hi / lo PAIRS planes and the hand-written kernel for every product of the forest where its height has configurations)
+            pairs = bool(planes) and self._pairs_ok(N, int(self.model.config.decoder_ffn_dim), L0["qkv_w"], L0["fc1"].weight, L0["fc2"].weight)
+
             def add_ln(res, y, ln):
-                return self._add_ln(L_, stream, res, y, ln, N, planes)
-            xp = self._planes_of(x) if planes else None
+                return self._add_ln(L_, stream, res, y, ln, N, planes, pairs)
+            xp = self._planes_of(x, pairs) if planes else None
             for li, L in enumerate(self.layers):
                 qkv = self._lin_p(x, xp, L["qkv_w"], L["qkv_b"], defer=True)
+                if isinstance(qkv, split_gemm.Deferred) and qkv.slabs > 1:       # (the tree kernel reads ONE slab)
+                    qkv = split_gemm.Deferred(qkv.acc.sum(0), qkv.bias, qkv.alpha)
                 a = torch.empty(N, self.d, dtype=x.dtype, device=dev)
                 if isinstance(qkv, split_gemm.Deferred):
                     check(lib().sealnn_tree_self_attn_acc(stream, qkv.acc.data_ptr(), qkv.bias.data_ptr(), float(qkv.alpha), anc32.data_ptr(), N, A,
                                                           self.h, float(self.scale), a.data_ptr()))
                 else:
                     check(L_.tree_self_attn(stream, qkv.data_ptr(), anc32.data_ptr(), N, A, self.h, float(self.scale), a.data_ptr()))
-                x, xp = add_ln(x, self._mod(a, L["so"], defer=True, slabs_ok=True), L["ln1"])
+                x, xp = add_ln(x, self._mod(a, L["so"], defer=True, slabs_ok=True, pairs=pairs), L["ln1"])
                 q = self._lin_p(x, xp, L["cq"].weight, L["cq"].bias)
                 c = torch.empty(N, self.d, dtype=x.dtype, device=dev)
                 ck, cv = cross[li]
@@ -406,8 +434,8 @@ class BartStepDecoder:
                 #  run's first reads its own from memory -- the same arithmetic as sealnn_cross_attn_rows on either path)
                 check(L_.cross_attn_runs(stream, q.data_ptr(), ck.data_ptr(), cv.data_ptr(), bias.data_ptr(), row_batch.data_ptr(),
                                          N, 16, self.h, S, float(self.scale), c.data_ptr()))
-                x, xp = add_ln(x, self._mod(c, L["co"], defer=True, slabs_ok=True), L["ln2"])
-                x, xp = add_ln(x, self._ffn(x, xp, L, defer=True), L["ln3"])
+                x, xp = add_ln(x, self._mod(c, L["co"], defer=True, slabs_ok=True, pairs=pairs), L["ln2"])
+                x, xp = add_ln(x, self._ffn(x, xp, L, defer=True, hand=pairs, pairs=pairs), L["ln3"])
             if hidden_only:
                 return x            # (the caller projects slices of x: lm_head -> _lin -> the split kernel per slice)
             return self._lin_p(x, xp, self.lm_w, self.lm_b.view(-1))
@@ -568,12 +596,8 @@ class BartStepDecoder:
             # / 12 us (300) becomes 11 / 7 us (profiles/r5_hgemm_probe.txt), with no pass over the activations in between.
             hand = bool(planes and x.dtype == torch.float32 and split_gemm.DEFER_EPILOGUE and split_gemm.hand_config(R, self.d, 3 * self.d) is not None)
             # every plane of a hand step as hi / lo PAIRS ([rows, 2d]): the products then move four tiles per K step instead of six (split_gemm.PAIRS)
-            ffn = int(self.model.config.decoder_ffn_dim)
             L0 = self.layers[0]
-            pairs = bool(hand and split_gemm.PAIRS and self.d % 32 == 0 and ffn % 32 == 0 and
-                         all(split_gemm.hand_config(R, n, 3 * k, True) is not None for n, k in ((3 * self.d, self.d), (self.d, self.d), (ffn, self.d), (self.d, ffn))) and
-                         # (every product of the step must BE a split product: nothing else reads pair planes)
-                         all(self.split_gemm.wants(w, R) for w in (L0["qkv_w"], L0["fc1"].weight, L0["fc2"].weight)))
+            pairs = hand and self._pairs_ok(R, int(self.model.config.decoder_ffn_dim), L0["qkv_w"], L0["fc1"].weight, L0["fc2"].weight)
             st.pairs = pairs
             xp = self._planes_of(x, pairs) if planes else None
             pw = 2 if pairs else 3

@@ -187,12 +187,17 @@ PAIRS_BIT = 1 << 29
 # 17.3 -> 16.1, 163 -> 114 (a third fewer bytes buys 14 .. 38 %: with the load path relieved the reads-and-MFMA phase of a step shows)
 _T4 = lambda tile, stages, kgroups, slices: tile | (stages << 8) | (kgroups << 12) | (slices << 16)
 HAND_CONFIGS_PAIRS = {
-    (1024, 12288): ((320, _TALL(6, 3, 16)), (640, _TALL(6, 3, 8))),
-    (1024, 3072): ((320, _T4(2, 2, 2, 4)), (640, _T4(2, 2, 1, 4))),
-    (3072, 3072): ((320, _T4(2, 2, 2, 2)), (640, _TALL(6, 3, 2))),
-    (4096, 3072): ((320, _T4(4, 2, 1, 4)), (640, _TALL(6, 3, 2))),
+    (1024, 12288): ((320, _TALL(6, 3, 16)), (640, _TALL(6, 3, 8)), (1536, _T4(4, 3, 1, 2)), (4096, _TALL(7, 3, 2))),
+    (1024, 3072): ((320, _T4(2, 2, 2, 4)), (640, _T4(2, 2, 1, 4)), (1536, _T4(4, 3, 1, 2)), (4096, _TALL(7, 3, 2))),
+    (3072, 3072): ((320, _T4(2, 2, 2, 2)), (640, _TALL(6, 3, 2)), (1536, _TALL(7, 3, 2)), (4096, _T4(3, 2, 1, 1))),
+    (4096, 3072): ((320, _T4(4, 2, 1, 4)), (640, _TALL(6, 3, 2)), (1536, _TALL(5, 2, 2)), (4096, _TALL(7, 3, 1))),
+    (2048, 3072): ((1536, _TALL(6, 3, 2)), (4096, _TALL(7, 3, 1))),
     (50265, 3072): ((320, _TALL(5, 2, 1)), (640, _TALL(7, 3, 1))),
 }
+# Beyond a decode step's 640 rows only the PAIRS form has configurations: with three-block planes the library's 0.9 PFLOP/s stays ahead of the hand-written
+# kernel at 1 280 rows (a batch's encoder: 40 inputs x 32 tokens) and at ~3 300 (the rescoring forest); with a third fewer bytes the hand-written kernel is
+# (profiles/r6_hgemm_probe_rescoring.txt, us, library -> pairs): 1 280 rows: qkv 37.3 -> 25.9, d x d 19.6 -> 15.1, fc1 44.3 -> 32.6, fc2 67.7 -> 43.5, K / V of
+# the encoder states 30.5 -> 19.0; 3 328 rows: 68.7 -> 61.8, 32.4 -> 24.2, 91.7 -> 81.6, 118.2 -> 79.1, 53.8 -> 41.2.
 # library GEMMs issued through this module and BartStepDecoder._lin since the process started: a step decoder that captures its graph reads it
 # before and after to learn whether the step is free of them (BartStepDecoder._step_static)
 LIBRARY_GEMMS = [0]
@@ -221,7 +226,9 @@ class SplitLinear:
         b = bias.detach().float().reshape(-1) if bias is not None else torch.zeros(self.N, device=weight.device)
         self.bias = b.contiguous()
 
-    def __call__(self, x: torch.Tensor, defer: bool = False, slabs_ok: bool = False):
+    def __call__(self, x: torch.Tensor, defer: bool = False, slabs_ok: bool = False, pairs: bool = False):
+        """``pairs``: split x into hi / lo PAIRS ([rows, 2K]: the hand-written kernel's three-products-per-K-step operand) where that product has a
+        configuration"""
         if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != self.K:
             raise ValueError(f"SplitLinear: expected fp32 [rows, {self.K}], got {x.dtype} {tuple(x.shape)}")
         if not x.is_cuda:
@@ -229,9 +236,10 @@ class SplitLinear:
             return self.from_planes(split_planes_reference(x), defer)
         from ._lib import check, lib
         x = x.contiguous()
-        a = torch.empty(x.shape[0], 3 * self.K, dtype=torch.float16, device=x.device)
-        check(lib().sealnn_split_planes(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.shape[0], self.K, a.data_ptr(),
-                                        _flag(x.device).data_ptr()))
+        pairs = bool(pairs and PAIRS and self.K % 32 == 0 and (self.N % 4 == 0 or defer) and hand_config(x.shape[0], self.N, 3 * self.K, True) is not None)
+        a = torch.empty(x.shape[0], (2 if pairs else 3) * self.K, dtype=torch.float16, device=x.device)
+        fn = lib().sealnn_split_planes_pairs if pairs else lib().sealnn_split_planes
+        check(fn(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.shape[0], self.K, a.data_ptr(), _flag(x.device).data_ptr()))
         return self.from_planes(a, defer, slabs_ok)
 
     def pair_planes(self) -> torch.Tensor:
@@ -320,12 +328,12 @@ class SplitLinears:
         self._by_weight[key] = (weakref.ref(weight), version, lin)
         return lin
 
-    def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias=None, defer: bool = False, slabs_ok: bool = False):
+    def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias=None, defer: bool = False, slabs_ok: bool = False, pairs: bool = False):
         """``defer``: a product that goes through the split comes back as ``Deferred`` (one that does not, as the finished tensor)"""
         if not self.wants(weight, x.shape[0], have_planes=False):
             LIBRARY_GEMMS[0] += 1 if x.is_cuda else 0
             return torch.nn.functional.linear(x, weight, bias)
-        return self._of(weight, bias)(x, defer and DEFER_EPILOGUE, slabs_ok)
+        return self._of(weight, bias)(x, defer and DEFER_EPILOGUE, slabs_ok, pairs and defer == (defer and DEFER_EPILOGUE))
 
     def from_planes(self, planes: torch.Tensor, weight: torch.Tensor, bias=None, defer: bool = False, slabs_ok: bool = False):
         return self._of(weight, bias).from_planes(planes, defer and DEFER_EPILOGUE, slabs_ok)

@@ -31,8 +31,20 @@ for M in (3328, 1280):
                         continue
                     cfg = tile | (stages << 8) | (1 << 12) | (slices << 16)
                     res.append((gtime(lambda: run(a, ws, cfg, out), n=100), tile, stages, slices))
+        # the PAIRS form of the same product: [M, 2K/3] x [N, 2K/3]^T pair planes, three products per K step
+        K2 = K // 3 * 2
+        a2 = torch.randn(M, K2, device=dev).half()
+        ws2 = [torch.randn(N, K2, device=dev).half() for _ in range(max(2, int(640e6 / (N * K2 * 2))))]
+        for tile, stage_opts in ((1, (2, 3)), (129, (2, 3)), (3, (2, 3)), (4, (2, 3)), (132, (2, 3)), (5, (2,)), (6, (3,)), (7, (3,))):
+            for stages in stage_opts:
+                for slices in (1, 2):
+                    if (K2 // 64) % slices:
+                        continue
+                    cfg = tile | (stages << 8) | (1 << 12) | (slices << 16) | (1 << 29)
+                    res.append((gtime(lambda: run(a2, ws2, cfg, out), n=100), 1000 + tile, stages, slices))
+        del ws2
         res.sort()
-        fmt = lambda r: f"{r[0]:.1f} (tile {r[1]} stages {r[2]} x{r[3]})"
+        fmt = lambda r: f"{r[0]:.1f} ({'pairs ' if r[1] >= 1000 else ''}tile {r[1] % 1000} stages {r[2]} x{r[3]})"
         gf = 2.0 * M * N * K / 1e9
-        print(f"M={M:4d} {name:6s} N={N:5d} K={K:5d} ({gf:5.1f} GF): library {t_lib:6.1f} us = {gf / t_lib:.0f} TF/s   hand: {', '.join(fmt(r) for r in res[:5])}", flush=True)
+        print(f"M={M:4d} {name:6s} N={N:5d} K={K:5d} ({gf:5.1f} GF): library {t_lib:6.1f} us   hand: {', '.join(fmt(r) for r in res[:5])}", flush=True)
         del ws
