@@ -440,11 +440,24 @@ class _PendingRescore:
     def __init__(self, totals, scores, decoded, length_penalty, split_flag=None, device=None):
         self._totals, self._scores, self._decoded, self._lp = totals, scores, decoded, length_penalty
         self._split_flag, self._device = split_flag, device
+        # The scores start for pinned host memory NOW, behind the forward that makes them, and an event marks their arrival: a ``.tolist()`` in
+        # ``result`` would be a copy on whatever the stream holds BY THEN -- the next batch's rescoring forward, if the searcher has enqueued it
+        self._host, self._ready = None, None
+        if totals and totals[0][1].is_cuda:
+            t = torch.cat([t for _, t in totals]) if len(totals) > 1 else totals[0][1]
+            self._host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self._host.copy_(t, non_blocking=True)
+            self._ready = torch.cuda.Event()
+            self._ready.record(torch.cuda.current_stream(t.device))
 
     def result(self):
         scores = self._scores
         if self._totals:
-            flat = torch.cat([t for _, t in self._totals]).tolist() if len(self._totals) > 1 else self._totals[0][1].tolist()
+            if self._host is not None:
+                self._ready.synchronize()
+                flat = self._host.tolist()
+            else:
+                flat = torch.cat([t for _, t in self._totals]).tolist() if len(self._totals) > 1 else self._totals[0][1].tolist()
             if self._split_flag is not None:          # (the read-back above waited for the stream the snapshot was enqueued on)
                 from . import split_gemm
                 flag, self._split_flag = self._split_flag, None
