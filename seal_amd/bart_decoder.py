@@ -698,6 +698,8 @@ class BartStepDecoder:
             check(L_.add_layernorm(stream, res.data_ptr(), y.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
                                    B, self.d, float(ln.eps), out.data_ptr()))
             return out
+        if self._first_step_by_hand(x, B):
+            return self._step_static_first_by_hand(st, x)
         for li, L in enumerate(self.layers):
             qkv = F.linear(x, L["qkv_w"], L["qkv_b"]).view(B, 3, H, dh)
             st.kv[li, 0].view(B, K, H, T, dh)[:, 0, :, 0].copy_(qkv[:, 1])
@@ -712,6 +714,58 @@ class BartStepDecoder:
         st.anc[0].copy_(st.beam0)
         st.t.add_(1)
         return F.linear(x, self.lm_w, self.lm_b.view(-1)).float()
+
+    first_step_by_hand = True      # the shared first step through the hand-written kernel (pair planes) where its few rows have configurations
+
+    def _first_step_by_hand(self, x: torch.Tensor, B: int) -> bool:
+        """The shared first step is ``batch`` rows (40 of the bench's 600): far below the heights where the split pays in the library, and 73 fp32 library
+        GEMMs of ~12 us -- each bound by reading its weight once.  As pair planes through ``sealnn_hgemm_nt`` the same products stream the same bytes in
+        ~5 us, and a decode holds no library GEMM at all"""
+        from . import split_gemm
+        if self.split_gemm is None:
+            BartStepDecoder.split_gemm = split_gemm.SplitLinears() if split_gemm.ENABLED else False
+        ffn = int(self.model.config.decoder_ffn_dim)
+        return bool(self.first_step_by_hand and self.use_fused_kernels and self.split_gemm and split_gemm.PAIRS and split_gemm.HAND_GEMM and split_gemm.DEFER_EPILOGUE
+                    and x.is_cuda and x.dtype == torch.float32 and self.dh == 64 and self.d % 32 == 0 and ffn % 32 == 0 and split_gemm.FUSED
+                    and all(split_gemm.hand_config(B, n, 3 * k, True) is not None
+                            for n, k in ((3 * self.d, self.d), (self.d, self.d), (ffn, self.d), (self.d, ffn))))
+
+    def _step_static_first_by_hand(self, st, x):
+        from . import split_gemm
+        from ._lib import check, lib
+        B, K, S_pad, T = st.shape
+        H, dh = self.h, self.dh
+        L_ = self._nn(x.dtype)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        cbias = st.cbias.view(B, S_pad)
+        flag = split_gemm._flag(x.device).data_ptr()
+        of = self.split_gemm._of
+        xp = self._planes_of(x, True)
+        for li, L in enumerate(self.layers):
+            qkv = of(L["qkv_w"], L["qkv_b"]).from_planes(xp).view(B, 3, H, dh)                 # (finished: the cache takes k and v)
+            st.kv[li, 0].view(B, K, H, T, dh)[:, 0, :, 0].copy_(qkv[:, 1])
+            st.kv[li, 1].view(B, K, H, T, dh)[:, 0, :, 0].copy_(qkv[:, 2])
+            # self-attention over the single position 0 is softmax([s]) = [1]: its output is v
+            y = of(L["so"].weight, L["so"].bias)(qkv[:, 2].reshape(B, self.d).contiguous(), True, True, True)
+            x, xp = self._add_ln(L_, stream, x, y, L["ln1"], B, True, True)
+            qd = of(L["cq"].weight, L["cq"].bias).from_planes(xp, True, True)
+            cp = torch.empty(B, 2 * self.d, dtype=torch.float16, device=x.device)
+            check(lib().sealnn_cross_attn_step_x_pairs(stream, qd.acc.data_ptr(), qd.slabs, qd.acc.stride(0) if qd.slabs > 1 else 0, qd.bias.data_ptr(),
+                                                       float(qd.alpha), st.ck[li].data_ptr(), st.cv[li].data_ptr(), cbias.data_ptr(), B, 1, H, S_pad,
+                                                       float(self.scale), None, cp.data_ptr(), flag))
+            x, xp = self._add_ln(L_, stream, x, of(L["co"].weight, L["co"].bias).from_planes(cp, True, True), L["ln2"], B, True, True)
+            h = of(L["fc1"].weight, L["fc1"].bias).from_planes(xp, True, True)
+            d1 = h.acc.shape[-1]
+            hp = torch.empty(B, 2 * d1, dtype=torch.float16, device=x.device)
+            check(lib().sealnn_gelu_planes_acc_slabs_pairs(stream, h.acc.data_ptr(), h.slabs, h.acc.stride(0) if h.slabs > 1 else 0, h.bias.data_ptr(),
+                                                           float(h.alpha), B, d1, hp.data_ptr(), flag))
+            x, xp = self._add_ln(L_, stream, x, of(L["fc2"].weight, L["fc2"].bias).from_planes(hp, True, True), L["ln3"], B, True, True)
+        st.anc[0].copy_(st.beam0)
+        st.t.add_(1)
+        if split_gemm.hand_config(B, self.lm_w.shape[0], 3 * self.d, True) is None:       # (a vocabulary without a configuration: the library's product)
+            split_gemm.LIBRARY_GEMMS[0] += 1
+            return F.linear(x, self.lm_w, self.lm_b.view(-1)).float()
+        return of(self.lm_w, self.lm_b.view(-1)).from_planes(xp, True, True).value().float()
 
     @torch.no_grad()
     def start(self, enc_hidden: torch.Tensor, attention_mask: torch.Tensor, num_beams: int, max_len: int, narrow_plan=()) -> None:

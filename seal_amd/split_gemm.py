@@ -187,13 +187,14 @@ PAIRS_BIT = 1 << 29
 # 17.3 -> 16.1, 163 -> 114 (a third fewer bytes buys 14 .. 38 %: with the load path relieved the reads-and-MFMA phase of a step shows)
 _T4 = lambda tile, stages, kgroups, slices: tile | (stages << 8) | (kgroups << 12) | (slices << 16)
 HAND_CONFIGS_PAIRS = {
-    (1024, 12288): ((320, _TALL(6, 3, 16)), (640, _TALL(6, 3, 8)), (1536, _T4(4, 3, 1, 2)), (4096, _TALL(7, 3, 2))),
-    (1024, 3072): ((320, _T4(2, 2, 2, 4)), (640, _T4(2, 2, 1, 4)), (1536, _T4(4, 3, 1, 2)), (4096, _TALL(7, 3, 2))),
-    (3072, 3072): ((320, _T4(2, 2, 2, 2)), (640, _TALL(6, 3, 2)), (1536, _TALL(7, 3, 2)), (4096, _T4(3, 2, 1, 1))),
-    (4096, 3072): ((320, _T4(4, 2, 1, 4)), (640, _TALL(6, 3, 2)), (1536, _TALL(5, 2, 2)), (4096, _TALL(7, 3, 1))),
+    (1024, 12288): ((64, _T4(2, 3, 1, 16)), (320, _TALL(6, 3, 16)), (640, _TALL(6, 3, 8)), (1536, _T4(4, 3, 1, 2)), (4096, _TALL(7, 3, 2))),
+    (1024, 3072): ((64, _T4(2, 3, 1, 8)), (320, _T4(2, 2, 2, 4)), (640, _T4(2, 2, 1, 4)), (1536, _T4(4, 3, 1, 2)), (4096, _TALL(7, 3, 2))),
+    (3072, 3072): ((64, _T4(2, 3, 1, 8)), (320, _T4(2, 2, 2, 2)), (640, _TALL(6, 3, 2)), (1536, _TALL(7, 3, 2)), (4096, _T4(3, 2, 1, 1))),
+    (4096, 3072): ((64, _T4(2, 3, 1, 4)), (320, _T4(4, 2, 1, 4)), (640, _TALL(6, 3, 2)), (1536, _TALL(5, 2, 2)), (4096, _TALL(7, 3, 1))),
     (2048, 3072): ((1536, _TALL(6, 3, 2)), (4096, _TALL(7, 3, 1))),
-    (50265, 3072): ((320, _TALL(5, 2, 1)), (640, _TALL(7, 3, 1))),
+    (50265, 3072): ((64, _T4(132, 3, 1, 1)), (320, _TALL(5, 2, 1)), (640, _TALL(7, 3, 1))),
 }
+# (<= 64 rows: the shared first step of a decode, 40 rows in the bench -- fp32 library GEMMs of ~12 us become 4 .. 7: BartStepDecoder._step_static_first_by_hand)
 # Beyond a decode step's 640 rows only the PAIRS form has configurations: with three-block planes the library's 0.9 PFLOP/s stays ahead of the hand-written
 # kernel at 1 280 rows (a batch's encoder: 40 inputs x 32 tokens) and at ~3 300 (the rescoring forest); with a third fewer bytes the hand-written kernel is
 # (profiles/r6_hgemm_probe_rescoring.txt, us, library -> pairs): 1 280 rows: qkv 37.3 -> 25.9, d x d 19.6 -> 15.1, fc1 44.3 -> 32.6, fc2 67.7 -> 43.5, K / V of

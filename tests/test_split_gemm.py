@@ -614,6 +614,52 @@ def test_split_k_slabs_are_summed_by_the_kernel_that_reads_them(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_shared_first_step_through_the_hand_written_kernel(monkeypatch):
+    """the shared first step of a decode (``batch`` rows: 40 in the bench) as pair planes through ``sealnn_hgemm_nt`` -- no library GEMM but, for a
+    vocabulary without a configuration, the output projection -- against the same step through the library's fp32 GEMMs and against HF's forward:
+    logits of the first step and of the steps after it (which read the cache slot it wrote) within 2e-4 / 1e-4"""
+    from transformers import BartConfig, BartForConditionalGeneration
+    from seal_amd import split_gemm
+    from seal_amd.bart_decoder import BartStepDecoder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    cfg = BartConfig(vocab_size=3000, d_model=1024, encoder_layers=1, decoder_layers=2, encoder_attention_heads=16, decoder_attention_heads=16,
+                     encoder_ffn_dim=4096, decoder_ffn_dim=4096, max_position_embeddings=64)
+    with torch.device(dev):
+        model = BartForConditionalGeneration(cfg).eval()
+    g = torch.Generator().manual_seed(9)
+    B, K, S_in, T = 40, 15, 12, 4
+    ids = torch.randint(3, 3000, (B, S_in), generator=g).to(dev)
+    mask = torch.ones(B, S_in, dtype=torch.long, device=dev)
+    mask[3, 8:] = 0
+    outs, lib_gemms = [], []
+    for by_hand in (True, False):
+        monkeypatch.setattr(BartStepDecoder, "first_step_by_hand", by_hand)
+        dec = BartStepDecoder(model)
+        enc = dec.encode(ids, mask)
+        dec.start(enc, mask, K, T)
+        before = split_gemm.LIBRARY_GEMMS[0]
+        assert dec._first_step_by_hand(enc.view(-1, 1024)[:B], B) is by_hand
+        tok = torch.full((B * K,), 2, dtype=torch.long, device=dev)
+        steps = []
+        for t in range(T - 1):
+            lg = dec.step(tok, beams_identical=(t == 0)).clone()
+            steps.append(lg)
+            tok = lg.argmax(-1) if not outs else outs[0][t].argmax(-1)
+        outs.append(torch.stack(steps))
+        lib_gemms.append(split_gemm.LIBRARY_GEMMS[0] - before)
+    assert torch.isfinite(outs[0]).all() and (outs[0] - outs[1]).abs().max().item() <= 2e-4 and split_gemm.overflowed(dev) == 0
+    # HF's cache-free forward on the tokens the first arm chose
+    rows = torch.full((B * K, 1), 2, dtype=torch.long, device=dev)
+    ids_rep, am_rep = ids.repeat_interleave(K, 0), mask.repeat_interleave(K, 0)
+    with torch.no_grad():
+        for t in range(T - 1):
+            want = model(input_ids=ids_rep, attention_mask=am_rep, decoder_input_ids=rows).logits[:, -1, :]
+            assert (outs[0][t] - want).abs().max().item() <= 1e-4, t
+            rows = torch.cat([rows, outs[0][t].argmax(-1)[:, None]], 1)
+
+
+@pytest.mark.gpu
 def test_encoder_through_the_split_gemm_matches_hf_encoder(monkeypatch):
     """``BartStepDecoder.encode`` with the encoder's linear layers through the split GEMM (the layer written out: q / k / v as one product, torch's
     fused attention, LayerNorms) against HF's own ``BartEncoder`` forward in fp32, at BART-large width with padded inputs: within 2e-5 on O(1)
