@@ -331,6 +331,49 @@ def test_kernels_that_apply_the_epilogue_themselves_on_the_gpu(monkeypatch):
     assert torch.isfinite(res[0]).all() and (res[0] - res[1]).abs().max().item() <= 1e-4 and split_gemm.overflowed(dev) == 0
 
 
+def test_hand_configuration_tables_are_well_formed():
+    """``split_gemm.HAND_CONFIGS`` / ``HAND_CONFIGS_PAIRS``: row tiers ascending, every configuration one ``sealnn_hgemm_nt`` accepts -- a known tile, stages that
+    fit its LDS, K groups the tile has, split-K slices that divide the K steps of the form (3K / 64, resp. 2K / 64 for pairs) into whole K groups, and no more
+    slabs than the kernels that add them take (16); ``hand_config`` answers the first tier that holds the rows, None beyond the last and with HAND_GEMM off"""
+    from seal_amd import split_gemm
+    for table, pairs in ((split_gemm.HAND_CONFIGS, False), (split_gemm.HAND_CONFIGS_PAIRS, True)):
+        assert table
+        for (n, k3), tiers in table.items():
+            assert k3 % 3 == 0 and [r for r, _ in tiers] == sorted({r for r, _ in tiers}), (n, k3)
+            steps = (k3 // 3 * 2 if pairs else k3) // 64
+            for rows, cfg in tiers:
+                tile, stages, kg, slices = cfg & 0x7f, (cfg >> 8) & 0xf, (cfg >> 12) & 0xf, (cfg >> 16) & 0x1fff
+                assert cfg >> 29 == 0 and tile in (1, 2, 3, 4, 5, 6, 7) and 1 <= slices <= 16, (n, k3, rows, hex(cfg))
+                assert steps % slices == 0 and (steps // slices) % kg == 0, (n, k3, rows, hex(cfg))
+                if tile >= 5:
+                    assert kg == 1 and 2 <= stages <= (2 if tile == 5 else 3)
+                else:
+                    assert (kg == 1 and 1 <= stages <= 3) or (stages == 2 and kg <= {1: 1, 2: 4, 3: 2, 4: 2}[tile])
+                assert split_gemm.hand_config(rows, n, k3, pairs) == cfg and split_gemm.hand_config(1, n, k3, pairs) == tiers[0][1]
+            assert split_gemm.hand_config(tiers[-1][0] + 1, n, k3, pairs) is None
+    try:
+        split_gemm.HAND_GEMM = False
+        assert split_gemm.hand_config(600, 1024, 3072) is None and split_gemm.hand_config(600, 1024, 3072, True) is None
+    finally:
+        split_gemm.HAND_GEMM = True
+
+
+def test_pair_planes_of_a_weight_interleave_its_hi_and_lo_planes():
+    """``SplitLinear.pair_planes``: [N, 2K], per 32 columns the hi plane's 32 values then the lo plane's (blocks 0 and 1 of the three-block planes; block 2 is
+    block 0 times 2^-11 and is not carried); a K that 32 does not divide is refused"""
+    from seal_amd import split_gemm
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(24, 96, generator=g) * 0.05
+    lin = split_gemm.SplitLinear(w, torch.zeros(24))
+    wp = lin.pair_planes()
+    assert wp.shape == (24, 192) and wp.dtype == torch.float16 and wp is lin.pair_planes()
+    v = wp.view(24, 3, 2, 32)
+    assert torch.equal(v[:, :, 0].reshape(24, 96), lin.planes[:, :96]) and torch.equal(v[:, :, 1].reshape(24, 96), lin.planes[:, 96:192])
+    assert torch.equal((lin.planes[:, :96].float() * 2.0 ** -11).half(), lin.planes[:, 192:])
+    with pytest.raises(ValueError):
+        split_gemm.SplitLinear(torch.randn(8, 48, generator=g), None).pair_planes()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(600, 1024, 3072), (300, 1024, 12288), (37, 200, 192), (640, 192, 256), (321, 4096 + 40, 512)])
 def test_hand_written_gemm_against_torch(M, N, K):
