@@ -137,6 +137,11 @@ int sealnn_add_layernorm_acc_slabs(void *stream, const float *x, const float *y_
  * K % 64 == 0, operands 16-byte aligned.  config: 0 = tile picked by shape; probes / tests: tile (1: 128 x 128, 2: 64 x 64, 3: 128 x 64,
  * 4: 64 x 128; 5: 320 x 128, 6: 320 x 64 -- the tall tiles of 8 waves, for 300 / 600 rows) | stages << 8 (LDS stages 1..3, 0: two) | 1 << 29 (the operands are PAIRS planes, K = 2 x in_features) | slices << 16 (split-K: slab s at C + s * M * ldc, the caller sums the slabs). */
 int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float *c, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t config);
+/* The same product FINISHED in the kernel's store: c[row][col] = alpha * acc + bias[row / rows_per_bias_row][col] (bias: [ceil(M / rows_per_bias_row)][N] fp32).
+ * One slab, the PAIRS form of the tall tiles (5..7) only -- the output projection of a decode step: bias = final_logits_bias + the per-query logit bias,
+ * rows_per_bias_row = beams (reference beam_search.py:246-253: lm_head, then the logits processors' additive terms). */
+int sealnn_hgemm_nt_ep(void *stream, const void *a, const void *w, float *c, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t config,
+                       const float *bias, uint32_t rows_per_bias_row, float alpha);
 
 #ifdef __cplusplus
 }

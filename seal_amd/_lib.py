@@ -170,6 +170,7 @@ NN_SIGNATURES = {
     "sealnn_cross_attn_step_x": (_int, [_vp, _vp, _u32, _u64, _vp, _f32, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _vp, _vp, _vp]),
     "sealnn_add_layernorm_acc_slabs": (_int, [_vp, _vp, _vp, _u32, _u64, _vp, _f32, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp]),
     "sealnn_hgemm_nt": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u64, _u32]),
+    "sealnn_hgemm_nt_ep": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _vp, _u32, _f32]),
 }
 
 _lib = None

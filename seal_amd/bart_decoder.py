@@ -643,6 +643,20 @@ class BartStepDecoder:
             # The output projection leaves the graph as RAW accumulators when it goes through the split GEMM: its epilogue (alpha * acc +
             # final_logits_bias) is applied by `step` in the same pass that adds a per-query logit bias, if there is one -- torch.addmm would
             # first copy the broadcast bias into the [rows, vocab] output (120 MB at 600 rows) and have the GEMM read it back.
+            cfg_lm = split_gemm.hand_config(R, self.lm_w.shape[0], 3 * self.d, True) if pairs else None
+            if self.lm_head_finished_in_store and cfg_lm is not None and (cfg_lm & 0x7f) in (5, 6, 7) and ((cfg_lm >> 16) & 0x1fff) <= 1:
+                # the output projection FINISHED in the kernel's store: alpha * acc + (final_logits_bias + the query's logit bias), the bias rows in a
+                # buffer of this static state that `step` refreshes when the searcher's bias changes -- no pass over the [rows, vocab] logits behind it
+                lin = self.split_gemm._of(self.lm_w, self.lm_b.view(-1))
+                if getattr(st, "lm_bias_q", None) is None:
+                    st.lm_bias_q = lin.bias[None, :].repeat(B, 1).contiguous()
+                    st.lm_bias_src, st.lm_bias_key = lin.bias, None
+                out = torch.empty(R, self.lm_w.shape[0], dtype=torch.float32, device=x.device)
+                check(lib().sealnn_hgemm_nt_ep(stream, xp.data_ptr(), lin.pair_planes().data_ptr(), out.data_ptr(), R, self.lm_w.shape[0], xp.shape[1],
+                                               self.lm_w.shape[0], cfg_lm | split_gemm.PAIRS_BIT, st.lm_bias_q.data_ptr(), K, float(lin.alpha)))
+                st.library_free = hand and split_gemm.LIBRARY_GEMMS[0] == library_before
+                st.lm_epilogue = "in the store"
+                return out
             y = self._lin_p(x, xp, self.lm_w, self.lm_b.view(-1), defer=True, slabs_ok=hand)
             # no library GEMM in this step: nothing in it waits for partner workgroups (hipBLASLt's kernels are stream-K), so another stream's
             # library GEMMs may run beside it (retrieval.py: the rescoring forward overlaps the decode steps)
@@ -715,6 +729,7 @@ class BartStepDecoder:
         st.t.add_(1)
         return F.linear(x, self.lm_w, self.lm_b.view(-1)).float()
 
+    lm_head_finished_in_store = True    # a hand step's output projection applies alpha, final_logits_bias and the per-query logit bias in its store
     first_step_by_hand = True      # the shared first step through the hand-written kernel (pair planes) where its few rows have configurations
 
     def _first_step_by_hand(self, x: torch.Tensor, B: int) -> bool:
@@ -956,12 +971,21 @@ class BartStepDecoder:
                 if self.logit_bias is not None:
                     logits = logits + self.logit_bias
                 return logits[:, None, :].expand(B, K, logits.shape[-1]).reshape(R, -1)
+            if getattr(st, "lm_epilogue", None) == "in the store":
+                # the bias rows the output projection's store adds: final_logits_bias (+ the searcher's per-query logit bias), refreshed when they change
+                src = self._bias_per_query(st.lm_bias_src) if self.logit_bias is not None else st.lm_bias_src
+                key = (src.data_ptr(), src._version, tuple(src.shape))
+                if st.lm_bias_key != key:
+                    st.lm_bias_q.copy_(src if src.dim() == 2 else src[None, :].expand_as(st.lm_bias_q))
+                    st.lm_bias_key = key
             st.graph.replay()
             self.t += 1
             if t == 0:
                 self._library_prefix_done()
             logits = st.logits
             ep = getattr(st, "lm_epilogue", None)
+            if ep == "in the store":
+                return logits
             if ep is not None:
                 alpha, bias = ep                                       # (alpha a power of two: alpha * acc is exact, one rounding in the add)
                 if self.logit_bias is not None:

@@ -254,7 +254,7 @@ constexpr bool NT_W = true;               // the weights' LDS-DMA pieces carry t
 template <uint32_t BN, uint32_t NS, uint32_t DBG = 0, bool PAIRS = false>      // PAIRS: see k_hgemm_nt;  DBG (probes only): 1 = no LDS-DMA after the prologue, 2 = no fragment reads / MFMAs
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_hgemm_tall(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, float *__restrict__ C,
                                                     uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t k_per_slice, uint64_t slab_stride,
-                                                    uint32_t tiles_m, uint32_t tiles_n)
+                                                    uint32_t tiles_m, uint32_t tiles_n, const float *__restrict__ ep_bias, uint32_t ep_group, float ep_alpha)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr uint32_t BM = TALL_BM, TM = BM / 4, TN = BN / 2, FM = TM / 16, FN = TN / 16;
@@ -463,6 +463,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return;
     }
     const bool inside = m0 + BM <= M && n0 + BN <= N;
+    if (ep_bias) {
+        // the product FINISHED in the store (sealnn_hgemm_nt_ep; one slab): C = ep_alpha * acc + ep_bias[row / ep_group][col] -- the output projection of a
+        // decode step with final_logits_bias + the per-query logit bias of the row's query (ep_group = beams), instead of a pass over the [rows, vocab] logits
+#pragma unroll
+        for (uint32_t i = 0; i < FM; i++) {
+            const uint32_t rbase = m0 + wm * TM + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (uint32_t r = 0; r < 4; r++) {
+                const uint32_t row = rbase + r;
+                if (row >= M) continue;
+                const float *brow = ep_bias + (uint64_t)(row / ep_group) * N;
+#pragma unroll
+                for (uint32_t j = 0; j < FN; j++) {
+                    const uint32_t col = n0 + wn * TN + j * 16 + (lane & 15);
+                    if (col < N) C[(uint64_t)row * ldc + col] = ep_alpha * acc[i][j][r] + brow[col];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (uint32_t i = 0; i < FM; i++) {
 #pragma unroll
@@ -482,14 +502,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+struct TallEpilogue { const float *bias = nullptr; uint32_t group = 1; float alpha = 1.f; };
+
 template <uint32_t BN, uint32_t NS, uint32_t DBG = 0, bool PAIRS = false>
-int launch_tall(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t slices)
+int launch_tall(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t slices, TallEpilogue ep = TallEpilogue())
 {
     const uint32_t tiles_m = (M + TALL_BM - 1) / TALL_BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds = (size_t)NS * (TALL_BM + BN) * ROW_BYTES;
     (void)hipFuncSetAttribute((const void *)k_hgemm_tall<BN, NS, DBG, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_hgemm_tall<BN, NS, DBG, PAIRS>), dim3(tiles_m * tiles_n * slices), dim3(512), lds, st, (const _Float16 *)A, (const _Float16 *)W, C, M, N, K, ldc,
-                       K / slices, (uint64_t)M * ldc, tiles_m, tiles_n);
+                       K / slices, (uint64_t)M * ldc, tiles_m, tiles_n, ep.bias, ep.group ? ep.group : 1u, ep.alpha);
     return hipGetLastError() == hipSuccess ? FMI_OK : FMI_ERR_HIP;
 }
 
@@ -535,7 +557,7 @@ int launch(hipStream_t st, const void *A, const void *W, float *C, uint32_t M, u
 // kgroups << 12 (K groups of 4 waves per workgroup: 1, 2 (tiles 2..4), 4 (tile 2); 0: one) | 1 << 29: the operands are hi / lo PAIRS (k_hgemm_nt) |
 // slices << 16 (up to 8191; split-K over workgroups: slab s of C
 // at C + s * M * ldc, the caller sums the slabs).  Probes and tests pass it explicitly.
-extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float *c, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t config)
+static int hgemm_nt(void *stream, const void *a, const void *w, float *c, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t config, TallEpilogue ep)
 {
     if (!a || !w || !c || M == 0 || N == 0) { fmi_set_error("sealnn_hgemm_nt: null / empty operand"); return FMI_ERR_ARG; }
     if (K == 0 || K % BK) { fmi_set_error("sealnn_hgemm_nt: K = %u must be a multiple of %u", K, BK); return FMI_ERR_UNSUPPORTED; }
@@ -562,10 +584,11 @@ extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float
             return FMI_ERR_ARG;
         }
         if (pairs) {
-            if (tile == 5) return launch_tall<128, 2, 0, true>(st, a, w, c, M, N, K, ldc, slices);
-            if (tile == 7) return stages == 2 ? launch_tall<96, 2, 0, true>(st, a, w, c, M, N, K, ldc, slices) : launch_tall<96, 3, 0, true>(st, a, w, c, M, N, K, ldc, slices);
-            return stages == 2 ? launch_tall<64, 2, 0, true>(st, a, w, c, M, N, K, ldc, slices) : launch_tall<64, 3, 0, true>(st, a, w, c, M, N, K, ldc, slices);
+            if (tile == 5) return launch_tall<128, 2, 0, true>(st, a, w, c, M, N, K, ldc, slices, ep);
+            if (tile == 7) return stages == 2 ? launch_tall<96, 2, 0, true>(st, a, w, c, M, N, K, ldc, slices, ep) : launch_tall<96, 3, 0, true>(st, a, w, c, M, N, K, ldc, slices, ep);
+            return stages == 2 ? launch_tall<64, 2, 0, true>(st, a, w, c, M, N, K, ldc, slices, ep) : launch_tall<64, 3, 0, true>(st, a, w, c, M, N, K, ldc, slices, ep);
         }
+        if (ep.bias) { fmi_set_error("sealnn_hgemm_nt_ep: the finishing store exists for the PAIRS form of the tall tiles"); return FMI_ERR_UNSUPPORTED; }
         if (tile == 5) return launch_tall<128, 2>(st, a, w, c, M, N, K, ldc, slices);
         // (config >> 30, probes only: 1 / 2 = the 320 x 64 kernel without its LDS-DMA / without its reads and MFMAs, 3 = step timestamps instead of C)
         if (tile == 7 && (config >> 30) == 3) return launch_tall<96, 3, 3>(st, a, w, c, M, N, K, ldc, slices);
@@ -574,6 +597,7 @@ extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float
         if (config >> 30) return (config >> 30) == 1 ? launch_tall<64, 3, 1>(st, a, w, c, M, N, K, ldc, slices) : launch_tall<64, 3, 2>(st, a, w, c, M, N, K, ldc, slices);
         return stages == 2 ? launch_tall<64, 2>(st, a, w, c, M, N, K, ldc, slices) : launch_tall<64, 3>(st, a, w, c, M, N, K, ldc, slices);
     }
+    if (pairs && ep.bias) { fmi_set_error("sealnn_hgemm_nt_ep: the finishing store exists for the PAIRS form of the tall tiles"); return FMI_ERR_UNSUPPORTED; }
     if (pairs) {
         switch (tile) {
         case 1: return launch<128, 128, true>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
@@ -583,6 +607,7 @@ extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float
         default: fmi_set_error("sealnn_hgemm_nt: unknown tile %u", tile); return FMI_ERR_ARG;
         }
     }
+    if (ep.bias) { fmi_set_error("sealnn_hgemm_nt_ep: the finishing store exists for the PAIRS form of the tall tiles"); return FMI_ERR_UNSUPPORTED; }
     switch (tile) {
     case 1: return launch<128, 128, false>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
     case 2: return launch<64, 64, false>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
@@ -590,4 +615,19 @@ extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float
     case 4: return launch<64, 128, false>(st, a, w, c, M, N, K, ldc, slices, stages, kgroups, mf);
     default: fmi_set_error("sealnn_hgemm_nt: unknown tile %u", tile); return FMI_ERR_ARG;
     }
+}
+
+extern "C" int sealnn_hgemm_nt(void *stream, const void *a, const void *w, float *c, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t config)
+{ return hgemm_nt(stream, a, w, c, M, N, K, ldc, config, TallEpilogue()); }
+
+// the same product FINISHED in the kernel's store: C[row][col] = alpha * acc + bias[row / rows_per_bias_row][col] (bias [ceil(M / rows_per_bias_row)][N], fp32).
+// One slab, PAIRS form, tall tiles (5..7): the output projection of a decode step (bias = final_logits_bias + the query's logit bias, rows_per_bias_row = beams).
+extern "C" int sealnn_hgemm_nt_ep(void *stream, const void *a, const void *w, float *c, uint32_t M, uint32_t N, uint32_t K, uint64_t ldc, uint32_t config,
+                                  const float *bias, uint32_t rows_per_bias_row, float alpha)
+{
+    if (!bias || rows_per_bias_row == 0) { fmi_set_error("sealnn_hgemm_nt_ep: a bias and >= 1 rows per bias row"); return FMI_ERR_ARG; }
+    if ((((config >> 16) & 0x1fff) ? ((config >> 16) & 0x1fff) : 1u) != 1u) { fmi_set_error("sealnn_hgemm_nt_ep: one slab only"); return FMI_ERR_ARG; }
+    TallEpilogue ep;
+    ep.bias = bias; ep.group = rows_per_bias_row; ep.alpha = alpha;
+    return hgemm_nt(stream, a, w, c, M, N, K, ldc, config, ep);
 }

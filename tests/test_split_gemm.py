@@ -703,6 +703,52 @@ def test_shared_first_step_through_the_hand_written_kernel(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_output_projection_finished_in_the_store(monkeypatch):
+    """a hand step's output projection with alpha, final_logits_bias and the per-query logit bias applied in the kernel's store
+    (``sealnn_hgemm_nt_ep``) == the raw accumulators + ``torch.add`` behind them, BIT FOR BIT (the same accumulators, the same one rounding), through a
+    change of the logit bias between two decodes, with -inf entries, at BART-large's vocabulary and width"""
+    from transformers import BartConfig, BartForConditionalGeneration
+    from seal_amd import split_gemm
+    from seal_amd.bart_decoder import BartStepDecoder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    cfg = BartConfig(vocab_size=50265, d_model=1024, encoder_layers=1, decoder_layers=1, encoder_attention_heads=16, decoder_attention_heads=16,
+                     encoder_ffn_dim=4096, decoder_ffn_dim=4096, max_position_embeddings=64)
+    with torch.device(dev):
+        model = BartForConditionalGeneration(cfg).eval()
+    g = torch.Generator().manual_seed(4)
+    B, K, S_in, T = 20, 15, 10, 4
+    ids = torch.randint(3, 50265, (B, S_in), generator=g).to(dev)
+    mask = torch.ones(B, S_in, dtype=torch.long, device=dev)
+    biases = []
+    for _ in range(2):
+        lb = torch.randn(B, 50265, generator=g)
+        lb[:, 1] = float("-inf")
+        lb[3, 100:200] = float("-inf")
+        biases.append(lb.to(dev))
+    outs = []
+    for in_store in (True, False):
+        monkeypatch.setattr(BartStepDecoder, "lm_head_finished_in_store", in_store)
+        dec = BartStepDecoder(model)
+        got = []
+        for lb in (biases[0], biases[1], None):
+            enc = dec.encode(ids, mask)
+            dec.start(enc, mask, K, T)
+            dec.logit_bias = lb
+            tok = torch.full((B * K,), 2, dtype=torch.long, device=dev)
+            for t in range(T - 1):
+                lg = dec.step(tok, beams_identical=(t == 0)).clone()
+                got.append(lg)
+                tok = torch.where(torch.isfinite(lg), lg, torch.full_like(lg, -1e30)).argmax(-1) if not outs else outs[0][len(got) - 1][1]
+                got[-1] = (lg, tok)
+        assert (getattr(dec._st, "lm_epilogue", None) == "in the store") is in_store
+        outs.append(got)
+    for (a, _), (b, _) in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert split_gemm.overflowed(dev) == 0
+
+
+@pytest.mark.gpu
 def test_encoder_through_the_split_gemm_matches_hf_encoder(monkeypatch):
     """``BartStepDecoder.encode`` with the encoder's linear layers through the split GEMM (the layer written out: q / k / v as one product, torch's
     fused attention, LayerNorms) against HF's own ``BartEncoder`` forward in fp32, at BART-large width with padded inputs: within 2e-5 on O(1)
