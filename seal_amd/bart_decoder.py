@@ -973,11 +973,13 @@ class BartStepDecoder:
                 return logits[:, None, :].expand(B, K, logits.shape[-1]).reshape(R, -1)
             if getattr(st, "lm_epilogue", None) == "in the store":
                 # the bias rows the output projection's store adds: final_logits_bias (+ the searcher's per-query logit bias), refreshed when they change
+                # (validated by the tensor OBJECT and its version, as _bias_per_query's own cache is: an address alone is reused by the allocator)
                 src = self._bias_per_query(st.lm_bias_src) if self.logit_bias is not None else st.lm_bias_src
-                key = (src.data_ptr(), src._version, tuple(src.shape))
-                if st.lm_bias_key != key:
+                key = st.lm_bias_key
+                if key is None or key[0]() is not src or key[1] != src._version:
+                    import weakref
                     st.lm_bias_q.copy_(src if src.dim() == 2 else src[None, :].expand_as(st.lm_bias_q))
-                    st.lm_bias_key = key
+                    st.lm_bias_key = (weakref.ref(src), src._version)
             st.graph.replay()
             self.t += 1
             if t == 0:
